@@ -1,0 +1,135 @@
+"""Seeded synthetic inputs shared by tests/golden/make_golden.py (which feeds them to the REFERENCE's code) and by
+the tests (which feed the same arrays to the oracle and to the HIP path).  numpy Generator streams are stable
+across numpy versions for the methods used here (uniform, normal, permutation, integers, choice).
+"""
+import numpy as np
+
+# (n boxes, threshold, seed) -- SURVEY.md section 8(d) "unit-kernel synthetic inputs"
+NMS_CASES = [(600, 0.3, 10), (6000, 0.7, 11), (1, 0.5, 12), (64, 0.5, 13), (65, 0.5, 14), (200, 0.0, 15)]
+# tag -> (instances, H, W, seed): a small canvas and BASELINE's 600 instances on a 600x1000 canvas
+VOTING_CASES = {"small": (120, 160, 240, 20), "full": (600, 600, 1000, 21)}
+
+
+def _boxes(rng, n, W, H, lo=16, hi=400):
+    x1 = rng.uniform(0, W - 64, n)
+    y1 = rng.uniform(0, H - 64, n)
+    x2 = np.minimum(x1 + rng.uniform(lo, hi, n), W - 1)
+    y2 = np.minimum(y1 + rng.uniform(lo, hi, n), H - 1)
+    return np.stack([x1, y1, x2, y2], 1).astype(np.float32)
+
+
+def nms_case(n, seed, W=1000, H=600):
+    """dets [n,5] float32 with DISTINCT scores (argsort()[::-1] of tied scores is unspecified)."""
+    rng = np.random.default_rng(seed)
+    b = _boxes(rng, n, W, H)
+    s = rng.permutation(np.linspace(0.01, 0.99, n)).astype(np.float32) if n > 1 else np.array([0.5], np.float32)
+    return np.hstack([b, s[:, None]]).astype(np.float32)
+
+
+def bbox_case(seed):
+    rng = np.random.default_rng(seed)
+    boxes = _boxes(rng, 64, 320, 200, 4, 120)
+    boxes[0] = [-5.0, -3.0, 10.0, 8.0]          # crosses the border -> clipped
+    boxes[1] = [300.0, 190.0, 330.0, 210.0]
+    deltas = rng.normal(0, 0.4, (64, 12)).astype(np.float32)   # K = 3 classes -> stride-4 slicing
+    return {"boxes": boxes, "deltas": deltas, "im_shape": (200.0, 320.0)}
+
+
+def proposal_case(fh, fw, seed):
+    """Softmax-shaped RPN outputs on an fh x fw stride-16 map: channels 0..8 bg, 9..17 fg (proposal_layer.py:75)."""
+    rng = np.random.default_rng(seed)
+    n = 9 * fh * fw
+    fg = rng.permutation(np.linspace(0.001, 0.999, n)).astype(np.float32).reshape(1, 9, fh, fw)
+    cls_prob = np.concatenate([(1.0 - fg).astype(np.float32), fg], axis=1)
+    bbox_pred = rng.normal(0, 0.5, (1, 36, fh, fw)).astype(np.float32)
+    H = 600 if fh == 38 else fh * 16
+    W = 1000 if fw == 63 else fw * 16
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    return {"cls_prob": cls_prob, "bbox_pred": bbox_pred, "im_info": im_info}
+
+
+def _softmax_rows(x):
+    e = np.exp(x - x.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+
+
+def stage_bridge_case(seed, R=50, H=600, W=1000):
+    rng = np.random.default_rng(seed)
+    rois = np.hstack([np.zeros((R, 1), np.float32), _boxes(rng, R, W, H)]).astype(np.float32)
+    bbox_pred = rng.normal(0, 0.1, (R, 84)).astype(np.float32)
+    scores = _softmax_rows(rng.normal(0, 2.0, (R, 21)))
+    return {"rois": rois, "bbox_pred": bbox_pred, "scores": scores, "im_info": np.array([[H, W, 1.0]], np.float32)}
+
+
+def _blob_masks(rng, n, S=21):
+    """Sigmoid masks with an object-like blob so that weighted sums exceed the 0.4 binarisation threshold."""
+    yy, xx = np.mgrid[0:S, 0:S].astype(np.float32)
+    cx = rng.uniform(7, 13, (n, 1, 1))
+    cy = rng.uniform(7, 13, (n, 1, 1))
+    rad = rng.uniform(4, 9, (n, 1, 1))
+    logit = 3.0 * (1.0 - ((xx - cx) ** 2 + (yy - cy) ** 2) / rad ** 2) + rng.normal(0, 0.7, (n, S, S))
+    return (1.0 / (1.0 + np.exp(-logit))).astype(np.float32).reshape(n, 1, S, S)
+
+
+def voting_case(n, H, W, seed, n_obj=8):
+    """`n` instances jittered around `n_obj` objects: boxes [n,4] f32 (original-image pixels), masks [n,1,21,21],
+    scores [n,21] (softmax rows, the object's class dominant)."""
+    rng = np.random.default_rng(seed)
+    ow = rng.uniform(0.15, 0.5, n_obj) * W
+    oh = rng.uniform(0.15, 0.6, n_obj) * H
+    ox = rng.uniform(0, 1, n_obj) * (W - ow)
+    oy = rng.uniform(0, 1, n_obj) * (H - oh)
+    ocls = rng.integers(1, 21, n_obj)
+    k = rng.integers(0, n_obj, n)
+    jit = rng.normal(0, 0.06, (n, 4)) * np.stack([ow[k], oh[k], ow[k], oh[k]], 1)
+    b = np.stack([ox[k], oy[k], ox[k] + ow[k], oy[k] + oh[k]], 1) + jit
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, W - 1)
+    b[:, 1::2] = np.clip(b[:, 1::2], 0, H - 1)
+    b[:, 2] = np.maximum(b[:, 2], b[:, 0] + 2)
+    b[:, 3] = np.maximum(b[:, 3], b[:, 1] + 2)
+    b[:, 2] = np.minimum(b[:, 2], W - 1)
+    b[:, 3] = np.minimum(b[:, 3], H - 1)
+    logits = rng.normal(0, 1.0, (n, 21))
+    logits[np.arange(n), ocls[k]] += rng.uniform(1.0, 6.0, n)
+    return {"boxes": b.astype(np.float32), "masks": _blob_masks(rng, n), "scores": _softmax_rows(logits)}
+
+
+def mv_case(seed, H=120, W=200):
+    """Direct mv() input: clustered boxes, 7 results incl. one whose masks never reach 0.4 (empty -> W/2,H/2
+    defaults, mv_kernel.cu:149,173), one touching the right/bottom image border, one single-candidate result."""
+    rng = np.random.default_rng(seed)
+    n = 40
+    base = np.array([[10, 10, 80, 70], [100, 30, 199, 119], [40, 60, 120, 110], [150, 5, 190, 40]], np.float32)
+    k = np.arange(n) % 4
+    b = base[k] + rng.normal(0, 2.0, (n, 4)).astype(np.float32)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, W - 1)
+    b[:, 1::2] = np.clip(b[:, 1::2], 0, H - 1)
+    b[1] = [100.0, 30.0, 199.0, 119.0]           # exactly on the image border
+    masks = _blob_masks(rng, n)
+    masks[k == 3] *= 0.3                          # cluster 3 never exceeds 0.4 after weighting
+    inds, start, wts = [], [], []
+    groups = [np.where(k == 0)[0], np.where(k == 1)[0], np.where(k == 2)[0], np.where(k == 3)[0],
+              np.array([1]), np.where(k == 1)[0][:3], np.concatenate([np.where(k == 0)[0][:4], np.where(k == 2)[0][:4]])]
+    for gidx in groups:
+        w = rng.uniform(0.2, 1.0, len(gidx)).astype(np.float32)
+        w = w / w.sum()
+        inds.extend(gidx)
+        wts.extend(w)
+        start.append(len(inds))
+    return {"boxes": b.astype(np.float32), "masks": masks, "inds": np.array(inds, np.int32),
+            "start": np.array(start, np.int32), "weights": np.array(wts, np.float32), "H": H, "W": W}
+
+
+def detect_case(seed, R=40, H=600, W=1000):
+    """A 600x1000 uint8 BGR image (scale factor exactly 1.0) and the six blobs im_detect reads (demo.py:84-90)."""
+    rng = np.random.default_rng(seed)
+    im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+
+    def stage():
+        rois = np.hstack([np.zeros((R, 1), np.float32), _boxes(rng, R, W + 40, H + 40)]).astype(np.float32)
+        return rois, _blob_masks(rng, R), _softmax_rows(rng.normal(0, 2.0, (R, 21)))
+
+    r1, m1, s1 = stage()
+    r2, m2, s2 = stage()
+    return {"im": im, "blobs": {"rois": r1, "mask_proposal": m1, "seg_cls_prob": s1,
+                                "rois_ext": r2, "mask_proposal_ext": m2, "seg_cls_prob_ext": s2}}
