@@ -1,0 +1,177 @@
+/* mnc_hip.h -- C ABI of libmnc_hip.so: MNC's per-image inference hot path on MI355X (gfx950).
+ *
+ * This header is the drop-in boundary.  Plain C: pointers, ints, floats; no torch / C++
+ * types.  Every entry point returns an int status (MNC_OK == 0) except the two reference-compatible `void`
+ * wrappers `_nms` / `_mv`; the text of the last error on the calling thread is available from mnc_last_error().
+ * Citations `file:line` are into the reference repository (daijifeng001/MNC).
+ *
+ * Pointer naming:  *_host = host memory owned by the caller;  d_* = device memory on the context's GPU.
+ *
+ * Device tensor layouts ("c8" = channel-blocked, chosen so that a wave's MFMA epilogue stores and the next layer's
+ * halo loads are both fully coalesced -- see DESIGN.md section 3):
+ *   feature map        c8   float [C/8][H][W][8]                      (batch is always 1, proposal_layer.py:65)
+ *   conv3x3 weights    packed by mnc_pack_conv3x3_weights             float [Cin/8][Cout][76]  (9 taps x 8 cin + 4 pad)
+ *   per-RoI features   hwc  float [R][PH][PW][C]   (a row of the FC GEMM is one RoI, k = (ph*PW+pw)*C + c)
+ *   FC weights         packed by mnc_pack_fc_weights: rows = outputs, columns permuted from Caffe's (c,h,w) order
+ *                      (test.prototxt InnerProduct, SURVEY App. A graph-5) to the hwc order above
+ *   everything else    as in Caffe: rois [R][5], masks [R][1][21][21], probabilities [R][21], ... row-major.
+ */
+#ifndef MNC_HIP_H_
+#define MNC_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNC_API __attribute__((visibility("default")))
+
+enum {
+  MNC_OK = 0,
+  MNC_ERR_INVALID = 1,     /* bad argument (null pointer, negative size, unsupported shape) */
+  MNC_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed */
+  MNC_ERR_NOMEM = 3,       /* device or host allocation failed */
+  MNC_ERR_STATE = 4,       /* call order violated (e.g. forward before weights were loaded) */
+  MNC_ERR_UNSUPPORTED = 5  /* valid request this build cannot serve */
+};
+
+/* Thread-local, never NULL; "" when the last call on this thread succeeded. */
+MNC_API const char* mnc_last_error(void);
+MNC_API int mnc_device_count(int* count);
+MNC_API const char* mnc_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * b1  nms.gpu_nms  --  replaces `_nms` (lib/nms/gpu_nms.hpp:1-2, lib/nms/nms_kernel.cu:91-144), called from
+ *     gpu_nms.pyx:16-31.  boxes_host: [boxes_num][boxes_dim] float32 ALREADY SORTED by descending score; only
+ *     columns 0..3 are read.  keep_out has capacity boxes_num and receives positions in the sorted array.
+ *     Suppression is `IoU > thresh` (strict, nms_kernel.cu:71) with +1 widths; results are bit-exact with the
+ *     reference.  boxes_num == 0 is legal (num_out = 0).  Synchronous.  max_keep < 0 means "all".
+ * ------------------------------------------------------------------------------------------------------------- */
+MNC_API int mnc_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                    float nms_overlap_thresh, int device_id);
+/* Same, but stops after max_keep survivors (ProposalLayer only uses keep[:300], proposal_layer.py:151-153);
+ * the first max_keep indices are identical to the unbounded call. */
+MNC_API int mnc_nms_topk(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                         float nms_overlap_thresh, int max_keep, int device_id);
+/* The raw 64x64-tiled suppression bitmask (nms_kernel.cu:34-78) for word-for-word parity tests:
+ * mask_host has boxes_num * ceil(boxes_num/64) uint64 words, row-major.  Lower-triangle words (never read by the
+ * scan, nms_kernel.cu:135) are written as 0. */
+MNC_API int mnc_nms_mask(unsigned long long* mask_host, const float* boxes_host, int boxes_num, int boxes_dim,
+                         float nms_overlap_thresh, int device_id);
+/* Signature-compatible with the reference symbol (errors are reported through mnc_last_error only). */
+MNC_API void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                  float nms_overlap_thresh, int device_id);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * b2  nms.mv  --  replaces `_mv` (lib/nms/gpu_mv.hpp:1-4, lib/nms/mv_kernel.cu:242-348), called from
+ *     gpu_mv.pyx:13-31.  Same 15 arguments, same meaning.  candidate_start[r] is the END offset of result r
+ *     (mask_transform.py:268).  finalize_output_mask: [result_num][mask_size][mask_size] float32;
+ *     finalize_output_box: [result_num][4] int32 (x1,y1,x2,y2).  result_num == 0 or candidate_num == 0 is legal.
+ *     The render -> aggregate -> reduce -> resize chain is fused; the N*H*W render buffer is never materialised.
+ *     Results are bit-exact with the reference kernels evaluated without FMA contraction.  device_id IS honoured
+ *     (the reference ignores it).
+ * ------------------------------------------------------------------------------------------------------------- */
+MNC_API int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, const int* candidate_inds,
+                   const int* candidate_start, const float* candidate_weights, int candidate_num, int image_height,
+                   int image_width, int box_dim, int mask_size, int result_num, float* finalize_output_mask,
+                   int* finalize_output_box, int device_id);
+MNC_API void _mv(const float* all_boxes, const float* all_masks, const int all_boxes_num, const int* candidate_inds,
+                 const int* candidate_start, const float* candidate_weights, const int candidate_num,
+                 const int image_height, const int image_width, const int box_dim, const int mask_size,
+                 const int result_num, float* finalize_output_mask, int* finalize_output_box, const int device_id);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * b3  utils.cython_bbox.bbox_overlaps (lib/utils/bbox.pyx:15-55): float64 IoU with +1 widths, [N][K] row-major.
+ *     A host function in the reference (Cython) and here (C); it is not a GPU kernel and has no GPU counterpart.
+ * ------------------------------------------------------------------------------------------------------------- */
+MNC_API int mnc_bbox_overlaps(const double* boxes, int n, const double* query_boxes, int k, double* overlaps);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Engine context: one per process per GPU (b5: `caffe.set_device`, one `caffe.Net` per process).  Owns a HIP
+ * stream and all device scratch.  Not thread-safe; use one context per thread.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct mnc_ctx mnc_ctx;
+
+MNC_API int mnc_ctx_create(mnc_ctx** out, int device_id);
+MNC_API int mnc_ctx_destroy(mnc_ctx* ctx);
+MNC_API int mnc_ctx_sync(mnc_ctx* ctx);
+MNC_API int mnc_ctx_device(const mnc_ctx* ctx, int* device_id);
+
+/* Device memory for the host-side executor (the caffe-shaped Net keeps its blobs here). */
+MNC_API int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr);
+MNC_API int mnc_dev_free(mnc_ctx* ctx, void* d_ptr);
+MNC_API int mnc_h2d(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t bytes);   /* stream-ordered + sync */
+MNC_API int mnc_d2h(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes);   /* stream-ordered + sync */
+MNC_API int mnc_d2d(mnc_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);      /* stream-ordered, async */
+MNC_API int mnc_dev_zero(mnc_ctx* ctx, void* d_ptr, size_t bytes);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's `roofline` numbers come from here).
+ * enable=1 records a start/stop event pair around every kernel launched through the context. */
+MNC_API int mnc_prof_enable(mnc_ctx* ctx, int enable);
+MNC_API int mnc_prof_reset(mnc_ctx* ctx);
+MNC_API int mnc_prof_count(mnc_ctx* ctx, int* n_records);                 /* synchronises the stream */
+MNC_API int mnc_prof_get(mnc_ctx* ctx, int index, char* name_buf, int name_cap, float* ms, double* flops,
+                         double* bytes);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Layout conversion and weight packing (device -> device, asynchronous on the context's stream).
+ * ------------------------------------------------------------------------------------------------------------- */
+MNC_API int mnc_nchw_to_c8(mnc_ctx* ctx, const float* d_nchw, float* d_c8, int C, int H, int W);  /* C%8==0 */
+MNC_API int mnc_c8_to_nchw(mnc_ctx* ctx, const float* d_c8, float* d_nchw, int C, int H, int W);
+/* [R][C][PH][PW] (Caffe) <-> [R][PH][PW][C] (engine) */
+MNC_API int mnc_rchw_to_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int C, int PH, int PW);
+MNC_API int mnc_rhwc_to_rchw(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int C, int PH, int PW);
+/* Caffe conv weight [Cout][Cin][3][3] -> packed [Cin/8][Cout][76].  Cin%8==0, Cout%32==0.  Elements: Cin/8*Cout*76 */
+MNC_API int mnc_pack_conv3x3_weights(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin);
+/* Caffe InnerProduct weight [N][C*PH*PW] (columns in (c,h,w) order) -> [N][PH*PW*C] ((h,w,c) order). */
+MNC_API int mnc_pack_fc_weights(mnc_ctx* ctx, const float* d_nchw_cols, float* d_hwc_cols, int N, int C, int PH, int PW);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Graph ops -- one per layer type of models/VGG16/mnc_5stage/test.prototxt.  All asynchronous on the
+ * context's stream; all tensors fp32.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* conv1_1 (test.prototxt:19-40): 3x3 pad 1, Cin = 3, reads the NCHW input blob, + bias + ReLU -> c8.  HBM-bound. */
+MNC_API int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias,
+                           float* d_out_c8, int H, int W, int Cout, int relu);
+/* Convolution 3x3 pad 1 stride 1 + bias (+ ReLU) (test.prototxt:41-412), c8 -> c8, fp32 MFMA implicit GEMM. */
+MNC_API int mnc_conv3x3(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
+                        float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
+/* Pooling MAX 2x2 stride 2 with Caffe's ceil output size (test.prototxt:69-79,...): c8 [C/8][H][W][8] ->
+ * [C/8][OH][OW][8], OH = ceil((H-2)/2)+1. */
+MNC_API int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W);
+/* rpn_cls_score / rpn_bbox_pred (test.prototxt:413-439): 1x1 conv c8 -> NCHW [Cout][H][W], weight [Cout][Cin]. */
+MNC_API int mnc_conv1x1_to_nchw(mnc_ctx* ctx, const float* d_in_c8, const float* d_w, const float* d_bias,
+                                float* d_out_nchw, int H, int W, int Cin, int Cout);
+/* Reshape(0,2,-1,0) -> Softmax(axis 1) -> Reshape(0,18,-1,0) (test.prototxt:440-462): pairs channel a with A+a. */
+MNC_API int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score_nchw, float* d_prob_nchw, int A, int H, int W);
+/* ROIWarping (test.prototxt:479-492, 809-820) per oracle/SPEC.md section 1, c8 feature -> [R][PH][PW][C].
+ * pool2 != 0 fuses the following Pooling MAX 2x2/2 (test.prototxt:494-505): the warp is evaluated at
+ * 2PH x 2PW and max-reduced, so the 28x28 "premax" tensor never reaches HBM. */
+MNC_API int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R,
+                         int PH, int PW, float spatial_scale, int pool2, float* d_out_rhwc);
+/* Pooling MAX 2x2/2 on per-RoI features [R][PH][PW][C] -> [R][PH/2][PW/2][C] (test.prototxt:571-582,...). */
+MNC_API int mnc_maxpool2_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C);
+/* MaskResize (test.prototxt:558-567) per SPEC.md section 2: [R][IH][IW] -> [R][OH][OW]. */
+MNC_API int mnc_mask_resize(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int IH, int IW, int OH, int OW);
+/* MaskPooling (test.prototxt:631-637) per SPEC.md section 3: feat[R][PH][PW][C] * mask[R][PH][PW].
+ * pool2 != 0 fuses the following Pooling MAX 2x2/2 (test.prototxt:639-650). */
+MNC_API int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH,
+                          int PW, int C, int pool2);
+/* InnerProduct (+ReLU / +Sigmoid): out[M][N] = act(A[M][K] . W[N][K]^T + bias[N]).  fp32 MFMA, split-K chosen
+ * internally; d_out may be a column slice of a wider matrix (ldc >= N) so Concat (test.prototxt:700-709) is free.
+ * act: 0 none, 1 ReLU, 2 sigmoid. */
+MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_out, int M,
+                   int N, int K, int ldc, int act);
+/* Softmax over the last axis of [M][N] (test.prototxt cls_prob / seg_cls_prob). */
+MNC_API int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N);
+/* Stand-alone ReLU (op 1) / Sigmoid (op 2) for graphs where the activation is not fused into its producer
+ * (test.prototxt:540-545 `mask_output` when run unfused).  In-place allowed. */
+MNC_API int mnc_eltwise(mnc_ctx* ctx, const float* d_in, float* d_out, size_t count, int op);
+/* Strided 2-D device copy of float rows (Concat, test.prototxt:700-709, when the producers could not write in place). */
+MNC_API int mnc_copy2d(mnc_ctx* ctx, float* d_dst, int dst_ld, const float* d_src, int src_ld, int rows, int cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNC_HIP_H_ */

@@ -1,0 +1,72 @@
+"""Build mnc_amd/libmnc_hip.so for gfx950 with hipcc (in-tree, so the library travels with the repo snapshot).
+
+    python -m mnc_amd._build [--force]
+
+hipcc cross-compiles without a GPU.  nms.hip / mv.hip / bbox.hip are compiled with -ffp-contract=off: their float
+expressions must be evaluated operation by operation to stay bit-exact with the reference (see the file headers).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmnc_hip.so")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+ARCH = "gfx950"
+NO_CONTRACT = {"nms.hip", "mv.hip", "bbox.hip"}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    paths.append(os.path.join(HERE, "..", "include", "mnc_hip.h"))
+    paths.append(os.path.abspath(__file__))
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def up_to_date():
+    return os.path.isfile(LIB) and os.path.getmtime(LIB) >= _deps_mtime()
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    cc = _hipcc()
+    base = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+            "-Wno-unused-function"]
+
+    def one(src):
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        cmd = base + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        objs = list(ex.map(one, sources()))
+    tmp = LIB + ".tmp"
+    r = subprocess.run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

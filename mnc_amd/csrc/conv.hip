@@ -1,0 +1,398 @@
+// VGG-16 trunk + RPN head kernels for gfx950 (models/VGG16/mnc_5stage/test.prototxt:19-462).
+//
+// Feature maps live in the "c8" layout  float [C/8][H][W][8]  (batch is 1, proposal_layer.py:65):
+//   * a halo row of one 8-channel block is (TW+2)*32 contiguous bytes -> coalesced staging loads;
+//   * the MFMA 32x32 accumulator of a wave holds, per lane, 4 consecutive output channels of ONE pixel in regs
+//     4g..4g+3, so the epilogue is one 16-byte store per register group and a wave writes 32 pixels x 32 B
+//     contiguous per 8-channel block.
+//
+// conv3x3 (3x3, pad 1, stride 1, + bias, + ReLU) is an implicit GEMM on the fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 cycles, 157 TFLOP/s peak):
+//   M = output channels (MFMA A operand = weights), N = pixels (B operand), K = 9 taps x Cin.
+//   A workgroup (4 waves) owns a 4-row x 32-column pixel tile and 32*CO_T output channels; wave w owns pixel row w.
+//   K is walked in 8-channel blocks.  Per block the (4+2)x(32+2) input halo (all 9 taps reuse it from LDS) and the
+//   32*CO_T x 72 weight panel are staged global -> registers -> LDS, double-buffered with one barrier per block:
+//   the loads for block c+1 are issued before the 36*CO_T MFMAs of block c and written to LDS after them.
+//   Each lane fetches its 4 k-values of a fragment with ONE ds_read_b128; pixel pitch 12 floats and weight row pitch
+//   76 floats make those reads bank-conflict-free (12*i mod 64 is a distinct multiple of 4 for 16 consecutive i).
+#include <cstdlib>
+
+#include "mnc_internal.h"
+
+namespace mnc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTileRows = 4, kTileCols = 32;
+constexpr int kHaloRows = kTileRows + 2, kHaloCols = kTileCols + 2;
+constexpr int kPixPitch = 12;            // floats per halo pixel in LDS (8 data + 4 pad)
+constexpr int kWPitch = 76;              // floats per weight row in LDS and in the packed global layout (72 + 4 pad)
+constexpr int kHaloFloats = kHaloRows * kHaloCols * kPixPitch;
+constexpr int kHaloVec = kHaloRows * kHaloCols * 2;  // float4 items per halo
+
+template <int CO_T>
+__global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                         int W, int Cin, int Cout, int relu) {
+  constexpr int NCO = 32 * CO_T;
+  constexpr int kWVec = NCO * (kWPitch / 4);                 // float4 items per weight panel (incl. pad)
+  constexpr int kWPerThread = (kWVec + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float s_halo[2][kHaloFloats];
+  __shared__ __attribute__((aligned(16))) float s_w[2][NCO * kWPitch];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, kk = lane >> 5;
+  const int w0 = blockIdx.x * kTileCols, h0 = blockIdx.y * kTileRows, co0 = blockIdx.z * NCO;
+  const int nchunks = Cin >> 3;
+
+  // ---- staging assignment (fixed per thread) ----
+  // halo: item q -> pixel q>>1 (row-major in the 6x34 halo), half q&1
+  int h_off[2];
+  long h_src[2];   // element offset inside one 8-channel block plane, or -1 when outside the image
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = tid + u * 256;
+    h_off[u] = -1;
+    h_src[u] = -1;
+    if (q < kHaloVec) {
+      const int pix = q >> 1, half = q & 1;
+      const int r = pix / kHaloCols, c = pix - r * kHaloCols;
+      const int gh = h0 - 1 + r, gw = w0 - 1 + c;
+      h_off[u] = pix * kPixPitch + half * 4;
+      if (gh >= 0 && gh < H && gw >= 0 && gw < W) h_src[u] = ((long)gh * W + gw) * 8 + half * 4;
+    }
+  }
+  const long plane = (long)H * W * 8;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // NB: staging registers must be initialised, otherwise hipcc keeps the (conditionally written) arrays as allocas
+  // -> scratch / promote-alloca-to-LDS instead of VGPRs.
+  float4 rh[2] = {zero4, zero4};
+  float4 rw[kWPerThread];
+#pragma unroll
+  for (int u = 0; u < kWPerThread; ++u) rw[u] = zero4;
+
+  auto load_chunk = [&](int c) {
+    const float* src = in + (long)c * plane;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h_src[u] >= 0) v = *reinterpret_cast<const float4*>(src + h_src[u]);
+      rh[u] = v;
+    }
+    const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * Cout + co0) * kWPitch);
+#pragma unroll
+    for (int u = 0; u < kWPerThread; ++u) {
+      const int q = tid + u * 256;
+      if (q < kWVec) rw[u] = wsrc[q];
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (h_off[u] >= 0) *reinterpret_cast<float4*>(&s_halo[buf][h_off[u]]) = rh[u];
+    float4* wdst = reinterpret_cast<float4*>(&s_w[buf][0]);
+#pragma unroll
+    for (int u = 0; u < kWPerThread; ++u) {
+      const int q = tid + u * 256;
+      if (q < kWVec) wdst[q] = rw[u];
+    }
+  };
+
+  f32x16 acc[CO_T];
+#pragma unroll
+  for (int t = 0; t < CO_T; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int p_base = (wave * kHaloCols + j) * kPixPitch + kk * 4;   // + (kh*34 + kw)*12 per tap
+  const int w_base = j * kWPitch + kk * 4;                          // + ct*32*76 + tap*8
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const float* sh = s_halo[buf];
+    const float* sw = s_w[buf];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const float4 p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
+#pragma unroll
+      for (int t = 0; t < CO_T; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, p.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, p.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, p.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, p.w, acc[t], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = cout (reg&3)+8*(reg>>2)+4*kk][col = pixel j] ----
+  const int oh = h0 + wave, ow = w0 + j;
+  if (oh < H && ow < W) {
+#pragma unroll
+    for (int t = 0; t < CO_T; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + t * 32 + g * 8 + kk * 4;
+        const float4 b = *reinterpret_cast<const float4*>(bias + co);
+        float4 v = make_float4(acc[t][4 * g + 0] + b.x, acc[t][4 * g + 1] + b.y, acc[t][4 * g + 2] + b.z,
+                               acc[t][4 * g + 3] + b.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(out + (((long)(co >> 3) * H + oh) * W + ow) * 8 + kk * 4) = v;
+      }
+    }
+  }
+}
+
+// ---- conv1_1: Cin = 3 (K = 27): HBM-bound, VALU.  One thread = one pixel x 8 output channels. --------------------
+__global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                         int W, int Cout, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float s_wt[];   // [27][Cout] then bias[Cout]
+  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
+    const int co = i / 27, k = i - co * 27;                       // OIHW: w[co][ci][kh][kw], k = ci*9 + kh*3 + kw
+    s_wt[k * Cout + co] = w[i];
+  }
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) s_wt[27 * Cout + i] = bias[i];
+  __syncthreads();
+  const int nblk = Cout >> 3;
+  const long total = (long)H * W * nblk;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // pixel fastest inside a channel block -> each wave writes 64 pixels x 32 B contiguous
+    const long pix = idx % ((long)H * W);
+    const int cb = (int)(idx / ((long)H * W));
+    const int h = (int)(pix / W), x = (int)(pix - (long)h * W);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = s_wt[27 * Cout + cb * 8 + e];
+#pragma unroll 1
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = h + kh - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = x + kw - 1;
+          const float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? in[((long)ci * H + ih) * W + iw] : 0.f;
+          const float* wr = s_wt + (ci * 9 + kh * 3 + kw) * Cout + cb * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wr[e], acc[e]);
+        }
+      }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    float4* dst = reinterpret_cast<float4*>(out + ((long)cb * H * W + pix) * 8);
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+// ---- Pooling MAX 2x2/2, Caffe ceil mode, c8 ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_c8_kernel(const float* __restrict__ in, float* __restrict__ out, int CB,
+                                                          int H, int W, int OH, int OW) {
+  const long total = (long)CB * OH * OW * 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int half = (int)(idx & 1);
+    long p = idx >> 1;
+    const int ow = (int)(p % OW);
+    p /= OW;
+    const int oh = (int)(p % OH);
+    const int cb = (int)(p / OH);
+    const int h0 = oh * 2, x0 = ow * 2;
+    const float* base = in + (long)cb * H * W * 8 + half * 4;
+    float4 m = *reinterpret_cast<const float4*>(base + ((long)h0 * W + x0) * 8);
+    auto upd = [&](int hh, int ww) {
+      if (hh < H && ww < W) {
+        const float4 v = *reinterpret_cast<const float4*>(base + ((long)hh * W + ww) * 8);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    };
+    upd(h0, x0 + 1); upd(h0 + 1, x0); upd(h0 + 1, x0 + 1);
+    *reinterpret_cast<float4*>(out + (((long)cb * OH + oh) * OW + ow) * 8 + half * 4) = m;
+  }
+}
+
+// ---- 1x1 conv c8 -> NCHW (rpn_cls_score, rpn_bbox_pred): 0.13 GFLOP, VALU ------------------------------------------
+__global__ __launch_bounds__(256) void conv1x1_to_nchw_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int HW, int Cin, int Cout) {
+  const long total = (long)HW * Cout;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % HW), o = (int)(idx / HW);
+    const float* wr = w + (long)o * Cin;
+    float acc = bias[o];
+    for (int cb = 0; cb < (Cin >> 3); ++cb) {
+      const float4 a0 = *reinterpret_cast<const float4*>(in + ((long)cb * HW + p) * 8);
+      const float4 a1 = *reinterpret_cast<const float4*>(in + ((long)cb * HW + p) * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(wr + cb * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(wr + cb * 8 + 4);
+      acc = fmaf(a0.x, b0.x, acc); acc = fmaf(a0.y, b0.y, acc); acc = fmaf(a0.z, b0.z, acc); acc = fmaf(a0.w, b0.w, acc);
+      acc = fmaf(a1.x, b1.x, acc); acc = fmaf(a1.y, b1.y, acc); acc = fmaf(a1.z, b1.z, acc); acc = fmaf(a1.w, b1.w, acc);
+    }
+    out[idx] = acc;
+  }
+}
+
+// Softmax over the (bg, fg) pair of every anchor: channel a against channel A+a (test.prototxt:440-462).
+__global__ void rpn_softmax_kernel(const float* __restrict__ s, float* __restrict__ p, int A, int HW) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= A * HW) return;
+  const float s0 = s[idx], s1 = s[idx + A * HW];
+  const float m = fmaxf(s0, s1);
+  const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+  const float sum = e0 + e1;
+  p[idx] = e0 / sum;
+  p[idx + A * HW] = e1 / sum;
+}
+
+// ---- layout conversion / weight packing ----------------------------------------------------------------------------
+__global__ void nchw_to_c8_kernel(const float* __restrict__ in, float* __restrict__ out, int C, long HW) {
+  const long total = (long)C * HW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7);
+    const long p = (idx >> 3) % HW;
+    const int cb = (int)((idx >> 3) / HW);
+    out[idx] = in[(long)(cb * 8 + e) * HW + p];
+  }
+}
+__global__ void c8_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, long HW) {
+  const long total = (long)C * HW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long p = idx % HW;
+    const int c = (int)(idx / HW);
+    out[idx] = in[((long)(c >> 3) * HW + p) * 8 + (c & 7)];
+  }
+}
+// OIHW [Cout][Cin][3][3] -> [Cin/8][Cout][76]: element (cb, co, tap*8 + e) = w[co][cb*8+e][tap]; pad = 0
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+  const long total = (long)(Cin >> 3) * Cout * kWPitch;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % kWPitch);
+    const long r = idx / kWPitch;
+    const int co = (int)(r % Cout), cb = (int)(r / Cout);
+    float v = 0.f;
+    if (k < 72) {
+      const int tap = k >> 3, e = k & 7;
+      v = w[((long)co * Cin + cb * 8 + e) * 9 + tap];
+    }
+    out[idx] = v;
+  }
+}
+
+static int grid_for(long total, int block = 256, int cap = 256 * 32) {
+  long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+extern "C" {
+
+int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                int Cin, int Cout, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_conv3x3: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin, Cout);
+  const int tx = cdiv(W, kTileCols), ty = cdiv(H, kTileRows);
+  // widest channel tile that still gives >= 4 workgroups per CU (256 CUs) so the tail round stays short; narrow maps
+  // fall back to 32 channels.  MNC_CONV_COT=1|2|4 overrides (tuning aid).
+  int co_t = 4;
+  while (co_t > 1 && (Cout % (32 * co_t) != 0 || (long)tx * ty * (Cout / (32 * co_t)) < 1024)) co_t >>= 1;
+  if (const char* e = getenv("MNC_CONV_COT")) {
+    const int v = atoi(e);
+    if ((v == 1 || v == 2 || v == 4) && Cout % (32 * v) == 0) co_t = v;
+  }
+  const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
+  const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
+  LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
+  dim3 grid(tx, ty, Cout / (32 * co_t));
+  if (co_t == 4)
+    hipLaunchKernelGGL(conv3x3_c8_kernel<4>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+  else if (co_t == 2)
+    hipLaunchKernelGGL(conv3x3_c8_kernel<2>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+  else
+    hipLaunchKernelGGL(conv3x3_c8_kernel<1>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+  return ls.finish("conv3x3_c8_kernel");
+}
+
+int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, float* d_out, int H, int W,
+                   int Cout, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out, "mnc_conv3x3_c3: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && Cout <= 512, "mnc_conv3x3_c3: unsupported shape");
+  const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + Cout);
+  LaunchScope ls(ctx, "conv3x3_c3", flops, bytes);
+  const long total = (long)H * W * (Cout / 8);
+  hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid_for(total)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w,
+                     d_bias, d_out, H, W, Cout, relu);
+  return ls.finish("conv3x3_c3_kernel");
+}
+
+int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W) {
+  MNC_REQUIRE(ctx && d_in && d_out && C > 0 && C % 8 == 0 && H >= 2 && W >= 2, "mnc_maxpool2_c8: bad argument");
+  const int OH = (H - 2 + 1) / 2 + 1, OW = (W - 2 + 1) / 2 + 1;
+  LaunchScope ls(ctx, "maxpool2_c8", 0.0, 4.0 * C * ((double)H * W + (double)OH * OW));
+  const long total = (long)(C / 8) * OH * OW * 2;
+  hipLaunchKernelGGL(maxpool2_c8_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_in, d_out, C / 8, H, W, OH, OW);
+  return ls.finish("maxpool2_c8_kernel");
+}
+
+int mnc_conv1x1_to_nchw(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, float* d_out, int H,
+                        int W, int Cin, int Cout) {
+  MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out && H > 0 && W > 0 && Cin % 8 == 0 && Cout > 0,
+              "mnc_conv1x1_to_nchw: bad argument");
+  LaunchScope ls(ctx, "conv1x1_to_nchw", 2.0 * H * W * Cin * Cout, 4.0 * H * W * (Cin + Cout));
+  const long total = (long)H * W * Cout;
+  hipLaunchKernelGGL(conv1x1_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_in, d_w, d_bias, d_out,
+                     H * W, Cin, Cout);
+  return ls.finish("conv1x1_to_nchw_kernel");
+}
+
+int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score, float* d_prob, int A, int H, int W) {
+  MNC_REQUIRE(ctx && d_score && d_prob && A > 0 && H > 0 && W > 0, "mnc_rpn_softmax: bad argument");
+  LaunchScope ls(ctx, "rpn_softmax");
+  hipLaunchKernelGGL(rpn_softmax_kernel, dim3(cdiv((long)A * H * W, 256)), dim3(256), 0, ctx->stream, d_score, d_prob, A,
+                     H * W);
+  return ls.finish("rpn_softmax_kernel");
+}
+
+int mnc_nchw_to_c8(mnc_ctx* ctx, const float* d_nchw, float* d_c8, int C, int H, int W) {
+  MNC_REQUIRE(ctx && d_nchw && d_c8 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "mnc_nchw_to_c8: bad argument");
+  LaunchScope ls(ctx, "nchw_to_c8");
+  hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(grid_for((long)C * H * W)), dim3(256), 0, ctx->stream, d_nchw, d_c8, C,
+                     (long)H * W);
+  return ls.finish("nchw_to_c8_kernel");
+}
+
+int mnc_c8_to_nchw(mnc_ctx* ctx, const float* d_c8, float* d_nchw, int C, int H, int W) {
+  MNC_REQUIRE(ctx && d_nchw && d_c8 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "mnc_c8_to_nchw: bad argument");
+  LaunchScope ls(ctx, "c8_to_nchw");
+  hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(grid_for((long)C * H * W)), dim3(256), 0, ctx->stream, d_c8, d_nchw, C,
+                     (long)H * W);
+  return ls.finish("c8_to_nchw_kernel");
+}
+
+int mnc_pack_conv3x3_weights(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_pack_conv3x3_weights: bad argument");
+  LaunchScope ls(ctx, "pack_conv3x3");
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((long)(Cin / 8) * Cout * kWPitch)), dim3(256), 0, ctx->stream,
+                     d_oihw, d_packed, Cout, Cin);
+  return ls.finish("pack_conv3x3_kernel");
+}
+
+}  // extern "C"

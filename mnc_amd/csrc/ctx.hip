@@ -1,0 +1,222 @@
+// Context, device memory, error reporting and HIP-event profiling for libmnc_hip.so.
+#include "mnc_internal.h"
+
+namespace mnc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+void clear_error() { g_err[0] = 0; }
+
+int ensure_scratch(mnc_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return MNC_OK;
+  if (ctx->scratch) {
+    MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    MNC_HIP_TRY(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  size_t want = bytes + (bytes >> 2);
+  hipError_t e = hipMalloc(&ctx->scratch, want);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu) for scratch failed: %s", want, hipGetErrorString(e));
+    return MNC_ERR_NOMEM;
+  }
+  ctx->scratch_bytes = want;
+  return MNC_OK;
+}
+
+static hipEvent_t take_event(mnc_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(mnc_ctx* ctx, const char* name, double flops, double bytes) {
+  ProfRecord r{name, take_event(ctx), take_event(ctx), flops, bytes};
+  (void)hipEventRecord(r.start, ctx->stream);
+  ctx->prof.push_back(r);
+}
+void prof_end(mnc_ctx* ctx) {
+  if (!ctx->prof.empty()) (void)hipEventRecord(ctx->prof.back().stop, ctx->stream);
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+extern "C" {
+
+const char* mnc_last_error(void) { return g_err; }
+const char* mnc_version(void) { return "mnc_hip 0.1 (gfx950)"; }
+
+int mnc_device_count(int* count) {
+  MNC_REQUIRE(count, "mnc_device_count: null pointer");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_ctx_create(mnc_ctx** out, int device_id) {
+  MNC_REQUIRE(out, "mnc_ctx_create: null out pointer");
+  *out = nullptr;
+  int n = 0;
+  MNC_HIP_TRY(hipGetDeviceCount(&n));
+  MNC_REQUIRE(device_id >= 0 && device_id < n, "mnc_ctx_create: device %d out of range (have %d)", device_id, n);
+  MNC_HIP_TRY(hipSetDevice(device_id));
+  mnc_ctx* ctx = new (std::nothrow) mnc_ctx();
+  if (!ctx) {
+    set_error("mnc_ctx_create: out of host memory");
+    return MNC_ERR_NOMEM;
+  }
+  ctx->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    return MNC_ERR_HIP;
+  }
+  *out = ctx;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_ctx_destroy(mnc_ctx* ctx) {
+  if (!ctx) return MNC_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& r : ctx->prof) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_ctx_sync(mnc_ctx* ctx) {
+  MNC_REQUIRE(ctx, "mnc_ctx_sync: null context");
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_ctx_device(const mnc_ctx* ctx, int* device_id) {
+  MNC_REQUIRE(ctx && device_id, "mnc_ctx_device: null pointer");
+  *device_id = ctx->device;
+  return MNC_OK;
+}
+
+int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr) {
+  MNC_REQUIRE(ctx && d_ptr, "mnc_dev_alloc: null pointer");
+  *d_ptr = nullptr;
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("mnc_dev_alloc: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MNC_ERR_NOMEM;
+  }
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_dev_free(mnc_ctx* ctx, void* d_ptr) {
+  MNC_REQUIRE(ctx, "mnc_dev_free: null context");
+  if (!d_ptr) return MNC_OK;
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  MNC_HIP_TRY(hipFree(d_ptr));
+  return MNC_OK;
+}
+
+int mnc_h2d(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t bytes) {
+  MNC_REQUIRE(ctx && (bytes == 0 || (d_dst && src_host)), "mnc_h2d: null pointer");
+  if (bytes == 0) return MNC_OK;
+  MNC_HIP_TRY(hipMemcpyAsync(d_dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_d2h(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes) {
+  MNC_REQUIRE(ctx && (bytes == 0 || (dst_host && d_src)), "mnc_d2h: null pointer");
+  if (bytes == 0) return MNC_OK;
+  MNC_HIP_TRY(hipMemcpyAsync(dst_host, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_d2d(mnc_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  MNC_REQUIRE(ctx && (bytes == 0 || (d_dst && d_src)), "mnc_d2d: null pointer");
+  if (bytes == 0) return MNC_OK;
+  MNC_HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_dev_zero(mnc_ctx* ctx, void* d_ptr, size_t bytes) {
+  MNC_REQUIRE(ctx && (bytes == 0 || d_ptr), "mnc_dev_zero: null pointer");
+  if (bytes == 0) return MNC_OK;
+  MNC_HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_prof_enable(mnc_ctx* ctx, int enable) {
+  MNC_REQUIRE(ctx, "mnc_prof_enable: null context");
+  ctx->profiling = enable != 0;
+  return MNC_OK;
+}
+
+int mnc_prof_reset(mnc_ctx* ctx) {
+  MNC_REQUIRE(ctx, "mnc_prof_reset: null context");
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->prof) {
+    ctx->event_pool.push_back(r.start);
+    ctx->event_pool.push_back(r.stop);
+  }
+  ctx->prof.clear();
+  return MNC_OK;
+}
+
+int mnc_prof_count(mnc_ctx* ctx, int* n_records) {
+  MNC_REQUIRE(ctx && n_records, "mnc_prof_count: null pointer");
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *n_records = (int)ctx->prof.size();
+  return MNC_OK;
+}
+
+int mnc_prof_get(mnc_ctx* ctx, int index, char* name_buf, int name_cap, float* ms, double* flops, double* bytes) {
+  MNC_REQUIRE(ctx && index >= 0 && index < (int)ctx->prof.size(), "mnc_prof_get: index %d out of range", index);
+  const ProfRecord& r = ctx->prof[index];
+  if (name_buf && name_cap > 0) {
+    strncpy(name_buf, r.name, name_cap - 1);
+    name_buf[name_cap - 1] = 0;
+  }
+  if (ms) {
+    float t = 0.f;
+    MNC_HIP_TRY(hipEventElapsedTime(&t, r.start, r.stop));
+    *ms = t;
+  }
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  return MNC_OK;
+}
+
+}  // extern "C"

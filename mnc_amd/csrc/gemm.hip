@@ -1,0 +1,263 @@
+// InnerProduct layers of the MNC heads (test.prototxt:509-785, 824-1106) for gfx950:
+//     out[M][N] = act(A[M][K] . W[N][K]^T + bias[N]),   M = #RoIs (<= 300), K up to 100352, N up to 4096.
+//
+// At M = 300 the fp32 arithmetic intensity is ~150 FLOP/B, far above the fp32-matrix ridge (157 TF / ~6 TB/s ~ 25),
+// so these GEMMs are MFMA-bound, not weight-streaming-bound; the kernel is built around v_mfma_f32_32x32x2_f32
+// (exact fp32).
+//
+// Tiling: a workgroup (4 waves) owns ALL rows of a 320-row block (10 MFMA row tiles; M = 300 fits one block, so the
+// weights are streamed from HBM exactly once) x 128 output columns (wave w owns columns 32w..32w+31) x one K split.
+// Per 32-deep K stage the A panel [320][32] and the W panel [128][32] go global -> registers -> LDS (row pitch 36
+// floats: conflict-free ds_read_b128 fragments), double-buffered with one barrier per stage; the loads of stage s+1
+// are issued before the 160 MFMAs per wave of stage s.  The MFMA A operand is the activation (row = RoI), the B
+// operand the weight (column = output), so for a fixed accumulator register 32 lanes hold 32 consecutive outputs of
+// one RoI -> 128-byte contiguous stores.
+//
+// Split-K (chosen so that tiles x splits ~ the 256 CUs) writes fp32 partials to the context scratch; a second kernel
+// sums them in fixed order (deterministic) and applies bias + activation.  With one split the epilogue is fused.
+#include "mnc_internal.h"
+
+namespace mnc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBN = 128, kBK = 32, kMT = 10, kBM = 32 * kMT;
+constexpr int kPitch = kBK + 4;
+constexpr int kAVec = kBM * (kBK / 4);   // 2560 float4
+constexpr int kBVec = kBN * (kBK / 4);   // 1024 float4
+constexpr int kAPer = kAVec / 256;       // 10
+constexpr int kBPer = kBVec / 256;       // 4
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// grid: (ceil(N/128), splits, ceil(M/320)).  k range of split s: [s*kper, min(K, (s+1)*kper)), kper % 32 == 0.
+// fused != 0: write act(acc + bias) to out (ldc); else write raw partials to part[split][M][N].
+__global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      float* __restrict__ part, int M, int N, int K, int ldc, int kper,
+                                                      int act, int fused) {
+  __shared__ __attribute__((aligned(16))) float sA[2][kBM * kPitch];
+  __shared__ __attribute__((aligned(16))) float sB[2][kBN * kPitch];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, kk = lane >> 5;
+  const int n0 = blockIdx.x * kBN, split = blockIdx.y, m0 = blockIdx.z * kBM;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
+  const int nstages = (kend - kbeg) / kBK;
+  const int mrows = min(M - m0, kBM);
+  const int mtiles = (mrows + 31) >> 5;
+
+  // staging map: item q -> row q>>3, float4 column q&7 (rows are K-contiguous in global memory)
+  const float* a_src[kAPer];
+  const float* b_src[kBPer];
+  int a_dst[kAPer], b_dst[kBPer];
+#pragma unroll
+  for (int u = 0; u < kAPer; ++u) {
+    const int q = tid + u * 256, r = q >> 3, c4 = q & 7;
+    const int gr = m0 + min(r, mrows - 1);               // rows past M re-read the last valid row; never stored
+    a_src[u] = A + (long)gr * K + kbeg + c4 * 4;
+    a_dst[u] = r * kPitch + c4 * 4;
+  }
+#pragma unroll
+  for (int u = 0; u < kBPer; ++u) {
+    const int q = tid + u * 256, r = q >> 3, c4 = q & 7;
+    const int gr = min(n0 + r, N - 1);
+    b_src[u] = Wt + (long)gr * K + kbeg + c4 * 4;
+    b_dst[u] = r * kPitch + c4 * 4;
+  }
+  float4 ra[kAPer], rb[kBPer];   // initialised: see the note in conv.hip (uninitialised staging arrays -> scratch)
+#pragma unroll
+  for (int u = 0; u < kAPer; ++u) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < kBPer; ++u) rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_stage = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < kAPer; ++u)
+      if (u < mtiles) ra[u] = *reinterpret_cast<const float4*>(a_src[u] + (long)s * kBK);
+#pragma unroll
+    for (int u = 0; u < kBPer; ++u) rb[u] = *reinterpret_cast<const float4*>(b_src[u] + (long)s * kBK);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < kAPer; ++u)
+      if (u < mtiles) *reinterpret_cast<float4*>(&sA[buf][a_dst[u]]) = ra[u];   // item u == row tile u
+#pragma unroll
+    for (int u = 0; u < kBPer; ++u) *reinterpret_cast<float4*>(&sB[buf][b_dst[u]]) = rb[u];
+  };
+
+  f32x16 acc[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  if (nstages > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  __syncthreads();
+  const int a_base = j * kPitch + kk * 4;
+  const int b_base = (wave * 32 + j) * kPitch + kk * 4;
+  for (int s = 0; s < nstages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstages) load_stage(s + 1);
+    const float* pa = sA[buf];
+    const float* pb = sB[buf];
+#pragma unroll
+    for (int kc = 0; kc < kBK / 8; ++kc) {
+      const float4 b = *reinterpret_cast<const float4*>(pb + b_base + kc * 8);
+#pragma unroll
+      for (int t = 0; t < kMT; ++t) {
+        if (t < mtiles) {
+          const float4 a = *reinterpret_cast<const float4*>(pa + a_base + t * 32 * kPitch + kc * 8);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (s + 1 < nstages) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // D[row = m (reg&3)+8*(reg>>2)+4*kk][col = n j]
+  const int n = n0 + wave * 32 + j;
+  if (n < N) {
+    const float bv = fused ? bias[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) {
+      if (t < mtiles) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+          if (m < M) {
+            if (fused) out[(long)m * ldc + n] = apply_act(acc[t][e] + bv, act);
+            else part[((long)split * M + m) * N + n] = acc[t][e];
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int M, int N, int ldc, int splits,
+                                                        int act) {
+  const long total = (long)M * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % N);
+    const long m = idx / N;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += part[(long)s * total + idx];
+    out[m * ldc + n] = apply_act(v + bias[n], act);
+  }
+}
+
+__global__ void softmax_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int N) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float* r = in + (long)m * N;
+  float mx = r[0];
+  for (int i = 1; i < N; ++i) mx = fmaxf(mx, r[i]);
+  float sum = 0.f;
+  for (int i = 0; i < N; ++i) sum += expf(r[i] - mx);
+  for (int i = 0; i < N; ++i) out[(long)m * N + i] = expf(r[i] - mx) / sum;
+}
+
+__global__ void eltwise_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int op) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = apply_act(in[i], op);
+}
+
+// [N][C][PH][PW] columns -> [N][PH][PW][C] columns
+__global__ void pack_fc_kernel(const float* __restrict__ in, float* __restrict__ out, long N, int C, int P) {
+  const long total = N * C * P;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const long r = idx / C;
+    const int p = (int)(r % P);
+    const long n = r / P;
+    out[idx] = in[(n * C + c) * P + p];
+  }
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+extern "C" {
+
+int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_out, int M, int N, int K,
+           int ldc, int act) {
+  MNC_REQUIRE(ctx && d_a && d_w && d_bias && d_out, "mnc_fc: null pointer");
+  MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kBK == 0 && ldc >= N && act >= 0 && act <= 2,
+              "mnc_fc: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
+  if (M == 0) return MNC_OK;
+  const int tn = cdiv(N, kBN), tm = cdiv(M, kBM), stages = K / kBK;
+  // enough splits to give every CU a workgroup, but at least 8 stages (256 deep) per split
+  int splits = cdiv(256, tn * tm);
+  if (splits > stages / 8) splits = stages / 8;
+  if (splits < 1) splits = 1;
+  const int kper = cdiv(stages, splits) * kBK;
+  splits = cdiv(K, kper);
+  float* part = nullptr;
+  if (splits > 1) {
+    int rc = ensure_scratch(ctx, (size_t)splits * M * N * 4);
+    if (rc) return rc;
+    part = (float*)ctx->scratch;
+  }
+  const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
+  LaunchScope ls(ctx, "fc_mfma", flops, bytes);
+  hipLaunchKernelGGL(fc_mfma_kernel, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N,
+                     K, ldc, kper, act, splits == 1 ? 1 : 0);
+  if (splits > 1) {
+    long total = (long)M * N;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(fc_reduce_kernel, dim3(g), dim3(256), 0, ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+  }
+  return ls.finish("fc_mfma_kernel");
+}
+
+int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N) {
+  MNC_REQUIRE(ctx && d_in && d_out && M >= 0 && N > 0, "mnc_softmax_rows: bad argument");
+  if (M == 0) return MNC_OK;
+  LaunchScope ls(ctx, "softmax_rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 64)), dim3(64), 0, ctx->stream, d_in, d_out, M, N);
+  return ls.finish("softmax_rows_kernel");
+}
+
+int mnc_eltwise(mnc_ctx* ctx, const float* d_in, float* d_out, size_t count, int op) {
+  MNC_REQUIRE(ctx && (count == 0 || (d_in && d_out)) && (op == 1 || op == 2), "mnc_eltwise: bad argument");
+  if (count == 0) return MNC_OK;
+  LaunchScope ls(ctx, "eltwise");
+  size_t g = (count + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(eltwise_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, count, op);
+  return ls.finish("eltwise_kernel");
+}
+
+int mnc_copy2d(mnc_ctx* ctx, float* d_dst, int dst_ld, const float* d_src, int src_ld, int rows, int cols) {
+  MNC_REQUIRE(ctx && rows >= 0 && cols >= 0 && dst_ld >= cols && src_ld >= cols, "mnc_copy2d: bad argument");
+  if (rows == 0 || cols == 0) return MNC_OK;
+  MNC_REQUIRE(d_dst && d_src, "mnc_copy2d: null pointer");
+  MNC_HIP_TRY(hipMemcpy2DAsync(d_dst, (size_t)dst_ld * 4, d_src, (size_t)src_ld * 4, (size_t)cols * 4, rows,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_pack_fc_weights(mnc_ctx* ctx, const float* d_in, float* d_out, int N, int C, int PH, int PW) {
+  MNC_REQUIRE(ctx && d_in && d_out && N > 0 && C > 0 && PH > 0 && PW > 0, "mnc_pack_fc_weights: bad argument");
+  LaunchScope ls(ctx, "pack_fc");
+  long total = (long)N * C * PH * PW;
+  long g = (total + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(pack_fc_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, (long)N, C, PH * PW);
+  return ls.finish("pack_fc_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal header of libmnc_hip.so (gfx950 only).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mnc_hip.h"
+
+namespace mnc {
+
+void set_error(const char* fmt, ...);
+void clear_error();
+
+struct ProfRecord {
+  const char* name;
+  hipEvent_t start, stop;
+  double flops, bytes;
+};
+
+}  // namespace mnc
+
+struct mnc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool profiling = false;
+  std::vector<mnc::ProfRecord> prof;
+  std::vector<hipEvent_t> event_pool;
+  // split-K scratch for mnc_fc and friends; grown on demand, never shrunk
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+namespace mnc {
+
+int ensure_scratch(mnc_ctx* ctx, size_t bytes);
+void prof_begin(mnc_ctx* ctx, const char* name, double flops, double bytes);
+void prof_end(mnc_ctx* ctx);
+
+#define MNC_HIP_TRY(expr)                                                                    \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      mnc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return MNC_ERR_HIP;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+#define MNC_REQUIRE(cond, ...)       \
+  do {                               \
+    if (!(cond)) {                   \
+      mnc::set_error(__VA_ARGS__);   \
+      return MNC_ERR_INVALID;        \
+    }                                \
+  } while (0)
+
+// RAII bracket: records a HIP event pair around the kernels launched inside its scope when profiling is on, and
+// turns a failed launch into MNC_ERR_HIP.
+struct LaunchScope {
+  mnc_ctx* ctx;
+  LaunchScope(mnc_ctx* c, const char* name, double flops = 0.0, double bytes = 0.0) : ctx(c) {
+    if (ctx->profiling) prof_begin(ctx, name, flops, bytes);
+  }
+  int finish(const char* name) {
+    if (ctx->profiling) prof_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("kernel launch %s failed: %s", name, hipGetErrorString(e));
+      return MNC_ERR_HIP;
+    }
+    return MNC_OK;
+  }
+};
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-device stream + growable device buffer behind the host-pointer entry points (_nms/_mv): the reference
+// cudaMalloc/cudaFree's its scratch on every call (nms_kernel.cu:99-143, mv_kernel.cu:250-347).
+struct LegacyWs {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  void* buf = nullptr;
+  size_t cap = 0;
+};
+int legacy_ws(int device_id, size_t bytes, LegacyWs** out);  // nms.hip
+
+}  // namespace mnc

@@ -1,0 +1,293 @@
+// Mask voting for gfx950 -- replaces lib/nms/mv_kernel.cu (reference: 7 kernels, an N*H*W float render buffer
+// -- 1.44 GB at 600 masks on a 600x1000 canvas -- an R*H*W aggregate buffer and 12 cudaMalloc/cudaFree per call).
+//
+// Fused design: the aggregate  A_r(h,w) = sum_{i in cand(r)} render_i(h,w) * weight_i  (mask_render :36-91 +
+// mask_aggregate :93-112) is a pure function of (r,h,w), so it is never stored:
+//   kernel 1  mv_bounds   : grid (R, splits).  Each block walks a slab of the union box of result r's candidate boxes
+//                           (outside it every render is 0, and 0 > 0.4 is false), evaluates A_r per pixel with the
+//                           candidate boxes/weights staged in LDS, and reduces "A_r > 0.4" to min/max x,y with
+//                           wave shuffles + one atomicMin/Max per block  (reduce_mask_col/row + reduce_bounding_x/y,
+//                           :114-190).
+//   kernel 2  mv_resample : grid R, 448 threads.  Re-evaluates A_r at the <= 4 integer pixels each of the 21x21
+//                           output samples needs (mask_resize :193-240).
+// HBM traffic is the algorithmic minimum: masks + boxes in (1.06 MB at N=600), R*441 floats + R*4 ints out.
+//
+// Compiled with -ffp-contract=off; every float expression is written in the reference's operation order, so the
+// outputs are bit-exact with mv_kernel.cu evaluated without FMA contraction (== oracle/mnc_oracle.c == oracle/_ref).
+#include <climits>
+#include <mutex>
+
+#include "mnc_internal.h"
+
+namespace mnc {
+
+constexpr int kMaxCandLds = 1024;  // candidate descriptors staged in LDS per result (6 KB x 4); more -> chunked
+
+struct CandLds {
+  float x1[kMaxCandLds], y1[kMaxCandLds], x2[kMaxCandLds], y2[kMaxCandLds], w[kMaxCandLds];
+  int m[kMaxCandLds];
+};
+
+// mask_render for one pixel of one mask, mv_kernel.cu:36-91 (operation order preserved).
+__device__ __forceinline__ float render_px(float x1, float y1, float x2, float y2, const float* __restrict__ mask, int S,
+                                           int h, int w) {
+  if (w < x1 || w > x2 || h < y1 || h > y2) return 0.0f;
+  const float bw = (float)((double)(x2 - x1) + 1.0);
+  const float bh = (float)((double)(y2 - y1) + 1.0);
+  const float rw = (float)S / bw, rh = (float)S / bh;
+  const float ix = ((float)w - x1) * rw, iy = ((float)h - y1) * rh;
+  const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+  if (sx == S - 1 || sy == S - 1) return mask[sy * S + sx];
+  const int tl = sy * S + sx, tr = tl + 1, bl = tl + S, br = bl + 1;
+  const float fx = ix - sx, fy = iy - sy;
+  const float wtl = (1 - fx) * (1 - fy), wtr = fx * (1 - fy), wbl = (1 - fx) * fy, wbr = fx * fy;
+  return wtl * mask[tl] + wtr * mask[tr] + wbl * mask[bl] + wbr * mask[br];
+}
+
+// A_r(h, w): candidates in list order, val += render * weight (mask_aggregate, mv_kernel.cu:104-110).
+__device__ __forceinline__ float aggregate_px(const CandLds& cl, int nc, const float* __restrict__ masks, int S, int h,
+                                              int w) {
+  float val = 0.0f;
+  for (int i = 0; i < nc; ++i) {
+    const float r = render_px(cl.x1[i], cl.y1[i], cl.x2[i], cl.y2[i], masks + (long)cl.m[i] * S * S, S, h, w);
+    val += r * cl.w[i];
+  }
+  return val;
+}
+
+// Slow path for results with more than kMaxCandLds candidates: descriptors straight from global memory.
+__device__ float aggregate_px_global(const float* __restrict__ boxes, int box_dim, const float* __restrict__ masks,
+                                     const int* __restrict__ inds, const float* __restrict__ wts, int c0, int c1, int S,
+                                     int h, int w) {
+  float val = 0.0f;
+  for (int i = c0; i < c1; ++i) {
+    const int m = inds[i];
+    const float* b = boxes + (long)m * box_dim;
+    val += render_px(b[0], b[1], b[2], b[3], masks + (long)m * S * S, S, h, w) * wts[i];
+  }
+  return val;
+}
+
+__device__ __forceinline__ void stage_cands(CandLds& cl, const float* __restrict__ boxes, int box_dim,
+                                            const int* __restrict__ inds, const float* __restrict__ wts, int c0, int nc) {
+  for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+    const int m = inds[c0 + i];
+    const float* b = boxes + (long)m * box_dim;
+    cl.x1[i] = b[0]; cl.y1[i] = b[1]; cl.x2[i] = b[2]; cl.y2[i] = b[3];
+    cl.w[i] = wts[c0 + i];
+    cl.m[i] = m;
+  }
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// bounds: [R][4] = (min x, min y, max x, max y), pre-set to (INT_MAX, INT_MAX, -1, -1).
+__global__ __launch_bounds__(256) void mv_bounds_kernel(const float* __restrict__ boxes, int box_dim,
+                                                        const float* __restrict__ masks, int S,
+                                                        const int* __restrict__ inds, const int* __restrict__ starts,
+                                                        const float* __restrict__ wts, int H, int W,
+                                                        int* __restrict__ bounds) {
+  __shared__ CandLds cl;
+  __shared__ int red[4][4];
+  __shared__ int ubox[4];
+  const int r = blockIdx.x;
+  const int c0 = r == 0 ? 0 : starts[r - 1], c1 = starts[r];
+  const int nc = c1 - c0;
+  if (nc <= 0) return;
+  const bool in_lds = nc <= kMaxCandLds;
+  if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
+  if (threadIdx.x == 0) { ubox[0] = INT_MAX; ubox[1] = INT_MAX; ubox[2] = -1; ubox[3] = -1; }
+  __syncthreads();
+  // union of the candidates' pixel extents: pixel w is inside box iff x1 <= w <= x2 (float compare, :52)
+  {
+    int lx = INT_MAX, ly = INT_MAX, hx = -1, hy = -1;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+      float x1, y1, x2, y2;
+      if (in_lds) { x1 = cl.x1[i]; y1 = cl.y1[i]; x2 = cl.x2[i]; y2 = cl.y2[i]; }
+      else { const float* b = boxes + (long)inds[c0 + i] * box_dim; x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3]; }
+      // conservative integer hull, clipped to the canvas
+      const int ax = max(0, (int)floorf(x1)), ay = max(0, (int)floorf(y1));
+      const int bx = min(W - 1, (int)ceilf(x2)), by = min(H - 1, (int)ceilf(y2));
+      if (ax <= bx && ay <= by) { lx = min(lx, ax); ly = min(ly, ay); hx = max(hx, bx); hy = max(hy, by); }
+    }
+    lx = wave_min(lx); ly = wave_min(ly); hx = wave_max(hx); hy = wave_max(hy);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&ubox[0], lx); atomicMin(&ubox[1], ly); atomicMax(&ubox[2], hx); atomicMax(&ubox[3], hy);
+    }
+  }
+  __syncthreads();
+  const int ux1 = ubox[0], uy1 = ubox[1], ux2 = ubox[2], uy2 = ubox[3];
+  if (ux2 < ux1 || uy2 < uy1) return;
+  const int uw = ux2 - ux1 + 1, uh = uy2 - uy1 + 1;
+  // this block's slab of rows
+  const int rows_per = (uh + gridDim.y - 1) / gridDim.y;
+  const int ya = uy1 + blockIdx.y * rows_per, yb = min(uy2 + 1, ya + rows_per);
+  int lx = INT_MAX, ly = INT_MAX, hx = -1, hy = -1;
+  const long npx = (long)uw * max(0, yb - ya);
+  for (long p = threadIdx.x; p < npx; p += blockDim.x) {
+    const int h = ya + (int)(p / uw), w = ux1 + (int)(p % uw);
+    const float v = in_lds ? aggregate_px(cl, nc, masks, S, h, w)
+                           : aggregate_px_global(boxes, box_dim, masks, inds, wts, c0, c1, S, h, w);
+    if (v > 0.4f) {  // BINARIZE_THRESH, strict (mv_kernel.cu:13, :121, :136)
+      lx = min(lx, w); hx = max(hx, w); ly = min(ly, h); hy = max(hy, h);
+    }
+  }
+  lx = wave_min(lx); ly = wave_min(ly); hx = wave_max(hx); hy = wave_max(hy);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wave][0] = lx; red[wave][1] = ly; red[wave][2] = hx; red[wave][3] = hy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      lx = min(lx, red[k][0]); ly = min(ly, red[k][1]); hx = max(hx, red[k][2]); hy = max(hy, red[k][3]);
+    }
+    if (hx >= 0) {
+      atomicMin(&bounds[r * 4 + 0], lx); atomicMin(&bounds[r * 4 + 1], ly);
+      atomicMax(&bounds[r * 4 + 2], hx); atomicMax(&bounds[r * 4 + 3], hy);
+    }
+  }
+}
+
+// grid R, block 448 (7 waves; 441 active).  Finalises the box (defaults W/2, H/2, :149,:173) and resamples (:193-240).
+__global__ __launch_bounds__(448) void mv_resample_kernel(const float* __restrict__ boxes, int box_dim,
+                                                          const float* __restrict__ masks, int S,
+                                                          const int* __restrict__ inds, const int* __restrict__ starts,
+                                                          const float* __restrict__ wts, int H, int W,
+                                                          const int* __restrict__ bounds, float* __restrict__ out_mask,
+                                                          int* __restrict__ out_box) {
+  __shared__ CandLds cl;
+  const int r = blockIdx.x;
+  const int c0 = r == 0 ? 0 : starts[r - 1], c1 = starts[r];
+  const int nc = max(c1 - c0, 0);
+  const bool in_lds = nc <= kMaxCandLds;
+  if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
+  __syncthreads();
+  int bx1 = bounds[r * 4 + 0], by1 = bounds[r * 4 + 1], bx2 = bounds[r * 4 + 2], by2 = bounds[r * 4 + 3];
+  if (bx2 < 0) { bx1 = W / 2; bx2 = W / 2; }   // no column reached 0.4
+  if (by2 < 0) { by1 = H / 2; by2 = H / 2; }
+  if (threadIdx.x == 0) {
+    out_box[r * 4 + 0] = bx1; out_box[r * 4 + 1] = by1; out_box[r * 4 + 2] = bx2; out_box[r * 4 + 3] = by2;
+  }
+  for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
+    const int w = idx % S, h = idx / S;
+    const float bw = (float)((double)(bx2 - bx1) + 1.0), bh = (float)((double)(by2 - by1) + 1.0);
+    const float rw = bw / (float)S, rh = bh / (float)S;
+    const float ix = bx1 + (float)w * rw, iy = by1 + (float)h * rh;
+    const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+#define MNC_AGG(hh, ww) (in_lds ? aggregate_px(cl, nc, masks, S, (hh), (ww)) \
+                                : aggregate_px_global(boxes, box_dim, masks, inds, wts, c0, c1, S, (hh), (ww)))
+    float v;
+    if (sx == W - 1 || sy == H - 1) {
+      v = MNC_AGG(sy, sx);
+    } else {
+      const float fx = ix - sx, fy = iy - sy;
+      const float wtl = (1 - fx) * (1 - fy), wtr = fx * (1 - fy), wbl = (1 - fx) * fy, wbr = fx * fy;
+      const float atl = MNC_AGG(sy, sx), atr = MNC_AGG(sy, sx + 1), abl = MNC_AGG(sy + 1, sx), abr = MNC_AGG(sy + 1, sx + 1);
+      v = wtl * atl + wtr * atr + wbl * abl + wbr * abr;
+    }
+#undef MNC_AGG
+    out_mask[((long)r * S + h) * S + w] = v;
+  }
+}
+
+__global__ void mv_init_bounds_kernel(int* bounds, int R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < R * 4) bounds[i] = (i & 3) < 2 ? INT_MAX : -1;
+}
+
+// All pointers device.  d_bounds: R*4 ints scratch.
+int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
+              const int* d_starts, const float* d_wts, int H, int W, int R, int* d_bounds, float* d_out_mask,
+              int* d_out_box) {
+  if (R <= 0) return MNC_OK;
+  hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
+  // ~2048 blocks in flight: R results x `splits` row slabs each
+  int splits = 2048 / R;
+  if (splits < 1) splits = 1;
+  if (splits > 32) splits = 32;
+  hipLaunchKernelGGL(mv_bounds_kernel, dim3(R, splits), dim3(256), 0, stream, d_boxes, box_dim, d_masks, S, d_inds,
+                     d_starts, d_wts, H, W, d_bounds);
+  hipLaunchKernelGGL(mv_resample_kernel, dim3(R), dim3(448), 0, stream, d_boxes, box_dim, d_masks, S, d_inds, d_starts,
+                     d_wts, H, W, d_bounds, d_out_mask, d_out_box);
+  return MNC_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace mnc
+
+using namespace mnc;
+
+extern "C" {
+
+int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, const int* candidate_inds,
+           const int* candidate_start, const float* candidate_weights, int candidate_num, int image_height,
+           int image_width, int box_dim, int mask_size, int result_num, float* out_mask, int* out_box, int device_id) {
+  MNC_REQUIRE(all_boxes_num >= 0 && candidate_num >= 0 && result_num >= 0, "mnc_mv: negative count");
+  MNC_REQUIRE(box_dim >= 4 && mask_size >= 2 && image_height > 0 && image_width > 0,
+              "mnc_mv: box_dim=%d mask_size=%d H=%d W=%d", box_dim, mask_size, image_height, image_width);
+  if (result_num == 0) { clear_error(); return MNC_OK; }
+  MNC_REQUIRE(out_mask && out_box && candidate_start, "mnc_mv: null pointer");
+  MNC_REQUIRE(candidate_num == 0 || (all_boxes && all_masks && candidate_inds && candidate_weights), "mnc_mv: null pointer");
+  for (int r = 0; r < result_num; ++r) {
+    const int a = r ? candidate_start[r - 1] : 0, b = candidate_start[r];
+    MNC_REQUIRE(a <= b && b <= candidate_num, "mnc_mv: candidate_start[%d]=%d not a monotone END offset <= %d", r, b,
+                candidate_num);
+  }
+  for (int i = 0; i < candidate_num; ++i)
+    MNC_REQUIRE(candidate_inds[i] >= 0 && candidate_inds[i] < all_boxes_num, "mnc_mv: candidate_inds[%d]=%d out of range",
+                i, candidate_inds[i]);
+  const int S = mask_size, R = result_num;
+  const size_t b_boxes = align256((size_t)all_boxes_num * box_dim * 4), b_masks = align256((size_t)all_boxes_num * S * S * 4);
+  const size_t b_inds = align256((size_t)candidate_num * 4), b_wts = b_inds, b_starts = align256((size_t)R * 4);
+  const size_t b_bounds = align256((size_t)R * 16), b_omask = align256((size_t)R * S * S * 4), b_obox = align256((size_t)R * 16);
+  LegacyWs* w = nullptr;
+  int rc = legacy_ws(device_id, b_boxes + b_masks + b_inds + b_wts + b_starts + b_bounds + b_omask + b_obox, &w);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(w->mu);
+  char* p = (char*)w->buf;
+  float* d_boxes = (float*)p; p += b_boxes;
+  float* d_masks = (float*)p; p += b_masks;
+  int* d_inds = (int*)p; p += b_inds;
+  float* d_wts = (float*)p; p += b_wts;
+  int* d_starts = (int*)p; p += b_starts;
+  int* d_bounds = (int*)p; p += b_bounds;
+  float* d_omask = (float*)p; p += b_omask;
+  int* d_obox = (int*)p;
+  hipStream_t s = w->stream;
+  if (all_boxes_num) {
+    MNC_HIP_TRY(hipMemcpyAsync(d_boxes, all_boxes, (size_t)all_boxes_num * box_dim * 4, hipMemcpyHostToDevice, s));
+    MNC_HIP_TRY(hipMemcpyAsync(d_masks, all_masks, (size_t)all_boxes_num * S * S * 4, hipMemcpyHostToDevice, s));
+  }
+  if (candidate_num) {
+    MNC_HIP_TRY(hipMemcpyAsync(d_inds, candidate_inds, (size_t)candidate_num * 4, hipMemcpyHostToDevice, s));
+    MNC_HIP_TRY(hipMemcpyAsync(d_wts, candidate_weights, (size_t)candidate_num * 4, hipMemcpyHostToDevice, s));
+  }
+  MNC_HIP_TRY(hipMemcpyAsync(d_starts, candidate_start, (size_t)R * 4, hipMemcpyHostToDevice, s));
+  mv_launch(s, d_boxes, box_dim, d_masks, S, d_inds, d_starts, d_wts, image_height, image_width, R, d_bounds, d_omask, d_obox);
+  MNC_HIP_TRY(hipGetLastError());
+  MNC_HIP_TRY(hipMemcpyAsync(out_mask, d_omask, (size_t)R * S * S * 4, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipMemcpyAsync(out_box, d_obox, (size_t)R * 16, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipStreamSynchronize(s));
+  clear_error();
+  return MNC_OK;
+}
+
+void _mv(const float* all_boxes, const float* all_masks, const int all_boxes_num, const int* candidate_inds,
+         const int* candidate_start, const float* candidate_weights, const int candidate_num, const int image_height,
+         const int image_width, const int box_dim, const int mask_size, const int result_num, float* out_mask,
+         int* out_box, const int device_id) {
+  if (mnc_mv(all_boxes, all_masks, all_boxes_num, candidate_inds, candidate_start, candidate_weights, candidate_num,
+             image_height, image_width, box_dim, mask_size, result_num, out_mask, out_box, device_id) != MNC_OK)
+    fprintf(stderr, "mnc_hip: _mv failed: %s\n", mnc_last_error());
+}
+
+}  // extern "C"

@@ -1,0 +1,740 @@
+"""Device-resident executor of MNC inference graphs (models/VGG16/mnc_5stage/test.prototxt) on MI355X.
+
+`Net` reproduces the slice of pycaffe's `caffe.Net` that the reference's entry points and Python layers use
+(tools/demo.py:70-90,126-129; lib/caffeWrapper/TesterWrapper.py:30-31,226-284):
+
+    net = Net(prototxt, weights, caffe.TEST)        weights: .npz path | {layer: [W, b]} | {"layer/0": W, ...}
+    net.blobs[name].reshape(*shape) / .data / .shape
+    net.params[layer][i].data
+    net.forward(data=..., im_info=...) -> {output blob: ndarray}
+    net.name  (settable)
+
+Every layer runs as a hand-written HIP kernel of libmnc_hip.so through the C ABI (include/mnc_hip.h); blobs stay on
+the GPU in the engine's layouts (c8 feature maps, hwc per-RoI features) and are converted to Caffe's NCHW order only
+when `.data` is read.  `type: 'Python'` layers are instantiated from their module/class exactly as Caffe does and
+see host views of their bottoms/tops (this is where the reference also crosses device<->host).
+
+There is no CPU execution path: constructing a Net without a working libmnc_hip.so + GPU raises."""
+import ctypes
+import importlib
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib, install_paths, prototxt
+
+install_paths()
+
+F32 = np.dtype(np.float32)
+
+
+def _pool_out(n):
+    """Caffe Pooling MAX 2x2/2 pad 0: ceil((n - 2) / 2) + 1."""
+    return (n - 2 + 1) // 2 + 1
+
+
+class _Ctx(object):
+    def __init__(self, device_id):
+        _lib.load()
+        h = ctypes.c_void_p()
+        _lib.call("mnc_ctx_create", ctypes.addressof(h), int(device_id))
+        self.h = h.value
+        self.device_id = int(device_id)
+
+    def alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _lib.call("mnc_dev_alloc", self.h, int(max(nbytes, 16)), ctypes.addressof(p))
+        return p.value
+
+    def free(self, p):
+        if p and self.h:
+            _lib.call("mnc_dev_free", self.h, p)
+
+    def close(self):
+        if self.h:
+            _lib.call("mnc_ctx_destroy", self.h)
+            self.h = None
+
+
+class _DevBuf(object):
+    """Growable device buffer."""
+
+    def __init__(self, ctx):
+        self.ctx, self.ptr, self.cap = ctx, 0, 0
+
+    def ensure(self, nbytes):
+        if nbytes > self.cap:
+            if self.ptr:
+                self.ctx.free(self.ptr)
+            self.cap = int(nbytes * 1.25) + 256
+            self.ptr = self.ctx.alloc(self.cap)
+        return self.ptr
+
+    def release(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+        self.ptr, self.cap = 0, 0
+
+
+class Blob(object):
+    """A named tensor with Caffe's logical shape.  Device storage uses one of the engine layouts:
+         'plain' row-major in Caffe order (optionally a column slice of a wider matrix: ld > shape[1])
+         'c8'    [C/8][H][W][8]      for shape (1, C, H, W)
+         'rhwc'  [R][PH][PW][C]      for shape (R, C, PH, PW)
+    Exactly one of (host, device) may be stale; `.data` makes the host copy current and hands it out."""
+
+    def __init__(self, net, name, shape=(1,)):
+        self._net = net
+        self.name = name
+        self.shape = tuple(int(s) for s in shape)
+        self._host = None
+        self._host_valid = False
+        self._dev_valid = False
+        self.layout = "plain"
+        self._buf = _DevBuf(net._ctx)
+        self._view = None           # (parent Blob, column offset) for Concat inputs written in place
+        self.diff = None
+
+    # ---- pycaffe surface ----
+    @property
+    def count(self):
+        return int(np.prod(self.shape))
+
+    @property
+    def num(self):
+        return self.shape[0]
+
+    @property
+    def channels(self):
+        return self.shape[1] if len(self.shape) > 1 else 1
+
+    def reshape(self, *dims):
+        dims = tuple(int(d) for d in dims)
+        if dims != self.shape:
+            self.shape = dims
+            self._host = None
+            self._host_valid = False
+            self._dev_valid = False
+
+    @property
+    def data(self):
+        """Host ndarray in Caffe order.  Handing it out makes the host copy authoritative (it may be written)."""
+        arr = self._host_read()
+        self._dev_valid = False
+        return arr
+
+    # ---- engine side ----
+    def _host_read(self):
+        if self._host is None or self._host.shape != self.shape:
+            self._host = np.zeros(self.shape, dtype=F32)
+            if not self._dev_valid:
+                self._host_valid = True
+        if not self._host_valid:
+            if not self._dev_valid:
+                raise RuntimeError("blob %r has no valid contents" % self.name)
+            self._download()
+            self._host_valid = True
+        return self._host
+
+    def set_host(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=F32)
+        self.shape = arr.shape
+        self._host = arr
+        self._host_valid = True
+        self._dev_valid = False
+
+    def _ld(self):
+        if self._view is not None:
+            return self._view[0].shape[1]
+        return self.shape[1] if len(self.shape) > 1 else 1
+
+    def dev_ptr(self):
+        if self._view is not None:
+            parent, off = self._view
+            return parent._buf.ensure(parent.count * 4) + off * 4
+        return self._buf.ensure(self.count * 4)
+
+    def dev_out(self, layout):
+        """Pointer for a kernel that is about to overwrite this blob in `layout`."""
+        self.layout = layout
+        self._dev_valid = True
+        self._host_valid = False
+        return self.dev_ptr()
+
+    def dev_in(self, layout):
+        """Pointer to current contents in `layout`, uploading / converting as needed."""
+        net = self._net
+        if not self._dev_valid:
+            if not self._host_valid:
+                raise RuntimeError("blob %r is read before it was produced" % self.name)
+            assert self._view is None
+            ptr = self._buf.ensure(self.count * 4)
+            _lib.call("mnc_h2d", net._ctx.h, ptr, _lib.ptr(self._host), self.count * 4)
+            self.layout = "plain"
+            self._dev_valid = True
+        if self.layout != layout:
+            self._convert(layout)
+        return self.dev_ptr()
+
+    def _convert(self, layout):
+        net = self._net
+        tmp = net._tmp.ensure(self.count * 4)
+        h = net._ctx.h
+        src = self.dev_ptr()
+        if self.layout == "plain" and layout == "c8":
+            _, C, H, W = self.shape
+            _lib.call("mnc_nchw_to_c8", h, src, tmp, C, H, W)
+        elif self.layout == "c8" and layout == "plain":
+            _, C, H, W = self.shape
+            _lib.call("mnc_c8_to_nchw", h, src, tmp, C, H, W)
+        elif self.layout == "plain" and layout == "rhwc":
+            R, C, PH, PW = self.shape
+            _lib.call("mnc_rchw_to_rhwc", h, src, tmp, R, C, PH, PW)
+        elif self.layout == "rhwc" and layout == "plain":
+            R, C, PH, PW = self.shape
+            _lib.call("mnc_rhwc_to_rchw", h, src, tmp, R, C, PH, PW)
+        else:
+            raise RuntimeError("no conversion %s -> %s for blob %r" % (self.layout, layout, self.name))
+        _lib.call("mnc_d2d", h, src, tmp, self.count * 4)
+        self.layout = layout
+
+    def _download(self):
+        net = self._net
+        h = net._ctx.h
+        n = self.count
+        if n == 0:
+            return
+        if self._view is not None:
+            rows, cols = self.shape[0], self.shape[1]
+            tmp = net._tmp.ensure(n * 4)
+            _lib.call("mnc_copy2d", h, tmp, cols, self.dev_ptr(), self._ld(), rows, cols)
+            _lib.call("mnc_d2h", h, _lib.ptr(self._host), tmp, n * 4)
+            return
+        if self.layout == "plain":
+            _lib.call("mnc_d2h", h, _lib.ptr(self._host), self.dev_ptr(), n * 4)
+            return
+        tmp = net._tmp.ensure(n * 4)
+        if self.layout == "c8":
+            _, C, H, W = self.shape
+            _lib.call("mnc_c8_to_nchw", h, self.dev_ptr(), tmp, C, H, W)
+        else:
+            R, C, PH, PW = self.shape
+            _lib.call("mnc_rhwc_to_rchw", h, self.dev_ptr(), tmp, R, C, PH, PW)
+        _lib.call("mnc_d2h", h, _lib.ptr(self._host), tmp, n * 4)
+
+
+class _ReadOnlyBlob(object):
+    """What a Python layer gets as `bottom[i]`: reading .data does not invalidate the device copy."""
+
+    def __init__(self, blob):
+        self._b = blob
+
+    @property
+    def data(self):
+        return self._b._host_read()
+
+    @property
+    def shape(self):
+        return self._b.shape
+
+    @property
+    def diff(self):
+        return None
+
+    def reshape(self, *dims):
+        self._b.reshape(*dims)
+
+
+class _Param(object):
+    def __init__(self, arr):
+        self.data = arr
+        self.shape = arr.shape
+
+
+class _Layer(object):
+    def __init__(self, msg):
+        self.msg = msg
+        self.name = msg.get1("name")
+        self.type = msg.get1("type")
+        self.bottoms = list(msg.all("bottom"))
+        self.tops = list(msg.all("top"))
+        self.param_names = [p.get1("name") for p in msg.all("param")]
+        self.skip = False
+        self.relu = False          # in-place ReLU folded into this layer
+        self.act = 0               # 1 relu / 2 sigmoid folded into an InnerProduct
+        self.fused_pool = False    # following MAX 2x2/2 folded into this ROIWarping / MaskPooling
+        self.out_name = None       # blob written when a fusion redirects the output
+        self.run = None
+
+
+class Net(object):
+    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None):
+        if device_id is None:
+            try:
+                import caffe
+                device_id = caffe.get_device()
+            except Exception:
+                device_id = 0
+        if _lib.device_count() <= device_id:
+            raise RuntimeError("mnc_amd.engine.Net needs GPU %d (found %d device(s)); there is no CPU path"
+                               % (device_id, _lib.device_count()))
+        self.name = os.path.splitext(os.path.basename(str(prototxt_path)))[0]
+        self.phase = "TEST" if phase in (1, "TEST") else "TRAIN"
+        if self.phase != "TEST":
+            raise NotImplementedError("only caffe.TEST graphs are executed")
+        self._fuse = (os.environ.get("MNC_NO_FUSE", "0") != "1") if fuse is None else bool(fuse)
+        self._ctx = _Ctx(device_id)
+        self._tmp = _DevBuf(self._ctx)
+        self._net_msg = prototxt.parse_file(prototxt_path)
+        self._layers = [_Layer(m) for m in self._net_msg.all("layer")]
+        self.blobs = OrderedDict()
+        self.params = OrderedDict()
+        self._dev_params = {}
+        self._py = {}
+        self.inputs = list(self._net_msg.all("input"))
+        for name, shp in zip(self.inputs, self._net_msg.all("input_shape")):
+            self.blobs[name] = Blob(self, name, shp.all("dim"))
+        for L in self._layers:
+            for t in L.tops:
+                if t not in self.blobs:
+                    self.blobs[t] = Blob(self, t)
+        consumed = set(b for L in self._layers for b in L.bottoms)
+        self.outputs = [n for n in self.blobs if n not in consumed and n not in self.inputs]
+        self._consumers = {}
+        for i, L in enumerate(self._layers):
+            for b in L.bottoms:
+                if b not in L.tops:           # in-place layers do not count as separate consumers
+                    self._consumers.setdefault(b, []).append(i)
+        self._plan_fusions()
+        self._host_weights = self._read_weights(weights)
+        self._bind_layers()
+        _lib.call("mnc_ctx_sync", self._ctx.h)
+
+    # ------------------------------------------------------------------------------------------------ weights
+    @staticmethod
+    def _read_weights(weights):
+        if isinstance(weights, dict):
+            src = weights
+        else:
+            path = str(weights)
+            if path.endswith(".npz"):
+                src = dict(np.load(path))
+            elif path.endswith((".h5", ".hdf5", ".caffemodel.h5")):
+                try:
+                    import h5py
+                except ImportError:
+                    raise RuntimeError("reading Caffe HDF5 weights needs h5py, which is not installed; convert the "
+                                       "file to .npz ('<layer>/0' = weights, '<layer>/1' = bias)")
+                src = {}
+                with h5py.File(path, "r") as f:
+                    for lname, grp in f["data"].items():
+                        for k, v in grp.items():
+                            src["%s/%s" % (lname, k)] = np.array(v)
+            else:
+                raise ValueError("unsupported weights container %r (use .npz or a dict)" % path)
+        out = {}
+        for k, v in src.items():
+            if isinstance(v, (list, tuple)):
+                out[k] = [np.asarray(a, dtype=F32) for a in v]
+            else:
+                lname, idx = k.rsplit("/", 1)
+                out.setdefault(lname, [None, None])[int(idx)] = np.asarray(v, dtype=F32)
+        return out
+
+    def _layer_weights(self, L):
+        """[W, b] of a layer, following Caffe's sharing by `param { name }` (test.prototxt:514-515 <-> :829-834)."""
+        if L.name in self._host_weights:
+            return self._host_weights[L.name]
+        for other in self._layers:
+            if other is not L and L.param_names and all(L.param_names) and other.param_names == L.param_names \
+                    and other.name in self._host_weights:
+                return self._host_weights[other.name]
+        raise KeyError("no weights for layer %r (param names %r)" % (L.name, L.param_names))
+
+    def _upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=F32)
+        p = self._ctx.alloc(arr.nbytes)
+        _lib.call("mnc_h2d", self._ctx.h, p, _lib.ptr(arr), arr.nbytes)
+        return p
+
+    def _dev_param(self, key, builder):
+        if key not in self._dev_params:
+            self._dev_params[key] = builder()
+        return self._dev_params[key]
+
+    # ------------------------------------------------------------------------------------------------ planning
+    def _sole_consumer(self, blob, typ):
+        c = self._consumers.get(blob, [])
+        if len(c) == 1 and self._layers[c[0]].type == typ and blob not in self.outputs:
+            return self._layers[c[0]]
+        return None
+
+    def _plan_fusions(self):
+        by_top = {}
+        for L in self._layers:
+            if L.type == "ReLU" and L.bottoms == L.tops:
+                prod = by_top.get(L.bottoms[0])
+                if prod is not None and prod.type in ("Convolution", "InnerProduct"):
+                    prod.relu = True
+                    L.skip = True          # always folded: an in-place ReLU has no blob of its own
+            for t in L.tops:
+                by_top[t] = L
+        if not self._fuse:
+            return
+        for L in self._layers:
+            if L.type == "InnerProduct" and not L.relu:
+                nxt = self._sole_consumer(L.tops[0], "Sigmoid")
+                if nxt is not None:
+                    L.act, L.out_name, nxt.skip = 2, nxt.tops[0], True
+            if L.type in ("ROIWarping", "MaskPooling"):
+                nxt = self._sole_consumer(L.tops[0], "Pooling")
+                if nxt is not None and self._is_pool2(nxt):
+                    if L.type == "ROIWarping":
+                        rp = L.msg.get1("roi_warping_param")
+                        if rp.get1("pooled_h") % 2 or rp.get1("pooled_w") % 2:
+                            continue
+                    L.fused_pool, L.out_name, nxt.skip = True, nxt.tops[0], True
+
+    @staticmethod
+    def _is_pool2(L):
+        p = L.msg.get1("pooling_param")
+        return (p.get1("pool", "MAX") == "MAX" and p.get1("kernel_size") == 2 and p.get1("stride") == 2
+                and p.get1("pad", 0) == 0)
+
+    # ------------------------------------------------------------------------------------------------ binding
+    def _bind_layers(self):
+        for i, L in enumerate(self._layers):
+            if L.skip:
+                continue
+            binder = getattr(self, "_bind_" + L.type, None)
+            if binder is None:
+                raise NotImplementedError("layer type %r (%s) is not supported by the MI355X engine" % (L.type, L.name))
+            L.run = binder(L, i)
+        # static channel/geometry facts the binders need are discovered lazily at first forward
+
+    def _h(self):
+        return self._ctx.h
+
+    def _bind_Convolution(self, L, i):
+        cp = L.msg.get1("convolution_param")
+        k, pad, stride = cp.get1("kernel_size"), cp.get1("pad", 0), cp.get1("stride", 1)
+        cout = cp.get1("num_output")
+        W, b = self._layer_weights(L)
+        self.params[L.name] = [_Param(W), _Param(b)]
+        cin = W.shape[1]
+        key = tuple(L.param_names) if all(L.param_names) and L.param_names else (L.name,)
+        d_b = self._dev_param(key + ("b",), lambda: self._upload(b))
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+        relu = 1 if L.relu else 0
+        if k == 3 and pad == 1 and stride == 1 and cin == 3:
+            d_w = self._dev_param(key + ("w",), lambda: self._upload(W))
+
+            def run():
+                _, _, H, Wd = bot.shape
+                src = bot.dev_in("plain")
+                top.reshape(1, cout, H, Wd)
+                _lib.call("mnc_conv3x3_c3", self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cout, relu)
+            return run
+        if k == 3 and pad == 1 and stride == 1:
+            def build():
+                raw = self._upload(W)
+                packed = self._ctx.alloc((cin // 8) * cout * 76 * 4)
+                _lib.call("mnc_pack_conv3x3_weights", self._h(), raw, packed, cout, cin)
+                self._ctx.free(raw)
+                return packed
+            d_w = self._dev_param(key + ("w",), build)
+
+            def run():
+                _, _, H, Wd = bot.shape
+                src = bot.dev_in("c8")
+                top.reshape(1, cout, H, Wd)
+                _lib.call("mnc_conv3x3", self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cin, cout, relu)
+            return run
+        if k == 1 and pad == 0 and stride == 1 and not L.relu:
+            d_w = self._dev_param(key + ("w",), lambda: self._upload(W.reshape(cout, cin)))
+
+            def run():
+                _, _, H, Wd = bot.shape
+                src = bot.dev_in("c8")
+                top.reshape(1, cout, H, Wd)
+                _lib.call("mnc_conv1x1_to_nchw", self._h(), src, d_w, d_b, top.dev_out("plain"), H, Wd, cin, cout)
+            return run
+        raise NotImplementedError("Convolution %s: kernel %r pad %r stride %r" % (L.name, k, pad, stride))
+
+    def _bind_ReLU(self, L, i):
+        raise NotImplementedError("stand-alone ReLU %s (only in-place ReLU after Convolution/InnerProduct)" % L.name)
+
+    def _bind_Pooling(self, L, i):
+        if not self._is_pool2(L):
+            raise NotImplementedError("Pooling %s: only MAX 2x2 stride 2 pad 0" % L.name)
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+
+        def run():
+            if bot.shape[0] == 1 and (bot._dev_valid and bot.layout == "c8"):
+                _, C, H, W = bot.shape
+                src = bot.dev_in("c8")
+                top.reshape(1, C, _pool_out(H), _pool_out(W))
+                _lib.call("mnc_maxpool2_c8", self._h(), src, top.dev_out("c8"), C, H, W)
+            else:
+                R, C, PH, PW = bot.shape
+                src = bot.dev_in("rhwc")
+                top.reshape(R, C, PH // 2, PW // 2)
+                if R:
+                    _lib.call("mnc_maxpool2_rhwc", self._h(), src, top.dev_out("rhwc"), R, PH, PW, C)
+                else:
+                    top.dev_out("rhwc")
+        return run
+
+    def _bind_Reshape(self, L, i):
+        # only as part of Reshape(0,2,-1,0) -> Softmax(axis 1) -> Reshape(0,2A,-1,0)  (test.prototxt:440-462)
+        dims = L.msg.get1("reshape_param").get1("shape").all("dim")
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+
+        def run():
+            shp = list(bot.shape)
+            out = [shp[k] if d == 0 else d for k, d in enumerate(dims)]
+            if -1 in out:
+                known = int(np.prod([d for d in out if d != -1]))
+                out[out.index(-1)] = bot.count // known
+            src = bot.dev_in("plain")
+            top.reshape(*out)
+            _lib.call("mnc_d2d", self._h(), top.dev_out("plain"), src, bot.count * 4)
+        return run
+
+    def _bind_Softmax(self, L, i):
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+
+        def run():
+            src = bot.dev_in("plain")
+            top.reshape(*bot.shape)
+            if len(bot.shape) == 2:
+                if bot.shape[0]:
+                    _lib.call("mnc_softmax_rows", self._h(), src, top.dev_out("plain"), bot.shape[0], bot.shape[1])
+                else:
+                    top.dev_out("plain")
+            elif len(bot.shape) == 4 and bot.shape[0] == 1 and bot.shape[1] == 2:
+                # (1, 2, A*H, W): channel a pairs with channel A + a of the un-reshaped score blob
+                _lib.call("mnc_rpn_softmax", self._h(), src, top.dev_out("plain"), 1, bot.shape[2], bot.shape[3])
+            else:
+                raise NotImplementedError("Softmax %s over shape %r" % (L.name, bot.shape))
+        return run
+
+    def _bind_Sigmoid(self, L, i):
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+
+        def run():
+            src = bot.dev_in("plain")
+            top.reshape(*bot.shape)
+            _lib.call("mnc_eltwise", self._h(), src, top.dev_out("plain"), bot.count, 2)
+        return run
+
+    def _bind_ROIWarping(self, L, i):
+        rp = L.msg.get1("roi_warping_param")
+        ph, pw, scale = rp.get1("pooled_h"), rp.get1("pooled_w"), float(rp.get1("spatial_scale"))
+        feat, rois = self.blobs[L.bottoms[0]], self.blobs[L.bottoms[1]]
+        top = self.blobs[L.out_name or L.tops[0]]
+        pool2 = 1 if L.fused_pool else 0
+        oh, ow = (ph // 2, pw // 2) if pool2 else (ph, pw)
+
+        def run():
+            _, C, H, W = feat.shape
+            R = rois.shape[0]
+            d_feat, d_rois = feat.dev_in("c8"), rois.dev_in("plain")
+            top.reshape(R, C, oh, ow)
+            _lib.call("mnc_roi_warp", self._h(), d_feat, C, H, W, d_rois, R, oh, ow, scale, pool2, top.dev_out("rhwc"))
+        return run
+
+    def _bind_MaskResize(self, L, i):
+        mp = L.msg.get1("mask_resize_param")
+        oh, ow = mp.get1("output_height"), mp.get1("output_width")
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+
+        def run():
+            R, C, IH, IW = bot.shape
+            src = bot.dev_in("plain")
+            top.reshape(R, C, oh, ow)
+            _lib.call("mnc_mask_resize", self._h(), src, top.dev_out("plain"), R * C, IH, IW, oh, ow)
+        return run
+
+    def _bind_MaskPooling(self, L, i):
+        feat, mask = self.blobs[L.bottoms[0]], self.blobs[L.bottoms[1]]
+        top = self.blobs[L.out_name or L.tops[0]]
+        pool2 = 1 if L.fused_pool else 0
+
+        def run():
+            R, C, PH, PW = feat.shape
+            d_feat, d_mask = feat.dev_in("rhwc"), mask.dev_in("plain")
+            top.reshape(R, C, PH // 2 if pool2 else PH, PW // 2 if pool2 else PW)
+            _lib.call("mnc_mask_pool", self._h(), d_feat, d_mask, top.dev_out("rhwc"), R, PH, PW, C, pool2)
+        return run
+
+    def _bind_InnerProduct(self, L, i):
+        n_out = L.msg.get1("inner_product_param").get1("num_output")
+        W, b = self._layer_weights(L)
+        self.params[L.name] = [_Param(W), _Param(b)]
+        key = tuple(L.param_names) if L.param_names and all(L.param_names) else (L.name,)
+        d_b = self._dev_param(key + ("b",), lambda: self._upload(b))
+        bot = self.blobs[L.bottoms[0]]
+        top = self.blobs[L.out_name or L.tops[0]]
+        act = 1 if L.relu else L.act
+        K = W.shape[1]
+        state = {}
+
+        def weights_for(shape):
+            """Caffe flattens (C,PH,PW); the engine's per-RoI features are (PH,PW,C): permute the columns once."""
+            if len(shape) == 4 and shape[2] * shape[3] > 1:
+                geo = (shape[1], shape[2], shape[3])
+
+                def build():
+                    raw = self._upload(W)
+                    packed = self._ctx.alloc(W.nbytes)
+                    _lib.call("mnc_pack_fc_weights", self._h(), raw, packed, n_out, geo[0], geo[1], geo[2])
+                    self._ctx.free(raw)
+                    return packed
+                return self._dev_param(key + ("w",) + geo, build), "rhwc"
+            return self._dev_param(key + ("w", "plain"), lambda: self._upload(W)), "plain"
+
+        def run():
+            M = bot.shape[0]
+            if int(np.prod(bot.shape[1:])) != K:
+                raise ValueError("InnerProduct %s: input %r does not flatten to K=%d" % (L.name, bot.shape, K))
+            if "w" not in state:
+                state["w"], state["layout"] = weights_for(bot.shape)
+            src = bot.dev_in(state["layout"]) if M else 0
+            top.reshape(M, n_out)
+            dst = top.dev_out("plain")
+            if M:
+                _lib.call("mnc_fc", self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+        return run
+
+    def _bind_Concat(self, L, i):
+        if L.msg.get1("concat_param").get1("axis", 1) != 1:
+            raise NotImplementedError("Concat %s: only axis 1" % L.name)
+        top = self.blobs[L.tops[0]]
+        bots = [self.blobs[b] for b in L.bottoms]
+        # When every bottom is produced by an InnerProduct and read by nothing else, the producers write straight
+        # into column slices of the concat buffer (ld = total width) and the layer itself is a no-op.
+        producers = {}
+        for P in self._layers[:i]:
+            for t in ([P.out_name] if P.out_name else P.tops):
+                producers[t] = P
+        in_place = self._fuse and all(
+            producers.get(b.name) is not None and producers[b.name].type == "InnerProduct"
+            and len(self._consumers.get(b.name, [])) == 1 and b.name not in self.outputs for b in bots)
+        widths = [self._layer_nout(producers[b.name]) if in_place else None for b in bots]
+        if in_place:
+            off = 0
+            for b, w in zip(bots, widths):
+                b._view = (top, off)
+                off += w
+            total = off
+
+            def run():
+                R = bots[0].shape[0]
+                top.reshape(R, total)
+                top.layout = "plain"
+                top._dev_valid = True
+                top._host_valid = False
+            # the parent must have its final shape BEFORE the producers run: hook a pre-step on the first producer
+            first = min(self._layers.index(producers[b.name]) for b in bots)
+            self._pre_steps = getattr(self, "_pre_steps", {})
+            src_blob = self.blobs[self._layers[first].bottoms[0]]
+            self._pre_steps.setdefault(first, []).append(lambda: top.reshape(src_blob.shape[0], total))
+            return run
+
+        def run():
+            R = bots[0].shape[0]
+            total = sum(b.shape[1] for b in bots)
+            srcs = [b.dev_in("plain") for b in bots]
+            top.reshape(R, total)
+            dst = top.dev_out("plain")
+            off = 0
+            for b, s in zip(bots, srcs):
+                _lib.call("mnc_copy2d", self._h(), dst + off * 4, total, s, b._ld(), R, b.shape[1])
+                off += b.shape[1]
+        return run
+
+    @staticmethod
+    def _layer_nout(L):
+        return L.msg.get1("inner_product_param").get1("num_output")
+
+    def _bind_Python(self, L, i):
+        pp = L.msg.get1("python_param")
+        mod = importlib.import_module(pp.get1("module"))
+        layer = getattr(mod, pp.get1("layer"))()
+        layer.param_str_ = pp.get1("param_str", "")
+        layer.phase = self.phase
+        bots = [self.blobs[b] for b in L.bottoms]
+        tops = [self.blobs[t] for t in L.tops]
+        self._py[L.name] = layer
+        done = {}
+
+        def run():
+            ro = [_ReadOnlyBlob(b) for b in bots]
+            if not done:
+                layer.setup(ro, tops)
+                done["setup"] = True
+            layer.reshape(ro, tops)
+            for t in tops:                      # the layer writes through top[i].data[...]
+                t._host_valid, t._dev_valid = True, False
+            layer.forward(ro, tops)
+            for t in tops:
+                t._host_valid, t._dev_valid = True, False
+        return run
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, **kwargs):
+        for name, arr in kwargs.items():
+            if name not in self.inputs:
+                raise KeyError("%r is not an input blob of this net (%r)" % (name, self.inputs))
+            self.blobs[name].set_host(arr)
+        pre = getattr(self, "_pre_steps", {})
+        for i, L in enumerate(self._layers):
+            if L.run is None:
+                continue
+            for fn in pre.get(i, ()):
+                fn()
+            L.run()
+        _lib.call("mnc_ctx_sync", self._ctx.h)
+        return {name: self.blobs[name]._host_read() for name in self.outputs if self.blobs[name]._dev_valid
+                or self.blobs[name]._host_valid}
+
+    # ------------------------------------------------------------------------------------------------ profiling
+    def profile(self, enable=True):
+        _lib.call("mnc_prof_enable", self._ctx.h, 1 if enable else 0)
+        _lib.call("mnc_prof_reset", self._ctx.h)
+
+    def profile_records(self):
+        """[(kernel name, ms, flops, bytes)] recorded since profile(True); HIP events on the engine's stream."""
+        n = ctypes.c_int(0)
+        _lib.call("mnc_prof_count", self._ctx.h, ctypes.addressof(n))
+        out = []
+        name = ctypes.create_string_buffer(64)
+        ms, fl, by = ctypes.c_float(0), ctypes.c_double(0), ctypes.c_double(0)
+        for i in range(n.value):
+            _lib.call("mnc_prof_get", self._ctx.h, i, ctypes.addressof(name), 64, ctypes.addressof(ms),
+                      ctypes.addressof(fl), ctypes.addressof(by))
+            out.append((name.value.decode(), float(ms.value), float(fl.value), float(by.value)))
+        _lib.call("mnc_prof_reset", self._ctx.h)
+        return out
+
+    def sync(self):
+        _lib.call("mnc_ctx_sync", self._ctx.h)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.h:
+            _lib.call("mnc_ctx_sync", self._ctx.h)
+            for b in self.blobs.values():
+                b._buf.release()
+            self._tmp.release()
+            for p in self._dev_params.values():
+                self._ctx.free(p)
+            self._dev_params = {}
+            self._ctx.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

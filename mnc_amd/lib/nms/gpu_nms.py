@@ -1,0 +1,28 @@
+"""`nms.gpu_nms.gpu_nms` -- same call as the reference's Cython wrapper (lib/nms/gpu_nms.pyx:16-31) over the HIP
+kernel behind mnc_nms (mnc_amd/csrc/nms.hip).  The score sort stays on the host exactly as in the reference
+(`argsort()[::-1]`), so tie order is whatever numpy gives there too."""
+import ctypes
+
+import numpy as np
+
+from mnc_amd import _lib
+
+
+def gpu_nms(dets, thresh, device_id=0, max_keep=-1):
+    dets = np.ascontiguousarray(dets, dtype=np.float32)
+    if dets.ndim != 2 or dets.shape[1] < 5:
+        raise ValueError("gpu_nms expects an (n, 5) float32 array")
+    n, dim = dets.shape
+    if n == 0:
+        return []
+    order = dets[:, 4].argsort()[::-1]
+    sorted_dets = np.ascontiguousarray(dets[order, :])
+    keep = np.zeros(n, dtype=np.int32)
+    num = ctypes.c_int(0)
+    if max_keep is None or max_keep < 0:
+        _lib.call("mnc_nms", _lib.ptr(keep), ctypes.addressof(num), _lib.ptr(sorted_dets), n, dim, float(thresh),
+                  int(device_id))
+    else:
+        _lib.call("mnc_nms_topk", _lib.ptr(keep), ctypes.addressof(num), _lib.ptr(sorted_dets), n, dim, float(thresh),
+                  int(max_keep), int(device_id))
+    return [int(i) for i in order[keep[:num.value]]]

@@ -1,0 +1,49 @@
+"""Image -> network input (reference: lib/utils/blob.py:17-50).  cv2 is not required: the INTER_LINEAR resize of a
+float32 image is implemented here (OpenCV convention: source = (dst + 0.5)/scale - 0.5, border-clamped)."""
+import numpy as np
+
+
+def _linear_taps(n_dst, n_src, scale):
+    src = ((np.arange(n_dst, dtype=np.float64) + 0.5) / scale - 0.5).astype(np.float32)
+    lo = np.floor(src).astype(np.int64)
+    frac = (src - lo).astype(np.float32)
+    under, over = lo < 0, lo >= n_src - 1
+    frac[under | over] = 0.0
+    lo[under] = 0
+    lo[over] = n_src - 1
+    return lo, np.minimum(lo + 1, n_src - 1), frac
+
+
+def resize_linear(im, fx, fy):
+    """cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) for float32 HxWxC."""
+    im = np.asarray(im, dtype=np.float32)
+    h, w = im.shape[:2]
+    if fx == 1.0 and fy == 1.0:
+        return im
+    x0, x1, ax = _linear_taps(int(round(w * fx)), w, fx)
+    y0, y1, ay = _linear_taps(int(round(h * fy)), h, fy)
+    one = np.float32(1.0)
+    rows = im[:, x0] * (one - ax)[None, :, None] + im[:, x1] * ax[None, :, None]
+    return (rows[y0] * (one - ay)[:, None, None] + rows[y1] * ay[:, None, None]).astype(np.float32)
+
+
+def im_list_to_blob(ims):
+    """Zero-padded stack of prepared HxWx3 images -> float32 [N,3,H,W]."""
+    hmax = max(im.shape[0] for im in ims)
+    wmax = max(im.shape[1] for im in ims)
+    blob = np.zeros((len(ims), 3, hmax, wmax), dtype=np.float32)
+    for i, im in enumerate(ims):
+        blob[i, :, :im.shape[0], :im.shape[1]] = im.transpose(2, 0, 1)
+    return blob
+
+
+def prep_im_for_blob(im, pixel_means, target_size, max_size):
+    """Subtract the BGR means (in float64, rounded once to float32 -- what `float32_array -= float64_array` does in
+    the reference), then scale the short side to target_size unless that pushes the long side past max_size."""
+    im = im.astype(np.float32, copy=True)
+    im -= pixel_means
+    short, long_ = min(im.shape[0:2]), max(im.shape[0:2])
+    scale = float(target_size) / float(short)
+    if np.round(scale * long_) > max_size:
+        scale = float(max_size) / float(long_)
+    return resize_linear(im, scale, scale), scale

@@ -1,0 +1,149 @@
+"""Programmatic description of the VGG-16 MNC 5-stage INFERENCE graph.
+
+The engine executes any prototxt given to `caffe.Net` (e.g. the reference's own
+models/VGG16/mnc_5stage/test.prototxt passed with --def).  For tests, the bench and the GPU box -- where the
+reference checkout is not available -- this module EMITS an equivalent prototxt from a compact builder, so no model
+file has to be vendored.  tests/test_graph_equivalence.py checks layer by layer (names, types, bottoms/tops, shared
+parameter names, hyper-parameters) that the emitted graph equals the reference file when that is mounted.
+
+Graph facts encoded here (citations into the reference's test.prototxt):
+  trunk conv1_1..conv5_3 with 4 MAX 2x2/2 pools (:19-387); RPN head + 2-way softmax via Reshape (:391-462);
+  `proposal` Python layer (:463-475); stage 2 warps 28x28 then pools to 14x14 (:479-505) while stage 4 warps
+  directly to 14x14 (:809-820); Concat order is (fc7_mask, fc7) (:700-709); stage 4/5 share all 9 weight/bias pairs
+  with stage 2/3 through `param { name }` (:514-515 <-> :829-834, ...)."""
+import os
+import tempfile
+
+VGG_CFG = [("1_1", 64), ("1_2", 64), "P1", ("2_1", 128), ("2_2", 128), "P2", ("3_1", 256), ("3_2", 256), ("3_3", 256),
+           "P3", ("4_1", 512), ("4_2", 512), ("4_3", 512), "P4", ("5_1", 512), ("5_2", 512), ("5_3", 512)]
+
+
+class _Emit(object):
+    def __init__(self, name):
+        self.lines = ['name: "%s"' % name]
+
+    def raw(self, text):
+        self.lines.append(text)
+
+    def layer(self, name, typ, bottoms, tops, body="", params=None):
+        out = ["layer {", '  name: "%s"' % name, '  type: "%s"' % typ]
+        out += ['  bottom: "%s"' % b for b in bottoms]
+        out += ['  top: "%s"' % t for t in tops]
+        for p in params or []:
+            out.append('  param { name: "%s" }' % p)
+        if body:
+            out.append("  " + body)
+        out.append("}")
+        self.lines.append("\n".join(out))
+
+    def text(self):
+        return "\n".join(self.lines) + "\n"
+
+
+def _conv(e, name, bottom, top, n_out, k, pad):
+    e.layer(name, "Convolution", [bottom], [top],
+            "convolution_param { num_output: %d kernel_size: %d pad: %d stride: 1 }" % (n_out, k, pad))
+
+
+def _relu(e, name, blob):
+    e.layer(name, "ReLU", [blob], [blob])
+
+
+def _pool(e, name, bottom, top):
+    e.layer(name, "Pooling", [bottom], [top], "pooling_param { pool: MAX kernel_size: 2 stride: 2 pad: 0 }")
+
+
+def _fc(e, name, bottom, top, n_out, pname):
+    e.layer(name, "InnerProduct", [bottom], [top], "inner_product_param { num_output: %d }" % n_out,
+            params=[pname + "_w", pname + "_b"])
+
+
+def _head(e, sfx, rois, warp_direct, d=1):
+    """Stages 2+3 (sfx '') or 4+5 (sfx '_ext'): mask estimation + box/mask classification on `rois`."""
+    wide, narrow = 4096 // d, max(256 // d, 32)
+    feat = "roi_interpolate_conv5" + sfx
+    if warp_direct:
+        e.layer(feat, "ROIWarping", ["conv5_3", rois], [feat],
+                "roi_warping_param { pooled_w: 14 pooled_h: 14 spatial_scale: 0.0625 }")
+    else:
+        pre = "roi_interpolate_conv5_premax" + sfx
+        e.layer(pre, "ROIWarping", ["conv5_3", rois], [pre],
+                "roi_warping_param { pooled_w: 28 pooled_h: 28 spatial_scale: 0.0625 }")
+        _pool(e, feat, pre, feat)
+    _fc(e, "fc6_maskest" + sfx, feat, "fc6_maskest" + sfx, narrow, "fc6_maskest")
+    _relu(e, "relu6_maskest" + sfx, "fc6_maskest" + sfx)
+    _fc(e, "mask_pred" + sfx, "fc6_maskest" + sfx, "mask_pred" + sfx, 441, "mask_pred")
+    e.layer("mask_output" + sfx, "Sigmoid", ["mask_pred" + sfx], ["mask_output" + sfx])
+    e.layer("mask_proposal" + sfx, "Python", ["mask_output" + sfx], ["mask_proposal" + sfx],
+            "python_param { module: 'pylayer.mask_layer' layer: 'MaskLayer' }")
+    e.layer("mask_resize" + sfx, "MaskResize", ["mask_proposal" + sfx], ["mask_proposal_resize" + sfx],
+            "mask_resize_param { output_height: 14 output_width: 14 }")
+    _pool(e, "roi_interpolate_conv5_box" + sfx, feat, "roi_interpolate_conv5_box" + sfx)
+    _fc(e, "fc6" + sfx, "roi_interpolate_conv5_box" + sfx, "fc6" + sfx, wide, "fc6")
+    _relu(e, "relu6" + sfx, "fc6" + sfx)
+    _fc(e, "fc7" + sfx, "fc6" + sfx, "fc7" + sfx, wide, "fc7")
+    _relu(e, "relu7" + sfx, "fc7" + sfx)
+    e.layer("mask_pooling" + sfx, "MaskPooling", [feat, "mask_proposal_resize" + sfx], ["roi_mask_conv5" + sfx])
+    _pool(e, "roi_interpolate_conv5_mask" + sfx, "roi_mask_conv5" + sfx, "roi_interpolate_conv5_mask" + sfx)
+    _fc(e, "fc6_mask" + sfx, "roi_interpolate_conv5_mask" + sfx, "fc6_mask" + sfx, wide, "fc6_mask")
+    _relu(e, "relu6_mask" + sfx, "fc6_mask" + sfx)
+    _fc(e, "fc7_mask" + sfx, "fc6_mask" + sfx, "fc7_mask" + sfx, wide, "fc7_mask")
+    _relu(e, "relu7_mask" + sfx, "fc7_mask" + sfx)
+    e.layer("join_box_mask" + sfx, "Concat", ["fc7_mask" + sfx, "fc7" + sfx], ["join_box_mask" + sfx],
+            "concat_param { axis: 1 }")
+    _fc(e, "cls_score" + sfx, "join_box_mask" + sfx, "cls_score" + sfx, 21, "cls_score")
+    e.layer("cls_prob" + sfx, "Softmax", ["cls_score" + sfx], ["cls_prob" + sfx])
+    _fc(e, "seg_cls_score" + sfx, "join_box_mask" + sfx, "seg_cls_score" + sfx, 21, "seg_cls_score")
+    e.layer("seg_cls_prob" + sfx, "Softmax", ["seg_cls_score" + sfx], ["seg_cls_prob" + sfx])
+    _fc(e, "bbox_pred" + sfx, "join_box_mask" + sfx, "bbox_pred" + sfx, 84, "bbox_pred")
+
+
+def mnc_5stage_test_prototxt(width_div=1):
+    """Text of the 5-stage test graph.  width_div > 1 divides every trunk/FC width (a reduced net for quick executor
+    tests; 1 is the real VGG-16 model)."""
+    d = width_div
+    e = _Emit("VGG16")
+    e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
+    e.raw('input: "im_info"\ninput_shape { dim: 1 dim: 3 }')
+    bottom = "data"
+    for item in VGG_CFG:
+        if isinstance(item, str):
+            top = "pool" + item[1]
+            _pool(e, top, bottom, top)
+        else:
+            tag, width = item
+            top = "conv" + tag
+            _conv(e, top, bottom, top, max(width // d, 32), 3, 1)
+            _relu(e, "relu" + tag, top)
+        bottom = top
+    _conv(e, "rpn_conv_3x3", "conv5_3", "rpn_output", max(512 // d, 32), 3, 1)
+    _relu(e, "rpn_relu_3x3", "rpn_output")
+    _conv(e, "rpn_cls_score", "rpn_output", "rpn_cls_score", 18, 1, 0)
+    _conv(e, "rpn_bbox_pred", "rpn_output", "rpn_bbox_pred", 36, 1, 0)
+    e.layer("rpn_cls_score_reshape", "Reshape", ["rpn_cls_score"], ["rpn_cls_score_reshape"],
+            "reshape_param { shape { dim: 0 dim: 2 dim: -1 dim: 0 } }")
+    e.layer("rpn_cls_prob", "Softmax", ["rpn_cls_score_reshape"], ["rpn_cls_prob"])
+    e.layer("rpn_cls_prob_reshape", "Reshape", ["rpn_cls_prob"], ["rpn_cls_prob_reshape"],
+            "reshape_param { shape { dim: 0 dim: 18 dim: -1 dim: 0 } }")
+    e.layer("proposal", "Python", ["rpn_cls_prob_reshape", "rpn_bbox_pred", "im_info"], ["rois"],
+            "python_param { module: 'pylayer.proposal_layer' layer: 'ProposalLayer' "
+            "param_str: \"{'feat_stride': 16, 'gradient_scale': 1}\" }")
+    _head(e, "", "rois", False, d)
+    e.layer("stage_bridge", "Python", ["rois", "bbox_pred", "seg_cls_prob", "im_info"], ["rois_ext"],
+            "python_param { module: 'pylayer.stage_bridge_layer' layer: 'StageBridgeLayer' }")
+    _head(e, "_ext", "rois_ext", True, d)
+    return e.text()
+
+
+def write_mnc_5stage_test_prototxt(path=None, width_div=1):
+    """Write the graph to `path` (default: a per-user temp file) and return the path."""
+    text = mnc_5stage_test_prototxt(width_div)
+    if path is None:
+        d = os.path.join(tempfile.gettempdir(), "mnc_amd_models")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "mnc_5stage_test_w%d.prototxt" % width_div)
+    tmp = path + ".%d.tmp" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(text)
+    os.replace(tmp, path)
+    return path

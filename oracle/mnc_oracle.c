@@ -198,6 +198,7 @@ ORC_EXPORT void orc_mv(const float* all_boxes, const float* all_masks, int all_b
  * the integer neighbours; taps outside the feature map contribute 0. */
 ORC_EXPORT void orc_roi_warp(const float* feat, int C, int H, int W, const float* rois, int R,
                              int PH, int PW, float scale, float* out) {
+#pragma omp parallel for schedule(dynamic, 1)
   for (int r = 0; r < R; ++r) {
     const float* roi = rois + 5 * r;
     const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
@@ -254,6 +255,7 @@ ORC_EXPORT void orc_mask_resize(const float* in, int R, int IH, int IW, int OH, 
 /* MaskPooling (test.prototxt:631-637, 958-964).  SPEC.md section 3.
  * SPEC-CHOICE: element-wise product of the per-RoI feature with the continuous mask, broadcast over channels. */
 ORC_EXPORT void orc_mask_pool(const float* feat, const float* mask, int R, int C, int H, int W, float* out) {
+#pragma omp parallel for
   for (int r = 0; r < R; ++r)
     for (int c = 0; c < C; ++c)
       for (int i = 0; i < H * W; ++i)
@@ -264,6 +266,7 @@ ORC_EXPORT void orc_mask_pool(const float* feat, const float* mask, int R, int C
  * clipped to the input (so 75 -> 38, 125 -> 63).  planes = N*C. */
 ORC_EXPORT void orc_maxpool2(const float* in, long planes, int H, int W, float* out) {
   const int OH = (H - 2 + 1) / 2 + 1, OW = (W - 2 + 1) / 2 + 1;
+#pragma omp parallel for
   for (long p = 0; p < planes; ++p) {
     const float* src = in + p * H * W;
     float* dst = out + p * OH * OW;

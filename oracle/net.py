@@ -1,0 +1,133 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the network graph models/VGG16/mnc_5stage/test.prototxt.
+
+Standard Caffe layers (Convolution = cross-correlation + bias, ReLU, MAX Pooling with Caffe's ceil output size,
+InnerProduct over a C-major (c,h,w) flatten, Softmax over axis 1, Sigmoid, Reshape, Concat) are public BVLC semantics;
+they are evaluated with torch on the CPU in float32.  The three MNC-specific layers come from oracle/mnc_oracle.c
+(oracle/SPEC.md; PARITY UNPINNED -- their source is in the un-vendored caffe-mnc submodule).  Python layers come from
+oracle/host.py.  All blobs are returned in Caffe's NCHW order under the prototxt's blob names.
+
+Also serves as bench.py's `cpu_baseline` ("port": the Caffe runtime itself cannot be built here).
+Nothing under mnc_amd/ may import this module."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import host, native
+
+TRUNK = ["conv1_1", "conv1_2", "P", "conv2_1", "conv2_2", "P", "conv3_1", "conv3_2", "conv3_3", "P",
+         "conv4_1", "conv4_2", "conv4_3", "P", "conv5_1", "conv5_2", "conv5_3"]        # test.prototxt:19-387
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def _conv(x, wb, relu=True, pad=1):
+    y = F.conv2d(x, _t(wb[0]), _t(wb[1]), padding=pad)
+    return F.relu(y) if relu else y
+
+
+def _fc(x, wb, act=None):
+    y = F.linear(x, _t(wb[0]), _t(wb[1]))
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "sigmoid":
+        y = torch.sigmoid(y)
+    return y
+
+
+def trunk(weights, data, blobs=None):
+    """conv1_1 .. conv5_3 (test.prototxt:19-387); pooling output size ceil((n-2)/2)+1 (75->38, 125->63)."""
+    x = _t(data)
+    pool_i = 0
+    for name in TRUNK:
+        if name == "P":
+            x = F.max_pool2d(x, 2, 2, ceil_mode=True)
+            pool_i += 1
+            if blobs is not None:
+                blobs["pool%d" % pool_i] = x.numpy()
+        else:
+            x = _conv(x, weights[name])
+            if blobs is not None:
+                blobs[name] = x.numpy()
+    return x
+
+
+def rpn(weights, conv5_3, blobs=None):
+    """rpn_conv_3x3 + ReLU, 1x1 heads, Reshape(0,2,-1,0)/Softmax/Reshape(0,18,-1,0) (test.prototxt:391-462)."""
+    r = _conv(conv5_3, weights["rpn_conv_3x3"])
+    score = _conv(r, weights["rpn_cls_score"], relu=False, pad=0)
+    bbox = _conv(r, weights["rpn_bbox_pred"], relu=False, pad=0)
+    n, c, h, w = score.shape
+    prob = F.softmax(score.reshape(n, 2, -1, w), dim=1).reshape(n, c, h, w)
+    if blobs is not None:
+        blobs.update(rpn_output=r.numpy(), rpn_cls_score=score.numpy(), rpn_bbox_pred=bbox.numpy(),
+                     rpn_cls_prob_reshape=prob.numpy())
+    return prob.numpy(), bbox.numpy()
+
+
+def head(weights, conv5_3, rois, warp_direct, sfx="", blobs=None):
+    """Stages 2+3 (28x28 warp + pool, test.prototxt:479-785) or 4+5 (direct 14x14 warp, :809-1106) on `rois`."""
+    out = {}
+    feat5 = conv5_3.numpy() if isinstance(conv5_3, torch.Tensor) else conv5_3
+    if warp_direct:
+        feat = native.roi_warp(feat5, rois, 14, 14, 0.0625)
+    else:
+        pre = native.roi_warp(feat5, rois, 28, 28, 0.0625)
+        out["roi_interpolate_conv5_premax"] = pre
+        feat = native.maxpool2(pre)
+    out["roi_interpolate_conv5"] = feat
+    R = feat.shape[0]
+    f6m = _fc(_t(feat).reshape(R, -1), weights["fc6_maskest"], "relu")
+    mask_out = _fc(f6m, weights["mask_pred"], "sigmoid").numpy()
+    out["fc6_maskest"], out["mask_output"] = f6m.numpy(), mask_out
+    mask_prop = host.mask_layer_forward_test(mask_out)
+    out["mask_proposal"] = mask_prop
+    mask14 = native.mask_resize(mask_prop, 14, 14)
+    out["mask_proposal_resize"] = mask14
+    box = native.maxpool2(feat)
+    out["roi_interpolate_conv5_box"] = box
+    fc6 = _fc(_t(box).reshape(R, -1), weights["fc6"], "relu")
+    fc7 = _fc(fc6, weights["fc7"], "relu")
+    masked = native.mask_pool(feat, mask14)
+    out["roi_mask_conv5"] = masked
+    mpool = native.maxpool2(masked)
+    out["roi_interpolate_conv5_mask"] = mpool
+    fc6m = _fc(_t(mpool).reshape(R, -1), weights["fc6_mask"], "relu")
+    fc7m = _fc(fc6m, weights["fc7_mask"], "relu")
+    join = torch.cat([fc7m, fc7], dim=1)                       # Concat order (fc7_mask, fc7), test.prototxt:700-709
+    out.update(fc6=fc6.numpy(), fc7=fc7.numpy(), fc6_mask=fc6m.numpy(), fc7_mask=fc7m.numpy(),
+               join_box_mask=join.numpy())
+    cls = _fc(join, weights["cls_score"])
+    seg = _fc(join, weights["seg_cls_score"])
+    out["cls_score"], out["seg_cls_score"] = cls.numpy(), seg.numpy()
+    out["cls_prob"] = F.softmax(cls, dim=1).numpy()
+    out["seg_cls_prob"] = F.softmax(seg, dim=1).numpy()
+    out["bbox_pred"] = _fc(join, weights["bbox_pred"]).numpy()
+    if blobs is not None:
+        for k, v in out.items():
+            blobs[k + sfx] = v
+    return out
+
+
+def forward(weights, data, im_info, blobs=None, nms_fn=None):
+    """Whole net.forward() (tools/demo.py:81): returns the dict of all blobs."""
+    torch.set_grad_enabled(False)
+    blobs = {} if blobs is None else blobs
+    c5 = trunk(weights, data, blobs)
+    prob, bbox = rpn(weights, c5, blobs)
+    rois = host.proposal_forward(prob, bbox, im_info, nms_fn)
+    blobs["rois"] = rois
+    h1 = head(weights, c5, rois, False, "", blobs)
+    rois_ext = host.stage_bridge_forward_test(rois, h1["bbox_pred"], h1["seg_cls_prob"], im_info)
+    blobs["rois_ext"] = rois_ext
+    head(weights, c5, rois_ext, True, "_ext", blobs)
+    return blobs
+
+
+def im_detect(weights, im, nms_fn=None):
+    """tools/demo.py:79-100: image (HxWx3 BGR) -> (boxes [2R,4], masks [2R,1,21,21], seg scores [2R,21])."""
+    data, im_info, scale = host.prepare_mnc_args(im)
+    b = forward(weights, data, im_info, nms_fn=nms_fn)
+    return host.im_detect_tail(b["rois"], b["mask_proposal"], b["seg_cls_prob"], b["rois_ext"],
+                               b["mask_proposal_ext"], b["seg_cls_prob_ext"], scale, im.shape)
