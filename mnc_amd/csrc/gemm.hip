@@ -211,16 +211,22 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     part = (float*)ctx->scratch;
   }
   const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
-  LaunchScope ls(ctx, "fc_mfma", flops, bytes);
-  hipLaunchKernelGGL(fc_mfma_kernel, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N,
-                     K, ldc, kper, act, splits == 1 ? 1 : 0);
+  {
+    LaunchScope ls(ctx, "fc_mfma", flops, bytes);
+    hipLaunchKernelGGL(fc_mfma_kernel, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part, M,
+                       N, K, ldc, kper, act, splits == 1 ? 1 : 0);
+    int rc = ls.finish("fc_mfma_kernel");
+    if (rc) return rc;
+  }
   if (splits > 1) {
+    LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
     long total = (long)M * N;
     int g = (int)((total + 255) / 256);
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(fc_reduce_kernel, dim3(g), dim3(256), 0, ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+    return ls.finish("fc_reduce_kernel");
   }
-  return ls.finish("fc_mfma_kernel");
+  return MNC_OK;
 }
 
 int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N) {

@@ -617,6 +617,8 @@ class Net(object):
         # into column slices of the concat buffer (ld = total width) and the layer itself is a no-op.
         producers = {}
         for P in self._layers[:i]:
+            if P.skip:
+                continue
             for t in ([P.out_name] if P.out_name else P.tops):
                 producers[t] = P
         in_place = self._fuse and all(

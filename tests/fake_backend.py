@@ -1,0 +1,222 @@
+"""TEST DOUBLE (CPU tests only): an emulation of libmnc_hip.so's entry points on host memory, used to exercise the HOST
+logic of mnc_amd.engine / mnc_amd.lib (graph planning, fusions, layouts, Concat views, Python-layer plumbing) where no
+GPU exists.  "Device pointers" are addresses of numpy buffers, so pointer arithmetic done by the engine works as on
+the device.  The arithmetic comes from torch / the oracle -- this file says nothing about the kernels; the -m gpu tests
+do.  It is never importable from mnc_amd/ and is installed only by the `fake_gpu` fixture below."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import native
+
+_bufs = {}
+
+
+def _f(ptr, shape):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, np.float32)
+    return np.ctypeslib.as_array((ctypes.c_float * n).from_address(int(ptr))).reshape(shape)
+
+
+def _i(ptr, shape):
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array((ctypes.c_int * n).from_address(int(ptr))).reshape(shape)
+
+
+def _write_ptr(addr, value):
+    ctypes.c_void_p.from_address(int(addr)).value = value
+
+
+def _c8(x):                      # [C,H,W] -> [C/8,H,W,8]
+    C, H, W = x.shape
+    return x.reshape(C // 8, 8, H, W).transpose(0, 2, 3, 1)
+
+
+def _unc8(x):                    # [C/8,H,W,8] -> [C,H,W]
+    CB, H, W, _ = x.shape
+    return x.transpose(0, 3, 1, 2).reshape(CB * 8, H, W)
+
+
+def _act(y, act):
+    return F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+class Fake(object):
+    def mnc_device_count(self, addr):
+        ctypes.c_int.from_address(int(addr)).value = 1
+
+    def mnc_ctx_create(self, addr, dev):
+        _write_ptr(addr, 0xC0FFEE)
+
+    def mnc_ctx_destroy(self, h):
+        pass
+
+    def mnc_ctx_sync(self, h):
+        pass
+
+    def mnc_dev_alloc(self, h, nbytes, addr):
+        buf = np.zeros(int(nbytes) + 64, np.uint8)
+        p = buf.ctypes.data
+        _bufs[p] = buf
+        _write_ptr(addr, p)
+
+    def mnc_dev_free(self, h, p):
+        _bufs.pop(int(p), None)
+
+    def mnc_h2d(self, h, dst, src, n):
+        ctypes.memmove(int(dst), int(src), int(n))
+
+    mnc_d2h = mnc_h2d
+    mnc_d2d = mnc_h2d
+
+    def mnc_prof_enable(self, h, e):
+        pass
+
+    def mnc_prof_reset(self, h):
+        pass
+
+    def mnc_prof_count(self, h, addr):
+        ctypes.c_int.from_address(int(addr)).value = 0
+
+    # ---- layouts / packing ----
+    def mnc_nchw_to_c8(self, h, src, dst, C, H, W):
+        _f(dst, (C // 8, H, W, 8))[...] = _c8(_f(src, (C, H, W)))
+
+    def mnc_c8_to_nchw(self, h, src, dst, C, H, W):
+        _f(dst, (C, H, W))[...] = _unc8(_f(src, (C // 8, H, W, 8)))
+
+    def mnc_rchw_to_rhwc(self, h, src, dst, R, C, PH, PW):
+        _f(dst, (R, PH, PW, C))[...] = _f(src, (R, C, PH, PW)).transpose(0, 2, 3, 1)
+
+    def mnc_rhwc_to_rchw(self, h, src, dst, R, C, PH, PW):
+        _f(dst, (R, C, PH, PW))[...] = _f(src, (R, PH, PW, C)).transpose(0, 3, 1, 2)
+
+    def mnc_pack_conv3x3_weights(self, h, src, dst, Cout, Cin):
+        w = _f(src, (Cout, Cin, 3, 3))
+        out = _f(dst, (Cin // 8, Cout, 76))
+        out[...] = 0
+        for cb in range(Cin // 8):
+            for tap in range(9):
+                out[cb, :, tap * 8:tap * 8 + 8] = w[:, cb * 8:cb * 8 + 8, tap // 3, tap % 3]
+
+    def mnc_pack_fc_weights(self, h, src, dst, N, C, PH, PW):
+        _f(dst, (N, PH * PW, C))[...] = _f(src, (N, C, PH * PW)).transpose(0, 2, 1)
+
+    # ---- graph ops ----
+    def mnc_conv3x3_c3(self, h, src, w, b, dst, H, W, Cout, relu):
+        y = F.conv2d(_t(_f(src, (1, 3, H, W))), _t(_f(w, (Cout, 3, 3, 3))), _t(_f(b, (Cout,))), padding=1)
+        _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
+
+    def mnc_conv3x3(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        pk = _f(wpk, (Cin // 8, Cout, 76))
+        w = np.zeros((Cout, Cin, 3, 3), np.float32)
+        for cb in range(Cin // 8):
+            for tap in range(9):
+                w[:, cb * 8:cb * 8 + 8, tap // 3, tap % 3] = pk[cb, :, tap * 8:tap * 8 + 8]
+        x = _unc8(_f(src, (Cin // 8, H, W, 8)))
+        y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
+        _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
+
+    def mnc_maxpool2_c8(self, h, src, dst, C, H, W):
+        x = _unc8(_f(src, (C // 8, H, W, 8)))
+        y = F.max_pool2d(_t(x)[None], 2, 2, ceil_mode=True)[0].numpy()
+        _f(dst, (C // 8,) + y.shape[1:] + (8,))[...] = _c8(y)
+
+    def mnc_conv1x1_to_nchw(self, h, src, w, b, dst, H, W, Cin, Cout):
+        x = _unc8(_f(src, (Cin // 8, H, W, 8)))
+        y = F.conv2d(_t(x)[None], _t(_f(w, (Cout, Cin, 1, 1))), _t(_f(b, (Cout,))))
+        _f(dst, (Cout, H, W))[...] = y[0].numpy()
+
+    def mnc_rpn_softmax(self, h, src, dst, A, H, W):
+        s = _t(_f(src, (2, A * H * W)))
+        _f(dst, (2, A * H * W))[...] = F.softmax(s, dim=0).numpy()
+
+    def mnc_roi_warp(self, h, feat, C, H, W, rois, R, PH, PW, scale, pool2, dst):
+        f = np.ascontiguousarray(_unc8(_f(feat, (C // 8, H, W, 8))))
+        r = np.ascontiguousarray(_f(rois, (R, 5)))
+        if pool2:
+            out = native.maxpool2(native.roi_warp(f, r, 2 * PH, 2 * PW, scale))
+        else:
+            out = native.roi_warp(f, r, PH, PW, scale)
+        _f(dst, (R, PH, PW, C))[...] = out.transpose(0, 2, 3, 1)
+
+    def mnc_maxpool2_rhwc(self, h, src, dst, R, PH, PW, C):
+        x = _f(src, (R, PH, PW, C)).transpose(0, 3, 1, 2)
+        _f(dst, (R, PH // 2, PW // 2, C))[...] = native.maxpool2(x).transpose(0, 2, 3, 1)
+
+    def mnc_mask_resize(self, h, src, dst, R, IH, IW, OH, OW):
+        _f(dst, (R, 1, OH, OW))[...] = native.mask_resize(_f(src, (R, 1, IH, IW)), OH, OW)
+
+    def mnc_mask_pool(self, h, feat, mask, dst, R, PH, PW, C, pool2):
+        f = np.ascontiguousarray(_f(feat, (R, PH, PW, C)).transpose(0, 3, 1, 2))
+        out = native.mask_pool(f, _f(mask, (R, 1, PH, PW)))
+        if pool2:
+            out = native.maxpool2(out)
+        _f(dst, (R,) + out.shape[2:] + (C,))[...] = out.transpose(0, 2, 3, 1)
+
+    def mnc_fc(self, h, a, w, b, dst, M, N, K, ldc, act):
+        y = _act(F.linear(_t(_f(a, (M, K))), _t(_f(w, (N, K))), _t(_f(b, (N,)))), act).numpy()
+        full = _f(dst, ((M - 1) * ldc + N,))
+        for m in range(M):
+            full[m * ldc: m * ldc + N] = y[m]
+
+    def mnc_softmax_rows(self, h, src, dst, M, N):
+        _f(dst, (M, N))[...] = F.softmax(_t(_f(src, (M, N))), dim=1).numpy()
+
+    def mnc_eltwise(self, h, src, dst, n, op):
+        _f(dst, (n,))[...] = _act(_t(_f(src, (n,)).copy()), op).numpy()
+
+    def mnc_copy2d(self, h, dst, dld, src, sld, rows, cols):
+        d, s = _f(dst, ((rows - 1) * dld + cols,)), _f(src, ((rows - 1) * sld + cols,))
+        for r in range(rows):
+            d[r * dld:r * dld + cols] = s[r * sld:r * sld + cols]
+
+    # ---- b1 / b2 / b3 on host pointers ----
+    def _nms(self, keep, num, boxes, n, dim, thr, max_keep):
+        if n == 0:
+            ctypes.c_int.from_address(int(num)).value = 0
+            return
+        k = native.nms_sorted(_f(boxes, (n, dim)), thr)
+        if max_keep is not None and max_keep >= 0:
+            k = k[:max_keep]
+        _i(keep, (n,))[:len(k)] = k
+        ctypes.c_int.from_address(int(num)).value = len(k)
+
+    def mnc_nms(self, keep, num, boxes, n, dim, thr, dev):
+        self._nms(keep, num, boxes, n, dim, thr, None)
+
+    def mnc_nms_topk(self, keep, num, boxes, n, dim, thr, max_keep, dev):
+        self._nms(keep, num, boxes, n, dim, thr, max_keep)
+
+    def mnc_mv(self, boxes, masks, nb, inds, start, wts, nc, H, W, bd, S, R, omask, obox, dev):
+        m, b = native.mv(_f(boxes, (nb, bd)), _f(masks, (nb, 1, S, S)), _i(inds, (nc,)) if nc else np.zeros(0, np.int32),
+                         _i(start, (R,)), _f(wts, (nc,)) if nc else np.zeros(0, np.float32), H, W)
+        _f(omask, (R, 1, S, S))[...] = m
+        _i(obox, (R, 4))[...] = b
+
+    def mnc_bbox_overlaps(self, boxes, n, query, k, out):
+        b = np.ctypeslib.as_array((ctypes.c_double * (n * 4)).from_address(int(boxes))).reshape(n, 4)
+        q = np.ctypeslib.as_array((ctypes.c_double * (k * 4)).from_address(int(query))).reshape(k, 4)
+        np.ctypeslib.as_array((ctypes.c_double * (n * k)).from_address(int(out))).reshape(n, k)[...] = \
+            native.bbox_overlaps(b, q)
+
+
+def install(monkeypatch):
+    from mnc_amd import _lib
+    fake = Fake()
+
+    def call(name, *args):
+        getattr(fake, name)(*args)
+        return 0
+
+    monkeypatch.setattr(_lib, "call", call)
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    monkeypatch.setattr(_lib, "device_count", lambda: 1)
+    return fake

@@ -1,0 +1,173 @@
+"""CPU: the HOST logic of the executor and of the reference-shaped modules (graph plan, fusions, Concat views, layouts,
+Python-layer plumbing, demo.im_detect, gpu_mask_voting orchestration) with the C ABI replaced by the test double in
+tests/fake_backend.py.  Kernel parity is the job of the -m gpu tests; this file guarantees that what reaches the
+kernels is shaped and ordered correctly, by comparing every blob with the oracle graph."""
+import numpy as np
+import pytest
+
+import fake_backend
+import mnc_amd
+from mnc_amd import models, synth
+from oracle import host as ohost
+from oracle import net as onet
+
+mnc_amd.install_paths()
+
+BLOBS = ["conv1_1", "pool1", "conv3_3", "conv5_3", "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois",
+         "roi_interpolate_conv5", "mask_output", "mask_proposal", "mask_proposal_resize", "roi_interpolate_conv5_box",
+         "roi_interpolate_conv5_mask", "fc6", "fc7", "fc7_mask", "join_box_mask", "cls_prob", "seg_cls_prob",
+         "bbox_pred", "rois_ext", "roi_interpolate_conv5_ext", "mask_proposal_ext", "seg_cls_prob_ext",
+         "bbox_pred_ext", "cls_prob_ext"]
+
+
+@pytest.fixture()
+def fake_gpu(monkeypatch):
+    import gc
+    yield fake_backend.install(monkeypatch)
+    gc.collect()          # Nets left behind by a failing test must be finalised while the double is still installed
+
+
+def _inputs(H, W, seed):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-120, 130, (1, 3, H, W)).astype(np.float32), np.array([[H, W, 1.0]], np.float32)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_reduced_graph_every_blob(fake_gpu, fuse):
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    net = Net(path, w, 1, device_id=0, fuse=fuse)
+    data, im_info = _inputs(96, 160, 0)
+    net.blobs["data"].reshape(*data.shape)
+    net.blobs["im_info"].reshape(*im_info.shape)
+    out = net.forward(data=data, im_info=im_info)
+    assert set(out) == {"cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"}
+    ref = onet.forward(w, data, im_info)
+    names = BLOBS + ([] if fuse else ["roi_interpolate_conv5_premax", "roi_mask_conv5", "roi_mask_conv5_ext"])
+    for n in names:
+        got, want = net.blobs[n].data, ref[n]
+        assert got.shape == want.shape, n
+        assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6), n
+    # a second image of another size through the same net (buffers are re-used / re-grown, shapes are dynamic)
+    data2, info2 = _inputs(130, 203, 1)
+    net.forward(data=data2, im_info=info2)
+    ref2 = onet.forward(w, data2, info2)
+    for n in ("conv5_3", "rois", "seg_cls_prob", "mask_proposal_ext", "seg_cls_prob_ext"):
+        assert net.blobs[n].data.shape == ref2[n].shape, n
+        assert np.abs(net.blobs[n].data - ref2[n]).max() <= 1e-4 * max(np.abs(ref2[n]).max(), 1e-6), n
+    assert sorted(net.params["fc6"][0].shape) == sorted(w["fc6"][0].shape)
+    net.close()
+
+
+def test_fusion_plan(fake_gpu):
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    net = Net(path, w, 1, device_id=0)
+    L = {l.name: l for l in net._layers}
+    assert L["relu3_2"].skip and L["conv3_2"].relu
+    assert L["roi_interpolate_conv5_premax"].fused_pool and L["roi_interpolate_conv5"].skip
+    assert not L["roi_interpolate_conv5_ext"].fused_pool           # stage 4 warps 14x14 directly, its consumers differ
+    assert L["mask_pred"].act == 2 and L["mask_output"].skip
+    assert L["mask_pooling"].fused_pool and L["roi_interpolate_conv5_mask"].skip
+    assert not L["roi_interpolate_conv5_box"].skip                  # its bottom is shared with other consumers
+    assert net.blobs["fc7"]._view is not None and net.blobs["fc7_mask"]._view[1] == 0 and net.blobs["fc7"]._view[1] == 512
+    assert net.outputs == ["cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"]
+    net.close()
+
+
+def test_demo_im_detect_and_voting(fake_gpu):
+    import demo
+    from mnc_amd.engine import Net
+    from transform.mask_transform import gpu_mask_voting
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=2)
+    net = Net(path, w, 1, device_id=0)
+    im = np.random.default_rng(4).integers(0, 256, (75, 100, 3), dtype=np.uint8)     # -> 600x800, scale 8.0
+    boxes, masks, scores = demo.im_detect(im, net)
+    oboxes, omasks, oscores = onet.im_detect(w, im)
+    assert boxes.shape == oboxes.shape and boxes.dtype == oboxes.dtype == np.float32
+    assert np.abs(boxes - oboxes).max() < 1e-3 and np.abs(scores - oscores).max() < 1e-4
+    assert np.abs(masks - omasks).max() < 1e-4
+    lm, lb = gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
+    om, ob = ohost.gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
+    assert np.array_equal(np.concatenate(lb, 0), np.concatenate(ob, 0))
+    assert np.array_equal(np.concatenate(lm, 0), np.concatenate(om, 0))
+    net.close()
+
+
+def test_pylayers_against_reference_fixtures(fake_gpu, golden):
+    """The product's Python layers (mnc_amd/lib/pylayer) driven through caffe.Layer's protocol, against the fixtures
+    produced by the reference's own layers."""
+    import golden_inputs as GI
+    from pylayer.mask_layer import MaskLayer
+    from pylayer.proposal_layer import ProposalLayer
+    from pylayer.stage_bridge_layer import StageBridgeLayer
+
+    class B(object):
+        def __init__(self, a=None):
+            self.data = np.zeros((1,), np.float32) if a is None else np.ascontiguousarray(a, np.float32)
+
+        def reshape(self, *d):
+            if tuple(d) != self.data.shape:
+                self.data = np.zeros(d, np.float32)
+
+    def run(cls, bottoms, param_str=""):
+        layer = cls()
+        layer.param_str_, layer.phase = param_str, "TEST"
+        bottom, top = [B(b) for b in bottoms], [B()]
+        layer.setup(bottom, top)
+        layer.reshape(bottom, top)
+        layer.forward(bottom, top)
+        return top[0].data
+
+    for tag in ("small", "full"):
+        fh, fw, seed = [int(v) for v in golden["prop_%s_meta" % tag]]
+        pc = GI.proposal_case(fh, fw, seed)
+        rois = run(ProposalLayer, [pc["cls_prob"], pc["bbox_pred"], pc["im_info"]], "{'feat_stride': 16}")
+        assert np.array_equal(rois, golden["prop_%s_rois" % tag])
+    out = run(StageBridgeLayer, [golden["sb_rois"], golden["sb_bbox_pred"], golden["sb_scores"], golden["sb_im_info"]])
+    assert np.array_equal(out, golden["sb_rois_ext"])
+    assert np.array_equal(run(MaskLayer, [golden["ml_in"]]), golden["ml_out"])
+
+
+def test_voting_host_code_against_reference_fixture(fake_gpu, golden):
+    import golden_inputs as GI
+    from transform.mask_transform import gpu_mask_voting
+    n, H, W, seed = GI.VOTING_CASES["small"]
+    vc = GI.voting_case(n, H, W, seed)
+    lm, lb = gpu_mask_voting(vc["masks"], vc["boxes"], vc["scores"], 21, 100, W, H)
+    assert np.array_equal(np.concatenate(lb, 0), golden["vote_small_box"])
+    assert np.array_equal(np.concatenate(lm, 0), golden["vote_small_mask"])
+
+
+def test_blob_semantics(fake_gpu):
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    net = Net(path, synth.synthetic_weights(path, seed=1), 1, device_id=0)
+    b = net.blobs["data"]
+    b.reshape(1, 3, 8, 8)
+    assert b.data.shape == (1, 3, 8, 8) and b.count == 192 and b.channels == 3
+    with pytest.raises(KeyError):
+        net.forward(nonexistent=np.zeros(3, np.float32))
+    assert not net.blobs["conv5_3"].data.any()          # never produced: zero-filled, like a fresh caffe blob
+    net.close()
+
+
+def test_config_surface(tmp_path):
+    from mnc_config import cfg, cfg_from_file
+    assert cfg.TEST.RPN_POST_NMS_TOP_N == 300 and cfg.TEST.RPN_NMS_THRESH == 0.7 and cfg.MASK_SIZE == 21
+    p = tmp_path / "c.yml"
+    p.write_text("EXP_DIR: mnc_5stage\nMASK_SIZE: 21\nTRAIN:\n  RPN_POST_NMS_TOP_N: 300\n  IMS_PER_BATCH: 1\n"
+                 "  BBOX_NORMALIZE_TARGETS_PRECOMPUTED: True\n")
+    cfg_from_file(str(p))
+    assert cfg.EXP_DIR == "mnc_5stage" and cfg.TRAIN.RPN_POST_NMS_TOP_N == 300
+    p.write_text("NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError):
+        cfg_from_file(str(p))
+    p.write_text("MASK_SIZE: 'x'\n")
+    with pytest.raises(ValueError):
+        cfg_from_file(str(p))
+    cfg.EXP_DIR = "default"
+    cfg.TRAIN.RPN_POST_NMS_TOP_N = 2000

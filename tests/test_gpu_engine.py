@@ -1,0 +1,129 @@
+"""GPU: the caffe-shaped Net (mnc_amd.engine) running the emitted 5-stage graph through the Python-layer API, blob by
+blob against the CPU oracle (oracle/net.py) on identical synthetic weights and inputs.
+
+Tolerance: north_star asks for 1e-3 on boxes / class scores / 21x21 masks.  Per blob we check max |diff| against
+1e-3 x the blob's dynamic range (probabilities and masks therefore to 1e-3 absolute, boxes to 1e-3 of ~1000 px; the
+measured values are 2-3 orders of magnitude tighter and are printed)."""
+import numpy as np
+import pytest
+
+import golden_inputs as GI
+import mnc_amd
+from gpu_util import err
+from mnc_amd import models, synth
+from oracle import host as ohost
+from oracle import net as onet
+
+pytestmark = pytest.mark.gpu
+mnc_amd.install_paths()
+
+CHECK = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_3", "conv5_3", "rpn_output",
+         "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "roi_interpolate_conv5", "mask_output", "mask_proposal",
+         "mask_proposal_resize", "roi_interpolate_conv5_box", "roi_interpolate_conv5_mask", "fc6", "fc7", "fc7_mask",
+         "join_box_mask", "cls_prob", "seg_cls_prob", "bbox_pred", "rois_ext", "roi_interpolate_conv5_ext",
+         "mask_proposal_ext", "seg_cls_prob_ext", "bbox_pred_ext", "cls_prob_ext"]
+
+
+def _compare(net, ref, names, tol=1e-3):
+    report, bad = [], []
+    for n in names:
+        if n not in ref:
+            continue
+        got = net.blobs[n].data
+        want = ref[n]
+        if got.shape != want.shape:
+            bad.append("%s: shape %r vs %r" % (n, got.shape, want.shape))
+            continue
+        d, rel = err(got, want)
+        report.append("%-28s %-22s max|d|=%.3e rel=%.3e" % (n, got.shape, d, rel))
+        if not rel < tol:
+            bad.append(report[-1])
+    print("\n".join(report))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.fixture(scope="module")
+def small():
+    import caffe
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    net = caffe.Net(path, w, caffe.TEST)
+    yield net, w
+    net.close()
+
+
+@pytest.mark.parametrize("H,W,seed", [(96, 160, 0), (130, 203, 1)])
+def test_reduced_net_blobwise(small, H, W, seed):
+    net, w = small
+    rng = np.random.default_rng(seed)
+    data = rng.uniform(-120, 130, (1, 3, H, W)).astype(np.float32)
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    net.blobs["data"].reshape(*data.shape)
+    net.blobs["im_info"].reshape(*im_info.shape)
+    out = net.forward(data=data, im_info=im_info)
+    ref = onet.forward(w, data, im_info)
+    assert set(out) == {"cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"}
+    assert net.blobs["rois"].data.shape == ref["rois"].shape
+    _compare(net, ref, CHECK)
+
+
+def test_unfused_graph_matches_fused(small):
+    """fuse=False materialises every blob of the prototxt (premax 28x28 warp, mask_pred, roi_mask_conv5) with separate
+    kernels; outputs must agree with the fused plan and with the oracle."""
+    import caffe
+    from mnc_amd.engine import Net
+    net, w = small
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    net2 = Net(path, w, caffe.TEST, fuse=False)
+    rng = np.random.default_rng(5)
+    data = rng.uniform(-120, 130, (1, 3, 112, 144)).astype(np.float32)
+    im_info = np.array([[112, 144, 1.0]], np.float32)
+    net.forward(data=data, im_info=im_info)
+    net2.forward(data=data, im_info=im_info)
+    ref = onet.forward(w, data, im_info)
+    _compare(net2, ref, CHECK + ["roi_interpolate_conv5_premax", "roi_mask_conv5", "roi_mask_conv5_ext"])
+    for n in ("rois", "seg_cls_prob", "mask_proposal", "rois_ext", "seg_cls_prob_ext", "mask_proposal_ext"):
+        assert np.array_equal(net.blobs[n].data, net2.blobs[n].data), n
+    net2.close()
+
+
+@pytest.fixture(scope="module")
+def full():
+    import caffe
+    path = models.write_mnc_5stage_test_prototxt()
+    w = synth.synthetic_weights(path, seed=0)
+    net = caffe.Net(path, w, caffe.TEST)
+    yield net, w
+    net.close()
+
+
+def test_full_vgg16_600x1000_blobwise(full):
+    """BASELINE configs[1]/[2] shape: one 600x1000 image, 300 proposals per stage, fp32."""
+    net, w = full
+    im = np.random.default_rng(0).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+    data, im_info, scale = ohost.prepare_mnc_args(im)
+    net.forward(data=data, im_info=im_info)
+    ref = onet.forward(w, data, im_info)
+    assert net.blobs["conv5_3"].data.shape == (1, 512, 38, 63)
+    assert net.blobs["rois"].data.shape == (300, 5)
+    _compare(net, ref, CHECK)
+
+
+def test_demo_pipeline_matches_oracle(full):
+    """tools/demo.py path: im_detect (prepare args, forward, un-scale, clip, concat) + gpu_mask_voting, on a VOC-sized
+    image that exercises the resize (375x500 -> 600x800, scale 1.6)."""
+    import demo
+    from transform.mask_transform import gpu_mask_voting
+    net, w = full
+    im = np.random.default_rng(3).integers(0, 256, (375, 500, 3), dtype=np.uint8)
+    boxes, masks, scores = demo.im_detect(im, net)
+    oboxes, omasks, oscores = onet.im_detect(w, im)
+    assert boxes.shape == oboxes.shape == (600, 4) and masks.shape == (600, 1, 21, 21) and scores.shape == (600, 21)
+    assert err(boxes, oboxes)[0] < 1e-3 * 500, err(boxes, oboxes)
+    assert err(scores, oscores)[0] < 1e-3 and err(masks, omasks)[0] < 1e-3
+    lm, lb = gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
+    # voting on the SAME inputs must be bit-exact with the oracle (== reference) voting
+    om, ob = ohost.gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
+    assert [len(b) for b in lb] == [len(b) for b in ob]
+    assert np.array_equal(np.concatenate(lb, 0), np.concatenate(ob, 0))
+    assert np.array_equal(np.concatenate(lm, 0), np.concatenate(om, 0))

@@ -1,0 +1,275 @@
+"""GPU: every graph op of include/mnc_hip.h, called through the C ABI on device buffers, against the CPU oracle
+(torch fp32 for the dense layers -- a floating-point kernel -- and oracle/mnc_oracle.c for the MNC-specific layers).
+
+Tolerances (written per test): dense fp32 MFMA kernels accumulate in a different order than torch, so they are held to
+1e-4 of the output's dynamic range (north_star allows 1e-3 end to end); gather/elementwise kernels mirror the oracle's
+operation order and are held to 1e-6 relative / bit-exact where no FMA contraction can occur."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as GI
+from gpu_util import Dev, err, from_c8, to_c8
+from oracle import native
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = Dev(0)
+    yield d
+    d.close()
+
+
+def _conv_ref(x, w, b, relu=True, pad=1):
+    y = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), padding=pad)
+    return (F.relu(y) if relu else y)[0].numpy()
+
+
+# (H, W, Cin, Cout): ragged edges, every channel-tile width the dispatcher can pick, and a VGG-sized slice
+CONV_SHAPES = [(6, 37, 16, 64), (9, 70, 8, 32), (38, 63, 64, 128), (13, 33, 128, 256), (75, 125, 32, 64), (4, 32, 8, 512)]
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES)
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv3x3_mfma(dev, H, W, Cin, Cout, relu):
+    rng = np.random.default_rng(H * 1000 + W)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    d_w_raw, d_b = dev.put(w), dev.put(b)
+    d_w = dev.empty(((Cin // 8) * Cout * 76,))
+    dev.call("mnc_pack_conv3x3_weights", d_w_raw, d_w, Cout, Cin)
+    d_x = dev.put(to_c8(x))
+    d_y = dev.empty((Cout * H * W,), fill=np.nan)
+    dev.call("mnc_conv3x3", d_x, d_w, d_b, d_y, H, W, Cin, Cout, relu)
+    got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+    want = _conv_ref(x, w, b, relu=bool(relu))
+    assert not np.isnan(got).any()
+    d, rel = err(got, want)
+    assert rel < 1e-4, (d, rel)
+
+
+def test_conv3x3_packed_weight_layout(dev):
+    rng = np.random.default_rng(0)
+    Cout, Cin = 64, 16
+    w = rng.normal(size=(Cout, Cin, 3, 3)).astype(np.float32)
+    d_raw = dev.put(w)
+    d_pk = dev.empty(((Cin // 8) * Cout * 76,))
+    dev.call("mnc_pack_conv3x3_weights", d_raw, d_pk, Cout, Cin)
+    pk = dev.get(d_pk, (Cin // 8, Cout, 76))
+    assert not pk[:, :, 72:].any()
+    for cb in range(Cin // 8):
+        for tap in range(9):
+            assert np.array_equal(pk[cb, :, tap * 8:tap * 8 + 8], w[:, cb * 8:cb * 8 + 8, tap // 3, tap % 3])
+
+
+@pytest.mark.parametrize("H,W", [(20, 33), (600, 1000)])
+def test_conv1_1_direct(dev, H, W):
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(3, H, W)).astype(np.float32)
+    w = (rng.normal(size=(64, 3, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    d_y = dev.empty((64 * H * W,), fill=np.nan)
+    dev.call("mnc_conv3x3_c3", dev.put(x), dev.put(w), dev.put(b), d_y, H, W, 64, 1)
+    got = from_c8(dev.get(d_y, (64 * H * W,)), 64, H, W)
+    _, rel = err(got, _conv_ref(x, w, b))
+    assert rel < 1e-5, rel
+
+
+@pytest.mark.parametrize("C,H,W", [(16, 75, 125), (8, 2, 2), (64, 600, 1000), (32, 37, 64)])
+def test_maxpool2_c8_ceil_mode(dev, C, H, W):
+    x = np.random.default_rng(2).normal(size=(C, H, W)).astype(np.float32)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    d_y = dev.empty((C * OH * OW,), fill=np.nan)
+    dev.call("mnc_maxpool2_c8", dev.put(to_c8(x)), d_y, C, H, W)
+    got = from_c8(dev.get(d_y, (C * OH * OW,)), C, OH, OW)
+    want = F.max_pool2d(torch.from_numpy(x)[None], 2, 2, ceil_mode=True)[0].numpy()
+    assert want.shape == (C, OH, OW) and np.array_equal(got, want)
+    assert np.array_equal(got, native.maxpool2(x))
+
+
+def test_conv1x1_and_rpn_softmax(dev):
+    rng = np.random.default_rng(3)
+    H, W, Cin = 38, 63, 512
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(18, Cin)) * 0.05).astype(np.float32)
+    b = rng.normal(size=18).astype(np.float32)
+    d_s = dev.empty((18 * H * W,), fill=np.nan)
+    dev.call("mnc_conv1x1_to_nchw", dev.put(to_c8(x)), dev.put(w), dev.put(b), d_s, H, W, Cin, 18)
+    score = dev.get(d_s, (18, H, W))
+    want = _conv_ref(x, w.reshape(18, Cin, 1, 1), b, relu=False, pad=0)
+    _, rel = err(score, want)
+    assert rel < 1e-5, rel
+    d_p = dev.empty((18 * H * W,), fill=np.nan)
+    dev.call("mnc_rpn_softmax", d_s, d_p, 9, H, W)
+    prob = dev.get(d_p, (18, H, W))
+    t = torch.from_numpy(score)[None]
+    wantp = F.softmax(t.reshape(1, 2, -1, W), dim=1).reshape(1, 18, H, W)[0].numpy()
+    assert err(prob, wantp)[0] < 1e-6
+    assert np.abs(prob[:9] + prob[9:] - 1).max() < 1e-6
+
+
+def _rois(rng, R, W, H):
+    b = GI._boxes(rng, R, W, H, 8, 500)
+    b[0] = [0, 0, W - 1, H - 1]                  # whole image
+    b[1] = [10.3, 20.7, 10.9, 21.2]              # sub-pixel
+    b[2] = [W - 1, H - 1, W - 1, H - 1]          # bottom-right corner
+    b[3] = [200, 100, 150, 60]                   # malformed x2 < x1
+    b[4] = [0, 0, 15, 15]
+    return np.hstack([np.zeros((R, 1), np.float32), b]).astype(np.float32)
+
+
+@pytest.mark.parametrize("pool2,P", [(0, 14), (1, 14), (0, 7)])
+def test_roi_warp(dev, pool2, P):
+    rng = np.random.default_rng(4)
+    C, H, W, R = 64, 38, 63, 40
+    feat = rng.normal(size=(C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, 1000, 600)
+    d_out = dev.empty((R * P * P * C,), fill=np.nan)
+    dev.call("mnc_roi_warp", dev.put(to_c8(feat)), C, H, W, dev.put(rois), R, P, P, 0.0625, pool2, d_out)
+    got = dev.get(d_out, (R, P, P, C)).transpose(0, 3, 1, 2)
+    if pool2:
+        want = native.maxpool2(native.roi_warp(feat, rois, 2 * P, 2 * P, 0.0625))
+    else:
+        want = native.roi_warp(feat, rois, P, P, 0.0625)
+    d, _ = err(got, want)
+    assert d < 2e-6, d           # same operation order; only FMA contraction of the 4-term sum may differ
+
+
+def test_roi_warp_interior_is_plain_bilinear(dev):
+    """SPEC.md 1 property: a RoI whose sample grid lands exactly on feature-map pixels reproduces them."""
+    C, H, W = 8, 20, 20
+    feat = np.random.default_rng(5).normal(size=(C, H, W)).astype(np.float32)
+    # x1s = 2, x2s = 2 + 7 - 1 -> roi_w = 7 = bin count -> samples at 2, 3, ..., 8
+    rois = np.array([[0, 32, 48, 32 + 6 * 16, 48 + 6 * 16]], np.float32)
+    d_out = dev.empty((7 * 7 * C,), fill=np.nan)
+    dev.call("mnc_roi_warp", dev.put(to_c8(feat)), C, H, W, dev.put(rois), 1, 7, 7, 0.0625, 0, d_out)
+    got = dev.get(d_out, (7, 7, C)).transpose(2, 0, 1)
+    assert np.array_equal(got, feat[:, 3:10, 2:9])
+
+
+def test_roi_elementwise_ops(dev):
+    rng = np.random.default_rng(6)
+    R, C = 37, 64
+    feat = rng.normal(size=(R, C, 14, 14)).astype(np.float32)
+    mask = rng.uniform(0, 1, (R, 1, 21, 21)).astype(np.float32)
+    hwc = np.ascontiguousarray(feat.transpose(0, 2, 3, 1))
+    # MaskResize 21 -> 14
+    d_m14 = dev.empty((R * 196,), fill=np.nan)
+    dev.call("mnc_mask_resize", dev.put(mask), d_m14, R, 21, 21, 14, 14)
+    m14 = dev.get(d_m14, (R, 1, 14, 14))
+    want14 = native.mask_resize(mask, 14, 14)
+    assert err(m14, want14)[0] < 1e-6
+    # MaskPooling (+ fused pool)
+    d_feat = dev.put(hwc)
+    d_o = dev.empty((R * 196 * C,), fill=np.nan)
+    dev.call("mnc_mask_pool", d_feat, d_m14, d_o, R, 14, 14, C, 0)
+    got = dev.get(d_o, (R, 14, 14, C)).transpose(0, 3, 1, 2)
+    want = native.mask_pool(feat, m14)
+    assert np.array_equal(got, want)
+    d_o2 = dev.empty((R * 49 * C,), fill=np.nan)
+    dev.call("mnc_mask_pool", d_feat, d_m14, d_o2, R, 14, 14, C, 1)
+    got2 = dev.get(d_o2, (R, 7, 7, C)).transpose(0, 3, 1, 2)
+    assert np.array_equal(got2, native.maxpool2(want))
+    # Pooling on per-RoI features
+    d_o3 = dev.empty((R * 49 * C,), fill=np.nan)
+    dev.call("mnc_maxpool2_rhwc", d_feat, d_o3, R, 14, 14, C)
+    assert np.array_equal(dev.get(d_o3, (R, 7, 7, C)).transpose(0, 3, 1, 2), native.maxpool2(feat))
+    # layout round trips
+    d_a, d_b = dev.empty((R * C * 196,)), dev.empty((R * C * 196,))
+    dev.call("mnc_rchw_to_rhwc", dev.put(feat), d_a, R, C, 14, 14)
+    assert np.array_equal(dev.get(d_a, hwc.shape), hwc)
+    dev.call("mnc_rhwc_to_rchw", d_a, d_b, R, C, 14, 14)
+    assert np.array_equal(dev.get(d_b, feat.shape), feat)
+    x = rng.normal(size=(16, 9, 11)).astype(np.float32)
+    d_c, d_d = dev.empty((x.size,)), dev.empty((x.size,))
+    dev.call("mnc_nchw_to_c8", dev.put(x), d_c, 16, 9, 11)
+    assert np.array_equal(dev.get(d_c, to_c8(x).shape), to_c8(x))
+    dev.call("mnc_c8_to_nchw", d_c, d_d, 16, 9, 11)
+    assert np.array_equal(dev.get(d_d, x.shape), x)
+
+
+# (M, N, K, act): split-K and fused paths, partial row/column tiles, the real head shapes
+FC_SHAPES = [(300, 4096, 4096, 1), (45, 150, 64, 0), (1, 441, 256, 2), (300, 441, 256, 2), (300, 126, 8192, 0),
+             (300, 256, 14 * 14 * 512, 1), (7, 4096, 25088, 1), (321, 128, 512, 0)]
+
+
+@pytest.mark.parametrize("M,N,K,act", FC_SHAPES)
+def test_fc_mfma(dev, M, N, K, act):
+    rng = np.random.default_rng(M + N + K)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_o = dev.empty((M * N,), fill=np.nan)
+    dev.call("mnc_fc", dev.put(a), dev.put(w), dev.put(b), d_o, M, N, K, N, act)
+    got = dev.get(d_o, (M, N))
+    y = F.linear(torch.from_numpy(a), torch.from_numpy(w), torch.from_numpy(b))
+    want = (F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y).numpy()
+    assert not np.isnan(got).any()
+    d, rel = err(got, want)
+    assert rel < 1e-4, (d, rel)
+
+
+def test_fc_column_slice_and_pack(dev):
+    """ldc > N writes a column slice (Concat in place); mnc_pack_fc_weights permutes (c,h,w) columns to (h,w,c)."""
+    rng = np.random.default_rng(9)
+    R, C, P, N = 20, 32, 7, 96
+    feat = rng.normal(size=(R, C, P, P)).astype(np.float32)
+    w = (rng.normal(size=(N, C * P * P)) * 0.02).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_wp = dev.empty((w.size,))
+    dev.call("mnc_pack_fc_weights", dev.put(w), d_wp, N, C, P, P)
+    wp = dev.get(d_wp, (N, P * P, C))
+    assert np.array_equal(wp, w.reshape(N, C, P * P).transpose(0, 2, 1))
+    wide = dev.empty((R * 2 * N,), fill=7.0)
+    dev.call("mnc_fc", dev.put(np.ascontiguousarray(feat.transpose(0, 2, 3, 1))), d_wp, dev.put(b), wide + N * 4, R, N,
+             C * P * P, 2 * N, 0)
+    out = dev.get(wide, (R, 2 * N))
+    want = feat.reshape(R, -1) @ w.T + b
+    assert np.all(out[:, :N] == 7.0)
+    assert err(out[:, N:], want)[1] < 1e-4
+
+
+def test_softmax_rows_and_eltwise(dev):
+    x = np.random.default_rng(10).normal(size=(300, 21)).astype(np.float32) * 3
+    d_o = dev.empty((x.size,))
+    dev.call("mnc_softmax_rows", dev.put(x), d_o, 300, 21)
+    assert err(dev.get(d_o, x.shape), F.softmax(torch.from_numpy(x), dim=1).numpy())[0] < 1e-6
+    dev.call("mnc_eltwise", dev.put(x), d_o, x.size, 2)
+    assert err(dev.get(d_o, x.shape), torch.sigmoid(torch.from_numpy(x)).numpy())[0] < 1e-6
+    dev.call("mnc_eltwise", dev.put(x), d_o, x.size, 1)
+    assert np.array_equal(dev.get(d_o, x.shape), np.maximum(x, 0))
+
+
+def test_argument_errors_are_reported(dev):
+    from mnc_amd import _lib
+    with pytest.raises(_lib.MncError) as e:
+        dev.call("mnc_conv3x3", 0, 0, 0, 0, 8, 8, 8, 32, 1)
+    assert e.value.code == 1 and "null" in str(e.value)
+    p = dev.empty((64,))
+    with pytest.raises(_lib.MncError):
+        dev.call("mnc_conv3x3", p, p, p, p, 8, 8, 12, 32, 1)        # Cin % 8 != 0
+    with pytest.raises(_lib.MncError):
+        dev.call("mnc_fc", p, p, p, p, 4, 4, 33, 4, 0)              # K % 32 != 0
+
+
+def test_profiling_records(dev):
+    x = np.zeros((8, 16, 16), np.float32)
+    d_y = dev.empty((8 * 8 * 8,))
+    dev.call("mnc_prof_enable", 1)
+    dev.call("mnc_prof_reset")
+    for _ in range(3):
+        dev.call("mnc_maxpool2_c8", dev.put(to_c8(x)), d_y, 8, 16, 16)
+    import ctypes
+    n = ctypes.c_int(0)
+    dev.call("mnc_prof_count", ctypes.addressof(n))
+    assert n.value == 3
+    name = ctypes.create_string_buffer(64)
+    ms = ctypes.c_float(-1)
+    dev.call("mnc_prof_get", 0, ctypes.addressof(name), 64, ctypes.addressof(ms), None, None)
+    assert name.value == b"maxpool2_c8" and ms.value >= 0
+    dev.call("mnc_prof_enable", 0)
+    dev.call("mnc_prof_reset")

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""MNC demo on MI355X -- same flags and flow as the reference's tools/demo.py:
+build the net, warm up twice on a grey image, then per image: im_detect (timed "forward time"), gpu_mask_voting,
+optional visualisation.
+
+    python tools/demo.py [--gpu 0] [--def test.prototxt] [--net weights.npz] [--images a.jpg b.jpg ...] [--no-vis]
+
+Differences that are deliberate: weights come from an .npz (h5py is optional); without --net seeded synthetic weights
+are used (the trained model cannot be fetched here), and --def defaults to the graph emitted by mnc_amd.models.
+`--cpu` is accepted and ignored, exactly as in the reference (demo.py:40-42 vs :126)."""
+import argparse
+import os
+import time
+
+import numpy as np
+
+import _init_paths  # noqa: F401
+import caffe
+from mnc_config import cfg
+from transform.bbox_transform import clip_boxes
+from transform.mask_transform import gpu_mask_voting
+from utils.blob import im_list_to_blob, prep_im_for_blob
+
+CLASSES = ("aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
+           "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor")
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="MNC demo (MI355X)")
+    p.add_argument("--gpu", dest="gpu_id", default=0, type=int, help="GPU device id to use [0]")
+    p.add_argument("--cpu", dest="cpu_mode", action="store_true", help="accepted for compatibility; ignored")
+    p.add_argument("--def", dest="prototxt", default=None, type=str, help="prototxt defining the network")
+    p.add_argument("--net", dest="caffemodel", default=None, type=str, help="weights (.npz; .h5 needs h5py)")
+    p.add_argument("--images", nargs="*", default=None, help="image files (default: data/demo/*.jpg if present)")
+    p.add_argument("--no-vis", dest="vis", action="store_false", help="skip writing visualisations")
+    return p.parse_args(argv)
+
+
+def prepare_mnc_args(im, net):
+    """image (H,W,3 BGR) -> ({'data','im_info'} float32 blobs, [scale]); reshapes the two input blobs."""
+    im_scaled, im_scale = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
+    data = im_list_to_blob([im_scaled])
+    im_scales = [np.array(im_scale)]
+    im_info = np.array([[data.shape[2], data.shape[3], im_scales[0]]], dtype=np.float32)
+    net.blobs["data"].reshape(*data.shape)
+    net.blobs["im_info"].reshape(*im_info.shape)
+    return {"data": data.astype(np.float32, copy=False), "im_info": im_info}, im_scales
+
+
+def im_detect(im, net):
+    """-> boxes [2R,4] (original-image pixels), masks [2R,1,21,21], seg scores [2R,21] of stages 3 and 5."""
+    forward_kwargs, im_scales = prepare_mnc_args(im, net)
+    net.forward(**forward_kwargs)
+    scale = np.float32(im_scales[0])      # float32 un-scaling: what numpy-1.x value-based casting did in the reference
+    stage_boxes = []
+    for name in ("rois", "rois_ext"):
+        rois = net.blobs[name].data.copy()
+        stage_boxes.append(clip_boxes(rois[:, 1:5] / scale, im.shape)[0])
+    masks = np.concatenate((net.blobs["mask_proposal"].data, net.blobs["mask_proposal_ext"].data), axis=0)
+    scores = np.concatenate((net.blobs["seg_cls_prob"].data, net.blobs["seg_cls_prob_ext"].data), axis=0)
+    return np.concatenate(stage_boxes, axis=0), masks, scores
+
+
+def get_vis_dict(result_box, result_mask, img_name, cls_names, vis_thresh=0.5):
+    boxes, masks, classes = [], [], []
+    for cls_ind in range(len(cls_names)):
+        det, seg = result_box[cls_ind], result_mask[cls_ind]
+        for k in np.where(det[:, -1] >= vis_thresh)[0]:
+            boxes.append(det[k])
+            masks.append(seg[k][0])
+            classes.append(cls_ind + 1)
+    return {"image_name": img_name, "cls_name": classes, "boxes": boxes, "masks": masks}
+
+
+def _read_image_bgr(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+
+def _visualise(im_bgr, pred, out_path):
+    """Paint each instance mask (binarised at cfg.BINARIZE_THRESH after resizing to its box) over the image."""
+    from PIL import Image
+    from utils.blob import resize_linear
+    canvas = im_bgr[:, :, ::-1].astype(np.float32).copy()
+    rng = np.random.default_rng(0)
+    for box, mask in zip(pred["boxes"], pred["masks"]):
+        x1, y1, x2, y2 = [int(round(v)) for v in box[:4]]
+        w, h = max(x2 - x1 + 1, 1), max(y2 - y1 + 1, 1)
+        m = resize_linear(mask[:, :, None].astype(np.float32), w / 21.0, h / 21.0)[:, :, 0] >= cfg.BINARIZE_THRESH
+        m = m[:min(h, canvas.shape[0] - y1), :min(w, canvas.shape[1] - x1)]
+        colour = rng.uniform(64, 255, 3).astype(np.float32)
+        region = canvas[y1:y1 + m.shape[0], x1:x1 + m.shape[1]]
+        region[m] = 0.4 * region[m] + 0.6 * colour
+    Image.fromarray(np.clip(canvas, 0, 255).astype(np.uint8)).save(out_path)
+
+
+def build_net(args):
+    from mnc_amd import models, synth
+    prototxt = args.prototxt or models.write_mnc_5stage_test_prototxt()
+    if args.caffemodel:
+        weights = args.caffemodel
+    else:
+        print("no --net given: using seeded synthetic weights (detections are meaningless, timing is not)")
+        weights = synth.synthetic_weights(prototxt, seed=0)
+    caffe.set_mode_gpu()
+    caffe.set_device(args.gpu_id)
+    cfg.GPU_ID = args.gpu_id
+    return caffe.Net(prototxt, weights, caffe.TEST)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    net = build_net(args)
+    warm = 128 * np.ones((300, 500, 3), dtype=np.float32)
+    for _ in range(2):
+        im_detect(warm, net)
+    images = args.images
+    if images is None:
+        demo_dir = os.path.join(cfg.DATA_DIR, "demo")
+        images = sorted(os.path.join(demo_dir, f) for f in os.listdir(demo_dir)) if os.path.isdir(demo_dir) else []
+    if not images:
+        print("no images given; running one synthetic 600x1000 image")
+        images = [None]
+    for path in images:
+        print("~" * 35)
+        print("Demo for {}".format(path or "<synthetic 600x1000>"))
+        im = _read_image_bgr(path) if path else np.random.default_rng(0).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+        start = time.time()
+        boxes, masks, seg_scores = im_detect(im, net)
+        print("forward time %f" % (time.time() - start))
+        start = time.time()
+        result_mask, result_box = gpu_mask_voting(masks, boxes, seg_scores, len(CLASSES) + 1, 100, im.shape[1], im.shape[0])
+        print("mask voting time %f" % (time.time() - start))
+        pred = get_vis_dict(result_box, result_mask, path or "synthetic", CLASSES)
+        print("%d instances with score >= 0.5" % len(pred["boxes"]))
+        if args.vis and path:
+            out = os.path.splitext(path)[0] + "_mnc.png"
+            _visualise(im, pred, out)
+            print("wrote", out)
+    net.close()
+
+
+if __name__ == "__main__":
+    main()
