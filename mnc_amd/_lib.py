@@ -27,8 +27,6 @@ _CTYPES = {
 
 def _map_type(t):
     t = t.replace("const ", "").strip()
-    if t.endswith("**"):
-        return ctypes.POINTER(ctypes.c_void_p)
     if t.endswith("*"):
         return ctypes.c_void_p        # every pointer argument is passed as a raw address (host or device)
     return _CTYPES[t]

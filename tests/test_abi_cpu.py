@@ -1,0 +1,90 @@
+"""CPU: libmnc_hip.so loads without a GPU, exports every symbol include/mnc_hip.h declares, marshals arguments, and
+fails loudly (status + message) instead of computing anything when there is no device.  No compute calls here except
+mnc_bbox_overlaps, which is a host function in the reference too (lib/utils/bbox.pyx)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mnc_amd
+from mnc_amd import _build, _lib
+
+mnc_amd.install_paths()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    decls = _lib.parse_header()
+    assert len(decls) >= 40
+    for name in decls:
+        assert hasattr(lib, name), name
+    for must in ("_nms", "_mv", "mnc_nms", "mnc_mv", "mnc_bbox_overlaps", "mnc_conv3x3", "mnc_fc", "mnc_roi_warp"):
+        assert must in decls
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(decls) <= exported
+    assert lib.mnc_version().startswith(b"mnc_hip")
+
+
+def test_reference_signatures_are_kept():
+    """b1/b2: `_nms` (gpu_nms.hpp:1-2) has 7 parameters, `_mv` (gpu_mv.hpp:1-4) has 15, in the reference's order."""
+    d = _lib.parse_header()
+    assert d["_nms"][2] == ["keep_out", "num_out", "boxes_host", "boxes_num", "boxes_dim", "nms_overlap_thresh", "device_id"]
+    assert d["_mv"][2] == ["all_boxes", "all_masks", "all_boxes_num", "candidate_inds", "candidate_start",
+                           "candidate_weights", "candidate_num", "image_height", "image_width", "box_dim", "mask_size",
+                           "result_num", "finalize_output_mask", "finalize_output_box", "device_id"]
+    assert d["_nms"][0] is None and d["_mv"][0] is None
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="a GPU is present")
+def test_no_gpu_means_errors_not_fallbacks():
+    h = ctypes.c_void_p()
+    with pytest.raises(_lib.MncError) as e:
+        _lib.call("mnc_ctx_create", ctypes.addressof(h), 0)
+    assert e.value.code in (1, 2) and str(e.value)
+    keep = np.zeros(4, np.int32)
+    num = ctypes.c_int(7)
+    dets = np.array([[0, 0, 10, 10, 0.9], [1, 1, 11, 11, 0.8]], np.float32)
+    with pytest.raises(_lib.MncError):
+        _lib.call("mnc_nms", _lib.ptr(keep), ctypes.addressof(num), _lib.ptr(dets), 2, 5, 0.5, 0)
+    from nms.gpu_nms import gpu_nms
+    with pytest.raises(_lib.MncError):
+        gpu_nms(dets, 0.5)
+    from mnc_amd.engine import Net
+    from mnc_amd import models
+    with pytest.raises(RuntimeError):
+        Net(models.write_mnc_5stage_test_prototxt(width_div=8), {}, 1)
+    # n == 0 short-circuits before any device work, as nms_wrapper.py:16-17 does
+    _lib.call("mnc_nms", _lib.ptr(keep), ctypes.addressof(num), None, 0, 5, 0.5, 0)
+    assert num.value == 0
+    from nms.nms_wrapper import nms
+    assert nms(np.zeros((0, 5), np.float32), 0.3) == []
+
+
+def test_bbox_overlaps_host_function():
+    from utils.cython_bbox import bbox_overlaps
+    from oracle import native
+    rng = np.random.default_rng(3)
+    a = rng.uniform(0, 500, (600, 4))
+    a[:, 2:] += a[:, :2]
+    q = a[:5] + 3.0
+    got = bbox_overlaps(a, q)
+    assert got.shape == (600, 5) and np.array_equal(got, native.bbox_overlaps(a, q))
+    assert bbox_overlaps(np.zeros((0, 4)), q).shape == (0, 5)
+    with pytest.raises(ValueError):
+        bbox_overlaps(np.zeros((3, 2)), q)
+
+
+def test_build_is_up_to_date_and_product_never_imports_the_oracle():
+    assert _build.up_to_date()
+    root = os.path.join(os.path.dirname(_lib.HERE), "mnc_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "libmnc_oracle" not in text, f
+    for f in ("tools/demo.py", "tools/_init_paths.py"):
+        text = open(os.path.join(os.path.dirname(_lib.HERE), f)).read()
+        assert "oracle" not in text

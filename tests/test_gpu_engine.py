@@ -17,7 +17,7 @@ from oracle import net as onet
 pytestmark = pytest.mark.gpu
 mnc_amd.install_paths()
 
-CHECK = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_3", "conv5_3", "rpn_output",
+_UNUSED = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_3", "conv5_3", "rpn_output",
          "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "roi_interpolate_conv5", "mask_output", "mask_proposal",
          "mask_proposal_resize", "roi_interpolate_conv5_box", "roi_interpolate_conv5_mask", "fc6", "fc7", "fc7_mask",
          "join_box_mask", "cls_prob", "seg_cls_prob", "bbox_pred", "rois_ext", "roi_interpolate_conv5_ext",
@@ -27,9 +27,10 @@ CHECK = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_3"
 def _compare(net, ref, names, tol=1e-3):
     report, bad = [], []
     for n in names:
-        if n not in ref:
+        b = net.blobs[n]
+        if n not in ref or not (b._dev_valid or b._host_valid):     # e.g. the premax blob of a fused plan
             continue
-        got = net.blobs[n].data
+        got = b._host_read()
         want = ref[n]
         if got.shape != want.shape:
             bad.append("%s: shape %r vs %r" % (n, got.shape, want.shape))
@@ -40,6 +41,44 @@ def _compare(net, ref, names, tol=1e-3):
             bad.append(report[-1])
     print("\n".join(report))
     assert not bad, "\n".join(bad)
+
+
+TRUNK_BLOBS = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_3", "conv5_3", "rpn_output",
+               "rpn_cls_prob_reshape", "rpn_bbox_pred"]
+HEAD_BLOBS = ["roi_interpolate_conv5", "mask_output", "mask_proposal", "mask_proposal_resize",
+              "roi_interpolate_conv5_box", "roi_interpolate_conv5_mask", "fc6", "fc7", "fc7_mask", "join_box_mask",
+              "cls_prob", "seg_cls_prob", "bbox_pred", "roi_interpolate_conv5_premax", "roi_mask_conv5"]
+
+
+def check_forward(net, w, data, im_info, extra=()):
+    """Parity protocol for one net.forward() that has already run on (data, im_info).
+
+    The cascade has two data-dependent host hops (proposal NMS, stage bridge arg-max).  A 1e-7 difference upstream can
+    legitimately flip a borderline IoU > 0.7 test, after which RoI lists differ row by row although every kernel is
+    right.  So each hop is teacher-forced, which is also how north_star words the bar ("bit-exact NMS keep indices" on
+    the same inputs, 1e-3 on the float outputs):
+      1. trunk + RPN blobs             device vs oracle from the same input                       (tolerance)
+      2. rois                          device == oracle ProposalLayer fed the DEVICE's RPN blobs   (bit-exact)
+      3. stage 2/3 blobs               device vs oracle head fed the device's rois                 (tolerance)
+      4. rois_ext                      device == oracle StageBridge fed the device's blobs         (bit-exact)
+      5. stage 4/5 blobs               device vs oracle head fed the device's rois_ext             (tolerance)"""
+    ref = {}
+    c5 = onet.trunk(w, data, ref)
+    onet.rpn(w, c5, ref)
+    _compare(net, ref, TRUNK_BLOBS)
+    g = lambda n: net.blobs[n]._host_read()
+    rois = g("rois")
+    want_rois = ohost.proposal_forward(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
+    assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
+    h1 = {}
+    onet.head(w, c5, rois, False, "", h1)
+    _compare(net, h1, [b for b in HEAD_BLOBS + list(extra) if b in h1])
+    rois_ext = g("rois_ext")
+    assert np.array_equal(rois_ext, ohost.stage_bridge_forward_test(rois, g("bbox_pred"), g("seg_cls_prob"), im_info))
+    h2 = {}
+    onet.head(w, c5, rois_ext, True, "_ext", h2)
+    _compare(net, h2, [b + "_ext" for b in HEAD_BLOBS + list(extra) if b + "_ext" in h2])
+    return ref, h1, h2
 
 
 @pytest.fixture(scope="module")
@@ -61,10 +100,8 @@ def test_reduced_net_blobwise(small, H, W, seed):
     net.blobs["data"].reshape(*data.shape)
     net.blobs["im_info"].reshape(*im_info.shape)
     out = net.forward(data=data, im_info=im_info)
-    ref = onet.forward(w, data, im_info)
     assert set(out) == {"cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"}
-    assert net.blobs["rois"].data.shape == ref["rois"].shape
-    _compare(net, ref, CHECK)
+    check_forward(net, w, data, im_info)
 
 
 def test_unfused_graph_matches_fused(small):
@@ -80,10 +117,10 @@ def test_unfused_graph_matches_fused(small):
     im_info = np.array([[112, 144, 1.0]], np.float32)
     net.forward(data=data, im_info=im_info)
     net2.forward(data=data, im_info=im_info)
-    ref = onet.forward(w, data, im_info)
-    _compare(net2, ref, CHECK + ["roi_interpolate_conv5_premax", "roi_mask_conv5", "roi_mask_conv5_ext"])
+    check_forward(net2, w, data, im_info)
+    assert net2.blobs["roi_interpolate_conv5_premax"]._host_read().shape[2:] == (28, 28)
     for n in ("rois", "seg_cls_prob", "mask_proposal", "rois_ext", "seg_cls_prob_ext", "mask_proposal_ext"):
-        assert np.array_equal(net.blobs[n].data, net2.blobs[n].data), n
+        assert np.array_equal(net.blobs[n]._host_read(), net2.blobs[n]._host_read()), n
     net2.close()
 
 
@@ -103,10 +140,9 @@ def test_full_vgg16_600x1000_blobwise(full):
     im = np.random.default_rng(0).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
     data, im_info, scale = ohost.prepare_mnc_args(im)
     net.forward(data=data, im_info=im_info)
-    ref = onet.forward(w, data, im_info)
-    assert net.blobs["conv5_3"].data.shape == (1, 512, 38, 63)
-    assert net.blobs["rois"].data.shape == (300, 5)
-    _compare(net, ref, CHECK)
+    assert net.blobs["conv5_3"]._host_read().shape == (1, 512, 38, 63)
+    assert net.blobs["rois"]._host_read().shape == (300, 5)
+    check_forward(net, w, data, im_info)
 
 
 def test_demo_pipeline_matches_oracle(full):
@@ -117,10 +153,16 @@ def test_demo_pipeline_matches_oracle(full):
     net, w = full
     im = np.random.default_rng(3).integers(0, 256, (375, 500, 3), dtype=np.uint8)
     boxes, masks, scores = demo.im_detect(im, net)
-    oboxes, omasks, oscores = onet.im_detect(w, im)
-    assert boxes.shape == oboxes.shape == (600, 4) and masks.shape == (600, 1, 21, 21) and scores.shape == (600, 21)
-    assert err(boxes, oboxes)[0] < 1e-3 * 500, err(boxes, oboxes)
-    assert err(scores, oscores)[0] < 1e-3 and err(masks, omasks)[0] < 1e-3
+    data, im_info, scale = ohost.prepare_mnc_args(im)
+    assert scale == 1.6 and data.shape == (1, 3, 600, 800)
+    assert err(net.blobs["data"]._host_read(), data)[0] < 1e-4          # product resize vs oracle resize
+    check_forward(net, w, net.blobs["data"]._host_read(), im_info)
+    g = lambda n: net.blobs[n]._host_read()
+    oboxes, omasks, oscores = ohost.im_detect_tail(g("rois"), g("mask_proposal"), g("seg_cls_prob"), g("rois_ext"),
+                                                   g("mask_proposal_ext"), g("seg_cls_prob_ext"), scale, im.shape)
+    assert boxes.shape == (600, 4) and masks.shape == (600, 1, 21, 21) and scores.shape == (600, 21)
+    assert boxes.dtype == np.float32 and np.array_equal(boxes, oboxes)
+    assert np.array_equal(masks, omasks) and np.array_equal(scores, oscores)
     lm, lb = gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
     # voting on the SAME inputs must be bit-exact with the oracle (== reference) voting
     om, ob = ohost.gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
