@@ -42,21 +42,6 @@ def parse():
     return p.parse_args()
 
 
-def pack_instances(result_mask, result_box, cap=100):
-    """20 per-class lists -> fixed [cap, 447] float32 block (x1,y1,x2,y2,score,class,441 mask values) + count."""
-    rec = np.zeros((cap, 447), np.float32)
-    n = 0
-    for c, (m, b) in enumerate(zip(result_mask, result_box)):
-        for k in range(len(b)):
-            if n >= cap:
-                break
-            rec[n, :5] = b[k]
-            rec[n, 5] = c + 1
-            rec[n, 6:] = m[k].reshape(-1)
-            n += 1
-    return rec, n
-
-
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -96,9 +81,8 @@ def main():
     scale = np.float32(im_scales[0])
     from transform.bbox_transform import clip_boxes
 
-    gather_buf = None
-    if world > 1:
-        gather_buf = [torch.empty((100, 447), dtype=torch.float32, device="cuda") for _ in range(world)]
+    from mnc_amd import dist as mdist
+    gatherer = mdist.InstanceGatherer(device="cuda") if world > 1 else None
 
     def step():
         net.forward()
@@ -110,8 +94,8 @@ def main():
         scores = np.concatenate((net.blobs["seg_cls_prob"]._host_read(), net.blobs["seg_cls_prob_ext"]._host_read()), 0)
         rm, rb = gpu_mask_voting(masks, np.concatenate(boxes, 0), scores, 21, 100, im.shape[1], im.shape[0])
         if world > 1:
-            rec, _ = pack_instances(rm, rb)
-            dist.all_gather(gather_buf, torch.from_numpy(rec).cuda(non_blocking=False))
+            rec, _ = mdist.pack_instances(rm, rb)
+            gatherer.gather(rec)
         return rm, rb
 
     def fence():
@@ -186,7 +170,9 @@ def cpu_baseline(weights, im, n_images):
     from oracle import host as ohost
     from oracle import native
     from oracle import net as onet
-    cores = os.cpu_count() or 1
+    # 32 threads is where torch-CPU convolutions peak on the 256-core bench host (tools/cpu_probe.py: 16 -> 0.94 s,
+    # 32 -> 0.81 s, 64 -> 1.30 s, 128 -> 2.43 s per image); `cores` reports the threads actually used
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     use_ref = native.ref_available()
     nms_fn = native.ref_gpu_nms if use_ref else native.gpu_nms
