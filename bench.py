@@ -84,18 +84,28 @@ def main():
     from mnc_amd import dist as mdist
     gatherer = mdist.InstanceGatherer(device="cuda") if world > 1 else None
 
+    phase_ms = {"forward": 0.0, "tail": 0.0, "voting": 0.0, "gather": 0.0}
+
     def step():
+        t_a = time.perf_counter()
         net.forward()
+        t_b = time.perf_counter()
         boxes = []
         for name in ("rois", "rois_ext"):
             r = net.blobs[name]._host_read()
             boxes.append(clip_boxes(r[:, 1:5] / scale, im.shape)[0])
         masks = np.concatenate((net.blobs["mask_proposal"]._host_read(), net.blobs["mask_proposal_ext"]._host_read()), 0)
         scores = np.concatenate((net.blobs["seg_cls_prob"]._host_read(), net.blobs["seg_cls_prob_ext"]._host_read()), 0)
-        rm, rb = gpu_mask_voting(masks, np.concatenate(boxes, 0), scores, 21, 100, im.shape[1], im.shape[0])
+        all_boxes = np.concatenate(boxes, 0)
+        t_c = time.perf_counter()
+        rm, rb = gpu_mask_voting(masks, all_boxes, scores, 21, 100, im.shape[1], im.shape[0])
+        t_d = time.perf_counter()
         if world > 1:
             rec, _ = mdist.pack_instances(rm, rb)
             gatherer.gather(rec)
+        t_e = time.perf_counter()
+        phase_ms["forward"] += 1e3 * (t_b - t_a); phase_ms["tail"] += 1e3 * (t_c - t_b)
+        phase_ms["voting"] += 1e3 * (t_d - t_c); phase_ms["gather"] += 1e3 * (t_e - t_d)
         return rm, rb
 
     def fence():
@@ -111,6 +121,8 @@ def main():
     fence()
     if events:
         net.profile(True)
+    for k in phase_ms:
+        phase_ms[k] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -136,6 +148,7 @@ def main():
                        "parallelism": "images sharded 1/GPU; RCCL all_gather of [100,447] instance blocks"
                        if world > 1 else "single GPU"},
         }
+        out["host_phase_ms_per_image"] = {k: round(v / args.steps, 3) for k, v in phase_ms.items()}
         if records:
             agg = {}
             for name, kms, fl, by in records:

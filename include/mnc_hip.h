@@ -54,6 +54,13 @@ MNC_API int mnc_nms(int* keep_out, int* num_out, const float* boxes_host, int bo
  * the first max_keep indices are identical to the unbounded call. */
 MNC_API int mnc_nms_topk(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
                          float nms_overlap_thresh, int max_keep, int device_id);
+/* Batched form for gpu_mask_voting's per-class loop (lib/transform/mask_transform.py:228-240): `batch` NMS problems
+ * over ONE box set.  order_host: [batch][boxes_num] int32, item b's boxes in descending score order (indices into
+ * boxes_host, i.e. the `argsort()[::-1]` gpu_nms.pyx:26 computes per call).  keep_out: [batch][boxes_num] int32 positions in
+ * item b's order (first num_out[b] valid); num_out: [batch].  Each item's result is bit-identical to mnc_nms_topk on
+ * boxes_host[order_host[b]].  One mask launch + one scan launch + one copy each way. */
+MNC_API int mnc_nms_batched(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                            const int* order_host, int batch, float nms_overlap_thresh, int max_keep, int device_id);
 /* The raw 64x64-tiled suppression bitmask (nms_kernel.cu:34-78) for word-for-word parity tests:
  * mask_host has boxes_num * ceil(boxes_num/64) uint64 words, row-major.  Lower-triangle words (never read by the
  * scan, nms_kernel.cu:135) are written as 0. */
@@ -80,6 +87,20 @@ MNC_API void _mv(const float* all_boxes, const float* all_masks, const int all_b
                  const int* candidate_start, const float* candidate_weights, const int candidate_num,
                  const int image_height, const int image_width, const int box_dim, const int mask_size,
                  const int result_num, float* finalize_output_mask, int* finalize_output_box, const int device_id);
+
+/* gpu_mask_voting in ONE call (lib/transform/mask_transform.py:213-286): per-class NMS (batched on the device) -> global
+ * score threshold -> candidate sets {IoU_f64 >= iou_thresh} with class-score weights normalised by a sequential float32 sum
+ * (python's sum(), :266) -> fused mask voting kernels.  All host pointers.
+ *   boxes [n][4] f32 (original-image pixels), masks [n][S][S] f32, scores [n][num_classes] f32 (column 0 = background),
+ *   order [num_classes-1][n] i32: for class c+1, box indices by descending scores[:,c+1] (the caller's argsort()[::-1], so
+ *         tie order is exactly the reference wrapper's, gpu_nms.pyx:26).
+ * Outputs (capacity (num_classes-1)*min(max_per_image, n) rows): out_mask [R][S][S], out_box [R][4] i32, out_score [R],
+ * class_count [num_classes-1] (rows per class, in class order), *result_num = R.
+ * Bit-identical to running nms.gpu_nms x (num_classes-1), utils.cython_bbox.bbox_overlaps and nms.mv.mv as the reference does. */
+MNC_API int mnc_mask_voting(const float* boxes, const float* masks, const float* scores, const int* order, int n,
+                            int num_classes, int mask_size, int max_per_image, float nms_thresh, float iou_thresh,
+                            int image_height, int image_width, float* out_mask, int* out_box, float* out_score,
+                            int* class_count, int* result_num, int device_id);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * b3  utils.cython_bbox.bbox_overlaps (lib/utils/bbox.pyx:15-55): float64 IoU with +1 widths, [N][K] row-major.
@@ -165,6 +186,8 @@ MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float
                    int N, int K, int ldc, int act);
 /* Softmax over the last axis of [M][N] (test.prototxt cls_prob / seg_cls_prob). */
 MNC_API int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N);
+/* Same with a row stride on the input (the input may be a column slice of a merged-GEMM output). */
+MNC_API int mnc_softmax_rows_ld(mnc_ctx* ctx, const float* d_in, int ld_in, float* d_out, int M, int N);
 /* Stand-alone ReLU (op 1) / Sigmoid (op 2) for graphs where the activation is not fused into its producer
  * (test.prototxt:540-545 `mask_output` when run unfused).  In-place allowed. */
 MNC_API int mnc_eltwise(mnc_ctx* ctx, const float* d_in, float* d_out, size_t count, int op);

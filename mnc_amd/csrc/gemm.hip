@@ -21,12 +21,13 @@ namespace mnc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBN = 128, kBK = 32, kMT = 10, kBM = 32 * kMT;
+constexpr int kBN = 128, kBK = 32;
 constexpr int kPitch = kBK + 4;
-constexpr int kAVec = kBM * (kBK / 4);   // 2560 float4
 constexpr int kBVec = kBN * (kBK / 4);   // 1024 float4
-constexpr int kAPer = kAVec / 256;       // 10
 constexpr int kBPer = kBVec / 256;       // 4
+// Two row-tile counts per workgroup: MT = 10 (320 rows: all RoIs in one block, weights streamed once -- the big FCs) and
+// MT = 2 (64 rows: the small GEMMs -- mask_pred 256->441 and the 8192->{21,21,84} heads -- where 320-row blocks would
+// leave most CUs idle; 55 KB of LDS lets two such workgroups share a CU).
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
@@ -36,10 +37,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // grid: (ceil(N/128), splits, ceil(M/320)).  k range of split s: [s*kper, min(K, (s+1)*kper)), kper % 32 == 0.
 // fused != 0: write act(acc + bias) to out (ldc); else write raw partials to part[split][M][N].
+template <int kMT>
 __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       float* __restrict__ part, int M, int N, int K, int ldc, int kper,
                                                       int act, int fused) {
+  constexpr int kBM = 32 * kMT;
+  constexpr int kAPer = kMT;               // float4 staging items per thread for the A panel (item u == row tile u)
   __shared__ __attribute__((aligned(16))) float sA[2][kBM * kPitch];
   __shared__ __attribute__((aligned(16))) float sB[2][kBN * kPitch];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -157,10 +161,10 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
   }
 }
 
-__global__ void softmax_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int N) {
+__global__ void softmax_rows_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int M, int N) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  const float* r = in + (long)m * N;
+  const float* r = in + (long)m * ld_in;
   float mx = r[0];
   for (int i = 1; i < N; ++i) mx = fmaxf(mx, r[i]);
   float sum = 0.f;
@@ -197,10 +201,14 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kBK == 0 && ldc >= N && act >= 0 && act <= 2,
               "mnc_fc: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
   if (M == 0) return MNC_OK;
-  const int tn = cdiv(N, kBN), tm = cdiv(M, kBM), stages = K / kBK;
-  // enough splits to give every CU a workgroup, but at least 8 stages (256 deep) per split
-  int splits = cdiv(256, tn * tm);
-  if (splits > stages / 8) splits = stages / 8;
+  // small problems (< 2 GFLOP) use 64-row workgroups so that rows, column tiles and K splits together fill the chip
+  const bool small = 2.0 * M * (double)N * K < 2.0e9;
+  const int bm = small ? 64 : 320;
+  const int tn = cdiv(N, kBN), tm = cdiv(M, bm), stages = K / kBK;
+  // enough splits to give every CU a workgroup (two for the small variant), but at least 2 stages (64 deep) per split
+  int splits = cdiv(small ? 512 : 256, tn * tm);
+  const int min_stages = small ? 2 : 8;
+  if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
   const int kper = cdiv(stages, splits) * kBK;
   splits = cdiv(K, kper);
@@ -212,9 +220,13 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   }
   const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
   {
-    LaunchScope ls(ctx, "fc_mfma", flops, bytes);
-    hipLaunchKernelGGL(fc_mfma_kernel, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part, M,
-                       N, K, ldc, kper, act, splits == 1 ? 1 : 0);
+    LaunchScope ls(ctx, small ? "fc_mfma_small" : "fc_mfma", flops, bytes);
+    if (small)
+      hipLaunchKernelGGL(fc_mfma_kernel<2>, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0);
+    else
+      hipLaunchKernelGGL(fc_mfma_kernel<10>, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0);
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }
@@ -229,12 +241,16 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   return MNC_OK;
 }
 
-int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N) {
-  MNC_REQUIRE(ctx && d_in && d_out && M >= 0 && N > 0, "mnc_softmax_rows: bad argument");
+int mnc_softmax_rows_ld(mnc_ctx* ctx, const float* d_in, int ld_in, float* d_out, int M, int N) {
+  MNC_REQUIRE(ctx && d_in && d_out && M >= 0 && N > 0 && ld_in >= N, "mnc_softmax_rows: bad argument");
   if (M == 0) return MNC_OK;
   LaunchScope ls(ctx, "softmax_rows");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 64)), dim3(64), 0, ctx->stream, d_in, d_out, M, N);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 64)), dim3(64), 0, ctx->stream, d_in, ld_in, d_out, M, N);
   return ls.finish("softmax_rows_kernel");
+}
+
+int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N) {
+  return mnc_softmax_rows_ld(ctx, d_in, N, d_out, M, N);
 }
 
 int mnc_eltwise(mnc_ctx* ctx, const float* d_in, float* d_out, size_t count, int op) {

@@ -88,4 +88,13 @@ struct LegacyWs {
 };
 int legacy_ws(int device_id, size_t bytes, LegacyWs** out);  // nms.hip
 
+// launchers shared between translation units (all asynchronous on `stream`, pointers are device pointers)
+int nms_mask_launch(hipStream_t stream, const float* d_boxes, const int* d_order, int n, int dim, float thr,
+                    unsigned long long* d_mask, int batch);
+int nms_scan_launch(hipStream_t stream, const unsigned long long* d_mask, int n, int max_keep, int* d_keep, int* d_num,
+                    int batch);
+int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
+              const int* d_starts, const float* d_wts, int H, int W, int R, int* d_bounds, float* d_out_mask,
+              int* d_out_box);
+
 }  // namespace mnc

@@ -14,7 +14,9 @@
 //
 // Compiled with -ffp-contract=off; every float expression is written in the reference's operation order, so the
 // outputs are bit-exact with mv_kernel.cu evaluated without FMA contraction (== oracle/mnc_oracle.c == oracle/_ref).
+#include <algorithm>
 #include <climits>
+#include <functional>
 #include <mutex>
 
 #include "mnc_internal.h"
@@ -273,6 +275,127 @@ int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, co
   }
   MNC_HIP_TRY(hipMemcpyAsync(d_starts, candidate_start, (size_t)R * 4, hipMemcpyHostToDevice, s));
   mv_launch(s, d_boxes, box_dim, d_masks, S, d_inds, d_starts, d_wts, image_height, image_width, R, d_bounds, d_omask, d_obox);
+  MNC_HIP_TRY(hipGetLastError());
+  MNC_HIP_TRY(hipMemcpyAsync(out_mask, d_omask, (size_t)R * S * S * 4, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipMemcpyAsync(out_box, d_obox, (size_t)R * 16, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipStreamSynchronize(s));
+  clear_error();
+  return MNC_OK;
+}
+
+// gpu_mask_voting in one call (lib/transform/mask_transform.py:213-286 + lib/nms/mv_kernel.cu).  See include/mnc_hip.h.
+int mnc_mask_voting(const float* boxes, const float* masks, const float* scores, const int* order, int n, int num_classes,
+                    int mask_size, int max_per_image, float nms_thresh, float iou_thresh, int image_height,
+                    int image_width, float* out_mask, int* out_box, float* out_score, int* class_count, int* result_num,
+                    int device_id) {
+  MNC_REQUIRE(result_num && class_count, "mnc_mask_voting: null output pointer");
+  MNC_REQUIRE(n >= 0 && num_classes >= 2 && mask_size >= 2 && max_per_image > 0 && image_height > 0 && image_width > 0,
+              "mnc_mask_voting: bad argument");
+  const int B = num_classes - 1, S = mask_size;
+  *result_num = 0;
+  for (int c = 0; c < B; ++c) class_count[c] = 0;
+  if (n == 0) { clear_error(); return MNC_OK; }
+  MNC_REQUIRE(boxes && masks && scores && order && out_mask && out_box && out_score, "mnc_mask_voting: null pointer");
+  for (long i = 0; i < (long)B * n; ++i)
+    MNC_REQUIRE(order[i] >= 0 && order[i] < n, "mnc_mask_voting: order[%ld]=%d out of range", i, order[i]);
+  const int cb = cdiv(n, 64);
+  const int keep_cap = max_per_image < n ? max_per_image : n;
+  const int Rmax = B * keep_cap;
+  const size_t b_boxes = align256((size_t)n * 16), b_masks = align256((size_t)n * S * S * 4), b_order = align256((size_t)B * n * 4);
+  const size_t b_bits = align256((size_t)B * n * cb * 8), b_keep = align256((size_t)B * n * 4), b_num = align256((size_t)B * 4);
+  const size_t b_cinds = align256((size_t)Rmax * n * 4), b_cw = b_cinds, b_cstart = align256((size_t)Rmax * 4);
+  const size_t b_bounds = align256((size_t)Rmax * 16), b_omask = align256((size_t)Rmax * S * S * 4), b_obox = b_bounds;
+  LegacyWs* w = nullptr;
+  int rc = legacy_ws(device_id, b_boxes + b_masks + b_order + b_bits + b_keep + b_num + b_cinds + b_cw + b_cstart + b_bounds +
+                                    b_omask + b_obox, &w);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(w->mu);
+  hipStream_t s = w->stream;
+  char* p = (char*)w->buf;
+  float* d_boxes = (float*)p; p += b_boxes;
+  float* d_masks = (float*)p; p += b_masks;
+  int* d_order = (int*)p; p += b_order;
+  unsigned long long* d_bits = (unsigned long long*)p; p += b_bits;
+  int* d_keep = (int*)p; p += b_keep;
+  int* d_num = (int*)p; p += b_num;
+  int* d_cinds = (int*)p; p += b_cinds;
+  float* d_cw = (float*)p; p += b_cw;
+  int* d_cstart = (int*)p; p += b_cstart;
+  int* d_bounds = (int*)p; p += b_bounds;
+  float* d_omask = (float*)p; p += b_omask;
+  int* d_obox = (int*)p;
+
+  // 1. the per-class NMS problems (mask_transform.py:228-240), batched; masks ride along on the same stream
+  MNC_HIP_TRY(hipMemcpyAsync(d_boxes, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
+  MNC_HIP_TRY(hipMemcpyAsync(d_order, order, (size_t)B * n * 4, hipMemcpyHostToDevice, s));
+  nms_mask_launch(s, d_boxes, d_order, n, 4, nms_thresh, d_bits, B);
+  nms_scan_launch(s, d_bits, n, keep_cap, d_keep, d_num, B);
+  MNC_HIP_TRY(hipGetLastError());
+  std::vector<int> h_keep((size_t)B * n), h_num(B);
+  MNC_HIP_TRY(hipMemcpyAsync(h_num.data(), d_num, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipMemcpyAsync(h_keep.data(), d_keep, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipMemcpyAsync(d_masks, masks, (size_t)n * S * S * 4, hipMemcpyHostToDevice, s));
+  MNC_HIP_TRY(hipStreamSynchronize(s));
+
+  // 2. global threshold = the max_per_image-th best kept score over all classes (:242-244)
+  std::vector<float> pool;
+  for (int c = 0; c < B; ++c)
+    for (int k = 0; k < h_num[c]; ++k) pool.push_back(scores[(size_t)order[(size_t)c * n + h_keep[(size_t)c * n + k]] * num_classes + c + 1]);
+  if (pool.empty()) { clear_error(); return MNC_OK; }
+  std::vector<float> ranked(pool);
+  const size_t kth = (ranked.size() < (size_t)max_per_image ? ranked.size() : (size_t)max_per_image) - 1;
+  std::nth_element(ranked.begin(), ranked.begin() + kth, ranked.end(), std::greater<float>());
+  const float thresh = ranked[kth];
+
+  // 3. candidate lists (:253-270): members = {i : IoU_f64(box_i, kept box) >= iou_thresh}, weights = class scores
+  //    normalised by python's sequential float32 sum
+  std::vector<int> cinds;
+  std::vector<float> cw;
+  std::vector<int> cstart;
+  int R = 0;
+  for (int c = 0; c < B; ++c) {
+    int cnt = 0;
+    for (int k = 0; k < h_num[c]; ++k) {
+      const int bi = order[(size_t)c * n + h_keep[(size_t)c * n + k]];
+      const float sc = scores[(size_t)bi * num_classes + c + 1];
+      if (!(sc >= thresh)) continue;
+      const double q0 = boxes[bi * 4 + 0], q1 = boxes[bi * 4 + 1], q2 = boxes[bi * 4 + 2], q3 = boxes[bi * 4 + 3];
+      const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
+      const size_t first = cinds.size();
+      float sum = 0.0f;
+      bool any = false;
+      for (int i = 0; i < n; ++i) {
+        const double b0 = boxes[i * 4 + 0], b1 = boxes[i * 4 + 1], b2 = boxes[i * 4 + 2], b3 = boxes[i * 4 + 3];
+        double ov = 0.0;
+        const double iw = (b2 < q2 ? b2 : q2) - (b0 > q0 ? b0 : q0) + 1;
+        if (iw > 0) {
+          const double ih = (b3 < q3 ? b3 : q3) - (b1 > q1 ? b1 : q1) + 1;
+          if (ih > 0) ov = iw * ih / ((b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih);
+        }
+        if (ov >= (double)iou_thresh) {
+          cinds.push_back(i);
+          const float wv = scores[(size_t)i * num_classes + c + 1];
+          sum = any ? sum + wv : wv;      // python: sum(w) == ((0 + w0) + w1) + ...  (0 + w0 is exact)
+          any = true;
+        }
+      }
+      for (size_t t = first; t < cinds.size(); ++t) cw.push_back(scores[(size_t)cinds[t] * num_classes + c + 1] / sum);
+      cstart.push_back((int)cinds.size());
+      out_score[R++] = sc;
+      ++cnt;
+    }
+    class_count[c] = cnt;
+  }
+  *result_num = R;
+  if (R == 0) { clear_error(); return MNC_OK; }
+
+  // 4. the fused mask-voting kernels
+  if (!cinds.empty()) {
+    MNC_HIP_TRY(hipMemcpyAsync(d_cinds, cinds.data(), cinds.size() * 4, hipMemcpyHostToDevice, s));
+    MNC_HIP_TRY(hipMemcpyAsync(d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, s));
+  }
+  MNC_HIP_TRY(hipMemcpyAsync(d_cstart, cstart.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+  mv_launch(s, d_boxes, 4, d_masks, S, d_cinds, d_cstart, d_cw, image_height, image_width, R, d_bounds, d_omask, d_obox);
   MNC_HIP_TRY(hipGetLastError());
   MNC_HIP_TRY(hipMemcpyAsync(out_mask, d_omask, (size_t)R * S * S * 4, hipMemcpyDeviceToHost, s));
   MNC_HIP_TRY(hipMemcpyAsync(out_box, d_obox, (size_t)R * 16, hipMemcpyDeviceToHost, s));

@@ -9,10 +9,11 @@
 //     8-byte store per lane.  Four waves (four column tiles) share one row tile through LDS.
 //   * only the upper triangle of tiles is computed; the reference launches all col_blocks^2 tiles (nms_kernel.cu:39
 //     has the early exit commented out) although its scan never reads the lower ones (:135).
-//   * the greedy scan runs on the device in ONE wave: per 64-box block, the 64 diagonal words are fetched with one
-//     vector load and the intra-block chain is resolved with v_readlane only; the rows of the survivors are then OR-ed
-//     into the per-lane `remv` words with independent (non-chained) loads.  So the serial dependency is one load per
-//     block of 64 boxes instead of one per kept box, and the 4.5 MB mask never crosses PCIe.
+//   * the greedy scan runs on the device in ONE wave per problem (see nms_scan_kernel): the serial dependency is one load
+//     latency per block of 64 boxes instead of one per kept box, the intra-block chain runs on the scalar unit, and the
+//     4.5 MB mask never crosses PCIe.
+//   * batched form (mnc_nms_batched): gpu_mask_voting's 20 per-class NMS problems over one box set run as ONE mask launch
+//     (grid.z = class) + ONE scan launch (one wave per class) + one copy each way, instead of 20 synchronous round trips.
 #include <mutex>
 
 #include "mnc_internal.h"
@@ -33,19 +34,27 @@ __device__ __forceinline__ float iou_ref_order(float a0, float a1, float a2, flo
 
 constexpr int kWavesPerBlock = 4;
 
-// grid: (ceil(cb / 4), cb); block: 256.  boxes: [n][dim] sorted by descending score.  mask: [n][cb].
-__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes, int n, int dim, float thr,
-                                                       u64* __restrict__ mask, int cb) {
+// Device bitmask layout: COLUMN-BLOCK major, mask[c * n + r] = word of (row box r, column tile c).  Both the mask
+// kernel's stores (lane = row within a tile) and the scan's loads (all rows of one column tile) are then contiguous.
+//
+// grid: (ceil(cb / 4), cb, batch); block: 256.  Item z of the batch uses boxes[order[z*n + i]] as its i-th (sorted)
+// box, or boxes[i] when order == nullptr.  mask + z * cb * n is its bitmask.
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ order,
+                                                       int n, int dim, float thr, u64* __restrict__ mask, int cb) {
   const int rt = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ct = blockIdx.x * kWavesPerBlock + wave;
   __shared__ float rowbox[64][4];
   if (blockIdx.x * kWavesPerBlock + kWavesPerBlock - 1 < rt) return;  // whole block below the diagonal
+  const int* ord = order ? order + (long)blockIdx.z * n : nullptr;
+  u64* m = mask + (long)blockIdx.z * cb * n;
   if (threadIdx.x < 64) {
     const int r = rt * 64 + threadIdx.x;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < n) v = make_float4(boxes[(long)r * dim + 0], boxes[(long)r * dim + 1], boxes[(long)r * dim + 2],
-                               boxes[(long)r * dim + 3]);
+    if (r < n) {
+      const float* b = boxes + (long)(ord ? ord[r] : r) * dim;
+      v = make_float4(b[0], b[1], b[2], b[3]);
+    }
     rowbox[threadIdx.x][0] = v.x; rowbox[threadIdx.x][1] = v.y; rowbox[threadIdx.x][2] = v.z; rowbox[threadIdx.x][3] = v.w;
   }
   __syncthreads();
@@ -55,8 +64,8 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
   const bool cvalid = c < n;
   float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
   if (cvalid) {
-    b0 = boxes[(long)c * dim + 0]; b1 = boxes[(long)c * dim + 1];
-    b2 = boxes[(long)c * dim + 2]; b3 = boxes[(long)c * dim + 3];
+    const float* b = boxes + (long)(ord ? ord[c] : c) * dim;
+    b0 = b[0]; b1 = b[1]; b2 = b[2]; b3 = b[3];
   }
   const float Sb = (b2 - b0 + 1) * (b3 - b1 + 1);
   const bool diag = (ct == rt);
@@ -70,66 +79,92 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
     const u64 word = __ballot(hit);
     if (lane == i) mine = word;
   }
-  if (lane < rows) mask[(long)(rt * 64 + lane) * cb + ct] = mine;
+  if (lane < rows) m[(long)ct * n + rt * 64 + lane] = mine;
 }
 
-constexpr int kMaxWordsPerLane = 8;  // device scan handles cb <= 512, i.e. n <= 32768
+constexpr int kMaxScanBlocks = 512;  // device scan handles cb <= 512, i.e. n <= 32768
 
-// One wave.  keep: capacity n.  Greedy scan of nms_kernel.cu:124-140, stopping after max_keep survivors.
+__device__ __forceinline__ u64 uniform64(u64 v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+template <int I>
+__device__ __forceinline__ u64 lane64(u64 v) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, I), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), I);
+  return ((u64)hi << 32) | lo;
+}
+
+// One step of the greedy in-block chain (nms_kernel.cu:128-139), entirely on the scalar unit.
+template <int I>
+__device__ __forceinline__ void resolve_step(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
+  const u64 di = lane64<I>(diag);
+  if (I < rows && nk < max_keep && !((cur >> I) & 1ull)) {
+    kept |= 1ull << I;
+    cur |= di;
+    ++nk;
+  }
+}
+template <int I0, int N>
+struct Resolve {
+  static __device__ __forceinline__ void run(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
+    Resolve<I0, N / 2>::run(diag, rows, max_keep, cur, kept, nk);
+    Resolve<I0 + N / 2, N - N / 2>::run(diag, rows, max_keep, cur, kept, nk);
+  }
+};
+template <int I0>
+struct Resolve<I0, 1> {
+  static __device__ __forceinline__ void run(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
+    resolve_step<I0>(diag, rows, max_keep, cur, kept, nk);
+  }
+};
+
+// grid: batch; block: ONE wave.  Greedy scan of nms_kernel.cu:124-140 on the column-block-major bitmask, stopping after
+// max_keep survivors.  Per 64-box block:
+//   1. removal word of the block = OR over ALL earlier survivors of their word in this column tile: lane l covers row
+//      64*bb + l of every earlier block bb (contiguous, independent loads; survivors' bits come from LDS), then one
+//      wave-wide OR reduction -- one load latency per block, not one per survivor;
+//   2. the intra-block chain runs on the scalar unit: v_readlane of the 64 diagonal words, 64 unrolled steps;
+//   3. survivors write their indices with one compacting vector store (prefix popcount).
 __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, int n, int cb, int max_keep,
                                                       int* __restrict__ keep, int* __restrict__ num_out) {
+  __shared__ u64 s_kept[kMaxScanBlocks];
   const int lane = threadIdx.x;
-  u64 remv[kMaxWordsPerLane];
-#pragma unroll
-  for (int q = 0; q < kMaxWordsPerLane; ++q) remv[q] = 0;
+  const u64* m = mask + (long)blockIdx.x * cb * n;
+  int* kp = keep + (long)blockIdx.x * n;
   int nk = 0;
-  for (int b = 0; b < cb && nk < max_keep; ++b) {
-    // current removal word of block b lives in lane (b & 63), slot (b >> 6)
-    u64 slot = 0;
+  for (int blk = 0; blk < cb && nk < max_keep; ++blk) {
+    const u64* col = m + (long)blk * n;
+    u64 acc = 0;
+    for (int bb = 0; bb < blk; ++bb)
+      if ((s_kept[bb] >> lane) & 1ull) acc |= col[bb * 64 + lane];
+    const int row = blk * 64 + lane;
+    const u64 diag = row < n ? col[row] : 0ull;
 #pragma unroll
-    for (int q = 0; q < kMaxWordsPerLane; ++q)
-      if (q == (b >> 6)) slot = remv[q];
-    u64 cur = __shfl(slot, b & 63);
-    const int row = b * 64 + lane;
-    const u64 dword = row < n ? mask[(long)row * cb + b] : 0ull;
-    const int rows = min(n - b * 64, 64);
-    u64 keptbits = 0;
-    for (int i = 0; i < rows && nk < max_keep; ++i) {
-      const u64 di = __shfl(dword, i);
-      if (!((cur >> i) & 1ull)) {
-        keptbits |= 1ull << i;
-        if (lane == 0) keep[nk] = b * 64 + i;
-        ++nk;
-        cur |= di;
-      }
-    }
-    // fold the survivors' rows into remv for the words this lane owns (independent loads)
-    u64 bits = keptbits;
-    while (bits) {
-      const int i = __ffsll((long long)bits) - 1;
-      bits &= bits - 1;
-      const long base = (long)(b * 64 + i) * cb;
-#pragma unroll
-      for (int q = 0; q < kMaxWordsPerLane; ++q) {
-        const int w = lane + 64 * q;
-        if (w > b && w < cb) remv[q] |= mask[base + w];
-      }
-    }
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
+    u64 cur = uniform64(acc);
+    const int rows = min(n - blk * 64, 64);
+    u64 kept = 0;
+    const int nk0 = nk;
+    Resolve<0, 64>::run(diag, rows, max_keep, cur, kept, nk);
+    if ((kept >> lane) & 1ull) kp[nk0 + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+    if (lane == 0) s_kept[blk] = kept;
+    __syncthreads();
   }
-  if (lane == 0) *num_out = nk;
+  if (lane == 0) num_out[blockIdx.x] = nk;
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------
-int nms_mask_launch(hipStream_t stream, const float* d_boxes, int n, int dim, float thr, u64* d_mask) {
+int nms_mask_launch(hipStream_t stream, const float* d_boxes, const int* d_order, int n, int dim, float thr, u64* d_mask,
+                    int batch) {
   const int cb = cdiv(n, 64);
-  dim3 grid(cdiv(cb, kWavesPerBlock), cb);
-  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(256), 0, stream, d_boxes, n, dim, thr, d_mask, cb);
+  dim3 grid(cdiv(cb, kWavesPerBlock), cb, batch);
+  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(256), 0, stream, d_boxes, d_order, n, dim, thr, d_mask, cb);
   return MNC_OK;
 }
 
-int nms_scan_launch(hipStream_t stream, const u64* d_mask, int n, int max_keep, int* d_keep, int* d_num) {
+int nms_scan_launch(hipStream_t stream, const u64* d_mask, int n, int max_keep, int* d_keep, int* d_num, int batch) {
   const int cb = cdiv(n, 64);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, d_mask, n, cb, max_keep, d_keep, d_num);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, stream, d_mask, n, cb, max_keep, d_keep, d_num);
   return MNC_OK;
 }
 
@@ -162,61 +197,76 @@ int legacy_ws(int device_id, size_t bytes, LegacyWs** out) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int nms_host_impl(int* keep_out, int* num_out, u64* mask_out, const float* boxes_host, int n, int dim, float thr,
-                         int max_keep, int device_id) {
-  MNC_REQUIRE(n >= 0 && dim >= 4, "mnc_nms: boxes_num=%d boxes_dim=%d", n, dim);
-  if (num_out) *num_out = 0;
+// boxes_host [n][dim]; order_host: nullptr (boxes already sorted, batch == 1) or [batch][n] indices into boxes.
+// keep_out [batch][n] positions in each item's order; num_out [batch].  mask_out (batch == 1 only): row-major [n][cb].
+static int nms_host_impl(int* keep_out, int* num_out, u64* mask_out, const float* boxes_host, int n, int dim,
+                         const int* order_host, int batch, float thr, int max_keep, int device_id) {
+  MNC_REQUIRE(n >= 0 && dim >= 4 && batch >= 1, "mnc_nms: boxes_num=%d boxes_dim=%d batch=%d", n, dim, batch);
+  if (num_out) for (int b = 0; b < batch; ++b) num_out[b] = 0;
   if (n == 0) { clear_error(); return MNC_OK; }
   MNC_REQUIRE(boxes_host, "mnc_nms: null boxes");
+  if (order_host)
+    for (long i = 0; i < (long)batch * n; ++i)
+      MNC_REQUIRE(order_host[i] >= 0 && order_host[i] < n, "mnc_nms_batched: order[%ld]=%d out of range", i, order_host[i]);
   const int cb = cdiv(n, 64);
   if (max_keep < 0 || max_keep > n) max_keep = n;
-  const size_t box_b = align256((size_t)n * dim * 4), mask_b = align256((size_t)n * cb * 8), keep_b = align256((size_t)n * 4);
+  const size_t box_b = align256((size_t)n * dim * 4), ord_b = order_host ? align256((size_t)batch * n * 4) : 0;
+  const size_t mask_b = align256((size_t)batch * n * cb * 8), keep_b = align256((size_t)batch * n * 4);
   LegacyWs* w = nullptr;
-  int rc = legacy_ws(device_id, box_b + mask_b + keep_b + 256, &w);
+  int rc = legacy_ws(device_id, box_b + ord_b + mask_b + keep_b + align256((size_t)batch * 4), &w);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(w->mu);
   char* base = (char*)w->buf;
   float* d_boxes = (float*)base;
-  u64* d_mask = (u64*)(base + box_b);
-  int* d_keep = (int*)(base + box_b + mask_b);
-  int* d_num = (int*)(base + box_b + mask_b + keep_b);
+  int* d_order = order_host ? (int*)(base + box_b) : nullptr;
+  u64* d_mask = (u64*)(base + box_b + ord_b);
+  int* d_keep = (int*)(base + box_b + ord_b + mask_b);
+  int* d_num = (int*)(base + box_b + ord_b + mask_b + keep_b);
   MNC_HIP_TRY(hipMemcpyAsync(d_boxes, boxes_host, (size_t)n * dim * 4, hipMemcpyHostToDevice, w->stream));
-  const bool device_scan = cb <= 64 * kMaxWordsPerLane && !mask_out;
-  if (mask_out) MNC_HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)n * cb * 8, w->stream));
-  nms_mask_launch(w->stream, d_boxes, n, dim, thr, d_mask);
+  if (order_host) MNC_HIP_TRY(hipMemcpyAsync(d_order, order_host, (size_t)batch * n * 4, hipMemcpyHostToDevice, w->stream));
+  const bool device_scan = cb <= kMaxScanBlocks && !mask_out;
+  if (!device_scan) MNC_HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)batch * n * cb * 8, w->stream));
+  nms_mask_launch(w->stream, d_boxes, d_order, n, dim, thr, d_mask, batch);
   MNC_HIP_TRY(hipGetLastError());
-  if (mask_out) {
-    MNC_HIP_TRY(hipMemcpyAsync(mask_out, d_mask, (size_t)n * cb * 8, hipMemcpyDeviceToHost, w->stream));
-    MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+  if (device_scan) {
+    nms_scan_launch(w->stream, d_mask, n, max_keep, d_keep, d_num, batch);
+    MNC_HIP_TRY(hipGetLastError());
+    MNC_HIP_TRY(hipMemcpyAsync(num_out, d_num, (size_t)batch * 4, hipMemcpyDeviceToHost, w->stream));
+    if (batch > 1) {  // one copy of the whole (small) keep table instead of a second dependent round trip
+      MNC_HIP_TRY(hipMemcpyAsync(keep_out, d_keep, (size_t)batch * n * 4, hipMemcpyDeviceToHost, w->stream));
+      MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+    } else {
+      MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+      if (num_out[0] > 0) {
+        MNC_HIP_TRY(hipMemcpyAsync(keep_out, d_keep, (size_t)num_out[0] * 4, hipMemcpyDeviceToHost, w->stream));
+        MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+      }
+    }
     clear_error();
     return MNC_OK;
   }
-  if (device_scan) {
-    nms_scan_launch(w->stream, d_mask, n, max_keep, d_keep, d_num);
-    MNC_HIP_TRY(hipGetLastError());
-    int nk = 0;
-    MNC_HIP_TRY(hipMemcpyAsync(&nk, d_num, 4, hipMemcpyDeviceToHost, w->stream));
+  // mask read-back (parity API) or n > 32768: the reference's own arrangement -- bitmask to the host, scan there
+  // (nms_kernel.cu:118-140).  The device layout is column-block major; rows are re-assembled here.
+  std::vector<u64> hm((size_t)n * cb);
+  for (int b = 0; b < batch; ++b) {
+    MNC_HIP_TRY(hipMemcpyAsync(hm.data(), d_mask + (size_t)b * n * cb, (size_t)n * cb * 8, hipMemcpyDeviceToHost, w->stream));
     MNC_HIP_TRY(hipStreamSynchronize(w->stream));
-    if (nk > 0) {
-      MNC_HIP_TRY(hipMemcpyAsync(keep_out, d_keep, (size_t)nk * 4, hipMemcpyDeviceToHost, w->stream));
-      MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+    if (mask_out) {
+      for (int r = 0; r < n; ++r)
+        for (int c = 0; c < cb; ++c) mask_out[(size_t)r * cb + c] = hm[(size_t)c * n + r];
+      continue;
     }
-    *num_out = nk;
-  } else {
-    // n > 32768: the reference's own arrangement -- bitmask to the host, scan there (nms_kernel.cu:118-140)
-    std::vector<u64> hm((size_t)n * cb), remv(cb, 0);
-    MNC_HIP_TRY(hipMemcpyAsync(hm.data(), d_mask, (size_t)n * cb * 8, hipMemcpyDeviceToHost, w->stream));
-    MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+    std::vector<u64> remv(cb, 0);
     int nk = 0;
+    int* kp = keep_out + (size_t)b * n;
     for (int i = 0; i < n && nk < max_keep; ++i) {
       const int nb = i / 64, ib = i % 64;
       if (!(remv[nb] & (1ULL << ib))) {
-        keep_out[nk++] = i;
-        const u64* p = hm.data() + (size_t)i * cb;
-        for (int j = nb; j < cb; ++j) remv[j] |= p[j];
+        kp[nk++] = i;
+        for (int j = nb; j < cb; ++j) remv[j] |= hm[(size_t)j * n + i];
       }
     }
-    *num_out = nk;
+    num_out[b] = nk;
   }
   clear_error();
   return MNC_OK;
@@ -231,19 +281,26 @@ extern "C" {
 int mnc_nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float thresh,
             int device_id) {
   MNC_REQUIRE(keep_out && num_out, "mnc_nms: null output pointer");
-  return nms_host_impl(keep_out, num_out, nullptr, boxes_host, boxes_num, boxes_dim, thresh, -1, device_id);
+  return nms_host_impl(keep_out, num_out, nullptr, boxes_host, boxes_num, boxes_dim, nullptr, 1, thresh, -1, device_id);
+}
+
+int mnc_nms_batched(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                    const int* order_host, int batch, float thresh, int max_keep, int device_id) {
+  MNC_REQUIRE(keep_out && num_out && (boxes_num == 0 || order_host), "mnc_nms_batched: null pointer");
+  return nms_host_impl(keep_out, num_out, nullptr, boxes_host, boxes_num, boxes_dim, order_host, batch, thresh, max_keep,
+                       device_id);
 }
 
 int mnc_nms_topk(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float thresh,
                  int max_keep, int device_id) {
   MNC_REQUIRE(keep_out && num_out, "mnc_nms_topk: null output pointer");
-  return nms_host_impl(keep_out, num_out, nullptr, boxes_host, boxes_num, boxes_dim, thresh, max_keep, device_id);
+  return nms_host_impl(keep_out, num_out, nullptr, boxes_host, boxes_num, boxes_dim, nullptr, 1, thresh, max_keep, device_id);
 }
 
 int mnc_nms_mask(unsigned long long* mask_host, const float* boxes_host, int boxes_num, int boxes_dim, float thresh,
                  int device_id) {
   MNC_REQUIRE(mask_host, "mnc_nms_mask: null output pointer");
-  return nms_host_impl(nullptr, nullptr, mask_host, boxes_host, boxes_num, boxes_dim, thresh, -1, device_id);
+  return nms_host_impl(nullptr, nullptr, mask_host, boxes_host, boxes_num, boxes_dim, nullptr, 1, thresh, -1, device_id);
 }
 
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float thresh,

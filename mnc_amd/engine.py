@@ -265,6 +265,8 @@ class _Layer(object):
         self.act = 0               # 1 relu / 2 sigmoid folded into an InnerProduct
         self.fused_pool = False    # following MAX 2x2/2 folded into this ROIWarping / MaskPooling
         self.out_name = None       # blob written when a fusion redirects the output
+        self.group = None          # [layers] of a merged sibling-InnerProduct GEMM (this layer is the leader)
+        self.group_leader = None   # set on the followers of such a group
         self.run = None
 
 
@@ -395,6 +397,17 @@ class Net(object):
                         if rp.get1("pooled_h") % 2 or rp.get1("pooled_w") % 2:
                             continue
                     L.fused_pool, L.out_name, nxt.skip = True, nxt.tops[0], True
+        # sibling InnerProducts on the same bottom without activation (cls_score / seg_cls_score / bbox_pred,
+        # test.prototxt:713-785) become ONE GEMM over the concatenated weights; their tops are column slices of it
+        by_bottom = {}
+        for L in self._layers:
+            if L.type == "InnerProduct" and not L.relu and L.act == 0 and not L.skip:
+                by_bottom.setdefault(L.bottoms[0], []).append(L)
+        for members in by_bottom.values():
+            if len(members) > 1:
+                members[0].group = members
+                for m in members[1:]:
+                    m.group_leader = members[0]
 
     @staticmethod
     def _is_pool2(L):
@@ -510,7 +523,8 @@ class Net(object):
             top.reshape(*bot.shape)
             if len(bot.shape) == 2:
                 if bot.shape[0]:
-                    _lib.call("mnc_softmax_rows", self._h(), src, top.dev_out("plain"), bot.shape[0], bot.shape[1])
+                    _lib.call("mnc_softmax_rows_ld", self._h(), src, bot._ld(), top.dev_out("plain"), bot.shape[0],
+                              bot.shape[1])
                 else:
                     top.dev_out("plain")
             elif len(bot.shape) == 4 and bot.shape[0] == 1 and bot.shape[1] == 2:
@@ -570,6 +584,12 @@ class Net(object):
         return run
 
     def _bind_InnerProduct(self, L, i):
+        if L.group_leader is not None:                 # computed by the group's leader
+            W, b = self._layer_weights(L)
+            self.params[L.name] = [_Param(W), _Param(b)]
+            return None
+        if L.group is not None:
+            return self._bind_ip_group(L)
         n_out = L.msg.get1("inner_product_param").get1("num_output")
         W, b = self._layer_weights(L)
         self.params[L.name] = [_Param(W), _Param(b)]
@@ -606,6 +626,46 @@ class Net(object):
             dst = top.dev_out("plain")
             if M:
                 _lib.call("mnc_fc", self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+        return run
+
+    def _bind_ip_group(self, L):
+        members = L.group
+        Ws, bs, widths = [], [], []
+        for m in members:
+            W, b = self._layer_weights(m)
+            if m is L:
+                self.params[m.name] = [_Param(W), _Param(b)]
+            Ws.append(W)
+            bs.append(b)
+            widths.append(W.shape[0])
+        K, total = Ws[0].shape[1], sum(widths)
+        key = tuple(p for m in members for p in (m.param_names if m.param_names and all(m.param_names) else [m.name]))
+        d_w = self._dev_param(key + ("w", "group"), lambda: self._upload(np.concatenate(Ws, 0)))
+        d_b = self._dev_param(key + ("b", "group"), lambda: self._upload(np.concatenate(bs, 0)))
+        bot = self.blobs[L.bottoms[0]]
+        parent = Blob(self, "__group_" + L.name)
+        self._hidden = getattr(self, "_hidden", [])
+        self._hidden.append(parent)
+        tops, off = [], 0
+        for m, wd in zip(members, widths):
+            t = self.blobs[m.tops[0]]
+            t._view = (parent, off)
+            tops.append((t, wd))
+            off += wd
+
+        def run():
+            M = bot.shape[0]
+            if int(np.prod(bot.shape[1:])) != K:
+                raise ValueError("InnerProduct group %s: input %r does not flatten to K=%d" % (L.name, bot.shape, K))
+            src = bot.dev_in("plain") if M else 0
+            parent.reshape(M, total)
+            dst = parent.dev_out("plain")
+            for t, wd in tops:
+                t.reshape(M, wd)
+                t.layout = "plain"
+                t._dev_valid, t._host_valid = True, False
+            if M:
+                _lib.call("mnc_fc", self._h(), src, d_w, d_b, dst, M, total, K, total, 0)
         return run
 
     def _bind_Concat(self, L, i):
@@ -727,7 +787,7 @@ class Net(object):
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.h:
             _lib.call("mnc_ctx_sync", self._ctx.h)
-            for b in self.blobs.values():
+            for b in list(self.blobs.values()) + getattr(self, "_hidden", []):
                 b._buf.release()
             self._tmp.release()
             for p in self._dev_params.values():

@@ -6,6 +6,7 @@ different interpolation and is not part of the hot path."""
 import numpy as np
 
 from mnc_config import cfg
+from nms.gpu_nms import gpu_nms_batched
 from nms.nms_wrapper import nms
 from nms.mv import mv
 from utils.cython_bbox import bbox_overlaps
@@ -17,8 +18,16 @@ def build_voting_candidates(boxes, scores, num_classes, max_per_image):
     boxes32 = boxes.astype(np.float32)
     kept = {}
     pool = []
+    if cfg.USE_GPU_NMS and boxes32.shape[0] > 0:
+        # the 20 per-class problems share the box set: one batched device call instead of 20 synchronous ones; only the
+        # first max_per_image survivors of each class are used below, so the scan stops there (identical prefix)
+        per_class = gpu_nms_batched(boxes32, scores[:, 1:num_classes], cfg.TEST.MASK_MERGE_NMS_THRESH,
+                                    device_id=cfg.GPU_ID, max_keep=max_per_image)
+    else:
+        per_class = [nms(np.hstack((boxes32, scores[:, c:c + 1])), cfg.TEST.MASK_MERGE_NMS_THRESH)
+                     for c in range(1, num_classes)]
     for c in range(1, num_classes):
-        order = nms(np.hstack((boxes32, scores[:, c:c + 1])), cfg.TEST.MASK_MERGE_NMS_THRESH)[:max_per_image]
+        order = per_class[c - 1][:max_per_image]
         kept[c] = (boxes[order], scores[order, c])
         pool.extend(kept[c][1])
     if not pool:      # the reference would raise IndexError here (mask_transform.py:244); nothing to vote on
@@ -45,9 +54,49 @@ def build_voting_candidates(boxes, scores, num_classes, max_per_image):
             np.array(out_scores, dtype=np.float32), class_bar)
 
 
+def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
+    """The whole of gpu_mask_voting in one C-ABI call (mnc_mask_voting): batched per-class NMS, candidate sets and the
+    fused voting kernels, with no Python between the steps.  The per-class score orderings are still numpy's
+    `argsort()[::-1]`, so tie order is exactly the reference wrapper's."""
+    import ctypes
+    from mnc_amd import _lib
+    n = boxes.shape[0]
+    S = masks.shape[3]
+    B = num_classes - 1
+    masks = np.ascontiguousarray(masks, dtype=np.float32)
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    order = np.empty((B, n), dtype=np.int32)
+    for c in range(B):
+        order[c] = np.ascontiguousarray(scores[:, c + 1]).argsort()[::-1]
+    cap = B * min(max_per_image, n)
+    out_mask = np.zeros((cap, 1, S, S), dtype=np.float32)
+    out_box = np.zeros((cap, 4), dtype=np.int32)
+    out_score = np.zeros(cap, dtype=np.float32)
+    counts = np.zeros(B, dtype=np.int32)
+    R = ctypes.c_int(0)
+    _lib.call("mnc_mask_voting", _lib.ptr(boxes), _lib.ptr(masks), _lib.ptr(scores), _lib.ptr(order), n, num_classes, S,
+              int(max_per_image), float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH),
+              int(im_height), int(im_width), _lib.ptr(out_mask), _lib.ptr(out_box), _lib.ptr(out_score),
+              _lib.ptr(counts), ctypes.addressof(R), int(cfg.GPU_ID))
+    R = R.value
+    result_box = np.hstack((out_box[:R], out_score[:R, np.newaxis]))       # int32 | float32 -> float64, as the reference
+    list_mask, list_box, lo = [], [], 0
+    for c in range(B):
+        hi = lo + int(counts[c])
+        list_box.append(result_box[lo:hi, :])
+        list_mask.append(out_mask[lo:hi])
+        lo = hi
+    return list_mask, list_box
+
+
 def gpu_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
     """masks [n,1,S,S], boxes [n,4], scores [n,num_classes] -> (list_result_mask, list_result_box), one entry per
     foreground class; boxes rows are [x1, y1, x2, y2, score]."""
+    if (cfg.USE_GPU_NMS and boxes.dtype == np.float32 and scores.dtype == np.float32 and boxes.shape[0] > 0
+            and boxes.shape[1] == 4 and masks.shape[2] == masks.shape[3]):
+        return _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height)
+    # generic path (float64 boxes, CPU NMS, ...): the reference's step-by-step composition
     inds, ends, weights, out_scores, class_bar = build_voting_candidates(boxes, scores, num_classes, max_per_image)
     result_mask, result_box = mv(boxes.astype(np.float32), masks, inds, ends, weights, im_height, im_width,
                                  device_id=cfg.GPU_ID)

@@ -170,6 +170,11 @@ class Fake(object):
     def mnc_softmax_rows(self, h, src, dst, M, N):
         _f(dst, (M, N))[...] = F.softmax(_t(_f(src, (M, N))), dim=1).numpy()
 
+    def mnc_softmax_rows_ld(self, h, src, ld, dst, M, N):
+        full = _f(src, ((M - 1) * ld + N,))
+        rows = np.stack([full[m * ld: m * ld + N] for m in range(M)])
+        _f(dst, (M, N))[...] = F.softmax(_t(rows), dim=1).numpy()
+
     def mnc_eltwise(self, h, src, dst, n, op):
         _f(dst, (n,))[...] = _act(_t(_f(src, (n,)).copy()), op).numpy()
 
@@ -194,6 +199,32 @@ class Fake(object):
 
     def mnc_nms_topk(self, keep, num, boxes, n, dim, thr, max_keep, dev):
         self._nms(keep, num, boxes, n, dim, thr, max_keep)
+
+    def mnc_nms_batched(self, keep, num, boxes, n, dim, order, batch, thr, max_keep, dev):
+        bx, od = _f(boxes, (n, dim)), _i(order, (batch, n))
+        kp, nm = _i(keep, (batch, n)), _i(num, (batch,))
+        for b in range(batch):
+            k = native.nms_sorted(np.ascontiguousarray(bx[od[b]]), thr)
+            if max_keep >= 0:
+                k = k[:max_keep]
+            kp[b, :len(k)] = k
+            nm[b] = len(k)
+
+    def mnc_mask_voting(self, boxes, masks, scores, order, n, K, S, max_per_image, nms_thr, iou_thr, H, W, omask, obox,
+                        oscore, counts, rnum, dev):
+        # test double: the oracle's step-by-step restatement of the reference (thresholds are its module constants)
+        from oracle import host as ohost
+        assert abs(nms_thr - ohost.MASK_MERGE_NMS_THRESH) < 1e-6 and abs(iou_thr - ohost.MASK_MERGE_IOU_THRESH) < 1e-6
+        lm, lb = ohost.gpu_mask_voting(_f(masks, (n, 1, S, S)), _f(boxes, (n, 4)), _f(scores, (n, K)), K, max_per_image,
+                                       W, H)
+        R = sum(len(b) for b in lb)
+        ctypes.c_int.from_address(int(rnum)).value = R
+        _i(counts, (K - 1,))[...] = [len(b) for b in lb]
+        if R:
+            allb = np.concatenate(lb, 0)
+            _i(obox, (R, 4))[...] = allb[:, :4].astype(np.int32)
+            _f(oscore, (R,))[...] = allb[:, 4].astype(np.float32)
+            _f(omask, (R, 1, S, S))[...] = np.concatenate(lm, 0)
 
     def mnc_mv(self, boxes, masks, nb, inds, start, wts, nc, H, W, bd, S, R, omask, obox, dev):
         m, b = native.mv(_f(boxes, (nb, bd)), _f(masks, (nb, 1, S, S)), _i(inds, (nc,)) if nc else np.zeros(0, np.int32),

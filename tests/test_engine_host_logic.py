@@ -74,6 +74,8 @@ def test_fusion_plan(fake_gpu):
     assert not L["roi_interpolate_conv5_box"].skip                  # its bottom is shared with other consumers
     assert net.blobs["fc7"]._view is not None and net.blobs["fc7_mask"]._view[1] == 0 and net.blobs["fc7"]._view[1] == 512
     assert net.outputs == ["cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"]
+    assert [m.name for m in L["cls_score"].group] == ["cls_score", "seg_cls_score", "bbox_pred"]
+    assert L["bbox_pred"].group_leader is L["cls_score"] and net.blobs["bbox_pred"]._view[1] == 42
     net.close()
 
 

@@ -66,6 +66,26 @@ def test_nms_topk_prefix_and_edges():
     assert np.array_equal(keep[:num.value], native.nms_sorted(dets[:600], 0.7))
 
 
+def test_nms_batched_equals_per_class_calls():
+    """mnc_nms_batched (one launch pair for all classes) == 20 independent gpu_nms calls == oracle, incl. max_keep."""
+    from nms.gpu_nms import gpu_nms, gpu_nms_batched
+    vc = GI.voting_case(600, 600, 1000, 21)
+    boxes, scores = vc["boxes"], vc["scores"]
+    full = gpu_nms_batched(boxes, scores[:, 1:], 0.3, 0)
+    top = gpu_nms_batched(boxes, scores[:, 1:], 0.3, 0, max_keep=100)
+    for c in range(1, 21):
+        dets = np.hstack((boxes, scores[:, c:c + 1]))
+        want = native.gpu_nms(dets, 0.3)
+        assert full[c - 1] == want == gpu_nms(dets, 0.3, 0)
+        assert top[c - 1] == want[:100]
+    big = GI.nms_case(6000, 55)
+    sc = np.stack([big[:, 4], big[::-1, 4].copy(), np.roll(big[:, 4], 17)], 1)
+    got = gpu_nms_batched(big[:, :4], sc, 0.7, 0, max_keep=300)
+    for b in range(3):
+        assert got[b] == native.gpu_nms(np.hstack((big[:, :4], sc[:, b:b + 1])), 0.7)[:300]
+    assert gpu_nms_batched(np.zeros((0, 4), np.float32), np.zeros((0, 3), np.float32), 0.3) == [[], [], []]
+
+
 def test_nms_large_n_host_scan_path():
     dets, _ = _sorted(GI.nms_case(33000, 42))                 # > 32768: bitmask to host + host scan (reference layout)
     keep = np.zeros(33000, np.int32)
@@ -100,6 +120,26 @@ def test_gpu_mask_voting_vs_reference_fixture(golden, tag):
     assert np.array_equal(np.array([len(b) for b in lb]), golden["vote_%s_count" % tag])
     assert np.array_equal(np.concatenate(lb, 0), golden["vote_%s_box" % tag])
     assert np.array_equal(np.concatenate(lm, 0), golden["vote_%s_mask" % tag])
+
+
+def test_fused_voting_equals_step_by_step_composition():
+    """mnc_mask_voting (fused) == the reference's composition of nms x20 + bbox_overlaps + mv, on the product's own
+    modular path and on the oracle, at BASELINE's 600 instances / 600x1000 canvas and on float64 boxes (generic path)."""
+    from mnc_config import cfg
+    from transform import mask_transform as mt
+    vc = GI.voting_case(600, 600, 1000, 23)
+    fused = mt.gpu_mask_voting(vc["masks"], vc["boxes"], vc["scores"], 21, 100, 1000, 600)
+    generic = mt.gpu_mask_voting(vc["masks"], vc["boxes"].astype(np.float64), vc["scores"], 21, 100, 1000, 600)
+    from oracle import host as ohost
+    want = ohost.gpu_mask_voting(vc["masks"], vc["boxes"], vc["scores"], 21, 100, 1000, 600)
+    for got in (fused, generic):
+        assert [len(b) for b in got[1]] == [len(b) for b in want[1]]
+        assert np.array_equal(np.concatenate(got[1], 0), np.concatenate(want[1], 0))
+        assert np.array_equal(np.concatenate(got[0], 0), np.concatenate(want[0], 0))
+    assert fused[1][0].dtype == np.float64
+    small = mt.gpu_mask_voting(vc["masks"][:3], vc["boxes"][:3], vc["scores"][:3], 21, 100, 1000, 600)
+    osmall = ohost.gpu_mask_voting(vc["masks"][:3], vc["boxes"][:3], vc["scores"][:3], 21, 100, 1000, 600)
+    assert np.array_equal(np.concatenate(small[1], 0), np.concatenate(osmall[1], 0))
 
 
 def test_mv_many_candidates_and_properties():

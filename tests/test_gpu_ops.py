@@ -237,6 +237,9 @@ def test_softmax_rows_and_eltwise(dev):
     d_o = dev.empty((x.size,))
     dev.call("mnc_softmax_rows", dev.put(x), d_o, 300, 21)
     assert err(dev.get(d_o, x.shape), F.softmax(torch.from_numpy(x), dim=1).numpy())[0] < 1e-6
+    wide = np.random.default_rng(11).normal(size=(300, 126)).astype(np.float32)
+    dev.call("mnc_softmax_rows_ld", dev.put(wide) + 21 * 4, 126, d_o, 300, 21)
+    assert err(dev.get(d_o, x.shape), F.softmax(torch.from_numpy(wide[:, 21:42].copy()), dim=1).numpy())[0] < 1e-6
     dev.call("mnc_eltwise", dev.put(x), d_o, x.size, 2)
     assert err(dev.get(d_o, x.shape), torch.sigmoid(torch.from_numpy(x)).numpy())[0] < 1e-6
     dev.call("mnc_eltwise", dev.put(x), d_o, x.size, 1)
