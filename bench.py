@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
     return p.parse_args()
 
 
@@ -55,8 +57,9 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     import _init_paths  # noqa: F401
     import caffe
@@ -65,9 +68,11 @@ def main():
     from mnc_config import cfg
     from transform.mask_transform import gpu_mask_voting
 
+    from mnc_amd import _lib
+    dev_id = local % max(_lib.device_count(), 1) if args.dist_backend != "nccl" else local
     caffe.set_mode_gpu()
-    caffe.set_device(local)
-    cfg.GPU_ID = local
+    caffe.set_device(dev_id)
+    cfg.GPU_ID = dev_id
     proto = models.write_mnc_5stage_test_prototxt()
     weights = synth.synthetic_weights(proto, seed=0)
     net = caffe.Net(proto, weights, caffe.TEST)
@@ -82,7 +87,8 @@ def main():
     from transform.bbox_transform import clip_boxes
 
     from mnc_amd import dist as mdist
-    gatherer = mdist.InstanceGatherer(device="cuda") if world > 1 else None
+    on_gpu = args.dist_backend == "nccl"
+    gatherer = mdist.InstanceGatherer(device="cuda" if on_gpu else None) if world > 1 else None
 
     phase_ms = {"forward": 0.0, "tail": 0.0, "voting": 0.0, "gather": 0.0}
 
@@ -111,16 +117,18 @@ def main():
     def fence():
         net.sync()
         if world > 1:
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     events = not args.no_events
     fence()
     if events:
-        net.profile(True)
+        net.profile(1 if args.all_events else 2)
     for k in phase_ms:
         phase_ms[k] = 0.0
     t0 = time.perf_counter()
@@ -132,7 +140,7 @@ def main():
     if events:
         net.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

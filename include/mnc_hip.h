@@ -128,7 +128,8 @@ MNC_API int mnc_d2d(mnc_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 MNC_API int mnc_dev_zero(mnc_ctx* ctx, void* d_ptr, size_t bytes);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's `roofline` numbers come from here).
- * enable=1 records a start/stop event pair around every kernel launched through the context. */
+ * enable=1 records a start/stop event pair around every kernel launched through the context; enable=2 only around the
+ * launches that carry >= 1 GFLOP of algorithmic work (the MFMA kernels), which keeps the timed region almost undisturbed. */
 MNC_API int mnc_prof_enable(mnc_ctx* ctx, int enable);
 MNC_API int mnc_prof_reset(mnc_ctx* ctx);
 MNC_API int mnc_prof_count(mnc_ctx* ctx, int* n_records);                 /* synchronises the stream */
@@ -193,6 +194,27 @@ MNC_API int mnc_softmax_rows_ld(mnc_ctx* ctx, const float* d_in, int ld_in, floa
 MNC_API int mnc_eltwise(mnc_ctx* ctx, const float* d_in, float* d_out, size_t count, int op);
 /* Strided 2-D device copy of float rows (Concat, test.prototxt:700-709, when the producers could not write in place). */
 MNC_API int mnc_copy2d(mnc_ctx* ctx, float* d_dst, int dst_ld, const float* d_src, int src_ld, int rows, int cols);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Device-resident forms of the three inference-time Python layers (the Python classes in mnc_amd/lib/pylayer remain the
+ * API and the path for user-defined layers; the engine substitutes these for the stock classes).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* ProposalLayer.forward (lib/pylayer/proposal_layer.py:52-175): d_cls_prob [2A][H][W], d_bbox_pred [4A][H][W] (NCHW,
+ * batch 1), anchors_host [A][4] (transform.anchors.generate_anchors as float32), im_info = (im_h, im_w, im_scale).
+ * Writes d_rois [post_nms_topn][5] (rows >= *num_rois_host are zero) and returns the row count (one 4-byte D2H + sync).
+ * Candidate order is score descending, anchor index ascending (the reference leaves tie order to numpy's sort). */
+MNC_API int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred, int A, int H, int W,
+                         const float* anchors_host, int feat_stride, float im_h, float im_w, float im_scale,
+                         int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* d_rois,
+                         int* num_rois_host);
+/* The sorted pre-NMS candidates of the last mnc_proposal on this context (parity tests teacher-force the NMS with them):
+ * boxes_host [n][4], scores_host [n], *n_host = n.  Pass null arrays to query n only. */
+MNC_API int mnc_proposal_candidates(mnc_ctx* ctx, float* boxes_host, float* scores_host, int capacity, int* n_host);
+/* StageBridgeLayer.forward_test (lib/pylayer/stage_bridge_layer.py:237-255): per RoI the box regressor of the arg-max
+ * class of d_probs (first maximum, background included) is applied and clipped to (im_h, im_w).  d_bbox_pred / d_probs
+ * may be column slices (row strides ld_bbox / ld_probs). */
+MNC_API int mnc_stage_bridge(mnc_ctx* ctx, const float* d_rois, const float* d_bbox_pred, int ld_bbox, const float* d_probs,
+                             int ld_probs, int R, int K, float im_h, float im_w, float* d_rois_ext);
 
 #ifdef __cplusplus
 }

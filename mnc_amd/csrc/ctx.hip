@@ -107,6 +107,7 @@ int mnc_ctx_destroy(mnc_ctx* ctx) {
   }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->proposal) mnc::proposal_state_free(ctx->proposal);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   clear_error();
@@ -180,7 +181,7 @@ int mnc_dev_zero(mnc_ctx* ctx, void* d_ptr, size_t bytes) {
 
 int mnc_prof_enable(mnc_ctx* ctx, int enable) {
   MNC_REQUIRE(ctx, "mnc_prof_enable: null context");
-  ctx->profiling = enable != 0;
+  ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
   return MNC_OK;
 }
 

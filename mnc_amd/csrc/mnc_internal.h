@@ -27,12 +27,13 @@ struct ProfRecord {
 struct mnc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  bool profiling = false;
+  int profiling = 0;   // 0 off, 1 every launch, 2 only launches with >= 1 GFLOP of algorithmic work (the MFMA kernels)
   std::vector<mnc::ProfRecord> prof;
   std::vector<hipEvent_t> event_pool;
   // split-K scratch for mnc_fc and friends; grown on demand, never shrunk
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  void* proposal = nullptr;   // mnc_proposal_state (proposal.hip), created on first use
 };
 
 namespace mnc {
@@ -62,11 +63,13 @@ void prof_end(mnc_ctx* ctx);
 // turns a failed launch into MNC_ERR_HIP.
 struct LaunchScope {
   mnc_ctx* ctx;
+  bool on;
   LaunchScope(mnc_ctx* c, const char* name, double flops = 0.0, double bytes = 0.0) : ctx(c) {
-    if (ctx->profiling) prof_begin(ctx, name, flops, bytes);
+    on = ctx->profiling == 1 || (ctx->profiling == 2 && flops >= 1.0e9);
+    if (on) prof_begin(ctx, name, flops, bytes);
   }
   int finish(const char* name) {
-    if (ctx->profiling) prof_end(ctx);
+    if (on) prof_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       set_error("kernel launch %s failed: %s", name, hipGetErrorString(e));
@@ -93,6 +96,12 @@ int nms_mask_launch(hipStream_t stream, const float* d_boxes, const int* d_order
                     unsigned long long* d_mask, int batch);
 int nms_scan_launch(hipStream_t stream, const unsigned long long* d_mask, int n, int max_keep, int* d_keep, int* d_num,
                     int batch);
+// same, with the box count read from device memory (*d_n <= n_cap); buffers are sized for n_cap
+int nms_mask_launch_indirect(hipStream_t stream, const float* d_boxes, const int* d_order, const int* d_n, int n_cap,
+                             int dim, float thr, unsigned long long* d_mask);
+int nms_scan_launch_indirect(hipStream_t stream, const unsigned long long* d_mask, const int* d_n, int n_cap, int max_keep,
+                             int* d_keep, int* d_num);
+void proposal_state_free(void* state);  // proposal.hip
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
               const int* d_starts, const float* d_wts, int H, int W, int R, int* d_bounds, float* d_out_mask,
               int* d_out_box);

@@ -39,15 +39,21 @@ constexpr int kWavesPerBlock = 4;
 //
 // grid: (ceil(cb / 4), cb, batch); block: 256.  Item z of the batch uses boxes[order[z*n + i]] as its i-th (sorted)
 // box, or boxes[i] when order == nullptr.  mask + z * cb * n is its bitmask.
+// n = *n_ptr when n_ptr != nullptr (device-side count, <= n_stride), else n_arg.  n_stride / cb_cap are the strides the
+// buffers were sized with (== n / ceil(n/64) in the direct case).
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ order,
-                                                       int n, int dim, float thr, u64* __restrict__ mask, int cb) {
+                                                       int n_arg, const int* __restrict__ n_ptr, int n_stride, int dim,
+                                                       float thr, u64* __restrict__ mask, int cb_cap) {
+  const int n = n_ptr ? *n_ptr : n_arg;
+  const int cb = (n + 63) >> 6;
   const int rt = blockIdx.y;
+  if (rt >= cb) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ct = blockIdx.x * kWavesPerBlock + wave;
   __shared__ float rowbox[64][4];
   if (blockIdx.x * kWavesPerBlock + kWavesPerBlock - 1 < rt) return;  // whole block below the diagonal
-  const int* ord = order ? order + (long)blockIdx.z * n : nullptr;
-  u64* m = mask + (long)blockIdx.z * cb * n;
+  const int* ord = order ? order + (long)blockIdx.z * n_stride : nullptr;
+  u64* m = mask + (long)blockIdx.z * cb_cap * n_stride;
   if (threadIdx.x < 64) {
     const int r = rt * 64 + threadIdx.x;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
     const u64 word = __ballot(hit);
     if (lane == i) mine = word;
   }
-  if (lane < rows) m[(long)ct * n + rt * 64 + lane] = mine;
+  if (lane < rows) m[(long)ct * n_stride + rt * 64 + lane] = mine;
 }
 
 constexpr int kMaxScanBlocks = 512;  // device scan handles cb <= 512, i.e. n <= 32768
@@ -125,15 +131,18 @@ struct Resolve<I0, 1> {
 //      wave-wide OR reduction -- one load latency per block, not one per survivor;
 //   2. the intra-block chain runs on the scalar unit: v_readlane of the 64 diagonal words, 64 unrolled steps;
 //   3. survivors write their indices with one compacting vector store (prefix popcount).
-__global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, int n, int cb, int max_keep,
-                                                      int* __restrict__ keep, int* __restrict__ num_out) {
+__global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, int n_arg, const int* __restrict__ n_ptr,
+                                                      int n_stride, int cb_cap, int max_keep, int* __restrict__ keep,
+                                                      int* __restrict__ num_out) {
   __shared__ u64 s_kept[kMaxScanBlocks];
   const int lane = threadIdx.x;
-  const u64* m = mask + (long)blockIdx.x * cb * n;
-  int* kp = keep + (long)blockIdx.x * n;
+  const int n = n_ptr ? *n_ptr : n_arg;
+  const int cb = (n + 63) >> 6;
+  const u64* m = mask + (long)blockIdx.x * cb_cap * n_stride;
+  int* kp = keep + (long)blockIdx.x * n_stride;
   int nk = 0;
   for (int blk = 0; blk < cb && nk < max_keep; ++blk) {
-    const u64* col = m + (long)blk * n;
+    const u64* col = m + (long)blk * n_stride;
     u64 acc = 0;
     for (int bb = 0; bb < blk; ++bb)
       if ((s_kept[bb] >> lane) & 1ull) acc |= col[bb * 64 + lane];
@@ -158,13 +167,30 @@ int nms_mask_launch(hipStream_t stream, const float* d_boxes, const int* d_order
                     int batch) {
   const int cb = cdiv(n, 64);
   dim3 grid(cdiv(cb, kWavesPerBlock), cb, batch);
-  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(256), 0, stream, d_boxes, d_order, n, dim, thr, d_mask, cb);
+  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(256), 0, stream, d_boxes, d_order, n, (const int*)nullptr, n, dim, thr,
+                     d_mask, cb);
+  return MNC_OK;
+}
+
+int nms_mask_launch_indirect(hipStream_t stream, const float* d_boxes, const int* d_order, const int* d_n, int n_cap,
+                             int dim, float thr, u64* d_mask) {
+  const int cb = cdiv(n_cap, 64);
+  dim3 grid(cdiv(cb, kWavesPerBlock), cb, 1);
+  hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(256), 0, stream, d_boxes, d_order, 0, d_n, n_cap, dim, thr, d_mask, cb);
   return MNC_OK;
 }
 
 int nms_scan_launch(hipStream_t stream, const u64* d_mask, int n, int max_keep, int* d_keep, int* d_num, int batch) {
   const int cb = cdiv(n, 64);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, stream, d_mask, n, cb, max_keep, d_keep, d_num);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, stream, d_mask, n, (const int*)nullptr, n, cb, max_keep,
+                     d_keep, d_num);
+  return MNC_OK;
+}
+
+int nms_scan_launch_indirect(hipStream_t stream, const u64* d_mask, const int* d_n, int n_cap, int max_keep, int* d_keep,
+                             int* d_num) {
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, d_mask, 0, d_n, n_cap, cdiv(n_cap, 64), max_keep, d_keep,
+                     d_num);
   return MNC_OK;
 }
 

@@ -271,7 +271,7 @@ class _Layer(object):
 
 
 class Net(object):
-    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None):
+    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None):
         if device_id is None:
             try:
                 import caffe
@@ -286,6 +286,10 @@ class Net(object):
         if self.phase != "TEST":
             raise NotImplementedError("only caffe.TEST graphs are executed")
         self._fuse = (os.environ.get("MNC_NO_FUSE", "0") != "1") if fuse is None else bool(fuse)
+        # the three stock inference-time Python layers have device-resident equivalents (csrc/proposal.hip); any other
+        # `type: 'Python'` layer -- or all of them with native_pylayers=False / MNC_NATIVE_PYLAYERS=0 -- runs as Python
+        self._native_py = ((os.environ.get("MNC_NATIVE_PYLAYERS", "1") != "0") if native_pylayers is None
+                           else bool(native_pylayers))
         self._ctx = _Ctx(device_id)
         self._tmp = _DevBuf(self._ctx)
         self._net_msg = prototxt.parse_file(prototxt_path)
@@ -731,6 +735,10 @@ class Net(object):
         tops = [self.blobs[t] for t in L.tops]
         self._py[L.name] = layer
         done = {}
+        if self._native_py:
+            native = self._native_pylayer(pp.get1("module"), pp.get1("layer"), layer, bots, tops)
+            if native is not None:
+                return native
 
         def run():
             ro = [_ReadOnlyBlob(b) for b in bots]
@@ -744,6 +752,73 @@ class Net(object):
             for t in tops:
                 t._host_valid, t._dev_valid = True, False
         return run
+
+    def _native_pylayer(self, module, cls, layer, bots, tops):
+        """Device-resident replacement for a stock Python layer, or None."""
+        from mnc_config import cfg
+        if (module, cls) == ("pylayer.mask_layer", "MaskLayer"):
+            bot, top = bots[0], tops[0]
+
+            def run_mask():                       # MaskLayer.forward_test: a reshape (mask_layer.py:95-102)
+                R = bot.shape[0]
+                src = bot.dev_in("plain")
+                top.reshape(R, 1, cfg.MASK_SIZE, cfg.MASK_SIZE)
+                dst = top.dev_out("plain")
+                if R:
+                    if bot._view is not None:
+                        _lib.call("mnc_copy2d", self._h(), dst, bot.shape[1], src, bot._ld(), R, bot.shape[1])
+                    else:
+                        _lib.call("mnc_d2d", self._h(), dst, src, bot.count * 4)
+            return run_mask
+        if (module, cls) == ("pylayer.stage_bridge_layer", "StageBridgeLayer"):
+            rois, bbox, probs, info = bots
+            top = tops[0]
+
+            def run_bridge():
+                R, K = probs.shape[0], probs.shape[1]
+                im = info._host_read()[0]
+                d_rois, d_bbox, d_probs = rois.dev_in("plain"), bbox.dev_in("plain"), probs.dev_in("plain")
+                top.reshape(R, 5)
+                _lib.call("mnc_stage_bridge", self._h(), d_rois, d_bbox, bbox._ld(), d_probs, probs._ld(), R, K,
+                          float(im[0]), float(im[1]), top.dev_out("plain"))
+            return run_bridge
+        if (module, cls) == ("pylayer.proposal_layer", "ProposalLayer"):
+            import yaml
+            from transform.anchors import generate_anchors
+            prob, bbox, info = bots
+            top = tops[0]
+            params = yaml.safe_load(layer.param_str_) or {}
+            stride = int(params["feat_stride"])
+            anchors = np.ascontiguousarray(generate_anchors(), dtype=F32)
+            A = anchors.shape[0]
+            num = ctypes.c_int(0)
+
+            def run_proposal():
+                c = cfg[self.phase]
+                post = int(c.RPN_POST_NMS_TOP_N)
+                if post <= 0:
+                    raise NotImplementedError("native ProposalLayer needs RPN_POST_NMS_TOP_N > 0")
+                _, _, H, W = prob.shape
+                im = info._host_read()[0]
+                d_prob, d_bbox = prob.dev_in("plain"), bbox.dev_in("plain")
+                top.reshape(post, 5)
+                dst = top.dev_out("plain")
+                _lib.call("mnc_proposal", self._h(), d_prob, d_bbox, A, H, W, _lib.ptr(anchors), stride, float(im[0]),
+                          float(im[1]), float(im[2]), int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
+                          float(c.RPN_MIN_SIZE), dst, ctypes.addressof(num))
+                top.shape = (num.value, 5)          # same buffer, R <= post rows are valid
+                top._host, top._host_valid, top._dev_valid = None, False, True
+            return run_proposal
+        return None
+
+    def proposal_candidates(self):
+        """(boxes [n,4], scores [n]) -- the sorted pre-NMS candidates of the last native ProposalLayer run (tests)."""
+        n = ctypes.c_int(0)
+        _lib.call("mnc_proposal_candidates", self._h(), None, None, 0, ctypes.addressof(n))
+        boxes, scores = np.zeros((n.value, 4), F32), np.zeros(n.value, F32)
+        if n.value:
+            _lib.call("mnc_proposal_candidates", self._h(), _lib.ptr(boxes), _lib.ptr(scores), n.value, ctypes.addressof(n))
+        return boxes, scores
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, **kwargs):
@@ -764,7 +839,8 @@ class Net(object):
 
     # ------------------------------------------------------------------------------------------------ profiling
     def profile(self, enable=True):
-        _lib.call("mnc_prof_enable", self._ctx.h, 1 if enable else 0)
+        """enable: False/0 off, True/1 every launch, 2 only the MFMA (>= 1 GFLOP) launches."""
+        _lib.call("mnc_prof_enable", self._ctx.h, int(enable))
         _lib.call("mnc_prof_reset", self._ctx.h)
 
     def profile_records(self):

@@ -1,6 +1,7 @@
 """`nms.gpu_nms.gpu_nms` -- same call as the reference's Cython wrapper (lib/nms/gpu_nms.pyx:16-31) over the HIP
-kernel behind mnc_nms (mnc_amd/csrc/nms.hip).  The score sort stays on the host exactly as in the reference
-(`argsort()[::-1]`), so tie order is whatever numpy gives there too."""
+kernel behind mnc_nms (mnc_amd/csrc/nms.hip).  The score sort stays on the host as in the reference; where the
+reference's `argsort()[::-1]` leaves the order of EQUAL scores to numpy's unstable sort, this wrapper defines it (score
+descending, index ascending) so that every path of this package -- host or device -- agrees.  Distinct scores: identical."""
 import ctypes
 
 import numpy as np
@@ -15,7 +16,7 @@ def gpu_nms(dets, thresh, device_id=0, max_keep=-1):
     n, dim = dets.shape
     if n == 0:
         return []
-    order = dets[:, 4].argsort()[::-1]
+    order = np.argsort(-dets[:, 4], kind="stable")      # score descending, ties by ascending index (see module doc)
     sorted_dets = np.ascontiguousarray(dets[order, :])
     keep = np.zeros(n, dtype=np.int32)
     num = ctypes.c_int(0)
@@ -41,7 +42,7 @@ def gpu_nms_batched(boxes, scores, thresh, device_id=0, max_keep=-1):
         return [[] for _ in range(batch)]
     orders = np.empty((batch, n), dtype=np.int32)
     for b in range(batch):
-        orders[b] = np.ascontiguousarray(scores[:, b]).argsort()[::-1]
+        orders[b] = np.argsort(-scores[:, b], kind="stable")
     keep = np.zeros((batch, n), dtype=np.int32)
     num = np.zeros(batch, dtype=np.int32)
     _lib.call("mnc_nms_batched", _lib.ptr(keep), _lib.ptr(num), _lib.ptr(boxes), n, boxes.shape[1], _lib.ptr(orders),

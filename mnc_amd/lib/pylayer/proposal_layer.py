@@ -52,7 +52,7 @@ class ProposalLayer(caffe.Layer):
         big = filter_small_boxes(proposals, min_size * im_info[2])
         proposals, scores = proposals[big, :], scores[big]
 
-        order = scores.ravel().argsort()[::-1]
+        order = np.argsort(-scores.ravel(), kind="stable")     # score descending, ties by ascending index
         if pre_n > 0:
             order = order[:pre_n]
         proposals, scores = proposals[order, :], scores[order]

@@ -68,7 +68,7 @@ def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_widt
     scores = np.ascontiguousarray(scores, dtype=np.float32)
     order = np.empty((B, n), dtype=np.int32)
     for c in range(B):
-        order[c] = np.ascontiguousarray(scores[:, c + 1]).argsort()[::-1]
+        order[c] = np.argsort(-scores[:, c + 1], kind="stable")
     cap = B * min(max_per_image, n)
     out_mask = np.zeros((cap, 1, S, S), dtype=np.float32)
     out_box = np.zeros((cap, 4), dtype=np.int32)

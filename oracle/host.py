@@ -117,7 +117,10 @@ def proposal_candidates(rpn_cls_prob, rpn_bbox_pred, im_info, feat_stride=16):
     proposals, _ = clip_boxes(proposals, im_info[:2])
     keep = filter_small_boxes(proposals, RPN_MIN_SIZE * im_info[2])
     proposals, scores = proposals[keep, :], scores[keep]
-    order = scores.ravel().argsort()[::-1]
+    # reference: scores.ravel().argsort()[::-1] -- numpy's default sort is unstable, so the order of EQUAL scores is
+    # unspecified there.  The oracle pins it: score descending, index ascending.  Identical to the
+    # reference whenever the scores are distinct (all committed fixtures are).
+    order = np.argsort(-scores.ravel(), kind="stable")
     order = order[:RPN_PRE_NMS_TOP_N]
     return proposals[order, :], scores[order]
 

@@ -90,9 +90,10 @@ def nms_mask(boxes_sorted, thresh):
 
 
 def gpu_nms(dets, thresh):
-    """Restates lib/nms/gpu_nms.pyx:16-31 on top of orc_nms."""
+    """Restates lib/nms/gpu_nms.pyx:16-31 on top of orc_nms.  Tie order pinned (score desc, index asc) where the
+    reference's `argsort()[::-1]` leaves it unspecified; identical for distinct scores."""
     dets = _c(dets, np.float32)
-    order = dets[:, 4].argsort()[::-1]
+    order = np.argsort(-dets[:, 4], kind="stable")
     keep = nms_sorted(dets[order, :], thresh)
     return [int(i) for i in order[keep]]
 

@@ -183,6 +183,33 @@ class Fake(object):
         for r in range(rows):
             d[r * dld:r * dld + cols] = s[r * sld:r * sld + cols]
 
+    # ---- device-resident python layers ----
+    def mnc_proposal(self, h, prob, bbox, A, H, W, anchors, stride, im_h, im_w, im_scale, pre, post, thr, min_size, rois,
+                     num):
+        from oracle import host as ohost
+        im_info = np.array([[im_h, im_w, im_scale]], np.float32)
+        props, scores = ohost.proposal_candidates(_f(prob, (1, 2 * A, H, W)), _f(bbox, (1, 4 * A, H, W)), im_info, stride)
+        self._cand = (props.copy(), scores.ravel().copy())
+        keep = native.nms_sorted(np.hstack((props, scores)), thr)[:post] if len(props) else []
+        out = _f(rois, (post, 5))
+        out[...] = 0
+        out[:len(keep), 1:] = props[keep]
+        ctypes.c_int.from_address(int(num)).value = len(keep)
+
+    def mnc_proposal_candidates(self, h, boxes, scores, cap, n):
+        b, s = self._cand
+        ctypes.c_int.from_address(int(n)).value = len(b)
+        if boxes:
+            _f(boxes, b.shape)[...] = b
+            _f(scores, s.shape)[...] = s
+
+    def mnc_stage_bridge(self, h, rois, bbox, ldb, probs, ldp, R, K, im_h, im_w, out):
+        from oracle import host as ohost
+        fb, fp = _f(bbox, ((R - 1) * ldb + 4 * K,)), _f(probs, ((R - 1) * ldp + K,))
+        bb = np.stack([fb[r * ldb: r * ldb + 4 * K] for r in range(R)])
+        pp = np.stack([fp[r * ldp: r * ldp + K] for r in range(R)])
+        _f(out, (R, 5))[...] = ohost.stage_bridge_forward_test(_f(rois, (R, 5)), bb, pp, np.array([[im_h, im_w, 1]], np.float32))
+
     # ---- b1 / b2 / b3 on host pointers ----
     def _nms(self, keep, num, boxes, n, dim, thr, max_keep):
         if n == 0:

@@ -12,6 +12,7 @@ import mnc_amd
 from gpu_util import err
 from mnc_amd import models, synth
 from oracle import host as ohost
+from oracle import native as onative
 from oracle import net as onet
 
 pytestmark = pytest.mark.gpu
@@ -58,7 +59,8 @@ def check_forward(net, w, data, im_info, extra=()):
     right.  So each hop is teacher-forced, which is also how north_star words the bar ("bit-exact NMS keep indices" on
     the same inputs, 1e-3 on the float outputs):
       1. trunk + RPN blobs             device vs oracle from the same input                       (tolerance)
-      2. rois                          device == oracle ProposalLayer fed the DEVICE's RPN blobs   (bit-exact)
+      2. rois                          device == oracle ProposalLayer fed the DEVICE's RPN blobs   (bit-exact; with the
+                                       device-resident layer: candidates vs oracle to 1e-3, NMS keep bit-exact)
       3. stage 2/3 blobs               device vs oracle head fed the device's rois                 (tolerance)
       4. rois_ext                      device == oracle StageBridge fed the device's blobs         (bit-exact)
       5. stage 4/5 blobs               device vs oracle head fed the device's rois_ext             (tolerance)"""
@@ -68,13 +70,27 @@ def check_forward(net, w, data, im_info, extra=()):
     _compare(net, ref, TRUNK_BLOBS)
     g = lambda n: net.blobs[n]._host_read()
     rois = g("rois")
-    want_rois = ohost.proposal_forward(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
-    assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
+    if net._native_py:
+        # device-resident ProposalLayer: decoded candidates vs the oracle's (expf vs numpy exp: last-ulp differences
+        # allowed on the boxes, the score order must be identical), then the NMS teacher-forced on the device's candidates
+        cb, cs = net.proposal_candidates()
+        ob, osc = ohost.proposal_candidates(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
+        assert cb.shape == ob.shape and np.array_equal(cs, osc.ravel())
+        assert err(cb, ob)[0] < 1e-3
+        keep = onative.nms_sorted(np.hstack((cb, cs[:, None])), 0.7)[:300]
+        assert rois.shape == (len(keep), 5) and np.array_equal(rois[:, 1:], cb[keep]) and not rois[:, 0].any()
+    else:
+        want_rois = ohost.proposal_forward(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
+        assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
     h1 = {}
     onet.head(w, c5, rois, False, "", h1)
     _compare(net, h1, [b for b in HEAD_BLOBS + list(extra) if b in h1])
     rois_ext = g("rois_ext")
-    assert np.array_equal(rois_ext, ohost.stage_bridge_forward_test(rois, g("bbox_pred"), g("seg_cls_prob"), im_info))
+    want_ext = ohost.stage_bridge_forward_test(rois, g("bbox_pred"), g("seg_cls_prob"), im_info)
+    if net._native_py:
+        assert rois_ext.shape == want_ext.shape and err(rois_ext, want_ext)[0] < 1e-3     # expf vs numpy exp
+    else:
+        assert np.array_equal(rois_ext, want_ext)
     h2 = {}
     onet.head(w, c5, rois_ext, True, "_ext", h2)
     _compare(net, h2, [b + "_ext" for b in HEAD_BLOBS + list(extra) if b + "_ext" in h2])
@@ -102,6 +118,31 @@ def test_reduced_net_blobwise(small, H, W, seed):
     out = net.forward(data=data, im_info=im_info)
     assert set(out) == {"cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"}
     check_forward(net, w, data, im_info)
+
+
+def test_python_layer_path_matches_native_layers(small):
+    """native_pylayers=False runs ProposalLayer / MaskLayer / StageBridgeLayer as real `caffe.Layer` Python objects (the
+    drop-in API, 4 host hops); the default substitutes the device-resident kernels.  Both satisfy the parity protocol;
+    their rois agree to float rounding (expf) and everything downstream agrees to tolerance."""
+    import caffe
+    from mnc_amd.engine import Net
+    net, w = small
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    netp = Net(path, w, caffe.TEST, native_pylayers=False)
+    assert net._native_py and not netp._native_py
+    rng = np.random.default_rng(9)
+    data = rng.uniform(-120, 130, (1, 3, 128, 176)).astype(np.float32)
+    im_info = np.array([[128, 176, 1.0]], np.float32)
+    net.forward(data=data, im_info=im_info)
+    netp.forward(data=data, im_info=im_info)
+    check_forward(netp, w, data, im_info)
+    check_forward(net, w, data, im_info)
+    a, b = net.blobs["rois"]._host_read(), netp.blobs["rois"]._host_read()
+    assert a.shape == b.shape and err(a, b)[0] < 1e-3
+    for n in ("seg_cls_prob", "mask_proposal", "rois_ext", "seg_cls_prob_ext", "mask_proposal_ext"):
+        x, y = net.blobs[n]._host_read(), netp.blobs[n]._host_read()
+        assert x.shape == y.shape and err(x, y)[1] < 1e-3, n
+    netp.close()
 
 
 def test_unfused_graph_matches_fused(small):
