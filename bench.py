@@ -176,6 +176,8 @@ def main():
                 out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "launches_per_image": cnt / args.steps,
                                    "avg_launch_ms": tot_ms / cnt}
+        if "roofline" in out:
+            out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, im, args.cpu_images)
         print(json.dumps(out), flush=True)
@@ -183,6 +185,29 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+PMC_KERNEL = {"conv3x3_c8_mfma": "conv3x3_c8_kernel", "fc_mfma": "fc_mfma_kernel<10>"}
+
+
+def pmc_traffic(scope_name):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this build, as committed in
+    profiles/pmc_latest.json by tools/prof_round.sh + tools/pmc_report.py (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE).  bench.py cannot run rocprofv3 on
+    itself, so this is null when no profile has been committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        return None
+    want = PMC_KERNEL.get(scope_name, scope_name)
+    calls = tot = 0.0
+    for k, v in data.items():
+        if k.startswith(want):
+            calls += v["calls"]
+            tot += v["calls"] * v["hbm_bytes_corrected"]
+    return tot / calls if calls else None
 
 
 def cpu_baseline(weights, im, n_images):

@@ -30,7 +30,9 @@ constexpr int kWPitch = 76;              // floats per weight row in LDS and in 
 constexpr int kHaloFloats = kHaloRows * kHaloCols * kPixPitch;
 constexpr int kHaloVec = kHaloRows * kHaloCols * 2;  // float4 items per halo
 
-template <int CO_T>
+// ABL != 0: ablation builds for tuning (MNC_CONV_ABL): 1 = no global loads / LDS stores in the loop, 2 = additionally no
+// barrier, 3 = full kernel with s_setprio(1) around the MFMA cluster, 4 = loads issued but never stored to LDS.
+template <int CO_T, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
                                                          int W, int Cin, int Cout, int relu) {
@@ -101,10 +103,13 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict
   };
 
   f32x16 acc[CO_T];
+  f32x16 acc2;                 // second accumulator of the CO_T == 1 variant (see the inner loop)
 #pragma unroll
   for (int t = 0; t < CO_T; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 
   load_chunk(0);
   store_chunk(0);
@@ -115,27 +120,51 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict
 
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
+    if (ABL != 1 && ABL != 2 && ABL != 5) { if (c + 1 < nchunks) load_chunk(c + 1); }
     const float* sh = s_halo[buf];
     const float* sw = s_w[buf];
+    if (ABL == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - kh * 3;
-      const float4 p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
+      float4 p;
+      if (ABL == 5) { p = make_float4(1.f, 2.f, 3.f, 4.f); asm volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w)); }
+      else p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
+      float4 a[CO_T];
 #pragma unroll
       for (int t = 0; t < CO_T; ++t) {
-        const float4 a = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, p.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, p.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, p.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, p.w, acc[t], 0, 0, 0);
+        if (ABL == 5) { a[t] = make_float4(1.f, 2.f, 3.f, 4.f); asm volatile("" : "+v"(a[t].x), "+v"(a[t].y), "+v"(a[t].z), "+v"(a[t].w)); }
+        else a[t] = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
+      }
+      // k-step outermost: consecutive MFMAs go to DIFFERENT accumulators (never two dependent MFMAs back to back);
+      // with a single channel tile the k-steps alternate between two accumulators that are summed in the epilogue
+      if (CO_T == 1) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, p.x, acc[0], 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, p.y, acc2, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, p.z, acc[0], 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, p.w, acc2, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, p.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, p.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, p.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, p.w, acc[t], 0, 0, 0);
       }
     }
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
-    __syncthreads();
+    if (ABL == 3) __builtin_amdgcn_s_setprio(0);
+    if (ABL == 0 || ABL == 3) { if (c + 1 < nchunks) store_chunk(buf ^ 1); }
+    if (ABL == 4) { asm volatile("" :: "v"(rh[0].x), "v"(rh[1].x), "v"(rw[0].x), "v"(rw[kWPerThread - 1].x)); }
+    if (ABL != 2 && ABL != 5) __syncthreads();
   }
 
   // ---- epilogue: D[row = cout (reg&3)+8*(reg>>2)+4*kk][col = pixel j] ----
+  if (CO_T == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][e] += acc2[e];
+  }
   const int oh = h0 + wave, ow = w0 + j;
   if (oh < H && ow < W) {
 #pragma unroll
@@ -321,6 +350,13 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
   dim3 grid(tx, ty, Cout / (32 * co_t));
+  if (const char* e = getenv("MNC_CONV_ABL")) {
+    const int a = atoi(e);
+#define MNC_ABL_CASE(T, A) if (co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, A>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu); return ls.finish("conv3x3_c8_kernel"); }
+    MNC_ABL_CASE(1, 1) MNC_ABL_CASE(1, 2) MNC_ABL_CASE(1, 3) MNC_ABL_CASE(1, 4) MNC_ABL_CASE(1, 5)
+    MNC_ABL_CASE(2, 1) MNC_ABL_CASE(2, 2) MNC_ABL_CASE(2, 3) MNC_ABL_CASE(2, 4) MNC_ABL_CASE(2, 5)
+#undef MNC_ABL_CASE
+  }
   if (co_t == 4)
     hipLaunchKernelGGL(conv3x3_c8_kernel<4>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
   else if (co_t == 2)

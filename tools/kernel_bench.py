@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the two MFMA kernels through the C ABI (HIP-event timing via mnc_prof_*).
+
+    python tools/kernel_bench.py conv [--reps 20]      the 13 conv3x3 shapes of the VGG-16 trunk at 600x1000
+    python tools/kernel_bench.py fc   [--reps 20]      the FC shapes of one head stage at 300 RoIs
+Environment knobs understood by the library (tuning aids): MNC_CONV_COT=1|2|4."""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_util import Dev  # noqa: E402
+
+CONV = [("conv1_2", 600, 1000, 64, 64), ("conv2_1", 300, 500, 64, 128), ("conv2_2", 300, 500, 128, 128),
+        ("conv3_1", 150, 250, 128, 256), ("conv3_2", 150, 250, 256, 256), ("conv4_1", 75, 125, 256, 512),
+        ("conv4_2", 75, 125, 512, 512), ("conv5_1", 38, 63, 512, 512)]
+FC = [("fc6_maskest", 300, 256, 100352), ("mask_pred", 300, 441, 256), ("fc6", 300, 4096, 25088), ("fc7", 300, 4096, 4096),
+      ("heads", 300, 126, 8192)]
+
+
+def records(dev):
+    n = ctypes.c_int(0)
+    dev.call("mnc_prof_count", ctypes.addressof(n))
+    out = []
+    name = ctypes.create_string_buffer(64)
+    ms = ctypes.c_float(0)
+    for i in range(n.value):
+        dev.call("mnc_prof_get", i, ctypes.addressof(name), 64, ctypes.addressof(ms), None, None)
+        out.append((name.value.decode(), ms.value))
+    dev.call("mnc_prof_reset")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["conv", "fc"])
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    dev = Dev(0)
+    rng = np.random.default_rng(0)
+    dev.call("mnc_prof_enable", 1)
+    total_ms, total_fl = 0.0, 0.0
+    if args.what == "conv":
+        for name, H, W, Cin, Cout in CONV:
+            if args.only and args.only not in name:
+                continue
+            x = dev.put(rng.normal(size=(Cin * H * W,)).astype(np.float32))
+            w = dev.put((rng.normal(size=((Cin // 8) * Cout * 76,)) * 0.05).astype(np.float32))
+            b = dev.put(np.zeros(Cout, np.float32))
+            y = dev.empty((Cout * H * W,))
+            for _ in range(3):
+                dev.call("mnc_conv3x3", x, w, b, y, H, W, Cin, Cout, 1)
+            dev.call("mnc_prof_reset")
+            for _ in range(args.reps):
+                dev.call("mnc_conv3x3", x, w, b, y, H, W, Cin, Cout, 1)
+            t = np.array([r[1] for r in records(dev)])
+            fl = 2.0 * H * W * 9 * Cin * Cout
+            print("%-10s %4dx%-4d %3d->%-3d  med %.1f us  min %.1f us  %.1f TF/s (med)  %.1f TF/s (best)" %
+                  (name, H, W, Cin, Cout, 1e3 * np.median(t), 1e3 * t.min(), fl / np.median(t) / 1e9, fl / t.min() / 1e9),
+                  flush=True)
+            mult = {"conv2_2": 1, "conv3_2": 2, "conv4_2": 2, "conv5_1": 4}.get(name, 1)
+            total_ms += mult * np.median(t)
+            total_fl += mult * fl
+        if not args.only:
+            print("trunk(12 layers)+rpn: %.3f ms, %.1f TF/s" % (total_ms, total_fl / total_ms / 1e9))
+    else:
+        for name, M, N, K in FC:
+            if args.only and args.only not in name:
+                continue
+            a = dev.put(rng.normal(size=(M * K,)).astype(np.float32))
+            w = dev.put((rng.normal(size=(N * K,)) * 0.01).astype(np.float32))
+            b = dev.put(np.zeros(N, np.float32))
+            y = dev.empty((M * N,))
+            for _ in range(3):
+                dev.call("mnc_fc", a, w, b, y, M, N, K, N, 1)
+            dev.call("mnc_prof_reset")
+            for _ in range(args.reps):
+                dev.call("mnc_fc", a, w, b, y, M, N, K, N, 1)
+            rec = records(dev)
+            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma")])
+            tr = np.array([r[1] for r in rec if r[0] == "fc_reduce"] or [0.0])
+            fl = 2.0 * M * N * K
+            print("%-12s M=%d N=%-4d K=%-6d  med %.1f us (+%.1f us reduce)  %.1f TF/s" %
+                  (name, M, N, K, 1e3 * np.median(t), 1e3 * np.median(tr), fl / np.median(t) / 1e9), flush=True)
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()

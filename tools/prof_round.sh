@@ -1,0 +1,20 @@
+#!/bin/bash
+# Per-round profiling recipe (run on the GPU box via gpurun): bench JSON + rocprofv3 kernel trace + 3 PMC passes.
+# usage: bash tools/prof_round.sh <tag>     -> gpurun_out/prof_<tag>/
+TAG=${1:-rXX}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $REPO/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events"
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $BENCH > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT -d $OUT/pmc_mfma -o bench -- $BENCH > $OUT/pmc_mfma.log 2>&1
+python $REPO/tools/rocpd_summary.py $OUT/trace/bench_results.db > $OUT/kernel_trace_stats.txt
+python $REPO/tools/pmc_report.py $OUT/pmc_mfma/bench_results.db $OUT/pmc_fetch/bench_results.db $OUT/pmc_write/bench_results.db --json $OUT/pmc.json > $OUT/pmc.txt
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+cat $OUT/bench.json
+head -12 $OUT/kernel_trace_stats.txt
+head -8 $OUT/pmc.txt
