@@ -185,6 +185,13 @@ MNC_API int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask
  * act: 0 none, 1 ReLU, 2 sigmoid. */
 MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_out, int M,
                    int N, int K, int ldc, int act);
+/* InnerProduct on the bf16 matrix pipe with fp32-class accuracy ("bf16x3": every operand split into hi + lo bf16, product =
+ * a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; relative error ~1e-5 per product, see mnc_amd/csrc/gemm_x3.hip).
+ * d_w_packed comes from mnc_pack_fc_bf16x3 (fp32 [N][K] -> [N][K/8][hi x8 | lo x8] bf16, N*K*4 bytes, K%8==0);
+ * activations stay fp32.  Same contract as mnc_fc otherwise. */
+MNC_API int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
+MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M,
+                          int N, int K, int ldc, int act);
 /* Softmax over the last axis of [M][N] (test.prototxt cls_prob / seg_cls_prob). */
 MNC_API int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N);
 /* Same with a row stride on the input (the input may be a column slice of a merged-GEMM output). */

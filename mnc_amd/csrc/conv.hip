@@ -23,38 +23,43 @@ namespace mnc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTileRows = 4, kTileCols = 32;
-constexpr int kHaloRows = kTileRows + 2, kHaloCols = kTileCols + 2;
+constexpr int kTileCols = 32;
+constexpr int kHaloCols = kTileCols + 2;
 constexpr int kPixPitch = 12;            // floats per halo pixel in LDS (8 data + 4 pad)
 constexpr int kWPitch = 76;              // floats per weight row in LDS and in the packed global layout (72 + 4 pad)
-constexpr int kHaloFloats = kHaloRows * kHaloCols * kPixPitch;
-constexpr int kHaloVec = kHaloRows * kHaloCols * 2;  // float4 items per halo
 
 // ABL != 0: ablation builds for tuning (MNC_CONV_ABL): 1 = no global loads / LDS stores in the loop, 2 = additionally no
 // barrier, 3 = full kernel with s_setprio(1) around the MFMA cluster, 4 = loads issued but never stored to LDS.
-template <int CO_T, int ABL = 0>
-__global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+// ROWS = pixel rows (= waves) per workgroup, CO_T = 32-channel tiles per wave.  The launcher picks (ROWS, CO_T) per layer
+// so that the number of workgroups is close to a multiple of what the chip holds at once (tile-quantisation tail).
+template <int CO_T, int ABL = 0, int ROWS = 4>
+__global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
                                                          int W, int Cin, int Cout, int relu) {
+  constexpr int NT = 64 * ROWS;
+  constexpr int kHaloRows = ROWS + 2;
+  constexpr int kHaloFloats = kHaloRows * kHaloCols * kPixPitch;
+  constexpr int kHaloVec = kHaloRows * kHaloCols * 2;        // float4 items per halo
+  constexpr int kHPerThread = (kHaloVec + NT - 1) / NT;
   constexpr int NCO = 32 * CO_T;
   constexpr int kWVec = NCO * (kWPitch / 4);                 // float4 items per weight panel (incl. pad)
-  constexpr int kWPerThread = (kWVec + 255) / 256;
+  constexpr int kWPerThread = (kWVec + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float s_halo[2][kHaloFloats];
   __shared__ __attribute__((aligned(16))) float s_w[2][NCO * kWPitch];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, kk = lane >> 5;
-  const int w0 = blockIdx.x * kTileCols, h0 = blockIdx.y * kTileRows, co0 = blockIdx.z * NCO;
+  const int w0 = blockIdx.x * kTileCols, h0 = blockIdx.y * ROWS, co0 = blockIdx.z * NCO;
   const int nchunks = Cin >> 3;
 
   // ---- staging assignment (fixed per thread) ----
   // halo: item q -> pixel q>>1 (row-major in the 6x34 halo), half q&1
-  int h_off[2];
-  long h_src[2];   // element offset inside one 8-channel block plane, or -1 when outside the image
+  int h_off[kHPerThread];
+  long h_src[kHPerThread];   // element offset inside one 8-channel block plane, or -1 when outside the image
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int q = tid + u * 256;
+  for (int u = 0; u < kHPerThread; ++u) {
+    const int q = tid + u * NT;
     h_off[u] = -1;
     h_src[u] = -1;
     if (q < kHaloVec) {
@@ -70,15 +75,17 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict
 
   // NB: staging registers must be initialised, otherwise hipcc keeps the (conditionally written) arrays as allocas
   // -> scratch / promote-alloca-to-LDS instead of VGPRs.
-  float4 rh[2] = {zero4, zero4};
+  float4 rh[kHPerThread];
   float4 rw[kWPerThread];
+#pragma unroll
+  for (int u = 0; u < kHPerThread; ++u) rh[u] = zero4;
 #pragma unroll
   for (int u = 0; u < kWPerThread; ++u) rw[u] = zero4;
 
   auto load_chunk = [&](int c) {
     const float* src = in + (long)c * plane;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kHPerThread; ++u) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (h_src[u] >= 0) v = *reinterpret_cast<const float4*>(src + h_src[u]);
       rh[u] = v;
@@ -86,18 +93,18 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict
     const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * Cout + co0) * kWPitch);
 #pragma unroll
     for (int u = 0; u < kWPerThread; ++u) {
-      const int q = tid + u * 256;
+      const int q = tid + u * NT;
       if (q < kWVec) rw[u] = wsrc[q];
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < kHPerThread; ++u)
       if (h_off[u] >= 0) *reinterpret_cast<float4*>(&s_halo[buf][h_off[u]]) = rh[u];
     float4* wdst = reinterpret_cast<float4*>(&s_w[buf][0]);
 #pragma unroll
     for (int u = 0; u < kWPerThread; ++u) {
-      const int q = tid + u * 256;
+      const int q = tid + u * NT;
       if (q < kWVec) wdst[q] = rw[u];
     }
   };
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const float* __restrict
     }
     if (ABL == 3) __builtin_amdgcn_s_setprio(0);
     if (ABL == 0 || ABL == 3) { if (c + 1 < nchunks) store_chunk(buf ^ 1); }
-    if (ABL == 4) { asm volatile("" :: "v"(rh[0].x), "v"(rh[1].x), "v"(rw[0].x), "v"(rw[kWPerThread - 1].x)); }
+    if (ABL == 4) { asm volatile("" :: "v"(rh[0].x), "v"(rh[kHPerThread - 1].x), "v"(rw[0].x), "v"(rw[kWPerThread - 1].x)); }
     if (ABL != 2 && ABL != 5) __syncthreads();
   }
 
@@ -337,32 +344,39 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3: null pointer");
   MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
               "mnc_conv3x3: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin, Cout);
-  const int tx = cdiv(W, kTileCols), ty = cdiv(H, kTileRows);
-  // widest channel tile that still gives >= 4 workgroups per CU (256 CUs) so the tail round stays short; narrow maps
-  // fall back to 32 channels.  MNC_CONV_COT=1|2|4 overrides (tuning aid).
-  int co_t = 4;
-  while (co_t > 1 && (Cout % (32 * co_t) != 0 || (long)tx * ty * (Cout / (32 * co_t)) < 1024)) co_t >>= 1;
+  // (rows per workgroup, channel tiles per wave).  Measured on MI355X (tools/kernel_bench.py, round 1): every shape with
+  // >= ~1000 workgroups plateaus at 95-105 TF/s regardless of the tile (4 or 8 rows, 32/64/128 channels); 5-row
+  // workgroups lose 30 % (5 waves do not spread evenly over 4 SIMDs).  So: 4 rows, and the widest channel tile that still
+  // leaves >= 4 workgroups per CU; narrow maps fall back to 32 channels.  MNC_CONV_ROWS=4|8 / MNC_CONV_COT=1|2|4 override.
+  int best_rows = 4, best_cot = 4;
+  while (best_cot > 1 && (Cout % (32 * best_cot) != 0 ||
+                          (long)cdiv(W, kTileCols) * cdiv(H, best_rows) * (Cout / (32 * best_cot)) < 1024))
+    best_cot >>= 1;
   if (const char* e = getenv("MNC_CONV_COT")) {
     const int v = atoi(e);
-    if ((v == 1 || v == 2 || v == 4) && Cout % (32 * v) == 0) co_t = v;
+    if ((v == 1 || v == 2 || v == 4) && Cout % (32 * v) == 0) best_cot = v;
   }
+  if (const char* e = getenv("MNC_CONV_ROWS")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8) best_rows = v;
+  }
+  const int rows = best_rows, co_t = best_cot;
+  const int tx = cdiv(W, kTileCols), ty = cdiv(H, rows);
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
   dim3 grid(tx, ty, Cout / (32 * co_t));
   if (const char* e = getenv("MNC_CONV_ABL")) {
     const int a = atoi(e);
-#define MNC_ABL_CASE(T, A) if (co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, A>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu); return ls.finish("conv3x3_c8_kernel"); }
+#define MNC_ABL_CASE(T, A) if (rows == 4 && co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, A, 4>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu); return ls.finish("conv3x3_c8_kernel"); }
     MNC_ABL_CASE(1, 1) MNC_ABL_CASE(1, 2) MNC_ABL_CASE(1, 3) MNC_ABL_CASE(1, 4) MNC_ABL_CASE(1, 5)
     MNC_ABL_CASE(2, 1) MNC_ABL_CASE(2, 2) MNC_ABL_CASE(2, 3) MNC_ABL_CASE(2, 4) MNC_ABL_CASE(2, 5)
 #undef MNC_ABL_CASE
   }
-  if (co_t == 4)
-    hipLaunchKernelGGL(conv3x3_c8_kernel<4>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
-  else if (co_t == 2)
-    hipLaunchKernelGGL(conv3x3_c8_kernel<2>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
-  else
-    hipLaunchKernelGGL(conv3x3_c8_kernel<1>, grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+#define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, 0, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+  MNC_CONV_CASE(4, 1) MNC_CONV_CASE(4, 2) MNC_CONV_CASE(4, 4)
+  MNC_CONV_CASE(8, 1) MNC_CONV_CASE(8, 2) MNC_CONV_CASE(8, 4)
+#undef MNC_CONV_CASE
   return ls.finish("conv3x3_c8_kernel");
 }
 

@@ -41,14 +41,16 @@ template <int kMT>
 __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       float* __restrict__ part, int M, int N, int K, int ldc, int kper,
-                                                      int act, int fused) {
+                                                      int act, int fused, int tn_, int splits_, int tm_) {
   constexpr int kBM = 32 * kMT;
   constexpr int kAPer = kMT;               // float4 staging items per thread for the A panel (item u == row tile u)
   __shared__ __attribute__((aligned(16))) float sA[2][kBM * kPitch];
   __shared__ __attribute__((aligned(16))) float sB[2][kBN * kPitch];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, kk = lane >> 5;
-  const int n0 = blockIdx.x * kBN, split = blockIdx.y, m0 = blockIdx.z * kBM;
+  int bn, split, bmz;
+  xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  const int n0 = bn * kBN, m0 = bmz * kBM;
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
   const int nstages = (kend - kbeg) / kBK;
   const int mrows = min(M - m0, kBM);
@@ -80,14 +82,14 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
   auto load_stage = [&](int s) {
 #pragma unroll
     for (int u = 0; u < kAPer; ++u)
-      if (u < mtiles) ra[u] = *reinterpret_cast<const float4*>(a_src[u] + (long)s * kBK);
+      ra[u] = *reinterpret_cast<const float4*>(a_src[u] + (long)s * kBK);
 #pragma unroll
     for (int u = 0; u < kBPer; ++u) rb[u] = *reinterpret_cast<const float4*>(b_src[u] + (long)s * kBK);
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < kAPer; ++u)
-      if (u < mtiles) *reinterpret_cast<float4*>(&sA[buf][a_dst[u]]) = ra[u];   // item u == row tile u
+      *reinterpret_cast<float4*>(&sA[buf][a_dst[u]]) = ra[u];   // item u == row tile u
 #pragma unroll
     for (int u = 0; u < kBPer; ++u) *reinterpret_cast<float4*>(&sB[buf][b_dst[u]]) = rb[u];
   };
@@ -115,13 +117,13 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
       const float4 b = *reinterpret_cast<const float4*>(pb + b_base + kc * 8);
 #pragma unroll
       for (int t = 0; t < kMT; ++t) {
-        if (t < mtiles) {
-          const float4 a = *reinterpret_cast<const float4*>(pa + a_base + t * 32 * kPitch + kc * 8);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-        }
+        // no per-tile branch: rows past M are clamped copies, multiplied but never stored (a branch here splits the loop
+        // into tiny basic blocks and exposes the LDS latency once per tile)
+        const float4 a = *reinterpret_cast<const float4*>(pa + a_base + t * 32 * kPitch + kc * 8);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
     if (s + 1 < nstages) store_stage(buf ^ 1);
@@ -203,7 +205,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   if (M == 0) return MNC_OK;
   // small problems (< 2 GFLOP) use 64-row workgroups so that rows, column tiles and K splits together fill the chip
   const bool small = 2.0 * M * (double)N * K < 2.0e9;
-  const int bm = small ? 64 : 320;
+  const int mt = small ? 2 : (M <= 160 ? 5 : 10);      // row tiles per workgroup (all of them are always multiplied)
+  const int bm = 32 * mt;
   const int tn = cdiv(N, kBN), tm = cdiv(M, bm), stages = K / kBK;
   // enough splits to give every CU a workgroup (two for the small variant), but at least 2 stages (64 deep) per split
   int splits = cdiv(small ? 512 : 256, tn * tm);
@@ -221,12 +224,15 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
   {
     LaunchScope ls(ctx, small ? "fc_mfma_small" : "fc_mfma", flops, bytes);
-    if (small)
-      hipLaunchKernelGGL(fc_mfma_kernel<2>, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0);
+    if (mt == 2)
+      hipLaunchKernelGGL(fc_mfma_kernel<2>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+    else if (mt == 5)
+      hipLaunchKernelGGL(fc_mfma_kernel<5>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
     else
-      hipLaunchKernelGGL(fc_mfma_kernel<10>, dim3(tn, splits, tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0);
+      hipLaunchKernelGGL(fc_mfma_kernel<10>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }

@@ -81,6 +81,22 @@ struct LaunchScope {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware block order for the GEMMs.  The dispatcher places block b on XCD b % 8 (observed, used for speed only:
+// a different placement changes nothing but L2 hit rates).  Blocks are re-numbered so that each XCD receives a
+// CONTIGUOUS range of the logical order (column tile fastest, then K split, then row block): the workgroups that share
+// one K split's activation panel then sit on one XCD and the panel stays in that XCD's 4 MB L2 instead of being
+// re-fetched from Infinity Cache by every column tile.  Bijective for any block count (cdna_hip_programming.md, T1).
+__device__ __forceinline__ void xcd_decode(int bid, int tn, int splits, int tm, int& bn, int& split, int& bm) {
+  const int total = tn * splits * tm;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bn = logical % tn;
+  const int rest = logical / tn;
+  split = rest % splits;
+  bm = rest / splits;
+}
+
 // Per-device stream + growable device buffer behind the host-pointer entry points (_nms/_mv): the reference
 // cudaMalloc/cudaFree's its scratch on every call (nms_kernel.cu:99-143, mv_kernel.cu:250-347).
 struct LegacyWs {

@@ -212,6 +212,27 @@ def test_fc_mfma(dev, M, N, K, act):
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("M,N,K,act", FC_SHAPES)
+def test_fc_bf16x3(dev, M, N, K, act):
+    """Split-precision FC (3 bf16 MFMAs per product): measured against the float64 product.  Bar: 1e-4 of the output's
+    dynamic range, the same bar as the exact-fp32 kernel (its error is ~1e-5, an fp32 GEMM's ~1e-6)."""
+    rng = np.random.default_rng(M + N + K + 1)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_wp = dev.empty((N * K,))
+    dev.call("mnc_pack_fc_bf16x3", dev.put(w), d_wp, N, K)
+    d_o = dev.empty((M * N,), fill=np.nan)
+    dev.call("mnc_fc_bf16x3", dev.put(a), d_wp, dev.put(b), d_o, M, N, K, N, act)
+    got = dev.get(d_o, (M, N))
+    y = a.astype(np.float64) @ w.astype(np.float64).T + b
+    want = np.maximum(y, 0) if act == 1 else 1 / (1 + np.exp(-y)) if act == 2 else y
+    assert not np.isnan(got).any()
+    d, rel = err(got, want)
+    print("bf16x3 M=%d N=%d K=%d: max|d|=%.3e rel=%.3e" % (M, N, K, d, rel))
+    assert rel < 1e-4, (d, rel)
+
+
 def test_fc_column_slice_and_pack(dev):
     """ldc > N writes a column slice (Concat in place); mnc_pack_fc_weights permutes (c,h,w) columns to (h,w,c)."""
     rng = np.random.default_rng(9)

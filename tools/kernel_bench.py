@@ -38,7 +38,7 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "fc"])
+    ap.add_argument("what", choices=["conv", "fc", "fcx3"])
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
@@ -77,13 +77,18 @@ def main():
             w = dev.put((rng.normal(size=(N * K,)) * 0.01).astype(np.float32))
             b = dev.put(np.zeros(N, np.float32))
             y = dev.empty((M * N,))
+            fn = "mnc_fc"
+            if args.what == "fcx3":
+                wp = dev.empty((N * K,))
+                dev.call("mnc_pack_fc_bf16x3", w, wp, N, K)
+                w, fn = wp, "mnc_fc_bf16x3"
             for _ in range(3):
-                dev.call("mnc_fc", a, w, b, y, M, N, K, N, 1)
+                dev.call(fn, a, w, b, y, M, N, K, N, 1)
             dev.call("mnc_prof_reset")
             for _ in range(args.reps):
-                dev.call("mnc_fc", a, w, b, y, M, N, K, N, 1)
+                dev.call(fn, a, w, b, y, M, N, K, N, 1)
             rec = records(dev)
-            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma")])
+            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0].startswith("fc_bf16x3")])
             tr = np.array([r[1] for r in rec if r[0] == "fc_reduce"] or [0.0])
             fl = 2.0 * M * N * K
             print("%-12s M=%d N=%-4d K=%-6d  med %.1f us (+%.1f us reduce)  %.1f TF/s" %

@@ -11,7 +11,7 @@ python - <<PY
 import sqlite3
 for p in ("p1","p2"):
     con=sqlite3.connect("$OUT/%s/k_results.db"%p)
-    q="select kernel_name, grid_size, counter_name, avg(value), count(*) , avg(duration) from counters_collection where kernel_name like '%conv3x3_c8%' or kernel_name like '%fc_mfma%' group by kernel_name, grid_size, counter_name order by grid_size, kernel_name"
+    q="select kernel_name, grid_size, counter_name, avg(value), count(*) , avg(duration) from counters_collection where kernel_name like '%conv3x3_c8%' or kernel_name like '%fc_mfma%' or kernel_name like '%fc_x3_kernel%' group by kernel_name, grid_size, counter_name order by grid_size, kernel_name"
     for r in con.execute(q):
         print("%-40s grid=%-9d %-30s avg=%-14.6g n=%d dur_us=%.1f"%(r[0].replace('void mnc::','')[:40],r[1],r[2],r[3],r[4],r[5]/1e3))
 PY
