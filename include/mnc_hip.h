@@ -159,6 +159,13 @@ MNC_API int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_
 /* Convolution 3x3 pad 1 stride 1 + bias (+ ReLU) (test.prototxt:41-412), c8 -> c8, fp32 MFMA implicit GEMM. */
 MNC_API int mnc_conv3x3(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
                         float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
+/* The same convolution on the bf16 matrix pipe with fp32-class accuracy ("bf16x3", see mnc_fc_bf16x3 and
+ * mnc_amd/csrc/conv_x3.hip; BASELINE.json configs[2] "bf16 convs via MFMA").  Activations stay fp32 c8 in and out;
+ * d_w_packed comes from mnc_pack_conv3x3_bf16x3: Caffe [Cout][Cin][3][3] fp32 -> [Cin/8][Cout][84 dwords]
+ * (10 tap slots x (hi x8 | lo x8) bf16 + 16 B pad; Cin/8*Cout*336 bytes).  Cin%8==0, Cout%32==0. */
+MNC_API int mnc_pack_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
+MNC_API int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias,
+                               float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
 /* Pooling MAX 2x2 stride 2 with Caffe's ceil output size (test.prototxt:69-79,...): c8 [C/8][H][W][8] ->
  * [C/8][OH][OW][8], OH = ceil((H-2)/2)+1. */
 MNC_API int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W);

@@ -1,8 +1,8 @@
 // InnerProduct on the bf16 matrix pipe with fp32-class accuracy ("bf16x3" split precision) for gfx950.
 //
-// Every fp32 operand is split into two bf16 terms, x = hi + lo (hi = trunc_bf16(x), lo = trunc_bf16(x - hi)); a product is
-// evaluated as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with three v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in
-// the fp32 accumulator).  The dropped terms are O(2^-17) relative, i.e. ~1e-5 per product and less on a dot product --
+// Every fp32 operand is split into two bf16 terms, x = hi + lo (x3_split.h); a product is evaluated as
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with three v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in
+// the fp32 accumulator).  The dropped terms are O(2^-16) relative, i.e. ~1e-5 per product and less on a dot product --
 // two orders of magnitude inside the 1e-3 parity bar (tests/test_gpu_ops.py::test_fc_bf16x3), while the matrix pipe
 // runs the three bf16 MFMAs 5.3x faster than the eight fp32 MFMAs they replace (16 K-values in 3 x 32 cycles instead of
 // 8 x 64).  At M = 300 that moves the FC layers from MFMA-bound to weight-streaming-bound.
@@ -15,12 +15,11 @@
 //   * LDS rows are 4 groups x 32 B + 16 B pad (pitch 36 dwords, conflict-free ds_read_b128); lane (row, kb) of K-step ks
 //     reads group 2*ks + kb: hi and lo are two adjacent 16-byte fragments.
 #include "mnc_internal.h"
+#include "x3_split.h"
 
 namespace mnc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kXBN = 128, kXBK = 32;
 constexpr int kXPitch = 36;            // dwords per LDS row: 4 groups x 8 dwords + 4 pad
@@ -31,26 +30,6 @@ __device__ __forceinline__ float x3_act(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
   if (act == 2) return 1.0f / (1.0f + expf(-v));
   return v;
-}
-
-// 8 consecutive fp32 -> (hi x8, lo x8) as two 16-byte vectors of bf16.
-// hi = x with the low 16 mantissa bits cleared (one v_and), lo = x - hi (exact in fp32, one v_sub) truncated to bf16;
-// two values are packed per dword with one v_perm_b32 each for hi and lo: 3 VALU per value (the compiler's
-// `(__bf16)x` round-to-nearest sequence costs ~10).  Truncation instead of rounding doubles the dropped-term bound to
-// ~2^-15.5 relative per product (measured 4e-6 on the test GEMMs), still far inside the 1e-3 bar.
-__device__ __forceinline__ unsigned pack_hi16(unsigned x0, unsigned x1) {      // {x1[31:16], x0[31:16]}
-  return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-}
-__device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
-  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  unsigned h[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    h[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
-    l[e] = __float_as_uint(x[e] - __uint_as_float(h[e]));
-  }
-  hi = make_uint4(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7]));
-  lo = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
 }
 
 template <int kMT>
@@ -125,7 +104,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const float* __restrict__ A,
 #pragma unroll
     for (int u = 0; u < kAPer; ++u) {
       uint4 hi, lo;
-      split8(R.a[u][0], R.a[u][1], hi, lo);
+      x3_split8(R.a[u][0], R.a[u][1], hi, lo);
       hi.x &= keep; hi.y &= keep; hi.z &= keep; hi.w &= keep;
       lo.x &= keep; lo.y &= keep; lo.z &= keep; lo.w &= keep;
       *reinterpret_cast<uint4*>(&sA[buf][a_dst[u]]) = hi;
@@ -218,8 +197,10 @@ __global__ __launch_bounds__(256) void fc_x3_reduce_kernel(const float* __restri
 __global__ void pack_x3_kernel(const float* __restrict__ in, uint4* __restrict__ out, long groups) {
   for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x) {
     const float4* p = reinterpret_cast<const float4*>(in + g * 8);
+    const float4 a = p[0], b = p[1];
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint4 hi, lo;
-    split8(p[0], p[1], hi, lo);
+    x3_split8_rne(x, hi, lo);
     out[g * 2] = hi;
     out[g * 2 + 1] = lo;
   }

@@ -1,0 +1,67 @@
+// Split-precision helpers shared by the bf16x3 kernels (gemm_x3.hip, conv_x3.hip).
+//
+// x = hi + lo with hi, lo bf16.  A product a*b is evaluated as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on
+// v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in the fp32 accumulator); the dropped terms are a_lo*b_lo
+// (2^-16 relative) and the representation error of lo (2^-17 relative), i.e. ~1e-5 per product and less on a dot product.
+#ifndef MNC_X3_SPLIT_H_
+#define MNC_X3_SPLIT_H_
+
+#include <hip/hip_runtime.h>
+
+namespace mnc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned x3_pack_hi16(unsigned x0, unsigned x1) {      // {x1[31:16], x0[31:16]}
+  return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+}
+
+// Activations, split while they are staged into LDS: hi = x with the low 16 bits cleared (one v_and), lo = x - hi (exact
+// in fp32) rounded half-up to bf16 (one v_add); two values are packed per dword with one v_perm_b32: 3.5 VALU per value
+// (the compiler's `(__bf16)x` round-to-nearest-even sequence costs ~10).
+__device__ __forceinline__ void x3_split(float x, unsigned& h, unsigned& l) {
+  h = __float_as_uint(x) & 0xFFFF0000u;
+  l = __float_as_uint(x - __uint_as_float(h)) + 0x8000u;
+}
+__device__ __forceinline__ void x3_split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x3_split(x[e], h[e], l[e]);
+  hi = make_uint4(x3_pack_hi16(h[0], h[1]), x3_pack_hi16(h[2], h[3]), x3_pack_hi16(h[4], h[5]), x3_pack_hi16(h[6], h[7]));
+  lo = make_uint4(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]), x3_pack_hi16(l[4], l[5]), x3_pack_hi16(l[6], l[7]));
+}
+__device__ __forceinline__ void x3_split4(const float4 a, uint2& hi, uint2& lo) {
+  unsigned h[4], l[4];
+  x3_split(a.x, h[0], l[0]);
+  x3_split(a.y, h[1], l[1]);
+  x3_split(a.z, h[2], l[2]);
+  x3_split(a.w, h[3], l[3]);
+  hi = make_uint2(x3_pack_hi16(h[0], h[1]), x3_pack_hi16(h[2], h[3]));
+  lo = make_uint2(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]));
+}
+
+// Weights, split once when they are packed: both terms rounded to nearest even.
+__device__ __forceinline__ unsigned x3_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+__device__ __forceinline__ void x3_split8_rne(const float* x, uint4& hi, uint4& lo) {
+  unsigned h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = x3_rne(x[e]);
+    l[e] = x3_rne(x[e] - __uint_as_float(h[e]));
+  }
+  hi = make_uint4(x3_pack_hi16(h[0], h[1]), x3_pack_hi16(h[2], h[3]), x3_pack_hi16(h[4], h[5]), x3_pack_hi16(h[6], h[7]));
+  lo = make_uint4(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]), x3_pack_hi16(l[4], l[5]), x3_pack_hi16(l[6], l[7]));
+}
+
+__device__ __forceinline__ bf16x8 x3_as_bf16x8(const uint4 v) {
+  union { uint4 u; bf16x8 b; } c;
+  c.u = v;
+  return c.b;
+}
+
+}  // namespace mnc
+#endif

@@ -24,6 +24,9 @@ import numpy as np
 
 from . import _lib, install_paths, prototxt
 
+# bf16x3 mode: InnerProducts below this many flops stay on the fp32 kernel (its small-tile variant is as fast there)
+_X3_MIN_FLOPS = 2.0e9
+
 install_paths()
 
 F32 = np.dtype(np.float32)
@@ -271,7 +274,7 @@ class _Layer(object):
 
 
 class Net(object):
-    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None):
+    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None, math=None):
         if device_id is None:
             try:
                 import caffe
@@ -290,6 +293,12 @@ class Net(object):
         # `type: 'Python'` layer -- or all of them with native_pylayers=False / MNC_NATIVE_PYLAYERS=0 -- runs as Python
         self._native_py = ((os.environ.get("MNC_NATIVE_PYLAYERS", "1") != "0") if native_pylayers is None
                            else bool(native_pylayers))
+        # arithmetic of the dense contractions: "fp32" = fp32 MFMA throughout (the default and the parity reference);
+        # "bf16x3" = the large InnerProducts and 3x3 convolutions run on the bf16 matrix pipe with every operand split
+        # into hi + lo bf16 and three products per term (fp32-class accuracy, see csrc/gemm_x3.hip); math= / MNC_MATH
+        self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
+        if self.math not in ("fp32", "bf16x3"):
+            raise ValueError("math must be 'fp32' or 'bf16x3', got %r" % self.math)
         self._ctx = _Ctx(device_id)
         self._tmp = _DevBuf(self._ctx)
         self._net_msg = prototxt.parse_file(prototxt_path)
@@ -454,19 +463,23 @@ class Net(object):
                 _lib.call("mnc_conv3x3_c3", self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cout, relu)
             return run
         if k == 3 and pad == 1 and stride == 1:
+            x3 = self.math == "bf16x3"
+            pitch, pack, conv = (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
+                                (76, "mnc_pack_conv3x3_weights", "mnc_conv3x3")
+
             def build():
                 raw = self._upload(W)
-                packed = self._ctx.alloc((cin // 8) * cout * 76 * 4)
-                _lib.call("mnc_pack_conv3x3_weights", self._h(), raw, packed, cout, cin)
+                packed = self._ctx.alloc((cin // 8) * cout * pitch * 4)
+                _lib.call(pack, self._h(), raw, packed, cout, cin)
                 self._ctx.free(raw)
                 return packed
-            d_w = self._dev_param(key + ("w",), build)
+            d_w = self._dev_param(key + ("w", "x3" if x3 else "fp32"), build)
 
             def run():
                 _, _, H, Wd = bot.shape
                 src = bot.dev_in("c8")
                 top.reshape(1, cout, H, Wd)
-                _lib.call("mnc_conv3x3", self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cin, cout, relu)
+                _lib.call(conv, self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cin, cout, relu)
             return run
         if k == 1 and pad == 0 and stride == 1 and not L.relu:
             d_w = self._dev_param(key + ("w",), lambda: self._upload(W.reshape(cout, cin)))
@@ -605,8 +618,20 @@ class Net(object):
         K = W.shape[1]
         state = {}
 
-        def weights_for(shape):
-            """Caffe flattens (C,PH,PW); the engine's per-RoI features are (PH,PW,C): permute the columns once."""
+        def weights_for(shape, M):
+            """Caffe flattens (C,PH,PW); the engine's per-RoI features are (PH,PW,C): permute the columns once.  In
+            bf16x3 mode the large products additionally get the weights pre-split into hi/lo bf16."""
+            x3 = self.math == "bf16x3" and K % 32 == 0 and 2.0 * M * n_out * K >= _X3_MIN_FLOPS
+            tag = ("x3",) if x3 else ()
+
+            def finish(d_w):
+                if not x3:
+                    return d_w
+                packed = self._ctx.alloc(W.nbytes)
+                _lib.call("mnc_pack_fc_bf16x3", self._h(), d_w, packed, n_out, K)
+                self._ctx.free(d_w)
+                return packed
+
             if len(shape) == 4 and shape[2] * shape[3] > 1:
                 geo = (shape[1], shape[2], shape[3])
 
@@ -615,21 +640,22 @@ class Net(object):
                     packed = self._ctx.alloc(W.nbytes)
                     _lib.call("mnc_pack_fc_weights", self._h(), raw, packed, n_out, geo[0], geo[1], geo[2])
                     self._ctx.free(raw)
-                    return packed
-                return self._dev_param(key + ("w",) + geo, build), "rhwc"
-            return self._dev_param(key + ("w", "plain"), lambda: self._upload(W)), "plain"
+                    return finish(packed)
+                return self._dev_param(key + ("w",) + geo + tag, build), "rhwc", x3
+            return self._dev_param(key + ("w", "plain") + tag, lambda: finish(self._upload(W))), "plain", x3
 
         def run():
             M = bot.shape[0]
             if int(np.prod(bot.shape[1:])) != K:
                 raise ValueError("InnerProduct %s: input %r does not flatten to K=%d" % (L.name, bot.shape, K))
-            if "w" not in state:
-                state["w"], state["layout"] = weights_for(bot.shape)
+            if M and "w" not in state:
+                state["w"], state["layout"], state["x3"] = weights_for(bot.shape, M)
             src = bot.dev_in(state["layout"]) if M else 0
             top.reshape(M, n_out)
             dst = top.dev_out("plain")
             if M:
-                _lib.call("mnc_fc", self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+                _lib.call("mnc_fc_bf16x3" if state["x3"] else "mnc_fc", self._h(), src, state["w"], d_b, dst, M, n_out,
+                          K, top._ld(), act)
         return run
 
     def _bind_ip_group(self, L):

@@ -124,6 +124,25 @@ class Fake(object):
         y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
         _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
 
+    def mnc_pack_conv3x3_bf16x3(self, h, src, dst, Cout, Cin):
+        w = _f(src, (Cout, Cin // 8, 8, 9)).transpose(1, 0, 3, 2)                 # [cb][co][tap][8]
+        hi = (np.ascontiguousarray(w).view(np.uint32) & 0xFFFF0000).view(np.float32)
+        lo = (((w - hi).view(np.uint32) + 0x8000) & 0xFFFF0000).view(np.float32)
+        out = np.ctypeslib.as_array(ctypes.cast(dst, ctypes.POINTER(ctypes.c_uint16)), (Cin // 8, Cout, 168))
+        out[...] = 0
+        body = out[:, :, :144].reshape(Cin // 8, Cout, 9, 2, 8)
+        body[:, :, :, 0, :] = (hi.view(np.uint32) >> 16).astype(np.uint16)
+        body[:, :, :, 1, :] = (lo.view(np.uint32) >> 16).astype(np.uint16)
+
+    def mnc_conv3x3_bf16x3(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        pk = np.ctypeslib.as_array(ctypes.cast(wpk, ctypes.POINTER(ctypes.c_uint16)), (Cin // 8, Cout, 168))
+        f = (pk[:, :, :144].astype(np.uint32) << 16).view(np.float32).reshape(Cin // 8, Cout, 9, 2, 8)
+        wt = f[:, :, :, 0, :] + f[:, :, :, 1, :]                                    # [cb][co][tap][8]
+        w = np.ascontiguousarray(wt.transpose(1, 0, 3, 2)).reshape(Cout, Cin, 3, 3)
+        x = _unc8(_f(src, (Cin // 8, H, W, 8)))
+        y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
+        _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
+
     def mnc_maxpool2_c8(self, h, src, dst, C, H, W):
         x = _unc8(_f(src, (C // 8, H, W, 8)))
         y = F.max_pool2d(_t(x)[None], 2, 2, ceil_mode=True)[0].numpy()
@@ -166,6 +185,20 @@ class Fake(object):
         full = _f(dst, ((M - 1) * ldc + N,))
         for m in range(M):
             full[m * ldc: m * ldc + N] = y[m]
+
+    def mnc_pack_fc_bf16x3(self, h, src, dst, N, K):
+        w = _f(src, (N, K // 8, 8))
+        hi = (w.view(np.uint32) & 0xFFFF0000).view(np.float32)
+        lo = (((w - hi).view(np.uint32) + 0x8000) & 0xFFFF0000).view(np.float32)
+        out = np.ctypeslib.as_array(ctypes.cast(dst, ctypes.POINTER(ctypes.c_uint16)), (N, K // 8, 2, 8))
+        out[:, :, 0, :] = (hi.view(np.uint32) >> 16).astype(np.uint16)
+        out[:, :, 1, :] = (lo.view(np.uint32) >> 16).astype(np.uint16)
+
+    def mnc_fc_bf16x3(self, h, a, wpk, b, dst, M, N, K, ldc, act):
+        pk = np.ctypeslib.as_array(ctypes.cast(wpk, ctypes.POINTER(ctypes.c_uint16)), (N, K // 8, 2, 8))
+        f = (pk.astype(np.uint32) << 16).view(np.float32)
+        w = np.ascontiguousarray((f[:, :, 0, :] + f[:, :, 1, :]).reshape(N, K))
+        self.mnc_fc(h, a, w.ctypes.data, b, dst, M, N, K, ldc, act)
 
     def mnc_softmax_rows(self, h, src, dst, M, N):
         _f(dst, (M, N))[...] = F.softmax(_t(_f(src, (M, N))), dim=1).numpy()

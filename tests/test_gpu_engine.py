@@ -186,6 +186,36 @@ def test_full_vgg16_600x1000_blobwise(full):
     check_forward(net, w, data, im_info)
 
 
+def test_full_vgg16_600x1000_bf16x3_math(full):
+    """BASELINE configs[2] ("bf16 convs via MFMA"): math="bf16x3" runs the 3x3 convolutions and the large InnerProducts
+    on the bf16 matrix pipe with split operands.  Same parity protocol, same 1e-3 bar, against the fp32 oracle."""
+    from mnc_amd.engine import Net
+    _, w = full
+    net = Net(models.write_mnc_5stage_test_prototxt(), w, 1, math="bf16x3")
+    try:
+        im = np.random.default_rng(0).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+        data, im_info, scale = ohost.prepare_mnc_args(im)
+        net.forward(data=data, im_info=im_info)
+        assert net.blobs["rois"]._host_read().shape == (300, 5)
+        check_forward(net, w, data, im_info)
+    finally:
+        net.close()
+
+
+def test_reduced_net_bf16x3_math(small):
+    from mnc_amd.engine import Net
+    _, w = small
+    net = Net(models.write_mnc_5stage_test_prototxt(width_div=8), w, 1, math="bf16x3")
+    try:
+        rng = np.random.default_rng(5)
+        data = rng.uniform(-120, 130, (1, 3, 130, 203)).astype(np.float32)
+        im_info = np.array([[130, 203, 1.0]], np.float32)
+        net.forward(data=data, im_info=im_info)
+        check_forward(net, w, data, im_info)
+    finally:
+        net.close()
+
+
 def test_demo_pipeline_matches_oracle(full):
     """tools/demo.py path: im_detect (prepare args, forward, un-scale, clip, concat) + gpu_mask_voting, on a VOC-sized
     image that exercises the resize (375x500 -> 600x800, scale 1.6)."""

@@ -52,6 +52,44 @@ def test_conv3x3_mfma(dev, H, W, Cin, Cout, relu):
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):
+    """Split-precision conv (3 bf16 MFMAs per product) against torch fp32; same 1e-4-of-range bar as the fp32 kernel
+    (measured error ~1e-5).  The two extra shapes reach the wide register tiles (CT=4/PR=2, CT=2/PR=2)."""
+    rng = np.random.default_rng(H * 1000 + W + 7)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    d_w = dev.empty(((Cin // 8) * Cout * 84,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_bf16x3", dev.put(w), d_w, Cout, Cin)
+    d_y = dev.empty((Cout * H * W,), fill=np.nan)
+    dev.call("mnc_conv3x3_bf16x3", dev.put(to_c8(x)), d_w, dev.put(b), d_y, H, W, Cin, Cout, relu)
+    got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+    want = _conv_ref(x, w, b, relu=bool(relu))
+    assert not np.isnan(got).any()
+    d, rel = err(got, want)
+    print("conv bf16x3 %dx%d %d->%d: max|d|=%.3e rel=%.3e" % (H, W, Cin, Cout, d, rel))
+    assert rel < 1e-4, (d, rel)
+
+
+def test_conv3x3_bf16x3_packed_weight_layout(dev):
+    """[Cin/8][Cout][10 slots x (hi x8 | lo x8) bf16 + pad]: hi + lo reproduces the fp32 weight to 2^-16 relative, slot 9
+    and the pad are zero."""
+    rng = np.random.default_rng(0)
+    Cout, Cin = 64, 16
+    w = rng.normal(size=(Cout, Cin, 3, 3)).astype(np.float32)
+    d_pk = dev.empty(((Cin // 8) * Cout * 84,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_bf16x3", dev.put(w), d_pk, Cout, Cin)
+    pk = dev.get(d_pk, (Cin // 8, Cout, 84)).view(np.uint16).reshape(Cin // 8, Cout, 168)
+    assert not pk[:, :, 144:].any()
+    f = (pk[:, :, :144].astype(np.uint32) << 16).view(np.float32).reshape(Cin // 8, Cout, 9, 2, 8)
+    rec = f[:, :, :, 0, :] + f[:, :, :, 1, :]
+    for cb in range(Cin // 8):
+        want = w[:, cb * 8:cb * 8 + 8].reshape(Cout, 8, 9).transpose(0, 2, 1)
+        assert np.max(np.abs(rec[cb] - want) / np.abs(want)) < 2.0 ** -15
+
+
 def test_conv3x3_packed_weight_layout(dev):
     rng = np.random.default_rng(0)
     Cout, Cin = 64, 16

@@ -2,7 +2,9 @@
 """Micro-benchmark of the two MFMA kernels through the C ABI (HIP-event timing via mnc_prof_*).
 
     python tools/kernel_bench.py conv [--reps 20]      the 13 conv3x3 shapes of the VGG-16 trunk at 600x1000
+    python tools/kernel_bench.py convx3                the same on the bf16x3 kernel (MNC_CONVX3_TILE=CT,PR overrides the tile)
     python tools/kernel_bench.py fc   [--reps 20]      the FC shapes of one head stage at 300 RoIs
+    python tools/kernel_bench.py fcx3                  the same on the bf16x3 kernel
 Environment knobs understood by the library (tuning aids): MNC_CONV_COT=1|2|4."""
 import argparse
 import ctypes
@@ -38,7 +40,7 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "fc", "fcx3"])
+    ap.add_argument("what", choices=["conv", "convx3", "fc", "fcx3"])
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
@@ -46,20 +48,27 @@ def main():
     rng = np.random.default_rng(0)
     dev.call("mnc_prof_enable", 1)
     total_ms, total_fl = 0.0, 0.0
-    if args.what == "conv":
+    if args.what in ("conv", "convx3"):
         for name, H, W, Cin, Cout in CONV:
             if args.only and args.only not in name:
                 continue
             x = dev.put(rng.normal(size=(Cin * H * W,)).astype(np.float32))
-            w = dev.put((rng.normal(size=((Cin // 8) * Cout * 76,)) * 0.05).astype(np.float32))
             b = dev.put(np.zeros(Cout, np.float32))
             y = dev.empty((Cout * H * W,))
+            fn = "mnc_conv3x3"
+            if args.what == "convx3":
+                raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
+                w = dev.empty(((Cin // 8) * Cout * 84,))
+                dev.call("mnc_pack_conv3x3_bf16x3", raw, w, Cout, Cin)
+                fn = "mnc_conv3x3_bf16x3"
+            else:
+                w = dev.put((rng.normal(size=((Cin // 8) * Cout * 76,)) * 0.05).astype(np.float32))
             for _ in range(3):
-                dev.call("mnc_conv3x3", x, w, b, y, H, W, Cin, Cout, 1)
+                dev.call(fn, x, w, b, y, H, W, Cin, Cout, 1)
             dev.call("mnc_prof_reset")
             for _ in range(args.reps):
-                dev.call("mnc_conv3x3", x, w, b, y, H, W, Cin, Cout, 1)
-            t = np.array([r[1] for r in records(dev)])
+                dev.call(fn, x, w, b, y, H, W, Cin, Cout, 1)
+            t = np.array([r[1] for r in records(dev) if r[0].startswith("conv3x3")])
             fl = 2.0 * H * W * 9 * Cin * Cout
             print("%-10s %4dx%-4d %3d->%-3d  med %.1f us  min %.1f us  %.1f TF/s (med)  %.1f TF/s (best)" %
                   (name, H, W, Cin, Cout, 1e3 * np.median(t), 1e3 * t.min(), fl / np.median(t) / 1e9, fl / t.min() / 1e9),
