@@ -92,8 +92,11 @@ MNC_API void _mv(const float* all_boxes, const float* all_masks, const int all_b
  * score threshold -> candidate sets {IoU_f64 >= iou_thresh} with class-score weights normalised by a sequential float32 sum
  * (python's sum(), :266) -> fused mask voting kernels.  All host pointers.
  *   boxes [n][4] f32 (original-image pixels), masks [n][S][S] f32, scores [n][num_classes] f32 (column 0 = background),
- *   order [num_classes-1][n] i32: for class c+1, box indices by descending scores[:,c+1] (the caller's argsort()[::-1], so
- *         tie order is exactly the reference wrapper's, gpu_nms.pyx:26).
+ *   order [num_classes-1][n] i32: for class c+1, box indices by descending scores[:,c+1] (the caller's argsort()[::-1],
+ *         gpu_nms.pyx:26), or NULL: the library orders each class itself (on the device) exactly as
+ *         np.argsort(-scores[:, c+1], kind="stable") does -- ties in index order, NaN last.
+ * Order, NMS, candidate sets (double-precision IoU) and voting all run on the device; the host only picks the global
+ * threshold and the result rows between two stream synchronisations.
  * Outputs (capacity (num_classes-1)*min(max_per_image, n) rows): out_mask [R][S][S], out_box [R][4] i32, out_score [R],
  * class_count [num_classes-1] (rows per class, in class order), *result_num = R.
  * Bit-identical to running nms.gpu_nms x (num_classes-1), utils.cython_bbox.bbox_overlaps and nms.mv.mv as the reference does. */

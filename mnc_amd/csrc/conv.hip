@@ -28,11 +28,15 @@ constexpr int kHaloCols = kTileCols + 2;
 constexpr int kPixPitch = 12;            // floats per halo pixel in LDS (8 data + 4 pad)
 constexpr int kWPitch = 76;              // floats per weight row in LDS and in the packed global layout (72 + 4 pad)
 
-// ABL != 0: ablation builds for tuning (MNC_CONV_ABL): 1 = no global loads / LDS stores in the loop, 2 = additionally no
-// barrier, 3 = full kernel with s_setprio(1) around the MFMA cluster, 4 = loads issued but never stored to LDS.
-// ROWS = pixel rows (= waves) per workgroup, CO_T = 32-channel tiles per wave.  The launcher picks (ROWS, CO_T) per layer
-// so that the number of workgroups is close to a multiple of what the chip holds at once (tile-quantisation tail).
-template <int CO_T, int ABL = 0, int ROWS = 4>
+// ROWS = pixel rows (= waves) per workgroup, CO_T = 32-channel tiles per wave.
+//
+// Staging is branch-free and two blocks deep: every thread always loads (addresses clamped into the image / the panel,
+// out-of-image pixels masked to zero, surplus threads repeat the last item) and there are two register sets -- the loads for
+// block c+2 are issued while block c is multiplied and block c+1 (requested a whole iteration earlier) is written to LDS.
+// Conditional loads make hipcc wait with s_waitcnt vmcnt(0) at every join, and with a single register set the LDS writes
+// form a serial phase after the MFMAs; this way every wait is for data that has long landed and the scheduler is free to
+// spread the LDS writes among the MFMAs.
+template <int CO_T, int ROWS = 4>
 __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
                                                          int W, int Cin, int Cout, int relu) {
@@ -54,59 +58,60 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
   const int nchunks = Cin >> 3;
 
   // ---- staging assignment (fixed per thread) ----
-  // halo: item q -> pixel q>>1 (row-major in the 6x34 halo), half q&1
+  // halo: item q -> pixel q>>1 (row-major in the (ROWS+2) x 34 halo), half q&1
   int h_off[kHPerThread];
-  long h_src[kHPerThread];   // element offset inside one 8-channel block plane, or -1 when outside the image
+  long h_src[kHPerThread];
+  unsigned h_keep[kHPerThread];
 #pragma unroll
   for (int u = 0; u < kHPerThread; ++u) {
-    const int q = tid + u * NT;
-    h_off[u] = -1;
-    h_src[u] = -1;
-    if (q < kHaloVec) {
-      const int pix = q >> 1, half = q & 1;
-      const int r = pix / kHaloCols, c = pix - r * kHaloCols;
-      const int gh = h0 - 1 + r, gw = w0 - 1 + c;
-      h_off[u] = pix * kPixPitch + half * 4;
-      if (gh >= 0 && gh < H && gw >= 0 && gw < W) h_src[u] = ((long)gh * W + gw) * 8 + half * 4;
-    }
+    const int q = min(tid + u * NT, kHaloVec - 1);
+    const int pix = q >> 1, half = q & 1;
+    const int r = pix / kHaloCols, c = pix - r * kHaloCols;
+    const int gh = h0 - 1 + r, gw = w0 - 1 + c;
+    h_off[u] = pix * kPixPitch + half * 4;
+    h_src[u] = ((long)min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1)) * 8 + half * 4;
+    h_keep[u] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? 0xFFFFFFFFu : 0u;
   }
+  int w_idx[kWPerThread];
+#pragma unroll
+  for (int u = 0; u < kWPerThread; ++u) w_idx[u] = min(tid + u * NT, kWVec - 1);
   const long plane = (long)H * W * 8;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // NB: staging registers must be initialised, otherwise hipcc keeps the (conditionally written) arrays as allocas
-  // -> scratch / promote-alloca-to-LDS instead of VGPRs.
-  float4 rh[kHPerThread];
-  float4 rw[kWPerThread];
+  // NB: staging registers must be initialised, otherwise hipcc keeps the arrays as allocas -> scratch
+  struct Regs {
+    float4 h[kHPerThread];
+    float4 w[kWPerThread];
+  };
+  Regs R0, R1;
 #pragma unroll
-  for (int u = 0; u < kHPerThread; ++u) rh[u] = zero4;
+  for (int u = 0; u < kHPerThread; ++u) R0.h[u] = R1.h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int u = 0; u < kWPerThread; ++u) rw[u] = zero4;
+  for (int u = 0; u < kWPerThread; ++u) R0.w[u] = R1.w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load_chunk = [&](int c) {
+  auto load_chunk = [&](int c, Regs& G) {
+    c = min(c, nchunks - 1);
     const float* src = in + (long)c * plane;
 #pragma unroll
-    for (int u = 0; u < kHPerThread; ++u) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h_src[u] >= 0) v = *reinterpret_cast<const float4*>(src + h_src[u]);
-      rh[u] = v;
-    }
+    for (int u = 0; u < kHPerThread; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
     const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * Cout + co0) * kWPitch);
 #pragma unroll
-    for (int u = 0; u < kWPerThread; ++u) {
-      const int q = tid + u * NT;
-      if (q < kWVec) rw[u] = wsrc[q];
-    }
+    for (int u = 0; u < kWPerThread; ++u) G.w[u] = wsrc[w_idx[u]];
   };
-  auto store_chunk = [&](int buf) {
+  // live == false: the phantom block behind an odd block count -- its halo is stored as zeros, so it multiplies to nothing
+  auto store_chunk = [&](int buf, const Regs& G, bool live) {
 #pragma unroll
-    for (int u = 0; u < kHPerThread; ++u)
-      if (h_off[u] >= 0) *reinterpret_cast<float4*>(&s_halo[buf][h_off[u]]) = rh[u];
+    for (int u = 0; u < kHPerThread; ++u) {
+      const unsigned keep = live ? h_keep[u] : 0u;
+      float4 v = G.h[u];
+      v.x = __uint_as_float(__float_as_uint(v.x) & keep);
+      v.y = __uint_as_float(__float_as_uint(v.y) & keep);
+      v.z = __uint_as_float(__float_as_uint(v.z) & keep);
+      v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+      *reinterpret_cast<float4*>(&s_halo[buf][h_off[u]]) = v;
+    }
     float4* wdst = reinterpret_cast<float4*>(&s_w[buf][0]);
 #pragma unroll
-    for (int u = 0; u < kWPerThread; ++u) {
-      const int q = tid + u * NT;
-      if (q < kWVec) wdst[q] = rw[u];
-    }
+    for (int u = 0; u < kWPerThread; ++u) wdst[w_idx[u]] = G.w[u];
   };
 
   f32x16 acc[CO_T];
@@ -118,31 +123,19 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
   const int p_base = (wave * kHaloCols + j) * kPixPitch + kk * 4;   // + (kh*34 + kw)*12 per tap
   const int w_base = j * kWPitch + kk * 4;                          // + ct*32*76 + tap*8
 
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (ABL != 1 && ABL != 2 && ABL != 5) { if (c + 1 < nchunks) load_chunk(c + 1); }
+  auto multiply = [&](int buf) {
     const float* sh = s_halo[buf];
     const float* sw = s_w[buf];
-    if (ABL == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - kh * 3;
-      float4 p;
-      if (ABL == 5) { p = make_float4(1.f, 2.f, 3.f, 4.f); asm volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w)); }
-      else p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
+      const float4 p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
       float4 a[CO_T];
 #pragma unroll
-      for (int t = 0; t < CO_T; ++t) {
-        if (ABL == 5) { a[t] = make_float4(1.f, 2.f, 3.f, 4.f); asm volatile("" : "+v"(a[t].x), "+v"(a[t].y), "+v"(a[t].z), "+v"(a[t].w)); }
-        else a[t] = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
-      }
+      for (int t = 0; t < CO_T; ++t) a[t] = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
       // k-step outermost: consecutive MFMAs go to DIFFERENT accumulators (never two dependent MFMAs back to back);
       // with a single channel tile the k-steps alternate between two accumulators that are summed in the epilogue
       if (CO_T == 1) {
@@ -161,10 +154,22 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
         for (int t = 0; t < CO_T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, p.w, acc[t], 0, 0, 0);
       }
     }
-    if (ABL == 3) __builtin_amdgcn_s_setprio(0);
-    if (ABL == 0 || ABL == 3) { if (c + 1 < nchunks) store_chunk(buf ^ 1); }
-    if (ABL == 4) { asm volatile("" :: "v"(rh[0].x), "v"(rh[kHPerThread - 1].x), "v"(rw[0].x), "v"(rw[kWPerThread - 1].x)); }
-    if (ABL != 2 && ABL != 5) __syncthreads();
+  };
+  // block c sits in LDS[buf], block c+1 in `cur`, block c+2 is requested into `nxt`
+  auto step = [&](int c, int buf, Regs& cur, Regs& nxt) {
+    load_chunk(c + 2, nxt);
+    multiply(buf);
+    store_chunk(buf ^ 1, cur, c + 1 < nchunks);
+    __syncthreads();
+  };
+
+  load_chunk(0, R0);
+  store_chunk(0, R0, true);
+  load_chunk(1, R0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    step(c, 0, R0, R1);
+    step(c + 1, 1, R1, R0);        // for an odd block count the last call multiplies the zero-filled phantom block
   }
 
   // ---- epilogue: D[row = cout (reg&3)+8*(reg>>2)+4*kk][col = pixel j] ----
@@ -366,14 +371,7 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
   dim3 grid(tx, ty, Cout / (32 * co_t));
-  if (const char* e = getenv("MNC_CONV_ABL")) {
-    const int a = atoi(e);
-#define MNC_ABL_CASE(T, A) if (rows == 4 && co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, A, 4>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu); return ls.finish("conv3x3_c8_kernel"); }
-    MNC_ABL_CASE(1, 1) MNC_ABL_CASE(1, 2) MNC_ABL_CASE(1, 3) MNC_ABL_CASE(1, 4) MNC_ABL_CASE(1, 5)
-    MNC_ABL_CASE(2, 1) MNC_ABL_CASE(2, 2) MNC_ABL_CASE(2, 3) MNC_ABL_CASE(2, 4) MNC_ABL_CASE(2, 5)
-#undef MNC_ABL_CASE
-  }
-#define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, 0, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+#define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
   MNC_CONV_CASE(4, 1) MNC_CONV_CASE(4, 2) MNC_CONV_CASE(4, 4)
   MNC_CONV_CASE(8, 1) MNC_CONV_CASE(8, 2) MNC_CONV_CASE(8, 4)
 #undef MNC_CONV_CASE

@@ -119,7 +119,7 @@ int nms_scan_launch_indirect(hipStream_t stream, const unsigned long long* d_mas
                              int* d_keep, int* d_num);
 void proposal_state_free(void* state);  // proposal.hip
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
-              const int* d_starts, const float* d_wts, int H, int W, int R, int* d_bounds, float* d_out_mask,
-              int* d_out_box);
+              const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, int* d_bounds,
+              float* d_out_mask, int* d_out_box);
 
 }  // namespace mnc

@@ -19,10 +19,14 @@
 #include <functional>
 #include <mutex>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "mnc_internal.h"
 
 namespace mnc {
 
+constexpr int kMaxOrderDevice = 4096;   // boxes per class the LDS bitonic sort orders on the device (32 KB of keys)
 constexpr int kMaxCandLds = 1024;  // candidate descriptors staged in LDS per result (6 KB x 4); more -> chunked
 
 struct CandLds {
@@ -95,14 +99,14 @@ __device__ __forceinline__ int wave_max(int v) {
 // bounds: [R][4] = (min x, min y, max x, max y), pre-set to (INT_MAX, INT_MAX, -1, -1).
 __global__ __launch_bounds__(256) void mv_bounds_kernel(const float* __restrict__ boxes, int box_dim,
                                                         const float* __restrict__ masks, int S,
-                                                        const int* __restrict__ inds, const int* __restrict__ starts,
-                                                        const float* __restrict__ wts, int H, int W,
-                                                        int* __restrict__ bounds) {
+                                                        const int* __restrict__ inds, const int* __restrict__ begins,
+                                                        const int* __restrict__ ends, const float* __restrict__ wts,
+                                                        int H, int W, int* __restrict__ bounds) {
   __shared__ CandLds cl;
   __shared__ int red[4][4];
   __shared__ int ubox[4];
   const int r = blockIdx.x;
-  const int c0 = r == 0 ? 0 : starts[r - 1], c1 = starts[r];
+  const int c0 = begins[r], c1 = ends[r];
   const int nc = c1 - c0;
   if (nc <= 0) return;
   const bool in_lds = nc <= kMaxCandLds;
@@ -161,13 +165,13 @@ __global__ __launch_bounds__(256) void mv_bounds_kernel(const float* __restrict_
 // grid R, block 448 (7 waves; 441 active).  Finalises the box (defaults W/2, H/2, :149,:173) and resamples (:193-240).
 __global__ __launch_bounds__(448) void mv_resample_kernel(const float* __restrict__ boxes, int box_dim,
                                                           const float* __restrict__ masks, int S,
-                                                          const int* __restrict__ inds, const int* __restrict__ starts,
-                                                          const float* __restrict__ wts, int H, int W,
-                                                          const int* __restrict__ bounds, float* __restrict__ out_mask,
-                                                          int* __restrict__ out_box) {
+                                                          const int* __restrict__ inds, const int* __restrict__ begins,
+                                                          const int* __restrict__ ends, const float* __restrict__ wts,
+                                                          int H, int W, const int* __restrict__ bounds,
+                                                          float* __restrict__ out_mask, int* __restrict__ out_box) {
   __shared__ CandLds cl;
   const int r = blockIdx.x;
-  const int c0 = r == 0 ? 0 : starts[r - 1], c1 = starts[r];
+  const int c0 = begins[r], c1 = ends[r];
   const int nc = max(c1 - c0, 0);
   const bool in_lds = nc <= kMaxCandLds;
   if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
@@ -205,10 +209,100 @@ __global__ void mv_init_bounds_kernel(int* bounds, int R) {
   if (i < R * 4) bounds[i] = (i & 3) < 2 ? INT_MAX : -1;
 }
 
-// All pointers device.  d_bounds: R*4 ints scratch.
+// ---- device-side preparation of the voting problem (mask_transform.py:228-270) ------------------------------------
+// Per-class descending score order == np.argsort(-scores[:, c], kind="stable"): one workgroup per class sorts 64-bit keys
+// (orderable(-score) << 32 | index) with a bitonic network in LDS.  -0/+0 are one value (ties -> index order) and NaN sorts
+// last, as in numpy.
+__global__ __launch_bounds__(1024) void mv_order_kernel(const float* __restrict__ scores, int n, int C, int NP,
+                                                        int* __restrict__ order) {
+  extern __shared__ unsigned long long s_keys[];
+  const int c = blockIdx.x;
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      const float v = -scores[(long)i * C + c + 1] + 0.0f;
+      const unsigned u = __float_as_uint(v);
+      const unsigned o = (v != v) ? 0xFFFFFFFFu : (u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u));
+      k = ((unsigned long long)o << 32) | (unsigned)i;
+    }
+    s_keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        const int x = i ^ j;
+        if (x > i) {
+          const unsigned long long a = s_keys[i], b = s_keys[x];
+          if ((a > b) == ((i & k) == 0)) { s_keys[i] = b; s_keys[x] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) order[(long)c * n + i] = (int)(s_keys[i] & 0xFFFFFFFFu);
+}
+
+// keep lists index the sorted order; the host wants box indices: keepbox[c][k] = order[c][keep[c][k]]
+__global__ void mv_keepbox_kernel(const int* __restrict__ order, const int* __restrict__ keep, const int* __restrict__ num,
+                                  int n, int* __restrict__ keepbox) {
+  const int c = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < num[c]) keepbox[(long)c * n + k] = order[(long)c * n + keep[(long)c * n + k]];
+}
+
+// Candidate set of result row r = (kept box bi, class c): members {i : IoU_f64(box_i, box_bi) >= iou_thresh} in index order,
+// weights = class scores normalised by python's sequential float32 sum (mask_transform.py:253-270).  One wave per row;
+// row r owns cinds/cw[r*n .. r*n + n).
+__global__ __launch_bounds__(64) void mv_candidates_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                           int n, int C, const int* __restrict__ rows, float iou_thresh,
+                                                           int* __restrict__ cinds, float* __restrict__ cw,
+                                                           int* __restrict__ cbegin, int* __restrict__ cend) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int bi = rows[2 * r], c = rows[2 * r + 1];
+  const double q0 = boxes[bi * 4 + 0], q1 = boxes[bi * 4 + 1], q2 = boxes[bi * 4 + 2], q3 = boxes[bi * 4 + 3];
+  const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
+  int* my_inds = cinds + (long)r * n;
+  float* my_w = cw + (long)r * n;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    bool member = false;
+    if (i < n) {
+      const double b0 = boxes[i * 4 + 0], b1 = boxes[i * 4 + 1], b2 = boxes[i * 4 + 2], b3 = boxes[i * 4 + 3];
+      double ov = 0.0;
+      const double iw = (b2 < q2 ? b2 : q2) - (b0 > q0 ? b0 : q0) + 1;
+      if (iw > 0) {
+        const double ih = (b3 < q3 ? b3 : q3) - (b1 > q1 ? b1 : q1) + 1;
+        if (ih > 0) ov = iw * ih / ((b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih);
+      }
+      member = ov >= (double)iou_thresh;
+    }
+    const unsigned long long bal = __ballot(member);
+    if (member) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      my_inds[pos] = i;
+      my_w[pos] = scores[(long)i * C + c + 1];
+    }
+    base += __popcll(bal);
+  }
+  __syncthreads();
+  float sum = 0.0f;
+  if (lane == 0)
+    for (int t = 0; t < base; ++t) sum = t ? sum + my_w[t] : my_w[t];      // ((0 + w0) + w1) + ...  (0 + w0 is exact)
+  sum = __shfl(sum, 0);
+  __syncthreads();
+  for (int t = lane; t < base; t += 64) my_w[t] = my_w[t] / sum;
+  if (lane == 0) {
+    cbegin[r] = r * n;
+    cend[r] = r * n + base;
+  }
+}
+
+// All pointers device.  d_bounds: R*4 ints scratch.  Result r's candidates are d_inds/d_wts[d_begins[r] .. d_ends[r]).
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
-              const int* d_starts, const float* d_wts, int H, int W, int R, int* d_bounds, float* d_out_mask,
-              int* d_out_box) {
+              const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, int* d_bounds,
+              float* d_out_mask, int* d_out_box) {
   if (R <= 0) return MNC_OK;
   hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
   // ~2048 blocks in flight: R results x `splits` row slabs each
@@ -216,9 +310,9 @@ int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float
   if (splits < 1) splits = 1;
   if (splits > 32) splits = 32;
   hipLaunchKernelGGL(mv_bounds_kernel, dim3(R, splits), dim3(256), 0, stream, d_boxes, box_dim, d_masks, S, d_inds,
-                     d_starts, d_wts, H, W, d_bounds);
-  hipLaunchKernelGGL(mv_resample_kernel, dim3(R), dim3(448), 0, stream, d_boxes, box_dim, d_masks, S, d_inds, d_starts,
-                     d_wts, H, W, d_bounds, d_out_mask, d_out_box);
+                     d_begins, d_ends, d_wts, H, W, d_bounds);
+  hipLaunchKernelGGL(mv_resample_kernel, dim3(R), dim3(448), 0, stream, d_boxes, box_dim, d_masks, S, d_inds, d_begins,
+                     d_ends, d_wts, H, W, d_bounds, d_out_mask, d_out_box);
   return MNC_OK;
 }
 
@@ -249,7 +343,7 @@ int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, co
                 i, candidate_inds[i]);
   const int S = mask_size, R = result_num;
   const size_t b_boxes = align256((size_t)all_boxes_num * box_dim * 4), b_masks = align256((size_t)all_boxes_num * S * S * 4);
-  const size_t b_inds = align256((size_t)candidate_num * 4), b_wts = b_inds, b_starts = align256((size_t)R * 4);
+  const size_t b_inds = align256((size_t)candidate_num * 4), b_wts = b_inds, b_starts = align256((size_t)R * 8);
   const size_t b_bounds = align256((size_t)R * 16), b_omask = align256((size_t)R * S * S * 4), b_obox = align256((size_t)R * 16);
   LegacyWs* w = nullptr;
   int rc = legacy_ws(device_id, b_boxes + b_masks + b_inds + b_wts + b_starts + b_bounds + b_omask + b_obox, &w);
@@ -273,8 +367,12 @@ int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, co
     MNC_HIP_TRY(hipMemcpyAsync(d_inds, candidate_inds, (size_t)candidate_num * 4, hipMemcpyHostToDevice, s));
     MNC_HIP_TRY(hipMemcpyAsync(d_wts, candidate_weights, (size_t)candidate_num * 4, hipMemcpyHostToDevice, s));
   }
-  MNC_HIP_TRY(hipMemcpyAsync(d_starts, candidate_start, (size_t)R * 4, hipMemcpyHostToDevice, s));
-  mv_launch(s, d_boxes, box_dim, d_masks, S, d_inds, d_starts, d_wts, image_height, image_width, R, d_bounds, d_omask, d_obox);
+  std::vector<int> h_begins(R);              // candidate_start holds END offsets (gpu_mv.pyx / mv_kernel.cu:100)
+  for (int r = 0; r < R; ++r) h_begins[r] = r ? candidate_start[r - 1] : 0;
+  MNC_HIP_TRY(hipMemcpyAsync(d_starts, h_begins.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+  MNC_HIP_TRY(hipMemcpyAsync(d_starts + R, candidate_start, (size_t)R * 4, hipMemcpyHostToDevice, s));
+  mv_launch(s, d_boxes, box_dim, d_masks, S, d_inds, d_starts, d_starts + R, d_wts, image_height, image_width, R, d_bounds,
+            d_omask, d_obox);
   MNC_HIP_TRY(hipGetLastError());
   MNC_HIP_TRY(hipMemcpyAsync(out_mask, d_omask, (size_t)R * S * S * 4, hipMemcpyDeviceToHost, s));
   MNC_HIP_TRY(hipMemcpyAsync(out_box, d_obox, (size_t)R * 16, hipMemcpyDeviceToHost, s));
@@ -295,19 +393,22 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
   *result_num = 0;
   for (int c = 0; c < B; ++c) class_count[c] = 0;
   if (n == 0) { clear_error(); return MNC_OK; }
-  MNC_REQUIRE(boxes && masks && scores && order && out_mask && out_box && out_score, "mnc_mask_voting: null pointer");
-  for (long i = 0; i < (long)B * n; ++i)
-    MNC_REQUIRE(order[i] >= 0 && order[i] < n, "mnc_mask_voting: order[%ld]=%d out of range", i, order[i]);
+  MNC_REQUIRE(boxes && masks && scores && out_mask && out_box && out_score, "mnc_mask_voting: null pointer");
+  if (order)
+    for (long i = 0; i < (long)B * n; ++i)
+      MNC_REQUIRE(order[i] >= 0 && order[i] < n, "mnc_mask_voting: order[%ld]=%d out of range", i, order[i]);
   const int cb = cdiv(n, 64);
   const int keep_cap = max_per_image < n ? max_per_image : n;
   const int Rmax = B * keep_cap;
   const size_t b_boxes = align256((size_t)n * 16), b_masks = align256((size_t)n * S * S * 4), b_order = align256((size_t)B * n * 4);
+  const size_t b_scores = align256((size_t)n * num_classes * 4);
   const size_t b_bits = align256((size_t)B * n * cb * 8), b_keep = align256((size_t)B * n * 4), b_num = align256((size_t)B * 4);
-  const size_t b_cinds = align256((size_t)Rmax * n * 4), b_cw = b_cinds, b_cstart = align256((size_t)Rmax * 4);
+  const size_t b_cinds = align256((size_t)Rmax * n * 4), b_cw = b_cinds, b_rows = align256((size_t)Rmax * 8);
+  const size_t b_cse = align256((size_t)Rmax * 4);
   const size_t b_bounds = align256((size_t)Rmax * 16), b_omask = align256((size_t)Rmax * S * S * 4), b_obox = b_bounds;
   LegacyWs* w = nullptr;
-  int rc = legacy_ws(device_id, b_boxes + b_masks + b_order + b_bits + b_keep + b_num + b_cinds + b_cw + b_cstart + b_bounds +
-                                    b_omask + b_obox, &w);
+  int rc = legacy_ws(device_id, b_boxes + b_masks + b_order + b_scores + b_bits + 2 * b_keep + b_num + b_cinds + b_cw + b_rows +
+                                    2 * b_cse + b_bounds + b_omask + b_obox, &w);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(w->mu);
   hipStream_t s = w->stream;
@@ -315,72 +416,84 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
   float* d_boxes = (float*)p; p += b_boxes;
   float* d_masks = (float*)p; p += b_masks;
   int* d_order = (int*)p; p += b_order;
+  float* d_scores = (float*)p; p += b_scores;
   unsigned long long* d_bits = (unsigned long long*)p; p += b_bits;
   int* d_keep = (int*)p; p += b_keep;
+  int* d_keepbox = (int*)p; p += b_keep;
   int* d_num = (int*)p; p += b_num;
   int* d_cinds = (int*)p; p += b_cinds;
   float* d_cw = (float*)p; p += b_cw;
-  int* d_cstart = (int*)p; p += b_cstart;
+  int* d_rows = (int*)p; p += b_rows;
+  int* d_cbegin = (int*)p; p += b_cse;
+  int* d_cend = (int*)p; p += b_cse;
   int* d_bounds = (int*)p; p += b_bounds;
   float* d_omask = (float*)p; p += b_omask;
   int* d_obox = (int*)p;
 
-  // 1. the per-class NMS problems (mask_transform.py:228-240), batched; masks ride along on the same stream
+  const bool timing = getenv("MNC_MV_TIMING") != nullptr;      // diagnostic: host wall-clock of each phase on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3;
+  };
+  const auto t0 = now();
+  // 1. per-class score order + the per-class NMS problems (mask_transform.py:228-240), batched; kept lists come back as
+  //    box indices; the masks ride along on the same stream
   MNC_HIP_TRY(hipMemcpyAsync(d_boxes, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
-  MNC_HIP_TRY(hipMemcpyAsync(d_order, order, (size_t)B * n * 4, hipMemcpyHostToDevice, s));
+  MNC_HIP_TRY(hipMemcpyAsync(d_scores, scores, (size_t)n * num_classes * 4, hipMemcpyHostToDevice, s));
+  std::vector<int> h_order;
+  if (order) {
+    MNC_HIP_TRY(hipMemcpyAsync(d_order, order, (size_t)B * n * 4, hipMemcpyHostToDevice, s));
+  } else if (n <= kMaxOrderDevice) {
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(mv_order_kernel, dim3(B), dim3(np2 < 1024 ? np2 : 1024), (size_t)np2 * 8, s, d_scores, n, num_classes,
+                       np2, d_order);
+  } else {                                 // larger than the LDS sort: the same order on the host
+    h_order.resize((size_t)B * n);
+    for (int c = 0; c < B; ++c) {
+      int* o = h_order.data() + (size_t)c * n;
+      for (int i = 0; i < n; ++i) o[i] = i;
+      const float* sc = scores + c + 1;
+      std::stable_sort(o, o + n, [&](int a, int b) {
+        const float va = -sc[(size_t)a * num_classes], vb = -sc[(size_t)b * num_classes];
+        return va < vb || (vb != vb && va == va);              // NaN last, as numpy
+      });
+    }
+    MNC_HIP_TRY(hipMemcpyAsync(d_order, h_order.data(), (size_t)B * n * 4, hipMemcpyHostToDevice, s));
+  }
   nms_mask_launch(s, d_boxes, d_order, n, 4, nms_thresh, d_bits, B);
   nms_scan_launch(s, d_bits, n, keep_cap, d_keep, d_num, B);
+  hipLaunchKernelGGL(mv_keepbox_kernel, dim3(cdiv(keep_cap, 256), B), dim3(256), 0, s, d_order, d_keep, d_num, n, d_keepbox);
   MNC_HIP_TRY(hipGetLastError());
-  std::vector<int> h_keep((size_t)B * n), h_num(B);
+  std::vector<int> h_keepbox((size_t)B * n), h_num(B);
   MNC_HIP_TRY(hipMemcpyAsync(h_num.data(), d_num, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-  MNC_HIP_TRY(hipMemcpyAsync(h_keep.data(), d_keep, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipMemcpyAsync(h_keepbox.data(), d_keepbox, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
   MNC_HIP_TRY(hipMemcpyAsync(d_masks, masks, (size_t)n * S * S * 4, hipMemcpyHostToDevice, s));
   MNC_HIP_TRY(hipStreamSynchronize(s));
+  const auto t1 = now();
 
   // 2. global threshold = the max_per_image-th best kept score over all classes (:242-244)
   std::vector<float> pool;
   for (int c = 0; c < B; ++c)
-    for (int k = 0; k < h_num[c]; ++k) pool.push_back(scores[(size_t)order[(size_t)c * n + h_keep[(size_t)c * n + k]] * num_classes + c + 1]);
+    for (int k = 0; k < h_num[c]; ++k) pool.push_back(scores[(size_t)h_keepbox[(size_t)c * n + k] * num_classes + c + 1]);
   if (pool.empty()) { clear_error(); return MNC_OK; }
   std::vector<float> ranked(pool);
   const size_t kth = (ranked.size() < (size_t)max_per_image ? ranked.size() : (size_t)max_per_image) - 1;
   std::nth_element(ranked.begin(), ranked.begin() + kth, ranked.end(), std::greater<float>());
   const float thresh = ranked[kth];
 
-  // 3. candidate lists (:253-270): members = {i : IoU_f64(box_i, kept box) >= iou_thresh}, weights = class scores
-  //    normalised by python's sequential float32 sum
-  std::vector<int> cinds;
-  std::vector<float> cw;
-  std::vector<int> cstart;
+  // 3. result rows = kept boxes at or above the threshold, class-major in keep order (:253-258); their candidate sets
+  //    (:259-270) are built on the device
+  std::vector<int> rows;
   int R = 0;
   for (int c = 0; c < B; ++c) {
     int cnt = 0;
     for (int k = 0; k < h_num[c]; ++k) {
-      const int bi = order[(size_t)c * n + h_keep[(size_t)c * n + k]];
+      const int bi = h_keepbox[(size_t)c * n + k];
       const float sc = scores[(size_t)bi * num_classes + c + 1];
       if (!(sc >= thresh)) continue;
-      const double q0 = boxes[bi * 4 + 0], q1 = boxes[bi * 4 + 1], q2 = boxes[bi * 4 + 2], q3 = boxes[bi * 4 + 3];
-      const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
-      const size_t first = cinds.size();
-      float sum = 0.0f;
-      bool any = false;
-      for (int i = 0; i < n; ++i) {
-        const double b0 = boxes[i * 4 + 0], b1 = boxes[i * 4 + 1], b2 = boxes[i * 4 + 2], b3 = boxes[i * 4 + 3];
-        double ov = 0.0;
-        const double iw = (b2 < q2 ? b2 : q2) - (b0 > q0 ? b0 : q0) + 1;
-        if (iw > 0) {
-          const double ih = (b3 < q3 ? b3 : q3) - (b1 > q1 ? b1 : q1) + 1;
-          if (ih > 0) ov = iw * ih / ((b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih);
-        }
-        if (ov >= (double)iou_thresh) {
-          cinds.push_back(i);
-          const float wv = scores[(size_t)i * num_classes + c + 1];
-          sum = any ? sum + wv : wv;      // python: sum(w) == ((0 + w0) + w1) + ...  (0 + w0 is exact)
-          any = true;
-        }
-      }
-      for (size_t t = first; t < cinds.size(); ++t) cw.push_back(scores[(size_t)cinds[t] * num_classes + c + 1] / sum);
-      cstart.push_back((int)cinds.size());
+      rows.push_back(bi);
+      rows.push_back(c);
       out_score[R++] = sc;
       ++cnt;
     }
@@ -388,18 +501,21 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
   }
   *result_num = R;
   if (R == 0) { clear_error(); return MNC_OK; }
+  const auto t2 = now();
 
-  // 4. the fused mask-voting kernels
-  if (!cinds.empty()) {
-    MNC_HIP_TRY(hipMemcpyAsync(d_cinds, cinds.data(), cinds.size() * 4, hipMemcpyHostToDevice, s));
-    MNC_HIP_TRY(hipMemcpyAsync(d_cw, cw.data(), cw.size() * 4, hipMemcpyHostToDevice, s));
-  }
-  MNC_HIP_TRY(hipMemcpyAsync(d_cstart, cstart.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
-  mv_launch(s, d_boxes, 4, d_masks, S, d_cinds, d_cstart, d_cw, image_height, image_width, R, d_bounds, d_omask, d_obox);
+  // 4. candidate sets + the fused mask-voting kernels
+  MNC_HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), (size_t)R * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(mv_candidates_kernel, dim3(R), dim3(64), 0, s, d_boxes, d_scores, n, num_classes, d_rows, iou_thresh,
+                     d_cinds, d_cw, d_cbegin, d_cend);
+  mv_launch(s, d_boxes, 4, d_masks, S, d_cinds, d_cbegin, d_cend, d_cw, image_height, image_width, R, d_bounds, d_omask,
+            d_obox);
   MNC_HIP_TRY(hipGetLastError());
   MNC_HIP_TRY(hipMemcpyAsync(out_mask, d_omask, (size_t)R * S * S * 4, hipMemcpyDeviceToHost, s));
   MNC_HIP_TRY(hipMemcpyAsync(out_box, d_obox, (size_t)R * 16, hipMemcpyDeviceToHost, s));
   MNC_HIP_TRY(hipStreamSynchronize(s));
+  if (timing)
+    fprintf(stderr, "mnc_mask_voting: order+nms+copies %.0f us, threshold+rows %.0f us (R=%d), candidates+voting+copies %.0f us\n",
+            us(t0, t1), us(t1, t2), R, us(t2, now()));
   clear_error();
   return MNC_OK;
 }

@@ -55,9 +55,9 @@ def build_voting_candidates(boxes, scores, num_classes, max_per_image):
 
 
 def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
-    """The whole of gpu_mask_voting in one C-ABI call (mnc_mask_voting): batched per-class NMS, candidate sets and the
-    fused voting kernels, with no Python between the steps.  The per-class score orderings are still numpy's
-    `argsort()[::-1]`, so tie order is exactly the reference wrapper's."""
+    """The whole of gpu_mask_voting in one C-ABI call (mnc_mask_voting): per-class score order, batched per-class NMS,
+    candidate sets and the fused voting kernels, all on the device with no Python between the steps.  The per-class
+    order is np.argsort(-scores[:, c], kind="stable") (ties in index order), computed by the library."""
     import ctypes
     from mnc_amd import _lib
     n = boxes.shape[0]
@@ -66,16 +66,13 @@ def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_widt
     masks = np.ascontiguousarray(masks, dtype=np.float32)
     boxes = np.ascontiguousarray(boxes, dtype=np.float32)
     scores = np.ascontiguousarray(scores, dtype=np.float32)
-    order = np.empty((B, n), dtype=np.int32)
-    for c in range(B):
-        order[c] = np.argsort(-scores[:, c + 1], kind="stable")
     cap = B * min(max_per_image, n)
     out_mask = np.zeros((cap, 1, S, S), dtype=np.float32)
     out_box = np.zeros((cap, 4), dtype=np.int32)
     out_score = np.zeros(cap, dtype=np.float32)
     counts = np.zeros(B, dtype=np.int32)
     R = ctypes.c_int(0)
-    _lib.call("mnc_mask_voting", _lib.ptr(boxes), _lib.ptr(masks), _lib.ptr(scores), _lib.ptr(order), n, num_classes, S,
+    _lib.call("mnc_mask_voting", _lib.ptr(boxes), _lib.ptr(masks), _lib.ptr(scores), None, n, num_classes, S,
               int(max_per_image), float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH),
               int(im_height), int(im_width), _lib.ptr(out_mask), _lib.ptr(out_box), _lib.ptr(out_score),
               _lib.ptr(counts), ctypes.addressof(R), int(cfg.GPU_ID))

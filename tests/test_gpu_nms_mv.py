@@ -142,6 +142,39 @@ def test_fused_voting_equals_step_by_step_composition():
     assert np.array_equal(np.concatenate(small[1], 0), np.concatenate(osmall[1], 0))
 
 
+@pytest.mark.parametrize("n,seed", [(600, 1), (67, 2), (1500, 3), (4500, 4)])
+def test_fused_voting_device_order_ties_and_sizes(n, seed):
+    """The library orders each class on the device (LDS bitonic sort, n <= 4096) or on the host (larger n) exactly as
+    np.argsort(-s, kind="stable"): scores quantised to 1/16 (hundreds of exact ties per class), signed zeros, and sizes
+    on both sides of the sort's power-of-two padding and of the device/host switch.  Also: an explicit `order` argument
+    (the caller's own argsort) gives the same result as the library's."""
+    import ctypes
+    from mnc_amd import _lib
+    from oracle import host as ohost
+    from transform import mask_transform as mt
+    vc = GI.voting_case(n, 300, 400, seed)
+    scores = (np.round(vc["scores"] * 16) / 16).astype(np.float32)
+    scores[::7, 3] = -0.0
+    scores[1::7, 3] = 0.0
+    got = mt.gpu_mask_voting(vc["masks"], vc["boxes"], scores, 21, 100, 400, 300)
+    want = ohost.gpu_mask_voting(vc["masks"], vc["boxes"], scores, 21, 100, 400, 300)
+    assert [len(b) for b in got[1]] == [len(b) for b in want[1]]
+    assert np.array_equal(np.concatenate(got[1], 0), np.concatenate(want[1], 0))
+    # (rows whose member scores all quantise to 0 have weights 0/0 = NaN in the reference too: equal_nan)
+    assert np.array_equal(np.concatenate(got[0], 0), np.concatenate(want[0], 0), equal_nan=True)
+    order = np.stack([np.argsort(-scores[:, c + 1], kind="stable") for c in range(20)]).astype(np.int32)
+    cap = 20 * min(100, n)
+    om, ob, osc = np.zeros((cap, 1, 21, 21), np.float32), np.zeros((cap, 4), np.int32), np.zeros(cap, np.float32)
+    cnt, R = np.zeros(20, np.int32), ctypes.c_int(0)
+    boxes, masks = np.ascontiguousarray(vc["boxes"], np.float32), np.ascontiguousarray(vc["masks"], np.float32)
+    _lib.call("mnc_mask_voting", _lib.ptr(boxes), _lib.ptr(masks), _lib.ptr(scores), _lib.ptr(order), n, 21, 21, 100,
+              float(ohost.MASK_MERGE_NMS_THRESH), float(ohost.MASK_MERGE_IOU_THRESH), 300, 400, _lib.ptr(om), _lib.ptr(ob),
+              _lib.ptr(osc), _lib.ptr(cnt), ctypes.addressof(R), 0)
+    assert list(cnt) == [len(b) for b in want[1]]
+    assert np.array_equal(om[:R.value], np.concatenate(want[0], 0), equal_nan=True)
+    assert np.array_equal(ob[:R.value], np.concatenate(want[1], 0)[:, :4].astype(np.int32))
+
+
 def test_mv_many_candidates_and_properties():
     """Size-independent properties at BASELINE's 600 instances / 600x1000 canvas: (a) a result whose candidate list
     has > 1024 entries takes the global-memory path and still matches the oracle; (b) duplicating a result duplicates
