@@ -329,29 +329,17 @@ class Net(object):
     # ------------------------------------------------------------------------------------------------ weights
     @staticmethod
     def _read_weights(weights):
+        """dict {"<layer>": [W, b]} / {"<layer>/<i>": array}, or a path to .npz / .caffemodel / .caffemodel.h5 (the two
+        containers the reference loads, tools/demo.py:46-48; read by mnc_amd/caffemodel.py without protobuf / h5py)."""
         if isinstance(weights, dict):
             src = weights
         else:
-            path = str(weights)
-            if path.endswith(".npz"):
-                src = dict(np.load(path))
-            elif path.endswith((".h5", ".hdf5", ".caffemodel.h5")):
-                try:
-                    import h5py
-                except ImportError:
-                    raise RuntimeError("reading Caffe HDF5 weights needs h5py, which is not installed; convert the "
-                                       "file to .npz ('<layer>/0' = weights, '<layer>/1' = bias)")
-                src = {}
-                with h5py.File(path, "r") as f:
-                    for lname, grp in f["data"].items():
-                        for k, v in grp.items():
-                            src["%s/%s" % (lname, k)] = np.array(v)
-            else:
-                raise ValueError("unsupported weights container %r (use .npz or a dict)" % path)
+            from . import caffemodel
+            src = caffemodel.load_weights(weights)
         out = {}
         for k, v in src.items():
             if isinstance(v, (list, tuple)):
-                out[k] = [np.asarray(a, dtype=F32) for a in v]
+                out[k] = [None if a is None else np.asarray(a, dtype=F32) for a in v]
             else:
                 lname, idx = k.rsplit("/", 1)
                 out.setdefault(lname, [None, None])[int(idx)] = np.asarray(v, dtype=F32)
