@@ -1,0 +1,125 @@
+"""Test-time driver of the 5-stage MNC net over an image database (reference: lib/caffeWrapper/TesterWrapper.py:25-83,
+149-284: `seg` task = per-image forward -> un-scale/clip/concat of both stages -> gpu_mask_voting (or per-class NMS) ->
+res_boxes.pkl / res_masks.pkl -> imdb.evaluate_segmentation).  Python-3 port of the caller on the output side of the hot
+path; the `det`, `cfm` and `vis_seg` tasks belong to other graphs and are not provided."""
+import heapq
+import os
+import pickle
+
+import numpy as np
+
+import caffe
+from mnc_config import cfg, get_output_dir
+from nms.nms_wrapper import apply_nms_mask_single
+from transform.bbox_transform import clip_boxes
+from transform.mask_transform import gpu_mask_voting
+from utils.blob import im_list_to_blob, prep_im_for_blob
+from utils.image_io import imread
+from utils.timer import Timer
+
+
+class TesterWrapper(object):
+    def __init__(self, test_prototxt, imdb, test_model, task_name):
+        self.net = caffe.Net(test_prototxt, test_model, caffe.TEST)
+        self.net.name = os.path.splitext(os.path.basename(str(test_model)))[0] if not isinstance(test_model, dict) \
+            else self.net.name
+        self.imdb = imdb
+        self.output_dir = get_output_dir(imdb, self.net)
+        self.task_name = task_name
+        self.num_images = len(self.imdb.image_index)
+        self.num_classes = self.imdb.num_classes
+        self.max_per_set = 40 * self.num_images       # heuristic: 40 detections per class per image before NMS
+        self.max_per_image = 100                      # heuristic: at most 100 detections per class per image
+        if not os.path.exists(self.output_dir):
+            os.makedirs(self.output_dir)
+
+    def get_result(self):
+        det_file = os.path.join(self.output_dir, 'res_boxes.pkl')
+        seg_file = os.path.join(self.output_dir, 'res_masks.pkl')
+        if self.task_name != 'seg':
+            raise NotImplementedError("task %r: only 'seg' (MNC 5-stage inference) is on this path" % self.task_name)
+        if os.path.isfile(det_file) and os.path.isfile(seg_file):
+            with open(det_file, 'rb') as f:
+                seg_box = pickle.load(f)
+            with open(seg_file, 'rb') as f:
+                seg_mask = pickle.load(f)
+        else:
+            seg_box, seg_mask = self.get_segmentation_result()
+            with open(det_file, 'wb') as f:
+                pickle.dump(seg_box, f, pickle.HIGHEST_PROTOCOL)
+            with open(seg_file, 'wb') as f:
+                pickle.dump(seg_mask, f, pickle.HIGHEST_PROTOCOL)
+        print('Evaluating segmentation using MNC 5 stage inference')
+        return self.imdb.evaluate_segmentation(seg_box, seg_mask, self.output_dir)
+
+    def get_segmentation_result(self):
+        """all_boxes[cls][image] = [n,5] (x1,y1,x2,y2,score), all_masks[cls][image] = [n,1,21,21] float."""
+        thresh = -np.inf * np.ones(self.num_classes)          # adaptively raised by the max_per_set constraint
+        top_scores = [[] for _ in range(self.num_classes)]    # one min-heap of scores per class
+        all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
+        all_masks = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
+        _t = {'im_detect': Timer(), 'misc': Timer()}
+        for i in range(self.num_images):
+            im = imread(self.imdb.image_path_at(i))
+            _t['im_detect'].tic()
+            masks, boxes, seg_scores = self._segmentation_forward(im)
+            _t['im_detect'].toc()
+            if not cfg.TEST.USE_MASK_MERGE:
+                for j in range(1, self.num_classes):
+                    inds = np.where(seg_scores[:, j] > thresh[j])[0]
+                    cls_scores, cls_boxes, cls_masks = seg_scores[inds, j], boxes[inds, :], masks[inds, :]
+                    top_inds = np.argsort(-cls_scores)[:self.max_per_image]
+                    cls_scores, cls_boxes, cls_masks = cls_scores[top_inds], cls_boxes[top_inds, :], cls_masks[top_inds, :]
+                    for val in cls_scores:
+                        heapq.heappush(top_scores[j], val)
+                    if len(top_scores[j]) > self.max_per_set:
+                        while len(top_scores[j]) > self.max_per_set:
+                            heapq.heappop(top_scores[j])
+                        thresh[j] = top_scores[j][0]
+                    box_before_nms = np.hstack((cls_boxes, cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+                    mask_before_nms = cls_masks.astype(np.float32, copy=False)
+                    all_boxes[j][i], all_masks[j][i] = apply_nms_mask_single(box_before_nms, mask_before_nms, cfg.TEST.NMS)
+            else:
+                if not cfg.TEST.USE_GPU_MASK_MERGE:
+                    # the reference's cpu_mask_voting (mask_transform.py:142-211) is its CPU-only alternative; this
+                    # package has no CPU compute path
+                    raise NotImplementedError("cfg.TEST.USE_GPU_MASK_MERGE=False (cpu_mask_voting) is not provided")
+                result_mask, result_box = gpu_mask_voting(masks, boxes, seg_scores, self.num_classes,
+                                                          self.max_per_image, im.shape[1], im.shape[0])
+                for j in range(1, self.num_classes):      # no heap: voting never returns more than max_per_image
+                    all_boxes[j][i] = result_box[j - 1]
+                    all_masks[j][i] = result_mask[j - 1]
+            print('process image %d/%d, forward average time %f' % (i, self.num_images, _t['im_detect'].average_time))
+
+        for j in range(1, self.num_classes):
+            for i in range(self.num_images):
+                inds = np.where(all_boxes[j][i][:, -1] > thresh[j])[0]
+                all_boxes[j][i] = all_boxes[j][i][inds, :]
+                all_masks[j][i] = all_masks[j][i][inds]
+        return all_boxes, all_masks
+
+    def _segmentation_forward(self, im):
+        forward_kwargs, im_scales = self._prepare_mnc_args(im)
+        self.net.forward(**forward_kwargs)
+        rois_phase1 = self.net.blobs['rois'].data.copy()
+        masks_phase1 = self.net.blobs['mask_proposal'].data[...]
+        scores_phase1 = self.net.blobs['seg_cls_prob'].data[...]
+        rois_phase2 = self.net.blobs['rois_ext'].data[...]
+        masks_phase2 = self.net.blobs['mask_proposal_ext'].data[...]
+        scores_phase2 = self.net.blobs['seg_cls_prob_ext'].data[...]
+        # boxes are in the resized image's coordinates: un-scale, clip to the original image
+        rois_phase1, _ = clip_boxes(rois_phase1[:, 1:5] / im_scales[0], im.shape)
+        rois_phase2, _ = clip_boxes(rois_phase2[:, 1:5] / im_scales[0], im.shape)
+        masks = np.concatenate((masks_phase1, masks_phase2), axis=0)
+        boxes = np.concatenate((rois_phase1, rois_phase2), axis=0)
+        scores = np.concatenate((scores_phase1, scores_phase2), axis=0)
+        return masks, boxes, scores
+
+    def _prepare_mnc_args(self, im):
+        im, im_scale_factors = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
+        data = im_list_to_blob([im])
+        im_scales = [np.array(im_scale_factors)]
+        im_info = np.array([[data.shape[2], data.shape[3], im_scales[0]]], dtype=np.float32)
+        self.net.blobs['data'].reshape(*data.shape)
+        self.net.blobs['im_info'].reshape(*im_info.shape)
+        return {'data': data.astype(np.float32, copy=False), 'im_info': im_info.astype(np.float32, copy=False)}, im_scales

@@ -54,6 +54,26 @@ def build_voting_candidates(boxes, scores, num_classes, max_per_image):
             np.array(out_scores, dtype=np.float32), class_bar)
 
 
+def mask_overlap(box1, box2, mask1, mask2):
+    """Region IoU of two boolean masks that live inside different integer boxes (mask_transform.py:16-46; used by the
+    mAP^r evaluation, utils/voc_eval.py)."""
+    x1, y1 = max(box1[0], box2[0]), max(box1[1], box2[1])
+    x2, y2 = min(box1[2], box2[2]), min(box1[3], box2[3])
+    if x1 > x2 or y1 > y2:
+        return 0
+    w, h = x2 - x1 + 1, y2 - y1 + 1
+    ya, xa = y1 - box1[1], x1 - box1[0]
+    yb, xb = y1 - box2[1], x1 - box2[0]
+    inter_a = mask1[ya: ya + h, xa: xa + w]
+    inter_b = mask2[yb: yb + h, xb: xb + w]
+    assert inter_a.shape == inter_b.shape
+    inter = np.logical_and(inter_b, inter_a).sum()
+    union = mask1.sum() + mask2.sum() - inter
+    if union < 1.0:
+        return 0
+    return float(inter) / float(union)
+
+
 def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
     """The whole of gpu_mask_voting in one C-ABI call (mnc_mask_voting): per-class score order, batched per-class NMS,
     candidate sets and the fused voting kernels, all on the device with no Python between the steps.  The per-class

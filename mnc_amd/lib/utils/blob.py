@@ -4,7 +4,7 @@ import numpy as np
 
 
 def _linear_taps(n_dst, n_src, scale):
-    src = ((np.arange(n_dst, dtype=np.float64) + 0.5) / scale - 0.5).astype(np.float32)
+    src = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (1.0 / scale) - 0.5).astype(np.float32)   # OpenCV: scale = 1/inv_scale
     lo = np.floor(src).astype(np.int64)
     frac = (src - lo).astype(np.float32)
     under, over = lo < 0, lo >= n_src - 1
@@ -25,6 +25,21 @@ def resize_linear(im, fx, fy):
     one = np.float32(1.0)
     rows = im[:, x0] * (one - ax)[None, :, None] + im[:, x1] * ax[None, :, None]
     return (rows[y0] * (one - ay)[:, None, None] + rows[y1] * ay[:, None, None]).astype(np.float32)
+
+
+def resize_to(im, width, height):
+    """cv2.resize(im, (width, height)) (INTER_LINEAR) for a float32 HxW or HxWxC array: the scale is dst/src per axis."""
+    im = np.asarray(im, dtype=np.float32)
+    squeeze = im.ndim == 2
+    if squeeze:
+        im = im[:, :, None]
+    h, w = im.shape[:2]
+    x0, x1, ax = _linear_taps(int(width), w, float(width) / w)
+    y0, y1, ay = _linear_taps(int(height), h, float(height) / h)
+    one = np.float32(1.0)
+    rows = im[:, x0] * (one - ax)[None, :, None] + im[:, x1] * ax[None, :, None]
+    out = (rows[y0] * (one - ay)[:, None, None] + rows[y1] * ay[:, None, None]).astype(np.float32)
+    return out[:, :, 0] if squeeze else out
 
 
 def im_list_to_blob(ims):

@@ -184,6 +184,36 @@ def resize_bilinear_cv(im, fx, fy):
     return (rows[y0] * (np.float32(1.0) - ay) + rows[y1] * ay).astype(np.float32)
 
 
+
+def resize_bilinear_cv_to(im, width, height):
+    """cv2.resize(im, (width, height)) (INTER_LINEAR), 2-D or HxWxC float32: the dsize form used for masks
+    (lib/utils/voc_eval.py:241, lib/transform/mask_transform.py:160).  OpenCV derives the factors from the sizes,
+    inv_scale = dsize / ssize, and then proceeds as for explicit factors (resize_bilinear_cv above)."""
+    im = np.asarray(im, dtype=np.float32)
+    squeeze = im.ndim == 2
+    if squeeze:
+        im = im[:, :, None]
+    h, w = im.shape[:2]
+    fx, fy = float(width) / w, float(height) / h
+
+    def taps(n_dst, n_src, f):
+        src = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (1.0 / f) - 0.5).astype(np.float32)
+        i0 = np.floor(src).astype(np.int64)
+        frac = (src - i0).astype(np.float32)
+        lo = i0 < 0
+        frac[lo], i0[lo] = 0.0, 0
+        hi = i0 >= n_src - 1
+        frac[hi], i0[hi] = 0.0, n_src - 1
+        return i0, np.minimum(i0 + 1, n_src - 1), frac
+
+    x0, x1, ax = taps(int(width), w, fx)
+    y0, y1, ay = taps(int(height), h, fy)
+    ax, ay = ax[None, :, None], ay[:, None, None]
+    rows = im[:, x0, :] * (np.float32(1.0) - ax) + im[:, x1, :] * ax
+    out = (rows[y0] * (np.float32(1.0) - ay) + rows[y1] * ay).astype(np.float32)
+    return out[:, :, 0] if squeeze else out
+
+
 def prep_im_for_blob(im, pixel_means=PIXEL_MEANS, target_size=TEST_SCALE, max_size=MAX_SIZE):
     """lib/utils/blob.py:36-50: float32, subtract BGR means BEFORE resizing, scale = 600/min side capped so that
     round(scale*max side) <= 1000."""

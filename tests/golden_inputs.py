@@ -2,6 +2,8 @@
 the tests (which feed the same arrays to the oracle and to the HIP path).  numpy Generator streams are stable
 across numpy versions for the methods used here (uniform, normal, permutation, integers, choice).
 """
+import os
+
 import numpy as np
 
 # (n boxes, threshold, seed) -- SURVEY.md section 8(d) "unit-kernel synthetic inputs"
@@ -133,3 +135,81 @@ def detect_case(seed, R=40, H=600, W=1000):
     r2, m2, s2 = stage()
     return {"im": im, "blobs": {"rois": r1, "mask_proposal": m1, "seg_cls_prob": s1,
                                 "rois_ext": r2, "mask_proposal_ext": m2, "seg_cls_prob_ext": s2}}
+
+
+# ---- a synthetic VOCdevkitSDS (test_net.py --task seg + voc_eval_sds) --------------------------------
+SDS_IMAGES = [("syn_%03d" % i, 90 + 10 * (i % 3), 120 + 16 * (i % 4)) for i in range(6)]     # (name, H, W)
+
+
+def sds_case(seed=11):
+    """Per image: uint8 BGR pixels, an instance-id map and a class-id map (SBD's inst/ and cls/ .mat contents) with 1-3
+    rectangular / elliptic instances, plus scored predictions per class derived from the ground truth (jittered true
+    positives at several qualities, duplicates, and false positives)."""
+    rng = np.random.default_rng(seed)
+    case = {"images": [], "pred_boxes": None, "pred_masks": None}
+    nimg = len(SDS_IMAGES)
+    boxes = [[np.zeros((0, 5), np.float32) for _ in range(nimg)] for _ in range(21)]
+    masks = [[np.zeros((0, 1, 21, 21), np.float32) for _ in range(nimg)] for _ in range(21)]
+    yy, xx = np.mgrid[0:21, 0:21]
+    for ii, (name, H, W) in enumerate(SDS_IMAGES):
+        inst = np.zeros((H, W), np.uint8)
+        cls = np.zeros((H, W), np.uint8)
+        for k in range(1 + ii % 3):
+            w, h = int(rng.integers(20, 50)), int(rng.integers(20, 45))
+            x1, y1 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+            c = int(rng.integers(1, 6))                                 # classes 1..5 only: most classes have no GT
+            Y, X = np.mgrid[0:h, 0:w]
+            shape = np.ones((h, w), bool) if k % 2 == 0 else \
+                (((X - (w - 1) / 2.0) / (w / 2.0)) ** 2 + ((Y - (h - 1) / 2.0) / (h / 2.0)) ** 2 <= 1.0)
+            region = inst[y1:y1 + h, x1:x1 + w]
+            free = shape & (region == 0)
+            if free.sum() < 50:
+                continue
+            region[free] = k + 1
+            cls[y1:y1 + h, x1:x1 + w][free] = c
+            # predictions for this instance: a good one, a sloppy one (shifted), and a duplicate of the good one
+            for q, (dx, dy, sc) in enumerate([(1, -1, 0.9), (9, 7, 0.6), (0, 1, 0.5)]):
+                bx = np.array([x1 + dx, y1 + dy, x1 + w - 1 + dx, y1 + h - 1 + dy], np.float32)
+                bx[0::2] = np.clip(bx[0::2], 0, W - 1)
+                bx[1::2] = np.clip(bx[1::2], 0, H - 1)
+                score = np.float32(sc * rng.uniform(0.8, 1.0))
+                soft = np.full((21, 21), 0.8, np.float32) if k % 2 == 0 else \
+                    (0.9 - 0.9 * np.hypot((xx - 10) / 11.0, (yy - 10) / 11.0)).astype(np.float32).clip(0, 1) + 0.2
+                soft = (soft + rng.normal(0, 0.03, (21, 21))).astype(np.float32)
+                boxes[c][ii] = np.vstack([boxes[c][ii], np.append(bx, score)[None].astype(np.float32)])
+                masks[c][ii] = np.concatenate([masks[c][ii], soft[None, None]], 0)
+        for _ in range(2):                                              # false positives, one in a GT-free class
+            c = int(rng.integers(1, 9))
+            bx = _boxes(rng, 1, W, H, lo=10, hi=40)[0]
+            boxes[c][ii] = np.vstack([boxes[c][ii], np.append(bx, np.float32(rng.uniform(0.1, 0.95)))[None].astype(np.float32)])
+            masks[c][ii] = np.concatenate([masks[c][ii], rng.uniform(0, 1, (1, 1, 21, 21)).astype(np.float32)], 0)
+        case["images"].append({"name": name, "im": rng.integers(0, 256, (H, W, 3), dtype=np.uint8), "inst": inst, "cls": cls})
+    case["pred_boxes"], case["pred_masks"] = boxes, masks
+    return case
+
+
+def write_sds_devkit(root, case, image_set="val"):
+    """img/<name>.npy, inst/<name>.mat, cls/<name>.mat, <image_set>.txt under `root` (SBD's struct layout)."""
+    import scipy.io as sio
+    for d in ("img", "inst", "cls"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    for rec in case["images"]:
+        np.save(os.path.join(root, "img", rec["name"] + ".npy"), rec["im"])
+        sio.savemat(os.path.join(root, "inst", rec["name"] + ".mat"), {"GTinst": {"Segmentation": rec["inst"]}})
+        sio.savemat(os.path.join(root, "cls", rec["name"] + ".mat"), {"GTcls": {"Segmentation": rec["cls"]}})
+    with open(os.path.join(root, image_set + ".txt"), "w") as f:
+        f.write("".join(rec["name"] + "\n" for rec in case["images"]))
+
+
+def tester_net_outputs(case, seed=12, R=30):
+    """What a net would leave in its blobs for each image of the case (two stages of R rois in the RESIZED image's
+    coordinates, masks, class probabilities) -- the canned outputs of the fake net that drives TesterWrapper."""
+    outs = []
+    for ii, rec in enumerate(case["images"]):
+        H, W = rec["im"].shape[:2]
+        scale = min(600.0 / min(H, W), 1000.0 / max(H, W))
+        vc = voting_case(2 * R, H, W, seed + ii, n_obj=4)
+        rois = np.hstack([np.zeros((2 * R, 1), np.float32), vc["boxes"] * np.float32(scale)]).astype(np.float32)
+        outs.append({"rois": rois[:R], "mask_proposal": vc["masks"][:R], "seg_cls_prob": vc["scores"][:R],
+                     "rois_ext": rois[R:], "mask_proposal_ext": vc["masks"][R:], "seg_cls_prob_ext": vc["scores"][R:]})
+    return outs

@@ -240,3 +240,35 @@ def test_demo_pipeline_matches_oracle(full):
     assert [len(b) for b in lb] == [len(b) for b in ob]
     assert np.array_equal(np.concatenate(lb, 0), np.concatenate(ob, 0))
     assert np.array_equal(np.concatenate(lm, 0), np.concatenate(om, 0))
+
+
+def test_tester_wrapper_seg_task_on_device(small, tmp_path, monkeypatch):
+    """tools/test_net.py --task seg on a synthetic VOCdevkitSDS: the per-image loop drives the real engine
+    and the fused voting; image 0's result lists equal the oracle voting applied to the device's own outputs, and the
+    evaluation runs to a number."""
+    import golden_inputs
+    from caffeWrapper.TesterWrapper import TesterWrapper
+    from datasets.pascal_voc_seg import PascalVOCSeg
+    from mnc_config import cfg
+    from utils.image_io import imread
+    _, w = small
+    case = golden_inputs.sds_case()
+    root = str(tmp_path / "VOCdevkitSDS")
+    golden_inputs.write_sds_devkit(root, case)
+    monkeypatch.setattr(cfg, "ROOT_DIR", str(tmp_path))
+    imdb = PascalVOCSeg("val", "2012", root, image_ext=".npy")
+    t = TesterWrapper(models.write_mnc_5stage_test_prototxt(width_div=8), imdb, w, "seg")
+    try:
+        all_boxes, all_masks = t.get_segmentation_result()
+        assert len(all_boxes) == 21 and len(all_boxes[1]) == 6
+        im0 = imread(imdb.image_path_at(0))
+        masks, boxes, scores = t._segmentation_forward(im0)
+        assert masks.shape == (600, 1, 21, 21) and boxes.shape == (600, 4) and scores.shape == (600, 21)
+        om, ob = ohost.gpu_mask_voting(masks, boxes, scores, 21, 100, im0.shape[1], im0.shape[0])
+        for c in range(1, 21):
+            assert np.array_equal(all_boxes[c][0], ob[c - 1]) and np.array_equal(all_masks[c][0], om[c - 1])
+        with np.errstate(all="ignore"):
+            res = t.get_result()
+        assert len(res[0.5]) == 20 and len(res[0.7]) == 20
+    finally:
+        t.net.close()
