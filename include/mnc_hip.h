@@ -197,8 +197,10 @@ MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float
                    int N, int K, int ldc, int act);
 /* InnerProduct on the bf16 matrix pipe with fp32-class accuracy ("bf16x3": every operand split into hi + lo bf16, product =
  * a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; relative error ~1e-5 per product, see mnc_amd/csrc/gemm_x3.hip).
- * d_w_packed comes from mnc_pack_fc_bf16x3 (fp32 [N][K] -> [N][K/8][hi x8 | lo x8] bf16, N*K*4 bytes, K%8==0);
- * activations stay fp32.  Same contract as mnc_fc otherwise. */
+ * d_w_packed comes from mnc_pack_fc_bf16x3: fp32 [N][K] -> stage-major tiles [ceil(N/128)][K/32][128][(hi x8 | lo x8) x 4] bf16,
+ * ceil(N/128)*128*K*4 bytes (rows past N are zero), K%32==0 -- the weight panel a workgroup needs for one K stage is one
+ * contiguous 16 KB.  Activations are fp32 at the interface (split per call into the context's scratch arena).
+ * Same contract as mnc_fc otherwise. */
 MNC_API int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
 MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M,
                           int N, int K, int ldc, int act);

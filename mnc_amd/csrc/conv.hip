@@ -36,7 +36,9 @@ constexpr int kWPitch = 76;              // floats per weight row in LDS and in 
 // Conditional loads make hipcc wait with s_waitcnt vmcnt(0) at every join, and with a single register set the LDS writes
 // form a serial phase after the MFMAs; this way every wait is for data that has long landed and the scheduler is free to
 // spread the LDS writes among the MFMAs.
-template <int CO_T, int ROWS = 4>
+// ABL != 0: ablation builds for tuning (MNC_CONV_ABL, 4-row tiles only): 1 = no global loads / LDS stores in the loop,
+// 2 = additionally no barrier, 3 = additionally no LDS fragment reads (MFMAs on constant registers).
+template <int CO_T, int ROWS = 4, int ABL = 0>
 __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
                                                          int W, int Cin, int Cout, int relu) {
@@ -132,10 +134,18 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - kh * 3;
-      const float4 p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
+      float4 p;
       float4 a[CO_T];
+      if (ABL == 3) {
+        p = make_float4(1.f, 2.f, 3.f, 4.f);
+        asm volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w));
 #pragma unroll
-      for (int t = 0; t < CO_T; ++t) a[t] = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
+        for (int t = 0; t < CO_T; ++t) a[t] = p;
+      } else {
+        p = *reinterpret_cast<const float4*>(sh + p_base + (kh * kHaloCols + kw) * kPixPitch);
+#pragma unroll
+        for (int t = 0; t < CO_T; ++t) a[t] = *reinterpret_cast<const float4*>(sw + w_base + t * 32 * kWPitch + tap * 8);
+      }
       // k-step outermost: consecutive MFMAs go to DIFFERENT accumulators (never two dependent MFMAs back to back);
       // with a single channel tile the k-steps alternate between two accumulators that are summed in the epilogue
       if (CO_T == 1) {
@@ -157,10 +167,10 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
   };
   // block c sits in LDS[buf], block c+1 in `cur`, block c+2 is requested into `nxt`
   auto step = [&](int c, int buf, Regs& cur, Regs& nxt) {
-    load_chunk(c + 2, nxt);
+    if (ABL == 0) load_chunk(c + 2, nxt);
     multiply(buf);
-    store_chunk(buf ^ 1, cur, c + 1 < nchunks);
-    __syncthreads();
+    if (ABL == 0) store_chunk(buf ^ 1, cur, c + 1 < nchunks);
+    if (ABL < 2) __syncthreads();
   };
 
   load_chunk(0, R0);
@@ -363,7 +373,7 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   }
   if (const char* e = getenv("MNC_CONV_ROWS")) {
     const int v = atoi(e);
-    if (v == 4 || v == 8) best_rows = v;
+    if (v == 2 || v == 4 || v == 8) best_rows = v;
   }
   const int rows = best_rows, co_t = best_cot;
   const int tx = cdiv(W, kTileCols), ty = cdiv(H, rows);
@@ -371,7 +381,14 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
   dim3 grid(tx, ty, Cout / (32 * co_t));
+  if (const char* e = getenv("MNC_CONV_ABL")) {
+    const int a = atoi(e);
+#define MNC_ABL_CASE(T, A) if (rows == 4 && co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, 4, A>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu); return ls.finish("conv3x3_c8_kernel"); }
+    MNC_ABL_CASE(1, 1) MNC_ABL_CASE(1, 2) MNC_ABL_CASE(1, 3) MNC_ABL_CASE(2, 1) MNC_ABL_CASE(2, 2) MNC_ABL_CASE(2, 3)
+#undef MNC_ABL_CASE
+  }
 #define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+  MNC_CONV_CASE(2, 1) MNC_CONV_CASE(2, 2) MNC_CONV_CASE(2, 4)
   MNC_CONV_CASE(4, 1) MNC_CONV_CASE(4, 2) MNC_CONV_CASE(4, 4)
   MNC_CONV_CASE(8, 1) MNC_CONV_CASE(8, 2) MNC_CONV_CASE(8, 4)
 #undef MNC_CONV_CASE

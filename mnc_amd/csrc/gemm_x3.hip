@@ -8,12 +8,15 @@
 // 8 x 64).  At M = 300 that moves the FC layers from MFMA-bound to weight-streaming-bound.
 //
 // Same tiling as gemm.hip (320 rows x 128 columns x one K split per workgroup, 32-deep stages, one barrier per stage):
-//   * weights are split ONCE at load (mnc_pack_fc_bf16x3): [N][K/8][hi x8 | lo x8] bf16 -- 32 B per 8 values, the same
-//     bytes as fp32, so a stage's weight panel is still a linear 16 KB copy;
-//   * activations stay fp32 in HBM and are split while they are staged into LDS (v_cvt_pk_bf16_f32 + one subtract per
-//     value, hidden behind the MFMAs);
+//   * weights are split ONCE at load (mnc_pack_fc_bf16x3) into [N/128 column tiles][K/32 stages][128][hi x8 | lo x8 per
+//     8 values] bf16 -- 4 bytes per value like fp32, and a workgroup's weight panel of one stage is ONE contiguous 16 KB;
+//   * activations are fp32 at the interface and split once per call into the same [M][K/8][hi x8 | lo x8] form in the
+//     context's scratch arena (a 10 us elementwise pass; splitting them while staging cost more VALU time per stage than
+//     the 60 MFMAs it was meant to hide behind, 256 times over);
 //   * LDS rows are 4 groups x 32 B + 16 B pad (pitch 36 dwords, conflict-free ds_read_b128); lane (row, kb) of K-step ks
 //     reads group 2*ks + kb: hi and lo are two adjacent 16-byte fragments.
+#include <cstdlib>
+
 #include "mnc_internal.h"
 #include "x3_split.h"
 
@@ -32,13 +35,18 @@ __device__ __forceinline__ float x3_act(float v, int act) {
   return v;
 }
 
-template <int kMT>
-__global__ __launch_bounds__(256) void fc_x3_kernel(const float* __restrict__ A, const uint4* __restrict__ Wx,
+// kWR = waves along M: 1 -> a wave owns all kMT row tiles x one 32-column tile (2 + 2*kMT fragment reads per 3*kMT MFMAs);
+// 2 -> a wave owns kMT/2 row tiles x two column tiles (4 + kMT reads for the same MFMAs: 14 instead of 22 at kMT = 10 --
+// LDS fragment bandwidth, not the matrix pipe, is what bounds this kernel).
+// ABL != 0: ablation builds for tuning (MNC_FCX3_ABL): 1 = no global loads / LDS stores in the loop, 2 = additionally no
+// barrier, 3 = additionally no LDS fragment reads (MFMAs on constant registers).
+template <int kMT, int kWR, int ABL = 0>
+__global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax, const uint4* __restrict__ Wx,
                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                     float* __restrict__ part, int M, int N, int K, int ldc, int kper,
                                                     int act, int fused, int tn_, int splits_, int tm_) {
   constexpr int kBM = 32 * kMT;
-  constexpr int kAPer = (kBM * 4 + 255) / 256;          // 8-value groups of the A panel per thread
+  constexpr int kAPer = (kBM * 8 + 255) / 256;          // uint4 items of the (pre-split) A panel per thread and stage
   __shared__ __attribute__((aligned(16))) unsigned sA[2][kBM * kXPitch];
   __shared__ __attribute__((aligned(16))) unsigned sB[2][kXBN * kXPitch];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -50,37 +58,40 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const float* __restrict__ A,
   const int nstages = (kend - kbeg) / kXBK;
   const int mrows = min(M - m0, kBM);
   const int mtiles = (mrows + 31) >> 5;
-  const int groups_per_row = K >> 3;                    // uint4 pairs per weight row
 
-  // staging map.  A: item q -> row q>>2, group q&3 (8 floats = 2 float4).  B: item q -> row q>>3, uint4 q&7.
+  // staging map, the same for both operands: item q -> row q>>3, uint4 q&7 of the row's 128 bytes of this stage.  Both
+  // operands arrive pre-split AND stage-major, so a workgroup's panel of one stage is one contiguous run in memory (16 KB of
+  // weights, M x 128 B of activations): with row-major [N][K] weights a stage touched 128 rows 100 KB apart -- 128 DRAM
+  // pages / TLB entries for 16 KB -- and the 411 MB fc6 matrix streamed at 1.7 TB/s.
   // Every staging load/store below is UNCONDITIONAL (ragged items are clamped onto the last row and simply rewrite it):
   // a load under a branch makes hipcc lose its vmcnt bookkeeping and drain the whole prefetch pipeline with
   // s_waitcnt vmcnt(0) every stage.
-  const float* a_src[kAPer];
+  const uint4* a_src[kAPer];
   int a_dst[kAPer];
 #pragma unroll
   for (int u = 0; u < kAPer; ++u) {
-    const int q = tid + u * 256, r = min(q >> 2, kBM - 1), g = q & 3;
+    const int q = tid + u * 256, r = min(q >> 3, kBM - 1), c = q & 7;
     const int gr = m0 + min(r, mrows - 1);
-    a_src[u] = A + (long)gr * K + kbeg + g * 8;
-    a_dst[u] = r * kXPitch + g * 8;
+    a_src[u] = Ax + (((long)(kbeg / kXBK) * M + gr) << 3) + c;         // [stage][row][8]
+    a_dst[u] = r * kXPitch + c * 4;
   }
   const uint4* b_src[kXBPer];
   int b_dst[kXBPer];
 #pragma unroll
   for (int u = 0; u < kXBPer; ++u) {
     const int q = tid + u * 256, r = q >> 3, c = q & 7;
-    const int gr = min(n0 + r, N - 1);
-    b_src[u] = Wx + ((long)gr * groups_per_row + (kbeg >> 3)) * 2 + c;
+    b_src[u] = Wx + ((((long)bn * (K / kXBK) + kbeg / kXBK) * kXBN + r) << 3) + c;   // [column tile][stage][128][8]
     b_dst[u] = r * kXPitch + c * 4;
   }
+  const long a_step = (long)M << 3, b_step = (long)kXBN << 3;         // uint4 per stage
   // Two register sets (R0/R1): the loads of stage s+2 are in flight while stage s is multiplied and stage s+1 -- already
-  // in registers -- is split into bf16 hi/lo and written to the free LDS buffer.  One barrier per stage; the global-load
-  // latency gets a whole stage to hide and the VALU split / ds_write work overlaps the MFMAs instead of preceding them.
-  struct Regs { float4 a[kAPer][2]; uint4 b[kXBPer]; };
+  // in registers -- is written to the free LDS buffer.  One barrier per stage; the global-load latency gets a whole stage
+  // to hide.  The main loop has no VALU work besides addressing: splitting the activations here cost ~140 VALU
+  // instructions per thread and stage next to 60 MFMAs, and every one of the 256 workgroups re-split the same panel.
+  struct Regs { uint4 a[kAPer]; uint4 b[kXBPer]; };
   Regs R0, R1;
 #pragma unroll
-  for (int u = 0; u < kAPer; ++u) R0.a[u][0] = R0.a[u][1] = R1.a[u][0] = R1.a[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < kAPer; ++u) R0.a[u] = R1.a[u] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int u = 0; u < kXBPer; ++u) R0.b[u] = R1.b[u] = make_uint4(0, 0, 0, 0);
 
@@ -89,90 +100,152 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const float* __restrict__ A,
   // branch around the loads would leave the compiler unsure how many loads are outstanding at the join and it then
   // over-waits (s_waitcnt vmcnt(0..12) on the loads it has just issued).
   auto load_stage = [&](int s, Regs& R) {
-    const long off = (long)min(s, nstages - 1) * kXBK;
+    const long st = min(s, nstages - 1);
 #pragma unroll
-    for (int u = 0; u < kAPer; ++u) {
-      const float4* p = reinterpret_cast<const float4*>(a_src[u] + off);
-      R.a[u][0] = p[0];
-      R.a[u][1] = p[1];
-    }
+    for (int u = 0; u < kAPer; ++u) R.a[u] = a_src[u][st * a_step];
 #pragma unroll
-    for (int u = 0; u < kXBPer; ++u) R.b[u] = b_src[u][off >> 2];       // 32 values = 4 groups = 8 uint4 per row per stage
+    for (int u = 0; u < kXBPer; ++u) R.b[u] = b_src[u][st * b_step];
   };
   auto store_stage = [&](int buf, const Regs& R, bool live) {
     const unsigned keep = live ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int u = 0; u < kAPer; ++u) {
-      uint4 hi, lo;
-      x3_split8(R.a[u][0], R.a[u][1], hi, lo);
-      hi.x &= keep; hi.y &= keep; hi.z &= keep; hi.w &= keep;
-      lo.x &= keep; lo.y &= keep; lo.z &= keep; lo.w &= keep;
-      *reinterpret_cast<uint4*>(&sA[buf][a_dst[u]]) = hi;
-      *reinterpret_cast<uint4*>(&sA[buf][a_dst[u] + 4]) = lo;
+      uint4 v = R.a[u];
+      v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+      *reinterpret_cast<uint4*>(&sA[buf][a_dst[u]]) = v;
     }
 #pragma unroll
     for (int u = 0; u < kXBPer; ++u) *reinterpret_cast<uint4*>(&sB[buf][b_dst[u]]) = R.b[u];
   };
 
-  f32x16 acc[kMT];
+  constexpr int TR = kMT / kWR;                 // row tiles per wave
+  constexpr int TC = kWR;                       // 32-column tiles per wave (4 waves cover 128 columns)
+  static_assert(kMT % kWR == 0 && (kWR == 1 || kWR == 2), "wave grid");
+  const int wr = kWR == 1 ? 0 : wave >> 1;      // wave's position along M
+  const int wc = kWR == 1 ? wave : wave & 1;    // ... and along N
+  f32x16 acc[TR][TC];
 #pragma unroll
-  for (int t = 0; t < kMT; ++t)
+  for (int t = 0; t < TR; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int c = 0; c < TC; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
 
-  const int a_base = j * kXPitch + kb * 8;                       // + t*32*pitch + ks*16
-  const int b_base = (wave * 32 + j) * kXPitch + kb * 8;
-  auto kstep = [&](int buf, int ks) {
+  const int a_base = (wr * TR * 32 + j) * kXPitch + kb * 8;      // + t*32*pitch + ks*16
+  const int b_base = (wc * TC * 32 + j) * kXPitch + kb * 8;      // + c*32*pitch + ks*16
+  // Software pipeline (one wave per SIMD here, so nothing hides a stall but the wave's own MFMAs):
+  //   * the fragments of a K-step are read from LDS while the MFMAs of the PREVIOUS K-step run (two fragment sets, F0 / F1);
+  //   * the global loads of stage s+2 and the LDS writes of stage s+1 are issued during K-step 0 of stage s;
+  //   * the stage barrier sits between K-step 0 and K-step 1, so the first fragments of stage s+1 are prefetched during
+  //     K-step 1 of stage s and no LDS latency is exposed at the stage boundary;
+  //   * sched_group_barrier pins the interleave (2 MFMAs : 1 ds_read : 1 ds_write : 1 global load); left alone hipcc
+  //     clusters each class, and the ablation (MNC_FCX3_ABL) showed the three phases simply adding up:
+  //     MFMA 112 us + fragment reads 43 us + staging 90 us = 245 us for fc6.
+  struct Frags { bf16x8 ah[TR], al[TR], bh[TC], bl[TC]; };
+  auto read_frags = [&](int buf, int ks, Frags& f) {
     const unsigned* pa = sA[buf];
     const unsigned* pb = sB[buf];
-    union { uint4 u; bf16x8 v; } bh, bl;
-    bh.u = *reinterpret_cast<const uint4*>(pb + b_base + ks * 16);
-    bl.u = *reinterpret_cast<const uint4*>(pb + b_base + ks * 16 + 4);
-    // NO per-tile branch here: all kMT row tiles are always multiplied (rows past M hold clamped copies and are never
-    // stored).  A branch per tile splits the loop into basic blocks of 2 ds_reads + 3 MFMAs and exposes the full LDS
-    // latency 20 times per stage (measured: 7500 cycles per stage instead of ~2500).
+    if (ABL == 3) {
+      uint4 k = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      asm volatile("" : "+v"(k.x), "+v"(k.y), "+v"(k.z), "+v"(k.w));
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) {
-      union { uint4 u; bf16x8 v; } ah, al;
-      ah.u = *reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16);
-      al.u = *reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16 + 4);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[t], 0, 0, 0);
+      for (int c = 0; c < TC; ++c) f.bh[c] = f.bl[c] = x3_as_bf16x8(k);
+#pragma unroll
+      for (int t = 0; t < TR; ++t) f.ah[t] = f.al[t] = x3_as_bf16x8(k);
+      return;
+    }
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      f.bh[c] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pb + b_base + c * 32 * kXPitch + ks * 16));
+      f.bl[c] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pb + b_base + c * 32 * kXPitch + ks * 16 + 4));
+    }
+    // NO per-tile branch: all row tiles are always multiplied (rows past M hold clamped copies and are never stored)
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+      f.ah[t] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16));
+      f.al[t] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16 + 4));
     }
   };
-  // one pipeline step: stage s sits in LDS[buf], stage s+1 in `cur`, stage s+2 is requested into `nxt`
-  auto step = [&](int s, int buf, Regs& cur, Regs& nxt) {
-    load_stage(s + 2, nxt);
-    kstep(buf, 0);
-    store_stage(buf ^ 1, cur, s + 1 < nstages);
-    kstep(buf, 1);
-    __syncthreads();
+  auto mfmas = [&](const Frags& f) {                 // term outermost: consecutive MFMAs never share an accumulator
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[t], f.bh[c], acc[t][c], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bl[c], acc[t][c], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh[c], acc[t][c], 0, 0, 0);
+  };
+  // MFMAs have no side effects, so instruction selection is free to drift them across the barrier, which breaks the
+  // per-region counts below; an empty asm that "modifies" the accumulators (they live in AGPRs: no instruction results)
+  // keeps each K-step's MFMAs on its side.
+  auto pin_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) asm volatile("" : "+a"(acc[t][c]));
+  };
+  constexpr int kNFrag = 2 * (TR + TC), kNMfma = 3 * TR * TC;
+  constexpr int kNStage = kAPer + kXBPer;            // global loads (= LDS writes) per thread and stage
+  constexpr int kSlots = kNMfma / 2;                 // interleave slots of one K-step: 2 MFMAs each
+  // stage s sits in LDS[buf] and its K-step-0 fragments in f0; stage s+1 is in `cur`; stage s+2 is requested into `nxt`
+  auto step = [&](int s, int buf, Regs& cur, Regs& nxt, Frags& f0) {
+    Frags f1;
+    read_frags(buf, 1, f1);
+    if (ABL == 0) store_stage(buf ^ 1, cur, s + 1 < nstages);
+    if (ABL == 0) load_stage(s + 2, nxt);
+    mfmas(f0);
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (ABL != 3 && i < kNFrag) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (ABL == 0 && i < kNStage) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if (ABL == 0 && i < kNStage) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    pin_acc();
+    if (ABL < 2) __syncthreads();
+    read_frags(buf ^ 1, 0, f0);                      // K-step 0 of the next stage (of the zero-filled phantom at the end)
+    mfmas(f1);
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      if (ABL != 3 && i < kNFrag) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    pin_acc();
   };
 
   if (nstages > 0) {
+    Frags F0;
     load_stage(0, R0);
     store_stage(0, R0, true);
     load_stage(1, R0);
     __syncthreads();
+    read_frags(0, 0, F0);
     for (int s = 0; s < nstages; s += 2) {
-      step(s, 0, R0, R1);
-      step(s + 1, 1, R1, R0);       // for an odd stage count the last call multiplies the zero-filled phantom stage
+      step(s, 0, R0, R1, F0);
+      step(s + 1, 1, R1, R0, F0);   // for an odd stage count the last call multiplies the zero-filled phantom stage
     }
   }
 
-  const int n = n0 + wave * 32 + j;
-  if (n < N) {
+#pragma unroll
+  for (int c = 0; c < TC; ++c) {
+    const int n = n0 + (wc * TC + c) * 32 + j;
+    if (n >= N) continue;
     const float bv = fused ? bias[n] : 0.f;
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) {
-      if (t < mtiles) {
+    for (int t = 0; t < TR; ++t) {
+      const int tile = wr * TR + t;
+      if (tile < mtiles) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
+          const int m = m0 + tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
           if (m < M) {
-            if (fused) out[(long)m * ldc + n] = x3_act(acc[t][e] + bv, act);
-            else part[((long)split * M + m) * N + n] = acc[t][e];
+            if (fused) out[(long)m * ldc + n] = x3_act(acc[t][c][e] + bv, act);
+            else part[((long)split * M + m) * N + n] = acc[t][c][e];
           }
         }
       }
@@ -193,17 +266,39 @@ __global__ __launch_bounds__(256) void fc_x3_reduce_kernel(const float* __restri
   }
 }
 
-// fp32 [N][K] -> [N][K/8][hi x8 | lo x8]
-__global__ void pack_x3_kernel(const float* __restrict__ in, uint4* __restrict__ out, long groups) {
-  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x) {
-    const float4* p = reinterpret_cast<const float4*>(in + g * 8);
-    const float4 a = p[0], b = p[1];
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint4 hi, lo;
-    x3_split8_rne(x, hi, lo);
-    out[g * 2] = hi;
-    out[g * 2 + 1] = lo;
+// fp32 row-major [rows][K] -> split bf16, stage-major: out[((tile * S + s) * tile_rows + r) * 8 + 2*g + {hi, lo}] with
+// row = tile * tile_rows + r, S = K/32 stages, g = 8-value group inside the stage.  Rows >= rows (padding of the last
+// tile) are written as zeros.  Weights: tile_rows = 128 (column tiles of the GEMM).  Activations: one tile of `rows` rows.
+__global__ void pack_x3_kernel(const float* __restrict__ in, uint4* __restrict__ out, int rows, int K, int tile_rows,
+                               int tiles) {
+  const int S = K / kXBK;
+  const long total = (long)tiles * S * tile_rows * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i & 3);
+    long t = i >> 2;
+    const int r = (int)(t % tile_rows);
+    t /= tile_rows;
+    const int st = (int)(t % S);
+    const int tile = (int)(t / S);
+    const long row = (long)tile * tile_rows + r;
+    uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
+    if (row < rows) {
+      const float4* p = reinterpret_cast<const float4*>(in + row * K + st * kXBK + g * 8);
+      const float4 a = p[0], b = p[1];
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      x3_split8_rne(x, hi, lo);
+    }
+    out[i * 2] = hi;
+    out[i * 2 + 1] = lo;
   }
+}
+
+static int x3_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles) {
+  const long total = (long)tiles * (K / kXBK) * tile_rows * 4;
+  long g = (total + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, rows, K, tile_rows, tiles);
+  return MNC_OK;
 }
 
 }  // namespace mnc
@@ -213,12 +308,9 @@ using namespace mnc;
 extern "C" {
 
 int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K) {
-  MNC_REQUIRE(ctx && d_w && d_packed && N > 0 && K > 0 && K % 8 == 0, "mnc_pack_fc_bf16x3: bad argument (K%%8==0)");
+  MNC_REQUIRE(ctx && d_w && d_packed && N > 0 && K > 0 && K % kXBK == 0, "mnc_pack_fc_bf16x3: bad argument (K%%32==0)");
   LaunchScope ls(ctx, "pack_fc_bf16x3");
-  const long groups = (long)N * (K / 8);
-  long g = (groups + 255) / 256;
-  if (g > 65536) g = 65536;
-  hipLaunchKernelGGL(pack_x3_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_w, (uint4*)d_packed, groups);
+  x3_pack_launch(ctx, d_w, (uint4*)d_packed, N, K, kXBN, cdiv(N, kXBN));
   return ls.finish("pack_x3_kernel");
 }
 
@@ -239,25 +331,40 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
   if (splits < 1) splits = 1;
   const int kper = cdiv(stages, splits) * kXBK;
   splits = cdiv(K, kper);
-  float* part = nullptr;
-  if (splits > 1) {
-    int rc = ensure_scratch(ctx, (size_t)splits * M * N * 4);
+  // scratch arena: [split-K partials | the activations split into hi/lo bf16 (same bytes as fp32)]
+  const size_t part_bytes = splits > 1 ? (((size_t)splits * M * N * 4 + 255) & ~(size_t)255) : 0;
+  int rc = ensure_scratch(ctx, part_bytes + (size_t)M * K * 4);
+  if (rc) return rc;
+  float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
+  uint4* d_ax = (uint4*)((char*)ctx->scratch + part_bytes);
+  {
+    // split once per call, not once per workgroup and stage
+    LaunchScope ls(ctx, "fc_bf16x3_split", 0.0, 8.0 * M * (double)K);
+    x3_pack_launch(ctx, d_a, d_ax, M, K, M, 1);
+    rc = ls.finish("pack_x3_kernel");
     if (rc) return rc;
-    part = (float*)ctx->scratch;
   }
   const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
   {
     LaunchScope ls(ctx, small ? "fc_bf16x3_small" : "fc_bf16x3", flops, bytes);
     if (mt == 2)
-      hipLaunchKernelGGL(fc_x3_kernel<2>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, (const uint4*)d_w_packed,
+      hipLaunchKernelGGL((fc_x3_kernel<2, 2>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax, (const uint4*)d_w_packed,
                          d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
     else if (mt == 5)
-      hipLaunchKernelGGL(fc_x3_kernel<5>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, (const uint4*)d_w_packed,
+      hipLaunchKernelGGL((fc_x3_kernel<5, 1>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax, (const uint4*)d_w_packed,
                          d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    else
-      hipLaunchKernelGGL(fc_x3_kernel<10>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, (const uint4*)d_w_packed,
-                         d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    int rc = ls.finish("fc_x3_kernel");
+    else {
+      const char* e = getenv("MNC_FCX3_ABL");
+      const int abl = e ? atoi(e) : 0;
+#define MNC_X3_CASE(A) hipLaunchKernelGGL((fc_x3_kernel<10, 2, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax, \
+                         (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
+      if (abl == 1) MNC_X3_CASE(1);
+      else if (abl == 2) MNC_X3_CASE(2);
+      else if (abl == 3) MNC_X3_CASE(3);
+      else MNC_X3_CASE(0);
+#undef MNC_X3_CASE
+    }
+    rc = ls.finish("fc_x3_kernel");
     if (rc) return rc;
   }
   if (splits > 1) {

@@ -7,7 +7,8 @@
 //
 // Layouts: conv5_3 in c8 [C/8][H][W][8]; per-RoI features [R][PH][PW][C] -- one RoI is one K-contiguous GEMM row, and
 // every kernel below reads/writes 16-byte vectors along C.  All of this is HBM/L2-bound gather/elementwise work: no LDS
-// staging is needed because conv5_3 (4.9 MB at 600x1000) stays L2/Infinity-Cache resident across the 300 RoIs.
+// staging is needed because conv5_3 (4.9 MB at 600x1000) stays L2/Infinity-Cache resident across the 300 RoIs; ROIWarping
+// first re-lays it out pixel-major so that every bilinear tap of a wave is one contiguous kilobyte.
 #include "mnc_internal.h"
 
 namespace mnc {
@@ -17,42 +18,53 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
   return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
-// One bilinear sample of an 8-channel block at feature-map position (sx, sy); taps outside the map contribute 0.
-// SPEC.md section 1: w00*f00 + w01*f01 + w10*f10 + w11*f11 in that order.
-__device__ __forceinline__ void warp_sample(const float* __restrict__ plane, int H, int W, float sx, float sy, float4& o0,
-                                            float4& o1) {
+// conv5_3 c8 [C/8][H][W][8] -> pixel-major [H][W][C]: the gather below reads whole pixels (all C channels of a tap are one
+// contiguous run), which c8 scatters over C/8 planes.  4.9 MB at 600x1000: the transposition costs a few microseconds.
+__global__ __launch_bounds__(256) void c8_to_hwc_kernel(const float* __restrict__ in, float* __restrict__ out, int CB,
+                                                        long HW) {
+  const long total = HW * CB * 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int half = (int)(idx & 1);
+    const long t = idx >> 1;
+    const int cb = (int)(t % CB);
+    const long p = t / CB;
+    *reinterpret_cast<float4*>(out + (p * CB + cb) * 8 + half * 4) = ld4(in + ((long)cb * HW + p) * 8 + half * 4);
+  }
+}
+
+// One bilinear sample of 4 channels at feature-map position (sx, sy); taps outside the map contribute 0.
+// SPEC.md section 1: w00*f00 + w01*f01 + w10*f10 + w11*f11 in that order.  `px` = hwc feature map + the lane's channel offset.
+__device__ __forceinline__ float4 warp_sample(const float* __restrict__ px, int H, int W, int C, float sx, float sy) {
   const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
   const float ax = sx - (float)x0, ay = sy - (float)y0;
   const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
   const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
   const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* p00 = plane + ((long)y0 * W + x0) * 8;
-  const float4 a00 = (vy0 && vx0) ? ld4(p00) : z, b00 = (vy0 && vx0) ? ld4(p00 + 4) : z;
-  const float4 a01 = (vy0 && vx1) ? ld4(p00 + 8) : z, b01 = (vy0 && vx1) ? ld4(p00 + 12) : z;
-  const float* p10 = p00 + (long)W * 8;
-  const float4 a10 = (vy1 && vx0) ? ld4(p10) : z, b10 = (vy1 && vx0) ? ld4(p10 + 4) : z;
-  const float4 a11 = (vy1 && vx1) ? ld4(p10 + 8) : z, b11 = (vy1 && vx1) ? ld4(p10 + 12) : z;
+  const float* p00 = px + ((long)y0 * W + x0) * C;
+  const float4 a00 = (vy0 && vx0) ? ld4(p00) : z;
+  const float4 a01 = (vy0 && vx1) ? ld4(p00 + C) : z;
+  const float* p10 = p00 + (long)W * C;
+  const float4 a10 = (vy1 && vx0) ? ld4(p10) : z;
+  const float4 a11 = (vy1 && vx1) ? ld4(p10 + C) : z;
 #define MNC_BL(f) (w00 * a00.f + w01 * a01.f + w10 * a10.f + w11 * a11.f)
-  o0 = make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
-#undef MNC_BL
-#define MNC_BL(f) (w00 * b00.f + w01 * b01.f + w10 * b10.f + w11 * b11.f)
-  o1 = make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
+  return make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
 #undef MNC_BL
 }
 
-// thread = (roi, ph, pw, channel block); channel block fastest -> a wave writes 64 x 32 B contiguous.
+// thread = (roi, ph, pw, 4-channel group); channels fastest -> a wave reads 1 KB contiguous per tap and writes 1 KB.
 // SPEC-CHOICE (SPEC.md 1): un-rounded edges x*scale; roi_w = max(x2s-x1s+1, 1); bin = roi_w/PWs; sample at x1s + pw*bin.
 // POOL2: the warp grid is (2PH)x(2PW) and each output is the max of its 2x2 samples (the fused Pooling layer).
 template <int POOL2>
-__global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__ feat, int CB, int H, int W,
+__global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
                                                        const float* __restrict__ rois, int R, int PH, int PW, float scale,
                                                        float* __restrict__ out) {
-  const long total = (long)R * PH * PW * CB;
+  const int C4 = C >> 2;
+  const long total = (long)R * PH * PW * C4;
   const int GH = POOL2 ? 2 * PH : PH, GW = POOL2 ? 2 * PW : PW;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int cb = (int)(idx % CB);
-    long t = idx / CB;
+    const int c4 = (int)(idx % C4);
+    long t = idx / C4;
     const int pw = (int)(t % PW);
     t /= PW;
     const int ph = (int)(t % PH);
@@ -61,23 +73,17 @@ __global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__
     const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
     const float rw = fmaxf(x2s - x1s + 1.0f, 1.0f), rh = fmaxf(y2s - y1s + 1.0f, 1.0f);
     const float bw = rw / (float)GW, bh = rh / (float)GH;
-    const float* plane = feat + (long)cb * H * W * 8;
-    float4 o0, o1;
+    const float* px = feat_hwc + c4 * 4;
+    float4 o;
     if (POOL2) {
-      float4 m0, m1;
-      warp_sample(plane, H, W, x1s + (float)(2 * pw) * bw, y1s + (float)(2 * ph) * bh, m0, m1);
-      warp_sample(plane, H, W, x1s + (float)(2 * pw + 1) * bw, y1s + (float)(2 * ph) * bh, o0, o1);
-      m0 = max4(m0, o0); m1 = max4(m1, o1);
-      warp_sample(plane, H, W, x1s + (float)(2 * pw) * bw, y1s + (float)(2 * ph + 1) * bh, o0, o1);
-      m0 = max4(m0, o0); m1 = max4(m1, o1);
-      warp_sample(plane, H, W, x1s + (float)(2 * pw + 1) * bw, y1s + (float)(2 * ph + 1) * bh, o0, o1);
-      o0 = max4(m0, o0); o1 = max4(m1, o1);
+      o = warp_sample(px, H, W, C, x1s + (float)(2 * pw) * bw, y1s + (float)(2 * ph) * bh);
+      o = max4(o, warp_sample(px, H, W, C, x1s + (float)(2 * pw + 1) * bw, y1s + (float)(2 * ph) * bh));
+      o = max4(o, warp_sample(px, H, W, C, x1s + (float)(2 * pw) * bw, y1s + (float)(2 * ph + 1) * bh));
+      o = max4(o, warp_sample(px, H, W, C, x1s + (float)(2 * pw + 1) * bw, y1s + (float)(2 * ph + 1) * bh));
     } else {
-      warp_sample(plane, H, W, x1s + (float)pw * bw, y1s + (float)ph * bh, o0, o1);
+      o = warp_sample(px, H, W, C, x1s + (float)pw * bw, y1s + (float)ph * bh);
     }
-    float* dst = out + idx * 8;     // == (((r*PH + ph)*PW + pw)*C + cb*8)
-    *reinterpret_cast<float4*>(dst) = o0;
-    *reinterpret_cast<float4*>(dst + 4) = o1;
+    *reinterpret_cast<float4*>(out + idx * 4) = o;      // == (((r*PH + ph)*PW + pw)*C + c4*4)
   }
 }
 
@@ -191,15 +197,26 @@ int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const f
   MNC_REQUIRE(ctx && d_feat && d_out && (R == 0 || d_rois), "mnc_roi_warp: null pointer");
   MNC_REQUIRE(C > 0 && C % 8 == 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "mnc_roi_warp: bad shape");
   if (R == 0) return MNC_OK;
-  const long total = (long)R * PH * PW * (C / 8);
+  const long total = (long)R * PH * PW * (C / 4);
   const double samples = pool2 ? 4.0 : 1.0;
+  // pixel-major copy of the feature map in the context's scratch arena (same stream: ordered after any earlier user)
+  int rc = ensure_scratch(ctx, (size_t)C * H * W * 4);
+  if (rc) return rc;
+  float* d_hwc = (float*)ctx->scratch;
+  {
+    LaunchScope lt(ctx, "c8_to_hwc", 0.0, 8.0 * C * (double)H * W);
+    hipLaunchKernelGGL(c8_to_hwc_kernel, dim3(grid_for((long)H * W * (C / 8) * 2)), dim3(256), 0, ctx->stream, d_feat, d_hwc,
+                       C / 8, (long)H * W);
+    rc = lt.finish("c8_to_hwc_kernel");
+    if (rc) return rc;
+  }
   LaunchScope ls(ctx, pool2 ? "roi_warp_pool2" : "roi_warp", 0.0, 4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)));
   if (pool2)
-    hipLaunchKernelGGL(roi_warp_kernel<1>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, C / 8, H, W, d_rois, R,
-                       PH, PW, scale, d_out);
+    hipLaunchKernelGGL(roi_warp_kernel<1>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH,
+                       PW, scale, d_out);
   else
-    hipLaunchKernelGGL(roi_warp_kernel<0>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, C / 8, H, W, d_rois, R,
-                       PH, PW, scale, d_out);
+    hipLaunchKernelGGL(roi_warp_kernel<0>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH,
+                       PW, scale, d_out);
   return ls.finish("roi_warp_kernel");
 }
 

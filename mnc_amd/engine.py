@@ -615,7 +615,7 @@ class Net(object):
             def finish(d_w):
                 if not x3:
                     return d_w
-                packed = self._ctx.alloc(W.nbytes)
+                packed = self._ctx.alloc((n_out + 127) // 128 * 128 * K * 4)
                 _lib.call("mnc_pack_fc_bf16x3", self._h(), d_w, packed, n_out, K)
                 self._ctx.free(d_w)
                 return packed

@@ -187,17 +187,22 @@ class Fake(object):
             full[m * ldc: m * ldc + N] = y[m]
 
     def mnc_pack_fc_bf16x3(self, h, src, dst, N, K):
-        w = _f(src, (N, K // 8, 8))
-        hi = (w.view(np.uint32) & 0xFFFF0000).view(np.float32)
+        T, S = (N + 127) // 128, K // 32
+        w = np.zeros((T * 128, K), np.float32)
+        w[:N] = _f(src, (N, K))
+        w = w.reshape(T, 128, S, 4, 8).transpose(0, 2, 1, 3, 4)                      # [tile][stage][row][group][8]
+        hi = (np.ascontiguousarray(w).view(np.uint32) & 0xFFFF0000).view(np.float32)
         lo = (((w - hi).view(np.uint32) + 0x8000) & 0xFFFF0000).view(np.float32)
-        out = np.ctypeslib.as_array(ctypes.cast(dst, ctypes.POINTER(ctypes.c_uint16)), (N, K // 8, 2, 8))
-        out[:, :, 0, :] = (hi.view(np.uint32) >> 16).astype(np.uint16)
-        out[:, :, 1, :] = (lo.view(np.uint32) >> 16).astype(np.uint16)
+        out = np.ctypeslib.as_array(ctypes.cast(dst, ctypes.POINTER(ctypes.c_uint16)), (T, S, 128, 4, 2, 8))
+        out[..., 0, :] = (hi.view(np.uint32) >> 16).astype(np.uint16)
+        out[..., 1, :] = (lo.view(np.uint32) >> 16).astype(np.uint16)
 
     def mnc_fc_bf16x3(self, h, a, wpk, b, dst, M, N, K, ldc, act):
-        pk = np.ctypeslib.as_array(ctypes.cast(wpk, ctypes.POINTER(ctypes.c_uint16)), (N, K // 8, 2, 8))
+        T, S = (N + 127) // 128, K // 32
+        pk = np.ctypeslib.as_array(ctypes.cast(wpk, ctypes.POINTER(ctypes.c_uint16)), (T, S, 128, 4, 2, 8))
         f = (pk.astype(np.uint32) << 16).view(np.float32)
-        w = np.ascontiguousarray((f[:, :, 0, :] + f[:, :, 1, :]).reshape(N, K))
+        w = (f[..., 0, :] + f[..., 1, :]).transpose(0, 2, 1, 3, 4).reshape(T * 128, K)[:N]
+        w = np.ascontiguousarray(w)
         self.mnc_fc(h, a, w.ctypes.data, b, dst, M, N, K, ldc, act)
 
     def mnc_softmax_rows(self, h, src, dst, M, N):

@@ -258,7 +258,7 @@ def test_fc_bf16x3(dev, M, N, K, act):
     a = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
     b = rng.normal(size=N).astype(np.float32)
-    d_wp = dev.empty((N * K,))
+    d_wp = dev.empty(((N + 127) // 128 * 128 * K,))
     dev.call("mnc_pack_fc_bf16x3", dev.put(w), d_wp, N, K)
     d_o = dev.empty((M * N,), fill=np.nan)
     dev.call("mnc_fc_bf16x3", dev.put(a), d_wp, dev.put(b), d_o, M, N, K, N, act)

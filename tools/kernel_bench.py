@@ -88,7 +88,7 @@ def main():
             y = dev.empty((M * N,))
             fn = "mnc_fc"
             if args.what == "fcx3":
-                wp = dev.empty((N * K,))
+                wp = dev.empty(((N + 127) // 128 * 128 * K,))
                 dev.call("mnc_pack_fc_bf16x3", w, wp, N, K)
                 w, fn = wp, "mnc_fc_bf16x3"
             for _ in range(3):
@@ -97,11 +97,14 @@ def main():
             for _ in range(args.reps):
                 dev.call(fn, a, w, b, y, M, N, K, N, 1)
             rec = records(dev)
-            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0].startswith("fc_bf16x3")])
+            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0] in ("fc_bf16x3", "fc_bf16x3_small")])
             tr = np.array([r[1] for r in rec if r[0] == "fc_reduce"] or [0.0])
+            ts = np.array([r[1] for r in rec if r[0] == "fc_bf16x3_split"] or [0.0])
             fl = 2.0 * M * N * K
-            print("%-12s M=%d N=%-4d K=%-6d  med %.1f us (+%.1f us reduce)  %.1f TF/s" %
-                  (name, M, N, K, 1e3 * np.median(t), 1e3 * np.median(tr), fl / np.median(t) / 1e9), flush=True)
+            tot = np.median(t) + np.median(tr) + np.median(ts)
+            print("%-12s M=%d N=%-4d K=%-6d  gemm %.1f us + reduce %.1f us + split %.1f us = %.1f us   %.1f TF/s (gemm)  %.1f TF/s (all)" %
+                  (name, M, N, K, 1e3 * np.median(t), 1e3 * np.median(tr), 1e3 * np.median(ts), 1e3 * tot,
+                   fl / np.median(t) / 1e9, fl / tot / 1e9), flush=True)
     dev.close()
 
 
