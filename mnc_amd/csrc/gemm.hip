@@ -15,6 +15,8 @@
 //
 // Split-K (chosen so that tiles x splits ~ the 256 CUs) writes fp32 partials to the context scratch; a second kernel
 // sums them in fixed order (deterministic) and applies bias + activation.  With one split the epilogue is fused.
+#include <cstdlib>
+
 #include "mnc_internal.h"
 
 namespace mnc {
@@ -37,7 +39,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 
 // grid: (ceil(N/128), splits, ceil(M/320)).  k range of split s: [s*kper, min(K, (s+1)*kper)), kper % 32 == 0.
 // fused != 0: write act(acc + bias) to out (ldc); else write raw partials to part[split][M][N].
-template <int kMT>
+// ABL != 0: ablation builds for tuning (MNC_FC_ABL, kMT = 10 only): 1 = no global loads / LDS stores in the loop,
+// 2 = additionally no barrier, 3 = additionally no LDS fragment reads.
+template <int kMT, int ABL = 0>
 __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       float* __restrict__ part, int M, int N, int K, int ldc, int kper,
@@ -74,24 +78,36 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
     b_src[u] = Wt + (long)gr * K + kbeg + c4 * 4;
     b_dst[u] = r * kPitch + c4 * 4;
   }
-  float4 ra[kAPer], rb[kBPer];   // initialised: see the note in conv.hip (uninitialised staging arrays -> scratch)
+  // Two register sets (R0/R1): the loads of stage s+2 are in flight while stage s is multiplied and stage s+1 -- already
+  // in registers -- is written to the free LDS buffer.  All staging is branch-free (clamped stage index; a phantom stage
+  // behind an odd stage count is stored as zeros): loads under a branch make hipcc drain the prefetch pipeline with
+  // s_waitcnt vmcnt(0) at every join.  (Initialised: uninitialised staging arrays become scratch, see conv.hip.)
+  struct Regs { float4 a[kAPer]; float4 b[kBPer]; };
+  Regs R0, R1;
 #pragma unroll
-  for (int u = 0; u < kAPer; ++u) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < kAPer; ++u) R0.a[u] = R1.a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int u = 0; u < kBPer; ++u) rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_stage = [&](int s) {
+  for (int u = 0; u < kBPer; ++u) R0.b[u] = R1.b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_stage = [&](int s, Regs& R) {
+    const long off = (long)min(s, nstages - 1) * kBK;
 #pragma unroll
-    for (int u = 0; u < kAPer; ++u)
-      ra[u] = *reinterpret_cast<const float4*>(a_src[u] + (long)s * kBK);
+    for (int u = 0; u < kAPer; ++u) R.a[u] = *reinterpret_cast<const float4*>(a_src[u] + off);
 #pragma unroll
-    for (int u = 0; u < kBPer; ++u) rb[u] = *reinterpret_cast<const float4*>(b_src[u] + (long)s * kBK);
+    for (int u = 0; u < kBPer; ++u) R.b[u] = *reinterpret_cast<const float4*>(b_src[u] + off);
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, const Regs& R, bool live) {
+    const unsigned keep = live ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-    for (int u = 0; u < kAPer; ++u)
-      *reinterpret_cast<float4*>(&sA[buf][a_dst[u]]) = ra[u];   // item u == row tile u
+    for (int u = 0; u < kAPer; ++u) {
+      float4 v = R.a[u];
+      v.x = __uint_as_float(__float_as_uint(v.x) & keep);
+      v.y = __uint_as_float(__float_as_uint(v.y) & keep);
+      v.z = __uint_as_float(__float_as_uint(v.z) & keep);
+      v.w = __uint_as_float(__float_as_uint(v.w) & keep);
+      *reinterpret_cast<float4*>(&sA[buf][a_dst[u]]) = v;        // item u == row tile u
+    }
 #pragma unroll
-    for (int u = 0; u < kBPer; ++u) *reinterpret_cast<float4*>(&sB[buf][b_dst[u]]) = rb[u];
+    for (int u = 0; u < kBPer; ++u) *reinterpret_cast<float4*>(&sB[buf][b_dst[u]]) = R.b[u];
   };
 
   f32x16 acc[kMT];
@@ -100,34 +116,88 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-  if (nstages > 0) {
-    load_stage(0);
-    store_stage(0);
-  }
-  __syncthreads();
   const int a_base = j * kPitch + kk * 4;
   const int b_base = (wave * 32 + j) * kPitch + kk * 4;
-  for (int s = 0; s < nstages; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nstages) load_stage(s + 1);
-    const float* pa = sA[buf];
-    const float* pb = sB[buf];
+  // Software pipeline (one wave per SIMD: only the wave's own MFMAs can hide its LDS and global latency; left alone the
+  // phases simply add up -- fc6: MFMA 464 us + fragment reads 61 us + barrier 12 us + staging 82 us = 619 us):
+  //   * the fragments of K-group kc+1 (8 k-values: one 16-byte read per row tile + one for the column) are read while the
+  //     40 MFMAs of group kc run (two fragment sets);
+  //   * the stage barrier sits before the LAST group, so group 0 of the next stage is prefetched during group 3;
+  //   * global loads (stage s+2) and LDS writes (stage s+1) are spread over groups 0-2;
+  //   * sched_group_barrier pins the interleave, the empty asm on the accumulators keeps each region's MFMAs inside it.
+  struct Frags { float4 a[kMT]; float4 b; };
+  auto read_frags = [&](int buf, int kc, Frags& f) {
+    if (ABL == 3) {
+      f.b = make_float4(1.f, 2.f, 3.f, 4.f);
+      asm volatile("" : "+v"(f.b.x), "+v"(f.b.y), "+v"(f.b.z), "+v"(f.b.w));
 #pragma unroll
-    for (int kc = 0; kc < kBK / 8; ++kc) {
-      const float4 b = *reinterpret_cast<const float4*>(pb + b_base + kc * 8);
-#pragma unroll
-      for (int t = 0; t < kMT; ++t) {
-        // no per-tile branch: rows past M are clamped copies, multiplied but never stored (a branch here splits the loop
-        // into tiny basic blocks and exposes the LDS latency once per tile)
-        const float4 a = *reinterpret_cast<const float4*>(pa + a_base + t * 32 * kPitch + kc * 8);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < kMT; ++t) f.a[t] = f.b;
+      return;
     }
-    if (s + 1 < nstages) store_stage(buf ^ 1);
+    f.b = *reinterpret_cast<const float4*>(sB[buf] + b_base + kc * 8);
+    // no per-tile branch: rows past M are clamped copies, multiplied but never stored
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) f.a[t] = *reinterpret_cast<const float4*>(sA[buf] + a_base + t * 32 * kPitch + kc * 8);
+  };
+  auto mfmas = [&](const Frags& f) {                 // k outermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].x, f.b.x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].y, f.b.y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].z, f.b.z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].w, f.b.w, acc[t], 0, 0, 0);
+  };
+  auto pin_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) asm volatile("" : "+a"(acc[t]));
+  };
+  constexpr int kNM = 4 * kMT;                       // MFMAs per K-group
+  constexpr int kNR = kMT + 1;                       // fragment reads per K-group
+  constexpr int kNS = kAPer + kBPer;                 // global loads (= LDS writes) per stage and thread
+  // stage s sits in LDS[buf] with its group-0 fragments in f0; stage s+1 is in `cur`; stage s+2 is requested into `nxt`
+  auto step = [&](int s, int buf, Regs& cur, Regs& nxt, Frags& f0) {
+    Frags f1;
+    if (ABL == 0) load_stage(s + 2, nxt);
+    read_frags(buf, 1, f1);
+    mfmas(f0);                                       // group 0
+    if (ABL == 0) store_stage(buf ^ 1, cur, s + 1 < nstages);
+    read_frags(buf, 2, f0);
+    mfmas(f1);                                       // group 1
+    read_frags(buf, 3, f1);
+    mfmas(f0);                                       // group 2
+#pragma unroll
+    for (int i = 0; i < 3 * kNM; ++i) {              // one slot per MFMA; the other classes spread evenly over the slots
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (ABL != 3 && (i + 1) * 3 * kNR / (3 * kNM) > i * 3 * kNR / (3 * kNM)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (ABL == 0 && i < kNM && (i + 1) * kNS / kNM > i * kNS / kNM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (ABL == 0 && i >= kNM && (i - kNM + 1) * kNS / (2 * kNM) > (i - kNM) * kNS / (2 * kNM))
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    pin_acc();
+    if (ABL < 2) __syncthreads();
+    read_frags(buf ^ 1, 0, f0);                      // group 0 of the next stage (of the zero-filled phantom at the end)
+    mfmas(f1);                                       // group 3
+#pragma unroll
+    for (int i = 0; i < kNM; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (ABL != 3 && (i + 1) * kNR / kNM > i * kNR / kNM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    pin_acc();
+  };
+
+  if (nstages > 0) {
+    Frags F0;
+    load_stage(0, R0);
+    store_stage(0, R0, true);
+    load_stage(1, R0);
     __syncthreads();
+    read_frags(0, 0, F0);
+    for (int s = 0; s < nstages; s += 2) {
+      step(s, 0, R0, R1, F0);
+      step(s + 1, 1, R1, R0, F0);   // for an odd stage count the last call multiplies the zero-filled phantom stage
+    }
   }
 
   // D[row = m (reg&3)+8*(reg>>2)+4*kk][col = n j]
@@ -230,9 +300,17 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     else if (mt == 5)
       hipLaunchKernelGGL(fc_mfma_kernel<5>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
                          M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    else
-      hipLaunchKernelGGL(fc_mfma_kernel<10>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+    else {
+      const char* e = getenv("MNC_FC_ABL");
+      const int abl = e ? atoi(e) : 0;
+#define MNC_FC_CASE(A) hipLaunchKernelGGL((fc_mfma_kernel<10, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, \
+                         d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
+      if (abl == 1) MNC_FC_CASE(1);
+      else if (abl == 2) MNC_FC_CASE(2);
+      else if (abl == 3) MNC_FC_CASE(3);
+      else MNC_FC_CASE(0);
+#undef MNC_FC_CASE
+    }
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }
