@@ -220,12 +220,16 @@ MNC_API int mnc_copy2d(mnc_ctx* ctx, float* d_dst, int dst_ld, const float* d_sr
  * ------------------------------------------------------------------------------------------------------------- */
 /* ProposalLayer.forward (lib/pylayer/proposal_layer.py:52-175): d_cls_prob [2A][H][W], d_bbox_pred [4A][H][W] (NCHW,
  * batch 1), anchors_host [A][4] (transform.anchors.generate_anchors as float32), im_info = (im_h, im_w, im_scale).
- * Writes d_rois [post_nms_topn][5] (rows >= *num_rois_host are zero) and returns the row count (one 4-byte D2H + sync).
+ * Writes d_rois [post_nms_topn][5] (rows >= the row count are zero) and returns the row count in *num_rois_host (one 4-byte
+ * D2H + stream sync).  num_rois_host == NULL: fully asynchronous, the count stays on the device until mnc_proposal_count
+ * (the engine launches the heads on all post_nms_topn rows meanwhile and checks the count with the outputs).
  * Candidate order is score descending, anchor index ascending (the reference leaves tie order to numpy's sort). */
 MNC_API int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred, int A, int H, int W,
                          const float* anchors_host, int feat_stride, float im_h, float im_w, float im_scale,
                          int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* d_rois,
                          int* num_rois_host);
+/* Row count of the last mnc_proposal on this context (4-byte D2H + stream sync). */
+MNC_API int mnc_proposal_count(mnc_ctx* ctx, int* num_rois_host);
 /* The sorted pre-NMS candidates of the last mnc_proposal on this context (parity tests teacher-force the NMS with them):
  * boxes_host [n][4], scores_host [n], *n_host = n.  Pass null arrays to query n only. */
 MNC_API int mnc_proposal_candidates(mnc_ctx* ctx, float* boxes_host, float* scores_host, int capacity, int* n_host);

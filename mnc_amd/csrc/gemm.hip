@@ -40,7 +40,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // grid: (ceil(N/128), splits, ceil(M/320)).  k range of split s: [s*kper, min(K, (s+1)*kper)), kper % 32 == 0.
 // fused != 0: write act(acc + bias) to out (ldc); else write raw partials to part[split][M][N].
 // ABL != 0: ablation builds for tuning (MNC_FC_ABL, kMT = 10 only): 1 = no global loads / LDS stores in the loop,
-// 2 = additionally no barrier, 3 = additionally no LDS fragment reads.
+// 2 = additionally no barrier, 3 = additionally no LDS fragment reads, 4 = global loads issued and awaited but not stored.
 template <int kMT, int ABL = 0>
 __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ out,
@@ -159,10 +159,16 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
   // stage s sits in LDS[buf] with its group-0 fragments in f0; stage s+1 is in `cur`; stage s+2 is requested into `nxt`
   auto step = [&](int s, int buf, Regs& cur, Regs& nxt, Frags& f0) {
     Frags f1;
-    if (ABL == 0) load_stage(s + 2, nxt);
+    if (ABL == 0 || ABL == 4) load_stage(s + 2, nxt);
     read_frags(buf, 1, f1);
     mfmas(f0);                                       // group 0
     if (ABL == 0) store_stage(buf ^ 1, cur, s + 1 < nstages);
+    if (ABL == 4) {                                  // loads issued and awaited, never written to LDS
+#pragma unroll
+      for (int u = 0; u < kAPer; ++u) asm volatile("" :: "v"(cur.a[u].x));
+#pragma unroll
+      for (int u = 0; u < kBPer; ++u) asm volatile("" :: "v"(cur.b[u].x));
+    }
     read_frags(buf, 2, f0);
     mfmas(f1);                                       // group 1
     read_frags(buf, 3, f1);
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
     for (int i = 0; i < 3 * kNM; ++i) {              // one slot per MFMA; the other classes spread evenly over the slots
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (ABL != 3 && (i + 1) * 3 * kNR / (3 * kNM) > i * 3 * kNR / (3 * kNM)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (ABL == 0 && i < kNM && (i + 1) * kNS / kNM > i * kNS / kNM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if ((ABL == 0 || ABL == 4) && i < kNM && (i + 1) * kNS / kNM > i * kNS / kNM)
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       if (ABL == 0 && i >= kNM && (i - kNM + 1) * kNS / (2 * kNM) > (i - kNM) * kNS / (2 * kNM))
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
@@ -308,6 +315,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
       if (abl == 1) MNC_FC_CASE(1);
       else if (abl == 2) MNC_FC_CASE(2);
       else if (abl == 3) MNC_FC_CASE(3);
+      else if (abl == 4) MNC_FC_CASE(4);
       else MNC_FC_CASE(0);
 #undef MNC_FC_CASE
     }

@@ -228,7 +228,7 @@ extern "C" {
 int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred, int A, int H, int W,
                  const float* anchors_host, int feat_stride, float im_h, float im_w, float im_scale, int pre_nms_topn,
                  int post_nms_topn, float nms_thresh, float min_size, float* d_rois, int* num_rois_host) {
-  MNC_REQUIRE(ctx && d_cls_prob && d_bbox_pred && anchors_host && d_rois && num_rois_host, "mnc_proposal: null pointer");
+  MNC_REQUIRE(ctx && d_cls_prob && d_bbox_pred && anchors_host && d_rois, "mnc_proposal: null pointer");
   MNC_REQUIRE(A > 0 && A <= 16 && H > 0 && W > 0 && post_nms_topn > 0, "mnc_proposal: bad shape A=%d H=%d W=%d", A, H, W);
   const int N = H * W * A;
   int topn = pre_nms_topn > 0 ? pre_nms_topn : N;
@@ -294,7 +294,19 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
     int rc = ls.finish("proposal_nms");
     if (rc) return rc;
   }
-  MNC_HIP_TRY(hipMemcpyAsync(num_rois_host, w.num, 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (num_rois_host) {                  // NULL: the count stays on the device (mnc_proposal_count), no synchronisation
+    MNC_HIP_TRY(hipMemcpyAsync(num_rois_host, w.num, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_proposal_count(mnc_ctx* ctx, int* num_rois_host) {
+  MNC_REQUIRE(ctx && num_rois_host, "mnc_proposal_count: null pointer");
+  mnc_proposal_state* st = (mnc_proposal_state*)ctx->proposal;
+  MNC_REQUIRE(st && st->buf, "mnc_proposal_count: mnc_proposal has not run on this context");
+  MNC_HIP_TRY(hipMemcpyAsync(num_rois_host, st->ws.num, 4, hipMemcpyDeviceToHost, ctx->stream));
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   clear_error();
   return MNC_OK;

@@ -299,6 +299,11 @@ class Net(object):
         self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
         if self.math not in ("fp32", "bf16x3"):
             raise ValueError("math must be 'fp32' or 'bf16x3', got %r" % self.math)
+        # MNC_SPECULATE_ROIS=0: read the ProposalLayer's RoI count back before the heads are launched (one stream sync in the
+        # middle of forward) instead of running the heads on RPN_POST_NMS_TOP_N rows and checking the count at the end
+        self._speculate = os.environ.get("MNC_SPECULATE_ROIS", "1") != "0"
+        self._speculated = None
+        self._running = 0
         self._ctx = _Ctx(device_id)
         self._tmp = _DevBuf(self._ctx)
         self._net_msg = prototxt.parse_file(prototxt_path)
@@ -817,10 +822,14 @@ class Net(object):
                 d_prob, d_bbox = prob.dev_in("plain"), bbox.dev_in("plain")
                 top.reshape(post, 5)
                 dst = top.dev_out("plain")
+                speculate = self._speculate and self._speculated is None
                 _lib.call("mnc_proposal", self._h(), d_prob, d_bbox, A, H, W, _lib.ptr(anchors), stride, float(im[0]),
                           float(im[1]), float(im[2]), int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
-                          float(c.RPN_MIN_SIZE), dst, ctypes.addressof(num))
-                top.shape = (num.value, 5)          # same buffer, R <= post rows are valid
+                          float(c.RPN_MIN_SIZE), dst, None if speculate else ctypes.addressof(num))
+                if speculate:                       # count stays on the device; forward() verifies it at the end
+                    self._speculated = (self._running, top, post)
+                else:
+                    top.shape = (num.value, 5)      # same buffer, R <= post rows are valid
                 top._host, top._host_valid, top._dev_valid = None, False, True
             return run_proposal
         return None
@@ -840,16 +849,37 @@ class Net(object):
             if name not in self.inputs:
                 raise KeyError("%r is not an input blob of this net (%r)" % (name, self.inputs))
             self.blobs[name].set_host(arr)
+        self._speculated = None
+        self._run_layers(0)
+        if self._speculated is not None:
+            # The native ProposalLayer left its RoI count on the device and the heads ran on all `post` rows (the rows are
+            # independent; rows past the count are zero boxes), so the trunk -> heads hand-over needs no host round trip.
+            # The count is checked here, with the outputs; in the rare case of fewer survivors the heads are run again on
+            # the exact row count, which is what the reference computes.
+            index, top, post = self._speculated
+            self._speculated = None
+            n = ctypes.c_int(0)
+            _lib.call("mnc_proposal_count", self._ctx.h, ctypes.addressof(n))
+            if n.value < post:
+                top.shape = (n.value, 5)
+                top._host, top._host_valid, top._dev_valid = None, False, True
+                self._run_layers(index + 1)
+                _lib.call("mnc_ctx_sync", self._ctx.h)
+        else:
+            _lib.call("mnc_ctx_sync", self._ctx.h)
+        return {name: self.blobs[name]._host_read() for name in self.outputs if self.blobs[name]._dev_valid
+                or self.blobs[name]._host_valid}
+
+    def _run_layers(self, start):
         pre = getattr(self, "_pre_steps", {})
-        for i, L in enumerate(self._layers):
+        for i in range(start, len(self._layers)):
+            L = self._layers[i]
             if L.run is None:
                 continue
             for fn in pre.get(i, ()):
                 fn()
+            self._running = i
             L.run()
-        _lib.call("mnc_ctx_sync", self._ctx.h)
-        return {name: self.blobs[name]._host_read() for name in self.outputs if self.blobs[name]._dev_valid
-                or self.blobs[name]._host_valid}
 
     # ------------------------------------------------------------------------------------------------ profiling
     def profile(self, enable=True):

@@ -232,7 +232,12 @@ class Fake(object):
         out = _f(rois, (post, 5))
         out[...] = 0
         out[:len(keep), 1:] = props[keep]
-        ctypes.c_int.from_address(int(num)).value = len(keep)
+        self._nprop = len(keep)
+        if num:
+            ctypes.c_int.from_address(int(num)).value = len(keep)
+
+    def mnc_proposal_count(self, h, num):
+        ctypes.c_int.from_address(int(num)).value = self._nprop
 
     def mnc_proposal_candidates(self, h, boxes, scores, cap, n):
         b, s = self._cand

@@ -176,3 +176,23 @@ def test_config_surface(tmp_path):
         cfg_from_file(str(p))
     cfg.EXP_DIR = "default"
     cfg.TRAIN.RPN_POST_NMS_TOP_N = 2000
+
+
+def test_speculative_roi_count_equals_synchronous_path(fake_gpu, monkeypatch):
+    """The heads are launched on RPN_POST_NMS_TOP_N rows before the RoI count is known and re-run on the exact count when
+    fewer proposals survive (a small image: far fewer than 300): same blobs as with the mid-forward read-back."""
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    data, im_info = _inputs(64, 96, 4)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MNC_SPECULATE_ROIS", flag)
+        net = Net(path, w, 1, device_id=0)
+        assert net._speculate == (flag == "1")
+        net.forward(data=data, im_info=im_info)
+        outs[flag] = {n: net.blobs[n].data.copy() for n in ("rois", "seg_cls_prob", "rois_ext", "mask_proposal_ext", "cls_prob_ext")}
+        net.close()
+    assert 0 < outs["1"]["rois"].shape[0] < 300
+    for n in outs["1"]:
+        assert outs["1"][n].shape == outs["0"][n].shape and np.array_equal(outs["1"][n], outs["0"][n]), n
