@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--math", default=os.environ.get("MNC_MATH", "fp32"), choices=["fp32", "bf16x3"],
                    help="arithmetic of the dense contractions for the headline number (default fp32)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 (BASELINE configs[2]) measurement")
+    p.add_argument("--host-results", action="store_true",
+                   help="round-trip boxes/masks/scores through numpy between forward and voting (cfg.TEST.DEVICE_RESULTS=False)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
     return p.parse_args()
 
@@ -103,18 +105,23 @@ def main():
         net.blobs["data"].dev_in("plain")
         scale = np.float32(im_scales[0])
         phase_ms = {"forward": 0.0, "tail": 0.0, "voting": 0.0, "gather": 0.0}
+        device_results = bool(cfg.TEST.get("DEVICE_RESULTS", True)) and not args.host_results
 
         def step():
             t_a = time.perf_counter()
             net.forward()
             t_b = time.perf_counter()
-            boxes = []
-            for name in ("rois", "rois_ext"):
-                r = net.blobs[name]._host_read()
-                boxes.append(clip_boxes(r[:, 1:5] / scale, im.shape)[0])
-            masks = np.concatenate((net.blobs["mask_proposal"]._host_read(), net.blobs["mask_proposal_ext"]._host_read()), 0)
-            scores = np.concatenate((net.blobs["seg_cls_prob"]._host_read(), net.blobs["seg_cls_prob_ext"]._host_read()), 0)
-            all_boxes = np.concatenate(boxes, 0)
+            # demo.im_detect's tail (un-scale, clip, stack both stages): on the device by default, as tools/demo.py runs it
+            if device_results:
+                all_boxes, masks, scores = net.detect_tail(scale, im.shape)
+            else:
+                boxes = []
+                for name in ("rois", "rois_ext"):
+                    r = net.blobs[name]._host_read()
+                    boxes.append(clip_boxes(r[:, 1:5] / scale, im.shape)[0])
+                masks = np.concatenate((net.blobs["mask_proposal"]._host_read(), net.blobs["mask_proposal_ext"]._host_read()), 0)
+                scores = np.concatenate((net.blobs["seg_cls_prob"]._host_read(), net.blobs["seg_cls_prob_ext"]._host_read()), 0)
+                all_boxes = np.concatenate(boxes, 0)
             t_c = time.perf_counter()
             rm, rb = gpu_mask_voting(masks, all_boxes, scores, 21, 100, im.shape[1], im.shape[0])
             t_d = time.perf_counter()

@@ -228,6 +228,19 @@ MNC_API int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_b
                          const float* anchors_host, int feat_stride, float im_h, float im_w, float im_scale,
                          int pre_nms_topn, int post_nms_topn, float nms_thresh, float min_size, float* d_rois,
                          int* num_rois_host);
+/* gpu_mask_voting (mnc_mask_voting above) with the inputs already on the device -- the engine's own outputs, produced on ctx's stream (no host round trip
+ * between net.forward and the voting): d_boxes [n][4], d_masks [n][S][S], d_scores [n][num_classes]; outputs are host
+ * arrays as above.  The library orders each class itself (order = NULL semantics). */
+MNC_API int mnc_mask_voting_dev(mnc_ctx* ctx, const float* d_boxes, const float* d_masks, const float* d_scores, int n,
+                                int num_classes, int mask_size, int max_per_image, float nms_thresh, float iou_thresh,
+                                int image_height, int image_width, float* out_mask, int* out_box, float* out_score,
+                                int* class_count, int* result_num);
+/* The tail of im_detect on the device (tools/demo.py:84-100, lib/caffeWrapper/TesterWrapper.py:240-260): d_boxes
+ * [R1+R2][4] = clip(rois[:, 1:5] / scale, image) of stage-1 rois followed by stage-2 rois (float32 division, clamp to
+ * [0, W-1] x [0, H-1] as transform/bbox_transform.py:clip_boxes). */
+MNC_API int mnc_detect_tail(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale,
+                            int image_height, int image_width, float* d_boxes);
+
 /* Row count of the last mnc_proposal on this context (4-byte D2H + stream sync). */
 MNC_API int mnc_proposal_count(mnc_ctx* ctx, int* num_rois_host);
 /* The sorted pre-NMS candidates of the last mnc_proposal on this context (parity tests teacher-force the NMS with them):

@@ -382,10 +382,12 @@ int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, co
 }
 
 // gpu_mask_voting in one call (lib/transform/mask_transform.py:213-286 + lib/nms/mv_kernel.cu).  See include/mnc_hip.h.
-int mnc_mask_voting(const float* boxes, const float* masks, const float* scores, const int* order, int n, int num_classes,
-                    int mask_size, int max_per_image, float nms_thresh, float iou_thresh, int image_height,
-                    int image_width, float* out_mask, int* out_box, float* out_score, int* class_count, int* result_num,
-                    int device_id) {
+// on_device: boxes / masks / scores are device pointers (the engine's own outputs) and `ext_stream` is the stream they were
+// produced on; otherwise they are host pointers and the library's per-device stream is used.
+static int mask_voting_core(bool on_device, hipStream_t ext_stream, const float* boxes, const float* masks,
+                            const float* scores, const int* order, int n, int num_classes, int mask_size, int max_per_image,
+                            float nms_thresh, float iou_thresh, int image_height, int image_width, float* out_mask,
+                            int* out_box, float* out_score, int* class_count, int* result_num, int device_id) {
   MNC_REQUIRE(result_num && class_count, "mnc_mask_voting: null output pointer");
   MNC_REQUIRE(n >= 0 && num_classes >= 2 && mask_size >= 2 && max_per_image > 0 && image_height > 0 && image_width > 0,
               "mnc_mask_voting: bad argument");
@@ -411,12 +413,12 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
                                     2 * b_cse + b_bounds + b_omask + b_obox, &w);
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(w->mu);
-  hipStream_t s = w->stream;
+  hipStream_t s = on_device ? ext_stream : w->stream;
   char* p = (char*)w->buf;
-  float* d_boxes = (float*)p; p += b_boxes;
-  float* d_masks = (float*)p; p += b_masks;
+  const float* d_boxes = on_device ? boxes : (const float*)p; p += b_boxes;
+  const float* d_masks = on_device ? masks : (const float*)p; p += b_masks;
   int* d_order = (int*)p; p += b_order;
-  float* d_scores = (float*)p; p += b_scores;
+  const float* d_scores = on_device ? scores : (const float*)p; p += b_scores;
   unsigned long long* d_bits = (unsigned long long*)p; p += b_bits;
   int* d_keep = (int*)p; p += b_keep;
   int* d_keepbox = (int*)p; p += b_keep;
@@ -438,8 +440,15 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
   const auto t0 = now();
   // 1. per-class score order + the per-class NMS problems (mask_transform.py:228-240), batched; kept lists come back as
   //    box indices; the masks ride along on the same stream
-  MNC_HIP_TRY(hipMemcpyAsync(d_boxes, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
-  MNC_HIP_TRY(hipMemcpyAsync(d_scores, scores, (size_t)n * num_classes * 4, hipMemcpyHostToDevice, s));
+  std::vector<float> h_scores;                 // the host picks the threshold and the result rows from the class scores
+  if (on_device) {
+    h_scores.resize((size_t)n * num_classes);
+    MNC_HIP_TRY(hipMemcpyAsync(h_scores.data(), d_scores, h_scores.size() * 4, hipMemcpyDeviceToHost, s));
+    scores = h_scores.data();                  // valid after the synchronisation below
+  } else {
+    MNC_HIP_TRY(hipMemcpyAsync((void*)d_boxes, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MNC_HIP_TRY(hipMemcpyAsync((void*)d_scores, scores, (size_t)n * num_classes * 4, hipMemcpyHostToDevice, s));
+  }
   std::vector<int> h_order;
   if (order) {
     MNC_HIP_TRY(hipMemcpyAsync(d_order, order, (size_t)B * n * 4, hipMemcpyHostToDevice, s));
@@ -449,6 +458,7 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
     hipLaunchKernelGGL(mv_order_kernel, dim3(B), dim3(np2 < 1024 ? np2 : 1024), (size_t)np2 * 8, s, d_scores, n, num_classes,
                        np2, d_order);
   } else {                                 // larger than the LDS sort: the same order on the host
+    if (on_device) MNC_HIP_TRY(hipStreamSynchronize(s));
     h_order.resize((size_t)B * n);
     for (int c = 0; c < B; ++c) {
       int* o = h_order.data() + (size_t)c * n;
@@ -468,7 +478,7 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
   std::vector<int> h_keepbox((size_t)B * n), h_num(B);
   MNC_HIP_TRY(hipMemcpyAsync(h_num.data(), d_num, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   MNC_HIP_TRY(hipMemcpyAsync(h_keepbox.data(), d_keepbox, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
-  MNC_HIP_TRY(hipMemcpyAsync(d_masks, masks, (size_t)n * S * S * 4, hipMemcpyHostToDevice, s));
+  if (!on_device) MNC_HIP_TRY(hipMemcpyAsync((void*)d_masks, masks, (size_t)n * S * S * 4, hipMemcpyHostToDevice, s));
   MNC_HIP_TRY(hipStreamSynchronize(s));
   const auto t1 = now();
 
@@ -518,6 +528,50 @@ int mnc_mask_voting(const float* boxes, const float* masks, const float* scores,
             us(t0, t1), us(t1, t2), R, us(t2, now()));
   clear_error();
   return MNC_OK;
+}
+
+int mnc_mask_voting(const float* boxes, const float* masks, const float* scores, const int* order, int n, int num_classes,
+                    int mask_size, int max_per_image, float nms_thresh, float iou_thresh, int image_height,
+                    int image_width, float* out_mask, int* out_box, float* out_score, int* class_count, int* result_num,
+                    int device_id) {
+  return mask_voting_core(false, nullptr, boxes, masks, scores, order, n, num_classes, mask_size, max_per_image, nms_thresh,
+                          iou_thresh, image_height, image_width, out_mask, out_box, out_score, class_count, result_num,
+                          device_id);
+}
+
+int mnc_mask_voting_dev(mnc_ctx* ctx, const float* d_boxes, const float* d_masks, const float* d_scores, int n,
+                        int num_classes, int mask_size, int max_per_image, float nms_thresh, float iou_thresh,
+                        int image_height, int image_width, float* out_mask, int* out_box, float* out_score, int* class_count,
+                        int* result_num) {
+  MNC_REQUIRE(ctx, "mnc_mask_voting_dev: null context");
+  MNC_REQUIRE(n == 0 || (d_boxes && d_masks && d_scores), "mnc_mask_voting_dev: null pointer");
+  return mask_voting_core(true, ctx->stream, d_boxes, d_masks, d_scores, nullptr, n, num_classes, mask_size, max_per_image,
+                          nms_thresh, iou_thresh, image_height, image_width, out_mask, out_box, out_score, class_count,
+                          result_num, ctx->device);
+}
+
+// im_detect's tail on the device (tools/demo.py:84-100, TesterWrapper.py:240-260): boxes = clip(rois[:, 1:5] / scale) of both
+// stages, stacked; float32 division and the clamp order of transform/bbox_transform.py:clip_boxes.
+__global__ void detect_tail_kernel(const float* __restrict__ rois1, int R1, const float* __restrict__ rois2, int R2, float scale,
+                                   float xmax, float ymax, float* __restrict__ boxes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (R1 + R2) * 4) return;
+  const int r = i >> 2, k = i & 3;
+  const float* roi = r < R1 ? rois1 + (long)r * 5 : rois2 + (long)(r - R1) * 5;
+  const float v = roi[1 + k] / scale;
+  const float hi = (k & 1) ? ymax : xmax;
+  boxes[i] = fmaxf(fminf(v, hi), 0.0f);
+}
+
+int mnc_detect_tail(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale, int image_height,
+                    int image_width, float* d_boxes) {
+  MNC_REQUIRE(ctx && d_boxes && R1 >= 0 && R2 >= 0 && (R1 == 0 || d_rois1) && (R2 == 0 || d_rois2) && scale > 0.0f,
+              "mnc_detect_tail: bad argument");
+  if (R1 + R2 == 0) return MNC_OK;
+  LaunchScope ls(ctx, "detect_tail");
+  hipLaunchKernelGGL(detect_tail_kernel, dim3(cdiv((R1 + R2) * 4, 256)), dim3(256), 0, ctx->stream, d_rois1, R1, d_rois2, R2,
+                     scale, (float)(image_width - 1), (float)(image_height - 1), d_boxes);
+  return ls.finish("detect_tail_kernel");
 }
 
 void _mv(const float* all_boxes, const float* all_masks, const int all_boxes_num, const int* candidate_inds,

@@ -870,6 +870,35 @@ class Net(object):
         return {name: self.blobs[name]._host_read() for name in self.outputs if self.blobs[name]._dev_valid
                 or self.blobs[name]._host_valid}
 
+    def detect_tail(self, scale, im_shape):
+        """The tail of im_detect (tools/demo.py:84-100) without leaving the GPU: (boxes [2R,4] in original-image pixels,
+        masks [2R,1,21,21], seg scores [2R,K]) of stages 3 and 5 as DeviceArrays (valid until the next call).
+        `gpu_mask_voting` consumes them in place; np.asarray() of any of them is the reference's numpy result."""
+        from .devarray import DeviceArray
+        B = self.blobs
+        r1, r2 = B["rois"], B["rois_ext"]
+        R1, R2 = r1.shape[0], r2.shape[0]
+        m1, m2, s1, s2 = B["mask_proposal"], B["mask_proposal_ext"], B["seg_cls_prob"], B["seg_cls_prob_ext"]
+        S, K = m1.shape[-1], s1.shape[1]
+        n = R1 + R2
+        if getattr(self, "_tail_bufs", None) is None:
+            self._tail_bufs = (_DevBuf(self._ctx), _DevBuf(self._ctx), _DevBuf(self._ctx))
+        d_boxes = self._tail_bufs[0].ensure(max(n, 1) * 16)
+        d_masks = self._tail_bufs[1].ensure(max(n, 1) * S * S * 4)
+        d_scores = self._tail_bufs[2].ensure(max(n, 1) * K * 4)
+        h = self._ctx.h
+        _lib.call("mnc_detect_tail", h, r1.dev_in("plain") if R1 else None, R1, r2.dev_in("plain") if R2 else None, R2,
+                  float(scale), int(im_shape[0]), int(im_shape[1]), d_boxes)
+        for blob1, blob2, dst, width in ((m1, m2, d_masks, S * S), (s1, s2, d_scores, K)):
+            if R1:
+                _lib.call("mnc_copy2d", h, dst, width, blob1.dev_in("plain"), blob1._ld() if blob1._view is not None else width,
+                          R1, width)
+            if R2:
+                _lib.call("mnc_copy2d", h, dst + R1 * width * 4, width, blob2.dev_in("plain"),
+                          blob2._ld() if blob2._view is not None else width, R2, width)
+        return (DeviceArray(self, d_boxes, (n, 4), self._tail_bufs), DeviceArray(self, d_masks, (n, 1, S, S), self._tail_bufs),
+                DeviceArray(self, d_scores, (n, K), self._tail_bufs))
+
     def _run_layers(self, start):
         pre = getattr(self, "_pre_steps", {})
         for i in range(start, len(self._layers)):
@@ -909,6 +938,8 @@ class Net(object):
             _lib.call("mnc_ctx_sync", self._ctx.h)
             for b in list(self.blobs.values()) + getattr(self, "_hidden", []):
                 b._buf.release()
+            for t in getattr(self, "_tail_bufs", None) or ():
+                t.release()
             self._tmp.release()
             for p in self._dev_params.values():
                 self._ctx.free(p)

@@ -101,6 +101,10 @@ class TesterWrapper(object):
     def _segmentation_forward(self, im):
         forward_kwargs, im_scales = self._prepare_mnc_args(im)
         self.net.forward(**forward_kwargs)
+        if cfg.TEST.get("DEVICE_RESULTS", True) and hasattr(self.net, "detect_tail"):
+            # same three results, left on the GPU for gpu_mask_voting (np.asarray() of them is the numpy path's output)
+            boxes, masks, scores = self.net.detect_tail(np.float32(im_scales[0]), im.shape)
+            return masks, boxes, scores
         rois_phase1 = self.net.blobs['rois'].data.copy()
         masks_phase1 = self.net.blobs['mask_proposal'].data[...]
         scores_phase1 = self.net.blobs['seg_cls_prob'].data[...]

@@ -51,7 +51,9 @@ cfg.TEST = AttrDict(
     RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_MIN_SIZE=16,   # mnc_config.py:121-129
     BBOX_REG=True, MASK_MERGE_IOU_THRESH=0.5, MASK_MERGE_NMS_THRESH=0.3,                   # :133-134
     CFM_INPUT_MASK_SIZE=14, MAX_ROIS_GPU=[2000], GROUP_SCALE=1, USE_TOP_K_MCG=0,
-    USE_MASK_MERGE=True, USE_GPU_MASK_MERGE=True)
+    USE_MASK_MERGE=True, USE_GPU_MASK_MERGE=True,
+    # not in the reference: im_detect / _segmentation_forward leave boxes, masks and scores on the GPU for gpu_mask_voting
+    DEVICE_RESULTS=True)
 
 
 def get_output_dir(imdb, net):

@@ -96,7 +96,10 @@ def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_widt
               int(max_per_image), float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH),
               int(im_height), int(im_width), _lib.ptr(out_mask), _lib.ptr(out_box), _lib.ptr(out_score),
               _lib.ptr(counts), ctypes.addressof(R), int(cfg.GPU_ID))
-    R = R.value
+    return _split_results(out_mask, out_box, out_score, counts, R.value, B)
+
+
+def _split_results(out_mask, out_box, out_score, counts, R, B):
     result_box = np.hstack((out_box[:R], out_score[:R, np.newaxis]))       # int32 | float32 -> float64, as the reference
     list_mask, list_box, lo = [], [], 0
     for c in range(B):
@@ -107,9 +110,32 @@ def _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_widt
     return list_mask, list_box
 
 
+def _device_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
+    """gpu_mask_voting on the engine's own device-resident outputs (mnc_amd.devarray.DeviceArray, from Net.detect_tail):
+    same call as _fused_mask_voting without the device -> host -> device round trip of its inputs."""
+    import ctypes
+    from mnc_amd import _lib
+    n, S, B = boxes.shape[0], masks.shape[3], num_classes - 1
+    cap = max(B * min(max_per_image, n), 1)
+    out_mask = np.zeros((cap, 1, S, S), dtype=np.float32)
+    out_box = np.zeros((cap, 4), dtype=np.int32)
+    out_score = np.zeros(cap, dtype=np.float32)
+    counts = np.zeros(B, dtype=np.int32)
+    R = ctypes.c_int(0)
+    _lib.call("mnc_mask_voting_dev", boxes._net._ctx.h, boxes.ptr, masks.ptr, scores.ptr, n, num_classes, S,
+              int(max_per_image), float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH),
+              int(im_height), int(im_width), _lib.ptr(out_mask), _lib.ptr(out_box), _lib.ptr(out_score), _lib.ptr(counts),
+              ctypes.addressof(R))
+    return _split_results(out_mask, out_box, out_score, counts, R.value, B)
+
+
 def gpu_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
     """masks [n,1,S,S], boxes [n,4], scores [n,num_classes] -> (list_result_mask, list_result_box), one entry per
     foreground class; boxes rows are [x1, y1, x2, y2, score]."""
+    from mnc_amd.devarray import DeviceArray
+    if cfg.USE_GPU_NMS and all(isinstance(a, DeviceArray) for a in (masks, boxes, scores)) and boxes.shape[0] > 0:
+        return _device_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height)
+    masks, boxes, scores = (np.asarray(a) for a in (masks, boxes, scores))
     if (cfg.USE_GPU_NMS and boxes.dtype == np.float32 and scores.dtype == np.float32 and boxes.shape[0] > 0
             and boxes.shape[1] == 4 and masks.shape[2] == masks.shape[3]):
         return _fused_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height)

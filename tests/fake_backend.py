@@ -296,6 +296,20 @@ class Fake(object):
             _f(oscore, (R,))[...] = allb[:, 4].astype(np.float32)
             _f(omask, (R, 1, S, S))[...] = np.concatenate(lm, 0)
 
+    def mnc_mask_voting_dev(self, h, boxes, masks, scores, n, K, S, max_per_image, nms_thr, iou_thr, H, W, omask, obox,
+                            oscore, counts, rnum):
+        self.mnc_mask_voting(boxes, masks, scores, None, n, K, S, max_per_image, nms_thr, iou_thr, H, W, omask, obox, oscore,
+                             counts, rnum, 0)
+
+    def mnc_detect_tail(self, h, rois1, R1, rois2, R2, scale, H, W, boxes):
+        from oracle import host as ohost
+        parts = []
+        for ptr, R in ((rois1, R1), (rois2, R2)):
+            if R:
+                parts.append(ohost.clip_boxes(_f(ptr, (R, 5))[:, 1:5] / np.float32(scale), (H, W))[0])
+        if parts:
+            _f(boxes, (R1 + R2, 4))[...] = np.concatenate(parts, 0)
+
     def mnc_mv(self, boxes, masks, nb, inds, start, wts, nc, H, W, bd, S, R, omask, obox, dev):
         m, b = native.mv(_f(boxes, (nb, bd)), _f(masks, (nb, 1, S, S)), _i(inds, (nc,)) if nc else np.zeros(0, np.int32),
                          _i(start, (R,)), _f(wts, (nc,)) if nc else np.zeros(0, np.float32), H, W)

@@ -272,3 +272,28 @@ def test_tester_wrapper_seg_task_on_device(small, tmp_path, monkeypatch):
         assert len(res[0.5]) == 20 and len(res[0.7]) == 20
     finally:
         t.net.close()
+
+
+def test_device_resident_results_equal_the_numpy_path(full, monkeypatch):
+    """cfg.TEST.DEVICE_RESULTS (default): im_detect leaves boxes / masks / scores on the GPU (mnc_detect_tail) and
+    gpu_mask_voting consumes them there (mnc_mask_voting_dev).  Same forward, both paths: identical arrays, identical
+    voting results; a DeviceArray behaves like the numpy array it stands for."""
+    import demo
+    from mnc_amd.devarray import DeviceArray
+    from mnc_config import cfg
+    from transform.mask_transform import gpu_mask_voting
+    net, _ = full
+    im = np.random.default_rng(11).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes, masks, scores = demo.im_detect(im, net)
+    assert all(isinstance(a, DeviceArray) for a in (boxes, masks, scores))
+    assert boxes.shape == (600, 4) and len(masks) == 600 and scores.dtype == np.float32 and masks[5].shape == (1, 21, 21)
+    dm, db = gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
+    monkeypatch.setitem(cfg.TEST, "DEVICE_RESULTS", False)
+    hboxes, hmasks, hscores = demo.im_detect(im, net)
+    assert isinstance(hboxes, np.ndarray)
+    assert np.array_equal(np.asarray(boxes), hboxes) and np.array_equal(np.asarray(masks), hmasks)
+    assert np.array_equal(np.asarray(scores), hscores)
+    hm, hb = gpu_mask_voting(hmasks, hboxes, hscores, 21, 100, im.shape[1], im.shape[0])
+    assert [len(b) for b in db] == [len(b) for b in hb]
+    assert np.array_equal(np.concatenate(db, 0), np.concatenate(hb, 0))
+    assert np.array_equal(np.concatenate(dm, 0), np.concatenate(hm, 0))

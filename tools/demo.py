@@ -48,10 +48,14 @@ def prepare_mnc_args(im, net):
 
 
 def im_detect(im, net):
-    """-> boxes [2R,4] (original-image pixels), masks [2R,1,21,21], seg scores [2R,21] of stages 3 and 5."""
+    """-> boxes [2R,4] (original-image pixels), masks [2R,1,21,21], seg scores [2R,21] of stages 3 and 5.
+    With cfg.TEST.DEVICE_RESULTS (default) the three results stay on the GPU as DeviceArrays -- gpu_mask_voting consumes them
+    there, np.asarray() / indexing gives the reference's numpy arrays."""
     forward_kwargs, im_scales = prepare_mnc_args(im, net)
     net.forward(**forward_kwargs)
     scale = np.float32(im_scales[0])      # float32 un-scaling: what numpy-1.x value-based casting did in the reference
+    if cfg.TEST.get("DEVICE_RESULTS", True) and hasattr(net, "detect_tail"):
+        return net.detect_tail(scale, im.shape)
     stage_boxes = []
     for name in ("rois", "rois_ext"):
         rois = net.blobs[name].data.copy()
