@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
 
 constexpr int kSelThreads = 1024;
 constexpr int kSortCap = 16384;      // pre_nms_topN up to 16384 (TEST 6000, TRAIN 12000)
+constexpr int kKeysPer = 24;         // candidate keys held in registers per thread: 24 576 anchors (600x1000: 21 546)
 
 // ONE workgroup.  Selects the K smallest keys (K = min(topn, #valid)), sorts them ascending in LDS and writes
 // order[j] = anchor index, sorted_scores[j]; *n_out = K.
@@ -78,17 +79,32 @@ __global__ __launch_bounds__(kSelThreads) void proposal_topk_kernel(const u64* _
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* sk = reinterpret_cast<u64*>(smem);                       // [cap] keys being sorted
   __shared__ unsigned hist[256];
+  __shared__ unsigned wsum[4];
   __shared__ unsigned s_cnt;
   __shared__ u64 s_prefix;
   __shared__ unsigned s_remaining;
   __shared__ unsigned s_valid;
   const int tid = threadIdx.x;
 
+  // The candidate keys are read ONCE into registers (kKeysPer per thread) and every pass below runs on them: with a single
+  // workgroup the ten passes over global memory were latency-bound (21 dependent-looking L2 round trips per thread and
+  // pass, ~150 us for 21 546 anchors).  Slots past N hold the "filtered" key ~0.  (N > kSelThreads * kKeysPer falls back to
+  // re-reading global memory for the surplus.)
+  u64 rk[kKeysPer];
+#pragma unroll
+  for (int u = 0; u < kKeysPer; ++u) {
+    const int i = tid + u * kSelThreads;
+    rk[u] = i < N ? keys[i] : ~0ull;
+  }
+  const int Nreg = min(N, kSelThreads * kKeysPer);
+
   // number of valid (unfiltered) boxes
   if (tid == 0) s_valid = 0;
   __syncthreads();
   unsigned local = 0;
-  for (int i = tid; i < N; i += kSelThreads) local += keys[i] != ~0ull;
+#pragma unroll
+  for (int u = 0; u < kKeysPer; ++u) local += rk[u] != ~0ull;
+  for (int i = Nreg + tid; i < N; i += kSelThreads) local += keys[i] != ~0ull;
   atomicAdd(&s_valid, local);
   __syncthreads();
   const unsigned K = min((unsigned)topn, s_valid);
@@ -105,20 +121,40 @@ __global__ __launch_bounds__(kSelThreads) void proposal_topk_kernel(const u64* _
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const u64 prefix = s_prefix;
-    for (int i = tid; i < N; i += kSelThreads) {
+    const unsigned rem = s_remaining;
+#pragma unroll
+    for (int u = 0; u < kKeysPer; ++u) {
+      const u64 k = rk[u];
+      if (k != ~0ull && (pass == 0 || (k >> (shift + 8)) == prefix)) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+    }
+    for (int i = Nreg + tid; i < N; i += kSelThreads) {
       const u64 k = keys[i];
-      if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+      if (k != ~0ull && (pass == 0 || (k >> (shift + 8)) == prefix)) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rem = s_remaining, acc = 0;
-      int b = 0;
-      for (; b < 256; ++b) {
-        if (acc + hist[b] >= rem) break;
-        acc += hist[b];
+    // the bin holding the rem-th smallest remaining key: parallel inclusive scan of the 256 counts (a serial walk by one
+    // thread is 256 dependent LDS reads -- ~7 us per pass)
+    unsigned v = 0, inc = 0;
+    if (tid < 256) {
+      v = hist[tid];
+      inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o);
+        if ((tid & 63) >= o) inc += t;
       }
-      s_remaining = rem - acc;
-      s_prefix = (prefix << 8) | (unsigned)b;
+      if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      unsigned off = 0;
+      for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
+      inc += off;
+      const unsigned exc = inc - v;
+      if (exc < rem && rem <= inc) {                     // exactly one bin satisfies this (rem >= 1, counts sum >= rem)
+        s_remaining = rem - exc;
+        s_prefix = (prefix << 8) | (unsigned)tid;
+      }
     }
     __syncthreads();
   }
@@ -129,7 +165,10 @@ __global__ __launch_bounds__(kSelThreads) void proposal_topk_kernel(const u64* _
   if (tid == 0) s_cnt = 0;
   for (unsigned j = tid; j < cap; j += kSelThreads) sk[j] = ~0ull;
   __syncthreads();
-  for (int i = tid; i < N; i += kSelThreads) {
+#pragma unroll
+  for (int u = 0; u < kKeysPer; ++u)
+    if (rk[u] <= kth) sk[atomicAdd(&s_cnt, 1u)] = rk[u];
+  for (int i = Nreg + tid; i < N; i += kSelThreads) {
     const u64 k = keys[i];
     if (k <= kth) sk[atomicAdd(&s_cnt, 1u)] = k;
   }
