@@ -23,10 +23,7 @@ namespace mnc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBN = 128, kBK = 32;
-constexpr int kPitch = kBK + 4;
-constexpr int kBVec = kBN * (kBK / 4);   // 1024 float4
-constexpr int kBPer = kBVec / 256;       // 4
+constexpr int kBN = 128, kBK = 32;       // kBK: K granularity of the interface (K % 32 == 0) and the default stage depth
 // Two row-tile counts per workgroup: MT = 10 (320 rows: all RoIs in one block, weights streamed once -- the big FCs) and
 // MT = 2 (64 rows: the small GEMMs -- mask_pred 256->441 and the 8192->{21,21,84} heads -- where 320-row blocks would
 // leave most CUs idle; 55 KB of LDS lets two such workgroups share a CU).
@@ -41,13 +38,21 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // fused != 0: write act(acc + bias) to out (ldc); else write raw partials to part[split][M][N].
 // ABL != 0: ablation builds for tuning (MNC_FC_ABL, kMT = 10 only): 1 = no global loads / LDS stores in the loop,
 // 2 = additionally no barrier, 3 = additionally no LDS fragment reads, 4 = global loads issued and awaited but not stored.
-template <int kMT, int ABL = 0>
+// kSK = K values per stage (32 or 16).  16 halves the LDS footprint: the 160-row variant <5, 16> needs 46 KB and two or three
+// workgroups share a CU, so one workgroup's staging / barrier phases are covered by another's MFMAs (at one workgroup per CU
+// -- the 320-row variant -- the phases of the single wave per SIMD largely add up, see the ablation numbers below).
+template <int kMT, int kSK = 32, int ABL = 0>
 __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, float* __restrict__ out,
                                                       float* __restrict__ part, int M, int N, int K, int ldc, int kper,
                                                       int act, int fused, int tn_, int splits_, int tm_) {
   constexpr int kBM = 32 * kMT;
-  constexpr int kAPer = kMT;               // float4 staging items per thread for the A panel (item u == row tile u)
+  constexpr int kPitch = kSK + 4;          // floats per LDS row: (kSK + 4) / 4 is odd -> conflict-free ds_read_b128
+  constexpr int kC4 = kSK / 4;             // float4 per row and stage
+  constexpr int kAPer = (kBM * kC4 + 255) / 256;   // float4 staging items per thread for the A panel
+  constexpr int kBPer = (kBN * kC4 + 255) / 256;   // ... and for the weight panel
+  constexpr int kNG = kSK / 8;             // K-groups (8 values: one 16-byte fragment per lane) per stage
+  static_assert(kSK == 32 || kSK == 16, "stage depth");
   __shared__ __attribute__((aligned(16))) float sA[2][kBM * kPitch];
   __shared__ __attribute__((aligned(16))) float sB[2][kBN * kPitch];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -56,24 +61,25 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
   xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
   const int n0 = bn * kBN, m0 = bmz * kBM;
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
-  const int nstages = (kend - kbeg) / kBK;
+  const int nstages = (kend - kbeg) / kSK;
   const int mrows = min(M - m0, kBM);
   const int mtiles = (mrows + 31) >> 5;
 
-  // staging map: item q -> row q>>3, float4 column q&7 (rows are K-contiguous in global memory)
+  // staging map: item q -> row q / kC4, float4 column q % kC4 (rows are K-contiguous in global memory); surplus items are
+  // clamped onto the last row and simply rewrite it
   const float* a_src[kAPer];
   const float* b_src[kBPer];
   int a_dst[kAPer], b_dst[kBPer];
 #pragma unroll
   for (int u = 0; u < kAPer; ++u) {
-    const int q = tid + u * 256, r = q >> 3, c4 = q & 7;
+    const int q = tid + u * 256, r = min(q / kC4, kBM - 1), c4 = q % kC4;
     const int gr = m0 + min(r, mrows - 1);               // rows past M re-read the last valid row; never stored
     a_src[u] = A + (long)gr * K + kbeg + c4 * 4;
     a_dst[u] = r * kPitch + c4 * 4;
   }
 #pragma unroll
   for (int u = 0; u < kBPer; ++u) {
-    const int q = tid + u * 256, r = q >> 3, c4 = q & 7;
+    const int q = tid + u * 256, r = min(q / kC4, kBN - 1), c4 = q % kC4;
     const int gr = min(n0 + r, N - 1);
     b_src[u] = Wt + (long)gr * K + kbeg + c4 * 4;
     b_dst[u] = r * kPitch + c4 * 4;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 #pragma unroll
   for (int u = 0; u < kBPer; ++u) R0.b[u] = R1.b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_stage = [&](int s, Regs& R) {
-    const long off = (long)min(s, nstages - 1) * kBK;
+    const long off = (long)min(s, nstages - 1) * kSK;
 #pragma unroll
     for (int u = 0; u < kAPer; ++u) R.a[u] = *reinterpret_cast<const float4*>(a_src[u] + off);
 #pragma unroll
@@ -157,11 +163,7 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
   constexpr int kNR = kMT + 1;                       // fragment reads per K-group
   constexpr int kNS = kAPer + kBPer;                 // global loads (= LDS writes) per stage and thread
   // stage s sits in LDS[buf] with its group-0 fragments in f0; stage s+1 is in `cur`; stage s+2 is requested into `nxt`
-  auto step = [&](int s, int buf, Regs& cur, Regs& nxt, Frags& f0) {
-    Frags f1;
-    if (ABL == 0 || ABL == 4) load_stage(s + 2, nxt);
-    read_frags(buf, 1, f1);
-    mfmas(f0);                                       // group 0
+  auto stage_io = [&](int s, int buf, Regs& cur, Regs& nxt) {
     if (ABL == 0) store_stage(buf ^ 1, cur, s + 1 < nstages);
     if (ABL == 4) {                                  // loads issued and awaited, never written to LDS
 #pragma unroll
@@ -169,23 +171,34 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < kBPer; ++u) asm volatile("" :: "v"(cur.b[u].x));
     }
-    read_frags(buf, 2, f0);
-    mfmas(f1);                                       // group 1
-    read_frags(buf, 3, f1);
-    mfmas(f0);                                       // group 2
+  };
+  auto step = [&](int s, int buf, Regs& cur, Regs& nxt, Frags& f0) {
+    Frags f1;
+    // ---- region 1: groups 0 .. kNG-2 (+ the reads for the last group), loads of stage s+2, LDS writes of stage s+1 ----
+    if (ABL == 0 || ABL == 4) load_stage(s + 2, nxt);
+    read_frags(buf, 1, f1);
+    mfmas(f0);                                       // group 0
+    stage_io(s, buf, cur, nxt);
+    if (kNG == 4) {
+      read_frags(buf, 2, f0);
+      mfmas(f1);                                     // group 1
+      read_frags(buf, 3, f1);
+      mfmas(f0);                                     // group 2
+    }
+    constexpr int kG1 = kNG - 1;                     // groups in region 1
 #pragma unroll
-    for (int i = 0; i < 3 * kNM; ++i) {              // one slot per MFMA; the other classes spread evenly over the slots
+    for (int i = 0; i < kG1 * kNM; ++i) {            // one slot per MFMA; the other classes spread evenly over the slots
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (ABL != 3 && (i + 1) * 3 * kNR / (3 * kNM) > i * 3 * kNR / (3 * kNM)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if ((ABL == 0 || ABL == 4) && i < kNM && (i + 1) * kNS / kNM > i * kNS / kNM)
+      if (ABL != 3 && (i + 1) * kG1 * kNR / (kG1 * kNM) > i * kG1 * kNR / (kG1 * kNM)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if ((ABL == 0 || ABL == 4) && (i + 1) * kNS / (kG1 * kNM) > i * kNS / (kG1 * kNM))
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      if (ABL == 0 && i >= kNM && (i - kNM + 1) * kNS / (2 * kNM) > (i - kNM) * kNS / (2 * kNM))
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if (ABL == 0 && (i + 1) * kNS / (kG1 * kNM) > i * kNS / (kG1 * kNM)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
     pin_acc();
     if (ABL < 2) __syncthreads();
-    read_frags(buf ^ 1, 0, f0);                      // group 0 of the next stage (of the zero-filled phantom at the end)
-    mfmas(f1);                                       // group 3
+    // ---- region 2: the last group, prefetching group 0 of the next stage (of the zero-filled phantom at the very end) ----
+    read_frags(buf ^ 1, 0, f0);
+    mfmas(f1);
 #pragma unroll
     for (int i = 0; i < kNM; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -280,17 +293,26 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kBK == 0 && ldc >= N && act >= 0 && act <= 2,
               "mnc_fc: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
   if (M == 0) return MNC_OK;
-  // small problems (< 2 GFLOP) use 64-row workgroups so that rows, column tiles and K splits together fill the chip
+  // small problems (< 2 GFLOP) use 64-row workgroups so that rows, column tiles and K splits together fill the chip; the
+  // large ones the smallest of {160, 320} rows that covers M in one block (weights streamed once).  Measured at M = 300
+  // (round 1): 320 rows x 32-deep stages, one workgroup per CU, and 160 rows x 16-deep stages, two per CU, are within 1 %
+  // of each other on every FC of the heads (MNC_FC_TILE=5|10 overrides).
   const bool small = 2.0 * M * (double)N * K < 2.0e9;
-  const int mt = small ? 2 : (M <= 160 ? 5 : 10);      // row tiles per workgroup (all of them are always multiplied)
+  int mt = small ? 2 : (M <= 160 ? 5 : 10);            // row tiles per workgroup (all of them are always multiplied)
+  if (const char* e = getenv("MNC_FC_TILE")) {
+    const int v = atoi(e);
+    if (!small && (v == 5 || v == 10)) mt = v;
+  }
+  const int sk = mt == 5 ? 16 : 32;                    // K values per stage
   const int bm = 32 * mt;
-  const int tn = cdiv(N, kBN), tm = cdiv(M, bm), stages = K / kBK;
-  // enough splits to give every CU a workgroup (two for the small variant), but at least 2 stages (64 deep) per split
-  int splits = cdiv(small ? 512 : 256, tn * tm);
-  const int min_stages = small ? 2 : 8;
+  const int tn = cdiv(N, kBN), tm = cdiv(M, bm), stages = K / sk;
+  // enough splits to give every CU its workgroups (two per CU except for the 320-row variant), but at least 64 K values
+  // (8 stages for the large variants) per split
+  int splits = cdiv(mt == 10 ? 256 : 512, tn * tm);
+  const int min_stages = small ? 2 : (mt == 5 ? 16 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
-  const int kper = cdiv(stages, splits) * kBK;
+  const int kper = cdiv(stages, splits) * sk;
   splits = cdiv(K, kper);
   float* part = nullptr;
   if (splits > 1) {
@@ -301,24 +323,23 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
   {
     LaunchScope ls(ctx, small ? "fc_mfma_small" : "fc_mfma", flops, bytes);
-    if (mt == 2)
-      hipLaunchKernelGGL(fc_mfma_kernel<2>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    else if (mt == 5)
-      hipLaunchKernelGGL(fc_mfma_kernel<5>, dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    else {
-      const char* e = getenv("MNC_FC_ABL");
-      const int abl = e ? atoi(e) : 0;
-#define MNC_FC_CASE(A) hipLaunchKernelGGL((fc_mfma_kernel<10, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_a, d_w, \
-                         d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
-      if (abl == 1) MNC_FC_CASE(1);
-      else if (abl == 2) MNC_FC_CASE(2);
-      else if (abl == 3) MNC_FC_CASE(3);
-      else if (abl == 4) MNC_FC_CASE(4);
-      else MNC_FC_CASE(0);
-#undef MNC_FC_CASE
+    const char* e = getenv("MNC_FC_ABL");
+    const int abl = e ? atoi(e) : 0;
+#define MNC_FC_LAUNCH(MT, SK, A) hipLaunchKernelGGL((fc_mfma_kernel<MT, SK, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, \
+                         d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
+    if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
+    else if (mt == 5) {
+      if (abl == 1) MNC_FC_LAUNCH(5, 16, 1);
+      else if (abl == 3) MNC_FC_LAUNCH(5, 16, 3);
+      else MNC_FC_LAUNCH(5, 16, 0);
+    } else {
+      if (abl == 1) MNC_FC_LAUNCH(10, 32, 1);
+      else if (abl == 2) MNC_FC_LAUNCH(10, 32, 2);
+      else if (abl == 3) MNC_FC_LAUNCH(10, 32, 3);
+      else if (abl == 4) MNC_FC_LAUNCH(10, 32, 4);
+      else MNC_FC_LAUNCH(10, 32, 0);
     }
+#undef MNC_FC_LAUNCH
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }
