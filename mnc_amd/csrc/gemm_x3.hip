@@ -322,11 +322,19 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
   if (M == 0) return MNC_OK;
   // row tiles per workgroup: 2 (64 rows) for the small GEMMs, else the smallest of {5, 10} that covers M in one block
   const bool small = 2.0 * M * (double)N * K < 2.0e9;
-  const int mt = small ? 2 : (M <= 160 ? 5 : 10);
+  int mt = small ? 2 : (M <= 160 ? 5 : 10);
+  // 320-row blocks stream the weights once but need many K splits to fill the chip; when a split would be shorter than 64
+  // stages, 160-row blocks (twice the tiles, half the splits and half the partial-sum traffic) are faster (measured at
+  // M = 300: fc7 59 vs 69 us, fc6_maskest 132 vs 151 us, fc6 274 vs 262 us)
+  if (mt == 10 && (K / kXBK) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < 64) mt = 5;
+  if (const char* e = getenv("MNC_FCX3_TILE")) {          // tuning override
+    const int v = atoi(e);
+    if (v == 2 || v == 5 || v == 10) mt = v;
+  }
   const int bm = 32 * mt;
   const int tn = cdiv(N, kXBN), tm = cdiv(M, bm), stages = K / kXBK;
-  int splits = cdiv(small ? 512 : 256, tn * tm);
-  const int min_stages = small ? 2 : 8;
+  int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
+  const int min_stages = mt == 2 ? 2 : 8;
   if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
   const int kper = cdiv(stages, splits) * kXBK;
