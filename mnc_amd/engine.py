@@ -488,6 +488,22 @@ class Net(object):
     def _bind_ReLU(self, L, i):
         raise NotImplementedError("stand-alone ReLU %s (only in-place ReLU after Convolution/InnerProduct)" % L.name)
 
+    def _bind_Dropout(self, L, i):
+        """Identity at test time (Caffe scales at train time; faster_rcnn_end2end/test.prototxt:546-555)."""
+        if L.tops[0] == L.bottoms[0]:
+            return None
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+
+        def run():
+            src = bot.dev_in("plain")
+            top.reshape(*bot.shape)
+            if bot.count:
+                _lib.call("mnc_copy2d", self._h(), top.dev_out("plain"), bot.shape[-1], src, bot._ld() if len(bot.shape) == 2
+                          else bot.shape[-1], bot.count // bot.shape[-1], bot.shape[-1])
+            else:
+                top.dev_out("plain")
+        return run
+
     def _bind_Pooling(self, L, i):
         if not self._is_pool2(L):
             raise NotImplementedError("Pooling %s: only MAX 2x2 stride 2 pad 0" % L.name)

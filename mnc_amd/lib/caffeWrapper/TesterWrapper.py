@@ -10,8 +10,8 @@ import numpy as np
 
 import caffe
 from mnc_config import cfg, get_output_dir
-from nms.nms_wrapper import apply_nms_mask_single
-from transform.bbox_transform import clip_boxes
+from nms.nms_wrapper import apply_nms, apply_nms_mask_single
+from transform.bbox_transform import bbox_transform_inv, clip_boxes
 from transform.mask_transform import gpu_mask_voting
 from utils.blob import im_list_to_blob, prep_im_for_blob
 from utils.image_io import imread
@@ -36,8 +36,11 @@ class TesterWrapper(object):
     def get_result(self):
         det_file = os.path.join(self.output_dir, 'res_boxes.pkl')
         seg_file = os.path.join(self.output_dir, 'res_masks.pkl')
+        if self.task_name == 'det':
+            return self.get_detection_result()
         if self.task_name != 'seg':
-            raise NotImplementedError("task %r: only 'seg' (MNC 5-stage inference) is on this path" % self.task_name)
+            raise NotImplementedError("task %r: 'seg' (MNC 5-stage) and 'det' (Faster R-CNN end2end) are provided; 'cfm' and "
+                                      "'vis_seg' are not" % self.task_name)
         if os.path.isfile(det_file) and os.path.isfile(seg_file):
             with open(det_file, 'rb') as f:
                 seg_box = pickle.load(f)
@@ -51,6 +54,55 @@ class TesterWrapper(object):
                 pickle.dump(seg_mask, f, pickle.HIGHEST_PROTOCOL)
         print('Evaluating segmentation using MNC 5 stage inference')
         return self.imdb.evaluate_segmentation(seg_box, seg_mask, self.output_dir)
+
+    def get_detection_result(self):
+        """Faster R-CNN end2end test loop (TesterWrapper.py:86-143): all_boxes[cls][image] = [n,5], per-class score
+        thresholds from the max_per_set heap, detections.pkl, per-class NMS, imdb.evaluate_detections."""
+        max_per_set = 40 * self.num_images
+        max_per_image = 100
+        thresh = -np.inf * np.ones(self.num_classes)
+        top_scores = [[] for _ in range(self.num_classes)]
+        all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
+        _t = {'im_detect': Timer(), 'misc': Timer()}
+        for i in range(self.num_images):
+            im = imread(self.imdb.image_path_at(i))
+            _t['im_detect'].tic()
+            scores, boxes = self._detection_forward(im)
+            _t['im_detect'].toc()
+            for j in range(1, self.num_classes):
+                inds = np.where(scores[:, j] > thresh[j])[0]
+                cls_scores = scores[inds, j]
+                cls_boxes = boxes[inds, j * 4:(j + 1) * 4]
+                top_inds = np.argsort(-cls_scores)[:max_per_image]
+                cls_scores, cls_boxes = cls_scores[top_inds], cls_boxes[top_inds, :]
+                for val in cls_scores:
+                    heapq.heappush(top_scores[j], val)
+                if len(top_scores[j]) > max_per_set:
+                    while len(top_scores[j]) > max_per_set:
+                        heapq.heappop(top_scores[j])
+                    thresh[j] = top_scores[j][0]
+                all_boxes[j][i] = np.hstack((cls_boxes, cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+            print('process image %d/%d, forward average time %f' % (i, self.num_images, _t['im_detect'].average_time))
+        for j in range(1, self.num_classes):
+            for i in range(self.num_images):
+                inds = np.where(all_boxes[j][i][:, -1] > thresh[j])[0]
+                all_boxes[j][i] = all_boxes[j][i][inds, :]
+        with open(os.path.join(self.output_dir, 'detections.pkl'), 'wb') as f:
+            pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+        print('Applying NMS to all detections')
+        nms_dets = apply_nms(all_boxes, cfg.TEST.NMS)
+        print('Evaluating detections')
+        return self.imdb.evaluate_detections(nms_dets, self.output_dir)
+
+    def _detection_forward(self, im):
+        """-> scores [R,K] and boxes [R,4K] (per-class regressed boxes in original-image pixels), TesterWrapper.py:216-238."""
+        forward_kwargs, im_scales = self._prepare_mnc_args(im)
+        blobs_out = self.net.forward(**forward_kwargs)
+        rois = self.net.blobs['rois'].data.copy()
+        boxes = rois[:, 1:5] / np.float32(im_scales[0])       # un-scale back to raw image space (float32, as numpy 1.x)
+        pred_boxes = bbox_transform_inv(boxes, blobs_out['bbox_pred'])
+        pred_boxes, _ = clip_boxes(pred_boxes, im.shape)
+        return blobs_out['cls_prob'], pred_boxes
 
     def get_segmentation_result(self):
         """all_boxes[cls][image] = [n,5] (x1,y1,x2,y2,score), all_masks[cls][image] = [n,1,21,21] float."""
@@ -112,8 +164,9 @@ class TesterWrapper(object):
         masks_phase2 = self.net.blobs['mask_proposal_ext'].data[...]
         scores_phase2 = self.net.blobs['seg_cls_prob_ext'].data[...]
         # boxes are in the resized image's coordinates: un-scale, clip to the original image
-        rois_phase1, _ = clip_boxes(rois_phase1[:, 1:5] / im_scales[0], im.shape)
-        rois_phase2, _ = clip_boxes(rois_phase2[:, 1:5] / im_scales[0], im.shape)
+        scale = np.float32(im_scales[0])      # float32 un-scaling: numpy-1.x value-based casting, as the reference ran
+        rois_phase1, _ = clip_boxes(rois_phase1[:, 1:5] / scale, im.shape)
+        rois_phase2, _ = clip_boxes(rois_phase2[:, 1:5] / scale, im.shape)
         masks = np.concatenate((masks_phase1, masks_phase2), axis=0)
         boxes = np.concatenate((rois_phase1, rois_phase2), axis=0)
         scores = np.concatenate((scores_phase1, scores_phase2), axis=0)

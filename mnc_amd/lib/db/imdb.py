@@ -1,10 +1,13 @@
-"""Image database factory (reference: lib/db/imdb.py:8-28).  Only the segmentation test sets are on the inference path;
+"""Image database factory (reference: lib/db/imdb.py:8-28).  Test-time surfaces only;
 extra sets can be registered with add_imdb (used by the tests for a synthetic devkit)."""
+from datasets.pascal_voc_det import PascalVOCDet
 from datasets.pascal_voc_seg import PascalVOCSeg
 
 _sets = {
     'voc_2012_seg_train': (lambda: PascalVOCSeg('train', '2012', 'data/VOCdevkitSDS/')),
     'voc_2012_seg_val': (lambda: PascalVOCSeg('val', '2012', 'data/VOCdevkitSDS/')),
+    'voc_2007_trainval': (lambda: PascalVOCDet('trainval', '2007')),
+    'voc_2007_test': (lambda: PascalVOCDet('test', '2007')),
 }
 
 

@@ -28,6 +28,97 @@ def voc_ap(rec, prec, use_07_metric=False):
     return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
 
 
+def parse_rec(filename):
+    """Objects of a PASCAL VOC annotation file: name, pose, truncated, difficult, bbox [xmin, ymin, xmax, ymax]."""
+    import xml.etree.ElementTree as ET
+    objects = []
+    for obj in ET.parse(filename).findall('object'):
+        bbox = obj.find('bndbox')
+        objects.append({'name': obj.find('name').text, 'pose': obj.find('pose').text,
+                        'truncated': int(obj.find('truncated').text), 'difficult': int(obj.find('difficult').text),
+                        'bbox': [int(bbox.find('xmin').text), int(bbox.find('ymin').text), int(bbox.find('xmax').text),
+                                 int(bbox.find('ymax').text)]})
+    return objects
+
+
+def voc_eval(detpath, annopath, imagesetfile, classname, cachedir, ovthresh=0.5, use_07_metric=False):
+    """PASCAL VOC detection AP of one class (reference: lib/utils/voc_eval.py:55-192): detpath.format(classname) is the
+    results file (`image score x1 y1 x2 y2` per line), annopath.format(image) the XML annotation.  Returns rec, prec, ap."""
+    if not os.path.isdir(cachedir):
+        os.mkdir(cachedir)
+    cachefile = os.path.join(cachedir, 'annots.pkl')
+    with open(imagesetfile, 'r') as f:
+        imagenames = [x.strip() for x in f.readlines()]
+    if not os.path.isfile(cachefile):
+        recs = {}
+        for i, imagename in enumerate(imagenames):
+            recs[imagename] = parse_rec(annopath.format(imagename))
+            if i % 100 == 0:
+                print('Reading annotation for {:d}/{:d}'.format(i + 1, len(imagenames)))
+        print('Saving cached annotations to {:s}'.format(cachefile))
+        with open(cachefile, 'wb') as f:
+            pickle.dump(recs, f)
+    else:
+        with open(cachefile, 'rb') as f:
+            recs = pickle.load(f)
+
+    class_recs = {}
+    npos = 0
+    for imagename in imagenames:
+        R = [obj for obj in recs[imagename] if obj['name'] == classname]
+        bbox = np.array([x['bbox'] for x in R])
+        difficult = np.array([x['difficult'] for x in R]).astype(bool)
+        npos = npos + sum(~difficult)
+        class_recs[imagename] = {'bbox': bbox, 'difficult': difficult, 'det': [False] * len(R)}
+
+    with open(detpath.format(classname), 'r') as f:
+        splitlines = [x.strip().split(' ') for x in f.readlines()]
+    image_ids = [x[0] for x in splitlines]
+    confidence = np.array([float(x[1]) for x in splitlines])
+    BB = np.array([[float(z) for z in x[2:]] for x in splitlines])
+
+    sorted_ind = np.argsort(-confidence)
+    BB = BB[sorted_ind, :] if len(sorted_ind) else BB
+    image_ids = [image_ids[x] for x in sorted_ind]
+
+    nd = len(image_ids)
+    tp = np.zeros(nd)
+    fp = np.zeros(nd)
+    for d in range(nd):
+        R = class_recs[image_ids[d]]
+        bb = BB[d, :].astype(float)
+        ovmax = -np.inf
+        BBGT = R['bbox'].astype(float)
+        if BBGT.size > 0:
+            ixmin = np.maximum(BBGT[:, 0], bb[0])
+            iymin = np.maximum(BBGT[:, 1], bb[1])
+            ixmax = np.minimum(BBGT[:, 2], bb[2])
+            iymax = np.minimum(BBGT[:, 3], bb[3])
+            iw = np.maximum(ixmax - ixmin + 1., 0.)
+            ih = np.maximum(iymax - iymin + 1., 0.)
+            inters = iw * ih
+            uni = ((bb[2] - bb[0] + 1.) * (bb[3] - bb[1] + 1.) +
+                   (BBGT[:, 2] - BBGT[:, 0] + 1.) * (BBGT[:, 3] - BBGT[:, 1] + 1.) - inters)
+            overlaps = inters / uni
+            ovmax = np.max(overlaps)
+            jmax = np.argmax(overlaps)
+        if ovmax > ovthresh:
+            if not R['difficult'][jmax]:
+                if not R['det'][jmax]:
+                    tp[d] = 1.
+                    R['det'][jmax] = 1
+                else:
+                    fp[d] = 1.
+        else:
+            fp[d] = 1.
+
+    fp = np.cumsum(fp)
+    tp = np.cumsum(tp)
+    rec = tp / float(npos)
+    prec = tp / (tp + fp)
+    return rec, prec, voc_ap(rec, prec, use_07_metric)
+
+
 def parse_inst(image_name, devkit_path):
     """Ground-truth instances of one SBD image: inst/<name>.mat (instance ids) + cls/<name>.mat (class ids) ->
     [{'mask': bool [h,w] inside its bounds, 'mask_cls': class id, 'mask_bound': [x1,y1,x2,y2]}]."""

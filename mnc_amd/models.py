@@ -53,9 +53,9 @@ def _pool(e, name, bottom, top):
     e.layer(name, "Pooling", [bottom], [top], "pooling_param { pool: MAX kernel_size: 2 stride: 2 pad: 0 }")
 
 
-def _fc(e, name, bottom, top, n_out, pname):
+def _fc(e, name, bottom, top, n_out, pname=None):
     e.layer(name, "InnerProduct", [bottom], [top], "inner_product_param { num_output: %d }" % n_out,
-            params=[pname + "_w", pname + "_b"])
+            params=[pname + "_w", pname + "_b"] if pname else None)
 
 
 def _head(e, sfx, rois, warp_direct, d=1):
@@ -98,9 +98,9 @@ def _head(e, sfx, rois, warp_direct, d=1):
     _fc(e, "bbox_pred" + sfx, "join_box_mask" + sfx, "bbox_pred" + sfx, 84, "bbox_pred")
 
 
-def mnc_5stage_test_prototxt(width_div=1):
-    """Text of the 5-stage test graph.  width_div > 1 divides every trunk/FC width (a reduced net for quick executor
-    tests; 1 is the real VGG-16 model)."""
+def _trunk_rpn_proposal(width_div):
+    """VGG-16 trunk, RPN head and the ProposalLayer -- shared by the three test graphs of the reference
+    (models/VGG16/{mnc_5stage,faster_rcnn_end2end,cfm}/test.prototxt:1-470)."""
     d = width_div
     e = _Emit("VGG16")
     e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
@@ -128,6 +128,13 @@ def mnc_5stage_test_prototxt(width_div=1):
     e.layer("proposal", "Python", ["rpn_cls_prob_reshape", "rpn_bbox_pred", "im_info"], ["rois"],
             "python_param { module: 'pylayer.proposal_layer' layer: 'ProposalLayer' "
             "param_str: \"{'feat_stride': 16, 'gradient_scale': 1}\" }")
+    return e, d
+
+
+def mnc_5stage_test_prototxt(width_div=1):
+    """Text of the 5-stage test graph.  width_div > 1 divides every trunk/FC width (a reduced net for quick executor
+    tests; 1 is the real VGG-16 model)."""
+    e, d = _trunk_rpn_proposal(width_div)
     _head(e, "", "rois", False, d)
     e.layer("stage_bridge", "Python", ["rois", "bbox_pred", "seg_cls_prob", "im_info"], ["rois_ext"],
             "python_param { module: 'pylayer.stage_bridge_layer' layer: 'StageBridgeLayer' }")
@@ -135,13 +142,40 @@ def mnc_5stage_test_prototxt(width_div=1):
     return e.text()
 
 
+def faster_rcnn_end2end_test_prototxt(width_div=1):
+    """Text of the Faster R-CNN end2end test graph (models/VGG16/faster_rcnn_end2end/test.prototxt:479-620): the same
+    trunk + RPN + ProposalLayer, then ROIWarping 7x7 -> fc6 -> fc7 (ReLU + test-time-identity Dropout) -> cls_score /
+    bbox_pred -> cls_prob.  SURVEY section 8f row n3: it runs on the kernels of the MNC path unchanged."""
+    e, d = _trunk_rpn_proposal(width_div)
+    wide = 4096 // d
+    e.layer("roi_pool5", "ROIWarping", ["conv5_3", "rois"], ["pool5"],
+            "roi_warping_param { pooled_w: 7 pooled_h: 7 spatial_scale: 0.0625 }")
+    _fc(e, "fc6", "pool5", "fc6", wide)
+    _relu(e, "relu6", "fc6")
+    e.layer("drop6", "Dropout", ["fc6"], ["fc6"], "dropout_param { dropout_ratio: 0.5 }")
+    _fc(e, "fc7", "fc6", "fc7", wide)
+    _relu(e, "relu7", "fc7")
+    e.layer("drop7", "Dropout", ["fc7"], ["fc7"], "dropout_param { dropout_ratio: 0.5 }")
+    _fc(e, "cls_score", "fc7", "cls_score", 21)
+    _fc(e, "bbox_pred", "fc7", "bbox_pred", 84)
+    e.layer("cls_prob", "Softmax", ["cls_score"], ["cls_prob"])
+    return e.text()
+
+
+def write_faster_rcnn_end2end_test_prototxt(path=None, width_div=1):
+    return _write(faster_rcnn_end2end_test_prototxt(width_div), path, "faster_rcnn_end2end_test_w%d.prototxt" % width_div)
+
+
 def write_mnc_5stage_test_prototxt(path=None, width_div=1):
     """Write the graph to `path` (default: a per-user temp file) and return the path."""
-    text = mnc_5stage_test_prototxt(width_div)
+    return _write(mnc_5stage_test_prototxt(width_div), path, "mnc_5stage_test_w%d.prototxt" % width_div)
+
+
+def _write(text, path, default_name):
     if path is None:
         d = os.path.join(tempfile.gettempdir(), "mnc_amd_models")
         os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "mnc_5stage_test_w%d.prototxt" % width_div)
+        path = os.path.join(d, default_name)
     tmp = path + ".%d.tmp" % os.getpid()
     with open(tmp, "w") as f:
         f.write(text)

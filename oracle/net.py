@@ -131,3 +131,32 @@ def im_detect(weights, im, nms_fn=None):
     b = forward(weights, data, im_info, nms_fn=nms_fn)
     return host.im_detect_tail(b["rois"], b["mask_proposal"], b["seg_cls_prob"], b["rois_ext"],
                                b["mask_proposal_ext"], b["seg_cls_prob_ext"], scale, im.shape)
+
+
+def head_frcnn(weights, conv5_3, rois, blobs=None):
+    """models/VGG16/faster_rcnn_end2end/test.prototxt:479-620 on given rois: ROIWarping 7x7 -> fc6 -> fc7 (Dropout is the
+    identity at test time) -> cls_score / bbox_pred -> cls_prob."""
+    blobs = {} if blobs is None else blobs
+    pool5 = native.roi_warp(conv5_3, rois, 7, 7, 0.0625)
+    blobs["pool5"] = pool5
+    x = _t(pool5.reshape(pool5.shape[0], -1))
+    fc6 = _fc(x, weights["fc6"], "relu")
+    fc7 = _fc(fc6, weights["fc7"], "relu")
+    cls_score = _fc(fc7, weights["cls_score"])
+    bbox_pred = _fc(fc7, weights["bbox_pred"])
+    blobs["fc6"], blobs["fc7"] = fc6.numpy(), fc7.numpy()
+    blobs["cls_score"], blobs["bbox_pred"] = cls_score.numpy(), bbox_pred.numpy()
+    blobs["cls_prob"] = F.softmax(cls_score, dim=1).numpy()
+    return blobs
+
+
+def forward_frcnn(weights, data, im_info, blobs=None, nms_fn=None):
+    """net.forward() of the Faster R-CNN end2end test graph."""
+    torch.set_grad_enabled(False)
+    blobs = {} if blobs is None else blobs
+    c5 = trunk(weights, data, blobs)
+    prob, bbox = rpn(weights, c5, blobs)
+    rois = host.proposal_forward(prob, bbox, im_info, nms_fn)
+    blobs["rois"] = rois
+    head_frcnn(weights, c5, rois, blobs)
+    return blobs

@@ -10,7 +10,8 @@ CODE in this container (same in-memory python-2 -> 3 patching and stubs as make_
     fake caffe.Net that leaves canned blobs (golden_inputs.tester_net_outputs), with gpu_mask_voting = the reference's
     mask_transform.gpu_mask_voting over oracle/_ref  -> tester_* arrays.
 
-cv2 is absent: cv2.resize is the oracle's restatement (oracle/host.py), cv2.imread reads the .npy images.
+The reference targets numpy 1.x: where its result dtype depends on value-based casting (`rois / im_scales[0]`) the legacy
+rule is applied explicitly.  cv2 is absent: cv2.resize is the oracle's restatement (oracle/host.py), cv2.imread reads the .npy images.
 
     python tests/golden/make_golden_eval.py        -> tests/golden/reference_eval_outputs.npz
 """
@@ -48,6 +49,11 @@ def _py3_more(src):
     src = MG._py3(_join_multiline_prints(src))
     src = src.replace("import cPickle", "import pickle as cPickle")
     src = re.sub(r"open\((\w+), 'wr?'\) as f:(\s+)cPickle\.dump", r"open(\1, 'wb') as f:\2cPickle.dump", src)
+    src = re.sub(r"open\((\w+), 'r'\) as f:(\s+)(\w+) = cPickle\.load", r"open(\1, 'rb') as f:\2\3 = cPickle.load", src)
+    src = src.replace("astype(np.bool)", "astype(bool)")
+    # numpy-1.x value-based casting (what the reference ran under): float32 array / 0-d float64 array stays float32; numpy 2
+    # would promote to float64
+    src = src.replace("/ im_scales[0]", "/ np.float32(im_scales[0])")
     src = src.replace("mask_bound[1]:mask_bound[3]+1, mask_bound[0]:mask_bound[2]+1",
                       "int(mask_bound[1]):int(mask_bound[3])+1, int(mask_bound[0]):int(mask_bound[2])+1")   # float slice indices
     return src
@@ -144,6 +150,65 @@ def main():
         g["tester_counts"] = np.array([[len(all_boxes[c][i]) for i in range(len(case["images"]))] for c in range(1, 21)])
         g["tester_boxes"] = np.concatenate([all_boxes[c][i] for c in range(1, 21) for i in range(len(case["images"]))], 0)
         g["tester_masks"] = np.concatenate([all_masks[c][i] for c in range(1, 21) for i in range(len(case["images"]))], 0)
+    # ---- 3. detection task: voc_eval + TesterWrapper.get_detection_result ----------------------------------
+    dcase = GI.voc_det_case()
+    with tempfile.TemporaryDirectory() as root:
+        GI.write_voc_devkit(root, dcase)
+        res = os.path.join(root, "results")
+        os.mkdir(res)
+        names = [r["name"] for r in dcase["images"]]
+        for c, cname in enumerate(GI.VOC_CLASSES):
+            if c == 0:
+                continue
+            with open(os.path.join(res, "det_%s.txt" % cname), "wt") as f:      # pascal_voc_det.py:_write_voc_results_file
+                for im_ind, index in enumerate(names):
+                    dets = dcase["dets"][c][im_ind]
+                    for k in range(dets.shape[0]):
+                        f.write('{:s} {:.3f} {:.1f} {:.1f} {:.1f} {:.1f}\n'.format(index, dets[k, -1], dets[k, 0] + 1,
+                                                                                  dets[k, 1] + 1, dets[k, 2] + 1, dets[k, 3] + 1))
+        aps = []
+        for cname in GI.VOC_CLASSES[1:]:
+            with np.errstate(all="ignore"):
+                rec, prec, ap = voc_eval.voc_eval(os.path.join(res, "det_{:s}.txt"),
+                                                  os.path.join(root, "VOC2007", "Annotations", "{:s}.xml"),
+                                                  os.path.join(root, "VOC2007", "ImageSets", "Main", "test.txt"), cname,
+                                                  os.path.join(root, "cache"), ovthresh=0.5, use_07_metric=True)
+            aps.append(ap)
+        g["det_ap"] = np.array(aps, np.float64)
+
+        dcanned = GI.tester_det_outputs(dcase)
+
+        class FakeDetNet(object):
+            def __init__(self, *a):
+                self.blobs = {k: MG.Blob() for k in ["rois", "data", "im_info"]}
+                self.calls, self.name = 0, "fakedet"
+
+            def forward(self, **kw):
+                out = dcanned[self.calls]
+                self.blobs["rois"].data = out["rois"].copy()
+                self.calls += 1
+                return {"bbox_pred": out["bbox_pred"].copy(), "cls_prob": out["cls_prob"].copy()}
+
+        sys.modules["caffe"].Net = FakeDetNet
+        captured = {}
+
+        class DetImdb(object):
+            name = "syn_voc_test"
+            image_index = names
+            num_classes = 21
+
+            def image_path_at(self, i):
+                return os.path.join(root, "VOC2007", "JPEGImages", self.image_index[i] + ".npy")
+
+            def evaluate_detections(self, all_boxes, output_dir):
+                captured["boxes"] = all_boxes
+
+        R.cfg.ROOT_DIR = root
+        t = tw.TesterWrapper("x.prototxt", DetImdb(), "fakedet.caffemodel", "det")
+        t.get_result()
+        nd = captured["boxes"]
+        g["tester_det_counts"] = np.array([[len(nd[c][i]) for i in range(len(names))] for c in range(1, 21)])
+        g["tester_det_boxes"] = np.concatenate([nd[c][i] for c in range(1, 21) for i in range(len(names)) if len(nd[c][i])], 0)
     np.savez_compressed(os.path.join(HERE, "reference_eval_outputs.npz"), **g)
     for k, v in g.items():
         print(k, v.shape, v.dtype, (np.round(v[:6] * 100, 2) if k.startswith("eval") else ""))

@@ -213,3 +213,70 @@ def tester_net_outputs(case, seed=12, R=30):
         outs.append({"rois": rois[:R], "mask_proposal": vc["masks"][:R], "seg_cls_prob": vc["scores"][:R],
                      "rois_ext": rois[R:], "mask_proposal_ext": vc["masks"][R:], "seg_cls_prob_ext": vc["scores"][R:]})
     return outs
+
+
+# ---- a synthetic VOCdevkit2007 (test_net.py --task det + voc_eval) -----------------------------------------
+VOC_CLASSES = ('__background__', 'aeroplane', 'bicycle', 'bird', 'boat', 'bottle', 'bus', 'car', 'cat', 'chair', 'cow',
+               'diningtable', 'dog', 'horse', 'motorbike', 'person', 'pottedplant', 'sheep', 'sofa', 'train', 'tvmonitor')
+
+
+def voc_det_case(seed=21):
+    """Per image: uint8 BGR pixels and annotated objects (class, difficult flag, 1-based inclusive bbox); plus per-class
+    scored detections [n,5] (0-based x1,y1,x2,y2,score): jittered true positives, duplicates, false positives, and hits on
+    'difficult' objects."""
+    rng = np.random.default_rng(seed)
+    nimg = len(SDS_IMAGES)
+    dets = [[np.zeros((0, 5), np.float32) for _ in range(nimg)] for _ in range(21)]
+    images = []
+    for ii, (name, H, W) in enumerate(SDS_IMAGES):
+        objs = []
+        for k in range(1 + (ii + 1) % 3):
+            w, h = int(rng.integers(20, 60)), int(rng.integers(20, 50))
+            x1, y1 = int(rng.integers(1, W - w)), int(rng.integers(1, H - h))
+            c = int(rng.integers(1, 5))
+            difficult = int(k == 2)
+            objs.append({"name": VOC_CLASSES[c], "difficult": difficult, "bbox": [x1, y1, x1 + w, y1 + h]})
+            for dx, dy, sc in [(1, 0, 0.95), (8, 9, 0.55), (-1, 1, 0.5)]:
+                b = np.array([x1 - 1 + dx, y1 - 1 + dy, x1 + w - 1 + dx, y1 + h - 1 + dy, sc * rng.uniform(0.8, 1.0)], np.float32)
+                dets[c][ii] = np.vstack([dets[c][ii], b[None]])
+        for _ in range(2):
+            c = int(rng.integers(1, 8))
+            b = np.append(_boxes(rng, 1, W, H, lo=10, hi=40)[0], np.float32(rng.uniform(0.1, 0.9))).astype(np.float32)
+            dets[c][ii] = np.vstack([dets[c][ii], b[None]])
+        images.append({"name": name.replace("syn", "det"), "im": rng.integers(0, 256, (H, W, 3), dtype=np.uint8), "objects": objs,
+                       "H": H, "W": W})
+    for c in range(1, 21):          # every class reports something (the reference's voc_eval cannot read an empty file)
+        b = np.append(_boxes(rng, 1, SDS_IMAGES[0][2], SDS_IMAGES[0][1], lo=10, hi=30)[0], np.float32(0.05)).astype(np.float32)
+        dets[c][0] = np.vstack([dets[c][0], b[None]])
+    return {"images": images, "dets": dets}
+
+
+def write_voc_devkit(root, case, year="2007", image_set="test"):
+    """VOC<year>/JPEGImages/<name>.npy, VOC<year>/Annotations/<name>.xml, VOC<year>/ImageSets/Main/<set>.txt under `root`."""
+    base = os.path.join(root, "VOC" + year)
+    for d in ("JPEGImages", "Annotations", os.path.join("ImageSets", "Main")):
+        os.makedirs(os.path.join(base, d), exist_ok=True)
+    for rec in case["images"]:
+        np.save(os.path.join(base, "JPEGImages", rec["name"] + ".npy"), rec["im"])
+        objs = "".join(
+            "<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>"
+            "<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+            % ((o["name"], o["difficult"]) + tuple(o["bbox"])) for o in rec["objects"])
+        with open(os.path.join(base, "Annotations", rec["name"] + ".xml"), "w") as f:
+            f.write("<annotation><filename>%s.jpg</filename><size><width>%d</width><height>%d</height><depth>3</depth></size>%s"
+                    "</annotation>" % (rec["name"], rec["W"], rec["H"], objs))
+    with open(os.path.join(base, "ImageSets", "Main", image_set + ".txt"), "w") as f:
+        f.write("".join(rec["name"] + "\n" for rec in case["images"]))
+
+
+def tester_det_outputs(case, seed=22, R=40):
+    """Canned blobs of a Faster R-CNN net per image: rois [R,5] (resized-image coordinates), bbox_pred [R,84], cls_prob [R,21]."""
+    outs = []
+    for ii, rec in enumerate(case["images"]):
+        rng = np.random.default_rng(seed + ii)
+        H, W = rec["H"], rec["W"]
+        scale = min(600.0 / min(H, W), 1000.0 / max(H, W))
+        rois = np.hstack([np.zeros((R, 1), np.float32), _boxes(rng, R, W, H, lo=12, hi=60) * np.float32(scale)]).astype(np.float32)
+        outs.append({"rois": rois, "bbox_pred": rng.normal(0, 0.2, (R, 84)).astype(np.float32),
+                     "cls_prob": _softmax_rows(rng.normal(0, 2.0, (R, 21)))})
+    return outs

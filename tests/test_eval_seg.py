@@ -118,7 +118,7 @@ def test_tester_wrapper_loop_matches_the_reference(devkit, ref, monkeypatch, tmp
         t.get_result()
     assert t.net.calls == calls
     with pytest.raises(NotImplementedError):
-        TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "det").get_result()
+        TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "cfm").get_result()
     gc.collect()
 
 

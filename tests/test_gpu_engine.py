@@ -4,6 +4,8 @@ blob against the CPU oracle (oracle/net.py) on identical synthetic weights and i
 Tolerance: north_star asks for 1e-3 on boxes / class scores / 21x21 masks.  Per blob we check max |diff| against
 1e-3 x the blob's dynamic range (probabilities and masks therefore to 1e-3 absolute, boxes to 1e-3 of ~1000 px; the
 measured values are 2-3 orders of magnitude tighter and are printed)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -297,3 +299,50 @@ def test_device_resident_results_equal_the_numpy_path(full, monkeypatch):
     assert [len(b) for b in db] == [len(b) for b in hb]
     assert np.array_equal(np.concatenate(db, 0), np.concatenate(hb, 0))
     assert np.array_equal(np.concatenate(dm, 0), np.concatenate(hm, 0))
+
+
+def test_faster_rcnn_end2end_graph_and_det_task(tmp_path, monkeypatch):
+    """models/VGG16/faster_rcnn_end2end/test.prototxt runs on the MNC path's kernels (ROIWarping 7x7, the FC
+    GEMMs, test-time Dropout).  Teacher-forced parity as for the MNC graph: trunk/RPN vs oracle, rois == oracle proposal on
+    the device's RPN outputs, head vs oracle head on the device's rois; then `--task det` end to end on a synthetic devkit."""
+    import caffe
+    import golden_inputs
+    from caffeWrapper.TesterWrapper import TesterWrapper
+    from datasets.pascal_voc_det import PascalVOCDet
+    from mnc_config import cfg
+    path = models.write_faster_rcnn_end2end_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=3)
+    net = caffe.Net(path, w, caffe.TEST)
+    try:
+        rng = np.random.default_rng(2)
+        data = rng.uniform(-120, 130, (1, 3, 130, 203)).astype(np.float32)
+        im_info = np.array([[130, 203, 1.0]], np.float32)
+        out = net.forward(data=data, im_info=im_info)
+        assert set(out) == {"cls_prob", "bbox_pred"}
+        ref = onet.forward_frcnn(w, data, im_info)
+        _compare(net, ref, TRUNK_BLOBS)
+        g = lambda n: net.blobs[n]._host_read()
+        # device-resident ProposalLayer: candidates vs the oracle's (expf vs numpy exp: last-ulp box differences, identical
+        # score order), NMS keep bit-exact on the device's own candidates -- as in check_forward
+        rois = g("rois")
+        cb, cs = net.proposal_candidates()
+        ob, osc = ohost.proposal_candidates(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
+        assert cb.shape == ob.shape and np.array_equal(cs, osc.ravel()) and err(cb, ob)[0] < 1e-3
+        keep = onative.nms_sorted(np.hstack((cb, cs[:, None])), 0.7)[:300]
+        assert rois.shape == (len(keep), 5) and np.array_equal(rois[:, 1:], cb[keep]) and not rois[:, 0].any()
+        head = onet.head_frcnn(w, g("conv5_3"), rois)
+        _compare(net, head, ["pool5", "fc6", "fc7", "cls_score", "bbox_pred", "cls_prob"])
+    finally:
+        net.close()
+    case = golden_inputs.voc_det_case()
+    root = str(tmp_path / "VOCdevkit2007")
+    golden_inputs.write_voc_devkit(root, case)
+    monkeypatch.setattr(cfg, "ROOT_DIR", str(tmp_path))
+    imdb = PascalVOCDet("test", "2007", root, image_ext=".npy")
+    t = TesterWrapper(path, imdb, w, "det")
+    try:
+        with np.errstate(all="ignore"):
+            aps = t.get_result()
+        assert len(aps) == 20 and os.path.isfile(os.path.join(t.output_dir, "detections.pkl"))
+    finally:
+        t.net.close()
