@@ -22,14 +22,16 @@ def main():
     for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
         g = s1 - e0
         key = (short(n0), short(n1))
-        a = gaps.setdefault(key, [0, 0.0, 0.0])
+        a = gaps.setdefault(key, [0, 0.0, 0.0, []])
         a[0] += 1
         a[1] += g
         a[2] = max(a[2], g)
+        a[3].append(g)
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
-    print("%-40s -> %-40s %6s %10s %10s" % ("after", "before", "n", "avg_us", "max_us"))
-    for (a, b), (n, tot, mx) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:top]:
-        print("%-40s -> %-40s %6d %10.2f %10.2f" % (a, b, n, tot / n / 1e3, mx / 1e3))
+    print("%-40s -> %-40s %6s %10s %10s %10s" % ("after", "before", "n", "median_us", "avg_us", "max_us"))
+    med = lambda v: sorted(v)[len(v) // 2]
+    for (a, b), (n, tot, mx, vals) in sorted(gaps.items(), key=lambda kv: -med(kv[1][3]) * kv[1][0])[:top]:
+        print("%-40s -> %-40s %6d %10.2f %10.2f %10.2f" % (a, b, n, med(vals) / 1e3, tot / n / 1e3, mx / 1e3))
     small = sum(v[1] for v in gaps.values() if v[1] / v[0] < 20e3)
     print("sum of gaps with avg < 20 us: %.3f ms over %d transitions" % (small / 1e6, sum(v[0] for v in gaps.values() if v[1] / v[0] < 20e3)))
 
