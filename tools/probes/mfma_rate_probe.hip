@@ -38,13 +38,12 @@ __global__ __launch_bounds__(256) void f32_loop(float* out, int iters) {
 }
 
 template <typename K>
-static void run(const char* name, K kern, int wgs_per_cu, double flops_per_mfma, int nacc) {
+static void run(const char* name, K kern, int wgs_per_cu, double flops_per_mfma, int nacc, int iters = 20000) {
   float* d;
   hipMalloc(&d, 64);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  const int iters = 20000;
   const int grid = 256 * wgs_per_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d, 100);
   hipDeviceSynchronize();
@@ -75,5 +74,9 @@ int main() {
   run("fp32 32x32x2,  2 accumulators", f32_loop<2>, 4, 4096.0, 2);
   run("fp32 32x32x2,  1 accumulator ", f32_loop<1>, 1, 4096.0, 1);
   run("fp32 32x32x2,  1 accumulator ", f32_loop<1>, 2, 4096.0, 1);
+  // sustained: ~50 ms and ~0.5 s of back-to-back MFMAs (does the clock hold?)
+  run("fp32 32x32x2, 8 acc, 50 ms ", f32_loop<8>, 2, 4096.0, 8, 120000);
+  run("fp32 32x32x2, 8 acc, 0.5 s ", f32_loop<8>, 2, 4096.0, 8, 1200000);
+  run("bf16 32x32x16, 8 acc, 50 ms", bf16_loop<8>, 2, 32768.0, 8, 200000);
   return 0;
 }
