@@ -10,7 +10,6 @@ Supported subset = what libhdf5 (1.8 / 1.10, default property lists) produces fo
 
     read_tree(path) -> {"data/conv1_1/0": ndarray, ...}      every dataset, soft links resolved, keyed by its path
 """
-import struct
 
 import numpy as np
 

@@ -9,7 +9,6 @@ import os
 import numpy as np
 import pytest
 
-import golden_inputs as GI
 import mnc_amd
 from gpu_util import err
 from mnc_amd import models, synth

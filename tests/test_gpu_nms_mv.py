@@ -125,7 +125,6 @@ def test_gpu_mask_voting_vs_reference_fixture(golden, tag):
 def test_fused_voting_equals_step_by_step_composition():
     """mnc_mask_voting (fused) == the reference's composition of nms x20 + bbox_overlaps + mv, on the product's own
     modular path and on the oracle, at BASELINE's 600 instances / 600x1000 canvas and on float64 boxes (generic path)."""
-    from mnc_config import cfg
     from transform import mask_transform as mt
     vc = GI.voting_case(600, 600, 1000, 23)
     fused = mt.gpu_mask_voting(vc["masks"], vc["boxes"], vc["scores"], 21, 100, 1000, 600)

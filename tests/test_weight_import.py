@@ -3,7 +3,6 @@
 fixtures produced by INDEPENDENT writers -- the real libhdf5 making Caffe's own calls, and google.protobuf
 (tests/golden/make_weight_fixtures.py)."""
 import os
-import struct
 
 import numpy as np
 import pytest
