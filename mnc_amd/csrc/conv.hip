@@ -38,10 +38,16 @@ constexpr int kWPitch = 76;              // floats per weight row in LDS and in 
 // spread the LDS writes among the MFMAs.
 // ABL != 0: ablation builds for tuning (MNC_CONV_ABL, 4-row tiles only): 1 = no global loads / LDS stores in the loop,
 // 2 = additionally no barrier, 3 = additionally no LDS fragment reads (MFMAs on constant registers).
+// ksplit > 1 (small maps): blockIdx.z = split * (Cout / NCO) + channel tile; split s walks channel blocks
+// [s * Cin/8/ksplit, (s+1) * Cin/8/ksplit) and writes its raw accumulators to part[s] (c8 planes); conv_splitk_reduce_kernel
+// sums the splits in order and applies bias + ReLU.  conv5_x / rpn_conv at 600x1000 are 320 workgroups on 256 CUs: a quarter
+// of the SIMDs carry two waves and the rest one, so the layer takes two waves' worth of MFMAs (pure-MFMA ablation: 145 us
+// against 80 us balanced); four K splits make it 1280 equal workgroups, five per CU.
 template <int CO_T, int ROWS = 4, int ABL = 0>
 __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
-                                                         int W, int Cin, int Cout, int relu) {
+                                                         int W, int Cin, int Cout, int relu, int ksplit,
+                                                         float* __restrict__ part) {
   constexpr int NT = 64 * ROWS;
   constexpr int kHaloRows = ROWS + 2;
   constexpr int kHaloFloats = kHaloRows * kHaloCols * kPixPitch;
@@ -56,8 +62,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, kk = lane >> 5;
-  const int w0 = blockIdx.x * kTileCols, h0 = blockIdx.y * ROWS, co0 = blockIdx.z * NCO;
-  const int nchunks = Cin >> 3;
+  const int ncot = Cout / NCO;
+  const int split = blockIdx.z / ncot;
+  const int w0 = blockIdx.x * kTileCols, h0 = blockIdx.y * ROWS, co0 = (blockIdx.z - split * ncot) * NCO;
+  const int nchunks = (Cin >> 3) / ksplit;                   // channel blocks of this split (the launcher makes it divide)
+  const int chunk0 = split * nchunks;
 
   // ---- staging assignment (fixed per thread) ----
   // halo: item q -> pixel q>>1 (row-major in the (ROWS+2) x 34 halo), half q&1
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
   for (int u = 0; u < kWPerThread; ++u) R0.w[u] = R1.w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto load_chunk = [&](int c, Regs& G) {
-    c = min(c, nchunks - 1);
+    c = chunk0 + min(c, nchunks - 1);
     const float* src = in + (long)c * plane;
 #pragma unroll
     for (int u = 0; u < kHPerThread; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
@@ -188,6 +197,20 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
     for (int e = 0; e < 16; ++e) acc[0][e] += acc2[e];
   }
   const int oh = h0 + wave, ow = w0 + j;
+  if (ksplit > 1) {
+    if (oh < H && ow < W) {
+      float* dst = part + (long)split * Cout * H * W;
+#pragma unroll
+      for (int t = 0; t < CO_T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + t * 32 + g * 8 + kk * 4;
+          *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * H + oh) * W + ow) * 8 + kk * 4) =
+              make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        }
+    }
+    return;
+  }
   if (oh < H && ow < W) {
 #pragma unroll
     for (int t = 0; t < CO_T; ++t) {
@@ -201,6 +224,26 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_c8_kernel(const float* __re
         *reinterpret_cast<float4*>(out + (((long)(co >> 3) * H + oh) * W + ow) * 8 + kk * 4) = v;
       }
     }
+  }
+}
+
+// out = act(sum_s part[s] + bias), c8 planes; one thread per float4 (4 channels of one pixel)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, long hw, int Cout, int ksplit,
+                                                                 int relu) {
+  const long total4 = (long)Cout * hw / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;                                   // element index in [C/8][HW][8]
+    const int co = (int)(e / (hw * 8)) * 8 + (int)(e & 7);
+    float4 v = *reinterpret_cast<const float4*>(part + e);
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 p = *reinterpret_cast<const float4*>(part + (long)s * Cout * hw + e);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>(bias + co);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(out + e) = v;
   }
 }
 
@@ -350,6 +393,14 @@ static int grid_for(long total, int block = 256, int cap = 256 * 32) {
 
 }  // namespace mnc
 
+namespace mnc {
+void conv_splitk_reduce_launch(hipStream_t stream, const float* d_part, const float* d_bias, float* d_out, int H, int W,
+                               int Cout, int ksplit, int relu) {
+  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid_for((long)Cout * H * W / 4)), dim3(256), 0, stream, d_part, d_bias,
+                     d_out, (long)H * W, Cout, ksplit, relu);
+}
+}  // namespace mnc
+
 using namespace mnc;
 
 extern "C" {
@@ -376,22 +427,41 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
     if (v == 2 || v == 4 || v == 8) best_rows = v;
   }
   const int rows = best_rows, co_t = best_cot;
+  // K splits for the small maps (see the kernel): fewer than two workgroups per CU -> split the channel blocks 4 (or 2) ways
+  int ksplit = 1;
+  {
+    const long wgs = (long)cdiv(W, kTileCols) * cdiv(H, rows) * (Cout / (32 * co_t));
+    const int blocks = Cin / 8;
+    if (wgs < 512) ksplit = blocks % 4 == 0 && blocks >= 16 ? 4 : (blocks % 2 == 0 && blocks >= 8 ? 2 : 1);
+    if (const char* e = getenv("MNC_CONV_KSPLIT")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
+    }
+  }
+  float* part = nullptr;
+  if (ksplit > 1) {
+    int rc = ensure_scratch(ctx, (size_t)ksplit * Cout * H * W * 4);
+    if (rc) return rc;
+    part = (float*)ctx->scratch;
+  }
   const int tx = cdiv(W, kTileCols), ty = cdiv(H, rows);
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
-  dim3 grid(tx, ty, Cout / (32 * co_t));
+  dim3 grid(tx, ty, Cout / (32 * co_t) * ksplit);
   if (const char* e = getenv("MNC_CONV_ABL")) {
     const int a = atoi(e);
-#define MNC_ABL_CASE(T, A) if (rows == 4 && co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, 4, A>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu); return ls.finish("conv3x3_c8_kernel"); }
+#define MNC_ABL_CASE(T, A) if (rows == 4 && co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, 4, A>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part); goto launched; }
     MNC_ABL_CASE(1, 1) MNC_ABL_CASE(1, 2) MNC_ABL_CASE(1, 3) MNC_ABL_CASE(2, 1) MNC_ABL_CASE(2, 2) MNC_ABL_CASE(2, 3)
 #undef MNC_ABL_CASE
   }
-#define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+#define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
   MNC_CONV_CASE(2, 1) MNC_CONV_CASE(2, 2) MNC_CONV_CASE(2, 4)
   MNC_CONV_CASE(4, 1) MNC_CONV_CASE(4, 2) MNC_CONV_CASE(4, 4)
   MNC_CONV_CASE(8, 1) MNC_CONV_CASE(8, 2) MNC_CONV_CASE(8, 4)
 #undef MNC_CONV_CASE
+launched:
+  if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);   // same profiling scope
   return ls.finish("conv3x3_c8_kernel");
 }
 

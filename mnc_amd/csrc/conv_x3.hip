@@ -34,7 +34,8 @@ constexpr int kX3WPitch = 84;          // dwords per weight row: 10 slots x 8 + 
 template <int CT, int PR, int ROWS>
 __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               int H, int W, int Cin, int Cout, int relu) {
+                                                               int H, int W, int Cin, int Cout, int relu, int ksplit,
+                                                               float* __restrict__ part) {
   constexpr int NT = 64 * ROWS;
   constexpr int R = ROWS * PR;                               // pixel rows per workgroup
   constexpr int kHaloPix = (R + 2) * kX3HaloCols;
@@ -52,8 +53,12 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __re
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, kb = lane >> 5;
-  const int w0 = blockIdx.x * kX3Cols, h0 = blockIdx.y * R, co0 = blockIdx.z * NCO;
-  const int nchunks = Cin >> 3;
+  // ksplit > 1 (small maps, see conv.hip): blockIdx.z = split * (Cout / NCO) + channel tile; raw partial sums go to part[split]
+  const int ncot = Cout / NCO;
+  const int split = blockIdx.z / ncot;
+  const int w0 = blockIdx.x * kX3Cols, h0 = blockIdx.y * R, co0 = (blockIdx.z - split * ncot) * NCO;
+  const int nchunks = (Cin >> 3) / ksplit;
+  const int chunk0 = split * nchunks;
 
   // ---- staging assignment (fixed per thread): every thread always loads and stores; surplus threads repeat the last item
   int h_dst[kHPer];
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __re
 #pragma unroll
   for (int u = 0; u < kWPer; ++u) R0.w[u] = R1.w[u] = make_uint4(0, 0, 0, 0);
   auto load_chunk = [&](int c, Regs& G) {
-    c = min(c, nchunks - 1);
+    c = chunk0 + min(c, nchunks - 1);
     const float* src = in + (long)c * plane;
 #pragma unroll
     for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
@@ -193,11 +198,16 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __re
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = co0 + t * 32 + g * 8 + kb * 4;
-          const float4 b = *reinterpret_cast<const float4*>(bias + co);
-          float4 v = make_float4(acc[r][t][4 * g + 0] + b.x, acc[r][t][4 * g + 1] + b.y, acc[r][t][4 * g + 2] + b.z,
-                                 acc[r][t][4 * g + 3] + b.w);
-          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<float4*>(out + (((long)(co >> 3) * H + oh) * W + ow) * 8 + kb * 4) = v;
+          float4 v = make_float4(acc[r][t][4 * g + 0], acc[r][t][4 * g + 1], acc[r][t][4 * g + 2], acc[r][t][4 * g + 3]);
+          float* dst = out;
+          if (ksplit > 1) {
+            dst = part + (long)split * Cout * H * W;
+          } else {
+            const float4 b = *reinterpret_cast<const float4*>(bias + co);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          }
+          *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * H + oh) * W + ow) * 8 + kb * 4) = v;
         }
       }
     }
@@ -235,7 +245,7 @@ static int x3_grid_for(long total) {
 
 template <int CT, int PR, int ROWS>
 static int launch_x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W,
-                     int Cin, int Cout, int relu) {
+                     int Cin, int Cout, int relu, int ksplit, float* part) {
   constexpr int R = ROWS * PR;
   constexpr size_t lds = 2 * 4 * ((size_t)(R + 2) * kX3HaloCols * kX3PixPitch + (size_t)32 * CT * kX3WPitch);
   static_assert(lds <= 160 * 1024, "conv3x3_x3: LDS budget");
@@ -245,9 +255,9 @@ static int launch_x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const f
     MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid(cdiv(W, kX3Cols), cdiv(H, R), Cout / (32 * CT));
+  dim3 grid(cdiv(W, kX3Cols), cdiv(H, R), Cout / (32 * CT) * ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(64 * ROWS), lds, ctx->stream, d_in, (const uint4*)d_wpk, d_bias, d_out, H, W, Cin,
-                     Cout, relu);
+                     Cout, relu, ksplit, part);
   return MNC_OK;
 }
 
@@ -286,15 +296,33 @@ int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const
       pr = b;
     }
   }
+  // K splits for the small maps (fewer than two workgroups per CU), as in mnc_conv3x3
+  int ksplit = 1;
+  {
+    const long wgs = (long)cdiv(W, kX3Cols) * cdiv(H, 4 * pr) * (Cout / (32 * ct));
+    const int blocks = Cin / 8;
+    if (wgs < 512) ksplit = blocks % 4 == 0 && blocks >= 16 ? 4 : (blocks % 2 == 0 && blocks >= 8 ? 2 : 1);
+    if (const char* e = getenv("MNC_CONV_KSPLIT")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
+    }
+  }
+  float* part = nullptr;
+  if (ksplit > 1) {
+    int rc = ensure_scratch(ctx, (size_t)ksplit * Cout * H * W * 4);
+    if (rc) return rc;
+    part = (float*)ctx->scratch;
+  }
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_bf16x3", flops, bytes);
   int rc = MNC_OK;
-  if (ct == 4 && pr == 2) rc = launch_x3<4, 2, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
-  else if (ct == 2 && pr == 2) rc = launch_x3<2, 2, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
-  else if (ct == 2 && pr == 1) rc = launch_x3<2, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
-  else rc = launch_x3<1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+  if (ct == 4 && pr == 2) rc = launch_x3<4, 2, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  else if (ct == 2 && pr == 2) rc = launch_x3<2, 2, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  else if (ct == 2 && pr == 1) rc = launch_x3<2, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  else rc = launch_x3<1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
   if (rc) return rc;
+  if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);
   return ls.finish("conv3x3_x3_kernel");
 }
 

@@ -118,6 +118,9 @@ int nms_mask_launch_indirect(hipStream_t stream, const float* d_boxes, const int
 int nms_scan_launch_indirect(hipStream_t stream, const unsigned long long* d_mask, const int* d_n, int n_cap, int max_keep,
                              int* d_keep, int* d_num);
 void proposal_state_free(void* state);  // proposal.hip
+// out = act(sum of the ksplit partial c8 tensors + bias)  (conv.hip; shared with conv_x3.hip)
+void conv_splitk_reduce_launch(hipStream_t stream, const float* d_part, const float* d_bias, float* d_out, int H, int W,
+                               int Cout, int ksplit, int relu);
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
               const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, int* d_bounds,
               float* d_out_mask, int* d_out_box);
