@@ -17,6 +17,7 @@
 //     for 3*PR*CT MFMAs -- the register tile is what keeps LDS traffic under the matrix pipe's appetite;
 //   * staging loads are unconditional (clamped addresses, out-of-image pixels masked to zero) and issued for block c+1
 //     before the MFMAs of block c, stored to the other LDS buffer after them: one barrier per block.
+#include <atomic>
 #include <cstdlib>
 
 #include "mnc_internal.h"
@@ -250,10 +251,11 @@ static int launch_x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const f
   constexpr size_t lds = 2 * 4 * ((size_t)(R + 2) * kX3HaloCols * kX3PixPitch + (size_t)32 * CT * kX3WPitch);
   static_assert(lds <= 160 * 1024, "conv3x3_x3: LDS budget");
   auto kern = conv3x3_x3_kernel<CT, PR, ROWS>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};          // one bit per device: function attributes are per device
+  const unsigned long long bit = 1ull << (ctx->device & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
     MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
   }
   dim3 grid(cdiv(W, kX3Cols), cdiv(H, R), Cout / (32 * CT) * ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(64 * ROWS), lds, ctx->stream, d_in, (const uint4*)d_wpk, d_bias, d_out, H, W, Cin,

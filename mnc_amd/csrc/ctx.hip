@@ -15,6 +15,7 @@ void clear_error() { g_err[0] = 0; }
 
 int ensure_scratch(mnc_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->scratch_bytes) return MNC_OK;
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->scratch) {
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
     MNC_HIP_TRY(hipFree(ctx->scratch));

@@ -65,6 +65,7 @@ struct LaunchScope {
   mnc_ctx* ctx;
   bool on;
   LaunchScope(mnc_ctx* c, const char* name, double flops = 0.0, double bytes = 0.0) : ctx(c) {
+    (void)hipSetDevice(ctx->device);    // several contexts on different GPUs may live in one process
     on = ctx->profiling == 1 || (ctx->profiling == 2 && flops >= 1.0e9);
     if (on) prof_begin(ctx, name, flops, bytes);
   }

@@ -20,6 +20,8 @@
 // the last ulp; the NMS decisions on the decoded boxes are bit-exact (tests teacher-force them).
 #include <cfloat>
 
+#include <atomic>
+
 #include "mnc_internal.h"
 
 namespace mnc {
@@ -278,6 +280,7 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   const size_t need = a256((size_t)N * 16) + a256((size_t)N * 8) + a256((size_t)N * 4) + a256((size_t)topn * 4) * 2 + 256 +
                       a256((size_t)topn * cb * 8) + a256((size_t)topn * 4) + 256;
   if (need > st->bytes) {
+    MNC_HIP_TRY(hipSetDevice(ctx->device));
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (st->buf) MNC_HIP_TRY(hipFree(st->buf));
     st->buf = nullptr; st->bytes = 0;
@@ -312,11 +315,12 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   {
     unsigned cap = 1;
     while (cap < (unsigned)topn) cap <<= 1;
-    static bool attr_set = false;
-    if (!attr_set) {   // up to 128 KB of dynamic LDS for the in-LDS sort
+    static std::atomic<unsigned long long> attr_set{0};      // one bit per device: function attributes are per device
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {   // up to 128 KB of dynamic LDS for the in-LDS sort
       MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(proposal_topk_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSortCap * 8));
-      attr_set = true;
+      attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
     LaunchScope ls(ctx, "proposal_topk");
     hipLaunchKernelGGL(proposal_topk_kernel, dim3(1), dim3(kSelThreads), (size_t)cap * 8, ctx->stream, w.keys, w.scores, N,
