@@ -19,6 +19,7 @@ import ctypes
 import importlib
 import os
 from collections import OrderedDict
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -271,6 +272,29 @@ class _Layer(object):
         self.group = None          # [layers] of a merged sibling-InnerProduct GEMM (this layer is the leader)
         self.group_leader = None   # set on the followers of such a group
         self.run = None
+
+
+class _Outputs(Mapping):
+    """What net.forward() returns: {output blob name: ndarray}, as pycaffe -- but an array is copied from the device when it
+    is first looked at (tools/demo.py ignores the return value and reads net.blobs[...]; four eager copies per forward were
+    four stream synchronisations)."""
+
+    def __init__(self, net, names):
+        self._net, self._names = net, list(names)
+
+    def __getitem__(self, name):
+        if name not in self._names:
+            raise KeyError(name)
+        return self._net.blobs[name]._host_read()
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __repr__(self):
+        return "{%s}" % ", ".join("%r: <%s>" % (n, "x".join(map(str, self._net.blobs[n].shape))) for n in self._names)
 
 
 class Net(object):
@@ -883,8 +907,7 @@ class Net(object):
                 _lib.call("mnc_ctx_sync", self._ctx.h)
         else:
             _lib.call("mnc_ctx_sync", self._ctx.h)
-        return {name: self.blobs[name]._host_read() for name in self.outputs if self.blobs[name]._dev_valid
-                or self.blobs[name]._host_valid}
+        return _Outputs(self, [name for name in self.outputs if self.blobs[name]._dev_valid or self.blobs[name]._host_valid])
 
     def detect_tail(self, scale, im_shape):
         """The tail of im_detect (tools/demo.py:84-100) without leaving the GPU: (boxes [2R,4] in original-image pixels,
