@@ -247,48 +247,57 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
   }
 }
 
-// ---- conv1_1: Cin = 3 (K = 27): HBM-bound, VALU.  One thread = one pixel x 8 output channels. --------------------
+// ---- conv1_1: Cin = 3 (K = 27): HBM-bound (154 MB written at 600x1000), VALU.  One thread = one pixel: its 27 inputs are
+// loaded once into registers and all Cout channels are produced from them, 8 at a time, with the weights read from LDS at
+// wave-uniform addresses (broadcast reads).  A wave writes 64 pixels x 32 B contiguous per channel block.
 __global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out, int H,
                                                          int W, int Cout, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float s_wt[];   // [27][Cout] then bias[Cout]
+  extern __shared__ __attribute__((aligned(16))) float s_wt[];   // [Cout/8][27][8] then bias[Cout]
   for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
     const int co = i / 27, k = i - co * 27;                       // OIHW: w[co][ci][kh][kw], k = ci*9 + kh*3 + kw
-    s_wt[k * Cout + co] = w[i];
+    s_wt[((co >> 3) * 27 + k) * 8 + (co & 7)] = w[i];
   }
   for (int i = threadIdx.x; i < Cout; i += blockDim.x) s_wt[27 * Cout + i] = bias[i];
   __syncthreads();
   const int nblk = Cout >> 3;
-  const long total = (long)H * W * nblk;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    // pixel fastest inside a channel block -> each wave writes 64 pixels x 32 B contiguous
-    const long pix = idx % ((long)H * W);
-    const int cb = (int)(idx / ((long)H * W));
+  const long hw = (long)H * W;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < hw; pix += (long)gridDim.x * blockDim.x) {
     const int h = (int)(pix / W), x = (int)(pix - (long)h * W);
-    float acc[8];
+    float v[27];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = s_wt[27 * Cout + cb * 8 + e];
-#pragma unroll 1
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int ih = h + kh - 1;
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int iw = x + kw - 1;
-          const float v = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? in[((long)ci * H + ih) * W + iw] : 0.f;
-          const float* wr = s_wt + (ci * 9 + kh * 3 + kw) * Cout + cb * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wr[e], acc[e]);
+          const int ih = h + kh - 1, iw = x + kw - 1;
+          // clamped address + select: no load under a branch
+          const float t = in[((long)ci * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
+          v[ci * 9 + kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? t : 0.f;
         }
-      }
-    if (relu) {
+#pragma unroll 1
+    for (int cb = 0; cb < nblk; ++cb) {
+      const float4* wr = reinterpret_cast<const float4*>(s_wt + (long)cb * 27 * 8);
+      const float4 b0 = *reinterpret_cast<const float4*>(s_wt + 27 * Cout + cb * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(s_wt + 27 * Cout + cb * 8 + 4);
+      float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+      for (int k = 0; k < 27; ++k) {                             // same k order as before: ci, kh, kw
+        const float4 w0 = wr[2 * k], w1 = wr[2 * k + 1];
+        acc[0] = fmaf(v[k], w0.x, acc[0]); acc[1] = fmaf(v[k], w0.y, acc[1]);
+        acc[2] = fmaf(v[k], w0.z, acc[2]); acc[3] = fmaf(v[k], w0.w, acc[3]);
+        acc[4] = fmaf(v[k], w1.x, acc[4]); acc[5] = fmaf(v[k], w1.y, acc[5]);
+        acc[6] = fmaf(v[k], w1.z, acc[6]); acc[7] = fmaf(v[k], w1.w, acc[7]);
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+      }
+      float4* dst = reinterpret_cast<float4*>(out + ((long)cb * hw + pix) * 8);
+      dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
-    float4* dst = reinterpret_cast<float4*>(out + ((long)cb * H * W + pix) * 8);
-    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
 }
 
@@ -471,8 +480,7 @@ int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in, const float* d_w, const floa
   MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && Cout <= 512, "mnc_conv3x3_c3: unsupported shape");
   const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + Cout);
   LaunchScope ls(ctx, "conv3x3_c3", flops, bytes);
-  const long total = (long)H * W * (Cout / 8);
-  hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid_for(total)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w,
+  hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid_for((long)H * W)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w,
                      d_bias, d_out, H, W, Cout, relu);
   return ls.finish("conv3x3_c3_kernel");
 }
