@@ -48,6 +48,11 @@ class InstanceGatherer(object):
         self.device = device
         self.send = torch.empty((cap, REC_DIM), dtype=torch.float32, device=device)
         self.recv = [torch.empty((cap, REC_DIM), dtype=torch.float32, device=device) for _ in range(self.world)]
+        # first collective = communicator setup (seconds with RCCL): pay it here, never inside a timed or latency-critical step
+        self.send.zero_()
+        dist.all_gather(self.recv, self.send)
+        if device is not None and str(device).startswith("cuda"):
+            torch.cuda.synchronize()
 
     def gather(self, rec):
         """rec: numpy [cap, 447].  Returns the list of per-rank blocks as tensors (valid on every rank)."""
