@@ -216,3 +216,27 @@ def test_bbox_overlaps_c_abi():
     a = GI._boxes(rng, 600, 1000, 600).astype(np.float64)
     q = GI._boxes(rng, 5, 1000, 600).astype(np.float64)
     assert np.array_equal(bbox_overlaps(a, q), native.bbox_overlaps(a, q))
+
+
+@pytest.mark.parametrize("n,thr", [(6000, 0.7), (600, 0.3)])
+def test_nms_properties_at_full_size(n, thr):
+    """Size-independent properties at the RPN's 6000 candidates / the voting's 600 instances: kept indices are in descending
+    score order, no two kept boxes overlap by more than the threshold, every suppressed box overlaps an earlier kept one, and
+    NMS of the kept set keeps everything (idempotence)."""
+    from nms.gpu_nms import gpu_nms
+    from oracle import native as onative
+    dets = GI.nms_case(n, 77)
+    keep = np.array(gpu_nms(dets, thr))
+    assert len(keep) and np.all(np.diff(dets[keep, 4]) <= 0)
+    iou = onative.bbox_overlaps(dets[keep, :4].astype(np.float64), dets[keep, :4].astype(np.float64))
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= thr + 1e-6
+    order = np.argsort(-dets[:, 4], kind="stable")
+    rank = np.empty(n, np.int64)
+    rank[order] = np.arange(n)
+    dropped = np.setdiff1d(np.arange(n), keep)
+    ov = onative.bbox_overlaps(dets[dropped, :4].astype(np.float64), dets[keep, :4].astype(np.float64))
+    earlier = rank[keep][None, :] < rank[dropped][:, None]
+    assert np.all(((ov > thr - 1e-6) & earlier).any(1))
+    again = gpu_nms(dets[keep], thr)
+    assert list(again) == list(range(len(keep)))

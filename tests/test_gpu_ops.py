@@ -334,3 +334,72 @@ def test_profiling_records(dev):
     assert name.value == b"maxpool2_c8" and ms.value >= 0
     dev.call("mnc_prof_enable", 0)
     dev.call("mnc_prof_reset")
+
+
+# ---- size-independent properties at BASELINE's full sizes (the oracle is too slow there) -----------------------------------
+@pytest.mark.parametrize("fn,pack,pitch", [("mnc_conv3x3", "mnc_pack_conv3x3_weights", 76),
+                                           ("mnc_conv3x3_bf16x3", "mnc_pack_conv3x3_bf16x3", 84)])
+def test_conv3x3_full_size_linearity_and_shift(dev, fn, pack, pitch):
+    """conv3_2's shape (150x250, 256 -> 256), no bias / ReLU: scaling the input by a power of two scales the output exactly
+    (fp32 and split-bf16 arithmetic alike), an impulse input reproduces the (flipped) filter taps, and a zero input gives
+    exactly the bias."""
+    H, W, Cin, Cout = 150, 250, 256, 256
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b0, b1 = np.zeros(Cout, np.float32), rng.normal(size=Cout).astype(np.float32)
+    d_w = dev.empty(((Cin // 8) * Cout * pitch,))
+    dev.call(pack, dev.put(w), d_w, Cout, Cin)
+
+    def run(inp, bias):
+        d_y = dev.empty((Cout * H * W,), fill=np.nan)
+        dev.call(fn, dev.put(to_c8(inp)), d_w, dev.put(bias), d_y, H, W, Cin, Cout, 0)
+        return from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+
+    y = run(x, b0)
+    assert np.isfinite(y).all()
+    assert np.array_equal(run(x * np.float32(4.0), b0), y * np.float32(4.0))
+    z = run(np.zeros_like(x), b1)
+    assert np.array_equal(z, np.broadcast_to(b1[:, None, None], z.shape))
+    imp = np.zeros_like(x)
+    imp[17, 70, 123] = 1.0
+    r = run(imp, b0)
+    tol = 0 if fn == "mnc_conv3x3" else 2.0 ** -15
+    for kh in range(3):
+        for kw in range(3):
+            got, want = r[:, 70 + 1 - kh, 123 + 1 - kw], w[:, 17, kh, kw]
+            assert np.all(np.abs(got - want) <= tol * np.abs(want)), (kh, kw)
+    r[:, 69:72, 122:125] = 0
+    assert not r.any()
+
+
+@pytest.mark.parametrize("fn,pack", [("mnc_fc", None), ("mnc_fc_bf16x3", "mnc_pack_fc_bf16x3")])
+def test_fc_full_size_linearity(dev, fn, pack):
+    """fc6's shape (300 x 25088 -> 4096), no bias / activation: exact power-of-two scaling, zero input -> bias, and a one-hot
+    row selects a weight column (exactly in fp32, to 2^-15 in split bf16)."""
+    M, N, K = 300, 4096, 25088
+    rng = np.random.default_rng(6)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b0, b1 = np.zeros(N, np.float32), rng.normal(size=N).astype(np.float32)
+    d_w = dev.put(w)
+    if pack:
+        d_wp = dev.empty(((N + 127) // 128 * 128 * K,))
+        dev.call(pack, d_w, d_wp, N, K)
+        d_w = d_wp
+
+    def run(inp, bias):
+        d_o = dev.empty((M * N,), fill=np.nan)
+        dev.call(fn, dev.put(inp), d_w, dev.put(bias), d_o, M, N, K, N, 0)
+        return dev.get(d_o, (M, N))
+
+    y = run(a, b0)
+    assert np.isfinite(y).all()
+    assert np.array_equal(run(a * np.float32(0.5), b0), y * np.float32(0.5))
+    assert np.array_equal(run(np.zeros_like(a), b1), np.broadcast_to(b1, (M, N)))
+    onehot = np.zeros_like(a)
+    cols = rng.integers(0, K, M)
+    onehot[np.arange(M), cols] = 1.0
+    got, want = run(onehot, b0), w[:, cols].T
+    tol = 0 if fn == "mnc_fc" else 2.0 ** -15
+    assert np.all(np.abs(got - want) <= tol * np.abs(want))
