@@ -182,6 +182,12 @@ MNC_API int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score_nchw, float* d_pr
  * 2PH x 2PW and max-reduced, so the 28x28 "premax" tensor never reaches HBM. */
 MNC_API int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R,
                          int PH, int PW, float spatial_scale, int pool2, float* d_out_rhwc);
+/* ROIPooling (models/VGG16/cfm/test.prototxt:397-407 7x7, :446-456 14x14; the Fast R-CNN layer of the absent caffe-mnc
+ * submodule, restated in oracle/SPEC.md section 4): max over the integer bins of round(roi * spatial_scale).  The feature
+ * is a batch of N c8 images [N][C/8][H][W][8] (CFM feeds an image pyramid, lib/caffeWrapper/TesterWrapper.py:371-399);
+ * rois are [R][5] = (batch index, x1, y1, x2, y2); output [R][PH][PW][C].  Empty bins give 0. */
+MNC_API int mnc_roi_pool(mnc_ctx* ctx, const float* d_feat_c8, int N, int C, int H, int W, const float* d_rois, int R,
+                         int PH, int PW, float spatial_scale, float* d_out_rhwc);
 /* Pooling MAX 2x2/2 on per-RoI features [R][PH][PW][C] -> [R][PH/2][PW/2][C] (test.prototxt:571-582,...). */
 MNC_API int mnc_maxpool2_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C);
 /* MaskResize (test.prototxt:558-567) per SPEC.md section 2: [R][IH][IW] -> [R][OH][OW]. */

@@ -264,6 +264,24 @@ __global__ void softmax_rows_kernel(const float* __restrict__ in, int ld_in, flo
   for (int i = 0; i < N; ++i) out[(long)m * N + i] = expf(r[i] - mx) / sum;
 }
 
+// N <= 64: one wavefront per row, one element per lane.  The exponentials are computed once, in parallel; the sum is
+// taken in the SAME sequential order as the kernel above (every lane walks the row through shuffles), so both variants
+// return identical bits.
+__global__ __launch_bounds__(256) void softmax_rows_wave_kernel(const float* __restrict__ in, int ld_in,
+                                                                float* __restrict__ out, int M, int N) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const bool live = lane < N;
+  const float v = live ? in[(long)m * ld_in + lane] : -INFINITY;
+  float mx = v;
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float e = live ? expf(v - mx) : 0.f;
+  float sum = 0.f;
+  for (int i = 0; i < N; ++i) sum += __shfl(e, i);
+  if (live) out[(long)m * N + lane] = e / sum;
+}
+
 __global__ void eltwise_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, int op) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     out[i] = apply_act(in[i], op);
@@ -363,7 +381,10 @@ int mnc_softmax_rows_ld(mnc_ctx* ctx, const float* d_in, int ld_in, float* d_out
   MNC_REQUIRE(ctx && d_in && d_out && M >= 0 && N > 0 && ld_in >= N, "mnc_softmax_rows: bad argument");
   if (M == 0) return MNC_OK;
   LaunchScope ls(ctx, "softmax_rows");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 64)), dim3(64), 0, ctx->stream, d_in, ld_in, d_out, M, N);
+  if (N <= 64)
+    hipLaunchKernelGGL(softmax_rows_wave_kernel, dim3(cdiv(M, 4)), dim3(256), 0, ctx->stream, d_in, ld_in, d_out, M, N);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 64)), dim3(64), 0, ctx->stream, d_in, ld_in, d_out, M, N);
   return ls.finish("softmax_rows_kernel");
 }
 

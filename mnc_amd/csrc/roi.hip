@@ -9,6 +9,8 @@
 // every kernel below reads/writes 16-byte vectors along C.  All of this is HBM/L2-bound gather/elementwise work: no LDS
 // staging is needed because conv5_3 (4.9 MB at 600x1000) stays L2/Infinity-Cache resident across the 300 RoIs; ROIWarping
 // first re-lays it out pixel-major so that every bilinear tap of a wave is one contiguous kilobyte.
+#include <cfloat>
+
 #include "mnc_internal.h"
 
 namespace mnc {
@@ -218,6 +220,65 @@ int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const f
     hipLaunchKernelGGL(roi_warp_kernel<0>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH,
                        PW, scale, d_out);
   return ls.finish("roi_warp_kernel");
+}
+
+// ---- ROIPooling (Fast R-CNN max pooling over integer bins; models/VGG16/cfm/test.prototxt:397-407, 446-456) ---------
+// One thread per (roi, ph, pw, group of 8 channels), channel group fastest: the [R][PH][PW][C] output is written in
+// contiguous 32-byte pieces and each read is one 32-byte c8 pixel.  `v > max` comparisons (not fmaxf) so that NaN features
+// are skipped exactly as in Caffe's kernel; an empty bin yields 0.
+__global__ __launch_bounds__(256) void roi_pool_kernel(const float* __restrict__ feat, int N, int C8, int H, int W,
+                                                       const float* __restrict__ rois, int PH, int PW, float scale,
+                                                       long total, float* __restrict__ out) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % C8);
+    long t = idx / C8;
+    const int pw = (int)(t % PW);
+    t /= PW;
+    const int ph = (int)(t % PH);
+    const long r = t / PH;
+    const float* roi = rois + r * 5;
+    int b = (int)roi[0];
+    b = b < 0 ? 0 : (b >= N ? N - 1 : b);               // Caffe CHECKs the index on its CPU path only; stay in bounds
+    const int x1 = (int)roundf(roi[1] * scale), y1 = (int)roundf(roi[2] * scale);
+    const int x2 = (int)roundf(roi[3] * scale), y2 = (int)roundf(roi[4] * scale);
+    const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+    int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+    hs = min(max(hs + y1, 0), H);
+    he = min(max(he + y1, 0), H);
+    ws = min(max(ws + x1, 0), W);
+    we = min(max(we + x1, 0), W);
+    const bool empty = he <= hs || we <= ws;
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = empty ? 0.f : -FLT_MAX;
+    const float* plane = feat + (((long)b * C8 + c8) * H) * (long)W * 8;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w) {
+        const float4 a = *reinterpret_cast<const float4*>(plane + ((long)h * W + w) * 8);
+        const float4 c = *reinterpret_cast<const float4*>(plane + ((long)h * W + w) * 8 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (v[k] > m[k]) m[k] = v[k];
+      }
+    float* o = out + idx * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(m[4], m[5], m[6], m[7]);
+  }
+}
+
+int mnc_roi_pool(mnc_ctx* ctx, const float* d_feat, int N, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
+                 float scale, float* d_out) {
+  MNC_REQUIRE(ctx && d_feat && d_out && (R == 0 || d_rois), "mnc_roi_pool: null pointer");
+  MNC_REQUIRE(N > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "mnc_roi_pool: bad shape");
+  if (R == 0) return MNC_OK;
+  const long total = (long)R * PH * PW * (C / 8);
+  LaunchScope ls(ctx, "roi_pool", 0.0, 4.0 * (double)R * PH * PW * C * 2.0);
+  hipLaunchKernelGGL(roi_pool_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, N, C / 8, H, W, d_rois, PH, PW,
+                     scale, total, d_out);
+  return ls.finish("roi_pool_kernel");
 }
 
 int mnc_maxpool2_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C) {

@@ -84,7 +84,7 @@ class _DevBuf(object):
 class Blob(object):
     """A named tensor with Caffe's logical shape.  Device storage uses one of the engine layouts:
          'plain' row-major in Caffe order (optionally a column slice of a wider matrix: ld > shape[1])
-         'c8'    [C/8][H][W][8]      for shape (1, C, H, W)
+         'c8'    [N][C/8][H][W][8]   for shape (N, C, H, W): N whole images back to back (N > 1 only in the CFM pyramid)
          'rhwc'  [R][PH][PW][C]      for shape (R, C, PH, PW)
     Exactly one of (host, device) may be stale; `.data` makes the host copy current and hands it out."""
 
@@ -187,11 +187,13 @@ class Blob(object):
         h = net._ctx.h
         src = self.dev_ptr()
         if self.layout == "plain" and layout == "c8":
-            _, C, H, W = self.shape
-            _lib.call("mnc_nchw_to_c8", h, src, tmp, C, H, W)
+            N, C, H, W = self.shape
+            for n in range(N):
+                _lib.call("mnc_nchw_to_c8", h, src + n * C * H * W * 4, tmp + n * C * H * W * 4, C, H, W)
         elif self.layout == "c8" and layout == "plain":
-            _, C, H, W = self.shape
-            _lib.call("mnc_c8_to_nchw", h, src, tmp, C, H, W)
+            N, C, H, W = self.shape
+            for n in range(N):
+                _lib.call("mnc_c8_to_nchw", h, src + n * C * H * W * 4, tmp + n * C * H * W * 4, C, H, W)
         elif self.layout == "plain" and layout == "rhwc":
             R, C, PH, PW = self.shape
             _lib.call("mnc_rchw_to_rhwc", h, src, tmp, R, C, PH, PW)
@@ -220,8 +222,9 @@ class Blob(object):
             return
         tmp = net._tmp.ensure(n * 4)
         if self.layout == "c8":
-            _, C, H, W = self.shape
-            _lib.call("mnc_c8_to_nchw", h, self.dev_ptr(), tmp, C, H, W)
+            N, C, H, W = self.shape
+            for i in range(N):
+                _lib.call("mnc_c8_to_nchw", h, self.dev_ptr() + i * C * H * W * 4, tmp + i * C * H * W * 4, C, H, W)
         else:
             R, C, PH, PW = self.shape
             _lib.call("mnc_rhwc_to_rchw", h, self.dev_ptr(), tmp, R, C, PH, PW)
@@ -298,6 +301,8 @@ class _Outputs(Mapping):
 
 
 class Net(object):
+    supports_partial_forward = True      # forward(start=..., end=...) re-uses the blobs of the previous call
+
     def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None, math=None):
         if device_id is None:
             try:
@@ -474,10 +479,13 @@ class Net(object):
             d_w = self._dev_param(key + ("w",), lambda: self._upload(W))
 
             def run():
-                _, _, H, Wd = bot.shape
+                N, _, H, Wd = bot.shape
                 src = bot.dev_in("plain")
-                top.reshape(1, cout, H, Wd)
-                _lib.call("mnc_conv3x3_c3", self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cout, relu)
+                top.reshape(N, cout, H, Wd)
+                dst = top.dev_out("c8")
+                for n in range(N):                       # one launch sequence per image of the batch
+                    _lib.call("mnc_conv3x3_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4,
+                              H, Wd, cout, relu)
             return run
         if k == 3 and pad == 1 and stride == 1:
             x3 = self.math == "bf16x3"
@@ -493,19 +501,25 @@ class Net(object):
             d_w = self._dev_param(key + ("w", "x3" if x3 else "fp32"), build)
 
             def run():
-                _, _, H, Wd = bot.shape
+                N, _, H, Wd = bot.shape
                 src = bot.dev_in("c8")
-                top.reshape(1, cout, H, Wd)
-                _lib.call(conv, self._h(), src, d_w, d_b, top.dev_out("c8"), H, Wd, cin, cout, relu)
+                top.reshape(N, cout, H, Wd)
+                dst = top.dev_out("c8")
+                for n in range(N):
+                    _lib.call(conv, self._h(), src + n * cin * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4, H, Wd, cin,
+                              cout, relu)
             return run
         if k == 1 and pad == 0 and stride == 1 and not L.relu:
             d_w = self._dev_param(key + ("w",), lambda: self._upload(W.reshape(cout, cin)))
 
             def run():
-                _, _, H, Wd = bot.shape
+                N, _, H, Wd = bot.shape
                 src = bot.dev_in("c8")
-                top.reshape(1, cout, H, Wd)
-                _lib.call("mnc_conv1x1_to_nchw", self._h(), src, d_w, d_b, top.dev_out("plain"), H, Wd, cin, cout)
+                top.reshape(N, cout, H, Wd)
+                dst = top.dev_out("plain")
+                for n in range(N):
+                    _lib.call("mnc_conv1x1_to_nchw", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
+                              dst + n * cout * H * Wd * 4, H, Wd, cin, cout)
             return run
         raise NotImplementedError("Convolution %s: kernel %r pad %r stride %r" % (L.name, k, pad, stride))
 
@@ -534,11 +548,14 @@ class Net(object):
         bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
 
         def run():
-            if bot.shape[0] == 1 and (bot._dev_valid and bot.layout == "c8"):
-                _, C, H, W = bot.shape
+            if bot._dev_valid and bot.layout == "c8":
+                N, C, H, W = bot.shape
                 src = bot.dev_in("c8")
-                top.reshape(1, C, _pool_out(H), _pool_out(W))
-                _lib.call("mnc_maxpool2_c8", self._h(), src, top.dev_out("c8"), C, H, W)
+                OH, OW = _pool_out(H), _pool_out(W)
+                top.reshape(N, C, OH, OW)
+                dst = top.dev_out("c8")
+                for n in range(N):
+                    _lib.call("mnc_maxpool2_c8", self._h(), src + n * C * H * W * 4, dst + n * C * OH * OW * 4, C, H, W)
             else:
                 R, C, PH, PW = bot.shape
                 src = bot.dev_in("rhwc")
@@ -602,11 +619,28 @@ class Net(object):
         oh, ow = (ph // 2, pw // 2) if pool2 else (ph, pw)
 
         def run():
-            _, C, H, W = feat.shape
+            N, C, H, W = feat.shape
+            if N != 1:
+                raise NotImplementedError("ROIWarping %s: one image per forward (got a batch of %d)" % (L.name, N))
             R = rois.shape[0]
             d_feat, d_rois = feat.dev_in("c8"), rois.dev_in("plain")
             top.reshape(R, C, oh, ow)
             _lib.call("mnc_roi_warp", self._h(), d_feat, C, H, W, d_rois, R, oh, ow, scale, pool2, top.dev_out("rhwc"))
+        return run
+
+    def _bind_ROIPooling(self, L, i):
+        """Fast R-CNN RoI max pooling over a batch of images (CFM: models/VGG16/cfm/test.prototxt:397-407, 446-456)."""
+        rp = L.msg.get1("roi_pooling_param")
+        ph, pw, scale = rp.get1("pooled_h"), rp.get1("pooled_w"), float(rp.get1("spatial_scale"))
+        feat, rois = self.blobs[L.bottoms[0]], self.blobs[L.bottoms[1]]
+        top = self.blobs[L.tops[0]]
+
+        def run():
+            N, C, H, W = feat.shape
+            R = rois.shape[0]
+            d_feat, d_rois = feat.dev_in("c8"), rois.dev_in("plain")
+            top.reshape(R, C, ph, pw)
+            _lib.call("mnc_roi_pool", self._h(), d_feat, N, C, H, W, d_rois, R, ph, pw, scale, top.dev_out("rhwc"))
         return run
 
     def _bind_MaskResize(self, L, i):
@@ -776,7 +810,8 @@ class Net(object):
             dst = top.dev_out("plain")
             off = 0
             for b, s in zip(bots, srcs):
-                _lib.call("mnc_copy2d", self._h(), dst + off * 4, total, s, b._ld(), R, b.shape[1])
+                if R:
+                    _lib.call("mnc_copy2d", self._h(), dst + off * 4, total, s, b._ld(), R, b.shape[1])
                 off += b.shape[1]
         return run
 
@@ -884,13 +919,22 @@ class Net(object):
         return boxes, scores
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, **kwargs):
+    def forward(self, blobs=None, start=None, end=None, **kwargs):
+        """pycaffe's Net.forward: kwargs are input blobs; `start` / `end` name the first / last layer to run (everything
+        before `start` keeps the values of the previous call -- the CFM tester re-runs only the RoI heads on the next chunk
+        of proposals, lib/caffeWrapper/TesterWrapper.py:386-407); `blobs` lists extra blobs to return."""
         for name, arr in kwargs.items():
             if name not in self.inputs:
                 raise KeyError("%r is not an input blob of this net (%r)" % (name, self.inputs))
             self.blobs[name].set_host(arr)
+        names = [L.name for L in self._layers]
+        for nm in (start, end):
+            if nm is not None and nm not in names:
+                raise KeyError("%r is not a layer of this net" % (nm,))
+        first = names.index(start) if start is not None else 0
+        stop = names.index(end) + 1 if end is not None else len(self._layers)
         self._speculated = None
-        self._run_layers(0)
+        self._run_layers(first, stop)
         if self._speculated is not None:
             # The native ProposalLayer left its RoI count on the device and the heads ran on all `post` rows (the rows are
             # independent; rows past the count are zero boxes), so the trunk -> heads hand-over needs no host round trip.
@@ -903,11 +947,12 @@ class Net(object):
             if n.value < post:
                 top.shape = (n.value, 5)
                 top._host, top._host_valid, top._dev_valid = None, False, True
-                self._run_layers(index + 1)
+                self._run_layers(index + 1, stop)
                 _lib.call("mnc_ctx_sync", self._ctx.h)
         else:
             _lib.call("mnc_ctx_sync", self._ctx.h)
-        return _Outputs(self, [name for name in self.outputs if self.blobs[name]._dev_valid or self.blobs[name]._host_valid])
+        wanted = list(self.outputs) + [b for b in (blobs or []) if b not in self.outputs]
+        return _Outputs(self, [name for name in wanted if self.blobs[name]._dev_valid or self.blobs[name]._host_valid])
 
     def detect_tail(self, scale, im_shape):
         """The tail of im_detect (tools/demo.py:84-100) without leaving the GPU: (boxes [2R,4] in original-image pixels,
@@ -938,9 +983,9 @@ class Net(object):
         return (DeviceArray(self, d_boxes, (n, 4), self._tail_bufs), DeviceArray(self, d_masks, (n, 1, S, S), self._tail_bufs),
                 DeviceArray(self, d_scores, (n, K), self._tail_bufs))
 
-    def _run_layers(self, start):
+    def _run_layers(self, start, stop=None):
         pre = getattr(self, "_pre_steps", {})
-        for i in range(start, len(self._layers)):
+        for i in range(start, len(self._layers) if stop is None else stop):
             L = self._layers[i]
             if L.run is None:
                 continue

@@ -1,7 +1,8 @@
-"""Test-time driver of the 5-stage MNC net over an image database (reference: lib/caffeWrapper/TesterWrapper.py:25-83,
-149-284: `seg` task = per-image forward -> un-scale/clip/concat of both stages -> gpu_mask_voting (or per-class NMS) ->
-res_boxes.pkl / res_masks.pkl -> imdb.evaluate_segmentation).  Python-3 port of the caller on the output side of the hot
-path; the `det`, `cfm` and `vis_seg` tasks belong to other graphs and are not provided."""
+"""Test-time driver of the reference's three inference graphs over an image database (reference:
+lib/caffeWrapper/TesterWrapper.py:25-414).  `seg` = MNC 5-stage: per-image forward -> un-scale/clip/concat of both stages ->
+gpu_mask_voting (or per-class NMS) -> res_boxes.pkl / res_masks.pkl -> imdb.evaluate_segmentation (SURVEY section 8f row
+n1); `det` = Faster R-CNN end2end and `cfm` = convolutional feature masking over MCG proposals (row n3).  `vis_seg` (image
+rendering) is not provided."""
 import heapq
 import os
 import pickle
@@ -11,9 +12,9 @@ import numpy as np
 import caffe
 from mnc_config import cfg, get_output_dir
 from nms.nms_wrapper import apply_nms, apply_nms_mask_single
-from transform.bbox_transform import bbox_transform_inv, clip_boxes
+from transform.bbox_transform import bbox_transform_inv, clip_boxes, filter_small_boxes
 from transform.mask_transform import gpu_mask_voting
-from utils.blob import im_list_to_blob, prep_im_for_blob
+from utils.blob import im_list_to_blob, prep_im_for_blob, prep_im_for_blob_cfm, pred_rois_for_blob, resize_to
 from utils.image_io import imread
 from utils.timer import Timer
 
@@ -38,21 +39,22 @@ class TesterWrapper(object):
         seg_file = os.path.join(self.output_dir, 'res_masks.pkl')
         if self.task_name == 'det':
             return self.get_detection_result()
-        if self.task_name != 'seg':
-            raise NotImplementedError("task %r: 'seg' (MNC 5-stage) and 'det' (Faster R-CNN end2end) are provided; 'cfm' and "
-                                      "'vis_seg' are not" % self.task_name)
+        if self.task_name not in ('seg', 'cfm'):
+            raise NotImplementedError("task %r: 'seg' (MNC 5-stage), 'det' (Faster R-CNN end2end) and 'cfm' are provided; "
+                                      "'vis_seg' is not" % self.task_name)
         if os.path.isfile(det_file) and os.path.isfile(seg_file):
             with open(det_file, 'rb') as f:
                 seg_box = pickle.load(f)
             with open(seg_file, 'rb') as f:
                 seg_mask = pickle.load(f)
         else:
-            seg_box, seg_mask = self.get_segmentation_result()
+            seg_box, seg_mask = self.get_segmentation_result() if self.task_name == 'seg' else self.get_cfm_result()
             with open(det_file, 'wb') as f:
                 pickle.dump(seg_box, f, pickle.HIGHEST_PROTOCOL)
             with open(seg_file, 'wb') as f:
                 pickle.dump(seg_mask, f, pickle.HIGHEST_PROTOCOL)
-        print('Evaluating segmentation using MNC 5 stage inference')
+        print('Evaluating segmentation using MNC 5 stage inference' if self.task_name == 'seg' else
+              'Evaluating segmentation using convolutional feature masking')
         return self.imdb.evaluate_segmentation(seg_box, seg_mask, self.output_dir)
 
     def get_detection_result(self):
@@ -180,3 +182,110 @@ class TesterWrapper(object):
         self.net.blobs['data'].reshape(*data.shape)
         self.net.blobs['im_info'].reshape(*im_info.shape)
         return {'data': data.astype(np.float32, copy=False), 'im_info': im_info.astype(np.float32, copy=False)}, im_scales
+
+    # ------------------------------------------------------------------------------------------------ CFM (row n3)
+    def get_cfm_result(self):
+        """TesterWrapper.py:286-335: per class score threshold heap, top max_per_image rows, NMS on boxes with the masks
+        riding along; all_boxes[cls][image] = [n,5], all_masks[cls][image] = [n,1,21,21]."""
+        thresh = -np.inf * np.ones(self.num_classes)
+        top_scores = [[] for _ in range(self.num_classes)]
+        all_boxes = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
+        all_masks = [[[] for _ in range(self.num_images)] for _ in range(self.num_classes)]
+        _t = {'im_detect': Timer(), 'misc': Timer()}
+        for i in range(self.num_images):
+            _t['im_detect'].tic()
+            masks, boxes, seg_scores = self.cfm_network_forward(i)
+            for j in range(1, self.num_classes):
+                inds = np.where(seg_scores[:, j] > thresh[j])[0]
+                cls_scores, cls_boxes, cls_masks = seg_scores[inds, j], boxes[inds, :], masks[inds, :]
+                top_inds = np.argsort(-cls_scores)[:self.max_per_image]
+                cls_scores, cls_boxes, cls_masks = cls_scores[top_inds], cls_boxes[top_inds, :], cls_masks[top_inds, :]
+                for val in cls_scores:
+                    heapq.heappush(top_scores[j], val)
+                if len(top_scores[j]) > self.max_per_set:
+                    while len(top_scores[j]) > self.max_per_set:
+                        heapq.heappop(top_scores[j])
+                    thresh[j] = top_scores[j][0]
+                box_before_nms = np.hstack((cls_boxes, cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+                mask_before_nms = cls_masks.astype(np.float32, copy=False)
+                all_boxes[j][i], all_masks[j][i] = apply_nms_mask_single(box_before_nms, mask_before_nms, cfg.TEST.NMS)
+            _t['im_detect'].toc()
+            print('process image %d/%d, forward average time %f' % (i, self.num_images, _t['im_detect'].average_time))
+        for j in range(1, self.num_classes):
+            for i in range(self.num_images):
+                inds = np.where(all_boxes[j][i][:, -1] > thresh[j])[0]
+                all_boxes[j][i] = all_boxes[j][i][inds, :]
+                all_masks[j][i] = all_masks[j][i][inds]
+        return all_boxes, all_masks
+
+    def _load_mcg_maskdb(self, im_i):
+        """{'boxes': [n,4], 'masks': [n,S,S]} of image im_i: the .mat files tools/prepare_mcg_maskdb.py writes
+        (TesterWrapper.py:339-341).  scipy is needed for this task only."""
+        import scipy.io
+        path = os.path.join(cfg.TEST.get('MCG_MASKDB_DIR', 'data/cache/voc_2012_val_mcg_maskdb/'),
+                            self.imdb._image_index[im_i] + '.mat')
+        return scipy.io.loadmat(path)
+
+    def cfm_network_forward(self, im_i):
+        """TesterWrapper.py:337-414: MCG proposals -> pyramid level per box (area closest to 224^2) -> per group of
+        cfg.TEST.GROUP_SCALE adjacent levels one data blob, rois fed in chunks of cfg.TEST.MAX_ROIS_GPU[group] ->
+        (mask_prob [n,1,21,21], the proposals' own boxes [n,4], seg_cls_prob [n,K]) in level-group order."""
+        im = imread(self.imdb.image_path_at(im_i))
+        roidb = self._load_mcg_maskdb(im_i)
+        boxes = roidb['boxes']
+        filter_keep = filter_small_boxes(boxes, min_size=16)
+        boxes = boxes[filter_keep, :]
+        masks = roidb['masks'][filter_keep, :, :]
+        assert boxes.shape[0] == masks.shape[0]
+        size = cfg.TEST.CFM_INPUT_MASK_SIZE
+        mask_resize = np.zeros((masks.shape[0], size, size))
+        for i in range(masks.shape[0]):
+            mask_resize[i, :, :] = resize_to(masks[i, :, :].astype(np.float32), size, size)    # cv2.resize(..., (size, size))
+        masks = mask_resize
+        if cfg.TEST.USE_TOP_K_MCG:
+            num_keep = min(boxes.shape[0], cfg.TEST.USE_TOP_K_MCG)
+            boxes, masks = boxes[:num_keep, :], masks[:num_keep, :, :]
+        # multi-scale test: adjacent levels are grouped into one forward
+        _, im_scale_factors = prep_im_for_blob_cfm(im, cfg.TEST.SCALES)
+        orig_boxes = boxes.copy()
+        boxes = pred_rois_for_blob(boxes, im_scale_factors)
+        group = cfg.TEST.GROUP_SCALE
+        num_scale_iter = int(np.ceil(len(cfg.TEST.SCALES) / float(group)))
+        lo_scale = 0
+        res_boxes = np.zeros((0, 4), dtype=np.float32)
+        res_masks = np.zeros((0, 1, cfg.MASK_SIZE, cfg.MASK_SIZE), dtype=np.float32)
+        res_seg_scores = np.zeros((0, self.num_classes), dtype=np.float32)
+        partial = getattr(self.net, 'supports_partial_forward', False)      # pycaffe's forward(start=...), see below
+        for scale_iter in range(num_scale_iter):
+            hi_scale = min(lo_scale + group, len(cfg.TEST.SCALES))
+            inds_this_scale = np.where((boxes[:, 0] >= lo_scale) & (boxes[:, 0] < hi_scale))[0]
+            if len(inds_this_scale) == 0:
+                lo_scale += group
+                continue
+            max_rois = cfg.TEST.MAX_ROIS_GPU[scale_iter]
+            boxes_this_scale = boxes[inds_this_scale, :]
+            masks_this_scale = masks[inds_this_scale, :, :]
+            # the batch index starts from the lowest level PRESENT (not from lo_scale), as in the reference (:381)
+            boxes_this_scale[:, 0] -= min(boxes_this_scale[:, 0])
+            data, _ = prep_im_for_blob_cfm(im, cfg.TEST.SCALES[lo_scale:hi_scale])
+            data = data.astype(np.float32, copy=False)
+            for test_iter, start in enumerate(range(0, boxes_this_scale.shape[0], max_rois)):
+                end = min(start + max_rois, boxes_this_scale.shape[0])
+                input_box = boxes_this_scale[start:end, :].astype(np.float32, copy=False)
+                input_mask = masks_this_scale[start:end, :, :].reshape(end - start, 1, size, size).astype(np.float32, copy=False)
+                input_mask = (input_mask >= cfg.BINARIZE_THRESH).astype(np.float32, copy=False)
+                self.net.blobs['rois'].reshape(*input_box.shape)
+                self.net.blobs['masks'].reshape(*input_mask.shape)
+                if partial and test_iter > 0:
+                    # same pyramid as the previous chunk: conv5_3 is still on the GPU, only the RoI heads are run again
+                    blobs_out = self.net.forward(start='roi_pooling_conv5', rois=input_box, masks=input_mask)
+                else:
+                    self.net.blobs['data'].reshape(*data.shape)
+                    blobs_out = self.net.forward(data=data, rois=input_box, masks=input_mask)
+                output_mask = np.array(blobs_out['mask_prob'], dtype=np.float32)
+                output_score = np.array(blobs_out['seg_cls_prob'], dtype=np.float32)
+                res_masks = np.vstack((res_masks, output_mask.reshape(end - start, 1, cfg.MASK_SIZE, cfg.MASK_SIZE)))
+                res_seg_scores = np.vstack((res_seg_scores, output_score))
+            res_boxes = np.vstack((res_boxes, orig_boxes[inds_this_scale, :]))
+            lo_scale += group
+        return res_masks, res_boxes, res_seg_scores

@@ -1,4 +1,4 @@
-"""Image -> network input (reference: lib/utils/blob.py:17-50).  cv2 is not required: the INTER_LINEAR resize of a
+"""Image -> network input (reference: lib/utils/blob.py:17-106).  cv2 is not required: the INTER_LINEAR resize of a
 float32 image is implemented here (OpenCV convention: source = (dst + 0.5)/scale - 0.5, border-clamped)."""
 import numpy as np
 
@@ -62,3 +62,34 @@ def prep_im_for_blob(im, pixel_means, target_size, max_size):
     if np.round(scale * long_) > max_size:
         scale = float(max_size) / float(long_)
     return resize_linear(im, scale, scale), scale
+
+
+def prep_im_for_blob_cfm(im, input_scales):
+    """Image pyramid of the CFM test path (lib/utils/blob.py:53-85): one level per target short side in `input_scales`
+    (long side capped at cfg.TEST.MAX_SIZE), zero-padded into one [L,3,H,W] blob -> (blob, scale factor per level)."""
+    from mnc_config import cfg
+    im_orig = im.astype(np.float32, copy=True)
+    im_orig -= cfg.PIXEL_MEANS
+    short, long_ = np.min(im_orig.shape[0:2]), np.max(im_orig.shape[0:2])
+    ims, factors = [], []
+    for target_size in input_scales:
+        scale = float(target_size) / float(short)
+        if np.round(scale * long_) > cfg.TEST.MAX_SIZE:
+            scale = float(cfg.TEST.MAX_SIZE) / float(long_)
+        ims.append(resize_linear(im_orig, scale, scale))
+        factors.append(scale)
+    return im_list_to_blob(ims), np.array(factors)
+
+
+def pred_rois_for_blob(im_rois, im_scales):
+    """Boxes -> net `rois` rows (level, x1, y1, x2, y2) in float64 (lib/utils/blob.py:88-106): each box goes to the pyramid
+    level where its scaled area is closest to 224 x 224 and is scaled by that level's factor."""
+    im_rois = im_rois.astype(np.float64, copy=False)
+    if len(im_scales) > 1:
+        widths = im_rois[:, 2] - im_rois[:, 0] + 1
+        heights = im_rois[:, 3] - im_rois[:, 1] + 1
+        scaled_areas = (widths * heights)[:, np.newaxis] * (im_scales[np.newaxis, :] ** 2)
+        levels = np.abs(scaled_areas - 224 * 224).argmin(axis=1)[:, np.newaxis]
+    else:
+        levels = np.zeros((im_rois.shape[0], 1), dtype=np.int64)
+    return np.hstack((levels.astype(np.float64), im_rois * im_scales[levels]))

@@ -98,13 +98,8 @@ def _head(e, sfx, rois, warp_direct, d=1):
     _fc(e, "bbox_pred" + sfx, "join_box_mask" + sfx, "bbox_pred" + sfx, 84, "bbox_pred")
 
 
-def _trunk_rpn_proposal(width_div):
-    """VGG-16 trunk, RPN head and the ProposalLayer -- shared by the three test graphs of the reference
-    (models/VGG16/{mnc_5stage,faster_rcnn_end2end,cfm}/test.prototxt:1-470)."""
-    d = width_div
-    e = _Emit("VGG16")
-    e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
-    e.raw('input: "im_info"\ninput_shape { dim: 1 dim: 3 }')
+def _trunk(e, d):
+    """conv1_1 .. conv5_3 with the four MAX 2x2/2 pools (every reference test graph, e.g. mnc_5stage/test.prototxt:19-387)."""
     bottom = "data"
     for item in VGG_CFG:
         if isinstance(item, str):
@@ -116,6 +111,16 @@ def _trunk_rpn_proposal(width_div):
             _conv(e, top, bottom, top, max(width // d, 32), 3, 1)
             _relu(e, "relu" + tag, top)
         bottom = top
+
+
+def _trunk_rpn_proposal(width_div):
+    """VGG-16 trunk, RPN head and the ProposalLayer -- shared by the two RPN test graphs of the reference
+    (models/VGG16/{mnc_5stage,faster_rcnn_end2end}/test.prototxt:1-470)."""
+    d = width_div
+    e = _Emit("VGG16")
+    e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
+    e.raw('input: "im_info"\ninput_shape { dim: 1 dim: 3 }')
+    _trunk(e, d)
     _conv(e, "rpn_conv_3x3", "conv5_3", "rpn_output", max(512 // d, 32), 3, 1)
     _relu(e, "rpn_relu_3x3", "rpn_output")
     _conv(e, "rpn_cls_score", "rpn_output", "rpn_cls_score", 18, 1, 0)
@@ -160,6 +165,49 @@ def faster_rcnn_end2end_test_prototxt(width_div=1):
     _fc(e, "bbox_pred", "fc7", "bbox_pred", 84)
     e.layer("cls_prob", "Softmax", ["cls_score"], ["cls_prob"])
     return e.text()
+
+
+def cfm_test_prototxt(width_div=1):
+    """Text of the CFM (convolutional feature masking) test graph, models/VGG16/cfm/test.prototxt: no RPN -- `rois`
+    (batch index + box per MCG proposal, over a batch of pyramid levels) and binary `masks` are inputs; ROIPooling 7x7 ->
+    fc6/fc7 (box feature), ROIPooling 14x14 -> MaskPooling -> pool -> fc6_mask/fc7_mask (mask feature) and -> fc6_maskest ->
+    mask_pred -> mask_prob; Concat (fc7_mask, fc7) -> cls / seg_cls / bbox heads (:395-620).  SURVEY section 8f row n3."""
+    d = width_div
+    e = _Emit("VGG16")
+    e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
+    e.raw('input: "rois"\ninput_shape { dim: 1 dim: 5 }')
+    e.raw('input: "masks"\ninput_shape { dim: 1 dim: 1 dim: 14 dim: 14 }')
+    _trunk(e, d)
+    wide, narrow = 4096 // d, max(256 // d, 32)
+    e.layer("roi_pooling_conv5", "ROIPooling", ["conv5_3", "rois"], ["roi_pooling_conv5"],
+            "roi_pooling_param { pooled_w: 7 pooled_h: 7 spatial_scale: 0.0625 }")
+    _fc(e, "fc6", "roi_pooling_conv5", "fc6", wide)
+    _relu(e, "relu6", "fc6")
+    _fc(e, "fc7", "fc6", "fc7", wide)
+    _relu(e, "relu7", "fc7")
+    e.layer("roi_pooling_conv5_mask", "ROIPooling", ["conv5_3", "rois"], ["roi_pooling_conv5_mask"],
+            "roi_pooling_param { pooled_w: 14 pooled_h: 14 spatial_scale: 0.0625 }")
+    e.layer("mask_pooling", "MaskPooling", ["roi_pooling_conv5_mask", "masks"], ["roi_mask_conv5"])
+    _pool(e, "roi_mask_conv5", "roi_mask_conv5", "roi_mask_conv5_pool")
+    _fc(e, "fc6_mask", "roi_mask_conv5_pool", "fc6_mask", wide)
+    _relu(e, "relu6_mask", "fc6_mask")
+    _fc(e, "fc7_mask", "fc6_mask", "fc7_mask", wide)
+    _relu(e, "relu7_mask", "fc7_mask")
+    _fc(e, "fc6_maskest", "roi_pooling_conv5_mask", "fc6_maskest", narrow)
+    _relu(e, "relu6_maskest", "fc6_maskest")
+    _fc(e, "mask_pred", "fc6_maskest", "mask_pred", 441)
+    e.layer("mask_prob", "Sigmoid", ["mask_pred"], ["mask_prob"])
+    e.layer("join_box_mask", "Concat", ["fc7_mask", "fc7"], ["join_box_mask"], "concat_param { axis: 1 }")
+    _fc(e, "cls_score", "join_box_mask", "cls_score", 21)
+    e.layer("cls_prob", "Softmax", ["cls_score"], ["cls_prob"])
+    _fc(e, "seg_cls_score", "join_box_mask", "seg_cls_score", 21)
+    e.layer("seg_cls_prob", "Softmax", ["seg_cls_score"], ["seg_cls_prob"])
+    _fc(e, "bbox_pred", "join_box_mask", "bbox_pred", 84)
+    return e.text()
+
+
+def write_cfm_test_prototxt(path=None, width_div=1):
+    return _write(cfm_test_prototxt(width_div), path, "cfm_test_w%d.prototxt" % width_div)
 
 
 def write_faster_rcnn_end2end_test_prototxt(path=None, width_div=1):

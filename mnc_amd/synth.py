@@ -42,6 +42,9 @@ def layer_shapes(prototxt_path):
         elif typ == "ROIWarping":
             rp = L.get1("roi_warping_param")
             geo[tops[0]] = (geo[bots[0]][0], rp.get1("pooled_h"), rp.get1("pooled_w"))
+        elif typ == "ROIPooling":
+            rp = L.get1("roi_pooling_param")
+            geo[tops[0]] = (geo[bots[0]][0], rp.get1("pooled_h"), rp.get1("pooled_w"))
         elif typ == "MaskResize":
             mp = L.get1("mask_resize_param")
             geo[tops[0]] = (1, mp.get1("output_height"), mp.get1("output_width"))

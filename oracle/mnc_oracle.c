@@ -11,7 +11,7 @@
  *   orc_nms / orc_mv / orc_bbox_overlaps : pinned against the reference's own code -- oracle/_ref/libmnc_ref.so is
  *       lib/nms/nms_kernel.cu + lib/nms/mv_kernel.cu compiled for the CPU (oracle/build_ref.py); see
  *       tests/test_oracle_vs_ref.py, and the committed fixtures in tests/golden/.
- *   orc_roi_warp / orc_mask_resize / orc_mask_pool / orc_maxpool2 : PARITY UNPINNED.  Their arithmetic lives in the
+ *   orc_roi_warp / orc_mask_resize / orc_mask_pool / orc_maxpool2 / orc_roi_pool : PARITY UNPINNED.  Their arithmetic lives in the
  *       un-vendored `caffe-mnc` submodule (.gitmodules:1-3, pinned SHA unknown, directory empty).  They follow
  *       oracle/SPEC.md; every convention that had to be chosen is marked SPEC-CHOICE.
  */
@@ -260,6 +260,42 @@ ORC_EXPORT void orc_mask_pool(const float* feat, const float* mask, int R, int C
     for (int c = 0; c < C; ++c)
       for (int i = 0; i < H * W; ++i)
         out[((long)r * C + c) * H * W + i] = feat[((long)r * C + c) * H * W + i] * mask[(long)r * H * W + i];
+}
+
+/* ROIPooling forward (models/VGG16/cfm/test.prototxt:397-407, 446-456).  The layer source sits in the absent caffe-mnc
+ * submodule; it is the Fast R-CNN layer (published algorithm, SPEC.md section 4): rounded RoI corners, float32 bin sizes,
+ * floor/ceil bin edges clipped to the map, `v > max` from -FLT_MAX, empty bin -> 0.  feat [N][C][H][W], rois [R][5]. */
+ORC_EXPORT void orc_roi_pool(const float* feat, int N, int C, int H, int W, const float* rois, int R, int PH, int PW,
+                             float scale, float* out) {
+#pragma omp parallel for
+  for (int r = 0; r < R; ++r) {
+    const float* roi = rois + (long)r * 5;
+    int b = (int)roi[0];
+    if (b < 0) b = 0;
+    if (b >= N) b = N - 1;
+    const int x1 = (int)roundf(roi[1] * scale), y1 = (int)roundf(roi[2] * scale);
+    const int x2 = (int)roundf(roi[3] * scale), y2 = (int)roundf(roi[4] * scale);
+    const int rw = x2 - x1 + 1 > 1 ? x2 - x1 + 1 : 1, rh = y2 - y1 + 1 > 1 ? y2 - y1 + 1 : 1;
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    for (int c = 0; c < C; ++c) {
+      const float* plane = feat + ((long)b * C + c) * H * W;
+      for (int ph = 0; ph < PH; ++ph)
+        for (int pw = 0; pw < PW; ++pw) {
+          int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+          int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+          hs += y1; he += y1; ws += x1; we += x1;
+          hs = hs < 0 ? 0 : (hs > H ? H : hs);
+          he = he < 0 ? 0 : (he > H ? H : he);
+          ws = ws < 0 ? 0 : (ws > W ? W : ws);
+          we = we < 0 ? 0 : (we > W ? W : we);
+          float m = (he <= hs || we <= ws) ? 0.f : -3.402823466e38f;
+          for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w)
+              if (plane[(long)h * W + w] > m) m = plane[(long)h * W + w];
+          out[(((long)r * C + c) * PH + ph) * PW + pw] = m;
+        }
+    }
+  }
 }
 
 /* Caffe Pooling MAX 2x2 stride 2 pad 0 (BVLC pooling_layer.cpp semantics): output = ceil((n-2)/2)+1, windows

@@ -141,6 +141,17 @@ def roi_warp(feat, rois, PH, PW, scale):
     return out
 
 
+def roi_pool(feat, rois, PH, PW, scale):
+    """Caffe ROIPooling: feat [N,C,H,W], rois [R,5] (batch index first) -> [R,C,PH,PW]."""
+    f, r = _c(feat, np.float32), _c(rois, np.float32)
+    N, C, H, W = f.shape
+    out = np.zeros((r.shape[0], C, PH, PW), np.float32)
+    lib().orc_roi_pool.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_float, _f32p]
+    lib().orc_roi_pool(_p(f, _f32p), N, C, H, W, _p(r, _f32p), r.shape[0], PH, PW, scale, _p(out, _f32p))
+    return out
+
+
 def mask_resize(mask, OH, OW):
     m = _c(mask, np.float32)
     R, _, IH, IW = m.shape

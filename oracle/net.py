@@ -160,3 +160,32 @@ def forward_frcnn(weights, data, im_info, blobs=None, nms_fn=None):
     blobs["rois"] = rois
     head_frcnn(weights, c5, rois, blobs)
     return blobs
+
+
+def forward_cfm(weights, data, rois, masks, blobs=None):
+    """net.forward() of the CFM test graph (models/VGG16/cfm/test.prototxt:395-620): `data` is a batch of
+    pyramid levels [N,3,H,W], `rois` [R,5] carry the level in column 0, `masks` [R,1,14,14] are the binarised MCG masks
+    (lib/caffeWrapper/TesterWrapper.py:386-399).  ROIPooling from oracle/mnc_oracle.c (SPEC.md section 4)."""
+    torch.set_grad_enabled(False)
+    blobs = {} if blobs is None else blobs
+    c5 = trunk(weights, data, blobs).numpy()
+    R = rois.shape[0]
+    p7 = native.roi_pool(c5, rois, 7, 7, 0.0625)
+    fc6 = _fc(_t(p7).flatten(1), weights["fc6"], "relu")
+    fc7 = _fc(fc6, weights["fc7"], "relu")
+    p14 = native.roi_pool(c5, rois, 14, 14, 0.0625)
+    masked = native.mask_pool(p14, masks)
+    mpool = native.maxpool2(masked)
+    fc6m = _fc(_t(mpool).flatten(1), weights["fc6_mask"], "relu")
+    fc7m = _fc(fc6m, weights["fc7_mask"], "relu")
+    f6e = _fc(_t(p14).flatten(1), weights["fc6_maskest"], "relu")
+    mask_prob = _fc(f6e, weights["mask_pred"], "sigmoid")
+    join = torch.cat([fc7m, fc7], dim=1)
+    cls = _fc(join, weights["cls_score"])
+    seg = _fc(join, weights["seg_cls_score"])
+    blobs.update(roi_pooling_conv5=p7, roi_pooling_conv5_mask=p14, roi_mask_conv5=masked, roi_mask_conv5_pool=mpool,
+                 fc6=fc6.numpy(), fc7=fc7.numpy(), fc6_mask=fc6m.numpy(), fc7_mask=fc7m.numpy(), fc6_maskest=f6e.numpy(),
+                 mask_prob=mask_prob.numpy(), join_box_mask=join.numpy(), cls_score=cls.numpy(), seg_cls_score=seg.numpy(),
+                 cls_prob=F.softmax(cls, dim=1).numpy(), seg_cls_prob=F.softmax(seg, dim=1).numpy(),
+                 bbox_pred=_fc(join, weights["bbox_pred"]).numpy())
+    return blobs

@@ -166,6 +166,11 @@ class Fake(object):
             out = native.roi_warp(f, r, PH, PW, scale)
         _f(dst, (R, PH, PW, C))[...] = out.transpose(0, 2, 3, 1)
 
+    def mnc_roi_pool(self, h, feat, N, C, H, W, rois, R, PH, PW, scale, dst):
+        f = np.stack([_unc8(x) for x in _f(feat, (N, C // 8, H, W, 8))])
+        out = native.roi_pool(np.ascontiguousarray(f), np.ascontiguousarray(_f(rois, (R, 5))), PH, PW, scale)
+        _f(dst, (R, PH, PW, C))[...] = out.transpose(0, 2, 3, 1)
+
     def mnc_maxpool2_rhwc(self, h, src, dst, R, PH, PW, C):
         x = _f(src, (R, PH, PW, C)).transpose(0, 3, 1, 2)
         _f(dst, (R, PH // 2, PW // 2, C))[...] = native.maxpool2(x).transpose(0, 2, 3, 1)

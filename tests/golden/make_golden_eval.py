@@ -150,6 +150,51 @@ def main():
         g["tester_counts"] = np.array([[len(all_boxes[c][i]) for i in range(len(case["images"]))] for c in range(1, 21)])
         g["tester_boxes"] = np.concatenate([all_boxes[c][i] for c in range(1, 21) for i in range(len(case["images"]))], 0)
         g["tester_masks"] = np.concatenate([all_masks[c][i] for c in range(1, 21) for i in range(len(case["images"]))], 0)
+        # ---- 2b. CFM task: TesterWrapper.get_cfm_result / cfm_network_forward with a deterministic net --------
+        mcg = GI.cfm_case(case)
+        cwd = os.getcwd()
+        os.chdir(root)                                   # the reference reads 'data/cache/voc_2012_val_mcg_maskdb/' from the cwd
+        try:
+            GI.write_mcg_maskdb(os.path.join(root, "data", "cache", "voc_2012_val_mcg_maskdb"), case, mcg)
+
+            class FakeCfmNet(object):
+                def __init__(self, *a):
+                    self.blobs = {k: MG.Blob() for k in ["data", "rois", "masks"]}
+                    self.name, self.seen = "fakecfm", []
+
+                def forward(self, **kw):
+                    self.seen.append((kw["data"].shape, float(np.asarray(kw["data"], np.float64).sum()), kw["rois"].copy(),
+                                      kw["masks"].reshape(kw["masks"].shape[0], -1).sum(1)))
+                    assert kw["rois"].dtype == np.float32 and kw["masks"].dtype == np.float32
+                    return GI.cfm_fake_forward(kw["data"], kw["rois"], kw["masks"])
+
+            sys.modules["caffe"].Net = FakeCfmNet
+            saved = {k: R.cfg.TEST[k] for k in GI.CFM_CFG}
+            for k, v in GI.CFM_CFG.items():
+                R.cfg.TEST[k] = v
+            tw.cv2.resize = resize
+            tw.cv2.imread = lambda path: np.load(path)
+
+            class CfmImdb(Imdb):
+                _image_index = names
+
+            t = tw.TesterWrapper("x.prototxt", CfmImdb(), "fakecfm.caffemodel", "cfm")
+            t.max_per_set = 12                                   # small enough for the per-class score heap to bite
+            t.max_per_image = 9
+            cb, cm = t.get_cfm_result()
+            g["cfm_data_shapes"] = np.array([s[0] for s in t.net.seen], np.int64)
+            g["cfm_data_sums"] = np.array([s[1] for s in t.net.seen], np.float64)
+            g["cfm_rois"] = np.concatenate([s[2] for s in t.net.seen], 0)
+            g["cfm_roi_counts"] = np.array([len(s[2]) for s in t.net.seen], np.int64)
+            g["cfm_mask_sums"] = np.concatenate([s[3] for s in t.net.seen], 0)
+            nimg = len(case["images"])
+            g["cfm_counts"] = np.array([[len(cb[c][i]) for i in range(nimg)] for c in range(1, 21)])
+            g["cfm_boxes"] = np.concatenate([cb[c][i] for c in range(1, 21) for i in range(nimg)], 0)
+            g["cfm_masks"] = np.concatenate([cm[c][i] for c in range(1, 21) for i in range(nimg)], 0)
+            for k, v in saved.items():
+                R.cfg.TEST[k] = v
+        finally:
+            os.chdir(cwd)
     # ---- 3. detection task: voc_eval + TesterWrapper.get_detection_result ----------------------------------
     dcase = GI.voc_det_case()
     with tempfile.TemporaryDirectory() as root:

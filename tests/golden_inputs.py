@@ -280,3 +280,51 @@ def tester_det_outputs(case, seed=22, R=40):
         outs.append({"rois": rois, "bbox_pred": rng.normal(0, 0.2, (R, 84)).astype(np.float32),
                      "cls_prob": _softmax_rows(rng.normal(0, 2.0, (R, 21)))})
     return outs
+
+
+# ---- CFM test path (test_net.py --task cfm): MCG-style proposals + a deterministic stand-in for the net ----
+CFM_CFG = {"SCALES": [120, 160, 220, 320, 440], "MAX_SIZE": 640, "GROUP_SCALE": 3, "MAX_ROIS_GPU": [7, 5], "USE_TOP_K_MCG": 30}
+
+
+def cfm_case(case, seed=31):
+    """Per image of an sds_case: {'boxes': [n,4] float64, 'masks': [n,21,21] bool} as tools/prepare_mcg_maskdb.py:88-94 writes
+    them for the val set -- sizes from below the 16-pixel filter up to most of the image, so that the proposals spread over
+    all pyramid levels; more rows than USE_TOP_K_MCG keeps."""
+    rng = np.random.default_rng(seed)
+    out = []
+    yy, xx = np.mgrid[0:21, 0:21]
+    for ii, rec in enumerate(case["images"]):
+        H, W = rec["im"].shape[:2]
+        n = 34 + ii
+        w = rng.integers(10, W - 4, n)
+        h = rng.integers(10, H - 4, n)
+        w[:4], h[:4] = [12, 40, 15, 16], [40, 12, 15, 16]        # three rows under the min_size=16 filter, one exactly on it
+        x1 = (rng.uniform(0, 1, n) * (W - w)).astype(np.int64)
+        y1 = (rng.uniform(0, 1, n) * (H - h)).astype(np.int64)
+        boxes = np.stack([x1, y1, x1 + w - 1, y1 + h - 1], 1).astype(np.float64)
+        cx, cy, r = rng.uniform(5, 15, n), rng.uniform(5, 15, n), rng.uniform(4, 12, n)
+        masks = ((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2) <= r[:, None, None] ** 2
+        out.append({"boxes": boxes, "masks": masks})
+    return out
+
+
+def write_mcg_maskdb(directory, case, mcg):
+    import scipy.io
+    os.makedirs(directory, exist_ok=True)
+    for rec, db in zip(case["images"], mcg):
+        scipy.io.savemat(os.path.join(directory, rec["name"] + ".mat"), {"boxes": db["boxes"], "masks": db["masks"]})
+
+
+def cfm_fake_forward(data, rois, masks, K=21, S=21):
+    """Deterministic stand-in for the CFM net: outputs are smooth functions of the INPUTS the tester built (level index and
+    scaled box per roi, the binarised mask, the pyramid blob), so any difference in those inputs changes the results."""
+    rois = np.asarray(rois, np.float64)
+    m = np.asarray(masks, np.float64).reshape(rois.shape[0], -1)
+    dsum = float(np.asarray(data, np.float64).mean())
+    key = rois[:, 1] * 0.013 + rois[:, 2] * 0.017 + rois[:, 3] * 0.007 + rois[:, 4] * 0.011 + rois[:, 0] * 0.5 + m.sum(1) * 0.03 + dsum
+    logits = 3.0 * np.sin(key[:, None] * (1.0 + 0.37 * np.arange(K)[None, :]))
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    seg = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    yy, xx = np.mgrid[0:S, 0:S]
+    mp = 0.5 + 0.5 * np.sin(key[:, None, None] + 0.3 * xx[None] + 0.2 * yy[None] + m.mean(1)[:, None, None])
+    return {"mask_prob": mp.reshape(-1, 1, S, S).astype(np.float32), "seg_cls_prob": seg}

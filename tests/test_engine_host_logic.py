@@ -196,3 +196,50 @@ def test_speculative_roi_count_equals_synchronous_path(fake_gpu, monkeypatch):
     assert 0 < outs["1"]["rois"].shape[0] < 300
     for n in outs["1"]:
         assert outs["1"][n].shape == outs["0"][n].shape and np.array_equal(outs["1"][n], outs["0"][n]), n
+
+
+def _cfm_inputs(seed, N, H, W, R):
+    """A batch of N pyramid levels (smaller levels zero-padded, utils/blob.py:im_list_to_blob), R rois over them (some
+    degenerate / partly outside, to reach the empty-bin and clipping branches) and binary 14x14 masks."""
+    rng = np.random.default_rng(seed)
+    data = np.zeros((N, 3, H, W), np.float32)
+    for n in range(N):
+        h, w = H - 9 * n, W - 14 * n
+        data[n, :, :h, :w] = rng.uniform(-120, 130, (3, h, w))
+    x1, y1 = rng.uniform(0, W - 20, R), rng.uniform(0, H - 20, R)
+    bw, bh = rng.uniform(4, W * 0.8, R), rng.uniform(4, H * 0.8, R)
+    rois = np.stack([rng.integers(0, N, R).astype(np.float64), x1, y1, np.minimum(x1 + bw, W + 30), np.minimum(y1 + bh, H + 30)],
+                    1).astype(np.float32)
+    rois[0, 1:] = [5, 5, 5, 5]                       # one-pixel roi: 1x1 map cell repeated over all bins
+    rois[1, 1:] = [W + 40, H + 40, W + 90, H + 90]     # entirely outside: every bin empty -> zeros
+    masks = (rng.uniform(0, 1, (R, 1, 14, 14)) >= 0.4).astype(np.float32)
+    return data, rois, masks
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_cfm_graph_every_blob(fake_gpu, fuse):
+    """CFM test graph: image batch > 1 through the trunk, ROIPooling with batch indices, binary MaskPooling."""
+    from mnc_amd.engine import Net
+    path = models.write_cfm_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=4)
+    net = Net(path, w, 1, device_id=0, fuse=fuse)
+    for seed, (N, H, W, R) in enumerate([(3, 96, 144, 37), (1, 70, 81, 5), (2, 64, 64, 0)]):
+        data, rois, masks = _cfm_inputs(seed, N, H, W, max(R, 2))
+        rois, masks = rois[:R], masks[:R]
+        net.blobs["data"].reshape(*data.shape)
+        net.blobs["rois"].reshape(*rois.shape)
+        net.blobs["masks"].reshape(*masks.shape)
+        out = net.forward(data=data, rois=rois, masks=masks)
+        assert set(out) == {"mask_prob", "cls_prob", "seg_cls_prob", "bbox_pred"}
+        ref = onet.forward_cfm(w, data, rois, masks)
+        names = ["conv1_1", "pool2", "conv5_3", "roi_pooling_conv5", "roi_pooling_conv5_mask", "roi_mask_conv5_pool", "fc7",
+                 "fc7_mask", "fc6_maskest", "join_box_mask", "mask_prob", "cls_prob", "seg_cls_prob", "bbox_pred"]
+        for n in names + ([] if fuse else ["roi_mask_conv5", "mask_pred"]):
+            got = net.blobs[n].data if n not in out else out[n]
+            want = ref[n] if n != "mask_pred" else None
+            if want is None:
+                continue
+            assert got.shape == want.shape, n
+            if want.size:
+                assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6), n
+    net.close()

@@ -118,7 +118,64 @@ def test_tester_wrapper_loop_matches_the_reference(devkit, ref, monkeypatch, tmp
         t.get_result()
     assert t.net.calls == calls
     with pytest.raises(NotImplementedError):
-        TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "cfm").get_result()
+        TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "vis_seg").get_result()
+    gc.collect()
+
+
+def test_cfm_task_matches_the_reference(devkit, ref, monkeypatch, tmp_path):
+    """`--task cfm` against the reference's get_cfm_result / cfm_network_forward run on the same synthetic MCG
+    maskdb with the same deterministic stand-in net: every forward's pyramid blob, rois (level index after the reference's
+    min-present-level shift, scaled boxes, chunking by MAX_ROIS_GPU) and binarised masks, then the per-class heap / top-k /
+    NMS-with-masks bookkeeping."""
+    import gc
+    fake_backend.install(monkeypatch)
+    import caffe
+    from caffeWrapper.TesterWrapper import TesterWrapper
+    from datasets.pascal_voc_seg import PascalVOCSeg
+    from mnc_config import cfg
+    root, case = devkit
+    GI.write_mcg_maskdb(str(tmp_path / "maskdb"), case, GI.cfm_case(case))
+
+    class Blob(object):
+        def reshape(self, *dims):
+            self.shape = dims
+
+    class FakeCfmNet(object):
+        def __init__(self, *a):
+            self.blobs = {k: Blob() for k in ["data", "rois", "masks"]}
+            self.name, self.seen = "fakecfm", []
+
+        def forward(self, **kw):
+            assert kw["rois"].dtype == np.float32 and kw["masks"].dtype == np.float32 and kw["data"].dtype == np.float32
+            assert self.blobs["data"].shape == kw["data"].shape and self.blobs["rois"].shape == kw["rois"].shape
+            self.seen.append((kw["data"].shape, float(np.asarray(kw["data"], np.float64).sum()), kw["rois"].copy(),
+                              kw["masks"].reshape(kw["masks"].shape[0], -1).sum(1)))
+            return GI.cfm_fake_forward(kw["data"], kw["rois"], kw["masks"])
+
+    monkeypatch.setattr(caffe, "Net", FakeCfmNet)
+    monkeypatch.setattr(cfg, "ROOT_DIR", str(tmp_path))
+    for k, v in GI.CFM_CFG.items():
+        monkeypatch.setitem(cfg.TEST, k, v)
+    monkeypatch.setitem(cfg.TEST, "MCG_MASKDB_DIR", str(tmp_path / "maskdb"))
+    imdb = PascalVOCSeg("val", "2012", root, image_ext=".npy")
+    t = TesterWrapper("x.prototxt", imdb, "fakecfm.caffemodel", "cfm")
+    t.max_per_set, t.max_per_image = 12, 9
+    cb, cm = t.get_cfm_result()
+    seen = t.net.seen
+    assert np.array_equal(np.array([s[0] for s in seen]), ref["cfm_data_shapes"])
+    assert np.array_equal(np.array([len(s[2]) for s in seen]), ref["cfm_roi_counts"])
+    assert np.array_equal(np.concatenate([s[2] for s in seen], 0), ref["cfm_rois"])
+    assert np.array_equal(np.concatenate([s[3] for s in seen], 0), ref["cfm_mask_sums"])
+    assert np.array_equal(np.array([s[1] for s in seen]), ref["cfm_data_sums"])
+    n = len(case["images"])
+    assert np.array_equal(np.array([[len(cb[c][i]) for i in range(n)] for c in range(1, 21)]), ref["cfm_counts"])
+    boxes = np.concatenate([cb[c][i] for c in range(1, 21) for i in range(n)], 0)
+    masks = np.concatenate([cm[c][i] for c in range(1, 21) for i in range(n)], 0)
+    assert boxes.dtype == ref["cfm_boxes"].dtype and np.array_equal(boxes, ref["cfm_boxes"])
+    assert masks.dtype == ref["cfm_masks"].dtype and np.array_equal(masks, ref["cfm_masks"])
+    with np.errstate(all="ignore"):
+        res = t.get_result()                                   # pickles + SDS evaluation on the CFM lists
+    assert set(res) == {0.5, 0.7} and os.path.isfile(os.path.join(t.output_dir, "res_masks.pkl"))
     gc.collect()
 
 

@@ -345,3 +345,85 @@ def test_faster_rcnn_end2end_graph_and_det_task(tmp_path, monkeypatch):
         assert len(aps) == 20 and os.path.isfile(os.path.join(t.output_dir, "detections.pkl"))
     finally:
         t.net.close()
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_cfm_graph(math, monkeypatch):
+    """models/VGG16/cfm/test.prototxt -- a batch of pyramid levels through the trunk (one launch sequence per
+    image), ROIPooling 7x7 / 14x14 with batch indices, binary MaskPooling, the FC heads on hundreds of MCG-style rois."""
+    import caffe
+    from test_engine_host_logic import _cfm_inputs
+    monkeypatch.setenv("MNC_MATH", math)
+    path = models.write_cfm_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=4)
+    net = caffe.Net(path, w, caffe.TEST)
+    try:
+        for seed, (N, H, W, R) in enumerate([(3, 96, 144, 300), (1, 70, 81, 5), (2, 130, 203, 64)]):
+            data, rois, masks = _cfm_inputs(seed, N, H, W, R)
+            net.blobs["data"].reshape(*data.shape)
+            net.blobs["rois"].reshape(*rois.shape)
+            net.blobs["masks"].reshape(*masks.shape)
+            out = net.forward(data=data, rois=rois, masks=masks)
+            assert set(out) == {"mask_prob", "cls_prob", "seg_cls_prob", "bbox_pred"}
+            ref = onet.forward_cfm(w, data, rois, masks)
+            _compare(net, ref, ["conv1_1", "pool1", "conv3_3", "conv5_3"])
+            # teacher-forced head: max-pooling picks among near-equal conv5_3 values bit-exactly only on the same features
+            c5 = net.blobs["conv5_3"]._host_read()
+            assert np.array_equal(net.blobs["roi_pooling_conv5"]._host_read(), onative.roi_pool(c5, rois, 7, 7, 0.0625))
+            assert np.array_equal(net.blobs["roi_pooling_conv5_mask"]._host_read(), onative.roi_pool(c5, rois, 14, 14, 0.0625))
+            _compare(net, ref, ["roi_pooling_conv5", "roi_pooling_conv5_mask", "roi_mask_conv5_pool", "fc6", "fc7", "fc7_mask",
+                                "fc6_maskest", "join_box_mask", "mask_prob", "cls_prob", "seg_cls_prob", "bbox_pred"])
+    finally:
+        net.close()
+
+
+def test_tester_wrapper_cfm_task_on_device(tmp_path, monkeypatch):
+    """`--task cfm` end to end on the GPU (reduced-width CFM net, synthetic SDS devkit + MCG maskdb): the chunks after the first
+    re-run only the RoI heads (forward(start=...)) and must give exactly what full forwards give; every chunk's outputs equal
+    the oracle graph on the inputs the tester built; then pickles + SDS evaluation."""
+    import golden_inputs
+    from caffeWrapper.TesterWrapper import TesterWrapper
+    from datasets.pascal_voc_seg import PascalVOCSeg
+    from mnc_config import cfg
+    from mnc_amd import engine
+    case = golden_inputs.sds_case()
+    root = str(tmp_path / "VOCdevkitSDS")
+    golden_inputs.write_sds_devkit(root, case)
+    golden_inputs.write_mcg_maskdb(str(tmp_path / "maskdb"), case, golden_inputs.cfm_case(case))
+    monkeypatch.setattr(cfg, "ROOT_DIR", str(tmp_path))
+    for k, v in golden_inputs.CFM_CFG.items():
+        monkeypatch.setitem(cfg.TEST, k, v)
+    monkeypatch.setitem(cfg.TEST, "MCG_MASKDB_DIR", str(tmp_path / "maskdb"))
+    path = models.write_cfm_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=4)
+    imdb = PascalVOCSeg("val", "2012", root, image_ext=".npy")
+    t = TesterWrapper(path, imdb, w, "cfm")
+    try:
+        calls = []
+        real_forward = t.net.forward
+
+        def spy(**kw):
+            out = real_forward(**kw)
+            calls.append((kw.get("start"), {k: np.array(v) for k, v in kw.items() if k in ("data", "rois", "masks")},
+                          {k: np.array(out[k]) for k in ("mask_prob", "seg_cls_prob")}))
+            return out
+        monkeypatch.setattr(t.net, "forward", spy)
+        m1, b1, s1 = t.cfm_network_forward(3)
+        assert any(c[0] == "roi_pooling_conv5" for c in calls) and calls[0][0] is None
+        data = None
+        for start, inp, out in calls:                           # every chunk vs the oracle graph on the same inputs
+            data = inp.get("data", data)
+            ref = onet.forward_cfm(w, data, inp["rois"], inp["masks"])
+            assert err(out["mask_prob"], ref["mask_prob"])[1] < 1e-3 and err(out["seg_cls_prob"], ref["seg_cls_prob"])[1] < 1e-3
+        monkeypatch.setattr(engine.Net, "supports_partial_forward", False)
+        n_partial = len(calls)
+        m2, b2, s2 = t.cfm_network_forward(3)
+        assert len(calls) == 2 * n_partial and all(c[0] is None for c in calls[n_partial:])
+        assert np.array_equal(m1, m2) and np.array_equal(b1, b2) and np.array_equal(s1, s2)
+        assert m1.shape[1:] == (1, 21, 21) and b1.shape == (m1.shape[0], 4) and s1.shape == (m1.shape[0], 21)
+        monkeypatch.setattr(engine.Net, "supports_partial_forward", True)
+        with np.errstate(all="ignore"):
+            res = t.get_result()
+        assert set(res) == {0.5, 0.7} and os.path.isfile(os.path.join(t.output_dir, "res_boxes.pkl"))
+    finally:
+        t.net.close()

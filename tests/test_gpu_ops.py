@@ -176,6 +176,33 @@ def test_roi_warp(dev, pool2, P):
     assert np.array_equal(got, want)      # roi.hip is built with -ffp-contract=off and mirrors the oracle op by op
 
 
+@pytest.mark.parametrize("P,N", [(7, 1), (14, 3)])
+def test_roi_pool(dev, P, N):
+    """ROIPooling (CFM graph) over a batch of c8 images: bit-exact with the oracle (pure max / integer bin arithmetic),
+    including one-pixel, partly-outside, fully-outside (empty bins -> 0) rois and a NaN feature (skipped by `v > max`)."""
+    rng = np.random.default_rng(14)
+    C, H, W, R = 64, 38, 63, 60
+    feat = rng.normal(size=(N, C, H, W)).astype(np.float32)
+    feat[0, 3, 5, 7] = np.nan
+    rois = np.hstack((rng.integers(0, N, (R, 1)).astype(np.float32), _rois(rng, R, 1000, 600)[:, 1:]))
+    rois[0, 1:] = [80, 80, 80, 80]
+    rois[1, 1:] = [1100, 700, 1300, 900]
+    rois[2, 1:] = [900, 500, 1200, 800]
+    rois[3] = [0, 100, 70, 130, 100]
+    d_out = dev.empty((R * P * P * C,), fill=np.nan)
+    c8 = np.stack([to_c8(f) for f in feat])
+    dev.call("mnc_roi_pool", dev.put(c8), N, C, H, W, dev.put(rois), R, P, P, 0.0625, d_out)
+    got = dev.get(d_out, (R, P, P, C)).transpose(0, 3, 1, 2)
+    want = native.roi_pool(feat, rois, P, P, 0.0625)
+    assert np.array_equal(got, want) and not np.isnan(got).any()
+    assert not got[1].any() and got[2].any()
+    # full-map roi at 1x1: the global max of each channel (property at the real conv5_3 size)
+    whole = np.array([[N - 1, 0, 0, (W - 1) * 16, (H - 1) * 16]], np.float32)
+    d_one = dev.empty((C,), fill=np.nan)
+    dev.call("mnc_roi_pool", dev.put(c8), N, C, H, W, dev.put(whole), 1, 1, 1, 0.0625, d_one)
+    assert np.array_equal(dev.get(d_one, (C,)), np.nanmax(feat[N - 1].reshape(C, -1), axis=1))
+
+
 def test_roi_warp_interior_is_plain_bilinear(dev):
     """SPEC.md 1 property: a RoI whose sample grid lands exactly on feature-map pixels reproduces them."""
     C, H, W = 8, 20, 20

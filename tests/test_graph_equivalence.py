@@ -16,8 +16,8 @@ def _norm(msg):
         if m is None:
             return None
         return tuple(sorted((k, tuple(hp(x) if isinstance(x, dict) else x for x in v)) for k, v in m.items()))
-    keys = ("convolution_param", "pooling_param", "inner_product_param", "roi_warping_param", "mask_resize_param",
-            "reshape_param", "python_param", "concat_param")
+    keys = ("convolution_param", "pooling_param", "inner_product_param", "roi_warping_param", "roi_pooling_param",
+            "mask_resize_param", "reshape_param", "python_param", "concat_param")
     out = {}
     for k in keys:
         m = msg.get1(k)
@@ -40,6 +40,17 @@ def test_emitted_graph_equals_reference():
     assert ref.all("input") == mine.all("input")
     a, b = [_norm(l) for l in ref.all("layer")], [_norm(l) for l in mine.all("layer")]
     assert len(a) == len(b) == 88
+    for x, y in zip(a, b):
+        assert x == y
+
+
+@pytest.mark.skipif(not os.path.isfile(REF), reason="reference checkout not mounted")
+def test_emitted_cfm_graph_equals_reference():
+    ref = prototxt.parse_file(REF.replace("mnc_5stage", "cfm"))
+    mine = prototxt.parse(models.cfm_test_prototxt())
+    assert ref.all("input") == mine.all("input") == ["data", "rois", "masks"]
+    a, b = [_norm(l) for l in ref.all("layer")], [_norm(l) for l in mine.all("layer")]
+    assert len(a) == len(b)
     for x, y in zip(a, b):
         assert x == y
 

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Evaluate an MNC network on an image database (reference: tools/test_net.py:24-84): `--task seg`, the 5-stage
-MNC graph this package accelerates, and `--task det`, Faster R-CNN end2end on the same kernels.
+MNC graph this package accelerates; `--task det`, Faster R-CNN end2end, and `--task cfm`, convolutional feature masking over
+MCG proposals (with `--cfg experiments/cfgs/VGG16/cfm.yml`: 5-level pyramid, levels grouped 3 + 2 per forward), on the same
+kernels.
 
     python tools/test_net.py --gpu 0 --def models/VGG16/mnc_5stage/test.prototxt \\
         --net data/mnc_model/mnc_model.caffemodel.h5 --imdb voc_2012_seg_val --task seg
