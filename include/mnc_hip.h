@@ -182,6 +182,15 @@ MNC_API int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score_nchw, float* d_pr
  * 2PH x 2PW and max-reduced, so the 28x28 "premax" tensor never reaches HBM. */
 MNC_API int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R,
                          int PH, int PW, float spatial_scale, int pool2, float* d_out_rhwc);
+/* prep_im_for_blob (lib/utils/blob.py:36-50) and one level of prep_im_for_blob_cfm (:53-85) on the device: a uint8 BGR image
+ * [H][W][3] -> float32 planes [3][PH][PW] holding (pixel - mean) resized with cv2.resize's INTER_LINEAR rule to OH x OW and
+ * zero-padded to the blob's PH x PW (im_list_to_blob, :17-33).  `means` = 3 host doubles (cfg.PIXEL_MEANS).  The resize
+ * taps come from the caller (the host function that the numpy path uses): d_x0[OW] / d_y0[OH] first source index,
+ * d_ax[OW] / d_ay[OH] fraction of the next one; the second index is min(first + 1, size - 1).  Bit-identical to the host
+ * path (tests/test_gpu_ops.py). */
+MNC_API int mnc_prep_image(mnc_ctx* ctx, const unsigned char* d_bgr_hwc, int H, int W, const double* means_host,
+                           const int* d_x0, const float* d_ax, int OW, const int* d_y0, const float* d_ay, int OH,
+                           float* d_out_chw, int PH, int PW);
 /* ROIPooling (models/VGG16/cfm/test.prototxt:397-407 7x7, :446-456 14x14; the Fast R-CNN layer of the absent caffe-mnc
  * submodule, restated in oracle/SPEC.md section 4): max over the integer bins of round(roi * spatial_scale).  The feature
  * is a batch of N c8 images [N][C/8][H][W][8] (CFM feeds an image pyramid, lib/caffeWrapper/TesterWrapper.py:371-399);

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmnc_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
-NO_CONTRACT = {"nms.hip", "mv.hip", "bbox.hip", "roi.hip", "proposal.hip"}
+NO_CONTRACT = {"nms.hip", "mv.hip", "bbox.hip", "roi.hip", "proposal.hip", "prep.hip"}
 
 
 def _hipcc():

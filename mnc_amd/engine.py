@@ -24,6 +24,7 @@ from collections.abc import Mapping
 import numpy as np
 
 from . import _lib, install_paths, prototxt
+from .devarray import DeviceArray
 
 # bf16x3 mode: InnerProducts below this many flops stay on the fp32 kernel (its small-tile variant is as fast there)
 _X3_MIN_FLOPS = 2.0e9
@@ -147,6 +148,17 @@ class Blob(object):
         self._host = arr
         self._host_valid = True
         self._dev_valid = False
+
+    def set_device(self, darr):
+        """Adopt the contents of a DeviceArray of this net (plain layout): one device-to-device copy, no host round trip."""
+        if darr._net is not self._net:
+            raise ValueError("blob %r: the DeviceArray belongs to another net" % self.name)
+        self.shape = tuple(darr.shape)
+        self._host, self._host_valid = None, False
+        if self.count:
+            _lib.call("mnc_d2d", self._net._ctx.h, self._buf.ensure(self.count * 4), darr.ptr, self.count * 4)
+        self.layout = "plain"
+        self._dev_valid = True
 
     def _ld(self):
         if self._view is not None:
@@ -926,7 +938,10 @@ class Net(object):
         for name, arr in kwargs.items():
             if name not in self.inputs:
                 raise KeyError("%r is not an input blob of this net (%r)" % (name, self.inputs))
-            self.blobs[name].set_host(arr)
+            if isinstance(arr, DeviceArray):
+                self.blobs[name].set_device(arr)
+            else:
+                self.blobs[name].set_host(arr)
         names = [L.name for L in self._layers]
         for nm in (start, end):
             if nm is not None and nm not in names:
@@ -954,11 +969,18 @@ class Net(object):
         wanted = list(self.outputs) + [b for b in (blobs or []) if b not in self.outputs]
         return _Outputs(self, [name for name in wanted if self.blobs[name]._dev_valid or self.blobs[name]._host_valid])
 
+    def prep_image(self, im, pixel_means, factors):
+        """uint8 BGR image -> DeviceArray [len(factors),3,H',W'] = the `data` blob prep_im_for_blob / prep_im_for_blob_cfm
+        (lib/utils/blob.py:36-85) build on the host, computed by mnc_prep_image (mnc_amd/prep.py).  Valid until the next call."""
+        if getattr(self, "_prep", None) is None:
+            from .prep import ImagePrep
+            self._prep = ImagePrep(self)
+        return self._prep.pyramid(im, pixel_means, factors)
+
     def detect_tail(self, scale, im_shape):
         """The tail of im_detect (tools/demo.py:84-100) without leaving the GPU: (boxes [2R,4] in original-image pixels,
         masks [2R,1,21,21], seg scores [2R,K]) of stages 3 and 5 as DeviceArrays (valid until the next call).
         `gpu_mask_voting` consumes them in place; np.asarray() of any of them is the reference's numpy result."""
-        from .devarray import DeviceArray
         B = self.blobs
         r1, r2 = B["rois"], B["rois_ext"]
         R1, R2 = r1.shape[0], r2.shape[0]
@@ -1024,6 +1046,8 @@ class Net(object):
                 b._buf.release()
             for t in getattr(self, "_tail_bufs", None) or ():
                 t.release()
+            if getattr(self, "_prep", None) is not None:
+                self._prep.release()
             self._tmp.release()
             for p in self._dev_params.values():
                 self._ctx.free(p)

@@ -14,7 +14,8 @@ from mnc_config import cfg, get_output_dir
 from nms.nms_wrapper import apply_nms, apply_nms_mask_single
 from transform.bbox_transform import bbox_transform_inv, clip_boxes, filter_small_boxes
 from transform.mask_transform import gpu_mask_voting
-from utils.blob import im_list_to_blob, prep_im_for_blob, prep_im_for_blob_cfm, pred_rois_for_blob, resize_to
+from utils.blob import (can_prep_on_device, cfm_scale_factors, im_list_to_blob, prep_im_for_blob, prep_im_for_blob_cfm,
+                        prep_im_for_blob_cfm_device, prep_im_for_blob_device, pred_rois_for_blob, resize_to)
 from utils.image_io import imread
 from utils.timer import Timer
 
@@ -175,13 +176,17 @@ class TesterWrapper(object):
         return masks, boxes, scores
 
     def _prepare_mnc_args(self, im):
-        im, im_scale_factors = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
-        data = im_list_to_blob([im])
+        if can_prep_on_device(self.net, im):         # mean subtraction + resize on the GPU; `data` stays there
+            data, im_scale_factors = prep_im_for_blob_device(self.net, im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0],
+                                                             cfg.TRAIN.MAX_SIZE)
+        else:
+            im, im_scale_factors = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
+            data = im_list_to_blob([im]).astype(np.float32, copy=False)
         im_scales = [np.array(im_scale_factors)]
         im_info = np.array([[data.shape[2], data.shape[3], im_scales[0]]], dtype=np.float32)
         self.net.blobs['data'].reshape(*data.shape)
         self.net.blobs['im_info'].reshape(*im_info.shape)
-        return {'data': data.astype(np.float32, copy=False), 'im_info': im_info.astype(np.float32, copy=False)}, im_scales
+        return {'data': data, 'im_info': im_info.astype(np.float32, copy=False)}, im_scales
 
     # ------------------------------------------------------------------------------------------------ CFM (row n3)
     def get_cfm_result(self):
@@ -238,15 +243,14 @@ class TesterWrapper(object):
         masks = roidb['masks'][filter_keep, :, :]
         assert boxes.shape[0] == masks.shape[0]
         size = cfg.TEST.CFM_INPUT_MASK_SIZE
-        mask_resize = np.zeros((masks.shape[0], size, size))
-        for i in range(masks.shape[0]):
-            mask_resize[i, :, :] = resize_to(masks[i, :, :].astype(np.float32), size, size)    # cv2.resize(..., (size, size))
-        masks = mask_resize
+        # cv2.resize(mask, (size, size)) of every proposal mask (:346-350), all masks in one pass (as channels of one image)
+        masks = resize_to(masks.transpose(1, 2, 0).astype(np.float32), size, size).transpose(2, 0, 1).astype(np.float64) \
+            if masks.shape[0] else np.zeros((0, size, size))
         if cfg.TEST.USE_TOP_K_MCG:
             num_keep = min(boxes.shape[0], cfg.TEST.USE_TOP_K_MCG)
             boxes, masks = boxes[:num_keep, :], masks[:num_keep, :, :]
         # multi-scale test: adjacent levels are grouped into one forward
-        _, im_scale_factors = prep_im_for_blob_cfm(im, cfg.TEST.SCALES)
+        im_scale_factors = cfm_scale_factors(im.shape, cfg.TEST.SCALES)     # (the reference builds the whole pyramid for these)
         orig_boxes = boxes.copy()
         boxes = pred_rois_for_blob(boxes, im_scale_factors)
         group = cfg.TEST.GROUP_SCALE
@@ -267,8 +271,11 @@ class TesterWrapper(object):
             masks_this_scale = masks[inds_this_scale, :, :]
             # the batch index starts from the lowest level PRESENT (not from lo_scale), as in the reference (:381)
             boxes_this_scale[:, 0] -= min(boxes_this_scale[:, 0])
-            data, _ = prep_im_for_blob_cfm(im, cfg.TEST.SCALES[lo_scale:hi_scale])
-            data = data.astype(np.float32, copy=False)
+            if can_prep_on_device(self.net, im):
+                data, _ = prep_im_for_blob_cfm_device(self.net, im, cfg.TEST.SCALES[lo_scale:hi_scale])
+            else:
+                data, _ = prep_im_for_blob_cfm(im, cfg.TEST.SCALES[lo_scale:hi_scale])
+                data = data.astype(np.float32, copy=False)
             for test_iter, start in enumerate(range(0, boxes_this_scale.shape[0], max_rois)):
                 end = min(start + max_rois, boxes_this_scale.shape[0])
                 input_box = boxes_this_scale[start:end, :].astype(np.float32, copy=False)

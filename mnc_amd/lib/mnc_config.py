@@ -53,7 +53,7 @@ cfg.TEST = AttrDict(
     CFM_INPUT_MASK_SIZE=14, MAX_ROIS_GPU=[2000], GROUP_SCALE=1, USE_TOP_K_MCG=0,
     USE_MASK_MERGE=True, USE_GPU_MASK_MERGE=True,
     # not in the reference: im_detect / _segmentation_forward leave boxes, masks and scores on the GPU for gpu_mask_voting
-    DEVICE_RESULTS=True)
+    DEVICE_RESULTS=True, DEVICE_PREP=True)
 
 
 def get_output_dir(imdb, net):

@@ -1,17 +1,11 @@
-"""Image -> network input (reference: lib/utils/blob.py:17-106).  cv2 is not required: the INTER_LINEAR resize of a
+"""Image -> network input (reference: lib/utils/blob.py:17-106).  With a net of this package and a uint8 image the resize
+runs on the GPU (`*_device` variants below, mnc_amd/prep.py); the numpy functions are the reference-shaped API and the
+definition of the result.  cv2 is not required: the INTER_LINEAR resize of a
 float32 image is implemented here (OpenCV convention: source = (dst + 0.5)/scale - 0.5, border-clamped)."""
 import numpy as np
 
 
-def _linear_taps(n_dst, n_src, scale):
-    src = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (1.0 / scale) - 0.5).astype(np.float32)   # OpenCV: scale = 1/inv_scale
-    lo = np.floor(src).astype(np.int64)
-    frac = (src - lo).astype(np.float32)
-    under, over = lo < 0, lo >= n_src - 1
-    frac[under | over] = 0.0
-    lo[under] = 0
-    lo[over] = n_src - 1
-    return lo, np.minimum(lo + 1, n_src - 1), frac
+from mnc_amd.prep import linear_taps as _linear_taps      # one tap function for the numpy path and the device path
 
 
 def resize_linear(im, fx, fy):
@@ -64,21 +58,27 @@ def prep_im_for_blob(im, pixel_means, target_size, max_size):
     return resize_linear(im, scale, scale), scale
 
 
+def cfm_scale_factors(im_shape, input_scales):
+    """Scale factor of every pyramid level (lib/utils/blob.py:70-79): target short side, long side capped at TEST.MAX_SIZE."""
+    from mnc_config import cfg
+    short, long_ = np.min(im_shape[0:2]), np.max(im_shape[0:2])
+    factors = []
+    for target_size in input_scales:
+        scale = float(target_size) / float(short)
+        if np.round(scale * long_) > cfg.TEST.MAX_SIZE:
+            scale = float(cfg.TEST.MAX_SIZE) / float(long_)
+        factors.append(scale)
+    return np.array(factors)
+
+
 def prep_im_for_blob_cfm(im, input_scales):
     """Image pyramid of the CFM test path (lib/utils/blob.py:53-85): one level per target short side in `input_scales`
     (long side capped at cfg.TEST.MAX_SIZE), zero-padded into one [L,3,H,W] blob -> (blob, scale factor per level)."""
     from mnc_config import cfg
     im_orig = im.astype(np.float32, copy=True)
     im_orig -= cfg.PIXEL_MEANS
-    short, long_ = np.min(im_orig.shape[0:2]), np.max(im_orig.shape[0:2])
-    ims, factors = [], []
-    for target_size in input_scales:
-        scale = float(target_size) / float(short)
-        if np.round(scale * long_) > cfg.TEST.MAX_SIZE:
-            scale = float(cfg.TEST.MAX_SIZE) / float(long_)
-        ims.append(resize_linear(im_orig, scale, scale))
-        factors.append(scale)
-    return im_list_to_blob(ims), np.array(factors)
+    factors = cfm_scale_factors(im_orig.shape, input_scales)
+    return im_list_to_blob([resize_linear(im_orig, f, f) for f in factors]), factors
 
 
 def pred_rois_for_blob(im_rois, im_scales):
@@ -93,3 +93,26 @@ def pred_rois_for_blob(im_rois, im_scales):
     else:
         levels = np.zeros((im_rois.shape[0], 1), dtype=np.int64)
     return np.hstack((levels.astype(np.float64), im_rois * im_scales[levels]))
+
+
+def prep_im_for_blob_device(net, im, pixel_means, target_size, max_size):
+    """prep_im_for_blob + im_list_to_blob on the GPU of `net`: -> (DeviceArray [1,3,H',W'], scale).  Same values as
+    im_list_to_blob([prep_im_for_blob(im, ...)[0]]) (bit-identical; tests/test_gpu_ops.py)."""
+    short, long_ = min(im.shape[0:2]), max(im.shape[0:2])
+    scale = float(target_size) / float(short)
+    if np.round(scale * long_) > max_size:
+        scale = float(max_size) / float(long_)
+    return net.prep_image(im, pixel_means, [scale]), scale
+
+
+def prep_im_for_blob_cfm_device(net, im, input_scales):
+    """prep_im_for_blob_cfm on the GPU of `net`: -> (DeviceArray [L,3,H',W'], scale factors)."""
+    from mnc_config import cfg
+    factors = cfm_scale_factors(im.shape, input_scales)
+    return net.prep_image(im, cfg.PIXEL_MEANS, list(factors)), factors
+
+
+def can_prep_on_device(net, im):
+    from mnc_config import cfg
+    return (cfg.TEST.get("DEVICE_PREP", True) and hasattr(net, "prep_image") and isinstance(im, np.ndarray)
+            and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3)

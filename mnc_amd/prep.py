@@ -1,0 +1,70 @@
+"""Device-side image preparation: prep_im_for_blob / prep_im_for_blob_cfm (lib/utils/blob.py:36-85) without the host resize.
+
+On a real VOC image (375x500 -> 600x800) the numpy resize costs several times the whole GPU forward; the CFM pyramid
+(five levels up to 1024 px) costs ~100 ms.  Here the uint8 image is uploaded once (0.5 MB) and every level is produced by
+mnc_prep_image straight into the layout of the net's `data` blob.  The result is a DeviceArray: `net.forward(data=...)`
+adopts it without a host round trip, np.asarray() of it is exactly the numpy path's blob (bit-identical, see csrc/prep.hip)."""
+import numpy as np
+
+from . import _lib
+from .devarray import DeviceArray
+
+
+def linear_taps(n_dst, n_src, scale):
+    """cv2.resize INTER_LINEAR taps for one axis: (first source index, second source index, fraction of the second).
+    OpenCV: source coordinate = (dst + 0.5) * (1/scale) - 0.5 evaluated in double, stored as float; floor; the border clamps
+    with a zero fraction.  Shared by the numpy path (lib/utils/blob.py) and the device path."""
+    src = ((np.arange(n_dst, dtype=np.float64) + 0.5) * (1.0 / scale) - 0.5).astype(np.float32)
+    lo = np.floor(src).astype(np.int64)
+    frac = (src - lo).astype(np.float32)
+    under, over = lo < 0, lo >= n_src - 1
+    frac[under | over] = 0.0
+    lo[under] = 0
+    lo[over] = n_src - 1
+    return lo, np.minimum(lo + 1, n_src - 1), frac
+
+
+class ImagePrep(object):
+    """Buffers of one Net for the device-side pyramid (image bytes, tap tables, output blob); grown on demand."""
+
+    def __init__(self, net):
+        from .engine import _DevBuf
+        self._net = net
+        self._im, self._taps, self._out = _DevBuf(net._ctx), _DevBuf(net._ctx), _DevBuf(net._ctx)
+
+    def release(self):
+        for b in (self._im, self._taps, self._out):
+            b.release()
+
+    def pyramid(self, im, pixel_means, factors):
+        """uint8 BGR [H,W,3] -> DeviceArray [L,3,PH,PW]: level l = (im - means) resized by factors[l] (both axes), zero-padded
+        to the largest level.  The same values as im_list_to_blob([resize_linear(im - means, f, f) for f in factors])."""
+        im = np.ascontiguousarray(im)
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise TypeError("device image preparation takes a uint8 HxWx3 image (got %s %r)" % (im.dtype, im.shape))
+        H, W = im.shape[:2]
+        means = np.ascontiguousarray(np.asarray(pixel_means, dtype=np.float64).reshape(-1))
+        if means.size != 3:
+            raise ValueError("pixel_means must hold 3 values")
+        sizes = [(int(round(H * f)), int(round(W * f))) for f in factors]
+        PH, PW = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        L = len(sizes)
+        # one packed table: per level [x0 int32 | ax float32 | y0 int32 | ay float32]
+        parts, offs, pos = [], [], 0
+        for (oh, ow), f in zip(sizes, factors):
+            x0, _, ax = linear_taps(ow, W, f)
+            y0, _, ay = linear_taps(oh, H, f)
+            offs.append((pos, pos + ow, pos + 2 * ow, pos + 2 * ow + oh))
+            parts += [x0.astype(np.int32).view(np.float32), ax, y0.astype(np.int32).view(np.float32), ay]
+            pos += 2 * ow + 2 * oh
+        table = np.ascontiguousarray(np.concatenate(parts))
+        h = self._net._ctx.h
+        d_im = self._im.ensure(im.nbytes)
+        d_t = self._taps.ensure(table.nbytes)
+        d_out = self._out.ensure(L * 3 * PH * PW * 4)
+        _lib.call("mnc_h2d", h, d_im, _lib.ptr(im), im.nbytes)
+        _lib.call("mnc_h2d", h, d_t, _lib.ptr(table), table.nbytes)
+        for l, ((oh, ow), (ox0, oax, oy0, oay)) in enumerate(zip(sizes, offs)):
+            _lib.call("mnc_prep_image", h, d_im, H, W, _lib.ptr(means), d_t + ox0 * 4, d_t + oax * 4, ow, d_t + oy0 * 4,
+                      d_t + oay * 4, oh, d_out + l * 3 * PH * PW * 4, PH, PW)
+        return DeviceArray(self._net, d_out, (L, 3, PH, PW), self)

@@ -166,6 +166,19 @@ class Fake(object):
             out = native.roi_warp(f, r, PH, PW, scale)
         _f(dst, (R, PH, PW, C))[...] = out.transpose(0, 2, 3, 1)
 
+    def mnc_prep_image(self, h, im, H, W, means, x0, ax, OW, y0, ay, OH, out, PH, PW):
+        img = np.ctypeslib.as_array((ctypes.c_ubyte * (H * W * 3)).from_address(int(im))).reshape(H, W, 3)
+        m = np.ctypeslib.as_array((ctypes.c_double * 3).from_address(int(means)))
+        f = (img.astype(np.float64) - m).astype(np.float32)
+        xa, fx, ya, fy = _i(x0, (OW,)), _f(ax, (OW,)), _i(y0, (OH,)), _f(ay, (OH,))
+        xb, yb = np.minimum(xa + 1, W - 1), np.minimum(ya + 1, H - 1)
+        one = np.float32(1.0)
+        rows = f[:, xa] * (one - fx)[None, :, None] + f[:, xb] * fx[None, :, None]
+        o = rows[ya] * (one - fy)[:, None, None] + rows[yb] * fy[:, None, None]
+        dst = _f(out, (3, PH, PW))
+        dst[...] = 0
+        dst[:, :OH, :OW] = o.transpose(2, 0, 1)
+
     def mnc_roi_pool(self, h, feat, N, C, H, W, rois, R, PH, PW, scale, dst):
         f = np.stack([_unc8(x) for x in _f(feat, (N, C // 8, H, W, 8))])
         out = native.roi_pool(np.ascontiguousarray(f), np.ascontiguousarray(_f(rois, (R, 5))), PH, PW, scale)

@@ -243,3 +243,45 @@ def test_cfm_graph_every_blob(fake_gpu, fuse):
             if want.size:
                 assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6), n
     net.close()
+
+
+def test_device_image_prep_plumbing(fake_gpu):
+    """net.prep_image (tap tables, level offsets, padding, DeviceArray hand-over to forward) equals the numpy functions of
+    lib/utils/blob.py bit for bit -- for the MNC single-scale input and for a CFM pyramid group."""
+    from mnc_amd.engine import Net
+    from mnc_config import cfg
+    from utils.blob import (im_list_to_blob, prep_im_for_blob, prep_im_for_blob_cfm, prep_im_for_blob_cfm_device,
+                            prep_im_for_blob_device)
+    path = models.write_cfm_test_prototxt(width_div=8)
+    net = Net(path, synth.synthetic_weights(path, seed=4), 1, device_id=0)
+    rng = np.random.default_rng(9)
+    for H, W in [(75, 100), (60, 60), (90, 37)]:
+        im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        host, hs = prep_im_for_blob(im, cfg.PIXEL_MEANS, 120, 170)
+        dev, ds = prep_im_for_blob_device(net, im, cfg.PIXEL_MEANS, 120, 170)
+        assert ds == hs and dev.shape == (1,) + host.transpose(2, 0, 1).shape
+        assert np.array_equal(np.asarray(dev), im_list_to_blob([host]))
+        old = cfg.TEST.MAX_SIZE
+        cfg.TEST.MAX_SIZE = 260
+        try:
+            hb, hf = prep_im_for_blob_cfm(im, [100, 150, 222])
+            db, df = prep_im_for_blob_cfm_device(net, im, [100, 150, 222])
+        finally:
+            cfg.TEST.MAX_SIZE = old
+        assert np.array_equal(hf, df) and db.shape == hb.shape and np.array_equal(np.asarray(db), hb)
+    # identity scale: the general path returns the mean-subtracted pixels themselves
+    im = rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)
+    dev = net.prep_image(im, cfg.PIXEL_MEANS, [1.0])
+    f = im.astype(np.float32, copy=True)
+    f -= cfg.PIXEL_MEANS
+    assert np.array_equal(np.asarray(dev)[0], f.transpose(2, 0, 1))
+    # forward adopts the DeviceArray: same conv1_1 as with the host blob
+    rois = np.array([[0, 4, 4, 60, 50]], np.float32)
+    masks = np.ones((1, 1, 14, 14), np.float32)
+    net.forward(data=dev, rois=rois, masks=masks)
+    a = net.blobs["conv1_1"].data.copy()
+    net.forward(data=np.asarray(dev).copy(), rois=rois, masks=masks)
+    assert np.array_equal(a, net.blobs["conv1_1"].data)
+    with pytest.raises(TypeError):
+        net.prep_image(im.astype(np.float32), cfg.PIXEL_MEANS, [1.0])
+    net.close()

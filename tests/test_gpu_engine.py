@@ -427,3 +427,38 @@ def test_tester_wrapper_cfm_task_on_device(tmp_path, monkeypatch):
         assert set(res) == {0.5, 0.7} and os.path.isfile(os.path.join(t.output_dir, "res_boxes.pkl"))
     finally:
         t.net.close()
+
+
+def test_device_image_prep_is_bit_identical_to_the_numpy_path(small):
+    """mnc_prep_image (csrc/prep.hip) vs lib/utils/blob.py: mean subtraction + INTER_LINEAR resize + CHW + zero padding, bit for
+    bit, at VOC-like sizes (up- and down-scaling, the MAX_SIZE cap, identity) and for a CFM pyramid; then the MNC forward fed
+    by the device blob equals the forward fed by the host blob."""
+    from mnc_config import cfg
+    from utils.blob import (im_list_to_blob, prep_im_for_blob, prep_im_for_blob_cfm, prep_im_for_blob_cfm_device,
+                            prep_im_for_blob_device)
+    net, w = small
+    rng = np.random.default_rng(12)
+    for (H, W), (target, cap) in [((375, 500), (600, 1000)), ((333, 500), (600, 1000)), ((500, 200), (600, 1000)),
+                                  ((600, 1000), (600, 1000)), ((800, 1100), (600, 1000)), ((97, 131), (48, 64))]:
+        im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        host, hs = prep_im_for_blob(im, cfg.PIXEL_MEANS, target, cap)
+        dev, ds = prep_im_for_blob_device(net, im, cfg.PIXEL_MEANS, target, cap)
+        assert ds == hs and np.array_equal(np.asarray(dev), im_list_to_blob([host])), (H, W)
+    im = rng.integers(0, 256, (375, 500, 3), dtype=np.uint8)
+    old = cfg.TEST.MAX_SIZE
+    cfg.TEST.MAX_SIZE = 1500
+    try:
+        for scales in ([480, 576, 688], [864, 1024]):
+            hb, hf = prep_im_for_blob_cfm(im, scales)
+            db, df = prep_im_for_blob_cfm_device(net, im, scales)
+            assert np.array_equal(hf, df) and db.shape == hb.shape and np.array_equal(np.asarray(db), hb)
+    finally:
+        cfg.TEST.MAX_SIZE = old
+    im = rng.integers(0, 256, (75, 100, 3), dtype=np.uint8)
+    dev, s = prep_im_for_blob_device(net, im, cfg.PIXEL_MEANS, 96, 160)
+    info = np.array([[dev.shape[2], dev.shape[3], s]], np.float32)
+    net.forward(data=dev, im_info=info)
+    a = {k: net.blobs[k]._host_read().copy() for k in ("conv1_1", "rois", "seg_cls_prob_ext")}
+    net.forward(data=np.asarray(dev).copy(), im_info=info)
+    for k, v in a.items():
+        assert np.array_equal(v, net.blobs[k]._host_read()), k

@@ -19,7 +19,7 @@ import caffe
 from mnc_config import cfg
 from transform.bbox_transform import clip_boxes
 from transform.mask_transform import gpu_mask_voting
-from utils.blob import im_list_to_blob, prep_im_for_blob
+from utils.blob import can_prep_on_device, im_list_to_blob, prep_im_for_blob, prep_im_for_blob_device
 
 CLASSES = ("aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
            "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor")
@@ -37,14 +37,19 @@ def parse_args(argv=None):
 
 
 def prepare_mnc_args(im, net):
-    """image (H,W,3 BGR) -> ({'data','im_info'} float32 blobs, [scale]); reshapes the two input blobs."""
-    im_scaled, im_scale = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
-    data = im_list_to_blob([im_scaled])
+    """image (H,W,3 BGR) -> ({'data','im_info'} float32 blobs, [scale]); reshapes the two input blobs.  A uint8 image is
+    mean-subtracted and resized on the GPU (cfg.TEST.DEVICE_PREP, default): `data` is then a DeviceArray holding the same
+    values, which net.forward adopts without a host round trip."""
+    if can_prep_on_device(net, im):
+        data, im_scale = prep_im_for_blob_device(net, im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
+    else:
+        im_scaled, im_scale = prep_im_for_blob(im, cfg.PIXEL_MEANS, cfg.TEST.SCALES[0], cfg.TRAIN.MAX_SIZE)
+        data = im_list_to_blob([im_scaled]).astype(np.float32, copy=False)
     im_scales = [np.array(im_scale)]
     im_info = np.array([[data.shape[2], data.shape[3], im_scales[0]]], dtype=np.float32)
     net.blobs["data"].reshape(*data.shape)
     net.blobs["im_info"].reshape(*im_info.shape)
-    return {"data": data.astype(np.float32, copy=False), "im_info": im_info}, im_scales
+    return {"data": data, "im_info": im_info}, im_scales
 
 
 def im_detect(im, net):
