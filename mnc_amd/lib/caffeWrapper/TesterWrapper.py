@@ -1,8 +1,8 @@
 """Test-time driver of the reference's three inference graphs over an image database (reference:
 lib/caffeWrapper/TesterWrapper.py:25-414).  `seg` = MNC 5-stage: per-image forward -> un-scale/clip/concat of both stages ->
 gpu_mask_voting (or per-class NMS) -> res_boxes.pkl / res_masks.pkl -> imdb.evaluate_segmentation (SURVEY section 8f row
-n1); `det` = Faster R-CNN end2end and `cfm` = convolutional feature masking over MCG proposals (row n3).  `vis_seg` (image
-rendering) is not provided."""
+n1); `det` = Faster R-CNN end2end and `cfm` = convolutional feature masking over MCG proposals (row n3); `vis_seg` renders
+the stored results (row n4's visualisation tail)."""
 import heapq
 import os
 import pickle
@@ -40,9 +40,11 @@ class TesterWrapper(object):
         seg_file = os.path.join(self.output_dir, 'res_masks.pkl')
         if self.task_name == 'det':
             return self.get_detection_result()
+        if self.task_name == 'vis_seg':
+            return self.vis_segmentation_result()
         if self.task_name not in ('seg', 'cfm'):
-            raise NotImplementedError("task %r: 'seg' (MNC 5-stage), 'det' (Faster R-CNN end2end) and 'cfm' are provided; "
-                                      "'vis_seg' is not" % self.task_name)
+            print("task name only support 'det', 'seg', 'cfm' and 'vis_seg'")
+            raise NotImplementedError(self.task_name)
         if os.path.isfile(det_file) and os.path.isfile(seg_file):
             with open(det_file, 'rb') as f:
                 seg_box = pickle.load(f)
@@ -57,6 +59,10 @@ class TesterWrapper(object):
         print('Evaluating segmentation using MNC 5 stage inference' if self.task_name == 'seg' else
               'Evaluating segmentation using convolutional feature masking')
         return self.imdb.evaluate_segmentation(seg_box, seg_mask, self.output_dir)
+
+    def vis_segmentation_result(self):
+        """TesterWrapper.py:146-147: render the result pickles a previous `seg` / `cfm` run left in output_dir."""
+        return self.imdb.visualization_segmentation(self.output_dir)
 
     def get_detection_result(self):
         """Faster R-CNN end2end test loop (TesterWrapper.py:86-143): all_boxes[cls][image] = [n,5], per-class score

@@ -1,6 +1,7 @@
 """PASCAL VOC / SBD instance-segmentation image database, test-time surface (reference:
 lib/datasets/pascal_voc_seg.py:19-44,155-228 and the parts of pascal_voc_det.py / db/imdb.py it inherits that
-tools/test_net.py --task seg touches: name, classes, image_index, image_path_at, evaluate_segmentation).
+tools/test_net.py --task seg / vis_seg touches: name, classes, image_index, image_path_at, evaluate_segmentation,
+visualization_segmentation).
 
 Layout of the devkit (data/VOCdevkitSDS): img/<id>.jpg, inst/<id>.mat, cls/<id>.mat, <image_set>.txt.
 Training-time members (roidb / maskdb construction, flipping) are outside the inference hot path and not provided."""
@@ -49,6 +50,11 @@ class PascalVOCSeg(object):
             return [x.strip() for x in f.readlines()]
 
     # --------------------------- Evaluation ---------------------------
+    def visualization_segmentation(self, output_dir):
+        """pascal_voc_seg.py:152-153: render res_boxes.pkl / res_masks.pkl of `output_dir` over the images."""
+        from utils.vis_seg import vis_seg
+        vis_seg(self.image_index, self.classes, output_dir, self._data_path, self._image_ext)
+
     def evaluate_segmentation(self, all_boxes, all_masks, output_dir):
         self._write_voc_seg_results_file(all_boxes, all_masks, output_dir)
         return self._py_evaluate_segmentation(output_dir)

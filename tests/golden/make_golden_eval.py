@@ -195,6 +195,15 @@ def main():
                 R.cfg.TEST[k] = v
         finally:
             os.chdir(cwd)
+    # ---- 2c. visualisation tail: lib/utils/vis_seg.py pure functions ----------------------------------------
+    vs = _load("utils.vis_seg", "lib/utils/vis_seg.py")
+    vs.cv2.resize = resize
+    g["vis_color_map"] = vs._get_voc_color_map()
+    for ii in (0, 3):
+        H, W = case["images"][ii]["im"].shape[:2]
+        pred = GI.vis_pred_dict(case, ii)
+        inst_img, cls_img = vs._convert_pred_to_image(W, H, pred)
+        g["vis_inst_%d" % ii], g["vis_cls_%d" % ii] = inst_img, cls_img
     # ---- 3. detection task: voc_eval + TesterWrapper.get_detection_result ----------------------------------
     dcase = GI.voc_det_case()
     with tempfile.TemporaryDirectory() as root:

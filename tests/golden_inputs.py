@@ -328,3 +328,22 @@ def cfm_fake_forward(data, rois, masks, K=21, S=21):
     yy, xx = np.mgrid[0:S, 0:S]
     mp = 0.5 + 0.5 * np.sin(key[:, None, None] + 0.3 * xx[None] + 0.2 * yy[None] + m.mean(1)[:, None, None])
     return {"mask_prob": mp.reshape(-1, 1, S, S).astype(np.float32), "seg_cls_prob": seg}
+
+
+def vis_pred_dict(case, ii, vis_thresh=0.3):
+    """What lib/utils/vis_seg.py:_prepare_dict builds for image ii from the case's predictions (plus one box touching the
+    image border and one hanging over it, to reach the clipping and the negative-slice outline branches)."""
+    boxes, masks, classes = [], [], []
+    for c in range(1, 21):
+        det, seg = case["pred_boxes"][c][ii], case["pred_masks"][c][ii]
+        for k in np.where(det[:, -1] >= vis_thresh)[0]:
+            boxes.append(det[k])
+            masks.append(seg[k][0])
+            classes.append(c)
+    H, W = case["images"][ii]["im"].shape[:2]
+    yy, xx = np.mgrid[0:21, 0:21]
+    disc = (np.hypot(xx - 10, yy - 10) <= 8).astype(np.float32)
+    boxes += [np.array([0, 0, 30.4, 25.6, 0.9], np.float32), np.array([W - 20.5, H - 18.5, W + 9, H + 7, 0.8], np.float32)]
+    masks += [disc, disc * np.float32(0.7)]
+    classes += [7, 15]
+    return {"image_name": case["images"][ii]["name"], "cls_name": classes, "boxes": boxes, "masks": masks}

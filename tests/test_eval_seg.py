@@ -117,8 +117,6 @@ def test_tester_wrapper_loop_matches_the_reference(devkit, ref, monkeypatch, tmp
     with np.errstate(all="ignore"):
         t.get_result()
     assert t.net.calls == calls
-    with pytest.raises(NotImplementedError):
-        TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "vis_seg").get_result()
     gc.collect()
 
 
@@ -177,6 +175,52 @@ def test_cfm_task_matches_the_reference(devkit, ref, monkeypatch, tmp_path):
         res = t.get_result()                                   # pickles + SDS evaluation on the CFM lists
     assert set(res) == {0.5, 0.7} and os.path.isfile(os.path.join(t.output_dir, "res_masks.pkl"))
     gc.collect()
+
+
+def test_visualisation_tail_matches_the_reference(devkit, ref, tmp_path, monkeypatch):
+    """SURVEY 8f n4 (visualisation tail): lib/utils/vis_seg.py's pure functions against the reference's own
+    (_get_voc_color_map, _convert_pred_to_image incl. clipping / overwrite order / the empty negative outline slices); then the
+    `vis_seg` task and demo._visualise write their files."""
+    import caffe
+    import demo
+    from caffeWrapper.TesterWrapper import TesterWrapper
+    from datasets.pascal_voc_seg import PascalVOCSeg
+    from mnc_config import cfg
+    from utils import vis_seg
+    import pickle
+    root, case = devkit
+    assert np.array_equal(vis_seg._get_voc_color_map(), ref["vis_color_map"])
+    for ii in (0, 3):
+        H, W = case["images"][ii]["im"].shape[:2]
+        inst, cls = vis_seg._convert_pred_to_image(W, H, GI.vis_pred_dict(case, ii))
+        assert inst.dtype == ref["vis_inst_%d" % ii].dtype and np.array_equal(inst, ref["vis_inst_%d" % ii])
+        assert np.array_equal(cls, ref["vis_cls_%d" % ii])
+
+    class NoNet(object):
+        def __init__(self, *a):
+            self.name = "fake"
+
+    monkeypatch.setattr(caffe, "Net", NoNet)
+    monkeypatch.setattr(cfg, "ROOT_DIR", str(tmp_path))
+    imdb = PascalVOCSeg("val", "2012", root, image_ext=".npy")
+    t = TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "vis_seg")
+    with open(os.path.join(t.output_dir, "res_boxes.pkl"), "wb") as f:
+        pickle.dump(case["pred_boxes"], f)
+    with open(os.path.join(t.output_dir, "res_masks.pkl"), "wb") as f:
+        pickle.dump(case["pred_masks"], f)
+    t.get_result()
+    from PIL import Image
+    for sub, ext in (("SegInst", ".jpg"), ("SegCls", ".jpg"), ("SegRes", ".png")):
+        for rec in case["images"]:
+            im = Image.open(os.path.join(t.output_dir, sub, rec["name"] + ext))
+            assert im.size == (rec["im"].shape[1], rec["im"].shape[0])
+    res = np.asarray(Image.open(os.path.join(t.output_dir, "SegRes", case["images"][0]["name"] + ".png")).convert("RGB"))
+    assert (res.astype(int) != case["images"][0]["im"][:, :, ::-1].astype(int)).any()
+    out = str(tmp_path / "demo_vis.png")
+    demo._visualise(case["images"][0]["im"], GI.vis_pred_dict(case, 0), out)
+    assert Image.open(out).size[0] > 100
+    with pytest.raises(NotImplementedError):
+        TesterWrapper("x.prototxt", imdb, "fake.caffemodel", "nothing").get_result()
 
 
 def test_imdb_factory():

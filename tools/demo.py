@@ -87,20 +87,32 @@ def _read_image_bgr(path):
 
 
 def _visualise(im_bgr, pred, out_path):
-    """Paint each instance mask (binarised at cfg.BINARIZE_THRESH after resizing to its box) over the image."""
+    """The tail of the reference demo (tools/demo.py:150-191): class-id image of the voted instances
+    (lib/utils/vis_seg.py:_convert_pred_to_image) in VOC colours, blended 0.8 over the photo, one "<class> <score>" label per
+    instance at its box corner, saved as PNG (matplotlib; PIL-only without the labels when matplotlib is missing)."""
     from PIL import Image
-    from utils.blob import resize_linear
-    canvas = im_bgr[:, :, ::-1].astype(np.float32).copy()
-    rng = np.random.default_rng(0)
-    for box, mask in zip(pred["boxes"], pred["masks"]):
-        x1, y1, x2, y2 = [int(round(v)) for v in box[:4]]
-        w, h = max(x2 - x1 + 1, 1), max(y2 - y1 + 1, 1)
-        m = resize_linear(mask[:, :, None].astype(np.float32), w / 21.0, h / 21.0)[:, :, 0] >= cfg.BINARIZE_THRESH
-        m = m[:min(h, canvas.shape[0] - y1), :min(w, canvas.shape[1] - x1)]
-        colour = rng.uniform(64, 255, 3).astype(np.float32)
-        region = canvas[y1:y1 + m.shape[0], x1:x1 + m.shape[1]]
-        region[m] = 0.4 * region[m] + 0.6 * colour
-    Image.fromarray(np.clip(canvas, 0, 255).astype(np.uint8)).save(out_path)
+    from utils.vis_seg import _convert_pred_to_image, _get_voc_color_map
+    h, w = im_bgr.shape[:2]
+    _, cls_img = _convert_pred_to_image(w, h, pred)
+    cls_rgb = _get_voc_color_map().astype(np.uint8)[cls_img]
+    background = Image.fromarray(np.ascontiguousarray(im_bgr[:, :, ::-1])).convert("RGBA")
+    blended = Image.blend(background, Image.fromarray(cls_rgb).convert("RGBA"), 0.8).convert("RGB")
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        blended.save(out_path)
+        return
+    fig, ax = plt.subplots(figsize=(12, 12))
+    ax.imshow(np.asarray(blended), aspect="equal")
+    for box, cls_ind in zip(pred["boxes"], pred["cls_name"]):
+        ax.text(box[0], box[1] - 8, "{:s} {:.4f}".format(CLASSES[cls_ind - 1], box[-1]), bbox=dict(facecolor="blue", alpha=0.5),
+                fontsize=14, color="white")
+    plt.axis("off")
+    plt.tight_layout()
+    fig.savefig(out_path)
+    plt.close(fig)
 
 
 def build_net(args):

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Time the CFM test path (models/VGG16/cfm/test.prototxt with experiments/cfgs/VGG16/cfm.yml's test settings:
-5-level pyramid 480..1024 capped at 1500, levels grouped 3 + 2 per forward, 2000 MCG proposals, chunks of 2000 / 500 rois) on
-one synthetic 375x500 image with seeded synthetic weights and proposals.  Prints per-image wall time and the per-kernel
-breakdown (HIP events).  Not the headline bench (bench.py): a measurement of the widened row.
+"""Time the per-image body of `tools/test_net.py` on one synthetic VOC-sized image, host work
+included (image preparation, forward, result hand-over) -- what bench.py's HBM-resident headline leaves out:
 
-    python tools/cfm_bench.py [--proposals 2000] [--iters 3] [--math fp32|bf16x3]
+  --task seg   TesterWrapper._segmentation_forward + gpu_mask_voting of the 5-stage MNC graph (375x500 -> 600x800)
+  --task cfm   TesterWrapper.cfm_network_forward with experiments/cfgs/VGG16/cfm.yml's test settings: 5-level pyramid
+               480..1024 capped at 1500, levels grouped 3 + 2 per forward, 2000 MCG proposals in chunks of 2000 / 500 rois
+
+Seeded synthetic weights, pixels and proposals.  Prints wall time per image and the per-kernel breakdown (HIP events).
+
+    python tools/task_bench.py --task seg|cfm [--iters 5] [--math fp32|bf16x3] [--host-prep]
 """
 import argparse
 import json
@@ -21,6 +25,8 @@ from mnc_amd import models, synth
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--task", default="cfm", choices=["seg", "cfm"])
+    ap.add_argument("--host-prep", action="store_true", help="numpy image preparation (cfg.TEST.DEVICE_PREP = False)")
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--math", default=os.environ.get("MNC_MATH", "fp32"))
@@ -31,8 +37,10 @@ def main():
     import scipy.io
     from caffeWrapper.TesterWrapper import TesterWrapper
     from mnc_config import cfg
-    cfg.TEST.SCALES, cfg.TEST.MAX_SIZE = [480, 576, 688, 864, 1024], 1500
-    cfg.TEST.GROUP_SCALE, cfg.TEST.MAX_ROIS_GPU, cfg.TEST.USE_TOP_K_MCG = 3, [2000, 500], 2000
+    cfg.TEST.DEVICE_PREP = not args.host_prep
+    if args.task == "cfm":
+        cfg.TEST.SCALES, cfg.TEST.MAX_SIZE = [480, 576, 688, 864, 1024], 1500
+        cfg.TEST.GROUP_SCALE, cfg.TEST.MAX_ROIS_GPU, cfg.TEST.USE_TOP_K_MCG = 3, [2000, 500], 2000
     rng = np.random.default_rng(0)
     H, W, n = args.height, args.width, args.proposals
     with tempfile.TemporaryDirectory() as root:
@@ -56,30 +64,41 @@ def main():
             def image_path_at(self, i):
                 return os.path.join(root, "im0.npy")
 
-        path = models.write_cfm_test_prototxt()
+        path = models.write_cfm_test_prototxt() if args.task == "cfm" else models.write_mnc_5stage_test_prototxt()
         t0 = time.time()
         weights = synth.synthetic_weights(path, seed=0)
-        t = TesterWrapper(path, Imdb(), weights, "cfm")
+        t = TesterWrapper(path, Imdb(), weights, args.task)
         print("net ready in %.1f s" % (time.time() - t0), file=sys.stderr)
+        from transform.mask_transform import gpu_mask_voting
+        from utils.image_io import imread
+
+        def body():
+            if args.task == "cfm":
+                return t.cfm_network_forward(0)
+            im = imread(Imdb().image_path_at(0))
+            masks, bxs, scores = t._segmentation_forward(im)
+            return gpu_mask_voting(masks, bxs, scores, 21, 100, im.shape[1], im.shape[0])
+
         calls = []
         real = t.net.forward
 
         def spy(**kw):
-            calls.append((kw.get("start"), tuple(kw["data"].shape) if "data" in kw else None, len(kw["rois"])))
+            calls.append((kw.get("start"), tuple(kw["data"].shape) if "data" in kw else None,
+                          len(kw["rois"]) if "rois" in kw else None))
             return real(**kw)
         t.net.forward = spy
-        t.cfm_network_forward(0)                                      # warm-up: weight packing, buffer growth
+        body()                                                        # warm-up: weight packing, buffer growth
         plan = list(calls)
         t.net.forward = real
         times = []
         for _ in range(args.iters):
             t.net.sync()
             t0 = time.perf_counter()
-            t.cfm_network_forward(0)
+            body()
             t.net.sync()
             times.append(time.perf_counter() - t0)
         t.net.profile(1)
-        t.cfm_network_forward(0)
+        body()
         t.net.sync()
         agg = {}
         for name, ms, fl, by in t.net.profile_records():
@@ -90,9 +109,10 @@ def main():
         t.net.profile(0)
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         dev_ms = sum(v[1] for v in agg.values())
-        print(json.dumps({"workload": "cfm vgg16 %dx%d, %d proposals, scales 480-1024 (3+2 levels/forward)" % (H, W, n),
-                          "math": args.math, "forwards": [{"start": c[0], "data": c[1], "rois": c[2]} for c in plan],
-                          "ms_per_image_wall": round(min(times) * 1e3, 2), "ms_per_image_kernels": round(dev_ms, 2),
+        what = ("cfm vgg16 %dx%d, %d proposals, scales 480-1024 (3+2 levels/forward)" % (H, W, n) if args.task == "cfm" else
+                "mnc 5-stage vgg16 %dx%d image -> %s, 300 rois/stage, mask voting" % (H, W, "x".join(map(str, plan[0][1][2:]))))
+        print(json.dumps({"workload": what, "math": args.math, "image_prep": "host" if args.host_prep else "device", "forwards": [{"start": c[0], "data": c[1], "rois": c[2]} for c in plan],
+                          "ms_per_image_wall": round(min(times) * 1e3, 2), "ms_per_image_wall_median": round(sorted(times)[len(times) // 2] * 1e3, 2), "ms_per_image_kernels": round(dev_ms, 2),
                           "kernels": [{"name": k, "calls": v[0], "ms": round(v[1], 3),
                                        "tflops": round(v[2] / v[1] / 1e9, 1) if v[1] > 0 and v[2] > 0 else None}
                                       for k, v in rows[:14]]}))
