@@ -182,6 +182,25 @@ MNC_API int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score_nchw, float* d_pr
  * 2PH x 2PW and max-reduced, so the 28x28 "premax" tensor never reaches HBM. */
 MNC_API int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R,
                          int PH, int PW, float spatial_scale, int pool2, float* d_out_rhwc);
+/* ---- general convolution / pooling / residual ops (graphs beyond VGG-16, e.g. a ResNet-50 trunk;
+ * BASELINE.json configs[4]).  Public BVLC Caffe semantics (convolution_param / pooling_param / eltwise_param); there is no
+ * such model in the reference repository. ---- */
+/* Caffe conv weight [Cout][Cin][KH][KW] -> [KH*KW][Cin/8][Cout][8] for mnc_conv2d.  Cin%8==0, Cout%8==0; same element count. */
+MNC_API int mnc_pack_conv_weights(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin, int KH, int KW);
+/* Convolution, any kernel / stride / pad, c8 -> c8 ([Cout/8][OH][OW][8], OH = (H + 2 pad - KH)/stride + 1), fp32 MFMA implicit
+ * GEMM: out = conv(in) + bias (+ d_residual, same layout as out, may be NULL) (+ ReLU).  A BatchNorm + Scale pair behind the
+ * convolution is folded into the weights and bias by the caller. */
+MNC_API int mnc_conv2d(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
+                       const float* d_residual_c8, float* d_out_c8, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                       int pad, int relu);
+/* First convolution of a 3-channel NCHW input blob (ResNet conv1 7x7/2 pad 3): weights [Cout][3][K][K] as in Caffe,
+ * + bias (+ ReLU) -> c8.  Cout%16==0. */
+MNC_API int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8,
+                             int H, int W, int Cout, int K, int stride, int pad, int relu);
+/* Pooling MAX with any kernel / stride / pad on a c8 map; Caffe's ceil output size, windows clipped to the image. */
+MNC_API int mnc_maxpool_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W, int K, int stride, int pad);
+/* Eltwise SUM of two tensors of the same layout (+ ReLU): d_out[i] = d_a[i] + d_b[i]. */
+MNC_API int mnc_add(mnc_ctx* ctx, const float* d_a, const float* d_b, float* d_out, size_t n, int relu);
 /* prep_im_for_blob (lib/utils/blob.py:36-50) and one level of prep_im_for_blob_cfm (:53-85) on the device: a uint8 BGR image
  * [H][W][3] -> float32 planes [3][PH][PW] holding (pixel - mean) resized with cv2.resize's INTER_LINEAR rule to OH x OW and
  * zero-padded to the blob's PH x PW (im_list_to_blob, :17-33).  `means` = 3 host doubles (cfg.PIXEL_MEANS).  The resize

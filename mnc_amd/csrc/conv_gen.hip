@@ -1,0 +1,308 @@
+// General convolution / pooling / residual kernels for graphs beyond VGG-16 (a ResNet-50 trunk has
+// 1x1, strided and 7x7 convolutions, 3x3/2 max pooling and residual adds; BASELINE.json configs[4]).  First correct path:
+// the stride-1 3x3 layers keep using the tuned kernels of conv.hip / conv_x3.hip; everything else comes through here.
+//
+//   conv2d_c8_kernel   any KHxKW / stride / pad, c8 -> c8, fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32):
+//                      M = output channels (A = weights), N = output pixels (B = gathered input pixels), K = taps x Cin walked
+//                      one (tap, 8-channel block) at a time.  WG = 4 waves = 64 channels x 128 pixels, wave = 32 x 64.
+//                      There is no halo to reuse for 1x1 / strided taps, so each step stages exactly the 128 x 8 input values
+//                      and 64 x 8 weights it multiplies (global -> registers -> LDS, double-buffered, one barrier per step,
+//                      branch-free clamped + masked loads).  Each lane feeds its 4 of the 8 channels with one ds_read_b128
+//                      (pitch 12 floats: conflict-free).  Epilogue: + bias (+ residual) (+ ReLU), 16-byte stores.
+//   conv_stem_c3_kernel  KxK / stride / pad on the 3-channel NCHW input blob -> c8 (ResNet conv1 7x7/2): VALU, one output pixel
+//                      per thread, 16 output channels at a time with the weights broadcast from LDS.  HBM/L2-bound.
+//   maxpool_c8_kernel  Caffe MAX pooling with any kernel / stride / pad (ceil output size, windows clipped to the image).
+//   add_kernel         out = a + b (+ ReLU): Eltwise SUM of two same-layout tensors.
+#include <cfloat>
+
+#include "mnc_internal.h"
+
+namespace mnc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGenCo = 64;      // output channels per workgroup
+constexpr int kGenPx = 128;     // output pixels per workgroup
+constexpr int kGenPitch = 12;   // floats per LDS row (8 data + 4 pad)
+
+// [Cout][Cin][KH][KW] -> [KH*KW][Cin/8][Cout][8]
+__global__ void pack_conv_gen_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KK) {
+  const long total = (long)KK * Cin * Cout;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % 8);
+    long r = idx / 8;
+    const int co = (int)(r % Cout);
+    r /= Cout;
+    const int cb = (int)(r % (Cin / 8));
+    const int t = (int)(r / (Cin / 8));
+    out[idx] = w[((long)co * Cin + cb * 8 + c) * KK + t];
+  }
+}
+
+__global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+                                                        const float* __restrict__ bias, const float* __restrict__ res,
+                                                        float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
+                                                        int KW, int stride, int pad, int OH, int OW, int relu) {
+  __shared__ __attribute__((aligned(16))) float s_act[2][kGenPx * kGenPitch];
+  __shared__ __attribute__((aligned(16))) float s_wt[2][kGenCo * kGenPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long P = (long)OH * OW;
+  const long p0 = (long)blockIdx.x * kGenPx;
+  const int co0 = blockIdx.y * kGenCo;
+  const int CB = Cin >> 3;
+  const int steps = KH * KW * CB;
+
+  // staging roles: activations -- pixel tid/2, channel half tid%2; weights -- channel tid/4, float2 tid%4
+  const int a_px = tid >> 1, a_half = tid & 1;
+  long ap = p0 + a_px;
+  const bool a_live = ap < P;
+  if (!a_live) ap = P - 1;
+  const int a_oy = (int)(ap / OW), a_ox = (int)(ap % OW);
+  const int a_iy0 = a_oy * stride - pad, a_ix0 = a_ox * stride - pad;
+  const int w_co = tid >> 2, w_q = tid & 3;
+  const bool w_live = co0 + w_co < Cout;
+  const int w_row = w_live ? co0 + w_co : Cout - 1;
+
+  float4 ra;
+  float2 rw;
+  auto load = [&](int s) {
+    const int t = s / CB, cb = s - t * CB;
+    const int ky = t / KW, kx = t - ky * KW;
+    const int iy = a_iy0 + ky, ix = a_ix0 + kx;
+    const bool ok = a_live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+    const float4 v = *reinterpret_cast<const float4*>(in + (((long)cb * H + cy) * W + cx) * 8 + a_half * 4);
+    ra = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 u = *reinterpret_cast<const float2*>(wpk + (((long)t * CB + cb) * Cout + w_row) * 8 + w_q * 2);
+    rw = w_live ? u : make_float2(0.f, 0.f);
+  };
+  auto store = [&](int buf) {
+    *reinterpret_cast<float4*>(&s_act[buf][a_px * kGenPitch + a_half * 4]) = ra;
+    *reinterpret_cast<float2*>(&s_wt[buf][w_co * kGenPitch + w_q * 2]) = rw;
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  const int co_half = wave & 1, px_half = wave >> 1;
+  const int frag_off = (lane >> 5) * 4;
+  const float* a_ptr0 = &s_wt[0][(co_half * 32 + (lane & 31)) * kGenPitch + frag_off];
+  const float* b_ptr0 = &s_act[0][(px_half * 64 + (lane & 31)) * kGenPitch + frag_off];
+
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    load(s + 1 < steps ? s + 1 : s);
+    const float4 a = *reinterpret_cast<const float4*>(a_ptr0 + buf * (kGenCo * kGenPitch));
+    const float4 b0 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch));
+    const float4 b1 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch) + 32 * kGenPitch);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+    store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds, per 32x32 block, 4 consecutive channels (regs 4g..4g+3) of one pixel for g = 0..3
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long px = p0 + px_half * 64 + j * 32 + (lane & 31);
+    if (px >= P) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + co_half * 32 + g * 8 + frag_off;
+      if (co >= Cout) continue;
+      const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+      float4 v = make_float4(acc[j][g * 4 + 0] + bv.x, acc[j][g * 4 + 1] + bv.y, acc[j][g * 4 + 2] + bv.z,
+                             acc[j][g * 4 + 3] + bv.w);
+      const long o = ((long)(co >> 3) * P + px) * 8 + (co & 7);
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(out + o) = v;
+    }
+  }
+}
+
+// Stem: Cin = 3, NCHW input, weights [Cout][3][K][K] re-laid in LDS as [Cout/16][3*K*K][16].
+__global__ __launch_bounds__(256) void conv_stem_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                           int W, int Cout, int K, int stride, int pad, int OH, int OW,
+                                                           int relu) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];
+  const int taps = 3 * K * K, groups = Cout / 16;
+  for (int i = threadIdx.x; i < Cout * taps; i += blockDim.x) {
+    const int co = i / taps, t = i - co * taps;
+    s_w[((co >> 4) * taps + t) * 16 + (co & 15)] = w[i];
+  }
+  __syncthreads();
+  const long P = (long)OH * OW;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int oy = (int)(p / OW), ox = (int)(p % OW);
+  const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+  for (int g = 0; g < groups; ++g) {
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bias[g * 16 + i];
+    const float* wg = s_w + (long)g * taps * 16;
+    int t = 0;
+    for (int c = 0; c < 3; ++c)
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = iy0 + ky;
+        const bool rowok = iy >= 0 && iy < H;
+        const float* row = in + ((long)c * H + min(max(iy, 0), H - 1)) * W;
+        for (int kx = 0; kx < K; ++kx, ++t) {
+          const int ix = ix0 + kx;
+          const float v = (rowok && ix >= 0 && ix < W) ? row[ix] : 0.f;
+          const float4* wp = reinterpret_cast<const float4*>(wg + t * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 ww = wp[q];
+            acc[q * 4 + 0] = fmaf(v, ww.x, acc[q * 4 + 0]);
+            acc[q * 4 + 1] = fmaf(v, ww.y, acc[q * 4 + 1]);
+            acc[q * 4 + 2] = fmaf(v, ww.z, acc[q * 4 + 2]);
+            acc[q * 4 + 3] = fmaf(v, ww.w, acc[q * 4 + 3]);
+          }
+        }
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* o = out + ((long)(g * 2 + h) * P + p) * 8;
+      float4 v0 = make_float4(acc[h * 8 + 0], acc[h * 8 + 1], acc[h * 8 + 2], acc[h * 8 + 3]);
+      float4 v1 = make_float4(acc[h * 8 + 4], acc[h * 8 + 5], acc[h * 8 + 6], acc[h * 8 + 7]);
+      if (relu) {
+        v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+        v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+      }
+      *reinterpret_cast<float4*>(o) = v0;
+      *reinterpret_cast<float4*>(o + 4) = v1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_c8_kernel(const float* __restrict__ in, float* __restrict__ out, int CB, int H,
+                                                         int W, int K, int stride, int pad, int OH, int OW) {
+  const long total = (long)CB * OH * OW * 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int half = (int)(idx & 1);
+    long r = idx >> 1;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int cb = (int)(r / OH);
+    const int y0 = max(oy * stride - pad, 0), y1 = min(oy * stride - pad + K, H);
+    const int x0 = max(ox * stride - pad, 0), x1 = min(ox * stride - pad + K, W);
+    float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const float4 v = *reinterpret_cast<const float4*>(in + (((long)cb * H + y) * W + x) * 8 + half * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    *reinterpret_cast<float4*>(out + (((long)cb * OH + oy) * OW + ox) * 8 + half * 4) = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n4, long n, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float v = a[i] + b[i];
+    out[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+static int grid1d(long total, int cap = 256 * 64) {
+  long g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+// Caffe's output sizes: convolution floor((n + 2p - k)/s) + 1; pooling ceil((n + 2p - k)/s) + 1, minus one when the last
+// window would start in the padding (pooling_layer.cpp).
+static inline int conv_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+static inline int pool_out(int n, int k, int s, int p) {
+  int o = (n + 2 * p - k + s - 1) / s + 1;
+  if (p > 0 && (o - 1) * s >= n + p) --o;
+  return o;
+}
+
+int mnc_pack_conv_weights(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin, int KH, int KW) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed, "mnc_pack_conv_weights: null pointer");
+  MNC_REQUIRE(Cout > 0 && Cout % 8 == 0 && Cin > 0 && Cin % 8 == 0 && KH > 0 && KW > 0, "mnc_pack_conv_weights: bad shape");
+  LaunchScope ls(ctx, "pack_conv_gen");
+  hipLaunchKernelGGL(pack_conv_gen_kernel, dim3(grid1d((long)KH * KW * Cin * Cout)), dim3(256), 0, ctx->stream, d_oihw, d_packed,
+                     Cout, Cin, KH * KW);
+  return ls.finish("pack_conv_gen_kernel");
+}
+
+int mnc_conv2d(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, const float* d_residual, float* d_out,
+               int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out, "mnc_conv2d: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0 && KH > 0 && KW > 0 && stride > 0 &&
+                  pad >= 0 && H + 2 * pad >= KH && W + 2 * pad >= KW,
+              "mnc_conv2d: bad shape (Cin, Cout multiples of 8)");
+  const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+  const long P = (long)OH * OW;
+  const double flops = 2.0 * P * Cout * (double)Cin * KH * KW;
+  LaunchScope ls(ctx, "conv2d_c8_mfma", flops, 4.0 * ((double)H * W * Cin + (double)P * Cout * (d_residual ? 2 : 1)));
+  hipLaunchKernelGGL(conv2d_c8_kernel, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, kGenCo)), dim3(256), 0, ctx->stream,
+                     d_in, d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);
+  return ls.finish("conv2d_c8_kernel");
+}
+
+int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8, int H,
+                     int W, int Cout, int K, int stride, int pad, int relu) {
+  MNC_REQUIRE(ctx && d_in_nchw && d_w_oihw && d_bias && d_out_c8, "mnc_conv_stem_c3: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 16 == 0 && K > 0 && stride > 0 && pad >= 0 && H + 2 * pad >= K &&
+                  W + 2 * pad >= K && (size_t)Cout * 3 * K * K * 4 <= 64 * 1024,
+              "mnc_conv_stem_c3: bad shape (Cout multiple of 16, weights <= 64 KB)");
+  const int OH = conv_out(H, K, stride, pad), OW = conv_out(W, K, stride, pad);
+  const long P = (long)OH * OW;
+  LaunchScope ls(ctx, "conv_stem_c3", 2.0 * P * Cout * 3.0 * K * K, 4.0 * (3.0 * H * W + (double)P * Cout));
+  hipLaunchKernelGGL(conv_stem_c3_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), (size_t)Cout * 3 * K * K * 4, ctx->stream,
+                     d_in_nchw, d_w_oihw, d_bias, d_out_c8, H, W, Cout, K, stride, pad, OH, OW, relu);
+  return ls.finish("conv_stem_c3_kernel");
+}
+
+int mnc_maxpool_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W, int K, int stride, int pad) {
+  MNC_REQUIRE(ctx && d_in && d_out && C > 0 && C % 8 == 0 && H > 0 && W > 0 && K > 0 && stride > 0 && pad >= 0 && pad < K,
+              "mnc_maxpool_c8: bad argument");
+  const int OH = pool_out(H, K, stride, pad), OW = pool_out(W, K, stride, pad);
+  LaunchScope ls(ctx, "maxpool_c8", 0.0, 4.0 * C * ((double)H * W + (double)OH * OW));
+  hipLaunchKernelGGL(maxpool_c8_kernel, dim3(grid1d((long)(C / 8) * OH * OW * 2)), dim3(256), 0, ctx->stream, d_in, d_out, C / 8,
+                     H, W, K, stride, pad, OH, OW);
+  return ls.finish("maxpool_c8_kernel");
+}
+
+int mnc_add(mnc_ctx* ctx, const float* d_a, const float* d_b, float* d_out, size_t n, int relu) {
+  MNC_REQUIRE(ctx && d_a && d_b && d_out, "mnc_add: null pointer");
+  if (n == 0) return MNC_OK;
+  LaunchScope ls(ctx, "add", 0.0, 12.0 * (double)n);
+  hipLaunchKernelGGL(add_kernel, dim3(grid1d((long)(n / 4) + 1)), dim3(256), 0, ctx->stream, d_a, d_b, d_out, (long)(n / 4),
+                     (long)n, relu);
+  return ls.finish("add_kernel");
+}

@@ -150,6 +150,67 @@ def test_conv1x1_and_rpn_softmax(dev):
     assert np.abs(prob[:9] + prob[9:] - 1).max() < 1e-6
 
 
+GEN_CONV = [  # H, W, Cin, Cout, K, stride, pad, residual   (ResNet-50 shapes in miniature, plus ragged tiles)
+    (37, 53, 64, 256, 1, 1, 0, False), (37, 53, 256, 64, 1, 1, 0, True), (40, 54, 256, 128, 1, 2, 0, False),
+    (33, 47, 64, 64, 3, 2, 1, False), (21, 30, 128, 72, 3, 1, 1, True), (12, 9, 8, 8, 5, 1, 2, False),
+    (50, 84, 1024, 256, 1, 1, 0, False)]
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,K,stride,pad,residual", GEN_CONV)
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv2d_general(dev, H, W, Cin, Cout, K, stride, pad, residual, relu):
+    """mnc_conv2d (any kernel / stride / pad, + bias + residual + ReLU) against torch fp32."""
+    rng = np.random.default_rng(H * 100 + W + K)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, K, K)) * np.sqrt(2.0 / (K * K * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    y = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=pad)[0]
+    OH, OW = y.shape[1:]
+    res = rng.normal(size=(Cout, OH, OW)).astype(np.float32) if residual else None
+    if residual:
+        y = y + torch.from_numpy(res)
+    want = (F.relu(y) if relu else y).numpy()
+    d_w = dev.empty((w.size,), fill=np.nan)
+    dev.call("mnc_pack_conv_weights", dev.put(w), d_w, Cout, Cin, K, K)
+    d_y = dev.empty((Cout * OH * OW,), fill=np.nan)
+    dev.call("mnc_conv2d", dev.put(to_c8(x)), d_w, dev.put(b), dev.put(to_c8(res)) if residual else None, d_y, H, W, Cin, Cout,
+             K, K, stride, pad, relu)
+    got = from_c8(dev.get(d_y, (Cout * OH * OW,)), Cout, OH, OW)
+    assert not np.isnan(got).any()
+    d, rel = err(got, want)
+    assert rel < 1e-4, (d, rel)
+
+
+@pytest.mark.parametrize("H,W,K,stride,pad", [(75, 101, 7, 2, 3), (64, 64, 7, 2, 3), (31, 45, 3, 1, 1)])
+def test_conv_stem_c3(dev, H, W, K, stride, pad):
+    rng = np.random.default_rng(H + W)
+    x = rng.uniform(-120, 130, (3, H, W)).astype(np.float32)
+    w = (rng.normal(size=(64, 3, K, K)) * 0.01).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    want = F.relu(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=pad))[0].numpy()
+    OH, OW = want.shape[1:]
+    d_y = dev.empty((64 * OH * OW,), fill=np.nan)
+    dev.call("mnc_conv_stem_c3", dev.put(x), dev.put(w), dev.put(b), d_y, H, W, 64, K, stride, pad, 1)
+    got = from_c8(dev.get(d_y, (64 * OH * OW,)), 64, OH, OW)
+    assert err(got, want)[1] < 1e-5
+
+
+@pytest.mark.parametrize("H,W,K,stride,pad", [(112, 112, 3, 2, 0), (100, 167, 3, 2, 0), (101, 166, 3, 2, 1), (37, 41, 2, 2, 0)])
+def test_maxpool_general_and_add(dev, H, W, K, stride, pad):
+    rng = np.random.default_rng(H)
+    x = rng.normal(size=(16, H, W)).astype(np.float32)
+    want = F.max_pool2d(torch.from_numpy(x)[None], K, stride, pad, ceil_mode=True)[0].numpy()      # Caffe's pooling size rule
+    OH, OW = want.shape[1:]
+    d_y = dev.empty((16 * OH * OW,), fill=np.nan)
+    dev.call("mnc_maxpool_c8", dev.put(to_c8(x)), d_y, 16, H, W, K, stride, pad)
+    assert np.array_equal(from_c8(dev.get(d_y, (16 * OH * OW,)), 16, OH, OW), want)
+    a, b = rng.normal(size=1003).astype(np.float32), rng.normal(size=1003).astype(np.float32)
+    for relu in (0, 1):
+        d_o = dev.empty((1003,), fill=np.nan)
+        dev.call("mnc_add", dev.put(a), dev.put(b), d_o, 1003, relu)
+        assert np.array_equal(dev.get(d_o, (1003,)), np.maximum(a + b, 0) if relu else a + b)
+
+
 def _rois(rng, R, W, H):
     b = GI._boxes(rng, R, W, H, 8, 500)
     b[0] = [0, 0, W - 1, H - 1]                  # whole image
