@@ -286,6 +286,9 @@ class _Layer(object):
         self.out_name = None       # blob written when a fusion redirects the output
         self.group = None          # [layers] of a merged sibling-InnerProduct GEMM (this layer is the leader)
         self.group_leader = None   # set on the followers of such a group
+        self.bn = None             # BatchNorm / Scale layers folded into this Convolution's weights and bias
+        self.scale = None
+        self.residual = None       # blob added in this Convolution's epilogue (a following Eltwise SUM folded in)
         self.run = None
 
 
@@ -388,7 +391,10 @@ class Net(object):
                 out[k] = [None if a is None else np.asarray(a, dtype=F32) for a in v]
             else:
                 lname, idx = k.rsplit("/", 1)
-                out.setdefault(lname, [None, None])[int(idx)] = np.asarray(v, dtype=F32)
+                lst = out.setdefault(lname, [None, None])
+                while len(lst) <= int(idx):
+                    lst.append(None)
+                lst[int(idx)] = np.asarray(v, dtype=F32)
         return out
 
     def _layer_weights(self, L):
@@ -424,9 +430,21 @@ class Net(object):
         for L in self._layers:
             if L.type == "ReLU" and L.bottoms == L.tops:
                 prod = by_top.get(L.bottoms[0])
-                if prod is not None and prod.type in ("Convolution", "InnerProduct"):
+                if prod is not None and prod.type in ("Convolution", "InnerProduct", "Eltwise"):
                     prod.relu = True
                     L.skip = True          # always folded: an in-place ReLU has no blob of its own
+            elif L.type in ("BatchNorm", "Scale") and L.bottoms == L.tops:
+                # conv -> BatchNorm(use_global_stats) -> Scale, all in place (the ResNet idiom): an affine map per output
+                # channel, folded into the convolution's weights and bias when they are uploaded.  Always folded -- there
+                # is no stand-alone kernel for them.
+                prod = by_top.get(L.bottoms[0])
+                ok = prod is not None and prod.type == "Convolution" and not prod.relu and prod.residual is None
+                if ok and L.type == "BatchNorm" and prod.bn is None and prod.scale is None:
+                    prod.bn, L.skip = L, True
+                elif ok and L.type == "Scale" and prod.scale is None:
+                    prod.scale, L.skip = L, True
+                if L.skip:
+                    continue               # by_top keeps naming the convolution as the producer of this blob
             for t in L.tops:
                 by_top[t] = L
         if not self._fuse:
@@ -444,6 +462,23 @@ class Net(object):
                         if rp.get1("pooled_h") % 2 or rp.get1("pooled_w") % 2:
                             continue
                     L.fused_pool, L.out_name, nxt.skip = True, nxt.tops[0], True
+        # residual add folded into the epilogue of the general convolution that produces its second operand:
+        # Eltwise SUM (x, conv(...)) [+ ReLU] -> conv writes relu(conv + bias + x) straight into the Eltwise's top
+        index = {id(L): i for i, L in enumerate(self._layers)}
+        producer = {}
+        for L in self._layers:
+            if not L.skip:
+                for t in L.tops:
+                    producer.setdefault(t, L)
+        for L in self._layers:
+            if L.type != "Eltwise" or len(L.bottoms) != 2 or self._eltwise_op(L) != "SUM":
+                continue
+            x, y = L.bottoms
+            conv = producer.get(y)
+            if (conv is not None and conv.type == "Convolution" and self._conv_is_general(conv) and not conv.relu
+                    and conv.residual is None and self._consumers.get(y, []) == [index[id(L)]] and y not in self.outputs
+                    and x in producer and index[id(producer[x])] < index[id(conv)]):
+                conv.residual, conv.out_name, conv.relu, L.skip = x, L.tops[0], L.relu, True
         # sibling InnerProducts on the same bottom without activation (cls_score / seg_cls_score / bbox_pred,
         # test.prototxt:713-785) become ONE GEMM over the concatenated weights; their tops are column slices of it
         by_bottom = {}
@@ -455,6 +490,41 @@ class Net(object):
                 members[0].group = members
                 for m in members[1:]:
                     m.group_leader = members[0]
+
+    @staticmethod
+    def _eltwise_op(L):
+        ep = L.msg.get1("eltwise_param")
+        op = ep.get1("operation", "SUM") if ep is not None else "SUM"
+        if ep is not None and ep.all("coeff"):
+            return "COEFF"
+        return {1: "SUM", 0: "PROD", 2: "MAX"}.get(op, op)
+
+    @staticmethod
+    def _conv_geometry(L):
+        cp = L.msg.get1("convolution_param")
+        return cp.get1("kernel_size"), cp.get1("pad", 0), cp.get1("stride", 1), cp.get1("num_output"), cp.get1("bias_term", True)
+
+    def _conv_kind(self, L):
+        """Which kernel family runs this Convolution: 'c3' / 'stem' (3-channel NCHW input blob), 'fast3x3' (the tuned 3x3 pad 1
+        stride 1 kernels), 'nchw1x1' (the RPN's 1x1 heads, which feed Reshape / Python layers in NCHW) or 'general' (mnc_conv2d)."""
+        k, pad, stride, cout, _ = self._conv_geometry(L)
+        first = L.bottoms[0] in self.inputs
+        if first:
+            return "c3" if (k == 3 and pad == 1 and stride == 1) else "stem"
+        if k == 3 and pad == 1 and stride == 1 and cout % 32 == 0 and L.residual is None:
+            return "fast3x3"
+        if k == 1 and pad == 0 and stride == 1 and not L.relu and L.bn is None and L.scale is None and L.residual is None \
+                and self._rpn_head_conv(L):
+            return "nchw1x1"
+        return "general"
+
+    def _conv_is_general(self, L):
+        return self._conv_kind(L) == "general"
+
+    def _rpn_head_conv(self, L):
+        """1x1 convolutions whose consumers want NCHW (Reshape / Python layers): rpn_cls_score, rpn_bbox_pred."""
+        cons = [self._layers[i].type for i in self._consumers.get(L.tops[0], [])]
+        return bool(cons) and all(t in ("Reshape", "Python", "Softmax") for t in cons)
 
     @staticmethod
     def _is_pool2(L):
@@ -476,18 +546,46 @@ class Net(object):
     def _h(self):
         return self._ctx.h
 
+    def _folded_conv_params(self, L):
+        """(W, b) of a Convolution with its in-place BatchNorm (use_global_stats: mean / var / moving-average factor blobs) and
+        Scale (gamma, beta) folded in: y = gamma * (conv(x) + b - mean) / sqrt(var + eps) + beta.  Folded in float64."""
+        _, _, _, cout, _ = self._conv_geometry(L)
+        blobs = self._layer_weights(L)
+        W = np.asarray(blobs[0], dtype=F32)
+        b = np.asarray(blobs[1], dtype=F32) if len(blobs) > 1 and blobs[1] is not None else np.zeros(cout, F32)
+        self.params[L.name] = [_Param(W), _Param(b)] if len(blobs) > 1 and blobs[1] is not None else [_Param(W)]
+        if L.bn is None and L.scale is None:
+            return W, b
+        a, c = np.ones(cout, np.float64), np.zeros(cout, np.float64)       # y = a * conv_out + c, per channel
+        if L.bn is not None:
+            mean, var, factor = [np.asarray(x, dtype=np.float64) for x in self._layer_weights(L.bn)[:3]]
+            bp = L.bn.msg.get1("batch_norm_param")
+            eps = float(bp.get1("eps", 1e-5)) if bp is not None else 1e-5
+            f = float(factor.reshape(-1)[0])
+            inv = 0.0 if f == 0.0 else 1.0 / f
+            a = 1.0 / np.sqrt(var.reshape(-1) * inv + eps)
+            c = -mean.reshape(-1) * inv * a
+            self.params[L.bn.name] = [_Param(np.asarray(x, dtype=F32)) for x in self._layer_weights(L.bn)[:3]]
+        if L.scale is not None:
+            sw = self._layer_weights(L.scale)
+            gamma = np.asarray(sw[0], dtype=np.float64).reshape(-1)
+            beta = np.asarray(sw[1], dtype=np.float64).reshape(-1) if len(sw) > 1 and sw[1] is not None else np.zeros(cout)
+            a, c = a * gamma, c * gamma + beta
+            self.params[L.scale.name] = [_Param(np.asarray(x, dtype=F32)) for x in sw if x is not None]
+        Wf = (W.astype(np.float64) * a[:, None, None, None]).astype(F32)
+        bf = (b.astype(np.float64) * a + c).astype(F32)
+        return Wf, bf
+
     def _bind_Convolution(self, L, i):
-        cp = L.msg.get1("convolution_param")
-        k, pad, stride = cp.get1("kernel_size"), cp.get1("pad", 0), cp.get1("stride", 1)
-        cout = cp.get1("num_output")
-        W, b = self._layer_weights(L)
-        self.params[L.name] = [_Param(W), _Param(b)]
+        k, pad, stride, cout, _ = self._conv_geometry(L)
+        kind = self._conv_kind(L)
+        W, b = self._folded_conv_params(L)
         cin = W.shape[1]
         key = tuple(L.param_names) if all(L.param_names) and L.param_names else (L.name,)
         d_b = self._dev_param(key + ("b",), lambda: self._upload(b))
-        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+        bot, top = self.blobs[L.bottoms[0]], self.blobs[L.out_name or L.tops[0]]
         relu = 1 if L.relu else 0
-        if k == 3 and pad == 1 and stride == 1 and cin == 3:
+        if kind == "c3":
             d_w = self._dev_param(key + ("w",), lambda: self._upload(W))
 
             def run():
@@ -499,7 +597,22 @@ class Net(object):
                     _lib.call("mnc_conv3x3_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4,
                               H, Wd, cout, relu)
             return run
-        if k == 3 and pad == 1 and stride == 1:
+        if kind == "stem":
+            if cin != 3 or W.shape[2] != W.shape[3]:
+                raise NotImplementedError("Convolution %s on the input blob: 3 channels, square kernel" % L.name)
+            d_w = self._dev_param(key + ("w",), lambda: self._upload(W))
+
+            def run():
+                N, _, H, Wd = bot.shape
+                OH, OW = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
+                src = bot.dev_in("plain")
+                top.reshape(N, cout, OH, OW)
+                dst = top.dev_out("c8")
+                for n in range(N):
+                    _lib.call("mnc_conv_stem_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * OH * OW * 4,
+                              H, Wd, cout, k, stride, pad, relu)
+            return run
+        if kind == "fast3x3":
             x3 = self.math == "bf16x3"
             pitch, pack, conv = (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
                                 (76, "mnc_pack_conv3x3_weights", "mnc_conv3x3")
@@ -521,7 +634,7 @@ class Net(object):
                     _lib.call(conv, self._h(), src + n * cin * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4, H, Wd, cin,
                               cout, relu)
             return run
-        if k == 1 and pad == 0 and stride == 1 and not L.relu:
+        if kind == "nchw1x1":
             d_w = self._dev_param(key + ("w",), lambda: self._upload(W.reshape(cout, cin)))
 
             def run():
@@ -533,7 +646,35 @@ class Net(object):
                     _lib.call("mnc_conv1x1_to_nchw", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
                               dst + n * cout * H * Wd * 4, H, Wd, cin, cout)
             return run
-        raise NotImplementedError("Convolution %s: kernel %r pad %r stride %r" % (L.name, k, pad, stride))
+        # general: any kernel / stride / pad on the fp32 matrix pipe (both math modes), residual add and ReLU in the epilogue
+        if cin % 8 or cout % 8:
+            raise NotImplementedError("Convolution %s: channel counts must be multiples of 8 (got %d -> %d)" % (L.name, cin, cout))
+        kh, kw = W.shape[2], W.shape[3]
+
+        def build_general():
+            raw = self._upload(W)
+            packed = self._ctx.alloc(W.nbytes)
+            _lib.call("mnc_pack_conv_weights", self._h(), raw, packed, cout, cin, kh, kw)
+            self._ctx.free(raw)
+            return packed
+        d_w = self._dev_param(key + ("w", "general"), build_general)
+        res = self.blobs[L.residual] if L.residual else None
+
+        def run():
+            N, _, H, Wd = bot.shape
+            OH, OW = (H + 2 * pad - kh) // stride + 1, (Wd + 2 * pad - kw) // stride + 1
+            src = bot.dev_in("c8")
+            rsrc = res.dev_in("c8") if res is not None else None
+            if res is not None and tuple(res.shape) != (N, cout, OH, OW):
+                raise ValueError("Convolution %s: residual %r has shape %r, expected %r" % (L.name, res.name, res.shape,
+                                                                                            (N, cout, OH, OW)))
+            top.reshape(N, cout, OH, OW)
+            dst = top.dev_out("c8")
+            for n in range(N):
+                _lib.call("mnc_conv2d", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
+                          (rsrc + n * cout * OH * OW * 4) if rsrc is not None else None, dst + n * cout * OH * OW * 4, H, Wd, cin,
+                          cout, kh, kw, stride, pad, relu)
+        return run
 
     def _bind_ReLU(self, L, i):
         raise NotImplementedError("stand-alone ReLU %s (only in-place ReLU after Convolution/InnerProduct)" % L.name)
@@ -555,9 +696,27 @@ class Net(object):
         return run
 
     def _bind_Pooling(self, L, i):
-        if not self._is_pool2(L):
-            raise NotImplementedError("Pooling %s: only MAX 2x2 stride 2 pad 0" % L.name)
         bot, top = self.blobs[L.bottoms[0]], self.blobs[L.tops[0]]
+        if not self._is_pool2(L):
+            p = L.msg.get1("pooling_param")
+            if p.get1("pool", "MAX") != "MAX":
+                raise NotImplementedError("Pooling %s: only MAX" % L.name)
+            k, stride, pad = p.get1("kernel_size"), p.get1("stride", 1), p.get1("pad", 0)
+
+            def out_size(n):                       # Caffe: ceil, and the last window must start inside the image
+                o = -(-(n + 2 * pad - k) // stride) + 1
+                return o - 1 if pad > 0 and (o - 1) * stride >= n + pad else o
+
+            def run_general():
+                N, C, H, W = bot.shape
+                src = bot.dev_in("c8")
+                OH, OW = out_size(H), out_size(W)
+                top.reshape(N, C, OH, OW)
+                dst = top.dev_out("c8")
+                for n in range(N):
+                    _lib.call("mnc_maxpool_c8", self._h(), src + n * C * H * W * 4, dst + n * C * OH * OW * 4, C, H, W, k, stride,
+                              pad)
+            return run_general
 
         def run():
             if bot._dev_valid and bot.layout == "c8":
@@ -576,6 +735,23 @@ class Net(object):
                     _lib.call("mnc_maxpool2_rhwc", self._h(), src, top.dev_out("rhwc"), R, PH, PW, C)
                 else:
                     top.dev_out("rhwc")
+        return run
+
+    def _bind_Eltwise(self, L, i):
+        """Eltwise SUM of two feature maps (+ folded in-place ReLU): ResNet's residual add when it was not folded into the
+        producing convolution."""
+        if self._eltwise_op(L) != "SUM" or len(L.bottoms) != 2:
+            raise NotImplementedError("Eltwise %s: only SUM of two bottoms without coefficients" % L.name)
+        a, b, top = self.blobs[L.bottoms[0]], self.blobs[L.bottoms[1]], self.blobs[L.tops[0]]
+        relu = 1 if L.relu else 0
+
+        def run():
+            if tuple(a.shape) != tuple(b.shape):
+                raise ValueError("Eltwise %s: shapes %r and %r differ" % (L.name, a.shape, b.shape))
+            layout = "c8" if len(a.shape) == 4 and a.shape[1] % 8 == 0 and (a._dev_valid and a.layout == "c8") else "plain"
+            pa, pb = a.dev_in(layout), b.dev_in(layout)
+            top.reshape(*a.shape)
+            _lib.call("mnc_add", self._h(), pa, pb, top.dev_out(layout), a.count, relu)
         return run
 
     def _bind_Reshape(self, L, i):

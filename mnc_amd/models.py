@@ -40,9 +40,10 @@ class _Emit(object):
         return "\n".join(self.lines) + "\n"
 
 
-def _conv(e, name, bottom, top, n_out, k, pad):
+def _conv(e, name, bottom, top, n_out, k, pad, stride=1, bias=True):
     e.layer(name, "Convolution", [bottom], [top],
-            "convolution_param { num_output: %d kernel_size: %d pad: %d stride: 1 }" % (n_out, k, pad))
+            "convolution_param { num_output: %d kernel_size: %d pad: %d stride: %d%s }"
+            % (n_out, k, pad, stride, "" if bias else " bias_term: false"))
 
 
 def _relu(e, name, blob):
@@ -58,16 +59,16 @@ def _fc(e, name, bottom, top, n_out, pname=None):
             params=[pname + "_w", pname + "_b"] if pname else None)
 
 
-def _head(e, sfx, rois, warp_direct, d=1):
+def _head(e, sfx, rois, warp_direct, d=1, trunk_top="conv5_3"):
     """Stages 2+3 (sfx '') or 4+5 (sfx '_ext'): mask estimation + box/mask classification on `rois`."""
     wide, narrow = 4096 // d, max(256 // d, 32)
     feat = "roi_interpolate_conv5" + sfx
     if warp_direct:
-        e.layer(feat, "ROIWarping", ["conv5_3", rois], [feat],
+        e.layer(feat, "ROIWarping", [trunk_top, rois], [feat],
                 "roi_warping_param { pooled_w: 14 pooled_h: 14 spatial_scale: 0.0625 }")
     else:
         pre = "roi_interpolate_conv5_premax" + sfx
-        e.layer(pre, "ROIWarping", ["conv5_3", rois], [pre],
+        e.layer(pre, "ROIWarping", [trunk_top, rois], [pre],
                 "roi_warping_param { pooled_w: 28 pooled_h: 28 spatial_scale: 0.0625 }")
         _pool(e, feat, pre, feat)
     _fc(e, "fc6_maskest" + sfx, feat, "fc6_maskest" + sfx, narrow, "fc6_maskest")
@@ -121,7 +122,14 @@ def _trunk_rpn_proposal(width_div):
     e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
     e.raw('input: "im_info"\ninput_shape { dim: 1 dim: 3 }')
     _trunk(e, d)
-    _conv(e, "rpn_conv_3x3", "conv5_3", "rpn_output", max(512 // d, 32), 3, 1)
+    _rpn_proposal(e, d, "conv5_3")
+    return e, d
+
+
+def _rpn_proposal(e, d, trunk_top):
+    """RPN head on the trunk's top (test.prototxt:391-475): 3x3 conv + ReLU, the two 1x1 heads, 2-way softmax via Reshape,
+    ProposalLayer."""
+    _conv(e, "rpn_conv_3x3", trunk_top, "rpn_output", max(512 // d, 32), 3, 1)
     _relu(e, "rpn_relu_3x3", "rpn_output")
     _conv(e, "rpn_cls_score", "rpn_output", "rpn_cls_score", 18, 1, 0)
     _conv(e, "rpn_bbox_pred", "rpn_output", "rpn_bbox_pred", 36, 1, 0)
@@ -133,7 +141,6 @@ def _trunk_rpn_proposal(width_div):
     e.layer("proposal", "Python", ["rpn_cls_prob_reshape", "rpn_bbox_pred", "im_info"], ["rois"],
             "python_param { module: 'pylayer.proposal_layer' layer: 'ProposalLayer' "
             "param_str: \"{'feat_stride': 16, 'gradient_scale': 1}\" }")
-    return e, d
 
 
 def mnc_5stage_test_prototxt(width_div=1):
@@ -208,6 +215,71 @@ def cfm_test_prototxt(width_div=1):
 
 def write_cfm_test_prototxt(path=None, width_div=1):
     return _write(cfm_test_prototxt(width_div), path, "cfm_test_w%d.prototxt" % width_div)
+
+
+RESNET50_STAGES = [(2, 3, 64, 1), (3, 4, 128, 2), (4, 6, 256, 2)]          # (stage, blocks, bottleneck width, first stride): C4
+
+
+def _bn_scale_relu(e, tag, blob, relu=True):
+    """conv -> BatchNorm(use_global_stats) -> Scale(bias) [-> ReLU], all in place: the ResNet deploy idiom."""
+    e.layer("bn" + tag, "BatchNorm", [blob], [blob], "batch_norm_param { use_global_stats: true }")
+    e.layer("scale" + tag, "Scale", [blob], [blob], "scale_param { bias_term: true }")
+    if relu:
+        _relu(e, blob + "_relu", blob)
+
+
+def _resnet50_c4(e, d):
+    """ResNet-50 conv1 .. res4f in the layout of the public ResNet-50-deploy.prototxt (He et al.): 7x7/2 stem + BN/Scale/ReLU,
+    MAX 3x3/2, bottleneck blocks res{2,3,4}{a..} with the stride on branch1 / branch2a of each stage's first block, no conv
+    biases, Eltwise SUM + ReLU.  Output `res4f`: 1024 // d channels at stride 16 -- the role conv5_3 plays for VGG-16."""
+    _conv(e, "conv1", "data", "conv1", max(64 // d, 16), 7, 3, stride=2)
+    _bn_scale_relu(e, "_conv1", "conv1")
+    e.layer("pool1", "Pooling", ["conv1"], ["pool1"], "pooling_param { pool: MAX kernel_size: 3 stride: 2 }")
+    prev = "pool1"
+    for stage, blocks, width, first_stride in RESNET50_STAGES:
+        mid, wide = max(width // d, 8), max(4 * width // d, 32)
+        for bi in range(blocks):
+            tag = "%d%s" % (stage, "abcdef"[bi])
+            stride = first_stride if bi == 0 else 1
+            if bi == 0:
+                _conv(e, "res%s_branch1" % tag, prev, "res%s_branch1" % tag, wide, 1, 0, stride, bias=False)
+                _bn_scale_relu(e, "%s_branch1" % tag, "res%s_branch1" % tag, relu=False)
+                shortcut = "res%s_branch1" % tag
+            else:
+                shortcut = prev
+            a, b, c = ("res%s_branch2%s" % (tag, x) for x in "abc")
+            _conv(e, a, prev, a, mid, 1, 0, stride, bias=False)
+            _bn_scale_relu(e, "%s_branch2a" % tag, a)
+            _conv(e, b, a, b, mid, 3, 1, 1, bias=False)
+            _bn_scale_relu(e, "%s_branch2b" % tag, b)
+            _conv(e, c, b, c, wide, 1, 0, 1, bias=False)
+            _bn_scale_relu(e, "%s_branch2c" % tag, c, relu=False)
+            e.layer("res" + tag, "Eltwise", [shortcut, c], ["res" + tag])
+            _relu(e, "res%s_relu" % tag, "res" + tag)
+            prev = "res" + tag
+    return prev
+
+
+def mnc_resnet50_test_prototxt(width_div=1):
+    """The 5-stage MNC test graph on a ResNet-50 C4 trunk (BASELINE.json configs[4]).  The reference
+    ships only VGG-16 models: this graph is this project's own composition -- the public ResNet-50 deploy trunk up to res4f
+    (stride 16, 1024 channels) in place of conv1_1..conv5_3, then the reference's RPN and cascade heads unchanged
+    (`_rpn_proposal`, `_head`: same layer names, shared-parameter names and Python layers as mnc_5stage/test.prototxt)."""
+    d = width_div
+    e = _Emit("ResNet50")
+    e.raw('input: "data"\ninput_shape { dim: 1 dim: 3 dim: 224 dim: 224 }')
+    e.raw('input: "im_info"\ninput_shape { dim: 1 dim: 3 }')
+    top = _resnet50_c4(e, d)
+    _rpn_proposal(e, d, top)
+    _head(e, "", "rois", False, d, trunk_top=top)
+    e.layer("stage_bridge", "Python", ["rois", "bbox_pred", "seg_cls_prob", "im_info"], ["rois_ext"],
+            "python_param { module: 'pylayer.stage_bridge_layer' layer: 'StageBridgeLayer' }")
+    _head(e, "_ext", "rois_ext", True, d, trunk_top=top)
+    return e.text()
+
+
+def write_mnc_resnet50_test_prototxt(path=None, width_div=1):
+    return _write(mnc_resnet50_test_prototxt(width_div), path, "mnc_resnet50_test_w%d.prototxt" % width_div)
 
 
 def write_faster_rcnn_end2end_test_prototxt(path=None, width_div=1):

@@ -29,7 +29,13 @@ def layer_shapes(prototxt_path):
             cin, cout, k = geo[bots[0]][0], cp.get1("num_output"), cp.get1("kernel_size")
             geo[tops[0]] = (cout,)
             if not shared:
-                out.append((name, "conv", (cout, cin, k, k), (cout,)))
+                out.append((name, "conv", (cout, cin, k, k), (cout,) if cp.get1("bias_term", True) else None))
+        elif typ in ("BatchNorm", "Scale"):
+            c = geo[bots[0]][0]
+            geo[tops[0]] = geo[bots[0]]
+            out.append((name, "bn" if typ == "BatchNorm" else "scale", (c,), (c,)))
+        elif typ == "Eltwise":
+            geo[tops[0]] = geo[bots[0]]
         elif typ == "InnerProduct":
             n = L.get1("inner_product_param").get1("num_output")
             k = int(np.prod(geo[bots[0]]))
@@ -82,17 +88,29 @@ def _fill(flat, std, seed, layer_idx, pool):
 
 
 def synthetic_weights(prototxt_path, seed=0):
-    """{layer: [W float32, b float32]} in Caffe layout (conv OIHW, fc [N][K] with (c,h,w) column order)."""
+    """{layer: [W float32, b float32]} in Caffe layout (conv OIHW, fc [N][K] with (c,h,w) column order); a convolution with
+    `bias_term: false` gets [W]; BatchNorm gets Caffe's three blobs [mean, variance, moving-average factor] and Scale
+    [gamma, beta], with statistics that keep the activations O(1) through a residual trunk."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     weights = {}
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
         for idx, (name, kind, wshape, bshape) in enumerate(layer_shapes(prototxt_path)):
+            if kind in ("bn", "scale"):
+                g = np.random.default_rng(np.random.SeedSequence(entropy=seed, spawn_key=(idx, 0)))
+                c = wshape[0]
+                if kind == "bn":          # stored un-normalised, as Caffe does: statistic * factor
+                    factor = np.float32(2.0)
+                    weights[name] = [(g.normal(0, 0.2, c) * factor).astype(np.float32),
+                                     (g.uniform(0.6, 1.6, c) * factor).astype(np.float32), np.array([factor], np.float32)]
+                else:
+                    weights[name] = [g.uniform(0.4, 0.9, c).astype(np.float32), g.normal(0, 0.1, c).astype(np.float32)]
+                continue
             fan_in = int(np.prod(wshape[1:]))
             std = SMALL_STD.get(name, float(np.sqrt(2.0 / fan_in)))
             if idx == 0:
                 std /= PIXEL_STD
             w = np.empty(wshape, dtype=np.float32)
             _fill(w.reshape(-1), std, seed, idx, pool)
-            weights[name] = [w, np.zeros(bshape, dtype=np.float32)]
+            weights[name] = [w, np.zeros(bshape, dtype=np.float32)] if bshape is not None else [w]
     return weights

@@ -189,3 +189,64 @@ def forward_cfm(weights, data, rois, masks, blobs=None):
                  cls_prob=F.softmax(cls, dim=1).numpy(), seg_cls_prob=F.softmax(seg, dim=1).numpy(),
                  bbox_pred=_fc(join, weights["bbox_pred"]).numpy())
     return blobs
+
+
+# ---- ResNet-50 C4 trunk (BASELINE configs[4]).  No such model exists in the reference repository: the graph is
+# the public ResNet-50 deploy definition (He et al.), evaluated layer by layer with public BVLC Caffe semantics --
+# Convolution without bias, BatchNorm with use_global_stats (blobs: mean, variance, moving-average factor; eps 1e-5), Scale
+# with bias, ReLU, MAX pooling 3x3/2 with Caffe's ceil output size, Eltwise SUM.  Nothing is folded here. ----
+RESNET50_STAGES = [(2, 3, 2, 1), (3, 4, 3, 2), (4, 6, 4, 2)]          # (stage, blocks, -, first stride)
+
+
+def _bn_scale(x, weights, tag, eps=1e-5):
+    mean, var, factor = [_t(a) for a in weights["bn" + tag][:3]]
+    f = float(factor.reshape(-1)[0])
+    inv = 0.0 if f == 0.0 else 1.0 / f
+    y = F.batch_norm(x, mean * inv, var * inv, None, None, False, 0.0, eps)
+    gamma, beta = [_t(a) for a in weights["scale" + tag][:2]]
+    return y * gamma[None, :, None, None] + beta[None, :, None, None]
+
+
+def trunk_resnet50(weights, data, blobs=None):
+    """data [N,3,H,W] -> res4f; records every block output (and conv1 / pool1) in `blobs`."""
+    torch.set_grad_enabled(False)
+    blobs = {} if blobs is None else blobs
+
+    def conv(name, x, stride, pad):
+        wb = weights[name]
+        return F.conv2d(x, _t(wb[0]), _t(wb[1]) if len(wb) > 1 and wb[1] is not None else None, stride=stride, padding=pad)
+
+    x = F.relu(_bn_scale(conv("conv1", _t(data), 2, 3), weights, "_conv1"))
+    blobs["conv1"] = x.numpy()
+    x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+    blobs["pool1"] = x.numpy()
+    for stage, nblocks, _, first_stride in RESNET50_STAGES:
+        for bi in range(nblocks):
+            tag = "%d%s" % (stage, "abcdef"[bi])
+            stride = first_stride if bi == 0 else 1
+            shortcut = x
+            if bi == 0:
+                shortcut = _bn_scale(conv("res%s_branch1" % tag, x, stride, 0), weights, "%s_branch1" % tag)
+                blobs["res%s_branch1" % tag] = shortcut.numpy()
+            y = F.relu(_bn_scale(conv("res%s_branch2a" % tag, x, stride, 0), weights, "%s_branch2a" % tag))
+            blobs["res%s_branch2a" % tag] = y.numpy()
+            y = F.relu(_bn_scale(conv("res%s_branch2b" % tag, y, 1, 1), weights, "%s_branch2b" % tag))
+            blobs["res%s_branch2b" % tag] = y.numpy()
+            y = _bn_scale(conv("res%s_branch2c" % tag, y, 1, 0), weights, "%s_branch2c" % tag)
+            x = F.relu(shortcut + y)
+            blobs["res" + tag] = x.numpy()
+    return x
+
+
+def forward_resnet50(weights, data, im_info, blobs=None, nms_fn=None):
+    """net.forward() of models.mnc_resnet50_test_prototxt: the ResNet-50 C4 trunk, then the reference's RPN and cascade."""
+    blobs = {} if blobs is None else blobs
+    c4 = trunk_resnet50(weights, data, blobs)
+    prob, bbox = rpn(weights, c4, blobs)
+    rois = host.proposal_forward(prob, bbox, im_info, nms_fn)
+    blobs["rois"] = rois
+    head(weights, c4, rois, False, "", blobs)
+    rois_ext = host.stage_bridge_forward_test(rois, blobs["bbox_pred"], blobs["seg_cls_prob"], im_info)
+    blobs["rois_ext"] = rois_ext
+    head(weights, c4, rois_ext, True, "_ext", blobs)
+    return blobs

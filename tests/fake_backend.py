@@ -166,6 +166,35 @@ class Fake(object):
             out = native.roi_warp(f, r, PH, PW, scale)
         _f(dst, (R, PH, PW, C))[...] = out.transpose(0, 2, 3, 1)
 
+    def mnc_pack_conv_weights(self, h, src, dst, Cout, Cin, KH, KW):
+        w = _f(src, (Cout, Cin // 8, 8, KH * KW))
+        _f(dst, (KH * KW, Cin // 8, Cout, 8))[...] = w.transpose(3, 1, 0, 2)
+
+    def mnc_conv2d(self, h, src, wpk, b, res, dst, H, W, Cin, Cout, KH, KW, stride, pad, relu):
+        w = _f(wpk, (KH * KW, Cin // 8, Cout, 8)).transpose(2, 1, 3, 0).reshape(Cout, Cin, KH, KW)
+        x = _t(_unc8(_f(src, (Cin // 8, H, W, 8))))[None]
+        y = F.conv2d(x, _t(w), _t(_f(b, (Cout,))), stride=stride, padding=pad)[0]
+        OH, OW = y.shape[1:]
+        if res:
+            y = y + _t(_unc8(_f(res, (Cout // 8, OH, OW, 8))))
+        if relu:
+            y = F.relu(y)
+        _f(dst, (Cout // 8, OH, OW, 8))[...] = _c8(y.numpy())
+
+    def mnc_conv_stem_c3(self, h, src, w, b, dst, H, W, Cout, K, stride, pad, relu):
+        y = F.conv2d(_t(_f(src, (1, 3, H, W))), _t(_f(w, (Cout, 3, K, K))), _t(_f(b, (Cout,))), stride=stride, padding=pad)[0]
+        if relu:
+            y = F.relu(y)
+        _f(dst, (Cout // 8,) + tuple(y.shape[1:]) + (8,))[...] = _c8(y.numpy())
+
+    def mnc_maxpool_c8(self, h, src, dst, C, H, W, K, stride, pad):
+        y = F.max_pool2d(_t(_unc8(_f(src, (C // 8, H, W, 8))))[None], K, stride, pad, ceil_mode=True)[0].numpy()
+        _f(dst, (C // 8,) + y.shape[1:] + (8,))[...] = _c8(y)
+
+    def mnc_add(self, h, a, b, dst, n, relu):
+        y = _f(a, (n,)) + _f(b, (n,))
+        _f(dst, (n,))[...] = np.maximum(y, 0) if relu else y
+
     def mnc_prep_image(self, h, im, H, W, means, x0, ax, OW, y0, ay, OH, out, PH, PW):
         img = np.ctypeslib.as_array((ctypes.c_ubyte * (H * W * 3)).from_address(int(im))).reshape(H, W, 3)
         m = np.ctypeslib.as_array((ctypes.c_double * 3).from_address(int(means)))

@@ -285,3 +285,39 @@ def test_device_image_prep_plumbing(fake_gpu):
     with pytest.raises(TypeError):
         net.prep_image(im.astype(np.float32), cfg.PIXEL_MEANS, [1.0])
     net.close()
+
+
+RESNET_BLOBS = ["conv1", "pool1", "res2a_branch1", "res2a_branch2a", "res2a_branch2b", "res2a", "res2c", "res3a", "res3d", "res4a",
+                "res4f", "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "roi_interpolate_conv5", "mask_proposal", "fc7",
+                "seg_cls_prob", "bbox_pred", "rois_ext", "mask_proposal_ext", "seg_cls_prob_ext"]
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_resnet50_graph_every_blob(fake_gpu, fuse):
+    """the 5-stage cascade on a ResNet-50 C4 trunk -- stem conv, BatchNorm/Scale folded into the convolutions,
+    strided 1x1 convolutions, MAX 3x3/2, residual adds (folded into branch2c's epilogue when fusing) -- blob by blob against the
+    unfolded oracle graph."""
+    from mnc_amd.engine import Net
+    path = models.write_mnc_resnet50_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=5)
+    net = Net(path, w, 1, device_id=0, fuse=fuse)
+    kinds = {L.name: net._conv_kind(L) for L in net._layers if L.type == "Convolution"}
+    assert kinds["conv1"] == "stem" and kinds["res2a_branch2a"] == "general" and kinds["rpn_conv_3x3"] == "fast3x3"
+    assert kinds["rpn_cls_score"] == "nchw1x1" and kinds["res3a_branch1"] == "general"
+    folded = [L for L in net._layers if L.type == "Convolution" and L.residual]
+    assert len(folded) == (13 if fuse else 0)          # 3 + 4 + 6 bottleneck blocks in C4
+    assert all(L.skip for L in net._layers if L.type in ("BatchNorm", "Scale"))
+    for seed, (H, W) in enumerate([(96, 160), (131, 203)]):
+        data, im_info = _inputs(H, W, seed)
+        net.blobs["data"].reshape(*data.shape)
+        net.forward(data=data, im_info=im_info)
+        ref = onet.forward_resnet50(w, data, im_info)
+        for n in RESNET_BLOBS:
+            b = net.blobs[n]
+            if not (b._dev_valid or b._host_valid):          # branch2c / shortcut blobs consumed inside a folded epilogue
+                continue
+            got, want = b.data, ref[n]
+            assert got.shape == want.shape, n
+            assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-6), n
+    assert [p.data.shape for p in net.params["bn_conv1"]] == [(16,), (16,), (1,)] and len(net.params["res2a_branch2a"]) == 1
+    net.close()

@@ -52,7 +52,7 @@ HEAD_BLOBS = ["roi_interpolate_conv5", "mask_output", "mask_proposal", "mask_pro
               "cls_prob", "seg_cls_prob", "bbox_pred", "roi_interpolate_conv5_premax", "roi_mask_conv5"]
 
 
-def check_forward(net, w, data, im_info, extra=()):
+def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None):
     """Parity protocol for one net.forward() that has already run on (data, im_info).
 
     The cascade has two data-dependent host hops (proposal NMS, stage bridge arg-max).  A 1e-7 difference upstream can
@@ -66,9 +66,9 @@ def check_forward(net, w, data, im_info, extra=()):
       4. rois_ext                      device == oracle StageBridge fed the device's blobs         (bit-exact)
       5. stage 4/5 blobs               device vs oracle head fed the device's rois_ext             (tolerance)"""
     ref = {}
-    c5 = onet.trunk(w, data, ref)
+    c5 = (trunk_fn or onet.trunk)(w, data, ref)
     onet.rpn(w, c5, ref)
-    _compare(net, ref, TRUNK_BLOBS)
+    _compare(net, ref, trunk_blobs or TRUNK_BLOBS)
     g = lambda n: net.blobs[n]._host_read()
     rois = g("rois")
     if net._native_py:
@@ -462,3 +462,27 @@ def test_device_image_prep_is_bit_identical_to_the_numpy_path(small):
     net.forward(data=np.asarray(dev).copy(), im_info=info)
     for k, v in a.items():
         assert np.array_equal(v, net.blobs[k]._host_read()), k
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_resnet50_trunk_graph(math, monkeypatch):
+    """SURVEY 8f n4 (BASELINE configs[4]): the cascade on a ResNet-50 C4 trunk (reduced width): stem, folded BatchNorm/Scale,
+    strided 1x1 convolutions, MAX 3x3/2 and the residual adds folded into branch2c -- every block output against the unfolded
+    oracle graph, then the same teacher-forced protocol as for VGG-16 (check_forward).  In bf16x3 mode the stride-1 3x3 layers
+    run on the split-bf16 kernels, everything else stays fp32."""
+    import caffe
+    monkeypatch.setenv("MNC_MATH", math)
+    path = models.write_mnc_resnet50_test_prototxt(width_div=4)
+    w = synth.synthetic_weights(path, seed=5)
+    net = caffe.Net(path, w, caffe.TEST)
+    try:
+        for seed, (H, W) in enumerate([(128, 200), (203, 157)]):
+            rng = np.random.default_rng(seed)
+            data = rng.uniform(-120, 130, (1, 3, H, W)).astype(np.float32)
+            im_info = np.array([[H, W, 1.0]], np.float32)
+            net.forward(data=data, im_info=im_info)
+            blobs = ["conv1", "pool1", "res2a_branch2b", "res2a", "res2c", "res3a", "res3d", "res4a", "res4c", "res4f", "rpn_output",
+                     "rpn_cls_prob_reshape", "rpn_bbox_pred"]
+            check_forward(net, w, data, im_info, trunk_fn=onet.trunk_resnet50, trunk_blobs=blobs)
+    finally:
+        net.close()

@@ -6,9 +6,12 @@ included (image preparation, forward, result hand-over) -- what bench.py's HBM-r
   --task cfm   TesterWrapper.cfm_network_forward with experiments/cfgs/VGG16/cfm.yml's test settings: 5-level pyramid
                480..1024 capped at 1500, levels grouped 3 + 2 per forward, 2000 MCG proposals in chunks of 2000 / 500 rois
 
+  --task resnet  the same seg body on the ResNet-50 C4 trunk graph (models.mnc_resnet50_test_prototxt; BASELINE configs[4]):
+               800x1333 image, 1000 proposals per stage (row n4 -- first correct path, general-convolution kernels untuned)
+
 Seeded synthetic weights, pixels and proposals.  Prints wall time per image and the per-kernel breakdown (HIP events).
 
-    python tools/task_bench.py --task seg|cfm [--iters 5] [--math fp32|bf16x3] [--host-prep]
+    python tools/task_bench.py --task seg|cfm|resnet [--iters 5] [--math fp32|bf16x3] [--host-prep]
 """
 import argparse
 import json
@@ -25,19 +28,26 @@ from mnc_amd import models, synth
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="cfm", choices=["seg", "cfm"])
+    ap.add_argument("--task", default="cfm", choices=["seg", "cfm", "resnet"])
     ap.add_argument("--host-prep", action="store_true", help="numpy image preparation (cfg.TEST.DEVICE_PREP = False)")
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--math", default=os.environ.get("MNC_MATH", "fp32"))
-    ap.add_argument("--height", type=int, default=375)
-    ap.add_argument("--width", type=int, default=500)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     args = ap.parse_args()
+    resnet = args.task == "resnet"
+    if resnet:
+        args.task = "seg"
+    args.height = args.height or (800 if resnet else 375)
+    args.width = args.width or (1333 if resnet else 500)
     os.environ["MNC_MATH"] = args.math
     import scipy.io
     from caffeWrapper.TesterWrapper import TesterWrapper
     from mnc_config import cfg
     cfg.TEST.DEVICE_PREP = not args.host_prep
+    if resnet:
+        cfg.TEST.SCALES, cfg.TRAIN.MAX_SIZE, cfg.TEST.RPN_POST_NMS_TOP_N = (800,), 1333, 1000
     if args.task == "cfm":
         cfg.TEST.SCALES, cfg.TEST.MAX_SIZE = [480, 576, 688, 864, 1024], 1500
         cfg.TEST.GROUP_SCALE, cfg.TEST.MAX_ROIS_GPU, cfg.TEST.USE_TOP_K_MCG = 3, [2000, 500], 2000
@@ -64,7 +74,8 @@ def main():
             def image_path_at(self, i):
                 return os.path.join(root, "im0.npy")
 
-        path = models.write_cfm_test_prototxt() if args.task == "cfm" else models.write_mnc_5stage_test_prototxt()
+        path = (models.write_cfm_test_prototxt() if args.task == "cfm" else
+                models.write_mnc_resnet50_test_prototxt() if resnet else models.write_mnc_5stage_test_prototxt())
         t0 = time.time()
         weights = synth.synthetic_weights(path, seed=0)
         t = TesterWrapper(path, Imdb(), weights, args.task)
@@ -110,7 +121,8 @@ def main():
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         dev_ms = sum(v[1] for v in agg.values())
         what = ("cfm vgg16 %dx%d, %d proposals, scales 480-1024 (3+2 levels/forward)" % (H, W, n) if args.task == "cfm" else
-                "mnc 5-stage vgg16 %dx%d image -> %s, 300 rois/stage, mask voting" % (H, W, "x".join(map(str, plan[0][1][2:]))))
+                "mnc 5-stage %s %dx%d image -> %s, %d rois/stage, mask voting"
+                % ("resnet50-c4" if resnet else "vgg16", H, W, "x".join(map(str, plan[0][1][2:])), cfg.TEST.RPN_POST_NMS_TOP_N))
         print(json.dumps({"workload": what, "math": args.math, "image_prep": "host" if args.host_prep else "device", "forwards": [{"start": c[0], "data": c[1], "rois": c[2]} for c in plan],
                           "ms_per_image_wall": round(min(times) * 1e3, 2), "ms_per_image_wall_median": round(sorted(times)[len(times) // 2] * 1e3, 2), "ms_per_image_kernels": round(dev_ms, 2),
                           "kernels": [{"name": k, "calls": v[0], "ms": round(v[1], 3),
