@@ -4,11 +4,12 @@
 //
 //   conv2d_c8_kernel   any KHxKW / stride / pad, c8 -> c8, fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32):
 //                      M = output channels (A = weights), N = output pixels (B = gathered input pixels), K = taps x Cin walked
-//                      one (tap, 8-channel block) at a time.  WG = 4 waves = 64 channels x 128 pixels, wave = 32 x 64.
-//                      There is no halo to reuse for 1x1 / strided taps, so each step stages exactly the 128 x 8 input values
-//                      and 64 x 8 weights it multiplies (global -> registers -> LDS, double-buffered, one barrier per step,
-//                      branch-free clamped + masked loads).  Each lane feeds its 4 of the 8 channels with one ds_read_b128
-//                      (pitch 12 floats: conflict-free).  Epilogue: + bias (+ residual) (+ ReLU), 16-byte stores.
+//                      one (tap, pair of 8-channel blocks) at a time.  WG = 4 waves = 64 channels x 128 pixels, wave = 32 x 64.
+//                      There is no halo to reuse for 1x1 / strided taps, so each step stages exactly the 128 x 16 input values
+//                      and 64 x 16 weights it multiplies -- one tap, two 8-channel blocks -- global -> registers -> LDS,
+//                      double-buffered, one barrier per step, branch-free clamped + masked loads.  Each lane feeds its 4 of
+//                      the 8 channels of a block with one ds_read_b128 (pitch 20 floats: conflict-free).  Epilogue: + bias
+//                      (+ residual) (+ ReLU), 16-byte stores.
 //   conv_stem_c3_kernel  KxK / stride / pad on the 3-channel NCHW input blob -> c8 (ResNet conv1 7x7/2): VALU, one output pixel
 //                      per thread, 16 output channels at a time with the weights broadcast from LDS.  HBM/L2-bound.
 //   maxpool_c8_kernel  Caffe MAX pooling with any kernel / stride / pad (ceil output size, windows clipped to the image).
@@ -23,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kGenCo = 64;      // output channels per workgroup
 constexpr int kGenPx = 128;     // output pixels per workgroup
-constexpr int kGenPitch = 12;   // floats per LDS row (8 data + 4 pad)
+constexpr int kGenPitch = 20;   // floats per LDS row (2 x 8 data + 4 pad; 20 / 4 odd: conflict-free 16-byte fragment reads)
 
 // [Cout][Cin][KH][KW] -> [KH*KW][Cin/8][Cout][8]
 __global__ void pack_conv_gen_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KK) {
@@ -50,9 +51,11 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
   const long p0 = (long)blockIdx.x * kGenPx;
   const int co0 = blockIdx.y * kGenCo;
   const int CB = Cin >> 3;
-  const int steps = KH * KW * CB;
+  const int CP = (CB + 1) >> 1;                 // pairs of 8-channel blocks: one step multiplies 16 channels of one tap
+  const int steps = KH * KW * CP;
 
-  // staging roles: activations -- pixel tid/2, channel half tid%2; weights -- channel tid/4, float2 tid%4
+  // staging roles: activations -- pixel tid/2, channel half tid%2 of BOTH blocks of the pair; weights -- channel tid/4,
+  // float4 tid%4 of the 16 values (quarters 0,1 = first block, 2,3 = second block)
   const int a_px = tid >> 1, a_half = tid & 1;
   long ap = p0 + a_px;
   const bool a_live = ap < P;
@@ -63,22 +66,29 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
   const bool w_live = co0 + w_co < Cout;
   const int w_row = w_live ? co0 + w_co : Cout - 1;
 
-  float4 ra;
-  float2 rw;
+  float4 ra0, ra1, rw;
   auto load = [&](int s) {
-    const int t = s / CB, cb = s - t * CB;
+    const int t = s / CP, cp = s - t * CP;
+    const int cb0 = cp * 2, cb1 = min(cb0 + 1, CB - 1);
+    const bool second = cb0 + 1 < CB;                      // an odd block count leaves the last pair half empty
     const int ky = t / KW, kx = t - ky * KW;
     const int iy = a_iy0 + ky, ix = a_ix0 + kx;
     const bool ok = a_live && iy >= 0 && iy < H && ix >= 0 && ix < W;
     const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-    const float4 v = *reinterpret_cast<const float4*>(in + (((long)cb * H + cy) * W + cx) * 8 + a_half * 4);
-    ra = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float2 u = *reinterpret_cast<const float2*>(wpk + (((long)t * CB + cb) * Cout + w_row) * 8 + w_q * 2);
-    rw = w_live ? u : make_float2(0.f, 0.f);
+    const long pix = ((long)cy * W + cx) * 8 + a_half * 4;
+    const float4 v0 = *reinterpret_cast<const float4*>(in + (long)cb0 * H * W * 8 + pix);
+    const float4 v1 = *reinterpret_cast<const float4*>(in + (long)cb1 * H * W * 8 + pix);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    ra0 = ok ? v0 : zero;
+    ra1 = (ok && second) ? v1 : zero;
+    const int wb = (w_q >> 1) ? cb1 : cb0;
+    const float4 u = *reinterpret_cast<const float4*>(wpk + (((long)t * CB + wb) * Cout + w_row) * 8 + (w_q & 1) * 4);
+    rw = (w_live && (second || !(w_q >> 1))) ? u : zero;
   };
   auto store = [&](int buf) {
-    *reinterpret_cast<float4*>(&s_act[buf][a_px * kGenPitch + a_half * 4]) = ra;
-    *reinterpret_cast<float2*>(&s_wt[buf][w_co * kGenPitch + w_q * 2]) = rw;
+    *reinterpret_cast<float4*>(&s_act[buf][a_px * kGenPitch + a_half * 4]) = ra0;
+    *reinterpret_cast<float4*>(&s_act[buf][a_px * kGenPitch + 8 + a_half * 4]) = ra1;
+    *reinterpret_cast<float4*>(&s_wt[buf][w_co * kGenPitch + w_q * 4]) = rw;
   };
 
   f32x16 acc[2];
@@ -98,17 +108,20 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
     load(s + 1 < steps ? s + 1 : s);
-    const float4 a = *reinterpret_cast<const float4*>(a_ptr0 + buf * (kGenCo * kGenPitch));
-    const float4 b0 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch));
-    const float4 b1 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch) + 32 * kGenPitch);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                           // the two 8-channel blocks of the pair
+      const float4 a = *reinterpret_cast<const float4*>(a_ptr0 + buf * (kGenCo * kGenPitch) + h * 8);
+      const float4 b0 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch) + h * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch) + 32 * kGenPitch + h * 8);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+    }
     store(buf ^ 1);
     __syncthreads();
   }

@@ -319,7 +319,8 @@ def test_roi_elementwise_ops(dev):
 
 # (M, N, K, act): split-K and fused paths, partial row/column tiles, the real head shapes
 FC_SHAPES = [(300, 4096, 4096, 1), (45, 150, 64, 0), (1, 441, 256, 2), (300, 441, 256, 2), (300, 126, 8192, 0),
-             (300, 256, 14 * 14 * 512, 1), (7, 4096, 25088, 1), (321, 128, 512, 0)]
+             (300, 256, 14 * 14 * 512, 1), (7, 4096, 25088, 1), (321, 128, 512, 0),
+             (1000, 512, 2048, 1), (760, 1024, 1536, 0), (640, 512, 3200, 2)]     # several row blocks: full blocks + ragged tail
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES)
