@@ -311,6 +311,16 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kBK == 0 && ldc >= N && act >= 0 && act <= 2,
               "mnc_fc: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
   if (M == 0) return MNC_OK;
+  // Several 320-row blocks with a ragged tail (the CFM / ResNet configurations: 500-2000 RoIs per call): every block
+  // multiplies all of its row tiles, so the full blocks and the tail are two launches, each with the tile height and split
+  // count that suit it (M = 760: 2 x 320 + one 160-row block instead of 3 x 320).  Same stream: the second launch re-uses
+  // the split-K scratch after the first one's reduction.  MNC_FC_NOTAIL=1 keeps one launch.
+  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
+    const int head = M / 320 * 320;
+    int rc = mnc_fc(ctx, d_a, d_w, d_bias, d_out, head, N, K, ldc, act);
+    if (rc) return rc;
+    return mnc_fc(ctx, d_a + (size_t)head * K, d_w, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+  }
   // small problems (< 2 GFLOP) use 64-row workgroups so that rows, column tiles and K splits together fill the chip; the
   // large ones the smallest of {160, 320} rows that covers M in one block (weights streamed once).  Measured at M = 300
   // (round 1): 320 rows x 32-deep stages, one workgroup per CU, and 160 rows x 16-deep stages, two per CU, are within 1 %
@@ -335,6 +345,9 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   const int min_stages = small ? (stages >= 64 ? 8 : 2) : (mt == 5 ? 16 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
+  if (tm > 1 && !small)      // several row blocks: pick the split count by cost (see choose_splits); one block: as tuned above
+    splits = choose_splits(tn * tm, stages, min_stages, mt == 10 ? 256 : 512,
+                           (double)bm * kBN * sk * 2.0 / 460.0e3 * (mt == 10 ? 1.0 : 2.0), 4.0 * M * (double)N);
   const int kper = cdiv(stages, splits) * sk;
   splits = cdiv(K, kper);
   float* part = nullptr;

@@ -320,6 +320,13 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
   MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kXBK == 0 && ldc >= N && act >= 0 && act <= 2,
               "mnc_fc_bf16x3: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
   if (M == 0) return MNC_OK;
+  // full 320-row blocks and a ragged tail of at most 160 rows are two launches, each with its own tile height (see mnc_fc)
+  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
+    const int head = M / 320 * 320;
+    int rc = mnc_fc_bf16x3(ctx, d_a, d_w_packed, d_bias, d_out, head, N, K, ldc, act);
+    if (rc) return rc;
+    return mnc_fc_bf16x3(ctx, d_a + (size_t)head * K, d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+  }
   // row tiles per workgroup: 2 (64 rows) for the small GEMMs, else the smallest of {5, 10} that covers M in one block
   const bool small = 2.0 * M * (double)N * K < 2.0e9;
   int mt = small ? 2 : (M <= 160 ? 5 : 10);
@@ -337,6 +344,8 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
   const int min_stages = mt == 2 ? 2 : 8;
   if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
+  if (tm > 1 && mt != 2)     // several row blocks: split count by cost (mnc_internal.h: choose_splits); bf16 pipe ~2.3x the fp32 rate
+    splits = choose_splits(tn * tm, stages, min_stages, 256, (double)bm * kXBN * kXBK * 2.0 / 1050.0e3, 4.0 * M * (double)N);
   const int kper = cdiv(stages, splits) * kXBK;
   splits = cdiv(K, kper);
   // scratch arena: [split-K partials | the activations split into hi/lo bf16 (same bytes as fp32)]

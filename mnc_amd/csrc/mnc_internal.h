@@ -82,6 +82,25 @@ struct LaunchScope {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// K-split count of a GEMM whose `tiles` output tiles do not fill the chip on their own, by a small cost model instead of
+// "tiles x splits ~ #CUs": workgroups run in rounds of `slots` (the CUs x workgroups per CU), a split of `per` stages costs
+// per * stage_us, and every split adds a pass over the M x N partial sums (mn_bytes each way at ~3 TB/s) to the reduction.
+// Used when there are several row blocks (M > one block: the CFM / ResNet configurations), where rounding the split count up
+// could leave a second, nearly empty round (96 tiles x 3 splits = 288 workgroups on 256 CUs: 72 instead of 100 TFLOP/s).
+static inline int choose_splits(int tiles, int stages, int min_stages, int slots, double stage_us, double mn_bytes) {
+  int best = 1;
+  double best_cost = 1e300;
+  const int smax = stages / min_stages > 1 ? stages / min_stages : 1;
+  for (int s = 1; s <= smax && s <= 1024; ++s) {
+    const int per = cdiv(stages, s);
+    if (cdiv(stages, per) != s) continue;                    // this count is not reachable after rounding `per` up
+    const double rounds = (double)cdiv((long)tiles * s, slots);
+    const double cost = rounds * per * stage_us + (s > 1 ? 3.0 + 2.0 * s * mn_bytes / 3.0e6 : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
 // XCD-aware block order for the GEMMs.  The dispatcher places block b on XCD b % 8 (observed, used for speed only:
 // a different placement changes nothing but L2 hit rates).  Blocks are re-numbered so that each XCD receives a
 // CONTIGUOUS range of the logical order (column tile fastest, then K split, then row block): the workgroups that share

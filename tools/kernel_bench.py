@@ -43,7 +43,11 @@ def main():
     ap.add_argument("what", choices=["conv", "convx3", "fc", "fcx3"])
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
     args = ap.parse_args()
+    if args.shape:
+        m, n, k = (int(v) for v in args.shape.split(","))
+        FC[:] = [("custom", m, n, k)]
     dev = Dev(0)
     rng = np.random.default_rng(0)
     dev.call("mnc_prof_enable", 1)
