@@ -1,7 +1,7 @@
 """Global configuration of the MNC inference path -- same surface as the reference's `mnc_config`
 (lib/mnc_config.py:8-206): a mutable attribute-dict `cfg` plus `cfg_from_file(yaml)`; `easydict` is not required.
-Only the keys the inference path reads are defaulted here; TRAIN keeps the handful that test-time code touches
-(demo.py:59 passes cfg.TRAIN.MAX_SIZE to prep_im_for_blob)."""
+Every key of the reference is declared (so that its experiment yml files merge); only the TEST keys and a handful of TRAIN
+keys are read by the inference path (demo.py:59 passes cfg.TRAIN.MAX_SIZE to prep_im_for_blob)."""
 import os
 
 import numpy as np
@@ -43,9 +43,23 @@ cfg.DATA_DIR = os.path.join(cfg.ROOT_DIR, "data")
 cfg.BINARIZE_THRESH = 0.4                   # mnc_config.py:26
 cfg.MASK_SIZE = 21                          # mnc_config.py:28
 
-cfg.TRAIN = AttrDict(SCALES=(600,), MAX_SIZE=1000, IMS_PER_BATCH=1, MIX_INDEX=True, RPN_POST_NMS_TOP_N=2000,
-                     RPN_PRE_NMS_TOP_N=12000, RPN_NMS_THRESH=0.7, RPN_MIN_SIZE=16,
-                     BBOX_NORMALIZE_TARGETS_PRECOMPUTED=False)
+# TRAIN: no training code exists in this package, but the reference's experiment files (experiments/cfgs/VGG16/*.yml) set
+# TRAIN keys next to the TEST ones and cfg_from_file rejects unknown keys (mnc_config.py:174-176) -- so every key of
+# mnc_config.py:31-108 is declared, with the reference's default.  Test-time readers: TRAIN.MAX_SIZE (demo.py:59,
+# TesterWrapper.py:271), TRAIN.MIX_INDEX, TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED.
+cfg.TRAIN = AttrDict(
+    IMS_PER_BATCH=1, BATCH_SIZE=64, ASPECT_GROUPING=True, USE_FLIPPED=True, SCALES=(600,), MAX_SIZE=1000,
+    SNAPSHOT_ITERS=5000, SNAPSHOT_INFIX='',
+    FG_FRACTION=[0.3], FG_THRESH_HI=[1.0], FG_THRESH_LO=[0.5], BG_FRACTION=[0.85, 0.15], BG_THRESH_HI=[0.5, 0.1],
+    BG_THRESH_LO=[0.1, 0.0], PROPOSAL_METHOD='gt',
+    BBOX_REG=True, BBOX_NORMALIZE_TARGETS=True, BBOX_NORMALIZE_TARGETS_PRECOMPUTED=False, BBOX_THRESH=0.5,
+    BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2),
+    BBOX_INSIDE_WEIGHTS=(1.0, 1.0, 1.0, 1.0),
+    HAS_RPN=True, RPN_POSITIVE_OVERLAP=0.7, RPN_NEGATIVE_OVERLAP=0.3, RPN_CLOBBER_POSITIVES=False, RPN_FG_FRACTION=0.5,
+    RPN_BATCHSIZE=256, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_MIN_SIZE=16,
+    RPN_BBOX_INSIDE_WEIGHTS=(1.0, 1.0, 1.0, 1.0), RPN_POSITIVE_WEIGHT=-1.0,
+    MIX_INDEX=True, CFM_INPUT_MASK_SIZE=14, FG_DET_THRESH=0.5, FG_SEG_THRESH=0.5, FRACTION_SAMPLE=[0.3, 0.5, 0.2],
+    THRESH_LO_SAMPLE=[0.5, 0.1, 0.0], THRESH_HI_SAMPLE=[1.0, 0.5, 0.1])
 cfg.TEST = AttrDict(
     SCALES=(600,), MAX_SIZE=1000, NMS=0.3, HAS_RPN=True,
     RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_MIN_SIZE=16,   # mnc_config.py:121-129

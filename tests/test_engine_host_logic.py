@@ -176,6 +176,45 @@ def test_config_surface(tmp_path):
         cfg_from_file(str(p))
     cfg.EXP_DIR = "default"
     cfg.TRAIN.RPN_POST_NMS_TOP_N = 2000
+    cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED = False
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/experiments/cfgs"), reason="reference checkout not mounted")
+def test_config_defaults_and_experiment_files_of_the_reference(monkeypatch):
+    """Every `__C.<KEY> = <literal>` default of the reference's lib/mnc_config.py is declared here with the same value, and
+    its three experiment files (experiments/cfgs/VGG16/*.yml) merge without unknown-key errors."""
+    import ast
+    import copy
+    import glob
+    import re
+    import mnc_config
+    seen = 0
+    for line in open("/root/reference/lib/mnc_config.py"):
+        m = re.match(r"^__C\.([A-Z_.]+) *= *(.+?)\s*(#.*)?$", line)
+        if not m:
+            continue
+        try:
+            want = ast.literal_eval(m.group(2))
+        except (ValueError, SyntaxError):
+            continue                                  # edict(), np.array(...), os.path expressions
+        node = mnc_config.cfg
+        for part in m.group(1).split("."):
+            assert part in node, m.group(1)
+            node = node[part]
+        same = node == want or (isinstance(want, (list, tuple)) and tuple(node) == tuple(want))
+        assert same, (m.group(1), node, want)
+        seen += 1
+    assert seen > 70
+    saved = copy.deepcopy(dict(mnc_config.cfg))
+    try:
+        for f in sorted(glob.glob("/root/reference/experiments/cfgs/VGG16/*.yml")):
+            mnc_config.cfg_from_file(f)
+        assert tuple(mnc_config.cfg.TEST.SCALES) == (600,) and mnc_config.cfg.EXP_DIR == "mnc_5stage"     # last file wins
+        mnc_config.cfg_from_file("/root/reference/experiments/cfgs/VGG16/cfm.yml")
+        assert list(mnc_config.cfg.TEST.MAX_ROIS_GPU) == [2000, 500] and mnc_config.cfg.TEST.GROUP_SCALE == 3
+    finally:
+        for k, v in saved.items():
+            mnc_config.cfg[k] = v
 
 
 def test_speculative_roi_count_equals_synchronous_path(fake_gpu, monkeypatch):
