@@ -209,7 +209,7 @@ def test_config_defaults_and_experiment_files_of_the_reference(monkeypatch):
     try:
         for f in sorted(glob.glob("/root/reference/experiments/cfgs/VGG16/*.yml")):
             mnc_config.cfg_from_file(f)
-        assert tuple(mnc_config.cfg.TEST.SCALES) == (600,) and mnc_config.cfg.EXP_DIR == "mnc_5stage"     # last file wins
+        assert mnc_config.cfg.EXP_DIR == "mnc_5stage" and mnc_config.cfg.TRAIN.RPN_POST_NMS_TOP_N == 300     # last file wins
         mnc_config.cfg_from_file("/root/reference/experiments/cfgs/VGG16/cfm.yml")
         assert list(mnc_config.cfg.TEST.MAX_ROIS_GPU) == [2000, 500] and mnc_config.cfg.TEST.GROUP_SCALE == 3
     finally:
