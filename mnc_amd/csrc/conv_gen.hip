@@ -15,6 +15,7 @@
 //   maxpool_c8_kernel  Caffe MAX pooling with any kernel / stride / pad (ceil output size, windows clipped to the image).
 //   add_kernel         out = a + b (+ ReLU): Eltwise SUM of two same-layout tensors.
 #include <cfloat>
+#include <cstdlib>
 
 #include "mnc_internal.h"
 
@@ -40,16 +41,18 @@ __global__ void pack_conv_gen_kernel(const float* __restrict__ w, float* __restr
   }
 }
 
+template <int CT>
 __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                         const float* __restrict__ bias, const float* __restrict__ res,
                                                         float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
                                                         int KW, int stride, int pad, int OH, int OW, int relu) {
   __shared__ __attribute__((aligned(16))) float s_act[2][kGenPx * kGenPitch];
-  __shared__ __attribute__((aligned(16))) float s_wt[2][kGenCo * kGenPitch];
+  constexpr int kCo = kGenCo * CT;              // output channels per workgroup: 64 (CT = 1) or 128 (CT = 2)
+  __shared__ __attribute__((aligned(16))) float s_wt[2][kCo * kGenPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long P = (long)OH * OW;
   const long p0 = (long)blockIdx.x * kGenPx;
-  const int co0 = blockIdx.y * kGenCo;
+  const int co0 = blockIdx.y * kCo;
   const int CB = Cin >> 3;
   const int CP = (CB + 1) >> 1;                 // pairs of 8-channel blocks: one step multiplies 16 channels of one tap
   const int steps = KH * KW * CP;
@@ -62,11 +65,16 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
   if (!a_live) ap = P - 1;
   const int a_oy = (int)(ap / OW), a_ox = (int)(ap % OW);
   const int a_iy0 = a_oy * stride - pad, a_ix0 = a_ox * stride - pad;
-  const int w_co = tid >> 2, w_q = tid & 3;
-  const bool w_live = co0 + w_co < Cout;
-  const int w_row = w_live ? co0 + w_co : Cout - 1;
+  const int w_co = tid >> 2, w_q = tid & 3;     // + 64 for the second weight item when CT = 2
+  bool w_live[CT];
+  int w_row[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    w_live[c] = co0 + w_co + 64 * c < Cout;
+    w_row[c] = w_live[c] ? co0 + w_co + 64 * c : Cout - 1;
+  }
 
-  float4 ra0, ra1, rw;
+  float4 ra0, ra1, rw[CT];
   auto load = [&](int s) {
     const int t = s / CP, cp = s - t * CP;
     const int cb0 = cp * 2, cb1 = min(cb0 + 1, CB - 1);
@@ -82,24 +90,31 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
     ra0 = ok ? v0 : zero;
     ra1 = (ok && second) ? v1 : zero;
     const int wb = (w_q >> 1) ? cb1 : cb0;
-    const float4 u = *reinterpret_cast<const float4*>(wpk + (((long)t * CB + wb) * Cout + w_row) * 8 + (w_q & 1) * 4);
-    rw = (w_live && (second || !(w_q >> 1))) ? u : zero;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const float4 u = *reinterpret_cast<const float4*>(wpk + (((long)t * CB + wb) * Cout + w_row[c]) * 8 + (w_q & 1) * 4);
+      rw[c] = (w_live[c] && (second || !(w_q >> 1))) ? u : zero;
+    }
   };
   auto store = [&](int buf) {
     *reinterpret_cast<float4*>(&s_act[buf][a_px * kGenPitch + a_half * 4]) = ra0;
     *reinterpret_cast<float4*>(&s_act[buf][a_px * kGenPitch + 8 + a_half * 4]) = ra1;
-    *reinterpret_cast<float4*>(&s_wt[buf][w_co * kGenPitch + w_q * 4]) = rw;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) *reinterpret_cast<float4*>(&s_wt[buf][(w_co + 64 * c) * kGenPitch + w_q * 4]) = rw[c];
   };
 
-  f32x16 acc[2];
+  // wave tile: CT x 32 channels by 64 pixels -> acc[c][j]
+  f32x16 acc[CT][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][j][i] = 0.f;
 
   const int co_half = wave & 1, px_half = wave >> 1;
   const int frag_off = (lane >> 5) * 4;
-  const float* a_ptr0 = &s_wt[0][(co_half * 32 + (lane & 31)) * kGenPitch + frag_off];
+  const float* a_ptr0 = &s_wt[0][(co_half * 32 * CT + (lane & 31)) * kGenPitch + frag_off];
   const float* b_ptr0 = &s_act[0][(px_half * 64 + (lane & 31)) * kGenPitch + frag_off];
 
   load(0);
@@ -110,17 +125,32 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
     load(s + 1 < steps ? s + 1 : s);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                           // the two 8-channel blocks of the pair
-      const float4 a = *reinterpret_cast<const float4*>(a_ptr0 + buf * (kGenCo * kGenPitch) + h * 8);
+      float4 a[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        a[c] = *reinterpret_cast<const float4*>(a_ptr0 + buf * (kCo * kGenPitch) + c * 32 * kGenPitch + h * 8);
       const float4 b0 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch) + h * 8);
       const float4 b1 = *reinterpret_cast<const float4*>(b_ptr0 + buf * (kGenPx * kGenPitch) + 32 * kGenPitch + h * 8);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, b0.x, acc[c][0], 0, 0, 0);
+        acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, b1.x, acc[c][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, b0.y, acc[c][0], 0, 0, 0);
+        acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, b1.y, acc[c][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, b0.z, acc[c][0], 0, 0, 0);
+        acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, b1.z, acc[c][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc[c][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, b0.w, acc[c][0], 0, 0, 0);
+        acc[c][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, b1.w, acc[c][1], 0, 0, 0);
+      }
     }
     store(buf ^ 1);
     __syncthreads();
@@ -128,25 +158,27 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
 
   // epilogue: lane holds, per 32x32 block, 4 consecutive channels (regs 4g..4g+3) of one pixel for g = 0..3
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long px = p0 + px_half * 64 + j * 32 + (lane & 31);
-    if (px >= P) continue;
+  for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = co0 + co_half * 32 + g * 8 + frag_off;
-      if (co >= Cout) continue;
-      const float4 bv = *reinterpret_cast<const float4*>(bias + co);
-      float4 v = make_float4(acc[j][g * 4 + 0] + bv.x, acc[j][g * 4 + 1] + bv.y, acc[j][g * 4 + 2] + bv.z,
-                             acc[j][g * 4 + 3] + bv.w);
-      const long o = ((long)(co >> 3) * P + px) * 8 + (co & 7);
-      if (res) {
-        const float4 r = *reinterpret_cast<const float4*>(res + o);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    for (int j = 0; j < 2; ++j) {
+      const long px = p0 + px_half * 64 + j * 32 + (lane & 31);
+      if (px >= P) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + (co_half * CT + c) * 32 + g * 8 + frag_off;
+        if (co >= Cout) continue;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+        float4 v = make_float4(acc[c][j][g * 4 + 0] + bv.x, acc[c][j][g * 4 + 1] + bv.y, acc[c][j][g * 4 + 2] + bv.z,
+                               acc[c][j][g * 4 + 3] + bv.w);
+        const long o = ((long)(co >> 3) * P + px) * 8 + (co & 7);
+        if (res) {
+          const float4 r = *reinterpret_cast<const float4*>(res + o);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(out + o) = v;
       }
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      *reinterpret_cast<float4*>(out + o) = v;
     }
-  }
 }
 
 // Stem: Cin = 3, NCHW input, weights [Cout][3][K][K] re-laid in LDS as [Cout/16][3*K*K][16].
@@ -282,8 +314,16 @@ int mnc_conv2d(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d
   const long P = (long)OH * OW;
   const double flops = 2.0 * P * Cout * (double)Cin * KH * KW;
   LaunchScope ls(ctx, "conv2d_c8_mfma", flops, 4.0 * ((double)H * W * Cin + (double)P * Cout * (d_residual ? 2 : 1)));
-  hipLaunchKernelGGL(conv2d_c8_kernel, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, kGenCo)), dim3(256), 0, ctx->stream,
-                     d_in, d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);
+  // MNC_CONV2D_WIDE=1 (tuning knob): 128-channel workgroup tiles (wave = 64 channels x 64 pixels: 8 B/clk/CU of staging
+  // instead of 12, half the barriers per MFMA).  Measured on the ResNet-50 C4 trunk at 800x1333: 40 vs 44 TFLOP/s for the
+  // 64-channel tile (fewer, fatter workgroups), so the narrow tile is the default.
+  const bool wide = Cout >= 128 && getenv("MNC_CONV2D_WIDE") != nullptr;
+  if (wide)
+    hipLaunchKernelGGL(conv2d_c8_kernel<2>, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, 128)), dim3(256), 0, ctx->stream,
+                       d_in, d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);
+  else
+    hipLaunchKernelGGL(conv2d_c8_kernel<1>, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, kGenCo)), dim3(256), 0,
+                       ctx->stream, d_in, d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);
   return ls.finish("conv2d_c8_kernel");
 }
 

@@ -153,13 +153,17 @@ def test_conv1x1_and_rpn_softmax(dev):
 GEN_CONV = [  # H, W, Cin, Cout, K, stride, pad, residual   (ResNet-50 shapes in miniature, plus ragged tiles)
     (37, 53, 64, 256, 1, 1, 0, False), (37, 53, 256, 64, 1, 1, 0, True), (40, 54, 256, 128, 1, 2, 0, False),
     (33, 47, 64, 64, 3, 2, 1, False), (21, 30, 128, 72, 3, 1, 1, True), (12, 9, 8, 8, 5, 1, 2, False),
-    (50, 84, 1024, 256, 1, 1, 0, False)]
+    (50, 84, 1024, 256, 1, 1, 0, False),
+    (200, 334, 64, 256, 1, 1, 0, True), (150, 250, 24, 136, 3, 2, 1, False)]     # large grids
 
 
 @pytest.mark.parametrize("H,W,Cin,Cout,K,stride,pad,residual", GEN_CONV)
-@pytest.mark.parametrize("relu", [1, 0])
-def test_conv2d_general(dev, H, W, Cin, Cout, K, stride, pad, residual, relu):
-    """mnc_conv2d (any kernel / stride / pad, + bias + residual + ReLU) against torch fp32."""
+@pytest.mark.parametrize("relu,wide", [(1, False), (0, False), (1, True)])
+def test_conv2d_general(dev, monkeypatch, H, W, Cin, Cout, K, stride, pad, residual, relu, wide):
+    """mnc_conv2d (any kernel / stride / pad, + bias + residual + ReLU) against torch fp32; `wide` = the 128-channel workgroup
+    tile (MNC_CONV2D_WIDE, a tuning knob -- the 64-channel tile is the default)."""
+    if wide:
+        monkeypatch.setenv("MNC_CONV2D_WIDE", "1")
     rng = np.random.default_rng(H * 100 + W + K)
     x = rng.normal(size=(Cin, H, W)).astype(np.float32)
     w = (rng.normal(size=(Cout, Cin, K, K)) * np.sqrt(2.0 / (K * K * Cin))).astype(np.float32)
