@@ -48,7 +48,7 @@ def parse():
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
-    p.add_argument("--math", default=os.environ.get("MNC_MATH", "fp32"), choices=["fp32", "bf16x3"],
+    p.add_argument("--math", default=os.environ.get("MNC_MATH", "fp32"), choices=["fp32", "bf16x3", "f16"],
                    help="arithmetic of the dense contractions for the headline number (default fp32)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 (BASELINE configs[2]) measurement")
     p.add_argument("--host-results", action="store_true",

@@ -238,6 +238,13 @@ MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float
 MNC_API int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
 MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M,
                           int N, int K, int ldc, int act);
+/* "f16" math mode (BASELINE.json configs[4] names fp16): InnerProduct with both operands rounded to IEEE fp16 (nearest even)
+ * and fp32 accumulation on v_mfma_f32_32x32x16_f16 -- one product per term, 2 bytes per value streamed instead of 4.
+ * mnc_pack_fc_f16: Caffe weight [N][K] -> [ceil(N/128)][K/64][128][64] halves (bytes: ceil(N/128)*128*K*2), once at load.
+ * mnc_fc_f16: same interface as mnc_fc (fp32 activations in, fp32 out); K%64==0.  Relative error vs fp32 ~3e-4 per layer. */
+MNC_API int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
+MNC_API int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N,
+                       int K, int ldc, int act);
 /* Softmax over the last axis of [M][N] (test.prototxt cls_prob / seg_cls_prob). */
 MNC_API int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N);
 /* Same with a row stride on the input (the input may be a column slice of a merged-GEMM output). */

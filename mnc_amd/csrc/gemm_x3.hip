@@ -40,7 +40,11 @@ __device__ __forceinline__ float x3_act(float v, int act) {
 // LDS fragment bandwidth, not the matrix pipe, is what bounds this kernel).
 // ABL != 0: ablation builds for tuning (MNC_FCX3_ABL): 1 = no global loads / LDS stores in the loop, 2 = additionally no
 // barrier, 3 = additionally no LDS fragment reads (MFMAs on constant registers).
-template <int kMT, int kWR, int ABL = 0>
+// F16 != 0: the same kernel on v_mfma_f32_32x32x16_f16 with ONE product per term ("f16" math mode, BASELINE configs[4]):
+// operands are fp16 (weights converted once at load, activations once per call, both stage-major), a stage is 64 K-values
+// -- the same 128 bytes per row as 32 split bf16 pairs, so staging, LDS layout and pipeline are unchanged; a half-stage
+// (what the split kernel calls a K-step) is two 16-value MFMA steps, two MFMAs per accumulator tile instead of three.
+template <int kMT, int kWR, int ABL = 0, int F16 = 0>
 __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax, const uint4* __restrict__ Wx,
                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                     float* __restrict__ part, int M, int N, int K, int ldc, int kper,
@@ -54,8 +58,9 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
   int bn, split, bmz;
   xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
   const int n0 = bn * kXBN, m0 = bmz * kBM;
+  constexpr int kStageK = F16 ? 64 : kXBK;     // K values per stage (128 bytes per row either way)
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
-  const int nstages = (kend - kbeg) / kXBK;
+  const int nstages = (kend - kbeg) / kStageK;
   const int mrows = min(M - m0, kBM);
   const int mtiles = (mrows + 31) >> 5;
 
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
   for (int u = 0; u < kAPer; ++u) {
     const int q = tid + u * 256, r = min(q >> 3, kBM - 1), c = q & 7;
     const int gr = m0 + min(r, mrows - 1);
-    a_src[u] = Ax + (((long)(kbeg / kXBK) * M + gr) << 3) + c;         // [stage][row][8]
+    a_src[u] = Ax + (((long)(kbeg / kStageK) * M + gr) << 3) + c;      // [stage][row][8]
     a_dst[u] = r * kXPitch + c * 4;
   }
   const uint4* b_src[kXBPer];
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
 #pragma unroll
   for (int u = 0; u < kXBPer; ++u) {
     const int q = tid + u * 256, r = q >> 3, c = q & 7;
-    b_src[u] = Wx + ((((long)bn * (K / kXBK) + kbeg / kXBK) * kXBN + r) << 3) + c;   // [column tile][stage][128][8]
+    b_src[u] = Wx + ((((long)bn * (K / kStageK) + kbeg / kStageK) * kXBN + r) << 3) + c;   // [column tile][stage][128][8]
     b_dst[u] = r * kXPitch + c * 4;
   }
   const long a_step = (long)M << 3, b_step = (long)kXBN << 3;         // uint4 per stage
@@ -131,8 +136,11 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
 
-  const int a_base = (wr * TR * 32 + j) * kXPitch + kb * 8;      // + t*32*pitch + ks*16
-  const int b_base = (wc * TC * 32 + j) * kXPitch + kb * 8;      // + c*32*pitch + ks*16
+  // split bf16: K-step ks = dwords [ks*16, ks*16+16) of the row: lane half kb takes 8 of them, hi then lo.
+  // f16: half-stage ks = the same 16 dwords = two 16-value MFMA steps q of 8 dwords each: lane half kb takes 4 of them.
+  constexpr int kKbOff = F16 ? 4 : 8, kTermOff = F16 ? 8 : 4;
+  const int a_base = (wr * TR * 32 + j) * kXPitch + kb * kKbOff;      // + t*32*pitch + ks*16 (+ kTermOff)
+  const int b_base = (wc * TC * 32 + j) * kXPitch + kb * kKbOff;      // + c*32*pitch + ks*16 (+ kTermOff)
   // Software pipeline (one wave per SIMD here, so nothing hides a stall but the wave's own MFMAs):
   //   * the fragments of a K-step are read from LDS while the MFMAs of the PREVIOUS K-step run (two fragment sets, F0 / F1);
   //   * the global loads of stage s+2 and the LDS writes of stage s+1 are issued during K-step 0 of stage s;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
   //   * sched_group_barrier pins the interleave (2 MFMAs : 1 ds_read : 1 ds_write : 1 global load); left alone hipcc
   //     clusters each class, and the ablation (MNC_FCX3_ABL) showed the three phases simply adding up:
   //     MFMA 112 us + fragment reads 43 us + staging 90 us = 245 us for fc6.
-  struct Frags { bf16x8 ah[TR], al[TR], bh[TC], bl[TC]; };
+  struct Frags { uint4 ah[TR], al[TR], bh[TC], bl[TC]; };     // f16: ah/bh = MFMA step 0, al/bl = MFMA step 1 of the half-stage
   auto read_frags = [&](int buf, int ks, Frags& f) {
     const unsigned* pa = sA[buf];
     const unsigned* pb = sB[buf];
@@ -149,36 +157,52 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
       uint4 k = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
       asm volatile("" : "+v"(k.x), "+v"(k.y), "+v"(k.z), "+v"(k.w));
 #pragma unroll
-      for (int c = 0; c < TC; ++c) f.bh[c] = f.bl[c] = x3_as_bf16x8(k);
+      for (int c = 0; c < TC; ++c) f.bh[c] = f.bl[c] = k;
 #pragma unroll
-      for (int t = 0; t < TR; ++t) f.ah[t] = f.al[t] = x3_as_bf16x8(k);
+      for (int t = 0; t < TR; ++t) f.ah[t] = f.al[t] = k;
       return;
     }
 #pragma unroll
     for (int c = 0; c < TC; ++c) {
-      f.bh[c] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pb + b_base + c * 32 * kXPitch + ks * 16));
-      f.bl[c] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pb + b_base + c * 32 * kXPitch + ks * 16 + 4));
+      f.bh[c] = *reinterpret_cast<const uint4*>(pb + b_base + c * 32 * kXPitch + ks * 16);
+      f.bl[c] = *reinterpret_cast<const uint4*>(pb + b_base + c * 32 * kXPitch + ks * 16 + kTermOff);
     }
     // NO per-tile branch: all row tiles are always multiplied (rows past M hold clamped copies and are never stored)
 #pragma unroll
     for (int t = 0; t < TR; ++t) {
-      f.ah[t] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16));
-      f.al[t] = x3_as_bf16x8(*reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16 + 4));
+      f.ah[t] = *reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16);
+      f.al[t] = *reinterpret_cast<const uint4*>(pa + a_base + t * 32 * kXPitch + ks * 16 + kTermOff);
     }
   };
   auto mfmas = [&](const Frags& f) {                 // term outermost: consecutive MFMAs never share an accumulator
+    if (F16) {
+#pragma unroll
+      for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.ah[t]), x3_as_f16x8(f.bh[c]), acc[t][c], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+          acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.al[t]), x3_as_f16x8(f.bl[c]), acc[t][c], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < TR; ++t)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[t], f.bh[c], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < TC; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.al[t]), x3_as_bf16x8(f.bh[c]), acc[t][c], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < TR; ++t)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bl[c], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < TC; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.ah[t]), x3_as_bf16x8(f.bl[c]), acc[t][c], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < TR; ++t)
 #pragma unroll
-      for (int c = 0; c < TC; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[t], f.bh[c], acc[t][c], 0, 0, 0);
+      for (int c = 0; c < TC; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.ah[t]), x3_as_bf16x8(f.bh[c]), acc[t][c], 0, 0, 0);
   };
   // MFMAs have no side effects, so instruction selection is free to drift them across the barrier, which breaks the
   // per-region counts below; an empty asm that "modifies" the accumulators (they live in AGPRs: no instruction results)
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
 #pragma unroll
       for (int c = 0; c < TC; ++c) asm volatile("" : "+a"(acc[t][c]));
   };
-  constexpr int kNFrag = 2 * (TR + TC), kNMfma = 3 * TR * TC;
+  constexpr int kNFrag = 2 * (TR + TC), kNMfma = (F16 ? 2 : 3) * TR * TC;
   constexpr int kNStage = kAPer + kXBPer;            // global loads (= LDS writes) per thread and stage
   constexpr int kSlots = kNMfma / 2;                 // interleave slots of one K-step: 2 MFMAs each
   // stage s sits in LDS[buf] and its K-step-0 fragments in f0; stage s+1 is in `cur`; stage s+2 is requested into `nxt`
@@ -293,6 +317,40 @@ __global__ void pack_x3_kernel(const float* __restrict__ in, uint4* __restrict__
   }
 }
 
+// fp32 row-major [rows][K] -> fp16 (round to nearest even), stage-major with 64-value stages:
+// out[((tile * S + s) * tile_rows + r) * 8 + g] = 8 halves of values s*64 + g*8 .. +7 of row tile * tile_rows + r, S = K/64.
+__global__ void pack_f16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int rows, int K, int tile_rows,
+                                int tiles) {
+  const int S = K / 64;
+  const long total = (long)tiles * S * tile_rows * 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i & 7);
+    long t = i >> 3;
+    const int r = (int)(t % tile_rows);
+    t /= tile_rows;
+    const int st = (int)(t % S);
+    const int tile = (int)(t / S);
+    const long row = (long)tile * tile_rows + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < rows) {
+      const float4* p = reinterpret_cast<const float4*>(in + row * K + st * 64 + g * 8);
+      const float4 a = p[0], b = p[1];
+      f16x8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z,
+                 (_Float16)b.w};
+      v = __builtin_bit_cast(uint4, h);
+    }
+    out[i] = v;
+  }
+}
+
+static int f16_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles) {
+  const long total = (long)tiles * (K / 64) * tile_rows * 8;
+  long g = (total + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, rows, K, tile_rows, tiles);
+  return MNC_OK;
+}
+
 static int x3_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles) {
   const long total = (long)tiles * (K / kXBK) * tile_rows * 4;
   long g = (total + 255) / 256;
@@ -382,6 +440,78 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
 #undef MNC_X3_CASE
     }
     rc = ls.finish("fc_x3_kernel");
+    if (rc) return rc;
+  }
+  if (splits > 1) {
+    LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
+    long total = (long)M * N;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(fc_x3_reduce_kernel, dim3(g), dim3(256), 0, ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+    return ls.finish("fc_x3_reduce_kernel");
+  }
+  return MNC_OK;
+}
+
+int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K) {
+  MNC_REQUIRE(ctx && d_w && d_packed && N > 0 && K > 0 && K % 64 == 0, "mnc_pack_fc_f16: bad argument (K%%64==0)");
+  LaunchScope ls(ctx, "pack_fc_f16");
+  f16_pack_launch(ctx, d_w, (uint4*)d_packed, N, K, kXBN, cdiv(N, kXBN));
+  return ls.finish("pack_f16_kernel");
+}
+
+// InnerProduct in fp16 arithmetic (fp32 accumulate): the launcher of mnc_fc_bf16x3 with 64-value stages.
+int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N, int K,
+               int ldc, int act) {
+  MNC_REQUIRE(ctx && d_a && d_w_packed && d_bias && d_out, "mnc_fc_f16: null pointer");
+  MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2,
+              "mnc_fc_f16: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%64==0)", M, N, K, ldc, act);
+  if (M == 0) return MNC_OK;
+  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
+    const int head = M / 320 * 320;               // full 320-row blocks, then the ragged tail (see mnc_fc)
+    int rc = mnc_fc_f16(ctx, d_a, d_w_packed, d_bias, d_out, head, N, K, ldc, act);
+    if (rc) return rc;
+    return mnc_fc_f16(ctx, d_a + (size_t)head * K, d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+  }
+  const bool small = 2.0 * M * (double)N * K < 2.0e9;
+  int mt = small ? 2 : (M <= 160 ? 5 : 10);
+  if (mt == 10 && (K / 64) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < 32) mt = 5;      // short K splits: 160-row blocks
+  if (const char* e = getenv("MNC_FCX3_TILE")) {
+    const int v = atoi(e);
+    if (v == 2 || v == 5 || v == 10) mt = v;
+  }
+  const int bm = 32 * mt;
+  const int tn = cdiv(N, kXBN), tm = cdiv(M, bm), stages = K / 64;
+  int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
+  const int min_stages = mt == 2 ? 1 : 4;
+  if (splits > stages / min_stages) splits = stages / min_stages;
+  if (splits < 1) splits = 1;
+  if (tm > 1 && mt != 2)
+    splits = choose_splits(tn * tm, stages, min_stages, 256, (double)bm * kXBN * 64 * 2.0 / 2000.0e3, 4.0 * M * (double)N);
+  const int kper = cdiv(stages, splits) * 64;
+  splits = cdiv(K, kper);
+  // scratch arena: [split-K partials | the activations in fp16, stage-major]
+  const size_t part_bytes = splits > 1 ? (((size_t)splits * M * N * 4 + 255) & ~(size_t)255) : 0;
+  int rc = ensure_scratch(ctx, part_bytes + (size_t)M * K * 2);
+  if (rc) return rc;
+  float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
+  uint4* d_ax = (uint4*)((char*)ctx->scratch + part_bytes);
+  {
+    LaunchScope ls(ctx, "fc_f16_convert", 0.0, 6.0 * M * (double)K);
+    f16_pack_launch(ctx, d_a, d_ax, M, K, M, 1);
+    rc = ls.finish("pack_f16_kernel");
+    if (rc) return rc;
+  }
+  const double flops = 2.0 * M * (double)N * K, bytes = 2.0 * ((double)N * K + (double)M * K) + 4.0 * (double)M * N;
+  {
+    LaunchScope ls(ctx, small ? "fc_f16_small" : "fc_f16", flops, bytes);
+#define MNC_F16_LAUNCH(MT, WR) hipLaunchKernelGGL((fc_x3_kernel<MT, WR, 0, 1>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, \
+                         d_ax, (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
+    if (mt == 2) MNC_F16_LAUNCH(2, 2);
+    else if (mt == 5) MNC_F16_LAUNCH(5, 1);
+    else MNC_F16_LAUNCH(10, 2);
+#undef MNC_F16_LAUNCH
+    rc = ls.finish("fc_x3_kernel<f16>");
     if (rc) return rc;
   }
   if (splits > 1) {

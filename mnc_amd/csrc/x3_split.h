@@ -11,6 +11,7 @@
 namespace mnc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned x3_pack_hi16(unsigned x0, unsigned x1) {      // {x1[31:16], x0[31:16]}
   return __builtin_amdgcn_perm(x1, x0, 0x07060302u);
@@ -56,6 +57,8 @@ __device__ __forceinline__ void x3_split8_rne(const float* x, uint4& hi, uint4& 
   hi = make_uint4(x3_pack_hi16(h[0], h[1]), x3_pack_hi16(h[2], h[3]), x3_pack_hi16(h[4], h[5]), x3_pack_hi16(h[6], h[7]));
   lo = make_uint4(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]), x3_pack_hi16(l[4], l[5]), x3_pack_hi16(l[6], l[7]));
 }
+
+__device__ __forceinline__ f16x8 x3_as_f16x8(const uint4 v) { return __builtin_bit_cast(f16x8, v); }
 
 __device__ __forceinline__ bf16x8 x3_as_bf16x8(const uint4 v) {
   union { uint4 u; bf16x8 b; } c;

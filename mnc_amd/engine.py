@@ -339,10 +339,12 @@ class Net(object):
                            else bool(native_pylayers))
         # arithmetic of the dense contractions: "fp32" = fp32 MFMA throughout (the default and the parity reference);
         # "bf16x3" = the large InnerProducts and 3x3 convolutions run on the bf16 matrix pipe with every operand split
-        # into hi + lo bf16 and three products per term (fp32-class accuracy, see csrc/gemm_x3.hip); math= / MNC_MATH
+        # into hi + lo bf16 and three products per term (fp32-class accuracy, see csrc/gemm_x3.hip); "f16" = additionally
+        # the large InnerProducts in plain fp16 (operands rounded to fp16, fp32 accumulate: one product per term, ~3e-4
+        # relative error per layer -- the reduced-precision mode BASELINE configs[4] names); math= / MNC_MATH
         self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
-        if self.math not in ("fp32", "bf16x3"):
-            raise ValueError("math must be 'fp32' or 'bf16x3', got %r" % self.math)
+        if self.math not in ("fp32", "bf16x3", "f16"):
+            raise ValueError("math must be 'fp32', 'bf16x3' or 'f16', got %r" % self.math)
         # MNC_SPECULATE_ROIS=0: read the ProposalLayer's RoI count back before the heads are launched (one stream sync in the
         # middle of forward) instead of running the heads on RPN_POST_NMS_TOP_N rows and checking the count at the end
         self._speculate = os.environ.get("MNC_SPECULATE_ROIS", "1") != "0"
@@ -613,7 +615,7 @@ class Net(object):
                               H, Wd, cout, k, stride, pad, relu)
             return run
         if kind == "fast3x3":
-            x3 = self.math == "bf16x3"
+            x3 = self.math in ("bf16x3", "f16")      # no fp16 convolution kernel: the trunk stays on the split-bf16 one
             pitch, pack, conv = (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
                                 (76, "mnc_pack_conv3x3_weights", "mnc_conv3x3")
 
@@ -876,14 +878,17 @@ class Net(object):
         def weights_for(shape, M):
             """Caffe flattens (C,PH,PW); the engine's per-RoI features are (PH,PW,C): permute the columns once.  In
             bf16x3 mode the large products additionally get the weights pre-split into hi/lo bf16."""
-            x3 = self.math == "bf16x3" and K % 32 == 0 and 2.0 * M * n_out * K >= _X3_MIN_FLOPS
-            tag = ("x3",) if x3 else ()
+            big = 2.0 * M * n_out * K >= _X3_MIN_FLOPS
+            f16 = self.math == "f16" and K % 64 == 0 and big
+            x3 = (not f16) and self.math in ("bf16x3", "f16") and K % 32 == 0 and big
+            tag = ("f16",) if f16 else ("x3",) if x3 else ()
+            fn = "mnc_fc_f16" if f16 else "mnc_fc_bf16x3" if x3 else "mnc_fc"
 
             def finish(d_w):
-                if not x3:
+                if not (x3 or f16):
                     return d_w
-                packed = self._ctx.alloc((n_out + 127) // 128 * 128 * K * 4)
-                _lib.call("mnc_pack_fc_bf16x3", self._h(), d_w, packed, n_out, K)
+                packed = self._ctx.alloc((n_out + 127) // 128 * 128 * K * (2 if f16 else 4))
+                _lib.call("mnc_pack_fc_f16" if f16 else "mnc_pack_fc_bf16x3", self._h(), d_w, packed, n_out, K)
                 self._ctx.free(d_w)
                 return packed
 
@@ -896,21 +901,20 @@ class Net(object):
                     _lib.call("mnc_pack_fc_weights", self._h(), raw, packed, n_out, geo[0], geo[1], geo[2])
                     self._ctx.free(raw)
                     return finish(packed)
-                return self._dev_param(key + ("w",) + geo + tag, build), "rhwc", x3
-            return self._dev_param(key + ("w", "plain") + tag, lambda: finish(self._upload(W))), "plain", x3
+                return self._dev_param(key + ("w",) + geo + tag, build), "rhwc", fn
+            return self._dev_param(key + ("w", "plain") + tag, lambda: finish(self._upload(W))), "plain", fn
 
         def run():
             M = bot.shape[0]
             if int(np.prod(bot.shape[1:])) != K:
                 raise ValueError("InnerProduct %s: input %r does not flatten to K=%d" % (L.name, bot.shape, K))
             if M and "w" not in state:
-                state["w"], state["layout"], state["x3"] = weights_for(bot.shape, M)
+                state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
             src = bot.dev_in(state["layout"]) if M else 0
             top.reshape(M, n_out)
             dst = top.dev_out("plain")
             if M:
-                _lib.call("mnc_fc_bf16x3" if state["x3"] else "mnc_fc", self._h(), src, state["w"], d_b, dst, M, n_out,
-                          K, top._ld(), act)
+                _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
         return run
 
     def _bind_ip_group(self, L):

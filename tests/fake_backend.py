@@ -252,6 +252,24 @@ class Fake(object):
         w = np.ascontiguousarray(w)
         self.mnc_fc(h, a, w.ctypes.data, b, dst, M, N, K, ldc, act)
 
+    def mnc_pack_fc_f16(self, h, src, dst, N, K):
+        w = _f(src, (N, K)).astype(np.float16)
+        tiles = (N + 127) // 128
+        pad = np.zeros((tiles * 128, K), np.float16)
+        pad[:N] = w
+        out = np.ctypeslib.as_array((ctypes.c_uint16 * (tiles * 128 * K)).from_address(int(dst)))
+        out[...] = pad.reshape(tiles, 128, K // 64, 64).transpose(0, 2, 1, 3).reshape(-1).view(np.uint16)
+
+    def mnc_fc_f16(self, h, a, wpk, b, dst, M, N, K, ldc, act):
+        tiles = (N + 127) // 128
+        raw = np.ctypeslib.as_array((ctypes.c_uint16 * (tiles * 128 * K)).from_address(int(wpk))).view(np.float16)
+        w = raw.reshape(tiles, K // 64, 128, 64).transpose(0, 2, 1, 3).reshape(tiles * 128, K)[:N].astype(np.float32)
+        x = _f(a, (M, K)).astype(np.float16).astype(np.float32)
+        y = _act(F.linear(_t(x), _t(w), _t(_f(b, (N,)))), act).numpy()
+        full = _f(dst, ((M - 1) * ldc + N,))
+        for m in range(M):
+            full[m * ldc:m * ldc + N] = y[m]
+
     def mnc_softmax_rows(self, h, src, dst, M, N):
         _f(dst, (M, N))[...] = F.softmax(_t(_f(src, (M, N))), dim=1).numpy()
 

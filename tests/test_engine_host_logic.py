@@ -32,7 +32,7 @@ def _inputs(H, W, seed):
     return rng.uniform(-120, 130, (1, 3, H, W)).astype(np.float32), np.array([[H, W, 1.0]], np.float32)
 
 
-@pytest.mark.parametrize("fuse,math", [(True, "fp32"), (False, "fp32"), (True, "bf16x3")])
+@pytest.mark.parametrize("fuse,math", [(True, "fp32"), (False, "fp32"), (True, "bf16x3"), (True, "f16")])
 def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     from mnc_amd import engine
     from mnc_amd.engine import Net
@@ -47,7 +47,9 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     assert set(out) == {"cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"}
     ref = onet.forward(w, data, im_info)
     names = BLOBS + ([] if fuse else ["roi_interpolate_conv5_premax", "roi_mask_conv5", "roi_mask_conv5_ext"])
-    tol = 1e-4 if math == "fp32" else 1e-3          # split weights are exact to 2^-16 only; 1e-3 is the end-to-end bar
+    # split weights are exact to 2^-16 only; 1e-3 is the end-to-end bar.  f16 rounds both FC operands to 11 bits: 1e-2 here
+    # (plumbing check; the measured accuracy of that mode is reported by the GPU tests)
+    tol = {"fp32": 1e-4, "bf16x3": 1e-3, "f16": 1e-2}[math]
     for n in names:
         got, want = net.blobs[n].data, ref[n]
         assert got.shape == want.shape, n

@@ -52,7 +52,7 @@ HEAD_BLOBS = ["roi_interpolate_conv5", "mask_output", "mask_proposal", "mask_pro
               "cls_prob", "seg_cls_prob", "bbox_pred", "roi_interpolate_conv5_premax", "roi_mask_conv5"]
 
 
-def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None):
+def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None, head_tol=1e-3):
     """Parity protocol for one net.forward() that has already run on (data, im_info).
 
     The cascade has two data-dependent host hops (proposal NMS, stage bridge arg-max).  A 1e-7 difference upstream can
@@ -85,7 +85,7 @@ def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=No
         assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
     h1 = {}
     onet.head(w, c5, rois, False, "", h1)
-    _compare(net, h1, [b for b in HEAD_BLOBS + list(extra) if b in h1])
+    _compare(net, h1, [b for b in HEAD_BLOBS + list(extra) if b in h1], head_tol)
     rois_ext = g("rois_ext")
     want_ext = ohost.stage_bridge_forward_test(rois, g("bbox_pred"), g("seg_cls_prob"), im_info)
     if net._native_py:
@@ -94,7 +94,7 @@ def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=No
         assert np.array_equal(rois_ext, want_ext)
     h2 = {}
     onet.head(w, c5, rois_ext, True, "_ext", h2)
-    _compare(net, h2, [b + "_ext" for b in HEAD_BLOBS + list(extra) if b + "_ext" in h2])
+    _compare(net, h2, [b + "_ext" for b in HEAD_BLOBS + list(extra) if b + "_ext" in h2], head_tol)
     return ref, h1, h2
 
 
@@ -213,6 +213,23 @@ def test_reduced_net_bf16x3_math(small):
         im_info = np.array([[130, 203, 1.0]], np.float32)
         net.forward(data=data, im_info=im_info)
         check_forward(net, w, data, im_info)
+    finally:
+        net.close()
+
+
+def test_full_vgg16_600x1000_f16_math(full, monkeypatch):
+    """math="f16" (the reduced-precision mode BASELINE configs[4] names): the large InnerProducts in fp16 with fp32 accumulation,
+    the trunk on the split-bf16 kernels.  Same teacher-forced protocol; the head blobs are held to 5e-3 of their range (fp16
+    operands carry 11 bits; the measured differences are printed), everything upstream of the first FC to the usual 1e-3."""
+    from mnc_amd.engine import Net
+    _, w = full
+    net = Net(models.write_mnc_5stage_test_prototxt(), w, 1, math="f16")
+    try:
+        im = np.random.default_rng(0).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+        data, im_info, scale = ohost.prepare_mnc_args(im)
+        net.forward(data=data, im_info=im_info)
+        assert net.blobs["rois"]._host_read().shape == (300, 5)
+        check_forward(net, w, data, im_info, head_tol=5e-3)
     finally:
         net.close()
 

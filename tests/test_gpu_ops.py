@@ -364,6 +364,32 @@ def test_fc_bf16x3(dev, M, N, K, act):
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(300, 4096, 4096, 1), (45, 150, 64, 0), (300, 256, 14 * 14 * 512, 1), (7, 4096, 25088, 1),
+                                       (300, 126, 8192, 0), (1000, 512, 2048, 1), (300, 441, 256, 2)])
+def test_fc_f16(dev, M, N, K, act):
+    """mnc_fc_f16: exact against torch on operands rounded to fp16 (products of halves are exact in the fp32 accumulator; only
+    the summation order differs), and within fp16's 11 bits of the fp32 product."""
+    rng = np.random.default_rng(M + N + K)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_wp = dev.empty(((N + 127) // 128 * 128 * K // 2,), fill=np.nan)
+    dev.call("mnc_pack_fc_f16", dev.put(w), d_wp, N, K)
+    d_o = dev.empty((M * N,), fill=np.nan)
+    dev.call("mnc_fc_f16", dev.put(a), d_wp, dev.put(b), d_o, M, N, K, N, act)
+    got = dev.get(d_o, (M, N))
+
+    def ref(x, y):
+        z = F.linear(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(b))
+        return (F.relu(z) if act == 1 else torch.sigmoid(z) if act == 2 else z).numpy()
+    exact = ref(a.astype(np.float16).astype(np.float32), w.astype(np.float16).astype(np.float32))
+    assert not np.isnan(got).any()
+    d, rel = err(got, exact)
+    d32, rel32 = err(got, ref(a, w))
+    print("f16 M=%d N=%d K=%d: vs fp16-rounded operands rel=%.3e, vs fp32 rel=%.3e" % (M, N, K, rel, rel32))
+    assert rel < 1e-5 and rel32 < 2e-3
+
+
 def test_fc_column_slice_and_pack(dev):
     """ldc > N writes a column slice (Concat in place); mnc_pack_fc_weights permutes (c,h,w) columns to (h,w,c)."""
     rng = np.random.default_rng(9)

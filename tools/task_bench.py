@@ -11,7 +11,7 @@ included (image preparation, forward, result hand-over) -- what bench.py's HBM-r
 
 Seeded synthetic weights, pixels and proposals.  Prints wall time per image and the per-kernel breakdown (HIP events).
 
-    python tools/task_bench.py --task seg|cfm|resnet [--iters 5] [--math fp32|bf16x3] [--host-prep]
+    python tools/task_bench.py --task seg|cfm|resnet [--iters 5] [--math fp32|bf16x3|f16] [--host-prep]
 """
 import argparse
 import json
