@@ -32,7 +32,11 @@ constexpr int kX3HaloCols = kX3Cols + 2;
 constexpr int kX3PixPitch = 12;        // dwords per halo pixel in LDS: hi x8 | lo x8 | pad
 constexpr int kX3WPitch = 84;          // dwords per weight row: 10 slots x 8 + 4 pad (global packed layout and LDS)
 
-template <int CT, int PR, int ROWS>
+// F16 != 0: the "f16" math mode (BASELINE configs[4]) -- one product per term on v_mfma_f32_32x32x16_f16: activations are
+// rounded to fp16 (nearest even) while the halo is staged and occupy the "hi" half of a pixel's LDS slot, the weights come
+// from mnc_pack_conv3x3_f16 (fp16 in the hi halves of the same packed layout, lo halves zero); only the hi fragments are read
+// and one MFMA per tile and K-step is issued instead of three.
+template <int CT, int PR, int ROWS, int F16 = 0>
 __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                int H, int W, int Cin, int Cout, int relu, int ksplit,
@@ -109,6 +113,14 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __re
 #pragma unroll
     for (int u = 0; u < kHPer; ++u) {
       const unsigned keep = live ? h_keep[u] : 0u;
+      if (F16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4 hv = {(_Float16)G.h[u].x, (_Float16)G.h[u].y, (_Float16)G.h[u].z, (_Float16)G.h[u].w};
+        uint2 hi = __builtin_bit_cast(uint2, hv);
+        hi.x &= keep; hi.y &= keep;
+        *reinterpret_cast<uint2*>(hdst + h_dst[u]) = hi;
+        continue;
+      }
       uint2 hi, lo;
       x3_split4(G.h[u], hi, lo);
       hi.x &= keep; hi.y &= keep;
@@ -143,6 +155,20 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __re
     const unsigned* sw = s_w + buf * kWDw;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
+      if (F16) {
+        f16x8 b[PR], a[CT];
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+          b[r] = x3_as_f16x8(*reinterpret_cast<const uint4*>(sh + p_off[s] + r * kX3HaloCols * kX3PixPitch));
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+          a[t] = x3_as_f16x8(*reinterpret_cast<const uint4*>(sw + w_base + t * 32 * kX3WPitch + s * 16));
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+#pragma unroll
+          for (int t = 0; t < CT; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], b[r], acc[r][t], 0, 0, 0);
+        continue;
+      }
       bf16x8 bh[PR], bl[PR], ah[CT], al[CT];
 #pragma unroll
       for (int r = 0; r < PR; ++r) {
@@ -216,7 +242,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const float* __re
 }
 
 // OIHW fp32 -> [Cin/8][Cout][21 uint4]: slot t < 9: (hi x8 | lo x8) of w[co][cb*8 .. +8][tap t]; slot 9 and the pad: zero
-__global__ void pack_conv_x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin) {
+// f16 != 0: hi = the 8 values rounded to fp16, lo = zero (conv3x3_x3_kernel<.., F16 = 1>)
+__global__ void pack_conv_x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin, int f16) {
   const long total = (long)(Cin >> 3) * Cout * 11;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int slot = (int)(i % 11);
@@ -232,7 +259,13 @@ __global__ void pack_conv_x3_kernel(const float* __restrict__ w, uint4* __restri
       float x[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = w[((long)co * Cin + cb * 8 + e) * 9 + slot];
-      x3_split8_rne(x, hi, lo);
+      if (f16) {
+        const f16x8 hv = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3],
+                          (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
+        hi = __builtin_bit_cast(uint4, hv);
+      } else {
+        x3_split8_rne(x, hi, lo);
+      }
     }
     dst[slot * 2] = hi;
     dst[slot * 2 + 1] = lo;
@@ -244,13 +277,13 @@ static int x3_grid_for(long total) {
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
-template <int CT, int PR, int ROWS>
+template <int CT, int PR, int ROWS, int F16>
 static int launch_x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W,
                      int Cin, int Cout, int relu, int ksplit, float* part) {
   constexpr int R = ROWS * PR;
   constexpr size_t lds = 2 * 4 * ((size_t)(R + 2) * kX3HaloCols * kX3PixPitch + (size_t)32 * CT * kX3WPitch);
   static_assert(lds <= 160 * 1024, "conv3x3_x3: LDS budget");
-  auto kern = conv3x3_x3_kernel<CT, PR, ROWS>;
+  auto kern = conv3x3_x3_kernel<CT, PR, ROWS, F16>;
   static std::atomic<unsigned long long> attr_set{0};          // one bit per device: function attributes are per device
   const unsigned long long bit = 1ull << (ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
@@ -267,23 +300,20 @@ static int launch_x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const f
 
 using namespace mnc;
 
-extern "C" {
-
-int mnc_pack_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
-  MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
-              "mnc_pack_conv3x3_bf16x3: bad argument");
-  LaunchScope ls(ctx, "pack_conv3x3_bf16x3");
+static int pack_conv_lowp(mnc_ctx* ctx, const char* name, const float* d_oihw, void* d_packed, int Cout, int Cin, int f16) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0, "%s: bad argument", name);
+  LaunchScope ls(ctx, name);
   hipLaunchKernelGGL(pack_conv_x3_kernel, dim3(x3_grid_for((long)(Cin / 8) * Cout * 11)), dim3(256), 0, ctx->stream, d_oihw,
-                     (uint4*)d_packed, Cout, Cin);
+                     (uint4*)d_packed, Cout, Cin, f16);
   return ls.finish("pack_conv_x3_kernel");
 }
 
-int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W,
-                       int Cin, int Cout, int relu) {
-  MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3_bf16x3: null pointer");
+template <int F16>
+static int conv3x3_lowp(mnc_ctx* ctx, const char* name, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out,
+                        int H, int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "%s: null pointer", name);
   MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
-              "mnc_conv3x3_bf16x3: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin,
-              Cout);
+              "%s: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", name, H, W, Cin, Cout);
   // (channel tiles CT, pixel rows PR) per wave.  Measured on MI355X (tools/kernel_bench.py convx3, round 1): the 2x2
   // register tile (8 LDS fragment reads per 12 MFMAs, 2 workgroups per CU) wins wherever it still yields >= 512 workgroups
   // (conv1_2 .. conv3_3: 280-335 TF/s fp32-equivalent); on the small maps (conv4_x, conv5_x, rpn_conv) the 1x1 tile with
@@ -317,15 +347,35 @@ int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const
   }
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
-  LaunchScope ls(ctx, "conv3x3_bf16x3", flops, bytes);
+  LaunchScope ls(ctx, name, flops, bytes);
   int rc = MNC_OK;
-  if (ct == 4 && pr == 2) rc = launch_x3<4, 2, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
-  else if (ct == 2 && pr == 2) rc = launch_x3<2, 2, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
-  else if (ct == 2 && pr == 1) rc = launch_x3<2, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
-  else rc = launch_x3<1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  if (ct == 4 && pr == 2) rc = launch_x3<4, 2, 4, F16>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  else if (ct == 2 && pr == 2) rc = launch_x3<2, 2, 4, F16>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  else if (ct == 2 && pr == 1) rc = launch_x3<2, 1, 4, F16>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  else rc = launch_x3<1, 1, 4, F16>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
   if (rc) return rc;
   if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);
   return ls.finish("conv3x3_x3_kernel");
+}
+
+extern "C" {
+
+int mnc_pack_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  return pack_conv_lowp(ctx, "pack_conv3x3_bf16x3", d_oihw, d_packed, Cout, Cin, 0);
+}
+
+int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  return pack_conv_lowp(ctx, "pack_conv3x3_f16", d_oihw, d_packed, Cout, Cin, 1);
+}
+
+int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                       int Cin, int Cout, int relu) {
+  return conv3x3_lowp<0>(ctx, "conv3x3_bf16x3", d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+}
+
+int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                    int Cout, int relu) {
+  return conv3x3_lowp<1>(ctx, "conv3x3_f16", d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
 }
 
 }  // extern "C"

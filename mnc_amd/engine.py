@@ -339,9 +339,9 @@ class Net(object):
                            else bool(native_pylayers))
         # arithmetic of the dense contractions: "fp32" = fp32 MFMA throughout (the default and the parity reference);
         # "bf16x3" = the large InnerProducts and 3x3 convolutions run on the bf16 matrix pipe with every operand split
-        # into hi + lo bf16 and three products per term (fp32-class accuracy, see csrc/gemm_x3.hip); "f16" = additionally
-        # the large InnerProducts in plain fp16 (operands rounded to fp16, fp32 accumulate: one product per term, ~3e-4
-        # relative error per layer -- the reduced-precision mode BASELINE configs[4] names); math= / MNC_MATH
+        # into hi + lo bf16 and three products per term (fp32-class accuracy, see csrc/gemm_x3.hip); "f16" = the same
+        # layers in plain fp16 (operands rounded to fp16, fp32 accumulate: one product per term, ~3e-4 relative error per
+        # layer -- the reduced-precision mode BASELINE configs[4] names); math= / MNC_MATH
         self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
         if self.math not in ("fp32", "bf16x3", "f16"):
             raise ValueError("math must be 'fp32', 'bf16x3' or 'f16', got %r" % self.math)
@@ -615,8 +615,9 @@ class Net(object):
                               H, Wd, cout, k, stride, pad, relu)
             return run
         if kind == "fast3x3":
-            x3 = self.math in ("bf16x3", "f16")      # no fp16 convolution kernel: the trunk stays on the split-bf16 one
-            pitch, pack, conv = (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
+            x3 = self.math in ("bf16x3", "f16")
+            pitch, pack, conv = (84, "mnc_pack_conv3x3_f16", "mnc_conv3x3_f16") if self.math == "f16" else \
+                                (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
                                 (76, "mnc_pack_conv3x3_weights", "mnc_conv3x3")
 
             def build():
@@ -625,7 +626,7 @@ class Net(object):
                 _lib.call(pack, self._h(), raw, packed, cout, cin)
                 self._ctx.free(raw)
                 return packed
-            d_w = self._dev_param(key + ("w", "x3" if x3 else "fp32"), build)
+            d_w = self._dev_param(key + ("w", self.math), build)
 
             def run():
                 N, _, H, Wd = bot.shape

@@ -143,6 +143,17 @@ class Fake(object):
         y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
         _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
 
+    def mnc_pack_conv3x3_f16(self, h, src, dst, Cout, Cin):
+        # test double: keep the fp16-rounded OIHW weights in the first Cout*Cin*9 floats of the packed buffer
+        _f(dst, (Cout * Cin * 9,))[...] = _f(src, (Cout * Cin * 9,)).astype(np.float16).astype(np.float32)
+
+    def mnc_conv3x3_f16(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        x = _t(_unc8(_f(src, (Cin // 8, H, W, 8))).astype(np.float16).astype(np.float32))[None]
+        y = F.conv2d(x, _t(_f(wpk, (Cout, Cin, 3, 3))), _t(_f(b, (Cout,))), padding=1)[0]
+        if relu:
+            y = F.relu(y)
+        _f(dst, (Cout // 8, H, W, 8))[...] = _c8(y.numpy())
+
     def mnc_maxpool2_c8(self, h, src, dst, C, H, W):
         x = _unc8(_f(src, (C // 8, H, W, 8)))
         y = F.max_pool2d(_t(x)[None], 2, 2, ceil_mode=True)[0].numpy()

@@ -52,7 +52,7 @@ HEAD_BLOBS = ["roi_interpolate_conv5", "mask_output", "mask_proposal", "mask_pro
               "cls_prob", "seg_cls_prob", "bbox_pred", "roi_interpolate_conv5_premax", "roi_mask_conv5"]
 
 
-def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None, head_tol=1e-3):
+def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None, head_tol=1e-3, trunk_tol=1e-3):
     """Parity protocol for one net.forward() that has already run on (data, im_info).
 
     The cascade has two data-dependent host hops (proposal NMS, stage bridge arg-max).  A 1e-7 difference upstream can
@@ -68,7 +68,7 @@ def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=No
     ref = {}
     c5 = (trunk_fn or onet.trunk)(w, data, ref)
     onet.rpn(w, c5, ref)
-    _compare(net, ref, trunk_blobs or TRUNK_BLOBS)
+    _compare(net, ref, trunk_blobs or TRUNK_BLOBS, trunk_tol)
     g = lambda n: net.blobs[n]._host_read()
     rois = g("rois")
     if net._native_py:
@@ -218,9 +218,9 @@ def test_reduced_net_bf16x3_math(small):
 
 
 def test_full_vgg16_600x1000_f16_math(full, monkeypatch):
-    """math="f16" (the reduced-precision mode BASELINE configs[4] names): the large InnerProducts in fp16 with fp32 accumulation,
-    the trunk on the split-bf16 kernels.  Same teacher-forced protocol; the head blobs are held to 5e-3 of their range (fp16
-    operands carry 11 bits; the measured differences are printed), everything upstream of the first FC to the usual 1e-3."""
+    """math="f16" (the reduced-precision mode BASELINE configs[4] names): the 3x3 convolutions and the large InnerProducts in
+    fp16 with fp32 accumulation.  Same teacher-forced protocol against the fp32 oracle; every blob is held to 5e-3 of its range
+    (fp16 operands carry 11 bits; the measured differences are printed)."""
     from mnc_amd.engine import Net
     _, w = full
     net = Net(models.write_mnc_5stage_test_prototxt(), w, 1, math="f16")
@@ -229,7 +229,7 @@ def test_full_vgg16_600x1000_f16_math(full, monkeypatch):
         data, im_info, scale = ohost.prepare_mnc_args(im)
         net.forward(data=data, im_info=im_info)
         assert net.blobs["rois"]._host_read().shape == (300, 5)
-        check_forward(net, w, data, im_info, head_tol=5e-3)
+        check_forward(net, w, data, im_info, head_tol=5e-3, trunk_tol=5e-3)
     finally:
         net.close()
 

@@ -73,6 +73,26 @@ def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128)])
+def test_conv3x3_f16(dev, H, W, Cin, Cout):
+    """f16 math mode: exact against torch on fp16-rounded operands (fp32 accumulation), ~3e-4 of range against fp32."""
+    rng = np.random.default_rng(H * 1000 + W + 9)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    d_w = dev.empty(((Cin // 8) * Cout * 84,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_f16", dev.put(w), d_w, Cout, Cin)
+    d_y = dev.empty((Cout * H * W,), fill=np.nan)
+    dev.call("mnc_conv3x3_f16", dev.put(to_c8(x)), d_w, dev.put(b), d_y, H, W, Cin, Cout, 1)
+    got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+    assert not np.isnan(got).any()
+    d, rel = err(got, _conv_ref(r16(x), r16(w), b, relu=True))
+    d32, rel32 = err(got, _conv_ref(x, w, b, relu=True))
+    print("conv f16 %dx%d %d->%d: vs fp16-rounded operands rel=%.3e, vs fp32 rel=%.3e" % (H, W, Cin, Cout, rel, rel32))
+    assert rel < 1e-5 and rel32 < 2e-3
+
+
 def test_conv3x3_bf16x3_packed_weight_layout(dev):
     """[Cin/8][Cout][10 slots x (hi x8 | lo x8) bf16 + pad]: hi + lo reproduces the fp32 weight to 2^-16 relative, slot 9
     and the pad are zero."""
