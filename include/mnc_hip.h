@@ -193,6 +193,13 @@ MNC_API int mnc_pack_conv_weights(mnc_ctx* ctx, const float* d_oihw, float* d_pa
 MNC_API int mnc_conv2d(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
                        const float* d_residual_c8, float* d_out_c8, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                        int pad, int relu);
+/* "f16" math mode of mnc_conv2d: activations rounded to fp16 while staged, weights from mnc_pack_conv_weights_f16
+ * ([KH*KW][ceil(Cin/32)][Cout][32] halves, channel groups zero-padded: ceil(Cin/32)*32*Cout*KH*KW*2 bytes), fp32 accumulate,
+ * same epilogue. */
+MNC_API int mnc_pack_conv_weights_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin, int KH, int KW);
+MNC_API int mnc_conv2d_f16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias,
+                           const float* d_residual_c8, float* d_out_c8, int H, int W, int Cin, int Cout, int KH, int KW,
+                           int stride, int pad, int relu);
 /* First convolution of a 3-channel NCHW input blob (ResNet conv1 7x7/2 pad 3): weights [Cout][3][K][K] as in Caffe,
  * + bias (+ ReLU) -> c8.  Cout%16==0. */
 MNC_API int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8,

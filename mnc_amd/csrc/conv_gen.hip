@@ -181,6 +181,136 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
     }
 }
 
+// ---- "f16" math mode of the general convolution: one v_mfma_f32_32x32x16_f16 per 16 channels instead of eight fp32 MFMAs.
+// Weights [KH*KW][ceil(Cin/32)][Cout][32 halves] (mnc_pack_conv_weights_f16, zero-padded channel groups); activations fp32 c8 in
+// HBM, rounded to fp16 while they are staged.  Same 64-channel x 128-pixel workgroup tile; a step covers one tap and 32
+// channels (four c8 blocks, two MFMA K-steps): LDS rows are 64 B + 16 B pad (pitch 20 dwords, conflict-free 16-byte reads).
+typedef _Float16 gen_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gen_f16x4 __attribute__((ext_vector_type(4)));
+
+__global__ void pack_conv_gen_f16_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin,
+                                         int KK) {
+  const int G = (Cin + 31) / 32;
+  const long total = (long)KK * G * Cout * 32;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % 32);
+    long r = idx / 32;
+    const int co = (int)(r % Cout);
+    r /= Cout;
+    const int g = (int)(r % G);
+    const int t = (int)(r / G);
+    const int ci = g * 32 + c;
+    const _Float16 h = ci < Cin ? (_Float16)w[((long)co * Cin + ci) * KK + t] : (_Float16)0.f;
+    out[idx] = __builtin_bit_cast(unsigned short, h);
+  }
+}
+
+__global__ __launch_bounds__(256) void conv2d_c8_f16_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            float* __restrict__ out, int H, int W, int Cin, int Cout, int KH,
+                                                            int KW, int stride, int pad, int OH, int OW, int relu) {
+  constexpr int kPitch = 20;                    // dwords per LDS row: 32 halves + 4 pad
+  __shared__ __attribute__((aligned(16))) unsigned s_act[2][kGenPx * kPitch];
+  __shared__ __attribute__((aligned(16))) unsigned s_wt[2][kGenCo * kPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long P = (long)OH * OW;
+  const long p0 = (long)blockIdx.x * kGenPx;
+  const int co0 = blockIdx.y * kGenCo;
+  const int CB = Cin >> 3;
+  const int G = (CB + 3) >> 2;                  // groups of four 8-channel blocks
+  const int steps = KH * KW * G;
+
+  // staging roles: activations -- pixel tid/2, channel half tid%2 of the four blocks; weights -- channel tid/4, 16 bytes tid%4
+  const int a_px = tid >> 1, a_half = tid & 1;
+  long ap = p0 + a_px;
+  const bool a_live = ap < P;
+  if (!a_live) ap = P - 1;
+  const int a_oy = (int)(ap / OW), a_ox = (int)(ap % OW);
+  const int a_iy0 = a_oy * stride - pad, a_ix0 = a_ox * stride - pad;
+  const int w_co = tid >> 2, w_q = tid & 3;
+  const bool w_live = co0 + w_co < Cout;
+  const int w_row = w_live ? co0 + w_co : Cout - 1;
+
+  float4 ra[4];
+  uint4 rw;
+  auto load = [&](int s) {
+    const int t = s / G, g = s - t * G;
+    const int ky = t / KW, kx = t - ky * KW;
+    const int iy = a_iy0 + ky, ix = a_ix0 + kx;
+    const bool ok = a_live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+    const long pix = ((long)cy * W + cx) * 8 + a_half * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int cb = g * 4 + b;
+      const float4 v = *reinterpret_cast<const float4*>(in + (long)min(cb, CB - 1) * H * W * 8 + pix);
+      ra[b] = (ok && cb < CB) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint4 u = wpk[(((long)t * G + g) * Cout + w_row) * 4 + w_q];
+    rw = w_live ? u : make_uint4(0, 0, 0, 0);
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const gen_f16x4 h = {(_Float16)ra[b].x, (_Float16)ra[b].y, (_Float16)ra[b].z, (_Float16)ra[b].w};
+      *reinterpret_cast<uint2*>(&s_act[buf][a_px * kPitch + b * 4 + a_half * 2]) = __builtin_bit_cast(uint2, h);
+    }
+    *reinterpret_cast<uint4*>(&s_wt[buf][w_co * kPitch + w_q * 4]) = rw;
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  const int co_half = wave & 1, px_half = wave >> 1;
+  const int kb = lane >> 5;                      // this lane's 8 of the 16 channels of an MFMA K-step = one c8 block
+  const unsigned* a_ptr0 = &s_wt[0][(co_half * 32 + (lane & 31)) * kPitch + kb * 4];
+  const unsigned* b_ptr0 = &s_act[0][(px_half * 64 + (lane & 31)) * kPitch + kb * 4];
+
+  load(0);
+  store(0);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const int buf = s & 1;
+    load(s + 1 < steps ? s + 1 : s);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                 // two MFMA K-steps of 16 channels
+      const gen_f16x8 a = __builtin_bit_cast(gen_f16x8, *reinterpret_cast<const uint4*>(a_ptr0 + buf * (kGenCo * kPitch) + h * 8));
+      const gen_f16x8 b0 = __builtin_bit_cast(gen_f16x8, *reinterpret_cast<const uint4*>(b_ptr0 + buf * (kGenPx * kPitch) + h * 8));
+      const gen_f16x8 b1 =
+          __builtin_bit_cast(gen_f16x8, *reinterpret_cast<const uint4*>(b_ptr0 + buf * (kGenPx * kPitch) + 32 * kPitch + h * 8));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc[1], 0, 0, 0);
+    }
+    store(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int frag_off = kb * 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const long px = p0 + px_half * 64 + j * 32 + (lane & 31);
+    if (px >= P) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + co_half * 32 + g * 8 + frag_off;
+      if (co >= Cout) continue;
+      const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+      float4 v = make_float4(acc[j][g * 4 + 0] + bv.x, acc[j][g * 4 + 1] + bv.y, acc[j][g * 4 + 2] + bv.z,
+                             acc[j][g * 4 + 3] + bv.w);
+      const long o = ((long)(co >> 3) * P + px) * 8 + (co & 7);
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(out + o) = v;
+    }
+  }
+}
+
 // Stem: Cin = 3, NCHW input, weights [Cout][3][K][K] re-laid in LDS as [Cout/16][3*K*K][16].
 __global__ __launch_bounds__(256) void conv_stem_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int H,
@@ -325,6 +455,30 @@ int mnc_conv2d(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d
     hipLaunchKernelGGL(conv2d_c8_kernel<1>, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, kGenCo)), dim3(256), 0,
                        ctx->stream, d_in, d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);
   return ls.finish("conv2d_c8_kernel");
+}
+
+int mnc_pack_conv_weights_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin, int KH, int KW) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed, "mnc_pack_conv_weights_f16: null pointer");
+  MNC_REQUIRE(Cout > 0 && Cout % 8 == 0 && Cin > 0 && Cin % 8 == 0 && KH > 0 && KW > 0, "mnc_pack_conv_weights_f16: bad shape");
+  LaunchScope ls(ctx, "pack_conv_gen_f16");
+  hipLaunchKernelGGL(pack_conv_gen_f16_kernel, dim3(grid1d((long)KH * KW * ((Cin + 31) / 32) * 32 * Cout)), dim3(256), 0,
+                     ctx->stream, d_oihw, (unsigned short*)d_packed, Cout, Cin, KH * KW);
+  return ls.finish("pack_conv_gen_f16_kernel");
+}
+
+int mnc_conv2d_f16(mnc_ctx* ctx, const float* d_in, const void* d_w, const float* d_bias, const float* d_residual, float* d_out,
+                   int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out, "mnc_conv2d_f16: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 8 == 0 && KH > 0 && KW > 0 && stride > 0 &&
+                  pad >= 0 && H + 2 * pad >= KH && W + 2 * pad >= KW,
+              "mnc_conv2d_f16: bad shape (Cin, Cout multiples of 8)");
+  const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+  const long P = (long)OH * OW;
+  const double flops = 2.0 * P * Cout * (double)Cin * KH * KW;
+  LaunchScope ls(ctx, "conv2d_c8_f16", flops, 4.0 * ((double)H * W * Cin + (double)P * Cout * (d_residual ? 2 : 1)));
+  hipLaunchKernelGGL(conv2d_c8_f16_kernel, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, kGenCo)), dim3(256), 0, ctx->stream,
+                     d_in, (const uint4*)d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);
+  return ls.finish("conv2d_c8_f16_kernel");
 }
 
 int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8, int H,

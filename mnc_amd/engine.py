@@ -649,18 +649,21 @@ class Net(object):
                     _lib.call("mnc_conv1x1_to_nchw", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
                               dst + n * cout * H * Wd * 4, H, Wd, cin, cout)
             return run
-        # general: any kernel / stride / pad on the fp32 matrix pipe (both math modes), residual add and ReLU in the epilogue
+        # general: any kernel / stride / pad on the fp32 matrix pipe (fp16 pipe in the f16 mode), residual add and ReLU in the epilogue
         if cin % 8 or cout % 8:
             raise NotImplementedError("Convolution %s: channel counts must be multiples of 8 (got %d -> %d)" % (L.name, cin, cout))
         kh, kw = W.shape[2], W.shape[3]
 
+        f16 = self.math == "f16"
+        conv2d = "mnc_conv2d_f16" if f16 else "mnc_conv2d"
+
         def build_general():
             raw = self._upload(W)
-            packed = self._ctx.alloc(W.nbytes)
-            _lib.call("mnc_pack_conv_weights", self._h(), raw, packed, cout, cin, kh, kw)
+            packed = self._ctx.alloc(kh * kw * ((cin + 31) // 32) * 32 * cout * 2 if f16 else W.nbytes)
+            _lib.call("mnc_pack_conv_weights_f16" if f16 else "mnc_pack_conv_weights", self._h(), raw, packed, cout, cin, kh, kw)
             self._ctx.free(raw)
             return packed
-        d_w = self._dev_param(key + ("w", "general"), build_general)
+        d_w = self._dev_param(key + ("w", "general", "f16" if f16 else "fp32"), build_general)
         res = self.blobs[L.residual] if L.residual else None
 
         def run():
@@ -674,7 +677,7 @@ class Net(object):
             top.reshape(N, cout, OH, OW)
             dst = top.dev_out("c8")
             for n in range(N):
-                _lib.call("mnc_conv2d", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
+                _lib.call(conv2d, self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
                           (rsrc + n * cout * OH * OW * 4) if rsrc is not None else None, dst + n * cout * OH * OW * 4, H, Wd, cin,
                           cout, kh, kw, stride, pad, relu)
         return run

@@ -192,6 +192,23 @@ class Fake(object):
             y = F.relu(y)
         _f(dst, (Cout // 8, OH, OW, 8))[...] = _c8(y.numpy())
 
+    def mnc_pack_conv_weights_f16(self, h, src, dst, Cout, Cin, KH, KW):
+        # test double: the fp16-rounded OIHW weights as floats at the start of the packed buffer (2 bytes/value were allocated
+        # for ceil(Cin/32)*32 channels, so Cout*Cin*KH*KW floats fit only when padded -- keep a side table instead)
+        self._f16_conv = getattr(self, "_f16_conv", {})
+        self._f16_conv[int(dst)] = _f(src, (Cout, Cin, KH, KW)).astype(np.float16).astype(np.float32)
+
+    def mnc_conv2d_f16(self, h, src, wpk, b, res, dst, H, W, Cin, Cout, KH, KW, stride, pad, relu):
+        w = self._f16_conv[int(wpk)]
+        x = _t(_unc8(_f(src, (Cin // 8, H, W, 8))).astype(np.float16).astype(np.float32))[None]
+        y = F.conv2d(x, _t(w), _t(_f(b, (Cout,))), stride=stride, padding=pad)[0]
+        OH, OW = y.shape[1:]
+        if res:
+            y = y + _t(_unc8(_f(res, (Cout // 8, OH, OW, 8))))
+        if relu:
+            y = F.relu(y)
+        _f(dst, (Cout // 8, OH, OW, 8))[...] = _c8(y.numpy())
+
     def mnc_conv_stem_c3(self, h, src, w, b, dst, H, W, Cout, K, stride, pad, relu):
         y = F.conv2d(_t(_f(src, (1, 3, H, W))), _t(_f(w, (Cout, 3, K, K))), _t(_f(b, (Cout,))), stride=stride, padding=pad)[0]
         if relu:

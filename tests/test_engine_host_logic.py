@@ -341,6 +341,22 @@ RESNET_BLOBS = ["conv1", "pool1", "res2a_branch1", "res2a_branch2a", "res2a_bran
                 "seg_cls_prob", "bbox_pred", "rois_ext", "mask_proposal_ext", "seg_cls_prob_ext"]
 
 
+def test_resnet50_graph_f16_mode_plumbing(fake_gpu):
+    """f16 math mode on the ResNet trunk: every convolution family takes its fp16 variant; trunk blobs within fp16's reach."""
+    from mnc_amd.engine import Net
+    path = models.write_mnc_resnet50_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=5)
+    net = Net(path, w, 1, device_id=0, math="f16")
+    data, im_info = _inputs(96, 160, 0)
+    net.forward(data=data, im_info=im_info)
+    ref = {}
+    onet.trunk_resnet50(w, data, ref)
+    for n in ("conv1", "res2a", "res3d", "res4f"):
+        got, want = net.blobs[n].data, ref[n]
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-2 * np.abs(want).max(), n
+    net.close()
+
+
 @pytest.mark.parametrize("fuse", [True, False])
 def test_resnet50_graph_every_blob(fake_gpu, fuse):
     """the 5-stage cascade on a ResNet-50 C4 trunk -- stem conv, BatchNorm/Scale folded into the convolutions,

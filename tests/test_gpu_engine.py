@@ -481,12 +481,13 @@ def test_device_image_prep_is_bit_identical_to_the_numpy_path(small):
         assert np.array_equal(v, net.blobs[k]._host_read()), k
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
 def test_resnet50_trunk_graph(math, monkeypatch):
     """SURVEY 8f n4 (BASELINE configs[4]): the cascade on a ResNet-50 C4 trunk (reduced width): stem, folded BatchNorm/Scale,
     strided 1x1 convolutions, MAX 3x3/2 and the residual adds folded into branch2c -- every block output against the unfolded
     oracle graph, then the same teacher-forced protocol as for VGG-16 (check_forward).  In bf16x3 mode the stride-1 3x3 layers
-    run on the split-bf16 kernels, everything else stays fp32."""
+    run on the split-bf16 kernels, everything else stays fp32; in f16 mode every convolution family and the large InnerProducts
+    take their fp16 variant."""
     import caffe
     monkeypatch.setenv("MNC_MATH", math)
     path = models.write_mnc_resnet50_test_prototxt(width_div=4)
@@ -500,6 +501,7 @@ def test_resnet50_trunk_graph(math, monkeypatch):
             net.forward(data=data, im_info=im_info)
             blobs = ["conv1", "pool1", "res2a_branch2b", "res2a", "res2c", "res3a", "res3d", "res4a", "res4c", "res4f", "rpn_output",
                      "rpn_cls_prob_reshape", "rpn_bbox_pred"]
-            check_forward(net, w, data, im_info, trunk_fn=onet.trunk_resnet50, trunk_blobs=blobs)
+            tol = 5e-3 if math == "f16" else 1e-3            # fp16 operands carry 11 bits
+            check_forward(net, w, data, im_info, trunk_fn=onet.trunk_resnet50, trunk_blobs=blobs, head_tol=tol, trunk_tol=tol)
     finally:
         net.close()

@@ -205,6 +205,34 @@ def test_conv2d_general(dev, monkeypatch, H, W, Cin, Cout, K, stride, pad, resid
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout,K,stride,pad,residual", GEN_CONV)
+def test_conv2d_general_f16(dev, H, W, Cin, Cout, K, stride, pad, residual):
+    """mnc_conv2d_f16: exact against torch on fp16-rounded operands (fp32 accumulation), ~3e-4 of range against fp32."""
+    rng = np.random.default_rng(H * 100 + W + K + 1)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, K, K)) * np.sqrt(2.0 / (K * K * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+
+    def ref(xx, ww):
+        y = F.conv2d(torch.from_numpy(xx)[None], torch.from_numpy(ww), torch.from_numpy(b), stride=stride, padding=pad)[0]
+        return y
+    OH, OW = ref(x, w).shape[1:]
+    res = rng.normal(size=(Cout, OH, OW)).astype(np.float32) if residual else None
+    fin = lambda y: F.relu(y + torch.from_numpy(res) if residual else y).numpy()
+    d_w = dev.empty((K * K * ((Cin + 31) // 32) * 32 * Cout // 2,), fill=np.nan)
+    dev.call("mnc_pack_conv_weights_f16", dev.put(w), d_w, Cout, Cin, K, K)
+    d_y = dev.empty((Cout * OH * OW,), fill=np.nan)
+    dev.call("mnc_conv2d_f16", dev.put(to_c8(x)), d_w, dev.put(b), dev.put(to_c8(res)) if residual else None, d_y, H, W, Cin,
+             Cout, K, K, stride, pad, 1)
+    got = from_c8(dev.get(d_y, (Cout * OH * OW,)), Cout, OH, OW)
+    assert not np.isnan(got).any()
+    rel = err(got, fin(ref(r16(x), r16(w))))[1]
+    rel32 = err(got, fin(ref(x, w)))[1]
+    print("conv2d f16 %dx%d %d->%d k%d s%d: vs fp16-rounded rel=%.3e, vs fp32 rel=%.3e" % (H, W, Cin, Cout, K, stride, rel, rel32))
+    assert rel < 1e-5 and rel32 < 2e-3
+
+
 @pytest.mark.parametrize("H,W,K,stride,pad", [(75, 101, 7, 2, 3), (64, 64, 7, 2, 3), (31, 45, 3, 1, 1)])
 def test_conv_stem_c3(dev, H, W, K, stride, pad):
     rng = np.random.default_rng(H + W)
