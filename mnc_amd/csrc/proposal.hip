@@ -16,13 +16,15 @@
 //   3. NMS      the bitmask + single-wave scan kernels of nms.hip, reading the boxes through the sorted index list and
 //               the candidate count from device memory, stopping at post_nms_topN survivors.                (:149-153)
 //   4. gather   rois[r] = (0, box[order[keep[r]]]).                                                           (:159-160)
-// expf on the device is not bit-identical to numpy's float32 exp, so decoded boxes may differ from the Python layer's in
-// the last ulp; the NMS decisions on the decoded boxes are bit-exact (tests teacher-force them).
+// exp: np_exp.h restates numpy's float32 exp loop bit for bit, and the decode is written in bbox_transform_inv's float32
+// operation order (-ffp-contract=off), so the decoded boxes -- and with them rois / rois_ext -- carry the same bits as the
+// reference's numpy Python layers on the same input blobs (tests/test_np_exp.py on the host, tests/test_gpu_engine.py on the GPU).
 #include <cfloat>
 
 #include <atomic>
 
 #include "mnc_internal.h"
+#include "np_exp.h"
 
 namespace mnc {
 
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
   const float widths = ax2 - ax1 + 1.0f, heights = ay2 - ay1 + 1.0f;
   const float ctr_x = ax1 + 0.5f * widths, ctr_y = ay1 + 0.5f * heights;
   const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
-  const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+  const float pw = np_exp_f32(dw) * widths, ph = np_exp_f32(dh) * heights;
   float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
   // clip_boxes, :110-119
   x1 = fmaxf(fminf(x1, im_w - 1.0f), 0.0f); y1 = fmaxf(fminf(y1, im_h - 1.0f), 0.0f);
@@ -223,7 +225,7 @@ __global__ void stage_bridge_kernel(const float* __restrict__ rois, const float*
   const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
   const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
   const float pcx = d[0] * widths + ctr_x, pcy = d[1] * heights + ctr_y;
-  const float pw = expf(d[2]) * widths, ph = expf(d[3]) * heights;
+  const float pw = np_exp_f32(d[2]) * widths, ph = np_exp_f32(d[3]) * heights;
   float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph, ox2 = pcx + 0.5f * pw, oy2 = pcy + 0.5f * ph;
   ox1 = fmaxf(fminf(ox1, im_w - 1.0f), 0.0f); oy1 = fmaxf(fminf(oy1, im_h - 1.0f), 0.0f);
   ox2 = fmaxf(fminf(ox2, im_w - 1.0f), 0.0f); oy2 = fmaxf(fminf(oy2, im_h - 1.0f), 0.0f);

@@ -1,9 +1,11 @@
 """GPU: the caffe-shaped Net (mnc_amd.engine) running the emitted 5-stage graph through the Python-layer API, blob by
 blob against the CPU oracle (oracle/net.py) on identical synthetic weights and inputs.
 
-Tolerance: north_star asks for 1e-3 on boxes / class scores / 21x21 masks.  Per blob we check max |diff| against
-1e-3 x the blob's dynamic range (probabilities and masks therefore to 1e-3 absolute, boxes to 1e-3 of ~1000 px; the
-measured values are 2-3 orders of magnitude tighter and are printed)."""
+Tolerance: north_star asks for 1e-3 on boxes / class scores / 21x21 masks.  The bars here are set from what is measured
+(every comparison is appended to gpurun_out/parity_report.txt): per blob max |diff| <= tol x the blob's dynamic range with
+tol = 1e-4 in fp32 mode (measured 1e-6 .. 2e-5; for probabilities and masks, whose range is 1, that is 1e-4 absolute),
+3e-4 in bf16x3 mode, 5e-3 in f16 mode (which does not claim the 1e-3 bar).  Boxes (rois, rois_ext) and NMS keeps are not
+held to a tolerance at all: they equal the reference's numpy layers bit for bit on the same input blobs."""
 import os
 
 import numpy as np
@@ -19,6 +21,11 @@ from oracle import net as onet
 pytestmark = pytest.mark.gpu
 mnc_amd.install_paths()
 
+# np.exp on float32 is numpy's own vector routine on every x86 build with AVX2/AVX512F (csrc/np_exp.h restates it); a build
+# without it falls back to libm's expf, and only then are decoded boxes compared with a tolerance
+_x = np.linspace(-3, 3, 4001, dtype=np.float32)
+NUMPY_SIMD_EXP = float((np.exp(_x) != np.exp(_x.astype(np.float64)).astype(np.float32)).mean()) > 0.1
+
 _UNUSED = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_3", "conv5_3", "rpn_output",
          "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "roi_interpolate_conv5", "mask_output", "mask_proposal",
          "mask_proposal_resize", "roi_interpolate_conv5_box", "roi_interpolate_conv5_mask", "fc6", "fc7", "fc7_mask",
@@ -26,7 +33,18 @@ _UNUSED = ["conv1_1", "conv1_2", "pool1", "conv2_2", "conv3_3", "pool3", "conv4_
          "mask_proposal_ext", "seg_cls_prob_ext", "bbox_pred_ext", "cls_prob_ext"]
 
 
-def _compare(net, ref, names, tol=1e-3):
+FP32_TOL, X3_TOL, F16_TOL = 1e-4, 3e-4, 5e-3
+
+
+def _log(lines):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write("# %s\n%s\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?"), "\n".join(lines)))
+
+
+def _compare(net, ref, names, tol=None):
+    tol = {"fp32": FP32_TOL, "bf16x3": X3_TOL, "f16": F16_TOL}[net.math] if tol is None else tol
     report, bad = [], []
     for n in names:
         b = net.blobs[n]
@@ -42,6 +60,7 @@ def _compare(net, ref, names, tol=1e-3):
         if not rel < tol:
             bad.append(report[-1])
     print("\n".join(report))
+    _log(report)
     assert not bad, "\n".join(bad)
 
 
@@ -52,7 +71,7 @@ HEAD_BLOBS = ["roi_interpolate_conv5", "mask_output", "mask_proposal", "mask_pro
               "cls_prob", "seg_cls_prob", "bbox_pred", "roi_interpolate_conv5_premax", "roi_mask_conv5"]
 
 
-def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None, head_tol=1e-3, trunk_tol=1e-3):
+def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=None, head_tol=None, trunk_tol=None):
     """Parity protocol for one net.forward() that has already run on (data, im_info).
 
     The cascade has two data-dependent host hops (proposal NMS, stage bridge arg-max).  A 1e-7 difference upstream can
@@ -60,8 +79,8 @@ def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=No
     right.  So each hop is teacher-forced, which is also how north_star words the bar ("bit-exact NMS keep indices" on
     the same inputs, 1e-3 on the float outputs):
       1. trunk + RPN blobs             device vs oracle from the same input                       (tolerance)
-      2. rois                          device == oracle ProposalLayer fed the DEVICE's RPN blobs   (bit-exact; with the
-                                       device-resident layer: candidates vs oracle to 1e-3, NMS keep bit-exact)
+      2. rois                          device == oracle ProposalLayer fed the DEVICE's RPN blobs   (bit-exact, Python-layer
+                                       path and device-resident layer alike)
       3. stage 2/3 blobs               device vs oracle head fed the device's rois                 (tolerance)
       4. rois_ext                      device == oracle StageBridge fed the device's blobs         (bit-exact)
       5. stage 4/5 blobs               device vs oracle head fed the device's rois_ext             (tolerance)"""
@@ -71,27 +90,29 @@ def check_forward(net, w, data, im_info, extra=(), trunk_fn=None, trunk_blobs=No
     _compare(net, ref, trunk_blobs or TRUNK_BLOBS, trunk_tol)
     g = lambda n: net.blobs[n]._host_read()
     rois = g("rois")
+    # rois: bit for bit the reference's ProposalLayer on the device's own RPN blobs -- for the Python-layer path and for the
+    # device-resident layer alike (its decode restates numpy's float32 exp, csrc/np_exp.h; tests/test_np_exp.py)
+    want_rois = ohost.proposal_forward(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
     if net._native_py:
-        # device-resident ProposalLayer: decoded candidates vs the oracle's (expf vs numpy exp: last-ulp differences
-        # allowed on the boxes, the score order must be identical), then the NMS teacher-forced on the device's candidates
         cb, cs = net.proposal_candidates()
         ob, osc = ohost.proposal_candidates(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
         assert cb.shape == ob.shape and np.array_equal(cs, osc.ravel())
-        assert err(cb, ob)[0] < 1e-3
-        keep = onative.nms_sorted(np.hstack((cb, cs[:, None])), 0.7)[:300]
-        assert rois.shape == (len(keep), 5) and np.array_equal(rois[:, 1:], cb[keep]) and not rois[:, 0].any()
-    else:
-        want_rois = ohost.proposal_forward(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
-        assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
+        if NUMPY_SIMD_EXP:
+            assert np.array_equal(cb, ob)
+        else:                                   # numpy built without its vector exp: np.exp is libm's expf here
+            assert err(cb, ob)[0] < 1e-3
+            keep = onative.nms_sorted(np.hstack((cb, cs[:, None])), 0.7)[:300]
+            want_rois = np.hstack((np.zeros((len(keep), 1), np.float32), cb[keep]))
+    assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
     h1 = {}
     onet.head(w, c5, rois, False, "", h1)
     _compare(net, h1, [b for b in HEAD_BLOBS + list(extra) if b in h1], head_tol)
     rois_ext = g("rois_ext")
     want_ext = ohost.stage_bridge_forward_test(rois, g("bbox_pred"), g("seg_cls_prob"), im_info)
-    if net._native_py:
-        assert rois_ext.shape == want_ext.shape and err(rois_ext, want_ext)[0] < 1e-3     # expf vs numpy exp
+    if net._native_py and not NUMPY_SIMD_EXP:
+        assert rois_ext.shape == want_ext.shape and err(rois_ext, want_ext)[0] < 1e-3
     else:
-        assert np.array_equal(rois_ext, want_ext)
+        assert rois_ext.shape == want_ext.shape and np.array_equal(rois_ext, want_ext)
     h2 = {}
     onet.head(w, c5, rois_ext, True, "_ext", h2)
     _compare(net, h2, [b + "_ext" for b in HEAD_BLOBS + list(extra) if b + "_ext" in h2], head_tol)
@@ -124,7 +145,7 @@ def test_reduced_net_blobwise(small, H, W, seed):
 def test_python_layer_path_matches_native_layers(small):
     """native_pylayers=False runs ProposalLayer / MaskLayer / StageBridgeLayer as real `caffe.Layer` Python objects (the
     drop-in API, 4 host hops); the default substitutes the device-resident kernels.  Both satisfy the parity protocol;
-    their rois agree to float rounding (expf) and everything downstream agrees to tolerance."""
+    their rois are identical (the device decode carries numpy's float32 exp bits) and everything downstream agrees."""
     import caffe
     from mnc_amd.engine import Net
     net, w = small
@@ -139,10 +160,10 @@ def test_python_layer_path_matches_native_layers(small):
     check_forward(netp, w, data, im_info)
     check_forward(net, w, data, im_info)
     a, b = net.blobs["rois"]._host_read(), netp.blobs["rois"]._host_read()
-    assert a.shape == b.shape and err(a, b)[0] < 1e-3
+    assert a.shape == b.shape and (np.array_equal(a, b) if NUMPY_SIMD_EXP else err(a, b)[0] < 1e-3)
     for n in ("seg_cls_prob", "mask_proposal", "rois_ext", "seg_cls_prob_ext", "mask_proposal_ext"):
         x, y = net.blobs[n]._host_read(), netp.blobs[n]._host_read()
-        assert x.shape == y.shape and err(x, y)[1] < 1e-3, n
+        assert x.shape == y.shape and (np.array_equal(x, y) if NUMPY_SIMD_EXP else err(x, y)[1] < 1e-3), n
     netp.close()
 
 
@@ -229,7 +250,7 @@ def test_full_vgg16_600x1000_f16_math(full, monkeypatch):
         data, im_info, scale = ohost.prepare_mnc_args(im)
         net.forward(data=data, im_info=im_info)
         assert net.blobs["rois"]._host_read().shape == (300, 5)
-        check_forward(net, w, data, im_info, head_tol=5e-3, trunk_tol=5e-3)
+        check_forward(net, w, data, im_info)
     finally:
         net.close()
 
@@ -338,14 +359,15 @@ def test_faster_rcnn_end2end_graph_and_det_task(tmp_path, monkeypatch):
         ref = onet.forward_frcnn(w, data, im_info)
         _compare(net, ref, TRUNK_BLOBS)
         g = lambda n: net.blobs[n]._host_read()
-        # device-resident ProposalLayer: candidates vs the oracle's (expf vs numpy exp: last-ulp box differences, identical
-        # score order), NMS keep bit-exact on the device's own candidates -- as in check_forward
+        # device-resident ProposalLayer == the reference's numpy layer on the device's own RPN blobs, as in check_forward
         rois = g("rois")
-        cb, cs = net.proposal_candidates()
-        ob, osc = ohost.proposal_candidates(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
-        assert cb.shape == ob.shape and np.array_equal(cs, osc.ravel()) and err(cb, ob)[0] < 1e-3
-        keep = onative.nms_sorted(np.hstack((cb, cs[:, None])), 0.7)[:300]
-        assert rois.shape == (len(keep), 5) and np.array_equal(rois[:, 1:], cb[keep]) and not rois[:, 0].any()
+        want_rois = ohost.proposal_forward(g("rpn_cls_prob_reshape"), g("rpn_bbox_pred"), im_info)
+        if NUMPY_SIMD_EXP:
+            assert rois.shape == want_rois.shape and np.array_equal(rois, want_rois)
+        else:
+            cb, cs = net.proposal_candidates()
+            keep = onative.nms_sorted(np.hstack((cb, cs[:, None])), 0.7)[:300]
+            assert rois.shape == (len(keep), 5) and np.array_equal(rois[:, 1:], cb[keep]) and not rois[:, 0].any()
         head = onet.head_frcnn(w, g("conv5_3"), rois)
         _compare(net, head, ["pool5", "fc6", "fc7", "cls_score", "bbox_pred", "cls_prob"])
     finally:
@@ -501,7 +523,6 @@ def test_resnet50_trunk_graph(math, monkeypatch):
             net.forward(data=data, im_info=im_info)
             blobs = ["conv1", "pool1", "res2a_branch2b", "res2a", "res2c", "res3a", "res3d", "res4a", "res4c", "res4f", "rpn_output",
                      "rpn_cls_prob_reshape", "rpn_bbox_pred"]
-            tol = 5e-3 if math == "f16" else 1e-3            # fp16 operands carry 11 bits
-            check_forward(net, w, data, im_info, trunk_fn=onet.trunk_resnet50, trunk_blobs=blobs, head_tol=tol, trunk_tol=tol)
+            check_forward(net, w, data, im_info, trunk_fn=onet.trunk_resnet50, trunk_blobs=blobs)
     finally:
         net.close()
