@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of the MNC 5-stage inference hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config vgg16|resnet50] [--math fp32|bf16x3|f16]
 
-A "step" is one pass of the whole hot path over one synthetic 600x1000 image per GPU (BASELINE configs[2] shape: VGG-16
-trunk, RPN + proposal NMS, 300 RoIs per stage through both head stages, un-scale/clip/concat, gpu_mask_voting of the
-600 instances on the 600x1000 canvas).  The image blob is resident in HBM before the timed region.  With N > 1 the
-images are sharded one per rank (weak scaling, no data-path collective) and every step ends with the RCCL gather of
-the padded [100, 447] instance block (box 4 + score + class + 21x21 mask) over xGMI, as north_star describes.
+`--gpus N` with N > 1 and no launcher in the environment re-executes itself under `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, so the plain command really starts N ranks, one per GPU (it fails
+loudly when the node has fewer devices than ranks).  Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank.
 
-The headline `value` is measured with fp32 MFMA arithmetic (--math fp32, BASELINE configs[1]); at N = 1 the same run
-also measures BASELINE configs[2] ("bf16 convs via MFMA": --math bf16x3, split-precision bf16 MFMA for the 3x3 convs and
-the large InnerProducts) and reports it under `alt_math`, with its feature-level difference from the fp32 run.
+A "step" is one pass of the whole hot path over one synthetic image per GPU, measured the way BASELINE.md section 3 asks
+(image H2D and result D2H inside the timed region):
+    a DIFFERENT uint8 600x1000 image every step (seeds 0..7 rotating, host memory)
+    -> upload + mean subtraction / layout on the GPU (tools/demo.py:prepare_mnc_args -> mnc_prep_image)
+    -> net.forward: VGG-16 trunk, RPN + proposal NMS, 300 RoIs through both head stages
+    -> im_detect's tail (un-scale / clip / concat) -> gpu_mask_voting of the 600 instances on the 600x1000 canvas
+    -> the voted masks / boxes / scores copied to host numpy arrays (N = 1), or
+       the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
+       device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
+Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
+The old protocol (same image resident in HBM, no upload) is reported next to it as `resident_input`.
+
+The headline `value` is measured with fp32 MFMA arithmetic (--math fp32, BASELINE configs[1]); at N = 1 the same run also
+measures BASELINE configs[2] ("bf16 convs via MFMA": bf16x3) and the f16 mode and reports them under `alt_math*`.
+`--config resnet50` measures BASELINE configs[4] (ResNet-50 C4 trunk, 800x1333, 1000 proposals, fp16 math) with the same
+step and the same JSON schema.
 
 One JSON line is printed by rank 0.  `roofline` is computed from HIP events recorded by the engine on ITS stream around
 every launch of the dominant kernel inside the timed region; `cpu_baseline` times the CPU oracle (torch-CPU restatement
@@ -21,6 +31,8 @@ of the graph + the reference's nms/mv code compiled for the CPU when oracle/_ref
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,160 +42,213 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-METRIC = "images/sec (600x1000, 300 RoIs) VGG16 MNC-5stage"
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MATRIX_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16, dense
+PEAK_BF16_MATRIX_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16 / _f16, dense
 PEAK_HBM_GBS = 8000.0
 DTYPE = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into hi+lo bf16, 3 bf16 MFMAs per product, f32 accumulate)",
          "f16": "f16 (3x3 convolutions and InnerProducts: operands rounded to fp16, f32 accumulate)"}
 MATH_NOTE = {"fp32": "fp32 MFMA", "bf16x3": "3x3 convs and large InnerProducts on the bf16 matrix pipe with split operands "
                                             "(fp32-class accuracy), everything else fp32",
-             "f16": "3x3 convs and large InnerProducts in fp16 with fp32 accumulation, everything else fp32"}
+             "f16": "convolutions and large InnerProducts in fp16 with fp32 accumulation, everything else fp32"}
+CONFIGS = {
+    "vgg16": {"metric": "images/sec (600x1000, 300 RoIs) VGG16 MNC-5stage", "hw": (600, 1000), "rois": 300, "math": "fp32",
+              "what": "VGG16 MNC 5-stage inference + gpu_mask_voting"},
+    "resnet50": {"metric": "images/sec (800x1333, 1000 RoIs) ResNet50-C4 MNC-5stage", "hw": (800, 1333), "rois": 1000,
+                 "math": "f16", "what": "ResNet-50 C4 trunk + MNC 5-stage heads + gpu_mask_voting (BASELINE configs[4]; no such "
+                                        "model in the reference)"},
+}
+N_IMAGES = 8                         # seeds 0..7
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--config", default="vgg16", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
-    p.add_argument("--math", default=os.environ.get("MNC_MATH", "fp32"), choices=["fp32", "bf16x3", "f16"],
-                   help="arithmetic of the dense contractions for the headline number (default fp32)")
-    p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 (BASELINE configs[2]) measurement")
-    p.add_argument("--host-results", action="store_true",
-                   help="round-trip boxes/masks/scores through numpy between forward and voting (cfg.TEST.DEVICE_RESULTS=False)")
+    p.add_argument("--math", default=os.environ.get("MNC_MATH"), choices=["fp32", "bf16x3", "f16"],
+                   help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
+    p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
+    p.add_argument("--no-resident", action="store_true", help="skip the secondary resident-input measurement")
     p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
     return p.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file under torch.distributed.run."""
+    from mnc_amd import _lib
+    have = _lib.device_count()
+    if args.dist_backend == "nccl" and have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this node has %d GPU(s); one rank per GPU is required" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    dist = None
-    torch = None
-    if world > 1:
+    conf = CONFIGS[args.config]
+    math = args.math or conf["math"]
+    launched = "WORLD_SIZE" in os.environ
+    dist = torch = None
+    on_gpu = args.dist_backend == "nccl"
+    from mnc_amd import _lib
+    ndev = _lib.device_count()
+    if on_gpu and ndev < (local + 1):
+        raise SystemExit("rank %d (local %d): only %d GPU(s) visible" % (rank, local, ndev))
+    dev_id = local if on_gpu else local % max(ndev, 1)
+    if launched:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(local)
+        if on_gpu:
+            torch.cuda.set_device(dev_id)
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     import _init_paths  # noqa: F401
     import caffe
     import demo
+    from mnc_amd import dist as mdist
     from mnc_amd import models, synth
+    from mnc_amd.engine import Net
     from mnc_config import cfg
     from transform.mask_transform import gpu_mask_voting
 
-    from mnc_amd import _lib
-    dev_id = local % max(_lib.device_count(), 1) if args.dist_backend != "nccl" else local
     caffe.set_mode_gpu()
     caffe.set_device(dev_id)
     cfg.GPU_ID = dev_id
-    proto = models.write_mnc_5stage_test_prototxt()
+    H, W = conf["hw"]
+    if args.config == "resnet50":
+        cfg.TEST.SCALES, cfg.TRAIN.MAX_SIZE, cfg.TEST.RPN_POST_NMS_TOP_N = (H,), W, conf["rois"]
+        proto = models.write_mnc_resnet50_test_prototxt()
+    else:
+        proto = models.write_mnc_5stage_test_prototxt()
     weights = synth.synthetic_weights(proto, seed=0)
-    im = np.random.default_rng(rank).integers(0, 256, (600, 1000, 3), dtype=np.uint8)   # BASELINE.md section 3 inputs
-    from transform.bbox_transform import clip_boxes
-    from mnc_amd import dist as mdist
-    from mnc_amd.engine import Net
-    on_gpu = args.dist_backend == "nccl"
-    gatherer = mdist.InstanceGatherer(device="cuda" if on_gpu else None) if world > 1 else None
+    # BASELINE.md section 3 inputs: uint8 images ~ U{0..255}, seeds 0..7; rank r starts the rotation at image r
+    images = [np.random.default_rng(s).integers(0, 256, (H, W, 3), dtype=np.uint8) for s in range(N_IMAGES)]
+    nms_t, iou_t = float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH)
 
-    def measure(math, steps, warmup):
-        """Build the net in `math` mode, run warmup + steps timed steps; returns (elapsed_s, phase_ms, records, last)."""
+    def measure(math, steps, warmup, resident_steps=0):
+        """Build the net in `math` mode; warmup + `steps` timed steps of the full protocol (upload .. results on the host), then
+        optionally `resident_steps` steps of the old resident-input protocol.  -> dict."""
         net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
-        # input resident in HBM before the timed region: prepare once, upload once, forward() re-uses the device blob
-        kwargs, im_scales = demo.prepare_mnc_args(im, net)
-        net.blobs["data"].set_host(kwargs["data"])
-        net.blobs["im_info"].set_host(kwargs["im_info"])
-        net.blobs["data"].dev_in("plain")
-        scale = np.float32(im_scales[0])
-        phase_ms = {"forward": 0.0, "tail": 0.0, "voting": 0.0, "gather": 0.0}
-        device_results = bool(cfg.TEST.get("DEVICE_RESULTS", True)) and not args.host_results
+        gatherer = mdist.InstanceGatherer(net=net, rank=rank, world=world) if (launched and on_gpu) else \
+            mdist.InstanceGatherer(device=None) if launched else None
+        phase = {"prep+forward+tail": 0.0, "voting": 0.0, "gather": 0.0, "results_to_host": 0.0}
+        last = {}
 
-        def step():
+        def step(k):
+            im = images[(rank + k) % N_IMAGES]
             t_a = time.perf_counter()
-            net.forward()
+            boxes, masks, scores = demo.im_detect(im, net)          # H2D + device prep + forward + device tail (DeviceArrays)
             t_b = time.perf_counter()
-            # demo.im_detect's tail (un-scale, clip, stack both stages): on the device by default, as tools/demo.py runs it
-            if device_results:
-                all_boxes, masks, scores = net.detect_tail(scale, im.shape)
-            else:
-                boxes = []
-                for name in ("rois", "rois_ext"):
-                    r = net.blobs[name]._host_read()
-                    boxes.append(clip_boxes(r[:, 1:5] / scale, im.shape)[0])
-                masks = np.concatenate((net.blobs["mask_proposal"]._host_read(), net.blobs["mask_proposal_ext"]._host_read()), 0)
-                scores = np.concatenate((net.blobs["seg_cls_prob"]._host_read(), net.blobs["seg_cls_prob_ext"]._host_read()), 0)
-                all_boxes = np.concatenate(boxes, 0)
+            blk = net.vote_instances(boxes, masks, scores, 21, 100, im.shape[1], im.shape[0], nms_t, iou_t)
             t_c = time.perf_counter()
-            rm, rb = gpu_mask_voting(masks, all_boxes, scores, 21, 100, im.shape[1], im.shape[0])
-            t_d = time.perf_counter()
-            if world > 1:
-                rec, _ = mdist.pack_instances(rm, rb)
-                gatherer.gather(rec)
+            if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks, same stream
+                gatherer.gather_block(blk)
+                t_d = time.perf_counter()
+                last["gathered"] = gatherer.fetch()                 # [world, 100, 447] on the host
+            elif gatherer is not None:                              # gloo functional path (host tensors)
+                rec, _ = mdist.pack_instances(*blk.lists())
+                t_d = time.perf_counter()
+                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(rec)])
+            else:
+                t_d = t_c
+                last["masks"], last["boxes"] = blk.lists()           # numpy lists per class, as gpu_mask_voting returns them
             t_e = time.perf_counter()
-            phase_ms["forward"] += 1e3 * (t_b - t_a); phase_ms["tail"] += 1e3 * (t_c - t_b)
-            phase_ms["voting"] += 1e3 * (t_d - t_c); phase_ms["gather"] += 1e3 * (t_e - t_d)
-            return masks, all_boxes, scores
+            phase["prep+forward+tail"] += t_b - t_a; phase["voting"] += t_c - t_b
+            phase["gather"] += t_d - t_c; phase["results_to_host"] += t_e - t_d
 
         def fence():
             net.sync()
-            if world > 1:
+            if launched:
                 if on_gpu:
                     torch.cuda.synchronize()
                 dist.barrier()
                 if on_gpu:
                     torch.cuda.synchronize()
+                net.sync()
 
-        for _ in range(warmup):
-            step()
+        for k in range(warmup):
+            step(k)
         events = not args.no_events
         fence()
         if events:
             net.profile(1 if args.all_events else 2)
-        for k in phase_ms:
-            phase_ms[k] = 0.0
+        for k in phase:
+            phase[k] = 0.0
         t0 = time.perf_counter()
-        for _ in range(steps):
-            last = step()
+        for k in range(steps):
+            step(warmup + k)
         fence()
         elapsed = time.perf_counter() - t0
         records = net.profile_records() if events else []
         if events:
             net.profile(False)
-        feats = {n: net.blobs[n]._host_read().copy() for n in ("conv5_3", "rpn_bbox_pred", "rpn_cls_prob_reshape")}
-        net.close()
-        return elapsed, phase_ms, records, last, feats
+        out = {"elapsed": elapsed, "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()}, "records": records,
+               "rccl_version": getattr(gatherer, "rccl_version", None)}
+        out["feats"] = {n: net.blobs[n]._host_read().copy() for n in ("rpn_bbox_pred", "rpn_cls_prob_reshape")}
+        if resident_steps:
+            # the round-1 protocol, for comparison: ONE image, blob already in HBM, no upload; results still come down
+            im = images[rank % N_IMAGES]
+            kwargs, im_scales = demo.prepare_mnc_args(im, net)
+            net.forward(**kwargs)
+            scale = np.float32(im_scales[0])
 
-    def summarise(math, steps, elapsed, phase_ms, records):
-        out = {"host_phase_ms_per_image": {k: round(v / steps, 3) for k, v in phase_ms.items()}}
+            def rstep():
+                net.forward()
+                b, m, s = net.detect_tail(scale, im.shape)
+                gpu_mask_voting(m, b, s, 21, 100, im.shape[1], im.shape[0])
+            for _ in range(3):
+                rstep()
+            net.sync()
+            t0 = time.perf_counter()
+            for _ in range(resident_steps):
+                rstep()
+            net.sync()
+            out["resident_s"] = (time.perf_counter() - t0) / resident_steps
+        if gatherer is not None:
+            gatherer.close()
+        net.close()
+        return out
+
+    def summarise(steps, m):
+        out = {"host_phase_ms_per_image": {k: round(v, 3) for k, v in m["phase_ms"].items()}}
+        records = m["records"]
         if records:
             agg = {}
             for name, kms, fl, by in records:
                 a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
                 a[0] += 1; a[1] += kms; a[2] += fl; a[3] += by
             out["kernel_ms_per_image"] = {k: round(v[1] / steps, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-            dom = max(agg.items(), key=lambda kv: kv[1][1])
-            name, (cnt, tot_ms, tot_fl, tot_by) = dom
+            name, (cnt, tot_ms, tot_fl, tot_by) = max(agg.items(), key=lambda kv: kv[1][1])
             if tot_fl > 0:
                 ach = tot_fl / (tot_ms * 1e-3) / 1e12
-                x3 = "bf16x3" in name
-                peak = PEAK_BF16_MATRIX_TFLOPS / 3.0 if x3 else PEAK_FP32_MATRIX_TFLOPS
+                x3, f16 = "bf16x3" in name, "f16" in name
+                peak = PEAK_BF16_MATRIX_TFLOPS / 3.0 if x3 else PEAK_BF16_MATRIX_TFLOPS if f16 else PEAK_FP32_MATRIX_TFLOPS
+                basis = ("bf16 dense MFMA peak %.0f TFLOP/s / 3 bf16 products per fp32-class product" % PEAK_BF16_MATRIX_TFLOPS
+                         if x3 else "fp16 dense MFMA peak (v_mfma_f32_32x32x16_f16)" if f16 else
+                         "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)")
                 out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                    "frac": ach / peak, "traffic": None, "launches_per_image": cnt / steps,
                                    "avg_launch_ms": tot_ms / cnt, "algorithmic_gflop_per_launch": tot_fl / cnt / 1e9,
-                                   "peak_basis": ("bf16 dense MFMA peak %.0f TFLOP/s / 3 bf16 products per fp32-class product"
-                                                  % PEAK_BF16_MATRIX_TFLOPS) if x3 else
-                                                 "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)"}
+                                   "peak_basis": basis}
             else:
                 ach = tot_by / (tot_ms * 1e-3) / 1e9
                 out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -192,53 +257,57 @@ def main():
             out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
         return out
 
-    math = args.math
-    elapsed, phase_ms, records, last, feats = measure(math, args.steps, args.warmup)
-    if world > 1:
+    want_resident = world == 1 and not args.no_resident
+    m = measure(math, args.steps, args.warmup, resident_steps=min(args.steps, 50) if want_resident else 0)
+    elapsed = m["elapsed"]
+    ranks = [{"rank": rank, "device": dev_id}]
+    if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        box = [None] * world
+        dist.all_gather_object(box, ranks[0])
+        ranks = box
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         out = {
-            "metric": METRIC, "value": world * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
+            "metric": conf["metric"], "value": world * args.steps / elapsed, "unit": "images/s",
+            "n_gpus": dist.get_world_size() if launched else 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[math], "data": "synthetic",
-            "config": {"workload": "VGG16 MNC 5-stage inference + gpu_mask_voting, one 600x1000 image per GPU per step, "
-                                   "300 RoIs per stage (600 instances voted on a 600x1000 canvas), %s, "
-                                   "seeded synthetic weights" % MATH_NOTE[math], "images_per_step": world,
-                       "rois_per_stage": 300, "math": math,
-                       "parallelism": "images sharded 1/GPU; RCCL all_gather of [100,447] instance blocks"
-                       if world > 1 else "single GPU"},
+            "config": {"workload": "%s, one %dx%d uint8 image per GPU per step (8 seeded images rotating), %d RoIs per stage "
+                                   "(%d instances voted on a %dx%d canvas); H2D + device prep + D2H of the voted instances "
+                                   "included in the timed region; %s; seeded synthetic weights (no trained model here: "
+                                   "mAP unverifiable)" % (conf["what"], H, W, conf["rois"], 2 * conf["rois"], H, W,
+                                                          MATH_NOTE[math]),
+                       "images_per_step": world, "rois_per_stage": conf["rois"], "math": math,
+                       "parallelism": ("images sharded 1/GPU, %d ranks; ncclAllGather of [100,447] instance blocks on the "
+                                       "engine stream" % world) if world > 1 else
+                                      ("single GPU (1 rank under the launcher, RCCL gather of the block included)" if launched
+                                       else "single GPU")},
+            "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
         }
-        out.update(summarise(math, args.steps, elapsed, phase_ms, records))
-        if world == 1 and math == "fp32" and not args.no_alt_math:
-            # BASELINE configs[2] ("bf16 convs via MFMA") measured in the same run, next to the fp32 headline: same image,
-            # same weights, same step; its outputs are compared with the fp32 run's (trunk features, and the head outputs
-            # that do not depend on which boxes survived NMS)
-            e2, p2, r2, last2, feats2 = measure("bf16x3", args.steps, args.warmup)
-            alt = {"math": "bf16x3", "dtype": DTYPE["bf16x3"], "value": args.steps / e2, "unit": "images/s",
-                   "ms_per_step": 1e3 * e2 / args.steps}
-            alt.update(summarise("bf16x3", args.steps, e2, p2, r2))
-            alt["max_rel_diff_vs_fp32"] = {
-                n: float(np.abs(feats2[n] - feats[n]).max() / max(np.abs(feats[n]).max(), 1e-30))
-                for n in ("conv5_3", "rpn_bbox_pred", "rpn_cls_prob_reshape")}       # blobs that do not depend on which RoIs survived
-            out["alt_math"] = alt
-            # the fp16 mode (BASELINE configs[4] names fp16): 3x3 convolutions and large InnerProducts with one fp16 product
-            # per term; compared with the fp32 run on the blobs that do not depend on which RoIs survived
-            e3, p3, r3, last3, feats3 = measure("f16", args.steps, args.warmup)
-            alt16 = {"math": "f16", "dtype": DTYPE["f16"], "value": args.steps / e3, "unit": "images/s",
-                     "ms_per_step": 1e3 * e3 / args.steps}
-            alt16.update({k: v for k, v in summarise("f16", args.steps, e3, p3, r3).items() if k != "roofline"})
-            alt16["max_rel_diff_vs_fp32"] = {
-                n: float(np.abs(feats3[n] - feats[n]).max() / max(np.abs(feats[n]).max(), 1e-30))
-                for n in ("conv5_3", "rpn_bbox_pred", "rpn_cls_prob_reshape")}
-            out["alt_math_f16"] = alt16
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(weights, im, args.cpu_images)
+        out.update(summarise(args.steps, m))
+        if "resident_s" in m:
+            out["resident_input"] = {"value": 1.0 / m["resident_s"], "unit": "images/s", "ms_per_step": 1e3 * m["resident_s"],
+                                     "protocol": "round-1 protocol: one image, input blob resident in HBM, no upload / device "
+                                                 "prep; voted results copied to the host"}
+        if world == 1 and not launched and args.config == "vgg16" and math == "fp32" and not args.no_alt_math:
+            # BASELINE configs[2] ("bf16 convs via MFMA") and the fp16 mode measured in the same run, same protocol; their RPN
+            # outputs on the LAST image are compared with the fp32 run's (blobs that do not depend on which RoIs survived)
+            for key, alt in (("alt_math", "bf16x3"), ("alt_math_f16", "f16")):
+                m2 = measure(alt, args.steps, args.warmup)
+                a = {"math": alt, "dtype": DTYPE[alt], "value": args.steps / m2["elapsed"], "unit": "images/s",
+                     "ms_per_step": 1e3 * m2["elapsed"] / args.steps}
+                a.update(summarise(args.steps, m2))
+                a["max_rel_diff_vs_fp32"] = {n: float(np.abs(m2["feats"][n] - m["feats"][n]).max() /
+                                                      max(np.abs(m["feats"][n]).max(), 1e-30)) for n in m["feats"]}
+                out[key] = a
+        if world == 1 and not launched and not args.no_cpu_baseline and args.config == "vgg16":
+            out["cpu_baseline"] = cpu_baseline(weights, images[0], args.cpu_images)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -291,7 +360,7 @@ def cpu_baseline(weights, im, n_images):
         one()
     dt = (time.perf_counter() - t0) / n_images
     return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d x the same 600x1000 image after 1 warm-up: torch-CPU (%d threads) restatement of the Caffe graph "
+            "sample": "%d x one 600x1000 image after 1 warm-up: torch-CPU (%d threads) restatement of the Caffe graph "
                       "(Caffe itself is not buildable here) + %s for nms/mask voting"
                       % (n_images, cores, "the reference's nms_kernel.cu/mv_kernel.cu compiled for the CPU (oracle/_ref)"
                          if use_ref else "oracle/mnc_oracle.c"),

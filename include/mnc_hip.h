@@ -89,14 +89,15 @@ MNC_API void _mv(const float* all_boxes, const float* all_masks, const int all_b
                  const int result_num, float* finalize_output_mask, int* finalize_output_box, const int device_id);
 
 /* gpu_mask_voting in ONE call (lib/transform/mask_transform.py:213-286): per-class NMS (batched on the device) -> global
- * score threshold -> candidate sets {IoU_f64 >= iou_thresh} with class-score weights normalised by a sequential float32 sum
- * (python's sum(), :266) -> fused mask voting kernels.  All host pointers.
+ * score threshold -> candidate sets {IoU_f64 >= iou_thresh} with class-score weights divided by float32(sequential float64 sum)
+ * (python's sum() under the numpy 1.x the reference ran on, :266) -> fused mask voting kernels.  All host pointers.
  *   boxes [n][4] f32 (original-image pixels), masks [n][S][S] f32, scores [n][num_classes] f32 (column 0 = background),
  *   order [num_classes-1][n] i32: for class c+1, box indices by descending scores[:,c+1] (the caller's argsort()[::-1],
  *         gpu_nms.pyx:26), or NULL: the library orders each class itself (on the device) exactly as
  *         np.argsort(-scores[:, c+1], kind="stable") does -- ties in index order, NaN last.
- * Order, NMS, candidate sets (double-precision IoU) and voting all run on the device; the host only picks the global
- * threshold and the result rows between two stream synchronisations.
+ * Order, NMS, the global threshold, result rows, candidate sets (double-precision IoU) and voting all run on the device as one
+ * asynchronous launch sequence; the host copies the inputs up and the result records down.
+ * Limit: (num_classes-1) * min(max_per_image, n) <= 8192 kept boxes.
  * Outputs (capacity (num_classes-1)*min(max_per_image, n) rows): out_mask [R][S][S], out_box [R][4] i32, out_score [R],
  * class_count [num_classes-1] (rows per class, in class order), *result_num = R.
  * Bit-identical to running nms.gpu_nms x (num_classes-1), utils.cython_bbox.bbox_overlaps and nms.mv.mv as the reference does. */
@@ -129,6 +130,12 @@ MNC_API int mnc_h2d(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t byte
 MNC_API int mnc_d2h(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes);   /* stream-ordered + sync */
 MNC_API int mnc_d2d(mnc_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);      /* stream-ordered, async */
 MNC_API int mnc_dev_zero(mnc_ctx* ctx, void* d_ptr, size_t bytes);
+/* Page-locked host memory for the image that goes up and the instance records that come down, and the stream-ordered copies
+ * that do NOT synchronise (from / to pinned memory they are truly asynchronous; the caller synchronises with mnc_ctx_sync). */
+MNC_API int mnc_host_alloc(mnc_ctx* ctx, size_t bytes, void** host_ptr);
+MNC_API int mnc_host_free(mnc_ctx* ctx, void* host_ptr);
+MNC_API int mnc_h2d_async(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t bytes);
+MNC_API int mnc_d2h_async(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's `roofline` numbers come from here).
  * enable=1 records a start/stop event pair around every kernel launched through the context; enable=2 only around the
@@ -289,6 +296,17 @@ MNC_API int mnc_mask_voting_dev(mnc_ctx* ctx, const float* d_boxes, const float*
                                 int num_classes, int mask_size, int max_per_image, float nms_thresh, float iou_thresh,
                                 int image_height, int image_width, float* out_mask, int* out_box, float* out_score,
                                 int* class_count, int* result_num);
+/* gpu_mask_voting with inputs AND outputs on the device, fully asynchronous on ctx's stream (no host decision, no
+ * synchronisation): the whole-image path's last stage, and the block the multi-GPU path gathers.
+ *   d_records [record_cap][6 + S*S] float32: (x1, y1, x2, y2, score, class id 1..num_classes-1, S*S mask values) of the
+ *             result rows in the reference's order (class-major, keep order); rows past the result count are zero (class 0).
+ *   d_counts  [num_classes] int32: [0] = R, the number of result rows (> max_per_image only when scores tie at the global
+ *             threshold; rows >= record_cap are not written), [c] = rows of class c.
+ * The global threshold and the result rows (mask_transform.py:242-258) are chosen by a kernel (np.sort()[::-1] order, NaN
+ * first).  Limits: n <= 4096, (num_classes-1) * min(max_per_image, n) <= 8192.  Records are bit-identical to mnc_mask_voting. */
+MNC_API int mnc_vote_instances(mnc_ctx* ctx, const float* d_boxes, const float* d_masks, const float* d_scores, int n,
+                               int num_classes, int mask_size, int max_per_image, float nms_thresh, float iou_thresh,
+                               int image_height, int image_width, float* d_records, int record_cap, int* d_counts);
 /* The tail of im_detect on the device (tools/demo.py:84-100, lib/caffeWrapper/TesterWrapper.py:240-260): d_boxes
  * [R1+R2][4] = clip(rois[:, 1:5] / scale, image) of stage-1 rois followed by stage-2 rois (float32 division, clamp to
  * [0, W-1] x [0, H-1] as transform/bbox_transform.py:clip_boxes). */
@@ -305,6 +323,21 @@ MNC_API int mnc_proposal_candidates(mnc_ctx* ctx, float* boxes_host, float* scor
  * may be column slices (row strides ld_bbox / ld_probs). */
 MNC_API int mnc_stage_bridge(mnc_ctx* ctx, const float* d_rois, const float* d_bbox_pred, int ld_bbox, const float* d_probs,
                              int ld_probs, int R, int K, float im_h, float im_w, float* d_rois_ext);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-GPU (the reference is single-GPU: batch is 1 per forward, lib/pylayer/proposal_layer.py:65).  Images are
+ * sharded one per rank, one process and one context per GPU, weights replicated, no data-path collective.  The only exchange
+ * is the all-gather of every rank's instance records (mnc_vote_instances' d_records, [100][447] float32 by default) issued as
+ * ncclAllGather ON THE CONTEXT'S STREAM, device pointer to device pointer.  librccl is loaded at run time.
+ *   mnc_comm_unique_id  rank 0 creates the 128-byte ncclUniqueId; the host program carries it to the other ranks.
+ *   mnc_comm_init       ncclCommInitRank for this context's device (collective: every rank calls it).
+ *   mnc_gather_instances d_recv [nranks][floats_per_rank] <- every rank's d_send [floats_per_rank]; asynchronous.
+ * ------------------------------------------------------------------------------------------------------------- */
+MNC_API int mnc_comm_unique_id(void* id_out, int capacity_bytes);
+MNC_API int mnc_comm_init(mnc_ctx* ctx, const void* id, int nranks, int rank);
+MNC_API int mnc_comm_info(mnc_ctx* ctx, int* nranks, int* rank, int* rccl_version);
+MNC_API int mnc_gather_instances(mnc_ctx* ctx, const float* d_send, float* d_recv, size_t floats_per_rank);
+MNC_API int mnc_comm_destroy(mnc_ctx* ctx);
 
 #ifdef __cplusplus
 }

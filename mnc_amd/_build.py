@@ -49,8 +49,14 @@ def build(force=False, verbose=False):
     base = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
             "-Wno-unused-function"]
 
+    hdr_mtime = max(os.path.getmtime(p) for p in
+                    [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] +
+                    [os.path.join(HERE, "..", "include", "mnc_hip.h"), os.path.abspath(__file__)])
+
     def one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if not force and os.path.isfile(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), hdr_mtime):
+            return obj
         cmd = base + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -62,7 +68,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(one, sources()))
     tmp = LIB + ".tmp"
-    r = subprocess.run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs, capture_output=True, text=True)
+    r = subprocess.run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     os.replace(tmp, LIB)

@@ -109,6 +109,8 @@ int mnc_ctx_destroy(mnc_ctx* ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->proposal) mnc::proposal_state_free(ctx->proposal);
+  if (ctx->vote_ws) (void)hipFree(ctx->vote_ws);
+  if (ctx->comm) mnc::comm_free(ctx);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   clear_error();
@@ -147,6 +149,42 @@ int mnc_dev_free(mnc_ctx* ctx, void* d_ptr) {
   if (!d_ptr) return MNC_OK;
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   MNC_HIP_TRY(hipFree(d_ptr));
+  return MNC_OK;
+}
+
+int mnc_host_alloc(mnc_ctx* ctx, size_t bytes, void** host_ptr) {
+  MNC_REQUIRE(ctx && host_ptr, "mnc_host_alloc: null pointer");
+  *host_ptr = nullptr;
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
+  hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("mnc_host_alloc: hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MNC_ERR_NOMEM;
+  }
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_host_free(mnc_ctx* ctx, void* host_ptr) {
+  MNC_REQUIRE(ctx, "mnc_host_free: null context");
+  if (!host_ptr) return MNC_OK;
+  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  MNC_HIP_TRY(hipHostFree(host_ptr));
+  return MNC_OK;
+}
+
+int mnc_h2d_async(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t bytes) {
+  MNC_REQUIRE(ctx && (bytes == 0 || (d_dst && src_host)), "mnc_h2d_async: null pointer");
+  if (bytes == 0) return MNC_OK;
+  MNC_HIP_TRY(hipMemcpyAsync(d_dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_d2h_async(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes) {
+  MNC_REQUIRE(ctx && (bytes == 0 || (dst_host && d_src)), "mnc_d2h_async: null pointer");
+  if (bytes == 0) return MNC_OK;
+  MNC_HIP_TRY(hipMemcpyAsync(dst_host, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   return MNC_OK;
 }
 

@@ -34,6 +34,9 @@ struct mnc_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   void* proposal = nullptr;   // mnc_proposal_state (proposal.hip), created on first use
+  void* vote_ws = nullptr;    // gpu_mask_voting scratch (mv.hip), grown on demand
+  size_t vote_ws_bytes = 0;
+  void* comm = nullptr;       // RCCL communicator state (comm.hip), set by mnc_comm_init
 };
 
 namespace mnc {
@@ -125,7 +128,9 @@ struct LegacyWs {
   void* buf = nullptr;
   size_t cap = 0;
 };
-int legacy_ws(int device_id, size_t bytes, LegacyWs** out);  // nms.hip
+// Returns the device's workspace with its mutex HELD in *lock (taken before the buffer may be re-allocated: ctypes releases
+// the GIL, so two host threads may be inside _nms / _mv / mnc_mask_voting on one device) and at least `bytes` of buffer.
+int legacy_ws(int device_id, size_t bytes, LegacyWs** out, std::unique_lock<std::mutex>* lock);  // nms.hip
 
 // launchers shared between translation units (all asynchronous on `stream`, pointers are device pointers)
 int nms_mask_launch(hipStream_t stream, const float* d_boxes, const int* d_order, int n, int dim, float thr,
@@ -138,6 +143,7 @@ int nms_mask_launch_indirect(hipStream_t stream, const float* d_boxes, const int
 int nms_scan_launch_indirect(hipStream_t stream, const unsigned long long* d_mask, const int* d_n, int n_cap, int max_keep,
                              int* d_keep, int* d_num);
 void proposal_state_free(void* state);  // proposal.hip
+void comm_free(mnc_ctx* ctx);           // comm.hip
 // out = act(sum of the ksplit partial c8 tensors + bias)  (conv.hip; shared with conv_x3.hip)
 void conv_splitk_reduce_launch(hipStream_t stream, const float* d_part, const float* d_bias, float* d_out, int H, int W,
                                int Cout, int ksplit, int relu);

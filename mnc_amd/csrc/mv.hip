@@ -97,110 +97,121 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // bounds: [R][4] = (min x, min y, max x, max y), pre-set to (INT_MAX, INT_MAX, -1, -1).
+// Result rows: r = blockIdx.x, blockIdx.x + gridDim.x, ... < R, where R = *rcount when the row count lives on the device (the
+// asynchronous voting path picks the rows in mv_select_kernel and never tells the host) and the argument R otherwise.
 __global__ __launch_bounds__(256) void mv_bounds_kernel(const float* __restrict__ boxes, int box_dim,
                                                         const float* __restrict__ masks, int S,
                                                         const int* __restrict__ inds, const int* __restrict__ begins,
                                                         const int* __restrict__ ends, const float* __restrict__ wts,
-                                                        int H, int W, int* __restrict__ bounds) {
+                                                        int H, int W, const int* __restrict__ rcount, int R,
+                                                        int* __restrict__ bounds) {
   __shared__ CandLds cl;
   __shared__ int red[4][4];
   __shared__ int ubox[4];
-  const int r = blockIdx.x;
-  const int c0 = begins[r], c1 = ends[r];
-  const int nc = c1 - c0;
-  if (nc <= 0) return;
-  const bool in_lds = nc <= kMaxCandLds;
-  if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
-  if (threadIdx.x == 0) { ubox[0] = INT_MAX; ubox[1] = INT_MAX; ubox[2] = -1; ubox[3] = -1; }
-  __syncthreads();
-  // union of the candidates' pixel extents: pixel w is inside box iff x1 <= w <= x2 (float compare, :52)
-  {
+  const int Rv = rcount ? *rcount : R;
+  for (int r = blockIdx.x; r < Rv; r += gridDim.x) {
+    __syncthreads();                      // the previous row's LDS contents are dead from here on
+    const int c0 = begins[r], c1 = ends[r];
+    const int nc = c1 - c0;
+    if (nc <= 0) continue;
+    const bool in_lds = nc <= kMaxCandLds;
+    if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
+    if (threadIdx.x == 0) { ubox[0] = INT_MAX; ubox[1] = INT_MAX; ubox[2] = -1; ubox[3] = -1; }
+    __syncthreads();
+    // union of the candidates' pixel extents: pixel w is inside box iff x1 <= w <= x2 (float compare, :52)
+    {
+      int lx = INT_MAX, ly = INT_MAX, hx = -1, hy = -1;
+      for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+        float x1, y1, x2, y2;
+        if (in_lds) { x1 = cl.x1[i]; y1 = cl.y1[i]; x2 = cl.x2[i]; y2 = cl.y2[i]; }
+        else { const float* b = boxes + (long)inds[c0 + i] * box_dim; x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3]; }
+        // conservative integer hull, clipped to the canvas
+        const int ax = max(0, (int)floorf(x1)), ay = max(0, (int)floorf(y1));
+        const int bx = min(W - 1, (int)ceilf(x2)), by = min(H - 1, (int)ceilf(y2));
+        if (ax <= bx && ay <= by) { lx = min(lx, ax); ly = min(ly, ay); hx = max(hx, bx); hy = max(hy, by); }
+      }
+      lx = wave_min(lx); ly = wave_min(ly); hx = wave_max(hx); hy = wave_max(hy);
+      if ((threadIdx.x & 63) == 0) {
+        atomicMin(&ubox[0], lx); atomicMin(&ubox[1], ly); atomicMax(&ubox[2], hx); atomicMax(&ubox[3], hy);
+      }
+    }
+    __syncthreads();
+    const int ux1 = ubox[0], uy1 = ubox[1], ux2 = ubox[2], uy2 = ubox[3];
+    if (ux2 < ux1 || uy2 < uy1) continue;
+    const int uw = ux2 - ux1 + 1, uh = uy2 - uy1 + 1;
+    // this block's slab of rows
+    const int rows_per = (uh + gridDim.y - 1) / gridDim.y;
+    const int ya = uy1 + blockIdx.y * rows_per, yb = min(uy2 + 1, ya + rows_per);
     int lx = INT_MAX, ly = INT_MAX, hx = -1, hy = -1;
-    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
-      float x1, y1, x2, y2;
-      if (in_lds) { x1 = cl.x1[i]; y1 = cl.y1[i]; x2 = cl.x2[i]; y2 = cl.y2[i]; }
-      else { const float* b = boxes + (long)inds[c0 + i] * box_dim; x1 = b[0]; y1 = b[1]; x2 = b[2]; y2 = b[3]; }
-      // conservative integer hull, clipped to the canvas
-      const int ax = max(0, (int)floorf(x1)), ay = max(0, (int)floorf(y1));
-      const int bx = min(W - 1, (int)ceilf(x2)), by = min(H - 1, (int)ceilf(y2));
-      if (ax <= bx && ay <= by) { lx = min(lx, ax); ly = min(ly, ay); hx = max(hx, bx); hy = max(hy, by); }
+    const long npx = (long)uw * max(0, yb - ya);
+    for (long p = threadIdx.x; p < npx; p += blockDim.x) {
+      const int h = ya + (int)(p / uw), w = ux1 + (int)(p % uw);
+      const float v = in_lds ? aggregate_px(cl, nc, masks, S, h, w)
+                             : aggregate_px_global(boxes, box_dim, masks, inds, wts, c0, c1, S, h, w);
+      if (v > 0.4f) {  // BINARIZE_THRESH, strict (mv_kernel.cu:13, :121, :136)
+        lx = min(lx, w); hx = max(hx, w); ly = min(ly, h); hy = max(hy, h);
+      }
     }
     lx = wave_min(lx); ly = wave_min(ly); hx = wave_max(hx); hy = wave_max(hy);
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(&ubox[0], lx); atomicMin(&ubox[1], ly); atomicMax(&ubox[2], hx); atomicMax(&ubox[3], hy);
-    }
-  }
-  __syncthreads();
-  const int ux1 = ubox[0], uy1 = ubox[1], ux2 = ubox[2], uy2 = ubox[3];
-  if (ux2 < ux1 || uy2 < uy1) return;
-  const int uw = ux2 - ux1 + 1, uh = uy2 - uy1 + 1;
-  // this block's slab of rows
-  const int rows_per = (uh + gridDim.y - 1) / gridDim.y;
-  const int ya = uy1 + blockIdx.y * rows_per, yb = min(uy2 + 1, ya + rows_per);
-  int lx = INT_MAX, ly = INT_MAX, hx = -1, hy = -1;
-  const long npx = (long)uw * max(0, yb - ya);
-  for (long p = threadIdx.x; p < npx; p += blockDim.x) {
-    const int h = ya + (int)(p / uw), w = ux1 + (int)(p % uw);
-    const float v = in_lds ? aggregate_px(cl, nc, masks, S, h, w)
-                           : aggregate_px_global(boxes, box_dim, masks, inds, wts, c0, c1, S, h, w);
-    if (v > 0.4f) {  // BINARIZE_THRESH, strict (mv_kernel.cu:13, :121, :136)
-      lx = min(lx, w); hx = max(hx, w); ly = min(ly, h); hy = max(hy, h);
-    }
-  }
-  lx = wave_min(lx); ly = wave_min(ly); hx = wave_max(hx); hy = wave_max(hy);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[wave][0] = lx; red[wave][1] = ly; red[wave][2] = hx; red[wave][3] = hy; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) {
-      lx = min(lx, red[k][0]); ly = min(ly, red[k][1]); hx = max(hx, red[k][2]); hy = max(hy, red[k][3]);
-    }
-    if (hx >= 0) {
-      atomicMin(&bounds[r * 4 + 0], lx); atomicMin(&bounds[r * 4 + 1], ly);
-      atomicMax(&bounds[r * 4 + 2], hx); atomicMax(&bounds[r * 4 + 3], hy);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = lx; red[wave][1] = ly; red[wave][2] = hx; red[wave][3] = hy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < 4; ++k) {
+        lx = min(lx, red[k][0]); ly = min(ly, red[k][1]); hx = max(hx, red[k][2]); hy = max(hy, red[k][3]);
+      }
+      if (hx >= 0) {
+        atomicMin(&bounds[r * 4 + 0], lx); atomicMin(&bounds[r * 4 + 1], ly);
+        atomicMax(&bounds[r * 4 + 2], hx); atomicMax(&bounds[r * 4 + 3], hy);
+      }
     }
   }
 }
 
-// grid R, block 448 (7 waves; 441 active).  Finalises the box (defaults W/2, H/2, :149,:173) and resamples (:193-240).
+// block 448 (7 waves; 441 active), rows as in mv_bounds_kernel.  Finalises the box (defaults W/2, H/2, :149,:173) and
+// resamples (:193-240).
 __global__ __launch_bounds__(448) void mv_resample_kernel(const float* __restrict__ boxes, int box_dim,
                                                           const float* __restrict__ masks, int S,
                                                           const int* __restrict__ inds, const int* __restrict__ begins,
                                                           const int* __restrict__ ends, const float* __restrict__ wts,
                                                           int H, int W, const int* __restrict__ bounds,
+                                                          const int* __restrict__ rcount, int R,
                                                           float* __restrict__ out_mask, int* __restrict__ out_box) {
   __shared__ CandLds cl;
-  const int r = blockIdx.x;
-  const int c0 = begins[r], c1 = ends[r];
-  const int nc = max(c1 - c0, 0);
-  const bool in_lds = nc <= kMaxCandLds;
-  if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
-  __syncthreads();
-  int bx1 = bounds[r * 4 + 0], by1 = bounds[r * 4 + 1], bx2 = bounds[r * 4 + 2], by2 = bounds[r * 4 + 3];
-  if (bx2 < 0) { bx1 = W / 2; bx2 = W / 2; }   // no column reached 0.4
-  if (by2 < 0) { by1 = H / 2; by2 = H / 2; }
-  if (threadIdx.x == 0) {
-    out_box[r * 4 + 0] = bx1; out_box[r * 4 + 1] = by1; out_box[r * 4 + 2] = bx2; out_box[r * 4 + 3] = by2;
-  }
-  for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
-    const int w = idx % S, h = idx / S;
-    const float bw = (float)((double)(bx2 - bx1) + 1.0), bh = (float)((double)(by2 - by1) + 1.0);
-    const float rw = bw / (float)S, rh = bh / (float)S;
-    const float ix = bx1 + (float)w * rw, iy = by1 + (float)h * rh;
-    const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+  const int Rv = rcount ? *rcount : R;
+  for (int r = blockIdx.x; r < Rv; r += gridDim.x) {
+    __syncthreads();
+    const int c0 = begins[r], c1 = ends[r];
+    const int nc = max(c1 - c0, 0);
+    const bool in_lds = nc <= kMaxCandLds;
+    if (in_lds) stage_cands(cl, boxes, box_dim, inds, wts, c0, nc);
+    __syncthreads();
+    int bx1 = bounds[r * 4 + 0], by1 = bounds[r * 4 + 1], bx2 = bounds[r * 4 + 2], by2 = bounds[r * 4 + 3];
+    if (bx2 < 0) { bx1 = W / 2; bx2 = W / 2; }   // no column reached 0.4
+    if (by2 < 0) { by1 = H / 2; by2 = H / 2; }
+    if (threadIdx.x == 0) {
+      out_box[r * 4 + 0] = bx1; out_box[r * 4 + 1] = by1; out_box[r * 4 + 2] = bx2; out_box[r * 4 + 3] = by2;
+    }
+    for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
+      const int w = idx % S, h = idx / S;
+      const float bw = (float)((double)(bx2 - bx1) + 1.0), bh = (float)((double)(by2 - by1) + 1.0);
+      const float rw = bw / (float)S, rh = bh / (float)S;
+      const float ix = bx1 + (float)w * rw, iy = by1 + (float)h * rh;
+      const int sx = (int)floorf(ix), sy = (int)floorf(iy);
 #define MNC_AGG(hh, ww) (in_lds ? aggregate_px(cl, nc, masks, S, (hh), (ww)) \
                                 : aggregate_px_global(boxes, box_dim, masks, inds, wts, c0, c1, S, (hh), (ww)))
-    float v;
-    if (sx == W - 1 || sy == H - 1) {
-      v = MNC_AGG(sy, sx);
-    } else {
-      const float fx = ix - sx, fy = iy - sy;
-      const float wtl = (1 - fx) * (1 - fy), wtr = fx * (1 - fy), wbl = (1 - fx) * fy, wbr = fx * fy;
-      const float atl = MNC_AGG(sy, sx), atr = MNC_AGG(sy, sx + 1), abl = MNC_AGG(sy + 1, sx), abr = MNC_AGG(sy + 1, sx + 1);
-      v = wtl * atl + wtr * atr + wbl * abl + wbr * abr;
-    }
+      float v;
+      if (sx == W - 1 || sy == H - 1) {
+        v = MNC_AGG(sy, sx);
+      } else {
+        const float fx = ix - sx, fy = iy - sy;
+        const float wtl = (1 - fx) * (1 - fy), wtr = fx * (1 - fy), wbl = (1 - fx) * fy, wbr = fx * fy;
+        const float atl = MNC_AGG(sy, sx), atr = MNC_AGG(sy, sx + 1), abl = MNC_AGG(sy + 1, sx), abr = MNC_AGG(sy + 1, sx + 1);
+        v = wtl * atl + wtr * atr + wbl * abl + wbr * abr;
+      }
 #undef MNC_AGG
-    out_mask[((long)r * S + h) * S + w] = v;
+      out_mask[((long)r * S + h) * S + w] = v;
+    }
   }
 }
 
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(1024) void mv_order_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[(long)c * n + i] = (int)(s_keys[i] & 0xFFFFFFFFu);
 }
 
-// keep lists index the sorted order; the host wants box indices: keepbox[c][k] = order[c][keep[c][k]]
+// keep lists index the sorted order; the voting wants box indices: keepbox[c][k] = order[c][keep[c][k]]
 __global__ void mv_keepbox_kernel(const int* __restrict__ order, const int* __restrict__ keep, const int* __restrict__ num,
                                   int n, int* __restrict__ keepbox) {
   const int c = blockIdx.y;
@@ -251,76 +262,371 @@ __global__ void mv_keepbox_kernel(const int* __restrict__ order, const int* __re
   if (k < num[c]) keepbox[(long)c * n + k] = order[(long)c * n + keep[(long)c * n + k]];
 }
 
-// Candidate set of result row r = (kept box bi, class c): members {i : IoU_f64(box_i, box_bi) >= iou_thresh} in index order,
-// weights = class scores normalised by python's sequential float32 sum (mask_transform.py:253-270).  One wave per row;
-// row r owns cinds/cw[r*n .. r*n + n).
-__global__ __launch_bounds__(64) void mv_candidates_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                           int n, int C, const int* __restrict__ rows, float iou_thresh,
-                                                           int* __restrict__ cinds, float* __restrict__ cw,
-                                                           int* __restrict__ cbegin, int* __restrict__ cend) {
-  const int r = blockIdx.x, lane = threadIdx.x;
-  const int bi = rows[2 * r], c = rows[2 * r + 1];
-  const double q0 = boxes[bi * 4 + 0], q1 = boxes[bi * 4 + 1], q2 = boxes[bi * 4 + 2], q3 = boxes[bi * 4 + 3];
-  const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
-  int* my_inds = cinds + (long)r * n;
-  float* my_w = cw + (long)r * n;
-  int base = 0;
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    const int i = i0 + lane;
-    bool member = false;
-    if (i < n) {
-      const double b0 = boxes[i * 4 + 0], b1 = boxes[i * 4 + 1], b2 = boxes[i * 4 + 2], b3 = boxes[i * 4 + 3];
-      double ov = 0.0;
-      const double iw = (b2 < q2 ? b2 : q2) - (b0 > q0 ? b0 : q0) + 1;
-      if (iw > 0) {
-        const double ih = (b3 < q3 ? b3 : q3) - (b1 > q1 ? b1 : q1) + 1;
-        if (ih > 0) ov = iw * ih / ((b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih);
-      }
-      member = ov >= (double)iou_thresh;
-    }
-    const unsigned long long bal = __ballot(member);
-    if (member) {
-      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-      my_inds[pos] = i;
-      my_w[pos] = scores[(long)i * C + c + 1];
-    }
-    base += __popcll(bal);
+constexpr int kSelThreads = 1024;
+constexpr int kSelCap = 8192;        // kept boxes over all classes the in-LDS selection sorts (20 classes x 100: 2000)
+constexpr int kSelMaxClasses = 1024;
+
+// The host part of gpu_mask_voting between the per-class NMS and the candidate sets (mask_transform.py:242-258), on the device,
+// ONE workgroup:  pool = kept scores of all classes (class-major, keep order; num[c] <= max_per_image already);
+//   thresh = np.sort(pool)[::-1][min(len(pool), max_per_image) - 1]      (NaN sorts FIRST in that order, as numpy's does)
+//   rows   = [(box, class) for class-major kept boxes with score >= thresh]            (NaN >= x is false)
+// Outputs: rows [R][2] = (box index, class - 1), rscore [R], counts[0] = R, counts[c] = rows of class c (1..B).
+// pool_* are global scratch of P entries.  NP = power of two >= P capacity (dynamic LDS: NP keys).
+__global__ __launch_bounds__(kSelThreads) void mv_select_kernel(const float* __restrict__ scores, int n, int C,
+                                                                const int* __restrict__ keepbox, const int* __restrict__ num,
+                                                                int max_per_image, int NP, int* __restrict__ pool_box,
+                                                                float* __restrict__ pool_score, int* __restrict__ pool_cls,
+                                                                int* __restrict__ rows, float* __restrict__ rscore,
+                                                                int* __restrict__ counts) {
+  extern __shared__ unsigned s_key[];
+  __shared__ int s_off[kSelMaxClasses + 1];
+  __shared__ int s_cc[kSelMaxClasses];
+  __shared__ int s_wsum[kSelThreads / 64];
+  const int tid = threadIdx.x, B = C - 1;
+  for (int c = tid; c < B; c += kSelThreads) s_cc[c] = 0;
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 0; c < B; ++c) { s_off[c] = acc; acc += num[c]; }
+    s_off[B] = acc;
   }
   __syncthreads();
-  float sum = 0.0f;
-  if (lane == 0)
-    for (int t = 0; t < base; ++t) sum = t ? sum + my_w[t] : my_w[t];      // ((0 + w0) + w1) + ...  (0 + w0 is exact)
-  sum = __shfl(sum, 0);
+  const int P = s_off[B];
+  if (P == 0) {
+    for (int c = tid; c < C; c += kSelThreads) counts[c] = 0;
+    return;
+  }
+  for (int j = tid; j < NP; j += kSelThreads) {
+    unsigned key = 0xFFFFFFFFu;                     // padding sorts last
+    if (j < P) {
+      int lo = 0, hi = B - 1;                       // class c with s_off[c] <= j < s_off[c + 1] (empty classes skipped)
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
+      }
+      const int c = lo, k = j - s_off[c];
+      const int bi = keepbox[(long)c * n + k];
+      const float v = scores[(long)bi * C + c + 1];
+      pool_box[j] = bi; pool_cls[j] = c; pool_score[j] = v;
+      if (v != v) {
+        key = 0u;                                   // NaN first
+      } else {
+        const unsigned u = __float_as_uint(v);
+        const unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // ascending-orderable; >= 0x007FFFFF
+        key = ~asc;                                 // descending; +inf -> 0x007FFFFF > 0, -inf -> 0xFF7FFFFF < padding
+      }
+    }
+    s_key[j] = key;
+  }
   __syncthreads();
-  for (int t = lane; t < base; t += 64) my_w[t] = my_w[t] / sum;
-  if (lane == 0) {
-    cbegin[r] = r * n;
-    cend[r] = r * n + base;
+  for (int size = 2; size <= NP; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (NP >> 1); t += kSelThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned x = s_key[lo], y = s_key[hi];
+        if ((x > y) == up) { s_key[lo] = y; s_key[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  const unsigned kkey = s_key[min(P, max_per_image) - 1];
+  float thresh;
+  if (kkey == 0u) {
+    thresh = __uint_as_float(0x7FC00000u);
+  } else {
+    const unsigned asc = ~kkey;
+    thresh = __uint_as_float((asc & 0x80000000u) ? (asc & 0x7FFFFFFFu) : ~asc);
+  }
+  // rows in pool order: each thread owns a contiguous run, block-wide exclusive scan of the run counts
+  const int per = (P + kSelThreads - 1) / kSelThreads;
+  const int j0 = min(tid * per, P), j1 = min(j0 + per, P);
+  int mine = 0;
+  for (int j = j0; j < j1; ++j) mine += (pool_score[j] >= thresh) ? 1 : 0;
+  int inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o);
+    if ((tid & 63) >= o) inc += t;
+  }
+  if ((tid & 63) == 63) s_wsum[tid >> 6] = inc;
+  __syncthreads();
+  int base = inc - mine;
+  for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+  for (int j = j0; j < j1; ++j) {
+    const float v = pool_score[j];
+    if (v >= thresh) {
+      rows[2 * base] = pool_box[j];
+      rows[2 * base + 1] = pool_cls[j];
+      rscore[base] = v;
+      atomicAdd(&s_cc[pool_cls[j]], 1);
+      ++base;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int total = 0;
+    for (int w = 0; w < kSelThreads / 64; ++w) total += s_wsum[w];
+    counts[0] = total;
+  }
+  for (int c = tid; c < B; c += kSelThreads) counts[c + 1] = s_cc[c];
+}
+
+// Candidate set of result row r = (kept box bi, class c): members {i : IoU_f64(box_i, box_bi) >= iou_thresh} in index order,
+// weights = class scores / sum (mask_transform.py:259-267).  The reference's `cur_weights / sum(cur_weights)` is python's
+// sum() over float32 scalars: under the numpy 1.x the reference ran on, 0 + np.float32 promotes to float64 (scalar-scalar
+// promotion of a python int), so the accumulation is sequential in float64, and the float32 array is then divided by that
+// float64 scalar in float32 (value-based casting): w / float32(sum64).  One wave per row; row r owns cinds/cw[r*n .. r*n + n).
+__global__ __launch_bounds__(64) void mv_candidates_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                           int n, int C, const int* __restrict__ rows,
+                                                           const int* __restrict__ rcount, int R, float iou_thresh,
+                                                           int* __restrict__ cinds, float* __restrict__ cw,
+                                                           int* __restrict__ cbegin, int* __restrict__ cend) {
+  const int lane = threadIdx.x;
+  const int Rv = rcount ? *rcount : R;
+  for (int r = blockIdx.x; r < Rv; r += gridDim.x) {
+    const int bi = rows[2 * r], c = rows[2 * r + 1];
+    const double q0 = boxes[bi * 4 + 0], q1 = boxes[bi * 4 + 1], q2 = boxes[bi * 4 + 2], q3 = boxes[bi * 4 + 3];
+    const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
+    int* my_inds = cinds + (long)r * n;
+    float* my_w = cw + (long)r * n;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      bool member = false;
+      if (i < n) {
+        const double b0 = boxes[i * 4 + 0], b1 = boxes[i * 4 + 1], b2 = boxes[i * 4 + 2], b3 = boxes[i * 4 + 3];
+        double ov = 0.0;
+        const double iw = (b2 < q2 ? b2 : q2) - (b0 > q0 ? b0 : q0) + 1;
+        if (iw > 0) {
+          const double ih = (b3 < q3 ? b3 : q3) - (b1 > q1 ? b1 : q1) + 1;
+          if (ih > 0) ov = iw * ih / ((b2 - b0 + 1) * (b3 - b1 + 1) + qarea - iw * ih);
+        }
+        member = ov >= (double)iou_thresh;
+      }
+      const unsigned long long bal = __ballot(member);
+      if (member) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        my_inds[pos] = i;
+        my_w[pos] = scores[(long)i * C + c + 1];
+      }
+      base += __popcll(bal);
+    }
+    __syncthreads();
+    double sum = 0.0;
+    if (lane == 0)
+      for (int t = 0; t < base; ++t) sum += (double)my_w[t];              // ((0 + w0) + w1) + ... in float64
+    const float sum32 = __shfl((float)sum, 0);
+    __syncthreads();
+    for (int t = lane; t < base; t += 64) my_w[t] = my_w[t] / sum32;
+    if (lane == 0) {
+      cbegin[r] = r * n;
+      cend[r] = r * n + base;
+    }
+    __syncthreads();
   }
 }
 
+// Final instances as fixed-shape records (the block the multi-GPU path gathers): record r < min(R, cap) =
+// (x1, y1, x2, y2, score, class id 1..B, S*S mask values); rows from R up to cap are zero (class 0 == padding).
+__global__ __launch_bounds__(256) void mv_pack_kernel(const float* __restrict__ omask, const int* __restrict__ obox,
+                                                      const float* __restrict__ rscore, const int* __restrict__ rows,
+                                                      const int* __restrict__ counts, int cap, int S,
+                                                      float* __restrict__ records) {
+  const int r = blockIdx.x;
+  const int R = counts[0];
+  const int D = 6 + S * S;
+  float* rec = records + (long)r * D;
+  if (r >= R) {
+    for (int i = threadIdx.x; i < D; i += blockDim.x) rec[i] = 0.0f;
+    return;
+  }
+  if (threadIdx.x < 4) rec[threadIdx.x] = (float)obox[r * 4 + threadIdx.x];
+  if (threadIdx.x == 4) rec[4] = rscore[r];
+  if (threadIdx.x == 5) rec[5] = (float)(rows[2 * r + 1] + 1);
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) rec[6 + i] = omask[(long)r * S * S + i];
+}
+
 // All pointers device.  d_bounds: R*4 ints scratch.  Result r's candidates are d_inds/d_wts[d_begins[r] .. d_ends[r]).
+// d_rcount != nullptr: the row count is read from the device (<= R rows of scratch/output exist) and the grid is `grid_rows`
+// workgroups striding over the rows.
+static int mv_launch_impl(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
+                          const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, const int* d_rcount,
+                          int grid_rows, int* d_bounds, float* d_out_mask, int* d_out_box) {
+  if (R <= 0) return MNC_OK;
+  hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
+  // ~2048 blocks in flight: rows x `splits` row slabs each
+  int splits = 2048 / grid_rows;
+  if (splits < 1) splits = 1;
+  if (splits > 32) splits = 32;
+  hipLaunchKernelGGL(mv_bounds_kernel, dim3(grid_rows, splits), dim3(256), 0, stream, d_boxes, box_dim, d_masks, S, d_inds,
+                     d_begins, d_ends, d_wts, H, W, d_rcount, R, d_bounds);
+  hipLaunchKernelGGL(mv_resample_kernel, dim3(grid_rows), dim3(448), 0, stream, d_boxes, box_dim, d_masks, S, d_inds, d_begins,
+                     d_ends, d_wts, H, W, d_bounds, d_rcount, R, d_out_mask, d_out_box);
+  return MNC_OK;
+}
+
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
               const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, int* d_bounds,
               float* d_out_mask, int* d_out_box) {
-  if (R <= 0) return MNC_OK;
-  hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
-  // ~2048 blocks in flight: R results x `splits` row slabs each
-  int splits = 2048 / R;
-  if (splits < 1) splits = 1;
-  if (splits > 32) splits = 32;
-  hipLaunchKernelGGL(mv_bounds_kernel, dim3(R, splits), dim3(256), 0, stream, d_boxes, box_dim, d_masks, S, d_inds,
-                     d_begins, d_ends, d_wts, H, W, d_bounds);
-  hipLaunchKernelGGL(mv_resample_kernel, dim3(R), dim3(448), 0, stream, d_boxes, box_dim, d_masks, S, d_inds, d_begins,
-                     d_ends, d_wts, H, W, d_bounds, d_out_mask, d_out_box);
-  return MNC_OK;
+  return mv_launch_impl(stream, d_boxes, box_dim, d_masks, S, d_inds, d_begins, d_ends, d_wts, H, W, R, nullptr, R, d_bounds,
+                        d_out_mask, d_out_box);
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Device scratch of one gpu_mask_voting problem (n boxes, C classes incl. background, S x S masks, keep_cap kept per class).
+struct VoteWs {
+  float *boxes, *masks, *scores;        // staging for host inputs (unused when the inputs are already on the device)
+  int* order; unsigned long long* bits; int *keep, *keepbox, *num;
+  int *pool_box, *pool_cls; float* pool_score;
+  int* rows; float* rscore; int* counts;
+  int *cinds; float* cw; int *cbegin, *cend, *bounds; float* omask; int* obox;
+  float* records;                       // [Rmax][6 + S*S]
+};
+
+static size_t vote_ws_layout(char* base, int n, int C, int S, int keep_cap, VoteWs* w) {
+  const int B = C - 1, cb = cdiv(n, 64), Rmax = B * keep_cap;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base + off; off += align256(bytes); return p; };
+  w->boxes = (float*)take((size_t)n * 16);
+  w->masks = (float*)take((size_t)n * S * S * 4);
+  w->scores = (float*)take((size_t)n * C * 4);
+  w->order = (int*)take((size_t)B * n * 4);
+  w->bits = (unsigned long long*)take((size_t)B * n * cb * 8);
+  w->keep = (int*)take((size_t)B * n * 4);
+  w->keepbox = (int*)take((size_t)B * n * 4);
+  w->num = (int*)take((size_t)B * 4);
+  w->pool_box = (int*)take((size_t)Rmax * 4);
+  w->pool_cls = (int*)take((size_t)Rmax * 4);
+  w->pool_score = (float*)take((size_t)Rmax * 4);
+  w->rows = (int*)take((size_t)Rmax * 8);
+  w->rscore = (float*)take((size_t)Rmax * 4);
+  w->counts = (int*)take((size_t)C * 4);
+  w->cinds = (int*)take((size_t)Rmax * n * 4);
+  w->cw = (float*)take((size_t)Rmax * n * 4);
+  w->cbegin = (int*)take((size_t)Rmax * 4);
+  w->cend = (int*)take((size_t)Rmax * 4);
+  w->bounds = (int*)take((size_t)Rmax * 16);
+  w->omask = (float*)take((size_t)Rmax * S * S * 4);
+  w->obox = (int*)take((size_t)Rmax * 16);
+  w->records = (float*)take((size_t)Rmax * (6 + S * S) * 4);
+  return off;
+}
+
+// gpu_mask_voting (lib/transform/mask_transform.py:213-286 + lib/nms/mv_kernel.cu) as ONE asynchronous launch sequence on
+// `s`, inputs and outputs on the device, no host decision anywhere:
+//   per-class order (unless order_ready) -> 20 batched NMS problems -> kept box indices -> threshold + result rows
+//   (mv_select_kernel) -> candidate sets -> fused voting kernels -> records.
+// d_records [record_cap][6+S*S] (record_cap <= B*keep_cap), d_counts [C].
+static int vote_async(hipStream_t s, const VoteWs& w, const float* d_boxes, const float* d_masks, const float* d_scores,
+                      bool order_ready, int n, int C, int S, int max_per_image, float nms_thresh, float iou_thresh, int H, int W,
+                      float* d_records, int record_cap, int* d_counts) {
+  const int B = C - 1;
+  const int keep_cap = max_per_image < n ? max_per_image : n;
+  const int Rmax = B * keep_cap;
+  if (!order_ready) {
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(mv_order_kernel, dim3(B), dim3(np2 < 1024 ? np2 : 1024), (size_t)np2 * 8, s, d_scores, n, C, np2, w.order);
+  }
+  nms_mask_launch(s, d_boxes, w.order, n, 4, nms_thresh, w.bits, B);
+  nms_scan_launch(s, w.bits, n, keep_cap, w.keep, w.num, B);
+  hipLaunchKernelGGL(mv_keepbox_kernel, dim3(cdiv(keep_cap, 256), B), dim3(256), 0, s, w.order, w.keep, w.num, n, w.keepbox);
+  int NP = 64;
+  while (NP < Rmax) NP <<= 1;
+  hipLaunchKernelGGL(mv_select_kernel, dim3(1), dim3(kSelThreads), (size_t)NP * 4, s, d_scores, n, C, w.keepbox, w.num,
+                     max_per_image, NP, w.pool_box, w.pool_score, w.pool_cls, w.rows, w.rscore, d_counts);
+  // the row count R = d_counts[0] stays on the device: R <= max_per_image unless scores tie at the threshold, so that many
+  // workgroups stride over the rows
+  const int grid_rows = Rmax < max_per_image ? Rmax : max_per_image;
+  hipLaunchKernelGGL(mv_candidates_kernel, dim3(grid_rows), dim3(64), 0, s, d_boxes, d_scores, n, C, w.rows, d_counts, Rmax,
+                     iou_thresh, w.cinds, w.cw, w.cbegin, w.cend);
+  mv_launch_impl(s, d_boxes, 4, d_masks, S, w.cinds, w.cbegin, w.cend, w.cw, H, W, Rmax, d_counts, grid_rows, w.bounds, w.omask,
+                 w.obox);
+  hipLaunchKernelGGL(mv_pack_kernel, dim3(record_cap), dim3(256), 0, s, w.omask, w.obox, w.rscore, w.rows, d_counts, record_cap, S,
+                     d_records);
+  MNC_HIP_TRY(hipGetLastError());
+  return MNC_OK;
+}
+
+static int vote_check_args(const char* who, int n, int C, int S, int max_per_image, int H, int W) {
+  MNC_REQUIRE(n >= 0 && C >= 2 && S >= 2 && max_per_image > 0 && H > 0 && W > 0, "%s: bad argument", who);
+  MNC_REQUIRE(C - 1 <= kSelMaxClasses, "%s: %d classes exceed the device selection's %d", who, C - 1, kSelMaxClasses);
+  const long Rmax = (long)(C - 1) * (max_per_image < n ? max_per_image : n);
+  MNC_REQUIRE(Rmax <= kSelCap, "%s: (num_classes-1) * min(max_per_image, n) = %ld exceeds the device selection's %d kept boxes",
+              who, Rmax, kSelCap);
+  return MNC_OK;
+}
+
+// Per-class descending order on the host for box counts beyond the LDS sort (the same order: stable, NaN last).
+static void host_order(const float* scores, int n, int C, std::vector<int>* out) {
+  const int B = C - 1;
+  out->resize((size_t)B * n);
+  for (int c = 0; c < B; ++c) {
+    int* o = out->data() + (size_t)c * n;
+    for (int i = 0; i < n; ++i) o[i] = i;
+    const float* sc = scores + c + 1;
+    std::stable_sort(o, o + n, [&](int a, int b) {
+      const float va = -sc[(size_t)a * C], vb = -sc[(size_t)b * C];
+      return va < vb || (vb != vb && va == va);              // NaN last, as numpy
+    });
+  }
+}
+
+// Host-facing outputs of a finished vote: counts + records from the device, split into the reference's arrays.
+static int vote_fetch(hipStream_t s, const float* d_records, const int* d_counts, int Rmax, int C, int S, int first_rows,
+                      float* out_mask, int* out_box, float* out_score, int* class_count, int* result_num) {
+  const int D = 6 + S * S;
+  std::vector<int> counts(C);
+  std::vector<float> rec;
+  int first = first_rows < Rmax ? first_rows : Rmax;
+  rec.resize((size_t)first * D);
+  MNC_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+  if (first) MNC_HIP_TRY(hipMemcpyAsync(rec.data(), d_records, rec.size() * 4, hipMemcpyDeviceToHost, s));
+  MNC_HIP_TRY(hipStreamSynchronize(s));
+  const int R = counts[0];
+  if (R > first) {                              // scores tied at the threshold: more rows than max_per_image
+    rec.resize((size_t)R * D);
+    MNC_HIP_TRY(hipMemcpyAsync(rec.data() + (size_t)first * D, d_records + (size_t)first * D, (size_t)(R - first) * D * 4,
+                               hipMemcpyDeviceToHost, s));
+    MNC_HIP_TRY(hipStreamSynchronize(s));
+  }
+  for (int r = 0; r < R; ++r) {
+    const float* q = rec.data() + (size_t)r * D;
+    for (int k = 0; k < 4; ++k) out_box[r * 4 + k] = (int)q[k];
+    out_score[r] = q[4];
+    memcpy(out_mask + (size_t)r * S * S, q + 6, (size_t)S * S * 4);
+  }
+  for (int c = 0; c < C - 1; ++c) class_count[c] = counts[c + 1];
+  *result_num = R;
+  return MNC_OK;
+}
+
 }  // namespace mnc
 
 using namespace mnc;
+
+// per-context voting scratch (mnc_ctx::vote_ws), grown on demand
+static int ctx_vote_ws(mnc_ctx* ctx, int n, int C, int S, int keep_cap, VoteWs* w) {
+  const size_t need = vote_ws_layout(nullptr, n, C, S, keep_cap, w);
+  if (need > ctx->vote_ws_bytes) {
+    MNC_HIP_TRY(hipSetDevice(ctx->device));
+    MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->vote_ws) MNC_HIP_TRY(hipFree(ctx->vote_ws));
+    ctx->vote_ws = nullptr;
+    ctx->vote_ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->vote_ws, need + (need >> 2));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("voting scratch: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+      return MNC_ERR_NOMEM;
+    }
+    ctx->vote_ws_bytes = need + (need >> 2);
+  }
+  vote_ws_layout((char*)ctx->vote_ws, n, C, S, keep_cap, w);
+  return MNC_OK;
+}
 
 extern "C" {
 
@@ -346,9 +652,9 @@ int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, co
   const size_t b_inds = align256((size_t)candidate_num * 4), b_wts = b_inds, b_starts = align256((size_t)R * 8);
   const size_t b_bounds = align256((size_t)R * 16), b_omask = align256((size_t)R * S * S * 4), b_obox = align256((size_t)R * 16);
   LegacyWs* w = nullptr;
-  int rc = legacy_ws(device_id, b_boxes + b_masks + b_inds + b_wts + b_starts + b_bounds + b_omask + b_obox, &w);
+  std::unique_lock<std::mutex> lock;
+  int rc = legacy_ws(device_id, b_boxes + b_masks + b_inds + b_wts + b_starts + b_bounds + b_omask + b_obox, &w, &lock);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(w->mu);
   char* p = (char*)w->buf;
   float* d_boxes = (float*)p; p += b_boxes;
   float* d_masks = (float*)p; p += b_masks;
@@ -381,17 +687,15 @@ int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes_num, co
   return MNC_OK;
 }
 
-// gpu_mask_voting in one call (lib/transform/mask_transform.py:213-286 + lib/nms/mv_kernel.cu).  See include/mnc_hip.h.
-// on_device: boxes / masks / scores are device pointers (the engine's own outputs) and `ext_stream` is the stream they were
-// produced on; otherwise they are host pointers and the library's per-device stream is used.
-static int mask_voting_core(bool on_device, hipStream_t ext_stream, const float* boxes, const float* masks,
-                            const float* scores, const int* order, int n, int num_classes, int mask_size, int max_per_image,
-                            float nms_thresh, float iou_thresh, int image_height, int image_width, float* out_mask,
-                            int* out_box, float* out_score, int* class_count, int* result_num, int device_id) {
+// gpu_mask_voting in one call on HOST arrays (see include/mnc_hip.h): inputs up, the asynchronous device sequence, records down.
+int mnc_mask_voting(const float* boxes, const float* masks, const float* scores, const int* order, int n, int num_classes,
+                    int mask_size, int max_per_image, float nms_thresh, float iou_thresh, int image_height,
+                    int image_width, float* out_mask, int* out_box, float* out_score, int* class_count, int* result_num,
+                    int device_id) {
   MNC_REQUIRE(result_num && class_count, "mnc_mask_voting: null output pointer");
-  MNC_REQUIRE(n >= 0 && num_classes >= 2 && mask_size >= 2 && max_per_image > 0 && image_height > 0 && image_width > 0,
-              "mnc_mask_voting: bad argument");
-  const int B = num_classes - 1, S = mask_size;
+  int rc = vote_check_args("mnc_mask_voting", n, num_classes, mask_size, max_per_image, image_height, image_width);
+  if (rc) return rc;
+  const int B = num_classes - 1, S = mask_size, C = num_classes;
   *result_num = 0;
   for (int c = 0; c < B; ++c) class_count[c] = 0;
   if (n == 0) { clear_error(); return MNC_OK; }
@@ -399,155 +703,103 @@ static int mask_voting_core(bool on_device, hipStream_t ext_stream, const float*
   if (order)
     for (long i = 0; i < (long)B * n; ++i)
       MNC_REQUIRE(order[i] >= 0 && order[i] < n, "mnc_mask_voting: order[%ld]=%d out of range", i, order[i]);
-  const int cb = cdiv(n, 64);
   const int keep_cap = max_per_image < n ? max_per_image : n;
-  const int Rmax = B * keep_cap;
-  const size_t b_boxes = align256((size_t)n * 16), b_masks = align256((size_t)n * S * S * 4), b_order = align256((size_t)B * n * 4);
-  const size_t b_scores = align256((size_t)n * num_classes * 4);
-  const size_t b_bits = align256((size_t)B * n * cb * 8), b_keep = align256((size_t)B * n * 4), b_num = align256((size_t)B * 4);
-  const size_t b_cinds = align256((size_t)Rmax * n * 4), b_cw = b_cinds, b_rows = align256((size_t)Rmax * 8);
-  const size_t b_cse = align256((size_t)Rmax * 4);
-  const size_t b_bounds = align256((size_t)Rmax * 16), b_omask = align256((size_t)Rmax * S * S * 4), b_obox = b_bounds;
+  VoteWs ws;
+  const size_t need = vote_ws_layout(nullptr, n, C, S, keep_cap, &ws);
   LegacyWs* w = nullptr;
-  int rc = legacy_ws(device_id, b_boxes + b_masks + b_order + b_scores + b_bits + 2 * b_keep + b_num + b_cinds + b_cw + b_rows +
-                                    2 * b_cse + b_bounds + b_omask + b_obox, &w);
+  std::unique_lock<std::mutex> lock;
+  rc = legacy_ws(device_id, need, &w, &lock);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(w->mu);
-  hipStream_t s = on_device ? ext_stream : w->stream;
-  char* p = (char*)w->buf;
-  const float* d_boxes = on_device ? boxes : (const float*)p; p += b_boxes;
-  const float* d_masks = on_device ? masks : (const float*)p; p += b_masks;
-  int* d_order = (int*)p; p += b_order;
-  const float* d_scores = on_device ? scores : (const float*)p; p += b_scores;
-  unsigned long long* d_bits = (unsigned long long*)p; p += b_bits;
-  int* d_keep = (int*)p; p += b_keep;
-  int* d_keepbox = (int*)p; p += b_keep;
-  int* d_num = (int*)p; p += b_num;
-  int* d_cinds = (int*)p; p += b_cinds;
-  float* d_cw = (float*)p; p += b_cw;
-  int* d_rows = (int*)p; p += b_rows;
-  int* d_cbegin = (int*)p; p += b_cse;
-  int* d_cend = (int*)p; p += b_cse;
-  int* d_bounds = (int*)p; p += b_bounds;
-  float* d_omask = (float*)p; p += b_omask;
-  int* d_obox = (int*)p;
-
-  const bool timing = getenv("MNC_MV_TIMING") != nullptr;      // diagnostic: host wall-clock of each phase on stderr
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-    return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3;
-  };
-  const auto t0 = now();
-  // 1. per-class score order + the per-class NMS problems (mask_transform.py:228-240), batched; kept lists come back as
-  //    box indices; the masks ride along on the same stream
-  std::vector<float> h_scores;                 // the host picks the threshold and the result rows from the class scores
-  if (on_device) {
-    h_scores.resize((size_t)n * num_classes);
-    MNC_HIP_TRY(hipMemcpyAsync(h_scores.data(), d_scores, h_scores.size() * 4, hipMemcpyDeviceToHost, s));
-    scores = h_scores.data();                  // valid after the synchronisation below
-  } else {
-    MNC_HIP_TRY(hipMemcpyAsync((void*)d_boxes, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
-    MNC_HIP_TRY(hipMemcpyAsync((void*)d_scores, scores, (size_t)n * num_classes * 4, hipMemcpyHostToDevice, s));
-  }
+  vote_ws_layout((char*)w->buf, n, C, S, keep_cap, &ws);
+  hipStream_t s = w->stream;
+  MNC_HIP_TRY(hipMemcpyAsync(ws.boxes, boxes, (size_t)n * 16, hipMemcpyHostToDevice, s));
+  MNC_HIP_TRY(hipMemcpyAsync(ws.scores, scores, (size_t)n * C * 4, hipMemcpyHostToDevice, s));
+  MNC_HIP_TRY(hipMemcpyAsync(ws.masks, masks, (size_t)n * S * S * 4, hipMemcpyHostToDevice, s));
   std::vector<int> h_order;
-  if (order) {
-    MNC_HIP_TRY(hipMemcpyAsync(d_order, order, (size_t)B * n * 4, hipMemcpyHostToDevice, s));
-  } else if (n <= kMaxOrderDevice) {
-    int np2 = 64;
-    while (np2 < n) np2 <<= 1;
-    hipLaunchKernelGGL(mv_order_kernel, dim3(B), dim3(np2 < 1024 ? np2 : 1024), (size_t)np2 * 8, s, d_scores, n, num_classes,
-                       np2, d_order);
-  } else {                                 // larger than the LDS sort: the same order on the host
-    if (on_device) MNC_HIP_TRY(hipStreamSynchronize(s));
-    h_order.resize((size_t)B * n);
-    for (int c = 0; c < B; ++c) {
-      int* o = h_order.data() + (size_t)c * n;
-      for (int i = 0; i < n; ++i) o[i] = i;
-      const float* sc = scores + c + 1;
-      std::stable_sort(o, o + n, [&](int a, int b) {
-        const float va = -sc[(size_t)a * num_classes], vb = -sc[(size_t)b * num_classes];
-        return va < vb || (vb != vb && va == va);              // NaN last, as numpy
-      });
-    }
-    MNC_HIP_TRY(hipMemcpyAsync(d_order, h_order.data(), (size_t)B * n * 4, hipMemcpyHostToDevice, s));
+  if (!order && n > kMaxOrderDevice) {
+    host_order(scores, n, C, &h_order);
+    order = h_order.data();
   }
-  nms_mask_launch(s, d_boxes, d_order, n, 4, nms_thresh, d_bits, B);
-  nms_scan_launch(s, d_bits, n, keep_cap, d_keep, d_num, B);
-  hipLaunchKernelGGL(mv_keepbox_kernel, dim3(cdiv(keep_cap, 256), B), dim3(256), 0, s, d_order, d_keep, d_num, n, d_keepbox);
-  MNC_HIP_TRY(hipGetLastError());
-  std::vector<int> h_keepbox((size_t)B * n), h_num(B);
-  MNC_HIP_TRY(hipMemcpyAsync(h_num.data(), d_num, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-  MNC_HIP_TRY(hipMemcpyAsync(h_keepbox.data(), d_keepbox, (size_t)B * n * 4, hipMemcpyDeviceToHost, s));
-  if (!on_device) MNC_HIP_TRY(hipMemcpyAsync((void*)d_masks, masks, (size_t)n * S * S * 4, hipMemcpyHostToDevice, s));
-  MNC_HIP_TRY(hipStreamSynchronize(s));
-  const auto t1 = now();
-
-  // 2. global threshold = the max_per_image-th best kept score over all classes (:242-244)
-  std::vector<float> pool;
-  for (int c = 0; c < B; ++c)
-    for (int k = 0; k < h_num[c]; ++k) pool.push_back(scores[(size_t)h_keepbox[(size_t)c * n + k] * num_classes + c + 1]);
-  if (pool.empty()) { clear_error(); return MNC_OK; }
-  std::vector<float> ranked(pool);
-  const size_t kth = (ranked.size() < (size_t)max_per_image ? ranked.size() : (size_t)max_per_image) - 1;
-  std::nth_element(ranked.begin(), ranked.begin() + kth, ranked.end(), std::greater<float>());
-  const float thresh = ranked[kth];
-
-  // 3. result rows = kept boxes at or above the threshold, class-major in keep order (:253-258); their candidate sets
-  //    (:259-270) are built on the device
-  std::vector<int> rows;
-  int R = 0;
-  for (int c = 0; c < B; ++c) {
-    int cnt = 0;
-    for (int k = 0; k < h_num[c]; ++k) {
-      const int bi = h_keepbox[(size_t)c * n + k];
-      const float sc = scores[(size_t)bi * num_classes + c + 1];
-      if (!(sc >= thresh)) continue;
-      rows.push_back(bi);
-      rows.push_back(c);
-      out_score[R++] = sc;
-      ++cnt;
-    }
-    class_count[c] = cnt;
-  }
-  *result_num = R;
-  if (R == 0) { clear_error(); return MNC_OK; }
-  const auto t2 = now();
-
-  // 4. candidate sets + the fused mask-voting kernels
-  MNC_HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), (size_t)R * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(mv_candidates_kernel, dim3(R), dim3(64), 0, s, d_boxes, d_scores, n, num_classes, d_rows, iou_thresh,
-                     d_cinds, d_cw, d_cbegin, d_cend);
-  mv_launch(s, d_boxes, 4, d_masks, S, d_cinds, d_cbegin, d_cend, d_cw, image_height, image_width, R, d_bounds, d_omask,
-            d_obox);
-  MNC_HIP_TRY(hipGetLastError());
-  MNC_HIP_TRY(hipMemcpyAsync(out_mask, d_omask, (size_t)R * S * S * 4, hipMemcpyDeviceToHost, s));
-  MNC_HIP_TRY(hipMemcpyAsync(out_box, d_obox, (size_t)R * 16, hipMemcpyDeviceToHost, s));
-  MNC_HIP_TRY(hipStreamSynchronize(s));
-  if (timing)
-    fprintf(stderr, "mnc_mask_voting: order+nms+copies %.0f us, threshold+rows %.0f us (R=%d), candidates+voting+copies %.0f us\n",
-            us(t0, t1), us(t1, t2), R, us(t2, now()));
+  if (order) MNC_HIP_TRY(hipMemcpyAsync(ws.order, order, (size_t)B * n * 4, hipMemcpyHostToDevice, s));
+  rc = vote_async(s, ws, ws.boxes, ws.masks, ws.scores, order != nullptr, n, C, S, max_per_image, nms_thresh, iou_thresh,
+                  image_height, image_width, ws.records, B * keep_cap, ws.counts);
+  if (rc) return rc;
+  rc = vote_fetch(s, ws.records, ws.counts, B * keep_cap, C, S, max_per_image, out_mask, out_box, out_score, class_count,
+                  result_num);
+  if (rc) return rc;
   clear_error();
   return MNC_OK;
 }
 
-int mnc_mask_voting(const float* boxes, const float* masks, const float* scores, const int* order, int n, int num_classes,
-                    int mask_size, int max_per_image, float nms_thresh, float iou_thresh, int image_height,
-                    int image_width, float* out_mask, int* out_box, float* out_score, int* class_count, int* result_num,
-                    int device_id) {
-  return mask_voting_core(false, nullptr, boxes, masks, scores, order, n, num_classes, mask_size, max_per_image, nms_thresh,
-                          iou_thresh, image_height, image_width, out_mask, out_box, out_score, class_count, result_num,
-                          device_id);
+// The same with inputs AND outputs on the device, asynchronous on the context's stream -- what the whole-image path uses.
+int mnc_vote_instances(mnc_ctx* ctx, const float* d_boxes, const float* d_masks, const float* d_scores, int n, int num_classes,
+                       int mask_size, int max_per_image, float nms_thresh, float iou_thresh, int image_height, int image_width,
+                       float* d_records, int record_cap, int* d_counts) {
+  MNC_REQUIRE(ctx && d_records && d_counts && record_cap >= 0, "mnc_vote_instances: null pointer");
+  int rc = vote_check_args("mnc_vote_instances", n, num_classes, mask_size, max_per_image, image_height, image_width);
+  if (rc) return rc;
+  const int B = num_classes - 1, S = mask_size, C = num_classes;
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) {
+    MNC_HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)C * 4, ctx->stream));
+    if (record_cap) MNC_HIP_TRY(hipMemsetAsync(d_records, 0, (size_t)record_cap * (6 + S * S) * 4, ctx->stream));
+    return MNC_OK;
+  }
+  MNC_REQUIRE(d_boxes && d_masks && d_scores, "mnc_vote_instances: null pointer");
+  MNC_REQUIRE(n <= kMaxOrderDevice, "mnc_vote_instances: n=%d exceeds the device ordering's %d boxes", n, kMaxOrderDevice);
+  const int keep_cap = max_per_image < n ? max_per_image : n;
+  VoteWs ws;
+  rc = ctx_vote_ws(ctx, n, C, S, keep_cap, &ws);
+  if (rc) return rc;
+  const int Rmax = B * keep_cap;
+  LaunchScope ls(ctx, "mask_voting");
+  if (record_cap > Rmax) {
+    MNC_HIP_TRY(hipMemsetAsync(d_records + (size_t)Rmax * (6 + S * S), 0, (size_t)(record_cap - Rmax) * (6 + S * S) * 4,
+                               ctx->stream));
+    record_cap = Rmax;
+  }
+  rc = vote_async(ctx->stream, ws, d_boxes, d_masks, d_scores, false, n, C, S, max_per_image, nms_thresh, iou_thresh,
+                  image_height, image_width, d_records, record_cap, d_counts);
+  if (rc) return rc;
+  return ls.finish("mask_voting");
 }
 
 int mnc_mask_voting_dev(mnc_ctx* ctx, const float* d_boxes, const float* d_masks, const float* d_scores, int n,
                         int num_classes, int mask_size, int max_per_image, float nms_thresh, float iou_thresh,
                         int image_height, int image_width, float* out_mask, int* out_box, float* out_score, int* class_count,
                         int* result_num) {
-  MNC_REQUIRE(ctx, "mnc_mask_voting_dev: null context");
-  MNC_REQUIRE(n == 0 || (d_boxes && d_masks && d_scores), "mnc_mask_voting_dev: null pointer");
-  return mask_voting_core(true, ctx->stream, d_boxes, d_masks, d_scores, nullptr, n, num_classes, mask_size, max_per_image,
-                          nms_thresh, iou_thresh, image_height, image_width, out_mask, out_box, out_score, class_count,
-                          result_num, ctx->device);
+  MNC_REQUIRE(ctx && result_num && class_count, "mnc_mask_voting_dev: null pointer");
+  int rc = vote_check_args("mnc_mask_voting_dev", n, num_classes, mask_size, max_per_image, image_height, image_width);
+  if (rc) return rc;
+  const int B = num_classes - 1, S = mask_size, C = num_classes;
+  *result_num = 0;
+  for (int c = 0; c < B; ++c) class_count[c] = 0;
+  if (n == 0) { clear_error(); return MNC_OK; }
+  MNC_REQUIRE(d_boxes && d_masks && d_scores && out_mask && out_box && out_score, "mnc_mask_voting_dev: null pointer");
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
+  const int keep_cap = max_per_image < n ? max_per_image : n;
+  VoteWs ws;
+  rc = ctx_vote_ws(ctx, n, C, S, keep_cap, &ws);
+  if (rc) return rc;
+  bool order_ready = false;
+  if (n > kMaxOrderDevice) {                  // beyond the LDS sort: the same order on the host (one extra round trip)
+    std::vector<float> h_scores((size_t)n * C);
+    std::vector<int> h_order;
+    MNC_HIP_TRY(hipMemcpyAsync(h_scores.data(), d_scores, h_scores.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    host_order(h_scores.data(), n, C, &h_order);
+    MNC_HIP_TRY(hipMemcpyAsync(ws.order, h_order.data(), h_order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    order_ready = true;
+  }
+  rc = vote_async(ctx->stream, ws, d_boxes, d_masks, d_scores, order_ready, n, C, S, max_per_image, nms_thresh, iou_thresh,
+                  image_height, image_width, ws.records, B * keep_cap, ws.counts);
+  if (rc) return rc;
+  rc = vote_fetch(ctx->stream, ws.records, ws.counts, B * keep_cap, C, S, max_per_image, out_mask, out_box, out_score,
+                  class_count, result_num);
+  if (rc) return rc;
+  clear_error();
+  return MNC_OK;
 }
 
 // im_detect's tail on the device (tools/demo.py:84-100, TesterWrapper.py:240-260): boxes = clip(rois[:, 1:5] / scale) of both

@@ -197,15 +197,19 @@ int nms_scan_launch_indirect(hipStream_t stream, const u64* d_mask, const int* d
 // ---- per-device workspace for the host-pointer entry points (b1/b2 allocate-per-call in the reference) ----------
 static LegacyWs g_ws[16];
 
-int legacy_ws(int device_id, size_t bytes, LegacyWs** out) {
+int legacy_ws(int device_id, size_t bytes, LegacyWs** out, std::unique_lock<std::mutex>* lock) {
   int ndev = 0;
   MNC_HIP_TRY(hipGetDeviceCount(&ndev));
   MNC_REQUIRE(device_id >= 0 && device_id < ndev && device_id < 16, "device %d out of range (have %d)", device_id, ndev);
   MNC_HIP_TRY(hipSetDevice(device_id));
   LegacyWs* w = &g_ws[device_id];
+  *lock = std::unique_lock<std::mutex>(w->mu);        // before anything is created, grown or freed
   if (!w->stream) MNC_HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
   if (bytes > w->cap) {
-    if (w->buf) MNC_HIP_TRY(hipFree(w->buf));
+    if (w->buf) {
+      MNC_HIP_TRY(hipStreamSynchronize(w->stream));
+      MNC_HIP_TRY(hipFree(w->buf));
+    }
     w->buf = nullptr;
     w->cap = 0;
     size_t want = bytes + (bytes >> 1) + 4096;
@@ -239,9 +243,9 @@ static int nms_host_impl(int* keep_out, int* num_out, u64* mask_out, const float
   const size_t box_b = align256((size_t)n * dim * 4), ord_b = order_host ? align256((size_t)batch * n * 4) : 0;
   const size_t mask_b = align256((size_t)batch * n * cb * 8), keep_b = align256((size_t)batch * n * 4);
   LegacyWs* w = nullptr;
-  int rc = legacy_ws(device_id, box_b + ord_b + mask_b + keep_b + align256((size_t)batch * 4), &w);
+  std::unique_lock<std::mutex> lock;
+  int rc = legacy_ws(device_id, box_b + ord_b + mask_b + keep_b + align256((size_t)batch * 4), &w, &lock);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(w->mu);
   char* base = (char*)w->buf;
   float* d_boxes = (float*)base;
   int* d_order = order_host ? (int*)(base + box_b) : nullptr;

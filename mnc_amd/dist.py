@@ -1,12 +1,21 @@
 """Multi-GPU plumbing for the batched-image path: independent images are sharded round-robin over one
 process per GPU (no data-path collective); the only exchange is an all-gather of each image's final instances as a
-fixed-shape block over RCCL/xGMI.  torch.distributed is the transport (backend "nccl" == RCCL on ROCm; "gloo" in the CPU
-tests) -- plumbing, not compute.
+fixed-shape block over RCCL/xGMI.
+
+Two transports behind one class:
+  * device (the product path): the block is the InstanceBlock mnc_vote_instances wrote on the GPU; the all-gather is
+    ncclAllGather issued by libmnc_hip.so on the engine's own stream (mnc_gather_instances, csrc/comm.hip) -- device pointer to
+    device pointer, no numpy hop, no torch tensor.  torch.distributed only carries the 128-byte ncclUniqueId at start-up.
+  * host ("gloo", the CPU tests; no GPU here): the same records as numpy arrays through torch.distributed.all_gather.
 
 Record layout per instance (447 float32): x1, y1, x2, y2, score, class id (1..20), 21x21 mask row-major."""
+import ctypes
+
 import numpy as np
 
-REC_CAP = 100            # gpu_mask_voting returns at most max_per_image = 100 instances (mask_transform.py:242-244)
+from .instances import records_from_lists
+
+REC_CAP = 100            # gpu_mask_voting returns max_per_image = 100 instances (mask_transform.py:242-244) unless scores tie
 REC_DIM = 4 + 1 + 1 + 21 * 21
 
 
@@ -16,18 +25,14 @@ def shard_indices(n_items, rank, world):
 
 
 def pack_instances(result_mask, result_box, cap=REC_CAP):
-    """(list_result_mask[20], list_result_box[20]) of gpu_mask_voting -> ([cap, 447] float32 block, count)."""
-    rec = np.zeros((cap, REC_DIM), np.float32)
-    n = 0
-    for c, (m, b) in enumerate(zip(result_mask, result_box)):
-        k = min(len(b), cap - n)
-        if k <= 0:
-            continue
-        rec[n:n + k, :5] = b[:k]
-        rec[n:n + k, 5] = c + 1
-        rec[n:n + k, 6:] = np.asarray(m[:k], np.float32).reshape(k, -1)
-        n += k
-    return rec, n
+    """(list_result_mask[20], list_result_box[20]) of gpu_mask_voting -> ([cap, 447] float32 block, rows packed).  More than
+    `cap` result rows (scores tied at the global threshold) are truncated class-major, and the truncation is reported."""
+    rec, total = records_from_lists(result_mask, result_box, cap)
+    if total > cap:
+        import warnings
+        warnings.warn("pack_instances: %d instances (scores tied at the voting threshold), block holds %d -- %d dropped"
+                      % (total, cap, total - cap))
+    return rec, min(total, cap)
 
 
 def unpack_instances(rec):
@@ -37,25 +42,86 @@ def unpack_instances(rec):
     return r[:, :5].copy(), r[:, 5].astype(np.int64), r[:, 6:].reshape(-1, 1, 21, 21).copy()
 
 
-class InstanceGatherer(object):
-    """Re-usable all-gather of one [cap, 447] block per rank (device tensors for nccl, host tensors for gloo)."""
+def _exchange_unique_id(make_id, rank):
+    """rank 0's ncclUniqueId to every rank through the torch.distributed process group the launcher set up."""
+    import torch.distributed as dist
+    box = [make_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
-    def __init__(self, device=None, cap=REC_CAP):
+
+class InstanceGatherer(object):
+    """All-gather of one [cap, 447] block per rank.
+
+    InstanceGatherer(net=net)        device transport: RCCL communicator on the net's context (created here -- communicator
+                                     setup takes seconds and must never land in a timed step), ncclAllGather on its stream
+    InstanceGatherer(device=None)    host transport over the initialised torch.distributed group (gloo)"""
+
+    def __init__(self, net=None, device=None, cap=REC_CAP, rank=None, world=None, unique_id=None):
+        self.cap = cap
+        self.net = net
+        if net is not None:
+            from . import _lib
+            from .engine import _DevBuf
+            self._lib = _lib
+            if world is None:
+                import torch.distributed as dist
+                rank, world = dist.get_rank(), dist.get_world_size()
+            self.rank, self.world = rank, world
+
+            def make_id():
+                buf = ctypes.create_string_buffer(128)
+                _lib.call("mnc_comm_unique_id", ctypes.addressof(buf), 128)
+                return buf.raw
+            if unique_id is None:
+                unique_id = make_id() if world == 1 else _exchange_unique_id(make_id, rank)
+            idbuf = ctypes.create_string_buffer(unique_id, 128)
+            _lib.call("mnc_comm_init", net._ctx.h, ctypes.addressof(idbuf), world, rank)
+            v = ctypes.c_int(0)
+            _lib.call("mnc_comm_info", net._ctx.h, None, None, ctypes.addressof(v))
+            self.rccl_version = v.value
+            self._recv = _DevBuf(net._ctx)
+            self._recv.ensure(world * cap * REC_DIM * 4)
+            self._send0 = _DevBuf(net._ctx)                      # warm-up block: the first collective builds the rings
+            p = self._send0.ensure(cap * REC_DIM * 4)
+            _lib.call("mnc_dev_zero", net._ctx.h, p, cap * REC_DIM * 4)
+            _lib.call("mnc_gather_instances", net._ctx.h, p, self._recv.ptr, cap * REC_DIM)
+            _lib.call("mnc_ctx_sync", net._ctx.h)
+            return
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.world = dist.get_world_size()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        self.rccl_version = None
         self.send = torch.empty((cap, REC_DIM), dtype=torch.float32, device=device)
         self.recv = [torch.empty((cap, REC_DIM), dtype=torch.float32, device=device) for _ in range(self.world)]
-        # first collective = communicator setup (seconds with RCCL): pay it here, never inside a timed or latency-critical step
         self.send.zero_()
         dist.all_gather(self.recv, self.send)
-        if device is not None and str(device).startswith("cuda"):
-            torch.cuda.synchronize()
+
+    def gather_block(self, block):
+        """Device transport: enqueue the all-gather of an InstanceBlock's first `cap` records on the net's stream
+        (asynchronous; fetch() synchronises).  The block's rows past `cap` (ties at the threshold) do not travel."""
+        if block.gather_rows != self.cap or block.rec_dim != REC_DIM:
+            raise ValueError("block shape [%d,%d] does not match the gatherer's [%d,%d]"
+                             % (block.gather_rows, block.rec_dim, self.cap, REC_DIM))
+        self._lib.call("mnc_gather_instances", self.net._ctx.h, block.records_ptr, self._recv.ptr, self.cap * REC_DIM)
+
+    def fetch(self):
+        """Device transport: the gathered [world, cap, 447] blocks as one numpy array (one copy, one synchronisation)."""
+        out = np.zeros((self.world, self.cap, REC_DIM), np.float32)
+        self._lib.call("mnc_d2h", self.net._ctx.h, self._lib.ptr(out), self._recv.ptr, out.nbytes)
+        return out
 
     def gather(self, rec):
-        """rec: numpy [cap, 447].  Returns the list of per-rank blocks as tensors (valid on every rank)."""
+        """Host transport: rec numpy [cap, 447] -> list of per-rank blocks as tensors (valid on every rank)."""
         self.send.copy_(self.torch.from_numpy(rec))
         self.dist.all_gather(self.recv, self.send)
         return self.recv
+
+    def close(self):
+        if self.net is not None and getattr(self, "_recv", None) is not None:
+            self._lib.call("mnc_comm_destroy", self.net._ctx.h)
+            self._recv.release()
+            self._send0.release()
+            self._recv = None

@@ -1189,6 +1189,23 @@ class Net(object):
         return (DeviceArray(self, d_boxes, (n, 4), self._tail_bufs), DeviceArray(self, d_masks, (n, 1, S, S), self._tail_bufs),
                 DeviceArray(self, d_scores, (n, K), self._tail_bufs))
 
+    def vote_instances(self, boxes, masks, scores, num_classes, max_per_image, im_width, im_height, nms_thresh, iou_thresh):
+        """gpu_mask_voting (lib/transform/mask_transform.py:213-286) on this net's own device-resident results (the DeviceArrays
+        of detect_tail), asynchronously on the net's stream: -> InstanceBlock (mnc_amd/instances.py) whose records stay on the
+        GPU until .fetch() / .lists() copies them down (one copy, one synchronisation) or the multi-GPU gather sends them."""
+        from .instances import InstanceBlock
+        n, S = boxes.shape[0], masks.shape[-1]
+        blk = getattr(self, "_inst", None)
+        if blk is None or not blk.fits(num_classes, S, max_per_image, n):
+            if blk is not None:
+                blk.release()
+            blk = self._inst = InstanceBlock(self, num_classes, S, max_per_image, n)
+        blk.invalidate()
+        _lib.call("mnc_vote_instances", self._ctx.h, boxes.ptr, masks.ptr, scores.ptr, n, int(num_classes), S, int(max_per_image),
+                  float(nms_thresh), float(iou_thresh), int(im_height), int(im_width), blk.records_ptr, blk.rows_cap,
+                  blk.counts_ptr)
+        return blk
+
     def _run_layers(self, start, stop=None):
         pre = getattr(self, "_pre_steps", {})
         for i in range(start, len(self._layers) if stop is None else stop):
@@ -1232,6 +1249,8 @@ class Net(object):
                 t.release()
             if getattr(self, "_prep", None) is not None:
                 self._prep.release()
+            if getattr(self, "_inst", None) is not None:
+                self._inst.release()
             self._tmp.release()
             for p in self._dev_params.values():
                 self._ctx.free(p)

@@ -1,0 +1,93 @@
+"""Final instances of one image as a fixed-shape device block: what gpu_mask_voting returns
+(lib/transform/mask_transform.py:213-286), produced and kept on the GPU by mnc_vote_instances.
+
+Device layout of one InstanceBlock:  [HEAD_BYTES: int32 counts[num_classes]: counts[0] = R, counts[c] = rows of class c]
+                                     [rows_cap records of REC_DIM float32: x1, y1, x2, y2, score, class id (1..20), 21x21 mask]
+Rows past R are zero (class id 0 == padding).  The first `gather_rows` (= max_per_image = 100) records are the block every rank
+contributes to the RCCL all-gather; R exceeds that only when scores tie at the global threshold (the reference's
+`cls_score >= thresh`, :258, admits every tied row), which a gather truncates -- and says so."""
+import numpy as np
+
+from . import _lib
+
+HEAD_BYTES = 256
+
+
+class InstanceBlock(object):
+    def __init__(self, net, num_classes, mask_size, max_per_image, n):
+        from .engine import _DevBuf
+        self._net = net
+        self.num_classes, self.S = int(num_classes), int(mask_size)
+        self.rec_dim = 6 + self.S * self.S
+        self.gather_rows = int(max_per_image)
+        self.rows_cap = max((self.num_classes - 1) * min(int(max_per_image), int(n)), self.gather_rows, 1)
+        if self.num_classes * 4 > HEAD_BYTES:
+            raise ValueError("at most %d classes" % (HEAD_BYTES // 4))
+        self._buf = _DevBuf(net._ctx)
+        self.ptr = self._buf.ensure(HEAD_BYTES + self.rows_cap * self.rec_dim * 4)
+        self._host = None
+
+    counts_ptr = property(lambda self: self.ptr)
+    records_ptr = property(lambda self: self.ptr + HEAD_BYTES)
+
+    def fits(self, num_classes, mask_size, max_per_image, n):
+        return (self.num_classes == num_classes and self.S == mask_size and self.gather_rows == max_per_image
+                and self.rows_cap >= (num_classes - 1) * min(max_per_image, n))
+
+    def invalidate(self):
+        self._host = None
+
+    def fetch(self):
+        """-> (counts int32[num_classes], records float32[R, rec_dim]): ONE device-to-host copy of the head and the first
+        gather_rows records (a second one only when more rows tied at the threshold); synchronises the net's stream."""
+        if self._host is None:
+            first = min(self.gather_rows, self.rows_cap)
+            nbytes = HEAD_BYTES + first * self.rec_dim * 4
+            raw = np.zeros(nbytes, np.uint8)
+            _lib.call("mnc_d2h", self._net._ctx.h, _lib.ptr(raw), self.ptr, nbytes)
+            counts = raw[:self.num_classes * 4].view(np.int32).copy()
+            rec = raw[HEAD_BYTES:].view(np.float32).reshape(first, self.rec_dim)
+            R = int(counts[0])
+            if R > first:
+                more = np.zeros((R - first, self.rec_dim), np.float32)
+                _lib.call("mnc_d2h", self._net._ctx.h, _lib.ptr(more), self.records_ptr + first * self.rec_dim * 4, more.nbytes)
+                rec = np.concatenate((rec, more), 0)
+            self._host = (counts, rec[:R])
+        return self._host
+
+    def lists(self):
+        """-> (list_result_mask, list_result_box) exactly as the reference's gpu_mask_voting returns them: one entry per
+        foreground class, masks [k,1,S,S] float32, boxes [k,5] = (x1, y1, x2, y2, score) (int32 | float32 hstack -> float64)."""
+        counts, rec = self.fetch()
+        return split_records(rec, counts[1:self.num_classes], self.S)
+
+    def release(self):
+        self._buf.release()
+
+
+def split_records(rec, class_counts, S):
+    boxes = np.hstack((rec[:, :4].astype(np.int32), rec[:, 4:5]))          # int32 | float32 -> float64, as the reference
+    masks = np.ascontiguousarray(rec[:, 6:]).reshape(-1, 1, S, S)
+    list_mask, list_box, lo = [], [], 0
+    for k in class_counts:
+        hi = lo + int(k)
+        list_box.append(boxes[lo:hi, :])
+        list_mask.append(masks[lo:hi])
+        lo = hi
+    return list_mask, list_box
+
+
+def records_from_lists(list_mask, list_box, cap, S=21):
+    """Host-side twin of the device block (the gloo tests and the numpy result path): ([cap, 6+S*S] float32, total rows)."""
+    rec = np.zeros((cap, 6 + S * S), np.float32)
+    n = total = 0
+    for c, (m, b) in enumerate(zip(list_mask, list_box)):
+        total += len(b)
+        k = min(len(b), cap - n)
+        if k <= 0:
+            continue
+        rec[n:n + k, :5] = b[:k]
+        rec[n:n + k, 5] = c + 1
+        rec[n:n + k, 6:] = np.asarray(m[:k], np.float32).reshape(k, -1)
+        n += k
+    return rec, total

@@ -44,7 +44,9 @@ def build_voting_candidates(boxes, scores, num_classes, max_per_image):
             ov = bbox_overlaps(boxes64, b[np.newaxis].astype(np.float64))
             members = np.where(ov >= cfg.TEST.MASK_MERGE_IOU_THRESH)[0]
             w = scores[members, c]
-            w = w / sum(w)          # python's sequential float32 sum, as in the reference (:266)
+            # python's sum() as the reference ran it (:266, numpy 1.x): sequential float64 accumulation (0 + np.float32 promoted
+            # to float64), then a float32 division by that scalar (value-based casting)
+            w = w / np.float32(sum(w.astype(np.float64)))
             inds.extend(members)
             weights.extend(w)
             ends.append(len(inds))
@@ -112,21 +114,11 @@ def _split_results(out_mask, out_box, out_score, counts, R, B):
 
 def _device_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):
     """gpu_mask_voting on the engine's own device-resident outputs (mnc_amd.devarray.DeviceArray, from Net.detect_tail):
-    same call as _fused_mask_voting without the device -> host -> device round trip of its inputs."""
-    import ctypes
-    from mnc_amd import _lib
-    n, S, B = boxes.shape[0], masks.shape[3], num_classes - 1
-    cap = max(B * min(max_per_image, n), 1)
-    out_mask = np.zeros((cap, 1, S, S), dtype=np.float32)
-    out_box = np.zeros((cap, 4), dtype=np.int32)
-    out_score = np.zeros(cap, dtype=np.float32)
-    counts = np.zeros(B, dtype=np.int32)
-    R = ctypes.c_int(0)
-    _lib.call("mnc_mask_voting_dev", boxes._net._ctx.h, boxes.ptr, masks.ptr, scores.ptr, n, num_classes, S,
-              int(max_per_image), float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH),
-              int(im_height), int(im_width), _lib.ptr(out_mask), _lib.ptr(out_box), _lib.ptr(out_score), _lib.ptr(counts),
-              ctypes.addressof(R))
-    return _split_results(out_mask, out_box, out_score, counts, R.value, B)
+    order, per-class NMS, threshold, result rows, candidate sets and voting as one asynchronous launch sequence on the net's
+    stream (mnc_vote_instances); the only host contact is the copy of the final records."""
+    blk = boxes._net.vote_instances(boxes, masks, scores, num_classes, max_per_image, im_width, im_height,
+                                    cfg.TEST.MASK_MERGE_NMS_THRESH, cfg.TEST.MASK_MERGE_IOU_THRESH)
+    return blk.lists()
 
 
 def gpu_mask_voting(masks, boxes, scores, num_classes, max_per_image, im_width, im_height):

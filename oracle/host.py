@@ -256,7 +256,8 @@ def im_detect_tail(rois, masks, scores, rois_ext, masks_ext, scores_ext, im_scal
 def mask_voting_candidates(boxes, scores, num_classes, max_per_image, nms_fn=None, overlaps_fn=None):
     """Host half of gpu_mask_voting, lib/transform/mask_transform.py:213-270: per-class NMS(0.3) keeping <= 100,
     global threshold = the max_per_image-th best kept score, then for every kept box >= threshold its candidate
-    set {IoU >= 0.5 over all boxes} with class-score weights normalised by python's sequential sum()."""
+    set {IoU >= 0.5 over all boxes} with class-score weights normalised by python's sequential sum() (float64 accumulation
+    as under numpy 1.x, see below)."""
     nms_fn = nms_fn or native.gpu_nms
     overlaps_fn = overlaps_fn or native.bbox_overlaps
     sup_boxes, sup_scores, tobesort = [[]], [[]], []
@@ -281,7 +282,11 @@ def mask_voting_candidates(boxes, scores, num_classes, max_per_image, nms_fn=Non
             cur = np.where(ov >= MASK_MERGE_IOU_THRESH)[0]
             cand_inds.extend(cur)
             w = scores[cur, c]
-            w = w / sum(w)
+            # reference: `cur_weights / sum(cur_weights)` (mask_transform.py:266).  Under the numpy 1.x the reference ran on,
+            # python's sum() starts from int 0 and 0 + np.float32 promotes to float64 (scalar-scalar promotion), so the
+            # accumulation is sequential float64; the float32 array is then divided by that float64 SCALAR in float32
+            # (value-based casting).  numpy 2 would accumulate in float32 -- pinned here to the original behaviour.
+            w = w / np.float32(sum(w.astype(np.float64)))
             cand_w.extend(w)
             cand_start.append(len(cand_inds))
         cand_scores.extend(cls_score[keep])

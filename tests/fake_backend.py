@@ -75,6 +75,8 @@ class Fake(object):
 
     mnc_d2h = mnc_h2d
     mnc_d2d = mnc_h2d
+    mnc_h2d_async = mnc_h2d
+    mnc_d2h_async = mnc_h2d
 
     def mnc_prof_enable(self, h, e):
         pass
@@ -393,6 +395,36 @@ class Fake(object):
                             oscore, counts, rnum):
         self.mnc_mask_voting(boxes, masks, scores, None, n, K, S, max_per_image, nms_thr, iou_thr, H, W, omask, obox, oscore,
                              counts, rnum, 0)
+
+    def mnc_vote_instances(self, h, boxes, masks, scores, n, K, S, max_per_image, nms_thr, iou_thr, H, W, records, cap, counts):
+        from oracle import host as ohost
+        from mnc_amd.instances import records_from_lists
+        lm, lb = ohost.gpu_mask_voting(_f(masks, (n, 1, S, S)), _f(boxes, (n, 4)), _f(scores, (n, K)), K, max_per_image, W, H)
+        rec, total = records_from_lists(lm, lb, cap, S)
+        _f(records, (cap, 6 + S * S))[...] = rec
+        c = _i(counts, (K,))
+        c[0] = total
+        c[1:] = [len(b) for b in lb]
+
+    # multi-GPU exchange: the double's "communicator" has one rank, whose all-gather is a copy
+    def mnc_comm_unique_id(self, addr, n):
+        ctypes.memset(int(addr), 7, 128)
+
+    def mnc_comm_init(self, h, uid, nranks, rank):
+        assert nranks == 1 and rank == 0
+
+    def mnc_comm_info(self, h, nranks, rank, version):
+        if version:
+            ctypes.c_int.from_address(int(version)).value = 22705
+
+    def mnc_gather_instances(self, h, send, recv, n):
+        ctypes.memmove(int(recv), int(send), int(n) * 4)
+
+    def mnc_comm_destroy(self, h):
+        pass
+
+    def mnc_dev_zero(self, h, p, n):
+        ctypes.memset(int(p), 0, int(n))
 
     def mnc_detect_tail(self, h, rois1, R1, rois2, R2, scale, H, W, boxes):
         from oracle import host as ohost

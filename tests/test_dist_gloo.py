@@ -4,6 +4,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from mnc_amd import dist as mdist
 
@@ -12,7 +13,8 @@ def test_pack_unpack_roundtrip_and_cap():
     rng = np.random.default_rng(0)
     lb = [np.hstack([rng.uniform(0, 99, (7, 4)), rng.uniform(0, 1, (7, 1))]) for _ in range(20)]     # 140 > cap
     lm = [rng.uniform(0, 1, (7, 1, 21, 21)).astype(np.float32) for _ in range(20)]
-    rec, n = mdist.pack_instances(lm, lb)
+    with pytest.warns(UserWarning, match="40 dropped"):       # truncation (ties at the voting threshold) is never silent
+        rec, n = mdist.pack_instances(lm, lb)
     assert rec.shape == (100, 447) and n == 100
     boxes, classes, masks = mdist.unpack_instances(rec)
     assert boxes.shape == (100, 5) and classes[0] == 1 and classes[-1] == 15 and masks.shape == (100, 1, 21, 21)

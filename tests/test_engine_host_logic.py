@@ -112,6 +112,21 @@ def test_demo_im_detect_and_voting(fake_gpu):
     net.close()
 
 
+def test_instance_block_and_gatherer_host_logic(fake_gpu):
+    """The host side of the device-resident result path (InstanceBlock head/records layout, the second copy when more rows
+    than max_per_image tie at the threshold, InstanceGatherer's device transport) against the oracle, on the test double.
+    The same function runs on the real kernels and a real RCCL communicator in tests/test_gpu_engine.py."""
+    import test_gpu_engine as T
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    net = Net(path, w, 1, device_id=0)
+    try:
+        T.test_device_instance_block_and_rccl_gather((net, w))
+    finally:
+        net.close()
+
+
 def test_pylayers_against_reference_fixtures(fake_gpu, golden):
     """The product's Python layers (mnc_amd/lib/pylayer) driven through caffe.Layer's protocol, against the fixtures
     produced by the reference's own layers."""

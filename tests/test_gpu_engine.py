@@ -526,3 +526,101 @@ def test_resnet50_trunk_graph(math, monkeypatch):
             check_forward(net, w, data, im_info, trunk_fn=onet.trunk_resnet50, trunk_blobs=blobs)
     finally:
         net.close()
+
+
+def _device_arrays(net, boxes, masks, scores):
+    """Host voting inputs as DeviceArrays of `net` (what Net.detect_tail hands to gpu_mask_voting)."""
+    from mnc_amd import _lib
+    from mnc_amd.devarray import DeviceArray
+    out = []
+    for a in (boxes, masks, scores):
+        a = np.ascontiguousarray(a, np.float32)
+        p = net._ctx.alloc(a.nbytes)
+        _lib.call("mnc_h2d", net._ctx.h, p, _lib.ptr(a), a.nbytes)
+        out.append(DeviceArray(net, p, a.shape))
+    return out
+
+
+def test_device_instance_block_and_rccl_gather(small):
+    """mnc_vote_instances: gpu_mask_voting as one asynchronous device sequence (threshold and result rows picked by a kernel),
+    results left on the GPU as [rows, 447] records.  (a) BASELINE's 600 instances: records == the oracle's voting, bit for bit;
+    (b) scores quantised to 1/16 -> hundreds of ties, more than max_per_image rows at the threshold: all of them come back, in
+    the reference's order; (c) the block goes through InstanceGatherer's device transport -- a real RCCL communicator
+    (world_size 1, backend nccl == librccl) and ncclAllGather on the engine's stream -- and arrives unchanged."""
+    import golden_inputs as GI
+    from mnc_amd import dist as mdist
+    from mnc_amd.instances import records_from_lists
+    net, _ = small
+    g = mdist.InstanceGatherer(net=net, rank=0, world=1)
+    try:
+        assert g.rccl_version and g.world == 1
+        for n, H, W, seed, quant in [(600, 600, 1000, 23, False), (600, 300, 400, 1, True), (67, 300, 400, 2, True)]:
+            vc = GI.voting_case(n, H, W, seed)
+            scores = vc["scores"]
+            if quant:
+                scores = (np.round(scores * 16) / 16).astype(np.float32)
+            b, m, s = _device_arrays(net, vc["boxes"], vc["masks"], scores)
+            blk = net.vote_instances(b, m, s, 21, 100, W, H, ohost.MASK_MERGE_NMS_THRESH, ohost.MASK_MERGE_IOU_THRESH)
+            g.gather_block(blk)
+            gathered = g.fetch()
+            counts, rec = blk.fetch()
+            lm, lb = blk.lists()
+            om, ob = ohost.gpu_mask_voting(vc["masks"], vc["boxes"], scores, 21, 100, W, H)
+            assert counts[0] == sum(len(x) for x in ob) == len(rec) and list(counts[1:21]) == [len(x) for x in ob]
+            if quant and n == 600:
+                assert counts[0] > 100                              # ties at the threshold really occurred
+            assert np.array_equal(np.concatenate(lb, 0), np.concatenate(ob, 0))
+            assert np.array_equal(np.concatenate(lm, 0), np.concatenate(om, 0), equal_nan=True)
+            want_block, _ = records_from_lists(om, ob, 100)
+            assert gathered.shape == (1, 100, 447) and np.array_equal(gathered[0], want_block, equal_nan=True)
+            for a in (b, m, s):
+                net._ctx.free(a.ptr)
+    finally:
+        g.close()
+
+
+def test_weight_containers_through_caffe_net(tmp_path):
+    """SURVEY 8f n2 on the device: caffe.Net(prototxt, <path>, TEST) with the Caffe-HDF5 file the reference snapshots MNC in
+    (written by the real libhdf5, tests/golden), the protobuf .caffemodel and the .npz give identical forwards, and that forward
+    matches torch-CPU on the arrays the file was written from."""
+    import caffe
+    import torch
+    import torch.nn.functional as F
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    proto = tmp_path / "tiny.prototxt"
+    proto.write_text("""name: "tiny"
+input: "data"
+input_shape { dim: 1 dim: 3 dim: 40 dim: 56 }
+layer { name: "conv1_1" type: "Convolution" bottom: "data" top: "conv1_1"
+  convolution_param { num_output: 32 kernel_size: 3 pad: 1 stride: 1 } }
+layer { name: "relu1_1" type: "ReLU" bottom: "conv1_1" top: "conv1_1" }
+layer { name: "conv1_2" type: "Convolution" bottom: "conv1_1" top: "conv1_2"
+  convolution_param { num_output: 32 kernel_size: 3 pad: 1 stride: 1 } }
+layer { name: "relu1_2" type: "ReLU" bottom: "conv1_2" top: "conv1_2" }
+layer { name: "rpn/cls_score" type: "Convolution" bottom: "conv1_2" top: "rpn_cls_score"
+  convolution_param { num_output: 18 kernel_size: 1 pad: 0 stride: 1 } }
+layer { name: "rpn_cls_score_reshape" type: "Reshape" bottom: "rpn_cls_score" top: "rpn_cls_score_reshape"
+  reshape_param { shape { dim: 0 dim: 2 dim: -1 dim: 0 } } }
+layer { name: "rpn_cls_prob" type: "Softmax" bottom: "rpn_cls_score_reshape" top: "rpn_cls_prob" }
+""")
+    data = np.random.default_rng(4).uniform(-1, 1, (1, 3, 40, 56)).astype(np.float32)
+    outs = {}
+    for src in ("tiny_weights.caffemodel.h5", "tiny_weights.caffemodel", "tiny_weights.npz"):
+        net = caffe.Net(str(proto), os.path.join(G, src), caffe.TEST)
+        try:
+            net.forward(data=data)
+            outs[src] = {k: net.blobs[k]._host_read().copy() for k in ("conv1_2", "rpn_cls_score", "rpn_cls_prob")}
+        finally:
+            net.close()
+    ref = outs["tiny_weights.npz"]
+    for src, o in outs.items():
+        for k in ref:
+            assert np.array_equal(o[k], ref[k]), (src, k)
+    w = np.load(os.path.join(G, "tiny_weights.npz"))
+    t = lambda k: torch.from_numpy(w[k])
+    x = F.relu(F.conv2d(torch.from_numpy(data), t("conv1_1/0"), t("conv1_1/1"), padding=1))
+    x = F.relu(F.conv2d(x, t("conv1_2/0"), t("conv1_2/1"), padding=1))
+    sc = F.conv2d(x, t("rpn/cls_score/0"), t("rpn/cls_score/1"))
+    prob = F.softmax(sc.reshape(1, 2, -1, 56), dim=1)
+    assert err(ref["conv1_2"], x.numpy())[1] < FP32_TOL and err(ref["rpn_cls_score"], sc.numpy())[1] < FP32_TOL
+    assert err(ref["rpn_cls_prob"], prob.numpy())[0] < FP32_TOL

@@ -107,6 +107,16 @@ def test_mv_direct_vs_reference_fixture(golden):
     with pytest.raises(_lib.MncError):
         mv(mc["boxes"], mc["masks"], np.array([999], np.int32), np.array([1], np.int32), np.array([1.0], np.float32),
            mc["H"], mc["W"])
+    # the void symbol with the reference's exact 15-argument signature (lib/nms/gpu_mv.hpp:1-4), called as gpu_mv.pyx:27-30 does
+    lib = _lib.load()
+    boxes, masks = np.ascontiguousarray(mc["boxes"], np.float32), np.ascontiguousarray(mc["masks"], np.float32)
+    inds, start = np.ascontiguousarray(mc["inds"], np.int32), np.ascontiguousarray(mc["start"], np.int32)
+    wts = np.ascontiguousarray(mc["weights"], np.float32)
+    R = len(start)
+    om, ob = np.full((R, 1, 21, 21), -1, np.float32), np.full((R, 4), -1, np.int32)
+    lib._mv(_lib.ptr(boxes), _lib.ptr(masks), boxes.shape[0], _lib.ptr(inds), _lib.ptr(start), _lib.ptr(wts), len(inds),
+            mc["H"], mc["W"], boxes.shape[1], 21, R, _lib.ptr(om), _lib.ptr(ob), 0)
+    assert np.array_equal(ob, golden["mv_box"]) and np.array_equal(om, golden["mv_mask"])
 
 
 @pytest.mark.parametrize("tag", ["small", "full"])
