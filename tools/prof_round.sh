@@ -1,13 +1,14 @@
 #!/bin/bash
 # Per-round profiling recipe (run on the GPU box via gpurun): bench JSON + rocprofv3 kernel trace + 3 PMC passes.
-# usage: bash tools/prof_round.sh <tag>     -> gpurun_out/prof_<tag>/
+# usage: bash tools/prof_round.sh <tag> [bench args]     -> gpurun_out/prof_<tag>/
 TAG=${1:-rXX}
+shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $REPO/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events"
+python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events --no-resident $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $BENCH > $OUT/pmc_write.log 2>&1
