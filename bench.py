@@ -108,18 +108,23 @@ def main():
     launched = "WORLD_SIZE" in os.environ
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
+    if launched:
+        # torch BEFORE libmnc_hip.so: the torch wheel bundles its own ROCm runtime (libamdhip64 / libhsa-runtime64 / librccl, same
+        # sonames as /opt/rocm's).  Loaded first, it is the one runtime of the process and libmnc_hip.so binds to it; loaded
+        # second, the process would hold two HSA runtimes and torch finds no GPU.
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if on_gpu:
+            if torch.cuda.device_count() < local + 1:
+                raise SystemExit("rank %d (local %d): only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
+            torch.cuda.set_device(local)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     from mnc_amd import _lib
     ndev = _lib.device_count()
     if on_gpu and ndev < (local + 1):
         raise SystemExit("rank %d (local %d): only %d GPU(s) visible" % (rank, local, ndev))
     dev_id = local if on_gpu else local % max(ndev, 1)
-    if launched:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
-            torch.cuda.set_device(dev_id)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     import _init_paths  # noqa: F401
     import caffe

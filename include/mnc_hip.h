@@ -325,6 +325,63 @@ MNC_API int mnc_stage_bridge(mnc_ctx* ctx, const float* d_rois, const float* d_b
                              int ld_probs, int R, int K, float im_h, float im_w, float* d_rois_ext);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * The whole image in ONE call (mnc_load_weights / mnc_forward_image): what tools/demo.py does per image
+ * (prepare_mnc_args :54-76, net.forward :79-83, the tail of im_detect :84-100, gpu_mask_voting :147) for the graph
+ * models/VGG16/mnc_5stage/test.prototxt, as a native object -- no Python, no prototxt parser: the layer sequence of that file
+ * (13 conv3x3 + 4 pools, RPN head + ProposalLayer, two head stages with the shared parameters, StageBridge) is fixed in
+ * csrc/pipeline.hip with the fused plan the Python engine derives from the prototxt (warp+pool, FC+activation, Concat-free
+ * column slices, merged sibling heads), the widths are configuration.  The launch sequence of an image size is captured in a
+ * HIP graph on first use and replayed afterwards (use_graph); everything is asynchronous on the context's stream and the
+ * call returns after ONE synchronisation, with the final instance records in host memory.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct mnc_net mnc_net;
+typedef struct mnc_net_config {
+  int trunk_channels[5];   /* conv1_x .. conv5_x widths (64, 128, 256, 512, 512)                      test.prototxt:19-387 */
+  int rpn_channels;        /* rpn_conv_3x3 width (512)                                                 :391-412 */
+  int num_anchors;         /* 9; anchors[a*4 + k] = transform.anchors.generate_anchors() as float32   lib/transform/anchors.py:38-49 */
+  float anchors[64];
+  int feat_stride;         /* 16 */
+  int pre_nms_topn, post_nms_topn;      /* 6000, 300                              lib/mnc_config.py TEST.RPN_{PRE,POST}_NMS_TOP_N */
+  float rpn_nms_thresh, rpn_min_size;   /* 0.7, 16 */
+  int mask_fc, mask_size;  /* fc6_maskest width 256, mask side 21 (mask_pred = mask_size^2 outputs)   :509-545 */
+  int fc_dim;              /* fc6 / fc7 / fc6_mask / fc7_mask width 4096                               :584-696 */
+  int num_classes;         /* 21 */
+  int roi_size;            /* 14: ROIWarping 28x28 + MAX 2x2 in stage 2, 14x14 direct in stage 4      :479-505, 809-820 */
+  float spatial_scale;     /* 0.0625 */
+  int target_size, max_size;            /* 600, 1000: TEST.SCALES[0], TRAIN.MAX_SIZE (tools/demo.py:59) */
+  double pixel_means[3];   /* cfg.PIXEL_MEANS, BGR */
+  int max_per_image;       /* 100 */
+  float vote_nms_thresh, vote_iou_thresh;   /* TEST.MASK_MERGE_NMS_THRESH 0.3, TEST.MASK_MERGE_IOU_THRESH 0.5 */
+  int math;                /* 0 fp32, 1 bf16x3, 2 f16 (the engine's math modes) */
+  int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
+} mnc_net_config;
+
+/* The reference's values for every field (VGG-16 widths, lib/mnc_config.py defaults). */
+MNC_API int mnc_net_default_config(mnc_net_config* cfg);
+MNC_API int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out);
+/* One parameter blob of one layer, in Caffe's own layout (what net.params[layer][index].data holds: Convolution
+ * [Cout][Cin][3][3], InnerProduct [N][K] with K in (c,h,w) order, bias [N]).  Layers: conv1_1 .. conv5_3, rpn_conv_3x3,
+ * rpn_cls_score, rpn_bbox_pred, fc6_maskest, mask_pred, fc6, fc7, fc6_mask, fc7_mask, cls_score, seg_cls_score, bbox_pred
+ * (the *_ext layers share these by `param { name }`, test.prototxt:514-515 <-> :829-834).  index 0 = weights, 1 = bias. */
+MNC_API int mnc_net_set_param(mnc_net* net, const char* layer, int index, const float* data_host, size_t count);
+/* mnc_load_weights: every blob from a flat little-endian file written by mnc_amd.caffemodel.save_flat / tools/convert_weights.py:
+ * "MNCW0001", uint32 n, then n x { uint16 name_len, name, uint8 blob index, uint8 ndim, uint32 dims[ndim], float32 data }. */
+MNC_API int mnc_net_load_file(mnc_net* net, const char* path);
+/* One image.  bgr_host: uint8 [H][W][3] (BGR, as cv2.imread gives the reference).  records_host: [record_cap][6 + S*S] float32
+ * = (x1, y1, x2, y2, score, class id, mask) of the voted instances, rows past the count zero; counts_host [num_classes]:
+ * [0] = number of instances, [c] = instances of class c.  record_cap <= (num_classes-1) * max_per_image. */
+MNC_API int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H, int W, float* records_host, int record_cap,
+                              int* counts_host);
+/* The same without the final copy + synchronisation: the records stay on the device (the block mnc_gather_instances sends);
+ * *d_records / *d_counts are valid until the next call on this net. */
+MNC_API int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host, int H, int W, float** d_records, int** d_counts);
+/* Device address and Caffe-order shape of an intermediate blob of the LAST image, for parity tests: "conv5_3" (c8),
+ * "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "rois_ext", "mask_proposal" [2R][S][S] (both stages stacked),
+ * "seg_cls_prob" [2R][num_classes], "boxes" [2R][4].  dims receives up to 4 ints, *ndim their number. */
+MNC_API int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* ndim);
+MNC_API int mnc_net_destroy(mnc_net* net);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Multi-GPU (the reference is single-GPU: batch is 1 per forward, lib/pylayer/proposal_layer.py:65).  Images are
  * sharded one per rank, one process and one context per GPU, weights replicated, no data-path collective.  The only exchange
  * is the all-gather of every rank's instance records (mnc_vote_instances' d_records, [100][447] float32 by default) issued as

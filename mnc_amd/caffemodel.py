@@ -157,3 +157,18 @@ def save_npz(weights, path):
             if b is not None:
                 flat["%s/%d" % (lname, i)] = np.asarray(b, dtype=np.float32)
     np.savez(path, **flat)
+
+
+def save_flat(weights, path):
+    """{"<layer>": [W, b]} -> the flat little-endian container mnc_net_load_file reads (include/mnc_hip.h): "MNCW0001",
+    uint32 n, then n x {uint16 name_len, name, uint8 blob index, uint8 ndim, uint32 dims[ndim], float32 data}.  For hosts that
+    load weights without Python (a C / Go / Java caller of mnc_forward_image)."""
+    import struct
+    entries = [(lname, i, np.ascontiguousarray(b, dtype="<f4")) for lname, blobs in weights.items()
+               for i, b in enumerate(blobs) if b is not None]
+    with open(path, "wb") as f:
+        f.write(b"MNCW0001" + struct.pack("<I", len(entries)))
+        for lname, i, a in entries:
+            nm = lname.encode()
+            f.write(struct.pack("<H", len(nm)) + nm + struct.pack("<BB", i, a.ndim) + struct.pack("<%dI" % a.ndim, *a.shape))
+            f.write(a.tobytes())

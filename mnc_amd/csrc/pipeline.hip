@@ -1,0 +1,681 @@
+// mnc_forward_image: the whole per-image hot path of MNC as one native call (include/mnc_hip.h, "The whole image in ONE call").
+//
+// What tools/demo.py does per image in the reference --
+//     prepare_mnc_args (tools/demo.py:54-76)  ->  net.forward (:79-83)  ->  un-scale / clip / concat (:84-100)  ->
+//     gpu_mask_voting (:147, lib/transform/mask_transform.py:213-286)
+// -- for the graph models/VGG16/mnc_5stage/test.prototxt, with the layer sequence of that file written down here instead of
+// parsed: this is the fixed-function form of the path, for hosts that are not Python (a cgo / JNI / plain C caller) and for the
+// bench, where ~100 ctypes calls per image would otherwise sit next to a 3 ms GPU step.  The per-layer kernels are the same
+// C-ABI entry points the Python engine calls (mnc_conv3x3*, mnc_fc*, mnc_roi_warp, mnc_proposal, mnc_vote_instances, ...), in
+// the fused plan the engine derives from the prototxt, so the two executors produce the same bits (tests/test_gpu_pipeline.py).
+//
+// Launch model: every launch is asynchronous on the context's stream; the image goes up from a pinned staging buffer and the
+// instance records come down into one, so the sequence [H2D, prep, trunk, RPN, proposal, stage 2/3 heads, bridge, stage 4/5
+// heads, tail, voting, D2H] has no host dependency at all and is captured into a HIP graph the second time an image size is
+// seen; later images of that size are one hipGraphLaunch + one stream synchronisation.  The RoI count of the ProposalLayer
+// stays on the device (the heads run on all post_nms_topn rows, rows past the count are zero boxes); it comes down with the
+// records, and only if fewer proposals survived are the heads re-run on the exact count -- what the reference computes.
+#include <cmath>
+#include <map>
+#include <string>
+
+#include "mnc_internal.h"
+
+namespace mnc {
+int* proposal_count_ptr(mnc_ctx* ctx);   // proposal.hip: device address of the last mnc_proposal's row count
+}
+
+using namespace mnc;
+
+namespace {
+
+struct HostBlob {
+  std::vector<float> v;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+const char* kTrunk[13] = {"conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3",
+                          "conv4_1", "conv4_2", "conv4_3", "conv5_1", "conv5_2", "conv5_3"};
+const int kTrunkStage[13] = {0, 0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4};
+const bool kPoolAfter[13] = {false, true, false, true, false, false, true, false, false, true, false, false, false};
+
+inline int pool_out(int n) { return (n - 2 + 1) / 2 + 1; }       // Caffe MAX 2x2/2 pad 0, ceil
+
+// cv2.resize INTER_LINEAR taps of one axis, as mnc_amd/prep.py:linear_taps (the definition shared with the numpy path):
+// source coordinate (dst + 0.5) * (1/scale) - 0.5 in double, stored as float; floor; border clamps with a zero fraction.
+void linear_taps(int n_dst, int n_src, double scale, int* lo, float* frac) {
+  const double inv = 1.0 / scale;
+  for (int i = 0; i < n_dst; ++i) {
+    const float src = (float)(((double)i + 0.5) * inv - 0.5);
+    long l = (long)std::floor((double)src);
+    float f = (float)((double)src - (double)l);
+    if (l < 0) { l = 0; f = 0.0f; }
+    if (l >= n_src - 1) { l = n_src - 1; f = 0.0f; }
+    lo[i] = (int)l;
+    frac[i] = f;
+  }
+}
+
+}  // namespace
+
+struct mnc_net {
+  mnc_ctx* ctx = nullptr;
+  mnc_net_config cfg;
+  std::map<std::string, HostBlob> params;      // "<layer>/<index>" as given by the caller (Caffe layout)
+  bool finalized = false;
+  // device weights
+  float* w_c3 = nullptr;                       // conv1_1 [Cout][3][3][3]
+  void* w_conv[14] = {nullptr};                // packed conv3x3 weights: trunk 1..12, [13] = rpn_conv_3x3
+  bool conv_fast[14] = {false};                // tuned 3x3 kernels (Cout % 32 == 0) or the general convolution (reduced widths)
+  float* b_conv[14] = {nullptr};               // biases: trunk 0..12 -> [0..12], rpn -> [13]
+  float *w_rpn_cls = nullptr, *b_rpn_cls = nullptr, *w_rpn_box = nullptr, *b_rpn_box = nullptr;
+  struct Fc { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, kind = 0; };   // kind 0 fp32, 1 bf16x3, 2 f16
+  Fc fc_maskest, fc_maskpred, fc6, fc7, fc6m, fc7m, fc_heads;
+  // geometry of the buffers below
+  int cap_ph = 0, cap_pw = 0, cap_src = 0;
+  DevBuf img, taps, data, act[13], pooled[4], rpn_out, rpn_score, rpn_bbox, rpn_prob;
+  DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores, records, counts;
+  unsigned char* pin_img = nullptr; size_t pin_img_cap = 0;
+  float* pin_out = nullptr; size_t pin_out_cap = 0;       // [counts (64 ints) | proposal count (64 ints) | records]
+  // per-image state
+  int H = 0, W = 0, OH = 0, OW = 0, fh = 0, fw = 0;
+  float im_scale = 1.0f;
+  int tap_key_h = -1, tap_key_w = -1;
+  int last_r1 = 0, last_r2 = 0;
+  // HIP graph of one image size
+  hipGraphExec_t gexec = nullptr;
+  int graph_h = -1, graph_w = -1, seen_h = -1, seen_w = -1;
+};
+
+namespace {
+
+int dev_ensure(mnc_net* n, DevBuf* b, size_t bytes) {
+  if (bytes <= b->cap) return MNC_OK;
+  if (b->p) {
+    int rc = mnc_dev_free(n->ctx, b->p);
+    if (rc) return rc;
+    b->p = nullptr; b->cap = 0;
+  }
+  const size_t want = bytes + (bytes >> 3) + 256;
+  int rc = mnc_dev_alloc(n->ctx, want, &b->p);
+  if (rc) return rc;
+  b->cap = want;
+  if (n->gexec) { (void)hipGraphExecDestroy(n->gexec); n->gexec = nullptr; n->graph_h = n->graph_w = -1; }   // addresses changed
+  return MNC_OK;
+}
+
+const HostBlob* find(mnc_net* n, const std::string& layer, int index) {
+  auto it = n->params.find(layer + "/" + std::to_string(index));
+  return it == n->params.end() ? nullptr : &it->second;
+}
+
+int upload(mnc_net* n, const std::vector<float>& v, float** out) {
+  void* p = nullptr;
+  int rc = mnc_dev_alloc(n->ctx, v.size() * 4, &p);
+  if (rc) return rc;
+  rc = mnc_h2d(n->ctx, p, v.data(), v.size() * 4);
+  if (rc) return rc;
+  *out = (float*)p;
+  return MNC_OK;
+}
+
+#define NET_TRY(expr)        \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+int need(mnc_net* n, const char* layer, int index, size_t count, const HostBlob** out) {
+  const HostBlob* b = find(n, layer, index);
+  if (!b) {
+    set_error("mnc_net: parameter %s/%d has not been set", layer, index);
+    return MNC_ERR_STATE;
+  }
+  if (b->v.size() != count) {
+    set_error("mnc_net: parameter %s/%d holds %zu values, the configured graph needs %zu", layer, index, b->v.size(), count);
+    return MNC_ERR_INVALID;
+  }
+  *out = b;
+  return MNC_OK;
+}
+
+// One InnerProduct's weights: [N][K] in Caffe order; geo = (C, PH, PW) when the bottom is a per-RoI feature (the engine's
+// rows are (h, w, c): permute the columns once), then the math mode's packed form when the product is large enough
+// (engine.py: 2*M*N*K >= 2e9 with M = post_nms_topn; f16 needs K % 64 == 0, bf16x3 K % 32 == 0).
+int prepare_fc(mnc_net* n, const char* layer, int N, int K, int C, int PH, int PW, mnc_net::Fc* fc) {
+  const HostBlob *w, *b;
+  NET_TRY(need(n, layer, 0, (size_t)N * K, &w));
+  NET_TRY(need(n, layer, 1, (size_t)N, &b));
+  fc->N = N; fc->K = K;
+  NET_TRY(upload(n, b->v, &fc->b));
+  float* raw = nullptr;
+  NET_TRY(upload(n, w->v, &raw));
+  if (PH * PW > 1) {
+    void* perm = nullptr;
+    NET_TRY(mnc_dev_alloc(n->ctx, (size_t)N * K * 4, &perm));
+    NET_TRY(mnc_pack_fc_weights(n->ctx, raw, (float*)perm, N, C, PH, PW));
+    NET_TRY(mnc_dev_free(n->ctx, raw));
+    raw = (float*)perm;
+  }
+  const bool big = 2.0 * n->cfg.post_nms_topn * (double)N * (double)K >= 2.0e9;
+  const bool f16 = n->cfg.math == 2 && K % 64 == 0 && big;
+  const bool x3 = !f16 && n->cfg.math != 0 && K % 32 == 0 && big;
+  fc->kind = f16 ? 2 : x3 ? 1 : 0;
+  if (fc->kind == 0) { fc->w = raw; return MNC_OK; }
+  void* packed = nullptr;
+  NET_TRY(mnc_dev_alloc(n->ctx, (size_t)((N + 127) / 128) * 128 * K * (f16 ? 2 : 4), &packed));
+  NET_TRY(f16 ? mnc_pack_fc_f16(n->ctx, raw, packed, N, K) : mnc_pack_fc_bf16x3(n->ctx, raw, packed, N, K));
+  NET_TRY(mnc_dev_free(n->ctx, raw));
+  fc->w = packed;
+  return MNC_OK;
+}
+
+int run_fc(mnc_net* n, const mnc_net::Fc& fc, const float* a, float* out, int M, int ldc, int act) {
+  if (M == 0) return MNC_OK;
+  if (fc.kind == 2) return mnc_fc_f16(n->ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  if (fc.kind == 1) return mnc_fc_bf16x3(n->ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  return mnc_fc(n->ctx, a, (const float*)fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+}
+
+int finalize(mnc_net* n) {
+  if (n->finalized) return MNC_OK;
+  const mnc_net_config& c = n->cfg;
+  const HostBlob *w, *b;
+  // trunk + rpn_conv_3x3
+  int cin = 3;
+  for (int i = 0; i < 14; ++i) {
+    const char* name = i < 13 ? kTrunk[i] : "rpn_conv_3x3";
+    const int cout = i < 13 ? c.trunk_channels[kTrunkStage[i]] : c.rpn_channels;
+    NET_TRY(need(n, name, 0, (size_t)cout * cin * 9, &w));
+    NET_TRY(need(n, name, 1, (size_t)cout, &b));
+    NET_TRY(upload(n, b->v, &n->b_conv[i]));
+    if (i == 0) {
+      NET_TRY(upload(n, w->v, &n->w_c3));
+    } else {
+      float* raw = nullptr;
+      NET_TRY(upload(n, w->v, &raw));
+      n->conv_fast[i] = cout % 32 == 0;        // engine.py:_conv_kind: 'fast3x3' needs Cout % 32 == 0, otherwise 'general'
+      if (n->conv_fast[i]) {
+        const int pitch = c.math == 0 ? 76 : 84;
+        NET_TRY(mnc_dev_alloc(n->ctx, (size_t)(cin / 8) * cout * pitch * 4, &n->w_conv[i]));
+        NET_TRY(c.math == 0 ? mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
+                : c.math == 1 ? mnc_pack_conv3x3_bf16x3(n->ctx, raw, n->w_conv[i], cout, cin)
+                              : mnc_pack_conv3x3_f16(n->ctx, raw, n->w_conv[i], cout, cin));
+      } else if (c.math == 2) {
+        NET_TRY(mnc_dev_alloc(n->ctx, (size_t)9 * ((cin + 31) / 32) * 32 * cout * 2, &n->w_conv[i]));
+        NET_TRY(mnc_pack_conv_weights_f16(n->ctx, raw, n->w_conv[i], cout, cin, 3, 3));
+      } else {
+        NET_TRY(mnc_dev_alloc(n->ctx, (size_t)cout * cin * 9 * 4, &n->w_conv[i]));
+        NET_TRY(mnc_pack_conv_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin, 3, 3));
+      }
+      NET_TRY(mnc_dev_free(n->ctx, raw));
+    }
+    cin = cout;
+  }
+  const int A = c.num_anchors, RC = c.rpn_channels;
+  NET_TRY(need(n, "rpn_cls_score", 0, (size_t)2 * A * RC, &w)); NET_TRY(upload(n, w->v, &n->w_rpn_cls));
+  NET_TRY(need(n, "rpn_cls_score", 1, (size_t)2 * A, &b));      NET_TRY(upload(n, b->v, &n->b_rpn_cls));
+  NET_TRY(need(n, "rpn_bbox_pred", 0, (size_t)4 * A * RC, &w)); NET_TRY(upload(n, w->v, &n->w_rpn_box));
+  NET_TRY(need(n, "rpn_bbox_pred", 1, (size_t)4 * A, &b));      NET_TRY(upload(n, b->v, &n->b_rpn_box));
+  // heads (shared by both stages, test.prototxt:514-515 <-> :829-834)
+  const int C5 = c.trunk_channels[4], P = c.roi_size, S = c.mask_size, F = c.fc_dim, K = c.num_classes;
+  NET_TRY(prepare_fc(n, "fc6_maskest", c.mask_fc, C5 * P * P, C5, P, P, &n->fc_maskest));
+  NET_TRY(prepare_fc(n, "mask_pred", S * S, c.mask_fc, c.mask_fc, 1, 1, &n->fc_maskpred));
+  NET_TRY(prepare_fc(n, "fc6", F, C5 * (P / 2) * (P / 2), C5, P / 2, P / 2, &n->fc6));
+  NET_TRY(prepare_fc(n, "fc7", F, F, F, 1, 1, &n->fc7));
+  NET_TRY(prepare_fc(n, "fc6_mask", F, C5 * (P / 2) * (P / 2), C5, P / 2, P / 2, &n->fc6m));
+  NET_TRY(prepare_fc(n, "fc7_mask", F, F, F, 1, 1, &n->fc7m));
+  {   // cls_score | seg_cls_score | bbox_pred as ONE GEMM over the concatenated weights (sibling InnerProducts on join_box_mask)
+    const char* names[3] = {"cls_score", "seg_cls_score", "bbox_pred"};
+    const int widths[3] = {K, K, 4 * K};
+    std::vector<float> W, B;
+    for (int i = 0; i < 3; ++i) {
+      NET_TRY(need(n, names[i], 0, (size_t)widths[i] * 2 * F, &w));
+      NET_TRY(need(n, names[i], 1, (size_t)widths[i], &b));
+      W.insert(W.end(), w->v.begin(), w->v.end());
+      B.insert(B.end(), b->v.begin(), b->v.end());
+    }
+    n->fc_heads.N = 6 * K; n->fc_heads.K = 2 * F; n->fc_heads.kind = 0;
+    float* dw = nullptr;
+    NET_TRY(upload(n, W, &dw));
+    n->fc_heads.w = dw;
+    NET_TRY(upload(n, B, &n->fc_heads.b));
+  }
+  NET_TRY(mnc_ctx_sync(n->ctx));
+  n->params.clear();                 // the host copies are no longer needed
+  n->finalized = true;
+  return MNC_OK;
+}
+
+// Buffers for an image whose network input is OH x OW; fixed-size RoI buffers on first use.
+int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
+  const mnc_net_config& c = n->cfg;
+  NET_TRY(dev_ensure(n, &n->img, (size_t)H * W * 3));
+  NET_TRY(dev_ensure(n, &n->taps, (size_t)(2 * OW + 2 * OH) * 4));
+  NET_TRY(dev_ensure(n, &n->data, (size_t)3 * OH * OW * 4));
+  int h = OH, w = OW, pi = 0;
+  for (int i = 0; i < 13; ++i) {
+    const int ch = c.trunk_channels[kTrunkStage[i]];
+    NET_TRY(dev_ensure(n, &n->act[i], (size_t)ch * h * w * 4));
+    if (kPoolAfter[i]) {
+      h = pool_out(h); w = pool_out(w);
+      NET_TRY(dev_ensure(n, &n->pooled[pi++], (size_t)ch * h * w * 4));
+    }
+  }
+  const int A = c.num_anchors;
+  NET_TRY(dev_ensure(n, &n->rpn_out, (size_t)c.rpn_channels * h * w * 4));
+  NET_TRY(dev_ensure(n, &n->rpn_score, (size_t)2 * A * h * w * 4));
+  NET_TRY(dev_ensure(n, &n->rpn_prob, (size_t)2 * A * h * w * 4));
+  NET_TRY(dev_ensure(n, &n->rpn_bbox, (size_t)4 * A * h * w * 4));
+  const int R = c.post_nms_topn, C5 = c.trunk_channels[4], P = c.roi_size, S = c.mask_size, F = c.fc_dim, K = c.num_classes;
+  NET_TRY(dev_ensure(n, &n->rois, (size_t)R * 5 * 4));
+  NET_TRY(dev_ensure(n, &n->rois_ext, (size_t)R * 5 * 4));
+  NET_TRY(dev_ensure(n, &n->feat14, (size_t)R * P * P * C5 * 4));
+  NET_TRY(dev_ensure(n, &n->h_mask, (size_t)R * c.mask_fc * 4));
+  NET_TRY(dev_ensure(n, &n->m14, (size_t)R * P * P * 4));
+  NET_TRY(dev_ensure(n, &n->box7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
+  NET_TRY(dev_ensure(n, &n->mask7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
+  NET_TRY(dev_ensure(n, &n->f6, (size_t)R * F * 4));
+  NET_TRY(dev_ensure(n, &n->f6m, (size_t)R * F * 4));
+  NET_TRY(dev_ensure(n, &n->join, (size_t)R * 2 * F * 4));
+  NET_TRY(dev_ensure(n, &n->heads, (size_t)R * 6 * K * 4));
+  NET_TRY(dev_ensure(n, &n->boxes, (size_t)2 * R * 4 * 4));
+  NET_TRY(dev_ensure(n, &n->masks, (size_t)2 * R * S * S * 4));
+  NET_TRY(dev_ensure(n, &n->scores, (size_t)2 * R * K * 4));
+  const size_t rows = (size_t)(K - 1) * c.max_per_image;
+  NET_TRY(dev_ensure(n, &n->records, rows * (6 + S * S) * 4));
+  NET_TRY(dev_ensure(n, &n->counts, 256));
+  if ((size_t)H * W * 3 > n->pin_img_cap) {
+    if (n->pin_img) NET_TRY(mnc_host_free(n->ctx, n->pin_img));
+    n->pin_img = nullptr;
+    NET_TRY(mnc_host_alloc(n->ctx, (size_t)H * W * 3 + 4096, (void**)&n->pin_img));
+    n->pin_img_cap = (size_t)H * W * 3 + 4096;
+    if (n->gexec) { (void)hipGraphExecDestroy(n->gexec); n->gexec = nullptr; n->graph_h = n->graph_w = -1; }
+  }
+  const size_t out_bytes = 512 + rows * (6 + S * S) * 4;
+  if (out_bytes > n->pin_out_cap) {
+    if (n->pin_out) NET_TRY(mnc_host_free(n->ctx, n->pin_out));
+    n->pin_out = nullptr;
+    NET_TRY(mnc_host_alloc(n->ctx, out_bytes, (void**)&n->pin_out));
+    n->pin_out_cap = out_bytes;
+    if (n->gexec) { (void)hipGraphExecDestroy(n->gexec); n->gexec = nullptr; n->graph_h = n->graph_w = -1; }
+  }
+  return MNC_OK;
+}
+
+// prepare_mnc_args (tools/demo.py:54-76): scale, network-input size, tap tables (uploaded when the geometry changes).
+int set_geometry(mnc_net* n, int H, int W) {
+  const mnc_net_config& c = n->cfg;
+  const int shortside = H < W ? H : W, longside = H < W ? W : H;
+  double scale = (double)c.target_size / (double)shortside;
+  if (std::nearbyint(scale * longside) > c.max_size) scale = (double)c.max_size / (double)longside;    // np.round: half to even
+  const int OH = (int)std::nearbyint(H * scale), OW = (int)std::nearbyint(W * scale);                  // python round()
+  NET_TRY(ensure_buffers(n, H, W, OH, OW));
+  n->H = H; n->W = W; n->OH = OH; n->OW = OW;
+  n->im_scale = (float)scale;
+  if (n->tap_key_h != H || n->tap_key_w != W) {
+    std::vector<int> lo(OW > OH ? OW : OH);
+    std::vector<float> fr(lo.size());
+    std::vector<float> table((size_t)2 * OW + 2 * OH);
+    linear_taps(OW, W, scale, lo.data(), fr.data());
+    memcpy(table.data(), lo.data(), (size_t)OW * 4);
+    memcpy(table.data() + OW, fr.data(), (size_t)OW * 4);
+    linear_taps(OH, H, scale, lo.data(), fr.data());
+    memcpy(table.data() + 2 * OW, lo.data(), (size_t)OH * 4);
+    memcpy(table.data() + 2 * OW + OH, fr.data(), (size_t)OH * 4);
+    NET_TRY(mnc_h2d(n->ctx, n->taps.p, table.data(), table.size() * 4));
+    n->tap_key_h = H; n->tap_key_w = W;
+  }
+  return MNC_OK;
+}
+
+int conv3(mnc_net* n, int i, const float* in, float* out, int h, int w, int cin, int cout) {
+  const mnc_net_config& c = n->cfg;
+  if (!n->conv_fast[i]) {
+    if (c.math == 2) return mnc_conv2d_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
+    return mnc_conv2d(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
+  }
+  if (c.math == 0) return mnc_conv3x3(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
+  if (c.math == 1) return mnc_conv3x3_bf16x3(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
+  return mnc_conv3x3_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
+}
+
+// data -> conv5_3 -> RPN -> rois (test.prototxt:19-475)
+int run_trunk(mnc_net* n) {
+  const mnc_net_config& c = n->cfg;
+  mnc_ctx* ctx = n->ctx;
+  const float* t = (const float*)n->taps.p;
+  NET_TRY(mnc_prep_image(ctx, (const unsigned char*)n->img.p, n->H, n->W, c.pixel_means, (const int*)t, t + n->OW, n->OW,
+                         (const int*)(t + 2 * n->OW), t + 2 * n->OW + n->OH, n->OH, (float*)n->data.p, n->OH, n->OW));
+  int h = n->OH, w = n->OW, pi = 0, cin = 3;
+  const float* cur = (const float*)n->data.p;
+  for (int i = 0; i < 13; ++i) {
+    const int cout = c.trunk_channels[kTrunkStage[i]];
+    float* out = (float*)n->act[i].p;
+    if (i == 0) NET_TRY(mnc_conv3x3_c3(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1));
+    else NET_TRY(conv3(n, i, cur, out, h, w, cin, cout));
+    cur = out; cin = cout;
+    if (kPoolAfter[i]) {
+      float* p = (float*)n->pooled[pi++].p;
+      NET_TRY(mnc_maxpool2_c8(ctx, cur, p, cout, h, w));
+      h = pool_out(h); w = pool_out(w);
+      cur = p;
+    }
+  }
+  n->fh = h; n->fw = w;
+  const int A = c.num_anchors;
+  NET_TRY(conv3(n, 13, cur, (float*)n->rpn_out.p, h, w, cin, c.rpn_channels));
+  NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn_cls, n->b_rpn_cls, (float*)n->rpn_score.p, h, w,
+                              c.rpn_channels, 2 * A));
+  NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn_box, n->b_rpn_box, (float*)n->rpn_bbox.p, h, w,
+                              c.rpn_channels, 4 * A));
+  NET_TRY(mnc_rpn_softmax(ctx, (const float*)n->rpn_score.p, (float*)n->rpn_prob.p, A, h, w));
+  NET_TRY(mnc_proposal(ctx, (const float*)n->rpn_prob.p, (const float*)n->rpn_bbox.p, A, h, w, c.anchors, c.feat_stride,
+                       (float)n->OH, (float)n->OW, n->im_scale, c.pre_nms_topn, c.post_nms_topn, c.rpn_nms_thresh,
+                       c.rpn_min_size, (float*)n->rois.p, nullptr));
+  return MNC_OK;
+}
+
+// One head stage on R rois (test.prototxt:479-785 resp. :809-1106): mask head, box + mask feature branches, the three sibling
+// classifiers; masks / seg scores land in rows [row0, row0 + R) of the stacked result arrays.
+int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
+  const mnc_net_config& c = n->cfg;
+  mnc_ctx* ctx = n->ctx;
+  const int C5 = c.trunk_channels[4], P = c.roi_size, S = c.mask_size, F = c.fc_dim, K = c.num_classes;
+  const float* conv5 = (const float*)n->act[12].p;
+  float* feat14 = (float*)n->feat14.p;
+  // stage 2: ROIWarping 28x28 + MAX 2x2/2 fused; stage 4: ROIWarping 14x14 directly (test.prototxt:479-505 vs :809-820)
+  NET_TRY(mnc_roi_warp(ctx, conv5, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14));
+  float* masks = (float*)n->masks.p + (size_t)row0 * S * S;
+  NET_TRY(run_fc(n, n->fc_maskest, feat14, (float*)n->h_mask.p, R, c.mask_fc, 1));
+  NET_TRY(run_fc(n, n->fc_maskpred, (const float*)n->h_mask.p, masks, R, S * S, 2));            // + Sigmoid; MaskLayer = reshape
+  NET_TRY(mnc_mask_resize(ctx, masks, (float*)n->m14.p, R, S, S, P, P));
+  NET_TRY(mnc_maxpool2_rhwc(ctx, feat14, (float*)n->box7.p, R, P, P, C5));
+  float* join = (float*)n->join.p;                                                             // Concat(fc7_mask, fc7): column slices
+  NET_TRY(run_fc(n, n->fc6, (const float*)n->box7.p, (float*)n->f6.p, R, F, 1));
+  NET_TRY(run_fc(n, n->fc7, (const float*)n->f6.p, join + F, R, 2 * F, 1));
+  NET_TRY(mnc_mask_pool(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1));
+  NET_TRY(run_fc(n, n->fc6m, (const float*)n->mask7.p, (float*)n->f6m.p, R, F, 1));
+  NET_TRY(run_fc(n, n->fc7m, (const float*)n->f6m.p, join, R, 2 * F, 1));
+  float* heads = (float*)n->heads.p;
+  NET_TRY(run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0));
+  float* scores = (float*)n->scores.p + (size_t)row0 * K;
+  if (R) NET_TRY(mnc_softmax_rows_ld(ctx, heads + K, 6 * K, scores, R, K));                     // seg_cls_prob
+  if (!second)
+    NET_TRY(mnc_stage_bridge(ctx, rois, heads + 2 * K, 6 * K, scores, K, R, K, (float)n->OH, (float)n->OW,
+                             (float*)n->rois_ext.p));
+  return MNC_OK;
+}
+
+// heads of both stages on r1 proposals, im_detect's tail, voting; records + counts + the proposal count to the pinned buffer
+int run_heads_and_vote(mnc_net* n, int r1) {
+  const mnc_net_config& c = n->cfg;
+  mnc_ctx* ctx = n->ctx;
+  const int S = c.mask_size, K = c.num_classes;
+  NET_TRY(run_stage(n, (const float*)n->rois.p, r1, false, 0));
+  NET_TRY(run_stage(n, (const float*)n->rois_ext.p, r1, true, r1));
+  NET_TRY(mnc_detect_tail(ctx, (const float*)n->rois.p, r1, (const float*)n->rois_ext.p, r1, n->im_scale, n->H, n->W,
+                          (float*)n->boxes.p));
+  const int rows = (K - 1) * c.max_per_image;
+  NET_TRY(mnc_vote_instances(ctx, (const float*)n->boxes.p, (const float*)n->masks.p, (const float*)n->scores.p, 2 * r1, K, S,
+                             c.max_per_image, c.vote_nms_thresh, c.vote_iou_thresh, n->H, n->W, (float*)n->records.p, rows,
+                             (int*)n->counts.p));
+  n->last_r1 = r1; n->last_r2 = r1;
+  return MNC_OK;
+}
+
+int enqueue_outputs(mnc_net* n) {
+  const mnc_net_config& c = n->cfg;
+  const size_t rec_bytes = (size_t)c.max_per_image * (6 + c.mask_size * c.mask_size) * 4;     // the first max_per_image rows
+  NET_TRY(mnc_d2h_async(n->ctx, n->pin_out, n->counts.p, (size_t)c.num_classes * 4));
+  NET_TRY(mnc_d2h_async(n->ctx, (char*)n->pin_out + 256, proposal_count_ptr(n->ctx), 4));
+  NET_TRY(mnc_d2h_async(n->ctx, (char*)n->pin_out + 512, n->records.p, rec_bytes));
+  return MNC_OK;
+}
+
+int enqueue_image(mnc_net* n) {
+  NET_TRY(mnc_h2d_async(n->ctx, n->img.p, n->pin_img, (size_t)n->H * n->W * 3));
+  NET_TRY(run_trunk(n));
+  NET_TRY(run_heads_and_vote(n, n->cfg.post_nms_topn));
+  return enqueue_outputs(n);
+}
+
+// The asynchronous part of one image: eager the first time a size is seen (buffers, scratch and function attributes settle),
+// captured into a graph the second time, replayed from then on.
+int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
+  MNC_REQUIRE(n && bgr_host && H >= 16 && W >= 16, "mnc_forward_image: bad argument");
+  NET_TRY(finalize(n));
+  MNC_HIP_TRY(hipSetDevice(n->ctx->device));
+  NET_TRY(set_geometry(n, H, W));
+  memcpy(n->pin_img, bgr_host, (size_t)H * W * 3);
+  hipStream_t s = n->ctx->stream;
+  const bool want_graph = n->cfg.use_graph && n->ctx->profiling == 0;
+  if (want_graph && n->gexec && n->graph_h == H && n->graph_w == W) {
+    MNC_HIP_TRY(hipGraphLaunch(n->gexec, s));
+    return MNC_OK;
+  }
+  if (want_graph && n->seen_h == H && n->seen_w == W) {
+    if (n->gexec) { (void)hipGraphExecDestroy(n->gexec); n->gexec = nullptr; }
+    hipGraph_t g = nullptr;
+    MNC_HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    int rc = enqueue_image(n);
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc == MNC_OK && e == hipSuccess && g) {
+      e = hipGraphInstantiate(&n->gexec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e == hipSuccess) {
+        n->graph_h = H; n->graph_w = W;
+        MNC_HIP_TRY(hipGraphLaunch(n->gexec, s));
+        return MNC_OK;
+      }
+      n->gexec = nullptr;
+    } else if (g) {
+      (void)hipGraphDestroy(g);
+    }
+    (void)hipGetLastError();
+    n->cfg.use_graph = 0;            // capture is not available here: stay on direct launches
+    if (rc) return rc;
+  }
+  n->seen_h = H; n->seen_w = W;
+  return enqueue_image(n);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mnc_net_default_config(mnc_net_config* cfg) {
+  MNC_REQUIRE(cfg, "mnc_net_default_config: null pointer");
+  memset(cfg, 0, sizeof(*cfg));
+  const int tc[5] = {64, 128, 256, 512, 512};
+  memcpy(cfg->trunk_channels, tc, sizeof(tc));
+  cfg->rpn_channels = 512;
+  cfg->num_anchors = 9;
+  // transform.anchors.generate_anchors(): ratios {0.5, 1, 2} x scales {8, 16, 32} around (0, 0, 15, 15)  (anchors.py:38-49)
+  const float a[36] = {-84, -40, 99, 55,  -176, -88, 191, 103,  -360, -184, 375, 199,  -56, -56, 71, 71,  -120, -120, 135, 135,
+                       -248, -248, 263, 263,  -36, -80, 51, 95,  -80, -168, 95, 183,  -168, -344, 183, 359};
+  memcpy(cfg->anchors, a, sizeof(a));
+  cfg->feat_stride = 16;
+  cfg->pre_nms_topn = 6000; cfg->post_nms_topn = 300;
+  cfg->rpn_nms_thresh = 0.7f; cfg->rpn_min_size = 16.0f;
+  cfg->mask_fc = 256; cfg->mask_size = 21;
+  cfg->fc_dim = 4096;
+  cfg->num_classes = 21;
+  cfg->roi_size = 14;
+  cfg->spatial_scale = 0.0625f;
+  cfg->target_size = 600; cfg->max_size = 1000;
+  cfg->pixel_means[0] = 102.9801; cfg->pixel_means[1] = 115.9465; cfg->pixel_means[2] = 122.7717;
+  cfg->max_per_image = 100;
+  cfg->vote_nms_thresh = 0.3f; cfg->vote_iou_thresh = 0.5f;
+  cfg->math = 0;
+  cfg->use_graph = 1;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
+  MNC_REQUIRE(ctx && cfg && out, "mnc_net_create: null pointer");
+  *out = nullptr;
+  for (int i = 0; i < 5; ++i)
+    MNC_REQUIRE(cfg->trunk_channels[i] > 0 && cfg->trunk_channels[i] % 8 == 0 && cfg->trunk_channels[i] <= 4096,
+                "mnc_net_create: trunk width %d must be a positive multiple of 8", cfg->trunk_channels[i]);
+  MNC_REQUIRE(cfg->trunk_channels[0] <= 512, "mnc_net_create: conv1 width %d > 512", cfg->trunk_channels[0]);
+  MNC_REQUIRE(cfg->rpn_channels > 0 && cfg->rpn_channels % 8 == 0 && cfg->num_anchors > 0 && cfg->num_anchors <= 16,
+              "mnc_net_create: RPN shape");
+  MNC_REQUIRE(cfg->roi_size > 0 && cfg->roi_size % 4 == 0 && cfg->mask_size >= 2 && cfg->num_classes >= 2 &&
+              cfg->post_nms_topn > 0 && cfg->max_per_image > 0 && cfg->fc_dim > 0 && cfg->mask_fc > 0,
+              "mnc_net_create: head shape");
+  MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 2, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3) or 2 (f16)");
+  MNC_REQUIRE(cfg->target_size > 0 && cfg->max_size >= cfg->target_size, "mnc_net_create: target_size / max_size");
+  mnc_net* n = new (std::nothrow) mnc_net();
+  if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
+  n->ctx = ctx;
+  n->cfg = *cfg;
+  *out = n;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_net_set_param(mnc_net* net, const char* layer, int index, const float* data_host, size_t count) {
+  MNC_REQUIRE(net && layer && data_host && index >= 0 && index <= 1 && count > 0, "mnc_net_set_param: bad argument");
+  MNC_REQUIRE(!net->finalized, "mnc_net_set_param: the weights of this net are already packed (set them before the first image)");
+  HostBlob& b = net->params[std::string(layer) + "/" + std::to_string(index)];
+  b.v.assign(data_host, data_host + count);
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_net_load_file(mnc_net* net, const char* path) {
+  MNC_REQUIRE(net && path, "mnc_net_load_file: null pointer");
+  FILE* f = fopen(path, "rb");
+  MNC_REQUIRE(f, "mnc_net_load_file: cannot open %s", path);
+  char magic[8];
+  unsigned n = 0;
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "MNCW0001", 8) == 0 && fread(&n, 4, 1, f) == 1;
+  int rc = MNC_OK;
+  for (unsigned i = 0; ok && i < n; ++i) {
+    unsigned short len = 0;
+    unsigned char idx = 0, nd = 0;
+    char name[256];
+    unsigned dims[8];
+    ok = fread(&len, 2, 1, f) == 1 && len < sizeof(name) && fread(name, 1, len, f) == len && fread(&idx, 1, 1, f) == 1 &&
+         fread(&nd, 1, 1, f) == 1 && nd <= 8 && fread(dims, 4, nd, f) == nd;
+    if (!ok) break;
+    name[len] = 0;
+    size_t count = 1;
+    for (int d = 0; d < nd; ++d) count *= dims[d];
+    std::vector<float> v(count);
+    ok = count > 0 && fread(v.data(), 4, count, f) == count;
+    if (!ok) break;
+    if (idx <= 1) {
+      rc = mnc_net_set_param(net, name, idx, v.data(), count);
+      if (rc) break;
+    }
+  }
+  fclose(f);
+  if (rc) return rc;
+  MNC_REQUIRE(ok, "mnc_net_load_file: %s is not a complete MNCW0001 file", path);
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host, int H, int W, float** d_records, int** d_counts) {
+  int rc = launch_image(net, bgr_host, H, W);
+  if (rc) return rc;
+  if (d_records) *d_records = (float*)net->records.p;
+  if (d_counts) *d_counts = (int*)net->counts.p;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H, int W, float* records_host, int record_cap,
+                      int* counts_host) {
+  MNC_REQUIRE(net && records_host && counts_host && record_cap >= 0, "mnc_forward_image: null pointer");
+  const mnc_net_config& c = net->cfg;
+  const int D = 6 + c.mask_size * c.mask_size;
+  MNC_REQUIRE(record_cap <= (c.num_classes - 1) * c.max_per_image, "mnc_forward_image: record_cap %d > %d", record_cap,
+              (c.num_classes - 1) * c.max_per_image);
+  int rc = launch_image(net, bgr_host, H, W);
+  if (rc) return rc;
+  MNC_HIP_TRY(hipStreamSynchronize(net->ctx->stream));
+  const int* head = (const int*)net->pin_out;
+  const int n_prop = *(const int*)((const char*)net->pin_out + 256);
+  if (n_prop < c.post_nms_topn) {
+    // fewer proposals survived the RPN's NMS than post_nms_topn: the speculative rows were zero boxes; the reference runs the
+    // heads on exactly n_prop rois -- so do that (direct launches; rare, and never with a trained RPN on a natural image)
+    NET_TRY(run_heads_and_vote(net, n_prop));
+    NET_TRY(enqueue_outputs(net));
+    MNC_HIP_TRY(hipStreamSynchronize(net->ctx->stream));
+  }
+  const int R = head[0];
+  for (int k = 0; k < c.num_classes; ++k) counts_host[k] = head[k];
+  const int first = c.max_per_image < record_cap ? c.max_per_image : record_cap;
+  const int have = R < first ? R : first;
+  memcpy(records_host, (const char*)net->pin_out + 512, (size_t)have * D * 4);
+  if (have < record_cap) memset(records_host + (size_t)have * D, 0, (size_t)(record_cap - have) * D * 4);
+  if (R > first && record_cap > first) {          // scores tied at the voting threshold: rows beyond max_per_image
+    const int more = (R < record_cap ? R : record_cap) - first;
+    NET_TRY(mnc_d2h(net->ctx, records_host + (size_t)first * D, (const float*)net->records.p + (size_t)first * D,
+                    (size_t)more * D * 4));
+  }
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* ndim) {
+  MNC_REQUIRE(net && name && d_ptr && dims && ndim, "mnc_net_blob: null pointer");
+  const mnc_net_config& c = net->cfg;
+  const std::string s(name);
+  const int A = c.num_anchors, R1 = net->last_r1, R2 = net->last_r2;
+  auto set = [&](void* p, int n, int a, int b, int cc, int d) {
+    *d_ptr = p; *ndim = n; dims[0] = a; dims[1] = b; dims[2] = cc; dims[3] = d;
+    return MNC_OK;
+  };
+  if (s == "data") return set(net->data.p, 4, 1, 3, net->OH, net->OW);
+  if (s == "conv5_3") return set(net->act[12].p, 4, 1, c.trunk_channels[4], net->fh, net->fw);
+  if (s == "rpn_cls_prob_reshape") return set(net->rpn_prob.p, 4, 1, 2 * A, net->fh, net->fw);
+  if (s == "rpn_bbox_pred") return set(net->rpn_bbox.p, 4, 1, 4 * A, net->fh, net->fw);
+  if (s == "rois") return set(net->rois.p, 2, R1, 5, 0, 0);
+  if (s == "rois_ext") return set(net->rois_ext.p, 2, R2, 5, 0, 0);
+  if (s == "mask_proposal") return set(net->masks.p, 4, R1 + R2, 1, c.mask_size, c.mask_size);
+  if (s == "seg_cls_prob") return set(net->scores.p, 2, R1 + R2, c.num_classes, 0, 0);
+  if (s == "boxes") return set(net->boxes.p, 2, R1 + R2, 4, 0, 0);
+  set_error("mnc_net_blob: unknown blob %s", name);
+  return MNC_ERR_INVALID;
+}
+
+int mnc_net_destroy(mnc_net* net) {
+  if (!net) return MNC_OK;
+  mnc_ctx* ctx = net->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (net->gexec) (void)hipGraphExecDestroy(net->gexec);
+  DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_bbox, &net->rpn_prob, &net->rois,
+                    &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
+                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->records, &net->counts};
+  for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+  for (auto& b : net->act) if (b.p) (void)hipFree(b.p);
+  for (auto& b : net->pooled) if (b.p) (void)hipFree(b.p);
+  void* singles[] = {net->w_c3, net->w_rpn_cls, net->b_rpn_cls, net->w_rpn_box, net->b_rpn_box};
+  for (void* p : singles) if (p) (void)hipFree(p);
+  for (int i = 0; i < 14; ++i) {
+    if (net->w_conv[i]) (void)hipFree(net->w_conv[i]);
+    if (net->b_conv[i]) (void)hipFree(net->b_conv[i]);
+  }
+  mnc_net::Fc* fcs[] = {&net->fc_maskest, &net->fc_maskpred, &net->fc6, &net->fc7, &net->fc6m, &net->fc7m, &net->fc_heads};
+  for (mnc_net::Fc* f : fcs) {
+    if (f->w) (void)hipFree(f->w);
+    if (f->b) (void)hipFree(f->b);
+  }
+  if (net->pin_img) (void)hipHostFree(net->pin_img);
+  if (net->pin_out) (void)hipHostFree(net->pin_out);
+  delete net;
+  clear_error();
+  return MNC_OK;
+}
+
+}  // extern "C"

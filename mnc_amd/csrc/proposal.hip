@@ -254,6 +254,10 @@ struct mnc_proposal_state {
 };
 
 namespace mnc {
+int* proposal_count_ptr(mnc_ctx* ctx) {
+  mnc_proposal_state* st = (mnc_proposal_state*)ctx->proposal;
+  return st ? st->ws.num : nullptr;
+}
 void proposal_state_free(void* state) {
   mnc_proposal_state* st = (mnc_proposal_state*)state;
   if (st->buf) (void)hipFree(st->buf);

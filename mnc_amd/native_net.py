@@ -1,0 +1,144 @@
+"""`NativeNet`: the whole-image C entry points (include/mnc_hip.h: mnc_net_* / mnc_forward_image; csrc/pipeline.hip) from Python.
+
+The caffe-shaped `mnc_amd.engine.Net` executes any prototxt layer by layer from Python (the drop-in for `caffe.Net`); this class
+drives the fixed-function form of ONE graph -- models/VGG16/mnc_5stage/test.prototxt, widths configurable -- where prep, forward,
+the im_detect tail and gpu_mask_voting of an image are one C call (and, after the second image of a size, one HIP graph launch).
+It exists for the bench and for tests; a non-Python host binds the same five functions."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .instances import split_records
+
+MATH = {"fp32": 0, "bf16x3": 1, "f16": 2}
+LAYERS = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1",
+          "conv5_2", "conv5_3", "rpn_conv_3x3", "rpn_cls_score", "rpn_bbox_pred", "fc6_maskest", "mask_pred", "fc6", "fc7",
+          "fc6_mask", "fc7_mask", "cls_score", "seg_cls_score", "bbox_pred"]
+
+
+class NetConfig(ctypes.Structure):
+    """Mirror of `mnc_net_config` (include/mnc_hip.h), field for field."""
+    _fields_ = [("trunk_channels", ctypes.c_int * 5), ("rpn_channels", ctypes.c_int), ("num_anchors", ctypes.c_int),
+                ("anchors", ctypes.c_float * 64), ("feat_stride", ctypes.c_int), ("pre_nms_topn", ctypes.c_int),
+                ("post_nms_topn", ctypes.c_int), ("rpn_nms_thresh", ctypes.c_float), ("rpn_min_size", ctypes.c_float),
+                ("mask_fc", ctypes.c_int), ("mask_size", ctypes.c_int), ("fc_dim", ctypes.c_int), ("num_classes", ctypes.c_int),
+                ("roi_size", ctypes.c_int), ("spatial_scale", ctypes.c_float), ("target_size", ctypes.c_int),
+                ("max_size", ctypes.c_int), ("pixel_means", ctypes.c_double * 3), ("max_per_image", ctypes.c_int),
+                ("vote_nms_thresh", ctypes.c_float), ("vote_iou_thresh", ctypes.c_float), ("math", ctypes.c_int),
+                ("use_graph", ctypes.c_int)]
+
+
+def default_config():
+    cfg = NetConfig()
+    _lib.call("mnc_net_default_config", ctypes.addressof(cfg))
+    return cfg
+
+
+def config_from_weights(weights, math="fp32", use_graph=True, **overrides):
+    """The reference's configuration (lib/mnc_config.py defaults) with the widths read off a weight dict {layer: [W, b]}."""
+    cfg = default_config()
+    stage_first = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
+    for i, name in enumerate(stage_first):
+        cfg.trunk_channels[i] = int(weights[name][0].shape[0])
+    cfg.rpn_channels = int(weights["rpn_conv_3x3"][0].shape[0])
+    cfg.mask_fc = int(weights["fc6_maskest"][0].shape[0])
+    cfg.fc_dim = int(weights["fc6"][0].shape[0])
+    cfg.num_classes = int(weights["cls_score"][0].shape[0])
+    cfg.math = MATH[math]
+    cfg.use_graph = 1 if use_graph else 0
+    for k, v in overrides.items():
+        if k == "pixel_means":
+            for i in range(3):
+                cfg.pixel_means[i] = float(np.asarray(v).reshape(-1)[i])
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+class NativeNet(object):
+    def __init__(self, weights, device_id=0, math="fp32", use_graph=True, **overrides):
+        """weights: {layer: [W, b]} in Caffe layout (what mnc_amd.synth / caffemodel.load_weights return), or the path of a
+        flat MNCW0001 file (caffemodel.save_flat) together with cfg=<NetConfig>."""
+        from .engine import _Ctx
+        cfg = overrides.pop("cfg", None)
+        self._ctx = _Ctx(device_id)
+        if cfg is None:
+            cfg = config_from_weights(weights, math, use_graph, **overrides)
+        self.cfg = cfg
+        h = ctypes.c_void_p()
+        _lib.call("mnc_net_create", self._ctx.h, ctypes.addressof(cfg), ctypes.addressof(h))
+        self.h = h.value
+        if isinstance(weights, str):
+            path = weights.encode()
+            _lib.call("mnc_net_load_file", self.h, ctypes.cast(ctypes.c_char_p(path), ctypes.c_void_p))
+        else:
+            for name in LAYERS:
+                for idx in (0, 1):
+                    a = np.ascontiguousarray(weights[name][idx], dtype=np.float32)
+                    nm = name.encode()
+                    _lib.call("mnc_net_set_param", self.h, ctypes.cast(ctypes.c_char_p(nm), ctypes.c_void_p), idx, _lib.ptr(a),
+                              a.size)
+        self.S = int(cfg.mask_size)
+        self.rec_dim = 6 + self.S * self.S
+        self.rows_cap = (int(cfg.num_classes) - 1) * int(cfg.max_per_image)
+
+    def forward_image(self, im, record_cap=None):
+        """uint8 BGR [H,W,3] -> (counts int32[num_classes], records float32[R, 6+S*S]): prep + forward + tail + voting, one call."""
+        im = np.ascontiguousarray(im)
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise TypeError("forward_image takes a uint8 HxWx3 image (got %s %r)" % (im.dtype, im.shape))
+        cap = self.rows_cap if record_cap is None else int(record_cap)
+        rec = np.zeros((cap, self.rec_dim), np.float32)
+        counts = np.zeros(int(self.cfg.num_classes), np.int32)
+        _lib.call("mnc_forward_image", self.h, _lib.ptr(im), im.shape[0], im.shape[1], _lib.ptr(rec), cap, _lib.ptr(counts))
+        return counts, rec[:min(int(counts[0]), cap)]
+
+    def detect(self, im):
+        """-> (list_result_mask, list_result_box) as the reference's gpu_mask_voting returns them."""
+        counts, rec = self.forward_image(im)
+        return split_records(rec, counts[1:], self.S)
+
+    def blob(self, name):
+        """(host copy, shape) of an intermediate blob of the last image in the engine's device layout (tests)."""
+        p, dims, nd = ctypes.c_void_p(), (ctypes.c_int * 4)(), ctypes.c_int(0)
+        nm = name.encode()
+        _lib.call("mnc_net_blob", self.h, ctypes.cast(ctypes.c_char_p(nm), ctypes.c_void_p), ctypes.addressof(p),
+                  ctypes.addressof(dims), ctypes.addressof(nd))
+        shape = tuple(int(dims[i]) for i in range(nd.value))
+        out = np.zeros(shape, np.float32)
+        if out.size:
+            _lib.call("mnc_d2h", self._ctx.h, _lib.ptr(out), p.value, out.nbytes)
+        return out
+
+    def profile(self, enable=True):
+        _lib.call("mnc_prof_enable", self._ctx.h, int(enable))
+        _lib.call("mnc_prof_reset", self._ctx.h)
+
+    def profile_records(self):
+        n = ctypes.c_int(0)
+        _lib.call("mnc_prof_count", self._ctx.h, ctypes.addressof(n))
+        out = []
+        name = ctypes.create_string_buffer(64)
+        ms, fl, by = ctypes.c_float(0), ctypes.c_double(0), ctypes.c_double(0)
+        for i in range(n.value):
+            _lib.call("mnc_prof_get", self._ctx.h, i, ctypes.addressof(name), 64, ctypes.addressof(ms), ctypes.addressof(fl),
+                      ctypes.addressof(by))
+            out.append((name.value.decode(), float(ms.value), float(fl.value), float(by.value)))
+        _lib.call("mnc_prof_reset", self._ctx.h)
+        return out
+
+    def sync(self):
+        _lib.call("mnc_ctx_sync", self._ctx.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.call("mnc_net_destroy", self.h)
+            self.h = None
+            self._ctx.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,150 @@
+"""GPU: the whole-image C entry points (mnc_net_* / mnc_forward_image, csrc/pipeline.hip) against the Python engine running the
+prototxt layer by layer (same kernels, same fused plan -> the same bits), against the oracle voting, and from a plain C program
+with no Python in the process."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import mnc_amd
+from gpu_util import from_c8
+from mnc_amd import caffemodel, models, synth
+from mnc_amd.native_net import NativeNet
+from oracle import host as ohost
+
+pytestmark = pytest.mark.gpu
+mnc_amd.install_paths()
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _engine_reference(net, im):
+    """tools/demo.py per-image body on the Python engine: (blobs, voting lists)."""
+    import demo
+    from transform.mask_transform import gpu_mask_voting
+    boxes, masks, scores = demo.im_detect(im, net)
+    g = lambda n: net.blobs[n]._host_read().copy()
+    blobs = {"rois": g("rois"), "rois_ext": g("rois_ext"), "conv5_3": g("conv5_3"),
+             "rpn_cls_prob_reshape": g("rpn_cls_prob_reshape"), "rpn_bbox_pred": g("rpn_bbox_pred"),
+             "boxes": np.asarray(boxes).copy(), "mask_proposal": np.asarray(masks).copy(), "seg_cls_prob": np.asarray(scores).copy()}
+    lm, lb = gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
+    return blobs, (lm, lb)
+
+
+def _check_against_engine(nat, net, im):
+    blobs, (lm, lb) = _engine_reference(net, im)
+    got_m, got_b = nat.detect(im)
+    c5 = nat.blob("conv5_3")
+    _, C, h, w = c5.shape
+    assert np.array_equal(from_c8(c5.reshape(-1), C, h, w)[None], blobs["conv5_3"])
+    for name in ("rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "rois_ext", "boxes", "mask_proposal", "seg_cls_prob"):
+        a = nat.blob(name)
+        assert a.shape == blobs[name].shape and np.array_equal(a, blobs[name]), name
+    assert [len(b) for b in got_b] == [len(b) for b in lb]
+    assert np.array_equal(np.concatenate(got_b, 0), np.concatenate(lb, 0))
+    assert np.array_equal(np.concatenate(got_m, 0), np.concatenate(lm, 0), equal_nan=True)
+    # and the voting itself against the oracle on the same device outputs
+    om, ob = ohost.gpu_mask_voting(blobs["mask_proposal"], blobs["boxes"], blobs["seg_cls_prob"], 21, 100, im.shape[1], im.shape[0])
+    assert np.array_equal(np.concatenate(got_b, 0), np.concatenate(ob, 0))
+    assert np.array_equal(np.concatenate(got_m, 0), np.concatenate(om, 0), equal_nan=True)
+    return got_m, got_b
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
+def test_native_pipeline_equals_python_engine(math):
+    """Reduced-width graph, three image sizes, several images per size: call 1 of a size launches every kernel, call 2 captures
+    the HIP graph, later calls replay it -- every call equals the Python engine bit for bit (intermediate blobs, rois of both
+    stages, voted instances)."""
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    net = Net(path, w, 1, math=math)
+    nat = NativeNet(w, math=math)
+    try:
+        rng = np.random.default_rng(7)
+        for (H, W), reps in (((75, 100), 4), ((120, 90), 3), ((75, 100), 2)):
+            for _ in range(reps):
+                im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+                _check_against_engine(nat, net, im)
+    finally:
+        nat.close()
+        net.close()
+
+
+def test_native_pipeline_without_graph_and_with_few_proposals(monkeypatch):
+    """use_graph=0 (direct launches every time) gives the same results; with pre_nms_topn = 40 fewer proposals survive than
+    post_nms_topn = 300 -- the speculative heads are re-run on the exact count, as the reference (and the engine) compute it."""
+    from mnc_amd.engine import Net
+    from mnc_config import cfg
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=2)
+    monkeypatch.setitem(cfg.TEST, "RPN_PRE_NMS_TOP_N", 40)
+    net = Net(path, w, 1)
+    nat = NativeNet(w, use_graph=False, pre_nms_topn=40)
+    nat_g = NativeNet(w, use_graph=True, pre_nms_topn=40)
+    try:
+        rng = np.random.default_rng(8)
+        for _ in range(3):
+            im = rng.integers(0, 256, (75, 100, 3), dtype=np.uint8)
+            a = _check_against_engine(nat, net, im)
+            b = _check_against_engine(nat_g, net, im)
+            assert nat.blob("rois").shape[0] <= 40
+            assert np.array_equal(np.concatenate(a[1], 0), np.concatenate(b[1], 0))
+    finally:
+        nat.close()
+        nat_g.close()
+        net.close()
+
+
+def test_native_pipeline_full_size_vgg16():
+    """BASELINE configs[1] shape through the one-call path: 600x1000, VGG-16 widths, 300 RoIs per stage, fp32."""
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt()
+    w = synth.synthetic_weights(path, seed=0)
+    net = Net(path, w, 1)
+    nat = NativeNet(w)
+    try:
+        for seed in (0, 1, 2):
+            im = np.random.default_rng(seed).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+            _check_against_engine(nat, net, im)
+            assert nat.blob("rois").shape == (300, 5)
+    finally:
+        nat.close()
+        net.close()
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc to build the C host program")
+def test_c_program_drives_one_image_without_python(tmp_path):
+    """tests/c/forward_image_main.c: weights from the flat container, one image, three calls (eager, graph capture, graph replay),
+    records to a file -- equal to what the Python wrapper of the same entry points returns."""
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=3)
+    exe = str(tmp_path / "forward_image_main")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "c", "forward_image_main.c"),
+                           "-o", exe, "-L", os.path.join(REPO, "mnc_amd"), "-lmnc_hip", "-Wl,-rpath," + os.path.join(REPO, "mnc_amd"),
+                           "-Wl,-rpath-link,/opt/rocm/lib"])
+    caffemodel.save_flat({k: v for k, v in w.items()}, str(tmp_path / "w.mncw"))
+    im = np.random.default_rng(5).integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    im.tofile(str(tmp_path / "im.raw"))
+    nat = NativeNet(w)
+    try:
+        cfg = nat.cfg
+        with open(str(tmp_path / "cfg.txt"), "w") as f:
+            for i in range(5):
+                f.write("trunk%d %d\n" % (i, cfg.trunk_channels[i]))
+            f.write("rpn_channels %d\nmask_fc %d\nfc_dim %d\nmath 0\nuse_graph 1\n" % (cfg.rpn_channels, cfg.mask_fc, cfg.fc_dim))
+        env = dict(os.environ)
+        env.pop("PYTHONPATH", None)
+        r = subprocess.run([exe, str(tmp_path / "w.mncw"), str(tmp_path / "im.raw"), "90", "120", str(tmp_path / "cfg.txt"),
+                            str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = np.fromfile(str(tmp_path / "out.bin"), dtype=np.uint8)
+        counts = raw[:84].view(np.int32)
+        rec = raw[84:].view(np.float32).reshape(100, 447)
+        want_counts, want_rec = nat.forward_image(im, record_cap=100)
+        assert np.array_equal(counts, want_counts)
+        assert np.array_equal(rec[:len(want_rec)], want_rec, equal_nan=True) and not rec[len(want_rec):].any()
+        assert "instances %d" % counts[0] in r.stdout
+    finally:
+        nat.close()

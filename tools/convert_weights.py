@@ -4,6 +4,7 @@ SolverWrapper.snapshot, lib/caffeWrapper/SolverWrapper.py:100-114) to the .npz c
 
     python tools/convert_weights.py mnc_model.caffemodel.h5 mnc_model.npz
     python tools/convert_weights.py --list mnc_model.caffemodel
+    python tools/convert_weights.py mnc_model.caffemodel.h5 mnc_model.mncw     (flat file for mnc_net_load_file / C hosts)
 
 `caffe.Net(prototxt, path, caffe.TEST)` of this package reads all three containers directly; the conversion is only a
 convenience (an .npz loads faster and is easy to inspect).  Shared parameters (soft links in the HDF5 container) come out as
@@ -31,7 +32,10 @@ def main():
             print("%-28s %s" % (name, "  ".join(shapes)))
     print("%d layers, %.1f M parameters" % (len(w), total / 1e6))
     if args.dst:
-        caffemodel.save_npz(w, args.dst)
+        if args.dst.endswith(".mncw"):                 # flat container for mnc_net_load_file (non-Python hosts)
+            caffemodel.save_flat(w, args.dst)
+        else:
+            caffemodel.save_npz(w, args.dst)
         print("wrote", args.dst)
 
 
