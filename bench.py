@@ -74,6 +74,9 @@ def parse():
                    help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
     p.add_argument("--no-resident", action="store_true", help="skip the secondary resident-input measurement")
+    p.add_argument("--engine", default="native", choices=["native", "python"],
+                   help="native: one C call per image (mnc_forward_image, csrc/pipeline.hip; vgg16 only); python: the caffe-shaped "
+                        "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
     return p.parse_args()
 
@@ -105,6 +108,8 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     conf = CONFIGS[args.config]
     math = args.math or conf["math"]
+    if args.config != "vgg16":
+        args.engine = "python"               # the native pipeline is the VGG-16 5-stage graph; other graphs run on the engine
     launched = "WORLD_SIZE" in os.environ
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
@@ -134,6 +139,7 @@ def main():
     from mnc_amd.engine import Net
     from mnc_config import cfg
     from transform.mask_transform import gpu_mask_voting
+    from mnc_amd.instances import split_records
 
     caffe.set_mode_gpu()
     caffe.set_device(dev_id)
@@ -149,10 +155,17 @@ def main():
     images = [np.random.default_rng(s).integers(0, 256, (H, W, 3), dtype=np.uint8) for s in range(N_IMAGES)]
     nms_t, iou_t = float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH)
 
-    def measure(math, steps, warmup, resident_steps=0):
+    def measure(math, steps, warmup, resident_steps=0, engine=None):
         """Build the net in `math` mode; warmup + `steps` timed steps of the full protocol (upload .. results on the host), then
         optionally `resident_steps` steps of the old resident-input protocol.  -> dict."""
-        net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
+        engine = engine or args.engine
+        native = engine == "native"
+        if native:
+            from mnc_amd.native_net import NativeNet
+            # direct launches while HIP events are recorded (the timed region); HIP-graph replay is measured separately below
+            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=False)
+        else:
+            net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
         gatherer = mdist.InstanceGatherer(net=net, rank=rank, world=world) if (launched and on_gpu) else \
             mdist.InstanceGatherer(device=None) if launched else None
         phase = {"prep+forward+tail": 0.0, "voting": 0.0, "gather": 0.0, "results_to_host": 0.0}
@@ -161,21 +174,29 @@ def main():
         def step(k):
             im = images[(rank + k) % N_IMAGES]
             t_a = time.perf_counter()
-            boxes, masks, scores = demo.im_detect(im, net)          # H2D + device prep + forward + device tail (DeviceArrays)
-            t_b = time.perf_counter()
-            blk = net.vote_instances(boxes, masks, scores, 21, 100, im.shape[1], im.shape[0], nms_t, iou_t)
-            t_c = time.perf_counter()
+            if native:
+                # ONE call: pinned staging + H2D + prep + forward + tail + voting + D2H of the records + stream sync
+                counts, rec = net.forward_image(im, record_cap=100)
+                t_b = t_c = time.perf_counter()
+                blk = None
+            else:
+                boxes, masks, scores = demo.im_detect(im, net)      # H2D + device prep + forward + device tail (DeviceArrays)
+                t_b = time.perf_counter()
+                blk = net.vote_instances(boxes, masks, scores, 21, 100, im.shape[1], im.shape[0], nms_t, iou_t)
+                t_c = time.perf_counter()
             if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks, same stream
-                gatherer.gather_block(blk)
+                gatherer.gather_block(net.block() if native else blk)
                 t_d = time.perf_counter()
                 last["gathered"] = gatherer.fetch()                 # [world, 100, 447] on the host
             elif gatherer is not None:                              # gloo functional path (host tensors)
-                rec, _ = mdist.pack_instances(*blk.lists())
+                lists = split_records(rec, counts[1:], 21) if native else blk.lists()
+                packed, _ = mdist.pack_instances(*lists)
                 t_d = time.perf_counter()
-                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(rec)])
+                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(packed)])
             else:
                 t_d = t_c
-                last["masks"], last["boxes"] = blk.lists()           # numpy lists per class, as gpu_mask_voting returns them
+                # numpy lists per class, exactly what gpu_mask_voting returns
+                last["masks"], last["boxes"] = split_records(rec, counts[1:], 21) if native else blk.lists()
             t_e = time.perf_counter()
             phase["prep+forward+tail"] += t_b - t_a; phase["voting"] += t_c - t_b
             phase["gather"] += t_d - t_c; phase["results_to_host"] += t_e - t_d
@@ -208,8 +229,22 @@ def main():
             net.profile(False)
         out = {"elapsed": elapsed, "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()}, "records": records,
                "rccl_version": getattr(gatherer, "rccl_version", None)}
-        out["feats"] = {n: net.blobs[n]._host_read().copy() for n in ("rpn_bbox_pred", "rpn_cls_prob_reshape")}
-        if resident_steps:
+        out["feats"] = {n: (net.blob(n) if native else net.blobs[n]._host_read().copy())
+                        for n in ("rpn_bbox_pred", "rpn_cls_prob_reshape")}
+        if native and not launched:
+            # the same step replaying the captured HIP graph of this image size (no per-kernel events inside a graph): one
+            # hipGraphLaunch + one synchronisation per image
+            from mnc_amd.native_net import NativeNet
+            net.close()
+            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=True)
+            gsteps = min(steps, 100)
+            for k in range(5):
+                net.forward_image(images[k % N_IMAGES], record_cap=100)
+            t0 = time.perf_counter()
+            for k in range(gsteps):
+                net.forward_image(images[(5 + k) % N_IMAGES], record_cap=100)
+            out["graph_s"] = (time.perf_counter() - t0) / gsteps
+        if resident_steps and not native:
             # the round-1 protocol, for comparison: ONE image, blob already in HBM, no upload; results still come down
             im = images[rank % N_IMAGES]
             kwargs, im_scales = demo.prepare_mnc_args(im, net)
@@ -262,7 +297,7 @@ def main():
             out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
         return out
 
-    want_resident = world == 1 and not args.no_resident
+    want_resident = world == 1 and not args.no_resident and args.engine == "python"
     m = measure(math, args.steps, args.warmup, resident_steps=min(args.steps, 50) if want_resident else 0)
     elapsed = m["elapsed"]
     ranks = [{"rank": rank, "device": dev_id}]
@@ -294,6 +329,20 @@ def main():
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
         }
         out.update(summarise(args.steps, m))
+        out["config"]["engine"] = ("native: one mnc_forward_image call per image (csrc/pipeline.hip), direct kernel launches"
+                                   if args.engine == "native" else "python: mnc_amd.engine.Net layer by layer (tools/demo.py body)")
+        if "graph_s" in m:
+            out["graph_replay"] = {"value": 1.0 / m["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m["graph_s"],
+                                   "protocol": "same step, the image size's captured HIP graph replayed (one hipGraphLaunch + one "
+                                               "synchronisation per image; no per-kernel events)"}
+        if args.engine == "native" and world == 1 and not launched and not args.no_resident:
+            mp = measure(math, min(args.steps, 100), args.warmup, resident_steps=50, engine="python")
+            out["python_engine"] = {"value": min(args.steps, 100) / mp["elapsed"], "unit": "images/s",
+                                    "ms_per_step": 1e3 * mp["elapsed"] / min(args.steps, 100),
+                                    "host_phase_ms_per_image": {k: round(v, 3) for k, v in mp["phase_ms"].items()},
+                                    "protocol": "same timed region through mnc_amd.engine.Net + demo.im_detect + gpu_mask_voting "
+                                                "(the caffe-shaped drop-in, ~100 C-ABI calls per image)"}
+            m["resident_s"] = mp["resident_s"]
         if "resident_s" in m:
             out["resident_input"] = {"value": 1.0 / m["resident_s"], "unit": "images/s", "ms_per_step": 1e3 * m["resident_s"],
                                      "protocol": "round-1 protocol: one image, input blob resident in HBM, no upload / device "
@@ -306,6 +355,8 @@ def main():
                 a = {"math": alt, "dtype": DTYPE[alt], "value": args.steps / m2["elapsed"], "unit": "images/s",
                      "ms_per_step": 1e3 * m2["elapsed"] / args.steps}
                 a.update(summarise(args.steps, m2))
+                if "graph_s" in m2:
+                    a["graph_replay"] = {"value": 1.0 / m2["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m2["graph_s"]}
                 a["max_rel_diff_vs_fp32"] = {n: float(np.abs(m2["feats"][n] - m["feats"][n]).max() /
                                                       max(np.abs(m["feats"][n]).max(), 1e-30)) for n in m["feats"]}
                 out[key] = a

@@ -377,7 +377,8 @@ MNC_API int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H
 MNC_API int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host, int H, int W, float** d_records, int** d_counts);
 /* Device address and Caffe-order shape of an intermediate blob of the LAST image, for parity tests: "conv5_3" (c8),
  * "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "rois_ext", "mask_proposal" [2R][S][S] (both stages stacked),
- * "seg_cls_prob" [2R][num_classes], "boxes" [2R][4].  dims receives up to 4 ints, *ndim their number. */
+ * "seg_cls_prob" [2R][num_classes], "boxes" [2R][4], "records" (the instance block of mnc_forward_image_async).  dims receives
+ * up to 4 ints, *ndim their number. */
 MNC_API int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* ndim);
 MNC_API int mnc_net_destroy(mnc_net* net);
 

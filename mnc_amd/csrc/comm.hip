@@ -4,7 +4,7 @@
 // (the stream the voting kernels wrote the block on), device pointer in, device pointer out: no host hop, no second stream,
 // no framework tensor.
 //
-// librccl is loaded at run time (dlopen by soname) so that libmnc_hip.so has no link-time dependency on it: single-GPU users
+// librccl is loaded at run time (dlopen) so that libmnc_hip.so has no link-time dependency on it: single-GPU users
 // never touch it, and inside a process that already loaded an RCCL (e.g. torch.distributed's) the same library instance is
 // reused.  The 128-byte ncclUniqueId is created by rank 0 (mnc_comm_unique_id) and carried to the other ranks by whatever
 // rendezvous the host program has (bench.py: torch.distributed's store; a C host: a file, MPI, a socket).
@@ -35,10 +35,26 @@ static std::mutex g_rccl_mu;
 static int rccl_load() {
   std::lock_guard<std::mutex> lock(g_rccl_mu);
   if (g_rccl.handle) return MNC_OK;
+  // The RCCL that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm installations (a torch
+  // wheel bundles its own libamdhip64 / librccl with the same sonames as /opt/rocm's), and a librccl resolved by soname could
+  // be the one attached to the other runtime -- whose communicators cannot see this library's devices or streams.  So look next
+  // to the libamdhip64 that hipGetDeviceCount resolves to first, by absolute path, and only then by soname.
   void* h = nullptr;
+  Dl_info info;
+  if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash + 1);
+      for (const char* leaf : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+      }
+    }
+  }
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (h) break;
+    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!h) {
     set_error("RCCL is not available: %s", dlerror());

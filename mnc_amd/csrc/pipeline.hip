@@ -526,7 +526,7 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   MNC_REQUIRE(cfg->trunk_channels[0] <= 512, "mnc_net_create: conv1 width %d > 512", cfg->trunk_channels[0]);
   MNC_REQUIRE(cfg->rpn_channels > 0 && cfg->rpn_channels % 8 == 0 && cfg->num_anchors > 0 && cfg->num_anchors <= 16,
               "mnc_net_create: RPN shape");
-  MNC_REQUIRE(cfg->roi_size > 0 && cfg->roi_size % 4 == 0 && cfg->mask_size >= 2 && cfg->num_classes >= 2 &&
+  MNC_REQUIRE(cfg->roi_size > 0 && cfg->roi_size % 2 == 0 && cfg->mask_size >= 2 && cfg->num_classes >= 2 &&
               cfg->post_nms_topn > 0 && cfg->max_per_image > 0 && cfg->fc_dim > 0 && cfg->mask_fc > 0,
               "mnc_net_create: head shape");
   MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 2, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3) or 2 (f16)");
@@ -644,6 +644,7 @@ int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* n
   if (s == "mask_proposal") return set(net->masks.p, 4, R1 + R2, 1, c.mask_size, c.mask_size);
   if (s == "seg_cls_prob") return set(net->scores.p, 2, R1 + R2, c.num_classes, 0, 0);
   if (s == "boxes") return set(net->boxes.p, 2, R1 + R2, 4, 0, 0);
+  if (s == "records") return set(net->records.p, 2, (c.num_classes - 1) * c.max_per_image, 6 + c.mask_size * c.mask_size, 0, 0);
   set_error("mnc_net_blob: unknown blob %s", name);
   return MNC_ERR_INVALID;
 }

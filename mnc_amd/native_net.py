@@ -99,6 +99,14 @@ class NativeNet(object):
         counts, rec = self.forward_image(im)
         return split_records(rec, counts[1:], self.S)
 
+    def block(self):
+        """The device-resident instance records of the last image as what InstanceGatherer.gather_block sends."""
+        import types
+        p, dims, nd = ctypes.c_void_p(), (ctypes.c_int * 4)(), ctypes.c_int(0)
+        _lib.call("mnc_net_blob", self.h, ctypes.cast(ctypes.c_char_p(b"records"), ctypes.c_void_p), ctypes.addressof(p),
+                  ctypes.addressof(dims), ctypes.addressof(nd))
+        return types.SimpleNamespace(records_ptr=p.value, gather_rows=int(self.cfg.max_per_image), rec_dim=self.rec_dim)
+
     def blob(self, name):
         """(host copy, shape) of an intermediate blob of the last image in the engine's device layout (tests)."""
         p, dims, nd = ctypes.c_void_p(), (ctypes.c_int * 4)(), ctypes.c_int(0)
