@@ -12,13 +12,20 @@ from . import _lib
 class DeviceArray(object):
     __array_priority__ = 100.0
 
-    def __init__(self, net, ptr, shape, keepalive=None):
+    def __init__(self, net, ptr, shape, keepalive=None, generation=None):
+        """generation = (owner object, attribute name): the owner's counter is bumped whenever the device buffer behind this
+        array is reused (the next image's detect_tail / prep_image); an array of an older generation that was never copied to
+        the host refuses to hand out another image's data."""
         self._net = net
         self.ptr = int(ptr)
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(np.float32)
         self._keep = keepalive
         self._host = None
+        self._gen = None if generation is None else (generation[0], generation[1], getattr(generation[0], generation[1]))
+
+    def is_current(self):
+        return self._gen is None or getattr(self._gen[0], self._gen[1]) == self._gen[2]
 
     ndim = property(lambda self: len(self.shape))
     size = property(lambda self: int(np.prod(self.shape)))
@@ -28,6 +35,9 @@ class DeviceArray(object):
 
     def numpy(self):
         if self._host is None:
+            if not self.is_current():
+                raise RuntimeError("this DeviceArray's buffer has been reused by a later image (copy results with np.asarray() "
+                                   "before the next im_detect / prep_image if they must outlive it)")
             out = np.zeros(self.shape, np.float32)
             if out.size:
                 _lib.call("mnc_d2h", self._net._ctx.h, _lib.ptr(out), self.ptr, out.nbytes)

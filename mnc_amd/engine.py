@@ -373,11 +373,29 @@ class Net(object):
                 if b not in L.tops:           # in-place layers do not count as separate consumers
                     self._consumers.setdefault(b, []).append(i)
         self._plan_fusions()
+        self._warn_unpinned_layers(weights)
         self._host_weights = self._read_weights(weights)
         self._bind_layers()
         _lib.call("mnc_ctx_sync", self._ctx.h)
 
     # ------------------------------------------------------------------------------------------------ weights
+    UNPINNED_LAYERS = ("ROIWarping", "MaskResize", "MaskPooling", "ROIPooling")
+
+    def _warn_unpinned_layers(self, weights):
+        """Trained Caffe weights + layers whose source is in the absent caffe-mnc submodule: say LOUDLY that their sampling
+        conventions (oracle/SPEC.md: un-rounded RoI edges, +1 widths, top-left-aligned taps, zero taps outside the map) are this
+        project's reading of the paper, not caffe-mnc's code -- masks and scores may differ from upstream until a golden vector from
+        real caffe-mnc outputs pins them.  MNC_ACCEPT_UNPINNED_LAYERS=1 acknowledges and silences."""
+        if isinstance(weights, dict) or not str(weights).endswith((".caffemodel", ".h5")):
+            return
+        kinds = sorted({L.type for L in self._layers if L.type in self.UNPINNED_LAYERS})
+        if kinds and os.environ.get("MNC_ACCEPT_UNPINNED_LAYERS", "0") != "1":
+            import warnings
+            warnings.warn("PARITY UNPINNED: %s is loaded into a graph with %s layers.  Their semantics follow oracle/SPEC.md "
+                          "(the caffe-mnc sources are not available to this project); outputs of trained weights may differ "
+                          "from upstream caffe-mnc.  Set MNC_ACCEPT_UNPINNED_LAYERS=1 to acknowledge."
+                          % (os.path.basename(str(weights)), ", ".join(kinds)), UserWarning, stacklevel=3)
+
     @staticmethod
     def _read_weights(weights):
         """dict {"<layer>": [W, b]} / {"<layer>/<i>": array}, or a path to .npz / .caffemodel / .caffemodel.h5 (the two
@@ -503,7 +521,20 @@ class Net(object):
 
     @staticmethod
     def _conv_geometry(L):
+        """(kernel, pad, stride, num_output, bias_term) of a square, dense, undilated Convolution -- the only kind the kernels
+        implement.  Anything else Caffe's convolution_param can express is refused here instead of being run with the wrong
+        geometry (dilated conv5 trunks, grouped convolutions, kernel_h != kernel_w ...)."""
         cp = L.msg.get1("convolution_param")
+        for key in ("kernel_h", "kernel_w", "pad_h", "pad_w", "stride_h", "stride_w"):
+            if cp.get1(key) is not None:
+                raise NotImplementedError("Convolution %s: %s is not supported (square kernel_size / pad / stride only)"
+                                          % (L.name, key))
+        if cp.get1("dilation", 1) != 1:
+            raise NotImplementedError("Convolution %s: dilation %r is not supported" % (L.name, cp.get1("dilation")))
+        if cp.get1("group", 1) != 1:
+            raise NotImplementedError("Convolution %s: group %r is not supported" % (L.name, cp.get1("group")))
+        if cp.get1("kernel_size") is None:
+            raise NotImplementedError("Convolution %s: kernel_size is required" % L.name)
         return cp.get1("kernel_size"), cp.get1("pad", 0), cp.get1("stride", 1), cp.get1("num_output"), cp.get1("bias_term", True)
 
     def _conv_kind(self, L):
@@ -735,6 +766,9 @@ class Net(object):
                     _lib.call("mnc_maxpool2_c8", self._h(), src + n * C * H * W * 4, dst + n * C * OH * OW * 4, C, H, W)
             else:
                 R, C, PH, PW = bot.shape
+                if PH % 2 or PW % 2:            # Caffe's ceil rule would give (PH + 1) // 2 (a 7x7 input -> 4x4): no kernel for it
+                    raise NotImplementedError("Pooling %s on per-RoI features: odd size %dx%d (MAX 2x2/2 needs even sizes)"
+                                              % (L.name, PH, PW))
                 src = bot.dev_in("rhwc")
                 top.reshape(R, C, PH // 2, PW // 2)
                 if R:
@@ -856,6 +890,8 @@ class Net(object):
 
         def run():
             R, C, PH, PW = feat.shape
+            if pool2 and (PH % 2 or PW % 2):
+                raise NotImplementedError("MaskPooling %s + MAX 2x2/2 fused: odd size %dx%d" % (L.name, PH, PW))
             d_feat, d_mask = feat.dev_in("rhwc"), mask.dev_in("plain")
             top.reshape(R, C, PH // 2 if pool2 else PH, PW // 2 if pool2 else PW)
             _lib.call("mnc_mask_pool", self._h(), d_feat, d_mask, top.dev_out("rhwc"), R, PH, PW, C, pool2)
@@ -1173,6 +1209,8 @@ class Net(object):
         n = R1 + R2
         if getattr(self, "_tail_bufs", None) is None:
             self._tail_bufs = (_DevBuf(self._ctx), _DevBuf(self._ctx), _DevBuf(self._ctx))
+            self._tail_gen = 0
+        self._tail_gen += 1                       # arrays of earlier images become stale (they alias these buffers)
         d_boxes = self._tail_bufs[0].ensure(max(n, 1) * 16)
         d_masks = self._tail_bufs[1].ensure(max(n, 1) * S * S * 4)
         d_scores = self._tail_bufs[2].ensure(max(n, 1) * K * 4)
@@ -1186,8 +1224,9 @@ class Net(object):
             if R2:
                 _lib.call("mnc_copy2d", h, dst + R1 * width * 4, width, blob2.dev_in("plain"),
                           blob2._ld() if blob2._view is not None else width, R2, width)
-        return (DeviceArray(self, d_boxes, (n, 4), self._tail_bufs), DeviceArray(self, d_masks, (n, 1, S, S), self._tail_bufs),
-                DeviceArray(self, d_scores, (n, K), self._tail_bufs))
+        gen = (self, "_tail_gen")
+        return (DeviceArray(self, d_boxes, (n, 4), self._tail_bufs, gen), DeviceArray(self, d_masks, (n, 1, S, S), self._tail_bufs, gen),
+                DeviceArray(self, d_scores, (n, K), self._tail_bufs, gen))
 
     def vote_instances(self, boxes, masks, scores, num_classes, max_per_image, im_width, im_height, nms_thresh, iou_thresh):
         """gpu_mask_voting (lib/transform/mask_transform.py:213-286) on this net's own device-resident results (the DeviceArrays

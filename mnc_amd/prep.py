@@ -31,6 +31,7 @@ class ImagePrep(object):
         from .engine import _DevBuf
         self._net = net
         self._im, self._taps, self._out = _DevBuf(net._ctx), _DevBuf(net._ctx), _DevBuf(net._ctx)
+        self._gen = 0
 
     def release(self):
         for b in (self._im, self._taps, self._out):
@@ -73,4 +74,5 @@ class ImagePrep(object):
         for l, ((oh, ow), (ox0, oax, oy0, oay)) in enumerate(zip(sizes, offs)):
             _lib.call("mnc_prep_image", h, d_im, H, W, _lib.ptr(means), d_t + ox0 * 4, d_t + oax * 4, ow, d_t + oy0 * 4,
                       d_t + oay * 4, oh, d_out + l * 3 * PH * PW * 4, PH, PW)
-        return DeviceArray(self._net, d_out, (L, 3, PH, PW), self)
+        self._gen += 1
+        return DeviceArray(self._net, d_out, (L, 3, PH, PW), self, (self, "_gen"))

@@ -109,6 +109,14 @@ def test_demo_im_detect_and_voting(fake_gpu):
     om, ob = ohost.gpu_mask_voting(masks, boxes, scores, 21, 100, im.shape[1], im.shape[0])
     assert np.array_equal(np.concatenate(lb, 0), np.concatenate(ob, 0))
     assert np.array_equal(np.concatenate(lm, 0), np.concatenate(om, 0))
+    # results alias device buffers that the next image reuses: an array that was copied to the host keeps its values, one that
+    # was never looked at refuses to hand out the next image's data
+    b2, m2, s2 = demo.im_detect(im, net)
+    kept = np.asarray(b2).copy()
+    b3, m3, s3 = demo.im_detect(im[::-1].copy(), net)
+    assert np.array_equal(np.asarray(b2), kept) and b3.is_current() and not m2.is_current()
+    with pytest.raises(RuntimeError, match="reused by a later image"):
+        np.asarray(m2)
     net.close()
 
 
@@ -170,6 +178,46 @@ def test_voting_host_code_against_reference_fixture(fake_gpu, golden):
     lm, lb = gpu_mask_voting(vc["masks"], vc["boxes"], vc["scores"], 21, 100, W, H)
     assert np.array_equal(np.concatenate(lb, 0), golden["vote_small_box"])
     assert np.array_equal(np.concatenate(lm, 0), golden["vote_small_mask"])
+
+
+def test_unsupported_layer_geometry_is_refused(fake_gpu, tmp_path):
+    """Convolution fields the kernels do not implement (dilation, group, kernel_h / pad_w ...) and odd per-RoI pooling sizes raise
+    instead of running with the wrong geometry."""
+    from mnc_amd.engine import Net
+    base = """name: "t"
+input: "data"
+input_shape { dim: 1 dim: 3 dim: 32 dim: 32 }
+layer { name: "c1" type: "Convolution" bottom: "data" top: "c1" convolution_param { num_output: 32 kernel_size: 3 pad: 1 %s } }
+"""
+    w = {"c1": [np.zeros((32, 3, 3, 3), np.float32), np.zeros(32, np.float32)]}
+    for extra, word in (("dilation: 2", "dilation"), ("group: 2", "group"), ("kernel_h: 3", "kernel_h"), ("pad_w: 1", "pad_w")):
+        path = tmp_path / ("%s.prototxt" % word)
+        path.write_text(base % extra)
+        with pytest.raises(NotImplementedError, match=word):
+            Net(str(path), w, 1, device_id=0)
+    ok = tmp_path / "ok.prototxt"
+    ok.write_text(base % "stride: 1")
+    Net(str(ok), w, 1, device_id=0).close()
+
+
+def test_trained_weights_into_unpinned_layers_warn_loudly(fake_gpu, tmp_path, monkeypatch):
+    """A real .caffemodel / .h5 loaded into a graph with ROIWarping / MaskResize / MaskPooling (source in the absent caffe-mnc
+    submodule, semantics from oracle/SPEC.md) produces a PARITY UNPINNED warning unless acknowledged; dict / .npz weights and
+    graphs without those layers do not."""
+    import warnings
+    from mnc_amd import caffemodel
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    monkeypatch.setattr(caffemodel, "load_weights", lambda p: w)
+    with pytest.warns(UserWarning, match="PARITY UNPINNED.*MaskPooling, MaskResize, ROIWarping"):
+        Net(path, str(tmp_path / "mnc_model.caffemodel.h5"), 1, device_id=0).close()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        Net(path, w, 1, device_id=0).close()
+        Net(path, str(tmp_path / "w.npz"), 1, device_id=0).close()
+        monkeypatch.setenv("MNC_ACCEPT_UNPINNED_LAYERS", "1")
+        Net(path, str(tmp_path / "mnc_model.caffemodel.h5"), 1, device_id=0).close()
 
 
 def test_blob_semantics(fake_gpu):
