@@ -372,9 +372,14 @@ MNC_API int mnc_net_load_file(mnc_net* net, const char* path);
  * [0] = number of instances, [c] = instances of class c.  record_cap <= (num_classes-1) * max_per_image. */
 MNC_API int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H, int W, float* records_host, int record_cap,
                               int* counts_host);
-/* The same without the final copy + synchronisation: the records stay on the device (the block mnc_gather_instances sends);
- * *d_records / *d_counts are valid until the next call on this net. */
+/* The two halves of mnc_forward_image, for hosts that keep several images in flight (one mnc_net + context + stream per image
+ * in flight; independent images overlap on the GPU, so the latency-bound stretches of one -- proposal top-k, NMS scan, voting --
+ * run beside the next one's convolutions):
+ *   mnc_forward_image_async  stages the image and enqueues everything (graph replay or direct launches); no synchronisation.
+ *                            *d_records / *d_counts (may be NULL) are the device-resident block mnc_gather_instances sends.
+ *   mnc_net_fetch            waits for that image and hands out its records exactly as mnc_forward_image does. */
 MNC_API int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host, int H, int W, float** d_records, int** d_counts);
+MNC_API int mnc_net_fetch(mnc_net* net, float* records_host, int record_cap, int* counts_host);
 /* Device address and Caffe-order shape of an intermediate blob of the LAST image, for parity tests: "conv5_3" (c8),
  * "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "rois_ext", "mask_proposal" [2R][S][S] (both stages stacked),
  * "seg_cls_prob" [2R][num_classes], "boxes" [2R][4], "records" (the instance block of mnc_forward_image_async).  dims receives

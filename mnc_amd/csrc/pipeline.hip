@@ -86,6 +86,7 @@ struct mnc_net {
   float im_scale = 1.0f;
   int tap_key_h = -1, tap_key_w = -1;
   int last_r1 = 0, last_r2 = 0;
+  bool in_flight = false;      // an image has been launched and not fetched: its staging buffers are still in use
   // HIP graph of one image size
   hipGraphExec_t gexec = nullptr;
   int graph_h = -1, graph_w = -1, seen_h = -1, seen_w = -1;
@@ -450,8 +451,10 @@ int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
   MNC_REQUIRE(n && bgr_host && H >= 16 && W >= 16, "mnc_forward_image: bad argument");
   NET_TRY(finalize(n));
   MNC_HIP_TRY(hipSetDevice(n->ctx->device));
+  if (n->in_flight) MNC_HIP_TRY(hipStreamSynchronize(n->ctx->stream));   // launch without fetch: the staged image must be consumed
   NET_TRY(set_geometry(n, H, W));
   memcpy(n->pin_img, bgr_host, (size_t)H * W * 3);
+  n->in_flight = true;
   hipStream_t s = n->ctx->stream;
   const bool want_graph = n->cfg.use_graph && n->ctx->profiling == 0;
   if (want_graph && n->gexec && n->graph_h == H && n->graph_w == W) {
@@ -592,16 +595,16 @@ int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host, int H, 
   return MNC_OK;
 }
 
-int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H, int W, float* records_host, int record_cap,
-                      int* counts_host) {
-  MNC_REQUIRE(net && records_host && counts_host && record_cap >= 0, "mnc_forward_image: null pointer");
+int mnc_net_fetch(mnc_net* net, float* records_host, int record_cap, int* counts_host) {
+  MNC_REQUIRE(net && records_host && counts_host && record_cap >= 0, "mnc_net_fetch: null pointer");
+  MNC_REQUIRE(net->H > 0, "mnc_net_fetch: no image has been launched on this net");
   const mnc_net_config& c = net->cfg;
   const int D = 6 + c.mask_size * c.mask_size;
-  MNC_REQUIRE(record_cap <= (c.num_classes - 1) * c.max_per_image, "mnc_forward_image: record_cap %d > %d", record_cap,
+  MNC_REQUIRE(record_cap <= (c.num_classes - 1) * c.max_per_image, "mnc_net_fetch: record_cap %d > %d", record_cap,
               (c.num_classes - 1) * c.max_per_image);
-  int rc = launch_image(net, bgr_host, H, W);
-  if (rc) return rc;
+  MNC_HIP_TRY(hipSetDevice(net->ctx->device));
   MNC_HIP_TRY(hipStreamSynchronize(net->ctx->stream));
+  net->in_flight = false;
   const int* head = (const int*)net->pin_out;
   const int n_prop = *(const int*)((const char*)net->pin_out + 256);
   if (n_prop < c.post_nms_topn) {
@@ -624,6 +627,14 @@ int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H, int W,
   }
   clear_error();
   return MNC_OK;
+}
+
+int mnc_forward_image(mnc_net* net, const unsigned char* bgr_host, int H, int W, float* records_host, int record_cap,
+                      int* counts_host) {
+  MNC_REQUIRE(net && records_host && counts_host && record_cap >= 0, "mnc_forward_image: null pointer");
+  int rc = launch_image(net, bgr_host, H, W);
+  if (rc) return rc;
+  return mnc_net_fetch(net, records_host, record_cap, counts_host);
 }
 
 int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* ndim) {

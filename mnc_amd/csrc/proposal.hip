@@ -20,6 +20,7 @@
 // operation order (-ffp-contract=off), so the decoded boxes -- and with them rois / rois_ext -- carry the same bits as the
 // reference's numpy Python layers on the same input blobs (tests/test_np_exp.py on the host, tests/test_gpu_engine.py on the GPU).
 #include <cfloat>
+#include <cstdlib>
 
 #include <atomic>
 
@@ -197,6 +198,88 @@ __global__ __launch_bounds__(kSelThreads) void proposal_topk_kernel(const u64* _
   if (tid == 0) *n_out = (int)K;
 }
 
+// ---- multi-workgroup top-K: sort runs + rank merge -------------------------------------------------------------------
+// The single-workgroup kernel above is a ~100 us latency chain at 600x1000 (one CU busy, 255 idle).  Same result from two
+// wide launches:
+//   1. proposal_sort_runs_kernel   one workgroup per run of kRun keys: bitonic sort in LDS, sorted run back to global memory
+//                                  (filtered keys ~0 sort to the end of their run);
+//   2. proposal_rank_kernel        one thread per key: its rank in the whole set = position in its own run + for every other
+//                                  run the number of smaller keys (lower_bound by binary search; the searches of one thread
+//                                  are independent chains, so their L2 latencies overlap).  Keys are unique (the anchor
+//                                  index is part of the key), so ranks are a permutation: key of rank r < K goes to slot r.
+// The output (order, sorted_scores, n_out) is identical to proposal_topk_kernel's.
+constexpr int kRun = 2048;
+constexpr int kMaxRuns = 32;          // up to 65 536 anchors (1000x1000: 35 721); larger maps use the single-workgroup kernel
+
+__global__ __launch_bounds__(1024) void proposal_sort_runs_kernel(const u64* __restrict__ keys, int N, u64* __restrict__ runs) {
+  __shared__ u64 sk[kRun];
+  const int base = blockIdx.x * kRun;
+  for (int i = threadIdx.x; i < kRun; i += 1024) sk[i] = base + i < N ? keys[base + i] : ~0ull;
+  __syncthreads();
+  for (unsigned size = 2; size <= kRun; size <<= 1) {
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      const unsigned t = threadIdx.x;                       // kRun / 2 == 1024 compare-exchanges per step
+      const unsigned lo = 2 * t - (t & (stride - 1));
+      const unsigned hi = lo + stride;
+      const bool up = ((lo & size) == 0);
+      const u64 a = sk[lo], b = sk[hi];
+      if ((a > b) == up) { sk[lo] = b; sk[hi] = a; }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < kRun; i += 1024) runs[base + i] = sk[i];
+}
+
+__global__ __launch_bounds__(256) void proposal_rank_kernel(const u64* __restrict__ runs, const float* __restrict__ scores,
+                                                            int nruns, int topn, int* __restrict__ order,
+                                                            float* __restrict__ sorted_scores, int* __restrict__ n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;      // position in the concatenated runs
+  const int total = nruns * kRun;
+  const u64 key = i < total ? runs[i] : ~0ull;
+  const int mine = i / kRun;
+  // lower_bound(key) in every run at once: lo[r] .. hi[r] halves per step, 11 steps for kRun = 2048.  For the count of valid
+  // keys the same search is run for the sentinel ~0 by the first thread of the grid only.
+  int lo[kMaxRuns], hi[kMaxRuns];
+#pragma unroll
+  for (int r = 0; r < kMaxRuns; ++r) { lo[r] = 0; hi[r] = kRun; }
+#pragma unroll 1
+  for (int step = 0; step < 11; ++step) {
+#pragma unroll
+    for (int r = 0; r < kMaxRuns; ++r) {
+      if (r < nruns) {
+        const int mid = (lo[r] + hi[r]) >> 1;
+        const u64 v = runs[r * kRun + mid];
+        if (v < key) lo[r] = mid + 1; else hi[r] = mid;
+      }
+    }
+  }
+  int rank = 0;
+#pragma unroll
+  for (int r = 0; r < kMaxRuns; ++r)
+    if (r < nruns) rank += (r == mine) ? (i - mine * kRun) : lo[r];
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    // number of valid (unfiltered) keys = sum over runs of lower_bound(~0) (runs are sorted, sentinels at the end): lane r of
+    // the grid's first wave searches run r, then a wave reduction
+    int a = 0;
+    if ((int)threadIdx.x < nruns) {
+      int b = kRun;
+      const u64* run = runs + (long)threadIdx.x * kRun;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (run[mid] != ~0ull) a = mid + 1; else b = mid;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (threadIdx.x == 0) *n_out = min(topn, a);
+  }
+  if (key != ~0ull && rank < topn) {
+    const int idx = (int)(unsigned)(key & 0xFFFFFFFFull);
+    order[rank] = idx;
+    sorted_scores[rank] = scores[idx];
+  }
+}
+
 // rois[r] = (0, boxes[order[keep[r]]]) for r < *num
 __global__ void proposal_gather_kernel(const float* __restrict__ boxes, const int* __restrict__ order,
                                        const int* __restrict__ keep, const int* __restrict__ num, float* __restrict__ rois,
@@ -234,7 +317,7 @@ __global__ void stage_bridge_kernel(const float* __restrict__ rois, const float*
 }
 
 struct ProposalWs {
-  float* boxes = nullptr; u64* keys = nullptr; float* scores = nullptr;
+  float* boxes = nullptr; u64* keys = nullptr; float* scores = nullptr; u64* runs = nullptr;
   int* order = nullptr; float* sorted_scores = nullptr; int* n_cand = nullptr;
   u64* mask = nullptr; int* keep = nullptr; int* num = nullptr;
   int cap_n = 0, cap_k = 0;
@@ -283,8 +366,10 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   MNC_REQUIRE(topn <= kSortCap, "mnc_proposal: pre_nms_topN=%d exceeds the LDS sort capacity %d", topn, kSortCap);
   const int cb = cdiv(topn, 64);
   mnc_proposal_state* st = state_of(ctx);
+  const int nruns = cdiv(N, kRun);
+  const bool wide_topk = nruns <= kMaxRuns && getenv("MNC_TOPK_SINGLE_WG") == nullptr;
   const size_t need = a256((size_t)N * 16) + a256((size_t)N * 8) + a256((size_t)N * 4) + a256((size_t)topn * 4) * 2 + 256 +
-                      a256((size_t)topn * cb * 8) + a256((size_t)topn * 4) + 256;
+                      a256((size_t)topn * cb * 8) + a256((size_t)topn * 4) + 256 + a256((size_t)nruns * kRun * 8);
   if (need > st->bytes) {
     MNC_HIP_TRY(hipSetDevice(ctx->device));
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -304,7 +389,8 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   w.n_cand = (int*)p; p += 256;
   w.mask = (u64*)p; p += a256((size_t)topn * cb * 8);
   w.keep = (int*)p; p += a256((size_t)topn * 4);
-  w.num = (int*)p;
+  w.num = (int*)p; p += 256;
+  w.runs = (u64*)p;
   st->last_n = N; st->last_topn = topn;
 
   Anchors anc;
@@ -318,7 +404,14 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
     int rc = ls.finish("proposal_decode_kernel");
     if (rc) return rc;
   }
-  {
+  if (wide_topk) {
+    LaunchScope ls(ctx, "proposal_topk");
+    hipLaunchKernelGGL(proposal_sort_runs_kernel, dim3(nruns), dim3(1024), 0, ctx->stream, w.keys, N, w.runs);
+    hipLaunchKernelGGL(proposal_rank_kernel, dim3(cdiv(nruns * kRun, 256)), dim3(256), 0, ctx->stream, w.runs, w.scores, nruns,
+                       topn, w.order, w.sorted_scores, w.n_cand);
+    int rc = ls.finish("proposal_rank_kernel");
+    if (rc) return rc;
+  } else {
     unsigned cap = 1;
     while (cap < (unsigned)topn) cap <<= 1;
     static std::atomic<unsigned long long> attr_set{0};      // one bit per device: function attributes are per device

@@ -94,6 +94,21 @@ class NativeNet(object):
         _lib.call("mnc_forward_image", self.h, _lib.ptr(im), im.shape[0], im.shape[1], _lib.ptr(rec), cap, _lib.ptr(counts))
         return counts, rec[:min(int(counts[0]), cap)]
 
+    def launch(self, im):
+        """First half of forward_image: stage the image and enqueue the whole path on this net's stream; returns immediately."""
+        im = np.ascontiguousarray(im)
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise TypeError("launch takes a uint8 HxWx3 image (got %s %r)" % (im.dtype, im.shape))
+        _lib.call("mnc_forward_image_async", self.h, _lib.ptr(im), im.shape[0], im.shape[1], None, None)
+
+    def fetch(self, record_cap=None):
+        """Second half: wait for the launched image, -> (counts, records) as forward_image."""
+        cap = self.rows_cap if record_cap is None else int(record_cap)
+        rec = np.zeros((cap, self.rec_dim), np.float32)
+        counts = np.zeros(int(self.cfg.num_classes), np.int32)
+        _lib.call("mnc_net_fetch", self.h, _lib.ptr(rec), cap, _lib.ptr(counts))
+        return counts, rec[:min(int(counts[0]), cap)]
+
     def detect(self, im):
         """-> (list_result_mask, list_result_box) as the reference's gpu_mask_voting returns them."""
         counts, rec = self.forward_image(im)

@@ -4,14 +4,20 @@
 Tolerances (written per test): dense fp32 MFMA kernels accumulate in a different order than torch, so they are held to
 1e-4 of the output's dynamic range (north_star allows 1e-3 end to end); gather/elementwise kernels mirror the oracle's
 operation order and are held to 1e-6 relative / bit-exact where no FMA contraction can occur."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 import golden_inputs as GI
+import mnc_amd
 from gpu_util import Dev, err, from_c8, to_c8
+from mnc_amd import _lib
 from oracle import native
+
+mnc_amd.install_paths()
 
 pytestmark = pytest.mark.gpu
 
@@ -570,3 +576,48 @@ def test_fc_full_size_linearity(dev, fn, pack):
     got, want = run(onehot, b0), w[:, cols].T
     tol = 0 if fn == "mnc_fc" else 2.0 ** -15
     assert np.all(np.abs(got - want) <= tol * np.abs(want))
+
+
+@pytest.mark.parametrize("fh,fw,seed,quant", [(38, 63, 3, False), (12, 20, 2, False), (38, 63, 5, True), (63, 63, 6, False),
+                                              (50, 84, 7, True)])
+def test_proposal_layer_golden_and_both_topk_paths(dev, golden, monkeypatch, fh, fw, seed, quant):
+    """mnc_proposal (device-resident ProposalLayer.forward, lib/pylayer/proposal_layer.py:52-175) on stand-alone RPN outputs:
+    rois == the oracle's ProposalLayer == the reference's own layer (golden `prop_*_rois`), bit for bit, with the multi-workgroup
+    top-K (sorted runs + rank merge) and with the single-workgroup radix select (MNC_TOPK_SINGLE_WG=1); scores quantised to 1/64
+    give thousands of exact ties (order: score descending, anchor index ascending) and boxes below the minimum size are filtered
+    -- both top-K paths must agree on every candidate."""
+    import golden_inputs as GI
+    from oracle import host as ohost
+    from transform.anchors import generate_anchors
+    pc = GI.proposal_case(fh, fw, seed)
+    prob, bbox, info = pc["cls_prob"].copy(), pc["bbox_pred"].copy(), pc["im_info"]
+    if quant:
+        prob = (np.round(prob * 64) / 64).astype(np.float32)
+        bbox[:, 2::4] -= 2.5                        # many boxes shrink below RPN_MIN_SIZE and are filtered
+    anchors = np.ascontiguousarray(generate_anchors(), np.float32)
+    d_prob, d_bbox = dev.put(prob), dev.put(bbox)
+    d_rois = dev.empty((300, 5))
+    want = ohost.proposal_forward(prob, bbox, info)
+    results = []
+    for single in (False, True):
+        if single:
+            monkeypatch.setenv("MNC_TOPK_SINGLE_WG", "1")
+        else:
+            monkeypatch.delenv("MNC_TOPK_SINGLE_WG", raising=False)
+        num = ctypes.c_int(-1)
+        dev.call("mnc_proposal", d_prob, d_bbox, 9, fh, fw, _lib.ptr(anchors), 16, float(info[0, 0]), float(info[0, 1]),
+                 float(info[0, 2]), 6000, 300, 0.7, 16.0, d_rois, ctypes.addressof(num))
+        rois = dev.get(d_rois, (300, 5))[:num.value]
+        n = ctypes.c_int(0)
+        dev.call("mnc_proposal_candidates", None, None, 0, ctypes.addressof(n))
+        cb, cs = np.zeros((n.value, 4), np.float32), np.zeros(n.value, np.float32)
+        if n.value:
+            dev.call("mnc_proposal_candidates", _lib.ptr(cb), _lib.ptr(cs), n.value, ctypes.addressof(n))
+        results.append((rois, cb, cs))
+        assert rois.shape == want.shape and np.array_equal(rois, want), ("single" if single else "wide")
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+    ob, osc = ohost.proposal_candidates(prob, bbox, info)
+    assert np.array_equal(results[0][2], osc.ravel()) and np.array_equal(results[0][1], ob)
+    if not quant and (fh, fw, seed) in ((38, 63, 3), (12, 20, 2)):
+        tag = "full" if fh == 38 else "small"
+        assert np.array_equal(want, golden["prop_%s_rois" % tag])

@@ -114,6 +114,36 @@ def test_native_pipeline_full_size_vgg16():
         net.close()
 
 
+def test_two_images_in_flight_equal_one_at_a_time():
+    """mnc_forward_image_async / mnc_net_fetch: two nets (own context, stream, buffers), image k+1 launched before image k is
+    fetched -- overlapping independent images on the GPU changes nothing in any result."""
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=4)
+    ref = NativeNet(w, use_graph=False)
+    nets = [NativeNet(w), NativeNet(w)]
+    try:
+        rng = np.random.default_rng(11)
+        images = [rng.integers(0, 256, (75, 100, 3), dtype=np.uint8) for _ in range(7)]
+        want = [ref.forward_image(im) for im in images]
+        got = []
+        nets[0].launch(images[0])
+        for k in range(1, len(images)):
+            nets[k % 2].launch(images[k])
+            got.append(nets[(k - 1) % 2].fetch())
+        got.append(nets[(len(images) - 1) % 2].fetch())
+        for (c0, r0), (c1, r1) in zip(want, got):
+            assert np.array_equal(c0, c1) and np.array_equal(r0, r1, equal_nan=True)
+        # launch without fetch: the net waits for its own previous image before reusing the staging buffers
+        nets[0].launch(images[1])
+        nets[0].launch(images[2])
+        c, r = nets[0].fetch()
+        assert np.array_equal(c, want[2][0]) and np.array_equal(r, want[2][1], equal_nan=True)
+    finally:
+        ref.close()
+        for n in nets:
+            n.close()
+
+
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc to build the C host program")
 def test_c_program_drives_one_image_without_python(tmp_path):
     """tests/c/forward_image_main.c: weights from the flat container, one image, three calls (eager, graph capture, graph replay),
