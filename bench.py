@@ -124,7 +124,8 @@ def main():
             if torch.cuda.device_count() < local + 1:
                 raise SystemExit("rank %d (local %d): only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local) if on_gpu else None)
     from mnc_amd import _lib
     ndev = _lib.device_count()
     if on_gpu and ndev < (local + 1):

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kSelThreads) void proposal_topk_kernel(const u64* _
 //                                  index is part of the key), so ranks are a permutation: key of rank r < K goes to slot r.
 // The output (order, sorted_scores, n_out) is identical to proposal_topk_kernel's.
 constexpr int kRun = 2048;
+static_assert(kRun == 1 << 11, "proposal_rank_kernel's step count is written for 2^11-element runs");
 constexpr int kMaxRuns = 32;          // up to 65 536 anchors (1000x1000: 35 721); larger maps use the single-workgroup kernel
 
 __global__ __launch_bounds__(1024) void proposal_sort_runs_kernel(const u64* __restrict__ keys, int N, u64* __restrict__ runs) {
@@ -237,16 +238,16 @@ __global__ __launch_bounds__(256) void proposal_rank_kernel(const u64* __restric
   const int total = nruns * kRun;
   const u64 key = i < total ? runs[i] : ~0ull;
   const int mine = i / kRun;
-  // lower_bound(key) in every run at once: lo[r] .. hi[r] halves per step, 11 steps for kRun = 2048.  For the count of valid
-  // keys the same search is run for the sentinel ~0 by the first thread of the grid only.
+  // lower_bound(key) in every run at once: the interval [lo[r], hi[r]) halves per step; kRun = 2^11 elements need 12 steps to
+  // reach the empty interval (2048 -> 1024 -> ... -> 1 -> 0).
   int lo[kMaxRuns], hi[kMaxRuns];
 #pragma unroll
   for (int r = 0; r < kMaxRuns; ++r) { lo[r] = 0; hi[r] = kRun; }
 #pragma unroll 1
-  for (int step = 0; step < 11; ++step) {
+  for (int step = 0; step < 12; ++step) {
 #pragma unroll
     for (int r = 0; r < kMaxRuns; ++r) {
-      if (r < nruns) {
+      if (r < nruns && lo[r] < hi[r]) {
         const int mid = (lo[r] + hi[r]) >> 1;
         const u64 v = runs[r * kRun + mid];
         if (v < key) lo[r] = mid + 1; else hi[r] = mid;
