@@ -176,6 +176,14 @@ MNC_API int mnc_conv3x3(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_pac
 MNC_API int mnc_pack_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias,
                                float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
+/* The same convolution (fp32 in, fp32 out, fp32 MFMA) by Winograd's minimal filtering F(2x2, 3x3): 16 instead of 36 multiplies
+ * per (input channel, output channel, 2x2 output tile) -- 2.25x fewer matrix-pipe cycles (mnc_amd/csrc/conv_wino.hip).  All
+ * transform coefficients are 0, +-1, +-1/2: input / output transforms are exact fp32 additions, the filter transform is evaluated
+ * in double and rounded once; results agree with mnc_conv3x3 to fp32 rounding (not bit for bit: different summation order).
+ * d_w_packed from mnc_pack_conv3x3_wino: Caffe [Cout][Cin][3][3] -> [Cin/8][Cout/32][2][32][68] floats (Cin*Cout*17 floats). */
+MNC_API int mnc_pack_conv3x3_wino(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin);
+MNC_API int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias, float* d_out_c8,
+                             int H, int W, int Cin, int Cout, int relu);
 /* Pooling MAX 2x2 stride 2 with Caffe's ceil output size (test.prototxt:69-79,...): c8 [C/8][H][W][8] ->
  * [C/8][OH][OW][8], OH = ceil((H-2)/2)+1. */
 MNC_API int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W);
@@ -354,6 +362,7 @@ typedef struct mnc_net_config {
   float vote_nms_thresh, vote_iou_thresh;   /* TEST.MASK_MERGE_NMS_THRESH 0.3, TEST.MASK_MERGE_IOU_THRESH 0.5 */
   int math;                /* 0 fp32, 1 bf16x3, 2 f16 (the engine's math modes) */
   int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
+  int winograd;            /* fp32 math: 1 = 3x3 convolutions by Winograd F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */
 } mnc_net_config;
 
 /* The reference's values for every field (VGG-16 widths, lib/mnc_config.py defaults). */

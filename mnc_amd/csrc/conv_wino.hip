@@ -1,0 +1,402 @@
+// 3x3 convolution (pad 1, stride 1) by Winograd's minimal filtering F(2x2, 3x3) on the fp32 matrix pipe, for gfx950
+// (models/VGG16/mnc_5stage/test.prototxt:41-412: 12 of the 13 trunk convolutions + rpn_conv_3x3).
+//
+// Why: the direct implicit GEMM (conv.hip) runs at 76 % of the fp32-matrix peak (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) -- the
+// contraction itself is what bounds the fp32 mode.  F(2x2, 3x3) computes every 2x2 output tile from a 4x4 input tile with 16
+// multiplies per (input channel, output channel) instead of 36: 2.25x fewer matrix-pipe cycles for the same result.
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A          (Lavin & Gray 2015; the transforms below are the standard ones)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// All transform coefficients are 0, +-1, +-1/2: the input and output transforms are exact additions in fp32, the filter
+// transform is evaluated in double and rounded once.  The products differ from the direct form's (different summation
+// order, 16 partial products per tile recombined with signs), so the result agrees with the direct kernel to fp32 rounding
+// (measured in tests/test_gpu_ops.py), not bit for bit.
+//
+// Mapping.  For each of the 16 transform positions xi the contraction over input channels is a GEMM
+//     M_xi[co][tile] += U_xi[co][ci] * V_xi[ci][tile]
+// run as MFMA 32x32x2: A operand = U (lane: co = lane % 32, k = lane / 32), B operand = V (lane: tile = lane % 32, k = lane / 32).
+//   * a wave owns 32 output channels x 32 Winograd tiles (2 tile rows x 16 tile columns = 4 pixel rows x 32 pixel columns)
+//     x all 16 positions: 16 accumulator tiles = 256 accumulator registers -> one wave per SIMD, by design; every MFMA of a
+//     channel block goes to a different accumulator than its predecessor (no dependent issue);
+//   * a workgroup is ROWS waves stacked vertically (4*ROWS pixel rows x 32 columns) sharing the weight panel;
+//   * K is walked in 8-channel blocks as in conv.hip: per block the (4*ROWS + 2) x 34 halo and the 32 x 8 x 16 transformed
+//     weights are staged global -> registers -> LDS (double-buffered, one barrier per block); each lane reads the 4x4 input
+//     tile of ITS Winograd tile (its 4 channels, two at a time: 2 x 16 ds_read_b64), transforms it in registers (32 additions per
+//     channel) and feeds 64 MFMAs (16 positions x 4 channel pairs), reading a position's weight fragment with ds_read_b64;
+//     channel pair m of a position multiplies channels m and 4+m (lane half k supplies channel 4k+m), the packed weights use
+//     the same pairing;
+//   * epilogue: the output transform in registers (24 additions per output channel), + bias + ReLU, 2x2 pixels x 16 channels per
+//     lane as float4 stores into the c8 layout; K-split partial sums go through the same transform (it is linear).
+#include <atomic>
+#include <cstdlib>
+
+#include "mnc_internal.h"
+
+namespace mnc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWCols = 32;                 // pixel columns per workgroup (16 Winograd tiles)
+constexpr int kWHaloCols = kWCols + 2;
+constexpr int kWPixPitch = 12;             // floats per halo pixel in LDS (8 channels + 4 pad)
+constexpr int kWRowPitch = 68;             // floats per (k half, output channel) weight row: 16 positions x 4 channels + 4 pad
+constexpr int kWPanel = 2 * 32 * kWRowPitch;   // floats per (channel block, 32-channel tile) weight panel = 4352
+
+// VAR: scheduling variant (tuning; MNC_WINO_VAR): bit 0 = pinned software pipeline of the two halves of a block (below).
+template <int ROWS, int VAR>
+__global__ __launch_bounds__(64 * ROWS) void conv3x3_wino_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int H, int W, int Cin, int Cout, int relu, int ksplit,
+                                                                  float* __restrict__ part) {
+  constexpr int NT = 64 * ROWS;
+  constexpr int kHaloRows = 4 * ROWS + 2;
+  constexpr int kHaloFloats = kHaloRows * kWHaloCols * kWPixPitch;
+  constexpr int kHaloVec = kHaloRows * kWHaloCols * 2;            // float4 items per halo
+  constexpr int kHPer = (kHaloVec + NT - 1) / NT;
+  constexpr int kWVec = kWPanel / 4;                              // float4 items per weight panel
+  constexpr int kWPer = (kWVec + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];   // halo[2] then weights[2]
+  float* const s_halo = s_mem;
+  float* const s_w = s_mem + 2 * kHaloFloats;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, kk = lane >> 5;
+  const int ty = j >> 4, tx = j & 15;                            // this lane's Winograd tile inside the wave's 2 x 16 tiles
+  const int ncot = Cout >> 5;
+  const int split = blockIdx.z / ncot;
+  const int cot = blockIdx.z - split * ncot;
+  const int w0 = blockIdx.x * kWCols, h0 = blockIdx.y * (4 * ROWS), co0 = cot * 32;
+  const int nchunks = (Cin >> 3) / ksplit;
+  const int chunk0 = split * nchunks;
+
+  // ---- staging assignment (fixed per thread), branch-free as in conv.hip ----
+  int h_off[kHPer];
+  int h_src[kHPer];
+  unsigned h_keep[kHPer];
+#pragma unroll
+  for (int u = 0; u < kHPer; ++u) {
+    const int q = min(tid + u * NT, kHaloVec - 1);
+    const int pix = q >> 1, half = q & 1;
+    const int r = pix / kWHaloCols, c = pix - r * kWHaloCols;
+    const int gh = h0 - 1 + r, gw = w0 - 1 + c;
+    h_off[u] = pix * kWPixPitch + half * 4;
+    h_src[u] = (min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1)) * 8 + half * 4;        // < 2^31 floats per plane
+    h_keep[u] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? 0xFFFFFFFFu : 0u;
+  }
+  int w_idx[kWPer];
+#pragma unroll
+  for (int u = 0; u < kWPer; ++u) w_idx[u] = min(tid + u * NT, kWVec - 1);
+  const long plane = (long)H * W * 8;
+
+  struct Regs {
+    float4 h[kHPer];
+    float4 w[kWPer];
+  };
+  Regs G;
+#pragma unroll
+  for (int u = 0; u < kHPer; ++u) G.h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < kWPer; ++u) G.w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load_chunk = [&](int c) {
+    c = chunk0 + min(c, nchunks - 1);
+    const float* src = in + (long)c * plane;
+#pragma unroll
+    for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
+    const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * ncot + cot) * kWPanel);
+#pragma unroll
+    for (int u = 0; u < kWPer; ++u) G.w[u] = wsrc[w_idx[u]];
+  };
+  auto store_chunk = [&](int buf) {
+    float* hdst = s_halo + buf * kHaloFloats;
+#pragma unroll
+    for (int u = 0; u < kHPer; ++u) {
+      float4 v = G.h[u];
+      v.x = __uint_as_float(__float_as_uint(v.x) & h_keep[u]);
+      v.y = __uint_as_float(__float_as_uint(v.y) & h_keep[u]);
+      v.z = __uint_as_float(__float_as_uint(v.z) & h_keep[u]);
+      v.w = __uint_as_float(__float_as_uint(v.w) & h_keep[u]);
+      *reinterpret_cast<float4*>(hdst + h_off[u]) = v;
+    }
+    float4* wdst = reinterpret_cast<float4*>(s_w + buf * kWPanel);
+#pragma unroll
+    for (int u = 0; u < kWPer; ++u) wdst[w_idx[u]] = G.w[u];
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+
+  // lane-constant LDS offsets: the 4x4 input window of this lane's tile starts at halo pixel (4*wave + 2*ty, 2*tx)
+  const int d_base = ((4 * wave + 2 * ty) * kWHaloCols + 2 * tx) * kWPixPitch + kk * 4;
+  const int u_base = (kk * 32 + j) * kWRowPitch;
+
+  // A block is multiplied in two channel-pair halves (the lane's channels 4*kk + {0,1}, then {2,3}; MFMA pair m multiplies
+  // channels m and 4 + m across the two lane halves), software-pipelined against the single wave per SIMD:
+  //   read half 0 (d, u) -> transform half 0 -> issue the reads of half 1 ->
+  //   32 MFMAs of half 0 with the 64 additions of half 1's transform interleaved (1 MFMA : 2 VALU) -> 32 MFMAs of half 1.
+  // hipcc on its own places every ds_read right before the MFMA that consumes it, and with one wave per SIMD nobody covers
+  // that latency; the scheduling fences pin the phases, sched_group_barrier pins the interleave.
+  // ablation builds (tuning only, wrong results): VAR & 16 no staging inside the loop, & 32 no barrier either, & 64 no LDS
+  // reads (operands are opaque register constants), & 128 no input transform
+  auto read_d = [&](const float* sh, float2 (&d)[4][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (VAR & 64) {
+          d[r][c] = make_float2(1.f, 2.f);
+          asm volatile("" : "+v"(d[r][c].x), "+v"(d[r][c].y));
+        } else {
+          d[r][c] = *reinterpret_cast<const float2*>(sh + (r * kWHaloCols + c) * kWPixPitch);
+        }
+      }
+  };
+  auto read_u = [&](const float* sw, float2 (&u)[16]) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      if (VAR & 64) {
+        u[p] = make_float2(3.f, 4.f);
+        asm volatile("" : "+v"(u[p].x), "+v"(u[p].y));
+      } else {
+        u[p] = *reinterpret_cast<const float2*>(sw + p * 4);
+      }
+    }
+  };
+  auto transform = [&](const float2 (&d)[4][4], float2 (&v)[16]) {
+    if (VAR & 128) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) v[p] = d[p >> 2][p & 3];
+      return;
+    }
+    float2 t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                                 // t = B^T d (rows)
+      t[0][c] = make_float2(d[0][c].x - d[2][c].x, d[0][c].y - d[2][c].y);
+      t[1][c] = make_float2(d[1][c].x + d[2][c].x, d[1][c].y + d[2][c].y);
+      t[2][c] = make_float2(d[2][c].x - d[1][c].x, d[2][c].y - d[1][c].y);
+      t[3][c] = make_float2(d[1][c].x - d[3][c].x, d[1][c].y - d[3][c].y);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                                 // V = t B (columns)
+      const float2 a = t[r][0], b = t[r][1], c = t[r][2], e = t[r][3];
+      v[r * 4 + 0] = make_float2(a.x - c.x, a.y - c.y);
+      v[r * 4 + 1] = make_float2(b.x + c.x, b.y + c.y);
+      v[r * 4 + 2] = make_float2(c.x - b.x, c.y - b.y);
+      v[r * 4 + 3] = make_float2(b.x - e.x, b.y - e.y);
+    }
+  };
+  auto mfma_half = [&](const float2 (&u)[16], const float2 (&v)[16]) {
+    // positions in pairs: consecutive MFMAs alternate between the two positions' accumulators
+#pragma unroll
+    for (int p = 0; p < 16; p += 2) {
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[p].x, v[p].x, acc[p], 0, 0, 0);
+      acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[p + 1].x, v[p + 1].x, acc[p + 1], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[p].y, v[p].y, acc[p], 0, 0, 0);
+      acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[p + 1].y, v[p + 1].y, acc[p + 1], 0, 0, 0);
+    }
+  };
+  auto multiply = [&](int buf) {
+    const float* sh = s_halo + buf * kHaloFloats + d_base;
+    const float* sw = s_w + buf * kWPanel + u_base;
+    float2 d0[4][4], d1[4][4], u0[16], u1[16], v0[16], v1[16];
+    read_d(sh, d0);
+    read_u(sw, u0);
+    transform(d0, v0);
+    if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
+    read_d(sh + 2, d1);
+    read_u(sw + 2, u1);
+    if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
+    mfma_half(u0, v0);
+    transform(d1, v1);
+    if (VAR & 1) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);        // 2 VALU (half 1's transform)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_half(u1, v1);
+  };
+
+  // One staging register set, T14-style: the registers always hold the block AFTER the one in LDS.  Per iteration: barrier
+  // (block c complete in LDS[buf], LDS[buf^1] free) -> write the registers (block c+1) to LDS[buf^1] -> re-issue the loads for
+  // block c+2 at once -> multiply block c.  The loads have a whole multiply (>= 4096 matrix-pipe cycles) to land before the
+  // next iteration's write; the scheduling fence keeps hipcc from sinking them below the MFMAs (it does, to shorten live
+  // ranges -- and then every block waits for HBM/L2 at its end).
+  load_chunk(0);
+  store_chunk(0);
+  load_chunk(1);
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (!(VAR & 32)) __syncthreads();
+    if (!(VAR & 16)) {
+      store_chunk(buf ^ 1);         // block c+1 (behind the last block: a clamped duplicate into the idle buffer, harmless)
+      load_chunk(c + 2);            // unconditional (clamped): no load under a branch
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(buf);
+  }
+
+  // ---- epilogue: Y = A^T M A per output channel; acc[p][e]: p = 4*xi_row + xi_col, e -> channel (e&3) + 8*(e>>2) + 4*kk ----
+  const int oy = h0 + 4 * wave + 2 * ty, ox = w0 + 2 * tx;
+  float* dst = out;
+  if (ksplit > 1) dst = part + (long)split * Cout * H * W;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int co = co0 + g * 8 + kk * 4;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ksplit == 1) b = *reinterpret_cast<const float4*>(bias + co);
+    float y[2][2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = 4 * g + q;
+      float s0[4], s1[4];                         // s = A^T M: rows of the 2 x 4 intermediate
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        s0[cc] = acc[0 + cc][e] + acc[4 + cc][e] + acc[8 + cc][e];
+        s1[cc] = acc[4 + cc][e] - acc[8 + cc][e] - acc[12 + cc][e];
+      }
+      y[0][0][q] = s0[0] + s0[1] + s0[2];
+      y[0][1][q] = s0[1] - s0[2] - s0[3];
+      y[1][0][q] = s1[0] + s1[1] + s1[2];
+      y[1][1][q] = s1[1] - s1[2] - s1[3];
+    }
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = oy + dy, xx = ox + dx;
+        if (yy < H && xx < W) {
+          float4 o = make_float4(y[dy][dx][0] + bb[0], y[dy][dx][1] + bb[1], y[dy][dx][2] + bb[2], y[dy][dx][3] + bb[3]);
+          if (relu && ksplit == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * H + yy) * W + xx) * 8 + kk * 4) = o;
+        }
+      }
+  }
+}
+
+// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (k half)][32 (co)][68]: element (cb, ct, kh, j, xi*4 + m) =
+// (G g G^T)[xi] of filter (co = ct*32 + j, ci = cb*8 + kh*4 + m), evaluated in double and rounded once; the 4 pad floats are 0.
+__global__ void pack_conv3x3_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+  const long rows = (long)(Cin >> 3) * (Cout >> 5) * 64;          // (cb, ct, kh, j)
+  for (long row = (long)blockIdx.x * blockDim.x + threadIdx.x; row < rows * 4; row += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(row & 3);
+    const long r = row >> 2;
+    const int jj = (int)(r & 31), kh = (int)((r >> 5) & 1);
+    const long t = r >> 6;
+    const int ct = (int)(t % (Cout >> 5)), cb = (int)(t / (Cout >> 5));
+    const int co = ct * 32 + jj, ci = cb * 8 + kh * 4 + m;
+    const float* g = w + ((long)co * Cin + ci) * 9;
+    double gg[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) gg[a][b] = (double)g[a * 3 + b];
+    double tmp[4][3];                                             // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      tmp[0][b] = gg[0][b];
+      tmp[1][b] = 0.5 * (gg[0][b] + gg[1][b] + gg[2][b]);
+      tmp[2][b] = 0.5 * (gg[0][b] - gg[1][b] + gg[2][b]);
+      tmp[3][b] = gg[2][b];
+    }
+    float* dst = out + r * kWRowPitch;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                                 // (G g) G^T
+      dst[(a * 4 + 0) * 4 + m] = (float)tmp[a][0];
+      dst[(a * 4 + 1) * 4 + m] = (float)(0.5 * (tmp[a][0] + tmp[a][1] + tmp[a][2]));
+      dst[(a * 4 + 2) * 4 + m] = (float)(0.5 * (tmp[a][0] - tmp[a][1] + tmp[a][2]));
+      dst[(a * 4 + 3) * 4 + m] = (float)tmp[a][2];
+    }
+    if (m == 0) { dst[64] = 0.f; dst[65] = 0.f; dst[66] = 0.f; dst[67] = 0.f; }
+  }
+}
+
+template <int ROWS, int VAR>
+static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                       int Cin, int Cout, int relu, int ksplit, float* part) {
+  constexpr size_t lds = 2 * 4 * ((size_t)(4 * ROWS + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
+  static_assert(lds <= 160 * 1024, "conv3x3_wino: LDS budget");
+  auto kern = conv3x3_wino_kernel<ROWS, VAR>;
+  static std::atomic<unsigned long long> attr_set{0};            // one bit per device: function attributes are per device
+  const unsigned long long bit = 1ull << (ctx->device & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+    MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
+  }
+  dim3 grid(cdiv(W, kWCols), cdiv(H, 4 * ROWS), (Cout >> 5) * ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * ROWS), lds, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit,
+                     part);
+  return MNC_OK;
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+extern "C" {
+
+int mnc_pack_conv3x3_wino(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_pack_conv3x3_wino: bad argument (Cin%%8==0, Cout%%32==0)");
+  LaunchScope ls(ctx, "pack_conv3x3_wino");
+  const long items = (long)(Cin >> 3) * (Cout >> 5) * 64 * 4;
+  long g = (items + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(pack_conv3x3_wino_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_oihw, d_packed, Cout, Cin);
+  return ls.finish("pack_conv3x3_wino_kernel");
+}
+
+int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                     int Cin, int Cout, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3_wino: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_conv3x3_wino: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin, Cout);
+  // Workgroup = ROWS waves (4*ROWS pixel rows x 32 columns x 32 channels), one workgroup per CU (256 accumulator registers per
+  // wave).  Pick the tallest workgroup that still gives every CU >= 3 workgroups; small maps additionally split K.
+  const int ncot = Cout >> 5;
+  // measured (tools/kernel_bench.py convwino, MNC_WINO_ROWS): 4-wave workgroups win on every trunk shape from 600x1000 down
+  // to 75x125 (one workgroup per CU either way; taller workgroups amortise the weight panel), 2 waves on maps under 64 rows
+  int rows = H >= 64 ? 4 : 2;
+  if (const char* e = getenv("MNC_WINO_ROWS")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) rows = v;
+  }
+  int ksplit = 1;
+  {
+    const long wgs = (long)cdiv(W, kWCols) * cdiv(H, 4 * rows) * ncot;
+    const int blocks = Cin / 8;
+    if (wgs < 2 * 256) ksplit = blocks % 4 == 0 && blocks >= 16 ? 4 : (blocks % 2 == 0 && blocks >= 8 ? 2 : 1);
+    if (const char* e = getenv("MNC_CONV_KSPLIT")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
+    }
+  }
+  float* part = nullptr;
+  if (ksplit > 1) {
+    int rc = ensure_scratch(ctx, (size_t)ksplit * Cout * H * W * 4);
+    if (rc) return rc;
+    part = (float*)ctx->scratch;
+  }
+  const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
+  const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
+  LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
+  int var = 0;
+  if (const char* e = getenv("MNC_WINO_VAR")) var = atoi(e);
+  int rc = MNC_ERR_INVALID;
+#define MNC_WINO_CASE(R, V) if (rows == R && var == V) rc = launch_wino<R, V>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  MNC_WINO_CASE(4, 0) MNC_WINO_CASE(4, 1) MNC_WINO_CASE(2, 0) MNC_WINO_CASE(2, 1) MNC_WINO_CASE(1, 0) MNC_WINO_CASE(1, 1)
+  MNC_WINO_CASE(4, 16) MNC_WINO_CASE(4, 48) MNC_WINO_CASE(4, 112) MNC_WINO_CASE(4, 240)      // ablations (tuning)
+#undef MNC_WINO_CASE
+  MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d MNC_WINO_VAR=%d", rows, var);
+  if (rc) return rc;
+  if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);
+  return ls.finish("conv3x3_wino_kernel");
+}
+
+}  // extern "C"

@@ -201,9 +201,10 @@ int finalize(mnc_net* n) {
       NET_TRY(upload(n, w->v, &raw));
       n->conv_fast[i] = cout % 32 == 0;        // engine.py:_conv_kind: 'fast3x3' needs Cout % 32 == 0, otherwise 'general'
       if (n->conv_fast[i]) {
-        const int pitch = c.math == 0 ? 76 : 84;
+        const int pitch = c.math == 0 ? (c.winograd ? 136 : 76) : 84;
         NET_TRY(mnc_dev_alloc(n->ctx, (size_t)(cin / 8) * cout * pitch * 4, &n->w_conv[i]));
-        NET_TRY(c.math == 0 ? mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
+        NET_TRY(c.math == 0 ? (c.winograd ? mnc_pack_conv3x3_wino(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
+                                          : mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin))
                 : c.math == 1 ? mnc_pack_conv3x3_bf16x3(n->ctx, raw, n->w_conv[i], cout, cin)
                               : mnc_pack_conv3x3_f16(n->ctx, raw, n->w_conv[i], cout, cin));
       } else if (c.math == 2) {
@@ -340,6 +341,8 @@ int conv3(mnc_net* n, int i, const float* in, float* out, int h, int w, int cin,
     if (c.math == 2) return mnc_conv2d_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
     return mnc_conv2d(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
   }
+  if (c.math == 0 && c.winograd)
+    return mnc_conv3x3_wino(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
   if (c.math == 0) return mnc_conv3x3(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
   if (c.math == 1) return mnc_conv3x3_bf16x3(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
   return mnc_conv3x3_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
@@ -516,6 +519,7 @@ int mnc_net_default_config(mnc_net_config* cfg) {
   cfg->vote_nms_thresh = 0.3f; cfg->vote_iou_thresh = 0.5f;
   cfg->math = 0;
   cfg->use_graph = 1;
+  cfg->winograd = 0;
   clear_error();
   return MNC_OK;
 }

@@ -26,6 +26,9 @@ import numpy as np
 from . import _lib, install_paths, prototxt
 from .devarray import DeviceArray
 
+# fp32 mode: 3x3 convolutions by Winograd F(2x2,3x3) unless MNC_CONV_WINOGRAD=0 / Net(winograd=False)
+WINOGRAD_DEFAULT = "0"
+
 # bf16x3 mode: InnerProducts below this many flops stay on the fp32 kernel (its small-tile variant is as fast there)
 _X3_MIN_FLOPS = 2.0e9
 
@@ -318,7 +321,8 @@ class _Outputs(Mapping):
 class Net(object):
     supports_partial_forward = True      # forward(start=..., end=...) re-uses the blobs of the previous call
 
-    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None, math=None):
+    def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None, math=None,
+                 winograd=None):
         if device_id is None:
             try:
                 import caffe
@@ -345,6 +349,7 @@ class Net(object):
         self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
         if self.math not in ("fp32", "bf16x3", "f16"):
             raise ValueError("math must be 'fp32', 'bf16x3' or 'f16', got %r" % self.math)
+        self._winograd = (os.environ.get("MNC_CONV_WINOGRAD", WINOGRAD_DEFAULT) != "0") if winograd is None else bool(winograd)
         # MNC_SPECULATE_ROIS=0: read the ProposalLayer's RoI count back before the heads are launched (one stream sync in the
         # middle of forward) instead of running the heads on RPN_POST_NMS_TOP_N rows and checking the count at the end
         self._speculate = os.environ.get("MNC_SPECULATE_ROIS", "1") != "0"
@@ -647,8 +652,11 @@ class Net(object):
             return run
         if kind == "fast3x3":
             x3 = self.math in ("bf16x3", "f16")
+            # fp32 mode: the direct implicit GEMM, or Winograd F(2x2,3x3) on the same fp32 matrix pipe (2.25x fewer multiplies,
+            # equal to the direct form up to fp32 rounding; MNC_CONV_WINOGRAD / Net(winograd=))
             pitch, pack, conv = (84, "mnc_pack_conv3x3_f16", "mnc_conv3x3_f16") if self.math == "f16" else \
                                 (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
+                                (136, "mnc_pack_conv3x3_wino", "mnc_conv3x3_wino") if self._winograd else \
                                 (76, "mnc_pack_conv3x3_weights", "mnc_conv3x3")
 
             def build():
@@ -657,7 +665,7 @@ class Net(object):
                 _lib.call(pack, self._h(), raw, packed, cout, cin)
                 self._ctx.free(raw)
                 return packed
-            d_w = self._dev_param(key + ("w", self.math), build)
+            d_w = self._dev_param(key + ("w", self.math, "wino" if (self._winograd and not x3) else "direct"), build)
 
             def run():
                 N, _, H, Wd = bot.shape

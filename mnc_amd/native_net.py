@@ -26,7 +26,7 @@ class NetConfig(ctypes.Structure):
                 ("roi_size", ctypes.c_int), ("spatial_scale", ctypes.c_float), ("target_size", ctypes.c_int),
                 ("max_size", ctypes.c_int), ("pixel_means", ctypes.c_double * 3), ("max_per_image", ctypes.c_int),
                 ("vote_nms_thresh", ctypes.c_float), ("vote_iou_thresh", ctypes.c_float), ("math", ctypes.c_int),
-                ("use_graph", ctypes.c_int)]
+                ("use_graph", ctypes.c_int), ("winograd", ctypes.c_int)]
 
 
 def default_config():
@@ -35,7 +35,7 @@ def default_config():
     return cfg
 
 
-def config_from_weights(weights, math="fp32", use_graph=True, **overrides):
+def config_from_weights(weights, math="fp32", use_graph=True, winograd=None, **overrides):
     """The reference's configuration (lib/mnc_config.py defaults) with the widths read off a weight dict {layer: [W, b]}."""
     cfg = default_config()
     stage_first = ["conv1_1", "conv2_1", "conv3_1", "conv4_1", "conv5_1"]
@@ -47,6 +47,11 @@ def config_from_weights(weights, math="fp32", use_graph=True, **overrides):
     cfg.num_classes = int(weights["cls_score"][0].shape[0])
     cfg.math = MATH[math]
     cfg.use_graph = 1 if use_graph else 0
+    if winograd is None:
+        import os
+        from .engine import WINOGRAD_DEFAULT
+        winograd = os.environ.get("MNC_CONV_WINOGRAD", WINOGRAD_DEFAULT) != "0"
+    cfg.winograd = 1 if winograd else 0
     for k, v in overrides.items():
         if k == "pixel_means":
             for i in range(3):
@@ -57,14 +62,14 @@ def config_from_weights(weights, math="fp32", use_graph=True, **overrides):
 
 
 class NativeNet(object):
-    def __init__(self, weights, device_id=0, math="fp32", use_graph=True, **overrides):
+    def __init__(self, weights, device_id=0, math="fp32", use_graph=True, winograd=None, **overrides):
         """weights: {layer: [W, b]} in Caffe layout (what mnc_amd.synth / caffemodel.load_weights return), or the path of a
         flat MNCW0001 file (caffemodel.save_flat) together with cfg=<NetConfig>."""
         from .engine import _Ctx
         cfg = overrides.pop("cfg", None)
         self._ctx = _Ctx(device_id)
         if cfg is None:
-            cfg = config_from_weights(weights, math, use_graph, **overrides)
+            cfg = config_from_weights(weights, math, use_graph, winograd, **overrides)
         self.cfg = cfg
         h = ctypes.c_void_p()
         _lib.call("mnc_net_create", self._ctx.h, ctypes.addressof(cfg), ctypes.addressof(h))

@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(key, "fc_dim")) cfg.fc_dim = (int)val;
     else if (!strcmp(key, "math")) cfg.math = (int)val;
     else if (!strcmp(key, "use_graph")) cfg.use_graph = (int)val;
+    else if (!strcmp(key, "winograd")) cfg.winograd = (int)val;
     else if (!strcmp(key, "target_size")) cfg.target_size = (int)val;
     else if (!strcmp(key, "max_size")) cfg.max_size = (int)val;
     else { fprintf(stderr, "unknown key %s\n", key); return 2; }

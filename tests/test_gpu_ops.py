@@ -58,6 +58,42 @@ def test_conv3x3_mfma(dev, H, W, Cin, Cout, relu):
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (75, 125, 64, 64), (5, 3, 8, 32), (38, 63, 128, 64)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
+    """mnc_conv3x3_wino (Winograd F(2x2,3x3) on the fp32 matrix pipe) against torch fp32 and against the direct kernel: odd
+    heights / widths (partial 2x2 tiles at the border), every workgroup height, K splits.  The transforms are exact in fp32
+    except for the summation order, so the bar is the direct kernel's own (1e-4 of the output range; measured ~1e-6)."""
+    rng = np.random.default_rng(H * 1000 + W + Cin + Cout)
+    x = rng.normal(0, 1, (Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(0, 0.1, Cout).astype(np.float32)
+    want = _conv_ref(x, w, b, bool(relu))
+    d_x, d_b = dev.put(to_c8(x)), dev.put(b)
+    d_raw = dev.put(w)
+    d_w = dev.empty((Cin * Cout * 17,))
+    dev.call("mnc_pack_conv3x3_wino", d_raw, d_w, Cout, Cin)
+    d_wd = dev.empty(((Cin // 8) * Cout * 76,))
+    dev.call("mnc_pack_conv3x3_weights", d_raw, d_wd, Cout, Cin)
+    d_y = dev.empty((Cout, H, W), fill=-7.0)
+    dev.call("mnc_conv3x3", d_x, d_wd, d_b, d_y, H, W, Cin, Cout, relu)
+    direct = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+    for rows, ks in ((None, None), ("1", "1"), ("2", "2"), ("4", "1"), ("1", "4")):
+        if ks is not None and (Cin // 8) % int(ks):
+            continue
+        if rows is None:
+            monkeypatch.delenv("MNC_WINO_ROWS", raising=False)
+            monkeypatch.delenv("MNC_CONV_KSPLIT", raising=False)
+        else:
+            monkeypatch.setenv("MNC_WINO_ROWS", rows)
+            monkeypatch.setenv("MNC_CONV_KSPLIT", ks)
+        dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
+        dev.call("mnc_conv3x3_wino", d_x, d_w, d_b, d_y, H, W, Cin, Cout, relu)
+        got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+        assert err(got, want)[1] < 1e-4, (rows, ks, err(got, want))
+        assert err(got, direct)[1] < 1e-5, (rows, ks, err(got, direct))
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):

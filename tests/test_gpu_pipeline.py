@@ -163,7 +163,8 @@ def test_c_program_drives_one_image_without_python(tmp_path):
         with open(str(tmp_path / "cfg.txt"), "w") as f:
             for i in range(5):
                 f.write("trunk%d %d\n" % (i, cfg.trunk_channels[i]))
-            f.write("rpn_channels %d\nmask_fc %d\nfc_dim %d\nmath 0\nuse_graph 1\n" % (cfg.rpn_channels, cfg.mask_fc, cfg.fc_dim))
+            f.write("rpn_channels %d\nmask_fc %d\nfc_dim %d\nmath 0\nuse_graph 1\nwinograd %d\n"
+                    % (cfg.rpn_channels, cfg.mask_fc, cfg.fc_dim, cfg.winograd))
         env = dict(os.environ)
         env.pop("PYTHONPATH", None)
         r = subprocess.run([exe, str(tmp_path / "w.mncw"), str(tmp_path / "im.raw"), "90", "120", str(tmp_path / "cfg.txt"),

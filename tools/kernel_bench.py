@@ -3,6 +3,7 @@
 
     python tools/kernel_bench.py conv [--reps 20]      the 13 conv3x3 shapes of the VGG-16 trunk at 600x1000
     python tools/kernel_bench.py convx3                the same on the bf16x3 kernel (MNC_CONVX3_TILE=CT,PR overrides the tile)
+    python tools/kernel_bench.py convwino              the same on the Winograd F(2x2,3x3) fp32 kernel (MNC_WINO_ROWS=1|2|4)
     python tools/kernel_bench.py fc   [--reps 20]      the FC shapes of one head stage at 300 RoIs
     python tools/kernel_bench.py fcx3                  the same on the bf16x3 kernel
 Environment knobs understood by the library (tuning aids): MNC_CONV_COT=1|2|4."""
@@ -40,7 +41,7 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "convx3", "fc", "fcx3"])
+    ap.add_argument("what", choices=["conv", "convx3", "convwino", "fc", "fcx3"])
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
@@ -52,7 +53,7 @@ def main():
     rng = np.random.default_rng(0)
     dev.call("mnc_prof_enable", 1)
     total_ms, total_fl = 0.0, 0.0
-    if args.what in ("conv", "convx3"):
+    if args.what in ("conv", "convx3", "convwino"):
         for name, H, W, Cin, Cout in CONV:
             if args.only and args.only not in name:
                 continue
@@ -65,6 +66,11 @@ def main():
                 w = dev.empty(((Cin // 8) * Cout * 84,))
                 dev.call("mnc_pack_conv3x3_bf16x3", raw, w, Cout, Cin)
                 fn = "mnc_conv3x3_bf16x3"
+            elif args.what == "convwino":
+                raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
+                w = dev.empty((Cin * Cout * 17,))
+                dev.call("mnc_pack_conv3x3_wino", raw, w, Cout, Cin)
+                fn = "mnc_conv3x3_wino"
             else:
                 w = dev.put((rng.normal(size=((Cin // 8) * Cout * 76,)) * 0.05).astype(np.float32))
             for _ in range(3):
