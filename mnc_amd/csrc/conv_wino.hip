@@ -280,6 +280,219 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_wino_kernel(const float* __
   }
 }
 
+// ---- v2: the 16 transform positions of a tile block split over a PAIR of waves ------------------------------------------
+// v1 spends 256 registers on accumulators, so one wave per SIMD and one workgroup per CU: nothing covers a workgroup's
+// prologue / epilogue, its staging, its LDS reads or its input transform (ablations on conv2_2: 315 us -> 217 us with all of
+// them removed; ideal matrix-pipe time 156 us).  Here wave (rg, hf) owns the 32 tiles of row group rg and transform rows
+// 2*hf, 2*hf + 1 (8 of the 16 positions): 128 accumulator registers, two waves per SIMD, two workgroups per CU -- one wave's
+// LDS reads / transform / staging / epilogue run under its SIMD partner's MFMAs.
+//   * input transform per wave: only the two rows of t = B^T d it needs (hf = 0: d0-d2, d1+d2; hf = 1: d2-d1, d1-d3) from three
+//     of the four input rows, then the column pass: 64 additions for the lane's 4 channels instead of 128;
+//   * per block: 12 + 8 ds_read_b128, 64 VALU, 32 MFMAs per wave;
+//   * epilogue: the output transform is linear, so each wave applies it to its own rows (hf = 0: s0 = M0 + M1, s1 = M1;
+//     hf = 1: s0 = M2, s1 = -M2 - M3) and the pair's two partial 2x2 outputs are added through LDS (the staging buffers are
+//     free by then): hf = 1 writes 64 floats per lane, hf = 0 adds bias / ReLU and stores.
+template <int RG>
+__global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     int H, int W, int Cin, int Cout, int relu, int ksplit,
+                                                                     float* __restrict__ part) {
+  constexpr int NT = 128 * RG;
+  constexpr int kHaloRows = 4 * RG + 2;
+  constexpr int kHaloFloats = kHaloRows * kWHaloCols * kWPixPitch;
+  constexpr int kHaloVec = kHaloRows * kWHaloCols * 2;
+  constexpr int kHPer = (kHaloVec + NT - 1) / NT;
+  constexpr int kWVec = kWPanel / 4;
+  constexpr int kWPer = (kWVec + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];   // halo[2] then weights[2]; the epilogue reuses it
+  float* const s_halo = s_mem;
+  float* const s_w = s_mem + 2 * kHaloFloats;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;     // scalar: the hf branches below are uniform
+  const int rg = wave % RG, hf = wave / RG;                      // waves w and w + RG are a pair (same tiles, other positions)
+  const int j = lane & 31, kk = lane >> 5;
+  const int ty = j >> 4, tx = j & 15;
+  const int ncot = Cout >> 5;
+  const int split = blockIdx.z / ncot;
+  const int cot = blockIdx.z - split * ncot;
+  const int w0 = blockIdx.x * kWCols, h0 = blockIdx.y * (4 * RG), co0 = cot * 32;
+  const int nchunks = (Cin >> 3) / ksplit;
+  const int chunk0 = split * nchunks;
+
+  int h_off[kHPer];
+  int h_src[kHPer];
+  unsigned h_keep[kHPer];
+#pragma unroll
+  for (int u = 0; u < kHPer; ++u) {
+    const int q = min(tid + u * NT, kHaloVec - 1);
+    const int pix = q >> 1, half = q & 1;
+    const int r = pix / kWHaloCols, c = pix - r * kWHaloCols;
+    const int gh = h0 - 1 + r, gw = w0 - 1 + c;
+    h_off[u] = pix * kWPixPitch + half * 4;
+    h_src[u] = (min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1)) * 8 + half * 4;
+    h_keep[u] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? 0xFFFFFFFFu : 0u;
+  }
+  int w_idx[kWPer];
+#pragma unroll
+  for (int u = 0; u < kWPer; ++u) w_idx[u] = min(tid + u * NT, kWVec - 1);
+  const long plane = (long)H * W * 8;
+
+  struct Regs {
+    float4 h[kHPer];
+    float4 w[kWPer];
+  };
+  Regs G;
+#pragma unroll
+  for (int u = 0; u < kHPer; ++u) G.h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < kWPer; ++u) G.w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_chunk = [&](int c) {
+    c = chunk0 + min(c, nchunks - 1);
+    const float* src = in + (long)c * plane;
+#pragma unroll
+    for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
+    const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * ncot + cot) * kWPanel);
+#pragma unroll
+    for (int u = 0; u < kWPer; ++u) G.w[u] = wsrc[w_idx[u]];
+  };
+  auto store_chunk = [&](int buf) {
+    float* hdst = s_halo + buf * kHaloFloats;
+#pragma unroll
+    for (int u = 0; u < kHPer; ++u) {
+      float4 v = G.h[u];
+      v.x = __uint_as_float(__float_as_uint(v.x) & h_keep[u]);
+      v.y = __uint_as_float(__float_as_uint(v.y) & h_keep[u]);
+      v.z = __uint_as_float(__float_as_uint(v.z) & h_keep[u]);
+      v.w = __uint_as_float(__float_as_uint(v.w) & h_keep[u]);
+      *reinterpret_cast<float4*>(hdst + h_off[u]) = v;
+    }
+    float4* wdst = reinterpret_cast<float4*>(s_w + buf * kWPanel);
+#pragma unroll
+    for (int u = 0; u < kWPer; ++u) wdst[w_idx[u]] = G.w[u];
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+
+  // input rows this wave reads: hf = 0 -> d0, d1, d2; hf = 1 -> d1, d2, d3 (three consecutive halo rows from row hf)
+  const int d_base = ((4 * rg + 2 * ty + hf) * kWHaloCols + 2 * tx) * kWPixPitch + kk * 4;
+  const int u_base = (kk * 32 + j) * kWRowPitch + hf * 32;       // positions 8*hf .. 8*hf + 7
+
+  auto multiply = [&](int buf) {
+    const float* sh = s_halo + buf * kHaloFloats + d_base;
+    const float* sw = s_w + buf * kWPanel + u_base;
+    float4 t0[4], t1[4];                                          // the wave's two rows of t = B^T d
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(sh + (0 * kWHaloCols + c) * kWPixPitch);
+      const float4 b = *reinterpret_cast<const float4*>(sh + (1 * kWHaloCols + c) * kWPixPitch);
+      const float4 e = *reinterpret_cast<const float4*>(sh + (2 * kWHaloCols + c) * kWPixPitch);
+      // hf = 0: (a, b, e) = (d0, d1, d2): t0 = d0 - d2, t1 = d1 + d2;   hf = 1: (a, b, e) = (d1, d2, d3): t2 = d2 - d1, t3 = d1 - d3
+      if (hf == 0) {
+        t0[c] = make_float4(a.x - e.x, a.y - e.y, a.z - e.z, a.w - e.w);
+        t1[c] = make_float4(b.x + e.x, b.y + e.y, b.z + e.z, b.w + e.w);
+      } else {
+        t0[c] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, b.w - a.w);
+        t1[c] = make_float4(a.x - e.x, a.y - e.y, a.z - e.z, a.w - e.w);
+      }
+    }
+    float4 v[8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float4 a = r ? t1[0] : t0[0], b = r ? t1[1] : t0[1], c = r ? t1[2] : t0[2], e = r ? t1[3] : t0[3];
+      v[r * 4 + 0] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+      v[r * 4 + 1] = make_float4(b.x + c.x, b.y + c.y, b.z + c.z, b.w + c.w);
+      v[r * 4 + 2] = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
+      v[r * 4 + 3] = make_float4(b.x - e.x, b.y - e.y, b.z - e.z, b.w - e.w);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) {
+      const float4 u0 = *reinterpret_cast<const float4*>(sw + p * 4);
+      const float4 u1 = *reinterpret_cast<const float4*>(sw + p * 4 + 4);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.x, v[p].x, acc[p], 0, 0, 0);
+      acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.x, v[p + 1].x, acc[p + 1], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.y, v[p].y, acc[p], 0, 0, 0);
+      acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.y, v[p + 1].y, acc[p + 1], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.z, v[p].z, acc[p], 0, 0, 0);
+      acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.z, v[p + 1].z, acc[p + 1], 0, 0, 0);
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.w, v[p].w, acc[p], 0, 0, 0);
+      acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.w, v[p + 1].w, acc[p + 1], 0, 0, 0);
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  load_chunk(1);
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    __syncthreads();
+    store_chunk(buf ^ 1);
+    load_chunk(c + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(buf);
+  }
+  __syncthreads();                                               // every wave is done with the staging buffers
+
+  // ---- epilogue.  acc[p][e], p = 4*r + c with r the wave's local row (global row 2*hf + r), e -> channel (e&3) + 8*(e>>2) + 4*kk.
+  // Partial output transform of this wave's rows:  hf = 0: s0 = M0 + M1, s1 = M1;   hf = 1: s0 = M2, s1 = -(M2 + M3).
+  float* xch = s_mem + ((long)rg * 64 * 64);                      // [value 0..63][lane] floats per row group
+  const int oy = h0 + 4 * rg + 2 * ty, ox = w0 + 2 * tx;
+  float* dst = out;
+  if (ksplit > 1) dst = part + (long)split * Cout * H * W;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int co = co0 + g * 8 + kk * 4;
+    float y[2][2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = 4 * g + q;
+      float s0[4], s1[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float m0 = acc[cc][e], m1 = acc[4 + cc][e];
+        s0[cc] = hf ? m0 : m0 + m1;
+        s1[cc] = hf ? -(m0 + m1) : m1;
+      }
+      y[0][0][q] = s0[0] + s0[1] + s0[2];
+      y[0][1][q] = s0[1] - s0[2] - s0[3];
+      y[1][0][q] = s1[0] + s1[1] + s1[2];
+      y[1][1][q] = s1[1] - s1[2] - s1[3];
+    }
+    if (hf == 1) {
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xch[(((g * 2 + dy) * 2 + dx) * 4 + q) * 64 + lane] = y[dy][dx][q];
+    }
+    __syncthreads();                                             // (uniform: every wave runs all four g iterations)
+    if (hf == 0) {
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ksplit == 1) b = *reinterpret_cast<const float4*>(bias + co);
+      const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (y[dy][dx][q] + xch[(((g * 2 + dy) * 2 + dx) * 4 + q) * 64 + lane]) + bb[q];
+          const int yy = oy + dy, xx = ox + dx;
+          if (yy < H && xx < W) {
+            float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+            if (relu && ksplit == 1) { ov.x = fmaxf(ov.x, 0.f); ov.y = fmaxf(ov.y, 0.f); ov.z = fmaxf(ov.z, 0.f); ov.w = fmaxf(ov.w, 0.f); }
+            *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * H + yy) * W + xx) * 8 + kk * 4) = ov;
+          }
+        }
+    }
+  }
+}
+
 // OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (k half)][32 (co)][68]: element (cb, ct, kh, j, xi*4 + m) =
 // (G g G^T)[xi] of filter (co = ct*32 + j, ci = cb*8 + kh*4 + m), evaluated in double and rounded once; the 4 pad floats are 0.
 __global__ void pack_conv3x3_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
@@ -335,6 +548,26 @@ static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, cons
   return MNC_OK;
 }
 
+template <int RG>
+static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                        int Cin, int Cout, int relu, int ksplit, float* part) {
+  constexpr size_t lds_stage = 2 * 4 * ((size_t)(4 * RG + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
+  constexpr size_t lds_xch = (size_t)RG * 64 * 64 * 4;
+  constexpr size_t lds = lds_stage > lds_xch ? lds_stage : lds_xch;
+  static_assert(lds <= 80 * 1024, "conv3x3_wino2: two workgroups per CU");
+  auto kern = conv3x3_wino2_kernel<RG>;
+  static std::atomic<unsigned long long> attr_set{0};
+  const unsigned long long bit = 1ull << (ctx->device & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+    MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
+  }
+  dim3 grid(cdiv(W, kWCols), cdiv(H, 4 * RG), (Cout >> 5) * ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(128 * RG), lds, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit,
+                     part);
+  return MNC_OK;
+}
+
 }  // namespace mnc
 
 using namespace mnc;
@@ -367,11 +600,14 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) rows = v;
   }
+  // K splits: the chip holds 512 workgroups at a time (two per CU); with fewer than ~1000 the last, partly filled round costs
+  // more than the extra pass over the partial sums (measured: conv4_x 640 workgroups 304 -> 279 us with 2 splits, conv5_x 160
+  // workgroups 118 -> 93 us with 4)
   int ksplit = 1;
   {
-    const long wgs = (long)cdiv(W, kWCols) * cdiv(H, 4 * rows) * ncot;
+    const long wgs = (long)cdiv(W, kWCols) * cdiv(H, 4 * (rows >= 2 ? 2 : 1)) * ncot;
     const int blocks = Cin / 8;
-    if (wgs < 2 * 256) ksplit = blocks % 4 == 0 && blocks >= 16 ? 4 : (blocks % 2 == 0 && blocks >= 8 ? 2 : 1);
+    while (ksplit < 4 && wgs * ksplit < 1024 && blocks % (2 * ksplit) == 0 && blocks / (2 * ksplit) >= 4) ksplit *= 2;
     if (const char* e = getenv("MNC_CONV_KSPLIT")) {
       const int v = atoi(e);
       if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
@@ -386,14 +622,20 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
-  int var = 0;
+  int var = 0, ver = 2;
   if (const char* e = getenv("MNC_WINO_VAR")) var = atoi(e);
+  if (const char* e = getenv("MNC_WINO_V")) ver = atoi(e);
   int rc = MNC_ERR_INVALID;
+  if (ver == 2) {                   // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
+    if (rows >= 2) rc = launch_wino2<2>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+    else rc = launch_wino2<1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+  } else {
 #define MNC_WINO_CASE(R, V) if (rows == R && var == V) rc = launch_wino<R, V>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
-  MNC_WINO_CASE(4, 0) MNC_WINO_CASE(4, 1) MNC_WINO_CASE(2, 0) MNC_WINO_CASE(2, 1) MNC_WINO_CASE(1, 0) MNC_WINO_CASE(1, 1)
-  MNC_WINO_CASE(4, 16) MNC_WINO_CASE(4, 48) MNC_WINO_CASE(4, 112) MNC_WINO_CASE(4, 240)      // ablations (tuning)
+    MNC_WINO_CASE(4, 0) MNC_WINO_CASE(4, 1) MNC_WINO_CASE(2, 0) MNC_WINO_CASE(2, 1) MNC_WINO_CASE(1, 0) MNC_WINO_CASE(1, 1)
+    MNC_WINO_CASE(4, 16) MNC_WINO_CASE(4, 48) MNC_WINO_CASE(4, 112) MNC_WINO_CASE(4, 240)      // ablations (tuning)
 #undef MNC_WINO_CASE
-  MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d MNC_WINO_VAR=%d", rows, var);
+  }
+  MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d MNC_WINO_VAR=%d MNC_WINO_V=%d", rows, var, ver);
   if (rc) return rc;
   if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);
   return ls.finish("conv3x3_wino_kernel");

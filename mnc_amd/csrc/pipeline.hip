@@ -519,7 +519,7 @@ int mnc_net_default_config(mnc_net_config* cfg) {
   cfg->vote_nms_thresh = 0.3f; cfg->vote_iou_thresh = 0.5f;
   cfg->math = 0;
   cfg->use_graph = 1;
-  cfg->winograd = 0;
+  cfg->winograd = 1;
   clear_error();
   return MNC_OK;
 }

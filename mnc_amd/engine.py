@@ -27,7 +27,7 @@ from . import _lib, install_paths, prototxt
 from .devarray import DeviceArray
 
 # fp32 mode: 3x3 convolutions by Winograd F(2x2,3x3) unless MNC_CONV_WINOGRAD=0 / Net(winograd=False)
-WINOGRAD_DEFAULT = "0"
+WINOGRAD_DEFAULT = "1"
 
 # bf16x3 mode: InnerProducts below this many flops stay on the fp32 kernel (its small-tile variant is as fast there)
 _X3_MIN_FLOPS = 2.0e9
