@@ -126,6 +126,17 @@ class Fake(object):
         y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
         _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
 
+    def mnc_pack_conv3x3_wino(self, h, src, dst, Cout, Cin):
+        # test double: the packed buffer (Cin*Cout*17 floats) keeps the OIHW weights in its first Cout*Cin*9 floats; the real
+        # transform G g G^T and the kernel are checked against torch on the GPU (tests/test_gpu_ops.py::test_conv3x3_winograd)
+        _f(dst, (Cout * Cin * 9,))[...] = _f(src, (Cout * Cin * 9,))
+
+    def mnc_conv3x3_wino(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        w = _f(wpk, (Cout, Cin, 3, 3))
+        x = _unc8(_f(src, (Cin // 8, H, W, 8)))
+        y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
+        _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
+
     def mnc_pack_conv3x3_bf16x3(self, h, src, dst, Cout, Cin):
         w = _f(src, (Cout, Cin // 8, 8, 9)).transpose(1, 0, 3, 2)                 # [cb][co][tap][8]
         hi = (np.ascontiguousarray(w).view(np.uint32) & 0xFFFF0000).view(np.float32)
