@@ -292,7 +292,10 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_wino_kernel(const float* __
 //   * epilogue: the output transform is linear, so each wave applies it to its own rows (hf = 0: s0 = M0 + M1, s1 = M1;
 //     hf = 1: s0 = M2, s1 = -M2 - M3) and the pair's two partial 2x2 outputs are added through LDS (the staging buffers are
 //     free by then): hf = 1 writes 64 floats per lane, hf = 0 adds bias / ReLU and stores.
-template <int RG>
+//   * DMA != 0: the weight panel of a block (17 KB, stored in global memory exactly as it sits in LDS) is copied by LDS-DMA
+//     (global_load_lds_dwordx4: 1 KB per wave instruction, no staging registers, no ds_write pass); only the halo -- which
+//     needs the out-of-image mask and the padded pixel pitch -- goes through registers.
+template <int RG, int ABL = 0, int DMA = 0>
 __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int H, int W, int Cin, int Cout, int relu, int ksplit,
@@ -352,9 +355,24 @@ __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float*
     const float* src = in + (long)c * plane;
 #pragma unroll
     for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
-    const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * ncot + cot) * kWPanel);
+    if (!DMA) {
+      const float4* wsrc = reinterpret_cast<const float4*>(wpk + ((long)c * ncot + cot) * kWPanel);
 #pragma unroll
-    for (int u = 0; u < kWPer; ++u) G.w[u] = wsrc[w_idx[u]];
+      for (int u = 0; u < kWPer; ++u) G.w[u] = wsrc[w_idx[u]];
+    }
+  };
+  // weight panel of block c -> s_w[buf] by LDS-DMA: kWPanel floats = 17 pieces of 1 KB, piece i issued by wave i % waves
+  auto dma_panel = [&](int c, int buf) {
+    c = chunk0 + min(c, nchunks - 1);
+    const float* src = wpk + ((long)c * ncot + cot) * kWPanel;
+    float* dstw = s_w + buf * kWPanel;
+#pragma unroll
+    for (int i = 0; i < (kWPanel / 256 + 2 * RG - 1) / (2 * RG); ++i) {
+      const int piece = wave + i * 2 * RG;
+      if (piece < kWPanel / 256)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dstw + piece * 256), 16, 0, 0);
+    }
   };
   auto store_chunk = [&](int buf) {
     float* hdst = s_halo + buf * kHaloFloats;
@@ -367,9 +385,11 @@ __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float*
       v.w = __uint_as_float(__float_as_uint(v.w) & h_keep[u]);
       *reinterpret_cast<float4*>(hdst + h_off[u]) = v;
     }
-    float4* wdst = reinterpret_cast<float4*>(s_w + buf * kWPanel);
+    if (!DMA) {
+      float4* wdst = reinterpret_cast<float4*>(s_w + buf * kWPanel);
 #pragma unroll
-    for (int u = 0; u < kWPer; ++u) wdst[w_idx[u]] = G.w[u];
+      for (int u = 0; u < kWPer; ++u) wdst[w_idx[u]] = G.w[u];
+    }
   };
 
   f32x16 acc[8];
@@ -388,9 +408,16 @@ __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float*
     float4 t0[4], t1[4];                                          // the wave's two rows of t = B^T d
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(sh + (0 * kWHaloCols + c) * kWPixPitch);
-      const float4 b = *reinterpret_cast<const float4*>(sh + (1 * kWHaloCols + c) * kWPixPitch);
-      const float4 e = *reinterpret_cast<const float4*>(sh + (2 * kWHaloCols + c) * kWPixPitch);
+      float4 a, b, e;
+      if (ABL & 64) {                                             // ablation: operands are opaque register constants
+        a = make_float4(1.f, 2.f, 3.f, 4.f);
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+        b = a; e = a;
+      } else {
+        a = *reinterpret_cast<const float4*>(sh + (0 * kWHaloCols + c) * kWPixPitch);
+        b = *reinterpret_cast<const float4*>(sh + (1 * kWHaloCols + c) * kWPixPitch);
+        e = *reinterpret_cast<const float4*>(sh + (2 * kWHaloCols + c) * kWPixPitch);
+      }
       // hf = 0: (a, b, e) = (d0, d1, d2): t0 = d0 - d2, t1 = d1 + d2;   hf = 1: (a, b, e) = (d1, d2, d3): t2 = d2 - d1, t3 = d1 - d3
       if (hf == 0) {
         t0[c] = make_float4(a.x - e.x, a.y - e.y, a.z - e.z, a.w - e.w);
@@ -411,8 +438,15 @@ __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float*
     }
 #pragma unroll
     for (int p = 0; p < 8; p += 2) {
-      const float4 u0 = *reinterpret_cast<const float4*>(sw + p * 4);
-      const float4 u1 = *reinterpret_cast<const float4*>(sw + p * 4 + 4);
+      float4 u0, u1;
+      if (ABL & 64) {
+        u0 = make_float4(1.f, 2.f, 3.f, 4.f);
+        asm volatile("" : "+v"(u0.x), "+v"(u0.y), "+v"(u0.z), "+v"(u0.w));
+        u1 = u0;
+      } else {
+        u0 = *reinterpret_cast<const float4*>(sw + p * 4);
+        u1 = *reinterpret_cast<const float4*>(sw + p * 4 + 4);
+      }
       acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.x, v[p].x, acc[p], 0, 0, 0);
       acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.x, v[p + 1].x, acc[p + 1], 0, 0, 0);
       acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.y, v[p].y, acc[p], 0, 0, 0);
@@ -425,13 +459,17 @@ __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float*
   };
 
   load_chunk(0);
+  if (DMA) dma_panel(0, 0);
   store_chunk(0);
   load_chunk(1);
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
-    __syncthreads();
-    store_chunk(buf ^ 1);
-    load_chunk(c + 2);
+    if (!(ABL & 32)) __syncthreads();      // with a DMA in flight hipcc puts s_waitcnt vmcnt(0) in front: block c's panel has landed
+    if (!(ABL & 16)) {
+      if (DMA) dma_panel(c + 1, buf ^ 1);  // s_w[buf^1] is free: everybody is past the barrier, i.e. done with block c-1
+      store_chunk(buf ^ 1);
+      load_chunk(c + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     multiply(buf);
   }
@@ -548,14 +586,14 @@ static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, cons
   return MNC_OK;
 }
 
-template <int RG>
+template <int RG, int ABL, int DMA>
 static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
                         int Cin, int Cout, int relu, int ksplit, float* part) {
   constexpr size_t lds_stage = 2 * 4 * ((size_t)(4 * RG + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
   constexpr size_t lds_xch = (size_t)RG * 64 * 64 * 4;
   constexpr size_t lds = lds_stage > lds_xch ? lds_stage : lds_xch;
   static_assert(lds <= 80 * 1024, "conv3x3_wino2: two workgroups per CU");
-  auto kern = conv3x3_wino2_kernel<RG>;
+  auto kern = conv3x3_wino2_kernel<RG, ABL, DMA>;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long bit = 1ull << (ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
@@ -627,8 +665,14 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   if (const char* e = getenv("MNC_WINO_V")) ver = atoi(e);
   int rc = MNC_ERR_INVALID;
   if (ver == 2) {                   // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
-    if (rows >= 2) rc = launch_wino2<2>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
-    else rc = launch_wino2<1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+    // measured (kernel_bench convwino, 13-layer trunk): register staging 2.526 ms, LDS-DMA weight panel 2.564 ms -- the DMA saves
+    // 20 registers and the ds_write pass but hipcc drains it with vmcnt(0) in front of every barrier; kept selectable
+    int dma = 0;
+    if (const char* e = getenv("MNC_WINO_DMA")) dma = atoi(e) != 0;
+#define MNC_WINO2_CASE(R, A, D) if ((rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+    MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
+    MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
+#undef MNC_WINO2_CASE
   } else {
 #define MNC_WINO_CASE(R, V) if (rows == R && var == V) rc = launch_wino<R, V>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
     MNC_WINO_CASE(4, 0) MNC_WINO_CASE(4, 1) MNC_WINO_CASE(2, 0) MNC_WINO_CASE(2, 1) MNC_WINO_CASE(1, 0) MNC_WINO_CASE(1, 1)
