@@ -295,11 +295,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_wino_kernel(const float* __
 //   * DMA != 0: the weight panel of a block (17 KB, stored in global memory exactly as it sits in LDS) is copied by LDS-DMA
 //     (global_load_lds_dwordx4: 1 KB per wave instruction, no staging registers, no ds_write pass); only the halo -- which
 //     needs the out-of-image mask and the padded pixel pitch -- goes through registers.
-template <int RG, int ABL = 0, int DMA = 0>
+template <int RG, int ABL = 0, int DMA = 0, int XCD = 1>
 __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int H, int W, int Cin, int Cout, int relu, int ksplit,
-                                                                     float* __restrict__ part) {
+                                                                     float* __restrict__ part, int tiles_x) {
   constexpr int NT = 128 * RG;
   constexpr int kHaloRows = 4 * RG + 2;
   constexpr int kHaloFloats = kHaloRows * kWHaloCols * kWPixPitch;
@@ -317,9 +317,24 @@ __global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float*
   const int j = lane & 31, kk = lane >> 5;
   const int ty = j >> 4, tx = j & 15;
   const int ncot = Cout >> 5;
-  const int split = blockIdx.z / ncot;
-  const int cot = blockIdx.z - split * ncot;
-  const int w0 = blockIdx.x * kWCols, h0 = blockIdx.y * (4 * RG), co0 = cot * 32;
+  // XCD-aware block order (1-D grid).  The dispatcher puts block b on XCD b % 8 (used for speed only).  Blocks are re-numbered
+  // so that every XCD gets a CONTIGUOUS range of the logical order (output-channel tile fastest, then K split, then pixel tile):
+  // the Cout/32 workgroups that read the same input halo then run on ONE XCD at about the same time and the halo is fetched
+  // into that XCD's L2 once instead of once per channel tile from Infinity Cache / HBM.  Bijective for any block count.
+  int bz, bx, by;
+  {
+    const int total = gridDim.x, b = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const int logical = XCD ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
+    const int nz = ncot * ksplit;
+    bz = logical % nz;
+    const int rest = logical / nz;
+    bx = rest % tiles_x;
+    by = rest / tiles_x;
+  }
+  const int split = bz / ncot;
+  const int cot = bz - split * ncot;
+  const int w0 = bx * kWCols, h0 = by * (4 * RG), co0 = cot * 32;
   const int nchunks = (Cin >> 3) / ksplit;
   const int chunk0 = split * nchunks;
 
@@ -586,23 +601,24 @@ static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, cons
   return MNC_OK;
 }
 
-template <int RG, int ABL, int DMA>
+template <int RG, int ABL, int DMA, int XCD = 1>
 static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
                         int Cin, int Cout, int relu, int ksplit, float* part) {
   constexpr size_t lds_stage = 2 * 4 * ((size_t)(4 * RG + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
   constexpr size_t lds_xch = (size_t)RG * 64 * 64 * 4;
   constexpr size_t lds = lds_stage > lds_xch ? lds_stage : lds_xch;
   static_assert(lds <= 80 * 1024, "conv3x3_wino2: two workgroups per CU");
-  auto kern = conv3x3_wino2_kernel<RG, ABL, DMA>;
+  auto kern = conv3x3_wino2_kernel<RG, ABL, DMA, XCD>;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long bit = 1ull << (ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
     MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set.fetch_or(bit, std::memory_order_relaxed);
   }
-  dim3 grid(cdiv(W, kWCols), cdiv(H, 4 * RG), (Cout >> 5) * ksplit);
+  const int tiles_x = cdiv(W, kWCols);
+  dim3 grid(tiles_x * cdiv(H, 4 * RG) * (Cout >> 5) * ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(128 * RG), lds, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit,
-                     part);
+                     part, tiles_x);
   return MNC_OK;
 }
 
@@ -669,7 +685,14 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     // 20 registers and the ds_write pass but hipcc drains it with vmcnt(0) in front of every barrier; kept selectable
     int dma = 0;
     if (const char* e = getenv("MNC_WINO_DMA")) dma = atoi(e) != 0;
-#define MNC_WINO2_CASE(R, A, D) if ((rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+    // XCD-aware order (see the kernel) where the channel tiles' shared input dominates the traffic; measured FETCH_SIZE per launch
+    // plain -> XCD-aware: conv1_2 197 -> 93 MB, conv2_x 153 -> 41, conv3_x 126 -> 60; for the 512-channel layers the 17.8 MB of
+    // transformed weights dominate and every XCD would stream all of them (conv4_x 84 -> 248 MB, conv5_x 38 -> 93): plain order
+    bool plain_order = Cout > 256;
+    if (const char* e = getenv("MNC_WINO_XCD")) plain_order = atoi(e) == 0;
+    if (plain_order && rows >= 2 && var == 0 && dma == 0)
+      rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+#define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
     MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
     MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
 #undef MNC_WINO2_CASE
