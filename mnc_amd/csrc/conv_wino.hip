@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_wino_kernel(const float* __
 //     (global_load_lds_dwordx4: 1 KB per wave instruction, no staging registers, no ds_write pass); only the halo -- which
 //     needs the out-of-image mask and the padded pixel pitch -- goes through registers.
 template <int RG, int ABL = 0, int DMA = 0, int XCD = 1>
-__global__ __launch_bounds__(128 * RG, 2) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+__global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int H, int W, int Cin, int Cout, int relu, int ksplit,
                                                                      float* __restrict__ part, int tiles_x) {
@@ -607,7 +607,7 @@ static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, con
   constexpr size_t lds_stage = 2 * 4 * ((size_t)(4 * RG + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
   constexpr size_t lds_xch = (size_t)RG * 64 * 64 * 4;
   constexpr size_t lds = lds_stage > lds_xch ? lds_stage : lds_xch;
-  static_assert(lds <= 80 * 1024, "conv3x3_wino2: two workgroups per CU");
+  static_assert(lds <= (RG <= 2 ? 80 : 160) * 1024, "conv3x3_wino2: LDS budget (two workgroups per CU up to RG = 2)");
   auto kern = conv3x3_wino2_kernel<RG, ABL, DMA, XCD>;
   static std::atomic<unsigned long long> attr_set{0};
   const unsigned long long bit = 1ull << (ctx->device & 63);
@@ -693,6 +693,8 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     if (plain_order && rows >= 2 && var == 0 && dma == 0)
       rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
 #define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+    if (rc == MNC_ERR_INVALID && rows == 4 && getenv("MNC_WINO_ROWS") && var == 0 && dma == 0)          // 8-wave workgroups (tuning)
+      rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
     MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
     MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
 #undef MNC_WINO2_CASE
