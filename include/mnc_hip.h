@@ -184,6 +184,11 @@ MNC_API int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in_c8, const void* d
 MNC_API int mnc_pack_conv3x3_wino(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias, float* d_out_c8,
                              int H, int W, int Cin, int Cout, int relu);
+/* The same followed by the Pooling MAX 2x2 stride 2 of the trunk (test.prototxt:69-79, 130-140, 216-226, 302-312) in the kernel's
+ * epilogue: a 2x2 Winograd output tile IS a pooling window, so the pooled value is the maximum of a lane's own outputs and the
+ * full-resolution tensor never reaches HBM.  d_out_pooled_c8: [Cout/8][ceil(H/2)][ceil(W/2)][8] (Caffe's ceil output size). */
+MNC_API int mnc_conv3x3_wino_pool(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
+                                  float* d_out_pooled_c8, int H, int W, int Cin, int Cout, int relu);
 /* Pooling MAX 2x2 stride 2 with Caffe's ceil output size (test.prototxt:69-79,...): c8 [C/8][H][W][8] ->
  * [C/8][OH][OW][8], OH = ceil((H-2)/2)+1. */
 MNC_API int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W);

@@ -299,7 +299,7 @@ template <int RG, int ABL = 0, int DMA = 0, int XCD = 1>
 __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                                      int H, int W, int Cin, int Cout, int relu, int ksplit,
-                                                                     float* __restrict__ part, int tiles_x) {
+                                                                     float* __restrict__ part, int tiles_x, int pool) {
   constexpr int NT = 128 * RG;
   constexpr int kHaloRows = 4 * RG + 2;
   constexpr int kHaloFloats = kHaloRows * kWHaloCols * kWPixPitch;
@@ -528,6 +528,11 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ksplit == 1) b = *reinterpret_cast<const float4*>(bias + co);
       const float bb[4] = {b.x, b.y, b.z, b.w};
+      // pool != 0 (ksplit == 1 only): the following Pooling MAX 2x2 stride 2 (test.prototxt:69-79, ...) is applied here -- a
+      // Winograd tile IS a pooling window (tile origins are even), so the pooled value is the maximum of the lane's own 2x2
+      // outputs that lie inside the image (Caffe's ceil rule: the last window of an odd-sized map is clipped), written to
+      // [C/8][OH][OW][8]; the full-resolution tensor never reaches HBM.
+      float pmax[4] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -539,9 +544,19 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
           if (yy < H && xx < W) {
             float4 ov = make_float4(o[0], o[1], o[2], o[3]);
             if (relu && ksplit == 1) { ov.x = fmaxf(ov.x, 0.f); ov.y = fmaxf(ov.y, 0.f); ov.z = fmaxf(ov.z, 0.f); ov.w = fmaxf(ov.w, 0.f); }
-            *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * H + yy) * W + xx) * 8 + kk * 4) = ov;
+            if (pool) {
+              pmax[0] = fmaxf(pmax[0], ov.x); pmax[1] = fmaxf(pmax[1], ov.y);
+              pmax[2] = fmaxf(pmax[2], ov.z); pmax[3] = fmaxf(pmax[3], ov.w);
+            } else {
+              *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * H + yy) * W + xx) * 8 + kk * 4) = ov;
+            }
           }
         }
+      if (pool && oy < H && ox < W) {
+        const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;             // ceil((n - 2) / 2) + 1 for n >= 2
+        *reinterpret_cast<float4*>(dst + (((long)(co >> 3) * OH + (oy >> 1)) * OW + (ox >> 1)) * 8 + kk * 4) =
+            make_float4(pmax[0], pmax[1], pmax[2], pmax[3]);
+      }
     }
   }
 }
@@ -603,7 +618,7 @@ static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, cons
 
 template <int RG, int ABL, int DMA, int XCD = 1>
 static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
-                        int Cin, int Cout, int relu, int ksplit, float* part) {
+                        int Cin, int Cout, int relu, int ksplit, float* part, int pool = 0) {
   constexpr size_t lds_stage = 2 * 4 * ((size_t)(4 * RG + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
   constexpr size_t lds_xch = (size_t)RG * 64 * 64 * 4;
   constexpr size_t lds = lds_stage > lds_xch ? lds_stage : lds_xch;
@@ -618,7 +633,7 @@ static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, con
   const int tiles_x = cdiv(W, kWCols);
   dim3 grid(tiles_x * cdiv(H, 4 * RG) * (Cout >> 5) * ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(128 * RG), lds, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit,
-                     part, tiles_x);
+                     part, tiles_x, pool);
   return MNC_OK;
 }
 
@@ -639,8 +654,11 @@ int mnc_pack_conv3x3_wino(mnc_ctx* ctx, const float* d_oihw, float* d_packed, in
   return ls.finish("pack_conv3x3_wino_kernel");
 }
 
-int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
-                     int Cin, int Cout, int relu) {
+}  // extern "C"
+
+// pool != 0: d_out is the pooled tensor [Cout/8][ceil(H/2)][ceil(W/2)][8] (the following Pooling MAX 2x2/2 applied in the epilogue)
+static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                     int Cin, int Cout, int relu, int pool) {
   MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3_wino: null pointer");
   MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
               "mnc_conv3x3_wino: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin, Cout);
@@ -668,17 +686,21 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     }
   }
   float* part = nullptr;
+  float* full = nullptr;            // pooled output of a K-split layer: the reduction writes full resolution here first
   if (ksplit > 1) {
-    int rc = ensure_scratch(ctx, (size_t)ksplit * Cout * H * W * 4);
+    int rc = ensure_scratch(ctx, (size_t)(ksplit + (pool ? 1 : 0)) * Cout * H * W * 4);
     if (rc) return rc;
     part = (float*)ctx->scratch;
+    if (pool) full = part + (size_t)ksplit * Cout * H * W;
   }
+  const int kpool = (pool && ksplit == 1) ? 1 : 0;               // pooling inside the kernel's epilogue
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
   int var = 0, ver = 2;
   if (const char* e = getenv("MNC_WINO_VAR")) var = atoi(e);
   if (const char* e = getenv("MNC_WINO_V")) ver = atoi(e);
+  MNC_REQUIRE(!pool || (ver == 2 && var == 0), "mnc_conv3x3_wino_pool: only the default kernel build fuses the pooling");
   int rc = MNC_ERR_INVALID;
   if (ver == 2) {                   // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
     // measured (kernel_bench convwino, 13-layer trunk): register staging 2.526 ms, LDS-DMA weight panel 2.564 ms -- the DMA saves
@@ -691,10 +713,10 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     bool plain_order = Cout > 256;
     if (const char* e = getenv("MNC_WINO_XCD")) plain_order = atoi(e) == 0;
     if (plain_order && rows >= 2 && var == 0 && dma == 0)
-      rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
-#define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+      rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+#define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
     if (rc == MNC_ERR_INVALID && rows == 4 && getenv("MNC_WINO_ROWS") && var == 0 && dma == 0)          // 8-wave workgroups (tuning)
-      rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
+      rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
     MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
     MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
 #undef MNC_WINO2_CASE
@@ -706,8 +728,24 @@ int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   }
   MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d MNC_WINO_VAR=%d MNC_WINO_V=%d", rows, var, ver);
   if (rc) return rc;
-  if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);
-  return ls.finish("conv3x3_wino_kernel");
+  if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, pool ? full : d_out, H, W, Cout, ksplit, relu);
+  rc = ls.finish("conv3x3_wino_kernel");
+  if (rc) return rc;
+  if (pool && ksplit > 1) return mnc_maxpool2_c8(ctx, full, d_out, Cout, H, W);     // K-split layer: pooled after the reduction
+  return MNC_OK;
+}
+
+extern "C" {
+
+int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                     int Cin, int Cout, int relu) {
+  return wino_impl(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, 0);
+}
+
+int mnc_conv3x3_wino_pool(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out_pooled, int H,
+                          int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(H >= 2 && W >= 2, "mnc_conv3x3_wino_pool: map %dx%d too small for MAX 2x2/2", H, W);
+  return wino_impl(ctx, d_in, d_wpk, d_bias, d_out_pooled, H, W, Cin, Cout, relu, 1);
 }
 
 }  // extern "C"

@@ -360,6 +360,14 @@ int run_trunk(mnc_net* n) {
   for (int i = 0; i < 13; ++i) {
     const int cout = c.trunk_channels[kTrunkStage[i]];
     float* out = (float*)n->act[i].p;
+    if (kPoolAfter[i] && i > 0 && c.math == 0 && c.winograd && n->conv_fast[i]) {
+      // conv + ReLU + MAX 2x2/2 in one kernel (the engine's fused plan; the full-resolution blob is not produced)
+      float* p = (float*)n->pooled[pi++].p;
+      NET_TRY(mnc_conv3x3_wino_pool(ctx, cur, (const float*)n->w_conv[i], n->b_conv[i], p, h, w, cin, cout, 1));
+      h = pool_out(h); w = pool_out(w);
+      cur = p; cin = cout;
+      continue;
+    }
     if (i == 0) NET_TRY(mnc_conv3x3_c3(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1));
     else NET_TRY(conv3(n, i, cur, out, h, w, cin, cout));
     cur = out; cin = cout;

@@ -479,6 +479,13 @@ class Net(object):
                 nxt = self._sole_consumer(L.tops[0], "Sigmoid")
                 if nxt is not None:
                     L.act, L.out_name, nxt.skip = 2, nxt.tops[0], True
+            if (L.type == "Convolution" and self.math == "fp32" and self._winograd and L.bn is None and L.scale is None
+                    and self._conv_kind(L) == "fast3x3"):
+                # conv3x3 + ReLU + Pooling MAX 2x2/2 (conv1_2 / conv2_2 / conv3_3 / conv4_3 of the trunk): a 2x2 Winograd
+                # output tile is a pooling window, the pool is applied in the convolution's epilogue (mnc_conv3x3_wino_pool)
+                nxt = self._sole_consumer(L.tops[0], "Pooling")
+                if nxt is not None and self._is_pool2(nxt):
+                    L.fused_pool, L.out_name, nxt.skip = True, nxt.tops[0], True
             if L.type in ("ROIWarping", "MaskPooling"):
                 nxt = self._sole_consumer(L.tops[0], "Pooling")
                 if nxt is not None and self._is_pool2(nxt):
@@ -670,6 +677,14 @@ class Net(object):
             def run():
                 N, _, H, Wd = bot.shape
                 src = bot.dev_in("c8")
+                if L.fused_pool:                           # top is the Pooling layer's blob
+                    OH, OW = _pool_out(H), _pool_out(Wd)
+                    top.reshape(N, cout, OH, OW)
+                    dst = top.dev_out("c8")
+                    for n in range(N):
+                        _lib.call("mnc_conv3x3_wino_pool", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
+                                  dst + n * cout * OH * OW * 4, H, Wd, cin, cout, relu)
+                    return
                 top.reshape(N, cout, H, Wd)
                 dst = top.dev_out("c8")
                 for n in range(N):

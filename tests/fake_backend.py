@@ -137,6 +137,13 @@ class Fake(object):
         y = F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1)
         _f(dst, (Cout // 8, H, W, 8))[...] = _c8(_act(y, relu)[0].numpy())
 
+    def mnc_conv3x3_wino_pool(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        w = _f(wpk, (Cout, Cin, 3, 3))
+        x = _unc8(_f(src, (Cin // 8, H, W, 8)))
+        y = _act(F.conv2d(_t(x)[None], _t(w), _t(_f(b, (Cout,))), padding=1), relu)
+        y = F.max_pool2d(y, 2, 2, ceil_mode=True)
+        _f(dst, (Cout // 8, y.shape[2], y.shape[3], 8))[...] = _c8(y[0].numpy())
+
     def mnc_pack_conv3x3_bf16x3(self, h, src, dst, Cout, Cin):
         w = _f(src, (Cout, Cin // 8, 8, 9)).transpose(1, 0, 3, 2)                 # [cb][co][tap][8]
         hi = (np.ascontiguousarray(w).view(np.uint32) & 0xFFFF0000).view(np.float32)

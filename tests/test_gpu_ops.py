@@ -92,6 +92,15 @@ def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
         got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
         assert err(got, want)[1] < 1e-4, (rows, ks, err(got, want))
         assert err(got, direct)[1] < 1e-5, (rows, ks, err(got, direct))
+        # + the following Pooling MAX 2x2/2 in the epilogue (Caffe's ceil output size: odd H / W clip the last window), with and
+        # without K splits: exactly the maximum over the un-fused kernel's own outputs
+        if rows in (None, "2") and H >= 2 and W >= 2:
+            OH, OW = (H + 1) // 2, (W + 1) // 2
+            d_p = dev.empty((Cout, OH, OW), fill=-7.0)
+            dev.call("mnc_conv3x3_wino_pool", d_x, d_w, d_b, d_p, H, W, Cin, Cout, relu)
+            pooled = from_c8(dev.get(d_p, (Cout * OH * OW,)), Cout, OH, OW)
+            ref = F.max_pool2d(torch.from_numpy(got)[None], 2, 2, ceil_mode=True)[0].numpy()
+            assert np.array_equal(pooled, ref), (rows, ks)
 
 
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
