@@ -271,6 +271,26 @@ MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed
 MNC_API int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,
                             int H, int W, int Cin, int Cout, int relu);
+/* Packed 2-byte activations between MFMA layers (bf16x3 and f16 math modes).  A c8 tensor [C/8][H][W][8] is kept as
+ *   bf16x3:  [C/8][H][W][hi x8 | lo x8] bf16 -- the split the kernels apply to an fp32 value (hi = truncation, lo = the
+ *            remainder rounded half-up), two 2-byte planes interleaved per pixel, 32 B per pixel and channel block;
+ *   f16:     [C/8][H][W][8] fp16 (round to nearest even), 16 B per pixel and channel block.
+ * A producer (in_packed / out_packed select the format of each side) applies in its epilogue exactly what the consumer's
+ * staging would apply to the fp32 value, so a packed chain gives bit for bit the results of the fp32-tensor chain
+ * (models/VGG16/mnc_5stage/test.prototxt:41-412 is such a chain: conv1_1 .. conv5_3 with four MAX 2x2/2 pools).
+ * mnc_maxpool2_c8_{bf16x3,f16}: Pooling MAX 2x2/2 (ceil output size) on the packed form; mnc_act_pack / mnc_act_unpack:
+ * fp32 c8 <-> packed, n = element count (multiple of 8), f16 = 0 for the bf16x3 form. */
+MNC_API int mnc_conv3x3_bf16x3_pk(mnc_ctx* ctx, const void* d_in, const void* d_w_packed, const float* d_bias, void* d_out,
+                                  int H, int W, int Cin, int Cout, int relu, int in_packed, int out_packed);
+MNC_API int mnc_conv3x3_f16_pk(mnc_ctx* ctx, const void* d_in, const void* d_w_packed, const float* d_bias, void* d_out,
+                               int H, int W, int Cin, int Cout, int relu, int in_packed, int out_packed);
+/* conv1_1 (mnc_conv3x3_c3) writing the packed form: out_fmt 0 = fp32 c8, 1 = bf16x3 packed, 2 = fp16 packed */
+MNC_API int mnc_conv3x3_c3_fmt(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, void* d_out,
+                               int H, int W, int Cout, int relu, int out_fmt);
+MNC_API int mnc_maxpool2_c8_bf16x3(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W);
+MNC_API int mnc_maxpool2_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W);
+MNC_API int mnc_act_pack(mnc_ctx* ctx, const float* d_c8, void* d_packed, size_t n, int f16);
+MNC_API int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size_t n, int f16);
 /* "f16" math mode (BASELINE.json configs[4] names fp16): InnerProduct with both operands rounded to IEEE fp16 (nearest even)
  * and fp32 accumulation on v_mfma_f32_32x32x16_f16 -- one product per term, 2 bytes per value streamed instead of 4.
  * mnc_pack_fc_f16: Caffe weight [N][K] -> [ceil(N/128)][K/64][128][64] halves (bytes: ceil(N/128)*128*K*2), once at load.

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "mnc_internal.h"
+#include "x3_split.h"
 
 namespace mnc {
 
@@ -250,8 +251,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 // ---- conv1_1: Cin = 3 (K = 27): HBM-bound (154 MB written at 600x1000), VALU.  One thread = one pixel: its 27 inputs are
 // loaded once into registers and all Cout channels are produced from them, 8 at a time, with the weights read from LDS at
 // wave-uniform addresses (broadcast reads).  A wave writes 64 pixels x 32 B contiguous per channel block.
+// OUT: 0 = fp32 c8, 1 = packed bf16x3 (hi x8 | lo x8), 2 = packed fp16 -- the activation formats of conv_x3.hip
+template <int OUT>
 __global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                         const float* __restrict__ bias, void* __restrict__ out, int H,
                                                          int W, int Cout, int relu) {
   extern __shared__ __attribute__((aligned(16))) float s_wt[];   // [Cout/8][27][8] then bias[Cout]
   for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) {
@@ -294,9 +297,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
       }
-      float4* dst = reinterpret_cast<float4*>(out + ((long)cb * hw + pix) * 8);
-      dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      x3_store8<OUT == 2, OUT != 0>(out, (long)cb * hw + pix, make_float4(acc[0], acc[1], acc[2], acc[3]),
+                                    make_float4(acc[4], acc[5], acc[6], acc[7]));
     }
   }
 }
@@ -474,15 +476,22 @@ launched:
   return ls.finish("conv3x3_c8_kernel");
 }
 
-int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, float* d_out, int H, int W,
-                   int Cout, int relu) {
+int mnc_conv3x3_c3_fmt(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, void* d_out, int H, int W,
+                       int Cout, int relu, int out_fmt) {
   MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out, "mnc_conv3x3_c3: null pointer");
   MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && Cout <= 512, "mnc_conv3x3_c3: unsupported shape");
-  const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + Cout);
+  MNC_REQUIRE(out_fmt >= 0 && out_fmt <= 2, "mnc_conv3x3_c3: out_fmt must be 0 (fp32), 1 (bf16x3 packed) or 2 (fp16 packed)");
+  const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + (out_fmt == 2 ? 0.5 : 1.0) * Cout);
   LaunchScope ls(ctx, "conv3x3_c3", flops, bytes);
-  hipLaunchKernelGGL(conv3x3_c3_kernel, dim3(grid_for((long)H * W)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w,
-                     d_bias, d_out, H, W, Cout, relu);
+  auto kern = out_fmt == 0 ? conv3x3_c3_kernel<0> : (out_fmt == 1 ? conv3x3_c3_kernel<1> : conv3x3_c3_kernel<2>);
+  hipLaunchKernelGGL(kern, dim3(grid_for((long)H * W)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w, d_bias, d_out,
+                     H, W, Cout, relu);
   return ls.finish("conv3x3_c3_kernel");
+}
+
+int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, float* d_out, int H, int W,
+                   int Cout, int relu) {
+  return mnc_conv3x3_c3_fmt(ctx, d_in, d_w, d_bias, d_out, H, W, Cout, relu, 0);
 }
 
 int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W) {

@@ -70,6 +70,7 @@ struct mnc_net {
   // device weights
   float* w_c3 = nullptr;                       // conv1_1 [Cout][3][3][3]
   void* w_conv[14] = {nullptr};                // packed conv3x3 weights: trunk 1..12, [13] = rpn_conv_3x3
+  bool packed_trunk = false;                   // bf16x3 / f16 with every trunk layer on the tuned kernel: 2-byte activations
   bool conv_fast[14] = {false};                // tuned 3x3 kernels (Cout % 32 == 0) or the general convolution (reduced widths)
   float* b_conv[14] = {nullptr};               // biases: trunk 0..12 -> [0..12], rpn -> [13]
   float *w_rpn_cls = nullptr, *b_rpn_cls = nullptr, *w_rpn_box = nullptr, *b_rpn_box = nullptr;
@@ -218,6 +219,8 @@ int finalize(mnc_net* n) {
     }
     cin = cout;
   }
+  n->packed_trunk = c.math != 0 && !(getenv("MNC_PACKED_ACT") && atoi(getenv("MNC_PACKED_ACT")) == 0);
+  for (int i = 1; i < 13; ++i) n->packed_trunk = n->packed_trunk && n->conv_fast[i];
   const int A = c.num_anchors, RC = c.rpn_channels;
   NET_TRY(need(n, "rpn_cls_score", 0, (size_t)2 * A * RC, &w)); NET_TRY(upload(n, w->v, &n->w_rpn_cls));
   NET_TRY(need(n, "rpn_cls_score", 1, (size_t)2 * A, &b));      NET_TRY(upload(n, b->v, &n->b_rpn_cls));
@@ -357,6 +360,29 @@ int run_trunk(mnc_net* n) {
                          (const int*)(t + 2 * n->OW), t + 2 * n->OW + n->OH, n->OH, (float*)n->data.p, n->OH, n->OW));
   int h = n->OH, w = n->OW, pi = 0, cin = 3;
   const float* cur = (const float*)n->data.p;
+  if (n->packed_trunk) {
+    // bf16x3 / f16: 2-byte activation tensors between the MFMA layers (include/mnc_hip.h "Packed 2-byte activations"): conv1_1
+    // and every convolution's epilogue write the form the next layer's staging copies verbatim; conv5_3 writes fp32 c8 for the
+    // RPN convolution and the RoI warps.  Bit for bit the fp32-tensor route (test_gpu_ops.py::test_conv3x3_packed_activations).
+    const int f16 = c.math == 2;
+    const void* pc = cur;
+    for (int i = 0; i < 13; ++i) {
+      const int cout = c.trunk_channels[kTrunkStage[i]];
+      void* out = n->act[i].p;
+      if (i == 0) NET_TRY(mnc_conv3x3_c3_fmt(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1, c.math));
+      else if (f16) NET_TRY(mnc_conv3x3_f16_pk(ctx, pc, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1, 1, i < 12));
+      else NET_TRY(mnc_conv3x3_bf16x3_pk(ctx, pc, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1, 1, i < 12));
+      pc = out; cin = cout;
+      if (kPoolAfter[i]) {
+        void* p = n->pooled[pi++].p;
+        if (f16) NET_TRY(mnc_maxpool2_c8_f16(ctx, pc, p, cout, h, w));
+        else NET_TRY(mnc_maxpool2_c8_bf16x3(ctx, pc, p, cout, h, w));
+        h = pool_out(h); w = pool_out(w);
+        pc = p;
+      }
+    }
+    cur = (const float*)pc;
+  } else
   for (int i = 0; i < 13; ++i) {
     const int cout = c.trunk_channels[kTrunkStage[i]];
     float* out = (float*)n->act[i].p;

@@ -58,6 +58,51 @@ __device__ __forceinline__ void x3_split8_rne(const float* x, uint4& hi, uint4& 
   lo = make_uint4(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]), x3_pack_hi16(l[4], l[5]), x3_pack_hi16(l[6], l[7]));
 }
 
+// 4 consecutive channels (channel-block half kb) of pixel `pix` of a c8 plane set, in the activation format of the math mode:
+// fp32 [..][8] float | packed bf16x3 [..][hi x8 | lo x8] (the x3_split of the value) | packed f16 [..][8] fp16 (nearest even)
+template <int F16, bool PACKED>
+__device__ __forceinline__ void x3_store4(void* out, long pix, int kb, const float4 v) {
+  if (!PACKED) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + pix * 8 + kb * 4) = v;
+  } else if (F16) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const f16x4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(out) + pix * 4 + kb * 2) = __builtin_bit_cast(uint2, hv);
+  } else {
+    uint2 hi, lo;
+    x3_split4(v, hi, lo);
+    unsigned* p = reinterpret_cast<unsigned*>(out) + pix * 8 + kb * 2;
+    *reinterpret_cast<uint2*>(p) = hi;
+    *reinterpret_cast<uint2*>(p + 4) = lo;
+  }
+}
+
+__device__ __forceinline__ uint2 x3_f16x4(const float4 v) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  const f16x4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  return __builtin_bit_cast(uint2, hv);
+}
+
+// all 8 channels of pixel `pix` (a = channels 0-3, b = 4-7): 16-byte stores
+template <int F16, bool PACKED>
+__device__ __forceinline__ void x3_store8(void* out, long pix, const float4 a, const float4 b) {
+  if (!PACKED) {
+    float4* p = reinterpret_cast<float4*>(out) + pix * 2;
+    p[0] = a;
+    p[1] = b;
+  } else if (F16) {
+    const uint2 lo = x3_f16x4(a), hi = x3_f16x4(b);
+    reinterpret_cast<uint4*>(out)[pix] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  } else {
+    uint2 ah, al, bh, bl;
+    x3_split4(a, ah, al);
+    x3_split4(b, bh, bl);
+    uint4* p = reinterpret_cast<uint4*>(out) + pix * 2;
+    p[0] = make_uint4(ah.x, ah.y, bh.x, bh.y);
+    p[1] = make_uint4(al.x, al.y, bl.x, bl.y);
+  }
+}
+
 __device__ __forceinline__ f16x8 x3_as_f16x8(const uint4 v) { return __builtin_bit_cast(f16x8, v); }
 
 __device__ __forceinline__ bf16x8 x3_as_bf16x8(const uint4 v) {

@@ -144,6 +144,56 @@ def test_conv3x3_f16(dev, H, W, Cin, Cout):
     assert rel < 1e-5 and rel32 < 2e-3
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16"])
+@pytest.mark.parametrize("H,W,Cin,Cout", [(9, 70, 8, 32), (38, 63, 64, 128), (13, 33, 128, 256), (75, 125, 32, 64), (150, 250, 16, 128)])
+def test_conv3x3_packed_activations(dev, mode, H, W, Cin, Cout):
+    """2-byte activations between MFMA layers: a producer that writes the packed form and a consumer that reads it give bit for
+    bit what the fp32-tensor route gives (the producer's epilogue applies the consumer's own split / rounding); the packed MAX
+    2x2/2 pool equals packing the pooled fp32 tensor.  Shapes cover both register tiles and the split-K reduction."""
+    f16 = int(mode == "f16")
+    rng = np.random.default_rng(H * 1000 + W + 11)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    d_w = dev.empty(((Cin // 8) * Cout * 84,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_" + mode, dev.put(w), d_w, Cout, Cin)
+    d_b, d_x = dev.put(b), dev.put(to_c8(x))
+    n_in, n_out = Cin * H * W, Cout * H * W
+    words = lambda n: n // 2 if f16 else n                      # 32-bit words of a packed tensor of n elements
+    d_xp = dev.empty((words(n_in),), fill=np.nan)
+    dev.call("mnc_act_pack", d_x, d_xp, n_in, f16)
+    # reference route: fp32 tensors in and out
+    d_y = dev.empty((n_out,), fill=np.nan)
+    dev.call("mnc_conv3x3_" + mode, d_x, d_w, d_b, d_y, H, W, Cin, Cout, 1)
+    y = dev.get(d_y, (n_out,))
+    d_yp = dev.empty((words(n_out),), fill=np.nan)
+    dev.call("mnc_act_pack", d_y, d_yp, n_out, f16)
+    yp = dev.get(d_yp, (words(n_out),)).view(np.uint32)
+    pk = "mnc_conv3x3_%s_pk" % mode
+    for in_pk, out_pk in ((1, 0), (0, 1), (1, 1)):
+        d_o = dev.empty((words(n_out) if out_pk else n_out,), fill=np.nan)
+        dev.call(pk, d_xp if in_pk else d_x, d_w, d_b, d_o, H, W, Cin, Cout, 1, in_pk, out_pk)
+        got = dev.get(d_o, (words(n_out) if out_pk else n_out,)).view(np.uint32)
+        assert np.array_equal(got, yp if out_pk else y.view(np.uint32)), (in_pk, out_pk)
+    # unpack(pack(y)) is y to the format's precision
+    d_u = dev.empty((n_out,), fill=np.nan)
+    dev.call("mnc_act_unpack", d_yp, d_u, n_out, f16)
+    u = dev.get(d_u, (n_out,))
+    assert np.abs(u - y).max() <= (1e-3 if f16 else 2.0 ** -15) * np.abs(y).max()
+    if f16:
+        assert np.array_equal(u, y.astype(np.float16).astype(np.float32))
+    # pool: packed(pool(y)) == pool_packed(packed(y))
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    d_p = dev.empty((Cout * OH * OW,), fill=np.nan)
+    dev.call("mnc_maxpool2_c8", d_y, d_p, Cout, H, W)
+    d_pp = dev.empty((words(Cout * OH * OW),), fill=np.nan)
+    dev.call("mnc_act_pack", d_p, d_pp, Cout * OH * OW, f16)
+    d_q = dev.empty((words(Cout * OH * OW),), fill=np.nan)
+    dev.call("mnc_maxpool2_c8_" + mode, d_yp, d_q, Cout, H, W)
+    a, c = dev.get(d_pp, (words(Cout * OH * OW),)).view(np.uint32), dev.get(d_q, (words(Cout * OH * OW),)).view(np.uint32)
+    assert np.array_equal(a, c)
+
+
 def test_conv3x3_bf16x3_packed_weight_layout(dev):
     """[Cin/8][Cout][10 slots x (hi x8 | lo x8) bf16 + pad]: hi + lo reproduces the fp32 weight to 2^-16 relative, slot 9
     and the pad are zero."""

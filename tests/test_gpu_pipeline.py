@@ -97,15 +97,18 @@ def test_native_pipeline_without_graph_and_with_few_proposals(monkeypatch):
         net.close()
 
 
-def test_native_pipeline_full_size_vgg16():
-    """BASELINE configs[1] shape through the one-call path: 600x1000, VGG-16 widths, 300 RoIs per stage, fp32."""
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
+def test_native_pipeline_full_size_vgg16(math):
+    """BASELINE configs[1] shape through the one-call path: 600x1000, VGG-16 widths, 300 RoIs per stage.  In the bf16x3 and f16
+    modes the native trunk keeps 2-byte activation tensors between the convolutions while the Python engine keeps fp32 tensors
+    and splits / rounds them in each consumer: the results are the same bits."""
     from mnc_amd.engine import Net
     path = models.write_mnc_5stage_test_prototxt()
     w = synth.synthetic_weights(path, seed=0)
-    net = Net(path, w, 1)
-    nat = NativeNet(w)
+    net = Net(path, w, 1, math=math)
+    nat = NativeNet(w, math=math)
     try:
-        for seed in (0, 1, 2):
+        for seed in ((0, 1, 2) if math == "fp32" else (0, 1)):
             im = np.random.default_rng(seed).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
             _check_against_engine(nat, net, im)
             assert nat.blob("rois").shape == (300, 5)

@@ -41,11 +41,15 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "convx3", "convwino", "fc", "fcx3"])
+    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "fc", "fcx3"])
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
+    ap.add_argument("--packed", action="store_true", help="convx3 / convf16: 2-byte activation tensors in and out")
+    ap.add_argument("--conv-shape", action="append", default=[], help="conv*: replace the layer list by H,W,Cin,Cout (repeatable)")
     args = ap.parse_args()
+    if args.conv_shape:
+        CONV[:] = [("custom%d" % i,) + tuple(int(v) for v in sh.split(",")) for i, sh in enumerate(args.conv_shape)]
     if args.shape:
         m, n, k = (int(v) for v in args.shape.split(","))
         FC[:] = [("custom", m, n, k)]
@@ -53,7 +57,7 @@ def main():
     rng = np.random.default_rng(0)
     dev.call("mnc_prof_enable", 1)
     total_ms, total_fl = 0.0, 0.0
-    if args.what in ("conv", "convx3", "convwino"):
+    if args.what in ("conv", "convx3", "convf16", "convwino"):
         for name, H, W, Cin, Cout in CONV:
             if args.only and args.only not in name:
                 continue
@@ -61,11 +65,15 @@ def main():
             b = dev.put(np.zeros(Cout, np.float32))
             y = dev.empty((Cout * H * W,))
             fn = "mnc_conv3x3"
-            if args.what == "convx3":
+            extra = ()
+            if args.what in ("convx3", "convf16"):
+                mode = "bf16x3" if args.what == "convx3" else "f16"
                 raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
                 w = dev.empty(((Cin // 8) * Cout * 84,))
-                dev.call("mnc_pack_conv3x3_bf16x3", raw, w, Cout, Cin)
-                fn = "mnc_conv3x3_bf16x3"
+                dev.call("mnc_pack_conv3x3_" + mode, raw, w, Cout, Cin)
+                fn = "mnc_conv3x3_" + mode
+                if args.packed:                       # 2-byte activations on both sides (buffers are large enough either way)
+                    fn, extra = fn + "_pk", (1, 1)
             elif args.what == "convwino":
                 raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
                 w = dev.empty((Cin * Cout * 17,))
@@ -74,10 +82,10 @@ def main():
             else:
                 w = dev.put((rng.normal(size=((Cin // 8) * Cout * 76,)) * 0.05).astype(np.float32))
             for _ in range(3):
-                dev.call(fn, x, w, b, y, H, W, Cin, Cout, 1)
+                dev.call(fn, x, w, b, y, H, W, Cin, Cout, 1, *extra)
             dev.call("mnc_prof_reset")
             for _ in range(args.reps):
-                dev.call(fn, x, w, b, y, H, W, Cin, Cout, 1)
+                dev.call(fn, x, w, b, y, H, W, Cin, Cout, 1, *extra)
             t = np.array([r[1] for r in records(dev) if r[0].startswith("conv3x3")])
             fl = 2.0 * H * W * 9 * Cin * Cout
             print("%-10s %4dx%-4d %3d->%-3d  med %.1f us  min %.1f us  %.1f TF/s (med)  %.1f TF/s (best)" %
