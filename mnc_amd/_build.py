@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     cc = _hipcc()
     base = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
-            "-Wno-unused-function"]
+            "-Wno-unused-function"] + os.environ.get("MNC_HIPCC_EXTRA", "").split()      # e.g. -DMNC_X3_ABL=3 (tuning builds)
 
     hdr_mtime = max(os.path.getmtime(p) for p in
                     [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] +

@@ -42,6 +42,12 @@ constexpr int kX3WPitch = 84;          // dwords per weight row: 10 slots x 8 + 
 // plain 16-byte copy into LDS (tests/test_gpu_ops.py::test_conv3x3_packed_activations).
 constexpr int kFmtInPacked = 1, kFmtOutPacked = 2;
 
+// Tuning ablations of the pipelined loop (never set in a product build): 1 = no global loads, 2 = no LDS stores,
+// 4 = no fragment reads (profiles/r02_x3_ablation.txt)
+#ifndef MNC_X3_ABL
+#define MNC_X3_ABL 0
+#endif
+
 // sched_group_barrier pins for one K-step: NM MFMAs in slots of two; the NR fragment reads of the NEXT K-step front-loaded
 // (so that the last of them has a slot of MFMAs behind it), NW LDS stores and NG global loads spread over the slots.
 template <int I, int S, int NM, int NR, int NW, int NG>
@@ -207,6 +213,14 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
 
   struct Frags { uint4 bh[PR], bl[PR], ah[CT], al[CT]; };   // f16: bl / al unused
   auto read_frags = [&](int buf, int s, Frags& f) {
+    if (MNC_X3_ABL & 4) {                                    // ablation: no fragment reads, opaque register contents
+      auto opaque = [](uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+#pragma unroll
+      for (int r = 0; r < PR; ++r) { opaque(f.bh[r]); opaque(f.bl[r]); }
+#pragma unroll
+      for (int t = 0; t < CT; ++t) { opaque(f.ah[t]); opaque(f.al[t]); }
+      return;
+    }
     const unsigned* sh = s_halo + buf * kHaloDw;
     const unsigned* sw = s_w + buf * kWDw;
 #pragma unroll
@@ -261,11 +275,11 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   constexpr int kNWH = kHPer * ((kInPk || F16) ? 1 : 2);
   constexpr int kS = kNM >= 2 ? kNM / 2 : 1;
   // block c sits in LDS[buf]; f[P] holds its K-step-0 fragments; on return f[P ^ 1] holds those of block c + 1
-  Frags f[2];
+  Frags f[2] = {};
   auto step = [&](int c, int buf, auto parity) {
     constexpr int P = decltype(parity)::value;
     read_frags(buf, 1, f[P ^ 1]);
-    load_chunk(c + 1, G);
+    if (!(MNC_X3_ABL & 1)) load_chunk(c + 1, G);
     mfmas(f[P]);
     X3Pin<0, kS, kNM, kNR, 0, kHPer + kWPer>::run();
     pin_acc();
@@ -274,12 +288,12 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
     X3Pin<0, kS, kNM, kNR, 0, 0>::run();
     pin_acc();
     read_frags(buf, 3, f[P ^ 1]);
-    store_halo(buf ^ 1, G, c + 1 < nchunks);
+    if (!(MNC_X3_ABL & 2)) store_halo(buf ^ 1, G, c + 1 < nchunks);
     mfmas(f[P]);
     X3Pin<0, kS, kNM, kNR, kNWH, 0>::run();
     pin_acc();
     read_frags(buf, 4, f[P]);
-    store_weights(buf ^ 1, G);
+    if (!(MNC_X3_ABL & 2)) store_weights(buf ^ 1, G);
     mfmas(f[P ^ 1]);
     X3Pin<0, kS, kNM, kNR, kWPer, 0>::run();
     pin_acc();

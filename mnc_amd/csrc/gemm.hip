@@ -240,10 +240,40 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
   }
 }
 
+// out = act(sum over splits (in split order) + bias).  VEC = 4: N % 4 == 0 and ldc % 4 == 0 -- one thread per four columns,
+// 16-byte loads, four splits in flight; the per-element order of the additions is that of the scalar kernel.
+template <int VEC>
 __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                         float* __restrict__ out, int M, int N, int ldc, int splits,
                                                         int act) {
   const long total = (long)M * N;
+  if (VEC == 4) {
+    const int n4 = N >> 2;
+    const long total4 = total >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+      const int n = (int)(i % n4) * 4;
+      const long m = i / n4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      int s = 0;
+      for (; s + 4 <= splits; s += 4) {
+        const float4 a = p4[(long)s * total4 + i], b = p4[(long)(s + 1) * total4 + i], c = p4[(long)(s + 2) * total4 + i],
+                     d = p4[(long)(s + 3) * total4 + i];
+        v.x = (((v.x + a.x) + b.x) + c.x) + d.x;
+        v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+        v.z = (((v.z + a.z) + b.z) + c.z) + d.z;
+        v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+      }
+      for (; s < splits; ++s) {
+        const float4 a = p4[(long)s * total4 + i];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      *reinterpret_cast<float4*>(out + m * ldc + n) =
+          make_float4(apply_act(v.x + b.x, act), apply_act(v.y + b.y, act), apply_act(v.z + b.z, act), apply_act(v.w + b.w, act));
+    }
+    return;
+  }
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int n = (int)(idx % N);
     const long m = idx / N;
@@ -251,6 +281,17 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
     for (int s = 0; s < splits; ++s) v += part[(long)s * total + idx];
     out[m * ldc + n] = apply_act(v + bias[n], act);
   }
+}
+
+void fc_reduce_launch(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
+                      int act) {
+  const bool vec = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+  const long items = vec ? (long)M * N / 4 : (long)M * N;
+  int g = (int)((items + 255) / 256);
+  if (g > 4096) g = 4096;
+  if (vec) hipLaunchKernelGGL(fc_reduce_kernel<4>, dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act);
+  else hipLaunchKernelGGL(fc_reduce_kernel<1>, dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act);
 }
 
 __global__ void softmax_rows_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int M, int N) {
@@ -381,10 +422,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   }
   if (splits > 1) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
-    long total = (long)M * N;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(fc_reduce_kernel, dim3(g), dim3(256), 0, ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
     return ls.finish("fc_reduce_kernel");
   }
   return MNC_OK;

@@ -277,19 +277,6 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
   }
 }
 
-__global__ __launch_bounds__(256) void fc_x3_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                           float* __restrict__ out, int M, int N, int ldc, int splits,
-                                                           int act) {
-  const long total = (long)M * N;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(idx % N);
-    const long m = idx / N;
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += part[(long)s * total + idx];
-    out[m * ldc + n] = x3_act(v + bias[n], act);
-  }
-}
-
 // fp32 row-major [rows][K] -> split bf16, stage-major: out[((tile * S + s) * tile_rows + r) * 8 + 2*g + {hi, lo}] with
 // row = tile * tile_rows + r, S = K/32 stages, g = 8-value group inside the stage.  Rows >= rows (padding of the last
 // tile) are written as zeros.  Weights: tile_rows = 128 (column tiles of the GEMM).  Activations: one tile of `rows` rows.
@@ -444,11 +431,8 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
   }
   if (splits > 1) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
-    long total = (long)M * N;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(fc_x3_reduce_kernel, dim3(g), dim3(256), 0, ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
-    return ls.finish("fc_x3_reduce_kernel");
+    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+    return ls.finish("fc_reduce_kernel");
   }
   return MNC_OK;
 }
@@ -516,11 +500,8 @@ int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const flo
   }
   if (splits > 1) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
-    long total = (long)M * N;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(fc_x3_reduce_kernel, dim3(g), dim3(256), 0, ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
-    return ls.finish("fc_x3_reduce_kernel");
+    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+    return ls.finish("fc_reduce_kernel");
   }
   return MNC_OK;
 }
