@@ -265,9 +265,9 @@ MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float
 MNC_API int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
 MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M,
                           int N, int K, int ldc, int act);
-/* "f16" math mode, 3x3 convolution: the split-bf16 kernel with one fp16 product per term (activations rounded to fp16 while
- * staged, fp32 accumulate, fp32 c8 tensors in HBM as for the other modes).  mnc_pack_conv3x3_f16 writes the same packed
- * layout as mnc_pack_conv3x3_bf16x3 ([Cin/8][Cout][84 dwords]) with fp16 values in the hi halves. */
+/* "f16" math mode, 3x3 convolution: one fp16 product per term on v_mfma_f32_32x32x16_f16 (activations rounded to fp16 while
+ * staged, fp32 accumulate).  mnc_pack_conv3x3_f16 writes [ceil(Cin/16)][Cout][76 dwords]: 9 taps x 16 channels fp16 + 16 B
+ * pad, channels past Cin zero (at most the (Cin/8)*Cout*84 dwords of the bf16x3 layout: one buffer size serves both). */
 MNC_API int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,
                             int H, int W, int Cin, int Cout, int relu);

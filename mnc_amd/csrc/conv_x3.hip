@@ -31,7 +31,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kX3Cols = 32;
 constexpr int kX3HaloCols = kX3Cols + 2;
 constexpr int kX3PixPitch = 12;        // dwords per halo pixel in LDS: hi x8 | lo x8 | pad
-constexpr int kX3WPitch = 84;          // dwords per weight row: 10 slots x 8 + 4 pad (global packed layout and LDS)
+constexpr int kX3WPitch = 84;          // bf16x3: dwords per weight row: 10 slots x 8 + 4 pad (global packed layout and LDS)
+constexpr int kF16WPitch = 76;         // f16: 9 taps x 16 channels x 2 B = 72 dwords + 4 pad
+// compile-time loop: f(std::integral_constant<int, 0>()) ... f(<N - 1>)
+template <int I, int N, class F>
+__device__ __forceinline__ void x3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    x3_static_for<I + 1, N>(f);
+  }
+}
 
 // Activation formats ("fmt" below; bit 0 = input, bit 1 = output):
 //   fp32 c8   [C/8][H][W][8] float                                            (32 B per pixel and channel block)
@@ -67,10 +76,13 @@ struct X3Pin {
   }
 };
 
-// F16 != 0: the "f16" math mode (BASELINE configs[4]) -- one product per term on v_mfma_f32_32x32x16_f16: activations are
-// rounded to fp16 (nearest even) and occupy the "hi" half of a pixel's LDS slot, the weights come from mnc_pack_conv3x3_f16
-// (fp16 in the hi halves of the same packed layout, lo halves zero); only the hi fragments are read and one MFMA per tile and
-// K-step is issued instead of three.
+// F16 != 0: the "f16" math mode (BASELINE configs[4]) -- one product per term on v_mfma_f32_32x32x16_f16, activations and
+// weights rounded to fp16 (nearest even).  Its own K layout (round 2; the first version reused the split layout with the lo
+// halves empty and spent its time staging them -- 25 bytes/clk/CU of L2 -> LDS traffic for 20 % of the matrix pipe): a block
+// is SIXTEEN channels (two c8 planes), one MFMA K-step = 16 channels x ONE tap (lane half kb = channels 8 kb .. 8 kb + 7), nine
+// K-steps per block and no padding slot; a pixel's LDS slot holds its 16 channels (32 B + 16 B pad, the same 12-dword pitch),
+// a weight row 9 taps x 16 channels (mnc_pack_conv3x3_f16: [ceil(Cin/16)][Cout][76 dwords], missing channels zero).  Per
+// 16 channels a workgroup stages 30 KB instead of 54 KB and passes one barrier instead of two.
 //
 // Schedule (round 2; profiles/r02_pmc_stalls_convx3_conv3_2.txt showed 55 % issue stalls with every K-step's fragment reads
 // placed right in front of its MFMAs): the fragments of K-step s+1 are read during the MFMAs of K-step s (two fragment sets),
@@ -86,14 +98,18 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   constexpr int NT = 64 * ROWS;
   constexpr int R = ROWS * PR;                               // pixel rows per workgroup
   constexpr int kHaloPix = (R + 2) * kX3HaloCols;
-  constexpr int kIpp = (kInPk && F16) ? 1 : 2;               // 16-byte items per pixel and channel block in HBM
+  constexpr int KS = F16 ? 9 : 5;                            // MFMA K-steps per block
+  constexpr int kWPitch = F16 ? kF16WPitch : kX3WPitch;
+  // staging items per halo pixel (16 bytes of HBM each): bf16x3: two -- fp32: channels 0-3 / 4-7, packed: hi x8 / lo x8;
+  // f16: fp32 input: four (plane h = 0 / 1 of the block, channels 0-3 / 4-7), packed: two (plane h)
+  constexpr int kIpp = (F16 && !kInPk) ? 4 : 2;
   constexpr int kHaloItems = kHaloPix * kIpp;
   constexpr int kHPer = (kHaloItems + NT - 1) / NT;
   constexpr int NCO = 32 * CT;
-  constexpr int kWVec = NCO * (kX3WPitch / 4);               // uint4 items per weight panel
+  constexpr int kWVec = NCO * (kWPitch / 4);                 // uint4 items per weight panel
   constexpr int kWPer = (kWVec + NT - 1) / NT;
   constexpr int kHaloDw = kHaloPix * kX3PixPitch;
-  constexpr int kWDw = NCO * kX3WPitch;
+  constexpr int kWDw = NCO * kWPitch;
   extern __shared__ __attribute__((aligned(16))) unsigned s_mem[];   // halo[2] then weights[2]
   unsigned* const s_halo = s_mem;
   unsigned* const s_w = s_mem + 2 * kHaloDw;
@@ -116,28 +132,44 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   }
   const int tx = tile % nx, tyz = tile / nx;
   const int w0 = tx * kX3Cols, h0 = (tyz % ny) * R, co0 = (tyz / ny) * NCO;
-  const int nchunks = (Cin >> 3) / ksplit;
+  const int nplanes = Cin >> 3;                              // c8 planes of the input
+  const int nchunks = (F16 ? (nplanes + 1) >> 1 : nplanes) / ksplit;
   const int chunk0 = split * nchunks;
 
   // ---- staging assignment (fixed per thread): every thread always loads and stores; surplus threads repeat the last item
   int h_dst[kHPer];
-  unsigned h_src[kHPer];                                     // byte offset inside one channel block's plane (< 2^32)
+  unsigned h_src[kHPer];                                     // byte offset from the block's first plane (< 2^32)
   unsigned h_keep[kHPer];
+  unsigned h_second[kHPer];                                  // f16: all ones for items of the block's second plane
+  const unsigned plane_bytes = (unsigned)H * W * ((F16 && kInPk) ? 16 : 32);
 #pragma unroll
   for (int u = 0; u < kHPer; ++u) {
     const int q = min(tid + u * NT, kHaloItems - 1);
-    const int pix = q / kIpp, half = q - pix * kIpp;
+    const int pix = q / kIpp, sub = q - pix * kIpp;
     const int r = pix / kX3HaloCols, c = pix - r * kX3HaloCols;
     const int gh = h0 - 1 + r, gw = w0 - 1 + c;
     const bool inside = gh >= 0 && gh < H && gw >= 0 && gw < W;
-    h_dst[u] = pix * kX3PixPitch + half * (kInPk ? 4 : 2);
-    h_src[u] = (unsigned)(((min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1)) * kIpp + half) * 16);
+    const unsigned gp = (unsigned)(min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1));
+    if (!F16) {                      // sub: fp32 -> channels 4 sub .. +3 (hi at +2 sub, lo at +4 + 2 sub); packed -> hi / lo
+      h_dst[u] = pix * kX3PixPitch + sub * (kInPk ? 4 : 2);
+      h_src[u] = (gp * 2 + sub) * 16;
+      h_second[u] = 0u;
+    } else if (kInPk) {              // sub = plane
+      h_dst[u] = pix * kX3PixPitch + sub * 4;
+      h_src[u] = gp * 16;
+      h_second[u] = sub ? 0xFFFFFFFFu : 0u;
+    } else {                         // sub = plane * 2 + channel half
+      h_dst[u] = pix * kX3PixPitch + sub * 2;
+      h_src[u] = (gp * 2 + (sub & 1)) * 16;
+      h_second[u] = (sub >> 1) ? 0xFFFFFFFFu : 0u;
+    }
     h_keep[u] = inside ? 0xFFFFFFFFu : 0u;
   }
   int w_idx[kWPer];
 #pragma unroll
   for (int u = 0; u < kWPer; ++u) w_idx[u] = min(tid + u * NT, kWVec - 1);
-  const long plane = (long)H * W * kIpp * 16;                // bytes; the block's base is wave-uniform, offsets are 32-bit
+  // bytes of one block in HBM; the block's base is wave-uniform, per-thread offsets are 32-bit
+  const long plane = (long)plane_bytes * (F16 ? 2 : 1);
 
   // (initialised: hipcc keeps arrays that a lambda writes first as allocas -> scratch otherwise)
   struct Regs {
@@ -150,21 +182,27 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   for (int u = 0; u < kHPer; ++u) G.h[u] = G1.h[u] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int u = 0; u < kWPer; ++u) G.w[u] = G1.w[u] = make_uint4(0, 0, 0, 0);
+  // f16, odd number of c8 planes: the last block has no second plane -- its items read the first plane again (any valid
+  // address) and are stored as zeros
+  auto second_missing = [&](int c) { return F16 && 2 * (chunk0 + min(c, nchunks - 1)) + 1 >= nplanes; };
   auto load_chunk = [&](int c, Regs& G) {
+    const unsigned sec = second_missing(c) ? 0u : plane_bytes;
     c = chunk0 + min(c, nchunks - 1);
     const char* src = reinterpret_cast<const char*>(in) + (long)c * plane;
 #pragma unroll
-    for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const uint4*>(src + h_src[u]);
-    const char* wsrc = reinterpret_cast<const char*>(wpk + ((long)c * Cout + co0) * (kX3WPitch / 4));
+    for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const uint4*>(src + (h_src[u] + (h_second[u] & sec)));
+    const char* wsrc = reinterpret_cast<const char*>(wpk + ((long)c * Cout + co0) * (kWPitch / 4));
 #pragma unroll
     for (int u = 0; u < kWPer; ++u) G.w[u] = *reinterpret_cast<const uint4*>(wsrc + (unsigned)(w_idx[u] * 16));
   };
   // live == false: a phantom block behind an odd block count -- its halo is stored as zeros, so it multiplies to nothing
-  auto store_halo = [&](int buf, const Regs& G, bool live) {
+  auto store_halo = [&](int buf, const Regs& G, int c) {      // c: the block held by G
     unsigned* hdst = s_halo + buf * kHaloDw;
+    const bool live = c < nchunks;
+    const unsigned nosec = second_missing(c) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int u = 0; u < kHPer; ++u) {
-      const unsigned keep = live ? h_keep[u] : 0u;
+      const unsigned keep = live ? (h_keep[u] & ~(h_second[u] & nosec)) : 0u;
       uint4 v = G.h[u];
       if (kInPk) {
         v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
@@ -202,14 +240,16 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
 
-  // per-lane fragment addresses: K-step s reads tap 2s + kb (slot 9 = zero weights; its pixel read repeats tap 8)
+  // per-lane fragment addresses.  bf16x3: K-step s reads tap 2s + kb (slot 9 = zero weights; its pixel read repeats tap 8),
+  // hi then lo 16 bytes.  f16: K-step s = tap s, lane half kb = channels 8 kb .. of the block's 16.
   int p_off[5];
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
     const int tap = min(2 * s + kb, 8);
     p_off[s] = ((wave * PR + tap / 3) * kX3HaloCols + j + tap % 3) * kX3PixPitch;
   }
-  const int w_base = j * kX3WPitch + kb * 8;                 // + t*32*84 + s*16 (+4 for lo)
+  const int p_f16 = ((wave * PR) * kX3HaloCols + j) * kX3PixPitch + kb * 4;   // + ((tap / 3) * 34 + tap % 3) * 12
+  const int w_base = j * kWPitch + kb * (F16 ? 4 : 8);       // + t * 32 * pitch + s * (F16 ? 8 : 16) (+ 4 for lo)
 
   struct Frags { uint4 bh[PR], bl[PR], ah[CT], al[CT]; };   // f16: bl / al unused
   auto read_frags = [&](int buf, int s, Frags& f) {
@@ -223,15 +263,16 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
     }
     const unsigned* sh = s_halo + buf * kHaloDw;
     const unsigned* sw = s_w + buf * kWDw;
+    const int po = F16 ? p_f16 + ((s / 3) * kX3HaloCols + s % 3) * kX3PixPitch : p_off[F16 ? 0 : s];
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
-      const unsigned* p = sh + p_off[s] + r * kX3HaloCols * kX3PixPitch;
+      const unsigned* p = sh + po + r * kX3HaloCols * kX3PixPitch;
       f.bh[r] = *reinterpret_cast<const uint4*>(p);
       if (!F16) f.bl[r] = *reinterpret_cast<const uint4*>(p + 4);
     }
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-      const unsigned* p = sw + w_base + t * 32 * kX3WPitch + s * 16;
+      const unsigned* p = sw + w_base + t * 32 * kWPitch + s * (F16 ? 8 : 16);
       f.ah[t] = *reinterpret_cast<const uint4*>(p);
       if (!F16) f.al[t] = *reinterpret_cast<const uint4*>(p + 4);
     }
@@ -274,34 +315,25 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   constexpr int kNR = (F16 ? 1 : 2) * (PR + CT);
   constexpr int kNWH = kHPer * ((kInPk || F16) ? 1 : 2);
   constexpr int kS = kNM >= 2 ? kNM / 2 : 1;
-  // block c sits in LDS[buf]; f[P] holds its K-step-0 fragments; on return f[P ^ 1] holds those of block c + 1
+  // block c sits in LDS[buf]; f[P] holds its K-step-0 fragments; on return f[P ^ 1] holds those of block c + 1 (KS is odd).
+  // K-step 0: global loads of block c + 1;  KS - 3: halo stores;  KS - 2: weight stores, then the barrier;  KS - 1: first
+  // fragments of block c + 1.
   Frags f[2] = {};
   auto step = [&](int c, int buf, auto parity) {
     constexpr int P = decltype(parity)::value;
-    read_frags(buf, 1, f[P ^ 1]);
-    if (!(MNC_X3_ABL & 1)) load_chunk(c + 1, G);
-    mfmas(f[P]);
-    X3Pin<0, kS, kNM, kNR, 0, kHPer + kWPer>::run();
-    pin_acc();
-    read_frags(buf, 2, f[P]);
-    mfmas(f[P ^ 1]);
-    X3Pin<0, kS, kNM, kNR, 0, 0>::run();
-    pin_acc();
-    read_frags(buf, 3, f[P ^ 1]);
-    if (!(MNC_X3_ABL & 2)) store_halo(buf ^ 1, G, c + 1 < nchunks);
-    mfmas(f[P]);
-    X3Pin<0, kS, kNM, kNR, kNWH, 0>::run();
-    pin_acc();
-    read_frags(buf, 4, f[P]);
-    if (!(MNC_X3_ABL & 2)) store_weights(buf ^ 1, G);
-    mfmas(f[P ^ 1]);
-    X3Pin<0, kS, kNM, kNR, kWPer, 0>::run();
-    pin_acc();
-    __syncthreads();
-    read_frags(buf ^ 1, 0, f[P ^ 1]);                // K-step 0 of the next block (of the zero-filled phantom at the end)
-    mfmas(f[P]);
-    X3Pin<0, kS, kNM, kNR, 0, 0>::run();
-    pin_acc();
+    x3_static_for<0, KS>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      constexpr int cur = (P + ks) & 1;
+      if (ks < KS - 1) read_frags(buf, ks + 1, f[cur ^ 1]);
+      else read_frags(buf ^ 1, 0, f[cur ^ 1]);           // K-step 0 of the next block (of the zero-filled phantom at the end)
+      if (ks == 0 && !(MNC_X3_ABL & 1)) load_chunk(c + 1, G);
+      if (ks == KS - 3 && !(MNC_X3_ABL & 2)) store_halo(buf ^ 1, G, c + 1);
+      if (ks == KS - 2 && !(MNC_X3_ABL & 2)) store_weights(buf ^ 1, G);
+      mfmas(f[cur]);
+      X3Pin<0, kS, kNM, kNR, ks == KS - 3 ? kNWH : (ks == KS - 2 ? kWPer : 0), ks == 0 ? kHPer + kWPer : 0>::run();
+      pin_acc();
+      if (ks == KS - 2) __syncthreads();
+    });
   };
   // Small register tiles (1 or 2 MFMAs per K-step and fragment set; 5-6 waves per SIMD): two K-steps of MFMAs do not cover
   // a global load, so the round-1 loop is kept -- two register sets (the loads for block c+2 are issued while block c is
@@ -310,17 +342,17 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   auto step_simple = [&](int c, int buf, Regs& cur, Regs& nxt) {
     load_chunk(c + 2, nxt);
 #pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       read_frags(buf, ks, f[0]);
       mfmas(f[0]);
     }
-    store_halo(buf ^ 1, cur, c + 1 < nchunks);
+    store_halo(buf ^ 1, cur, c + 1);
     store_weights(buf ^ 1, cur);
     __syncthreads();
   };
 
   load_chunk(0, G);
-  store_halo(0, G, true);
+  store_halo(0, G, 0);
   store_weights(0, G);
   if (kPipe) {
     __syncthreads();
@@ -428,6 +460,27 @@ __global__ void pack_conv_x3_kernel(const float* __restrict__ w, uint4* __restri
   }
 }
 
+// f16 layout: OIHW fp32 -> [ceil(Cin/16)][Cout][19 uint4]: tap t < 9: uint4 2t, 2t+1 = the 16 channels of the block rounded to
+// fp16 (channels past Cin: zero); uint4 18: pad
+__global__ void pack_conv_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin) {
+  const int nblk = (Cin + 15) / 16;
+  const long total = (long)nblk * Cout * 19;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int slot = (int)(i % 19);
+    const long row = i / 19;
+    const int co = (int)(row % Cout), blk = (int)(row / Cout);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (slot < 18) {
+      const int tap = slot >> 1, c0 = blk * 16 + (slot & 1) * 8;
+      f16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = c0 + e < Cin ? (_Float16)w[((long)co * Cin + c0 + e) * 9 + tap] : (_Float16)0.f;
+      v = __builtin_bit_cast(uint4, h);
+    }
+    out[row * 19 + slot] = v;
+  }
+}
+
 static int x3_grid_for(long total) {
   const long g = (total + 255) / 256;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -472,7 +525,7 @@ template <int CT, int PR, int ROWS, int F16, int FMT>
 static int launch_x3(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out, int H, int W,
                      int Cin, int Cout, int relu, int force_ks) {
   constexpr int R = ROWS * PR, NCO = 32 * CT;
-  constexpr size_t lds = 2 * 4 * ((size_t)(R + 2) * kX3HaloCols * kX3PixPitch + (size_t)32 * CT * kX3WPitch);
+  constexpr size_t lds = 2 * 4 * ((size_t)(R + 2) * kX3HaloCols * kX3PixPitch + (size_t)32 * CT * (F16 ? kF16WPitch : kX3WPitch));
   static_assert(lds <= 160 * 1024, "conv3x3_x3: LDS budget");
   auto kern = conv3x3_x3_kernel<CT, PR, ROWS, F16, FMT>;
   static std::atomic<unsigned long long> attr_set{0};          // one bit per device: function attributes are per device
@@ -488,7 +541,7 @@ static int launch_x3(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
   }
   const int cap = resident.load(std::memory_order_relaxed);
   const int ntiles = cdiv(W, kX3Cols) * cdiv(H, R) * (Cout / NCO);
-  const int blocks = Cin / 8;
+  const int blocks = F16 ? (Cin / 8 + 1) / 2 : Cin / 8;        // K blocks: 16 channels in the f16 layout, 8 otherwise
   auto best_ks = [&](int limit) {                              // largest of 4, 2 that divides the K blocks and leaves >= 4 per range
     for (int k = 4; k >= 2; k >>= 1)
       if (k <= limit && blocks % k == 0 && blocks / k >= 4) return k;
@@ -607,8 +660,13 @@ using namespace mnc;
 static int pack_conv_lowp(mnc_ctx* ctx, const char* name, const float* d_oihw, void* d_packed, int Cout, int Cin, int f16) {
   MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0, "%s: bad argument", name);
   LaunchScope ls(ctx, name);
+  if (f16) {
+    hipLaunchKernelGGL(pack_conv_f16_kernel, dim3(x3_grid_for((long)((Cin + 15) / 16) * Cout * 19)), dim3(256), 0, ctx->stream, d_oihw,
+                       (uint4*)d_packed, Cout, Cin);
+    return ls.finish("pack_conv_f16_kernel");
+  }
   hipLaunchKernelGGL(pack_conv_x3_kernel, dim3(x3_grid_for((long)(Cin / 8) * Cout * 11)), dim3(256), 0, ctx->stream, d_oihw,
-                     (uint4*)d_packed, Cout, Cin, f16);
+                     (uint4*)d_packed, Cout, Cin, 0);
   return ls.finish("pack_conv_x3_kernel");
 }
 
