@@ -25,7 +25,9 @@ measures BASELINE configs[2] ("bf16 convs via MFMA": bf16x3) and the f16 mode an
 step and the same JSON schema.
 
 One JSON line is printed by rank 0.  `roofline` is computed from HIP events recorded by the engine on ITS stream around
-every launch of the dominant kernel inside the timed region; `cpu_baseline` times the CPU oracle (torch-CPU restatement
+every launch of the dominant kernel on every --event-every-th step of the timed region (an event pair costs the stream
+about 3 us per bracketed launch -- 0.17 ms per image with all 30 MFMA launches bracketed -- and cannot be captured into
+the HIP graph the library replays by default, so the event steps run as direct launches and the others replay the graph); `cpu_baseline` times the CPU oracle (torch-CPU restatement
 of the graph + the reference's nms/mv code compiled for the CPU when oracle/_ref is present) on the same workload.
 """
 import argparse
@@ -70,6 +72,9 @@ def parse():
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
+    p.add_argument("--event-every", type=int, default=4,
+                   help="native engine: record the per-kernel HIP events on every N-th timed step (those steps run as direct "
+                        "launches, the others replay the captured HIP graph -- the library's default path)")
     p.add_argument("--math", default=os.environ.get("MNC_MATH"), choices=["fp32", "bf16x3", "f16"],
                    help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
@@ -163,8 +168,9 @@ def main():
         native = engine == "native"
         if native:
             from mnc_amd.native_net import NativeNet
-            # direct launches while HIP events are recorded (the timed region); HIP-graph replay is measured separately below
-            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=False)
+            # the library's default path: the image size's HIP graph is captured on its second image and replayed from then on;
+            # a step with per-kernel HIP events runs as direct launches (events are not captured), see --event-every
+            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=True)
         else:
             net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
         gatherer = mdist.InstanceGatherer(net=net, rank=rank, world=world) if (launched and on_gpu) else \
@@ -216,12 +222,18 @@ def main():
             step(k)
         events = not args.no_events
         fence()
+        level = 1 if args.all_events else 2
+        every = max(1, args.event_every) if native else 1
         if events:
-            net.profile(1 if args.all_events else 2)
+            net.profile(level)                       # (resets the record list)
         for k in phase:
             phase[k] = 0.0
+        event_steps = 0
         t0 = time.perf_counter()
         for k in range(steps):
+            if events and every > 1:
+                net.profile_enable(level if k % every == 0 else 0)
+            event_steps += int(events and k % every == 0)
             step(warmup + k)
         fence()
         elapsed = time.perf_counter() - t0
@@ -229,12 +241,12 @@ def main():
         if events:
             net.profile(False)
         out = {"elapsed": elapsed, "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()}, "records": records,
-               "rccl_version": getattr(gatherer, "rccl_version", None)}
+               "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None)}
         out["feats"] = {n: (net.blob(n) if native else net.blobs[n]._host_read().copy())
                         for n in ("rpn_bbox_pred", "rpn_cls_prob_reshape")}
         if native and not launched:
-            # the same step replaying the captured HIP graph of this image size (no per-kernel events inside a graph): one
-            # hipGraphLaunch + one synchronisation per image
+            # the same step with every image on the captured HIP graph (no event steps): one hipGraphLaunch + one
+            # synchronisation per image
             from mnc_amd.native_net import NativeNet
             net.close()
             net = NativeNet(weights, device_id=dev_id, math=math, use_graph=True)
@@ -292,6 +304,8 @@ def main():
     def summarise(steps, m):
         out = {"host_phase_ms_per_image": {k: round(v, 3) for k, v in m["phase_ms"].items()}}
         records = m["records"]
+        steps = m.get("event_steps") or steps        # the steps whose launches carry events
+        out["event_steps"] = steps if records else 0
         if records:
             agg = {}
             for name, kms, fl, by in records:
@@ -351,12 +365,14 @@ def main():
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
         }
         out.update(summarise(args.steps, m))
-        out["config"]["engine"] = ("native: one mnc_forward_image call per image (csrc/pipeline.hip), direct kernel launches"
+        out["config"]["engine"] = (("native: one mnc_forward_image call per image (csrc/pipeline.hip); the image size's captured HIP "
+                                    "graph is replayed, every %d%s timed step runs as direct launches with HIP events around the MFMA "
+                                    "kernels" % (max(1, args.event_every), {1: "st", 2: "nd", 3: "rd"}.get(max(1, args.event_every), "th")))
                                    if args.engine == "native" else "python: mnc_amd.engine.Net layer by layer (tools/demo.py body)")
         if "graph_s" in m:
             out["graph_replay"] = {"value": 1.0 / m["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m["graph_s"],
-                                   "protocol": "same step, the image size's captured HIP graph replayed (one hipGraphLaunch + one "
-                                               "synchronisation per image; no per-kernel events)"}
+                                   "protocol": "same step, every image on the captured HIP graph (one hipGraphLaunch + one "
+                                               "synchronisation per image; no event steps)"}
         if args.engine == "native" and world == 1 and not launched and not args.no_resident:
             mp = measure(math, min(args.steps, 100), args.warmup, resident_steps=50, engine="python")
             out["python_engine"] = {"value": min(args.steps, 100) / mp["elapsed"], "unit": "images/s",

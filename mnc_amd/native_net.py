@@ -143,6 +143,11 @@ class NativeNet(object):
         _lib.call("mnc_prof_enable", self._ctx.h, int(enable))
         _lib.call("mnc_prof_reset", self._ctx.h)
 
+    def profile_enable(self, level):
+        """Switch event recording on (1 every launch, 2 MFMA launches) / off without touching the records collected so far
+        (no synchronisation; profile() starts a fresh list, profile_records() drains it)."""
+        _lib.call("mnc_prof_enable", self._ctx.h, int(level))
+
     def profile_records(self):
         n = ctypes.c_int(0)
         _lib.call("mnc_prof_count", self._ctx.h, ctypes.addressof(n))
