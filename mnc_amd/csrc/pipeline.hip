@@ -64,6 +64,12 @@ void linear_taps(int n_dst, int n_src, double scale, int* lo, float* frac) {
 
 struct mnc_net {
   mnc_ctx* ctx = nullptr;
+  // Second context (own stream, own scratch arena) for the box-feature branch of a head stage, which does not depend on the
+  // mask branch until the Concat: fc6 / fc7 run beside fc6_maskest .. fc7_mask, so each branch's small kernels (K-split
+  // reductions, pools, mask resampling) and launch gaps sit under the other's GEMMs.  Not used while per-kernel events are
+  // recorded (durations are measured without overlap).  MNC_BRANCH_STREAMS=0 disables it.
+  mnc_ctx* ctx_b = nullptr;
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
   mnc_net_config cfg;
   std::map<std::string, HostBlob> params;      // "<layer>/<index>" as given by the caller (Caffe layout)
   bool finalized = false;
@@ -176,11 +182,14 @@ int prepare_fc(mnc_net* n, const char* layer, int N, int K, int C, int PH, int P
   return MNC_OK;
 }
 
-int run_fc(mnc_net* n, const mnc_net::Fc& fc, const float* a, float* out, int M, int ldc, int act) {
+int run_fc(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, float* out, int M, int ldc, int act) {
   if (M == 0) return MNC_OK;
-  if (fc.kind == 2) return mnc_fc_f16(n->ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
-  if (fc.kind == 1) return mnc_fc_bf16x3(n->ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
-  return mnc_fc(n->ctx, a, (const float*)fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  if (fc.kind == 2) return mnc_fc_f16(ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  if (fc.kind == 1) return mnc_fc_bf16x3(ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  return mnc_fc(ctx, a, (const float*)fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+}
+int run_fc(mnc_net* n, const mnc_net::Fc& fc, const float* a, float* out, int M, int ldc, int act) {
+  return run_fc(n->ctx, fc, a, out, M, ldc, act);
 }
 
 int finalize(mnc_net* n) {
@@ -432,13 +441,23 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   NET_TRY(run_fc(n, n->fc_maskest, feat14, (float*)n->h_mask.p, R, c.mask_fc, 1));
   NET_TRY(run_fc(n, n->fc_maskpred, (const float*)n->h_mask.p, masks, R, S * S, 2));            // + Sigmoid; MaskLayer = reshape
   NET_TRY(mnc_mask_resize(ctx, masks, (float*)n->m14.p, R, S, S, P, P));
-  NET_TRY(mnc_maxpool2_rhwc(ctx, feat14, (float*)n->box7.p, R, P, P, C5));
   float* join = (float*)n->join.p;                                                             // Concat(fc7_mask, fc7): column slices
-  NET_TRY(run_fc(n, n->fc6, (const float*)n->box7.p, (float*)n->f6.p, R, F, 1));
-  NET_TRY(run_fc(n, n->fc7, (const float*)n->f6.p, join + F, R, 2 * F, 1));
+  // box-feature branch (test.prototxt:604-652): on the second stream when it is available, otherwise in line
+  const bool fork = n->ctx_b && ctx->profiling == 0 && R > 0;
+  mnc_ctx* cb = fork ? n->ctx_b : ctx;
+  const int si = second ? 1 : 0;
+  if (fork) {
+    MNC_HIP_TRY(hipEventRecord(n->ev_fork[si], ctx->stream));                                   // feat14 is complete
+    MNC_HIP_TRY(hipStreamWaitEvent(cb->stream, n->ev_fork[si], 0));
+  }
+  NET_TRY(mnc_maxpool2_rhwc(cb, feat14, (float*)n->box7.p, R, P, P, C5));
+  NET_TRY(run_fc(cb, n->fc6, (const float*)n->box7.p, (float*)n->f6.p, R, F, 1));
+  NET_TRY(run_fc(cb, n->fc7, (const float*)n->f6.p, join + F, R, 2 * F, 1));
+  if (fork) MNC_HIP_TRY(hipEventRecord(n->ev_join[si], cb->stream));
   NET_TRY(mnc_mask_pool(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1));
   NET_TRY(run_fc(n, n->fc6m, (const float*)n->mask7.p, (float*)n->f6m.p, R, F, 1));
   NET_TRY(run_fc(n, n->fc7m, (const float*)n->f6m.p, join, R, 2 * F, 1));
+  if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));
   float* heads = (float*)n->heads.p;
   NET_TRY(run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0));
   float* scores = (float*)n->scores.p + (size_t)row0 * K;
@@ -576,6 +595,16 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
   n->ctx = ctx;
   n->cfg = *cfg;
+  if (!(getenv("MNC_BRANCH_STREAMS") && atoi(getenv("MNC_BRANCH_STREAMS")) == 0)) {
+    if (mnc_ctx_create(&n->ctx_b, ctx->device) != MNC_OK) n->ctx_b = nullptr;     // optional: the net works on one stream
+    for (int i = 0; i < 2 && n->ctx_b; ++i) {
+      if (hipEventCreateWithFlags(&n->ev_fork[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&n->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+        (void)mnc_ctx_destroy(n->ctx_b);
+        n->ctx_b = nullptr;
+      }
+    }
+  }
   *out = n;
   clear_error();
   return MNC_OK;
@@ -723,6 +752,11 @@ int mnc_net_destroy(mnc_net* net) {
   }
   if (net->pin_img) (void)hipHostFree(net->pin_img);
   if (net->pin_out) (void)hipHostFree(net->pin_out);
+  for (int i = 0; i < 2; ++i) {
+    if (net->ev_fork[i]) (void)hipEventDestroy(net->ev_fork[i]);
+    if (net->ev_join[i]) (void)hipEventDestroy(net->ev_join[i]);
+  }
+  if (net->ctx_b) (void)mnc_ctx_destroy(net->ctx_b);
   delete net;
   clear_error();
   return MNC_OK;
