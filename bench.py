@@ -72,6 +72,7 @@ def parse():
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
+    p.add_argument("--no-graph", action="store_true", help="native engine: direct launches on every step (counter-profiling runs)")
     p.add_argument("--event-every", type=int, default=4,
                    help="native engine: record the per-kernel HIP events on every N-th timed step (those steps run as direct "
                         "launches, the others replay the captured HIP graph -- the library's default path)")
@@ -170,7 +171,7 @@ def main():
             from mnc_amd.native_net import NativeNet
             # the library's default path: the image size's HIP graph is captured on its second image and replayed from then on;
             # a step with per-kernel HIP events runs as direct launches (events are not captured), see --event-every
-            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=True)
+            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph)
         else:
             net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
         gatherer = mdist.InstanceGatherer(net=net, rank=rank, world=world) if (launched and on_gpu) else \

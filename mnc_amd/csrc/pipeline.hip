@@ -67,7 +67,9 @@ struct mnc_net {
   // Second context (own stream, own scratch arena) for the box-feature branch of a head stage, which does not depend on the
   // mask branch until the Concat: fc6 / fc7 run beside fc6_maskest .. fc7_mask, so each branch's small kernels (K-split
   // reductions, pools, mask resampling) and launch gaps sit under the other's GEMMs.  Not used while per-kernel events are
-  // recorded (durations are measured without overlap).  MNC_BRANCH_STREAMS=0 disables it.
+  // recorded.  Opt-in (MNC_BRANCH_STREAMS=1): measured +1 % for one image at a time (170.9 vs 169.3 images/s; two GEMMs that
+  // each fill the chip gain nothing from sharing it) and -12 % with two images in flight (four streams: 172 vs 195), and the
+  // overlap makes a kernel trace of the run disagree with the event-step durations.
   mnc_ctx* ctx_b = nullptr;
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
   mnc_net_config cfg;
@@ -595,7 +597,7 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
   n->ctx = ctx;
   n->cfg = *cfg;
-  if (!(getenv("MNC_BRANCH_STREAMS") && atoi(getenv("MNC_BRANCH_STREAMS")) == 0)) {
+  if (getenv("MNC_BRANCH_STREAMS") && atoi(getenv("MNC_BRANCH_STREAMS")) == 1) {
     if (mnc_ctx_create(&n->ctx_b, ctx->device) != MNC_OK) n->ctx_b = nullptr;     // optional: the net works on one stream
     for (int i = 0; i < 2 && n->ctx_b; ++i) {
       if (hipEventCreateWithFlags(&n->ev_fork[i], hipEventDisableTiming) != hipSuccess ||

@@ -10,9 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events --no-resident $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $BENCH > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $BENCH > $OUT/pmc_write.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT -d $OUT/pmc_mfma -o bench -- $BENCH > $OUT/pmc_mfma.log 2>&1
+PMCB="$BENCH --no-graph"      # counter passes: direct launches (same kernels, same order; counters serialise the dispatches anyway)
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $PMCB > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $PMCB > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT -d $OUT/pmc_mfma -o bench -- $PMCB > $OUT/pmc_mfma.log 2>&1
 python $REPO/tools/rocpd_summary.py $OUT/trace/bench_results.db > $OUT/kernel_trace_stats.txt
 python $REPO/tools/pmc_report.py $OUT/pmc_mfma/bench_results.db $OUT/pmc_fetch/bench_results.db $OUT/pmc_write/bench_results.db --json $OUT/pmc.json > $OUT/pmc.txt
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
