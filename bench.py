@@ -416,8 +416,11 @@ def main():
         dist.destroy_process_group()
 
 
-PMC_KERNEL = {"conv3x3_c8_mfma": "conv3x3_c8_kernel", "fc_mfma": "fc_mfma_kernel<10>", "conv3x3_bf16x3": "conv3x3_x3_kernel",
-              "fc_bf16x3": "fc_x3_kernel"}
+# profiling scope of the engine -> the kernels (rocprofv3 names, regular expressions) launched inside it
+PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"conv3x3_wino2?_kernel",
+              "fc_mfma": r"fc_mfma_kernel<(10|5),", "fc_mfma_small": r"fc_mfma_kernel<2,",
+              "conv3x3_bf16x3": r"conv3x3_x3_kernel<\d+, \d+, \d+, 0,", "conv3x3_f16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 1,",
+              "fc_bf16x3": r"fc_x3_kernel<\d+, \d+, \d+, 0>", "fc_f16": r"fc_x3_kernel<\d+, \d+, \d+, 1>"}
 
 
 def pmc_traffic(scope_name):
@@ -431,10 +434,11 @@ def pmc_traffic(scope_name):
             data = json.load(f)
     except (OSError, ValueError):
         return None
-    want = PMC_KERNEL.get(scope_name, scope_name)
+    import re
+    want = re.compile(PMC_KERNEL.get(scope_name, re.escape(scope_name)))
     calls = tot = 0.0
     for k, v in data.items():
-        if k.startswith(want):
+        if want.match(k):
             calls += v["calls"]
             tot += v["calls"] * v["hbm_bytes_corrected"]
     return tot / calls if calls else None
