@@ -220,12 +220,32 @@ MNC_API int mnc_pack_conv_weights_f16(mnc_ctx* ctx, const float* d_oihw, void* d
 MNC_API int mnc_conv2d_f16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias,
                            const float* d_residual_c8, float* d_out_c8, int H, int W, int Cin, int Cout, int KH, int KW,
                            int stride, int pad, int relu);
+/* 1x1 convolution, stride 1 or 2, no padding, as a plain GEMM (csrc/conv1x1.hip): the c8 layout is already the MFMA B
+ * fragment order, so both operands go global -> registers -> matrix pipe with no LDS staging.  Same epilogue as mnc_conv2d
+ * (+ bias, + residual, ReLU).  Weights from mnc_pack_conv1x1: Caffe [Cout][Cin] fp32 -> A-fragment order
+ * [K-steps][ceil(Cout/32)][64 lanes] x 16 bytes (f16 != 0: halves, K-step 16, Cin%16==0; else fp32, K-step 8):
+ * Cin * ceil(Cout/32)*32 * (f16 ? 2 : 4) bytes.
+ * mnc_conv1x1: fp32 c8 in / residual / out on the fp32 matrix pipe.
+ * mnc_conv1x1_f16_pk ("f16" math mode): d_in is the packed fp16 c8 tensor ([C/8][H][W][8] halves, see "2-byte activation
+ * tensors" below); d_out packed fp16 (out_packed != 0; nearest-even rounding of the fp32 result) or fp32 c8; d_residual
+ * (may be NULL) packed fp16 (res_packed != 0) or fp32 c8; fp32 accumulate. */
+MNC_API int mnc_pack_conv1x1(mnc_ctx* ctx, const float* d_w, void* d_packed, int Cout, int Cin, int f16);
+MNC_API int mnc_conv1x1(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias,
+                        const float* d_residual_c8, float* d_out_c8, int H, int W, int Cin, int Cout, int stride, int relu);
+MNC_API int mnc_conv1x1_f16_pk(mnc_ctx* ctx, const void* d_in_pk, const void* d_w_packed, const float* d_bias,
+                               const void* d_residual, void* d_out, int H, int W, int Cin, int Cout, int stride, int relu,
+                               int res_packed, int out_packed);
 /* First convolution of a 3-channel NCHW input blob (ResNet conv1 7x7/2 pad 3): weights [Cout][3][K][K] as in Caffe,
- * + bias (+ ReLU) -> c8.  Cout%16==0. */
+ * + bias (+ ReLU) -> c8.  Cout%16==0.  mnc_conv_stem_c3_fmt: out_packed != 0 writes the packed fp16 c8 tensor instead. */
 MNC_API int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8,
                              int H, int W, int Cout, int K, int stride, int pad, int relu);
-/* Pooling MAX with any kernel / stride / pad on a c8 map; Caffe's ceil output size, windows clipped to the image. */
+MNC_API int mnc_conv_stem_c3_fmt(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, void* d_out,
+                                 int H, int W, int Cout, int K, int stride, int pad, int relu, int out_packed);
+/* Pooling MAX with any kernel / stride / pad on a c8 map; Caffe's ceil output size, windows clipped to the image.
+ * mnc_maxpool_c8_f16: the same on the packed fp16 c8 tensor (max commutes with the rounding: bit for bit the fp16 form of
+ * the fp32 result). */
 MNC_API int mnc_maxpool_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W, int K, int stride, int pad);
+MNC_API int mnc_maxpool_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W, int K, int stride, int pad);
 /* Eltwise SUM of two tensors of the same layout (+ ReLU): d_out[i] = d_a[i] + d_b[i]. */
 MNC_API int mnc_add(mnc_ctx* ctx, const float* d_a, const float* d_b, float* d_out, size_t n, int relu);
 /* prep_im_for_blob (lib/utils/blob.py:36-50) and one level of prep_im_for_blob_cfm (:53-85) on the device: a uint8 BGR image

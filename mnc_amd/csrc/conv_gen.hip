@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "mnc_internal.h"
+#include "x3_split.h"
 
 namespace mnc {
 
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256) void conv2d_c8_f16_kernel(const float* __restr
 
 // Stem: Cin = 3, NCHW input, weights [Cout][3][K][K] re-laid in LDS as [Cout/16][3*K*K][16].
 __global__ __launch_bounds__(256) void conv_stem_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                           const float* __restrict__ bias, void* __restrict__ out, int H,
                                                            int W, int Cout, int K, int stride, int pad, int OH, int OW,
-                                                           int relu) {
+                                                           int relu, int out_pk) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];
   const int taps = 3 * K * K, groups = Cout / 16;
   for (int i = threadIdx.x; i < Cout * taps; i += blockDim.x) {
@@ -355,16 +356,40 @@ __global__ __launch_bounds__(256) void conv_stem_c3_kernel(const float* __restri
       }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float* o = out + ((long)(g * 2 + h) * P + p) * 8;
       float4 v0 = make_float4(acc[h * 8 + 0], acc[h * 8 + 1], acc[h * 8 + 2], acc[h * 8 + 3]);
       float4 v1 = make_float4(acc[h * 8 + 4], acc[h * 8 + 5], acc[h * 8 + 6], acc[h * 8 + 7]);
       if (relu) {
         v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
         v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
       }
-      *reinterpret_cast<float4*>(o) = v0;
-      *reinterpret_cast<float4*>(o + 4) = v1;
+      const long pix = (long)(g * 2 + h) * P + p;
+      if (out_pk) x3_store8<1, true>(out, pix, v0, v1);         // packed fp16 c8 (nearest even): the f16 mode's activation tensor
+      else x3_store8<1, false>(out, pix, v0, v1);
     }
+  }
+}
+
+// MAX pooling on the packed fp16 c8 tensor: one thread per (channel block, output pixel), 16-byte loads and stores
+__global__ __launch_bounds__(256) void maxpool_c8_f16_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int CB, int H,
+                                                             int W, int K, int stride, int pad, int OH, int OW) {
+  const long total = (long)CB * OH * OW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long r = idx;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int cb = (int)(r / OH);
+    const int y0 = max(oy * stride - pad, 0), y1 = min(oy * stride - pad + K, H);
+    const int x0 = max(ox * stride - pad, 0), x1 = min(ox * stride - pad + K, W);
+    f16x8 m = {(_Float16)-65504.f, (_Float16)-65504.f, (_Float16)-65504.f, (_Float16)-65504.f,
+               (_Float16)-65504.f, (_Float16)-65504.f, (_Float16)-65504.f, (_Float16)-65504.f};
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x) {
+        const f16x8 v = __builtin_bit_cast(f16x8, in[((long)cb * H + y) * W + x]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    out[idx] = __builtin_bit_cast(uint4, m);
   }
 }
 
@@ -481,18 +506,33 @@ int mnc_conv2d_f16(mnc_ctx* ctx, const float* d_in, const void* d_w, const float
   return ls.finish("conv2d_c8_f16_kernel");
 }
 
-int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8, int H,
-                     int W, int Cout, int K, int stride, int pad, int relu) {
-  MNC_REQUIRE(ctx && d_in_nchw && d_w_oihw && d_bias && d_out_c8, "mnc_conv_stem_c3: null pointer");
+int mnc_conv_stem_c3_fmt(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, void* d_out, int H,
+                         int W, int Cout, int K, int stride, int pad, int relu, int out_packed) {
+  MNC_REQUIRE(ctx && d_in_nchw && d_w_oihw && d_bias && d_out, "mnc_conv_stem_c3: null pointer");
   MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 16 == 0 && K > 0 && stride > 0 && pad >= 0 && H + 2 * pad >= K &&
                   W + 2 * pad >= K && (size_t)Cout * 3 * K * K * 4 <= 64 * 1024,
               "mnc_conv_stem_c3: bad shape (Cout multiple of 16, weights <= 64 KB)");
   const int OH = conv_out(H, K, stride, pad), OW = conv_out(W, K, stride, pad);
   const long P = (long)OH * OW;
-  LaunchScope ls(ctx, "conv_stem_c3", 2.0 * P * Cout * 3.0 * K * K, 4.0 * (3.0 * H * W + (double)P * Cout));
+  LaunchScope ls(ctx, "conv_stem_c3", 2.0 * P * Cout * 3.0 * K * K, 4.0 * 3.0 * H * W + (out_packed ? 2.0 : 4.0) * (double)P * Cout);
   hipLaunchKernelGGL(conv_stem_c3_kernel, dim3((unsigned)cdiv(P, 256)), dim3(256), (size_t)Cout * 3 * K * K * 4, ctx->stream,
-                     d_in_nchw, d_w_oihw, d_bias, d_out_c8, H, W, Cout, K, stride, pad, OH, OW, relu);
+                     d_in_nchw, d_w_oihw, d_bias, d_out, H, W, Cout, K, stride, pad, OH, OW, relu, out_packed ? 1 : 0);
   return ls.finish("conv_stem_c3_kernel");
+}
+
+int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, float* d_out_c8, int H,
+                     int W, int Cout, int K, int stride, int pad, int relu) {
+  return mnc_conv_stem_c3_fmt(ctx, d_in_nchw, d_w_oihw, d_bias, d_out_c8, H, W, Cout, K, stride, pad, relu, 0);
+}
+
+int mnc_maxpool_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W, int K, int stride, int pad) {
+  MNC_REQUIRE(ctx && d_in && d_out && C > 0 && C % 8 == 0 && H > 0 && W > 0 && K > 0 && stride > 0 && pad >= 0 && pad < K,
+              "mnc_maxpool_c8_f16: bad argument");
+  const int OH = pool_out(H, K, stride, pad), OW = pool_out(W, K, stride, pad);
+  LaunchScope ls(ctx, "maxpool_c8_f16", 0.0, 2.0 * C * ((double)H * W + (double)OH * OW));
+  hipLaunchKernelGGL(maxpool_c8_f16_kernel, dim3(grid1d((long)(C / 8) * OH * OW)), dim3(256), 0, ctx->stream, (const uint4*)d_in,
+                     (uint4*)d_out, C / 8, H, W, K, stride, pad, OH, OW);
+  return ls.finish("maxpool_c8_f16_kernel");
 }
 
 int mnc_maxpool_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W, int K, int stride, int pad) {

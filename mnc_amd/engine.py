@@ -89,6 +89,8 @@ class Blob(object):
     """A named tensor with Caffe's logical shape.  Device storage uses one of the engine layouts:
          'plain' row-major in Caffe order (optionally a column slice of a wider matrix: ld > shape[1])
          'c8'    [N][C/8][H][W][8]   for shape (N, C, H, W): N whole images back to back (N > 1 only in the CFM pyramid)
+         'c8h'   the same order in IEEE fp16 (the "f16" math mode's 2-byte activation tensors between trunk layers; the buffer
+                 keeps its fp32 size, so the blob can be widened to 'c8' in place when a consumer or `.data` wants fp32)
          'rhwc'  [R][PH][PW][C]      for shape (R, C, PH, PW)
     Exactly one of (host, device) may be stale; `.data` makes the host copy current and hands it out."""
 
@@ -201,6 +203,21 @@ class Blob(object):
         tmp = net._tmp.ensure(self.count * 4)
         h = net._ctx.h
         src = self.dev_ptr()
+        if self.layout == "c8h" or layout == "c8h":
+            # fp16 <-> fp32 in the c8 order is elementwise (batch and all); any other pairing goes through 'c8'
+            if self.layout == "c8h":
+                _lib.call("mnc_act_unpack", h, src, tmp, self.count, 1)
+                _lib.call("mnc_d2d", h, src, tmp, self.count * 4)
+                self.layout = "c8"
+                if layout != "c8":
+                    self._convert(layout)
+                return
+            if self.layout != "c8":
+                self._convert("c8")
+            _lib.call("mnc_act_pack", h, src, tmp, self.count, 1)
+            _lib.call("mnc_d2d", h, src, tmp, self.count * 2)
+            self.layout = "c8h"
+            return
         if self.layout == "plain" and layout == "c8":
             N, C, H, W = self.shape
             for n in range(N):
@@ -232,6 +249,8 @@ class Blob(object):
             _lib.call("mnc_copy2d", h, tmp, cols, self.dev_ptr(), self._ld(), rows, cols)
             _lib.call("mnc_d2h", h, _lib.ptr(self._host), tmp, n * 4)
             return
+        if self.layout == "c8h":
+            self._convert("c8")          # widened in place: the values are unchanged, a later fp16 consumer re-packs them exactly
         if self.layout == "plain":
             _lib.call("mnc_d2h", h, _lib.ptr(self._host), self.dev_ptr(), n * 4)
             return
@@ -292,6 +311,7 @@ class _Layer(object):
         self.bn = None             # BatchNorm / Scale layers folded into this Convolution's weights and bias
         self.scale = None
         self.residual = None       # blob added in this Convolution's epilogue (a following Eltwise SUM folded in)
+        self.out_h = False         # "f16" math mode: this layer writes its top as a packed fp16 c8 tensor ('c8h')
         self.run = None
 
 
@@ -380,6 +400,7 @@ class Net(object):
         self._plan_fusions()
         self._warn_unpinned_layers(weights)
         self._host_weights = self._read_weights(weights)
+        self._plan_formats()
         self._bind_layers()
         _lib.call("mnc_ctx_sync", self._ctx.h)
 
@@ -523,6 +544,50 @@ class Net(object):
                 for m in members[1:]:
                     m.group_leader = members[0]
 
+    def _conv_fast1x1(self, L):
+        """A 'general' Convolution that is a plain GEMM: 1x1, no padding, stride 1 or 2 (csrc/conv1x1.hip; MNC_CONV1X1=0 sends
+        it through mnc_conv2d like any other geometry).  The fp16 variant walks K in steps of 16 channels."""
+        if os.environ.get("MNC_CONV1X1", "1") == "0" or self._conv_kind(L) != "general":
+            return False
+        k, pad, stride, _, _ = self._conv_geometry(L)
+        cin = int(np.asarray(self._layer_weights(L)[0]).shape[1])
+        return k == 1 and pad == 0 and stride in (1, 2) and cin % (16 if self.math == "f16" else 8) == 0
+
+    def _plan_formats(self):
+        """"f16" math mode: trunk activations travel between the MFMA layers as packed fp16 c8 tensors ('c8h', half the HBM
+        bytes; the producer's epilogue rounds exactly as the consumer's staging would).  A Convolution / Pooling writes 'c8h'
+        when every reader of its top can take it: the tuned 3x3 kernels, the 1x1 GEMM, MAX pooling, and the residual input of
+        a 1x1 GEMM.  Anything else (ROIWarping, the RPN's NCHW heads, Python layers, `.data`) gets fp32 -- written as fp32 by
+        the producer, or widened in place by Blob._convert.  MNC_F16_ACTS=0 keeps every tensor fp32."""
+        if self.math != "f16" or os.environ.get("MNC_F16_ACTS", "1") == "0":
+            return
+        fused_res = {}                      # index of a folded Eltwise -> the convolution that took it over
+        for L in self._layers:
+            if L.type == "Convolution" and L.residual is not None:
+                for i, E in enumerate(self._layers):
+                    if E.type == "Eltwise" and E.skip and E.tops[0] == L.out_name:
+                        fused_res[i] = L
+
+        def reads_h(i, blob):
+            C = self._layers[i]
+            if C.type == "Convolution" and not C.skip and C.bottoms[0] == blob:
+                return self._conv_kind(C) == "fast3x3" or self._conv_fast1x1(C)
+            if C.type == "Pooling" and not C.skip:
+                return (C.msg.get1("pooling_param").get1("pool", "MAX") == "MAX")
+            if i in fused_res:              # read as the residual (the convolution's own output never exists as a blob)
+                return blob == fused_res[i].residual and self._conv_fast1x1(fused_res[i])
+            return False
+
+        for L in self._layers:
+            if L.skip or L.type != "Convolution":
+                continue
+            kind = self._conv_kind(L)
+            if not (kind in ("c3", "stem", "fast3x3") or self._conv_fast1x1(L)):
+                continue
+            top = L.out_name or L.tops[0]
+            cons = self._consumers.get(top, [])
+            L.out_h = bool(cons) and top not in self.outputs and all(reads_h(i, top) for i in cons)
+
     @staticmethod
     def _eltwise_op(L):
         ep = L.msg.get1("eltwise_param")
@@ -637,10 +702,15 @@ class Net(object):
                 N, _, H, Wd = bot.shape
                 src = bot.dev_in("plain")
                 top.reshape(N, cout, H, Wd)
-                dst = top.dev_out("c8")
+                dst = top.dev_out("c8h" if L.out_h else "c8")
+                ob = 2 if L.out_h else 4
                 for n in range(N):                       # one launch sequence per image of the batch
-                    _lib.call("mnc_conv3x3_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4,
-                              H, Wd, cout, relu)
+                    if L.out_h:
+                        _lib.call("mnc_conv3x3_c3_fmt", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b,
+                                  dst + n * cout * H * Wd * ob, H, Wd, cout, relu, 2)
+                    else:
+                        _lib.call("mnc_conv3x3_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4,
+                                  H, Wd, cout, relu)
             return run
         if kind == "stem":
             if cin != 3 or W.shape[2] != W.shape[3]:
@@ -652,10 +722,11 @@ class Net(object):
                 OH, OW = (H + 2 * pad - k) // stride + 1, (Wd + 2 * pad - k) // stride + 1
                 src = bot.dev_in("plain")
                 top.reshape(N, cout, OH, OW)
-                dst = top.dev_out("c8")
+                dst = top.dev_out("c8h" if L.out_h else "c8")
+                ob = 2 if L.out_h else 4
                 for n in range(N):
-                    _lib.call("mnc_conv_stem_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * OH * OW * 4,
-                              H, Wd, cout, k, stride, pad, relu)
+                    _lib.call("mnc_conv_stem_c3_fmt", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b,
+                              dst + n * cout * OH * OW * ob, H, Wd, cout, k, stride, pad, relu, 1 if L.out_h else 0)
             return run
         if kind == "fast3x3":
             x3 = self.math in ("bf16x3", "f16")
@@ -676,7 +747,8 @@ class Net(object):
 
             def run():
                 N, _, H, Wd = bot.shape
-                src = bot.dev_in("c8")
+                in_h = self.math == "f16" and bot._dev_valid and bot.layout == "c8h"
+                src = bot.dev_in("c8h" if in_h else "c8")
                 if L.fused_pool:                           # top is the Pooling layer's blob
                     OH, OW = _pool_out(H), _pool_out(Wd)
                     top.reshape(N, cout, OH, OW)
@@ -686,6 +758,13 @@ class Net(object):
                                   dst + n * cout * OH * OW * 4, H, Wd, cin, cout, relu)
                     return
                 top.reshape(N, cout, H, Wd)
+                if in_h or L.out_h:                        # "f16" mode with 2-byte activation tensors on either side
+                    dst = top.dev_out("c8h" if L.out_h else "c8")
+                    ib, ob = (2 if in_h else 4), (2 if L.out_h else 4)
+                    for n in range(N):
+                        _lib.call("mnc_conv3x3_f16_pk", self._h(), src + n * cin * H * Wd * ib, d_w, d_b,
+                                  dst + n * cout * H * Wd * ob, H, Wd, cin, cout, relu, 1 if in_h else 0, 1 if L.out_h else 0)
+                    return
                 dst = top.dev_out("c8")
                 for n in range(N):
                     _lib.call(conv, self._h(), src + n * cin * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4, H, Wd, cin,
@@ -710,6 +789,8 @@ class Net(object):
 
         f16 = self.math == "f16"
         conv2d = "mnc_conv2d_f16" if f16 else "mnc_conv2d"
+        if self._conv_fast1x1(L):
+            return self._bind_conv1x1(L, W, d_b, key, bot, top, stride, relu)
 
         def build_general():
             raw = self._upload(W)
@@ -734,6 +815,50 @@ class Net(object):
                 _lib.call(conv2d, self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
                           (rsrc + n * cout * OH * OW * 4) if rsrc is not None else None, dst + n * cout * OH * OW * 4, H, Wd, cin,
                           cout, kh, kw, stride, pad, relu)
+        return run
+
+    def _bind_conv1x1(self, L, W, d_b, key, bot, top, stride, relu):
+        """1x1 convolution (stride 1 / 2) as a plain GEMM straight from the c8 tensors (csrc/conv1x1.hip).  fp32 / bf16x3 modes:
+        fp32 matrix pipe, fp32 tensors.  f16 mode: packed fp16 input (converted once if a producer left fp32), packed or fp32
+        output as planned (_plan_formats), residual in whichever form its producer wrote."""
+        cout, cin = int(W.shape[0]), int(W.shape[1])
+        f16 = self.math == "f16"
+
+        def build():
+            raw = self._upload(W.reshape(cout, cin))
+            packed = self._ctx.alloc(cin * ((cout + 31) // 32) * 32 * (2 if f16 else 4))
+            _lib.call("mnc_pack_conv1x1", self._h(), raw, packed, cout, cin, 1 if f16 else 0)
+            self._ctx.free(raw)
+            return packed
+        d_w = self._dev_param(key + ("w", "1x1", "f16" if f16 else "fp32"), build)
+        res = self.blobs[L.residual] if L.residual else None
+
+        def run():
+            N, _, H, Wd = bot.shape
+            OH, OW = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+            if res is not None and tuple(res.shape) != (N, cout, OH, OW):
+                raise ValueError("Convolution %s: residual %r has shape %r, expected %r" % (L.name, res.name, res.shape,
+                                                                                            (N, cout, OH, OW)))
+            if not f16:
+                src = bot.dev_in("c8")
+                rsrc = res.dev_in("c8") if res is not None else None
+                top.reshape(N, cout, OH, OW)
+                dst = top.dev_out("c8")
+                for n in range(N):
+                    _lib.call("mnc_conv1x1", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
+                              (rsrc + n * cout * OH * OW * 4) if rsrc is not None else None, dst + n * cout * OH * OW * 4,
+                              H, Wd, cin, cout, stride, relu)
+                return
+            src = bot.dev_in("c8h")
+            res_h = res is not None and res._dev_valid and res.layout == "c8h"
+            rsrc = res.dev_in("c8h" if res_h else "c8") if res is not None else None
+            rb, ob = (2 if res_h else 4), (2 if L.out_h else 4)
+            top.reshape(N, cout, OH, OW)
+            dst = top.dev_out("c8h" if L.out_h else "c8")
+            for n in range(N):
+                _lib.call("mnc_conv1x1_f16_pk", self._h(), src + n * cin * H * Wd * 2, d_w, d_b,
+                          (rsrc + n * cout * OH * OW * rb) if rsrc is not None else None, dst + n * cout * OH * OW * ob,
+                          H, Wd, cin, cout, stride, relu, 1 if res_h else 0, 1 if L.out_h else 0)
         return run
 
     def _bind_ReLU(self, L, i):
@@ -769,24 +894,29 @@ class Net(object):
 
             def run_general():
                 N, C, H, W = bot.shape
-                src = bot.dev_in("c8")
+                half = bot._dev_valid and bot.layout == "c8h"       # packed fp16 in -> packed fp16 out (max commutes with rounding)
+                lay, eb = ("c8h", 2) if half else ("c8", 4)
+                src = bot.dev_in(lay)
                 OH, OW = out_size(H), out_size(W)
                 top.reshape(N, C, OH, OW)
-                dst = top.dev_out("c8")
+                dst = top.dev_out(lay)
                 for n in range(N):
-                    _lib.call("mnc_maxpool_c8", self._h(), src + n * C * H * W * 4, dst + n * C * OH * OW * 4, C, H, W, k, stride,
-                              pad)
+                    _lib.call("mnc_maxpool_c8_f16" if half else "mnc_maxpool_c8", self._h(), src + n * C * H * W * eb,
+                              dst + n * C * OH * OW * eb, C, H, W, k, stride, pad)
             return run_general
 
         def run():
-            if bot._dev_valid and bot.layout == "c8":
+            if bot._dev_valid and bot.layout in ("c8", "c8h"):
                 N, C, H, W = bot.shape
-                src = bot.dev_in("c8")
+                half = bot.layout == "c8h"
+                lay, eb = ("c8h", 2) if half else ("c8", 4)
+                src = bot.dev_in(lay)
                 OH, OW = _pool_out(H), _pool_out(W)
                 top.reshape(N, C, OH, OW)
-                dst = top.dev_out("c8")
+                dst = top.dev_out(lay)
                 for n in range(N):
-                    _lib.call("mnc_maxpool2_c8", self._h(), src + n * C * H * W * 4, dst + n * C * OH * OW * 4, C, H, W)
+                    _lib.call("mnc_maxpool2_c8_f16" if half else "mnc_maxpool2_c8", self._h(), src + n * C * H * W * eb,
+                              dst + n * C * OH * OW * eb, C, H, W)
             else:
                 R, C, PH, PW = bot.shape
                 if PH % 2 or PW % 2:            # Caffe's ceil rule would give (PH + 1) // 2 (a 7x7 input -> 4x4): no kernel for it
@@ -811,7 +941,7 @@ class Net(object):
         def run():
             if tuple(a.shape) != tuple(b.shape):
                 raise ValueError("Eltwise %s: shapes %r and %r differ" % (L.name, a.shape, b.shape))
-            layout = "c8" if len(a.shape) == 4 and a.shape[1] % 8 == 0 and (a._dev_valid and a.layout == "c8") else "plain"
+            layout = "c8" if len(a.shape) == 4 and a.shape[1] % 8 == 0 and (a._dev_valid and a.layout in ("c8", "c8h")) else "plain"
             pa, pb = a.dev_in(layout), b.dev_in(layout)
             top.reshape(*a.shape)
             _lib.call("mnc_add", self._h(), pa, pb, top.dev_out(layout), a.count, relu)

@@ -48,6 +48,27 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+def _h16(ptr, shape):
+    """A packed fp16 tensor at a "device" address."""
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(ptr))).view(np.float16).reshape(shape)
+
+
+def _rd_c8(ptr, C, H, W, packed):
+    """[C,H,W] float32 from a c8 tensor that is fp32 or (packed) fp16."""
+    x = _h16(ptr, (C // 8, H, W, 8)).astype(np.float32) if packed else _f(ptr, (C // 8, H, W, 8))
+    return _unc8(x)
+
+
+def _wr_c8(ptr, y, packed):
+    """[C,H,W] float32 -> c8 tensor, rounded to fp16 (nearest even) when packed."""
+    C, H, W = y.shape
+    if packed:
+        _h16(ptr, (C // 8, H, W, 8))[...] = _c8(y).astype(np.float16)
+    else:
+        _f(ptr, (C // 8, H, W, 8))[...] = _c8(y)
+
+
 class Fake(object):
     def mnc_device_count(self, addr):
         ctypes.c_int.from_address(int(addr)).value = 1
@@ -238,6 +259,64 @@ class Fake(object):
     def mnc_maxpool_c8(self, h, src, dst, C, H, W, K, stride, pad):
         y = F.max_pool2d(_t(_unc8(_f(src, (C // 8, H, W, 8))))[None], K, stride, pad, ceil_mode=True)[0].numpy()
         _f(dst, (C // 8,) + y.shape[1:] + (8,))[...] = _c8(y)
+
+    # ---- 2-byte activation tensors of the "f16" mode and the 1x1 GEMM (csrc/conv1x1.hip) ----
+    def mnc_act_pack(self, h, src, dst, n, f16):
+        assert f16 == 1, "test double: fp16 form only"
+        _h16(dst, (n,))[...] = _f(src, (n,)).astype(np.float16)
+
+    def mnc_act_unpack(self, h, src, dst, n, f16):
+        assert f16 == 1, "test double: fp16 form only"
+        _f(dst, (n,))[...] = _h16(src, (n,)).astype(np.float32)
+
+    def mnc_conv3x3_c3_fmt(self, h, src, w, b, dst, H, W, Cout, relu, out_fmt):
+        assert out_fmt in (0, 2), "test double: fp32 or fp16 output"
+        y = F.conv2d(_t(_f(src, (1, 3, H, W))), _t(_f(w, (Cout, 3, 3, 3))), _t(_f(b, (Cout,))), padding=1)
+        _wr_c8(dst, _act(y, relu)[0].numpy(), out_fmt == 2)
+
+    def mnc_conv3x3_f16_pk(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed):
+        x = _t(_rd_c8(src, Cin, H, W, in_packed).astype(np.float16).astype(np.float32))[None]
+        y = F.conv2d(x, _t(_f(wpk, (Cout, Cin, 3, 3))), _t(_f(b, (Cout,))), padding=1)[0]
+        if relu:
+            y = F.relu(y)
+        _wr_c8(dst, y.numpy(), out_packed)
+
+    def mnc_maxpool2_c8_f16(self, h, src, dst, C, H, W):
+        y = F.max_pool2d(_t(_rd_c8(src, C, H, W, True))[None], 2, 2, ceil_mode=True)[0].numpy()
+        _wr_c8(dst, y, True)
+
+    def mnc_maxpool_c8_f16(self, h, src, dst, C, H, W, K, stride, pad):
+        y = F.max_pool2d(_t(_rd_c8(src, C, H, W, True))[None], K, stride, pad, ceil_mode=True)[0].numpy()
+        _wr_c8(dst, y, True)
+
+    def mnc_conv_stem_c3_fmt(self, h, src, w, b, dst, H, W, Cout, K, stride, pad, relu, out_packed):
+        y = F.conv2d(_t(_f(src, (1, 3, H, W))), _t(_f(w, (Cout, 3, K, K))), _t(_f(b, (Cout,))), stride=stride, padding=pad)[0]
+        if relu:
+            y = F.relu(y)
+        _wr_c8(dst, y.numpy(), out_packed)
+
+    def mnc_pack_conv1x1(self, h, src, dst, Cout, Cin, f16):
+        # test double: a side table keyed by the packed buffer's address (the fragment-order packing is checked on the GPU)
+        w = _f(src, (Cout, Cin)).copy()
+        self._c11 = getattr(self, "_c11", {})
+        self._c11[int(dst)] = w.astype(np.float16).astype(np.float32) if f16 else w
+
+    def _conv1x1(self, x, wpk, b, res, Cout, stride, relu):
+        w = self._c11[int(wpk)]
+        y = F.conv2d(_t(x)[None], _t(w[:, :, None, None]), _t(_f(b, (Cout,))), stride=stride)[0]
+        if res is not None:
+            y = y + _t(np.ascontiguousarray(res))
+        return (F.relu(y) if relu else y).numpy()
+
+    def mnc_conv1x1(self, h, src, wpk, b, res, dst, H, W, Cin, Cout, stride, relu):
+        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+        r = _rd_c8(res, Cout, OH, OW, False) if res else None
+        _wr_c8(dst, self._conv1x1(_rd_c8(src, Cin, H, W, False), wpk, b, r, Cout, stride, relu), False)
+
+    def mnc_conv1x1_f16_pk(self, h, src, wpk, b, res, dst, H, W, Cin, Cout, stride, relu, res_packed, out_packed):
+        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+        r = _rd_c8(res, Cout, OH, OW, res_packed) if res else None
+        _wr_c8(dst, self._conv1x1(_rd_c8(src, Cin, H, W, True), wpk, b, r, Cout, stride, relu), out_packed)
 
     def mnc_add(self, h, a, b, dst, n, relu):
         y = _f(a, (n,)) + _f(b, (n,))

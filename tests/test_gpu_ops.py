@@ -334,6 +334,111 @@ def test_conv2d_general_f16(dev, H, W, Cin, Cout, K, stride, pad, residual):
     assert rel < 1e-5 and rel32 < 2e-3
 
 
+# 1x1 GEMM convolution (csrc/conv1x1.hip): H, W, Cin, Cout, stride, residual.  Ragged pixel counts, channel counts that leave the
+# last 32-channel tile / channel group partly empty, K-step counts 1, 2, 3, 5 (the 4-deep prefetch's phantom steps), the ResNet-50
+# C4 shapes at 800x1333, and both strides.
+C11 = [(13, 17, 16, 8, 1, False), (13, 17, 16, 24, 1, True), (20, 33, 32, 72, 2, True), (31, 45, 48, 64, 1, False),
+       (31, 45, 80, 160, 2, True), (50, 84, 256, 1024, 1, True), (100, 167, 512, 256, 2, False), (200, 334, 64, 256, 1, True),
+       (200, 334, 256, 64, 1, False), (100, 167, 128, 512, 1, True)]
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,stride,residual", C11)
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv1x1_fp32(dev, monkeypatch, H, W, Cin, Cout, stride, residual, relu):
+    """mnc_conv1x1 (fp32 matrix pipe, operands straight from the c8 tensors) against torch fp32, default tile and two forced ones."""
+    rng = np.random.default_rng(H * 100 + W + Cin)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 1, 1)) * np.sqrt(2.0 / Cin)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    y = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), stride=stride)[0]
+    OH, OW = y.shape[1:]
+    res = rng.normal(size=(Cout, OH, OW)).astype(np.float32) if residual else None
+    if residual:
+        y = y + torch.from_numpy(res)
+    want = (F.relu(y) if relu else y).numpy()
+    d_w = dev.empty((Cin * ((Cout + 31) // 32) * 32,), fill=np.nan)
+    dev.call("mnc_pack_conv1x1", dev.put(w), d_w, Cout, Cin, 0)
+    d_x, d_b, d_r = dev.put(to_c8(x)), dev.put(b), dev.put(to_c8(res)) if residual else None
+    for tile in (None, "4,2", "1,1", "2,1"):
+        if tile:
+            monkeypatch.setenv("MNC_CONV1X1_TILE", tile)
+        d_y = dev.empty((Cout * OH * OW,), fill=np.nan)
+        dev.call("mnc_conv1x1", d_x, d_w, d_b, d_r, d_y, H, W, Cin, Cout, stride, relu)
+        got = from_c8(dev.get(d_y, (Cout * OH * OW,)), Cout, OH, OW)
+        assert not np.isnan(got).any(), tile
+        d, rel = err(got, want)
+        assert rel < 1e-4, (tile, d, rel)
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,stride,residual", C11)
+@pytest.mark.parametrize("res_packed,out_packed", [(1, 1), (0, 0), (1, 0), (0, 1)])
+def test_conv1x1_f16_packed(dev, monkeypatch, H, W, Cin, Cout, stride, residual, res_packed, out_packed):
+    """mnc_conv1x1_f16_pk: packed fp16 c8 activations in, packed fp16 or fp32 out, residual in either form.  Against torch on the
+    same fp16-rounded operands the fp32 result agrees to accumulation order (1e-5 of range); a packed output is that result
+    rounded to fp16 once (half an fp16 ulp of the value on top)."""
+    if not residual and res_packed:
+        pytest.skip("no residual")
+    rng = np.random.default_rng(H * 100 + W + Cin + 7)
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+    x = r16(rng.normal(size=(Cin, H, W)).astype(np.float32))
+    w = (rng.normal(size=(Cout, Cin, 1, 1)) * np.sqrt(2.0 / Cin)).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    y = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(r16(w)), torch.from_numpy(b), stride=stride)[0]
+    OH, OW = y.shape[1:]
+    res = rng.normal(size=(Cout, OH, OW)).astype(np.float32) if residual else None
+    if residual and res_packed:
+        res = r16(res)
+    if residual:
+        y = y + torch.from_numpy(res)
+    want = F.relu(y).numpy()
+    d_w = dev.empty((Cin * ((Cout + 31) // 32) * 32 // 2,), fill=np.nan)
+    dev.call("mnc_pack_conv1x1", dev.put(w), d_w, Cout, Cin, 1)
+    d_x = dev.put(to_c8(x).astype(np.float16), dtype=np.float16)
+    d_r = None
+    if residual:
+        d_r = dev.put(to_c8(res).astype(np.float16), dtype=np.float16) if res_packed else dev.put(to_c8(res))
+    for tile in (None, "4,2", "1,2"):
+        if tile:
+            monkeypatch.setenv("MNC_CONV1X1_TILE", tile)
+        n = Cout * OH * OW
+        d_y = dev.empty((n,), fill=np.nan)
+        dev.call("mnc_conv1x1_f16_pk", d_x, d_w, dev.put(b), d_r, d_y, H, W, Cin, Cout, stride, 1, res_packed, out_packed)
+        if out_packed:
+            got = from_c8(dev.get(d_y, (n,), dtype=np.float16).astype(np.float32), Cout, OH, OW)
+            assert not np.isnan(got).any(), tile
+            # the fp32 result rounded once: within half an fp16 ulp (2^-11 relative, 2^-25 absolute floor) + the fp32 slack
+            tol = np.abs(want) * 2.0 ** -11 + 2.0 ** -24 + 2e-5 * np.abs(want).max()
+            assert (np.abs(got - want) <= tol).all(), (tile, float(np.abs(got - want).max()))
+        else:
+            got = from_c8(dev.get(d_y, (n,)), Cout, OH, OW)
+            assert not np.isnan(got).any(), tile
+            d, rel = err(got, want)
+            assert rel < 1e-5, (tile, d, rel)
+
+
+@pytest.mark.parametrize("H,W,K,stride,pad", [(112, 112, 3, 2, 0), (101, 166, 3, 2, 1), (37, 41, 2, 2, 0)])
+def test_packed_fp16_stem_and_general_maxpool(dev, H, W, K, stride, pad):
+    """The f16 mode's 2-byte tensors outside the MFMA kernels: the stem convolution's packed output is its fp32 output rounded to
+    fp16 (nearest even), MAX pooling on the packed tensor is bit for bit the fp16 form of pooling the fp32 tensor."""
+    rng = np.random.default_rng(H + K)
+    x = rng.normal(size=(16, H, W)).astype(np.float32).astype(np.float16)
+    want = F.max_pool2d(torch.from_numpy(x.astype(np.float32))[None], K, stride, pad, ceil_mode=True)[0].numpy()
+    OH, OW = want.shape[1:]
+    d_y = dev.empty((16 * OH * OW,), dtype=np.float16, fill=np.nan)
+    dev.call("mnc_maxpool_c8_f16", dev.put(to_c8(x), dtype=np.float16), d_y, 16, H, W, K, stride, pad)
+    got = from_c8(dev.get(d_y, (16 * OH * OW,), dtype=np.float16), 16, OH, OW)
+    assert np.array_equal(got.astype(np.float32), want)
+    im = rng.uniform(-120, 130, (3, H, W)).astype(np.float32)
+    w = (rng.normal(size=(64, 3, 7, 7)) * 0.01).astype(np.float32)
+    b = rng.normal(size=64).astype(np.float32)
+    SH, SW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    d_a, d_h = dev.empty((64 * SH * SW,), fill=np.nan), dev.empty((64 * SH * SW,), dtype=np.float16, fill=np.nan)
+    dev.call("mnc_conv_stem_c3", dev.put(im), dev.put(w), dev.put(b), d_a, H, W, 64, 7, 2, 3, 1)
+    dev.call("mnc_conv_stem_c3_fmt", dev.put(im), dev.put(w), dev.put(b), d_h, H, W, 64, 7, 2, 3, 1, 1)
+    a = dev.get(d_a, (64 * SH * SW,))
+    assert np.array_equal(dev.get(d_h, (64 * SH * SW,), dtype=np.float16), a.astype(np.float16))
+
+
 @pytest.mark.parametrize("H,W,K,stride,pad", [(75, 101, 7, 2, 3), (64, 64, 7, 2, 3), (31, 45, 3, 1, 1)])
 def test_conv_stem_c3(dev, H, W, K, stride, pad):
     rng = np.random.default_rng(H + W)

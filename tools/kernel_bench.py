@@ -6,6 +6,8 @@
     python tools/kernel_bench.py convwino              the same on the Winograd F(2x2,3x3) fp32 kernel (MNC_WINO_ROWS=1|2|4)
     python tools/kernel_bench.py fc   [--reps 20]      the FC shapes of one head stage at 300 RoIs
     python tools/kernel_bench.py fcx3                  the same on the bf16x3 kernel
+    python tools/kernel_bench.py conv1x1 [--f16]       the 1x1 convolutions of the ResNet-50 C4 trunk at 800x1333: the GEMM kernel
+                                                       (csrc/conv1x1.hip; MNC_CONV1X1_TILE=ct,pt) next to the general kernel
 Environment knobs understood by the library (tuning aids): MNC_CONV_COT=1|2|4."""
 import argparse
 import ctypes
@@ -22,6 +24,13 @@ from gpu_util import Dev  # noqa: E402
 CONV = [("conv1_2", 600, 1000, 64, 64), ("conv2_1", 300, 500, 64, 128), ("conv2_2", 300, 500, 128, 128),
         ("conv3_1", 150, 250, 128, 256), ("conv3_2", 150, 250, 256, 256), ("conv4_1", 75, 125, 256, 512),
         ("conv4_2", 75, 125, 512, 512), ("conv5_1", 38, 63, 512, 512)]
+# ResNet-50 C4 at 800x1333 (pool1 200x334): (name, H, W, Cin, Cout, stride, residual, how many such layers)
+C11 = [("res2a_2a", 200, 334, 64, 64, 1, False, 1), ("res2_2c", 200, 334, 64, 256, 1, True, 3), ("res2a_b1", 200, 334, 64, 256, 1, False, 1),
+       ("res2_2a", 200, 334, 256, 64, 1, False, 2), ("res3a_2a", 200, 334, 256, 128, 2, False, 1),
+       ("res3a_b1", 200, 334, 256, 512, 2, False, 1), ("res3_2c", 100, 167, 128, 512, 1, True, 4),
+       ("res3_2a", 100, 167, 512, 128, 1, False, 3), ("res4a_2a", 100, 167, 512, 256, 2, False, 1),
+       ("res4a_b1", 100, 167, 512, 1024, 2, False, 1), ("res4_2c", 50, 84, 256, 1024, 1, True, 6),
+       ("res4_2a", 50, 84, 1024, 256, 1, False, 5)]
 FC = [("fc6_maskest", 300, 256, 100352), ("mask_pred", 300, 441, 256), ("fc6", 300, 4096, 25088), ("fc7", 300, 4096, 4096),
       ("heads", 300, 126, 8192)]
 
@@ -41,7 +50,8 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "fc", "fcx3"])
+    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "fc", "fcx3", "conv1x1"])
+    ap.add_argument("--f16", action="store_true", help="conv1x1: packed fp16 tensors (mnc_conv1x1_f16_pk) instead of fp32")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
@@ -57,7 +67,56 @@ def main():
     rng = np.random.default_rng(0)
     dev.call("mnc_prof_enable", 1)
     total_ms, total_fl = 0.0, 0.0
-    if args.what in ("conv", "convx3", "convf16", "convwino"):
+    if args.what == "conv1x1":
+        tot_new = tot_old = tot_fl = tot_by = 0.0
+        for name, H, W, Cin, Cout, stride, residual, count in C11:
+            if args.only and args.only not in name:
+                continue
+            OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+            xf = rng.normal(size=(Cin * H * W,)).astype(np.float32)
+            wf = (rng.normal(size=(Cout * Cin,)) * 0.05).astype(np.float32)
+            b = dev.put(np.zeros(Cout, np.float32))
+            rf = rng.normal(size=(Cout * OH * OW,)).astype(np.float32)
+            y = dev.empty((Cout * OH * OW,))
+            raw = dev.put(wf)
+            wn = dev.empty((Cin * ((Cout + 31) // 32) * 32,))
+            dev.call("mnc_pack_conv1x1", raw, wn, Cout, Cin, 1 if args.f16 else 0)
+            if args.f16:
+                x = dev.put(xf.astype(np.float16), dtype=np.float16)
+                r = dev.put(rf.astype(np.float16), dtype=np.float16) if residual else None
+                new = lambda: dev.call("mnc_conv1x1_f16_pk", x, wn, b, r, y, H, W, Cin, Cout, stride, 1, 1, 1)
+                wo = dev.empty((((Cin + 31) // 32) * 32 * Cout,))
+                dev.call("mnc_pack_conv_weights_f16", raw, wo, Cout, Cin, 1, 1)
+                x32, r32 = dev.put(xf), (dev.put(rf) if residual else None)
+                old = lambda: dev.call("mnc_conv2d_f16", x32, wo, b, r32, y, H, W, Cin, Cout, 1, 1, stride, 0, 1)
+                by = 2.0 * (Cin * OH * OW + Cout * OH * OW * (2 if residual else 1) + Cin * Cout)
+            else:
+                x = dev.put(xf)
+                r = dev.put(rf) if residual else None
+                new = lambda: dev.call("mnc_conv1x1", x, wn, b, r, y, H, W, Cin, Cout, stride, 1)
+                wo = dev.empty((Cin * Cout,))
+                dev.call("mnc_pack_conv_weights", raw, wo, Cout, Cin, 1, 1)
+                old = lambda: dev.call("mnc_conv2d", x, wo, b, r, y, H, W, Cin, Cout, 1, 1, stride, 0, 1)
+                by = 4.0 * (Cin * OH * OW + Cout * OH * OW * (2 if residual else 1) + Cin * Cout)
+            res = {}
+            for tag, fn in (("new", new), ("old", old)):
+                for _ in range(3):
+                    fn()
+                dev.call("mnc_prof_reset")
+                for _ in range(args.reps):
+                    fn()
+                res[tag] = np.array([t for n_, t in records(dev) if n_.startswith("conv")])
+            fl = 2.0 * OH * OW * Cin * Cout
+            tn, to = np.median(res["new"]), np.median(res["old"])
+            print("%-9s %3dx%-3d %4d->%-4d s%d %s x%d  gemm %.1f us (min %.1f)  %.1f TF/s  %.2f TB/s | general %.1f us  %.1f TF/s" %
+                  (name, H, W, Cin, Cout, stride, "res" if residual else "   ", count, 1e3 * tn, 1e3 * res["new"].min(),
+                   fl / tn / 1e9, by / tn / 1e9, 1e3 * to, fl / to / 1e9), flush=True)
+            tot_new += count * tn; tot_old += count * to; tot_fl += count * fl; tot_by += count * by
+        if not args.only:
+            print("all 1x1 layers of the trunk (%s): gemm %.3f ms = %.1f TF/s, %.2f TB/s algorithmic | general %.3f ms = %.1f TF/s"
+                  % ("f16, packed tensors" if args.f16 else "fp32", tot_new, tot_fl / tot_new / 1e9, tot_by / tot_new / 1e9,
+                     tot_old, tot_fl / tot_old / 1e9))
+    elif args.what in ("conv", "convx3", "convf16", "convwino"):
         for name, H, W, Cin, Cout in CONV:
             if args.only and args.only not in name:
                 continue
