@@ -318,6 +318,30 @@ MNC_API int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size
 MNC_API int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
 MNC_API int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N,
                        int K, int ldc, int act);
+/* ---- InnerProduct activations already in the reduced-precision kernels' own form ----
+ * mnc_fc_bf16x3 / mnc_fc_f16 multiply the activations from a stage-major 2-byte tensor, which they otherwise make from the fp32
+ * rows on every call (an elementwise pass over M x K: 0.2 ms per image at 300 RoIs, 0.75 ms at 1000 RoIs x 1024 channels):
+ *   fmt 1 (f16)    [K/64][M][64] halves (nearest even of the fp32 value),                 M*K*2 bytes
+ *   fmt 2 (bf16x3) [K/32][M][4 x (hi x8 | lo x8)] bf16 (x = hi + lo, both nearest even), M*K*4 bytes
+ * with row r of the fp32 tensor [M][K] at row r of every stage.  The producers of the per-RoI tensors write this form next to the
+ * fp32 tensor in their epilogue (the *_sm entry points below: d_sm may be NULL / sm_fmt 0 = no second output; values are bit for
+ * bit what mnc_fc_pack_act makes of the fp32 output), and mnc_fc_{bf16x3,f16}_pre take it: m_stride = rows of the stage-major
+ * tensor (>= M: a call may multiply its first M rows), everything else as mnc_fc_*.
+ *   mnc_roi_warp_sm        = mnc_roi_warp        (+ d_sm of d_out_rhwc as [R][PH*PW*C])
+ *   mnc_maxpool2_rhwc_sm   = mnc_maxpool2_rhwc   (+ d_sm of d_out)
+ *   mnc_mask_pool_sm       = mnc_mask_pool       (+ d_sm of d_out)
+ * C%64==0 (fmt 1) / C%32==0 (fmt 2) so that an 8-channel group never straddles a stage. */
+MNC_API int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, int f16);
+MNC_API int mnc_fc_f16_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
+                           float* d_out, int M, int N, int K, int ldc, int act);
+MNC_API int mnc_fc_bf16x3_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
+                              float* d_out, int M, int N, int K, int ldc, int act);
+MNC_API int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
+                            float spatial_scale, int pool2, float* d_out_rhwc, void* d_sm, int sm_fmt);
+MNC_API int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C, void* d_sm,
+                                 int sm_fmt);
+MNC_API int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH, int PW, int C,
+                             int pool2, void* d_sm, int sm_fmt);
 /* Softmax over the last axis of [M][N] (test.prototxt cls_prob / seg_cls_prob). */
 MNC_API int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N);
 /* Same with a row stride on the input (the input may be a column slice of a merged-GEMM output). */

@@ -10,8 +10,8 @@
 // load in the A operand's fragment order ([K-step][32-channel tile][lane] x 16 bytes: one contiguous kilobyte per wave load);
 // they are small (<= 1 MB per layer) and stay in L2.
 //
-// Wave tile = CT x 32 output channels by PT x 32 pixels, four waves of a workgroup take four consecutive pixel ranges of the
-// same channel group (their weight loads hit L1).  K loop: four fragment sets in flight (loads for K-step k+3 are issued while
+// Wave tile = CT x 32 output channels by PT x 32 pixels (chosen per call, see conv1x1_launch), four waves of a workgroup take
+// four consecutive pixel ranges of the same channel group (their weight loads hit L1).  K loop: four fragment sets in flight (loads for K-step k+3 are issued while
 // k is multiplied), every load unconditional with a clamped K index (a load under a branch makes hipcc drain vmcnt), phantom
 // K-steps past the end are multiplied by zeroed B fragments.  Workgroups are numbered so that all channel groups of one pixel
 // range run on the same XCD (the activations are fetched into that XCD's L2 once).
@@ -221,12 +221,19 @@ static int conv1x1_launch(mnc_ctx* ctx, const char* scope, const void* d_in, con
   const int P = OH * OW;
   const int KS = Cin / (F16 ? 16 : 8), CoT = cdiv(Cout, 32);
   MNC_REQUIRE((double)(Cout / 8) * P * 2.0 < 2.0e9 && (double)H * W * (Cin / 8) * 2.0 < 2.0e9, "%s: tensor too large for 32-bit offsets", scope);
-  // tile: 128 channels x 64 pixels per wave when that still gives every CU two workgroups; narrower otherwise (the small maps
-  // of res4 are latency-bound chains: more, thinner waves)
-  int ct = CoT >= 4 ? 4 : CoT >= 2 ? 2 : 1, pt = 2;
-  auto blocks = [&]() { return (long)cdiv(P, 128 * pt) * cdiv(CoT, ct); };
-  if (blocks() < 512) pt = 1;
-  while (blocks() < 512 && ct > 1) ct >>= 1;
+  // Tile per wave.  Measured on the ResNet-50 C4 shapes at 800x1333 (tools/kernel_bench.py conv1x1, MNC_CONV1X1_TILE sweep):
+  // f16 is bound by HBM and by the length of the K chain, not by the matrix pipe -- 32 channels x 64 pixels (3 waves per SIMD)
+  // is best or within 5 % of the best on every layer (0.41 ms for the 29 layers; 128 x 64: 0.57 ms).  fp32 is bound by the
+  // matrix pipe and by how evenly the waves fill the 1024 SIMDs: 64 x 64 while that gives >= 512 workgroups, thinner after.
+  int ct, pt = 2;
+  if (F16) {
+    ct = 1;
+  } else {
+    ct = CoT >= 2 ? 2 : 1;
+    auto blocks = [&]() { return (long)cdiv(P, 128 * pt) * cdiv(CoT, ct); };
+    if (blocks() < 512) pt = 1;
+    while (blocks() < 512 && ct > 1) ct >>= 1;
+  }
   if (const char* e = getenv("MNC_CONV1X1_TILE")) {          // tuning override "ct,pt"
     int a = 0, b = 0;
     if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2)) { ct = a; pt = b; }

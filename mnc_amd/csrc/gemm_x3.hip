@@ -48,7 +48,7 @@ template <int kMT, int kWR, int ABL = 0, int F16 = 0>
 __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax, const uint4* __restrict__ Wx,
                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                     float* __restrict__ part, int M, int N, int K, int ldc, int kper,
-                                                    int act, int fused, int tn_, int splits_, int tm_) {
+                                                    int act, int fused, int tn_, int splits_, int tm_, int mstride) {
   constexpr int kBM = 32 * kMT;
   constexpr int kAPer = (kBM * 8 + 255) / 256;          // uint4 items of the (pre-split) A panel per thread and stage
   __shared__ __attribute__((aligned(16))) unsigned sA[2][kBM * kXPitch];
@@ -56,7 +56,13 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, kb = lane >> 5;
   int bn, split, bmz;
-  xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  if (tm_ < 0) {            // row block fastest (see fc_lowp): the workgroups that share a weight panel are neighbours
+    int a, b, c;
+    xcd_decode(blockIdx.x, -tm_, tn_, splits_, a, b, c);
+    bmz = a; bn = b; split = c;
+  } else {
+    xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  }
   const int n0 = bn * kXBN, m0 = bmz * kBM;
   constexpr int kStageK = F16 ? 64 : kXBK;     // K values per stage (128 bytes per row either way)
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
   for (int u = 0; u < kAPer; ++u) {
     const int q = tid + u * 256, r = min(q >> 3, kBM - 1), c = q & 7;
     const int gr = m0 + min(r, mrows - 1);
-    a_src[u] = Ax + (((long)(kbeg / kStageK) * M + gr) << 3) + c;      // [stage][row][8]
+    a_src[u] = Ax + (((long)(kbeg / kStageK) * mstride + gr) << 3) + c;      // [stage][row of mstride][8]
     a_dst[u] = r * kXPitch + c * 4;
   }
   const uint4* b_src[kXBPer];
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
     b_src[u] = Wx + ((((long)bn * (K / kStageK) + kbeg / kStageK) * kXBN + r) << 3) + c;   // [column tile][stage][128][8]
     b_dst[u] = r * kXPitch + c * 4;
   }
-  const long a_step = (long)M << 3, b_step = (long)kXBN << 3;         // uint4 per stage
+  const long a_step = (long)mstride << 3, b_step = (long)kXBN << 3;   // uint4 per stage (the panel may hold more rows than this call multiplies)
   // Two register sets (R0/R1): the loads of stage s+2 are in flight while stage s is multiplied and stage s+1 -- already
   // in registers -- is written to the free LDS buffer.  One barrier per stage; the global-load latency gets a whole stage
   // to hide.  The main loop has no VALU work besides addressing: splitting the activations here cost ~140 VALU
@@ -350,6 +356,113 @@ static int x3_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int row
 
 using namespace mnc;
 
+// Shared launcher of the split-bf16 (F16 = 0) and fp16 (F16 = 1) InnerProducts.  The activations are multiplied from their
+// stage-major 2-byte form [K/stage][mstride rows][128 B]: either `d_pre` -- already in that form, written by the producer of the
+// tensor (mnc_roi_warp_sm, mnc_maxpool2_rhwc_sm, mnc_mask_pool_sm, mnc_fc_pack_act) -- or `d_a`, fp32 row-major, converted here
+// into the scratch arena (one elementwise pass per call: 10-200 us that the producers' epilogues make unnecessary).
+template <int F16>
+static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4* d_pre, int mstride, const void* d_w_packed,
+                   const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act) {
+  constexpr int kStage = F16 ? 64 : kXBK;
+  if (M == 0) return MNC_OK;
+  // Several row blocks (M > 320: the 1000-RoI ResNet configuration, CFM): every block streams its whole weight panel, so a
+  // block costs about (rows + 128) -- measured: the 40-row tail of M = 1000 took 0.19 of the time of the 960 rows before it.
+  // 256-row blocks (fc_x3_kernel<8, 2>) in ONE launch when that is cheaper than 320-row blocks plus a tail launch:
+  // M = 1000: 4 x (256 + 128) = 1536 against 3 x 448 + 288 = 1632; M = 960 or 2000 stay on 320-row blocks.
+  bool rows256 = false;
+  if (M > 320 && 2.0 * M * (double)N * K >= 2.0e9) {
+    const int tail = M % 320;
+    const long cost320 = (long)(M / 320) * 448 + (tail == 0 ? 0 : tail <= 160 ? 288 : 448);
+    const long cost256 = (long)cdiv(M, 256) * 384;
+    rows256 = cost256 < cost320 && !getenv("MNC_FC_NO256");
+  }
+  // full 320-row blocks and a ragged tail of at most 160 rows are two launches, each with its own tile height (see mnc_fc)
+  if (!rows256 && M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
+    const int head = M / 320 * 320;
+    int rc = fc_lowp<F16>(ctx, what, d_a, d_pre, mstride, d_w_packed, d_bias, d_out, head, N, K, ldc, act);
+    if (rc) return rc;
+    return fc_lowp<F16>(ctx, what, d_a ? d_a + (size_t)head * K : nullptr, d_pre ? d_pre + (size_t)head * 8 : nullptr, mstride,
+                        d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+  }
+  // row tiles per workgroup: 2 (64 rows) for the small GEMMs, else the smallest of {5, 10} that covers M in one block
+  const bool small = 2.0 * M * (double)N * K < 2.0e9;
+  int mt = small ? 2 : (M <= 160 ? 5 : 10);
+  // 320-row blocks stream the weights once but need many K splits to fill the chip; when a split would be shorter than 64 stages
+  // (bf16x3; 32 for fp16), 160-row blocks (twice the tiles, half the splits and half the partial-sum traffic) are faster
+  // (measured at M = 300, bf16x3: fc7 59 vs 69 us, fc6_maskest 132 vs 151 us, fc6 274 vs 262 us)
+  if (mt == 10 && (K / kStage) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < (F16 ? 32 : 64)) mt = 5;
+  if (rows256) mt = 8;
+  if (const char* e = getenv("MNC_FCX3_TILE")) {          // tuning override
+    const int v = atoi(e);
+    if (v == 2 || v == 5 || v == 8 || v == 10) mt = v;
+  }
+  const int bm = 32 * mt;
+  const int tn = cdiv(N, kXBN), tm = cdiv(M, bm), stages = K / kStage;
+  int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
+  const int min_stages = F16 ? (mt == 2 ? 1 : 4) : (mt == 2 ? 2 : 8);
+  if (splits > stages / min_stages) splits = stages / min_stages;
+  if (splits < 1) splits = 1;
+  if (tm > 1 && mt != 2)     // several row blocks: split count by cost (mnc_internal.h: choose_splits)
+    splits = choose_splits(tn * tm, stages, min_stages, 256,
+                           (double)bm * kXBN * kStage * 2.0 / (F16 ? 2000.0e3 : 1050.0e3), 4.0 * M * (double)N);
+  const int kper = cdiv(stages, splits) * kStage;
+  splits = cdiv(K, kper);
+  // scratch arena: [split-K partials | the activations in their 2-byte stage-major form (when they arrive as fp32)]
+  const size_t part_bytes = splits > 1 ? (((size_t)splits * M * N * 4 + 255) & ~(size_t)255) : 0;
+  int rc = ensure_scratch(ctx, part_bytes + (d_pre ? 0 : (size_t)M * K * (F16 ? 2 : 4)));
+  if (rc) return rc;
+  float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
+  const uint4* d_ax = d_pre;
+  if (!d_pre) {
+    uint4* conv = (uint4*)((char*)ctx->scratch + part_bytes);
+    LaunchScope ls(ctx, F16 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (F16 ? 6.0 : 8.0) * M * (double)K);
+    if (F16) f16_pack_launch(ctx, d_a, conv, M, K, M, 1);
+    else x3_pack_launch(ctx, d_a, conv, M, K, M, 1);
+    rc = ls.finish(F16 ? "pack_f16_kernel" : "pack_x3_kernel");
+    if (rc) return rc;
+    d_ax = conv;
+    mstride = M;
+  }
+  const double flops = 2.0 * M * (double)N * K;
+  const double bytes = (F16 ? 2.0 : 4.0) * ((double)N * K + (double)M * K) + 4.0 * (double)M * N;
+  // Block order with several row blocks: row block fastest, so the workgroups that multiply the same weight panel are
+  // neighbours on one XCD and stream it from L2 together instead of once per row block from HBM (measured, fp16, M = 960:
+  // N = 4096, K = 50176: 612 -> 555 us; M = 2000, K = 25088: 302 -> 282 us; with two column tiles (N = 256) it is 3 % slower,
+  // so only from 8 column tiles on).  MNC_FC_ORDER=0 / 1 forces the column-tile-fastest / row-block-fastest order.
+  static const char* order_env = getenv("MNC_FC_ORDER");
+  const bool rows_fastest = order_env ? atoi(order_env) == 1 : tn >= 8;
+  const int tm_arg = (rows_fastest && tm > 1) ? -tm : tm;
+  {
+    LaunchScope ls(ctx, F16 ? (small ? "fc_f16_small" : "fc_f16") : (small ? "fc_bf16x3_small" : "fc_bf16x3"), flops, bytes);
+#define MNC_X3_LAUNCH(MT, WR, A)                                                                                              \
+  hipLaunchKernelGGL((fc_x3_kernel<MT, WR, A, F16>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax,                 \
+                     (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, \
+                     tm_arg, mstride)
+    if (mt == 2) MNC_X3_LAUNCH(2, 2, 0);
+    else if (mt == 5) MNC_X3_LAUNCH(5, 1, 0);
+    else if (mt == 8) MNC_X3_LAUNCH(8, 2, 0);
+    else if constexpr (F16 != 0) {
+      MNC_X3_LAUNCH(10, 2, 0);
+    } else {
+      const char* e = getenv("MNC_FCX3_ABL");                       // ablation builds of the split-bf16 kernel (tuning)
+      const int abl = e ? atoi(e) : 0;
+      if (abl == 1) MNC_X3_LAUNCH(10, 2, 1);
+      else if (abl == 2) MNC_X3_LAUNCH(10, 2, 2);
+      else if (abl == 3) MNC_X3_LAUNCH(10, 2, 3);
+      else MNC_X3_LAUNCH(10, 2, 0);
+    }
+#undef MNC_X3_LAUNCH
+    rc = ls.finish(F16 ? "fc_x3_kernel<f16>" : "fc_x3_kernel");
+    if (rc) return rc;
+  }
+  if (splits > 1) {
+    LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
+    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
+    return ls.finish("fc_reduce_kernel");
+  }
+  return MNC_OK;
+}
+
 extern "C" {
 
 int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K) {
@@ -364,77 +477,16 @@ int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const 
   MNC_REQUIRE(ctx && d_a && d_w_packed && d_bias && d_out, "mnc_fc_bf16x3: null pointer");
   MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kXBK == 0 && ldc >= N && act >= 0 && act <= 2,
               "mnc_fc_bf16x3: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
-  if (M == 0) return MNC_OK;
-  // full 320-row blocks and a ragged tail of at most 160 rows are two launches, each with its own tile height (see mnc_fc)
-  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
-    const int head = M / 320 * 320;
-    int rc = mnc_fc_bf16x3(ctx, d_a, d_w_packed, d_bias, d_out, head, N, K, ldc, act);
-    if (rc) return rc;
-    return mnc_fc_bf16x3(ctx, d_a + (size_t)head * K, d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
-  }
-  // row tiles per workgroup: 2 (64 rows) for the small GEMMs, else the smallest of {5, 10} that covers M in one block
-  const bool small = 2.0 * M * (double)N * K < 2.0e9;
-  int mt = small ? 2 : (M <= 160 ? 5 : 10);
-  // 320-row blocks stream the weights once but need many K splits to fill the chip; when a split would be shorter than 64
-  // stages, 160-row blocks (twice the tiles, half the splits and half the partial-sum traffic) are faster (measured at
-  // M = 300: fc7 59 vs 69 us, fc6_maskest 132 vs 151 us, fc6 274 vs 262 us)
-  if (mt == 10 && (K / kXBK) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < 64) mt = 5;
-  if (const char* e = getenv("MNC_FCX3_TILE")) {          // tuning override
-    const int v = atoi(e);
-    if (v == 2 || v == 5 || v == 10) mt = v;
-  }
-  const int bm = 32 * mt;
-  const int tn = cdiv(N, kXBN), tm = cdiv(M, bm), stages = K / kXBK;
-  int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
-  const int min_stages = mt == 2 ? 2 : 8;
-  if (splits > stages / min_stages) splits = stages / min_stages;
-  if (splits < 1) splits = 1;
-  if (tm > 1 && mt != 2)     // several row blocks: split count by cost (mnc_internal.h: choose_splits); bf16 pipe ~2.3x the fp32 rate
-    splits = choose_splits(tn * tm, stages, min_stages, 256, (double)bm * kXBN * kXBK * 2.0 / 1050.0e3, 4.0 * M * (double)N);
-  const int kper = cdiv(stages, splits) * kXBK;
-  splits = cdiv(K, kper);
-  // scratch arena: [split-K partials | the activations split into hi/lo bf16 (same bytes as fp32)]
-  const size_t part_bytes = splits > 1 ? (((size_t)splits * M * N * 4 + 255) & ~(size_t)255) : 0;
-  int rc = ensure_scratch(ctx, part_bytes + (size_t)M * K * 4);
-  if (rc) return rc;
-  float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
-  uint4* d_ax = (uint4*)((char*)ctx->scratch + part_bytes);
-  {
-    // split once per call, not once per workgroup and stage
-    LaunchScope ls(ctx, "fc_bf16x3_split", 0.0, 8.0 * M * (double)K);
-    x3_pack_launch(ctx, d_a, d_ax, M, K, M, 1);
-    rc = ls.finish("pack_x3_kernel");
-    if (rc) return rc;
-  }
-  const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
-  {
-    LaunchScope ls(ctx, small ? "fc_bf16x3_small" : "fc_bf16x3", flops, bytes);
-    if (mt == 2)
-      hipLaunchKernelGGL((fc_x3_kernel<2, 2>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax, (const uint4*)d_w_packed,
-                         d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    else if (mt == 5)
-      hipLaunchKernelGGL((fc_x3_kernel<5, 1>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax, (const uint4*)d_w_packed,
-                         d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-    else {
-      const char* e = getenv("MNC_FCX3_ABL");
-      const int abl = e ? atoi(e) : 0;
-#define MNC_X3_CASE(A) hipLaunchKernelGGL((fc_x3_kernel<10, 2, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax, \
-                         (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
-      if (abl == 1) MNC_X3_CASE(1);
-      else if (abl == 2) MNC_X3_CASE(2);
-      else if (abl == 3) MNC_X3_CASE(3);
-      else MNC_X3_CASE(0);
-#undef MNC_X3_CASE
-    }
-    rc = ls.finish("fc_x3_kernel");
-    if (rc) return rc;
-  }
-  if (splits > 1) {
-    LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
-    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
-    return ls.finish("fc_reduce_kernel");
-  }
-  return MNC_OK;
+  return fc_lowp<0>(ctx, "mnc_fc_bf16x3", d_a, nullptr, M, d_w_packed, d_bias, d_out, M, N, K, ldc, act);
+}
+
+int mnc_fc_bf16x3_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias, float* d_out,
+                      int M, int N, int K, int ldc, int act) {
+  MNC_REQUIRE(ctx && d_a_sm && d_w_packed && d_bias && d_out, "mnc_fc_bf16x3_pre: null pointer");
+  MNC_REQUIRE(M >= 0 && m_stride >= M && N > 0 && K > 0 && K % kXBK == 0 && ldc >= N && act >= 0 && act <= 2,
+              "mnc_fc_bf16x3_pre: unsupported shape M=%d (stride %d) N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, m_stride, N, K,
+              ldc, act);
+  return fc_lowp<0>(ctx, "mnc_fc_bf16x3_pre", nullptr, (const uint4*)d_a_sm, m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act);
 }
 
 int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K) {
@@ -444,66 +496,32 @@ int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K
   return ls.finish("pack_f16_kernel");
 }
 
-// InnerProduct in fp16 arithmetic (fp32 accumulate): the launcher of mnc_fc_bf16x3 with 64-value stages.
+// InnerProduct in fp16 arithmetic (fp32 accumulate): the same launcher with 64-value stages.
 int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N, int K,
                int ldc, int act) {
   MNC_REQUIRE(ctx && d_a && d_w_packed && d_bias && d_out, "mnc_fc_f16: null pointer");
   MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2,
               "mnc_fc_f16: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%64==0)", M, N, K, ldc, act);
-  if (M == 0) return MNC_OK;
-  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
-    const int head = M / 320 * 320;               // full 320-row blocks, then the ragged tail (see mnc_fc)
-    int rc = mnc_fc_f16(ctx, d_a, d_w_packed, d_bias, d_out, head, N, K, ldc, act);
-    if (rc) return rc;
-    return mnc_fc_f16(ctx, d_a + (size_t)head * K, d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
-  }
-  const bool small = 2.0 * M * (double)N * K < 2.0e9;
-  int mt = small ? 2 : (M <= 160 ? 5 : 10);
-  if (mt == 10 && (K / 64) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < 32) mt = 5;      // short K splits: 160-row blocks
-  if (const char* e = getenv("MNC_FCX3_TILE")) {
-    const int v = atoi(e);
-    if (v == 2 || v == 5 || v == 10) mt = v;
-  }
-  const int bm = 32 * mt;
-  const int tn = cdiv(N, kXBN), tm = cdiv(M, bm), stages = K / 64;
-  int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
-  const int min_stages = mt == 2 ? 1 : 4;
-  if (splits > stages / min_stages) splits = stages / min_stages;
-  if (splits < 1) splits = 1;
-  if (tm > 1 && mt != 2)
-    splits = choose_splits(tn * tm, stages, min_stages, 256, (double)bm * kXBN * 64 * 2.0 / 2000.0e3, 4.0 * M * (double)N);
-  const int kper = cdiv(stages, splits) * 64;
-  splits = cdiv(K, kper);
-  // scratch arena: [split-K partials | the activations in fp16, stage-major]
-  const size_t part_bytes = splits > 1 ? (((size_t)splits * M * N * 4 + 255) & ~(size_t)255) : 0;
-  int rc = ensure_scratch(ctx, part_bytes + (size_t)M * K * 2);
-  if (rc) return rc;
-  float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
-  uint4* d_ax = (uint4*)((char*)ctx->scratch + part_bytes);
-  {
-    LaunchScope ls(ctx, "fc_f16_convert", 0.0, 6.0 * M * (double)K);
-    f16_pack_launch(ctx, d_a, d_ax, M, K, M, 1);
-    rc = ls.finish("pack_f16_kernel");
-    if (rc) return rc;
-  }
-  const double flops = 2.0 * M * (double)N * K, bytes = 2.0 * ((double)N * K + (double)M * K) + 4.0 * (double)M * N;
-  {
-    LaunchScope ls(ctx, small ? "fc_f16_small" : "fc_f16", flops, bytes);
-#define MNC_F16_LAUNCH(MT, WR) hipLaunchKernelGGL((fc_x3_kernel<MT, WR, 0, 1>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, \
-                         d_ax, (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
-    if (mt == 2) MNC_F16_LAUNCH(2, 2);
-    else if (mt == 5) MNC_F16_LAUNCH(5, 1);
-    else MNC_F16_LAUNCH(10, 2);
-#undef MNC_F16_LAUNCH
-    rc = ls.finish("fc_x3_kernel<f16>");
-    if (rc) return rc;
-  }
-  if (splits > 1) {
-    LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
-    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
-    return ls.finish("fc_reduce_kernel");
-  }
-  return MNC_OK;
+  return fc_lowp<1>(ctx, "mnc_fc_f16", d_a, nullptr, M, d_w_packed, d_bias, d_out, M, N, K, ldc, act);
+}
+
+int mnc_fc_f16_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias, float* d_out,
+                   int M, int N, int K, int ldc, int act) {
+  MNC_REQUIRE(ctx && d_a_sm && d_w_packed && d_bias && d_out, "mnc_fc_f16_pre: null pointer");
+  MNC_REQUIRE(M >= 0 && m_stride >= M && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2,
+              "mnc_fc_f16_pre: unsupported shape M=%d (stride %d) N=%d K=%d ldc=%d act=%d (need K%%64==0)", M, m_stride, N, K, ldc,
+              act);
+  return fc_lowp<1>(ctx, "mnc_fc_f16_pre", nullptr, (const uint4*)d_a_sm, m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act);
+}
+
+// fp32 row-major [M][K] -> the stage-major 2-byte activation form of mnc_fc_{f16,bf16x3}_pre (what those entry points' producers
+// write in their epilogues): f16 != 0: [K/64][M][64 halves], M*K*2 bytes; else [K/32][M][(hi x8 | lo x8) x 4] bf16, M*K*4 bytes.
+int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, int f16) {
+  MNC_REQUIRE(ctx && d_a && d_a_sm && M > 0 && K > 0 && K % (f16 ? 64 : kXBK) == 0, "mnc_fc_pack_act: bad argument");
+  LaunchScope ls(ctx, f16 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (f16 ? 6.0 : 8.0) * M * (double)K);
+  if (f16) f16_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
+  else x3_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
+  return ls.finish(f16 ? "pack_f16_kernel" : "pack_x3_kernel");
 }
 
 }  // extern "C"

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__
 }
 
 constexpr int kMaxScanBlocks = 512;  // device scan handles cb <= 512, i.e. n <= 32768
+constexpr int kSurvCap = 4096;        // survivor list of the scan (LDS, 8 KB): used when min(max_keep, n) fits
 
 __device__ __forceinline__ u64 uniform64(u64 v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -100,29 +101,25 @@ __device__ __forceinline__ u64 lane64(u64 v) {
   return ((u64)hi << 32) | lo;
 }
 
-// One step of the greedy in-block chain (nms_kernel.cu:128-139), entirely on the scalar unit.
-template <int I>
-__device__ __forceinline__ void resolve_step(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
-  const u64 di = lane64<I>(diag);
-  if (I < rows && nk < max_keep && !((cur >> I) & 1ull)) {
-    kept |= 1ull << I;
+// The greedy chain inside one 64-box block (nms_kernel.cu:128-139) on the scalar unit, visiting only the SURVIVORS: a row
+// survives iff no earlier survivor suppressed it, so the next survivor is always the lowest row not yet suppressed
+// (s_ff1 on the complement of the removal word), and keeping it ORs its word in.  A block of RPN boxes keeps 3-10 of its 64
+// rows; stepping through all 64 rows one readlane pair at a time was ~0.8 us of the ~1.6 us a block took.
+// diag: lane i holds the word of row i in the block's own column tile; cur: removal word so far (uniform); rows: valid rows.
+__device__ __forceinline__ void resolve_block(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
+  const u64 valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+  u64 live = uniform64(~cur & valid);
+  const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+  while (live != 0ull && nk < max_keep) {
+    const int i = __builtin_ctzll(live);
+    const u64 di = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+    kept |= 1ull << i;
     cur |= di;
+    live &= ~di;
+    live &= ~(1ull << i);
     ++nk;
   }
 }
-template <int I0, int N>
-struct Resolve {
-  static __device__ __forceinline__ void run(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
-    Resolve<I0, N / 2>::run(diag, rows, max_keep, cur, kept, nk);
-    Resolve<I0 + N / 2, N - N / 2>::run(diag, rows, max_keep, cur, kept, nk);
-  }
-};
-template <int I0>
-struct Resolve<I0, 1> {
-  static __device__ __forceinline__ void run(u64 diag, int rows, int max_keep, u64& cur, u64& kept, int& nk) {
-    resolve_step<I0>(diag, rows, max_keep, cur, kept, nk);
-  }
-};
 
 // grid: batch; block: ONE wave.  Greedy scan of nms_kernel.cu:124-140 on the column-block-major bitmask, stopping after
 // max_keep survivors.  Per 64-box block:
@@ -135,12 +132,60 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
                                                       int n_stride, int cb_cap, int max_keep, int* __restrict__ keep,
                                                       int* __restrict__ num_out) {
   __shared__ u64 s_kept[kMaxScanBlocks];
+  __shared__ unsigned short s_surv[kSurvCap];       // rows of the survivors so far (n <= 32768: a row fits in 16 bits)
   const int lane = threadIdx.x;
   const int n = n_ptr ? *n_ptr : n_arg;
   const int cb = (n + 63) >> 6;
   const u64* m = mask + (long)blockIdx.x * cb_cap * n_stride;
   int* kp = keep + (long)blockIdx.x * n_stride;
   int nk = 0;
+  // With a bounded survivor count (ProposalLayer: 300 / 1000 of 6000; voting: 100 per class) the removal word of a block is the OR
+  // over the LIST of survivors -- ceil(nk / 64) loads per block -- instead of a pass over every earlier block (blk loads per
+  // block, cb^2 / 2 = 4400 wave loads at n = 6000).  Same set of words, same result.
+  if (min(max_keep, n) <= kSurvCap) {
+    // The words of column tile c are requested TWO blocks ahead (while block c - 2 is resolved), so that the load latency
+    // (~1 us: the mask was written by other XCDs and comes from Infinity Cache) is not paid once per block: at that time the
+    // survivors of blocks < c - 2 are known (list loads), blocks c - 2 and c - 1 are not -- so ALL their rows' words for
+    // tile c are fetched (one coalesced 512-byte load each) and a row's word is folded in once its block is resolved and
+    // the row turned out to survive.  part* are lane-local partial ORs; the wave-wide OR happens when the tile is consumed.
+    auto word = [&](int c, int row) -> u64 { return (c < cb && row < n) ? m[(long)c * n_stride + row] : 0ull; };
+    // tile 0: nothing precedes it; tile 1: only block 0 precedes it
+    u64 part0 = 0, diag0 = word(0, lane);
+    u64 part1 = 0, prev1 = word(1, lane), diag1 = word(1, 64 + lane);        // prev1: rows of block 0 in tile 1
+    for (int blk = 0; blk < cb && nk < max_keep; ++blk) {
+      // request tile blk + 2: known survivors (blocks < blk), every row of blocks blk and blk + 1, its own diagonal rows
+      const int c2 = blk + 2;
+      u64 part2 = 0;
+      if (c2 < cb)
+        for (int s = lane; s < nk; s += 64) part2 |= m[(long)c2 * n_stride + s_surv[s]];
+      const u64 rows2a = word(c2, blk * 64 + lane), rows2b = word(c2, (blk + 1) * 64 + lane), diag2 = word(c2, c2 * 64 + lane);
+      // consume tile blk
+      u64 acc = part0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
+      u64 cur = uniform64(acc);
+      const int rows = min(n - blk * 64, 64);
+      u64 kept = 0;
+      const int nk0 = nk;
+      resolve_block(diag0, rows, max_keep, cur, kept, nk);
+      const bool mine = (kept >> lane) & 1ull;
+      if (mine) {
+        const int pos = nk0 + __popcll(kept & ((1ull << lane) - 1ull));
+        kp[pos] = blk * 64 + lane;
+        s_surv[pos] = (unsigned short)(blk * 64 + lane);
+      }
+      // fold this block's survivors into the two tiles already in flight, then advance the window
+      part0 = part1 | (mine ? prev1 : 0ull);
+      diag0 = diag1;
+      part1 = part2 | (mine ? rows2a : 0ull);
+      prev1 = rows2b;
+      diag1 = diag2;
+      __syncthreads();                               // s_surv of this block is read by the next iteration's list loads
+    }
+    if (lane == 0) num_out[blockIdx.x] = nk;
+    return;
+  }
+  // unbounded survivor count (mnc_nms with max_keep < 0 on a large n): one pass over the earlier blocks per block
   for (int blk = 0; blk < cb && nk < max_keep; ++blk) {
     const u64* col = m + (long)blk * n_stride;
     u64 acc = 0;
@@ -154,7 +199,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
     const int rows = min(n - blk * 64, 64);
     u64 kept = 0;
     const int nk0 = nk;
-    Resolve<0, 64>::run(diag, rows, max_keep, cur, kept, nk);
+    resolve_block(diag, rows, max_keep, cur, kept, nk);
     if ((kept >> lane) & 1ull) kp[nk0 + __popcll(kept & ((1ull << lane) - 1ull))] = row;
     if (lane == 0) s_kept[blk] = kept;
     __syncthreads();

@@ -88,6 +88,9 @@ struct mnc_net {
   int cap_ph = 0, cap_pw = 0, cap_src = 0;
   DevBuf img, taps, data, act[13], pooled[4], rpn_out, rpn_score, rpn_bbox, rpn_prob;
   DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores, records, counts;
+  // the per-RoI tensors a second time, in the stage-major 2-byte form their reduced-precision InnerProduct multiplies from
+  // (written by the producing kernel's epilogue: mnc_roi_warp_sm / mnc_maxpool2_rhwc_sm / mnc_mask_pool_sm), bf16x3 / f16 modes
+  DevBuf feat14_sm, box7_sm, mask7_sm;
   unsigned char* pin_img = nullptr; size_t pin_img_cap = 0;
   float* pin_out = nullptr; size_t pin_out_cap = 0;       // [counts (64 ints) | proposal count (64 ints) | records]
   // per-image state
@@ -193,6 +196,23 @@ int run_fc(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, float* out, int 
 int run_fc(mnc_net* n, const mnc_net::Fc& fc, const float* a, float* out, int M, int ldc, int act) {
   return run_fc(n->ctx, fc, a, out, M, ldc, act);
 }
+// 1 (fp16) / 2 (split bf16): the stage-major activation form this InnerProduct's kernel multiplies from, when the producer of its
+// per-RoI input (C channels per position) can write it (an 8-channel group must not straddle a stage); 0: fp32 rows only.
+// MNC_FC_SM=0 switches the second outputs off (the InnerProduct then converts the fp32 rows itself, as in round 1).
+int sm_format(const mnc_net::Fc& fc, int C) {
+  static const bool off = getenv("MNC_FC_SM") && atoi(getenv("MNC_FC_SM")) == 0;
+  if (off) return 0;
+  if (fc.kind == 2) return C % 64 == 0 ? 1 : 0;
+  if (fc.kind == 1) return C % 32 == 0 ? 2 : 0;
+  return 0;
+}
+// the InnerProduct on rows that exist in both forms: a_sm (m_stride = M rows) when the kernel takes it, the fp32 rows otherwise
+int run_fc_sm(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, const void* a_sm, int fmt, float* out, int M, int ldc, int act) {
+  if (M == 0) return MNC_OK;
+  if (fmt == 1) return mnc_fc_f16_pre(ctx, a_sm, M, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  if (fmt == 2) return mnc_fc_bf16x3_pre(ctx, a_sm, M, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  return run_fc(ctx, fc, a, out, M, ldc, act);
+}
 
 int finalize(mnc_net* n) {
   if (n->finalized) return MNC_OK;
@@ -295,6 +315,9 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   NET_TRY(dev_ensure(n, &n->m14, (size_t)R * P * P * 4));
   NET_TRY(dev_ensure(n, &n->box7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
   NET_TRY(dev_ensure(n, &n->mask7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
+  if (sm_format(n->fc_maskest, C5)) NET_TRY(dev_ensure(n, &n->feat14_sm, (size_t)R * P * P * C5 * (n->fc_maskest.kind == 2 ? 2 : 4)));
+  if (sm_format(n->fc6, C5)) NET_TRY(dev_ensure(n, &n->box7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6.kind == 2 ? 2 : 4)));
+  if (sm_format(n->fc6m, C5)) NET_TRY(dev_ensure(n, &n->mask7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6m.kind == 2 ? 2 : 4)));
   NET_TRY(dev_ensure(n, &n->f6, (size_t)R * F * 4));
   NET_TRY(dev_ensure(n, &n->f6m, (size_t)R * F * 4));
   NET_TRY(dev_ensure(n, &n->join, (size_t)R * 2 * F * 4));
@@ -438,9 +461,11 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   const float* conv5 = (const float*)n->act[12].p;
   float* feat14 = (float*)n->feat14.p;
   // stage 2: ROIWarping 28x28 + MAX 2x2/2 fused; stage 4: ROIWarping 14x14 directly (test.prototxt:479-505 vs :809-820)
-  NET_TRY(mnc_roi_warp(ctx, conv5, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14));
+  const int sm_feat = sm_format(n->fc_maskest, C5), sm_box = sm_format(n->fc6, C5), sm_mask = sm_format(n->fc6m, C5);
+  NET_TRY(mnc_roi_warp_sm(ctx, conv5, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14, n->feat14_sm.p,
+                          sm_feat));
   float* masks = (float*)n->masks.p + (size_t)row0 * S * S;
-  NET_TRY(run_fc(n, n->fc_maskest, feat14, (float*)n->h_mask.p, R, c.mask_fc, 1));
+  NET_TRY(run_fc_sm(ctx, n->fc_maskest, feat14, n->feat14_sm.p, sm_feat, (float*)n->h_mask.p, R, c.mask_fc, 1));
   NET_TRY(run_fc(n, n->fc_maskpred, (const float*)n->h_mask.p, masks, R, S * S, 2));            // + Sigmoid; MaskLayer = reshape
   NET_TRY(mnc_mask_resize(ctx, masks, (float*)n->m14.p, R, S, S, P, P));
   float* join = (float*)n->join.p;                                                             // Concat(fc7_mask, fc7): column slices
@@ -452,12 +477,12 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
     MNC_HIP_TRY(hipEventRecord(n->ev_fork[si], ctx->stream));                                   // feat14 is complete
     MNC_HIP_TRY(hipStreamWaitEvent(cb->stream, n->ev_fork[si], 0));
   }
-  NET_TRY(mnc_maxpool2_rhwc(cb, feat14, (float*)n->box7.p, R, P, P, C5));
-  NET_TRY(run_fc(cb, n->fc6, (const float*)n->box7.p, (float*)n->f6.p, R, F, 1));
+  NET_TRY(mnc_maxpool2_rhwc_sm(cb, feat14, (float*)n->box7.p, R, P, P, C5, n->box7_sm.p, sm_box));
+  NET_TRY(run_fc_sm(cb, n->fc6, (const float*)n->box7.p, n->box7_sm.p, sm_box, (float*)n->f6.p, R, F, 1));
   NET_TRY(run_fc(cb, n->fc7, (const float*)n->f6.p, join + F, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipEventRecord(n->ev_join[si], cb->stream));
-  NET_TRY(mnc_mask_pool(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1));
-  NET_TRY(run_fc(n, n->fc6m, (const float*)n->mask7.p, (float*)n->f6m.p, R, F, 1));
+  NET_TRY(mnc_mask_pool_sm(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1, n->mask7_sm.p, sm_mask));
+  NET_TRY(run_fc_sm(ctx, n->fc6m, (const float*)n->mask7.p, n->mask7_sm.p, sm_mask, (float*)n->f6m.p, R, F, 1));
   NET_TRY(run_fc(n, n->fc7m, (const float*)n->f6m.p, join, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));
   float* heads = (float*)n->heads.p;
@@ -737,6 +762,7 @@ int mnc_net_destroy(mnc_net* net) {
   if (net->gexec) (void)hipGraphExecDestroy(net->gexec);
   DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_bbox, &net->rpn_prob, &net->rois,
                     &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
+                    &net->feat14_sm, &net->box7_sm, &net->mask7_sm,
                     &net->heads, &net->boxes, &net->masks, &net->scores, &net->records, &net->counts};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);

@@ -10,8 +10,10 @@
 // staging is needed because conv5_3 (4.9 MB at 600x1000) stays L2/Infinity-Cache resident across the 300 RoIs; ROIWarping
 // first re-lays it out pixel-major so that every bilinear tap of a wave is one contiguous kilobyte.
 #include <cfloat>
+#include <cstdlib>
 
 #include "mnc_internal.h"
+#include "x3_split.h"
 
 namespace mnc {
 
@@ -31,6 +33,41 @@ __global__ __launch_bounds__(256) void c8_to_hwc_kernel(const float* __restrict_
     const int cb = (int)(t % CB);
     const long p = t / CB;
     *reinterpret_cast<float4*>(out + (p * CB + cb) * 8 + half * 4) = ld4(in + ((long)cb * HW + p) * 8 + half * 4);
+  }
+}
+
+// Second output of the per-RoI producers: the tensor in the stage-major 2-byte form the reduced-precision InnerProducts multiply
+// from (mnc_hip.h: mnc_fc_{f16,bf16x3}_pre), written by the threads that hold the fp32 values -- the FC's own conversion pass
+// (read M x K fp32, write M x K halves; 0.2 ms per image at 300 RoIs, 0.75 ms at 1000 RoIs x 1024 channels) disappears.
+// SM: 0 none, 1 = fp16 [K/64][M][64], 2 = split bf16 [K/32][M][4][hi x8 | lo x8]; k = position * C + channel.
+// A thread owns 4 consecutive channels (k a multiple of 4), its neighbour lane (lane ^ 1) the other half of the same 8-channel
+// group: the two exchange halves so that every store is a full 16-byte group (8-byte stores from every lane measured 15-20 %
+// slower on these kernels: 521 vs 430 us for the 14x14 warp of 1000 RoIs x 1024 channels).  All 64 lanes must call it together
+// (the callers' element counts are multiples of 64 per wave: C % 8 == 0 and whole positions).
+template <int SM>
+__device__ __forceinline__ void sm_store4(void* __restrict__ sm, long M, long r, long k, const float4 v) {
+  const bool odd = (k >> 2) & 1;
+  const long k8 = k & ~7L;
+  if (SM == 1) {
+    const uint2 mine = x3_f16x4(v);
+    const unsigned ox = __shfl_xor(mine.x, 1), oy = __shfl_xor(mine.y, 1);
+    if (!odd) reinterpret_cast<uint4*>(sm)[((k8 >> 6) * M + r) * 8 + ((k8 & 63) >> 3)] = make_uint4(mine.x, mine.y, ox, oy);
+  } else if (SM == 2) {
+    unsigned h[4], l[4];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = x3_rne(x[e]);
+      l[e] = x3_rne(x[e] - __uint_as_float(h[e]));
+    }
+    const uint2 hi = make_uint2(x3_pack_hi16(h[0], h[1]), x3_pack_hi16(h[2], h[3]));
+    const uint2 lo = make_uint2(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]));
+    // the even lane writes the group's hi x8 (its own half, then the neighbour's), the odd lane the lo x8 (neighbour's, then own)
+    const uint2 give = odd ? hi : lo;
+    const uint2 got = make_uint2(__shfl_xor(give.x, 1), __shfl_xor(give.y, 1));
+    uint4* p = reinterpret_cast<uint4*>(sm) + (((k8 >> 5) * M + r) * 4 + ((k8 & 31) >> 3)) * 2;
+    if (!odd) p[0] = make_uint4(hi.x, hi.y, got.x, got.y);
+    else p[1] = make_uint4(got.x, got.y, lo.x, lo.y);
   }
 }
 
@@ -57,20 +94,22 @@ __device__ __forceinline__ float4 warp_sample(const float* __restrict__ px, int 
 // thread = (roi, ph, pw, 4-channel group); channels fastest -> a wave reads 1 KB contiguous per tap and writes 1 KB.
 // SPEC-CHOICE (SPEC.md 1): un-rounded edges x*scale; roi_w = max(x2s-x1s+1, 1); bin = roi_w/PWs; sample at x1s + pw*bin.
 // POOL2: the warp grid is (2PH)x(2PW) and each output is the max of its 2x2 samples (the fused Pooling layer).
-template <int POOL2>
+template <int POOL2, int SM>
 __global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
                                                        const float* __restrict__ rois, int R, int PH, int PW, float scale,
-                                                       float* __restrict__ out) {
-  const int C4 = C >> 2;
-  const long total = (long)R * PH * PW * C4;
+                                                       float* __restrict__ out, void* __restrict__ sm) {
+  const unsigned C4 = (unsigned)C >> 2;
+  // 32-bit index arithmetic (the launcher checks total < 2^31): three 64-bit divisions by run-time values were ~400 of the ~700
+  // VALU instructions of an iteration of this kernel
+  const unsigned total = (unsigned)R * PH * PW * C4;
   const int GH = POOL2 ? 2 * PH : PH, GW = POOL2 ? 2 * PW : PW;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % C4);
-    long t = idx / C4;
-    const int pw = (int)(t % PW);
-    t /= PW;
-    const int ph = (int)(t % PH);
-    const int r = (int)(t / PH);
+    unsigned t = idx / C4;
+    const int pw = (int)(t % (unsigned)PW);
+    t /= (unsigned)PW;
+    const int ph = (int)(t % (unsigned)PH);
+    const int r = (int)(t / (unsigned)PH);
     const float* roi = rois + (long)r * 5;
     const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
     const float rw = fmaxf(x2s - x1s + 1.0f, 1.0f), rh = fmaxf(y2s - y1s + 1.0f, 1.0f);
@@ -85,27 +124,30 @@ __global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__
     } else {
       o = warp_sample(px, H, W, C, x1s + (float)pw * bw, y1s + (float)ph * bh);
     }
-    *reinterpret_cast<float4*>(out + idx * 4) = o;      // == (((r*PH + ph)*PW + pw)*C + c4*4)
+    *reinterpret_cast<float4*>(out + (long)idx * 4) = o;      // == (((r*PH + ph)*PW + pw)*C + c4*4)
+    if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
   }
 }
 
 // [R][PH][PW][C] -> [R][PH/2][PW/2][C], MAX 2x2/2 (PH, PW even on this path: 28->14, 14->7)
+template <int SM>
 __global__ __launch_bounds__(256) void maxpool2_rhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
-                                                            int PH, int PW, int C4) {
+                                                            int PH, int PW, int C4, void* __restrict__ sm) {
   const int OH = PH / 2, OW = PW / 2;
-  const long total = (long)R * OH * OW * C4;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    long t = idx / C4;
-    const int ow = (int)(t % OW);
-    t /= OW;
-    const int oh = (int)(t % OH);
-    const long r = t / OH;
+  const unsigned total = (unsigned)R * OH * OW * C4;              // < 2^31 (checked by the launcher): 32-bit divisions
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % (unsigned)C4);
+    unsigned t = idx / (unsigned)C4;
+    const int ow = (int)(t % (unsigned)OW);
+    t /= (unsigned)OW;
+    const int oh = (int)(t % (unsigned)OH);
+    const long r = t / (unsigned)OH;
     const float* p = in + (((r * PH + 2 * oh) * PW + 2 * ow) * C4 + c4) * 4;
     float4 m = max4(ld4(p), ld4(p + (long)C4 * 4));
     m = max4(m, ld4(p + (long)PW * C4 * 4));
     m = max4(m, ld4(p + (long)(PW + 1) * C4 * 4));
-    *reinterpret_cast<float4*>(out + idx * 4) = m;
+    *reinterpret_cast<float4*>(out + (long)idx * 4) = m;
+    if (SM) sm_store4<SM>(sm, R, r, ((long)oh * OW + ow) * C4 * 4 + c4 * 4, m);
   }
 }
 
@@ -132,18 +174,19 @@ __global__ void mask_resize_kernel(const float* __restrict__ in, float* __restri
 }
 
 // SPEC-CHOICE (SPEC.md 3): feature * continuous mask, broadcast over channels; POOL2 fuses the MAX 2x2/2 that follows.
-template <int POOL2>
+template <int POOL2, int SM>
 __global__ __launch_bounds__(256) void mask_pool_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
-                                                        float* __restrict__ out, int R, int PH, int PW, int C4) {
+                                                        float* __restrict__ out, int R, int PH, int PW, int C4,
+                                                        void* __restrict__ sm) {
   const int OH = POOL2 ? PH / 2 : PH, OW = POOL2 ? PW / 2 : PW;
-  const long total = (long)R * OH * OW * C4;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    long t = idx / C4;
-    const int ow = (int)(t % OW);
-    t /= OW;
-    const int oh = (int)(t % OH);
-    const long r = t / OH;
+  const unsigned total = (unsigned)R * OH * OW * C4;              // < 2^31 (checked by the launcher): 32-bit divisions
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % (unsigned)C4);
+    unsigned t = idx / (unsigned)C4;
+    const int ow = (int)(t % (unsigned)OW);
+    t /= (unsigned)OW;
+    const int oh = (int)(t % (unsigned)OH);
+    const long r = t / (unsigned)OH;
     auto prod = [&](int h, int w) {
       const float mk = mask[(r * PH + h) * PW + w];
       const float4 f = ld4(feat + (((r * PH + h) * PW + w) * C4 + c4) * 4);
@@ -155,9 +198,224 @@ __global__ __launch_bounds__(256) void mask_pool_kernel(const float* __restrict_
     } else {
       v = prod(oh, ow);
     }
-    *reinterpret_cast<float4*>(out + idx * 4) = v;
+    *reinterpret_cast<float4*>(out + (long)idx * 4) = v;
+    if (SM) sm_store4<SM>(sm, R, r, ((long)oh * OW + ow) * C4 * 4 + c4 * 4, v);
   }
 }
+
+
+// ---- ROIWarping, one wave per output position ------------------------------------------------------------------------------
+// All channels of an output position (r, ph, pw) share its sample coordinates, bilinear weights and tap validity.  The kernels
+// above recompute them in every thread (4 channels each): ~120 of their ~260 VALU instructions per output at POOL2, on top of
+// three run-time integer divisions.  Here a wave takes whole positions: the position is wave-uniform (scalar unit), the sample
+// set-up runs once per position, and the lanes stride over the channel groups (4 iterations at C = 1024, 2 at C = 512) doing
+// only taps x weights -- in the same operation order as warp_sample, value for value.  Positions whose taps all lie inside the
+// map (almost all) take straight-line unconditional loads; the others select zero taps as before.
+struct WarpSample {
+  int off;                           // ((y0 * W + x0) * C), clamped into the map for the unconditional loads
+  float w00, w01, w10, w11;
+  bool v00, v01, v10, v11;
+};
+
+__device__ __forceinline__ WarpSample warp_setup(int H, int W, int C, float sx, float sy) {
+  WarpSample s;
+  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  const float ax = sx - (float)x0, ay = sy - (float)y0;
+  s.w00 = (1.0f - ax) * (1.0f - ay); s.w01 = ax * (1.0f - ay); s.w10 = (1.0f - ax) * ay; s.w11 = ax * ay;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  s.v00 = vy0 && vx0; s.v01 = vy0 && vx1; s.v10 = vy1 && vx0; s.v11 = vy1 && vx1;
+  s.off = (min(max(y0, 0), H - 2) * W + min(max(x0, 0), W - 2)) * C;       // any in-map 2x2 cell when a tap is outside
+  return s;
+}
+
+// every tap of the sample is inside the map (off is the true cell): unconditional loads
+__device__ __forceinline__ float4 warp_taps(const float* __restrict__ px, int W, int C, const WarpSample& s) {
+  const float* p00 = px + s.off;
+  const float* p10 = p00 + (long)W * C;
+  const float4 a00 = ld4(p00), a01 = ld4(p00 + C), a10 = ld4(p10), a11 = ld4(p10 + C);
+#define MNC_BL(f) (s.w00 * a00.f + s.w01 * a01.f + s.w10 * a10.f + s.w11 * a11.f)
+  return make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
+#undef MNC_BL
+}
+
+template <int POOL2, int SM>
+__global__ __launch_bounds__(256) void roi_warp_wave_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
+                                                            const float* __restrict__ rois, int R, int PH, int PW, float scale,
+                                                            float* __restrict__ out, void* __restrict__ sm) {
+  constexpr int NS = POOL2 ? 4 : 1;
+  const int C4 = C >> 2, lane = threadIdx.x & 63;
+  const unsigned npos = (unsigned)R * PH * PW;
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int GH = POOL2 ? 2 * PH : PH, GW = POOL2 ? 2 * PW : PW;
+  for (unsigned p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; p < npos; p += nwaves) {
+    const unsigned pos = __builtin_amdgcn_readfirstlane(p);        // wave-uniform: the index arithmetic runs on the scalar unit
+    const int pw = (int)(pos % (unsigned)PW);
+    const unsigned t = pos / (unsigned)PW;
+    const int ph = (int)(t % (unsigned)PH), r = (int)(t / (unsigned)PH);
+    const float* roi = rois + (long)r * 5;
+    const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
+    const float rw = fmaxf(x2s - x1s + 1.0f, 1.0f), rh = fmaxf(y2s - y1s + 1.0f, 1.0f);
+    const float bw = rw / (float)GW, bh = rh / (float)GH;
+    WarpSample smp[NS];
+    bool safe = true;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int gx = POOL2 ? 2 * pw + (i & 1) : pw, gy = POOL2 ? 2 * ph + (i >> 1) : ph;
+      smp[i] = warp_setup(H, W, C, x1s + (float)gx * bw, y1s + (float)gy * bh);
+      safe = safe && smp[i].v00 && smp[i].v01 && smp[i].v10 && smp[i].v11;
+    }
+    float* orow = out + (long)pos * C;
+    if (safe) {
+      for (int c4 = lane; c4 < C4; c4 += 64) {
+        const float* px = feat_hwc + c4 * 4;
+        float4 o = warp_taps(px, W, C, smp[0]);
+#pragma unroll
+        for (int i = 1; i < NS; ++i) o = max4(o, warp_taps(px, W, C, smp[i]));
+        *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+        if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
+      }
+    } else {
+      for (int c4 = lane; c4 < C4; c4 += 64) {
+        const float* px = feat_hwc + c4 * 4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int gx = POOL2 ? 2 * pw + (i & 1) : pw, gy = POOL2 ? 2 * ph + (i >> 1) : ph;
+          const float4 v = warp_sample(px, H, W, C, x1s + (float)gx * bw, y1s + (float)gy * bh);
+          o = i == 0 ? v : max4(o, v);
+        }
+        *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+        if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
+      }
+    }
+  }
+}
+
+// ---- 8 channels per thread: the variant used when a second output is written (except the fused 28x28 warp).  A thread then owns
+// a whole 16-byte group of the stage-major tensor, and the per-thread index arithmetic of the second output is spent once per 8
+// channels: measured at 1000 RoIs x 1024 channels with the fp16 second output: 14x14 warp 430 us (4 channels per thread + lane
+// exchange: 520; no second output: 432), MAX pool 175 (190; 174), MaskPooling + pool 184 (192; 173).  Same fp32 arithmetic.
+template <int SM>
+__device__ __forceinline__ void sm_store8(void* __restrict__ sm, long M, long r, long k, const float4 a, const float4 b) {
+  if (SM == 1) {
+    const uint2 lo = x3_f16x4(a), hi = x3_f16x4(b);
+    reinterpret_cast<uint4*>(sm)[((k >> 6) * M + r) * 8 + ((k & 63) >> 3)] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  } else {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint4 hi, lo;
+    x3_split8_rne(x, hi, lo);
+    uint4* p = reinterpret_cast<uint4*>(sm) + (((k >> 5) * M + r) * 4 + ((k & 31) >> 3)) * 2;
+    p[0] = hi;
+    p[1] = lo;
+  }
+}
+
+template <int POOL2, int SM>
+__global__ __launch_bounds__(256) void roi_warp8_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
+                                                        const float* __restrict__ rois, int R, int PH, int PW, float scale,
+                                                        float* __restrict__ out, void* __restrict__ sm) {
+  const unsigned C8 = (unsigned)C >> 3;
+  const unsigned total = (unsigned)R * PH * PW * C8;
+  const int GH = POOL2 ? 2 * PH : PH, GW = POOL2 ? 2 * PW : PW;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % C8);
+    unsigned t = idx / C8;
+    const int pw = (int)(t % (unsigned)PW);
+    t /= (unsigned)PW;
+    const int ph = (int)(t % (unsigned)PH);
+    const int r = (int)(t / (unsigned)PH);
+    const float* roi = rois + (long)r * 5;
+    const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
+    const float rw = fmaxf(x2s - x1s + 1.0f, 1.0f), rh = fmaxf(y2s - y1s + 1.0f, 1.0f);
+    const float bw = rw / (float)GW, bh = rh / (float)GH;
+    float4 o[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* px = feat_hwc + c8 * 8 + h * 4;
+      if (POOL2) {
+        o[h] = warp_sample(px, H, W, C, x1s + (float)(2 * pw) * bw, y1s + (float)(2 * ph) * bh);
+        o[h] = max4(o[h], warp_sample(px, H, W, C, x1s + (float)(2 * pw + 1) * bw, y1s + (float)(2 * ph) * bh));
+        o[h] = max4(o[h], warp_sample(px, H, W, C, x1s + (float)(2 * pw) * bw, y1s + (float)(2 * ph + 1) * bh));
+        o[h] = max4(o[h], warp_sample(px, H, W, C, x1s + (float)(2 * pw + 1) * bw, y1s + (float)(2 * ph + 1) * bh));
+      } else {
+        o[h] = warp_sample(px, H, W, C, x1s + (float)pw * bw, y1s + (float)ph * bh);
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(out + (long)idx * 8);      // == (((r*PH + ph)*PW + pw)*C + c8*8)
+    dst[0] = o[0];
+    dst[1] = o[1];
+    sm_store8<SM>(sm, R, r, ((long)ph * PW + pw) * C + c8 * 8, o[0], o[1]);
+  }
+}
+
+template <int SM>
+__global__ __launch_bounds__(256) void maxpool2_rhwc8_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int PH,
+                                                             int PW, int C8, void* __restrict__ sm) {
+  const int OH = PH / 2, OW = PW / 2;
+  const unsigned total = (unsigned)R * OH * OW * C8;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % (unsigned)C8);
+    unsigned t = idx / (unsigned)C8;
+    const int ow = (int)(t % (unsigned)OW);
+    t /= (unsigned)OW;
+    const int oh = (int)(t % (unsigned)OH);
+    const long r = t / (unsigned)OH;
+    float4 m[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* p = in + (((r * PH + 2 * oh) * PW + 2 * ow) * C8 + c8) * 8 + h * 4;
+      m[h] = max4(ld4(p), ld4(p + (long)C8 * 8));
+      m[h] = max4(m[h], ld4(p + (long)PW * C8 * 8));
+      m[h] = max4(m[h], ld4(p + (long)(PW + 1) * C8 * 8));
+    }
+    float4* dst = reinterpret_cast<float4*>(out + (long)idx * 8);
+    dst[0] = m[0];
+    dst[1] = m[1];
+    sm_store8<SM>(sm, R, r, ((long)oh * OW + ow) * C8 * 8 + c8 * 8, m[0], m[1]);
+  }
+}
+
+template <int POOL2, int SM>
+__global__ __launch_bounds__(256) void mask_pool8_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
+                                                         float* __restrict__ out, int R, int PH, int PW, int C8,
+                                                         void* __restrict__ sm) {
+  const int OH = POOL2 ? PH / 2 : PH, OW = POOL2 ? PW / 2 : PW;
+  const unsigned total = (unsigned)R * OH * OW * C8;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % (unsigned)C8);
+    unsigned t = idx / (unsigned)C8;
+    const int ow = (int)(t % (unsigned)OW);
+    t /= (unsigned)OW;
+    const int oh = (int)(t % (unsigned)OH);
+    const long r = t / (unsigned)OH;
+    float4 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      auto prod = [&](int y, int x) {
+        const float mk = mask[(r * PH + y) * PW + x];
+        const float4 f = ld4(feat + (((r * PH + y) * PW + x) * C8 + c8) * 8 + h * 4);
+        return make_float4(f.x * mk, f.y * mk, f.z * mk, f.w * mk);
+      };
+      if (POOL2)
+        v[h] = max4(max4(prod(2 * oh, 2 * ow), prod(2 * oh, 2 * ow + 1)), max4(prod(2 * oh + 1, 2 * ow), prod(2 * oh + 1, 2 * ow + 1)));
+      else
+        v[h] = prod(oh, ow);
+    }
+    float4* dst = reinterpret_cast<float4*>(out + (long)idx * 8);
+    dst[0] = v[0];
+    dst[1] = v[1];
+    sm_store8<SM>(sm, R, r, ((long)oh * OW + ow) * C8 * 8 + c8 * 8, v[0], v[1]);
+  }
+}
+
+// which variant of the two pooling kernels writes the second output: 8 channels per thread (MNC_ROI_SM_VARIANT=4 forces the other)
+static bool sm_variant8(bool) {
+  const char* e = getenv("MNC_ROI_SM_VARIANT");
+  return e ? atoi(e) == 8 : true;
+}
+
+static bool sm_ok(int C, int fmt) { return fmt == 1 ? C % 64 == 0 : fmt == 2 ? C % 32 == 0 : false; }
 
 // [R][C][P] <-> [R][P][C]  (P = PH*PW)
 __global__ void rchw_to_rhwc_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C, int P) {
@@ -194,12 +452,16 @@ using namespace mnc;
 
 extern "C" {
 
-int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
-                 float scale, int pool2, float* d_out) {
+int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
+                    float scale, int pool2, float* d_out, void* d_sm, int sm_fmt) {
   MNC_REQUIRE(ctx && d_feat && d_out && (R == 0 || d_rois), "mnc_roi_warp: null pointer");
   MNC_REQUIRE(C > 0 && C % 8 == 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "mnc_roi_warp: bad shape");
+  if (!d_sm) sm_fmt = 0;
+  MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_roi_warp_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
+              sm_fmt == 1 ? 64 : 32, C);
   if (R == 0) return MNC_OK;
   const long total = (long)R * PH * PW * (C / 4);
+  MNC_REQUIRE(total < (1L << 31), "mnc_roi_warp: %ld outputs exceed the kernel's 32-bit index range", total * 4);
   const double samples = pool2 ? 4.0 : 1.0;
   // pixel-major copy of the feature map in the context's scratch arena (same stream: ordered after any earlier user)
   int rc = ensure_scratch(ctx, (size_t)C * H * W * 4);
@@ -212,14 +474,46 @@ int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const f
     rc = lt.finish("c8_to_hwc_kernel");
     if (rc) return rc;
   }
-  LaunchScope ls(ctx, pool2 ? "roi_warp_pool2" : "roi_warp", 0.0, 4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)));
-  if (pool2)
-    hipLaunchKernelGGL(roi_warp_kernel<1>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH,
-                       PW, scale, d_out);
-  else
-    hipLaunchKernelGGL(roi_warp_kernel<0>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH,
-                       PW, scale, d_out);
+  LaunchScope ls(ctx, pool2 ? "roi_warp_pool2" : "roi_warp", 0.0,
+                 4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)) + (sm_fmt == 1 ? 2.0 : sm_fmt == 2 ? 4.0 : 0.0) * R * PH * PW * C);
+  // One wave per output position from 1024 channels on (4+ channel iterations share a position's set-up: 1000 RoIs x 1024
+  // channels, fp16 second output: 28x28+pool 490 us against 629 / 680 for the 4- / 8-channels-per-thread kernels, 14x14 401
+  // against 520 / 430); below that the 4-channels-per-thread kernel (300 RoIs x 512 channels: 75 / 37 us against 88 / 43).
+  // MNC_ROI_WARP_VARIANT = 1 (wave) / 4 / 8 forces one.
+  const char* variant = getenv("MNC_ROI_WARP_VARIANT");
+  const int vsel = variant ? atoi(variant) : (C >= 1024 ? 1 : 4);
+  if (vsel != 4 && vsel != 8) {
+    MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
+    const int g = grid_for((long)R * PH * PW * 64);
+#define MNC_WARPW(P2, SM)                                                                                                    \
+  hipLaunchKernelGGL((roi_warp_wave_kernel<P2, SM>), dim3(g), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, PW, scale, \
+                     d_out, d_sm)
+    if (pool2) { if (sm_fmt == 1) MNC_WARPW(1, 1); else if (sm_fmt == 2) MNC_WARPW(1, 2); else MNC_WARPW(1, 0); }
+    else { if (sm_fmt == 1) MNC_WARPW(0, 1); else if (sm_fmt == 2) MNC_WARPW(0, 2); else MNC_WARPW(0, 0); }
+#undef MNC_WARPW
+    return ls.finish("roi_warp_wave_kernel");
+  }
+  if (sm_fmt && vsel == 8) {
+#define MNC_WARP8(P2, SM)                                                                                                   \
+  hipLaunchKernelGGL((roi_warp8_kernel<P2, SM>), dim3(grid_for(total / 2)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, \
+                     PH, PW, scale, d_out, d_sm)
+    if (pool2) { if (sm_fmt == 1) MNC_WARP8(1, 1); else MNC_WARP8(1, 2); }
+    else { if (sm_fmt == 1) MNC_WARP8(0, 1); else MNC_WARP8(0, 2); }
+#undef MNC_WARP8
+    return ls.finish("roi_warp8_kernel");
+  }
+#define MNC_WARP(P2, SM)                                                                                                \
+  hipLaunchKernelGGL((roi_warp_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, \
+                     PW, scale, d_out, d_sm)
+  if (pool2) { if (sm_fmt == 1) MNC_WARP(1, 1); else if (sm_fmt == 2) MNC_WARP(1, 2); else MNC_WARP(1, 0); }
+  else { if (sm_fmt == 1) MNC_WARP(0, 1); else if (sm_fmt == 2) MNC_WARP(0, 2); else MNC_WARP(0, 0); }
+#undef MNC_WARP
   return ls.finish("roi_warp_kernel");
+}
+
+int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
+                 float scale, int pool2, float* d_out) {
+  return mnc_roi_warp_sm(ctx, d_feat, C, H, W, d_rois, R, PH, PW, scale, pool2, d_out, nullptr, 0);
 }
 
 // ---- ROIPooling (Fast R-CNN max pooling over integer bins; models/VGG16/cfm/test.prototxt:397-407, 446-456) ---------
@@ -281,14 +575,31 @@ int mnc_roi_pool(mnc_ctx* ctx, const float* d_feat, int N, int C, int H, int W, 
   return ls.finish("roi_pool_kernel");
 }
 
-int mnc_maxpool2_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C) {
+int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C, void* d_sm, int sm_fmt) {
   MNC_REQUIRE(ctx && d_in && d_out && R >= 0 && PH > 0 && PW > 0 && PH % 2 == 0 && PW % 2 == 0 && C > 0 && C % 4 == 0,
               "mnc_maxpool2_rhwc: bad argument (PH, PW must be even, C%%4==0)");
+  if (!d_sm) sm_fmt = 0;
+  MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_maxpool2_rhwc_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
+              sm_fmt == 1 ? 64 : 32, C);
   if (R == 0) return MNC_OK;
+  MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_maxpool2_rhwc: tensor exceeds the kernel's 32-bit index range");
   LaunchScope ls(ctx, "maxpool2_rhwc", 0.0, 4.0 * R * (double)C * PH * PW * 1.25);
-  hipLaunchKernelGGL(maxpool2_rhwc_kernel, dim3(grid_for((long)R * (PH / 2) * (PW / 2) * (C / 4))), dim3(256), 0,
-                     ctx->stream, d_in, d_out, R, PH, PW, C / 4);
+  if (sm_fmt && sm_variant8(false)) {
+    const int g8 = grid_for((long)R * (PH / 2) * (PW / 2) * (C / 8));
+    if (sm_fmt == 1) hipLaunchKernelGGL(maxpool2_rhwc8_kernel<1>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
+    else hipLaunchKernelGGL(maxpool2_rhwc8_kernel<2>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
+    return ls.finish("maxpool2_rhwc8_kernel");
+  }
+#define MNC_POOLR(SM)                                                                                                  \
+  hipLaunchKernelGGL(maxpool2_rhwc_kernel<SM>, dim3(grid_for((long)R * (PH / 2) * (PW / 2) * (C / 4))), dim3(256), 0, ctx->stream, \
+                     d_in, d_out, R, PH, PW, C / 4, d_sm)
+  if (sm_fmt == 1) MNC_POOLR(1); else if (sm_fmt == 2) MNC_POOLR(2); else MNC_POOLR(0);
+#undef MNC_POOLR
   return ls.finish("maxpool2_rhwc_kernel");
+}
+
+int mnc_maxpool2_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C) {
+  return mnc_maxpool2_rhwc_sm(ctx, d_in, d_out, R, PH, PW, C, nullptr, 0);
 }
 
 int mnc_mask_resize(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int IH, int IW, int OH, int OW) {
@@ -300,22 +611,40 @@ int mnc_mask_resize(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int IH
   return ls.finish("mask_resize_kernel");
 }
 
-int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH, int PW, int C,
-                  int pool2) {
+int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH, int PW, int C,
+                     int pool2, void* d_sm, int sm_fmt) {
   MNC_REQUIRE(ctx && d_feat && d_mask && d_out && R >= 0 && PH > 0 && PW > 0 && C > 0 && C % 4 == 0,
               "mnc_mask_pool: bad argument");
   MNC_REQUIRE(!pool2 || (PH % 2 == 0 && PW % 2 == 0), "mnc_mask_pool: pool2 needs even PH, PW");
+  if (!d_sm) sm_fmt = 0;
+  MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_mask_pool_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
+              sm_fmt == 1 ? 64 : 32, C);
   if (R == 0) return MNC_OK;
+  MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_mask_pool: tensor exceeds the kernel's 32-bit index range");
   const int OH = pool2 ? PH / 2 : PH, OW = pool2 ? PW / 2 : PW;
   LaunchScope ls(ctx, pool2 ? "mask_pool_pool2" : "mask_pool", 0.0, 4.0 * R * (double)C * (PH * PW + OH * OW));
   const long total = (long)R * OH * OW * (C / 4);
-  if (pool2)
-    hipLaunchKernelGGL(mask_pool_kernel<1>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, PH,
-                       PW, C / 4);
-  else
-    hipLaunchKernelGGL(mask_pool_kernel<0>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, PH,
-                       PW, C / 4);
+  if (sm_fmt && sm_variant8(false)) {
+#define MNC_MP8(P2, SM)                                                                                                     \
+  hipLaunchKernelGGL((mask_pool8_kernel<P2, SM>), dim3(grid_for(total / 2)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, \
+                     PH, PW, C / 8, d_sm)
+    if (pool2) { if (sm_fmt == 1) MNC_MP8(1, 1); else MNC_MP8(1, 2); }
+    else { if (sm_fmt == 1) MNC_MP8(0, 1); else MNC_MP8(0, 2); }
+#undef MNC_MP8
+    return ls.finish("mask_pool8_kernel");
+  }
+#define MNC_MP(P2, SM)                                                                                                  \
+  hipLaunchKernelGGL((mask_pool_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, PH, \
+                     PW, C / 4, d_sm)
+  if (pool2) { if (sm_fmt == 1) MNC_MP(1, 1); else if (sm_fmt == 2) MNC_MP(1, 2); else MNC_MP(1, 0); }
+  else { if (sm_fmt == 1) MNC_MP(0, 1); else if (sm_fmt == 2) MNC_MP(0, 2); else MNC_MP(0, 0); }
+#undef MNC_MP
   return ls.finish("mask_pool_kernel");
+}
+
+int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH, int PW, int C,
+                  int pool2) {
+  return mnc_mask_pool_sm(ctx, d_feat, d_mask, d_out, R, PH, PW, C, pool2, nullptr, 0);
 }
 
 int mnc_rchw_to_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int C, int PH, int PW) {

@@ -105,6 +105,10 @@ class Blob(object):
         self._buf = _DevBuf(net._ctx)
         self._view = None           # (parent Blob, column offset) for Concat inputs written in place
         self.diff = None
+        # second copy of a per-RoI tensor in the stage-major 2-byte form a reduced-precision InnerProduct multiplies from, written
+        # by the tensor's producer (mnc_*_sm): {"fmt": 1 f16 | 2 bf16x3, "M": rows, "K": row length, "ptr": device address}
+        self._sm = None
+        self._smbuf = None
 
     # ---- pycaffe surface ----
     @property
@@ -132,6 +136,7 @@ class Blob(object):
         """Host ndarray in Caffe order.  Handing it out makes the host copy authoritative (it may be written)."""
         arr = self._host_read()
         self._dev_valid = False
+        self._sm = None
         return arr
 
     # ---- engine side ----
@@ -153,6 +158,7 @@ class Blob(object):
         self._host = arr
         self._host_valid = True
         self._dev_valid = False
+        self._sm = None
 
     def set_device(self, darr):
         """Adopt the contents of a DeviceArray of this net (plain layout): one device-to-device copy, no host round trip."""
@@ -164,6 +170,7 @@ class Blob(object):
             _lib.call("mnc_d2d", self._net._ctx.h, self._buf.ensure(self.count * 4), darr.ptr, self.count * 4)
         self.layout = "plain"
         self._dev_valid = True
+        self._sm = None
 
     def _ld(self):
         if self._view is not None:
@@ -181,7 +188,16 @@ class Blob(object):
         self.layout = layout
         self._dev_valid = True
         self._host_valid = False
+        self._sm = None
         return self.dev_ptr()
+
+    def sm_out(self, fmt, M, K):
+        """Device address for the producer's second output (stage-major 2-byte form, see __init__); call after dev_out."""
+        if self._smbuf is None:
+            self._smbuf = _DevBuf(self._net._ctx)
+        ptr = self._smbuf.ensure(M * K * (2 if fmt == 1 else 4))
+        self._sm = {"fmt": fmt, "M": M, "K": K, "ptr": ptr}
+        return ptr
 
     def dev_in(self, layout):
         """Pointer to current contents in `layout`, uploading / converting as needed."""
@@ -924,10 +940,13 @@ class Net(object):
                                               % (L.name, PH, PW))
                 src = bot.dev_in("rhwc")
                 top.reshape(R, C, PH // 2, PW // 2)
-                if R:
-                    _lib.call("mnc_maxpool2_rhwc", self._h(), src, top.dev_out("rhwc"), R, PH, PW, C)
-                else:
-                    top.dev_out("rhwc")
+                dst = top.dev_out("rhwc")
+                K = C * (PH // 2) * (PW // 2)
+                fmt = self._sm_format(top.name, R, K, C) if R else 0
+                if fmt:
+                    _lib.call("mnc_maxpool2_rhwc_sm", self._h(), src, dst, R, PH, PW, C, top.sm_out(fmt, R, K), fmt)
+                elif R:
+                    _lib.call("mnc_maxpool2_rhwc", self._h(), src, dst, R, PH, PW, C)
         return run
 
     def _bind_Eltwise(self, L, i):
@@ -991,6 +1010,27 @@ class Net(object):
             _lib.call("mnc_eltwise", self._h(), src, top.dev_out("plain"), bot.count, 2)
         return run
 
+    def _sm_format(self, blob, M, K, C):
+        """Second output of a per-RoI producer (ROIWarping / Pooling / MaskPooling) -> 0 none, 1 f16, 2 bf16x3: the stage-major
+        2-byte form (Blob._sm) when an InnerProduct that reads `blob` will run on the reduced-precision kernels for this M
+        (same rule as _bind_InnerProduct.weights_for), so that it does not have to convert the fp32 rows itself.  MNC_FC_SM=0
+        switches the second outputs off."""
+        if self.math == "fp32" or M <= 0 or os.environ.get("MNC_FC_SM", "1") == "0":
+            return 0
+        fmt = 0
+        for i in self._consumers.get(blob, []):
+            L = self._layers[i]
+            if L.type != "InnerProduct" or L.skip or L.group is not None or L.group_leader is not None:
+                continue
+            n_out = L.msg.get1("inner_product_param").get1("num_output")
+            if 2.0 * M * n_out * K < _X3_MIN_FLOPS:
+                continue
+            if self.math == "f16" and K % 64 == 0 and C % 64 == 0:
+                fmt = 1
+            elif K % 32 == 0 and C % 32 == 0 and not (self.math == "f16" and K % 64 == 0):
+                fmt = 2
+        return fmt
+
     def _bind_ROIWarping(self, L, i):
         rp = L.msg.get1("roi_warping_param")
         ph, pw, scale = rp.get1("pooled_h"), rp.get1("pooled_w"), float(rp.get1("spatial_scale"))
@@ -1006,7 +1046,13 @@ class Net(object):
             R = rois.shape[0]
             d_feat, d_rois = feat.dev_in("c8"), rois.dev_in("plain")
             top.reshape(R, C, oh, ow)
-            _lib.call("mnc_roi_warp", self._h(), d_feat, C, H, W, d_rois, R, oh, ow, scale, pool2, top.dev_out("rhwc"))
+            dst = top.dev_out("rhwc")
+            fmt = self._sm_format(top.name, R, C * oh * ow, C)
+            if fmt:
+                _lib.call("mnc_roi_warp_sm", self._h(), d_feat, C, H, W, d_rois, R, oh, ow, scale, pool2, dst,
+                          top.sm_out(fmt, R, C * oh * ow), fmt)
+            else:
+                _lib.call("mnc_roi_warp", self._h(), d_feat, C, H, W, d_rois, R, oh, ow, scale, pool2, dst)
         return run
 
     def _bind_ROIPooling(self, L, i):
@@ -1046,8 +1092,15 @@ class Net(object):
             if pool2 and (PH % 2 or PW % 2):
                 raise NotImplementedError("MaskPooling %s + MAX 2x2/2 fused: odd size %dx%d" % (L.name, PH, PW))
             d_feat, d_mask = feat.dev_in("rhwc"), mask.dev_in("plain")
-            top.reshape(R, C, PH // 2 if pool2 else PH, PW // 2 if pool2 else PW)
-            _lib.call("mnc_mask_pool", self._h(), d_feat, d_mask, top.dev_out("rhwc"), R, PH, PW, C, pool2)
+            oh, ow = (PH // 2, PW // 2) if pool2 else (PH, PW)
+            top.reshape(R, C, oh, ow)
+            dst = top.dev_out("rhwc")
+            fmt = self._sm_format(top.name, R, C * oh * ow, C)
+            if fmt:
+                _lib.call("mnc_mask_pool_sm", self._h(), d_feat, d_mask, dst, R, PH, PW, C, pool2, top.sm_out(fmt, R, C * oh * ow),
+                          fmt)
+            else:
+                _lib.call("mnc_mask_pool", self._h(), d_feat, d_mask, dst, R, PH, PW, C, pool2)
         return run
 
     def _bind_InnerProduct(self, L, i):
@@ -1103,6 +1156,15 @@ class Net(object):
                 raise ValueError("InnerProduct %s: input %r does not flatten to K=%d" % (L.name, bot.shape, K))
             if M and "w" not in state:
                 state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
+            want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2}.get(state.get("fn"), 0)
+            sm = bot._sm
+            if (M and want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K and bot._dev_valid
+                    and bot.layout == state["layout"]):
+                # the producer already wrote the rows in this kernel's own 2-byte form (Blob._sm): no conversion pass
+                top.reshape(M, n_out)
+                dst = top.dev_out("plain")
+                _lib.call(state["fn"] + "_pre", self._h(), sm["ptr"], M, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+                return
             src = bot.dev_in(state["layout"]) if M else 0
             top.reshape(M, n_out)
             dst = top.dev_out("plain")
@@ -1437,6 +1499,8 @@ class Net(object):
             _lib.call("mnc_ctx_sync", self._ctx.h)
             for b in list(self.blobs.values()) + getattr(self, "_hidden", []):
                 b._buf.release()
+                if b._smbuf is not None:
+                    b._smbuf.release()
             for t in getattr(self, "_tail_bufs", None) or ():
                 t.release()
             if getattr(self, "_prep", None) is not None:

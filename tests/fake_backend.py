@@ -397,6 +397,41 @@ class Fake(object):
         for m in range(M):
             full[m * ldc:m * ldc + N] = y[m]
 
+    # ---- stage-major 2-byte activation forms of the reduced-precision InnerProducts (Blob._sm) ----
+    @staticmethod
+    def _sm_write(dst, rows, fmt):
+        """rows [M][K] float32 -> the test double's stand-in for the stage-major tensor: the rounded values as float32/float16 in
+        row-major order (the real layout is checked on the GPU against mnc_fc_pack_act)."""
+        M, K = rows.shape
+        if fmt == 1:
+            _h16(dst, (M, K))[...] = rows.astype(np.float16)
+        else:
+            _f(dst, (M, K))[...] = rows
+
+    def mnc_roi_warp_sm(self, h, feat, C, H, W, rois, R, PH, PW, scale, pool2, dst, sm, fmt):
+        self.mnc_roi_warp(h, feat, C, H, W, rois, R, PH, PW, scale, pool2, dst)
+        if sm and fmt:
+            self._sm_write(sm, _f(dst, (R, PH * PW * C)), fmt)
+
+    def mnc_maxpool2_rhwc_sm(self, h, src, dst, R, PH, PW, C, sm, fmt):
+        self.mnc_maxpool2_rhwc(h, src, dst, R, PH, PW, C)
+        if sm and fmt:
+            self._sm_write(sm, _f(dst, (R, (PH // 2) * (PW // 2) * C)), fmt)
+
+    def mnc_mask_pool_sm(self, h, feat, mask, dst, R, PH, PW, C, pool2, sm, fmt):
+        self.mnc_mask_pool(h, feat, mask, dst, R, PH, PW, C, pool2)
+        if sm and fmt:
+            oh, ow = (PH // 2, PW // 2) if pool2 else (PH, PW)
+            self._sm_write(sm, _f(dst, (R, oh * ow * C)), fmt)
+
+    def mnc_fc_f16_pre(self, h, sm, mstride, wpk, b, dst, M, N, K, ldc, act):
+        a = np.ascontiguousarray(_h16(sm, (mstride, K))[:M].astype(np.float32))
+        self.mnc_fc_f16(h, a.ctypes.data, wpk, b, dst, M, N, K, ldc, act)
+
+    def mnc_fc_bf16x3_pre(self, h, sm, mstride, wpk, b, dst, M, N, K, ldc, act):
+        a = np.ascontiguousarray(_f(sm, (mstride, K))[:M])
+        self.mnc_fc_bf16x3(h, a.ctypes.data, wpk, b, dst, M, N, K, ldc, act)
+
     def mnc_softmax_rows(self, h, src, dst, M, N):
         _f(dst, (M, N))[...] = F.softmax(_t(_f(src, (M, N))), dim=1).numpy()
 
@@ -549,7 +584,10 @@ def install(monkeypatch):
     from mnc_amd import _lib
     fake = Fake()
 
+    fake.calls = {}                          # entry point -> number of calls (tests assert on the plan through it)
+
     def call(name, *args):
+        fake.calls[name] = fake.calls.get(name, 0) + 1
         getattr(fake, name)(*args)
         return 0
 

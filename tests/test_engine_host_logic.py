@@ -45,6 +45,21 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     net.blobs["im_info"].reshape(*im_info.shape)
     out = net.forward(data=data, im_info=im_info)
     assert set(out) == {"cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"}
+    calls = fake_gpu.calls
+    if math == "fp32":
+        assert not any(k.endswith(("_sm", "_pre")) for k in calls)
+    else:
+        # reduced-precision InnerProducts: the per-RoI producers write the rows in the GEMM's own stage-major 2-byte form and the
+        # six big InnerProducts on per-RoI features (fc6_maskest, fc6, fc6_mask of both stages) take them without converting
+        pre = "mnc_fc_f16_pre" if math == "f16" else "mnc_fc_bf16x3_pre"
+        # (twice when fewer proposals survive than were speculated and the heads are re-run on the exact count)
+        runs = calls.get("mnc_roi_warp_sm", 0) // 2
+        assert runs in (1, 2) and calls.get(pre) == 6 * runs and calls.get("mnc_mask_pool_sm") == 2 * runs
+        assert calls.get("mnc_maxpool2_rhwc_sm") == 2 * runs and "mnc_roi_warp" not in calls
+    if math == "f16":
+        # 2-byte trunk activations: conv1_1 .. conv5_2 write packed fp16, conv5_3 (read by the RoI layers) fp32
+        assert calls.get("mnc_conv3x3_f16_pk") == 12 and calls.get("mnc_conv3x3_c3_fmt") == 1 and calls.get("mnc_maxpool2_c8_f16") == 4
+        assert net.blobs["conv5_2"].layout == "c8h" and net.blobs["conv5_3"].layout == "c8"
     ref = onet.forward(w, data, im_info)
     names = BLOBS + ([] if fuse else ["roi_interpolate_conv5_premax", "roi_mask_conv5", "roi_mask_conv5_ext"])
     if fuse and math == "fp32":
@@ -416,6 +431,16 @@ def test_resnet50_graph_f16_mode_plumbing(fake_gpu):
     net = Net(path, w, 1, device_id=0, math="f16")
     data, im_info = _inputs(96, 160, 0)
     net.forward(data=data, im_info=im_info)
+    # 2-byte activations between the layers that can take them: the stem, MAX 3x3/2, every 1x1 convolution whose input has a
+    # multiple of 16 channels (at this width: all but the 8-channel bottlenecks of res2) and the tuned 3x3 kernels; res4f is
+    # written as fp32 for the RoI layers
+    by_name = {L.name: L for L in net._layers}
+    assert by_name["conv1"].out_h and by_name["res4a_branch2a"].out_h and by_name["res4c_branch2b"].out_h
+    assert by_name["res4e_branch2c"].out_h and not by_name["res4f_branch2c"].out_h and not by_name["rpn_conv_3x3"].out_h
+    assert net._conv_fast1x1(by_name["res3a_branch1"]) and not net._conv_fast1x1(by_name["res2a_branch2c"])     # Cin = 8
+    calls = fake_gpu.calls
+    assert calls.get("mnc_conv_stem_c3_fmt") == 1 and calls.get("mnc_maxpool_c8_f16") == 1 and calls.get("mnc_conv1x1_f16_pk", 0) >= 20
+    assert net.blobs["res4e"].layout == "c8h" and net.blobs["res4f"].layout == "c8"
     ref = {}
     onet.trunk_resnet50(w, data, ref)
     for n in ("conv1", "res2a", "res3d", "res4f"):

@@ -480,7 +480,12 @@ def _rois(rng, R, W, H):
 
 
 @pytest.mark.parametrize("pool2,P", [(0, 14), (1, 14), (0, 7)])
-def test_roi_warp(dev, pool2, P):
+@pytest.mark.parametrize("variant", [None, "1", "4"])
+def test_roi_warp(dev, monkeypatch, pool2, P, variant):
+    """(variant: the library's choice by channel count, or MNC_ROI_WARP_VARIANT forcing the one-wave-per-position / the
+    4-channels-per-thread kernel -- all bit-exact with the oracle, rois partly and wholly outside the map included.)"""
+    if variant:
+        monkeypatch.setenv("MNC_ROI_WARP_VARIANT", variant)
     rng = np.random.default_rng(4)
     C, H, W, R = 64, 38, 63, 40
     feat = rng.normal(size=(C, H, W)).astype(np.float32)
@@ -493,6 +498,94 @@ def test_roi_warp(dev, pool2, P):
     else:
         want = native.roi_warp(feat, rois, P, P, 0.0625)
     assert np.array_equal(got, want)      # roi.hip is built with -ffp-contract=off and mirrors the oracle op by op
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("variant", [None, "4", "8"])
+def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, variant):
+    """(variant: the library's choice, or MNC_ROI_SM_VARIANT forcing the 4- / 8-channels-per-thread kernels.)
+    mnc_roi_warp_sm / mnc_maxpool2_rhwc_sm / mnc_mask_pool_sm: the fp32 output is bit for bit that of the plain entry point, and
+    the second output is bit for bit what mnc_fc_pack_act (the InnerProduct's own conversion pass) makes of it -- fp16 stage-major
+    (fmt 1) and split bf16 stage-major (fmt 2)."""
+    if variant:
+        monkeypatch.setenv("MNC_ROI_SM_VARIANT", variant)
+        monkeypatch.setenv("MNC_ROI_WARP_VARIANT", {"4": "4", "8": "8"}[variant])
+    rng = np.random.default_rng(40 + fmt)
+    C, H, W, R, P = 64, 38, 63, 37, 14
+    feat = rng.normal(size=(C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, 1000, 600)
+    d_feat, d_rois = dev.put(to_c8(feat)), dev.put(rois)
+    eb = 2 if fmt == 1 else 4
+
+    def shadow_of(d_rows, M, K):
+        d = dev.empty((M * K * eb,), dtype=np.uint8, fill=0)
+        dev.call("mnc_fc_pack_act", d_rows, d, M, K, 1 if fmt == 1 else 0)
+        return dev.get(d, (M * K * eb,), dtype=np.uint8)
+
+    for pool2, wave in ((0, False), (1, False), (0, True), (1, True)):
+        if wave:
+            if variant:
+                continue
+            monkeypatch.setenv("MNC_ROI_WARP_VARIANT", "1")         # the one-wave-per-position kernel writes it too
+        K = P * P * C
+        d_a, d_b = dev.empty((R * K,), fill=np.nan), dev.empty((R * K,), fill=np.nan)
+        d_sm = dev.empty((R * K * eb,), dtype=np.uint8, fill=0xAB)
+        dev.call("mnc_roi_warp", d_feat, C, H, W, d_rois, R, P, P, 0.0625, pool2, d_a)
+        dev.call("mnc_roi_warp_sm", d_feat, C, H, W, d_rois, R, P, P, 0.0625, pool2, d_b, d_sm, fmt)
+        assert np.array_equal(dev.get(d_a, (R * K,)), dev.get(d_b, (R * K,)))
+        assert np.array_equal(dev.get(d_sm, (R * K * eb,), dtype=np.uint8), shadow_of(d_b, R, K)), ("roi_warp", pool2, wave)
+    monkeypatch.delenv("MNC_ROI_WARP_VARIANT", raising=False)
+    # Pooling and MaskPooling on the 14x14 tensor
+    x = rng.normal(size=(R, P, P, C)).astype(np.float32)
+    m = rng.uniform(0, 1, (R, P, P)).astype(np.float32)
+    d_x, d_m = dev.put(x), dev.put(m)
+    K7 = 49 * C
+    d_a, d_b = dev.empty((R * K7,), fill=np.nan), dev.empty((R * K7,), fill=np.nan)
+    d_sm = dev.empty((R * K7 * eb,), dtype=np.uint8, fill=0xAB)
+    dev.call("mnc_maxpool2_rhwc", d_x, d_a, R, P, P, C)
+    dev.call("mnc_maxpool2_rhwc_sm", d_x, d_b, R, P, P, C, d_sm, fmt)
+    assert np.array_equal(dev.get(d_a, (R * K7,)), dev.get(d_b, (R * K7,)))
+    assert np.array_equal(dev.get(d_sm, (R * K7 * eb,), dtype=np.uint8), shadow_of(d_b, R, K7))
+    for pool2, K in ((1, K7), (0, P * P * C)):
+        d_a, d_b = dev.empty((R * K,), fill=np.nan), dev.empty((R * K,), fill=np.nan)
+        d_sm = dev.empty((R * K * eb,), dtype=np.uint8, fill=0xAB)
+        dev.call("mnc_mask_pool", d_x, d_m, d_a, R, P, P, C, pool2)
+        dev.call("mnc_mask_pool_sm", d_x, d_m, d_b, R, P, P, C, pool2, d_sm, fmt)
+        assert np.array_equal(dev.get(d_a, (R * K,)), dev.get(d_b, (R * K,)))
+        assert np.array_equal(dev.get(d_sm, (R * K * eb,), dtype=np.uint8), shadow_of(d_b, R, K)), ("mask_pool", pool2)
+    # a channel count whose 8-channel groups would straddle a stage is refused, not mis-packed
+    with pytest.raises(Exception):
+        dev.call("mnc_maxpool2_rhwc_sm", d_x, d_b, R, P, P, 24, d_sm, fmt)
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 12544), (1000, 512, 12544), (700, 256, 6272), (37, 256, 12544), (160, 4096, 1024)])
+def test_fc_on_prepacked_activations(dev, fmt, M, N, K):
+    """mnc_fc_{f16,bf16x3}_pre on the stage-major activation tensor == mnc_fc_{f16,bf16x3} on the fp32 rows, bit for bit, for
+    one row block, several row blocks with a ragged tail (two launches sharing one tensor: m_stride > M), the small-GEMM tile
+    and the 160-row tile; and on a tensor that holds more rows than the call multiplies."""
+    rng = np.random.default_rng(M + N + fmt)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * 0.02).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    eb = 2 if fmt == 1 else 4
+    name = "f16" if fmt == 1 else "bf16x3"
+    d_w = dev.empty(((N + 127) // 128 * 128 * K * eb,), dtype=np.uint8)
+    dev.call("mnc_pack_fc_" + name, dev.put(w), d_w, N, K)
+    d_a, d_b = dev.put(a), dev.put(b)
+    d_sm = dev.empty((M * K * eb,), dtype=np.uint8)
+    dev.call("mnc_fc_pack_act", d_a, d_sm, M, K, 1 if fmt == 1 else 0)
+    d_y0, d_y1 = dev.empty((M * N,), fill=np.nan), dev.empty((M * N,), fill=np.nan)
+    dev.call("mnc_fc_" + name, d_a, d_w, d_b, d_y0, M, N, K, N, 1)
+    dev.call("mnc_fc_%s_pre" % name, d_sm, M, d_w, d_b, d_y1, M, N, K, N, 1)
+    y0 = dev.get(d_y0, (M, N))
+    assert not np.isnan(y0).any() and np.array_equal(y0, dev.get(d_y1, (M, N)))
+    if M >= 300:        # the first 2/3 of the rows of the same tensor (m_stride = M > rows multiplied)
+        Mh = M * 2 // 3
+        d_y2, d_y3 = dev.empty((Mh * N,), fill=np.nan), dev.empty((Mh * N,), fill=np.nan)
+        dev.call("mnc_fc_" + name, d_a, d_w, d_b, d_y2, Mh, N, K, N, 1)
+        dev.call("mnc_fc_%s_pre" % name, d_sm, M, d_w, d_b, d_y3, Mh, N, K, N, 1)
+        assert np.array_equal(dev.get(d_y2, (Mh, N)), dev.get(d_y3, (Mh, N)))
 
 
 @pytest.mark.parametrize("P,N", [(7, 1), (14, 3)])

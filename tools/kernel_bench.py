@@ -50,7 +50,7 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "fc", "fcx3", "conv1x1"])
+    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "fc", "fcx3", "fcf16", "conv1x1"])
     ap.add_argument("--f16", action="store_true", help="conv1x1: packed fp16 tensors (mnc_conv1x1_f16_pk) instead of fp32")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
@@ -168,15 +168,19 @@ def main():
                 wp = dev.empty(((N + 127) // 128 * 128 * K,))
                 dev.call("mnc_pack_fc_bf16x3", w, wp, N, K)
                 w, fn = wp, "mnc_fc_bf16x3"
+            elif args.what == "fcf16":
+                wp = dev.empty(((N + 127) // 128 * 128 * K // 2,))
+                dev.call("mnc_pack_fc_f16", w, wp, N, K)
+                w, fn = wp, "mnc_fc_f16"
             for _ in range(3):
                 dev.call(fn, a, w, b, y, M, N, K, N, 1)
             dev.call("mnc_prof_reset")
             for _ in range(args.reps):
                 dev.call(fn, a, w, b, y, M, N, K, N, 1)
             rec = records(dev)
-            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0] in ("fc_bf16x3", "fc_bf16x3_small")])
+            t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0] in ("fc_bf16x3", "fc_bf16x3_small", "fc_f16", "fc_f16_small")])
             tr = np.array([r[1] for r in rec if r[0] == "fc_reduce"] or [0.0])
-            ts = np.array([r[1] for r in rec if r[0] == "fc_bf16x3_split"] or [0.0])
+            ts = np.array([r[1] for r in rec if r[0] in ("fc_bf16x3_split", "fc_f16_convert")] or [0.0])
             fl = 2.0 * M * N * K
             tot = np.median(t) + np.median(tr) + np.median(ts)
             print("%-12s M=%d N=%-4d K=%-6d  gemm %.1f us + reduce %.1f us + split %.1f us = %.1f us   %.1f TF/s (gemm)  %.1f TF/s (all)" %
