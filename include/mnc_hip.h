@@ -342,6 +342,11 @@ MNC_API int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, 
                                  int sm_fmt);
 MNC_API int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH, int PW, int C,
                              int pool2, void* d_sm, int sm_fmt);
+/* The box-feature Pooling (MAX 2x2/2 of the per-RoI tensor, test.prototxt:571-582) and MaskPooling + its Pooling (:631-650) of
+ * the SAME tensor in one pass: d_box_out = mnc_maxpool2_rhwc(d_feat), d_mask_out = mnc_mask_pool(d_feat, d_mask, pool2 = 1), bit
+ * for bit; d_feat is read once instead of twice.  d_box_sm / d_mask_sm: their stage-major second outputs (both or neither). */
+MNC_API int mnc_box_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_box_out, float* d_mask_out, int R,
+                              int PH, int PW, int C, void* d_box_sm, void* d_mask_sm, int sm_fmt);
 /* Softmax over the last axis of [M][N] (test.prototxt cls_prob / seg_cls_prob). */
 MNC_API int mnc_softmax_rows(mnc_ctx* ctx, const float* d_in, float* d_out, int M, int N);
 /* Same with a row stride on the input (the input may be a column slice of a merged-GEMM output). */

@@ -469,19 +469,27 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   NET_TRY(run_fc(n, n->fc_maskpred, (const float*)n->h_mask.p, masks, R, S * S, 2));            // + Sigmoid; MaskLayer = reshape
   NET_TRY(mnc_mask_resize(ctx, masks, (float*)n->m14.p, R, S, S, P, P));
   float* join = (float*)n->join.p;                                                             // Concat(fc7_mask, fc7): column slices
+  // box-feature Pooling and MaskPooling + Pooling read the same 14x14 tensor: one pass (mnc_box_mask_pool) when their
+  // InnerProducts take the same activation form (always, with fc6 / fc6_mask of equal shape); MNC_FUSE_POOLS=0: two kernels
+  static const bool fuse_pools = !(getenv("MNC_FUSE_POOLS") && atoi(getenv("MNC_FUSE_POOLS")) == 0);
+  const bool one_pass = fuse_pools && sm_box == sm_mask;
+  if (one_pass)
+    NET_TRY(mnc_box_mask_pool(ctx, feat14, (const float*)n->m14.p, (float*)n->box7.p, (float*)n->mask7.p, R, P, P, C5,
+                              n->box7_sm.p, n->mask7_sm.p, sm_box));
   // box-feature branch (test.prototxt:604-652): on the second stream when it is available, otherwise in line
   const bool fork = n->ctx_b && ctx->profiling == 0 && R > 0;
   mnc_ctx* cb = fork ? n->ctx_b : ctx;
   const int si = second ? 1 : 0;
   if (fork) {
-    MNC_HIP_TRY(hipEventRecord(n->ev_fork[si], ctx->stream));                                   // feat14 is complete
+    MNC_HIP_TRY(hipEventRecord(n->ev_fork[si], ctx->stream));                                   // feat14 / box7 are complete
     MNC_HIP_TRY(hipStreamWaitEvent(cb->stream, n->ev_fork[si], 0));
   }
-  NET_TRY(mnc_maxpool2_rhwc_sm(cb, feat14, (float*)n->box7.p, R, P, P, C5, n->box7_sm.p, sm_box));
+  if (!one_pass) NET_TRY(mnc_maxpool2_rhwc_sm(cb, feat14, (float*)n->box7.p, R, P, P, C5, n->box7_sm.p, sm_box));
   NET_TRY(run_fc_sm(cb, n->fc6, (const float*)n->box7.p, n->box7_sm.p, sm_box, (float*)n->f6.p, R, F, 1));
   NET_TRY(run_fc(cb, n->fc7, (const float*)n->f6.p, join + F, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipEventRecord(n->ev_join[si], cb->stream));
-  NET_TRY(mnc_mask_pool_sm(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1, n->mask7_sm.p, sm_mask));
+  if (!one_pass)
+    NET_TRY(mnc_mask_pool_sm(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1, n->mask7_sm.p, sm_mask));
   NET_TRY(run_fc_sm(ctx, n->fc6m, (const float*)n->mask7.p, n->mask7_sm.p, sm_mask, (float*)n->f6m.p, R, F, 1));
   NET_TRY(run_fc(n, n->fc7m, (const float*)n->f6m.p, join, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));

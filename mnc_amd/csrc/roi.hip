@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void mask_pool_kernel(const float* __restrict_
 // map (almost all) take straight-line unconditional loads; the others select zero taps as before.
 struct WarpSample {
   int off;                           // ((y0 * W + x0) * C), clamped into the map for the unconditional loads
+  int x0, y0;
   float w00, w01, w10, w11;
   bool v00, v01, v10, v11;
 };
@@ -220,6 +221,7 @@ struct WarpSample {
 __device__ __forceinline__ WarpSample warp_setup(int H, int W, int C, float sx, float sy) {
   WarpSample s;
   const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  s.x0 = x0; s.y0 = y0;
   const float ax = sx - (float)x0, ay = sy - (float)y0;
   s.w00 = (1.0f - ax) * (1.0f - ay); s.w01 = ax * (1.0f - ay); s.w10 = (1.0f - ax) * ay; s.w11 = ax * ay;
   const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
@@ -237,6 +239,36 @@ __device__ __forceinline__ float4 warp_taps(const float* __restrict__ px, int W,
 #define MNC_BL(f) (s.w00 * a00.f + s.w01 * a01.f + s.w10 * a10.f + s.w11 * a11.f)
   return make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
 #undef MNC_BL
+}
+
+// POOL2, all taps inside the map, and the 2x2 samples of the pooling window at most one cell apart in x and in y (always, for a
+// RoI narrower than 28 cells): the four samples' 16 taps are (2 + DX) x (2 + DY) = 4, 6 or 9 distinct pixels.  They are loaded
+// once; each sample then blends its own four, in warp_sample's order -- same values, 16 -> 4..9 L1 reads per 4 channels.
+template <int DX, int DY, int SM>
+__device__ __forceinline__ void warp_pool2_shared_taps(const float* __restrict__ feat_hwc, int W, int C, int C4, int lane,
+                                                       const WarpSample (&smp)[4], float* __restrict__ orow, void* __restrict__ sm,
+                                                       long M, long r, long kpos) {
+  for (int c4 = lane; c4 < C4; c4 += 64) {
+    const float* base = feat_hwc + c4 * 4 + smp[0].off;
+    float4 g[2 + DY][2 + DX];
+#pragma unroll
+    for (int y = 0; y < 2 + DY; ++y)
+#pragma unroll
+      for (int x = 0; x < 2 + DX; ++x) g[y][x] = ld4(base + ((long)y * W + x) * C);
+    float4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ox = (i & 1) * DX, oy = (i >> 1) * DY;
+      const WarpSample& q = smp[i];
+      const float4 a00 = g[oy][ox], a01 = g[oy][ox + 1], a10 = g[oy + 1][ox], a11 = g[oy + 1][ox + 1];
+#define MNC_BL(f) (q.w00 * a00.f + q.w01 * a01.f + q.w10 * a10.f + q.w11 * a11.f)
+      const float4 v = make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
+#undef MNC_BL
+      o = i == 0 ? v : max4(o, v);
+    }
+    *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+    if (SM) sm_store4<SM>(sm, M, r, kpos + c4 * 4, o);
+  }
 }
 
 template <int POOL2, int SM>
@@ -266,7 +298,15 @@ __global__ __launch_bounds__(256) void roi_warp_wave_kernel(const float* __restr
       safe = safe && smp[i].v00 && smp[i].v01 && smp[i].v10 && smp[i].v11;
     }
     float* orow = out + (long)pos * C;
-    if (safe) {
+    const long kpos = ((long)ph * PW + pw) * C;
+    if (POOL2 && safe && smp[NS - 1].x0 - smp[0].x0 <= 1 && smp[NS - 1].y0 - smp[0].y0 <= 1) {
+      const int dx = smp[NS - 1].x0 - smp[0].x0, dy = smp[NS - 1].y0 - smp[0].y0;      // 0 or 1 each, wave-uniform
+      const WarpSample(&q)[4] = reinterpret_cast<const WarpSample(&)[4]>(smp);
+      if (dx == 0 && dy == 0) warp_pool2_shared_taps<0, 0, SM>(feat_hwc, W, C, C4, lane, q, orow, sm, R, r, kpos);
+      else if (dy == 0) warp_pool2_shared_taps<1, 0, SM>(feat_hwc, W, C, C4, lane, q, orow, sm, R, r, kpos);
+      else if (dx == 0) warp_pool2_shared_taps<0, 1, SM>(feat_hwc, W, C, C4, lane, q, orow, sm, R, r, kpos);
+      else warp_pool2_shared_taps<1, 1, SM>(feat_hwc, W, C, C4, lane, q, orow, sm, R, r, kpos);
+    } else if (safe) {
       for (int c4 = lane; c4 < C4; c4 += 64) {
         const float* px = feat_hwc + c4 * 4;
         float4 o = warp_taps(px, W, C, smp[0]);
@@ -409,6 +449,49 @@ __global__ __launch_bounds__(256) void mask_pool8_kernel(const float* __restrict
   }
 }
 
+// ---- box-feature MAX pool and MaskPooling (+ its MAX pool) of the same 14x14 tensor in ONE pass (test.prototxt:571-582 and
+// :631-650): both read every value of `feat` once -- 803 MB at 1000 RoIs x 1024 channels -- so running them as two kernels
+// reads it twice.  out_box = the Pooling layer's output, out_mask = MaskPooling + Pooling; the arithmetic per output is that
+// of maxpool2_rhwc_kernel / mask_pool_kernel<1> (max of the four values resp. of the four products, same order).  NV float4 per
+// thread (2 when second outputs are written: a whole 16-byte group of the stage-major tensors, see above).
+template <int SM, int NV>
+__global__ __launch_bounds__(256) void box_mask_pool_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
+                                                            float* __restrict__ out_box, float* __restrict__ out_mask, int R,
+                                                            int PH, int PW, int CV, void* __restrict__ sm_box,
+                                                            void* __restrict__ sm_mask) {
+  const int OH = PH / 2, OW = PW / 2;
+  const unsigned total = (unsigned)R * OH * OW * CV;              // CV = channel groups of 4*NV; < 2^31: checked by the launcher
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % (unsigned)CV);
+    unsigned t = idx / (unsigned)CV;
+    const int ow = (int)(t % (unsigned)OW);
+    t /= (unsigned)OW;
+    const int oh = (int)(t % (unsigned)OH);
+    const long r = t / (unsigned)OH;
+    const long m00 = (r * PH + 2 * oh) * PW + 2 * ow;               // window's first position in the [R][PH][PW] grids
+    const float k00 = mask[m00], k01 = mask[m00 + 1], k10 = mask[m00 + PW], k11 = mask[m00 + PW + 1];
+    float4 b[NV], v[NV];
+#pragma unroll
+    for (int h = 0; h < NV; ++h) {
+      const float* p = feat + (m00 * CV + cv) * (4 * NV) + h * 4;
+      const float4 f00 = ld4(p), f01 = ld4(p + (long)CV * 4 * NV), f10 = ld4(p + (long)PW * CV * 4 * NV),
+                   f11 = ld4(p + (long)(PW + 1) * CV * 4 * NV);
+      b[h] = max4(max4(max4(f00, f01), f10), f11);                  // maxpool2_rhwc_kernel's order
+      auto mul = [](const float4 f, float k) { return make_float4(f.x * k, f.y * k, f.z * k, f.w * k); };
+      v[h] = max4(max4(mul(f00, k00), mul(f01, k01)), max4(mul(f10, k10), mul(f11, k11)));      // mask_pool_kernel<1>'s order
+    }
+    float4* db = reinterpret_cast<float4*>(out_box + (long)idx * 4 * NV);
+    float4* dm = reinterpret_cast<float4*>(out_mask + (long)idx * 4 * NV);
+#pragma unroll
+    for (int h = 0; h < NV; ++h) { db[h] = b[h]; dm[h] = v[h]; }
+    if (SM) {
+      const long k = ((long)oh * OW + ow) * CV * 4 * NV + cv * 4 * NV;
+      sm_store8<SM>(sm_box, R, r, k, b[0], b[NV - 1]);
+      sm_store8<SM>(sm_mask, R, r, k, v[0], v[NV - 1]);
+    }
+  }
+}
+
 // which variant of the two pooling kernels writes the second output: 8 channels per thread (MNC_ROI_SM_VARIANT=4 forces the other)
 static bool sm_variant8(bool) {
   const char* e = getenv("MNC_ROI_SM_VARIANT");
@@ -476,12 +559,13 @@ int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, cons
   }
   LaunchScope ls(ctx, pool2 ? "roi_warp_pool2" : "roi_warp", 0.0,
                  4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)) + (sm_fmt == 1 ? 2.0 : sm_fmt == 2 ? 4.0 : 0.0) * R * PH * PW * C);
-  // One wave per output position from 1024 channels on (4+ channel iterations share a position's set-up: 1000 RoIs x 1024
-  // channels, fp16 second output: 28x28+pool 490 us against 629 / 680 for the 4- / 8-channels-per-thread kernels, 14x14 401
-  // against 520 / 430); below that the 4-channels-per-thread kernel (300 RoIs x 512 channels: 75 / 37 us against 88 / 43).
-  // MNC_ROI_WARP_VARIANT = 1 (wave) / 4 / 8 forces one.
+  // One wave per output position for the fused 28x28 warp + pool (its set-up is four samples' worth and the window's taps are
+  // shared), and for the plain warp from 1024 channels on (4+ channel iterations share a position's set-up).  Measured, fp16
+  // second output, 1000 RoIs x 1024 channels: 28x28+pool 452 us against 629 / 680 for the 4- / 8-channels-per-thread kernels,
+  // 14x14 407 against 520 / 430; fp32 only, 300 RoIs x 512 channels: 28x28+pool 61 against 68, 14x14 44 against 32 (so the
+  // 4-channels-per-thread kernel keeps that case).  MNC_ROI_WARP_VARIANT = 1 (wave) / 4 / 8 forces one.
   const char* variant = getenv("MNC_ROI_WARP_VARIANT");
-  const int vsel = variant ? atoi(variant) : (C >= 1024 ? 1 : 4);
+  const int vsel = variant ? atoi(variant) : ((pool2 || C >= 1024) ? 1 : 4);
   if (vsel != 4 && vsel != 8) {
     MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
     const int g = grid_for((long)R * PH * PW * 64);
@@ -645,6 +729,30 @@ int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, flo
 int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_out, int R, int PH, int PW, int C,
                   int pool2) {
   return mnc_mask_pool_sm(ctx, d_feat, d_mask, d_out, R, PH, PW, C, pool2, nullptr, 0);
+}
+
+int mnc_box_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_box_out, float* d_mask_out, int R, int PH,
+                      int PW, int C, void* d_box_sm, void* d_mask_sm, int sm_fmt) {
+  MNC_REQUIRE(ctx && d_feat && d_mask && d_box_out && d_mask_out && R >= 0 && PH > 0 && PW > 0 && PH % 2 == 0 && PW % 2 == 0 &&
+                  C > 0 && C % 8 == 0,
+              "mnc_box_mask_pool: bad argument (PH, PW even, C%%8==0)");
+  if (!d_box_sm || !d_mask_sm) sm_fmt = 0;
+  MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_box_mask_pool: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
+              sm_fmt == 1 ? 64 : 32, C);
+  if (R == 0) return MNC_OK;
+  MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_box_mask_pool: tensor exceeds the kernel's 32-bit index range");
+  const int OH = PH / 2, OW = PW / 2;
+  LaunchScope ls(ctx, "box_mask_pool", 0.0, 4.0 * R * (double)C * (PH * PW + 2.0 * OH * OW));
+  if (sm_fmt == 1)
+    hipLaunchKernelGGL((box_mask_pool_kernel<1, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm);
+  else if (sm_fmt == 2)
+    hipLaunchKernelGGL((box_mask_pool_kernel<2, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm);
+  else
+    hipLaunchKernelGGL((box_mask_pool_kernel<0, 1>), dim3(grid_for((long)R * OH * OW * (C / 4))), dim3(256), 0, ctx->stream, d_feat,
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 4, d_box_sm, d_mask_sm);
+  return ls.finish("box_mask_pool_kernel");
 }
 
 int mnc_rchw_to_rhwc(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int C, int PH, int PW) {

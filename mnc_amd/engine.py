@@ -328,6 +328,7 @@ class _Layer(object):
         self.scale = None
         self.residual = None       # blob added in this Convolution's epilogue (a following Eltwise SUM folded in)
         self.out_h = False         # "f16" math mode: this layer writes its top as a packed fp16 c8 tensor ('c8h')
+        self.with_mask = None      # Pooling on a per-RoI tensor: the MaskPooling (+ its Pooling) of the same tensor done in the same pass
         self.run = None
 
 
@@ -531,6 +532,22 @@ class Net(object):
                         if rp.get1("pooled_h") % 2 or rp.get1("pooled_w") % 2:
                             continue
                     L.fused_pool, L.out_name, nxt.skip = True, nxt.tops[0], True
+        # The box-feature Pooling and MaskPooling (+ its folded Pooling) read the same per-RoI tensor (test.prototxt:571-582 and
+        # :631-650): one pass over it (mnc_box_mask_pool) when the mask is ready by the time the Pooling layer runs
+        if os.environ.get("MNC_FUSE_POOLS", "1") != "0":
+            first_producer = {}
+            for i, L in enumerate(self._layers):
+                for t in ([L.out_name] if L.out_name else L.tops):
+                    first_producer.setdefault(t, i)
+            for im, Lm in enumerate(self._layers):
+                if Lm.type != "MaskPooling" or not Lm.fused_pool or Lm.skip:
+                    continue
+                feat, mask = Lm.bottoms[0], Lm.bottoms[1]
+                for ib, Lb in enumerate(self._layers[:im]):
+                    if (Lb.type == "Pooling" and not Lb.skip and Lb.with_mask is None and Lb.bottoms[0] == feat
+                            and self._is_pool2(Lb) and first_producer.get(mask, len(self._layers)) < ib):
+                        Lb.with_mask, Lm.skip = Lm, True
+                        break
         # residual add folded into the epilogue of the general convolution that produces its second operand:
         # Eltwise SUM (x, conv(...)) [+ ReLU] -> conv writes relu(conv + bias + x) straight into the Eltwise's top
         index = {id(L): i for i, L in enumerate(self._layers)}
@@ -943,6 +960,21 @@ class Net(object):
                 dst = top.dev_out("rhwc")
                 K = C * (PH // 2) * (PW // 2)
                 fmt = self._sm_format(top.name, R, K, C) if R else 0
+                if L.with_mask is not None:             # + MaskPooling and its Pooling of the same tensor, same pass
+                    mtop = self.blobs[L.with_mask.out_name]
+                    d_mask = self.blobs[L.with_mask.bottoms[1]].dev_in("plain")
+                    mtop.reshape(R, C, PH // 2, PW // 2)
+                    mdst = mtop.dev_out("rhwc")
+                    mfmt = self._sm_format(mtop.name, R, K, C) if R else 0
+                    if R and fmt == mfmt and C % 8 == 0:
+                        _lib.call("mnc_box_mask_pool", self._h(), src, d_mask, dst, mdst, R, PH, PW, C,
+                                  top.sm_out(fmt, R, K) if fmt else None, mtop.sm_out(fmt, R, K) if fmt else None, fmt)
+                        return
+                    if R:
+                        if mfmt:
+                            _lib.call("mnc_mask_pool_sm", self._h(), src, d_mask, mdst, R, PH, PW, C, 1, mtop.sm_out(mfmt, R, K), mfmt)
+                        else:
+                            _lib.call("mnc_mask_pool", self._h(), src, d_mask, mdst, R, PH, PW, C, 1)
                 if fmt:
                     _lib.call("mnc_maxpool2_rhwc_sm", self._h(), src, dst, R, PH, PW, C, top.sm_out(fmt, R, K), fmt)
                 elif R:

@@ -424,6 +424,10 @@ class Fake(object):
             oh, ow = (PH // 2, PW // 2) if pool2 else (PH, PW)
             self._sm_write(sm, _f(dst, (R, oh * ow * C)), fmt)
 
+    def mnc_box_mask_pool(self, h, feat, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt):
+        self.mnc_maxpool2_rhwc_sm(h, feat, box, R, PH, PW, C, box_sm, fmt)
+        self.mnc_mask_pool_sm(h, feat, mask, mout, R, PH, PW, C, 1, mask_sm, fmt)
+
     def mnc_fc_f16_pre(self, h, sm, mstride, wpk, b, dst, M, N, K, ldc, act):
         a = np.ascontiguousarray(_h16(sm, (mstride, K))[:M].astype(np.float32))
         self.mnc_fc_f16(h, a.ctypes.data, wpk, b, dst, M, N, K, ldc, act)

@@ -48,14 +48,16 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     calls = fake_gpu.calls
     if math == "fp32":
         assert not any(k.endswith(("_sm", "_pre")) for k in calls)
+        assert (calls.get("mnc_box_mask_pool", 0) > 0) == fuse and ("mnc_mask_pool" in calls) == (not fuse)
     else:
         # reduced-precision InnerProducts: the per-RoI producers write the rows in the GEMM's own stage-major 2-byte form and the
         # six big InnerProducts on per-RoI features (fc6_maskest, fc6, fc6_mask of both stages) take them without converting
         pre = "mnc_fc_f16_pre" if math == "f16" else "mnc_fc_bf16x3_pre"
         # (twice when fewer proposals survive than were speculated and the heads are re-run on the exact count)
         runs = calls.get("mnc_roi_warp_sm", 0) // 2
-        assert runs in (1, 2) and calls.get(pre) == 6 * runs and calls.get("mnc_mask_pool_sm") == 2 * runs
-        assert calls.get("mnc_maxpool2_rhwc_sm") == 2 * runs and "mnc_roi_warp" not in calls
+        assert runs in (1, 2) and calls.get(pre) == 6 * runs and "mnc_roi_warp" not in calls
+        # the box-feature Pooling and MaskPooling + Pooling of a stage read the same tensor: one pass, both second outputs
+        assert calls.get("mnc_box_mask_pool") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
     if math == "f16":
         # 2-byte trunk activations: conv1_1 .. conv5_2 write packed fp16, conv5_3 (read by the RoI layers) fp32
         assert calls.get("mnc_conv3x3_f16_pk") == 12 and calls.get("mnc_conv3x3_c3_fmt") == 1 and calls.get("mnc_maxpool2_c8_f16") == 4

@@ -553,6 +553,20 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
         dev.call("mnc_mask_pool_sm", d_x, d_m, d_b, R, P, P, C, pool2, d_sm, fmt)
         assert np.array_equal(dev.get(d_a, (R * K,)), dev.get(d_b, (R * K,)))
         assert np.array_equal(dev.get(d_sm, (R * K * eb,), dtype=np.uint8), shadow_of(d_b, R, K)), ("mask_pool", pool2)
+    # both poolings of the tensor in one pass (mnc_box_mask_pool): the two outputs and their second outputs, bit for bit
+    d_box, d_mk = dev.empty((R * K7,), fill=np.nan), dev.empty((R * K7,), fill=np.nan)
+    dev.call("mnc_maxpool2_rhwc", d_x, d_box, R, P, P, C)
+    dev.call("mnc_mask_pool", d_x, d_m, d_mk, R, P, P, C, 1)
+    for f in (0, fmt):
+        d_b2, d_m2 = dev.empty((R * K7,), fill=np.nan), dev.empty((R * K7,), fill=np.nan)
+        d_bsm = dev.empty((R * K7 * eb,), dtype=np.uint8, fill=0xAB)
+        d_msm = dev.empty((R * K7 * eb,), dtype=np.uint8, fill=0xAB)
+        dev.call("mnc_box_mask_pool", d_x, d_m, d_b2, d_m2, R, P, P, C, d_bsm if f else None, d_msm if f else None, f)
+        assert np.array_equal(dev.get(d_box, (R * K7,)), dev.get(d_b2, (R * K7,))), f
+        assert np.array_equal(dev.get(d_mk, (R * K7,)), dev.get(d_m2, (R * K7,))), f
+        if f:
+            assert np.array_equal(dev.get(d_bsm, (R * K7 * eb,), dtype=np.uint8), shadow_of(d_b2, R, K7))
+            assert np.array_equal(dev.get(d_msm, (R * K7 * eb,), dtype=np.uint8), shadow_of(d_m2, R, K7))
     # a channel count whose 8-channel groups would straddle a stage is refused, not mis-packed
     with pytest.raises(Exception):
         dev.call("mnc_maxpool2_rhwc_sm", d_x, d_b, R, P, P, 24, d_sm, fmt)

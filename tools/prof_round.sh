@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events --no-resident $*"
+BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events --no-resident --no-resnet $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 PMCB="$BENCH --no-graph"      # counter passes: direct launches (same kernels, same order; counters serialise the dispatches anyway)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $PMCB > $OUT/pmc_fetch.log 2>&1
