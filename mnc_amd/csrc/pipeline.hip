@@ -81,12 +81,13 @@ struct mnc_net {
   bool packed_trunk = false;                   // bf16x3 / f16 with every trunk layer on the tuned kernel: 2-byte activations
   bool conv_fast[14] = {false};                // tuned 3x3 kernels (Cout % 32 == 0) or the general convolution (reduced widths)
   float* b_conv[14] = {nullptr};               // biases: trunk 0..12 -> [0..12], rpn -> [13]
-  float *w_rpn_cls = nullptr, *b_rpn_cls = nullptr, *w_rpn_box = nullptr, *b_rpn_box = nullptr;
+  float *w_rpn = nullptr, *b_rpn = nullptr;    // rpn_cls_score (2A rows) and rpn_bbox_pred (4A rows) as ONE [6A][RC] 1x1 convolution
   struct Fc { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, kind = 0; };   // kind 0 fp32, 1 bf16x3, 2 f16
   Fc fc_maskest, fc_maskpred, fc6, fc7, fc6m, fc7m, fc_heads;
   // geometry of the buffers below
   int cap_ph = 0, cap_pw = 0, cap_src = 0;
-  DevBuf img, taps, data, act[13], pooled[4], rpn_out, rpn_score, rpn_bbox, rpn_prob;
+  DevBuf img, taps, data, act[13], pooled[4], rpn_out, rpn_score, rpn_prob;      // rpn_score: [2A score | 4A bbox] planes
+  float* rpn_bbox_p = nullptr;                                                      // = rpn_score + 2A planes (set per image size)
   DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores, records, counts;
   // the per-RoI tensors a second time, in the stage-major 2-byte form their reduced-precision InnerProduct multiplies from
   // (written by the producing kernel's epilogue: mnc_roi_warp_sm / mnc_maxpool2_rhwc_sm / mnc_mask_pool_sm), bf16x3 / f16 modes
@@ -253,10 +254,20 @@ int finalize(mnc_net* n) {
   n->packed_trunk = c.math != 0 && !(getenv("MNC_PACKED_ACT") && atoi(getenv("MNC_PACKED_ACT")) == 0);
   for (int i = 1; i < 13; ++i) n->packed_trunk = n->packed_trunk && n->conv_fast[i];
   const int A = c.num_anchors, RC = c.rpn_channels;
-  NET_TRY(need(n, "rpn_cls_score", 0, (size_t)2 * A * RC, &w)); NET_TRY(upload(n, w->v, &n->w_rpn_cls));
-  NET_TRY(need(n, "rpn_cls_score", 1, (size_t)2 * A, &b));      NET_TRY(upload(n, b->v, &n->b_rpn_cls));
-  NET_TRY(need(n, "rpn_bbox_pred", 0, (size_t)4 * A * RC, &w)); NET_TRY(upload(n, w->v, &n->w_rpn_box));
-  NET_TRY(need(n, "rpn_bbox_pred", 1, (size_t)4 * A, &b));      NET_TRY(upload(n, b->v, &n->b_rpn_box));
+  {
+    // the two sibling 1x1 heads read the same rpn_output: one launch over the concatenated weights, their NCHW outputs are the
+    // first 2A and the last 4A planes of one buffer (same arithmetic per channel; one 22 us latency-bound launch instead of two)
+    const HostBlob *wc, *bc, *wb, *bb;
+    NET_TRY(need(n, "rpn_cls_score", 0, (size_t)2 * A * RC, &wc));
+    NET_TRY(need(n, "rpn_cls_score", 1, (size_t)2 * A, &bc));
+    NET_TRY(need(n, "rpn_bbox_pred", 0, (size_t)4 * A * RC, &wb));
+    NET_TRY(need(n, "rpn_bbox_pred", 1, (size_t)4 * A, &bb));
+    std::vector<float> wcat(wc->v), bcat(bc->v);
+    wcat.insert(wcat.end(), wb->v.begin(), wb->v.end());
+    bcat.insert(bcat.end(), bb->v.begin(), bb->v.end());
+    NET_TRY(upload(n, wcat, &n->w_rpn));
+    NET_TRY(upload(n, bcat, &n->b_rpn));
+  }
   // heads (shared by both stages, test.prototxt:514-515 <-> :829-834)
   const int C5 = c.trunk_channels[4], P = c.roi_size, S = c.mask_size, F = c.fc_dim, K = c.num_classes;
   NET_TRY(prepare_fc(n, "fc6_maskest", c.mask_fc, C5 * P * P, C5, P, P, &n->fc_maskest));
@@ -304,9 +315,9 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   }
   const int A = c.num_anchors;
   NET_TRY(dev_ensure(n, &n->rpn_out, (size_t)c.rpn_channels * h * w * 4));
-  NET_TRY(dev_ensure(n, &n->rpn_score, (size_t)2 * A * h * w * 4));
+  NET_TRY(dev_ensure(n, &n->rpn_score, (size_t)6 * A * h * w * 4));
   NET_TRY(dev_ensure(n, &n->rpn_prob, (size_t)2 * A * h * w * 4));
-  NET_TRY(dev_ensure(n, &n->rpn_bbox, (size_t)4 * A * h * w * 4));
+  n->rpn_bbox_p = (float*)n->rpn_score.p + (size_t)2 * A * h * w;
   const int R = c.post_nms_topn, C5 = c.trunk_channels[4], P = c.roi_size, S = c.mask_size, F = c.fc_dim, K = c.num_classes;
   NET_TRY(dev_ensure(n, &n->rois, (size_t)R * 5 * 4));
   NET_TRY(dev_ensure(n, &n->rois_ext, (size_t)R * 5 * 4));
@@ -441,12 +452,10 @@ int run_trunk(mnc_net* n) {
   n->fh = h; n->fw = w;
   const int A = c.num_anchors;
   NET_TRY(conv3(n, 13, cur, (float*)n->rpn_out.p, h, w, cin, c.rpn_channels));
-  NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn_cls, n->b_rpn_cls, (float*)n->rpn_score.p, h, w,
-                              c.rpn_channels, 2 * A));
-  NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn_box, n->b_rpn_box, (float*)n->rpn_bbox.p, h, w,
-                              c.rpn_channels, 4 * A));
+  NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn, n->b_rpn, (float*)n->rpn_score.p, h, w, c.rpn_channels,
+                              6 * A));
   NET_TRY(mnc_rpn_softmax(ctx, (const float*)n->rpn_score.p, (float*)n->rpn_prob.p, A, h, w));
-  NET_TRY(mnc_proposal(ctx, (const float*)n->rpn_prob.p, (const float*)n->rpn_bbox.p, A, h, w, c.anchors, c.feat_stride,
+  NET_TRY(mnc_proposal(ctx, (const float*)n->rpn_prob.p, (const float*)n->rpn_bbox_p, A, h, w, c.anchors, c.feat_stride,
                        (float)n->OH, (float)n->OW, n->im_scale, c.pre_nms_topn, c.post_nms_topn, c.rpn_nms_thresh,
                        c.rpn_min_size, (float*)n->rois.p, nullptr));
   return MNC_OK;
@@ -751,7 +760,7 @@ int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* n
   if (s == "data") return set(net->data.p, 4, 1, 3, net->OH, net->OW);
   if (s == "conv5_3") return set(net->act[12].p, 4, 1, c.trunk_channels[4], net->fh, net->fw);
   if (s == "rpn_cls_prob_reshape") return set(net->rpn_prob.p, 4, 1, 2 * A, net->fh, net->fw);
-  if (s == "rpn_bbox_pred") return set(net->rpn_bbox.p, 4, 1, 4 * A, net->fh, net->fw);
+  if (s == "rpn_bbox_pred") return set(net->rpn_bbox_p, 4, 1, 4 * A, net->fh, net->fw);
   if (s == "rois") return set(net->rois.p, 2, R1, 5, 0, 0);
   if (s == "rois_ext") return set(net->rois_ext.p, 2, R2, 5, 0, 0);
   if (s == "mask_proposal") return set(net->masks.p, 4, R1 + R2, 1, c.mask_size, c.mask_size);
@@ -768,14 +777,14 @@ int mnc_net_destroy(mnc_net* net) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (net->gexec) (void)hipGraphExecDestroy(net->gexec);
-  DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_bbox, &net->rpn_prob, &net->rois,
+  DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_prob, &net->rois,
                     &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
                     &net->feat14_sm, &net->box7_sm, &net->mask7_sm,
                     &net->heads, &net->boxes, &net->masks, &net->scores, &net->records, &net->counts};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);
   for (auto& b : net->pooled) if (b.p) (void)hipFree(b.p);
-  void* singles[] = {net->w_c3, net->w_rpn_cls, net->b_rpn_cls, net->w_rpn_box, net->b_rpn_box};
+  void* singles[] = {net->w_c3, net->w_rpn, net->b_rpn};
   for (void* p : singles) if (p) (void)hipFree(p);
   for (int i = 0; i < 14; ++i) {
     if (net->w_conv[i]) (void)hipFree(net->w_conv[i]);

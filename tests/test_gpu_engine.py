@@ -528,6 +528,45 @@ def test_resnet50_trunk_graph(math, monkeypatch):
         net.close()
 
 
+def test_resnet50_full_width_f16_activation_tensors(monkeypatch):
+    """The ResNet-50 C4 trunk at FULL width in the f16 mode: with fp16 activation tensors from conv1 to res4e (the residual stream
+    is rounded to fp16 once per block, 16 blocks deep) the trunk stays as close to the fp32 oracle as with fp32 tensors between
+    the fp16-arithmetic layers (MNC_F16_ACTS=0) -- both are logged -- and inside the mode's 5e-3 bar; planned formats checked."""
+    import caffe
+    path = models.write_mnc_resnet50_test_prototxt(width_div=1)
+    # trunk only: the RoI heads of the full-width graph need 1.7 GB of synthetic FC weights; cut the graph after rpn_conv_3x3
+    text = open(path).read()
+    cut = text.rfind("layer {", 0, text.index('name: "rpn_cls_score"'))
+    trunk_path = path.replace(".prototxt", "_trunk.prototxt")
+    with open(trunk_path, "w") as f:
+        f.write(text[:cut])
+    w = synth.synthetic_weights(trunk_path, seed=11)
+    H, W = 256, 384
+    rng = np.random.default_rng(3)
+    data = rng.uniform(-120, 130, (1, 3, H, W)).astype(np.float32)
+    im_info = np.array([[H, W, 1.0]], np.float32)
+    ref = {}
+    onet.trunk_resnet50(w, data, ref)
+    errs = {}
+    for acts in ("1", "0"):
+        monkeypatch.setenv("MNC_MATH", "f16")
+        monkeypatch.setenv("MNC_F16_ACTS", acts)
+        net = caffe.Net(trunk_path, w, caffe.TEST)
+        try:
+            net.forward(data=data, im_info=im_info)
+            if acts == "1":
+                by_name = {L.name: L for L in net._layers}
+                assert by_name["conv1"].out_h and by_name["res2a_branch2c"].out_h and by_name["res4e_branch2c"].out_h
+                assert net.blobs["res4e"].layout == "c8h"       # (res4f too in this cut graph: only rpn_conv_3x3 reads it)
+            errs[acts] = {n: err(net.blobs[n]._host_read(), ref[n])[1] for n in ("pool1", "res2c", "res3d", "res4f")}
+        finally:
+            net.close()
+    lines = ["%-6s fp16 tensors %.3e   fp32 tensors %.3e" % (n, errs["1"][n], errs["0"][n]) for n in errs["1"]]
+    print("\n".join(lines))
+    _log(lines)
+    assert errs["1"]["res4f"] < F16_TOL and errs["1"]["res4f"] < 3.0 * errs["0"]["res4f"] + 1e-3
+
+
 def _device_arrays(net, boxes, masks, scores):
     """Host voting inputs as DeviceArrays of `net` (what Net.detect_tail hands to gpu_mask_voting)."""
     from mnc_amd import _lib
