@@ -241,6 +241,13 @@ MNC_API int mnc_conv_stem_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* 
                              int H, int W, int Cout, int K, int stride, int pad, int relu);
 MNC_API int mnc_conv_stem_c3_fmt(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, void* d_out,
                                  int H, int W, int Cout, int K, int stride, int pad, int relu, int out_packed);
+/* "f16" math mode of the stem: the same convolution on the fp16 matrix pipe (csrc/conv_gen.hip: the kernel rows padded to 8 taps,
+ * so a lane's 8 K-values are 8 consecutive input pixels read straight from the NCHW blob; weights in registers).  Input rounded
+ * to fp16 in registers, weights once by mnc_pack_conv_stem_f16 ([ceil(3K/2)][Cout/32][64] x 16 bytes), fp32 accumulate; output
+ * fp32 c8 or packed fp16 c8.  K = 3, 5 or 7; Cout%32==0. */
+MNC_API int mnc_pack_conv_stem_f16(mnc_ctx* ctx, const float* d_w_oihw, void* d_packed, int Cout, int K);
+MNC_API int mnc_conv_stem_f16(mnc_ctx* ctx, const float* d_in_nchw, const void* d_w_packed, const float* d_bias, void* d_out, int H,
+                              int W, int Cout, int K, int stride, int pad, int relu, int out_packed);
 /* Pooling MAX with any kernel / stride / pad on a c8 map; Caffe's ceil output size, windows clipped to the image.
  * mnc_maxpool_c8_f16: the same on the packed fp16 c8 tensor (max commutes with the rounding: bit for bit the fp16 form of
  * the fp32 result). */

@@ -553,3 +553,143 @@ int mnc_add(mnc_ctx* ctx, const float* d_a, const float* d_b, float* d_out, size
                      (long)n, relu);
   return ls.finish("add_kernel");
 }
+
+// ---- stem convolution on the fp16 matrix pipe ("f16" math mode; ResNet conv1 7x7/2 pad 3 on the 3-channel input blob) ---------
+// The VALU stem above runs at 19 TFLOP/s (0.26 ms at 800x1333: one LDS weight read per 4 FMAs, the input re-read per 16-channel
+// group).  As a GEMM: M = output channels, N = pixels, K = (input channel, kernel row) x 8 kernel columns -- the kernel row is
+// padded from K to 8 taps with zero weights, so that a lane's 8 K-values are 8 CONSECUTIVE input pixels of one row: the B
+// fragment of pixel (oy, ox), K-step ks, lane half kb is in[c][oy * stride - pad + ky][ox * stride - pad .. + 7] with
+// (c, ky) = divmod(2 ks + kb, K), straight from the NCHW fp32 blob (rounded to fp16 in registers), no im2col buffer, no LDS.
+// The weights (3 K rows x 8 taps = 168 values for 7x7: 11 K-steps) are packed once in A-fragment order and live in REGISTERS
+// for the whole kernel (CT x KS x 4 VGPRs); a wave walks 32-pixel row segments with a grid stride.  Row segments whose windows
+// lie inside the image take unconditional loads; border segments select zeros per element.
+template <int CT, int KS>
+__global__ __launch_bounds__(256) void conv_stem_f16_kernel(const float* __restrict__ in, const uint4* __restrict__ wpk,
+                                                            const float* __restrict__ bias, void* __restrict__ out, int H, int W,
+                                                            int stride, int pad, int OH, int OW, int relu, int out_pk) {
+  constexpr int K = (2 * KS) / 3;                         // KS = ceil(3 K / 2): 11 -> 7, 8 -> 5, 5 -> 3
+  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };     // a dword-aligned 16-byte global load
+  const int lane = threadIdx.x & 63, j = lane & 31, kb = lane >> 5;
+  const int co_group = blockIdx.y;                        // CT x 32 output channels
+  uint4 a[KS][CT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) a[ks][c] = wpk[((long)ks * gridDim.y * CT + co_group * CT + c) * 64 + lane];
+  const int segs = (OW + 31) >> 5;
+  const unsigned ntiles = (unsigned)OH * segs;
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  const long P = (long)OH * OW;
+  for (unsigned t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; t < ntiles; t += nwaves) {
+    const unsigned tile = __builtin_amdgcn_readfirstlane(t);
+    const int oy = (int)(tile / (unsigned)segs), ox0 = (int)(tile % (unsigned)segs) * 32;
+    const int ox = ox0 + j;
+    const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+    // the segment's windows: rows iy0 .. iy0 + K - 1, columns (ox0 * stride - pad) .. ((ox0 + 31) * stride - pad + 7)
+    const bool inside = iy0 >= 0 && iy0 + K <= H && ox0 * stride - pad >= 0 && (ox0 + 31) * stride - pad + 8 <= W;
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int q = 2 * ks + kb;                          // (input channel, kernel row); q >= 3 K: the zero-weight padding of K
+      const int c = min(q / K, 2), ky = q - (q / K) * K;
+      const int iy = iy0 + ky;
+      float v[8];
+      if (inside) {
+        const F4* p = reinterpret_cast<const F4*>(in + ((long)c * H + iy) * W + ix0);
+        const F4 lo = p[0], hi = p[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      } else {
+        const bool rowok = iy >= 0 && iy < H && q < 3 * K;
+        const float* p = in + ((long)c * H + min(max(iy, 0), H - 1)) * W;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ix = ix0 + e;
+          const float x = p[min(max(ix, 0), W - 1)];
+          v[e] = (rowok && ix >= 0 && ix < W) ? x : 0.f;
+        }
+      }
+      const gen_f16x8 b = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3],
+                           (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc)
+        acc[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gen_f16x8, a[ks][cc]), b, acc[cc], 0, 0, 0);
+    }
+    if (ox < OW) {
+      const long p = (long)oy * OW + ox;
+#pragma unroll
+      for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = (co_group * CT + cc) * 32 + g * 8 + kb * 4;
+          const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+          float4 o = make_float4(acc[cc][g * 4 + 0] + bv.x, acc[cc][g * 4 + 1] + bv.y, acc[cc][g * 4 + 2] + bv.z,
+                                 acc[cc][g * 4 + 3] + bv.w);
+          if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          const long idx = ((long)(co >> 3) * P + p) * 2 + kb;
+          if (out_pk) reinterpret_cast<uint2*>(out)[idx] = x3_f16x4(o);
+          else reinterpret_cast<float4*>(out)[idx] = o;
+        }
+    }
+  }
+}
+
+// [Cout][3][K][K] fp32 -> A fragments [KS][Cout/32][64 lanes] x 8 halves: lane (i, kb) of (ks, ct) holds, for (c, ky) =
+// divmod(2 ks + kb, K), W[ct*32 + i][c][ky][0..7] (taps >= K and rows >= 3 K are zero).
+__global__ void pack_conv_stem_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int K, int KS) {
+  const int CoT = Cout >> 5;
+  const int total = KS * CoT * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, t = idx >> 6;
+    const int ct = t % CoT, ks = t / CoT;
+    const int co = ct * 32 + (lane & 31), q = 2 * ks + (lane >> 5);
+    gen_f16x8 h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    if (q < 3 * K) {
+      const float* p = w + ((long)co * 3 * K + q) * K;          // [co][c][ky][.] with q = c * K + ky
+      for (int e = 0; e < K; ++e) h[e] = (_Float16)p[e];
+    }
+    out[idx] = __builtin_bit_cast(uint4, h);
+  }
+}
+
+extern "C" {
+
+int mnc_pack_conv_stem_f16(mnc_ctx* ctx, const float* d_w_oihw, void* d_packed, int Cout, int K) {
+  MNC_REQUIRE(ctx && d_w_oihw && d_packed && Cout > 0 && Cout % 32 == 0 && K > 0 && K <= 8,
+              "mnc_pack_conv_stem_f16: bad argument (Cout%%32==0, K <= 8)");
+  const int KS = (3 * K + 1) / 2;
+  LaunchScope ls(ctx, "pack_conv_stem_f16");
+  hipLaunchKernelGGL(pack_conv_stem_f16_kernel, dim3(cdiv((long)KS * (Cout / 32) * 64, 256)), dim3(256), 0, ctx->stream, d_w_oihw,
+                     (uint4*)d_packed, Cout, K, KS);
+  return ls.finish("pack_conv_stem_f16_kernel");
+}
+
+int mnc_conv_stem_f16(mnc_ctx* ctx, const float* d_in_nchw, const void* d_w_packed, const float* d_bias, void* d_out, int H, int W,
+                      int Cout, int K, int stride, int pad, int relu, int out_packed) {
+  MNC_REQUIRE(ctx && d_in_nchw && d_w_packed && d_bias && d_out, "mnc_conv_stem_f16: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 32 == 0 && (K == 7 || K == 3 || K == 5) && stride > 0 && pad >= 0 &&
+                  H + 2 * pad >= K && W + 2 * pad >= K,
+              "mnc_conv_stem_f16: bad shape (Cout multiple of 32; K = 3, 5 or 7)");
+  const int OH = conv_out(H, K, stride, pad), OW = conv_out(W, K, stride, pad);
+  const long P = (long)OH * OW;
+  const int CoT = Cout / 32;
+  const int ct = CoT % 2 == 0 ? 2 : 1;
+  const long tiles = (long)OH * cdiv(OW, 32);
+  long gx = (tiles + 3) / 4;                               // 4 waves per workgroup, one row segment per wave and iteration
+  if (gx > 1024) gx = 1024;                                // ~4 waves per SIMD; the rest by the grid-stride loop
+  LaunchScope ls(ctx, "conv_stem_f16", 2.0 * P * Cout * 3.0 * K * K, 4.0 * 3.0 * H * W + (out_packed ? 2.0 : 4.0) * (double)P * Cout);
+  dim3 grid((unsigned)gx, (unsigned)(CoT / ct));
+#define MNC_STEM(CT, KS)                                                                                                    \
+  hipLaunchKernelGGL((conv_stem_f16_kernel<CT, KS>), grid, dim3(256), 0, ctx->stream, d_in_nchw, (const uint4*)d_w_packed, d_bias, \
+                     d_out, H, W, stride, pad, OH, OW, relu, out_packed ? 1 : 0)
+  if (K == 7) { if (ct == 2) MNC_STEM(2, 11); else MNC_STEM(1, 11); }
+  else if (K == 5) { if (ct == 2) MNC_STEM(2, 8); else MNC_STEM(1, 8); }
+  else { if (ct == 2) MNC_STEM(2, 5); else MNC_STEM(1, 5); }
+#undef MNC_STEM
+  return ls.finish("conv_stem_f16_kernel");
+}
+
+}  // extern "C"

@@ -95,12 +95,6 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return ((u64)hi << 32) | lo;
 }
-template <int I>
-__device__ __forceinline__ u64 lane64(u64 v) {
-  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, I), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), I);
-  return ((u64)hi << 32) | lo;
-}
-
 // The greedy chain inside one 64-box block (nms_kernel.cu:128-139) on the scalar unit, visiting only the SURVIVORS: a row
 // survives iff no earlier survivor suppressed it, so the next survivor is always the lowest row not yet suppressed
 // (s_ff1 on the complement of the removal word), and keeping it ORs its word in.  A block of RPN boxes keeps 3-10 of its 64

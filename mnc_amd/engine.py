@@ -748,7 +748,19 @@ class Net(object):
         if kind == "stem":
             if cin != 3 or W.shape[2] != W.shape[3]:
                 raise NotImplementedError("Convolution %s on the input blob: 3 channels, square kernel" % L.name)
-            d_w = self._dev_param(key + ("w",), lambda: self._upload(W))
+            # "f16" mode: the stem on the fp16 matrix pipe like every other convolution of the mode (kernel rows padded to 8 taps,
+            # weights in registers; csrc/conv_gen.hip) -- MNC_STEM_F16=0 keeps the fp32 VALU kernel
+            mfma = (self.math == "f16" and k in (3, 5, 7) and cout % 32 == 0 and os.environ.get("MNC_STEM_F16", "1") != "0")
+            if mfma:
+                def build_stem():
+                    raw = self._upload(W)
+                    packed = self._ctx.alloc(((3 * k + 1) // 2) * (cout // 32) * 1024)
+                    _lib.call("mnc_pack_conv_stem_f16", self._h(), raw, packed, cout, k)
+                    self._ctx.free(raw)
+                    return packed
+                d_w = self._dev_param(key + ("w", "stem_f16"), build_stem)
+            else:
+                d_w = self._dev_param(key + ("w",), lambda: self._upload(W))
 
             def run():
                 N, _, H, Wd = bot.shape
@@ -758,7 +770,7 @@ class Net(object):
                 dst = top.dev_out("c8h" if L.out_h else "c8")
                 ob = 2 if L.out_h else 4
                 for n in range(N):
-                    _lib.call("mnc_conv_stem_c3_fmt", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b,
+                    _lib.call("mnc_conv_stem_f16" if mfma else "mnc_conv_stem_c3_fmt", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b,
                               dst + n * cout * OH * OW * ob, H, Wd, cout, k, stride, pad, relu, 1 if L.out_h else 0)
             return run
         if kind == "fast3x3":

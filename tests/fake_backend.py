@@ -295,6 +295,17 @@ class Fake(object):
             y = F.relu(y)
         _wr_c8(dst, y.numpy(), out_packed)
 
+    def mnc_pack_conv_stem_f16(self, h, src, dst, Cout, K):
+        self._stem16 = getattr(self, "_stem16", {})
+        self._stem16[int(dst)] = _f(src, (Cout, 3, K, K)).astype(np.float16).astype(np.float32)
+
+    def mnc_conv_stem_f16(self, h, src, wpk, b, dst, H, W, Cout, K, stride, pad, relu, out_packed):
+        x = _t(_f(src, (1, 3, H, W)).astype(np.float16).astype(np.float32))
+        y = F.conv2d(x, _t(self._stem16[int(wpk)]), _t(_f(b, (Cout,))), stride=stride, padding=pad)[0]
+        if relu:
+            y = F.relu(y)
+        _wr_c8(dst, y.numpy(), out_packed)
+
     def mnc_pack_conv1x1(self, h, src, dst, Cout, Cin, f16):
         # test double: a side table keyed by the packed buffer's address (the fragment-order packing is checked on the GPU)
         w = _f(src, (Cout, Cin)).copy()

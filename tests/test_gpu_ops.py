@@ -453,6 +453,41 @@ def test_conv_stem_c3(dev, H, W, K, stride, pad):
     assert err(got, want)[1] < 1e-5
 
 
+@pytest.mark.parametrize("H,W,K,stride,pad,Cout", [(75, 101, 7, 2, 3, 64), (64, 64, 7, 2, 3, 64), (31, 45, 3, 1, 1, 32),
+                                                    (40, 150, 5, 2, 2, 96), (9, 70, 7, 2, 3, 64), (200, 333, 7, 2, 3, 64)])
+@pytest.mark.parametrize("out_packed", [0, 1])
+def test_conv_stem_f16_mfma(dev, H, W, K, stride, pad, Cout, out_packed):
+    """mnc_conv_stem_f16 (the stem as a GEMM on the fp16 matrix pipe, B fragments straight from the NCHW blob): exact against torch
+    on fp16-rounded operands up to accumulation order, ~3e-4 of range against fp32; image borders, row segments that end inside
+    a 32-pixel tile, maps narrower than a tile's windows (every segment takes the border path), odd sizes."""
+    rng = np.random.default_rng(H + W + K)
+    x = rng.uniform(-120, 130, (3, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, 3, K, K)) * 0.02).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+    ref = lambda xx, ww: F.relu(F.conv2d(torch.from_numpy(xx)[None], torch.from_numpy(ww), torch.from_numpy(b), stride=stride,
+                                         padding=pad))[0].numpy()
+    want16, want32 = ref(r16(x), r16(w)), ref(x, w)
+    OH, OW = want32.shape[1:]
+    KS = (3 * K + 1) // 2
+    d_w = dev.empty((KS * (Cout // 32) * 1024,), dtype=np.uint8, fill=0xFF)
+    dev.call("mnc_pack_conv_stem_f16", dev.put(w), d_w, Cout, K)
+    n = Cout * OH * OW
+    d_y = dev.empty((n,), fill=np.nan)
+    dev.call("mnc_conv_stem_f16", dev.put(x), d_w, dev.put(b), d_y, H, W, Cout, K, stride, pad, 1, out_packed)
+    if out_packed:
+        got = from_c8(dev.get(d_y, (n,), dtype=np.float16).astype(np.float32), Cout, OH, OW)
+        assert not np.isnan(got).any()
+        tol = np.abs(want16) * 2.0 ** -11 + 2.0 ** -24 + 2e-5 * np.abs(want16).max()
+        assert (np.abs(got - want16) <= tol).all(), float(np.abs(got - want16).max())
+    else:
+        got = from_c8(dev.get(d_y, (n,)), Cout, OH, OW)
+        assert not np.isnan(got).any()
+        rel, rel32 = err(got, want16)[1], err(got, want32)[1]
+        print("stem f16 %dx%d k%d s%d -> %d: vs fp16-rounded rel=%.3e, vs fp32 rel=%.3e" % (H, W, K, stride, Cout, rel, rel32))
+        assert rel < 1e-5 and rel32 < 2e-3
+
+
 @pytest.mark.parametrize("H,W,K,stride,pad", [(112, 112, 3, 2, 0), (100, 167, 3, 2, 0), (101, 166, 3, 2, 1), (37, 41, 2, 2, 0)])
 def test_maxpool_general_and_add(dev, H, W, K, stride, pad):
     rng = np.random.default_rng(H)
