@@ -363,8 +363,11 @@ def main():
                                    "mAP unverifiable)" % (conf["what"], H, W, conf["rois"], 2 * conf["rois"], H, W,
                                                           MATH_NOTE[math]),
                        "images_per_step": world, "rois_per_stage": conf["rois"], "math": math,
-                       "parallelism": ("images sharded 1/GPU, %d ranks; ncclAllGather of [100,447] instance blocks on the "
-                                       "engine stream" % world) if world > 1 else
+                       "parallelism": (("images sharded 1/GPU, %d ranks; ncclAllGather of [100,447] instance blocks on the "
+                                        "engine stream" % world) if on_gpu else
+                                       ("images sharded over %d ranks on %d GPU(s); functional run: [100,447] instance blocks "
+                                        "gathered through torch.distributed/%s on the host" % (world, ndev, args.dist_backend)))
+                                      if world > 1 else
                                       ("single GPU (1 rank under the launcher, RCCL gather of the block included)" if launched
                                        else "single GPU")},
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
