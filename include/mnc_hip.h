@@ -343,6 +343,15 @@ MNC_API int mnc_fc_f16_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const
                            float* d_out, int M, int N, int K, int ldc, int act);
 MNC_API int mnc_fc_bf16x3_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
                               float* d_out, int M, int N, int K, int ldc, int act);
+/* The general form of the two: activations as fp32 rows (d_a) or stage-major (d_a_sm, m_stride) -- exactly one non-NULL -- and,
+ * optionally (d_out_sm != NULL), the result rows written a second time in the stage-major form of the NEXT reduced-precision
+ * InnerProduct (out_sm_fmt 1: [N/64][M][64] halves, N%64==0; 2: split bf16, N%32==0) by the K-split reduction: fc6 -> fc7 without a
+ * conversion pass.  Bit for bit mnc_fc_pack_act of d_out. */
+MNC_API int mnc_fc_f16_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed,
+                          const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt);
+MNC_API int mnc_fc_bf16x3_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed,
+                             const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm,
+                             int out_sm_fmt);
 MNC_API int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
                             float spatial_scale, int pool2, float* d_out_rhwc, void* d_sm, int sm_fmt);
 MNC_API int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C, void* d_sm,

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "mnc_internal.h"
+#include "x3_split.h"
 
 namespace mnc {
 
@@ -242,10 +243,14 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 
 // out = act(sum over splits (in split order) + bias).  VEC = 4: N % 4 == 0 and ldc % 4 == 0 -- one thread per four columns,
 // 16-byte loads, four splits in flight; the per-element order of the additions is that of the scalar kernel.
-template <int VEC>
+// SM != 0 (VEC = 4 only): the result rows are written a second time in the stage-major 2-byte form the NEXT reduced-precision
+// InnerProduct multiplies from (x3_split.h: sm_store4; sm_rows rows, this call's rows start at sm_row0) -- fc6 -> fc7 without
+// a conversion pass.
+template <int VEC, int SM = 0>
 __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                         float* __restrict__ out, int M, int N, int ldc, int splits,
-                                                        int act) {
+                                                        int act, void* __restrict__ sm = nullptr, long sm_rows = 0,
+                                                        long sm_row0 = 0) {
   const long total = (long)M * N;
   if (VEC == 4) {
     const int n4 = N >> 2;
@@ -269,8 +274,10 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
       }
       const float4 b = *reinterpret_cast<const float4*>(bias + n);
-      *reinterpret_cast<float4*>(out + m * ldc + n) =
+      const float4 y =
           make_float4(apply_act(v.x + b.x, act), apply_act(v.y + b.y, act), apply_act(v.z + b.z, act), apply_act(v.w + b.w, act));
+      *reinterpret_cast<float4*>(out + m * ldc + n) = y;
+      if (SM) sm_store4<SM>(sm, sm_rows, sm_row0 + m, n, y);          // lanes 2j / 2j+1 hold the halves of one 8-column group
     }
     return;
   }
@@ -285,13 +292,26 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
 
 void fc_reduce_launch(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
                       int act) {
+  fc_reduce_launch_sm(stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0, 0, 0);
+}
+
+// as above + the second output (sm_fmt 1 fp16 / 2 split bf16; needs N % 64 resp. % 32 == 0 and the vector path); returns false
+// when the second output could not be written (the caller then converts the fp32 rows)
+bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
+                         int act, void* sm, int sm_fmt, long sm_rows, long sm_row0) {
   const bool vec = N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                    (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
   const long items = vec ? (long)M * N / 4 : (long)M * N;
   int g = (int)((items + 255) / 256);
   if (g > 4096) g = 4096;
-  if (vec) hipLaunchKernelGGL(fc_reduce_kernel<4>, dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act);
-  else hipLaunchKernelGGL(fc_reduce_kernel<1>, dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act);
+  const bool sm_ok = sm && vec && ((sm_fmt == 1 && N % 64 == 0) || (sm_fmt == 2 && N % 32 == 0));
+  if (sm_ok && sm_fmt == 1)
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 1>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, sm, sm_rows, sm_row0);
+  else if (sm_ok)
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 2>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, sm, sm_rows, sm_row0);
+  else if (vec) hipLaunchKernelGGL((fc_reduce_kernel<4, 0>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0L, 0L);
+  else hipLaunchKernelGGL((fc_reduce_kernel<1, 0>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0L, 0L);
+  return sm_ok;
 }
 
 __global__ void softmax_rows_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int M, int N) {

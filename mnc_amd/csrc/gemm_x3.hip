@@ -362,7 +362,8 @@ using namespace mnc;
 // into the scratch arena (one elementwise pass per call: 10-200 us that the producers' epilogues make unnecessary).
 template <int F16>
 static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4* d_pre, int mstride, const void* d_w_packed,
-                   const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act) {
+                   const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act, void* d_osm = nullptr, int osm_fmt = 0,
+                   long osm_rows = 0, long osm_row0 = 0) {
   constexpr int kStage = F16 ? 64 : kXBK;
   if (M == 0) return MNC_OK;
   // Several row blocks (M > 320: the 1000-RoI ResNet configuration, CFM): every block streams its whole weight panel, so a
@@ -379,10 +380,12 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   // full 320-row blocks and a ragged tail of at most 160 rows are two launches, each with its own tile height (see mnc_fc)
   if (!rows256 && M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
     const int head = M / 320 * 320;
-    int rc = fc_lowp<F16>(ctx, what, d_a, d_pre, mstride, d_w_packed, d_bias, d_out, head, N, K, ldc, act);
+    int rc = fc_lowp<F16>(ctx, what, d_a, d_pre, mstride, d_w_packed, d_bias, d_out, head, N, K, ldc, act, d_osm, osm_fmt, osm_rows,
+                          osm_row0);
     if (rc) return rc;
     return fc_lowp<F16>(ctx, what, d_a ? d_a + (size_t)head * K : nullptr, d_pre ? d_pre + (size_t)head * 8 : nullptr, mstride,
-                        d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+                        d_w_packed, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act, d_osm, osm_fmt, osm_rows,
+                        osm_row0 + head);
   }
   // row tiles per workgroup: 2 (64 rows) for the small GEMMs, else the smallest of {5, 10} that covers M in one block
   const bool small = 2.0 * M * (double)N * K < 2.0e9;
@@ -455,10 +458,21 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     rc = ls.finish(F16 ? "fc_x3_kernel<f16>" : "fc_x3_kernel");
     if (rc) return rc;
   }
+  bool osm_done = false;
   if (splits > 1) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
-    fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
-    return ls.finish("fc_reduce_kernel");
+    osm_done = fc_reduce_launch_sm(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act, d_osm, osm_fmt, osm_rows, osm_row0);
+    rc = ls.finish("fc_reduce_kernel");
+    if (rc) return rc;
+  }
+  if (d_osm && !osm_done) {
+    // no reduction pass to write it from (one K split: the GEMM's epilogue stored the rows), or a shape the reduction's vector
+    // path does not take: convert the rows just written (row-major, ldc == N required by the entry point in that case)
+    MNC_REQUIRE(ldc == N && osm_rows == M && osm_row0 == 0, "%s: the second output needs a K-split reduction or dense rows", what);
+    LaunchScope ls(ctx, osm_fmt == 1 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (osm_fmt == 1 ? 6.0 : 8.0) * M * (double)N);
+    if (osm_fmt == 1) f16_pack_launch(ctx, d_out, (uint4*)d_osm, M, N, M, 1);
+    else x3_pack_launch(ctx, d_out, (uint4*)d_osm, M, N, M, 1);
+    return ls.finish("pack kernel");
   }
   return MNC_OK;
 }
@@ -512,6 +526,29 @@ int mnc_fc_f16_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d
               "mnc_fc_f16_pre: unsupported shape M=%d (stride %d) N=%d K=%d ldc=%d act=%d (need K%%64==0)", M, m_stride, N, K, ldc,
               act);
   return fc_lowp<1>(ctx, "mnc_fc_f16_pre", nullptr, (const uint4*)d_a_sm, m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act);
+}
+
+// The general form: activations as fp32 rows (d_a) or already stage-major (d_a_sm, m_stride rows) -- exactly one of the two --
+// and, optionally, the result rows a second time in the stage-major form of the NEXT reduced-precision InnerProduct
+// (d_out_sm: [N/64][M][64] halves for out_sm_fmt 1, [N/32][M][4][hi x8 | lo x8] for 2; written by the K-split reduction).
+int mnc_fc_f16_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
+                  float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt) {
+  MNC_REQUIRE(ctx && (d_a != nullptr) != (d_a_sm != nullptr) && d_w_packed && d_bias && d_out, "mnc_fc_f16_ex: null pointer / both inputs");
+  MNC_REQUIRE(M >= 0 && (d_a || m_stride >= M) && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2 &&
+                  (!d_out_sm || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
+              "mnc_fc_f16_ex: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
+  return fc_lowp<1>(ctx, "mnc_fc_f16_ex", d_a, (const uint4*)d_a_sm, d_a ? M : m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act,
+                    d_out_sm, d_out_sm ? out_sm_fmt : 0, M, 0);
+}
+
+int mnc_fc_bf16x3_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
+                     float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt) {
+  MNC_REQUIRE(ctx && (d_a != nullptr) != (d_a_sm != nullptr) && d_w_packed && d_bias && d_out, "mnc_fc_bf16x3_ex: null pointer / both inputs");
+  MNC_REQUIRE(M >= 0 && (d_a || m_stride >= M) && N > 0 && K > 0 && K % kXBK == 0 && ldc >= N && act >= 0 && act <= 2 &&
+                  (!d_out_sm || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
+              "mnc_fc_bf16x3_ex: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
+  return fc_lowp<0>(ctx, "mnc_fc_bf16x3_ex", d_a, (const uint4*)d_a_sm, d_a ? M : m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act,
+                    d_out_sm, d_out_sm ? out_sm_fmt : 0, M, 0);
 }
 
 // fp32 row-major [M][K] -> the stage-major 2-byte activation form of mnc_fc_{f16,bf16x3}_pre (what those entry points' producers

@@ -147,6 +147,8 @@ void comm_free(mnc_ctx* ctx);           // comm.hip
 // out = act(sum of the ksplit partial c8 tensors + bias)  (conv.hip; shared with conv_x3.hip)
 void fc_reduce_launch(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
                       int act);   // gemm.hip: out = act(sum of the K splits' partial sums + bias), shared by the three FC kernels
+bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
+                         int act, void* sm, int sm_fmt, long sm_rows, long sm_row0);   // + the rows in the next InnerProduct's form
 void conv_splitk_reduce_launch(hipStream_t stream, const float* d_part, const float* d_bias, float* d_out, int H, int W,
                                int Cout, int ksplit, int relu);
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,

@@ -91,7 +91,7 @@ struct mnc_net {
   DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores, records, counts;
   // the per-RoI tensors a second time, in the stage-major 2-byte form their reduced-precision InnerProduct multiplies from
   // (written by the producing kernel's epilogue: mnc_roi_warp_sm / mnc_maxpool2_rhwc_sm / mnc_mask_pool_sm), bf16x3 / f16 modes
-  DevBuf feat14_sm, box7_sm, mask7_sm;
+  DevBuf feat14_sm, box7_sm, mask7_sm, f6_sm, f6m_sm;       // f6 / f6m: written by fc6 / fc6_mask's reduction for fc7 / fc7_mask
   unsigned char* pin_img = nullptr; size_t pin_img_cap = 0;
   float* pin_out = nullptr; size_t pin_out_cap = 0;       // [counts (64 ints) | proposal count (64 ints) | records]
   // per-image state
@@ -208,10 +208,15 @@ int sm_format(const mnc_net::Fc& fc, int C) {
   return 0;
 }
 // the InnerProduct on rows that exist in both forms: a_sm (m_stride = M rows) when the kernel takes it, the fp32 rows otherwise
-int run_fc_sm(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, const void* a_sm, int fmt, float* out, int M, int ldc, int act) {
+// out_sm / out_fmt: the result rows a second time in the form the NEXT InnerProduct (of format out_fmt) multiplies from
+int run_fc_sm(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, const void* a_sm, int fmt, float* out, int M, int ldc, int act,
+              void* out_sm = nullptr, int out_fmt = 0) {
   if (M == 0) return MNC_OK;
-  if (fmt == 1) return mnc_fc_f16_pre(ctx, a_sm, M, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
-  if (fmt == 2) return mnc_fc_bf16x3_pre(ctx, a_sm, M, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
+  if (!out_sm) out_fmt = 0;
+  if (fc.kind == 2) return mnc_fc_f16_ex(ctx, fmt == 1 ? nullptr : a, fmt == 1 ? a_sm : nullptr, M, fc.w, fc.b, out, M, fc.N, fc.K, ldc,
+                                         act, out_fmt ? out_sm : nullptr, out_fmt);
+  if (fc.kind == 1) return mnc_fc_bf16x3_ex(ctx, fmt == 2 ? nullptr : a, fmt == 2 ? a_sm : nullptr, M, fc.w, fc.b, out, M, fc.N, fc.K,
+                                            ldc, act, out_fmt ? out_sm : nullptr, out_fmt);
   return run_fc(ctx, fc, a, out, M, ldc, act);
 }
 
@@ -331,6 +336,8 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   if (sm_format(n->fc6m, C5)) NET_TRY(dev_ensure(n, &n->mask7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6m.kind == 2 ? 2 : 4)));
   NET_TRY(dev_ensure(n, &n->f6, (size_t)R * F * 4));
   NET_TRY(dev_ensure(n, &n->f6m, (size_t)R * F * 4));
+  if (sm_format(n->fc7, F)) NET_TRY(dev_ensure(n, &n->f6_sm, (size_t)R * F * (n->fc7.kind == 2 ? 2 : 4)));
+  if (sm_format(n->fc7m, F)) NET_TRY(dev_ensure(n, &n->f6m_sm, (size_t)R * F * (n->fc7m.kind == 2 ? 2 : 4)));
   NET_TRY(dev_ensure(n, &n->join, (size_t)R * 2 * F * 4));
   NET_TRY(dev_ensure(n, &n->heads, (size_t)R * 6 * K * 4));
   NET_TRY(dev_ensure(n, &n->boxes, (size_t)2 * R * 4 * 4));
@@ -494,13 +501,14 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
     MNC_HIP_TRY(hipStreamWaitEvent(cb->stream, n->ev_fork[si], 0));
   }
   if (!one_pass) NET_TRY(mnc_maxpool2_rhwc_sm(cb, feat14, (float*)n->box7.p, R, P, P, C5, n->box7_sm.p, sm_box));
-  NET_TRY(run_fc_sm(cb, n->fc6, (const float*)n->box7.p, n->box7_sm.p, sm_box, (float*)n->f6.p, R, F, 1));
-  NET_TRY(run_fc(cb, n->fc7, (const float*)n->f6.p, join + F, R, 2 * F, 1));
+  const int sm_f6 = sm_format(n->fc7, F), sm_f6m = sm_format(n->fc7m, F);
+  NET_TRY(run_fc_sm(cb, n->fc6, (const float*)n->box7.p, n->box7_sm.p, sm_box, (float*)n->f6.p, R, F, 1, n->f6_sm.p, sm_f6));
+  NET_TRY(run_fc_sm(cb, n->fc7, (const float*)n->f6.p, n->f6_sm.p, n->fc6.kind ? sm_f6 : 0, join + F, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipEventRecord(n->ev_join[si], cb->stream));
   if (!one_pass)
     NET_TRY(mnc_mask_pool_sm(ctx, feat14, (const float*)n->m14.p, (float*)n->mask7.p, R, P, P, C5, 1, n->mask7_sm.p, sm_mask));
-  NET_TRY(run_fc_sm(ctx, n->fc6m, (const float*)n->mask7.p, n->mask7_sm.p, sm_mask, (float*)n->f6m.p, R, F, 1));
-  NET_TRY(run_fc(n, n->fc7m, (const float*)n->f6m.p, join, R, 2 * F, 1));
+  NET_TRY(run_fc_sm(ctx, n->fc6m, (const float*)n->mask7.p, n->mask7_sm.p, sm_mask, (float*)n->f6m.p, R, F, 1, n->f6m_sm.p, sm_f6m));
+  NET_TRY(run_fc_sm(ctx, n->fc7m, (const float*)n->f6m.p, n->f6m_sm.p, n->fc6m.kind ? sm_f6m : 0, join, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));
   float* heads = (float*)n->heads.p;
   NET_TRY(run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0));
@@ -779,7 +787,7 @@ int mnc_net_destroy(mnc_net* net) {
   if (net->gexec) (void)hipGraphExecDestroy(net->gexec);
   DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_prob, &net->rois,
                     &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
-                    &net->feat14_sm, &net->box7_sm, &net->mask7_sm,
+                    &net->feat14_sm, &net->box7_sm, &net->mask7_sm, &net->f6_sm, &net->f6m_sm,
                     &net->heads, &net->boxes, &net->masks, &net->scores, &net->records, &net->counts};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);

@@ -36,40 +36,8 @@ __global__ __launch_bounds__(256) void c8_to_hwc_kernel(const float* __restrict_
   }
 }
 
-// Second output of the per-RoI producers: the tensor in the stage-major 2-byte form the reduced-precision InnerProducts multiply
-// from (mnc_hip.h: mnc_fc_{f16,bf16x3}_pre), written by the threads that hold the fp32 values -- the FC's own conversion pass
-// (read M x K fp32, write M x K halves; 0.2 ms per image at 300 RoIs, 0.75 ms at 1000 RoIs x 1024 channels) disappears.
-// SM: 0 none, 1 = fp16 [K/64][M][64], 2 = split bf16 [K/32][M][4][hi x8 | lo x8]; k = position * C + channel.
-// A thread owns 4 consecutive channels (k a multiple of 4), its neighbour lane (lane ^ 1) the other half of the same 8-channel
-// group: the two exchange halves so that every store is a full 16-byte group (8-byte stores from every lane measured 15-20 %
-// slower on these kernels: 521 vs 430 us for the 14x14 warp of 1000 RoIs x 1024 channels).  All 64 lanes must call it together
-// (the callers' element counts are multiples of 64 per wave: C % 8 == 0 and whole positions).
-template <int SM>
-__device__ __forceinline__ void sm_store4(void* __restrict__ sm, long M, long r, long k, const float4 v) {
-  const bool odd = (k >> 2) & 1;
-  const long k8 = k & ~7L;
-  if (SM == 1) {
-    const uint2 mine = x3_f16x4(v);
-    const unsigned ox = __shfl_xor(mine.x, 1), oy = __shfl_xor(mine.y, 1);
-    if (!odd) reinterpret_cast<uint4*>(sm)[((k8 >> 6) * M + r) * 8 + ((k8 & 63) >> 3)] = make_uint4(mine.x, mine.y, ox, oy);
-  } else if (SM == 2) {
-    unsigned h[4], l[4];
-    const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      h[e] = x3_rne(x[e]);
-      l[e] = x3_rne(x[e] - __uint_as_float(h[e]));
-    }
-    const uint2 hi = make_uint2(x3_pack_hi16(h[0], h[1]), x3_pack_hi16(h[2], h[3]));
-    const uint2 lo = make_uint2(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]));
-    // the even lane writes the group's hi x8 (its own half, then the neighbour's), the odd lane the lo x8 (neighbour's, then own)
-    const uint2 give = odd ? hi : lo;
-    const uint2 got = make_uint2(__shfl_xor(give.x, 1), __shfl_xor(give.y, 1));
-    uint4* p = reinterpret_cast<uint4*>(sm) + (((k8 >> 5) * M + r) * 4 + ((k8 & 31) >> 3)) * 2;
-    if (!odd) p[0] = make_uint4(hi.x, hi.y, got.x, got.y);
-    else p[1] = make_uint4(got.x, got.y, lo.x, lo.y);
-  }
-}
+// sm_store4 / sm_store8 (x3_split.h): the second output of the per-RoI producers, the tensor in the stage-major 2-byte form the
+// reduced-precision InnerProducts multiply from (mnc_hip.h: mnc_fc_{f16,bf16x3}_pre).
 
 // One bilinear sample of 4 channels at feature-map position (sx, sy); taps outside the map contribute 0.
 // SPEC.md section 1: w00*f00 + w01*f01 + w10*f10 + w11*f11 in that order.  `px` = hwc feature map + the lane's channel offset.

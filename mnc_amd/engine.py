@@ -1202,12 +1202,17 @@ class Net(object):
                 state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
             want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2}.get(state.get("fn"), 0)
             sm = bot._sm
-            if (M and want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K and bot._dev_valid
-                    and bot.layout == state["layout"]):
-                # the producer already wrote the rows in this kernel's own 2-byte form (Blob._sm): no conversion pass
+            pre = (M and want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K and bot._dev_valid
+                   and bot.layout == state["layout"])
+            if M and want:
+                # reduced-precision kernel: the rows arrive in its own 2-byte form when the producer wrote them (Blob._sm: no
+                # conversion pass), and leave in the NEXT InnerProduct's form as well when one will read them (fc6 -> fc7)
+                src = None if pre else bot.dev_in(state["layout"])
                 top.reshape(M, n_out)
                 dst = top.dev_out("plain")
-                _lib.call(state["fn"] + "_pre", self._h(), sm["ptr"], M, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+                ofmt = self._sm_format(top.name, M, n_out, n_out) if top._view is None else 0
+                _lib.call(state["fn"] + "_ex", self._h(), src, sm["ptr"] if pre else None, M, state["w"], d_b, dst, M, n_out, K,
+                          top._ld(), act, top.sm_out(ofmt, M, n_out) if ofmt else None, ofmt)
                 return
             src = bot.dev_in(state["layout"]) if M else 0
             top.reshape(M, n_out)

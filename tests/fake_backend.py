@@ -439,6 +439,23 @@ class Fake(object):
         self.mnc_maxpool2_rhwc_sm(h, feat, box, R, PH, PW, C, box_sm, fmt)
         self.mnc_mask_pool_sm(h, feat, mask, mout, R, PH, PW, C, 1, mask_sm, fmt)
 
+    def _fc_ex(self, fn, fmt16, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
+        if sm:
+            rows = _h16(sm, (mstride, K))[:M].astype(np.float32) if fmt16 else _f(sm, (mstride, K))[:M]
+            a = np.ascontiguousarray(rows).ctypes.data
+            self._keep = rows
+        fn(h, a, wpk, b, dst, M, N, K, ldc, act)
+        if osm and ofmt:
+            full = _f(dst, ((M - 1) * ldc + N,))
+            out = np.stack([full[m * ldc:m * ldc + N] for m in range(M)])
+            self._sm_write(osm, out, ofmt)
+
+    def mnc_fc_f16_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
+        self._fc_ex(self.mnc_fc_f16, True, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt)
+
+    def mnc_fc_bf16x3_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
+        self._fc_ex(self.mnc_fc_bf16x3, False, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt)
+
     def mnc_fc_f16_pre(self, h, sm, mstride, wpk, b, dst, M, N, K, ldc, act):
         a = np.ascontiguousarray(_h16(sm, (mstride, K))[:M].astype(np.float32))
         self.mnc_fc_f16(h, a.ctypes.data, wpk, b, dst, M, N, K, ldc, act)

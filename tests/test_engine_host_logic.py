@@ -52,10 +52,15 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     else:
         # reduced-precision InnerProducts: the per-RoI producers write the rows in the GEMM's own stage-major 2-byte form and the
         # six big InnerProducts on per-RoI features (fc6_maskest, fc6, fc6_mask of both stages) take them without converting
-        pre = "mnc_fc_f16_pre" if math == "f16" else "mnc_fc_bf16x3_pre"
+        ex = "mnc_fc_f16_ex" if math == "f16" else "mnc_fc_bf16x3_ex"
         # (twice when fewer proposals survive than were speculated and the heads are re-run on the exact count)
         runs = calls.get("mnc_roi_warp_sm", 0) // 2
-        assert runs in (1, 2) and calls.get(pre) == 6 * runs and "mnc_roi_warp" not in calls
+        # every reduced-precision InnerProduct goes through the general entry point: 6 per stage here (fc6_maskest, mask_pred, fc6,
+        # fc7, fc6_mask, fc7_mask -- _X3_MIN_FLOPS = 0 makes mask_pred one of them, and with K = 32 it takes the split-bf16 kernel
+        # in the f16 mode too; the merged sibling heads stay fp32); none converts its input rows itself
+        n_ex = calls.get("mnc_fc_f16_ex", 0) + calls.get("mnc_fc_bf16x3_ex", 0)
+        assert runs in (1, 2) and n_ex == 12 * runs and calls.get(ex, 0) >= 10 * runs and "mnc_roi_warp" not in calls
+        assert "mnc_fc_f16" not in calls and "mnc_fc_bf16x3" not in calls
         # the box-feature Pooling and MaskPooling + Pooling of a stage read the same tensor: one pass, both second outputs
         assert calls.get("mnc_box_mask_pool") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
     if math == "f16":

@@ -629,6 +629,20 @@ def test_fc_on_prepacked_activations(dev, fmt, M, N, K):
     dev.call("mnc_fc_%s_pre" % name, d_sm, M, d_w, d_b, d_y1, M, N, K, N, 1)
     y0 = dev.get(d_y0, (M, N))
     assert not np.isnan(y0).any() and np.array_equal(y0, dev.get(d_y1, (M, N)))
+    # the general entry point: either input form, and the result rows a second time in the NEXT InnerProduct's form (written by
+    # the K-split reduction, or converted from the stored rows when there is a single split) == mnc_fc_pack_act of the output
+    if N % 64 == 0:
+        for ofmt in (1, 2):
+            oeb = 2 if ofmt == 1 else 4
+            d_y4, d_osm = dev.empty((M * N,), fill=np.nan), dev.empty((M * N * oeb,), dtype=np.uint8, fill=0xCD)
+            dev.call("mnc_fc_%s_ex" % name, None, d_sm, M, d_w, d_b, d_y4, M, N, K, N, 1, d_osm, ofmt)
+            assert np.array_equal(y0, dev.get(d_y4, (M, N)))
+            d_ref = dev.empty((M * N * oeb,), dtype=np.uint8, fill=0)
+            dev.call("mnc_fc_pack_act", d_y4, d_ref, M, N, 1 if ofmt == 1 else 0)
+            assert np.array_equal(dev.get(d_osm, (M * N * oeb,), dtype=np.uint8), dev.get(d_ref, (M * N * oeb,), dtype=np.uint8)), ofmt
+        d_y5 = dev.empty((M * N,), fill=np.nan)
+        dev.call("mnc_fc_%s_ex" % name, d_a, None, 0, d_w, d_b, d_y5, M, N, K, N, 1, None, 0)
+        assert np.array_equal(y0, dev.get(d_y5, (M, N)))
     if M >= 300:        # the first 2/3 of the rows of the same tensor (m_stride = M > rows multiplied)
         Mh = M * 2 // 3
         d_y2, d_y3 = dev.empty((Mh * N,), fill=np.nan), dev.empty((Mh * N,), fill=np.nan)
