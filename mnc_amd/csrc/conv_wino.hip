@@ -365,8 +365,35 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
   for (int u = 0; u < kHPer; ++u) G.h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int u = 0; u < kWPer; ++u) G.w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ABL & 1: buffer loads.  One descriptor per operand (wave-uniform kernel arguments), the block's offset in the scalar
+  // soffset, the lane's part in a 32-bit voffset: no 64-bit address arithmetic, and a halo element outside the image carries an
+  // out-of-range voffset, which the hardware answers with zeros -- no keep masks (3 registers, 12 v_and per block).
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)min((long)Cin * H * W * 4, 0x7FFFFFFFL), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpk), 0, (int)min((long)(Cin >> 3) * ncot * kWPanel * 4, 0x7FFFFFFFL), 0x00020000);
+  int hb_off[kHPer];                                              // byte voffsets of the halo pieces (out of range: 0x7FFFFFF0)
+#pragma unroll
+  for (int u = 0; u < kHPer; ++u) hb_off[u] = h_keep[u] ? h_src[u] * 4 : 0x7FFFFFF0;
+  const int wb_off = tid * 16, wb_last = min(tid, kWVec - 1 - (kWPer - 1) * NT) * 16;
   auto load_chunk = [&](int c) {
     c = chunk0 + min(c, nchunks - 1);
+    if (ABL & 1) {
+      const int hs = __builtin_amdgcn_readfirstlane(c * (int)(plane * 4));
+      const int ws = __builtin_amdgcn_readfirstlane((c * ncot + cot) * (kWPanel * 4));
+#pragma unroll
+      for (int u = 0; u < kHPer; ++u) {
+        const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hb_off[u], hs, 0);
+        G.h[u] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+      }
+      if (!DMA) {
+#pragma unroll
+        for (int u = 0; u < kWPer; ++u) {
+          const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, u == kWPer - 1 ? wb_last : wb_off, ws + u * NT * 16, 0);
+          G.w[u] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+        }
+      }
+      return;
+    }
     const float* src = in + (long)c * plane;
 #pragma unroll
     for (int u = 0; u < kHPer; ++u) G.h[u] = *reinterpret_cast<const float4*>(src + h_src[u]);
@@ -383,9 +410,8 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
     float* dstw = s_w + buf * kWPanel;
 #pragma unroll
     for (int i = 0; i < (kWPanel / 256 + 2 * RG - 1) / (2 * RG); ++i) {
-      const int piece = wave + i * 2 * RG;
-      if (piece < kWPanel / 256)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
+      const int piece = min(wave + i * 2 * RG, kWPanel / 256 - 1);   // branch-free: the waves without a last piece repeat piece 16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(dstw + piece * 256), 16, 0, 0);
     }
   };
@@ -394,6 +420,10 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
 #pragma unroll
     for (int u = 0; u < kHPer; ++u) {
       float4 v = G.h[u];
+      if (ABL & 1) {
+        *reinterpret_cast<float4*>(hdst + h_off[u]) = v;
+        continue;
+      }
       v.x = __uint_as_float(__float_as_uint(v.x) & h_keep[u]);
       v.y = __uint_as_float(__float_as_uint(v.y) & h_keep[u]);
       v.z = __uint_as_float(__float_as_uint(v.z) & h_keep[u]);
@@ -402,6 +432,13 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
     }
     if (!DMA) {
       float4* wdst = reinterpret_cast<float4*>(s_w + buf * kWPanel);
+      if (ABL & 1) {
+        char* wb = reinterpret_cast<char*>(wdst);
+#pragma unroll
+        for (int u = 0; u < kWPer; ++u)
+          *reinterpret_cast<float4*>(wb + (u == kWPer - 1 ? wb_last : wb_off) + u * NT * 16) = G.w[u];
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < kWPer; ++u) wdst[w_idx[u]] = G.w[u];
     }
@@ -473,6 +510,198 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
     }
   };
 
+  // ---- ABL & 1: the same block as ONE basic block with its LDS reads up front.  multiply() above branches on hf inside the
+  // column loop: four basic blocks, each opening with three ds_reads and a full LDS round trip before its eight additions, and
+  // the MFMAs wait behind all four.  Here the wave's three halo rows are named by ROLE instead of by position --
+  //   hf = 0: (A, B, C) = (d0, d1, d2): t0 = A - C = d0 - d2, t1 = C + B = d1 + d2
+  //   hf = 1: (A, B, C) = (d2, d3, d1): t0 = A - C = d2 - d1, t1 = C - B = d1 - d3
+  // -- i.e. t0 = A - C and t1 = fma(sgn, B, C) with a scalar sgn = +-1 (one rounding, the same value as the add / subtract) and
+  // per-wave scalar row offsets: no branch.  All 12 halo reads and the first pair of weight fragments are issued right behind
+  // the barrier, before anything else of the block.
+  const int rowA = hf ? 2 : 0, rowB = hf ? 3 : 1, rowC = hf ? 1 : 2;
+  const float sgn = hf ? -1.f : 1.f;
+  const int d_row0 = ((4 * rg + 2 * ty) * kWHaloCols + 2 * tx) * kWPixPitch + kk * 4;
+  const int offA = d_row0 + rowA * kWHaloCols * kWPixPitch, offB = d_row0 + rowB * kWHaloCols * kWPixPitch,
+            offC = d_row0 + rowC * kWHaloCols * kWPixPitch;
+  // (ext_vector_type operands: hipcc lowers their arithmetic to v_pk_add_f32 / v_pk_fma_f32 on the register pairs the LDS reads
+  // delivered -- 32 VALU instructions per block; on float4 structs its SLP pass pairs elements of different reads and pays
+  // for every packed operation with register moves)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 sgn4 = {sgn, sgn, sgn, sgn};
+  f32x4 fA[4], fB[4], fC[4], fu0, fu1;
+  auto read_block = [&](int buf) {
+    const float* sh = s_halo + buf * kHaloFloats;
+    const float* sw = s_w + buf * kWPanel + u_base;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      fA[c] = *reinterpret_cast<const f32x4*>(sh + offA + c * kWPixPitch);
+      fC[c] = *reinterpret_cast<const f32x4*>(sh + offC + c * kWPixPitch);
+    }
+    fu0 = *reinterpret_cast<const f32x4*>(sw);
+    fu1 = *reinterpret_cast<const f32x4*>(sw + 4);
+  };
+  // One block in five pinned segments (sched_barrier between them, sched_group_barrier inside): (1) t0 = A - C and the first
+  // transform row -- all that stands between the LDS reads and the first MFMA; (2) row B is requested, MFMAs of positions 0-1
+  // with the second row's arithmetic under the later ones; (3) positions 2-3 with the LDS stores of block c + 1 (loaded an
+  // iteration ago) and then the loads of block c + 2 into the same registers; (4) positions 4-5; (5) positions 6-7.  The weight
+  // fragments of the next segment are requested at the head of each.
+  auto mfma_pair = [&](int p, const f32x4& u0, const f32x4& u1, const f32x4 (&v)[8]) {
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.x, v[p].x, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.x, v[p + 1].x, acc[p + 1], 0, 0, 0);
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.y, v[p].y, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.y, v[p + 1].y, acc[p + 1], 0, 0, 0);
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.z, v[p].z, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.z, v[p + 1].z, acc[p + 1], 0, 0, 0);
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0.w, v[p].w, acc[p], 0, 0, 0);
+    acc[p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1.w, v[p + 1].w, acc[p + 1], 0, 0, 0);
+  };
+  auto transform_row = [&](const f32x4 (&t)[4], f32x4* v) {
+    v[0] = t[0] - t[2];
+    v[1] = t[1] + t[2];
+    v[2] = t[2] - t[1];
+    v[3] = t[1] - t[3];
+  };
+  auto multiply_flat = [&](int buf, int c_next) {
+    const float* sw = s_w + buf * kWPanel + u_base;
+    f32x4 t0[4], t1[4], v[8];
+    // (1)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t0[c] = fA[c] - fC[c];
+    transform_row(t0, v);
+    __builtin_amdgcn_sched_barrier(0);
+    // (2)  (row B arrives in the registers row A has just left: with all three rows in flight at once the wave is 14 registers
+    // short of its 128 + 128)
+    {
+      const float* sh = s_halo + buf * kHaloFloats;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) fB[c] = *reinterpret_cast<const f32x4*>(sh + offB + c * kWPixPitch);
+    }
+    f32x4 n0 = *reinterpret_cast<const f32x4*>(sw + 8), n1 = *reinterpret_cast<const f32x4*>(sw + 12);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t1[c] = __builtin_elementwise_fma(sgn4, fB[c], fC[c]);
+    transform_row(t1, v + 4);
+    mfma_pair(0, fu0, fu1, v);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (3)
+    f32x4 m0 = *reinterpret_cast<const f32x4*>(sw + 16), m1 = *reinterpret_cast<const f32x4*>(sw + 20);
+    if (!(ABL & 16)) {
+      store_chunk(buf ^ 1);
+      load_chunk(c_next);
+    }
+    mfma_pair(2, n0, n1, v);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (4)
+    n0 = *reinterpret_cast<const f32x4*>(sw + 24);
+    n1 = *reinterpret_cast<const f32x4*>(sw + 28);
+    mfma_pair(4, m0, m1, v);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // (5)
+    mfma_pair(6, n0, n1, v);
+  };
+
+  // ---- ABL & 2 (with ABL & 1 and DMA): the loop rotated so that the barrier sits in the MIDDLE of a block's MFMAs.  Every LDS read
+  // of block c is issued before the barrier of iteration c (the fragments of positions 4-7 wait in registers), so behind it
+  // buffer c % 2 is free and block c + 1 is complete in the other: the wave requests block c + 2 (halo into registers, weight
+  // panel by LDS-DMA straight into buffer c % 2), reads block c + 1's rows A and C and builds its first transform row UNDER the
+  // MFMAs of positions 4-7.  The next iteration opens with MFMAs: nothing but the barrier itself is exposed.  The DMA that made
+  // the plain loop slower (hipcc drains it with vmcnt(0) in front of every barrier, right after it was issued) is issued right
+  // BEHIND a barrier here and has 24 MFMAs to land; the halo registers are the only staging registers left.
+  if constexpr ((ABL & 2) != 0) {
+    static_assert(DMA == 1 && (ABL & 1), "rotated Winograd loop: LDS-DMA weight panel, flat block");
+    auto read_AC = [&](int buf) {
+      const float* sh = s_halo + buf * kHaloFloats;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        fA[c] = *reinterpret_cast<const f32x4*>(sh + offA + c * kWPixPitch);
+        fC[c] = *reinterpret_cast<const f32x4*>(sh + offC + c * kWPixPitch);
+      }
+      fu0 = *reinterpret_cast<const f32x4*>(s_w + buf * kWPanel + u_base);
+      fu1 = *reinterpret_cast<const f32x4*>(s_w + buf * kWPanel + u_base + 4);
+    };
+    f32x4 v[8], t0[4], t1[4];
+    load_chunk(0);
+    dma_panel(0, 0);
+    store_chunk(0);
+    load_chunk(1);
+    dma_panel(1, 1);
+    __syncthreads();
+    read_AC(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t0[c] = fA[c] - fC[c];
+    transform_row(t0, v);
+    for (int c = 0; c < nchunks; ++c) {
+      const int buf = c & 1;
+      const float* sh = s_halo + buf * kHaloFloats;
+      const float* sw = s_w + buf * kWPanel + u_base;
+      __builtin_amdgcn_sched_barrier(0);
+      // positions 0-1; row B in, second transform row under the MFMAs
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fB[q] = *reinterpret_cast<const f32x4*>(sh + offB + q * kWPixPitch);
+      f32x4 n0 = *reinterpret_cast<const f32x4*>(sw + 8), n1 = *reinterpret_cast<const f32x4*>(sw + 12);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t1[q] = __builtin_elementwise_fma(sgn4, fB[q], fC[q]);
+      transform_row(t1, v + 4);
+      mfma_pair(0, fu0, fu1, v);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // positions 2-3; the last fragments of block c in, block c + 1's halo out
+      f32x4 m0 = *reinterpret_cast<const f32x4*>(sw + 16), m1 = *reinterpret_cast<const f32x4*>(sw + 20);
+      f32x4 q0 = *reinterpret_cast<const f32x4*>(sw + 24), q1 = *reinterpret_cast<const f32x4*>(sw + 28);
+      store_chunk(buf ^ 1);
+      mfma_pair(2, n0, n1, v);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // positions 4-5; block c + 2 requested, block c + 1's rows A, C in, its first transform row under the MFMAs
+      load_chunk(c + 2);
+      dma_panel(c + 2, buf);
+      read_AC(buf ^ 1);
+      mfma_pair(4, m0, m1, v);
+      __builtin_amdgcn_sched_group_barrier(0x020, kHPer + (kWPanel / 256 + 2 * RG - 1) / (2 * RG), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // positions 6-7
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t0[q] = fA[q] - fC[q];
+      mfma_pair(6, q0, q1, v);
+      __builtin_amdgcn_sched_barrier(0);
+      transform_row(t0, v);                 // (v[0..3] were last read by the MFMAs of positions 2-3)
+    }
+    __syncthreads();
+  } else {
   load_chunk(0);
   if (DMA) dma_panel(0, 0);
   store_chunk(0);
@@ -480,6 +709,12 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
   for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     if (!(ABL & 32)) __syncthreads();      // with a DMA in flight hipcc puts s_waitcnt vmcnt(0) in front: block c's panel has landed
+    if (ABL & 1) {
+      read_block(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply_flat(buf, c + 2);
+      continue;
+    }
     if (!(ABL & 16)) {
       if (DMA) dma_panel(c + 1, buf ^ 1);  // s_w[buf^1] is free: everybody is past the barrier, i.e. done with block c-1
       store_chunk(buf ^ 1);
@@ -489,6 +724,7 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
     multiply(buf);
   }
   __syncthreads();                                               // every wave is done with the staging buffers
+  }
 
   // ---- epilogue.  acc[p][e], p = 4*r + c with r the wave's local row (global row 2*hf + r), e -> channel (e&3) + 8*(e>>2) + 4*kk.
   // Partial output transform of this wave's rows:  hf = 0: s0 = M0 + M1, s1 = M1;   hf = 1: s0 = M2, s1 = -(M2 + M3).
@@ -697,10 +933,14 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
-  int var = 0, ver = 2;
+  // MNC_WINO_VAR: 3 (default) rotated loop + LDS-DMA weight panel, 1 flat block schedule with register staging, 0 the round-2
+  // v2 loop (13-layer trunk, kernel_bench convwino: 2.23 / 2.28 / 2.54 ms); 16 / 48 / 112 ablations
+  int var = 3, ver = 2;
   if (const char* e = getenv("MNC_WINO_VAR")) var = atoi(e);
   if (const char* e = getenv("MNC_WINO_V")) ver = atoi(e);
-  MNC_REQUIRE(!pool || (ver == 2 && var == 0), "mnc_conv3x3_wino_pool: only the default kernel build fuses the pooling");
+  // var 1 (flat block schedule, buffer loads): two-row-group workgroups only, 32-bit byte offsets into the input
+  if ((var == 1 || var == 3) && (rows < 2 || ver != 2 || (double)Cin * H * W * 4.0 >= 2147483648.0 || getenv("MNC_WINO_DMA"))) var = 0;
+  MNC_REQUIRE(!pool || (ver == 2 && (var == 0 || var == 1 || var == 3)), "mnc_conv3x3_wino_pool: only the default kernel build fuses the pooling");
   int rc = MNC_ERR_INVALID;
   if (ver == 2) {                   // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
     // measured (kernel_bench convwino, 13-layer trunk): register staging 2.526 ms, LDS-DMA weight panel 2.564 ms -- the DMA saves
@@ -714,10 +954,16 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     if (const char* e = getenv("MNC_WINO_XCD")) plain_order = atoi(e) == 0;
     if (plain_order && rows >= 2 && var == 0 && dma == 0)
       rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+    if (plain_order && rows >= 2 && var == 1 && dma == 0)
+      rc = launch_wino2<2, 1, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+    if (var == 3) dma = 1;
+    if (plain_order && rows >= 2 && var == 3)
+      rc = launch_wino2<2, 3, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
 #define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
     if (rc == MNC_ERR_INVALID && rows == 4 && getenv("MNC_WINO_ROWS") && var == 0 && dma == 0)          // 8-wave workgroups (tuning)
       rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
     MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
+    MNC_WINO2_CASE(2, 1, 0) MNC_WINO2_CASE(2, 3, 1)
     MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
 #undef MNC_WINO2_CASE
   } else {

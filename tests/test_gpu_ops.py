@@ -775,10 +775,12 @@ def test_fc_bf16x3(dev, M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(300, 4096, 4096, 1), (45, 150, 64, 0), (300, 256, 14 * 14 * 512, 1), (7, 4096, 25088, 1),
-                                       (300, 126, 8192, 0), (1000, 512, 2048, 1), (300, 441, 256, 2)])
+                                       (300, 126, 8192, 0), (1000, 512, 2048, 1), (300, 441, 256, 2),
+                                       (1000, 4096, 12544, 1), (700, 300, 6272, 0), (513, 320, 4096, 1), (2000, 256, 8192, 1)])
 def test_fc_f16(dev, M, N, K, act):
     """mnc_fc_f16: exact against torch on operands rounded to fp16 (products of halves are exact in the fp32 accumulator; only
-    the summation order differs), and within fp16's 11 bits of the fp32 product."""
+    the summation order differs), and within fp16's 11 bits of the fp32 product.  M >= 512 runs on the 256 x 256 tiles of
+    gemm_big.hip (ragged last row block, N that does not fill a column tile, several K splits and a single one)."""
     rng = np.random.default_rng(M + N + K)
     a = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
@@ -798,6 +800,12 @@ def test_fc_f16(dev, M, N, K, act):
     d32, rel32 = err(got, ref(a, w))
     print("f16 M=%d N=%d K=%d: vs fp16-rounded operands rel=%.3e, vs fp32 rel=%.3e" % (M, N, K, rel, rel32))
     assert rel < 1e-5 and rel32 < 2e-3
+    if M >= 512:        # a column slice of a wider matrix (ldc > N), as the Concat-in-place plan writes fc7 / fc7_mask
+        ld = N + 64
+        d_wide = dev.empty((M * ld,), fill=np.nan)
+        dev.call("mnc_fc_f16", dev.put(a), d_wp, dev.put(b), d_wide, M, N, K, ld, act)
+        wide = dev.get(d_wide, (M, ld))
+        assert np.array_equal(wide[:, :N], got) and np.isnan(wide[:, N:]).all()
 
 
 def test_fc_column_slice_and_pack(dev):
