@@ -298,8 +298,9 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_wino_kernel(const float* __
 template <int RG, int ABL = 0, int DMA = 0, int XCD = 1>
 __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                                     int H, int W, int Cin, int Cout, int relu, int ksplit,
-                                                                     float* __restrict__ part, int tiles_x, int pool) {
+                                                                     int H, int W, int Cin, int Cout, int relu, int ksplit_a,
+                                                                     float* __restrict__ part, int tiles_x, int pool_a,
+                                                                     int pix_a, int ksplit_b) {
   constexpr int NT = 128 * RG;
   constexpr int kHaloRows = 4 * RG + 2;
   constexpr int kHaloFloats = kHaloRows * kWHaloCols * kWPixPitch;
@@ -321,22 +322,31 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
   // so that every XCD gets a CONTIGUOUS range of the logical order (output-channel tile fastest, then K split, then pixel tile):
   // the Cout/32 workgroups that read the same input halo then run on ONE XCD at about the same time and the halo is fetched
   // into that XCD's L2 once instead of once per channel tile from Infinity Cache / HBM.  Bijective for any block count.
-  int bz, bx, by;
+  // Two SECTIONS of the grid (the launcher's tail plan, wino_impl): blocks [0, pix_a * ncot * ksplit_a) are the pixel tiles
+  // [0, pix_a) with ksplit_a K ranges each, the blocks behind them the remaining pixel tiles with ksplit_b ranges each -- the tiles
+  // of a last, partly filled round of workgroups are cut into shorter pieces.  A tile with one range writes the finished output
+  // (bias, ReLU, pooling); with several, each range writes raw partial sums to its plane of `part` (wino_section_reduce_kernel
+  // finishes them).  K ranges may be uneven: range k of s covers blocks [k * nb / s, (k + 1) * nb / s).
+  int bz, bx, by, ksplit;
   {
-    const int total = gridDim.x, b = blockIdx.x;
+    const int n_a = pix_a * ncot * ksplit_a;
+    int b = blockIdx.x, total = n_a, pix0 = 0;
+    ksplit = ksplit_a;
+    if (b >= n_a) { b -= n_a; total = gridDim.x - n_a; pix0 = pix_a; ksplit = ksplit_b; }
     const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
     const int logical = XCD ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
     const int nz = ncot * ksplit;
     bz = logical % nz;
-    const int rest = logical / nz;
+    const int rest = pix0 + logical / nz;
     bx = rest % tiles_x;
     by = rest / tiles_x;
   }
+  const int pool = ksplit == 1 ? pool_a : 0;
   const int split = bz / ncot;
   const int cot = bz - split * ncot;
   const int w0 = bx * kWCols, h0 = by * (4 * RG), co0 = cot * 32;
-  const int nchunks = (Cin >> 3) / ksplit;
-  const int chunk0 = split * nchunks;
+  const int chunk0 = split * (Cin >> 3) / ksplit;
+  const int nchunks = (split + 1) * (Cin >> 3) / ksplit - chunk0;
 
   int h_off[kHPer];
   int h_src[kHPer];
@@ -639,11 +649,17 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
       fu1 = *reinterpret_cast<const f32x4*>(s_w + buf * kWPanel + u_base + 4);
     };
     f32x4 v[8], t0[4], t1[4];
+    // prologue: blocks 0 and 1 requested together -- ONE global round trip in front of the first MFMA, not two (the halo of
+    // block 1 waits in a second register set that only lives here)
     load_chunk(0);
     dma_panel(0, 0);
-    store_chunk(0);
+    const Regs G0 = G;
     load_chunk(1);
     dma_panel(1, 1);
+    const Regs G1 = G;
+    G = G0;
+    store_chunk(0);
+    G = G1;
     __syncthreads();
     read_AC(0);
 #pragma unroll
@@ -834,6 +850,54 @@ __global__ void pack_conv3x3_wino_kernel(const float* __restrict__ w, float* __r
   }
 }
 
+// Finishes the pixel tiles [pix0, pix0 + npix) of a section whose tiles were cut into `s` K ranges: out = act(sum_k part[k] + bias)
+// over the tile's 4*RG x 32 pixels (clipped to the image), all channels; POOL: followed by the Pooling MAX 2x2/2 that the
+// unsplit tiles apply in their epilogue (same order: ReLU, then the maximum over the window's in-image pixels), written to
+// the pooled tensor.  One thread per 4 channels of a pixel (of a pooling window).
+template <int POOL>
+__global__ __launch_bounds__(256) void wino_section_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                  float* __restrict__ out, int H, int W, int Cout, int s, int relu,
+                                                                  int pix0, int npix, int tiles_x, int tile_rows) {
+  const int rows = POOL ? tile_rows >> 1 : tile_rows, cols = POOL ? kWCols >> 1 : kWCols;
+  const int per_tile = (Cout >> 3) * rows * cols * 2;
+  const long plane = (long)Cout * H * W;
+  const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)npix * per_tile; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / per_tile);
+    int r = (int)(i - (long)t * per_tile);
+    const int half = r & 1; r >>= 1;
+    const int col = r % cols; r /= cols;
+    const int row = r % rows;
+    const int cb = r / rows;
+    const int pix = pix0 + t, bx = pix % tiles_x, by = pix / tiles_x;
+    const float4 b = *reinterpret_cast<const float4*>(bias + cb * 8 + half * 4);
+    const int y0 = by * tile_rows + (POOL ? 2 * row : row), x0 = bx * kWCols + (POOL ? 2 * col : col);
+    if (y0 >= H || x0 >= W) continue;
+    float4 best = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+#pragma unroll
+    for (int dy = 0; dy < (POOL ? 2 : 1); ++dy)
+#pragma unroll
+      for (int dx = 0; dx < (POOL ? 2 : 1); ++dx) {
+        const int y = y0 + dy, x = x0 + dx;
+        if (y >= H || x >= W) continue;
+        const long e = (((long)cb * H + y) * W + x) * 8 + half * 4;
+        float4 v = *reinterpret_cast<const float4*>(part + e);
+        for (int k = 1; k < s; ++k) {
+          const float4 q = *reinterpret_cast<const float4*>(part + k * plane + e);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (POOL) {
+          best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+        } else {
+          *reinterpret_cast<float4*>(out + e) = v;
+        }
+      }
+    if (POOL) *reinterpret_cast<float4*>(out + (((long)cb * OH + (y0 >> 1)) * OW + (x0 >> 1)) * 8 + half * 4) = best;
+  }
+}
+
 template <int ROWS, int VAR>
 static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
                        int Cin, int Cout, int relu, int ksplit, float* part) {
@@ -854,7 +918,7 @@ static int launch_wino(mnc_ctx* ctx, const float* d_in, const float* d_wpk, cons
 
 template <int RG, int ABL, int DMA, int XCD = 1>
 static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
-                        int Cin, int Cout, int relu, int ksplit, float* part, int pool = 0) {
+                        int Cin, int Cout, int relu, int ksplit, float* part, int pool, int pix_a, int ksplit_b) {
   constexpr size_t lds_stage = 2 * 4 * ((size_t)(4 * RG + 2) * kWHaloCols * kWPixPitch + (size_t)kWPanel);
   constexpr size_t lds_xch = (size_t)RG * 64 * 64 * 4;
   constexpr size_t lds = lds_stage > lds_xch ? lds_stage : lds_xch;
@@ -867,9 +931,11 @@ static int launch_wino2(mnc_ctx* ctx, const float* d_in, const float* d_wpk, con
     attr_set.fetch_or(bit, std::memory_order_relaxed);
   }
   const int tiles_x = cdiv(W, kWCols);
-  dim3 grid(tiles_x * cdiv(H, 4 * RG) * (Cout >> 5) * ksplit);
+  const int pix = tiles_x * cdiv(H, 4 * RG);
+  if (pix_a < 0 || pix_a > pix) pix_a = pix;                     // no second section
+  dim3 grid((pix_a * ksplit + (pix - pix_a) * ksplit_b) * (Cout >> 5));
   hipLaunchKernelGGL(kern, grid, dim3(128 * RG), lds, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit,
-                     part, tiles_x, pool);
+                     part, tiles_x, pool, pix_a, ksplit_b);
   return MNC_OK;
 }
 
@@ -921,13 +987,38 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
       if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
     }
   }
+  // Tail plan (two-row-group kernel, no MNC_CONV_KSPLIT override; MNC_WINO_TAIL=0 keeps the uniform rule above).  The chip holds
+  // `slots` workgroups (two per CU).  The pixel tiles of the full rounds run unsplit; the tiles of the last, partly filled
+  // round are cut into sB >= 3 K ranges -- as many as fill that round once, with at least 8 blocks each -- and finished by
+  // wino_section_reduce_kernel.  600x1000: conv4_x 512 + 128 x 4 workgroups instead of 640 x 2 (2.5 rounds): 256 -> 240 us;
+  // conv5_x / rpn_conv 160 x 3 instead of 160 x 4 (1.25 rounds): 84.5 -> 73.4 us.  A tail workgroup that has its CU to itself
+  // runs faster than one of a pair, so a lightly filled last round costs less than its length suggests: cutting conv3_x's 192
+  // tail tiles in two (the reduce pass included) LOST 11 us, and those layers stay whole.
+  int pix_a = -1, ksplit_b = 1;
+  {
+    const bool tail_on = !(getenv("MNC_WINO_TAIL") && atoi(getenv("MNC_WINO_TAIL")) == 0);
+    int ver_env = 2;
+    if (const char* e = getenv("MNC_WINO_V")) ver_env = atoi(e);
+    if (tail_on && rows >= 2 && ver_env == 2 && !getenv("MNC_CONV_KSPLIT")) {
+      const int pix = cdiv(W, kWCols) * cdiv(H, 8), blocks = Cin / 8, slots = 512;      // MI355X: 256 CUs x two workgroups
+      const int full_pix = (int)((long)pix * ncot / slots) * slots / ncot;      // pixel tiles of the full rounds
+      const int rest = (pix - full_pix) * ncot;
+      ksplit = 1;
+      if (rest > 0) {
+        int sb = slots / rest;
+        if (sb > blocks / 8) sb = blocks / 8;
+        if (sb > 8) sb = 8;
+        if (sb >= 3) { pix_a = full_pix; ksplit_b = sb; }       // two ranges do not pay (conv3_x, 192 tail tiles: 237 -> 248 us)
+      }
+    }
+  }
   float* part = nullptr;
   float* full = nullptr;            // pooled output of a K-split layer: the reduction writes full resolution here first
-  if (ksplit > 1) {
-    int rc = ensure_scratch(ctx, (size_t)(ksplit + (pool ? 1 : 0)) * Cout * H * W * 4);
+  if (ksplit > 1 || ksplit_b > 1) {
+    int rc = ensure_scratch(ctx, (size_t)((ksplit > ksplit_b ? ksplit : ksplit_b) + (pool && ksplit > 1 ? 1 : 0)) * Cout * H * W * 4);
     if (rc) return rc;
     part = (float*)ctx->scratch;
-    if (pool) full = part + (size_t)ksplit * Cout * H * W;
+    if (pool && ksplit > 1) full = part + (size_t)ksplit * Cout * H * W;
   }
   const int kpool = (pool && ksplit == 1) ? 1 : 0;               // pooling inside the kernel's epilogue
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
@@ -953,15 +1044,15 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     bool plain_order = Cout > 256;
     if (const char* e = getenv("MNC_WINO_XCD")) plain_order = atoi(e) == 0;
     if (plain_order && rows >= 2 && var == 0 && dma == 0)
-      rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+      rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     if (plain_order && rows >= 2 && var == 1 && dma == 0)
-      rc = launch_wino2<2, 1, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+      rc = launch_wino2<2, 1, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     if (var == 3) dma = 1;
     if (plain_order && rows >= 2 && var == 3)
-      rc = launch_wino2<2, 3, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
-#define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+      rc = launch_wino2<2, 3, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
+#define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     if (rc == MNC_ERR_INVALID && rows == 4 && getenv("MNC_WINO_ROWS") && var == 0 && dma == 0)          // 8-wave workgroups (tuning)
-      rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool);
+      rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
     MNC_WINO2_CASE(2, 1, 0) MNC_WINO2_CASE(2, 3, 1)
     MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
@@ -975,6 +1066,17 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d MNC_WINO_VAR=%d MNC_WINO_V=%d", rows, var, ver);
   if (rc) return rc;
   if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, pool ? full : d_out, H, W, Cout, ksplit, relu);
+  if (ksplit_b > 1) {
+    const int tiles_x = cdiv(W, kWCols), npix = tiles_x * cdiv(H, 8) - pix_a;
+    const long items = (long)npix * (Cout >> 3) * 8 * kWCols * 2 / (pool ? 4 : 1);
+    auto grid_for = [](long n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); };
+    if (pool)
+      hipLaunchKernelGGL(wino_section_reduce_kernel<1>, dim3(grid_for(items)), dim3(256), 0, ctx->stream, part, d_bias, d_out, H, W,
+                         Cout, ksplit_b, relu, pix_a, npix, tiles_x, 8);
+    else
+      hipLaunchKernelGGL(wino_section_reduce_kernel<0>, dim3(grid_for(items)), dim3(256), 0, ctx->stream, part, d_bias, d_out, H, W,
+                         Cout, ksplit_b, relu, pix_a, npix, tiles_x, 8);
+  }
   rc = ls.finish("conv3x3_wino_kernel");
   if (rc) return rc;
   if (pool && ksplit > 1) return mnc_maxpool2_c8(ctx, full, d_out, Cout, H, W);     // K-split layer: pooled after the reduction

@@ -58,12 +58,15 @@ def test_conv3x3_mfma(dev, H, W, Cin, Cout, relu):
     assert rel < 1e-4, (d, rel)
 
 
-@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (75, 125, 64, 64), (5, 3, 8, 32), (38, 63, 128, 64)])
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (75, 125, 64, 64), (5, 3, 8, 32), (38, 63, 128, 64),
+                                                        (75, 125, 256, 512), (37, 63, 256, 512)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
     """mnc_conv3x3_wino (Winograd F(2x2,3x3) on the fp32 matrix pipe) against torch fp32 and against the direct kernel: odd
     heights / widths (partial 2x2 tiles at the border), every workgroup height, K splits.  The transforms are exact in fp32
-    except for the summation order, so the bar is the direct kernel's own (1e-4 of the output range; measured ~1e-6)."""
+    except for the summation order, so the bar is the direct kernel's own (1e-4 of the output range; measured ~1e-6).
+    The default run of the last two shapes takes the launcher's tail plan: (75,125,256,512) 512 unsplit workgroups + 128 tiles
+    in 4 K ranges, (37,63,256,512) every tile in 3 uneven ranges (32 blocks) with odd H and W under the pooling reduce."""
     rng = np.random.default_rng(H * 1000 + W + Cin + Cout)
     x = rng.normal(0, 1, (Cin, H, W)).astype(np.float32)
     w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
@@ -78,29 +81,35 @@ def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
     d_y = dev.empty((Cout, H, W), fill=-7.0)
     dev.call("mnc_conv3x3", d_x, d_wd, d_b, d_y, H, W, Cin, Cout, relu)
     direct = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
-    for rows, ks in ((None, None), ("1", "1"), ("2", "2"), ("4", "1"), ("1", "4")):
+    # (rows, K splits, kernel build): the default plan; forced workgroup heights / uniform K splits; the two older loop builds
+    # (MNC_WINO_VAR 1: flat block, register staging; 0: round-2 v2 loop) and the default build without the tail plan
+    for rows, ks, var in ((None, None, None), ("1", "1", None), ("2", "2", None), ("4", "1", None), ("1", "4", None),
+                          (None, None, "1"), (None, None, "0"), ("2", "2", "1"), (None, None, "notail")):
         if ks is not None and (Cin // 8) % int(ks):
             continue
-        if rows is None:
-            monkeypatch.delenv("MNC_WINO_ROWS", raising=False)
-            monkeypatch.delenv("MNC_CONV_KSPLIT", raising=False)
-        else:
+        for k in ("MNC_WINO_ROWS", "MNC_CONV_KSPLIT", "MNC_WINO_VAR", "MNC_WINO_TAIL"):
+            monkeypatch.delenv(k, raising=False)
+        if rows is not None:
             monkeypatch.setenv("MNC_WINO_ROWS", rows)
             monkeypatch.setenv("MNC_CONV_KSPLIT", ks)
+        if var == "notail":
+            monkeypatch.setenv("MNC_WINO_TAIL", "0")
+        elif var is not None:
+            monkeypatch.setenv("MNC_WINO_VAR", var)
         dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
         dev.call("mnc_conv3x3_wino", d_x, d_w, d_b, d_y, H, W, Cin, Cout, relu)
         got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
-        assert err(got, want)[1] < 1e-4, (rows, ks, err(got, want))
-        assert err(got, direct)[1] < 1e-5, (rows, ks, err(got, direct))
+        assert err(got, want)[1] < 1e-4, (rows, ks, var, err(got, want))
+        assert err(got, direct)[1] < 1e-5, (rows, ks, var, err(got, direct))
         # + the following Pooling MAX 2x2/2 in the epilogue (Caffe's ceil output size: odd H / W clip the last window), with and
         # without K splits: exactly the maximum over the un-fused kernel's own outputs
-        if rows in (None, "2") and H >= 2 and W >= 2:
+        if rows in (None, "2") and H >= 2 and W >= 2:     # (every build above fuses the pooling)
             OH, OW = (H + 1) // 2, (W + 1) // 2
             d_p = dev.empty((Cout, OH, OW), fill=-7.0)
             dev.call("mnc_conv3x3_wino_pool", d_x, d_w, d_b, d_p, H, W, Cin, Cout, relu)
             pooled = from_c8(dev.get(d_p, (Cout * OH * OW,)), Cout, OH, OW)
             ref = F.max_pool2d(torch.from_numpy(got)[None], 2, 2, ceil_mode=True)[0].numpy()
-            assert np.array_equal(pooled, ref), (rows, ks)
+            assert np.array_equal(pooled, ref), (rows, ks, var)
 
 
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
