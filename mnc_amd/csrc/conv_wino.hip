@@ -357,7 +357,12 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
     const int pix = q >> 1, half = q & 1;
     const int r = pix / kWHaloCols, c = pix - r * kWHaloCols;
     const int gh = h0 - 1 + r, gw = w0 - 1 + c;
-    h_off[u] = pix * kWPixPitch + half * 4;
+    // ABL & 1: the two 16-byte halves of a pixel are swapped in halo rows 2, 3, 6, 7, ... ((row >> 1) odd).  A halo read is a
+    // ds_read_b128 whose 16-lane groups hold tile columns of BOTH tile rows of the wave (rows R and R + 2); with a pixel pitch
+    // of 12 dwords a tile column step is 24 dwords, so the bank of every lane starts on a multiple of 8 and each group's 16
+    // lanes x 4 banks fold onto 32 of the 64 banks: 2-way conflicts on every read (SQ_LDS_BANK_CONFLICT = 39 % of the LDS cycles).
+    // With the swap the lanes of row R + 2 start 4 banks off those of row R: conflict-free.
+    h_off[u] = pix * kWPixPitch + (((ABL & 1) ? half ^ ((r >> 1) & 1) : half)) * 4;
     h_src[u] = (min(max(gh, 0), H - 1) * W + min(max(gw, 0), W - 1)) * 8 + half * 4;
     h_keep[u] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? 0xFFFFFFFFu : 0u;
   }
@@ -530,9 +535,11 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
   // the barrier, before anything else of the block.
   const int rowA = hf ? 2 : 0, rowB = hf ? 3 : 1, rowC = hf ? 1 : 2;
   const float sgn = hf ? -1.f : 1.f;
-  const int d_row0 = ((4 * rg + 2 * ty) * kWHaloCols + 2 * tx) * kWPixPitch + kk * 4;
-  const int offA = d_row0 + rowA * kWHaloCols * kWPixPitch, offB = d_row0 + rowB * kWHaloCols * kWPixPitch,
-            offC = d_row0 + rowC * kWHaloCols * kWPixPitch;
+  const int d_row0 = ((4 * rg + 2 * ty) * kWHaloCols + 2 * tx) * kWPixPitch;
+  auto row_off = [&](int row) {     // halo row 4 rg + 2 ty + row, this lane's channel half (swapped where (halo row >> 1) is odd)
+    return d_row0 + row * kWHaloCols * kWPixPitch + (kk ^ ((ty + (row >> 1)) & 1)) * 4;
+  };
+  const int offA = row_off(rowA), offB = row_off(rowB), offC = row_off(rowC);
   // (ext_vector_type operands: hipcc lowers their arithmetic to v_pk_add_f32 / v_pk_fma_f32 on the register pairs the LDS reads
   // delivered -- 32 VALU instructions per block; on float4 structs its SLP pass pairs elements of different reads and pays
   // for every packed operation with register moves)
@@ -662,6 +669,85 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
     G = G1;
     __syncthreads();
     read_AC(0);
+    if constexpr ((ABL & 4) != 0) {
+      // ABL & 4: ALL of block c + 1's halo rows are read behind the barrier (the LDS-DMA freed 20 staging registers), both
+      // rows of t = B^T d are built under the MFMAs of positions 6-7 and the two rows of the column pass under positions 6-7 and
+      // 0-1: an iteration opens with MFMAs whose operands are in registers, not with an LDS round trip for row B.
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fB[q] = *reinterpret_cast<const f32x4*>(s_halo + offB + q * kWPixPitch);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        t0[q] = fA[q] - fC[q];
+        t1[q] = __builtin_elementwise_fma(sgn4, fB[q], fC[q]);
+      }
+      transform_row(t0, v);
+      for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const float* sw = s_w + buf * kWPanel + u_base;
+        __builtin_amdgcn_sched_barrier(0);
+        // positions 0-1, the second row of the column pass under them
+        f32x4 n0 = *reinterpret_cast<const f32x4*>(sw + 8), n1 = *reinterpret_cast<const f32x4*>(sw + 12);
+        transform_row(t1, v + 4);
+        mfma_pair(0, fu0, fu1, v);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // (first the MFMA: a read in front of it would make the
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        //  loop-carried fragments wait for an LDS round trip)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // positions 2-3; the last fragments of block c in, block c + 1's halo out
+        f32x4 m0 = *reinterpret_cast<const f32x4*>(sw + 16), m1 = *reinterpret_cast<const f32x4*>(sw + 20);
+        f32x4 q0 = *reinterpret_cast<const f32x4*>(sw + 24), q1 = *reinterpret_cast<const f32x4*>(sw + 28);
+        store_chunk(buf ^ 1);
+        mfma_pair(2, n0, n1, v);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // positions 4-5: block c + 1's rows and first fragments requested behind the first MFMA, then block c + 2 from memory
+        read_AC(buf ^ 1);
+        {
+          const float* sh = s_halo + (buf ^ 1) * kHaloFloats;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fB[q] = *reinterpret_cast<const f32x4*>(sh + offB + q * kWPixPitch);
+        }
+        load_chunk(c + 2);
+        dma_panel(c + 2, buf);
+        mfma_pair(4, m0, m1, v);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // positions 6-7, block c + 1's transform rows and the first row of its column pass under them
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          t0[q] = fA[q] - fC[q];
+          t1[q] = __builtin_elementwise_fma(sgn4, fB[q], fC[q]);
+        }
+        transform_row(t0, v);               // (v[0..3] were last read by the MFMAs of positions 2-3)
+        mfma_pair(6, q0, q1, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+      }
+      __syncthreads();
+    } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) t0[c] = fA[c] - fC[c];
     transform_row(t0, v);
@@ -717,6 +803,7 @@ __global__ __launch_bounds__(128 * RG, RG <= 2 ? 2 : 1) void conv3x3_wino2_kerne
       transform_row(t0, v);                 // (v[0..3] were last read by the MFMAs of positions 2-3)
     }
     __syncthreads();
+    }
   } else {
   load_chunk(0);
   if (DMA) dma_panel(0, 0);
@@ -1024,14 +1111,15 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
-  // MNC_WINO_VAR: 3 (default) rotated loop + LDS-DMA weight panel, 1 flat block schedule with register staging, 0 the round-2
-  // v2 loop (13-layer trunk, kernel_bench convwino: 2.23 / 2.28 / 2.54 ms); 16 / 48 / 112 ablations
-  int var = 3, ver = 2;
+  // MNC_WINO_VAR: 7 (default) rotated loop, all halo rows read behind the barrier; 3 rotated loop, row B read at the head of the
+  // iteration; 1 flat block schedule with register staging; 0 the round-2 v2 loop (13-layer trunk, kernel_bench convwino:
+  // 2.19 / 2.22 / 2.28 / 2.54 ms); 16 / 48 / 112 ablations
+  int var = 7, ver = 2;
   if (const char* e = getenv("MNC_WINO_VAR")) var = atoi(e);
   if (const char* e = getenv("MNC_WINO_V")) ver = atoi(e);
   // var 1 (flat block schedule, buffer loads): two-row-group workgroups only, 32-bit byte offsets into the input
-  if ((var == 1 || var == 3) && (rows < 2 || ver != 2 || (double)Cin * H * W * 4.0 >= 2147483648.0 || getenv("MNC_WINO_DMA"))) var = 0;
-  MNC_REQUIRE(!pool || (ver == 2 && (var == 0 || var == 1 || var == 3)), "mnc_conv3x3_wino_pool: only the default kernel build fuses the pooling");
+  if ((var == 1 || var == 3 || var == 7) && (rows < 2 || ver != 2 || (double)Cin * H * W * 4.0 >= 2147483648.0 || getenv("MNC_WINO_DMA"))) var = 0;
+  MNC_REQUIRE(!pool || (ver == 2 && (var == 0 || var == 1 || var == 3 || var == 7)), "mnc_conv3x3_wino_pool: only the default kernel build fuses the pooling");
   int rc = MNC_ERR_INVALID;
   if (ver == 2) {                   // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
     // measured (kernel_bench convwino, 13-layer trunk): register staging 2.526 ms, LDS-DMA weight panel 2.564 ms -- the DMA saves
@@ -1047,14 +1135,16 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
       rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     if (plain_order && rows >= 2 && var == 1 && dma == 0)
       rc = launch_wino2<2, 1, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
-    if (var == 3) dma = 1;
+    if (var == 3 || var == 7) dma = 1;
     if (plain_order && rows >= 2 && var == 3)
       rc = launch_wino2<2, 3, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
+    if (plain_order && rows >= 2 && var == 7)
+      rc = launch_wino2<2, 7, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
 #define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     if (rc == MNC_ERR_INVALID && rows == 4 && getenv("MNC_WINO_ROWS") && var == 0 && dma == 0)          // 8-wave workgroups (tuning)
       rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
-    MNC_WINO2_CASE(2, 1, 0) MNC_WINO2_CASE(2, 3, 1)
+    MNC_WINO2_CASE(2, 1, 0) MNC_WINO2_CASE(2, 3, 1) MNC_WINO2_CASE(2, 7, 1)
     MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
 #undef MNC_WINO2_CASE
   } else {

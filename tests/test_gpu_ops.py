@@ -81,10 +81,10 @@ def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
     d_y = dev.empty((Cout, H, W), fill=-7.0)
     dev.call("mnc_conv3x3", d_x, d_wd, d_b, d_y, H, W, Cin, Cout, relu)
     direct = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
-    # (rows, K splits, kernel build): the default plan; forced workgroup heights / uniform K splits; the two older loop builds
-    # (MNC_WINO_VAR 1: flat block, register staging; 0: round-2 v2 loop) and the default build without the tail plan
+    # (rows, K splits, kernel build): the default plan; forced workgroup heights / uniform K splits; the older loop builds
+    # (MNC_WINO_VAR 3: rotated loop, 1: flat block with register staging, 0: round-2 v2 loop) and the default without the tail plan
     for rows, ks, var in ((None, None, None), ("1", "1", None), ("2", "2", None), ("4", "1", None), ("1", "4", None),
-                          (None, None, "1"), (None, None, "0"), ("2", "2", "1"), (None, None, "notail")):
+                          (None, None, "3"), (None, None, "1"), (None, None, "0"), ("2", "2", "1"), (None, None, "notail")):
         if ks is not None and (Cin // 8) % int(ks):
             continue
         for k in ("MNC_WINO_ROWS", "MNC_CONV_KSPLIT", "MNC_WINO_VAR", "MNC_WINO_TAIL"):
