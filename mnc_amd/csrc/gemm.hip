@@ -15,6 +15,7 @@
 //
 // Split-K (chosen so that tiles x splits ~ the 256 CUs) writes fp32 partials to the context scratch; a second kernel
 // sums them in fixed order (deterministic) and applies bias + activation.  With one split the epilogue is fused.
+#include <atomic>
 #include <cstdlib>
 
 #include "mnc_internal.h"
@@ -241,6 +242,182 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
   }
 }
 
+// ---- the 320-row kernel with its operand panels copied by LDS-DMA -------------------------------------------------------------
+// Ablations of fc_mfma_kernel<10, 32> on fc6 (M = 300, N = 4096, K = 25088, random operands, tools/kernel_bench.py fc with
+// MNC_FC_ABL): 621 us; 570 without the LDS stores of the staged panels; 520 without their global loads as well; 469 for the MFMAs
+// alone -- one wave per SIMD pays for the 14 ds_write_b128 + 14 global loads per thread and stage (and their 190 VGPRs)
+// although none of them is on a critical path.  Here a stage's panels ([320][32] activations + [128][32] weights = 56 KB) go
+// global -> LDS with global_load_lds_dwordx4 (1 KB per wave instruction, 14 per wave and stage): no staging registers, no
+// ds_write, no keep masks.  A DMA instruction places its 64 lanes' 16-byte pieces CONTIGUOUSLY in LDS, so rows cannot be
+// padded; instead row r (128 bytes = 8 chunks) stores its k-chunk c in chunk slot c ^ ((r >> 1) & 7) -- the lane picks the
+// global address for its slot -- and a fragment read of chunk c goes to that slot: within each 16-lane group of a
+// ds_read_b128 (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a tile) the pairs (r & 1, (r >> 1) & 7) are all
+// different, i.e. 16 distinct starts of 4 banks: conflict-free without padding.
+// Pipeline as fc_mfma_kernel's (fragments of K-group g + 1 read during the MFMAs of group g, stage barrier before the last
+// group), with the copy of stage s + 2 issued right BEHIND the barrier of stage s -- every wave is past its reads of that
+// buffer -- so it has a full stage of MFMAs to land and the vmcnt(0) hipcc puts in front of a barrier while a DMA is in flight
+// is the wait the next stage needs anyway.
+template <int kMT>
+__global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          float* __restrict__ part, int M, int N, int K, int ldc, int kper,
+                                                          int act, int fused, int tn_, int splits_, int tm_) {
+  constexpr int kBM = 32 * kMT;
+  constexpr int kRows = kBM + kBN;                   // operand rows per stage: activations, then weights
+  constexpr int kPer = kRows * 128 / 1024 / 4;       // DMA instructions per wave and stage (1 KB = 8 rows each)
+  static_assert(kRows % 32 == 0, "whole pieces per wave");
+  // Two stage buffers 64 KB apart (57 KB used each), so that every LDS offset switches buffer with one XOR.  The loop runs ONE
+  // stage per iteration with the DMA issue as its last LDS-related instruction: hipcc's wait-count pass makes every ds_read that
+  // FOLLOWS a DMA issue in straight-line code wait for vmcnt(0) ("may alias"; the reads go to the other buffer, the barrier
+  // protocol orders the real dependence), but not the reads of the next iteration -- with two stages per iteration the second
+  // stage's fragment reads each waited for the copy issued by the first.
+  extern __shared__ __attribute__((aligned(1024))) char s_fc_dma[];
+  constexpr int kBufXor = 65536;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, kk = lane >> 5;
+  int bn, split, bmz;
+  xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  const int n0 = bn * kBN, m0 = bmz * kBM;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
+  const int nstages = (kend - kbeg) / 32;
+  const int mrows = min(M - m0, kBM);
+  const int mtiles = (mrows + 31) >> 5;
+
+  // piece p = wave + 4 i covers buffer bytes [1024 p, 1024 p + 1024): lane L fills slot 64 p + L = (row r, chunk slot L & 7)
+  const float* src[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int slot = (wave + 4 * i) * 64 + lane, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    src[i] = (r < kBM ? A + (long)(m0 + min(r, mrows - 1)) * K               // rows past M re-read the last valid row; never stored
+                      : Wt + (long)min(n0 + r - kBM, N - 1) * K) + kbeg + c * 4;
+  }
+  // The copy is issued through inline assembly: hipcc's wait-count pass makes the first ds_read behind a DMA builtin wait for
+  // vmcnt(0) ("the LDS it writes may alias"), also across the loop's back edge, which would expose the whole global latency once
+  // per stage.  The reads behind an issue go to the OTHER buffer; the real dependence -- stage s + 1 complete before anybody reads
+  // it -- is the explicit s_waitcnt vmcnt(0) + barrier below.  (s_nop: one wait state between the write of M0 and its use.)
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_fc_dma;
+  auto dma_piece = [&](int i, long off, int buf_byte) {
+    const float* g = src[i] + off;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 4 * i) * 1024u);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
+  };
+  auto dma_stage = [&](int s, int buf_byte) {
+    const long off = (long)min(s, nstages - 1) * 32;             // past the end: the last stage once more, never multiplied
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) dma_piece(i, off, buf_byte);
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  f32x16 acc[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  // fragment of K-group kc (8 k values): chunk 2 kc + kk of row (tile row j) -> slot (2 kc + kk) ^ ((j >> 1) & 7); the tile
+  // offsets (32 rows = 4 KB) and the weight rows (kBM + 32 wave + j) leave (row >> 1) & 7 unchanged.  Byte offsets.
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) {
+    const int c = (2 * kc + kk) ^ ((j >> 1) & 7);
+    a_off[kc] = (j * 32 + c * 4) * 4;
+    b_off[kc] = ((kBM + wave * 32 + j) * 32 + c * 4) * 4;
+  }
+  struct Frags { float4 a[kMT]; float4 b; };
+  auto read_frags = [&](int kc, int flip, Frags& f) {
+    f.b = *reinterpret_cast<const float4*>(s_fc_dma + (b_off[kc] ^ flip));
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) f.a[t] = *reinterpret_cast<const float4*>(s_fc_dma + (a_off[kc] ^ flip) + t * 4096);
+  };
+  auto mfmas = [&](const Frags& f) {                 // k outermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].x, f.b.x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].y, f.b.y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].z, f.b.z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].w, f.b.w, acc[t], 0, 0, 0);
+  };
+  auto pin_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) asm volatile("" : "+a"(acc[t]));
+  };
+  constexpr int kNM = 4 * kMT, kNR = kMT + 1;
+
+  if (nstages > 0) {
+    Frags f0, f1;
+    dma_stage(0, 0);
+    dma_stage(1, kBufXor);
+    dma_wait();
+    __syncthreads();
+    read_frags(0, 0, f0);
+    int cur = 0;                                     // byte offset of the buffer stage s sits in (scalar)
+    for (int s = 0; s < nstages; ++s) {
+      // stage s sits in buffer `cur` (a_off / b_off point into it) with its group-0 fragments in f0; stage s + 1 is landing in
+      // (or already in) the other buffer
+      read_frags(1, 0, f1);
+      mfmas(f0);                                     // group 0
+      read_frags(2, 0, f0);
+      mfmas(f1);                                     // group 1
+      read_frags(3, 0, f1);
+      mfmas(f0);                                     // group 2
+#pragma unroll
+      for (int i = 0; i < 3 * kNM; ++i) {            // one slot per MFMA; the fragment reads spread evenly over the slots
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if ((i + 1) * 3 * kNR / (3 * kNM) > i * 3 * kNR / (3 * kNM)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      pin_acc();
+      dma_wait();                                    // stage s + 1 has landed ...
+      __syncthreads();                               // ... for every wave, and nobody reads buffer `cur` any more
+      read_frags(0, kBufXor, f0);                    // group 0 of stage s + 1
+      {                                              // group 3: the 11 reads under the first MFMAs, then one copy per MFMA
+        const long off = (long)min(s + 2, nstages - 1) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < kMT; ++t) {
+            const int i = q * kMT + t;
+            const float av = q == 0 ? f1.a[t].x : q == 1 ? f1.a[t].y : q == 2 ? f1.a[t].z : f1.a[t].w;
+            const float bv = q == 0 ? f1.b.x : q == 1 ? f1.b.y : q == 2 ? f1.b.z : f1.b.w;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            if (i >= kNM - kPer - 2 && i < kNM - 2) {
+              __builtin_amdgcn_sched_barrier(0);
+              dma_piece(i - (kNM - kPer - 2), off, cur);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
+      pin_acc();
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) { a_off[kc] ^= kBufXor; b_off[kc] ^= kBufXor; }
+      cur ^= kBufXor;
+    }
+    dma_wait();                                      // the copies issued by the last two stages have landed before the LDS is released
+    __syncthreads();
+  }
+
+  // D[row = m (reg&3)+8*(reg>>2)+4*kk][col = n j]
+  const int n = n0 + wave * 32 + j;
+  if (n < N) {
+    const float bv = fused ? bias[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < kMT; ++t) {
+      if (t < mtiles) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+          if (m < M) {
+            if (fused) out[(long)m * ldc + n] = apply_act(acc[t][e] + bv, act);
+            else part[((long)split * M + m) * N + n] = acc[t][e];
+          }
+        }
+      }
+    }
+  }
+}
+
 // out = act(sum over splits (in split order) + bias).  VEC = 4: N % 4 == 0 and ldc % 4 == 0 -- one thread per four columns,
 // 16-byte loads, four splits in flight; the per-element order of the additions is that of the scalar kernel.
 // SM != 0 (VEC = 4 only): the result rows are written a second time in the stage-major 2-byte form the NEXT reduced-precision
@@ -409,7 +586,10 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   if (tm > 1 && !small)      // several row blocks: pick the split count by cost (see choose_splits); one block: as tuned above
     splits = choose_splits(tn * tm, stages, min_stages, mt == 10 ? 256 : 512,
                            (double)bm * kBN * sk * 2.0 / 460.0e3 * (mt == 10 ? 1.0 : 2.0), 4.0 * M * (double)N);
-  const int kper = cdiv(stages, splits) * sk;
+  int kper = cdiv(stages, splits) * sk;
+  // LDS-DMA build of the 320-row kernel (fc_mfma_dma_kernel; MNC_FC_DMA=0: the register-staged one): even stage counts per split
+  const bool dma = mt == 10 && K % 64 == 0 && !getenv("MNC_FC_ABL") && !(getenv("MNC_FC_DMA") && atoi(getenv("MNC_FC_DMA")) == 0);
+  if (dma) kper = cdiv(kper, 64) * 64;
   splits = cdiv(K, kper);
   float* part = nullptr;
   if (splits > 1) {
@@ -424,7 +604,19 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     const int abl = e ? atoi(e) : 0;
 #define MNC_FC_LAUNCH(MT, SK, A) hipLaunchKernelGGL((fc_mfma_kernel<MT, SK, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, \
                          d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
-    if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
+    if (dma) {
+      constexpr int lds = 65536 + (320 + kBN) * 32 * 4;
+      static std::atomic<unsigned long long> attr_set{0};            // one bit per device: function attributes are per device
+      const unsigned long long bit = 1ull << (ctx->device & 63);
+      if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set.fetch_or(bit, std::memory_order_relaxed);
+      }
+      hipLaunchKernelGGL(fc_mfma_dma_kernel<10>, dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+    }
+    else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
     else if (mt == 5) {
       if (abl == 1) MNC_FC_LAUNCH(5, 16, 1);
       else if (abl == 3) MNC_FC_LAUNCH(5, 16, 3);

@@ -762,6 +762,36 @@ def test_fc_mfma(dev, M, N, K, act):
     assert rel < 1e-4, (d, rel)
 
 
+@pytest.mark.parametrize("M,N,K,act,ldc_pad", [(300, 4096, 25088, 1, 0), (300, 520, 4096, 1, 8), (290, 1024, 2112, 0, 0),
+                                               (640, 256, 6400, 1, 0), (161, 128, 8192, 2, 64)])
+def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad):
+    """fc_mfma_dma_kernel (320-row blocks, operand panels copied global -> LDS by DMA into XOR-swizzled rows; fc6's kernel):
+    against torch, and against the register-staged kernel (MNC_FC_DMA=0) on the same call -- the products and the order inside a
+    K split are the same, the split boundaries differ (even stage counts).  MNC_FC_TILE=10 puts shapes on it that the tile
+    heuristic would give to the 160-row kernel: N that does not fill the last column tile, rows that do not fill the block,
+    two row blocks, a K with an odd number of 64-deep steps, a column slice (ldc > N), sigmoid."""
+    rng = np.random.default_rng(M + N + K + 5)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_a, d_w, d_b = dev.put(a), dev.put(w), dev.put(b)
+    ld = N + ldc_pad
+    y = F.linear(torch.from_numpy(a), torch.from_numpy(w), torch.from_numpy(b))
+    want = (F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y).numpy()
+    monkeypatch.setenv("MNC_FC_TILE", "10")
+    outs = []
+    for dma in ("1", "0"):
+        monkeypatch.setenv("MNC_FC_DMA", dma)
+        d_o = dev.empty((M * ld,), fill=np.nan)
+        dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
+        got = dev.get(d_o, (M, ld))
+        assert not np.isnan(got[:, :N]).any() and np.isnan(got[:, N:]).all()
+        d, rel = err(got[:, :N], want)
+        assert rel < 1e-4, (dma, d, rel)
+        outs.append(got[:, :N])
+    assert err(outs[0], outs[1])[1] < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES)
 def test_fc_bf16x3(dev, M, N, K, act):
     """Split-precision FC (3 bf16 MFMAs per product): measured against the float64 product.  Bar: 1e-4 of the output's
