@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 // group), with the copy of stage s + 2 issued right BEHIND the barrier of stage s -- every wave is past its reads of that
 // buffer -- so it has a full stage of MFMAs to land and the vmcnt(0) hipcc puts in front of a barrier while a DMA is in flight
 // is the wait the next stage needs anyway.
-template <int kMT>
+template <int kMT, int ABL = 0>
 __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ part, int M, int N, int K, int ldc, int kper,
@@ -298,12 +298,13 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
   // it -- is the explicit s_waitcnt vmcnt(0) + barrier below.  (s_nop: one wait state between the write of M0 and its use.)
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_fc_dma;
   auto dma_piece = [&](int i, long off, int buf_byte) {
+    if (ABL == 3 && wave + 4 * i >= kBM / 8) off = 0;            // tuning: weight pieces re-read stage 0 (activations stream)
     const float* g = src[i] + off;
     const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 4 * i) * 1024u);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
   };
   auto dma_stage = [&](int s, int buf_byte) {
-    const long off = (long)min(s, nstages - 1) * 32;             // past the end: the last stage once more, never multiplied
+    const long off = ABL == 1 ? 0 : (long)min(s, nstages - 1) * 32;   // past the end: the last stage once more, never multiplied
 #pragma unroll
     for (int i = 0; i < kPer; ++i) dma_piece(i, off, buf_byte);
   };
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
       __syncthreads();                               // ... for every wave, and nobody reads buffer `cur` any more
       read_frags(0, kBufXor, f0);                    // group 0 of stage s + 1
       {                                              // group 3: the 11 reads under the first MFMAs, then one copy per MFMA
-        const long off = (long)min(s + 2, nstages - 1) * 32;
+        const long off = ABL == 1 ? 0 : (long)min(s + 2, nstages - 1) * 32;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -609,11 +610,22 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
       static std::atomic<unsigned long long> attr_set{0};            // one bit per device: function attributes are per device
       const unsigned long long bit = 1ull << (ctx->device & 63);
       if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10>),
+        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 0>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set.fetch_or(bit, std::memory_order_relaxed);
       }
-      hipLaunchKernelGGL(fc_mfma_dma_kernel<10>, dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
+      // tuning builds: 1 every copy re-reads stage 0 (L2-hot operands), 3 only the weight copies do
+      const int dabl = getenv("MNC_FC_DMA_ABL") ? atoi(getenv("MNC_FC_DMA_ABL")) : 0;
+      if (dabl == 1) {
+        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 1>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                           M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+      } else if (dabl == 3) {
+        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 3>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                           M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+      } else
+      hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 0>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
                          M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
