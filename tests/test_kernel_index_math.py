@@ -155,3 +155,139 @@ def test_lds_pitches_are_conflict_free():
                 for d in range(4):
                     banks.add((lane * pitch + d) % 64)
             assert len(banks) == 64, (pitch, len(banks))
+
+
+B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+               [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]       # + the same two for lanes 32-63
+
+
+def _b128_conflict_free(dword_addr):
+    """dword_addr[64]: start address of each lane's 16-byte read -> True if every 16-lane group hits 64 distinct banks."""
+    for base in (0, 32):
+        for g in B128_GROUPS:
+            banks = set()
+            for lane in g:
+                for d in range(4):
+                    banks.add(int(dword_addr[base + lane] + d) % 64)
+            if len(banks) != 64:
+                return False
+    return True
+
+
+def test_winograd_halo_half_swap():
+    """conv_wino.hip, flat / rotated builds: a lane's halo read is pixel (4 rg + 2 ty + row, 2 tx + c), channel half kk, of a
+    [10][34] pixel halo with a 12-dword pixel pitch.  Tile columns are 24 dwords apart, so without the swap every lane starts
+    on a multiple of 8 banks and a 16-lane group covers 32 banks (2-way conflicts); with the two 16-byte halves of a pixel
+    swapped in halo rows whose (row >> 1) is odd, the two tile rows of a group are 4 banks apart: conflict-free.  Writer
+    (store_chunk: h_off) and reader (row_off) must agree on where a half lives."""
+    pitch, cols = 12, 34
+    ty, tx = (LANES & 31) >> 4, LANES & 15
+    kk = LANES >> 5
+
+    def writer(r, c, half, swap):
+        return (r * cols + c) * pitch + ((half ^ ((r >> 1) & 1)) if swap else half) * 4
+
+    def reader(rg, row, c, swap):
+        base = ((4 * rg + 2 * ty + row) * cols + 2 * tx + c) * pitch
+        return base + ((kk ^ ((ty + (row >> 1)) & 1)) if swap else kk) * 4
+
+    # every (pixel, half) has its own 4 dwords inside the pixel's 8 data dwords
+    for swap in (False, True):
+        seen = set()
+        for r in range(10):
+            for c in range(cols):
+                for half in (0, 1):
+                    a = writer(r, c, half, swap)
+                    assert a not in seen and (r * cols + c) * pitch <= a < (r * cols + c) * pitch + 8
+                    seen.add(a)
+    for rg in (0, 1):
+        for row in range(4):
+            for c in range(4):
+                got = reader(rg, row, c, True)
+                want = np.array([writer(4 * rg + 2 * int(ty[l]) + row, 2 * int(tx[l]) + c, int(kk[l]), True) for l in LANES])
+                assert np.array_equal(got, want)
+                assert _b128_conflict_free(reader(rg, row, c, True))
+                assert not _b128_conflict_free(reader(rg, row, c, False))     # what SQ_LDS_BANK_CONFLICT showed (39 % of LDS cycles)
+
+
+def test_fc_dma_swizzle():
+    """gemm.hip fc_mfma_dma_kernel: a stage is 448 rows (320 activation + 128 weight) of 128 bytes = 8 chunks, copied by 56
+    DMA instructions whose 64 lanes land contiguously; lane L of piece p fills slot 64 p + L = (row slot >> 3, chunk slot & 7)
+    with k-chunk (slot & 7) ^ ((row >> 1) & 7) of that row.  A fragment read of K-group kc by lane (j, kk) goes to chunk slot
+    (2 kc + kk) ^ ((j >> 1) & 7) of row (tile base + j).  Checks: the copy covers every (row, k-chunk) once; the reads find
+    their chunk; every ds_read_b128 lane group is conflict-free on the unpadded rows; one XOR switches buffers."""
+    rows, kBM = 448, 320
+    where = {}
+    for wave in range(4):
+        for i in range(14):
+            p = wave + 4 * i
+            for lane in range(64):
+                slot = p * 64 + lane
+                r, c = slot >> 3, (slot & 7) ^ ((slot >> 4) & 7)          # (r >> 1) & 7 with r = slot >> 3
+                assert (r, c) not in where
+                where[(r, c)] = slot * 16                                  # byte offset in the buffer
+    assert len(where) == rows * 8
+    j, kk = LANES & 31, LANES >> 5
+    for kc in range(4):
+        c = (2 * kc + kk) ^ ((j >> 1) & 7)
+        a_off = (j * 32 + c * 4) * 4
+        for t in range(10):                                               # activation tiles: + t * 4096 bytes
+            got = a_off + t * 4096
+            want = np.array([where[(t * 32 + int(j[l]), 2 * kc + int(kk[l]))] for l in LANES])
+            assert np.array_equal(got, want)
+            assert _b128_conflict_free(got // 4)
+        for wave in range(4):                                             # weight rows kBM + 32 wave + j
+            got = ((kBM + wave * 32 + j) * 32 + c * 4) * 4
+            want = np.array([where[(kBM + wave * 32 + int(j[l]), 2 * kc + int(kk[l]))] for l in LANES])
+            assert np.array_equal(got, want)
+            assert _b128_conflict_free(got // 4)
+            assert got.max() + 16 <= rows * 128 <= 65536 and np.array_equal(got ^ 65536, got + 65536)
+    # the plain row-major placement (chunk c in slot c) would put all 16 lanes of a group on 2 x 4 banks per parity
+    assert not _b128_conflict_free((j * 32 + (2 * 0 + kk) * 4))
+
+
+def _wino_plan(H, W, Cin, Cout, slots=512):
+    """wino_impl's tail plan (conv_wino.hip) for the two-row-group kernel: -> (pix_a, ksplit_a, ksplit_b)."""
+    pix = -(-W // 32) * -(-H // 8)
+    ncot, blocks = Cout // 32, Cin // 8
+    full_pix = (pix * ncot // slots) * slots // ncot
+    rest = (pix - full_pix) * ncot
+    if rest > 0:
+        sb = min(slots // rest, blocks // 8, 8)
+        if sb >= 3:
+            return full_pix, 1, sb
+    return pix, 1, 1
+
+
+def test_winograd_tail_plan_covers_every_tile_once():
+    """The launcher's two grid sections and the kernel's block decode: every (pixel tile, channel tile) appears with each of
+    its K ranges exactly once, the ranges partition the blocks, and the XCD renumbering is a bijection inside a section."""
+    def xcd(b, total):
+        q, r, x, idx = total >> 3, total & 7, b & 7, b >> 3
+        return (x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + idx
+
+    for (H, W, Cin, Cout), want in (((75, 125, 512, 512), (32, 1, 4)), ((38, 63, 512, 512), (0, 1, 3)),
+                                    ((150, 250, 256, 256), (152, 1, 1)), ((600, 1000, 64, 64), (2400, 1, 1)),
+                                    ((37, 63, 256, 512), (0, 1, 3))):
+        pix_a, sa, sb = _wino_plan(H, W, Cin, Cout)
+        assert (pix_a, sa, sb) == want
+        tiles_x, ncot, nb = -(-W // 32), Cout // 32, Cin // 8
+        pix = tiles_x * -(-H // 8)
+        n_a = pix_a * ncot * sa
+        grid = n_a + (pix - pix_a) * ncot * sb
+        seen = {}
+        for blk in range(grid):
+            b, total, pix0, s = (blk, n_a, 0, sa) if blk < n_a else (blk - n_a, grid - n_a, pix_a, sb)
+            logical = xcd(b, total)
+            assert 0 <= logical < total
+            nz = ncot * s
+            bz, p = logical % nz, pix0 + logical // nz
+            split, cot = bz // ncot, bz % ncot
+            c0, c1 = split * nb // s, (split + 1) * nb // s
+            assert p < pix and c1 > c0
+            seen.setdefault((p, cot), []).append((c0, c1))
+        assert len(seen) == pix * ncot
+        for ranges in seen.values():
+            ranges.sort()
+            assert ranges[0][0] == 0 and ranges[-1][1] == nb
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
