@@ -1076,7 +1076,8 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   }
   // Tail plan (two-row-group kernel, no MNC_CONV_KSPLIT override; MNC_WINO_TAIL=0 keeps the uniform rule above).  The chip holds
   // `slots` workgroups (two per CU).  The pixel tiles of the full rounds run unsplit; the tiles of the last, partly filled
-  // round are cut into sB >= 3 K ranges -- as many as fill that round once, with at least 8 blocks each -- and finished by
+  // round are cut into sB >= 3 K ranges -- as many as fill that round once, with at least 8 blocks each; on small maps whose
+  // last round leaves three quarters of the chip idle also 2 ranges, of at least 4 blocks -- and finished by
   // wino_section_reduce_kernel.  600x1000: conv4_x 512 + 128 x 4 workgroups instead of 640 x 2 (2.5 rounds): 256 -> 240 us;
   // conv5_x / rpn_conv 160 x 3 instead of 160 x 4 (1.25 rounds): 84.5 -> 73.4 us.  A tail workgroup that has its CU to itself
   // runs faster than one of a pair, so a lightly filled last round costs less than its length suggests: cutting conv3_x's 192
@@ -1092,10 +1093,13 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
       const int rest = (pix - full_pix) * ncot;
       ksplit = 1;
       if (rest > 0) {
+        const bool light = rest <= slots / 4;                    // a last round that leaves three quarters of the chip idle
+        const int min_blocks = light ? 4 : 8;                    // (small maps: ranges of 4 blocks, as the uniform rule had)
         int sb = slots / rest;
-        if (sb > blocks / 8) sb = blocks / 8;
+        if (sb > blocks / min_blocks) sb = blocks / min_blocks;
         if (sb > 8) sb = 8;
-        if (sb >= 3) { pix_a = full_pix; ksplit_b = sb; }       // two ranges do not pay (conv3_x, 192 tail tiles: 237 -> 248 us)
+        // two ranges do not pay on a well filled round (conv3_x, 192 tail tiles: 237 -> 248 us)
+        if (sb >= 3 || (sb == 2 && light)) { pix_a = full_pix; ksplit_b = sb; }
       }
     }
   }

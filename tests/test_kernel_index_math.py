@@ -253,8 +253,9 @@ def _wino_plan(H, W, Cin, Cout, slots=512):
     full_pix = (pix * ncot // slots) * slots // ncot
     rest = (pix - full_pix) * ncot
     if rest > 0:
-        sb = min(slots // rest, blocks // 8, 8)
-        if sb >= 3:
+        light = rest <= slots // 4
+        sb = min(slots // rest, blocks // (4 if light else 8), 8)
+        if sb >= 3 or (sb == 2 and light):
             return full_pix, 1, sb
     return pix, 1, 1
 
@@ -268,7 +269,8 @@ def test_winograd_tail_plan_covers_every_tile_once():
 
     for (H, W, Cin, Cout), want in (((75, 125, 512, 512), (32, 1, 4)), ((38, 63, 512, 512), (0, 1, 3)),
                                     ((150, 250, 256, 256), (152, 1, 1)), ((600, 1000, 64, 64), (2400, 1, 1)),
-                                    ((37, 63, 256, 512), (0, 1, 3))):
+                                    ((37, 63, 256, 512), (0, 1, 3)), ((13, 33, 128, 256), (0, 1, 4)),
+                                    ((38, 63, 128, 64), (0, 1, 4)), ((75, 125, 64, 64), (0, 1, 2)), ((5, 3, 8, 32), (1, 1, 1))):
         pix_a, sa, sb = _wino_plan(H, W, Cin, Cout)
         assert (pix_a, sa, sb) == want
         tiles_x, ncot, nb = -(-W // 32), Cout // 32, Cin // 8
