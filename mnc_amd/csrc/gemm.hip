@@ -257,15 +257,20 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 // group), with the copy of stage s + 2 issued right BEHIND the barrier of stage s -- every wave is past its reads of that
 // buffer -- so it has a full stage of MFMAs to land and the vmcnt(0) hipcc puts in front of a barrier while a DMA is in flight
 // is the wait the next stage needs anyway.
-template <int kMT, int ABL = 0>
-__global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
+// kWM = waves along M: 1 -> four waves, each all kMT row tiles x its 32 columns (one wave per SIMD); 2 -> eight waves, wave
+// (wm, wn) owns kMT / 2 row tiles x columns 32 wn: half the accumulators, two waves per SIMD -- one wave's barrier and fragment
+// waits run under its partner's MFMAs.
+template <int kMT, int ABL = 0, int kWM = 1>
+__global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ part, int M, int N, int K, int ldc, int kper,
                                                           int act, int fused, int tn_, int splits_, int tm_) {
   constexpr int kBM = 32 * kMT;
   constexpr int kRows = kBM + kBN;                   // operand rows per stage: activations, then weights
-  constexpr int kPer = kRows * 128 / 1024 / 4;       // DMA instructions per wave and stage (1 KB = 8 rows each)
-  static_assert(kRows % 32 == 0, "whole pieces per wave");
+  constexpr int kNW = 4 * kWM;                       // waves
+  constexpr int TR = kMT / kWM;                      // row tiles per wave
+  constexpr int kPer = kRows * 128 / 1024 / kNW;     // DMA instructions per wave and stage (1 KB = 8 rows each)
+  static_assert(kRows % (8 * kNW) == 0 && kMT % kWM == 0, "whole pieces and row tiles per wave");
   // Two stage buffers 64 KB apart (57 KB used each), so that every LDS offset switches buffer with one XOR.  The loop runs ONE
   // stage per iteration with the DMA issue as its last LDS-related instruction: hipcc's wait-count pass makes every ds_read that
   // FOLLOWS a DMA issue in straight-line code wait for vmcnt(0) ("may alias"; the reads go to the other buffer, the barrier
@@ -275,6 +280,7 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
   constexpr int kBufXor = 65536;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;           // column group, row half
   const int j = lane & 31, kk = lane >> 5;
   int bn, split, bmz;
   xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
@@ -284,11 +290,11 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
   const int mrows = min(M - m0, kBM);
   const int mtiles = (mrows + 31) >> 5;
 
-  // piece p = wave + 4 i covers buffer bytes [1024 p, 1024 p + 1024): lane L fills slot 64 p + L = (row r, chunk slot L & 7)
+  // piece p = wave + kNW i covers buffer bytes [1024 p, 1024 p + 1024): lane L fills slot 64 p + L = (row r, chunk slot L & 7)
   const float* src[kPer];
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
-    const int slot = (wave + 4 * i) * 64 + lane, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    const int slot = (wave + kNW * i) * 64 + lane, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
     src[i] = (r < kBM ? A + (long)(m0 + min(r, mrows - 1)) * K               // rows past M re-read the last valid row; never stored
                       : Wt + (long)min(n0 + r - kBM, N - 1) * K) + kbeg + c * 4;
   }
@@ -298,9 +304,9 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
   // it -- is the explicit s_waitcnt vmcnt(0) + barrier below.  (s_nop: one wait state between the write of M0 and its use.)
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_fc_dma;
   auto dma_piece = [&](int i, long off, int buf_byte) {
-    if (ABL == 3 && wave + 4 * i >= kBM / 8) off = 0;            // tuning: weight pieces re-read stage 0 (activations stream)
+    if (ABL == 3 && wave + kNW * i >= kBM / 8) off = 0;            // tuning: weight pieces re-read stage 0 (activations stream)
     const float* g = src[i] + off;
-    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 4 * i) * 1024u);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + kNW * i) * 1024u);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
   };
   auto dma_stage = [&](int s, int buf_byte) {
@@ -310,9 +316,9 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  f32x16 acc[kMT];
+  f32x16 acc[TR];
 #pragma unroll
-  for (int t = 0; t < kMT; ++t)
+  for (int t = 0; t < TR; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
@@ -322,30 +328,30 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
 #pragma unroll
   for (int kc = 0; kc < 4; ++kc) {
     const int c = (2 * kc + kk) ^ ((j >> 1) & 7);
-    a_off[kc] = (j * 32 + c * 4) * 4;
-    b_off[kc] = ((kBM + wave * 32 + j) * 32 + c * 4) * 4;
+    a_off[kc] = ((wm * TR * 32 + j) * 32 + c * 4) * 4;
+    b_off[kc] = ((kBM + wn * 32 + j) * 32 + c * 4) * 4;
   }
-  struct Frags { float4 a[kMT]; float4 b; };
+  struct Frags { float4 a[TR]; float4 b; };
   auto read_frags = [&](int kc, int flip, Frags& f) {
     f.b = *reinterpret_cast<const float4*>(s_fc_dma + (b_off[kc] ^ flip));
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) f.a[t] = *reinterpret_cast<const float4*>(s_fc_dma + (a_off[kc] ^ flip) + t * 4096);
+    for (int t = 0; t < TR; ++t) f.a[t] = *reinterpret_cast<const float4*>(s_fc_dma + (a_off[kc] ^ flip) + t * 4096);
   };
   auto mfmas = [&](const Frags& f) {                 // k outermost: consecutive MFMAs go to different accumulators
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].x, f.b.x, acc[t], 0, 0, 0);
+    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].x, f.b.x, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].y, f.b.y, acc[t], 0, 0, 0);
+    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].y, f.b.y, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].z, f.b.z, acc[t], 0, 0, 0);
+    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].z, f.b.z, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].w, f.b.w, acc[t], 0, 0, 0);
+    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].w, f.b.w, acc[t], 0, 0, 0);
   };
   auto pin_acc = [&]() {
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) asm volatile("" : "+a"(acc[t]));
+    for (int t = 0; t < TR; ++t) asm volatile("" : "+a"(acc[t]));
   };
-  constexpr int kNM = 4 * kMT, kNR = kMT + 1;
+  constexpr int kNM = 4 * TR, kNR = TR + 1;
 
   if (nstages > 0) {
     Frags f0, f1;
@@ -378,8 +384,8 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int t = 0; t < kMT; ++t) {
-            const int i = q * kMT + t;
+          for (int t = 0; t < TR; ++t) {
+            const int i = q * TR + t;
             const float av = q == 0 ? f1.a[t].x : q == 1 ? f1.a[t].y : q == 2 ? f1.a[t].z : f1.a[t].w;
             const float bv = q == 0 ? f1.b.x : q == 1 ? f1.b.y : q == 2 ? f1.b.z : f1.b.w;
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
@@ -400,15 +406,15 @@ __global__ __launch_bounds__(256) void fc_mfma_dma_kernel(const float* __restric
   }
 
   // D[row = m (reg&3)+8*(reg>>2)+4*kk][col = n j]
-  const int n = n0 + wave * 32 + j;
+  const int n = n0 + wn * 32 + j;
   if (n < N) {
     const float bv = fused ? bias[n] : 0.f;
 #pragma unroll
-    for (int t = 0; t < kMT; ++t) {
-      if (t < mtiles) {
+    for (int t = 0; t < TR; ++t) {
+      if (wm * TR + t < mtiles) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+          const int m = m0 + (wm * TR + t) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
           if (m < M) {
             if (fused) out[(long)m * ldc + n] = apply_act(acc[t][e] + bv, act);
             else part[((long)split * M + m) * N + n] = acc[t][e];
@@ -623,6 +629,11 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
       } else if (dabl == 3) {
         MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 3>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
+                           M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+      } else if (!(getenv("MNC_FC_DMA_WAVES") && atoi(getenv("MNC_FC_DMA_WAVES")) == 4)) {
+        // eight waves, two per SIMD (default; MNC_FC_DMA_WAVES=4: four waves, one per SIMD): fc6 610 -> 595 us, same bits
+        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 0, 2>), dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
                            M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
       } else
       hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 0>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,

@@ -780,8 +780,12 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad):
     want = (F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y).numpy()
     monkeypatch.setenv("MNC_FC_TILE", "10")
     outs = []
-    for dma in ("1", "0"):
-        monkeypatch.setenv("MNC_FC_DMA", dma)
+    for dma in ("1", "0", "4"):        # default: eight waves (two per SIMD); "4": the four-wave build of the DMA kernel
+        monkeypatch.setenv("MNC_FC_DMA", "0" if dma == "0" else "1")
+        if dma == "4":
+            monkeypatch.setenv("MNC_FC_DMA_WAVES", "4")
+        else:
+            monkeypatch.delenv("MNC_FC_DMA_WAVES", raising=False)
         d_o = dev.empty((M * ld,), fill=np.nan)
         dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
         got = dev.get(d_o, (M, ld))
@@ -789,7 +793,7 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad):
         d, rel = err(got[:, :N], want)
         assert rel < 1e-4, (dma, d, rel)
         outs.append(got[:, :N])
-    assert err(outs[0], outs[1])[1] < 1e-5
+    assert err(outs[0], outs[1])[1] < 1e-5 and np.array_equal(outs[0], outs[2])      # same K order per accumulator
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES)
