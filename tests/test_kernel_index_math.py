@@ -293,3 +293,63 @@ def test_winograd_tail_plan_covers_every_tile_once():
             ranges.sort()
             assert ranges[0][0] == 0 and ranges[-1][1] == nb
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+
+
+def test_fc_dma_kernel_index_math():
+    """fc_mfma_dma_kernel<10, 0, 2> lane by lane: the copy's slot -> (row, k-chunk) map with clamped rows, the swizzled fragment
+    addresses of wave (wm, wn), the v_mfma_f32_32x32x2_f32 operand layout, the epilogue's accumulator -> (m, n) map and the
+    K-split partial sums, against a float64 product.  Two row blocks (the second ragged), a ragged column tile, two K splits of
+    unequal length."""
+    rng = np.random.default_rng(3)
+    M, N, K, kper = 333, 150, 192, 128           # splits: stages [0, 4) and [4, 6)
+    A = rng.normal(size=(M, K)).astype(np.float32)
+    Wt = rng.normal(size=(N, K)).astype(np.float32)
+    kBM, kBN, kNW, TR = 320, 128, 8, 5
+    rows = kBM + kBN
+    splits = -(-K // kper)
+    part = np.full((splits, M, N), np.nan, np.float64)
+    for bmz in range(-(-M // kBM)):
+        m0 = bmz * kBM
+        mrows = min(M - m0, kBM)
+        mtiles = (mrows + 31) >> 5
+        for bn in range(-(-N // kBN)):
+            n0 = bn * kBN
+            for split in range(splits):
+                kbeg, kend = split * kper, min(K, split * kper + kper)
+                acc = np.zeros((kNW, TR, 64, 16), np.float64)
+                for s in range((kend - kbeg) // 32):
+                    buf = np.full(rows * 32, np.nan, np.float32)          # one stage buffer, in floats
+                    for wave in range(kNW):
+                        for i in range(rows // 8 // kNW):
+                            for lane in range(64):
+                                slot = (wave + kNW * i) * 64 + lane
+                                r, c = slot >> 3, (slot & 7) ^ ((slot >> 4) & 7)
+                                src = A[m0 + min(r, mrows - 1)] if r < kBM else Wt[min(n0 + r - kBM, N - 1)]
+                                k0 = kbeg + s * 32 + c * 4
+                                buf[slot * 4: slot * 4 + 4] = src[k0: k0 + 4]
+                    assert not np.isnan(buf).any()
+                    for wave in range(kNW):
+                        wn, wm = wave & 3, wave >> 2
+                        for kc in range(4):
+                            c = (2 * kc + KK) ^ ((J >> 1) & 7)
+                            a_off = (wm * TR * 32 + J) * 32 + c * 4
+                            b_off = (kBM + wn * 32 + J) * 32 + c * 4
+                            for t in range(TR):
+                                for e in range(4):
+                                    mfma_32x32x2(buf[a_off + t * 1024 + e], buf[b_off + e], acc[wave, t])
+                for wave in range(kNW):
+                    wn, wm = wave & 3, wave >> 2
+                    for lane in range(64):
+                        j, kk = lane & 31, lane >> 5
+                        n = n0 + wn * 32 + j
+                        if n >= N:
+                            continue
+                        for t in range(TR):
+                            if wm * TR + t < mtiles:
+                                for e in range(16):
+                                    m = m0 + (wm * TR + t) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk
+                                    if m < M:
+                                        assert np.isnan(part[split, m, n])               # every element written once
+                                        part[split, m, n] = acc[wave, t, lane, e]
+    assert not np.isnan(part).any()
+    assert np.abs(part.sum(0) - A.astype(np.float64) @ Wt.astype(np.float64).T).max() < 1e-4
