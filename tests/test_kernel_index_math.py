@@ -353,3 +353,36 @@ def test_fc_dma_kernel_index_math():
                                         part[split, m, n] = acc[wave, t, lane, e]
     assert not np.isnan(part).any()
     assert np.abs(part.sum(0) - A.astype(np.float64) @ Wt.astype(np.float64).T).max() < 1e-4
+
+
+def test_winograd_wave_pair_roles_and_partial_output_transform():
+    """conv_wino.hip, flat / rotated builds, one tile and one channel pair in scalar form: wave hf of a pair names its three
+    halo rows by role -- hf = 0: (A, B, C) = (d0, d1, d2), hf = 1: (d2, d3, d1) -- builds t0 = A - C, t1 = fma(sgn, B, C) with
+    sgn = +1 / -1 (rows 2 hf, 2 hf + 1 of B^T d), runs the column pass, multiplies with rows 2 hf, 2 hf + 1 of U = G g G^T and
+    applies the output transform to its own rows (hf = 0: s0 = M0 + M1, s1 = M1; hf = 1: s0 = M2, s1 = -(M2 + M3)); the pair's
+    partial 2x2 outputs add up to the 3x3 correlation.  Exact in float64 up to rounding of the G transform."""
+    rng = np.random.default_rng(5)
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    for _ in range(20):
+        d = rng.normal(size=(4, 4))
+        g = rng.normal(size=(3, 3))
+        U = G @ g @ G.T
+        y = np.zeros((2, 2))
+        for hf in (0, 1):
+            rowA, rowB, rowC = (2, 3, 1) if hf else (0, 1, 2)
+            sgn = -1.0 if hf else 1.0
+            t0 = d[rowA] - d[rowC]
+            t1 = sgn * d[rowB] + d[rowC]
+            want = (d[2] - d[1], d[1] - d[3]) if hf else (d[0] - d[2], d[1] + d[2])
+            assert np.array_equal(t0, want[0]) and np.array_equal(t1, want[1])
+            m = []
+            for r, t in enumerate((t0, t1)):
+                v = np.array([t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]])
+                m.append(U[2 * hf + r] * v)                       # positions 8 hf + 4 r + c
+            s0 = m[0] if hf else m[0] + m[1]
+            s1 = -(m[0] + m[1]) if hf else m[1]
+            for dy, s in enumerate((s0, s1)):
+                y[dy, 0] += s[0] + s[1] + s[2]
+                y[dy, 1] += s[1] - s[2] - s[3]
+        direct = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(2)] for i in range(2)])
+        assert np.abs(y - direct).max() < 1e-12
