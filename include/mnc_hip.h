@@ -66,9 +66,27 @@ MNC_API int mnc_nms_batched(int* keep_out, int* num_out, const float* boxes_host
  * scan, nms_kernel.cu:135) are written as 0. */
 MNC_API int mnc_nms_mask(unsigned long long* mask_host, const float* boxes_host, int boxes_num, int boxes_dim,
                          float nms_overlap_thresh, int device_id);
-/* Signature-compatible with the reference symbol (errors are reported through mnc_last_error only). */
+/* The reference's own symbol, twice.
+ *  (1) C++ linkage -- `_Z4_nmsPiS_PKfiifi` -- which is what the reference's extension links: gpu_nms.pyx:13-14 declares it with
+ *      `cdef extern from "gpu_nms.hpp"` and lib/setup.py:126-130 compiles that extension with language='c++', so the call is a
+ *      C++ call of `void _nms(int*, int*, const float*, int, int, float, int)` (gpu_nms.hpp:1-2).  libmnc_hip.so exports that
+ *      mangled name (csrc/ref_cxx_abi.hip); a C++ translation unit gets the declaration by including the reference's
+ *      gpu_nms.hpp itself, or this header with MNC_HIP_REF_CXX_NAMES defined.
+ *  (2) C linkage `_nms`, same arguments, for dlsym / ctypes / cgo callers (the default declaration of this header).
+ * Both report errors through mnc_last_error() and a line on stderr, and set *num_out = 0 (the reference aborts in CUDA_CHECK). */
+#if defined(__cplusplus) && defined(MNC_HIP_REF_CXX_NAMES)
+}  /* leave extern "C" for the two C++-linkage names */
 MNC_API void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
                   float nms_overlap_thresh, int device_id);
+MNC_API void _mv(const float* all_boxes, const float* all_masks, const int all_boxes_num, const int* candidate_inds,
+                 const int* candidate_start, const float* candidate_weights, const int candidate_num,
+                 const int image_height, const int image_width, const int box_dim, const int mask_size,
+                 const int result_num, float* finalize_output_mask, int* finalize_output_box, const int device_id);
+extern "C" {
+#else
+MNC_API void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                  float nms_overlap_thresh, int device_id);
+#endif
 
 /* ---------------------------------------------------------------------------------------------------------------
  * b2  nms.mv  --  replaces `_mv` (lib/nms/gpu_mv.hpp:1-4, lib/nms/mv_kernel.cu:242-348), called from
@@ -83,10 +101,14 @@ MNC_API int mnc_mv(const float* all_boxes, const float* all_masks, int all_boxes
                    const int* candidate_start, const float* candidate_weights, int candidate_num, int image_height,
                    int image_width, int box_dim, int mask_size, int result_num, float* finalize_output_mask,
                    int* finalize_output_box, int device_id);
+/* `_mv`: exported with C++ linkage (`_Z3_mvPKfS0_iPKiS2_S0_iiiiiiPfPii`, what gpu_mv.pyx:7-8 + lib/setup.py:143-147 link)
+ * and with C linkage, as `_nms` above. */
+#if !(defined(__cplusplus) && defined(MNC_HIP_REF_CXX_NAMES))
 MNC_API void _mv(const float* all_boxes, const float* all_masks, const int all_boxes_num, const int* candidate_inds,
                  const int* candidate_start, const float* candidate_weights, const int candidate_num,
                  const int image_height, const int image_width, const int box_dim, const int mask_size,
                  const int result_num, float* finalize_output_mask, int* finalize_output_box, const int device_id);
+#endif
 
 /* gpu_mask_voting in ONE call (lib/transform/mask_transform.py:213-286): per-class NMS (batched on the device) -> global
  * score threshold -> candidate sets {IoU_f64 >= iou_thresh} with class-score weights divided by float32(sequential float64 sum)
@@ -122,6 +144,10 @@ MNC_API int mnc_ctx_create(mnc_ctx** out, int device_id);
 MNC_API int mnc_ctx_destroy(mnc_ctx* ctx);
 MNC_API int mnc_ctx_sync(mnc_ctx* ctx);
 MNC_API int mnc_ctx_device(const mnc_ctx* ctx, int* device_id);
+/* Number of times one of the context's internal device arenas (split-K / Winograd scratch, proposal state, voting scratch) has
+ * been re-allocated.  A captured HIP graph holds their addresses: mnc_forward_image drops its graph when this value has moved
+ * since the capture; a caller that captures library launches into its own graph must do the same. */
+MNC_API int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation);
 
 /* Device memory for the host-side executor (the caffe-shaped Net keeps its blobs here). */
 MNC_API int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr);

@@ -37,8 +37,25 @@ def _deps_mtime():
     return max(os.path.getmtime(p) for p in paths)
 
 
+def _base_flags():
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+            "-Wno-unused-function"] + os.environ.get("MNC_HIPCC_EXTRA", "").split()      # e.g. -DMNC_TUNING (tuning builds)
+
+
+STAMP = os.path.join(OBJ, "flags.stamp")
+
+
+def _flags_match():
+    """Objects and library were compiled with today's command line (compiler, arch, MNC_HIPCC_EXTRA)?  mtimes alone would reuse
+    objects of a tuning build (-DMNC_TUNING ...) for the product library and the other way round."""
+    try:
+        return open(STAMP).read() == " ".join([_hipcc()] + _base_flags())
+    except OSError:
+        return False
+
+
 def up_to_date():
-    return os.path.isfile(LIB) and os.path.getmtime(LIB) >= _deps_mtime()
+    return os.path.isfile(LIB) and os.path.getmtime(LIB) >= _deps_mtime() and _flags_match()
 
 
 def build(force=False, verbose=False):
@@ -46,8 +63,9 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     cc = _hipcc()
-    base = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
-            "-Wno-unused-function"] + os.environ.get("MNC_HIPCC_EXTRA", "").split()      # e.g. -DMNC_X3_ABL=3 (tuning builds)
+    base = [cc] + _base_flags()
+    if not _flags_match():
+        force = True                      # different command line: nothing compiled before may be reused
 
     hdr_mtime = max(os.path.getmtime(p) for p in
                     [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] +
@@ -72,6 +90,8 @@ def build(force=False, verbose=False):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(base))
     return LIB
 
 

@@ -21,6 +21,7 @@ int ensure_scratch(mnc_ctx* ctx, size_t bytes) {
     MNC_HIP_TRY(hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
+    ++ctx->arena_gen;
   }
   size_t want = bytes + (bytes >> 2);
   hipError_t e = hipMalloc(&ctx->scratch, want);
@@ -29,6 +30,7 @@ int ensure_scratch(mnc_ctx* ctx, size_t bytes) {
     return MNC_ERR_NOMEM;
   }
   ctx->scratch_bytes = want;
+  ++ctx->arena_gen;
   return MNC_OK;
 }
 
@@ -127,6 +129,12 @@ int mnc_ctx_sync(mnc_ctx* ctx) {
 int mnc_ctx_device(const mnc_ctx* ctx, int* device_id) {
   MNC_REQUIRE(ctx && device_id, "mnc_ctx_device: null pointer");
   *device_id = ctx->device;
+  return MNC_OK;
+}
+
+int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation) {
+  MNC_REQUIRE(ctx && generation, "mnc_ctx_arena_generation: null pointer");
+  *generation = ctx->arena_gen;
   return MNC_OK;
 }
 

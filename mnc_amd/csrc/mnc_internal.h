@@ -37,6 +37,10 @@ struct mnc_ctx {
   void* vote_ws = nullptr;    // gpu_mask_voting scratch (mv.hip), grown on demand
   size_t vote_ws_bytes = 0;
   void* comm = nullptr;       // RCCL communicator state (comm.hip), set by mnc_comm_init
+  // Bumped whenever one of the context-owned arenas above (scratch, proposal state, voting scratch) is re-allocated: a captured
+  // HIP graph holds their raw addresses, so a graph owner (pipeline.hip) records the value at capture and drops its graph when
+  // the value has moved on.
+  unsigned long arena_gen = 0;
 };
 
 namespace mnc {

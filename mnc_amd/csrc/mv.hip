@@ -616,6 +616,7 @@ static int ctx_vote_ws(mnc_ctx* ctx, int n, int C, int S, int keep_cap, VoteWs* 
     if (ctx->vote_ws) MNC_HIP_TRY(hipFree(ctx->vote_ws));
     ctx->vote_ws = nullptr;
     ctx->vote_ws_bytes = 0;
+    ++ctx->arena_gen;                  // a captured graph that holds the old address must not be replayed (pipeline.hip)
     hipError_t e = hipMalloc(&ctx->vote_ws, need + (need >> 2));
     if (e != hipSuccess) {
       (void)hipGetLastError();

@@ -103,6 +103,7 @@ struct mnc_net {
   // HIP graph of one image size
   hipGraphExec_t gexec = nullptr;
   int graph_h = -1, graph_w = -1, seen_h = -1, seen_w = -1;
+  unsigned long graph_gen = 0;   // arena generation (mnc_ctx::arena_gen of both contexts) the graph was captured under
 };
 
 namespace {
@@ -553,6 +554,8 @@ int enqueue_image(mnc_net* n) {
   return enqueue_outputs(n);
 }
 
+unsigned long arena_gen(const mnc_net* n) { return n->ctx->arena_gen + (n->ctx_b ? n->ctx_b->arena_gen : 0); }
+
 // The asynchronous part of one image: eager the first time a size is seen (buffers, scratch and function attributes settle),
 // captured into a graph the second time, replayed from then on.
 int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
@@ -565,6 +568,13 @@ int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
   n->in_flight = true;
   hipStream_t s = n->ctx->stream;
   const bool want_graph = n->cfg.use_graph && n->ctx->profiling == 0;
+  if (n->gexec && n->graph_gen != arena_gen(n)) {
+    // a context-owned arena (split-K / Winograd scratch, proposal state, voting scratch) was re-allocated since the capture --
+    // by another image size run eagerly on this net (the scratch need is not monotonic in the image size) or by another user of
+    // the context: the graph holds freed addresses.  Drop it; this image runs as direct launches, the next one re-captures.
+    (void)hipGraphExecDestroy(n->gexec);
+    n->gexec = nullptr; n->graph_h = n->graph_w = -1; n->seen_h = n->seen_w = -1;
+  }
   if (want_graph && n->gexec && n->graph_h == H && n->graph_w == W) {
     MNC_HIP_TRY(hipGraphLaunch(n->gexec, s));
     return MNC_OK;
@@ -573,13 +583,22 @@ int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
     if (n->gexec) { (void)hipGraphExecDestroy(n->gexec); n->gexec = nullptr; }
     hipGraph_t g = nullptr;
     MNC_HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    const unsigned long gen0 = arena_gen(n);
     int rc = enqueue_image(n);
     hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc == MNC_OK && e == hipSuccess && g && gen0 != arena_gen(n)) {
+      // an arena grew while capturing (cannot happen after an eager run of the same size; kept as a guard): the captured nodes
+      // may hold the old address -- discard the capture and run this image directly
+      (void)hipGraphDestroy(g);
+      n->seen_h = H; n->seen_w = W;
+      return enqueue_image(n);
+    }
     if (rc == MNC_OK && e == hipSuccess && g) {
       e = hipGraphInstantiate(&n->gexec, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e == hipSuccess) {
         n->graph_h = H; n->graph_w = W;
+        n->graph_gen = gen0;
         MNC_HIP_TRY(hipGraphLaunch(n->gexec, s));
         return MNC_OK;
       }
@@ -641,6 +660,8 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   MNC_REQUIRE(cfg->roi_size > 0 && cfg->roi_size % 2 == 0 && cfg->mask_size >= 2 && cfg->num_classes >= 2 &&
               cfg->post_nms_topn > 0 && cfg->max_per_image > 0 && cfg->fc_dim > 0 && cfg->mask_fc > 0,
               "mnc_net_create: head shape");
+  // the per-class counts travel in a fixed 256-byte header (device `counts` buffer, pinned [counts | proposal count | records])
+  MNC_REQUIRE(cfg->num_classes <= 64, "mnc_net_create: num_classes %d > 64 (the result header holds 64 counts)", cfg->num_classes);
   MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 2, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3) or 2 (f16)");
   MNC_REQUIRE(cfg->target_size > 0 && cfg->max_size >= cfg->target_size, "mnc_net_create: target_size / max_size");
   mnc_net* n = new (std::nothrow) mnc_net();
@@ -665,8 +686,13 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
 int mnc_net_set_param(mnc_net* net, const char* layer, int index, const float* data_host, size_t count) {
   MNC_REQUIRE(net && layer && data_host && index >= 0 && index <= 1 && count > 0, "mnc_net_set_param: bad argument");
   MNC_REQUIRE(!net->finalized, "mnc_net_set_param: the weights of this net are already packed (set them before the first image)");
-  HostBlob& b = net->params[std::string(layer) + "/" + std::to_string(index)];
-  b.v.assign(data_host, data_host + count);
+  try {
+    HostBlob& b = net->params[std::string(layer) + "/" + std::to_string(index)];
+    b.v.assign(data_host, data_host + count);
+  } catch (const std::exception&) {
+    set_error("mnc_net_set_param: out of host memory for %s/%d (%zu values)", layer, index, count);
+    return MNC_ERR_NOMEM;
+  }
   clear_error();
   return MNC_OK;
 }
@@ -675,32 +701,49 @@ int mnc_net_load_file(mnc_net* net, const char* path) {
   MNC_REQUIRE(net && path, "mnc_net_load_file: null pointer");
   FILE* f = fopen(path, "rb");
   MNC_REQUIRE(f, "mnc_net_load_file: cannot open %s", path);
+  // the file is untrusted input: every count is checked against what is left of the file before anything is allocated, and
+  // nothing may throw across the C boundary
+  long file_bytes = 0;
+  if (fseek(f, 0, SEEK_END) == 0) file_bytes = ftell(f);
+  rewind(f);
   char magic[8];
   unsigned n = 0;
-  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "MNCW0001", 8) == 0 && fread(&n, 4, 1, f) == 1;
+  bool ok = file_bytes >= 12 && fread(magic, 1, 8, f) == 8 && memcmp(magic, "MNCW0001", 8) == 0 && fread(&n, 4, 1, f) == 1;
   int rc = MNC_OK;
-  for (unsigned i = 0; ok && i < n; ++i) {
-    unsigned short len = 0;
-    unsigned char idx = 0, nd = 0;
-    char name[256];
-    unsigned dims[8];
-    ok = fread(&len, 2, 1, f) == 1 && len < sizeof(name) && fread(name, 1, len, f) == len && fread(&idx, 1, 1, f) == 1 &&
-         fread(&nd, 1, 1, f) == 1 && nd <= 8 && fread(dims, 4, nd, f) == nd;
-    if (!ok) break;
-    name[len] = 0;
-    size_t count = 1;
-    for (int d = 0; d < nd; ++d) count *= dims[d];
-    std::vector<float> v(count);
-    ok = count > 0 && fread(v.data(), 4, count, f) == count;
-    if (!ok) break;
-    if (idx <= 1) {
+  const char* why = "is not a complete MNCW0001 file";
+  try {
+    std::vector<float> v;
+    for (unsigned i = 0; ok && i < n; ++i) {
+      unsigned short len = 0;
+      unsigned char idx = 0, nd = 0;
+      char name[256];
+      unsigned dims[8];
+      ok = fread(&len, 2, 1, f) == 1 && len < sizeof(name) && fread(name, 1, len, f) == len && fread(&idx, 1, 1, f) == 1 &&
+           fread(&nd, 1, 1, f) == 1 && nd <= 8 && fread(dims, 4, nd, f) == nd;
+      if (!ok) break;
+      name[len] = 0;
+      if (idx > 1) { ok = false; why = "holds a blob index > 1 (a layer has a weight [0] and a bias [1])"; break; }
+      const size_t left = (size_t)(file_bytes - ftell(f)) / 4;
+      size_t count = 1;
+      for (int d = 0; d < nd && ok; ++d) {
+        if (dims[d] == 0 || count > left / dims[d]) ok = false;      // empty blob, or more values than the file has left
+        else count *= dims[d];
+      }
+      if (!ok) { why = "declares a blob larger than the file"; break; }
+      v.resize(count);
+      ok = fread(v.data(), 4, count, f) == count;
+      if (!ok) break;
       rc = mnc_net_set_param(net, name, idx, v.data(), count);
       if (rc) break;
     }
+  } catch (const std::exception&) {
+    fclose(f);
+    set_error("mnc_net_load_file: out of host memory while reading %s", path);
+    return MNC_ERR_NOMEM;
   }
   fclose(f);
   if (rc) return rc;
-  MNC_REQUIRE(ok, "mnc_net_load_file: %s is not a complete MNCW0001 file", path);
+  MNC_REQUIRE(ok, "mnc_net_load_file: %s %s", path, why);
   clear_error();
   return MNC_OK;
 }

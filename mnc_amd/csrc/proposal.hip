@@ -376,6 +376,7 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (st->buf) MNC_HIP_TRY(hipFree(st->buf));
     st->buf = nullptr; st->bytes = 0;
+    ++ctx->arena_gen;                  // a captured graph that holds the old address must not be replayed (pipeline.hip)
     hipError_t e = hipMalloc(&st->buf, need + (need >> 2));
     if (e != hipSuccess) { set_error("mnc_proposal: hipMalloc(%zu) failed", need); return MNC_ERR_NOMEM; }
     st->bytes = need + (need >> 2);

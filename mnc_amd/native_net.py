@@ -164,6 +164,12 @@ class NativeNet(object):
     def sync(self):
         _lib.call("mnc_ctx_sync", self._ctx.h)
 
+    def arena_generation(self):
+        """How often the context re-allocated one of its internal device arenas (a captured graph is dropped when it moves)."""
+        g = ctypes.c_ulong(0)
+        _lib.call("mnc_ctx_arena_generation", self._ctx.h, ctypes.addressof(g))
+        return int(g.value)
+
     def close(self):
         if getattr(self, "h", None):
             _lib.call("mnc_net_destroy", self.h)

@@ -28,6 +28,43 @@ def test_library_exports_every_declared_symbol():
     assert lib.mnc_version().startswith(b"mnc_hip")
 
 
+REF_NMS_DIR = "/root/reference/lib/nms"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_ref_binding_program(exe):
+    """tests/c/ref_binding_main.cpp -> exe: a C++ TU that knows `_nms` / `_mv` only from the reference's headers (the real ones when
+    /root/reference is mounted, their two declarations verbatim otherwise), linked against libmnc_hip.so."""
+    cmd = ["g++", "-O1", "-std=c++11", os.path.join(REPO, "tests", "c", "ref_binding_main.cpp"), "-o", exe,
+           "-L", os.path.join(REPO, "mnc_amd"), "-lmnc_hip", "-Wl,-rpath," + os.path.join(REPO, "mnc_amd"),
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    if os.path.isfile(os.path.join(REF_NMS_DIR, "gpu_nms.hpp")) and os.path.isfile(os.path.join(REF_NMS_DIR, "gpu_mv.hpp")):
+        cmd += ["-DMNC_REF_HEADERS", "-I", REF_NMS_DIR]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, "the reference's C++ binding does not link against libmnc_hip.so:\n" + r.stderr
+    return exe
+
+
+def test_reference_cxx_binding_links(tmp_path):
+    """b1/b2 at link level: the reference's extensions are C++ (lib/setup.py:126-130, 143-147 language='c++';
+    gpu_nms.pyx:13-14, gpu_mv.pyx:7-8 `cdef extern from "gpu_nms.hpp"`), so they import the MANGLED names -- the ones
+    oracle/_ref/libmnc_ref.so (the reference's own .cu files) exports.  libmnc_hip.so must export the same two."""
+    _lib.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    want = {"_Z4_nmsPiS_PKfiifi", "_Z3_mvPKfS0_iPKiS2_S0_iiiiiiPfPii"}
+    assert want <= exported
+    ref_so = os.path.join(REPO, "oracle", "_ref", "libmnc_ref.so")
+    if os.path.isfile(ref_so):          # what the reference's own sources export under the same compiler ABI
+        ref = subprocess.run(["nm", "-D", "--defined-only", ref_so], capture_output=True, text=True).stdout
+        assert want <= {l.split()[-1] for l in ref.splitlines() if " T " in l}
+    exe = build_ref_binding_program(str(tmp_path / "ref_binding_main"))
+    und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert "_Z4_nmsPiS_PKfiifi" in und and "_Z3_mvPKfS0_iPKiS2_S0_iiiiiiPfPii" in und      # bound to the mangled exports
+    r = subprocess.run([exe, "link"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "_nms 0x" in r.stdout, r.stdout + r.stderr
+
+
 def test_reference_signatures_are_kept():
     """b1/b2: `_nms` (gpu_nms.hpp:1-2) has 7 parameters, `_mv` (gpu_mv.hpp:1-4) has 15, in the reference's order."""
     d = _lib.parse_header()

@@ -44,6 +44,63 @@ def test_nms_bitmask_words(n, thr, seed):
     assert not mask[~upper].any()
 
 
+def test_reference_cxx_binding_runs(golden, tmp_path):
+    """b1/b2 as the reference binds them: a C++ program that sees `_nms` / `_mv` only through the reference's headers
+    (tests/c/ref_binding_main.cpp), linked to the mangled exports of libmnc_hip.so, fed the fixture inputs through files --
+    keep lists and voted masks / boxes equal the reference-generated fixtures."""
+    import subprocess
+    from test_abi_cpu import build_ref_binding_program
+    exe = build_ref_binding_program(str(tmp_path / "ref_binding_main"))
+    for n, thr, seed in GI.NMS_CASES:
+        dets = GI.nms_case(n, seed)
+        srt, order = _sorted(dets)
+        srt.tofile(str(tmp_path / "dets.f32"))
+        subprocess.run([exe, "nms", str(tmp_path / "dets.f32"), str(n), repr(float(thr)), str(tmp_path / "keep.i32")], check=True,
+                       timeout=300)
+        out = np.fromfile(str(tmp_path / "keep.i32"), np.int32)
+        assert out[0] == len(out) - 1
+        want = golden["nms_%d_%s_keep" % (n, str(thr).replace(".", "p"))]
+        assert np.array_equal(order[out[1:]], want)             # gpu_nms.pyx:31 maps sorted positions back through `order`
+    mc = GI.mv_case(8)
+    d = tmp_path / "mv"
+    d.mkdir()
+    boxes = np.ascontiguousarray(mc["boxes"][:, :4], np.float32)
+    for name, a, t in (("boxes.f32", boxes, np.float32), ("masks.f32", mc["masks"], np.float32), ("wts.f32", mc["weights"], np.float32),
+                       ("inds.i32", mc["inds"], np.int32), ("start.i32", mc["start"], np.int32)):
+        np.ascontiguousarray(a, t).tofile(str(d / name))
+    S = mc["masks"].shape[-1]
+    R = len(mc["start"])
+    subprocess.run([exe, "mv", str(d), str(len(boxes)), str(len(mc["inds"])), str(R), str(mc["H"]), str(mc["W"]), str(S)], check=True,
+                   timeout=300)
+    assert np.array_equal(np.fromfile(str(d / "out_box.i32"), np.int32).reshape(R, 4), golden["mv_box"])
+    assert np.array_equal(np.fromfile(str(d / "out_mask.f32"), np.float32).reshape(golden["mv_mask"].shape), golden["mv_mask"])
+
+
+def test_reference_cython_extensions_on_libmnc_hip(golden):
+    """The reference's OWN extension modules -- lib/nms/gpu_nms.pyx and gpu_mv.pyx cythonized as C++ against the reference's
+    gpu_nms.hpp / gpu_mv.hpp and linked with -lmnc_hip instead of the two .cu files (oracle/build_ref_ext.py; INTEGRATION.md A,
+    executed where /root/reference is mounted, prebuilt modules travel here) -- called on the fixture inputs: the reference's
+    Python-visible results, produced by the HIP kernels."""
+    import importlib
+    import os
+    import sys
+    ext = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ext")
+    if not (os.path.isfile(os.path.join(ext, "gpu_nms.so")) and os.path.isfile(os.path.join(ext, "gpu_mv.so"))):
+        pytest.skip("oracle/_ref/ext not built (needs /root/reference + Cython at build time)")
+    sys.path.insert(0, ext)
+    try:
+        ref_nms = importlib.import_module("gpu_nms")
+        ref_mv = importlib.import_module("gpu_mv")
+    finally:
+        sys.path.remove(ext)
+    for n, thr, seed in GI.NMS_CASES:
+        keep = ref_nms.gpu_nms(GI.nms_case(n, seed), float(thr), 0)
+        assert np.array_equal(np.array(keep, np.int64), golden["nms_%d_%s_keep" % (n, str(thr).replace(".", "p"))])
+    mc = GI.mv_case(8)
+    rm, rb = ref_mv.mv(mc["boxes"], mc["masks"], mc["inds"], mc["start"], mc["weights"], mc["H"], mc["W"], 0)
+    assert np.array_equal(rb, golden["mv_box"]) and np.array_equal(rm, golden["mv_mask"])
+
+
 def test_nms_topk_prefix_and_edges():
     dets, _ = _sorted(GI.nms_case(6000, 41))
     keep = np.zeros(6000, np.int32)

@@ -117,6 +117,32 @@ def test_native_pipeline_full_size_vgg16(math):
         net.close()
 
 
+def test_graph_is_dropped_when_a_context_arena_moves():
+    """A, A (graph captured), B (seen once: runs eagerly), A again.  With full VGG widths the Winograd tail plan's split-K scratch
+    is not monotonic in the image size (net input 600x898 needs less than the SMALLER 562x1000), so B re-allocates the context's
+    scratch arena while every net buffer still fits its head-room: the graph captured for A holds the freed address and must not
+    be replayed.  Every call equals a net that never uses a graph."""
+    path = models.write_mnc_5stage_test_prototxt()
+    w = synth.synthetic_weights(path, seed=0)
+    ref = NativeNet(w, use_graph=False)
+    nat = NativeNet(w, use_graph=True)
+    try:
+        rng = np.random.default_rng(21)
+        gens = []
+        for (H, W) in ((334, 500), (334, 500), (281, 500), (334, 500), (334, 500), (334, 500)):
+            im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            c0, r0 = ref.forward_image(im)
+            c1, r1 = nat.forward_image(im)
+            assert np.array_equal(c0, c1) and np.array_equal(r0, r1, equal_nan=True), (H, W, len(gens))
+            gens.append(nat.arena_generation())
+        assert gens[0] == gens[1], "the second image of a size must not move an arena (it is the captured one)"
+        assert gens[2] > gens[1], "this test needs B to grow a context arena after A's graph was captured: %r" % (gens,)
+        assert gens[3] == gens[4] == gens[5] == gens[2]
+    finally:
+        nat.close()
+        ref.close()
+
+
 def test_two_images_in_flight_equal_one_at_a_time():
     """mnc_forward_image_async / mnc_net_fetch: two nets (own context, stream, buffers), image k+1 launched before image k is
     fetched -- overlapping independent images on the GPU changes nothing in any result."""
