@@ -199,7 +199,7 @@ def main():
             if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks, same stream
                 gatherer.gather_block(net.block() if native else blk)
                 t_d = time.perf_counter()
-                last["gathered"] = gatherer.fetch()                 # [world, 100, 447] on the host
+                last["gathered"] = gatherer.fetch(rows=int(counts[0]) if native else None)   # [world, 100, 447] on the host
             elif gatherer is not None:                              # gloo functional path (host tensors)
                 lists = split_records(rec, counts[1:], 21) if native else blk.lists()
                 packed, _ = mdist.pack_instances(*lists)

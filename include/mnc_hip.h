@@ -149,6 +149,29 @@ MNC_API int mnc_ctx_device(const mnc_ctx* ctx, int* device_id);
  * since the capture; a caller that captures library launches into its own graph must do the same. */
 MNC_API int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation);
 
+/* Conventions of the three Caffe layers whose source (caffe-mnc) is not available: ROIWarping, MaskResize, MaskPooling
+ * (models/VGG16/mnc_5stage/test.prototxt:479-492, 558-567, 631-637, 809-820).  Every SPEC-CHOICE of oracle/SPEC.md is a field;
+ * all fields zero (maskpool_thresh unused) IS the SPEC and the default of every context -- PARITY UNPINNED either way.  A user who
+ * can read caffe-mnc (or holds the published mnc_model.caffemodel.h5 and an image with known output) selects the matching
+ * convention here / in mnc_net_config / with `caffe.Net(..., layer_conventions={...})` / cfg.LAYER_CONVENTIONS; nothing is
+ * recompiled.  The CPU oracle evaluates the same switches (oracle/mnc_oracle.c: orc_roi_warp_ex, orc_mask_resize_ex,
+ * orc_mask_pool_ex), bit for bit; oracle/SPEC.md section 6 tabulates how far each alternative moves the outputs.
+ * Read by mnc_roi_warp[_sm], mnc_mask_resize, mnc_mask_pool[_sm], mnc_box_mask_pool at launch time. */
+typedef struct mnc_layer_conventions {
+  int warp_sample;       /* ROIWarping sample position in bin g: 0 x1s + g*bin (top-left, SPEC) | 1 x1s + (g+0.5)*bin (bin centre)
+                          * | 2 x1s + (g+0.5)*bin - 0.5 (bin centre, pixel-centre coordinates) */
+  int warp_round_edges;  /* 0 scaled RoI edges un-rounded (SPEC) | 1 floor(x*scale + 0.5), as ROIPooling */
+  int warp_no_plus_one;  /* 0 roi_w = max(x2s - x1s + 1, 1) (SPEC) | 1 roi_w = max(x2s - x1s, 1) */
+  int warp_oob;          /* 0 bilinear taps outside the map contribute 0 (SPEC) | 1 taps clamped to the border */
+  int resize_mode;       /* MaskResize source position: 0 dst*in/out, nearest on the last row/column (mv_kernel.cu:193-240, SPEC)
+                          * | 1 (dst+0.5)*in/out - 0.5 (half-pixel centres) | 2 dst*(in-1)/(out-1) (align_corners) */
+  int maskpool_binary;   /* MaskPooling: 0 feature * continuous mask (SPEC) | 1 feature * (mask >= maskpool_thresh) */
+  float maskpool_thresh; /* 0.4 = cfg.BINARIZE_THRESH */
+  int reserved;          /* 0 */
+} mnc_layer_conventions;
+MNC_API int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventions* conv);   /* NULL: back to the SPEC */
+MNC_API int mnc_ctx_get_layer_conventions(const mnc_ctx* ctx, mnc_layer_conventions* conv);
+
 /* Device memory for the host-side executor (the caffe-shaped Net keeps its blobs here). */
 MNC_API int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr);
 MNC_API int mnc_dev_free(mnc_ctx* ctx, void* d_ptr);
@@ -479,6 +502,7 @@ typedef struct mnc_net_config {
   int math;                /* 0 fp32, 1 bf16x3, 2 f16 (the engine's math modes) */
   int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
   int winograd;            /* fp32 math: 1 = 3x3 convolutions by Winograd F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */
+  mnc_layer_conventions conventions;   /* ROIWarping / MaskResize / MaskPooling conventions; all zero = oracle/SPEC.md */
 } mnc_net_config;
 
 /* The reference's values for every field (VGG-16 widths, lib/mnc_config.py defaults). */

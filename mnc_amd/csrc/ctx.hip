@@ -138,6 +138,27 @@ int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation) {
   return MNC_OK;
 }
 
+int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventions* conv) {
+  MNC_REQUIRE(ctx, "mnc_ctx_set_layer_conventions: null context");
+  const mnc_layer_conventions spec = {0, 0, 0, 0, 0, 0, 0.4f, 0};
+  const mnc_layer_conventions c = conv ? *conv : spec;
+  MNC_REQUIRE(c.warp_sample >= 0 && c.warp_sample <= 2, "layer conventions: warp_sample %d not in {0,1,2}", c.warp_sample);
+  MNC_REQUIRE(c.resize_mode >= 0 && c.resize_mode <= 2, "layer conventions: resize_mode %d not in {0,1,2}", c.resize_mode);
+  MNC_REQUIRE((c.warp_round_edges | 1) == 1 && (c.warp_no_plus_one | 1) == 1 && (c.warp_oob | 1) == 1 && (c.maskpool_binary | 1) == 1,
+              "layer conventions: warp_round_edges / warp_no_plus_one / warp_oob / maskpool_binary are 0 or 1");
+  MNC_REQUIRE(c.maskpool_thresh == c.maskpool_thresh, "layer conventions: maskpool_thresh is NaN");
+  ctx->conv = c;
+  ctx->conv.reserved = 0;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_ctx_get_layer_conventions(const mnc_ctx* ctx, mnc_layer_conventions* conv) {
+  MNC_REQUIRE(ctx && conv, "mnc_ctx_get_layer_conventions: null pointer");
+  *conv = ctx->conv;
+  return MNC_OK;
+}
+
 int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr) {
   MNC_REQUIRE(ctx && d_ptr, "mnc_dev_alloc: null pointer");
   *d_ptr = nullptr;

@@ -41,6 +41,8 @@ struct mnc_ctx {
   // HIP graph holds their raw addresses, so a graph owner (pipeline.hip) records the value at capture and drops its graph when
   // the value has moved on.
   unsigned long arena_gen = 0;
+  // conventions of the three Caffe layers whose source is unavailable (all zero = oracle/SPEC.md); read by roi.hip's launchers
+  mnc_layer_conventions conv = {0, 0, 0, 0, 0, 0, 0.4f, 0};
 };
 
 namespace mnc {

@@ -644,6 +644,7 @@ int mnc_net_default_config(mnc_net_config* cfg) {
   cfg->math = 0;
   cfg->use_graph = 1;
   cfg->winograd = 1;
+  cfg->conventions.maskpool_thresh = 0.4f;         // every switch 0: oracle/SPEC.md
   clear_error();
   return MNC_OK;
 }
@@ -664,12 +665,17 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   MNC_REQUIRE(cfg->num_classes <= 64, "mnc_net_create: num_classes %d > 64 (the result header holds 64 counts)", cfg->num_classes);
   MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 2, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3) or 2 (f16)");
   MNC_REQUIRE(cfg->target_size > 0 && cfg->max_size >= cfg->target_size, "mnc_net_create: target_size / max_size");
+  {
+    int rc = mnc_ctx_set_layer_conventions(ctx, &cfg->conventions);      // validated; the RoI launchers read them from the context
+    if (rc) return rc;
+  }
   mnc_net* n = new (std::nothrow) mnc_net();
   if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
   n->ctx = ctx;
   n->cfg = *cfg;
   if (getenv("MNC_BRANCH_STREAMS") && atoi(getenv("MNC_BRANCH_STREAMS")) == 1) {
     if (mnc_ctx_create(&n->ctx_b, ctx->device) != MNC_OK) n->ctx_b = nullptr;     // optional: the net works on one stream
+    if (n->ctx_b) (void)mnc_ctx_set_layer_conventions(n->ctx_b, &cfg->conventions);
     for (int i = 0; i < 2 && n->ctx_b; ++i) {
       if (hipEventCreateWithFlags(&n->ev_fork[i], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&n->ev_join[i], hipEventDisableTiming) != hipSuccess) {

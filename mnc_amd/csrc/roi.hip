@@ -97,6 +97,76 @@ __global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__
   }
 }
 
+// ---- ROIWarping with the SPEC-CHOICEs as run-time switches (mnc_layer_conventions, include/mnc_hip.h; oracle/SPEC.md section 6) ----
+// The kernels above and the wave kernels below are the SPEC's conventions compiled in.  When a context carries any other
+// convention the launcher takes this kernel instead: same thread mapping as roi_warp_kernel, the edge rounding, width rule,
+// sample position inside the bin and border rule evaluated from the struct, in oracle/mnc_oracle.c:orc_roi_warp_ex's operation
+// order (bit-exact with it for every combination, tests/test_gpu_ops.py).  Untuned on purpose: it exists so that swapping a
+// convention is configuration the day the caffe-mnc source can be read; the chosen one then moves into the tuned kernels.
+__device__ __forceinline__ float warp_coord(float lo, float bin, int g, int sample) {
+  return sample == 0 ? lo + (float)g * bin : sample == 1 ? lo + ((float)g + 0.5f) * bin : lo + ((float)g + 0.5f) * bin - 0.5f;
+}
+
+__device__ __forceinline__ float4 warp_sample_conv(const float* __restrict__ px, int H, int W, int C, float sx, float sy, int oob) {
+  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  const float ax = sx - (float)x0, ay = sy - (float)y0;
+  const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
+  bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+  bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  int ya = y0, yb = y0 + 1, xa = x0, xb = x0 + 1;
+  if (oob) {                                   // taps clamped to the border instead of contributing 0
+    ya = min(max(ya, 0), H - 1); yb = min(max(yb, 0), H - 1);
+    xa = min(max(xa, 0), W - 1); xb = min(max(xb, 0), W - 1);
+    vy0 = vy1 = vx0 = vx1 = true;
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 a00 = (vy0 && vx0) ? ld4(px + ((long)ya * W + xa) * C) : z;
+  const float4 a01 = (vy0 && vx1) ? ld4(px + ((long)ya * W + xb) * C) : z;
+  const float4 a10 = (vy1 && vx0) ? ld4(px + ((long)yb * W + xa) * C) : z;
+  const float4 a11 = (vy1 && vx1) ? ld4(px + ((long)yb * W + xb) * C) : z;
+#define MNC_BL(f) (w00 * a00.f + w01 * a01.f + w10 * a10.f + w11 * a11.f)
+  return make_float4(MNC_BL(x), MNC_BL(y), MNC_BL(z), MNC_BL(w));
+#undef MNC_BL
+}
+
+template <int POOL2, int SM>
+__global__ __launch_bounds__(256) void roi_warp_conv_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
+                                                            const float* __restrict__ rois, int R, int PH, int PW, float scale,
+                                                            mnc_layer_conventions cv, float* __restrict__ out,
+                                                            void* __restrict__ sm) {
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned total = (unsigned)R * PH * PW * C4;
+  const int GH = POOL2 ? 2 * PH : PH, GW = POOL2 ? 2 * PW : PW;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    unsigned t = idx / C4;
+    const int pw = (int)(t % (unsigned)PW);
+    t /= (unsigned)PW;
+    const int ph = (int)(t % (unsigned)PH);
+    const int r = (int)(t / (unsigned)PH);
+    const float* roi = rois + (long)r * 5;
+    float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
+    if (cv.warp_round_edges) { x1s = floorf(x1s + 0.5f); y1s = floorf(y1s + 0.5f); x2s = floorf(x2s + 0.5f); y2s = floorf(y2s + 0.5f); }
+    const float extra = cv.warp_no_plus_one ? 0.0f : 1.0f;
+    const float rw = fmaxf(x2s - x1s + extra, 1.0f), rh = fmaxf(y2s - y1s + extra, 1.0f);
+    const float bw = rw / (float)GW, bh = rh / (float)GH;
+    const float* px = feat_hwc + c4 * 4;
+    float4 o;
+    if (POOL2) {
+      const float xa = warp_coord(x1s, bw, 2 * pw, cv.warp_sample), xb = warp_coord(x1s, bw, 2 * pw + 1, cv.warp_sample);
+      const float ya = warp_coord(y1s, bh, 2 * ph, cv.warp_sample), yb = warp_coord(y1s, bh, 2 * ph + 1, cv.warp_sample);
+      o = warp_sample_conv(px, H, W, C, xa, ya, cv.warp_oob);
+      o = max4(o, warp_sample_conv(px, H, W, C, xb, ya, cv.warp_oob));
+      o = max4(o, warp_sample_conv(px, H, W, C, xa, yb, cv.warp_oob));
+      o = max4(o, warp_sample_conv(px, H, W, C, xb, yb, cv.warp_oob));
+    } else {
+      o = warp_sample_conv(px, H, W, C, warp_coord(x1s, bw, pw, cv.warp_sample), warp_coord(y1s, bh, ph, cv.warp_sample), cv.warp_oob);
+    }
+    *reinterpret_cast<float4*>(out + (long)idx * 4) = o;
+    if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
+  }
+}
+
 // [R][PH][PW][C] -> [R][PH/2][PW/2][C], MAX 2x2/2 (PH, PW even on this path: 28->14, 14->7)
 template <int SM>
 __global__ __launch_bounds__(256) void maxpool2_rhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
@@ -119,33 +189,50 @@ __global__ __launch_bounds__(256) void maxpool2_rhwc_kernel(const float* __restr
   }
 }
 
-// SPEC-CHOICE (SPEC.md 2): ratio = in/out, source = dst*ratio (top-left aligned), floor + bilinear, nearest on the last
-// source row/column -- the author's own convention in lib/nms/mv_kernel.cu:193-240.
+// SPEC-CHOICE (SPEC.md 2; mode 0): ratio = in/out, source = dst*ratio (top-left aligned), floor + bilinear, nearest on the last
+// source row/column -- the author's own convention in lib/nms/mv_kernel.cu:193-240.  mode 1 (half-pixel centres) / 2
+// (align_corners): the alternatives of mnc_layer_conventions, as oracle/mnc_oracle.c:orc_mask_resize_ex evaluates them.
 __global__ void mask_resize_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int IH, int IW, int OH,
-                                   int OW) {
+                                   int OW, int mode) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * OH * OW) return;
   const int w = idx % OW, h = (idx / OW) % OH, r = idx / (OW * OH);
   const float rh = (float)IH / (float)OH, rw = (float)IW / (float)OW;
-  const float ix = (float)w * rw, iy = (float)h * rh;
-  const int sx = (int)floorf(ix), sy = (int)floorf(iy);
   const float* m = in + (long)r * IH * IW;
   float v;
-  if (sx == IW - 1 || sy == IH - 1) {
-    v = m[sy * IW + sx];
+  if (mode == 0) {
+    const float ix = (float)w * rw, iy = (float)h * rh;
+    const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+    if (sx == IW - 1 || sy == IH - 1) {
+      v = m[sy * IW + sx];
+    } else {
+      const float fx = ix - (float)sx, fy = iy - (float)sy;
+      v = (1.0f - fx) * (1.0f - fy) * m[sy * IW + sx] + fx * (1.0f - fy) * m[sy * IW + sx + 1] +
+          (1.0f - fx) * fy * m[(sy + 1) * IW + sx] + fx * fy * m[(sy + 1) * IW + sx + 1];
+    }
   } else {
+    const float ah = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.0f, aw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.0f;
+    float ix = mode == 1 ? ((float)w + 0.5f) * rw - 0.5f : (float)w * aw;
+    float iy = mode == 1 ? ((float)h + 0.5f) * rh - 0.5f : (float)h * ah;
+    ix = fminf(fmaxf(ix, 0.0f), (float)(IW - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(IH - 1));
+    const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+    const int tx = min(sx + 1, IW - 1), ty = min(sy + 1, IH - 1);
     const float fx = ix - (float)sx, fy = iy - (float)sy;
-    v = (1.0f - fx) * (1.0f - fy) * m[sy * IW + sx] + fx * (1.0f - fy) * m[sy * IW + sx + 1] +
-        (1.0f - fx) * fy * m[(sy + 1) * IW + sx] + fx * fy * m[(sy + 1) * IW + sx + 1];
+    v = (1.0f - fx) * (1.0f - fy) * m[sy * IW + sx] + fx * (1.0f - fy) * m[sy * IW + tx] +
+        (1.0f - fx) * fy * m[ty * IW + sx] + fx * fy * m[ty * IW + tx];
   }
   out[idx] = v;
 }
 
 // SPEC-CHOICE (SPEC.md 3): feature * continuous mask, broadcast over channels; POOL2 fuses the MAX 2x2/2 that follows.
+// bin_on (mnc_layer_conventions::maskpool_binary): the alternative -- the mask is binarised first, m >= bin_thr ? 1 : 0.
+__device__ __forceinline__ float mask_value(float m, int bin_on, float bin_thr) { return bin_on ? (m >= bin_thr ? 1.0f : 0.0f) : m; }
+
 template <int POOL2, int SM>
 __global__ __launch_bounds__(256) void mask_pool_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
                                                         float* __restrict__ out, int R, int PH, int PW, int C4,
-                                                        void* __restrict__ sm) {
+                                                        void* __restrict__ sm, int bin_on, float bin_thr) {
   const int OH = POOL2 ? PH / 2 : PH, OW = POOL2 ? PW / 2 : PW;
   const unsigned total = (unsigned)R * OH * OW * C4;              // < 2^31 (checked by the launcher): 32-bit divisions
   for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -156,7 +243,7 @@ __global__ __launch_bounds__(256) void mask_pool_kernel(const float* __restrict_
     const int oh = (int)(t % (unsigned)OH);
     const long r = t / (unsigned)OH;
     auto prod = [&](int h, int w) {
-      const float mk = mask[(r * PH + h) * PW + w];
+      const float mk = mask_value(mask[(r * PH + h) * PW + w], bin_on, bin_thr);
       const float4 f = ld4(feat + (((r * PH + h) * PW + w) * C4 + c4) * 4);
       return make_float4(f.x * mk, f.y * mk, f.z * mk, f.w * mk);
     };
@@ -387,7 +474,7 @@ __global__ __launch_bounds__(256) void maxpool2_rhwc8_kernel(const float* __rest
 template <int POOL2, int SM>
 __global__ __launch_bounds__(256) void mask_pool8_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
                                                          float* __restrict__ out, int R, int PH, int PW, int C8,
-                                                         void* __restrict__ sm) {
+                                                         void* __restrict__ sm, int bin_on, float bin_thr) {
   const int OH = POOL2 ? PH / 2 : PH, OW = POOL2 ? PW / 2 : PW;
   const unsigned total = (unsigned)R * OH * OW * C8;
   for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -401,7 +488,7 @@ __global__ __launch_bounds__(256) void mask_pool8_kernel(const float* __restrict
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       auto prod = [&](int y, int x) {
-        const float mk = mask[(r * PH + y) * PW + x];
+        const float mk = mask_value(mask[(r * PH + y) * PW + x], bin_on, bin_thr);
         const float4 f = ld4(feat + (((r * PH + y) * PW + x) * C8 + c8) * 8 + h * 4);
         return make_float4(f.x * mk, f.y * mk, f.z * mk, f.w * mk);
       };
@@ -426,7 +513,7 @@ template <int SM, int NV>
 __global__ __launch_bounds__(256) void box_mask_pool_kernel(const float* __restrict__ feat, const float* __restrict__ mask,
                                                             float* __restrict__ out_box, float* __restrict__ out_mask, int R,
                                                             int PH, int PW, int CV, void* __restrict__ sm_box,
-                                                            void* __restrict__ sm_mask) {
+                                                            void* __restrict__ sm_mask, int bin_on, float bin_thr) {
   const int OH = PH / 2, OW = PW / 2;
   const unsigned total = (unsigned)R * OH * OW * CV;              // CV = channel groups of 4*NV; < 2^31: checked by the launcher
   for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -437,7 +524,8 @@ __global__ __launch_bounds__(256) void box_mask_pool_kernel(const float* __restr
     const int oh = (int)(t % (unsigned)OH);
     const long r = t / (unsigned)OH;
     const long m00 = (r * PH + 2 * oh) * PW + 2 * ow;               // window's first position in the [R][PH][PW] grids
-    const float k00 = mask[m00], k01 = mask[m00 + 1], k10 = mask[m00 + PW], k11 = mask[m00 + PW + 1];
+    const float k00 = mask_value(mask[m00], bin_on, bin_thr), k01 = mask_value(mask[m00 + 1], bin_on, bin_thr),
+                k10 = mask_value(mask[m00 + PW], bin_on, bin_thr), k11 = mask_value(mask[m00 + PW + 1], bin_on, bin_thr);
     float4 b[NV], v[NV];
 #pragma unroll
     for (int h = 0; h < NV; ++h) {
@@ -532,6 +620,16 @@ int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, cons
   // second output, 1000 RoIs x 1024 channels: 28x28+pool 452 us against 629 / 680 for the 4- / 8-channels-per-thread kernels,
   // 14x14 407 against 520 / 430; fp32 only, 300 RoIs x 512 channels: 28x28+pool 61 against 68, 14x14 44 against 32 (so the
   // 4-channels-per-thread kernel keeps that case).  MNC_ROI_WARP_VARIANT = 1 (wave) / 4 / 8 forces one.
+  if (ctx->conv.warp_sample || ctx->conv.warp_round_edges || ctx->conv.warp_no_plus_one || ctx->conv.warp_oob) {
+    // a convention other than the SPEC's: the generic kernel (see roi_warp_conv_kernel)
+#define MNC_WARPC(P2, SM)                                                                                                       \
+  hipLaunchKernelGGL((roi_warp_conv_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, \
+                     PW, scale, ctx->conv, d_out, d_sm)
+    if (pool2) { if (sm_fmt == 1) MNC_WARPC(1, 1); else if (sm_fmt == 2) MNC_WARPC(1, 2); else MNC_WARPC(1, 0); }
+    else { if (sm_fmt == 1) MNC_WARPC(0, 1); else if (sm_fmt == 2) MNC_WARPC(0, 2); else MNC_WARPC(0, 0); }
+#undef MNC_WARPC
+    return ls.finish("roi_warp_conv_kernel");
+  }
   const char* variant = getenv("MNC_ROI_WARP_VARIANT");
   const int vsel = variant ? atoi(variant) : ((pool2 || C >= 1024) ? 1 : 4);
   if (vsel != 4 && vsel != 8) {
@@ -659,7 +757,7 @@ int mnc_mask_resize(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int IH
   if (R == 0) return MNC_OK;
   LaunchScope ls(ctx, "mask_resize");
   hipLaunchKernelGGL(mask_resize_kernel, dim3(cdiv((long)R * OH * OW, 256)), dim3(256), 0, ctx->stream, d_in, d_out, R, IH,
-                     IW, OH, OW);
+                     IW, OH, OW, ctx->conv.resize_mode);
   return ls.finish("mask_resize_kernel");
 }
 
@@ -679,7 +777,7 @@ int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, flo
   if (sm_fmt && sm_variant8(false)) {
 #define MNC_MP8(P2, SM)                                                                                                     \
   hipLaunchKernelGGL((mask_pool8_kernel<P2, SM>), dim3(grid_for(total / 2)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, \
-                     PH, PW, C / 8, d_sm)
+                     PH, PW, C / 8, d_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)
     if (pool2) { if (sm_fmt == 1) MNC_MP8(1, 1); else MNC_MP8(1, 2); }
     else { if (sm_fmt == 1) MNC_MP8(0, 1); else MNC_MP8(0, 2); }
 #undef MNC_MP8
@@ -687,7 +785,7 @@ int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, flo
   }
 #define MNC_MP(P2, SM)                                                                                                  \
   hipLaunchKernelGGL((mask_pool_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, PH, \
-                     PW, C / 4, d_sm)
+                     PW, C / 4, d_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)
   if (pool2) { if (sm_fmt == 1) MNC_MP(1, 1); else if (sm_fmt == 2) MNC_MP(1, 2); else MNC_MP(1, 0); }
   else { if (sm_fmt == 1) MNC_MP(0, 1); else if (sm_fmt == 2) MNC_MP(0, 2); else MNC_MP(0, 0); }
 #undef MNC_MP
@@ -713,13 +811,13 @@ int mnc_box_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, fl
   LaunchScope ls(ctx, "box_mask_pool", 0.0, 4.0 * R * (double)C * (PH * PW + 2.0 * OH * OW));
   if (sm_fmt == 1)
     hipLaunchKernelGGL((box_mask_pool_kernel<1, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
-                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm);
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);
   else if (sm_fmt == 2)
     hipLaunchKernelGGL((box_mask_pool_kernel<2, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
-                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm);
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);
   else
     hipLaunchKernelGGL((box_mask_pool_kernel<0, 1>), dim3(grid_for((long)R * OH * OW * (C / 4))), dim3(256), 0, ctx->stream, d_feat,
-                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 4, d_box_sm, d_mask_sm);
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 4, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);
   return ls.finish("box_mask_pool_kernel");
 }
 

@@ -106,11 +106,21 @@ class InstanceGatherer(object):
             raise ValueError("block shape [%d,%d] does not match the gatherer's [%d,%d]"
                              % (block.gather_rows, block.rec_dim, self.cap, REC_DIM))
         self._lib.call("mnc_gather_instances", self.net._ctx.h, block.records_ptr, self._recv.ptr, self.cap * REC_DIM)
+        self._sent = block
 
-    def fetch(self):
-        """Device transport: the gathered [world, cap, 447] blocks as one numpy array (one copy, one synchronisation)."""
+    def fetch(self, rows=None):
+        """Device transport: the gathered [world, cap, 447] blocks as one numpy array (one copy, one synchronisation).
+        Truncation is reported, as pack_instances does on the host path: `rows` = this rank's instance count when the caller
+        already has it (mnc_net_fetch's counts[0]); otherwise the sent block's 256-byte head is read after the gather."""
         out = np.zeros((self.world, self.cap, REC_DIM), np.float32)
         self._lib.call("mnc_d2h", self.net._ctx.h, self._lib.ptr(out), self._recv.ptr, out.nbytes)
+        blk, self._sent = getattr(self, "_sent", None), None
+        if rows is None and blk is not None and hasattr(blk, "head"):
+            rows = int(blk.head()[0])
+        if rows is not None and rows > self.cap:
+            import warnings
+            warnings.warn("gather_block: rank %d has %d instances (scores tied at the voting threshold), the gathered block holds "
+                          "%d -- %d dropped" % (self.rank, rows, self.cap, rows - self.cap))
         return out
 
     def gather(self, rec):

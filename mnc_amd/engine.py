@@ -359,7 +359,7 @@ class Net(object):
     supports_partial_forward = True      # forward(start=..., end=...) re-uses the blobs of the previous call
 
     def __init__(self, prototxt_path, weights, phase=1, device_id=None, fuse=None, native_pylayers=None, math=None,
-                 winograd=None):
+                 winograd=None, layer_conventions=None):
         if device_id is None:
             try:
                 import caffe
@@ -393,6 +393,18 @@ class Net(object):
         self._speculated = None
         self._running = 0
         self._ctx = _Ctx(device_id)
+        # ROIWarping / MaskResize / MaskPooling conventions (include/mnc_hip.h: mnc_layer_conventions; oracle/SPEC.md section 6):
+        # layer_conventions= {field: value}, else cfg.LAYER_CONVENTIONS (lib/mnc_config.py); {} = the SPEC.  Set on the context:
+        # the RoI kernels' launchers read them there.
+        if layer_conventions is None:
+            try:
+                from mnc_config import cfg as _cfg
+                layer_conventions = dict(_cfg.get("LAYER_CONVENTIONS", {}) or {})
+            except ImportError:
+                layer_conventions = {}
+        from .native_net import LayerConventions
+        self.layer_conventions = LayerConventions.make(layer_conventions)
+        _lib.call("mnc_ctx_set_layer_conventions", self._ctx.h, ctypes.addressof(self.layer_conventions))
         self._tmp = _DevBuf(self._ctx)
         self._net_msg = prototxt.parse_file(prototxt_path)
         self._layers = [_Layer(m) for m in self._net_msg.all("layer")]
@@ -1494,8 +1506,9 @@ class Net(object):
 
     def vote_instances(self, boxes, masks, scores, num_classes, max_per_image, im_width, im_height, nms_thresh, iou_thresh):
         """gpu_mask_voting (lib/transform/mask_transform.py:213-286) on this net's own device-resident results (the DeviceArrays
-        of detect_tail), asynchronously on the net's stream: -> InstanceBlock (mnc_amd/instances.py) whose records stay on the
-        GPU until .fetch() / .lists() copies them down (one copy, one synchronisation) or the multi-GPU gather sends them."""
+        of detect_tail), asynchronously on the net's stream: -> a view of the net's InstanceBlock (mnc_amd/instances.py) whose
+        records stay on the GPU until .fetch() / .lists() copies them down (one copy, one synchronisation) or the multi-GPU gather
+        sends them.  The buffer is reused by the next image: a view that was never copied refuses to read another image's rows."""
         from .instances import InstanceBlock
         n, S = boxes.shape[0], masks.shape[-1]
         blk = getattr(self, "_inst", None)
@@ -1507,7 +1520,7 @@ class Net(object):
         _lib.call("mnc_vote_instances", self._ctx.h, boxes.ptr, masks.ptr, scores.ptr, n, int(num_classes), S, int(max_per_image),
                   float(nms_thresh), float(iou_thresh), int(im_height), int(im_width), blk.records_ptr, blk.rows_cap,
                   blk.counts_ptr)
-        return blk
+        return blk.view()
 
     def _run_layers(self, start, stop=None):
         pre = getattr(self, "_pre_steps", {})

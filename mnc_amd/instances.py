@@ -26,6 +26,7 @@ class InstanceBlock(object):
         self._buf = _DevBuf(net._ctx)
         self.ptr = self._buf.ensure(HEAD_BYTES + self.rows_cap * self.rec_dim * 4)
         self._host = None
+        self.generation = 0            # bumped by invalidate(): every image voted into this buffer is one generation
 
     counts_ptr = property(lambda self: self.ptr)
     records_ptr = property(lambda self: self.ptr + HEAD_BYTES)
@@ -35,7 +36,22 @@ class InstanceBlock(object):
                 and self.rows_cap >= (num_classes - 1) * min(max_per_image, n))
 
     def invalidate(self):
+        """The buffer is about to receive another image's instances."""
         self._host = None
+        self.generation += 1
+
+    def view(self):
+        """What Net.vote_instances returns: this image's handle on the (reused) buffer.  It reads the device records lazily like
+        the block itself, keeps what it has copied, and refuses to hand out a LATER image's data (as DeviceArray.is_current)."""
+        return InstanceView(self)
+
+    def head(self):
+        """counts int32[num_classes] alone (a 256-byte copy; synchronises the net's stream)."""
+        if self._host is not None:
+            return self._host[0]
+        raw = np.zeros(HEAD_BYTES, np.uint8)
+        _lib.call("mnc_d2h", self._net._ctx.h, _lib.ptr(raw), self.ptr, HEAD_BYTES)
+        return raw[:self.num_classes * 4].view(np.int32).copy()
 
     def fetch(self):
         """-> (counts int32[num_classes], records float32[R, rec_dim]): ONE device-to-host copy of the head and the first
@@ -63,6 +79,44 @@ class InstanceBlock(object):
 
     def release(self):
         self._buf.release()
+
+
+class InstanceView(object):
+    """One image's instances in an InstanceBlock whose buffer later images reuse."""
+
+    def __init__(self, block):
+        self._blk = block
+        self._gen = block.generation
+        self._host = None
+        self.num_classes, self.S, self.rec_dim = block.num_classes, block.S, block.rec_dim
+        self.gather_rows, self.rows_cap = block.gather_rows, block.rows_cap
+
+    def is_current(self):
+        return self._blk.generation == self._gen
+
+    def _check(self):
+        if not self.is_current():
+            raise RuntimeError("this image's instance block has been reused by a later vote_instances (call .fetch() / .lists() "
+                               "before the next image if the results must outlive it)")
+
+    counts_ptr = property(lambda self: (self._check(), self._blk.counts_ptr)[1])
+    records_ptr = property(lambda self: (self._check(), self._blk.records_ptr)[1])
+
+    def fetch(self):
+        if self._host is None:
+            self._check()
+            self._host = self._blk.fetch()
+        return self._host
+
+    def head(self):
+        if self._host is not None:
+            return self._host[0]
+        self._check()
+        return self._blk.head()
+
+    def lists(self):
+        counts, rec = self.fetch()
+        return split_records(rec, counts[1:self.num_classes], self.S)
 
 
 def split_records(rec, class_counts, S):

@@ -42,6 +42,10 @@ cfg.ROOT_DIR = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..
 cfg.DATA_DIR = os.path.join(cfg.ROOT_DIR, "data")
 cfg.BINARIZE_THRESH = 0.4                   # mnc_config.py:26
 cfg.MASK_SIZE = 21                          # mnc_config.py:28
+# Not in the reference: which convention the three Caffe layers whose source is unavailable (ROIWarping, MaskResize, MaskPooling)
+# follow -- fields of `mnc_layer_conventions` (include/mnc_hip.h), e.g. LAYER_CONVENTIONS: {warp_sample: 2, resize_mode: 1} in an
+# experiment .yml.  Empty = oracle/SPEC.md (PARITY UNPINNED either way; SPEC.md section 6 lists the alternatives).
+cfg.LAYER_CONVENTIONS = AttrDict()
 
 # TRAIN: no training code exists in this package, but the reference's experiment files (experiments/cfgs/VGG16/*.yml) set
 # TRAIN keys next to the TEST ones and cfg_from_file rejects unknown keys (mnc_config.py:174-176) -- so every key of

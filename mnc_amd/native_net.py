@@ -17,6 +17,27 @@ LAYERS = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "con
           "fc6_mask", "fc7_mask", "cls_score", "seg_cls_score", "bbox_pred"]
 
 
+class LayerConventions(ctypes.Structure):
+    """Mirror of `mnc_layer_conventions` (include/mnc_hip.h): the SPEC-CHOICEs of ROIWarping / MaskResize / MaskPooling."""
+    _fields_ = [("warp_sample", ctypes.c_int), ("warp_round_edges", ctypes.c_int), ("warp_no_plus_one", ctypes.c_int),
+                ("warp_oob", ctypes.c_int), ("resize_mode", ctypes.c_int), ("maskpool_binary", ctypes.c_int),
+                ("maskpool_thresh", ctypes.c_float), ("reserved", ctypes.c_int)]
+
+    @classmethod
+    def make(cls, conv=None):
+        """dict {field: value} (None / {} = the SPEC) -> struct; unknown names raise."""
+        c = cls(0, 0, 0, 0, 0, 0, 0.4, 0)
+        for k, v in (conv or {}).items():
+            if k not in ("warp_sample", "warp_round_edges", "warp_no_plus_one", "warp_oob", "resize_mode", "maskpool_binary",
+                         "maskpool_thresh"):
+                raise KeyError("unknown layer convention %r" % k)
+            setattr(c, k, float(v) if k == "maskpool_thresh" else int(v))
+        return c
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 class NetConfig(ctypes.Structure):
     """Mirror of `mnc_net_config` (include/mnc_hip.h), field for field."""
     _fields_ = [("trunk_channels", ctypes.c_int * 5), ("rpn_channels", ctypes.c_int), ("num_anchors", ctypes.c_int),
@@ -26,7 +47,7 @@ class NetConfig(ctypes.Structure):
                 ("roi_size", ctypes.c_int), ("spatial_scale", ctypes.c_float), ("target_size", ctypes.c_int),
                 ("max_size", ctypes.c_int), ("pixel_means", ctypes.c_double * 3), ("max_per_image", ctypes.c_int),
                 ("vote_nms_thresh", ctypes.c_float), ("vote_iou_thresh", ctypes.c_float), ("math", ctypes.c_int),
-                ("use_graph", ctypes.c_int), ("winograd", ctypes.c_int)]
+                ("use_graph", ctypes.c_int), ("winograd", ctypes.c_int), ("conventions", LayerConventions)]
 
 
 def default_config():
@@ -53,7 +74,9 @@ def config_from_weights(weights, math="fp32", use_graph=True, winograd=None, **o
         winograd = os.environ.get("MNC_CONV_WINOGRAD", WINOGRAD_DEFAULT) != "0"
     cfg.winograd = 1 if winograd else 0
     for k, v in overrides.items():
-        if k == "pixel_means":
+        if k == "layer_conventions":
+            cfg.conventions = LayerConventions.make(v)
+        elif k == "pixel_means":
             for i in range(3):
                 cfg.pixel_means[i] = float(np.asarray(v).reshape(-1)[i])
         else:

@@ -195,33 +195,51 @@ ORC_EXPORT void orc_mv(const float* all_boxes, const float* all_masks, int all_b
  * SPEC-CHOICE: un-rounded RoI edges x*spatial_scale; roi_w = max(x2s - x1s + 1, 1); bin = roi_w / pooled_w;
  * sample position  x1s + pw*bin  (the MNC paper's  x0 + (u'/W') * w_i ,  arXiv:1512.04412 eq. 5-8, the same
  * top-left alignment as the author's own mv_kernel.cu:36-91);  bilinear kernel kappa(d) = max(0, 1-|d|) over
- * the integer neighbours; taps outside the feature map contribute 0. */
-ORC_EXPORT void orc_roi_warp(const float* feat, int C, int H, int W, const float* rois, int R,
-                             int PH, int PW, float scale, float* out) {
+ * the integer neighbours; taps outside the feature map contribute 0.
+ *
+ * Every SPEC-CHOICE is a run-time argument of the _ex form (the same switches as `mnc_layer_conventions` of include/mnc_hip.h,
+ * evaluated in the same operation order as mnc_amd/csrc/roi.hip), all zero = the SPEC:
+ *   sample       0 top-left of the bin: x1s + g*bin          1 bin centre: x1s + (g + 0.5)*bin
+ *                2 bin centre in pixel-centre coordinates: x1s + (g + 0.5)*bin - 0.5
+ *   round_edges  0 scaled edges as they are                   1 floor(x*scale + 0.5) (ROIPooling's rounding)
+ *   no_plus_one  0 roi_w = max(x2s - x1s + 1, 1)              1 roi_w = max(x2s - x1s, 1)
+ *   oob          0 taps outside the map contribute 0          1 tap coordinates clamped to the border (replicate) */
+ORC_EXPORT void orc_roi_warp_ex(const float* feat, int C, int H, int W, const float* rois, int R,
+                                int PH, int PW, float scale, int sample, int round_edges, int no_plus_one, int oob, float* out) {
 #pragma omp parallel for schedule(dynamic, 1)
   for (int r = 0; r < R; ++r) {
     const float* roi = rois + 5 * r;
-    const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
-    const float rw = fmax_(x2s - x1s + 1.0f, 1.0f), rh = fmax_(y2s - y1s + 1.0f, 1.0f);
+    float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
+    if (round_edges) { x1s = floorf(x1s + 0.5f); y1s = floorf(y1s + 0.5f); x2s = floorf(x2s + 0.5f); y2s = floorf(y2s + 0.5f); }
+    const float extra = no_plus_one ? 0.0f : 1.0f;
+    const float rw = fmax_(x2s - x1s + extra, 1.0f), rh = fmax_(y2s - y1s + extra, 1.0f);
     const float bw = rw / (float)PW, bh = rh / (float)PH;
     for (int ph = 0; ph < PH; ++ph) {
-      const float sy = y1s + (float)ph * bh;
+      const float sy = sample == 0 ? y1s + (float)ph * bh : sample == 1 ? y1s + ((float)ph + 0.5f) * bh
+                                                                        : y1s + ((float)ph + 0.5f) * bh - 0.5f;
       const int y0 = (int)floorf(sy);
       const float ay = sy - (float)y0;
       for (int pw = 0; pw < PW; ++pw) {
-        const float sx = x1s + (float)pw * bw;
+        const float sx = sample == 0 ? x1s + (float)pw * bw : sample == 1 ? x1s + ((float)pw + 0.5f) * bw
+                                                                          : x1s + ((float)pw + 0.5f) * bw - 0.5f;
         const int x0 = (int)floorf(sx);
         const float ax = sx - (float)x0;
         const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay);
         const float w10 = (1.0f - ax) * ay, w11 = ax * ay;
-        const int vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
-        const int vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        int vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+        int vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        int ya = y0, yb = y0 + 1, xa = x0, xb = x0 + 1;
+        if (oob) {
+          ya = ya < 0 ? 0 : (ya > H - 1 ? H - 1 : ya); yb = yb < 0 ? 0 : (yb > H - 1 ? H - 1 : yb);
+          xa = xa < 0 ? 0 : (xa > W - 1 ? W - 1 : xa); xb = xb < 0 ? 0 : (xb > W - 1 ? W - 1 : xb);
+          vy0 = vy1 = vx0 = vx1 = 1;
+        }
         for (int c = 0; c < C; ++c) {
           const float* f = feat + (long)c * H * W;
-          const float f00 = (vy0 && vx0) ? f[(long)y0 * W + x0] : 0.0f;
-          const float f01 = (vy0 && vx1) ? f[(long)y0 * W + x0 + 1] : 0.0f;
-          const float f10 = (vy1 && vx0) ? f[(long)(y0 + 1) * W + x0] : 0.0f;
-          const float f11 = (vy1 && vx1) ? f[(long)(y0 + 1) * W + x0 + 1] : 0.0f;
+          const float f00 = (vy0 && vx0) ? f[(long)ya * W + xa] : 0.0f;
+          const float f01 = (vy0 && vx1) ? f[(long)ya * W + xb] : 0.0f;
+          const float f10 = (vy1 && vx0) ? f[(long)yb * W + xa] : 0.0f;
+          const float f11 = (vy1 && vx1) ? f[(long)yb * W + xb] : 0.0f;
           out[(((long)r * C + c) * PH + ph) * PW + pw] = w00 * f00 + w01 * f01 + w10 * f10 + w11 * f11;
         }
       }
@@ -229,37 +247,71 @@ ORC_EXPORT void orc_roi_warp(const float* feat, int C, int H, int W, const float
   }
 }
 
+ORC_EXPORT void orc_roi_warp(const float* feat, int C, int H, int W, const float* rois, int R,
+                             int PH, int PW, float scale, float* out) {
+  orc_roi_warp_ex(feat, C, H, W, rois, R, PH, PW, scale, 0, 0, 0, 0, out);
+}
+
 /* MaskResize (test.prototxt:558-567, 885-894).  SPEC.md section 2.
- * SPEC-CHOICE: the author's own resampling convention from mv_kernel.cu:193-240 -- ratio = in/out, source
- * position = dst*ratio (top-left aligned), floor + bilinear, nearest on the last source row/column. */
-ORC_EXPORT void orc_mask_resize(const float* in, int R, int IH, int IW, int OH, int OW, float* out) {
+ * SPEC-CHOICE (mode 0): the author's own resampling convention from mv_kernel.cu:193-240 -- ratio = in/out, source
+ * position = dst*ratio (top-left aligned), floor + bilinear, nearest on the last source row/column.
+ * mode 1: half-pixel centres, src = (dst + 0.5)*ratio - 0.5 (cv2.resize / align_corners=False); mode 2: align_corners,
+ * src = dst*(in-1)/(out-1).  Modes 1 and 2 clamp src to [0, in-1], take lo = floor(src), hi = min(lo+1, in-1) and blend with the
+ * same four products in the same order. */
+ORC_EXPORT void orc_mask_resize_ex(const float* in, int R, int IH, int IW, int OH, int OW, int mode, float* out) {
   const float rh = (float)IH / (float)OH, rw = (float)IW / (float)OW;
+  const float ah = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.0f, aw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.0f;
   for (int r = 0; r < R; ++r) {
     const float* m = in + (long)r * IH * IW;
     for (int h = 0; h < OH; ++h)
       for (int w = 0; w < OW; ++w) {
-        const float ix = (float)w * rw, iy = (float)h * rh;
-        const int sx = (int)floorf(ix), sy = (int)floorf(iy);
         float v;
-        if (sx == IW - 1 || sy == IH - 1) v = m[sy * IW + sx];
-        else {
+        if (mode == 0) {
+          const float ix = (float)w * rw, iy = (float)h * rh;
+          const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+          if (sx == IW - 1 || sy == IH - 1) v = m[sy * IW + sx];
+          else {
+            const float fx = ix - (float)sx, fy = iy - (float)sy;
+            v = (1.0f - fx) * (1.0f - fy) * m[sy * IW + sx] + fx * (1.0f - fy) * m[sy * IW + sx + 1] +
+                (1.0f - fx) * fy * m[(sy + 1) * IW + sx] + fx * fy * m[(sy + 1) * IW + sx + 1];
+          }
+        } else {
+          float ix = mode == 1 ? ((float)w + 0.5f) * rw - 0.5f : (float)w * aw;
+          float iy = mode == 1 ? ((float)h + 0.5f) * rh - 0.5f : (float)h * ah;
+          ix = fmin_(fmax_(ix, 0.0f), (float)(IW - 1));
+          iy = fmin_(fmax_(iy, 0.0f), (float)(IH - 1));
+          const int sx = (int)floorf(ix), sy = (int)floorf(iy);
+          const int tx = sx + 1 < IW ? sx + 1 : IW - 1, ty = sy + 1 < IH ? sy + 1 : IH - 1;
           const float fx = ix - (float)sx, fy = iy - (float)sy;
-          v = (1.0f - fx) * (1.0f - fy) * m[sy * IW + sx] + fx * (1.0f - fy) * m[sy * IW + sx + 1] +
-              (1.0f - fx) * fy * m[(sy + 1) * IW + sx] + fx * fy * m[(sy + 1) * IW + sx + 1];
+          v = (1.0f - fx) * (1.0f - fy) * m[sy * IW + sx] + fx * (1.0f - fy) * m[sy * IW + tx] +
+              (1.0f - fx) * fy * m[ty * IW + sx] + fx * fy * m[ty * IW + tx];
         }
         out[((long)r * OH + h) * OW + w] = v;
       }
   }
 }
 
+ORC_EXPORT void orc_mask_resize(const float* in, int R, int IH, int IW, int OH, int OW, float* out) {
+  orc_mask_resize_ex(in, R, IH, IW, OH, OW, 0, out);
+}
+
 /* MaskPooling (test.prototxt:631-637, 958-964).  SPEC.md section 3.
- * SPEC-CHOICE: element-wise product of the per-RoI feature with the continuous mask, broadcast over channels. */
-ORC_EXPORT void orc_mask_pool(const float* feat, const float* mask, int R, int C, int H, int W, float* out) {
+ * SPEC-CHOICE (binary 0): element-wise product of the per-RoI feature with the continuous mask, broadcast over channels.
+ * binary 1: the mask is binarised first, m >= thresh ? 1 : 0 (what the CFM tester feeds, TesterWrapper.py:398). */
+ORC_EXPORT void orc_mask_pool_ex(const float* feat, const float* mask, int R, int C, int H, int W, int binary, float thresh,
+                                 float* out) {
 #pragma omp parallel for
   for (int r = 0; r < R; ++r)
     for (int c = 0; c < C; ++c)
-      for (int i = 0; i < H * W; ++i)
-        out[((long)r * C + c) * H * W + i] = feat[((long)r * C + c) * H * W + i] * mask[(long)r * H * W + i];
+      for (int i = 0; i < H * W; ++i) {
+        float mk = mask[(long)r * H * W + i];
+        if (binary) mk = mk >= thresh ? 1.0f : 0.0f;
+        out[((long)r * C + c) * H * W + i] = feat[((long)r * C + c) * H * W + i] * mk;
+      }
+}
+
+ORC_EXPORT void orc_mask_pool(const float* feat, const float* mask, int R, int C, int H, int W, float* out) {
+  orc_mask_pool_ex(feat, mask, R, C, H, W, 0, 0.0f, out);
 }
 
 /* ROIPooling forward (models/VGG16/cfm/test.prototxt:397-407, 446-456).  The layer source sits in the absent caffe-mnc

@@ -129,6 +129,33 @@ def mv(all_boxes, all_masks, cand_inds, cand_start, cand_weights, H, W):
     return _mv_call(lib().orc_mv, all_boxes, all_masks, cand_inds, cand_start, cand_weights, H, W, False)
 
 
+# The SPEC-CHOICEs of the three unpinned layers as switches (oracle/SPEC.md section 6; the same names and values as
+# `mnc_layer_conventions` in include/mnc_hip.h / mnc_amd.engine.LAYER_CONVENTIONS).  All defaults = the SPEC.
+SPEC_CONVENTIONS = {"warp_sample": 0, "warp_round_edges": 0, "warp_no_plus_one": 0, "warp_oob": 0, "resize_mode": 0,
+                    "maskpool_binary": 0, "maskpool_thresh": 0.4}
+_conv = dict(SPEC_CONVENTIONS)
+
+
+class conventions(object):
+    """with native.conventions(warp_sample=1): ...  -- roi_warp / mask_resize / mask_pool (and with them oracle.net.head)
+    evaluate the alternative convention inside the block."""
+
+    def __init__(self, **kw):
+        bad = set(kw) - set(SPEC_CONVENTIONS)
+        if bad:
+            raise KeyError("unknown layer convention(s): %s" % sorted(bad))
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(_conv)
+        _conv.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        _conv.clear()
+        _conv.update(self.saved)
+
+
 def roi_warp(feat, rois, PH, PW, scale):
     f = _c(feat, np.float32)
     if f.ndim == 4:
@@ -136,8 +163,9 @@ def roi_warp(feat, rois, PH, PW, scale):
     r = _c(rois, np.float32)
     C, H, W = f.shape
     out = np.zeros((r.shape[0], C, PH, PW), np.float32)
-    lib().orc_roi_warp(_p(f, _f32p), C, H, W, _p(r, _f32p), r.shape[0], PH, PW, ctypes.c_float(scale),
-                       _p(out, _f32p))
+    lib().orc_roi_warp_ex(_p(f, _f32p), C, H, W, _p(r, _f32p), r.shape[0], PH, PW, ctypes.c_float(scale),
+                          int(_conv["warp_sample"]), int(_conv["warp_round_edges"]), int(_conv["warp_no_plus_one"]),
+                          int(_conv["warp_oob"]), _p(out, _f32p))
     return out
 
 
@@ -156,7 +184,7 @@ def mask_resize(mask, OH, OW):
     m = _c(mask, np.float32)
     R, _, IH, IW = m.shape
     out = np.zeros((R, 1, OH, OW), np.float32)
-    lib().orc_mask_resize(_p(m, _f32p), R, IH, IW, OH, OW, _p(out, _f32p))
+    lib().orc_mask_resize_ex(_p(m, _f32p), R, IH, IW, OH, OW, int(_conv["resize_mode"]), _p(out, _f32p))
     return out
 
 
@@ -164,7 +192,8 @@ def mask_pool(feat, mask):
     f, m = _c(feat, np.float32), _c(mask, np.float32)
     R, C, H, W = f.shape
     out = np.zeros_like(f)
-    lib().orc_mask_pool(_p(f, _f32p), _p(m, _f32p), R, C, H, W, _p(out, _f32p))
+    lib().orc_mask_pool_ex(_p(f, _f32p), _p(m, _f32p), R, C, H, W, int(_conv["maskpool_binary"]),
+                           ctypes.c_float(_conv["maskpool_thresh"]), _p(out, _f32p))
     return out
 
 

@@ -79,6 +79,13 @@ class Fake(object):
     def mnc_ctx_destroy(self, h):
         pass
 
+    def mnc_ctx_set_layer_conventions(self, h, addr):
+        """The fake has one context: the conventions go straight to the oracle's switches (oracle.native.conventions)."""
+        from mnc_amd.native_net import LayerConventions
+        c = LayerConventions.from_address(int(addr)) if addr else LayerConventions.make()
+        native._conv.clear()
+        native._conv.update(c.as_dict())
+
     def mnc_ctx_sync(self, h):
         pass
 
