@@ -531,8 +531,9 @@ MNC_API int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host,
 MNC_API int mnc_net_fetch(mnc_net* net, float* records_host, int record_cap, int* counts_host);
 /* Device address and Caffe-order shape of an intermediate blob of the LAST image, for parity tests: "conv5_3" (c8),
  * "rpn_cls_prob_reshape", "rpn_bbox_pred", "rois", "rois_ext", "mask_proposal" [2R][S][S] (both stages stacked),
- * "seg_cls_prob" [2R][num_classes], "boxes" [2R][4], "records" (the instance block of mnc_forward_image_async).  dims receives
- * up to 4 ints, *ndim their number. */
+ * "seg_cls_prob" [2R][num_classes], "boxes" [2R][4], "head_scores" [2R][6*num_classes] = [cls_score | seg_cls_score | bbox_pred]
+ * of both stages, "data" (the prepared network input), "records" (the instance block of mnc_forward_image_async).  dims
+ * receives up to 4 ints, *ndim their number. */
 MNC_API int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* ndim);
 MNC_API int mnc_net_destroy(mnc_net* net);
 

@@ -340,7 +340,7 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   if (sm_format(n->fc7, F)) NET_TRY(dev_ensure(n, &n->f6_sm, (size_t)R * F * (n->fc7.kind == 2 ? 2 : 4)));
   if (sm_format(n->fc7m, F)) NET_TRY(dev_ensure(n, &n->f6m_sm, (size_t)R * F * (n->fc7m.kind == 2 ? 2 : 4)));
   NET_TRY(dev_ensure(n, &n->join, (size_t)R * 2 * F * 4));
-  NET_TRY(dev_ensure(n, &n->heads, (size_t)R * 6 * K * 4));
+  NET_TRY(dev_ensure(n, &n->heads, (size_t)2 * R * 6 * K * 4));        // both stages' rows (stage 4/5 behind stage 2/3)
   NET_TRY(dev_ensure(n, &n->boxes, (size_t)2 * R * 4 * 4));
   NET_TRY(dev_ensure(n, &n->masks, (size_t)2 * R * S * S * 4));
   NET_TRY(dev_ensure(n, &n->scores, (size_t)2 * R * K * 4));
@@ -511,7 +511,7 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   NET_TRY(run_fc_sm(ctx, n->fc6m, (const float*)n->mask7.p, n->mask7_sm.p, sm_mask, (float*)n->f6m.p, R, F, 1, n->f6m_sm.p, sm_f6m));
   NET_TRY(run_fc_sm(ctx, n->fc7m, (const float*)n->f6m.p, n->f6m_sm.p, n->fc6m.kind ? sm_f6m : 0, join, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));
-  float* heads = (float*)n->heads.p;
+  float* heads = (float*)n->heads.p + (size_t)row0 * 6 * K;      // kept per stage: mnc_net_blob("head_scores")
   NET_TRY(run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0));
   float* scores = (float*)n->scores.p + (size_t)row0 * K;
   if (R) NET_TRY(mnc_softmax_rows_ld(ctx, heads + K, 6 * K, scores, R, K));                     // seg_cls_prob
@@ -823,6 +823,8 @@ int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* n
   if (s == "mask_proposal") return set(net->masks.p, 4, R1 + R2, 1, c.mask_size, c.mask_size);
   if (s == "seg_cls_prob") return set(net->scores.p, 2, R1 + R2, c.num_classes, 0, 0);
   if (s == "boxes") return set(net->boxes.p, 2, R1 + R2, 4, 0, 0);
+  // rows of both stages, columns [cls_score (K) | seg_cls_score (K) | bbox_pred (4K)]: the three sibling InnerProducts are one GEMM
+  if (s == "head_scores") return set(net->heads.p, 2, R1 + R2, 6 * c.num_classes, 0, 0);
   if (s == "records") return set(net->records.p, 2, (c.num_classes - 1) * c.max_per_image, 6 + c.mask_size * c.mask_size, 0, 0);
   set_error("mnc_net_blob: unknown blob %s", name);
   return MNC_ERR_INVALID;

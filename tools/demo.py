@@ -33,6 +33,9 @@ def parse_args(argv=None):
     p.add_argument("--net", dest="caffemodel", default=None, type=str, help="weights (.npz; .h5 needs h5py)")
     p.add_argument("--images", nargs="*", default=None, help="image files (default: data/demo/*.jpg if present)")
     p.add_argument("--no-vis", dest="vis", action="store_false", help="skip writing visualisations")
+    p.add_argument("--out-dir", dest="out_dir", default=None, help="where the *_mnc.png visualisations go [next to each image]")
+    p.add_argument("--vis-thresh", dest="vis_thresh", default=0.5, type=float,
+                   help="score threshold of the drawn instances [0.5, the reference's constant, demo.py:103]")
     return p.parse_args(argv)
 
 
@@ -152,10 +155,13 @@ def main(argv=None):
         start = time.time()
         result_mask, result_box = gpu_mask_voting(masks, boxes, seg_scores, len(CLASSES) + 1, 100, im.shape[1], im.shape[0])
         print("mask voting time %f" % (time.time() - start))
-        pred = get_vis_dict(result_box, result_mask, path or "synthetic", CLASSES)
-        print("%d instances with score >= 0.5" % len(pred["boxes"]))
+        pred = get_vis_dict(result_box, result_mask, path or "synthetic", CLASSES, args.vis_thresh)
+        print("%d instances with score >= %g" % (len(pred["boxes"]), args.vis_thresh))
         if args.vis and path:
             out = os.path.splitext(path)[0] + "_mnc.png"
+            if args.out_dir:
+                os.makedirs(args.out_dir, exist_ok=True)
+                out = os.path.join(args.out_dir, os.path.basename(out))
             _visualise(im, pred, out)
             print("wrote", out)
     net.close()
