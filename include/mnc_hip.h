@@ -170,6 +170,12 @@ typedef struct mnc_layer_conventions {
   int reserved;          /* 0 */
 } mnc_layer_conventions;
 MNC_API int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventions* conv);   /* NULL: back to the SPEC */
+/* Override one of the launchers' own choices on this context (a tile shape, a kernel variant, a plan switch): name as in
+ * csrc/mnc_internal.h MNC_TUNE_KEYS, e.g. "FC_TILE" / "5", "CONV1X1_TILE" / "2,4"; value NULL or "" = the library's choice again.
+ * The environment variable MNC_<NAME> sets the same value when the context is created -- launch paths never read the
+ * environment.  For tests (every variant reachable at a small shape) and A/B measurements; results never change beyond the
+ * summation grouping of K splits. */
+MNC_API int mnc_ctx_set_tuning(mnc_ctx* ctx, const char* name, const char* value);
 MNC_API int mnc_ctx_get_layer_conventions(const mnc_ctx* ctx, mnc_layer_conventions* conv);
 
 /* Device memory for the host-side executor (the caffe-shaped Net keeps its blobs here). */

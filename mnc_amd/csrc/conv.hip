@@ -429,12 +429,12 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   while (best_cot > 1 && (Cout % (32 * best_cot) != 0 ||
                           (long)cdiv(W, kTileCols) * cdiv(H, best_rows) * (Cout / (32 * best_cot)) < 1024))
     best_cot >>= 1;
-  if (const char* e = getenv("MNC_CONV_COT")) {
-    const int v = atoi(e);
+  if (tune_set(ctx, T_CONV_COT)) {
+    const int v = tune(ctx, T_CONV_COT, 0);
     if ((v == 1 || v == 2 || v == 4) && Cout % (32 * v) == 0) best_cot = v;
   }
-  if (const char* e = getenv("MNC_CONV_ROWS")) {
-    const int v = atoi(e);
+  if (tune_set(ctx, T_CONV_ROWS)) {
+    const int v = tune(ctx, T_CONV_ROWS, 0);
     if (v == 2 || v == 4 || v == 8) best_rows = v;
   }
   const int rows = best_rows, co_t = best_cot;
@@ -444,8 +444,8 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
     const long wgs = (long)cdiv(W, kTileCols) * cdiv(H, rows) * (Cout / (32 * co_t));
     const int blocks = Cin / 8;
     if (wgs < 512) ksplit = blocks % 4 == 0 && blocks >= 16 ? 4 : (blocks % 2 == 0 && blocks >= 8 ? 2 : 1);
-    if (const char* e = getenv("MNC_CONV_KSPLIT")) {
-      const int v = atoi(e);
+    if (tune_set(ctx, T_CONV_KSPLIT)) {
+      const int v = tune(ctx, T_CONV_KSPLIT, 0);
       if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
     }
   }
@@ -460,18 +460,22 @@ int mnc_conv3x3(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_c8_mfma", flops, bytes);
   dim3 grid(tx, ty, Cout / (32 * co_t) * ksplit);
-  if (const char* e = getenv("MNC_CONV_ABL")) {
-    const int a = atoi(e);
+#ifdef MNC_TUNING
+  if (tune_set(ctx, T_CONV_ABL)) {
+    const int a = tune(ctx, T_CONV_ABL, 0);
 #define MNC_ABL_CASE(T, A) if (rows == 4 && co_t == T && a == A) { hipLaunchKernelGGL((conv3x3_c8_kernel<T, 4, A>), grid, dim3(256), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part); goto launched; }
     MNC_ABL_CASE(1, 1) MNC_ABL_CASE(1, 2) MNC_ABL_CASE(1, 3) MNC_ABL_CASE(2, 1) MNC_ABL_CASE(2, 2) MNC_ABL_CASE(2, 3)
 #undef MNC_ABL_CASE
   }
+#endif
 #define MNC_CONV_CASE(R, T) if (rows == R && co_t == T) hipLaunchKernelGGL((conv3x3_c8_kernel<T, R>), grid, dim3(64 * R), 0, ctx->stream, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
   MNC_CONV_CASE(2, 1) MNC_CONV_CASE(2, 2) MNC_CONV_CASE(2, 4)
   MNC_CONV_CASE(4, 1) MNC_CONV_CASE(4, 2) MNC_CONV_CASE(4, 4)
   MNC_CONV_CASE(8, 1) MNC_CONV_CASE(8, 2) MNC_CONV_CASE(8, 4)
 #undef MNC_CONV_CASE
+#ifdef MNC_TUNING
 launched:
+#endif
   if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, d_out, H, W, Cout, ksplit, relu);   // same profiling scope
   return ls.finish("conv3x3_c8_kernel");
 }

@@ -234,9 +234,9 @@ static int conv1x1_launch(mnc_ctx* ctx, const char* scope, const void* d_in, con
     if (blocks() < 512) pt = 1;
     while (blocks() < 512 && ct > 1) ct >>= 1;
   }
-  if (const char* e = getenv("MNC_CONV1X1_TILE")) {          // tuning override "ct,pt"
-    int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2 || a == 4) && (b == 1 || b == 2)) { ct = a; pt = b; }
+  if (tune_set(ctx, T_CONV1X1_TILE)) {                        // override "ct,pt" (mnc_ctx_set_tuning: ct * 1000 + pt)
+    const int a = tune(ctx, T_CONV1X1_TILE, 0) / 1000, b = tune(ctx, T_CONV1X1_TILE, 0) % 1000;
+    if ((a == 1 || a == 2 || a == 4) && (b == 1 || b == 2)) { ct = a; pt = b; }
   }
   const int npg = cdiv(P, 128 * pt), ncg = cdiv(CoT, ct);
   const double act_b = F16 ? 2.0 : 4.0;

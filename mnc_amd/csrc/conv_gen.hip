@@ -472,7 +472,7 @@ int mnc_conv2d(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d
   // MNC_CONV2D_WIDE=1 (tuning knob): 128-channel workgroup tiles (wave = 64 channels x 64 pixels: 8 B/clk/CU of staging
   // instead of 12, half the barriers per MFMA).  Measured on the ResNet-50 C4 trunk at 800x1333: 40 vs 44 TFLOP/s for the
   // 64-channel tile (fewer, fatter workgroups), so the narrow tile is the default.
-  const bool wide = Cout >= 128 && getenv("MNC_CONV2D_WIDE") != nullptr;
+  const bool wide = Cout >= 128 && tune(ctx, T_CONV2D_WIDE, 0) != 0;
   if (wide)
     hipLaunchKernelGGL(conv2d_c8_kernel<2>, dim3((unsigned)cdiv(P, kGenPx), (unsigned)cdiv(Cout, 128)), dim3(256), 0, ctx->stream,
                        d_in, d_w, d_bias, d_residual, d_out, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, relu);

@@ -1057,8 +1057,8 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   // measured (tools/kernel_bench.py convwino, MNC_WINO_ROWS): 4-wave workgroups win on every trunk shape from 600x1000 down
   // to 75x125 (one workgroup per CU either way; taller workgroups amortise the weight panel), 2 waves on maps under 64 rows
   int rows = H >= 64 ? 4 : 2;
-  if (const char* e = getenv("MNC_WINO_ROWS")) {
-    const int v = atoi(e);
+  if (tune_set(ctx, T_WINO_ROWS)) {
+    const int v = tune(ctx, T_WINO_ROWS, 0);
     if (v == 1 || v == 2 || v == 4) rows = v;
   }
   // K splits: the chip holds 512 workgroups at a time (two per CU); with fewer than ~1000 the last, partly filled round costs
@@ -1069,8 +1069,8 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     const long wgs = (long)cdiv(W, kWCols) * cdiv(H, 4 * (rows >= 2 ? 2 : 1)) * ncot;
     const int blocks = Cin / 8;
     while (ksplit < 4 && wgs * ksplit < 1024 && blocks % (2 * ksplit) == 0 && blocks / (2 * ksplit) >= 4) ksplit *= 2;
-    if (const char* e = getenv("MNC_CONV_KSPLIT")) {
-      const int v = atoi(e);
+    if (tune_set(ctx, T_CONV_KSPLIT)) {
+      const int v = tune(ctx, T_CONV_KSPLIT, 0);
       if (v >= 1 && v <= 8 && blocks % v == 0) ksplit = v;
     }
   }
@@ -1084,10 +1084,9 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   // tail tiles in two (the reduce pass included) LOST 11 us, and those layers stay whole.
   int pix_a = -1, ksplit_b = 1;
   {
-    const bool tail_on = !(getenv("MNC_WINO_TAIL") && atoi(getenv("MNC_WINO_TAIL")) == 0);
-    int ver_env = 2;
-    if (const char* e = getenv("MNC_WINO_V")) ver_env = atoi(e);
-    if (tail_on && rows >= 2 && ver_env == 2 && !getenv("MNC_CONV_KSPLIT")) {
+    const bool tail_on = tune(ctx, T_WINO_TAIL, 1) != 0;
+    const int ver_env = tune(ctx, T_WINO_V, 2);
+    if (tail_on && rows >= 2 && ver_env == 2 && !tune_set(ctx, T_CONV_KSPLIT)) {
       const int pix = cdiv(W, kWCols) * cdiv(H, 8), blocks = Cin / 8, slots = 512;      // MI355X: 256 CUs x two workgroups
       const int full_pix = (int)((long)pix * ncot / slots) * slots / ncot;      // pixel tiles of the full rounds
       const int rest = (pix - full_pix) * ncot;
@@ -1115,49 +1114,53 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
   const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
-  // MNC_WINO_VAR: 7 (default) rotated loop, all halo rows read behind the barrier; 3 rotated loop, row B read at the head of the
-  // iteration; 1 flat block schedule with register staging; 0 the round-2 v2 loop (13-layer trunk, kernel_bench convwino:
-  // 2.19 / 2.22 / 2.28 / 2.54 ms); 16 / 48 / 112 ablations
-  int var = 7, ver = 2;
-  if (const char* e = getenv("MNC_WINO_VAR")) var = atoi(e);
-  if (const char* e = getenv("MNC_WINO_V")) ver = atoi(e);
-  // var 1 (flat block schedule, buffer loads): two-row-group workgroups only, 32-bit byte offsets into the input
-  if ((var == 1 || var == 3 || var == 7) && (rows < 2 || ver != 2 || (double)Cin * H * W * 4.0 >= 2147483648.0 || getenv("MNC_WINO_DMA"))) var = 0;
+  // WINO_VAR: 7 (the product build) rotated loop, all halo rows read behind the barrier, LDS-DMA weight panel.  -DMNC_TUNING builds
+  // also carry 3 (row B read at the head of the iteration), 1 (flat block schedule, register staging), 0 (the round-2 v2 loop)
+  // (13-layer trunk, kernel_bench convwino: 2.19 / 2.22 / 2.28 / 2.54 ms), the ablations 16 / 48 / 112 and WINO_V = 1 (v1 kernel).
+  // One-row-group workgroups (maps under 64 rows) and inputs beyond 32-bit byte offsets run the v2 loop (var 0) in every build.
+  int var = tune(ctx, T_WINO_VAR, 7), ver = tune(ctx, T_WINO_V, 2);
+#ifndef MNC_TUNING
+  var = 7; ver = 2;
+#endif
+  if ((var == 1 || var == 3 || var == 7) && (rows < 2 || ver != 2 || (double)Cin * H * W * 4.0 >= 2147483648.0 || tune_set(ctx, T_WINO_DMA))) var = 0;
   MNC_REQUIRE(!pool || (ver == 2 && (var == 0 || var == 1 || var == 3 || var == 7)), "mnc_conv3x3_wino_pool: only the default kernel build fuses the pooling");
   int rc = MNC_ERR_INVALID;
-  if (ver == 2) {                   // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
+  // XCD-aware order (see the kernel) where the channel tiles' shared input dominates the traffic; measured FETCH_SIZE per launch
+  // plain -> XCD-aware: conv1_2 197 -> 93 MB, conv2_x 153 -> 41, conv3_x 126 -> 60; for the 512-channel layers the 17.8 MB of
+  // transformed weights dominate and every XCD would stream all of them (conv4_x 84 -> 248 MB, conv5_x 38 -> 93): plain order
+  const bool plain_order = tune_set(ctx, T_WINO_XCD) ? tune(ctx, T_WINO_XCD, 1) == 0 : Cout > 256;
+  if (ver == 2 && var == 7)
+    rc = plain_order ? launch_wino2<2, 7, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b)
+                     : launch_wino2<2, 7, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
+  else if (ver == 2 && var == 0 && !tune_set(ctx, T_WINO_DMA) && !(rows == 4 && tune_set(ctx, T_WINO_ROWS)))
+    rc = rows >= 2 ? launch_wino2<2, 0, 0, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b)
+                   : launch_wino2<1, 0, 0, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
+#ifdef MNC_TUNING
+  else if (ver == 2) {              // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
     // measured (kernel_bench convwino, 13-layer trunk): register staging 2.526 ms, LDS-DMA weight panel 2.564 ms -- the DMA saves
     // 20 registers and the ds_write pass but hipcc drains it with vmcnt(0) in front of every barrier; kept selectable
-    int dma = 0;
-    if (const char* e = getenv("MNC_WINO_DMA")) dma = atoi(e) != 0;
-    // XCD-aware order (see the kernel) where the channel tiles' shared input dominates the traffic; measured FETCH_SIZE per launch
-    // plain -> XCD-aware: conv1_2 197 -> 93 MB, conv2_x 153 -> 41, conv3_x 126 -> 60; for the 512-channel layers the 17.8 MB of
-    // transformed weights dominate and every XCD would stream all of them (conv4_x 84 -> 248 MB, conv5_x 38 -> 93): plain order
-    bool plain_order = Cout > 256;
-    if (const char* e = getenv("MNC_WINO_XCD")) plain_order = atoi(e) == 0;
+    int dma = tune(ctx, T_WINO_DMA, 0) != 0;
     if (plain_order && rows >= 2 && var == 0 && dma == 0)
       rc = launch_wino2<2, 0, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
     if (plain_order && rows >= 2 && var == 1 && dma == 0)
       rc = launch_wino2<2, 1, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
-    if (var == 3 || var == 7) dma = 1;
+    if (var == 3) dma = 1;
     if (plain_order && rows >= 2 && var == 3)
       rc = launch_wino2<2, 3, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
-    if (plain_order && rows >= 2 && var == 7)
-      rc = launch_wino2<2, 7, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
 #define MNC_WINO2_CASE(R, A, D) if (rc == MNC_ERR_INVALID && (rows >= 2 ? 2 : 1) == R && var == A && dma == D) rc = launch_wino2<R, A, D>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
-    if (rc == MNC_ERR_INVALID && rows == 4 && getenv("MNC_WINO_ROWS") && var == 0 && dma == 0)          // 8-wave workgroups (tuning)
+    if (rc == MNC_ERR_INVALID && rows == 4 && tune_set(ctx, T_WINO_ROWS) && var == 0 && dma == 0)          // 8-wave workgroups
       rc = launch_wino2<4, 0, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
-    MNC_WINO2_CASE(2, 0, 0) MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 0) MNC_WINO2_CASE(1, 0, 1)
-    MNC_WINO2_CASE(2, 1, 0) MNC_WINO2_CASE(2, 3, 1) MNC_WINO2_CASE(2, 7, 1)
-    MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations (tuning)
+    MNC_WINO2_CASE(2, 0, 1) MNC_WINO2_CASE(1, 0, 1) MNC_WINO2_CASE(2, 1, 0) MNC_WINO2_CASE(2, 3, 1)
+    MNC_WINO2_CASE(2, 16, 0) MNC_WINO2_CASE(2, 48, 0) MNC_WINO2_CASE(2, 112, 0)                  // ablations
 #undef MNC_WINO2_CASE
   } else {
 #define MNC_WINO_CASE(R, V) if (rows == R && var == V) rc = launch_wino<R, V>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part);
     MNC_WINO_CASE(4, 0) MNC_WINO_CASE(4, 1) MNC_WINO_CASE(2, 0) MNC_WINO_CASE(2, 1) MNC_WINO_CASE(1, 0) MNC_WINO_CASE(1, 1)
-    MNC_WINO_CASE(4, 16) MNC_WINO_CASE(4, 48) MNC_WINO_CASE(4, 112) MNC_WINO_CASE(4, 240)      // ablations (tuning)
+    MNC_WINO_CASE(4, 16) MNC_WINO_CASE(4, 48) MNC_WINO_CASE(4, 112) MNC_WINO_CASE(4, 240)      // ablations
 #undef MNC_WINO_CASE
   }
-  MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d MNC_WINO_VAR=%d MNC_WINO_V=%d", rows, var, ver);
+#endif
+  MNC_REQUIRE(rc != MNC_ERR_INVALID, "mnc_conv3x3_wino: no kernel for rows=%d WINO_VAR=%d WINO_V=%d (ablation / superseded builds need -DMNC_TUNING)", rows, var, ver);
   if (rc) return rc;
   if (ksplit > 1) conv_splitk_reduce_launch(ctx->stream, part, d_bias, pool ? full : d_out, H, W, Cout, ksplit, relu);
   if (ksplit_b > 1) {

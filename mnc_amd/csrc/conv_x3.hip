@@ -557,7 +557,7 @@ static int launch_x3(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
     ks = best_ks(4);
     if (ks > 1) main_tiles = 0;
   } else {
-    static const bool tail_on = !(getenv("MNC_CONVX3_TAIL") && atoi(getenv("MNC_CONVX3_TAIL")) == 0);
+    const bool tail_on = tune(ctx, T_CONVX3_TAIL, 1) != 0;
     const int tail = ntiles % cap;
     if (tail_on && tail > 0 && tail * 4 <= cap) {
       ks = best_ks(cap / tail);
@@ -682,16 +682,16 @@ static int conv3x3_lowp(mnc_ctx* ctx, const char* name, const void* d_in, const 
   // 4x the workgroups and 5 waves per SIMD is faster (175-285 vs 120-250).  4x2 (1 workgroup per CU) never wins.
   int ct = 1, pr = 1;
   if (Cout % 64 == 0 && (long)cdiv(W, kX3Cols) * cdiv(H, 8) * (Cout / 64) >= 512) ct = 2, pr = 2;
-  if (const char* e = getenv("MNC_CONVX3_TILE")) {          // "CT,PR" tuning override
-    int a = 0, b = 0;
-    if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 1 || a == 2) && (b == 1 || b == 2) && Cout % (32 * a) == 0 && !(a == 1 && b == 2)) {
+  if (tune_set(ctx, T_CONVX3_TILE)) {                        // "CT,PR" override (mnc_ctx_set_tuning: CT * 1000 + PR)
+    const int a = tune(ctx, T_CONVX3_TILE, 0) / 1000, b = tune(ctx, T_CONVX3_TILE, 0) % 1000;
+    if ((a == 1 || a == 2) && (b == 1 || b == 2) && Cout % (32 * a) == 0 && !(a == 1 && b == 2)) {
       ct = a;
       pr = b;
     }
   }
-  int force_ks = 0;                                          // MNC_CONV_KSPLIT: 1 = no splits at all, k > 1 = every tile in k ranges
-  if (const char* e = getenv("MNC_CONV_KSPLIT")) {
-    const int v = atoi(e);
+  int force_ks = 0;                                          // CONV_KSPLIT: 1 = no splits at all, k > 1 = every tile in k ranges
+  if (tune_set(ctx, T_CONV_KSPLIT)) {
+    const int v = tune(ctx, T_CONV_KSPLIT, 0);
     if (v >= 1 && v <= 8) force_ks = v;
   }
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;

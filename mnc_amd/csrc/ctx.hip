@@ -1,9 +1,23 @@
 // Context, device memory, error reporting and HIP-event profiling for libmnc_hip.so.
+#include <cstdlib>
+
 #include "mnc_internal.h"
 
 namespace mnc {
 
 static thread_local char g_err[512] = "";
+
+static const char* const kTuneNames[T_COUNT] = {
+#define MNC_TUNE_NAME(n) #n,
+    MNC_TUNE_KEYS(MNC_TUNE_NAME)
+#undef MNC_TUNE_NAME
+};
+
+// "5" -> 5; "2,4" (a tile pair) -> 2 * 1000 + 4
+static int parse_tune(const char* v) {
+  const char* comma = strchr(v, ',');
+  return comma ? atoi(v) * 1000 + atoi(comma + 1) : atoi(v);
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -61,7 +75,11 @@ using namespace mnc;
 extern "C" {
 
 const char* mnc_last_error(void) { return g_err; }
-const char* mnc_version(void) { return "mnc_hip 0.1 (gfx950)"; }
+#ifdef MNC_TUNING
+const char* mnc_version(void) { return "mnc_hip 0.3 (gfx950, tuning build: ablation and superseded kernels included)"; }
+#else
+const char* mnc_version(void) { return "mnc_hip 0.3 (gfx950)"; }
+#endif
 
 int mnc_device_count(int* count) {
   MNC_REQUIRE(count, "mnc_device_count: null pointer");
@@ -89,6 +107,12 @@ int mnc_ctx_create(mnc_ctx** out, int device_id) {
     return MNC_ERR_NOMEM;
   }
   ctx->device = device_id;
+  for (int k = 0; k < T_COUNT; ++k) {                 // the environment is read here, once per context, never on a launch path
+    char name[64];
+    snprintf(name, sizeof(name), "MNC_%s", kTuneNames[k]);
+    const char* v = getenv(name);
+    ctx->tune[k] = v && *v ? parse_tune(v) : kTuneUnset;
+  }
   hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete ctx;
@@ -136,6 +160,19 @@ int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation) {
   MNC_REQUIRE(ctx && generation, "mnc_ctx_arena_generation: null pointer");
   *generation = ctx->arena_gen;
   return MNC_OK;
+}
+
+int mnc_ctx_set_tuning(mnc_ctx* ctx, const char* name, const char* value) {
+  MNC_REQUIRE(ctx && name, "mnc_ctx_set_tuning: null pointer");
+  if (!strncmp(name, "MNC_", 4)) name += 4;
+  for (int k = 0; k < T_COUNT; ++k)
+    if (!strcmp(name, kTuneNames[k])) {
+      ctx->tune[k] = value && *value ? parse_tune(value) : kTuneUnset;
+      clear_error();
+      return MNC_OK;
+    }
+  set_error("mnc_ctx_set_tuning: unknown key %s", name);
+  return MNC_ERR_INVALID;
 }
 
 int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventions* conv) {

@@ -560,7 +560,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   // multiplies all of its row tiles, so the full blocks and the tail are two launches, each with the tile height and split
   // count that suit it (M = 760: 2 x 320 + one 160-row block instead of 3 x 320).  Same stream: the second launch re-uses
   // the split-K scratch after the first one's reduction.  MNC_FC_NOTAIL=1 keeps one launch.
-  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
+  if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !tune(ctx, T_FC_NOTAIL, 0)) {
     const int head = M / 320 * 320;
     int rc = mnc_fc(ctx, d_a, d_w, d_bias, d_out, head, N, K, ldc, act);
     if (rc) return rc;
@@ -575,8 +575,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   // when the K splits of the 320-row variant would be shorter than 64 stages (fc7, fc6_maskest), 160-row blocks are a few
   // per cent faster (measured: 107 vs 112 us, 160 vs 169 us; fc6 stays at 320 rows: 615 vs 625 us)
   if (mt == 10 && (K / 32) / cdiv(256, cdiv(N, kBN) * cdiv(M, 320)) < 64) mt = 5;
-  if (const char* e = getenv("MNC_FC_TILE")) {
-    const int v = atoi(e);
+  if (tune_set(ctx, T_FC_TILE)) {
+    const int v = tune(ctx, T_FC_TILE, 0);
     if (!small && (v == 5 || v == 10)) mt = v;
   }
   const int sk = mt == 5 ? 16 : 32;                    // K values per stage
@@ -595,7 +595,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
                            (double)bm * kBN * sk * 2.0 / 460.0e3 * (mt == 10 ? 1.0 : 2.0), 4.0 * M * (double)N);
   int kper = cdiv(stages, splits) * sk;
   // LDS-DMA build of the 320-row kernel (fc_mfma_dma_kernel; MNC_FC_DMA=0: the register-staged one): even stage counts per split
-  const bool dma = mt == 10 && K % 64 == 0 && !getenv("MNC_FC_ABL") && !(getenv("MNC_FC_DMA") && atoi(getenv("MNC_FC_DMA")) == 0);
+  const bool dma = mt == 10 && K % 64 == 0 && !tune_set(ctx, T_FC_ABL) && tune(ctx, T_FC_DMA, 1) != 0;
   if (dma) kper = cdiv(kper, 64) * 64;
   splits = cdiv(K, kper);
   float* part = nullptr;
@@ -607,51 +607,56 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)M * N);
   {
     LaunchScope ls(ctx, small ? "fc_mfma_small" : "fc_mfma", flops, bytes);
-    const char* e = getenv("MNC_FC_ABL");
-    const int abl = e ? atoi(e) : 0;
 #define MNC_FC_LAUNCH(MT, SK, A) hipLaunchKernelGGL((fc_mfma_kernel<MT, SK, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, \
                          d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
+#define MNC_FC_DMA_LAUNCH(A, WM)                                                                                                    \
+  do {                                                                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};            /* one bit per device: function attributes are per device */   \
+    const unsigned long long bit = 1ull << (ctx->device & 63);                                                                      \
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {                                                                        \
+      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, A, WM>),                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                            \
+      attr_set.fetch_or(bit, std::memory_order_relaxed);                                                                            \
+    }                                                                                                                               \
+    hipLaunchKernelGGL((fc_mfma_dma_kernel<10, A, WM>), dim3(tn * splits * tm), dim3(256 * WM), lds, ctx->stream, d_a, d_w, d_bias, \
+                       d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);                                  \
+  } while (0)
     if (dma) {
       constexpr int lds = 65536 + (320 + kBN) * 32 * 4;
-      static std::atomic<unsigned long long> attr_set{0};            // one bit per device: function attributes are per device
-      const unsigned long long bit = 1ull << (ctx->device & 63);
-      if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set.fetch_or(bit, std::memory_order_relaxed);
-      }
+      // eight waves, two per SIMD (default; FC_DMA_WAVES=4: four waves, one per SIMD): fc6 610 -> 595 us, same bits
+      const int waves = tune(ctx, T_FC_DMA_WAVES, 8);
+#ifdef MNC_TUNING
       // tuning builds: 1 every copy re-reads stage 0 (L2-hot operands), 3 only the weight copies do
-      const int dabl = getenv("MNC_FC_DMA_ABL") ? atoi(getenv("MNC_FC_DMA_ABL")) : 0;
-      if (dabl == 1) {
-        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 1>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                           M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-      } else if (dabl == 3) {
-        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 3>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                           M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-      } else if (!(getenv("MNC_FC_DMA_WAVES") && atoi(getenv("MNC_FC_DMA_WAVES")) == 4)) {
-        // eight waves, two per SIMD (default; MNC_FC_DMA_WAVES=4: four waves, one per SIMD): fc6 610 -> 595 us, same bits
-        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 0, 2>), dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                           M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
-      } else
-      hipLaunchKernelGGL((fc_mfma_dma_kernel<10, 0>), dim3(tn * splits * tm), dim3(256), lds, ctx->stream, d_a, d_w, d_bias, d_out, part,
-                         M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);
+      const int dabl = tune(ctx, T_FC_DMA_ABL, 0);
+      if (dabl == 1) MNC_FC_DMA_LAUNCH(1, 1);
+      else if (dabl == 3) MNC_FC_DMA_LAUNCH(3, 1);
+      else
+#endif
+      if (waves == 4) MNC_FC_DMA_LAUNCH(0, 1);
+      else MNC_FC_DMA_LAUNCH(0, 2);
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
     else if (mt == 5) {
+#ifdef MNC_TUNING
+      const int abl = tune(ctx, T_FC_ABL, 0);
       if (abl == 1) MNC_FC_LAUNCH(5, 16, 1);
       else if (abl == 3) MNC_FC_LAUNCH(5, 16, 3);
-      else MNC_FC_LAUNCH(5, 16, 0);
+      else
+#endif
+      MNC_FC_LAUNCH(5, 16, 0);
     } else {
+#ifdef MNC_TUNING
+      const int abl = tune(ctx, T_FC_ABL, 0);
       if (abl == 1) MNC_FC_LAUNCH(10, 32, 1);
       else if (abl == 2) MNC_FC_LAUNCH(10, 32, 2);
       else if (abl == 3) MNC_FC_LAUNCH(10, 32, 3);
       else if (abl == 4) MNC_FC_LAUNCH(10, 32, 4);
-      else MNC_FC_LAUNCH(10, 32, 0);
+      else
+#endif
+      MNC_FC_LAUNCH(10, 32, 0);
     }
 #undef MNC_FC_LAUNCH
+#undef MNC_FC_DMA_LAUNCH
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }

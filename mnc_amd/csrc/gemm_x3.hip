@@ -375,10 +375,10 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     const int tail = M % 320;
     const long cost320 = (long)(M / 320) * 448 + (tail == 0 ? 0 : tail <= 160 ? 288 : 448);
     const long cost256 = (long)cdiv(M, 256) * 384;
-    rows256 = cost256 < cost320 && !getenv("MNC_FC_NO256");
+    rows256 = cost256 < cost320 && !tune(ctx, T_FC_NO256, 0);
   }
   // full 320-row blocks and a ragged tail of at most 160 rows are two launches, each with its own tile height (see mnc_fc)
-  if (!rows256 && M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !getenv("MNC_FC_NOTAIL")) {
+  if (!rows256 && M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !tune(ctx, T_FC_NOTAIL, 0)) {
     const int head = M / 320 * 320;
     int rc = fc_lowp<F16>(ctx, what, d_a, d_pre, mstride, d_w_packed, d_bias, d_out, head, N, K, ldc, act, d_osm, osm_fmt, osm_rows,
                           osm_row0);
@@ -395,8 +395,8 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   // (measured at M = 300, bf16x3: fc7 59 vs 69 us, fc6_maskest 132 vs 151 us, fc6 274 vs 262 us)
   if (mt == 10 && (K / kStage) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < (F16 ? 32 : 64)) mt = 5;
   if (rows256) mt = 8;
-  if (const char* e = getenv("MNC_FCX3_TILE")) {          // tuning override
-    const int v = atoi(e);
+  if (tune_set(ctx, T_FCX3_TILE)) {
+    const int v = tune(ctx, T_FCX3_TILE, 0);
     if (v == 2 || v == 5 || v == 8 || v == 10) mt = v;
   }
   const int bm = 32 * mt;
@@ -432,8 +432,7 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   // neighbours on one XCD and stream it from L2 together instead of once per row block from HBM (measured, fp16, M = 960:
   // N = 4096, K = 50176: 612 -> 555 us; M = 2000, K = 25088: 302 -> 282 us; with two column tiles (N = 256) it is 3 % slower,
   // so only from 8 column tiles on).  MNC_FC_ORDER=0 / 1 forces the column-tile-fastest / row-block-fastest order.
-  static const char* order_env = getenv("MNC_FC_ORDER");
-  const bool rows_fastest = order_env ? atoi(order_env) == 1 : tn >= 8;
+  const bool rows_fastest = tune_set(ctx, T_FC_ORDER) ? tune(ctx, T_FC_ORDER, 0) == 1 : tn >= 8;
   const int tm_arg = (rows_fastest && tm > 1) ? -tm : tm;
   {
     LaunchScope ls(ctx, F16 ? (small ? "fc_f16_small" : "fc_f16") : (small ? "fc_bf16x3_small" : "fc_bf16x3"), flops, bytes);
@@ -447,12 +446,14 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     else if constexpr (F16 != 0) {
       MNC_X3_LAUNCH(10, 2, 0);
     } else {
-      const char* e = getenv("MNC_FCX3_ABL");                       // ablation builds of the split-bf16 kernel (tuning)
-      const int abl = e ? atoi(e) : 0;
+#ifdef MNC_TUNING
+      const int abl = tune(ctx, T_FCX3_ABL, 0);                     // ablation builds of the split-bf16 kernel
       if (abl == 1) MNC_X3_LAUNCH(10, 2, 1);
       else if (abl == 2) MNC_X3_LAUNCH(10, 2, 2);
       else if (abl == 3) MNC_X3_LAUNCH(10, 2, 3);
-      else MNC_X3_LAUNCH(10, 2, 0);
+      else
+#endif
+      MNC_X3_LAUNCH(10, 2, 0);
     }
 #undef MNC_X3_LAUNCH
     rc = ls.finish(F16 ? "fc_x3_kernel<f16>" : "fc_x3_kernel");

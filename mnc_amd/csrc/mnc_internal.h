@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -24,6 +25,25 @@ struct ProfRecord {
 
 }  // namespace mnc
 
+namespace mnc {
+// Per-context overrides of the launchers' own choices (tile shapes, kernel variants, plan switches): mnc_ctx_set_tuning(ctx, "FC_TILE", 5)
+// or, once, at context creation, the environment variable MNC_<NAME>.  They exist so that every variant a launcher can pick by
+// shape is reachable from a test at a small shape, and for A/B measurements; no launch path calls getenv.  Ablation and
+// superseded kernel builds (FC_ABL, FC_DMA_ABL, FCX3_ABL, CONV_ABL, WINO_V = 1, WINO_VAR != 7) are only compiled with -DMNC_TUNING.
+#define MNC_TUNE_KEYS(X)                                                                                                          \
+  X(CONV_COT) X(CONV_ROWS) X(CONV_KSPLIT) X(CONV_ABL) X(CONV1X1_TILE) X(CONV2D_WIDE) X(WINO_ROWS) X(WINO_TAIL) X(WINO_V) X(WINO_VAR)  \
+  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TAIL) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
+  X(FC_NO256) X(FCX3_TILE) X(FC_ORDER) X(FCX3_ABL) X(FC_SM) X(PACKED_ACT) X(FUSE_POOLS) X(BRANCH_STREAMS) X(TOPK_SINGLE_WG)           \
+  X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL)
+enum TuneKey {
+#define MNC_TUNE_ENUM(n) T_##n,
+  MNC_TUNE_KEYS(MNC_TUNE_ENUM)
+#undef MNC_TUNE_ENUM
+  T_COUNT
+};
+constexpr int kTuneUnset = INT_MIN;
+}  // namespace mnc
+
 struct mnc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -43,7 +63,13 @@ struct mnc_ctx {
   unsigned long arena_gen = 0;
   // conventions of the three Caffe layers whose source is unavailable (all zero = oracle/SPEC.md); read by roi.hip's launchers
   mnc_layer_conventions conv = {0, 0, 0, 0, 0, 0, 0.4f, 0};
+  int tune[mnc::T_COUNT];     // kTuneUnset = the launcher decides (filled by mnc_ctx_create; mnc_ctx_set_tuning)
 };
+
+namespace mnc {
+inline bool tune_set(const mnc_ctx* ctx, TuneKey k) { return ctx->tune[k] != kTuneUnset; }
+inline int tune(const mnc_ctx* ctx, TuneKey k, int dflt) { return ctx->tune[k] != kTuneUnset ? ctx->tune[k] : dflt; }
+}  // namespace mnc
 
 namespace mnc {
 

@@ -99,6 +99,7 @@ struct mnc_net {
   float im_scale = 1.0f;
   int tap_key_h = -1, tap_key_w = -1;
   int last_r1 = 0, last_r2 = 0;
+  bool fc_sm = true, fuse_pools = true;   // plan switches, read from the context's tuning values when the net is created
   bool in_flight = false;      // an image has been launched and not fetched: its staging buffers are still in use
   // HIP graph of one image size
   hipGraphExec_t gexec = nullptr;
@@ -200,10 +201,9 @@ int run_fc(mnc_net* n, const mnc_net::Fc& fc, const float* a, float* out, int M,
 }
 // 1 (fp16) / 2 (split bf16): the stage-major activation form this InnerProduct's kernel multiplies from, when the producer of its
 // per-RoI input (C channels per position) can write it (an 8-channel group must not straddle a stage); 0: fp32 rows only.
-// MNC_FC_SM=0 switches the second outputs off (the InnerProduct then converts the fp32 rows itself, as in round 1).
-int sm_format(const mnc_net::Fc& fc, int C) {
-  static const bool off = getenv("MNC_FC_SM") && atoi(getenv("MNC_FC_SM")) == 0;
-  if (off) return 0;
+// FC_SM=0 (mnc_ctx_set_tuning) switches the second outputs off (the InnerProduct then converts the fp32 rows itself, as in round 1).
+int sm_format(const mnc_net* n, const mnc_net::Fc& fc, int C) {
+  if (!n->fc_sm) return 0;
   if (fc.kind == 2) return C % 64 == 0 ? 1 : 0;
   if (fc.kind == 1) return C % 32 == 0 ? 2 : 0;
   return 0;
@@ -257,7 +257,7 @@ int finalize(mnc_net* n) {
     }
     cin = cout;
   }
-  n->packed_trunk = c.math != 0 && !(getenv("MNC_PACKED_ACT") && atoi(getenv("MNC_PACKED_ACT")) == 0);
+  n->packed_trunk = c.math != 0 && tune(n->ctx, T_PACKED_ACT, 1) != 0;
   for (int i = 1; i < 13; ++i) n->packed_trunk = n->packed_trunk && n->conv_fast[i];
   const int A = c.num_anchors, RC = c.rpn_channels;
   {
@@ -332,13 +332,13 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   NET_TRY(dev_ensure(n, &n->m14, (size_t)R * P * P * 4));
   NET_TRY(dev_ensure(n, &n->box7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
   NET_TRY(dev_ensure(n, &n->mask7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
-  if (sm_format(n->fc_maskest, C5)) NET_TRY(dev_ensure(n, &n->feat14_sm, (size_t)R * P * P * C5 * (n->fc_maskest.kind == 2 ? 2 : 4)));
-  if (sm_format(n->fc6, C5)) NET_TRY(dev_ensure(n, &n->box7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6.kind == 2 ? 2 : 4)));
-  if (sm_format(n->fc6m, C5)) NET_TRY(dev_ensure(n, &n->mask7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6m.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc_maskest, C5)) NET_TRY(dev_ensure(n, &n->feat14_sm, (size_t)R * P * P * C5 * (n->fc_maskest.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc6, C5)) NET_TRY(dev_ensure(n, &n->box7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc6m, C5)) NET_TRY(dev_ensure(n, &n->mask7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6m.kind == 2 ? 2 : 4)));
   NET_TRY(dev_ensure(n, &n->f6, (size_t)R * F * 4));
   NET_TRY(dev_ensure(n, &n->f6m, (size_t)R * F * 4));
-  if (sm_format(n->fc7, F)) NET_TRY(dev_ensure(n, &n->f6_sm, (size_t)R * F * (n->fc7.kind == 2 ? 2 : 4)));
-  if (sm_format(n->fc7m, F)) NET_TRY(dev_ensure(n, &n->f6m_sm, (size_t)R * F * (n->fc7m.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc7, F)) NET_TRY(dev_ensure(n, &n->f6_sm, (size_t)R * F * (n->fc7.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc7m, F)) NET_TRY(dev_ensure(n, &n->f6m_sm, (size_t)R * F * (n->fc7m.kind == 2 ? 2 : 4)));
   NET_TRY(dev_ensure(n, &n->join, (size_t)R * 2 * F * 4));
   NET_TRY(dev_ensure(n, &n->heads, (size_t)2 * R * 6 * K * 4));        // both stages' rows (stage 4/5 behind stage 2/3)
   NET_TRY(dev_ensure(n, &n->boxes, (size_t)2 * R * 4 * 4));
@@ -478,7 +478,7 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   const float* conv5 = (const float*)n->act[12].p;
   float* feat14 = (float*)n->feat14.p;
   // stage 2: ROIWarping 28x28 + MAX 2x2/2 fused; stage 4: ROIWarping 14x14 directly (test.prototxt:479-505 vs :809-820)
-  const int sm_feat = sm_format(n->fc_maskest, C5), sm_box = sm_format(n->fc6, C5), sm_mask = sm_format(n->fc6m, C5);
+  const int sm_feat = sm_format(n, n->fc_maskest, C5), sm_box = sm_format(n, n->fc6, C5), sm_mask = sm_format(n, n->fc6m, C5);
   NET_TRY(mnc_roi_warp_sm(ctx, conv5, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14, n->feat14_sm.p,
                           sm_feat));
   float* masks = (float*)n->masks.p + (size_t)row0 * S * S;
@@ -488,8 +488,7 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   float* join = (float*)n->join.p;                                                             // Concat(fc7_mask, fc7): column slices
   // box-feature Pooling and MaskPooling + Pooling read the same 14x14 tensor: one pass (mnc_box_mask_pool) when their
   // InnerProducts take the same activation form (always, with fc6 / fc6_mask of equal shape); MNC_FUSE_POOLS=0: two kernels
-  static const bool fuse_pools = !(getenv("MNC_FUSE_POOLS") && atoi(getenv("MNC_FUSE_POOLS")) == 0);
-  const bool one_pass = fuse_pools && sm_box == sm_mask;
+  const bool one_pass = n->fuse_pools && sm_box == sm_mask;
   if (one_pass)
     NET_TRY(mnc_box_mask_pool(ctx, feat14, (const float*)n->m14.p, (float*)n->box7.p, (float*)n->mask7.p, R, P, P, C5,
                               n->box7_sm.p, n->mask7_sm.p, sm_box));
@@ -502,7 +501,7 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
     MNC_HIP_TRY(hipStreamWaitEvent(cb->stream, n->ev_fork[si], 0));
   }
   if (!one_pass) NET_TRY(mnc_maxpool2_rhwc_sm(cb, feat14, (float*)n->box7.p, R, P, P, C5, n->box7_sm.p, sm_box));
-  const int sm_f6 = sm_format(n->fc7, F), sm_f6m = sm_format(n->fc7m, F);
+  const int sm_f6 = sm_format(n, n->fc7, F), sm_f6m = sm_format(n, n->fc7m, F);
   NET_TRY(run_fc_sm(cb, n->fc6, (const float*)n->box7.p, n->box7_sm.p, sm_box, (float*)n->f6.p, R, F, 1, n->f6_sm.p, sm_f6));
   NET_TRY(run_fc_sm(cb, n->fc7, (const float*)n->f6.p, n->f6_sm.p, n->fc6.kind ? sm_f6 : 0, join + F, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipEventRecord(n->ev_join[si], cb->stream));
@@ -673,7 +672,9 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
   n->ctx = ctx;
   n->cfg = *cfg;
-  if (getenv("MNC_BRANCH_STREAMS") && atoi(getenv("MNC_BRANCH_STREAMS")) == 1) {
+  n->fc_sm = tune(ctx, T_FC_SM, 1) != 0;
+  n->fuse_pools = tune(ctx, T_FUSE_POOLS, 1) != 0;
+  if (tune(ctx, T_BRANCH_STREAMS, 0) == 1) {
     if (mnc_ctx_create(&n->ctx_b, ctx->device) != MNC_OK) n->ctx_b = nullptr;     // optional: the net works on one stream
     if (n->ctx_b) (void)mnc_ctx_set_layer_conventions(n->ctx_b, &cfg->conventions);
     for (int i = 0; i < 2 && n->ctx_b; ++i) {

@@ -368,7 +368,7 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   const int cb = cdiv(topn, 64);
   mnc_proposal_state* st = state_of(ctx);
   const int nruns = cdiv(N, kRun);
-  const bool wide_topk = nruns <= kMaxRuns && getenv("MNC_TOPK_SINGLE_WG") == nullptr;
+  const bool wide_topk = nruns <= kMaxRuns && !tune(ctx, T_TOPK_SINGLE_WG, 0);
   const size_t need = a256((size_t)N * 16) + a256((size_t)N * 8) + a256((size_t)N * 4) + a256((size_t)topn * 4) * 2 + 256 +
                       a256((size_t)topn * cb * 8) + a256((size_t)topn * 4) + 256 + a256((size_t)nruns * kRun * 8);
   if (need > st->bytes) {

@@ -549,10 +549,7 @@ __global__ __launch_bounds__(256) void box_mask_pool_kernel(const float* __restr
 }
 
 // which variant of the two pooling kernels writes the second output: 8 channels per thread (MNC_ROI_SM_VARIANT=4 forces the other)
-static bool sm_variant8(bool) {
-  const char* e = getenv("MNC_ROI_SM_VARIANT");
-  return e ? atoi(e) == 8 : true;
-}
+static bool sm_variant8(const mnc_ctx* ctx) { return tune(ctx, T_ROI_SM_VARIANT, 8) == 8; }
 
 static bool sm_ok(int C, int fmt) { return fmt == 1 ? C % 64 == 0 : fmt == 2 ? C % 32 == 0 : false; }
 
@@ -630,8 +627,7 @@ int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, cons
 #undef MNC_WARPC
     return ls.finish("roi_warp_conv_kernel");
   }
-  const char* variant = getenv("MNC_ROI_WARP_VARIANT");
-  const int vsel = variant ? atoi(variant) : ((pool2 || C >= 1024) ? 1 : 4);
+  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, (pool2 || C >= 1024) ? 1 : 4);
   if (vsel != 4 && vsel != 8) {
     MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
     const int g = grid_for((long)R * PH * PW * 64);
@@ -734,7 +730,7 @@ int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, int R, i
   if (R == 0) return MNC_OK;
   MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_maxpool2_rhwc: tensor exceeds the kernel's 32-bit index range");
   LaunchScope ls(ctx, "maxpool2_rhwc", 0.0, 4.0 * R * (double)C * PH * PW * 1.25);
-  if (sm_fmt && sm_variant8(false)) {
+  if (sm_fmt && sm_variant8(ctx)) {
     const int g8 = grid_for((long)R * (PH / 2) * (PW / 2) * (C / 8));
     if (sm_fmt == 1) hipLaunchKernelGGL(maxpool2_rhwc8_kernel<1>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
     else hipLaunchKernelGGL(maxpool2_rhwc8_kernel<2>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
@@ -774,7 +770,7 @@ int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, flo
   const int OH = pool2 ? PH / 2 : PH, OW = pool2 ? PW / 2 : PW;
   LaunchScope ls(ctx, pool2 ? "mask_pool_pool2" : "mask_pool", 0.0, 4.0 * R * (double)C * (PH * PW + OH * OW));
   const long total = (long)R * OH * OW * (C / 4);
-  if (sm_fmt && sm_variant8(false)) {
+  if (sm_fmt && sm_variant8(ctx)) {
 #define MNC_MP8(P2, SM)                                                                                                     \
   hipLaunchKernelGGL((mask_pool8_kernel<P2, SM>), dim3(grid_for(total / 2)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, \
                      PH, PW, C / 8, d_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)

@@ -50,6 +50,12 @@ class Dev(object):
     def sync(self):
         _lib.call("mnc_ctx_sync", self.h)
 
+    def tune(self, name, value):
+        """mnc_ctx_set_tuning: value None = the library's own choice again."""
+        n = ctypes.c_char_p(name.encode())
+        v = ctypes.c_char_p(str(value).encode()) if value is not None else None
+        _lib.call("mnc_ctx_set_tuning", self.h, ctypes.cast(n, ctypes.c_void_p), ctypes.cast(v, ctypes.c_void_p) if v else None)
+
     def close(self):
         if self.h:
             for p in self._ptrs:

@@ -29,6 +29,22 @@ def dev():
     d.close()
 
 
+TUNING_BUILD = b"tuning" in _lib.load().mnc_version()     # built with MNC_HIPCC_EXTRA=-DMNC_TUNING (ablation / superseded kernels)
+
+
+@pytest.fixture
+def tune(dev):
+    """tune(name, value): override one of the launchers' choices on the module's context (mnc_ctx_set_tuning) for this test."""
+    keys = []
+
+    def set_(name, value):
+        keys.append(name)
+        dev.tune(name, value)
+    yield set_
+    for k in keys:
+        dev.tune(k, None)
+
+
 def _conv_ref(x, w, b, relu=True, pad=1):
     y = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), torch.from_numpy(b), padding=pad)
     return (F.relu(y) if relu else y)[0].numpy()
@@ -61,7 +77,7 @@ def test_conv3x3_mfma(dev, H, W, Cin, Cout, relu):
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (75, 125, 64, 64), (5, 3, 8, 32), (38, 63, 128, 64),
                                                         (75, 125, 256, 512), (37, 63, 256, 512)])
 @pytest.mark.parametrize("relu", [1, 0])
-def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
+def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu, tune):
     """mnc_conv3x3_wino (Winograd F(2x2,3x3) on the fp32 matrix pipe) against torch fp32 and against the direct kernel: odd
     heights / widths (partial 2x2 tiles at the border), every workgroup height, K splits.  The transforms are exact in fp32
     except for the summation order, so the bar is the direct kernel's own (1e-4 of the output range; measured ~1e-6).
@@ -87,15 +103,17 @@ def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu):
                           (None, None, "3"), (None, None, "1"), (None, None, "0"), ("2", "2", "1"), (None, None, "notail")):
         if ks is not None and (Cin // 8) % int(ks):
             continue
-        for k in ("MNC_WINO_ROWS", "MNC_CONV_KSPLIT", "MNC_WINO_VAR", "MNC_WINO_TAIL"):
-            monkeypatch.delenv(k, raising=False)
+        if var in ("3", "1", "0") and not TUNING_BUILD:          # superseded loop builds: only in -DMNC_TUNING libraries
+            continue
+        for k in ("WINO_ROWS", "CONV_KSPLIT", "WINO_VAR", "WINO_TAIL"):
+            dev.tune(k, None)
         if rows is not None:
-            monkeypatch.setenv("MNC_WINO_ROWS", rows)
-            monkeypatch.setenv("MNC_CONV_KSPLIT", ks)
+            tune("WINO_ROWS", rows)
+            tune("CONV_KSPLIT", ks)
         if var == "notail":
-            monkeypatch.setenv("MNC_WINO_TAIL", "0")
+            tune("WINO_TAIL", "0")
         elif var is not None:
-            monkeypatch.setenv("MNC_WINO_VAR", var)
+            tune("WINO_VAR", var)
         dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
         dev.call("mnc_conv3x3_wino", d_x, d_w, d_b, d_y, H, W, Cin, Cout, relu)
         got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
@@ -289,11 +307,11 @@ GEN_CONV = [  # H, W, Cin, Cout, K, stride, pad, residual   (ResNet-50 shapes in
 
 @pytest.mark.parametrize("H,W,Cin,Cout,K,stride,pad,residual", GEN_CONV)
 @pytest.mark.parametrize("relu,wide", [(1, False), (0, False), (1, True)])
-def test_conv2d_general(dev, monkeypatch, H, W, Cin, Cout, K, stride, pad, residual, relu, wide):
+def test_conv2d_general(dev, monkeypatch, H, W, Cin, Cout, K, stride, pad, residual, relu, wide, tune):
     """mnc_conv2d (any kernel / stride / pad, + bias + residual + ReLU) against torch fp32; `wide` = the 128-channel workgroup
     tile (MNC_CONV2D_WIDE, a tuning knob -- the 64-channel tile is the default)."""
     if wide:
-        monkeypatch.setenv("MNC_CONV2D_WIDE", "1")
+        tune("CONV2D_WIDE", "1")
     rng = np.random.default_rng(H * 100 + W + K)
     x = rng.normal(size=(Cin, H, W)).astype(np.float32)
     w = (rng.normal(size=(Cout, Cin, K, K)) * np.sqrt(2.0 / (K * K * Cin))).astype(np.float32)
@@ -353,7 +371,7 @@ C11 = [(13, 17, 16, 8, 1, False), (13, 17, 16, 24, 1, True), (20, 33, 32, 72, 2,
 
 @pytest.mark.parametrize("H,W,Cin,Cout,stride,residual", C11)
 @pytest.mark.parametrize("relu", [1, 0])
-def test_conv1x1_fp32(dev, monkeypatch, H, W, Cin, Cout, stride, residual, relu):
+def test_conv1x1_fp32(dev, monkeypatch, H, W, Cin, Cout, stride, residual, relu, tune):
     """mnc_conv1x1 (fp32 matrix pipe, operands straight from the c8 tensors) against torch fp32, default tile and two forced ones."""
     rng = np.random.default_rng(H * 100 + W + Cin)
     x = rng.normal(size=(Cin, H, W)).astype(np.float32)
@@ -370,7 +388,7 @@ def test_conv1x1_fp32(dev, monkeypatch, H, W, Cin, Cout, stride, residual, relu)
     d_x, d_b, d_r = dev.put(to_c8(x)), dev.put(b), dev.put(to_c8(res)) if residual else None
     for tile in (None, "4,2", "1,1", "2,1"):
         if tile:
-            monkeypatch.setenv("MNC_CONV1X1_TILE", tile)
+            tune("CONV1X1_TILE", tile)
         d_y = dev.empty((Cout * OH * OW,), fill=np.nan)
         dev.call("mnc_conv1x1", d_x, d_w, d_b, d_r, d_y, H, W, Cin, Cout, stride, relu)
         got = from_c8(dev.get(d_y, (Cout * OH * OW,)), Cout, OH, OW)
@@ -381,7 +399,7 @@ def test_conv1x1_fp32(dev, monkeypatch, H, W, Cin, Cout, stride, residual, relu)
 
 @pytest.mark.parametrize("H,W,Cin,Cout,stride,residual", C11)
 @pytest.mark.parametrize("res_packed,out_packed", [(1, 1), (0, 0), (1, 0), (0, 1)])
-def test_conv1x1_f16_packed(dev, monkeypatch, H, W, Cin, Cout, stride, residual, res_packed, out_packed):
+def test_conv1x1_f16_packed(dev, monkeypatch, H, W, Cin, Cout, stride, residual, res_packed, out_packed, tune):
     """mnc_conv1x1_f16_pk: packed fp16 c8 activations in, packed fp16 or fp32 out, residual in either form.  Against torch on the
     same fp16-rounded operands the fp32 result agrees to accumulation order (1e-5 of range); a packed output is that result
     rounded to fp16 once (half an fp16 ulp of the value on top)."""
@@ -408,7 +426,7 @@ def test_conv1x1_f16_packed(dev, monkeypatch, H, W, Cin, Cout, stride, residual,
         d_r = dev.put(to_c8(res).astype(np.float16), dtype=np.float16) if res_packed else dev.put(to_c8(res))
     for tile in (None, "4,2", "1,2"):
         if tile:
-            monkeypatch.setenv("MNC_CONV1X1_TILE", tile)
+            tune("CONV1X1_TILE", tile)
         n = Cout * OH * OW
         d_y = dev.empty((n,), fill=np.nan)
         dev.call("mnc_conv1x1_f16_pk", d_x, d_w, dev.put(b), d_r, d_y, H, W, Cin, Cout, stride, 1, res_packed, out_packed)
@@ -525,11 +543,11 @@ def _rois(rng, R, W, H):
 
 @pytest.mark.parametrize("pool2,P", [(0, 14), (1, 14), (0, 7)])
 @pytest.mark.parametrize("variant", [None, "1", "4"])
-def test_roi_warp(dev, monkeypatch, pool2, P, variant):
+def test_roi_warp(dev, monkeypatch, pool2, P, variant, tune):
     """(variant: the library's choice by channel count, or MNC_ROI_WARP_VARIANT forcing the one-wave-per-position / the
     4-channels-per-thread kernel -- all bit-exact with the oracle, rois partly and wholly outside the map included.)"""
     if variant:
-        monkeypatch.setenv("MNC_ROI_WARP_VARIANT", variant)
+        tune("ROI_WARP_VARIANT", variant)
     rng = np.random.default_rng(4)
     C, H, W, R = 64, 38, 63, 40
     feat = rng.normal(size=(C, H, W)).astype(np.float32)
@@ -546,14 +564,14 @@ def test_roi_warp(dev, monkeypatch, pool2, P, variant):
 
 @pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("variant", [None, "4", "8"])
-def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, variant):
+def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, variant, tune):
     """(variant: the library's choice, or MNC_ROI_SM_VARIANT forcing the 4- / 8-channels-per-thread kernels.)
     mnc_roi_warp_sm / mnc_maxpool2_rhwc_sm / mnc_mask_pool_sm: the fp32 output is bit for bit that of the plain entry point, and
     the second output is bit for bit what mnc_fc_pack_act (the InnerProduct's own conversion pass) makes of it -- fp16 stage-major
     (fmt 1) and split bf16 stage-major (fmt 2)."""
     if variant:
-        monkeypatch.setenv("MNC_ROI_SM_VARIANT", variant)
-        monkeypatch.setenv("MNC_ROI_WARP_VARIANT", {"4": "4", "8": "8"}[variant])
+        tune("ROI_SM_VARIANT", variant)
+        tune("ROI_WARP_VARIANT", {"4": "4", "8": "8"}[variant])
     rng = np.random.default_rng(40 + fmt)
     C, H, W, R, P = 64, 38, 63, 37, 14
     feat = rng.normal(size=(C, H, W)).astype(np.float32)
@@ -570,7 +588,7 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
         if wave:
             if variant:
                 continue
-            monkeypatch.setenv("MNC_ROI_WARP_VARIANT", "1")         # the one-wave-per-position kernel writes it too
+            tune("ROI_WARP_VARIANT", "1")         # the one-wave-per-position kernel writes it too
         K = P * P * C
         d_a, d_b = dev.empty((R * K,), fill=np.nan), dev.empty((R * K,), fill=np.nan)
         d_sm = dev.empty((R * K * eb,), dtype=np.uint8, fill=0xAB)
@@ -578,7 +596,7 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
         dev.call("mnc_roi_warp_sm", d_feat, C, H, W, d_rois, R, P, P, 0.0625, pool2, d_b, d_sm, fmt)
         assert np.array_equal(dev.get(d_a, (R * K,)), dev.get(d_b, (R * K,)))
         assert np.array_equal(dev.get(d_sm, (R * K * eb,), dtype=np.uint8), shadow_of(d_b, R, K)), ("roi_warp", pool2, wave)
-    monkeypatch.delenv("MNC_ROI_WARP_VARIANT", raising=False)
+    dev.tune("ROI_WARP_VARIANT", None)
     # Pooling and MaskPooling on the 14x14 tensor
     x = rng.normal(size=(R, P, P, C)).astype(np.float32)
     m = rng.uniform(0, 1, (R, P, P)).astype(np.float32)
@@ -764,7 +782,7 @@ def test_fc_mfma(dev, M, N, K, act):
 
 @pytest.mark.parametrize("M,N,K,act,ldc_pad", [(300, 4096, 25088, 1, 0), (300, 520, 4096, 1, 8), (290, 1024, 2112, 0, 0),
                                                (640, 256, 6400, 1, 0), (161, 128, 8192, 2, 64)])
-def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad):
+def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
     """fc_mfma_dma_kernel (320-row blocks, operand panels copied global -> LDS by DMA into XOR-swizzled rows; fc6's kernel):
     against torch, and against the register-staged kernel (MNC_FC_DMA=0) on the same call -- the products and the order inside a
     K split are the same, the split boundaries differ (even stage counts).  MNC_FC_TILE=10 puts shapes on it that the tile
@@ -778,14 +796,14 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad):
     ld = N + ldc_pad
     y = F.linear(torch.from_numpy(a), torch.from_numpy(w), torch.from_numpy(b))
     want = (F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y).numpy()
-    monkeypatch.setenv("MNC_FC_TILE", "10")
+    tune("FC_TILE", "10")
     outs = []
     for dma in ("1", "0", "4"):        # default: eight waves (two per SIMD); "4": the four-wave build of the DMA kernel
-        monkeypatch.setenv("MNC_FC_DMA", "0" if dma == "0" else "1")
+        tune("FC_DMA", "0" if dma == "0" else "1")
         if dma == "4":
-            monkeypatch.setenv("MNC_FC_DMA_WAVES", "4")
+            tune("FC_DMA_WAVES", "4")
         else:
-            monkeypatch.delenv("MNC_FC_DMA_WAVES", raising=False)
+            dev.tune("FC_DMA_WAVES", None)
         d_o = dev.empty((M * ld,), fill=np.nan)
         dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
         got = dev.get(d_o, (M, ld))
@@ -987,7 +1005,7 @@ def test_fc_full_size_linearity(dev, fn, pack):
 
 @pytest.mark.parametrize("fh,fw,seed,quant", [(38, 63, 3, False), (12, 20, 2, False), (38, 63, 5, True), (63, 63, 6, False),
                                               (50, 84, 7, True)])
-def test_proposal_layer_golden_and_both_topk_paths(dev, golden, monkeypatch, fh, fw, seed, quant):
+def test_proposal_layer_golden_and_both_topk_paths(dev, golden, monkeypatch, fh, fw, seed, quant, tune):
     """mnc_proposal (device-resident ProposalLayer.forward, lib/pylayer/proposal_layer.py:52-175) on stand-alone RPN outputs:
     rois == the oracle's ProposalLayer == the reference's own layer (golden `prop_*_rois`), bit for bit, with the multi-workgroup
     top-K (sorted runs + rank merge) and with the single-workgroup radix select (MNC_TOPK_SINGLE_WG=1); scores quantised to 1/64
@@ -1008,9 +1026,9 @@ def test_proposal_layer_golden_and_both_topk_paths(dev, golden, monkeypatch, fh,
     results = []
     for single in (False, True):
         if single:
-            monkeypatch.setenv("MNC_TOPK_SINGLE_WG", "1")
+            tune("TOPK_SINGLE_WG", "1")
         else:
-            monkeypatch.delenv("MNC_TOPK_SINGLE_WG", raising=False)
+            dev.tune("TOPK_SINGLE_WG", None)
         num = ctypes.c_int(-1)
         dev.call("mnc_proposal", d_prob, d_bbox, 9, fh, fw, _lib.ptr(anchors), 16, float(info[0, 0]), float(info[0, 1]),
                  float(info[0, 2]), 6000, 300, 0.7, 16.0, d_rois, ctypes.addressof(num))
