@@ -161,7 +161,7 @@ def main():
         proto = models.write_mnc_resnet50_test_prototxt()
     else:
         proto = models.write_mnc_5stage_test_prototxt()
-    weights = synth.synthetic_weights(proto, seed=0)
+    weights = shared_weights(proto, synth, rank, world, dist if launched else None)
     # BASELINE.md section 3 inputs: uint8 images ~ U{0..255}, seeds 0..7; rank r starts the rotation at image r
     images = [np.random.default_rng(s).integers(0, 256, (H, W, 3), dtype=np.uint8) for s in range(N_IMAGES)]
     nms_t, iou_t = float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH)
@@ -320,11 +320,7 @@ def main():
             name, (cnt, tot_ms, tot_fl, tot_by) = max(agg.items(), key=lambda kv: kv[1][1])
             if tot_fl > 0:
                 ach = tot_fl / (tot_ms * 1e-3) / 1e12
-                x3, f16 = "bf16x3" in name, "f16" in name
-                peak = PEAK_BF16_MATRIX_TFLOPS / 3.0 if x3 else PEAK_BF16_MATRIX_TFLOPS if f16 else PEAK_FP32_MATRIX_TFLOPS
-                basis = ("bf16 dense MFMA peak %.0f TFLOP/s / 3 bf16 products per fp32-class product" % PEAK_BF16_MATRIX_TFLOPS
-                         if x3 else "fp16 dense MFMA peak (v_mfma_f32_32x32x16_f16)" if f16 else
-                         "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)")
+                peak, basis = mfma_peak(name)
                 out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                    "frac": ach / peak, "traffic": None, "launches_per_image": cnt / steps,
                                    "avg_launch_ms": tot_ms / cnt, "algorithmic_gflop_per_launch": tot_fl / cnt / 1e9,
@@ -334,14 +330,50 @@ def main():
                 out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "launches_per_image": cnt / steps,
                                    "avg_launch_ms": tot_ms / cnt}
-            out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(out["roofline"]["kernel"])
+            out["roofline_by_kernel"] = roofline_by_kernel(records, steps)
         return out
 
+    def roofline_by_kernel(records, steps):
+        """One entry per (profiling scope, shape): the dominant InnerProduct split into its three shapes, the Winograd trunk with
+        algorithmic AND executed flop, conv1_1 against HBM.  Same events as `roofline` (HIP events on the engine's stream)."""
+        groups = {}
+        for name, kms, fl, by in records:
+            g = groups.setdefault((name, round(fl / 1e7)), [name, 0, 0.0, fl, by])
+            g[1] += 1; g[2] += kms
+        rows = []
+        for (name, _), (_, cnt, tot_ms, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+            avg_s = tot_ms / cnt * 1e-3
+            label = FC_SHAPES.get((name, round(fl / 1e9, 2)), name)
+            e = {"scope": name, "what": label, "launches_per_image": round(cnt / steps, 3), "avg_launch_ms": tot_ms / cnt,
+                 "ms_per_image": tot_ms / steps, "algorithmic_gflop_per_launch": fl / 1e9, "algorithmic_mb_per_launch": by / 1e6}
+            hbm_frac = by / avg_s / 1e9 / PEAK_HBM_GBS if by else None
+            if fl >= 1e9 and name not in HBM_BOUND_SCOPES:
+                peak, basis = mfma_peak(name)
+                e.update(bound="mfma", achieved=fl / avg_s / 1e12, peak=peak, unit="TFLOP/s", frac=fl / avg_s / 1e12 / peak,
+                         peak_basis=basis)
+                if "wino" in name:          # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
+                    ex = fl / 2.25
+                    e.update(executed_gflop_per_launch=ex / 1e9, executed_tflops=ex / avg_s / 1e12,
+                             executed_frac_of_peak=ex / avg_s / 1e12 / peak,
+                             note="frac = algorithmic (direct-form) flop / time / peak, can exceed what the pipe executes; "
+                                  "executed_* = the MFMA work Winograd F(2x2,3x3) actually issues (algorithmic / 2.25)")
+                e["hbm_frac_algorithmic"] = hbm_frac
+            else:
+                e.update(bound="hbm", achieved=by / avg_s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
+            pos = FC_POSITIONS.get(label)
+            e["traffic"], e["traffic_source"] = pmc_traffic(name, positions=pos)
+            if e["traffic"] and by:
+                e["traffic_over_algorithmic"] = e["traffic"] / by
+            rows.append(e)
+        return rows
     want_resident = world == 1 and not args.no_resident and args.engine == "python"
     m = measure(math, args.steps, args.warmup, resident_steps=min(args.steps, 50) if want_resident else 0,
                 pipelined_steps=0 if args.no_resident else min(args.steps, 100))
     elapsed = m["elapsed"]
-    ranks = [{"rank": rank, "device": dev_id}]
+    # every rank's own clock next to the max-over-ranks one: a straggler shows up as one large ms_per_step
+    ranks = [{"rank": rank, "device": dev_id, "host": socket.gethostname(), "ms_per_step": 1e3 * elapsed / args.steps,
+              "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}]
     if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -373,6 +405,20 @@ def main():
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
         }
         out.update(summarise(args.steps, m))
+        conv = [r for r in m["records"] if r[0].startswith("conv3x3")]
+        if conv and out.get("event_steps"):
+            # north_star: images/s "as fraction of the conv roofline".  conv roofline = the trunk + RPN convolutions' algorithmic
+            # (direct-form) flop at the dense MFMA peak of the math mode; Winograd executes 2.25x fewer (roofline_by_kernel).
+            ev = out["event_steps"]
+            fl, ms_c = sum(r[2] for r in conv) / ev, sum(r[1] for r in conv) / ev
+            peak, basis = mfma_peak(max(conv, key=lambda r: r[2])[0])
+            at_peak = peak * 1e12 / fl
+            out["conv_roofline"] = {
+                "conv_gflop_per_image": fl / 1e9, "conv_ms_per_image": ms_c, "conv_achieved_tflops": fl / ms_c / 1e9,
+                "peak_tflops": peak, "peak_basis": basis, "conv_kernels_frac_of_peak": fl / ms_c / 1e9 / peak,
+                "images_per_s_at_conv_roofline": at_peak, "value_as_frac_of_conv_roofline": out["value"] / world / at_peak,
+                "definition": "conv roofline = images/s one GPU would reach if the 3x3 convolutions (trunk + rpn_conv, algorithmic "
+                              "direct-form flop) ran at the dense MFMA peak and nothing else took time; per-GPU value / that"}
         out["config"]["engine"] = (("native: one mnc_forward_image call per image (csrc/pipeline.hip); the image size's captured HIP "
                                     "graph is replayed, every %d%s timed step runs as direct launches with HIP events around the MFMA "
                                     "kernels" % (max(1, args.event_every), {1: "st", 2: "nd", 3: "rd"}.get(max(1, args.event_every), "th")))
@@ -426,6 +472,33 @@ def main():
         dist.destroy_process_group()
 
 
+def shared_weights(proto, synth, rank, world, dist):
+    """Seeded synthetic weights, generated ONCE per node: under a launcher with several ranks, rank 0 synthesises them (1.1 GB of
+    normal deviates on up to 16 threads -- eight ranks doing that at once would oversubscribe the host at start-up) and writes the
+    flat MNCW0001 container (mnc_amd.caffemodel.save_flat, what mnc_net_load_file reads) to shared memory; the other ranks map
+    it.  Every rank then uploads its own copy to its GPU (the replicated-weights layout of SURVEY 8e)."""
+    if dist is None or world == 1:
+        return synth.synthetic_weights(proto, seed=0)
+    import tempfile
+    from mnc_amd import caffemodel
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(base, "mnc_bench_weights_%s_%s.mncw" % (os.environ.get("MASTER_PORT", "0"), os.path.basename(proto)))
+    if rank == 0:
+        w = synth.synthetic_weights(proto, seed=0)
+        caffemodel.save_flat(w, path + ".tmp")
+        os.replace(path + ".tmp", path)
+    dist.barrier()
+    if rank != 0:
+        w = caffemodel.load_flat(path)
+    dist.barrier()                      # everybody has the file mapped: the name can go (the pages stay while mapped)
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return w
+
+
 def resnet50_line():
     """BASELINE configs[4] (ResNet-50 C4 trunk, 800x1333, 1000 proposals, fp16 math) measured with the same step and schema by a
     child process of this file, so that the driver's plain `python bench.py` line carries it too.  -> the child's JSON line,
@@ -446,30 +519,59 @@ def resnet50_line():
 
 # profiling scope of the engine -> the kernels (rocprofv3 names, regular expressions) launched inside it
 PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"conv3x3_wino2?_kernel",
-              "fc_mfma": r"fc_mfma_(dma_)?kernel<(10|5),", "fc_mfma_small": r"fc_mfma_kernel<2,",
+              "fc_mfma": r"fc_mfma_(dma_)?kernel<(10|5),", "fc_mfma_small": r"fc_mfma_kernel<2,", "conv3x3_c3": r"conv3x3_c3_kernel",
               "conv3x3_bf16x3": r"conv3x3_x3_kernel<\d+, \d+, \d+, 0,", "conv3x3_f16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 1,",
               "fc_bf16x3": r"fc_x3_kernel<\d+, \d+, \d+, 0>", "fc_f16": r"fc_x3_kernel<\d+, \d+, \d+, 1>"}
+HBM_BOUND_SCOPES = {"conv3x3_c3"}          # conv1_1: 2 GFLOP over 161 MB -- bound by writing its output
+# the big InnerProducts of one 300-RoI head stage by algorithmic GFLOP, and their positions in the 10-launch
+# cycle of the InnerProduct kernel per image (tools/pmc_report.py --cycle): fc6_maskest, fc6, fc7, fc6_mask, fc7_mask, twice
+FC_SHAPES = {("fc_mfma", 15.41): "fc6_maskest (300 x 256 x 100352)", ("fc_mfma", 61.66): "fc6 / fc6_mask (300 x 4096 x 25088)",
+             ("fc_mfma", 10.07): "fc7 / fc7_mask (300 x 4096 x 4096)"}
+FC_POSITIONS = {"fc6_maskest (300 x 256 x 100352)": (0, 5), "fc6 / fc6_mask (300 x 4096 x 25088)": (1, 3, 6, 8),
+                "fc7 / fc7_mask (300 x 4096 x 4096)": (2, 4, 7, 9)}
 
 
-def pmc_traffic(scope_name):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this build, as committed in
-    profiles/pmc_latest.json by tools/prof_round.sh + tools/pmc_report.py (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE).  bench.py cannot run rocprofv3 on
-    itself, so this is null when no profile has been committed."""
+def mfma_peak(scope_name):
+    x3, f16 = "bf16x3" in scope_name, "f16" in scope_name
+    if x3:
+        return PEAK_BF16_MATRIX_TFLOPS / 3.0, "bf16 dense MFMA peak %.0f TFLOP/s / 3 bf16 products per fp32-class product" % PEAK_BF16_MATRIX_TFLOPS
+    if f16:
+        return PEAK_BF16_MATRIX_TFLOPS, "fp16 dense MFMA peak (v_mfma_f32_32x32x16_f16)"
+    return PEAK_FP32_MATRIX_TFLOPS, "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)"
+
+
+def pmc_traffic(scope_name, positions=None):
+    """-> (HBM bytes per launch, source) of a scope's kernel from the rocprofv3 PMC passes committed in profiles/pmc_latest.json
+    (tools/prof_round.sh + tools/pmc_report.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
+    gfx950, + WRITE_SIZE) -- ONLY when that profile was taken on the build this process runs (the JSON's "_build" equals
+    mnc_amd._build.source_hash()); otherwise (None, why).  bench.py cannot run rocprofv3 on itself.  positions: average only these
+    positions of the kernel's per-image launch cycle (shapes sharing one template instantiation)."""
+    import re
+    from mnc_amd import _build
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             data = json.load(f)
     except (OSError, ValueError):
-        return None
-    import re
+        return None, "no profiles/pmc_latest.json"
+    have, want_build = data.get("_build"), _build.source_hash()
+    if have != want_build:
+        return None, "profiles/pmc_latest.json is of build %s, this is build %s" % (have, want_build)
     want = re.compile(PMC_KERNEL.get(scope_name, re.escape(scope_name)))
     calls = tot = 0.0
     for k, v in data.items():
-        if want.match(k):
+        if k.startswith("_") or not want.match(k):
+            continue
+        if positions is not None and v.get("by_position"):
+            for pidx in positions:
+                calls += 1
+                tot += v["by_position"][pidx]["hbm_bytes_corrected"]
+        else:
             calls += v["calls"]
             tot += v["calls"] * v["hbm_bytes_corrected"]
-    return tot / calls if calls else None
+    if not calls:
+        return None, "kernel not in profiles/pmc_latest.json"
+    return tot / calls, "rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, profiles/pmc_latest.json, build %s" % have
 
 
 def cpu_baseline(weights, im, n_images):

@@ -54,6 +54,21 @@ def _flags_match():
         return False
 
 
+def source_hash():
+    """16 hex digits over the kernel sources, the internal headers and the public header -- the identity of a build.  Profiles
+    (profiles/pmc_latest.json) carry it; bench.py reports counter traffic only from a profile of the build it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    paths = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    paths.append(os.path.join(HERE, "..", "include", "mnc_hip.h"))
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(_base_flags()).encode())
+    return h.hexdigest()[:16]
+
+
 def up_to_date():
     return os.path.isfile(LIB) and os.path.getmtime(LIB) >= _deps_mtime() and _flags_match()
 
@@ -96,4 +111,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -172,3 +172,29 @@ def save_flat(weights, path):
             nm = lname.encode()
             f.write(struct.pack("<H", len(nm)) + nm + struct.pack("<BB", i, a.ndim) + struct.pack("<%dI" % a.ndim, *a.shape))
             f.write(a.tobytes())
+
+
+def load_flat(path):
+    """The flat MNCW0001 container (save_flat) -> {"<layer>": [W, b]} as read-only memory maps of the file: nothing is copied,
+    ranks that map the same file share its pages (bench.py: one rank synthesises / converts the weights, the others map them)."""
+    import struct
+    weights = {}
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if head[:8] != b"MNCW0001":
+            raise ValueError("%s is not an MNCW0001 file" % path)
+        (n,) = struct.unpack("<I", head[8:])
+        for _ in range(n):
+            (ln,) = struct.unpack("<H", f.read(2))
+            name = f.read(ln).decode()
+            idx, nd = struct.unpack("<BB", f.read(2))
+            dims = struct.unpack("<%dI" % nd, f.read(4 * nd))
+            count = int(np.prod(dims)) if nd else 1
+            off = f.tell()
+            a = np.memmap(path, dtype="<f4", mode="r", offset=off, shape=tuple(dims)) if count else np.zeros(dims, "<f4")
+            f.seek(off + 4 * count)
+            blobs = weights.setdefault(name, [])
+            while len(blobs) <= idx:
+                blobs.append(None)
+            blobs[idx] = a
+    return weights

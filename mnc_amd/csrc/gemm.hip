@@ -572,9 +572,11 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   // of each other on every FC of the heads (MNC_FC_TILE=5|10 overrides).
   const bool small = 2.0 * M * (double)N * K < 2.0e9;
   int mt = small ? 2 : (M <= 160 ? 5 : 10);            // row tiles per workgroup (all of them are always multiplied)
-  // when the K splits of the 320-row variant would be shorter than 64 stages (fc7, fc6_maskest), 160-row blocks are a few
-  // per cent faster (measured: 107 vs 112 us, 160 vs 169 us; fc6 stays at 320 rows: 615 vs 625 us)
-  if (mt == 10 && (K / 32) / cdiv(256, cdiv(N, kBN) * cdiv(M, 320)) < 64) mt = 5;
+  // When the K splits of the 320-row variant would be shorter than 64 stages (fc7, fc6_maskest), 160-row blocks were a few per
+  // cent faster than the REGISTER-STAGED 320-row kernel (round 1: 107 vs 112 us, 160 vs 169 us).  Against the LDS-DMA kernel
+  // (K % 64 == 0) they lose: fc7 105.7 -> 100.7 us, fc6_maskest 159.6 -> 153.5 us on the 320-row DMA kernel (round 3,
+  // kernel_bench fc), and the weights are streamed once instead of once per row block -- so the rule only applies without it.
+  if (mt == 10 && (K % 64 != 0 || tune(ctx, T_FC_DMA, 1) == 0) && (K / 32) / cdiv(256, cdiv(N, kBN) * cdiv(M, 320)) < 64) mt = 5;
   if (tune_set(ctx, T_FC_TILE)) {
     const int v = tune(ctx, T_FC_TILE, 0);
     if (!small && (v == 5 || v == 10)) mt = v;

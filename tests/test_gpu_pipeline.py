@@ -208,3 +208,27 @@ def test_c_program_drives_one_image_without_python(tmp_path):
         assert "instances %d" % counts[0] in r.stdout
     finally:
         nat.close()
+
+
+def test_bench_launcher_two_ranks_native_engine_on_one_gpu():
+    """De-risking the first 8-rank run on hardware this box cannot provide: `bench.py --gpus 2 --dist-backend gloo` starts two
+    ranks of the NATIVE engine under torch.distributed.run on the one GPU here -- the launcher path (self-launch, torch-first import
+    order, rank-0-only weight synthesis + the shared flat container mapped by rank 1, image sharding, per-step gather of the
+    instance blocks, barrier + max-over-ranks timing, per-rank figures in the JSON line) end to end; only the transport of the
+    gather differs from the RCCL run (host tensors through gloo: two RCCL ranks need two devices)."""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "6",
+                        "--warmup", "2", "--no-cpu-baseline", "--no-alt-math", "--no-resnet", "--no-resident"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["images_per_step"] == 2 and d["dist_backend"] == "gloo"
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and all(x["ms_per_step"] > 0 for x in d["ranks"])
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["ms_per_step"] >= max(x["ms_per_step"] for x in d["ranks"]) * 0.999       # the max over ranks is what is reported
+    assert "native" in d["config"]["engine"]
