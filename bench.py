@@ -84,9 +84,11 @@ def parse():
     p.add_argument("--no-resnet", action="store_true",
                    help="skip the BASELINE configs[4] measurement (ResNet-50 C4, 800x1333, 1000 RoIs, f16) that the default N = 1 "
                         "run appends as `config_resnet50` (a child process: python bench.py --config resnet50)")
-    p.add_argument("--engine", default="native", choices=["native", "python"],
+    p.add_argument("--engine", default="native", choices=["native", "graph", "python"],
                    help="native: one C call per image (mnc_forward_image, csrc/pipeline.hip; vgg16 only); python: the caffe-shaped "
-                        "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body)")
+                        "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
+                        "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
+                        "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
     return p.parse_args()
 
@@ -118,8 +120,10 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     conf = CONFIGS[args.config]
     math = args.math or conf["math"]
-    if args.config != "vgg16":
-        args.engine = "python"               # the native pipeline is the VGG-16 5-stage graph; other graphs run on the engine
+    if args.config != "vgg16" and args.engine == "native":
+        # the hand-written native pipeline is the VGG-16 5-stage graph; any other prototxt runs on the engine's plan, captured
+        # into a HIP graph per image size and replayed (Net.detect_image)
+        args.engine = "graph"
     launched = "WORLD_SIZE" in os.environ
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
@@ -191,24 +195,28 @@ def main():
                 counts, rec = net.forward_image(im, record_cap=100)
                 t_b = t_c = time.perf_counter()
                 blk = None
+            elif engine == "graph":
+                counts, rec = net.detect_image(im, 21, 100, nms_t, iou_t, use_graph=not args.no_graph)
+                t_b = t_c = time.perf_counter()
+                blk = None
             else:
                 boxes, masks, scores = demo.im_detect(im, net)      # H2D + device prep + forward + device tail (DeviceArrays)
                 t_b = time.perf_counter()
                 blk = net.vote_instances(boxes, masks, scores, 21, 100, im.shape[1], im.shape[0], nms_t, iou_t)
                 t_c = time.perf_counter()
             if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks, same stream
-                gatherer.gather_block(net.block() if native else blk)
+                gatherer.gather_block(net.block() if native else (net._inst.view() if blk is None else blk))
                 t_d = time.perf_counter()
-                last["gathered"] = gatherer.fetch(rows=int(counts[0]) if native else None)   # [world, 100, 447] on the host
+                last["gathered"] = gatherer.fetch(rows=int(counts[0]) if blk is None else None)   # [world, 100, 447] on the host
             elif gatherer is not None:                              # gloo functional path (host tensors)
-                lists = split_records(rec, counts[1:], 21) if native else blk.lists()
+                lists = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
                 packed, _ = mdist.pack_instances(*lists)
                 t_d = time.perf_counter()
                 last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(packed)])
             else:
                 t_d = t_c
                 # numpy lists per class, exactly what gpu_mask_voting returns
-                last["masks"], last["boxes"] = split_records(rec, counts[1:], 21) if native else blk.lists()
+                last["masks"], last["boxes"] = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
             t_e = time.perf_counter()
             phase["prep+forward+tail"] += t_b - t_a; phase["voting"] += t_c - t_b
             phase["gather"] += t_d - t_c; phase["results_to_host"] += t_e - t_d
@@ -228,7 +236,7 @@ def main():
         events = not args.no_events
         fence()
         level = 1 if args.all_events else 2
-        every = max(1, args.event_every) if native else 1
+        every = max(1, args.event_every) if (native or engine == "graph") else 1
         if events:
             net.profile(level)                       # (resets the record list)
         for k in phase:
@@ -422,7 +430,12 @@ def main():
         out["config"]["engine"] = (("native: one mnc_forward_image call per image (csrc/pipeline.hip); the image size's captured HIP "
                                     "graph is replayed, every %d%s timed step runs as direct launches with HIP events around the MFMA "
                                     "kernels" % (max(1, args.event_every), {1: "st", 2: "nd", 3: "rd"}.get(max(1, args.event_every), "th")))
-                                   if args.engine == "native" else "python: mnc_amd.engine.Net layer by layer (tools/demo.py body)")
+                                   if args.engine == "native" else
+                                   ("graph: mnc_amd.engine.Net's own plan for the prototxt (Net.detect_image): the launch sequence of an image "
+                                    "size is captured into a HIP graph on its second image and replayed -- one graph launch + one "
+                                    "synchronisation per image; every %d%s timed step runs as direct launches with HIP events"
+                                    % (max(1, args.event_every), {1: "st", 2: "nd", 3: "rd"}.get(max(1, args.event_every), "th")))
+                                   if args.engine == "graph" else "python: mnc_amd.engine.Net layer by layer (tools/demo.py body)")
         if "graph_s" in m:
             out["graph_replay"] = {"value": 1.0 / m["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m["graph_s"],
                                    "protocol": "same step, every image on the captured HIP graph (one hipGraphLaunch + one "

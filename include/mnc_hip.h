@@ -178,6 +178,23 @@ MNC_API int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventi
 MNC_API int mnc_ctx_set_tuning(mnc_ctx* ctx, const char* name, const char* value);
 MNC_API int mnc_ctx_get_layer_conventions(const mnc_ctx* ctx, mnc_layer_conventions* conv);
 
+/* Launch-sequence capture for hosts that drive the per-layer entry points themselves (the caffe-shaped Python engine does, for
+ * any prototxt): everything the library enqueues on the context's stream between capture_begin and capture_end -- kernels,
+ * mnc_h2d_async / mnc_d2h_async / mnc_d2d copies -- becomes one HIP graph; mnc_graph_launch replays it with one call.  Inside a
+ * capture nothing may synchronise or allocate (mnc_h2d, mnc_d2h, mnc_dev_alloc / _free, a growing internal arena): such a call
+ * fails with MNC_ERR_HIP and mnc_ctx_capture_end then returns the failure (run the sequence once eagerly first, so that every
+ * buffer has its size).  The graph holds raw device addresses: mnc_graph_launch returns MNC_ERR_STATE when an internal arena of
+ * the context has been re-allocated since the capture (mnc_ctx_arena_generation) -- capture again.  The caller keeps its own
+ * buffers in place.  mnc_forward_image uses the same mechanism internally. */
+typedef struct mnc_graph mnc_graph;
+MNC_API int mnc_ctx_capture_begin(mnc_ctx* ctx);
+MNC_API int mnc_ctx_capture_end(mnc_ctx* ctx, mnc_graph** out);     /* *out = NULL and an error status when the capture failed */
+MNC_API int mnc_graph_launch(mnc_ctx* ctx, mnc_graph* graph);        /* asynchronous on the context's stream */
+MNC_API int mnc_graph_destroy(mnc_graph* graph);
+/* Device address of the row count the last mnc_proposal left on the device (valid until the proposal state is re-allocated):
+ * lets a captured sequence copy it down with its results instead of calling mnc_proposal_count (which synchronises). */
+MNC_API int mnc_proposal_count_ptr(mnc_ctx* ctx, void** d_count);
+
 /* Device memory for the host-side executor (the caffe-shaped Net keeps its blobs here). */
 MNC_API int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr);
 MNC_API int mnc_dev_free(mnc_ctx* ctx, void* d_ptr);

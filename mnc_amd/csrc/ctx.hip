@@ -162,6 +162,72 @@ int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation) {
   return MNC_OK;
 }
 
+int mnc_ctx_capture_begin(mnc_ctx* ctx) {
+  MNC_REQUIRE(ctx, "mnc_ctx_capture_begin: null context");
+  MNC_REQUIRE(!ctx->capturing, "mnc_ctx_capture_begin: a capture is already open on this context");
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
+  MNC_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  ctx->capturing = true;
+  ctx->capture_gen = ctx->arena_gen;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_ctx_capture_end(mnc_ctx* ctx, mnc_graph** out) {
+  MNC_REQUIRE(ctx && out, "mnc_ctx_capture_end: null pointer");
+  *out = nullptr;
+  MNC_REQUIRE(ctx->capturing, "mnc_ctx_capture_end: no capture is open on this context");
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (e != hipSuccess || !g) {
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    set_error("mnc_ctx_capture_end: the capture was invalidated (%s): something synchronised or allocated inside it",
+              hipGetErrorString(e));
+    return MNC_ERR_HIP;
+  }
+  if (ctx->capture_gen != ctx->arena_gen) {          // an internal arena moved while capturing: earlier nodes hold the old address
+    (void)hipGraphDestroy(g);
+    set_error("mnc_ctx_capture_end: an internal arena was re-allocated during the capture (run the sequence eagerly once first)");
+    return MNC_ERR_STATE;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess || !exec) {
+    (void)hipGetLastError();
+    set_error("mnc_ctx_capture_end: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return MNC_ERR_HIP;
+  }
+  mnc_graph* gr = new (std::nothrow) mnc_graph();
+  if (!gr) { (void)hipGraphExecDestroy(exec); set_error("mnc_ctx_capture_end: out of host memory"); return MNC_ERR_NOMEM; }
+  gr->exec = exec;
+  gr->ctx = ctx;
+  gr->arena_gen = ctx->arena_gen;
+  *out = gr;
+  clear_error();
+  return MNC_OK;
+}
+
+int mnc_graph_launch(mnc_ctx* ctx, mnc_graph* graph) {
+  MNC_REQUIRE(ctx && graph && graph->ctx == ctx, "mnc_graph_launch: null pointer, or a graph of another context");
+  if (graph->arena_gen != ctx->arena_gen) {
+    set_error("mnc_graph_launch: an internal arena of the context was re-allocated since the capture; capture again");
+    return MNC_ERR_STATE;
+  }
+  MNC_HIP_TRY(hipSetDevice(ctx->device));
+  MNC_HIP_TRY(hipGraphLaunch(graph->exec, ctx->stream));
+  return MNC_OK;
+}
+
+int mnc_graph_destroy(mnc_graph* graph) {
+  if (!graph) return MNC_OK;
+  if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+  delete graph;
+  return MNC_OK;
+}
+
 int mnc_ctx_set_tuning(mnc_ctx* ctx, const char* name, const char* value) {
   MNC_REQUIRE(ctx && name, "mnc_ctx_set_tuning: null pointer");
   if (!strncmp(name, "MNC_", 4)) name += 4;

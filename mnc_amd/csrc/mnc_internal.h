@@ -63,7 +63,15 @@ struct mnc_ctx {
   unsigned long arena_gen = 0;
   // conventions of the three Caffe layers whose source is unavailable (all zero = oracle/SPEC.md); read by roi.hip's launchers
   mnc_layer_conventions conv = {0, 0, 0, 0, 0, 0, 0.4f, 0};
+  bool capturing = false;     // between mnc_ctx_capture_begin / _end
+  unsigned long capture_gen = 0;
   int tune[mnc::T_COUNT];     // kTuneUnset = the launcher decides (filled by mnc_ctx_create; mnc_ctx_set_tuning)
+};
+
+struct mnc_graph {
+  hipGraphExec_t exec = nullptr;
+  mnc_ctx* ctx = nullptr;
+  unsigned long arena_gen = 0;
 };
 
 namespace mnc {

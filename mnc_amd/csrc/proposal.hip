@@ -456,6 +456,15 @@ int mnc_proposal_count(mnc_ctx* ctx, int* num_rois_host) {
   return MNC_OK;
 }
 
+int mnc_proposal_count_ptr(mnc_ctx* ctx, void** d_count) {
+  MNC_REQUIRE(ctx && d_count, "mnc_proposal_count_ptr: null pointer");
+  mnc_proposal_state* st = (mnc_proposal_state*)ctx->proposal;
+  MNC_REQUIRE(st && st->buf, "mnc_proposal_count_ptr: mnc_proposal has not run on this context");
+  *d_count = st->ws.num;
+  clear_error();
+  return MNC_OK;
+}
+
 int mnc_proposal_candidates(mnc_ctx* ctx, float* boxes_host, float* scores_host, int capacity, int* n_host) {
   MNC_REQUIRE(ctx && n_host, "mnc_proposal_candidates: null pointer");
   mnc_proposal_state* st = (mnc_proposal_state*)ctx->proposal;

@@ -49,10 +49,12 @@ class _Ctx(object):
         _lib.call("mnc_ctx_create", ctypes.addressof(h), int(device_id))
         self.h = h.value
         self.device_id = int(device_id)
+        self.allocs = 0                 # device allocations so far: a captured launch sequence is only replayed while this stands
 
     def alloc(self, nbytes):
         p = ctypes.c_void_p()
         _lib.call("mnc_dev_alloc", self.h, int(max(nbytes, 16)), ctypes.addressof(p))
+        self.allocs += 1
         return p.value
 
     def free(self, p):
@@ -1427,7 +1429,7 @@ class Net(object):
         return boxes, scores
 
     # ------------------------------------------------------------------------------------------------ forward
-    def forward(self, blobs=None, start=None, end=None, **kwargs):
+    def forward(self, blobs=None, start=None, end=None, _finish=True, **kwargs):
         """pycaffe's Net.forward: kwargs are input blobs; `start` / `end` name the first / last layer to run (everything
         before `start` keeps the values of the previous call -- the CFM tester re-runs only the RoI heads on the next chunk
         of proposals, lib/caffeWrapper/TesterWrapper.py:386-407); `blobs` lists extra blobs to return."""
@@ -1446,6 +1448,9 @@ class Net(object):
         stop = names.index(end) + 1 if end is not None else len(self._layers)
         self._speculated = None
         self._run_layers(first, stop)
+        if not _finish:
+            # detect_image: the caller checks the speculative RoI count itself, with its results, and synchronises then
+            return None
         if self._speculated is not None:
             # The native ProposalLayer left its RoI count on the device and the heads ran on all `post` rows (the rows are
             # independent; rows past the count are zero boxes), so the trunk -> heads hand-over needs no host round trip.
@@ -1465,13 +1470,13 @@ class Net(object):
         wanted = list(self.outputs) + [b for b in (blobs or []) if b not in self.outputs]
         return _Outputs(self, [name for name in wanted if self.blobs[name]._dev_valid or self.blobs[name]._host_valid])
 
-    def prep_image(self, im, pixel_means, factors):
+    def prep_image(self, im, pixel_means, factors, staged=None):
         """uint8 BGR image -> DeviceArray [len(factors),3,H',W'] = the `data` blob prep_im_for_blob / prep_im_for_blob_cfm
         (lib/utils/blob.py:36-85) build on the host, computed by mnc_prep_image (mnc_amd/prep.py).  Valid until the next call."""
         if getattr(self, "_prep", None) is None:
             from .prep import ImagePrep
             self._prep = ImagePrep(self)
-        return self._prep.pyramid(im, pixel_means, factors)
+        return self._prep.pyramid(im, pixel_means, factors, staged)
 
     def detect_tail(self, scale, im_shape):
         """The tail of im_detect (tools/demo.py:84-100) without leaving the GPU: (boxes [2R,4] in original-image pixels,
@@ -1522,6 +1527,160 @@ class Net(object):
                   blk.counts_ptr)
         return blk.view()
 
+    # ------------------------------------------------------------------------------------------------ one image, one launch
+    def detect_image(self, im, num_classes=None, max_per_image=100, nms_thresh=None, iou_thresh=None, use_graph=True):
+        """tools/demo.py's per-image body -- prepare_mnc_args, net.forward, im_detect's tail, gpu_mask_voting (demo.py:54-100, 147)
+        -- for ONE uint8 BGR image as one asynchronous launch sequence with a single synchronisation:
+            pinned staging -> H2D -> device prep -> every layer of the prototxt -> tail -> voting -> records D2H into pinned memory
+        -> (counts int32[num_classes], records float32[R, 6 + S*S]) exactly as NativeNet.forward_image / InstanceBlock.fetch return
+        them.  With use_graph the sequence of an image SIZE is captured into a HIP graph the second time the size is seen
+        (mnc_ctx_capture_*) and replayed afterwards: one hipGraphLaunch per image for ANY graph this engine executes (ResNet-50,
+        Faster R-CNN heads excluded: the graph must end in the MNC result blobs), which is what mnc_forward_image does for the
+        hand-written VGG-16 sequence.  The graph is dropped when any device buffer of the net or an arena of the context has been
+        re-allocated since the capture, and an image whose RPN keeps fewer than RPN_POST_NMS_TOP_N proposals is re-run eagerly on
+        the exact count (what the reference computes).  Bit-identical to the layer-by-layer path (tests/test_gpu_engine.py)."""
+        from mnc_config import cfg
+        from .instances import HEAD_BYTES
+        im = np.ascontiguousarray(im)
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise TypeError("detect_image takes a uint8 HxWx3 image (got %s %r)" % (im.dtype, im.shape))
+        K = int(num_classes or 21)
+        nms_t = float(cfg.TEST.MASK_MERGE_NMS_THRESH if nms_thresh is None else nms_thresh)
+        iou_t = float(cfg.TEST.MASK_MERGE_IOU_THRESH if iou_thresh is None else iou_thresh)
+        H, W = im.shape[:2]
+        st = self.__dict__.setdefault("_img", {"pin_in": 0, "pin_in_cap": 0, "pin_out": 0, "pin_out_cap": 0, "graphs": {}, "seen": None})
+        h = self._ctx.h
+        if im.nbytes > st["pin_in_cap"]:
+            self._drop_image_graphs()
+            if st["pin_in"]:
+                _lib.call("mnc_host_free", h, st["pin_in"])
+            p = ctypes.c_void_p()
+            _lib.call("mnc_host_alloc", h, im.nbytes + 4096, ctypes.addressof(p))
+            st["pin_in"], st["pin_in_cap"] = p.value, im.nbytes + 4096
+        ctypes.memmove(st["pin_in"], im.ctypes.data, im.nbytes)          # the image is staged before anything is enqueued
+        key = (H, W, K, int(max_per_image), nms_t, iou_t)
+        use_graph = bool(use_graph) and not getattr(self, "_prof_level", 0)
+
+        def body():
+            """Everything asynchronous on the net's stream; returns (block view, bytes of [head | first records | count])."""
+            short, long_ = min(H, W), max(H, W)
+            scale = float(cfg.TEST.SCALES[0]) / float(short)
+            if np.round(scale * long_) > cfg.TRAIN.MAX_SIZE:
+                scale = float(cfg.TRAIN.MAX_SIZE) / float(long_)
+            data = self.prep_image(im, cfg.PIXEL_MEANS, [scale], staged=st["pin_in"])
+            im_info = np.array([[data.shape[2], data.shape[3], scale]], dtype=F32)
+            self.blobs["data"].reshape(*data.shape)
+            self.blobs["im_info"].reshape(*im_info.shape)
+            self.forward(data=data, im_info=im_info, _finish=False)
+            boxes, masks, scores = self.detect_tail(np.float32(scale), im.shape)
+            blk = self.vote_instances(boxes, masks, scores, K, max_per_image, W, H, nms_t, iou_t)
+            first = min(blk.gather_rows, blk.rows_cap)
+            nbytes = HEAD_BYTES + first * blk.rec_dim * 4
+            if nbytes + 64 > st["pin_out_cap"]:
+                if st["pin_out"]:
+                    _lib.call("mnc_host_free", h, st["pin_out"])
+                p = ctypes.c_void_p()
+                _lib.call("mnc_host_alloc", h, nbytes + 64, ctypes.addressof(p))
+                st["pin_out"], st["pin_out_cap"] = p.value, nbytes + 64
+                self._ctx.allocs += 1                                   # (a captured sequence must not outlive this buffer)
+            _lib.call("mnc_d2h_async", h, st["pin_out"], blk.counts_ptr, nbytes)
+            if self._speculated is not None:
+                cp = ctypes.c_void_p()
+                _lib.call("mnc_proposal_count_ptr", h, ctypes.addressof(cp))
+                _lib.call("mnc_d2h_async", h, st["pin_out"] + nbytes, cp.value, 4)
+            return blk, nbytes
+
+        mode = "eager"
+        g = st["graphs"].get(key)
+        if use_graph and g is not None and g["allocs"] == self._ctx.allocs:
+            try:
+                _lib.call("mnc_graph_launch", h, g["graph"])
+                mode = "replay"
+            except _lib.MncError:
+                self._drop_image_graphs()                               # an arena of the context moved: this image runs eagerly
+                g = None
+        elif g is not None:
+            self._drop_image_graphs()
+            g = None
+        if mode == "eager":
+            if use_graph and st["seen"] == key and key not in st.get("no_graph", ()):
+                _lib.call("mnc_ctx_capture_begin", h)
+                allocs0 = self._ctx.allocs
+                try:
+                    blk, nbytes = body()
+                    gp = ctypes.c_void_p()
+                    _lib.call("mnc_ctx_capture_end", h, ctypes.addressof(gp))
+                except Exception:
+                    try:
+                        gp = ctypes.c_void_p()
+                        _lib.call("mnc_ctx_capture_end", h, ctypes.addressof(gp))
+                    except _lib.MncError:
+                        pass
+                    st.setdefault("no_graph", set()).add(key)           # this graph / size cannot be captured: direct launches
+                    st["seen"] = None
+                    return self.detect_image(im, num_classes, max_per_image, nms_thresh, iou_thresh, use_graph=False)
+                if allocs0 != self._ctx.allocs:                         # something was (re-)allocated while capturing
+                    _lib.call("mnc_graph_destroy", gp.value)
+                    blk, nbytes = body()
+                else:
+                    # what the pycaffe surface knows about every blob after this sequence: a replay runs no Python, so it restores
+                    # this state (and drops host copies, which belong to an earlier image)
+                    snap = [(b, b.shape, b.layout, b._dev_valid, b._sm) for b in list(self.blobs.values()) + getattr(self, "_hidden", [])]
+                    g = {"graph": gp.value, "allocs": self._ctx.allocs, "blk": blk, "nbytes": nbytes, "snap": snap,
+                         "speculated": self._speculated is not None, "post": self._speculated[2] if self._speculated else 0}
+                    st["graphs"][key] = g
+                    _lib.call("mnc_graph_launch", h, g["graph"])
+            else:
+                blk, nbytes = body()
+                st["seen"] = key
+                g = None
+        if g is not None:
+            blk, nbytes, speculated, post = g["blk"], g["nbytes"], g["speculated"], g["post"]
+            if mode == "replay":
+                for b, shape, layout, dev_valid, sm in g["snap"]:
+                    if b._host_valid and not dev_valid:
+                        continue                                        # an input set from the host (im_info): same values
+                    b.shape, b.layout, b._dev_valid, b._sm = shape, layout, dev_valid, sm
+                    b._host, b._host_valid = None, False
+                blk._blk.invalidate()                                   # the buffer now holds this image
+                blk = blk._blk.view()
+                g["blk"] = blk
+        else:
+            speculated, post = self._speculated is not None, (self._speculated[2] if self._speculated else 0)
+        self._speculated = None
+        _lib.call("mnc_ctx_sync", h)
+        raw = (ctypes.c_char * (nbytes + 4)).from_address(st["pin_out"])
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        if speculated and int(buf[nbytes:nbytes + 4].view(np.int32)[0]) < post:
+            # fewer proposals than RPN_POST_NMS_TOP_N survived: the speculative rows were zero boxes; the reference runs the heads
+            # on exactly the surviving rois -- the layer-by-layer path does that
+            short, long_ = min(H, W), max(H, W)
+            scale = float(cfg.TEST.SCALES[0]) / float(short)
+            if np.round(scale * long_) > cfg.TRAIN.MAX_SIZE:
+                scale = float(cfg.TRAIN.MAX_SIZE) / float(long_)
+            data = self.prep_image(im, cfg.PIXEL_MEANS, [scale])
+            self.forward(data=data, im_info=np.array([[data.shape[2], data.shape[3], scale]], dtype=F32))
+            b, m, sc = self.detect_tail(np.float32(scale), im.shape)
+            c2, r2 = self.vote_instances(b, m, sc, K, max_per_image, W, H, nms_t, iou_t).fetch()
+            return c2.copy(), r2.copy()
+        counts = buf[:K * 4].view(np.int32).copy()
+        first = (nbytes - HEAD_BYTES) // (blk.rec_dim * 4)
+        rec = buf[HEAD_BYTES:nbytes].view(F32).reshape(first, blk.rec_dim)
+        R = int(counts[0])
+        if R > first:                                                   # scores tied at the voting threshold: the rows beyond
+            more = np.zeros((R - first, blk.rec_dim), F32)
+            _lib.call("mnc_d2h", h, _lib.ptr(more), blk.records_ptr + first * blk.rec_dim * 4, more.nbytes)
+            return counts, np.concatenate((rec.copy(), more), 0)
+        return counts, rec[:R].copy()
+
+    def _drop_image_graphs(self):
+        st = self.__dict__.get("_img")
+        if st:
+            for g in st["graphs"].values():
+                _lib.call("mnc_graph_destroy", g["graph"])
+            st["graphs"].clear()
+            st["seen"] = None
+
     def _run_layers(self, start, stop=None):
         pre = getattr(self, "_pre_steps", {})
         for i in range(start, len(self._layers) if stop is None else stop):
@@ -1536,8 +1695,15 @@ class Net(object):
     # ------------------------------------------------------------------------------------------------ profiling
     def profile(self, enable=True):
         """enable: False/0 off, True/1 every launch, 2 only the MFMA (>= 1 GFLOP) launches."""
+        self._prof_level = int(enable)
         _lib.call("mnc_prof_enable", self._ctx.h, int(enable))
         _lib.call("mnc_prof_reset", self._ctx.h)
+
+    def profile_enable(self, level):
+        """Switch event recording on / off without touching the records collected so far (no synchronisation).  While it is on,
+        detect_image launches directly: events are not part of a captured launch sequence."""
+        self._prof_level = int(level)
+        _lib.call("mnc_prof_enable", self._ctx.h, int(level))
 
     def profile_records(self):
         """[(kernel name, ms, flops, bytes)] recorded since profile(True); HIP events on the engine's stream."""
@@ -1559,6 +1725,11 @@ class Net(object):
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.h:
             _lib.call("mnc_ctx_sync", self._ctx.h)
+            self._drop_image_graphs()
+            for k in ("pin_in", "pin_out"):
+                if self.__dict__.get("_img", {}).get(k):
+                    _lib.call("mnc_host_free", self._ctx.h, self._img[k])
+                    self._img[k] = 0
             for b in list(self.blobs.values()) + getattr(self, "_hidden", []):
                 b._buf.release()
                 if b._smbuf is not None:

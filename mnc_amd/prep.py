@@ -37,7 +37,7 @@ class ImagePrep(object):
         for b in (self._im, self._taps, self._out):
             b.release()
 
-    def pyramid(self, im, pixel_means, factors):
+    def pyramid(self, im, pixel_means, factors, staged=None):
         """uint8 BGR [H,W,3] -> DeviceArray [L,3,PH,PW]: level l = (im - means) resized by factors[l] (both axes), zero-padded
         to the largest level.  The same values as im_list_to_blob([resize_linear(im - means, f, f) for f in factors])."""
         im = np.ascontiguousarray(im)
@@ -69,7 +69,9 @@ class ImagePrep(object):
         d_im = self._im.ensure(im.nbytes)
         d_t = self._taps.ptr
         d_out = self._out.ensure(L * 3 * PH * PW * 4)
-        _lib.call("mnc_h2d_async", h, d_im, _lib.ptr(im), im.nbytes)       # stream-ordered before the kernels that read it
+        # stream-ordered before the kernels that read it; `staged` = the address of a pinned copy of `im` the caller keeps (a truly
+        # asynchronous copy, and one a captured launch sequence may hold: Net.detect_image)
+        _lib.call("mnc_h2d_async", h, d_im, staged if staged else _lib.ptr(im), im.nbytes)
         self._src = im                                                      # the source stays alive until the next upload
         for l, ((oh, ow), (ox0, oax, oy0, oay)) in enumerate(zip(sizes, offs)):
             _lib.call("mnc_prep_image", h, d_im, H, W, _lib.ptr(means), d_t + ox0 * 4, d_t + oax * 4, ow, d_t + oy0 * 4,

@@ -505,6 +505,18 @@ class Fake(object):
     def mnc_proposal_count(self, h, num):
         ctypes.c_int.from_address(int(num)).value = self._nprop
 
+    def mnc_proposal_count_ptr(self, h, addr):
+        if getattr(self, "_nprop_buf", None) is None:
+            self._nprop_buf = np.zeros(1, np.int32)
+        self._nprop_buf[0] = self._nprop
+        _write_ptr(addr, self._nprop_buf.ctypes.data)
+
+    def mnc_host_alloc(self, h, nbytes, addr):
+        self.mnc_dev_alloc(h, nbytes, addr)
+
+    def mnc_host_free(self, h, p):
+        self.mnc_dev_free(h, p)
+
     def mnc_proposal_candidates(self, h, boxes, scores, cap, n):
         b, s = self._cand
         ctypes.c_int.from_address(int(n)).value = len(b)

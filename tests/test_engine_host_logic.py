@@ -485,3 +485,34 @@ def test_resnet50_graph_every_blob(fake_gpu, fuse):
             assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-6), n
     assert [p.data.shape for p in net.params["bn_conv1"]] == [(16,), (16,), (1,)] and len(net.params["res2a_branch2a"]) == 1
     net.close()
+
+
+def test_detect_image_equals_the_demo_body(fake_gpu, monkeypatch):
+    """Net.detect_image (one launch sequence per image, results through pinned memory) == demo.im_detect + gpu_mask_voting, for an
+    image whose proposals fill RPN_POST_NMS_TOP_N and for one where fewer survive (the exact-count re-run).  Direct launches here;
+    capture / replay of the same sequence is the GPU suite's (tests/test_gpu_engine.py)."""
+    import demo
+    from mnc_amd import models, synth
+    from mnc_amd.engine import Net
+    from mnc_amd.instances import split_records
+    from mnc_config import cfg
+    from transform.mask_transform import gpu_mask_voting
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=1)
+    for post in (300, 12):
+        monkeypatch.setitem(cfg.TEST, "RPN_POST_NMS_TOP_N", post)
+        net = Net(path, w, 1)
+        ref = Net(path, w, 1)
+        try:
+            for seed in (0, 1):
+                im = np.random.default_rng(seed).integers(0, 256, (48, 64, 3), dtype=np.uint8)
+                counts, rec = net.detect_image(im, use_graph=False)
+                b, m, s = demo.im_detect(im, ref)
+                lm, lb = gpu_mask_voting(m, b, s, 21, 100, im.shape[1], im.shape[0])
+                gm, gb = split_records(rec, counts[1:], 21)
+                assert [len(x) for x in gb] == [len(x) for x in lb]
+                assert np.array_equal(np.concatenate(gb, 0), np.concatenate(lb, 0))
+                assert np.array_equal(np.concatenate(gm, 0), np.concatenate(lm, 0), equal_nan=True)
+        finally:
+            net.close()
+            ref.close()

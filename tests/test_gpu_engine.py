@@ -680,3 +680,48 @@ layer { name: "rpn_cls_prob" type: "Softmax" bottom: "rpn_cls_score_reshape" top
     prob = F.softmax(sc.reshape(1, 2, -1, 56), dim=1)
     assert err(ref["conv1_2"], x.numpy())[1] < FP32_TOL and err(ref["rpn_cls_score"], sc.numpy())[1] < FP32_TOL
     assert err(ref["rpn_cls_prob"], prob.numpy())[0] < FP32_TOL
+
+
+@pytest.mark.parametrize("graph,math", [("vgg16", "fp32"), ("vgg16", "f16"), ("resnet50", "fp32"), ("resnet50", "f16")])
+def test_detect_image_graph_replay_equals_layer_by_layer(graph, math, monkeypatch):
+    """Net.detect_image: the per-image body of tools/demo.py (prep, forward of ANY prototxt, tail, voting) as ONE launch sequence,
+    captured into a HIP graph the second time an image size is seen and replayed afterwards (mnc_ctx_capture_* -- what
+    mnc_forward_image does for the hand-written VGG-16 sequence, here for the engine's own plan: the VGG-16 cascade and the
+    ResNet-50 C4 cascade of BASELINE configs[4]).  Every call -- eager, capturing, replaying, after a size change, after a size
+    whose scratch need re-allocates a context arena -- equals demo.im_detect + gpu_mask_voting on a second net, bit for bit."""
+    import demo
+    from mnc_amd.engine import Net
+    from mnc_amd.instances import split_records
+    from mnc_config import cfg
+    from transform.mask_transform import gpu_mask_voting
+    if graph == "vgg16":
+        path = models.write_mnc_5stage_test_prototxt(width_div=8)
+        sizes = [(75, 100)] * 4 + [(120, 90)] * 3 + [(75, 100)] * 2
+    else:
+        path = models.write_mnc_resnet50_test_prototxt(width_div=4)
+        sizes = [(96, 128)] * 4 + [(150, 110)] * 2 + [(96, 128)] * 2
+    w = synth.synthetic_weights(path, seed=6)
+    net = Net(path, w, 1, math=math)
+    ref = Net(path, w, 1, math=math)
+    try:
+        rng = np.random.default_rng(31)
+        modes = []
+        for (H, W) in sizes:
+            im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            n_graphs = len(net._img["graphs"]) if hasattr(net, "_img") else 0
+            counts, rec = net.detect_image(im)
+            modes.append((len(net._img["graphs"]), n_graphs))
+            b, m, s = demo.im_detect(im, ref)
+            lm, lb = gpu_mask_voting(m, b, s, 21, 100, W, H)
+            gm, gb = split_records(rec, counts[1:], 21)
+            assert [len(x) for x in gb] == [len(x) for x in lb], (H, W, modes)
+            assert np.array_equal(np.concatenate(gb, 0), np.concatenate(lb, 0)), (H, W, modes)
+            assert np.array_equal(np.concatenate(gm, 0), np.concatenate(lm, 0), equal_nan=True), (H, W, modes)
+            # intermediate blobs stay readable through the pycaffe surface after a replay
+            for name in ("rois", "seg_cls_prob_ext", "mask_proposal"):
+                assert np.array_equal(net.blobs[name]._host_read(), ref.blobs[name]._host_read()), (name, H, W, modes)
+        assert not net._img.get("no_graph"), "the launch sequence of this graph could not be captured: %r" % (net._img.get("no_graph"),)
+        assert modes[1][0] == 1 and modes[2] == (1, 1) and modes[3] == (1, 1), modes     # 2nd image captures, 3rd and 4th replay
+    finally:
+        net.close()
+        ref.close()
