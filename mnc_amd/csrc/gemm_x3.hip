@@ -15,6 +15,7 @@
 //     the 60 MFMAs it was meant to hide behind, 256 times over);
 //   * LDS rows are 4 groups x 32 B + 16 B pad (pitch 36 dwords, conflict-free ds_read_b128); lane (row, kb) of K-step ks
 //     reads group 2*ks + kb: hi and lo are two adjacent 16-byte fragments.
+#include <atomic>
 #include <cstdlib>
 
 #include "mnc_internal.h"
@@ -336,6 +337,208 @@ __global__ void pack_f16_kernel(const float* __restrict__ in, uint4* __restrict_
   }
 }
 
+// ---- fp16 / split-bf16 InnerProduct, 256-column workgroup tiles, operand panels copied by LDS-DMA (round 3) ----------------------------------
+// What bounds fc_x3_kernel in the fp16 mode is neither pipe nor HBM but the load path of a CU: ~11-13 B/clk/CU sustained
+// (MI355X_MICROARCH.md: LDS-DMA prologue burst 12-13 B/clk/CU; 6.4 TB/s over the chip).  A 320 x 128 tile moves (320 + 128) x 128 B
+// per 64-deep stage for 5.2 MFLOP: at 12.5 B/clk that is 4590 clk per stage against 1290 clk of MFMA -- 0.28 of the fp16 pipe at
+// best, 0.23 measured (fc6 at 300 RoIs), and at 1000 RoIs the activation panel re-streamed per 128-column tile (32 x 100 MB) plus
+// the weights per row block (4 x 411 MB) make 4.8 GB through that path per call: 641 us at 7.5 TB/s.  The lever is bytes per
+// flop: a 256-column tile reads the activations half as often.  This kernel: workgroup = 8 waves (two per SIMD) = 32 kMT rows x
+// 256 columns, wave (wm, wn) owns kMT/2 row tiles x columns [64 wn, 64 wn + 64) (10 or 8 accumulator tiles = 160 / 128 AGPRs);
+// a stage's panels ([32 kMT][128 B] activations + [256][128 B] weights, both already stage-major and contiguous in memory) go
+// global -> LDS with global_load_lds_dwordx4 -- no staging registers, which is what lets eight 10-tile waves fit the register
+// file -- into the XOR-swizzled unpadded row layout of fc_mfma_dma_kernel (gemm.hip: row r keeps its 16-byte chunk c in slot
+// c ^ ((r >> 1) & 7); conflict-free ds_read_b128 fragments), double-buffered: 2 x 72 KB of LDS at kMT = 10.
+// F16 = 0: the split-bf16 products (three MFMAs per term, 32-deep stages) on the same panels.
+// Same operands, same K order per accumulator and the same epilogue as fc_x3_kernel: results differ from it only by
+// the K-split grouping (fewer column tiles -> more splits).
+template <int kMT, int F16>
+__global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restrict__ Ax, const uint4* __restrict__ Wx,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         float* __restrict__ part, int M, int N, int K, int ldc, int kper, int act,
+                                                         int fused, int tn_, int splits_, int tm_, int mstride) {
+  constexpr int kBM = 32 * kMT, kBN2 = 256;
+  constexpr int kRows = kBM + kBN2;                  // operand rows per stage: activations, then weights
+  constexpr int kBuf = kRows * 128;                  // bytes per stage buffer
+  constexpr int kPieces = kRows / 8;                 // 1 KB DMA pieces per stage (8 rows each)
+  constexpr int kPer = kPieces / 8;                  // per wave
+  constexpr int TR = kMT / 2;                        // row tiles per wave
+  static_assert(kMT % 2 == 0 && kPieces % 8 == 0, "wave grid");
+  extern __shared__ __attribute__((aligned(1024))) char s_lp[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int j = lane & 31, kb = lane >> 5;
+  int bn, split, bmz;
+  if (tm_ < 0) {            // row block fastest: the workgroups that share a weight panel are neighbours on one XCD
+    int a, b, c;
+    xcd_decode(blockIdx.x, -tm_, tn_, splits_, a, b, c);
+    bmz = a; bn = b; split = c;
+  } else {
+    xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  }
+  const int n0 = bn * kBN2, m0 = bmz * kBM;
+  constexpr int kStageK = F16 ? 64 : kXBK;           // K values per stage: 128 bytes per row in either format
+  const int S = K / kStageK;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
+  const int stage0 = kbeg / kStageK, nstages = (kend - kbeg) / kStageK;
+  const int mrows = min(M - m0, kBM);
+  const int mtiles = (mrows + 31) >> 5;
+  const int npanels = (N + 127) >> 7;
+
+  // Piece p = wave + 8 i covers buffer bytes [1024 p, 1024 p + 1024): lane L fills slot 64 p + L = row r = 8 p + (L >> 3), chunk
+  // slot L & 7, i.e. it fetches chunk c = (L & 7) ^ ((r >> 1) & 7) of that row -- and (r >> 1) & 7 = 4 (wave & 1) + (L >> 4) for
+  // every i, so c is one lane constant.  r = r0 + 64 i with r0 = 8 wave + (L >> 3) < 64: pieces i < kBM / 64 are activation rows
+  // (stage stride mstride x 128 B), the others weight rows r0 + 64 k of the two 128-row panels of this column tile (stage stride
+  // 128 x 128 B).  Nothing per piece is kept in registers: the addresses are rebuilt from (r0, c) at every stage.
+  static_assert(kBM % 64 == 0, "whole pieces per operand");
+  constexpr int kPerA = kBM / 64;
+  const int r0 = wave * 8 + (lane >> 3);
+  const int cch = (lane & 7) ^ ((wave & 1) * 4 + (lane >> 4));
+  const int panel0 = min(bn * 2, npanels - 1), panel1 = min(bn * 2 + 1, npanels - 1);     // a panel past N re-reads the last one
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_lp;
+  // (inline assembly, as in fc_mfma_dma_kernel: behind the builtin hipcc makes every later ds_read wait for vmcnt(0))
+  auto dma_stage = [&](int s, int buf_byte) {
+    const long st = stage0 + min(s, nstages - 1);    // past the end: the last stage once more, never multiplied
+    const uint4* abase = Ax + ((st * mstride + m0) << 3) + cch;
+    const uint4* w0 = Wx + (((long)panel0 * S + st) << 10) + cch;
+    const uint4* w1 = Wx + (((long)panel1 * S + st) << 10) + cch;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const uint4* g;
+      if (i < kPerA) {
+        g = abase + ((long)min(r0 + 64 * i, mrows - 1) << 3);     // rows past M re-read the last valid row; never stored
+      } else {
+        const int k = i - kPerA;
+        g = ((k >> 1) ? w1 : w0) + ((r0 + 64 * (k & 1)) << 3);
+      }
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 8 * i) * 1024u);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
+    }
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  f32x16 acc[TR][2];
+#pragma unroll
+  for (int t = 0; t < TR; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+
+  // fp16: MFMA step q (16 K-values, 4 per stage) reads the 16-byte chunk 2 q + kb of a row.  Split bf16: K-step ks (16 K-values, 2
+  // per stage) is the groups 2 ks and 2 ks + 1 of 8 values, lane half kb takes group g = 2 ks + kb: chunk 2 g = its hi halves,
+  // 2 g + 1 = its lo halves.  Chunk c of row r sits in slot c ^ ((r >> 1) & 7); tile offsets (32 rows = 4 KB) leave
+  // (r >> 1) & 7 = (j >> 1) & 7 unchanged.  Byte offsets inside a buffer.
+  constexpr int kSteps = F16 ? 4 : 2;
+  const int swz = (j >> 1) & 7;
+  int coff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) coff[q] = F16 ? ((2 * q + kb) ^ swz) * 16 : ((2 * (2 * (q >> 1) + kb) + (q & 1)) ^ swz) * 16;   // bf16x3: [ks][hi, lo]
+  const int a_row = (wm * TR * 32 + j) * 128, b_row = (kBM + wn * 64 + j) * 128;
+  struct Frags { uint4 a[TR]; uint4 b[2]; uint4 al[F16 ? 1 : TR]; uint4 bl[F16 ? 1 : 2]; };
+  auto read_frags = [&](int buf_byte, int q, Frags& f) {
+    const char* base = s_lp + buf_byte + coff[F16 ? q : 2 * q];
+    f.b[0] = *reinterpret_cast<const uint4*>(base + b_row);
+    f.b[1] = *reinterpret_cast<const uint4*>(base + b_row + 4096);
+#pragma unroll
+    for (int t = 0; t < TR; ++t) f.a[t] = *reinterpret_cast<const uint4*>(base + a_row + t * 4096);
+    if (!F16) {
+      const char* lo = s_lp + buf_byte + coff[2 * q + 1];
+      f.bl[0] = *reinterpret_cast<const uint4*>(lo + b_row);
+      f.bl[1] = *reinterpret_cast<const uint4*>(lo + b_row + 4096);
+#pragma unroll
+      for (int t = 0; t < TR; ++t) f.al[t] = *reinterpret_cast<const uint4*>(lo + a_row + t * 4096);
+    }
+  };
+  auto mfmas = [&](const Frags& f) {
+    if (F16) {
+#pragma unroll
+      for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.a[t]), x3_as_f16x8(f.b[c]), acc[t][c], 0, 0, 0);
+      return;
+    }
+    // a_lo b_hi + a_hi b_lo + a_hi b_hi, term outermost -- fc_x3_kernel's order
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.al[t]), x3_as_bf16x8(f.b[c]), acc[t][c], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.a[t]), x3_as_bf16x8(f.bl[c]), acc[t][c], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.a[t]), x3_as_bf16x8(f.b[c]), acc[t][c], 0, 0, 0);
+  };
+  // The accumulators stay in ARCHITECTURAL registers ("+v"): a 512-thread workgroup leaves a wave 256 registers, and as soon as a
+  // function touches AGPRs hipcc splits that budget 128 / 128 -- the 160 accumulator registers of kMT = 10 then spill (800
+  // v_accvgpr moves and 53 scratch accesses per stage).  MFMA reads and writes VGPR accumulators at the same rate on gfx950.
+  auto pin_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(acc[t][c]));
+  };
+
+  // One fragment set: with 160 accumulator registers a wave has ~90 VGPRs left, and two waves share each SIMD -- one wave's
+  // fragment reads run under its partner's MFMAs.  (Two sets, software-pipelined as in fc_mfma_dma_kernel, spilled 400 registers.)
+  if (nstages > 0) {
+    Frags f;
+    dma_stage(0, 0);
+    dma_stage(1, kBuf);
+    dma_wait();
+    __syncthreads();
+    int cur = 0;                                     // byte offset of the buffer stage s sits in
+    for (int s = 0; s < nstages; ++s) {
+#pragma unroll
+      for (int q = 0; q < kSteps - 1; ++q) {
+        read_frags(cur, q, f);
+        mfmas(f);
+      }
+      read_frags(cur, kSteps - 1, f);
+      pin_acc();
+      dma_wait();                                    // stage s + 1 has landed ...
+      __syncthreads();                               // ... for every wave, and every wave holds its last fragments of buffer `cur`
+      __builtin_amdgcn_sched_barrier(0);
+      dma_stage(s + 2, cur);                         // refill the buffer just released: a whole stage to land
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(f);                                      // the last step
+      pin_acc();
+      cur = kBuf - cur;
+    }
+    dma_wait();                                      // the copies issued by the last two stages have landed before the LDS is released
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int n = n0 + wn * 64 + c * 32 + j;
+    if (n >= N) continue;
+    const float bv = fused ? bias[n] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+      const int tile = wm * TR + t;
+      if (tile < mtiles) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
+          if (m < M) {
+            if (fused) out[(long)m * ldc + n] = x3_act(acc[t][c][e] + bv, act);
+            else part[((long)split * M + m) * N + n] = acc[t][c][e];
+          }
+        }
+      }
+    }
+  }
+}
+
 static int f16_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles) {
   const long total = (long)tiles * (K / 64) * tile_rows * 8;
   long g = (total + 255) / 256;
@@ -400,14 +603,27 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     if (v == 2 || v == 5 || v == 8 || v == 10) mt = v;
   }
   const int bm = 32 * mt;
-  const int tn = cdiv(N, kXBN), tm = cdiv(M, bm), stages = K / kStage;
+  const int stages = K / kStage, tm = cdiv(M, bm);
+  // 256- or 320-row blocks, N a multiple of 256: the 256-column LDS-DMA kernel (fc_lowp_dma_kernel) -- half the activation
+  // traffic per flop through the CU's load path, which is what bounds this mode -- when its K splits keep at least 8 stages
+  // (fc7 at 300 RoIs would get 4: prologue and epilogue of a workgroup then outweigh the traffic saved).  FCX3_WIDE=0: off.
+  bool wide = false;
+  if ((mt == 8 || mt == 10) && N % 256 == 0 && N >= 512 && tune(ctx, T_FCX3_WIDE, 1) != 0) {
+    const int sp = cdiv(256, (N / 256) * tm);
+    wide = stages / (sp > 0 ? sp : 1) >= (F16 ? 8 : 16);
+    // split bf16 at one row block (300 RoIs): three MFMAs per term keep the matrix pipe busier than the load path, and the doubled
+    // K splits cost in the reduction what the kernel gains (fc6: 213.9 + 10.8 us vs 204.5 + 16.9 us) -- the 128-column kernel stays
+    if (!F16 && tm == 1 && !tune_set(ctx, T_FCX3_WIDE)) wide = false;
+  }
+  const int bn_w = wide ? 256 : kXBN;
+  const int tn = cdiv(N, bn_w);
   int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
   const int min_stages = F16 ? (mt == 2 ? 1 : 4) : (mt == 2 ? 2 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
   if (tm > 1 && mt != 2)     // several row blocks: split count by cost (mnc_internal.h: choose_splits)
     splits = choose_splits(tn * tm, stages, min_stages, 256,
-                           (double)bm * kXBN * kStage * 2.0 / (F16 ? 2000.0e3 : 1050.0e3), 4.0 * M * (double)N);
+                           (double)bm * bn_w * kStage * 2.0 / (F16 ? 2000.0e3 : 1050.0e3), 4.0 * M * (double)N);
   const int kper = cdiv(stages, splits) * kStage;
   splits = cdiv(K, kper);
   // scratch arena: [split-K partials | the activations in their 2-byte stage-major form (when they arrive as fp32)]
@@ -440,7 +656,28 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   hipLaunchKernelGGL((fc_x3_kernel<MT, WR, A, F16>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax,                 \
                      (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, \
                      tm_arg, mstride)
-    if (mt == 2) MNC_X3_LAUNCH(2, 2, 0);
+    if (wide) {
+      {
+#define MNC_WIDE_LAUNCH(MT)                                                                                                     \
+  do {                                                                                                                          \
+    constexpr int lds = 2 * (32 * MT + 256) * 128;                                                                              \
+    static std::atomic<unsigned long long> attr_set{0};            /* one bit per device */                                    \
+    const unsigned long long bit = 1ull << (ctx->device & 63);                                                                  \
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {                                                                    \
+      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_lowp_dma_kernel<MT, F16>),                                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                        \
+      attr_set.fetch_or(bit, std::memory_order_relaxed);                                                                        \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((fc_lowp_dma_kernel<MT, F16>), dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_ax,                      \
+                       (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, \
+                       tm_arg, mstride);                                                                                        \
+  } while (0)
+        if (mt == 8) MNC_WIDE_LAUNCH(8);
+        else MNC_WIDE_LAUNCH(10);
+#undef MNC_WIDE_LAUNCH
+      }
+    }
+    else if (mt == 2) MNC_X3_LAUNCH(2, 2, 0);
     else if (mt == 5) MNC_X3_LAUNCH(5, 1, 0);
     else if (mt == 8) MNC_X3_LAUNCH(8, 2, 0);
     else if constexpr (F16 != 0) {

@@ -814,10 +814,11 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
     assert err(outs[0], outs[1])[1] < 1e-5 and np.array_equal(outs[0], outs[2])      # same K order per accumulator
 
 
-@pytest.mark.parametrize("M,N,K,act", FC_SHAPES)
-def test_fc_bf16x3(dev, M, N, K, act):
+@pytest.mark.parametrize("M,N,K,act", FC_SHAPES + [(300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2)])
+def test_fc_bf16x3(dev, M, N, K, act, tune):
     """Split-precision FC (3 bf16 MFMAs per product): measured against the float64 product.  Bar: 1e-4 of the output's
-    dynamic range, the same bar as the exact-fp32 kernel (its error is ~1e-5, an fp32 GEMM's ~1e-6)."""
+    dynamic range, the same bar as the exact-fp32 kernel (its error is ~1e-5, an fp32 GEMM's ~1e-6).  The last three shapes run
+    on the 256-column LDS-DMA kernel (fc_lowp_dma_kernel<.., 0>) and are also held against the 128-column kernel (FCX3_WIDE=0)."""
     rng = np.random.default_rng(M + N + K + 1)
     a = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
@@ -833,15 +834,25 @@ def test_fc_bf16x3(dev, M, N, K, act):
     d, rel = err(got, want)
     print("bf16x3 M=%d N=%d K=%d: max|d|=%.3e rel=%.3e" % (M, N, K, d, rel))
     assert rel < 1e-4, (d, rel)
+    if N % 256 == 0 and N >= 512:
+        for force in ("0", "1"):            # the 128-column kernel, and the 256-column one also where the launcher would not pick it
+            tune("FCX3_WIDE", force)
+            d_alt = dev.empty((M * N,), fill=np.nan)
+            dev.call("mnc_fc_bf16x3", dev.put(a), d_wp, dev.put(b), d_alt, M, N, K, N, act)
+            assert err(dev.get(d_alt, (M, N)), got)[1] < 2e-6, force
+        dev.tune("FCX3_WIDE", None)
 
 
 @pytest.mark.parametrize("M,N,K,act", [(300, 4096, 4096, 1), (45, 150, 64, 0), (300, 256, 14 * 14 * 512, 1), (7, 4096, 25088, 1),
                                        (300, 126, 8192, 0), (1000, 512, 2048, 1), (300, 441, 256, 2),
-                                       (1000, 4096, 12544, 1), (700, 300, 6272, 0), (513, 320, 4096, 1), (2000, 256, 8192, 1)])
-def test_fc_f16(dev, M, N, K, act):
+                                       (1000, 4096, 12544, 1), (700, 300, 6272, 0), (513, 320, 4096, 1), (2000, 256, 8192, 1),
+                                       (300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2), (520, 1024, 8192, 1)])
+def test_fc_f16(dev, M, N, K, act, tune):
     """mnc_fc_f16: exact against torch on operands rounded to fp16 (products of halves are exact in the fp32 accumulator; only
-    the summation order differs), and within fp16's 11 bits of the fp32 product.  M >= 512 runs on the 256 x 256 tiles of
-    gemm_big.hip (ragged last row block, N that does not fill a column tile, several K splits and a single one)."""
+    the summation order differs), and within fp16's 11 bits of the fp32 product.  Covers 64- / 160- / 256- / 320-row blocks,
+    ragged last row blocks, N that does not fill a column tile, several K splits and a single one, and -- N a multiple of 256 with
+    at least 8 stages per K split: (1000, 4096, 12544) and the last four shapes -- the 256-column LDS-DMA kernel
+    (fc_f16_dma_kernel, 256- and 320-row blocks), which must also agree with the 128-column kernel it replaces (FCX3_WIDE=0)."""
     rng = np.random.default_rng(M + N + K)
     a = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
@@ -861,6 +872,12 @@ def test_fc_f16(dev, M, N, K, act):
     d32, rel32 = err(got, ref(a, w))
     print("f16 M=%d N=%d K=%d: vs fp16-rounded operands rel=%.3e, vs fp32 rel=%.3e" % (M, N, K, rel, rel32))
     assert rel < 1e-5 and rel32 < 2e-3
+    if N % 256 == 0 and N >= 512:
+        tune("FCX3_WIDE", "0")
+        d_old = dev.empty((M * N,), fill=np.nan)
+        dev.call("mnc_fc_f16", dev.put(a), d_wp, dev.put(b), d_old, M, N, K, N, act)
+        dev.tune("FCX3_WIDE", None)
+        assert err(dev.get(d_old, (M, N)), got)[1] < 2e-6
     if M >= 512:        # a column slice of a wider matrix (ldc > N), as the Concat-in-place plan writes fc7 / fc7_mask
         ld = N + 64
         d_wide = dev.empty((M * ld,), fill=np.nan)
