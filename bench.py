@@ -17,6 +17,11 @@ A "step" is one pass of the whole hot path over one synthetic image per GPU, mea
        the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
        device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
 Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
+Round 3: by default every GPU keeps TWO images in flight (--in-flight 2: one mnc_net + context + stream per image in flight;
+mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k), because a third of an image's GPU time is spent
+in kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- another image's convolutions
+run there.  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` in the
+same line is the rounds 1-2 protocol (--in-flight 1 makes it the headline).
 The old protocol (same image resident in HBM, no upload) is reported next to it as `resident_input`.
 
 The headline `value` is measured with fp32 MFMA arithmetic (--math fp32, BASELINE configs[1]); at N = 1 the same run also
@@ -89,6 +94,10 @@ def parse():
                         "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
                         "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
                         "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
+    p.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+                   help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
+                        "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
+                        "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
     return p.parse_args()
 
@@ -170,7 +179,7 @@ def main():
     images = [np.random.default_rng(s).integers(0, 256, (H, W, 3), dtype=np.uint8) for s in range(N_IMAGES)]
     nms_t, iou_t = float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH)
 
-    def measure(math, steps, warmup, resident_steps=0, engine=None, pipelined_steps=0):
+    def measure(math, steps, warmup, resident_steps=0, engine=None, pipelined_steps=0, in_flight=None):
         """Build the net in `math` mode; warmup + `steps` timed steps of the full protocol (upload .. results on the host), then
         optionally `resident_steps` steps of the old resident-input protocol.  -> dict."""
         engine = engine or args.engine
@@ -182,10 +191,37 @@ def main():
             net = NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph)
         else:
             net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
-        gatherer = mdist.InstanceGatherer(net=net, rank=rank, world=world) if (launched and on_gpu) else \
+        inflight = args.in_flight if (native and in_flight is None) else (in_flight or 1)
+        nets = [net] + [NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph) for _ in range(inflight - 1)]
+        holder = net
+        if launched and on_gpu and inflight > 1:
+            # the communicator lives on its own context / stream: a gather enqueued on one image's stream would wait behind the
+            # other image that is running there
+            import types
+            from mnc_amd.engine import _Ctx
+            holder = types.SimpleNamespace(_ctx=_Ctx(dev_id))
+        gatherer = mdist.InstanceGatherer(net=holder, rank=rank, world=world) if (launched and on_gpu) else \
             mdist.InstanceGatherer(device=None) if launched else None
         phase = {"prep+forward+tail": 0.0, "voting": 0.0, "gather": 0.0, "results_to_host": 0.0}
         last = {}
+
+        def finish(counts, rec, blk, which, t_c):
+            """what happens to one image's voted instances: the RCCL / gloo gather of the [100,447] block (N > 1) or numpy lists"""
+            if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks
+                gatherer.gather_block(nets[which].block() if native else (net._inst.view() if blk is None else blk))
+                t_d = time.perf_counter()
+                last["gathered"] = gatherer.fetch(rows=int(counts[0]) if blk is None else None)   # [world, 100, 447] on the host
+            elif gatherer is not None:                              # gloo functional path (host tensors)
+                lists = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
+                packed, _ = mdist.pack_instances(*lists)
+                t_d = time.perf_counter()
+                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(packed)])
+            else:
+                t_d = t_c
+                # numpy lists per class, exactly what gpu_mask_voting returns
+                last["masks"], last["boxes"] = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
+            t_e = time.perf_counter()
+            phase["gather"] += t_d - t_c; phase["results_to_host"] += t_e - t_d
 
         def step(k):
             im = images[(rank + k) % N_IMAGES]
@@ -204,25 +240,45 @@ def main():
                 t_b = time.perf_counter()
                 blk = net.vote_instances(boxes, masks, scores, 21, 100, im.shape[1], im.shape[0], nms_t, iou_t)
                 t_c = time.perf_counter()
-            if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks, same stream
-                gatherer.gather_block(net.block() if native else (net._inst.view() if blk is None else blk))
-                t_d = time.perf_counter()
-                last["gathered"] = gatherer.fetch(rows=int(counts[0]) if blk is None else None)   # [world, 100, 447] on the host
-            elif gatherer is not None:                              # gloo functional path (host tensors)
-                lists = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
-                packed, _ = mdist.pack_instances(*lists)
-                t_d = time.perf_counter()
-                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(packed)])
-            else:
-                t_d = t_c
-                # numpy lists per class, exactly what gpu_mask_voting returns
-                last["masks"], last["boxes"] = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
-            t_e = time.perf_counter()
             phase["prep+forward+tail"] += t_b - t_a; phase["voting"] += t_c - t_b
-            phase["gather"] += t_d - t_c; phase["results_to_host"] += t_e - t_d
+            finish(counts, rec, blk, 0, t_c)
+
+        pending = []                                 # (which net) of the images launched and not yet fetched, oldest first
+
+        def drain():
+            while pending:
+                which = pending.pop(0)
+                t_a = time.perf_counter()
+                counts, rec = nets[which].fetch(record_cap=100)
+                t_c = time.perf_counter()
+                phase["prep+forward+tail"] += t_c - t_a
+                finish(counts, rec, None, which, t_c)
+
+        def step_pipelined(k, with_events):
+            """image k on net k % inflight: launched BEFORE the previous image is fetched (mnc_forward_image_async /
+            mnc_net_fetch); an event step first drains the pipeline and runs alone, so that its per-kernel durations are not
+            inflated by the other image's kernels"""
+            if with_events:
+                drain()
+                step(k)
+                return
+            which = k % inflight
+            t_a = time.perf_counter()
+            nets[which].launch(images[(rank + k) % N_IMAGES])
+            phase["prep+forward+tail"] += time.perf_counter() - t_a
+            pending.append(which)
+            while len(pending) >= inflight:
+                which0 = pending.pop(0)
+                t_a = time.perf_counter()
+                counts, rec = nets[which0].fetch(record_cap=100)
+                t_c = time.perf_counter()
+                phase["prep+forward+tail"] += t_c - t_a
+                finish(counts, rec, None, which0, t_c)
 
         def fence():
-            net.sync()
+            drain()
+            for nn in nets:
+                nn.sync()
             if launched:
                 if on_gpu:
                     torch.cuda.synchronize()
@@ -232,7 +288,10 @@ def main():
                 net.sync()
 
         for k in range(warmup):
-            step(k)
+            if inflight > 1:
+                step_pipelined(k, False)
+            else:
+                step(k)
         events = not args.no_events
         fence()
         level = 1 if args.all_events else 2
@@ -247,14 +306,23 @@ def main():
             if events and every > 1:
                 net.profile_enable(level if k % every == 0 else 0)
             event_steps += int(events and k % every == 0)
-            step(warmup + k)
+            if inflight > 1:
+                step_pipelined(warmup + k, events and k % every == 0)
+            else:
+                step(warmup + k)
         fence()
         elapsed = time.perf_counter() - t0
         records = net.profile_records() if events else []
         if events:
             net.profile(False)
         out = {"elapsed": elapsed, "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()}, "records": records,
-               "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None)}
+               "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None), "in_flight": inflight}
+        for nn in nets[1:]:
+            nn.close()
+        if holder is not net and gatherer is not None:
+            gatherer.close()
+            holder._ctx.close()
+            gatherer = None
         out["feats"] = {n: (net.blob(n) if native else net.blobs[n]._host_read().copy())
                         for n in ("rpn_bbox_pred", "rpn_cls_prob_reshape")}
         if native and not launched:
@@ -376,8 +444,9 @@ def main():
             rows.append(e)
         return rows
     want_resident = world == 1 and not args.no_resident and args.engine == "python"
+    headline_pipelined = args.engine == "native" and args.in_flight > 1
     m = measure(math, args.steps, args.warmup, resident_steps=min(args.steps, 50) if want_resident else 0,
-                pipelined_steps=0 if args.no_resident else min(args.steps, 100))
+                pipelined_steps=0 if (args.no_resident or headline_pipelined) else min(args.steps, 100))
     elapsed = m["elapsed"]
     # every rank's own clock next to the max-over-ranks one: a straggler shows up as one large ms_per_step
     ranks = [{"rank": rank, "device": dev_id, "host": socket.gethostname(), "ms_per_step": 1e3 * elapsed / args.steps,
@@ -402,14 +471,15 @@ def main():
                                    "included in the timed region; %s; seeded synthetic weights (no trained model here: "
                                    "mAP unverifiable)" % (conf["what"], H, W, conf["rois"], 2 * conf["rois"], H, W,
                                                           MATH_NOTE[math]),
-                       "images_per_step": world, "rois_per_stage": conf["rois"], "math": math,
+                       "images_per_step": world, "rois_per_stage": conf["rois"], "math": math, "images_in_flight_per_gpu": m["in_flight"],
                        "parallelism": (("images sharded 1/GPU, %d ranks; ncclAllGather of [100,447] instance blocks on the "
                                         "engine stream" % world) if on_gpu else
                                        ("images sharded over %d ranks on %d GPU(s); functional run: [100,447] instance blocks "
                                         "gathered through torch.distributed/%s on the host" % (world, ndev, args.dist_backend)))
                                       if world > 1 else
                                       ("single GPU (1 rank under the launcher, RCCL gather of the block included)" if launched
-                                       else "single GPU")},
+                                       else "single GPU") + ("; %d images in flight per GPU (own stream each: image k+1 is launched "
+                                                             "before image k is fetched)" % m["in_flight"] if m["in_flight"] > 1 else "")},
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
         }
         out.update(summarise(args.steps, m))
@@ -438,8 +508,10 @@ def main():
                                    if args.engine == "graph" else "python: mnc_amd.engine.Net layer by layer (tools/demo.py body)")
         if "graph_s" in m:
             out["graph_replay"] = {"value": 1.0 / m["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m["graph_s"],
-                                   "protocol": "same step, every image on the captured HIP graph (one hipGraphLaunch + one "
-                                               "synchronisation per image; no event steps)"}
+                                   "protocol": "ONE image at a time (the rounds 1-2 headline protocol; latency of an image): same step, "
+                                               "every image on the captured HIP graph (one hipGraphLaunch + one synchronisation per "
+                                               "image; no event steps)"}
+            out["one_image_at_a_time"] = out["graph_replay"]
         if args.engine == "native" and world == 1 and not launched and not args.no_resident:
             mp = measure(math, min(args.steps, 100), args.warmup, resident_steps=50, engine="python")
             out["python_engine"] = {"value": min(args.steps, 100) / mp["elapsed"], "unit": "images/s",
@@ -462,9 +534,10 @@ def main():
             # BASELINE configs[2] ("bf16 convs via MFMA") and the fp16 mode measured in the same run, same protocol; their RPN
             # outputs on the LAST image are compared with the fp32 run's (blobs that do not depend on which RoIs survived)
             for key, alt in (("alt_math", "bf16x3"), ("alt_math_f16", "f16")):
-                m2 = measure(alt, args.steps, args.warmup, pipelined_steps=0 if args.no_resident else min(args.steps, 100))
+                m2 = measure(alt, args.steps, args.warmup,
+                             pipelined_steps=0 if (args.no_resident or headline_pipelined) else min(args.steps, 100))
                 a = {"math": alt, "dtype": DTYPE[alt], "value": args.steps / m2["elapsed"], "unit": "images/s",
-                     "ms_per_step": 1e3 * m2["elapsed"] / args.steps}
+                     "ms_per_step": 1e3 * m2["elapsed"] / args.steps, "images_in_flight_per_gpu": m2["in_flight"]}
                 a.update(summarise(args.steps, m2))
                 if "graph_s" in m2:
                     a["graph_replay"] = {"value": 1.0 / m2["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m2["graph_s"]}
