@@ -79,9 +79,9 @@ def parse():
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
     p.add_argument("--no-graph", action="store_true", help="native engine: direct launches on every step (counter-profiling runs)")
-    p.add_argument("--event-every", type=int, default=4,
+    p.add_argument("--event-every", type=int, default=0,
                    help="native engine: record the per-kernel HIP events on every N-th timed step (those steps run as direct "
-                        "launches, the others replay the captured HIP graph -- the library's default path)")
+                        "launches, the others replay the captured HIP graph -- the library's default path); 0 = max(4, steps / 8)")
     p.add_argument("--math", default=os.environ.get("MNC_MATH"), choices=["fp32", "bf16x3", "f16"],
                    help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
@@ -98,7 +98,10 @@ def parse():
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
                         "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline)")
-    p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) | gloo (functional test on fewer GPUs than ranks)")
+    p.add_argument("--dist-backend", default="nccl",
+                   help="transport of the instance blocks: nccl = RCCL all-gather issued by libmnc_hip.so on a device stream (one rank "
+                        "per GPU) | gloo = host tensors (functional test on fewer GPUs than ranks).  torch.distributed itself -- the "
+                        "control plane: rendezvous, barrier, the ncclUniqueId -- always runs on gloo")
     return p.parse_args()
 
 
@@ -128,6 +131,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     conf = CONFIGS[args.config]
+    if args.event_every <= 0:
+        args.event_every = max(4, args.steps // 8)
     math = args.math or conf["math"]
     if args.config != "vgg16" and args.engine == "native":
         # the hand-written native pipeline is the VGG-16 5-stage graph; any other prototxt runs on the engine's plan, captured
@@ -137,18 +142,18 @@ def main():
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
     if launched:
-        # torch BEFORE libmnc_hip.so: the torch wheel bundles its own ROCm runtime (libamdhip64 / libhsa-runtime64 / librccl, same
-        # sonames as /opt/rocm's).  Loaded first, it is the one runtime of the process and libmnc_hip.so binds to it; loaded
-        # second, the process would hold two HSA runtimes and torch finds no GPU.
+        # libmnc_hip.so BEFORE torch, and torch.distributed on gloo: torch is only the control plane here (rendezvous, barrier,
+        # max-over-ranks, carrying the 128-byte ncclUniqueId) and never touches a GPU; the data path -- kernels, streams, the RCCL
+        # all-gather of the instance blocks -- is libmnc_hip.so's, bound to /opt/rocm's runtime exactly as in the N = 1 run without a
+        # launcher.  (The torch wheel bundles an older ROCm runtime under the same sonames: loaded first it becomes the process's
+        # runtime -- measured in round 3: HIP graphs on two streams do not overlap there and the 1-rank launcher run lost the whole
+        # gain of the second image in flight, 191 vs 200 images/s.)
+        from mnc_amd import _lib as _early
+        _early.load()
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:
-            if torch.cuda.device_count() < local + 1:
-                raise SystemExit("rank %d (local %d): only %d GPU(s) visible" % (rank, local, torch.cuda.device_count()))
-            torch.cuda.set_device(local)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local) if on_gpu else None)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from mnc_amd import _lib
     ndev = _lib.device_count()
     if on_gpu and ndev < (local + 1):
@@ -240,6 +245,7 @@ def main():
                 t_b = time.perf_counter()
                 blk = net.vote_instances(boxes, masks, scores, 21, 100, im.shape[1], im.shape[0], nms_t, iou_t)
                 t_c = time.perf_counter()
+                counts = rec = None
             phase["prep+forward+tail"] += t_b - t_a; phase["voting"] += t_c - t_b
             finish(counts, rec, blk, 0, t_c)
 
@@ -280,12 +286,7 @@ def main():
             for nn in nets:
                 nn.sync()
             if launched:
-                if on_gpu:
-                    torch.cuda.synchronize()
                 dist.barrier()
-                if on_gpu:
-                    torch.cuda.synchronize()
-                net.sync()
 
         for k in range(warmup):
             if inflight > 1:
@@ -452,7 +453,7 @@ def main():
     ranks = [{"rank": rank, "device": dev_id, "host": socket.gethostname(), "ms_per_step": 1e3 * elapsed / args.steps,
               "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}]
     if launched:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         box = [None] * world
@@ -481,6 +482,7 @@ def main():
                                        else "single GPU") + ("; %d images in flight per GPU (own stream each: image k+1 is launched "
                                                              "before image k is fetched)" % m["in_flight"] if m["in_flight"] > 1 else "")},
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
+            "control_plane": "torch.distributed/gloo" if launched else None,
         }
         out.update(summarise(args.steps, m))
         conv = [r for r in m["records"] if r[0].startswith("conv3x3")]

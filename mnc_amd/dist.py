@@ -82,6 +82,11 @@ class InstanceGatherer(object):
             self.rccl_version = v.value
             self._recv = _DevBuf(net._ctx)
             self._recv.ensure(world * cap * REC_DIM * 4)
+            # the gathered blocks come down into PINNED memory: a copy into pageable memory goes through the runtime's staging
+            # path, which waits for the whole device -- i.e. for the other image in flight on another stream
+            pin = ctypes.c_void_p()
+            _lib.call("mnc_host_alloc", net._ctx.h, world * cap * REC_DIM * 4, ctypes.addressof(pin))
+            self._pin = pin.value
             self._send0 = _DevBuf(net._ctx)                      # warm-up block: the first collective builds the rings
             p = self._send0.ensure(cap * REC_DIM * 4)
             _lib.call("mnc_dev_zero", net._ctx.h, p, cap * REC_DIM * 4)
@@ -112,8 +117,11 @@ class InstanceGatherer(object):
         """Device transport: the gathered [world, cap, 447] blocks as one numpy array (one copy, one synchronisation).
         Truncation is reported, as pack_instances does on the host path: `rows` = this rank's instance count when the caller
         already has it (mnc_net_fetch's counts[0]); otherwise the sent block's 256-byte head is read after the gather."""
-        out = np.zeros((self.world, self.cap, REC_DIM), np.float32)
-        self._lib.call("mnc_d2h", self.net._ctx.h, self._lib.ptr(out), self._recv.ptr, out.nbytes)
+        nbytes = self.world * self.cap * REC_DIM * 4
+        self._lib.call("mnc_d2h_async", self.net._ctx.h, self._pin, self._recv.ptr, nbytes)
+        self._lib.call("mnc_ctx_sync", self.net._ctx.h)
+        out = np.frombuffer((ctypes.c_char * nbytes).from_address(self._pin), dtype=np.float32).reshape(
+            self.world, self.cap, REC_DIM).copy()
         blk, self._sent = getattr(self, "_sent", None), None
         if rows is None and blk is not None and hasattr(blk, "head"):
             rows = int(blk.head()[0])
@@ -132,6 +140,9 @@ class InstanceGatherer(object):
     def close(self):
         if self.net is not None and getattr(self, "_recv", None) is not None:
             self._lib.call("mnc_comm_destroy", self.net._ctx.h)
+            if getattr(self, "_pin", None):
+                self._lib.call("mnc_host_free", self.net._ctx.h, self._pin)
+                self._pin = None
             self._recv.release()
             self._send0.release()
             self._recv = None
