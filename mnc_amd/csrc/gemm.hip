@@ -16,6 +16,7 @@
 // Split-K (chosen so that tiles x splits ~ the 256 CUs) writes fp32 partials to the context scratch; a second kernel
 // sums them in fixed order (deterministic) and applies bias + activation.  With one split the epilogue is fused.
 #include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 #include "mnc_internal.h"
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void fc_mfma_kernel(const float* __restrict__ 
 // kWM = waves along M: 1 -> four waves, each all kMT row tiles x its 32 columns (one wave per SIMD); 2 -> eight waves, wave
 // (wm, wn) owns kMT / 2 row tiles x columns 32 wn: half the accumulators, two waves per SIMD -- one wave's barrier and fragment
 // waits run under its partner's MFMAs.
-template <int kMT, int ABL = 0, int kWM = 1>
+template <int kMT, int ABL = 0, int kWM = 1, int HALF = 0>
 __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           float* __restrict__ part, int M, int N, int K, int ldc, int kper,
@@ -322,6 +323,29 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+  // HALF (M in (32 kMT - 32, 32 kMT - 16], e.g. 300 RoIs = 9 row tiles + 12 rows): the last row tile holds at most 16 live rows, so
+  // the waves that own it (wm = kWM - 1) multiply it with v_mfma_f32_16x16x4_f32 on rows [32 (kMT - 1), +16) only -- 16 x 32
+  // outputs as two 16-column halves, 4 K-values per instruction: four 32-cycle MFMAs per K-group instead of four 64-cycle ones,
+  // i.e. 304 rows of matrix-pipe work instead of 320 (the padding of 300 -> 320 was 6.7 % of the pipe time).  Operand layout of
+  // that instruction: lane l supplies A[row l % 16][k = l / 16] and B[col l % 16][k = l / 16]; D register i is row 4 (l / 16) + i.
+  // A K-group (8 values = chunks 2 kc, 2 kc + 1 of a row) is two such MFMAs; each lane reads ONE float per operand and MFMA
+  // (ds_read_b32 at element l / 16 of the chunk; 16 rows x 4 elements land on 64 different banks under the row swizzle).
+  constexpr bool kHalf = HALF != 0;
+  static_assert(!kHalf || (kWM == 2 && ABL == 0), "the half tile exists in the eight-wave product build only");
+  const bool last_wave = kHalf && wm == kWM - 1;                 // wave-uniform
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v hacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // K order: a 32 x 32 x 2 MFMA on component q of the fragments multiplies k = q (lanes 0-31) and k = 4 + q (lanes 32-63) of the
+  // K-group, so an output accumulates k0, k4, k1, k5, k2, k6, k3, k7.  The two 16 x 16 x 4 MFMAs keep that order: MFMA h takes
+  // (k_2h, k_4+2h, k_2h+1, k_4+2h+1) from its lane groups 0..3, i.e. group g reads chunk 2 kc + (g & 1), element 2 h + (g >> 1).
+  const int r16 = lane & 15, g4 = lane >> 4;
+  int h_off[8];                                                   // [2 kc + h]: byte offset inside this lane's half-tile row
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    h_off[c] = ((2 * (c >> 1) + (g4 & 1)) ^ ((r16 >> 1) & 7)) * 16 + (2 * (c & 1) + (g4 >> 1)) * 4;
+  const int ha_base = ((kMT - 1) * 32 + r16) * 128, hb_base = (kBM + wn * 32 + r16) * 128;
+  int hflip = 0;                                                  // which stage buffer the half-tile offsets point into
+
   // fragment of K-group kc (8 k values): chunk 2 kc + kk of row (tile row j) -> slot (2 kc + kk) ^ ((j >> 1) & 7); the tile
   // offsets (32 rows = 4 KB) and the weight rows (kBM + 32 wave + j) leave (row >> 1) & 7 unchanged.  Byte offsets.
   int a_off[4], b_off[4];
@@ -331,45 +355,67 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
     a_off[kc] = ((wm * TR * 32 + j) * 32 + c * 4) * 4;
     b_off[kc] = ((kBM + wn * 32 + j) * 32 + c * 4) * 4;
   }
-  struct Frags { float4 a[TR]; float4 b; };
-  auto read_frags = [&](int kc, int flip, Frags& f) {
+  struct Frags { float4 a[TR]; float4 b; float ha[2]; float hb[2][2]; };
+  // LAST: the wave's last row tile is the half tile (its 32 x 32 fragment is not read)
+  auto read_frags = [&](int kc, int flip, Frags& f, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     f.b = *reinterpret_cast<const float4*>(s_fc_dma + (b_off[kc] ^ flip));
 #pragma unroll
-    for (int t = 0; t < TR; ++t) f.a[t] = *reinterpret_cast<const float4*>(s_fc_dma + (a_off[kc] ^ flip) + t * 4096);
+    for (int t = 0; t < (LAST ? TR - 1 : TR); ++t) f.a[t] = *reinterpret_cast<const float4*>(s_fc_dma + (a_off[kc] ^ flip) + t * 4096);
+    if (LAST) {
+      const int hf = hflip ^ flip;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f.ha[h] = *reinterpret_cast<const float*>(s_fc_dma + ((ha_base + h_off[2 * kc + h]) ^ hf));
+        f.hb[h][0] = *reinterpret_cast<const float*>(s_fc_dma + ((hb_base + h_off[2 * kc + h]) ^ hf));
+        f.hb[h][1] = *reinterpret_cast<const float*>(s_fc_dma + ((hb_base + 2048 + h_off[2 * kc + h]) ^ hf));
+      }
+    }
   };
-  auto mfmas = [&](const Frags& f) {                 // k outermost: consecutive MFMAs go to different accumulators
+  auto half_mfmas = [&](const Frags& f) {            // k 0-3 then k 4-7 of the group, the two 16-column halves alternating
+    hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ha[0], f.hb[0][0], hacc[0], 0, 0, 0);
+    hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ha[0], f.hb[0][1], hacc[1], 0, 0, 0);
+    hacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ha[1], f.hb[1][0], hacc[0], 0, 0, 0);
+    hacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.ha[1], f.hb[1][1], hacc[1], 0, 0, 0);
+  };
+  auto mfmas = [&](const Frags& f, auto last_tag) {  // k outermost: consecutive MFMAs go to different accumulators
+    constexpr bool LAST = decltype(last_tag)::value;
+    constexpr int NT = LAST ? TR - 1 : TR;
 #pragma unroll
-    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].x, f.b.x, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].x, f.b.x, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].y, f.b.y, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].y, f.b.y, acc[t], 0, 0, 0);
+    if (LAST) half_mfmas(f);
 #pragma unroll
-    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].z, f.b.z, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].z, f.b.z, acc[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < TR; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].w, f.b.w, acc[t], 0, 0, 0);
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t].w, f.b.w, acc[t], 0, 0, 0);
   };
   auto pin_acc = [&]() {
 #pragma unroll
     for (int t = 0; t < TR; ++t) asm volatile("" : "+a"(acc[t]));
   };
-  constexpr int kNM = 4 * TR, kNR = TR + 1;
 
-  if (nstages > 0) {
+  auto run = [&](auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    constexpr int NT = LAST ? TR - 1 : TR;
+    constexpr int kNM = 4 * NT + (LAST ? 4 : 0), kNR = NT + 1 + (LAST ? 6 : 0);    // MFMAs / LDS reads per K-group
     Frags f0, f1;
     dma_stage(0, 0);
     dma_stage(1, kBufXor);
     dma_wait();
     __syncthreads();
-    read_frags(0, 0, f0);
+    read_frags(0, 0, f0, last_tag);
     int cur = 0;                                     // byte offset of the buffer stage s sits in (scalar)
     for (int s = 0; s < nstages; ++s) {
       // stage s sits in buffer `cur` (a_off / b_off point into it) with its group-0 fragments in f0; stage s + 1 is landing in
       // (or already in) the other buffer
-      read_frags(1, 0, f1);
-      mfmas(f0);                                     // group 0
-      read_frags(2, 0, f0);
-      mfmas(f1);                                     // group 1
-      read_frags(3, 0, f1);
-      mfmas(f0);                                     // group 2
+      read_frags(1, 0, f1, last_tag);
+      mfmas(f0, last_tag);                           // group 0
+      read_frags(2, 0, f0, last_tag);
+      mfmas(f1, last_tag);                           // group 1
+      read_frags(3, 0, f1, last_tag);
+      mfmas(f0, last_tag);                           // group 2
 #pragma unroll
       for (int i = 0; i < 3 * kNM; ++i) {            // one slot per MFMA; the fragment reads spread evenly over the slots
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -378,31 +424,38 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
       pin_acc();
       dma_wait();                                    // stage s + 1 has landed ...
       __syncthreads();                               // ... for every wave, and nobody reads buffer `cur` any more
-      read_frags(0, kBufXor, f0);                    // group 0 of stage s + 1
-      {                                              // group 3: the 11 reads under the first MFMAs, then one copy per MFMA
+      read_frags(0, kBufXor, f0, last_tag);          // group 0 of stage s + 1
+      {                                              // group 3: the reads under the first MFMAs, then one copy per MFMA
         const long off = ABL == 1 ? 0 : (long)min(s + 2, nstages - 1) * 32;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-          for (int t = 0; t < TR; ++t) {
-            const int i = q * TR + t;
+          for (int t = 0; t < NT; ++t) {
+            const int i = q * NT + t;
             const float av = q == 0 ? f1.a[t].x : q == 1 ? f1.a[t].y : q == 2 ? f1.a[t].z : f1.a[t].w;
             const float bv = q == 0 ? f1.b.x : q == 1 ? f1.b.y : q == 2 ? f1.b.z : f1.b.w;
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            if (i >= kNM - kPer - 2 && i < kNM - 2) {
+            if (i >= 4 * NT - kPer - 2 && i < 4 * NT - 2) {
               __builtin_amdgcn_sched_barrier(0);
-              dma_piece(i - (kNM - kPer - 2), off, cur);
+              dma_piece(i - (4 * NT - kPer - 2), off, cur);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+          if (LAST && q == 0) half_mfmas(f1);
+        }
       }
       pin_acc();
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) { a_off[kc] ^= kBufXor; b_off[kc] ^= kBufXor; }
+      hflip ^= kBufXor;
       cur ^= kBufXor;
     }
     dma_wait();                                      // the copies issued by the last two stages have landed before the LDS is released
     __syncthreads();
+  };
+  if (nstages > 0) {
+    if (last_wave) run(std::true_type{});
+    else run(std::false_type{});
   }
 
   // D[row = m (reg&3)+8*(reg>>2)+4*kk][col = n j]
@@ -411,6 +464,7 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
     const float bv = fused ? bias[n] : 0.f;
 #pragma unroll
     for (int t = 0; t < TR; ++t) {
+      if (last_wave && t == TR - 1) continue;        // the half tile is stored below
       if (wm * TR + t < mtiles) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -419,6 +473,22 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
             if (fused) out[(long)m * ldc + n] = apply_act(acc[t][e] + bv, act);
             else part[((long)split * M + m) * N + n] = acc[t][e];
           }
+        }
+      }
+    }
+  }
+  if (last_wave) {                                   // D[row = 4 (lane / 16) + reg][col = lane % 16] of the two 16-column halves
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int nh = n0 + wn * 32 + ch * 16 + r16;
+      if (nh >= N) continue;
+      const float bh = fused ? bias[nh] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + (kMT - 1) * 32 + 4 * g4 + e;
+        if (m < M) {
+          if (fused) out[(long)m * ldc + nh] = apply_act(hacc[ch][e] + bh, act);
+          else part[((long)split * M + m) * N + nh] = hacc[ch][e];
         }
       }
     }
@@ -611,16 +681,17 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     LaunchScope ls(ctx, small ? "fc_mfma_small" : "fc_mfma", flops, bytes);
 #define MNC_FC_LAUNCH(MT, SK, A) hipLaunchKernelGGL((fc_mfma_kernel<MT, SK, A>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, \
                          d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm)
-#define MNC_FC_DMA_LAUNCH(A, WM)                                                                                                    \
+#define MNC_FC_DMA_LAUNCH(A, WM) MNC_FC_DMA_LAUNCH_H(A, WM, 0)
+#define MNC_FC_DMA_LAUNCH_H(A, WM, H)                                                                                               \
   do {                                                                                                                              \
     static std::atomic<unsigned long long> attr_set{0};            /* one bit per device: function attributes are per device */   \
     const unsigned long long bit = 1ull << (ctx->device & 63);                                                                      \
     if (!(attr_set.load(std::memory_order_relaxed) & bit)) {                                                                        \
-      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, A, WM>),                                 \
+      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma_kernel<10, A, WM, H>),                                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                            \
       attr_set.fetch_or(bit, std::memory_order_relaxed);                                                                            \
     }                                                                                                                               \
-    hipLaunchKernelGGL((fc_mfma_dma_kernel<10, A, WM>), dim3(tn * splits * tm), dim3(256 * WM), lds, ctx->stream, d_a, d_w, d_bias, \
+    hipLaunchKernelGGL((fc_mfma_dma_kernel<10, A, WM, H>), dim3(tn * splits * tm), dim3(256 * WM), lds, ctx->stream, d_a, d_w, d_bias, \
                        d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm);                                  \
   } while (0)
     if (dma) {
@@ -635,6 +706,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
       else
 #endif
       if (waves == 4) MNC_FC_DMA_LAUNCH(0, 1);
+      // one row block whose last row tile holds at most 16 rows (300 RoIs: 288 + 12): that tile on 16 x 16 x 4 MFMAs (FC_HALF=0: off)
+      else if (tm == 1 && M > 288 && M <= 304 && tune(ctx, T_FC_HALF, 1) != 0) MNC_FC_DMA_LAUNCH_H(0, 2, 1);
       else MNC_FC_DMA_LAUNCH(0, 2);
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
@@ -659,6 +732,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     }
 #undef MNC_FC_LAUNCH
 #undef MNC_FC_DMA_LAUNCH
+#undef MNC_FC_DMA_LAUNCH_H
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }

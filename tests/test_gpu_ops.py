@@ -781,7 +781,8 @@ def test_fc_mfma(dev, M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K,act,ldc_pad", [(300, 4096, 25088, 1, 0), (300, 520, 4096, 1, 8), (290, 1024, 2112, 0, 0),
-                                               (640, 256, 6400, 1, 0), (161, 128, 8192, 2, 64)])
+                                               (640, 256, 6400, 1, 0), (161, 128, 8192, 2, 64), (304, 384, 8192, 0, 0),
+                                               (289, 1000, 4096, 2, 24)])
 def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
     """fc_mfma_dma_kernel (320-row blocks, operand panels copied global -> LDS by DMA into XOR-swizzled rows; fc6's kernel):
     against torch, and against the register-staged kernel (MNC_FC_DMA=0) on the same call -- the products and the order inside a
@@ -812,6 +813,15 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
         assert rel < 1e-4, (dma, d, rel)
         outs.append(got[:, :N])
     assert err(outs[0], outs[1])[1] < 1e-5 and np.array_equal(outs[0], outs[2])      # same K order per accumulator
+    if 288 < M <= 304:
+        # one row block whose last row tile has at most 16 live rows: the default run above multiplied it with 16 x 16 x 4 MFMAs
+        # (HALF build: 304 instead of 320 rows of matrix-pipe work); FC_HALF=0 is the all-32x32 build -- same K order per output
+        tune("FC_HALF", "0")
+        d_o = dev.empty((M * ld,), fill=np.nan)
+        dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
+        full = dev.get(d_o, (M, ld))[:, :N]
+        print("half tile vs full tile: max rel %.3e, identical %s" % (err(outs[0], full)[1], np.array_equal(outs[0], full)))
+        assert err(outs[0], full)[1] < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES + [(300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2)])
