@@ -196,8 +196,20 @@ def main():
             net = NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph)
         else:
             net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
-        inflight = args.in_flight if (native and in_flight is None) else (in_flight or 1)
-        nets = [net] + [NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph) for _ in range(inflight - 1)]
+        inflight = args.in_flight if ((native or engine == "graph") and in_flight is None) else (in_flight or 1)
+        if native:
+            nets = [net] + [NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph) for _ in range(inflight - 1)]
+        else:
+            nets = [net] + [Net(proto, weights, caffe.TEST, device_id=dev_id, math=math) for _ in range(inflight - 1)]
+
+        def launch_on(which, im):
+            if native:
+                nets[which].launch(im)
+            else:
+                nets[which].launch_image(im, 21, 100, nms_t, iou_t, use_graph=not args.no_graph)
+
+        def fetch_from(which):
+            return nets[which].fetch(record_cap=100) if native else nets[which].fetch_image()
         holder = net
         if launched and on_gpu and inflight > 1:
             # the communicator lives on its own context / stream: a gather enqueued on one image's stream would wait behind the
@@ -213,7 +225,7 @@ def main():
         def finish(counts, rec, blk, which, t_c):
             """what happens to one image's voted instances: the RCCL / gloo gather of the [100,447] block (N > 1) or numpy lists"""
             if gatherer is not None and gatherer.net is not None:   # RCCL, device block -> device blocks
-                gatherer.gather_block(nets[which].block() if native else (net._inst.view() if blk is None else blk))
+                gatherer.gather_block(nets[which].block() if native else (nets[which]._inst.view() if blk is None else blk))
                 t_d = time.perf_counter()
                 last["gathered"] = gatherer.fetch(rows=int(counts[0]) if blk is None else None)   # [world, 100, 447] on the host
             elif gatherer is not None:                              # gloo functional path (host tensors)
@@ -255,7 +267,7 @@ def main():
             while pending:
                 which = pending.pop(0)
                 t_a = time.perf_counter()
-                counts, rec = nets[which].fetch(record_cap=100)
+                counts, rec = fetch_from(which)
                 t_c = time.perf_counter()
                 phase["prep+forward+tail"] += t_c - t_a
                 finish(counts, rec, None, which, t_c)
@@ -270,13 +282,13 @@ def main():
                 return
             which = k % inflight
             t_a = time.perf_counter()
-            nets[which].launch(images[(rank + k) % N_IMAGES])
+            launch_on(which, images[(rank + k) % N_IMAGES])
             phase["prep+forward+tail"] += time.perf_counter() - t_a
             pending.append(which)
             while len(pending) >= inflight:
                 which0 = pending.pop(0)
                 t_a = time.perf_counter()
-                counts, rec = nets[which0].fetch(record_cap=100)
+                counts, rec = fetch_from(which0)
                 t_c = time.perf_counter()
                 phase["prep+forward+tail"] += t_c - t_a
                 finish(counts, rec, None, which0, t_c)
@@ -445,7 +457,7 @@ def main():
             rows.append(e)
         return rows
     want_resident = world == 1 and not args.no_resident and args.engine == "python"
-    headline_pipelined = args.engine == "native" and args.in_flight > 1
+    headline_pipelined = args.engine in ("native", "graph") and args.in_flight > 1
     m = measure(math, args.steps, args.warmup, resident_steps=min(args.steps, 50) if want_resident else 0,
                 pipelined_steps=0 if (args.no_resident or headline_pipelined) else min(args.steps, 100))
     elapsed = m["elapsed"]

@@ -1529,7 +1529,14 @@ class Net(object):
 
     # ------------------------------------------------------------------------------------------------ one image, one launch
     def detect_image(self, im, num_classes=None, max_per_image=100, nms_thresh=None, iou_thresh=None, use_graph=True):
-        """tools/demo.py's per-image body -- prepare_mnc_args, net.forward, im_detect's tail, gpu_mask_voting (demo.py:54-100, 147)
+        """launch_image + fetch_image: one image, results on the host."""
+        self.launch_image(im, num_classes, max_per_image, nms_thresh, iou_thresh, use_graph)
+        return self.fetch_image()
+
+    def launch_image(self, im, num_classes=None, max_per_image=100, nms_thresh=None, iou_thresh=None, use_graph=True):
+        """First half of detect_image: returns as soon as the image's launch sequence is enqueued (fetch_image waits for it) -- a
+        host that keeps two Nets in flight launches image k+1 on one before fetching image k from the other.
+        tools/demo.py's per-image body -- prepare_mnc_args, net.forward, im_detect's tail, gpu_mask_voting (demo.py:54-100, 147)
         -- for ONE uint8 BGR image as one asynchronous launch sequence with a single synchronisation:
             pinned staging -> H2D -> device prep -> every layer of the prototxt -> tail -> voting -> records D2H into pinned memory
         -> (counts int32[num_classes], records float32[R, 6 + S*S]) exactly as NativeNet.forward_image / InstanceBlock.fetch return
@@ -1618,7 +1625,7 @@ class Net(object):
                         pass
                     st.setdefault("no_graph", set()).add(key)           # this graph / size cannot be captured: direct launches
                     st["seen"] = None
-                    return self.detect_image(im, num_classes, max_per_image, nms_thresh, iou_thresh, use_graph=False)
+                    return self.launch_image(im, num_classes, max_per_image, nms_thresh, iou_thresh, use_graph=False)
                 if allocs0 != self._ctx.allocs:                         # something was (re-)allocated while capturing
                     _lib.call("mnc_graph_destroy", gp.value)
                     blk, nbytes = body()
@@ -1648,6 +1655,19 @@ class Net(object):
         else:
             speculated, post = self._speculated is not None, (self._speculated[2] if self._speculated else 0)
         self._speculated = None
+        st["pending"] = (im, blk, nbytes, speculated, post, K, int(max_per_image), nms_t, iou_t)
+        return None
+
+    def fetch_image(self):
+        """Second half of detect_image: wait for the launched image -> (counts, records)."""
+        from mnc_config import cfg
+        from .instances import HEAD_BYTES
+        st = self.__dict__.get("_img")
+        if not st or not st.get("pending"):
+            raise RuntimeError("fetch_image: no image has been launched on this net")
+        im, blk, nbytes, speculated, post, K, max_per_image, nms_t, iou_t = st.pop("pending")
+        H, W = im.shape[:2]
+        h = self._ctx.h
         _lib.call("mnc_ctx_sync", h)
         raw = (ctypes.c_char * (nbytes + 4)).from_address(st["pin_out"])
         buf = np.frombuffer(raw, dtype=np.uint8)

@@ -57,10 +57,20 @@ class InstanceBlock(object):
         """-> (counts int32[num_classes], records float32[R, rec_dim]): ONE device-to-host copy of the head and the first
         gather_rows records (a second one only when more rows tied at the threshold); synchronises the net's stream."""
         if self._host is None:
+            import ctypes
             first = min(self.gather_rows, self.rows_cap)
             nbytes = HEAD_BYTES + first * self.rec_dim * 4
-            raw = np.zeros(nbytes, np.uint8)
-            _lib.call("mnc_d2h", self._net._ctx.h, _lib.ptr(raw), self.ptr, nbytes)
+            # through pinned memory: a copy into pageable memory takes the runtime's staging path (0.45 ms for these 179 KB at
+            # 1000 RoIs, and it waits for every stream of the device)
+            if getattr(self, "_pin", None) is None or self._pin_cap < nbytes:
+                if getattr(self, "_pin", None):
+                    _lib.call("mnc_host_free", self._net._ctx.h, self._pin)
+                p = ctypes.c_void_p()
+                _lib.call("mnc_host_alloc", self._net._ctx.h, nbytes, ctypes.addressof(p))
+                self._pin, self._pin_cap = p.value, nbytes
+            _lib.call("mnc_d2h_async", self._net._ctx.h, self._pin, self.ptr, nbytes)
+            _lib.call("mnc_ctx_sync", self._net._ctx.h)
+            raw = np.frombuffer((ctypes.c_char * nbytes).from_address(self._pin), dtype=np.uint8).copy()
             counts = raw[:self.num_classes * 4].view(np.int32).copy()
             rec = raw[HEAD_BYTES:].view(np.float32).reshape(first, self.rec_dim)
             R = int(counts[0])
@@ -78,6 +88,9 @@ class InstanceBlock(object):
         return split_records(rec, counts[1:self.num_classes], self.S)
 
     def release(self):
+        if getattr(self, "_pin", None):
+            _lib.call("mnc_host_free", self._net._ctx.h, self._pin)
+            self._pin = None
         self._buf.release()
 
 
