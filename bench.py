@@ -423,39 +423,6 @@ def main():
             out["roofline_by_kernel"] = roofline_by_kernel(records, steps)
         return out
 
-    def roofline_by_kernel(records, steps):
-        """One entry per (profiling scope, shape): the dominant InnerProduct split into its three shapes, the Winograd trunk with
-        algorithmic AND executed flop, conv1_1 against HBM.  Same events as `roofline` (HIP events on the engine's stream)."""
-        groups = {}
-        for name, kms, fl, by in records:
-            g = groups.setdefault((name, round(fl / 1e7)), [name, 0, 0.0, fl, by])
-            g[1] += 1; g[2] += kms
-        rows = []
-        for (name, _), (_, cnt, tot_ms, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
-            avg_s = tot_ms / cnt * 1e-3
-            label = FC_SHAPES.get((name, round(fl / 1e9, 2)), name)
-            e = {"scope": name, "what": label, "launches_per_image": round(cnt / steps, 3), "avg_launch_ms": tot_ms / cnt,
-                 "ms_per_image": tot_ms / steps, "algorithmic_gflop_per_launch": fl / 1e9, "algorithmic_mb_per_launch": by / 1e6}
-            hbm_frac = by / avg_s / 1e9 / PEAK_HBM_GBS if by else None
-            if fl >= 1e9 and name not in HBM_BOUND_SCOPES:
-                peak, basis = mfma_peak(name)
-                e.update(bound="mfma", achieved=fl / avg_s / 1e12, peak=peak, unit="TFLOP/s", frac=fl / avg_s / 1e12 / peak,
-                         peak_basis=basis)
-                if "wino" in name:          # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
-                    ex = fl / 2.25
-                    e.update(executed_gflop_per_launch=ex / 1e9, executed_tflops=ex / avg_s / 1e12,
-                             executed_frac_of_peak=ex / avg_s / 1e12 / peak,
-                             note="frac = algorithmic (direct-form) flop / time / peak, can exceed what the pipe executes; "
-                                  "executed_* = the MFMA work Winograd F(2x2,3x3) actually issues (algorithmic / 2.25)")
-                e["hbm_frac_algorithmic"] = hbm_frac
-            else:
-                e.update(bound="hbm", achieved=by / avg_s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
-            pos = FC_POSITIONS.get(label)
-            e["traffic"], e["traffic_source"] = pmc_traffic(name, positions=pos)
-            if e["traffic"] and by:
-                e["traffic_over_algorithmic"] = e["traffic"] / by
-            rows.append(e)
-        return rows
     want_resident = world == 1 and not args.no_resident and args.engine == "python"
     headline_pipelined = args.engine in ("native", "graph") and args.in_flight > 1
     m = measure(math, args.steps, args.warmup, resident_steps=min(args.steps, 50) if want_resident else 0,
@@ -615,6 +582,41 @@ def resnet50_line():
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "config", "host_phase_ms_per_image",
             "kernel_ms_per_image", "roofline")
     return {k: d[k] for k in keep if k in d}
+
+
+def roofline_by_kernel(records, steps):
+    """One entry per (profiling scope, shape): the dominant InnerProduct split into its three shapes, the Winograd trunk with
+    algorithmic AND executed flop, conv1_1 against HBM.  Same events as `roofline` (HIP events on the engine's stream)."""
+    groups = {}
+    for name, kms, fl, by in records:
+        g = groups.setdefault((name, round(fl / 1e7)), [name, 0, 0.0, fl, by])
+        g[1] += 1; g[2] += kms
+    rows = []
+    for (name, _), (_, cnt, tot_ms, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+        avg_s = tot_ms / cnt * 1e-3
+        label = FC_SHAPES.get((name, round(fl / 1e9, 2)), name)
+        e = {"scope": name, "what": label, "launches_per_image": round(cnt / steps, 3), "avg_launch_ms": tot_ms / cnt,
+             "ms_per_image": tot_ms / steps, "algorithmic_gflop_per_launch": fl / 1e9, "algorithmic_mb_per_launch": by / 1e6}
+        hbm_frac = by / avg_s / 1e9 / PEAK_HBM_GBS if by else None
+        if fl >= 1e9 and name not in HBM_BOUND_SCOPES:
+            peak, basis = mfma_peak(name)
+            e.update(bound="mfma", achieved=fl / avg_s / 1e12, peak=peak, unit="TFLOP/s", frac=fl / avg_s / 1e12 / peak,
+                     peak_basis=basis)
+            if "wino" in name:          # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
+                ex = fl / 2.25
+                e.update(executed_gflop_per_launch=ex / 1e9, executed_tflops=ex / avg_s / 1e12,
+                         executed_frac_of_peak=ex / avg_s / 1e12 / peak,
+                         note="frac = algorithmic (direct-form) flop / time / peak, can exceed what the pipe executes; "
+                              "executed_* = the MFMA work Winograd F(2x2,3x3) actually issues (algorithmic / 2.25)")
+            e["hbm_frac_algorithmic"] = hbm_frac
+        else:
+            e.update(bound="hbm", achieved=by / avg_s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
+        pos = FC_POSITIONS.get(label)
+        e["traffic"], e["traffic_source"] = pmc_traffic(name, positions=pos)
+        if e["traffic"] and by:
+            e["traffic_over_algorithmic"] = e["traffic"] / by
+        rows.append(e)
+    return rows
 
 
 # profiling scope of the engine -> the kernels (rocprofv3 names, regular expressions) launched inside it

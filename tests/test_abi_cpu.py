@@ -125,3 +125,59 @@ def test_build_is_up_to_date_and_product_never_imports_the_oracle():
     for f in ("tools/demo.py", "tools/_init_paths.py"):
         text = open(os.path.join(os.path.dirname(_lib.HERE), f)).read()
         assert "oracle" not in text
+
+
+def test_bench_roofline_by_kernel_groups_shapes_and_tags_traffic(tmp_path, monkeypatch):
+    """bench.roofline_by_kernel: the InnerProduct scope is split by shape (algorithmic flop), the Winograd scope carries executed
+    flop next to algorithmic, conv1_1 is priced against HBM; counter traffic is reported only from a PMC profile whose build tag
+    equals the running build's source hash, per position of the InnerProduct kernel's launch cycle."""
+    import json
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    from mnc_amd import _build
+    rec = []
+    for _ in range(3):                                      # three event steps
+        rec += [("fc_mfma", 0.14, 15.4140672e9, 223.5e6), ("fc_mfma", 0.47, 61.6562688e9, 446.1e6), ("fc_mfma", 0.09, 10.0663296e9, 76.9e6),
+                ("fc_mfma", 0.47, 61.6562688e9, 446.1e6), ("fc_mfma", 0.09, 10.0663296e9, 76.9e6),
+                ("conv3x3_wino_mfma", 0.2, 44.2368e9, 307.3e6), ("conv3x3_c3", 0.064, 2.0736e9, 160.8e6)]
+    prof = {"_build": "stale", "fc_mfma_dma_kernel<10, 0, 2, 1>": {"calls": 15, "hbm_bytes_corrected": 3.0e8,
+            "by_position": [{"hbm_bytes_corrected": 2.6e8}, {"hbm_bytes_corrected": 4.8e8}, {"hbm_bytes_corrected": 1.2e8},
+                            {"hbm_bytes_corrected": 4.8e8}, {"hbm_bytes_corrected": 1.2e8}] * 2},
+            "conv3x3_c3_kernel<0>": {"calls": 3, "hbm_bytes_corrected": 1.7e8}}
+    os.makedirs(str(tmp_path / "profiles"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    with open(str(tmp_path / "profiles" / "pmc_latest.json"), "w") as f:
+        json.dump(prof, f)
+    rows = bench.roofline_by_kernel(rec, 3)
+    what = {r["what"]: r for r in rows}
+    assert set(what) == {"fc6_maskest (300 x 256 x 100352)", "fc6 / fc6_mask (300 x 4096 x 25088)", "fc7 / fc7_mask (300 x 4096 x 4096)",
+                         "conv3x3_wino_mfma", "conv3x3_c3"}
+    fc6 = what["fc6 / fc6_mask (300 x 4096 x 25088)"]
+    assert fc6["launches_per_image"] == 2.0 and abs(fc6["frac"] - 61.6562688e9 / 0.47e-3 / 1e12 / 157.3) < 1e-9
+    assert all(r["traffic"] is None and "stale" in r["traffic_source"] for r in rows)          # wrong build: no traffic
+    w = what["conv3x3_wino_mfma"]
+    assert abs(w["executed_gflop_per_launch"] - 44.2368 / 2.25) < 1e-9 and w["executed_frac_of_peak"] < w["frac"]
+    assert what["conv3x3_c3"]["bound"] == "hbm" and what["conv3x3_c3"]["unit"] == "GB/s"
+    prof["_build"] = _build.source_hash()
+    with open(str(tmp_path / "profiles" / "pmc_latest.json"), "w") as f:
+        json.dump(prof, f)
+    what = {r["what"]: r for r in bench.roofline_by_kernel(rec, 3)}
+    assert what["fc6 / fc6_mask (300 x 4096 x 25088)"]["traffic"] == 4.8e8                       # positions 1, 3, 6, 8
+    assert what["fc7 / fc7_mask (300 x 4096 x 4096)"]["traffic"] == 1.2e8
+    assert what["fc6_maskest (300 x 256 x 100352)"]["traffic"] == 2.6e8
+    assert abs(what["fc7 / fc7_mask (300 x 4096 x 4096)"]["traffic_over_algorithmic"] - 1.2e8 / 76.9e6) < 1e-9
+    assert what["conv3x3_c3"]["traffic"] == 1.7e8
+
+
+def test_tuning_values_are_per_context_and_checked():
+    """mnc_ctx_set_tuning is declared and exported; keys are validated by name (no context needed to check the table)."""
+    d = _lib.parse_header()
+    assert d["mnc_ctx_set_tuning"][2] == ["ctx", "name", "value"]
+    src = open(os.path.join(REPO, "mnc_amd", "csrc", "mnc_internal.h")).read()
+    for key in ("FC_TILE", "FC_HALF", "FCX3_WIDE", "WINO_ROWS", "ROI_WARP_VARIANT", "TOPK_SINGLE_WG"):
+        assert "X(%s)" % key in src
+    # no launch path reads the environment: getenv appears in ctx.hip (context creation) only
+    import glob
+    users = [os.path.basename(p) for p in glob.glob(os.path.join(REPO, "mnc_amd", "csrc", "*.hip")) if "getenv(" in open(p).read()]
+    assert users == ["ctx.hip"], users
