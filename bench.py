@@ -94,7 +94,7 @@ def parse():
                         "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
                         "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
                         "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
-    p.add_argument("--in-flight", type=int, default=2, choices=[1, 2],
+    p.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
                         "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline)")

@@ -725,3 +725,31 @@ def test_detect_image_graph_replay_equals_layer_by_layer(graph, math, monkeypatc
     finally:
         net.close()
         ref.close()
+
+
+def test_detect_image_falls_back_when_the_sequence_cannot_be_captured():
+    """With the three stock Python layers run as Python objects (native_pylayers=False) the forward has host hops (blobs down,
+    numpy, tops up): such a sequence cannot be captured into a HIP graph.  detect_image notices (the capture is invalidated by the
+    first synchronising call), marks the size as not capturable and keeps launching directly -- same results as the demo body."""
+    import demo
+    from mnc_amd.engine import Net
+    from mnc_amd.instances import split_records
+    from transform.mask_transform import gpu_mask_voting
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=6)
+    net = Net(path, w, 1, native_pylayers=False)
+    ref = Net(path, w, 1)
+    try:
+        rng = np.random.default_rng(41)
+        for k in range(4):
+            im = rng.integers(0, 256, (75, 100, 3), dtype=np.uint8)
+            counts, rec = net.detect_image(im)
+            b, m, s = demo.im_detect(im, ref)
+            lm, lb = gpu_mask_voting(m, b, s, 21, 100, 100, 75)
+            gm, gb = split_records(rec, counts[1:], 21)
+            assert np.array_equal(np.concatenate(gb, 0), np.concatenate(lb, 0)), k
+            assert np.array_equal(np.concatenate(gm, 0), np.concatenate(lm, 0), equal_nan=True), k
+        assert not net._img["graphs"] and net._img.get("no_graph")
+    finally:
+        net.close()
+        ref.close()
