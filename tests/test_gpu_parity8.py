@@ -1,6 +1,6 @@
 """GPU: the BENCHMARKED executor -- the one-call native pipeline (mnc_forward_image, csrc/pipeline.hip) -- against the CPU oracle
 DIRECTLY (not through the Python engine), at BASELINE's full size (600x1000, VGG-16 widths, 300 RoIs per stage), on all eight
-BASELINE images (seeds 0..7), in fp32 and in bf16x3.
+BASELINE images (seeds 0..7), in fp32, in bf16x3 and in f16 (the last with its own 5e-3 bar).
 
 Two protocols per image:
 
@@ -29,7 +29,7 @@ from mnc_amd import models, synth
 from mnc_amd.native_net import NativeNet
 from oracle import host as ohost
 from oracle import net as onet
-from test_gpu_engine import FP32_TOL, NUMPY_SIMD_EXP, X3_TOL, _log
+from test_gpu_engine import F16_TOL, FP32_TOL, NUMPY_SIMD_EXP, X3_TOL, _log
 
 pytestmark = pytest.mark.gpu
 mnc_amd.install_paths()
@@ -39,8 +39,9 @@ SEEDS = tuple(range(8))
 # themselves are the result
 # first recorded run: fp32 300/300 rois on every image, 100/100 instances matched, 0-2 of 44100 mask cells off by > 1e-3;
 # bf16x3 290-299 rois, 98-100 instances matched
-FLOOR_ROIS = {"fp32": 295, "bf16x3": 280}
-FLOOR_MATCHED = {"fp32": 0.97, "bf16x3": 0.9}
+# (f16 does not claim the 1e-3 bar: its floors only guard against a collapse)
+FLOOR_ROIS = {"fp32": 295, "bf16x3": 280, "f16": 150}
+FLOOR_MATCHED = {"fp32": 0.97, "bf16x3": 0.9, "f16": 0.5}
 _cache = {}
 
 
@@ -116,10 +117,10 @@ def _free_running(o, got_m, got_b, dev_rois, dev_rois_ext):
                 max_box=max_box)
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
 def test_native_pipeline_vs_oracle_on_the_eight_baseline_images(vgg, math):
     w = vgg
-    tol = FP32_TOL if math == "fp32" else X3_TOL
+    tol = {"fp32": FP32_TOL, "bf16x3": X3_TOL, "f16": F16_TOL}[math]
     nat = NativeNet(w, math=math)
     K, R = 21, 300
     lines, stats = [], []
