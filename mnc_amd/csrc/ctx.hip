@@ -29,6 +29,7 @@ void clear_error() { g_err[0] = 0; }
 
 int ensure_scratch(mnc_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->scratch_bytes) return MNC_OK;
+  MNC_NO_CAPTURE(ctx, "scratch arena growth");
   MNC_HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->scratch) {
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -145,6 +146,7 @@ int mnc_ctx_destroy(mnc_ctx* ctx) {
 
 int mnc_ctx_sync(mnc_ctx* ctx) {
   MNC_REQUIRE(ctx, "mnc_ctx_sync: null context");
+  MNC_NO_CAPTURE(ctx, "mnc_ctx_sync");
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   clear_error();
   return MNC_OK;
@@ -279,6 +281,7 @@ int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr) {
 int mnc_dev_free(mnc_ctx* ctx, void* d_ptr) {
   MNC_REQUIRE(ctx, "mnc_dev_free: null context");
   if (!d_ptr) return MNC_OK;
+  MNC_NO_CAPTURE(ctx, "mnc_dev_free");
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   MNC_HIP_TRY(hipFree(d_ptr));
   return MNC_OK;
@@ -301,6 +304,7 @@ int mnc_host_alloc(mnc_ctx* ctx, size_t bytes, void** host_ptr) {
 int mnc_host_free(mnc_ctx* ctx, void* host_ptr) {
   MNC_REQUIRE(ctx, "mnc_host_free: null context");
   if (!host_ptr) return MNC_OK;
+  MNC_NO_CAPTURE(ctx, "mnc_host_free");
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   MNC_HIP_TRY(hipHostFree(host_ptr));
   return MNC_OK;
@@ -323,6 +327,7 @@ int mnc_d2h_async(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes)
 int mnc_h2d(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t bytes) {
   MNC_REQUIRE(ctx && (bytes == 0 || (d_dst && src_host)), "mnc_h2d: null pointer");
   if (bytes == 0) return MNC_OK;
+  MNC_NO_CAPTURE(ctx, "mnc_h2d");
   MNC_HIP_TRY(hipMemcpyAsync(d_dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return MNC_OK;
@@ -331,6 +336,7 @@ int mnc_h2d(mnc_ctx* ctx, void* d_dst, const void* src_host, size_t bytes) {
 int mnc_d2h(mnc_ctx* ctx, void* dst_host, const void* d_src, size_t bytes) {
   MNC_REQUIRE(ctx && (bytes == 0 || (dst_host && d_src)), "mnc_d2h: null pointer");
   if (bytes == 0) return MNC_OK;
+  MNC_NO_CAPTURE(ctx, "mnc_d2h");
   MNC_HIP_TRY(hipMemcpyAsync(dst_host, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   return MNC_OK;
@@ -358,6 +364,7 @@ int mnc_prof_enable(mnc_ctx* ctx, int enable) {
 
 int mnc_prof_reset(mnc_ctx* ctx) {
   MNC_REQUIRE(ctx, "mnc_prof_reset: null context");
+  MNC_NO_CAPTURE(ctx, "mnc_prof_reset");
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (auto& r : ctx->prof) {
     ctx->event_pool.push_back(r.start);
@@ -369,6 +376,7 @@ int mnc_prof_reset(mnc_ctx* ctx) {
 
 int mnc_prof_count(mnc_ctx* ctx, int* n_records) {
   MNC_REQUIRE(ctx && n_records, "mnc_prof_count: null pointer");
+  MNC_NO_CAPTURE(ctx, "mnc_prof_count");
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   *n_records = (int)ctx->prof.size();
   return MNC_OK;

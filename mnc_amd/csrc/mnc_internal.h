@@ -94,6 +94,17 @@ void prof_end(mnc_ctx* ctx);
     }                                                                                        \
   } while (0)
 
+// Entry points that synchronise the stream or re-allocate an arena refuse to run while a launch sequence is being captured on the
+// context (mnc_ctx_capture_begin): the call fails BEFORE it touches the stream, so the capture itself stays valid and can be ended
+// and discarded cleanly (a hipStreamSynchronize inside a capture leaves the stream unusable on this runtime).
+#define MNC_NO_CAPTURE(ctx, what)                                                                        \
+  do {                                                                                                   \
+    if ((ctx)->capturing) {                                                                              \
+      mnc::set_error("%s: synchronises or re-allocates; not allowed while a launch sequence is captured", what); \
+      return MNC_ERR_STATE;                                                                              \
+    }                                                                                                    \
+  } while (0)
+
 #define MNC_REQUIRE(cond, ...)       \
   do {                               \
     if (!(cond)) {                   \

@@ -611,6 +611,7 @@ using namespace mnc;
 static int ctx_vote_ws(mnc_ctx* ctx, int n, int C, int S, int keep_cap, VoteWs* w) {
   const size_t need = vote_ws_layout(nullptr, n, C, S, keep_cap, w);
   if (need > ctx->vote_ws_bytes) {
+    MNC_NO_CAPTURE(ctx, "voting scratch growth");
     MNC_HIP_TRY(hipSetDevice(ctx->device));
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->vote_ws) MNC_HIP_TRY(hipFree(ctx->vote_ws));

@@ -372,6 +372,7 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   const size_t need = a256((size_t)N * 16) + a256((size_t)N * 8) + a256((size_t)N * 4) + a256((size_t)topn * 4) * 2 + 256 +
                       a256((size_t)topn * cb * 8) + a256((size_t)topn * 4) + 256 + a256((size_t)nruns * kRun * 8);
   if (need > st->bytes) {
+    MNC_NO_CAPTURE(ctx, "proposal state growth");
     MNC_HIP_TRY(hipSetDevice(ctx->device));
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (st->buf) MNC_HIP_TRY(hipFree(st->buf));
@@ -438,6 +439,10 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
     int rc = ls.finish("proposal_nms");
     if (rc) return rc;
   }
+  if (num_rois_host && ctx->capturing) {
+    set_error("mnc_proposal: reading the row count back synchronises; pass NULL while a launch sequence is captured");
+    return MNC_ERR_STATE;
+  }
   if (num_rois_host) {                  // NULL: the count stays on the device (mnc_proposal_count), no synchronisation
     MNC_HIP_TRY(hipMemcpyAsync(num_rois_host, w.num, 4, hipMemcpyDeviceToHost, ctx->stream));
     MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -450,6 +455,7 @@ int mnc_proposal_count(mnc_ctx* ctx, int* num_rois_host) {
   MNC_REQUIRE(ctx && num_rois_host, "mnc_proposal_count: null pointer");
   mnc_proposal_state* st = (mnc_proposal_state*)ctx->proposal;
   MNC_REQUIRE(st && st->buf, "mnc_proposal_count: mnc_proposal has not run on this context");
+  MNC_NO_CAPTURE(ctx, "mnc_proposal_count");
   MNC_HIP_TRY(hipMemcpyAsync(num_rois_host, st->ws.num, 4, hipMemcpyDeviceToHost, ctx->stream));
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
   clear_error();
@@ -469,6 +475,7 @@ int mnc_proposal_candidates(mnc_ctx* ctx, float* boxes_host, float* scores_host,
   MNC_REQUIRE(ctx && n_host, "mnc_proposal_candidates: null pointer");
   mnc_proposal_state* st = (mnc_proposal_state*)ctx->proposal;
   MNC_REQUIRE(st && st->buf, "mnc_proposal_candidates: mnc_proposal has not run on this context");
+  MNC_NO_CAPTURE(ctx, "mnc_proposal_candidates");
   int n = 0;
   MNC_HIP_TRY(hipMemcpyAsync(&n, st->ws.n_cand, 4, hipMemcpyDeviceToHost, ctx->stream));
   MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));

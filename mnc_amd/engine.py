@@ -1618,13 +1618,18 @@ class Net(object):
                     gp = ctypes.c_void_p()
                     _lib.call("mnc_ctx_capture_end", h, ctypes.addressof(gp))
                 except Exception:
+                    # something in the sequence synchronises (a Python layer's host hop, a growing arena): the library refused that
+                    # call, the capture itself is intact -- end it, throw the partial graph away, and launch this size directly
+                    gp = ctypes.c_void_p()
                     try:
-                        gp = ctypes.c_void_p()
                         _lib.call("mnc_ctx_capture_end", h, ctypes.addressof(gp))
                     except _lib.MncError:
                         pass
-                    st.setdefault("no_graph", set()).add(key)           # this graph / size cannot be captured: direct launches
+                    if gp.value:
+                        _lib.call("mnc_graph_destroy", gp.value)
+                    st.setdefault("no_graph", set()).add(key)
                     st["seen"] = None
+                    self._speculated = None
                     return self.launch_image(im, num_classes, max_per_image, nms_thresh, iou_thresh, use_graph=False)
                 if allocs0 != self._ctx.allocs:                         # something was (re-)allocated while capturing
                     _lib.call("mnc_graph_destroy", gp.value)
