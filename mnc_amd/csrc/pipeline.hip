@@ -583,16 +583,13 @@ int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
     hipGraph_t g = nullptr;
     MNC_HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     const unsigned long gen0 = arena_gen(n);
+    n->ctx->capturing = true;          // an arena that would have to grow now fails its launch instead of synchronising the stream
+    if (n->ctx_b) n->ctx_b->capturing = true;
     int rc = enqueue_image(n);
+    n->ctx->capturing = false;
+    if (n->ctx_b) n->ctx_b->capturing = false;
     hipError_t e = hipStreamEndCapture(s, &g);
-    if (rc == MNC_OK && e == hipSuccess && g && gen0 != arena_gen(n)) {
-      // an arena grew while capturing (cannot happen after an eager run of the same size; kept as a guard): the captured nodes
-      // may hold the old address -- discard the capture and run this image directly
-      (void)hipGraphDestroy(g);
-      n->seen_h = H; n->seen_w = W;
-      return enqueue_image(n);
-    }
-    if (rc == MNC_OK && e == hipSuccess && g) {
+    if (rc == MNC_OK && e == hipSuccess && g && gen0 == arena_gen(n)) {
       e = hipGraphInstantiate(&n->gexec, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e == hipSuccess) {
@@ -602,12 +599,16 @@ int launch_image(mnc_net* n, const unsigned char* bgr_host, int H, int W) {
         return MNC_OK;
       }
       n->gexec = nullptr;
-    } else if (g) {
-      (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
+      n->cfg.use_graph = 0;            // instantiation is not available here: stay on direct launches
+    } else {
+      // the sequence could not be captured as it stands (an arena had to grow -- cannot happen after an eager run of the same size,
+      // kept as a guard -- or the runtime refused): discard what was recorded; this image runs directly and the size is captured
+      // again on its next image
+      if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError();
+      if (e != hipSuccess) n->cfg.use_graph = 0;
     }
-    (void)hipGetLastError();
-    n->cfg.use_graph = 0;            // capture is not available here: stay on direct launches
-    if (rc) return rc;
   }
   n->seen_h = H; n->seen_w = W;
   return enqueue_image(n);
