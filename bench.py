@@ -217,8 +217,28 @@ def main():
             import types
             from mnc_amd.engine import _Ctx
             holder = types.SimpleNamespace(_ctx=_Ctx(dev_id))
-        gatherer = mdist.InstanceGatherer(net=holder, rank=rank, world=world) if (launched and on_gpu) else \
-            mdist.InstanceGatherer(device=None) if launched else None
+        gatherer, transport = None, None
+        if launched and on_gpu:
+            # RCCL communicator (ncclCommInitRank through libmnc_hip.so).  If it cannot be brought up on ANY rank (librccl not
+            # loadable, no peer access ...) every rank falls back to gathering the blocks as host tensors over the gloo control
+            # plane, and the JSON line says so -- a scaling run then still measures the sharded compute instead of dying.
+            err = None
+            try:
+                gatherer = mdist.InstanceGatherer(net=holder, rank=rank, world=world)
+            except Exception as e:  # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                if gatherer is not None:
+                    gatherer.close()
+                gatherer = mdist.InstanceGatherer(device=None)
+                transport = "gloo fallback (RCCL communicator failed%s)" % ((": " + err) if err else " on another rank")
+            else:
+                transport = "rccl"
+        elif launched:
+            gatherer = mdist.InstanceGatherer(device=None)
+            transport = "gloo"
         phase = {"prep+forward+tail": 0.0, "voting": 0.0, "gather": 0.0, "results_to_host": 0.0}
         last = {}
 
@@ -329,7 +349,8 @@ def main():
         if events:
             net.profile(False)
         out = {"elapsed": elapsed, "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()}, "records": records,
-               "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None), "in_flight": inflight}
+               "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None), "in_flight": inflight,
+               "gather_transport": transport}
         for nn in nets[1:]:
             nn.close()
         if holder is not net and gatherer is not None:
@@ -461,7 +482,7 @@ def main():
                                        else "single GPU") + ("; %d images in flight per GPU (own stream each: image k+1 is launched "
                                                              "before image k is fetched)" % m["in_flight"] if m["in_flight"] > 1 else "")},
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
-            "control_plane": "torch.distributed/gloo" if launched else None,
+            "control_plane": "torch.distributed/gloo" if launched else None, "gather_transport": m.get("gather_transport"),
         }
         out.update(summarise(args.steps, m))
         conv = [r for r in m["records"] if r[0].startswith("conv3x3")]

