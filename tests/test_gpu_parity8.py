@@ -40,8 +40,9 @@ SEEDS = tuple(range(8))
 # first recorded run: fp32 300/300 rois on every image, 100/100 instances matched, 0-2 of 44100 mask cells off by > 1e-3;
 # bf16x3 290-299 rois, 98-100 instances matched
 # (f16 does not claim the 1e-3 bar: its floors only guard against a collapse)
-FLOOR_ROIS = {"fp32": 295, "bf16x3": 280, "f16": 150}
-FLOOR_MATCHED = {"fp32": 0.97, "bf16x3": 0.9, "f16": 0.5}
+# (recorded f16 run: no `rois` row within 0.01 px -- its RPN deltas differ by 1e-3 of their range --, 78-92 of 100 instances matched)
+FLOOR_ROIS = {"fp32": 295, "bf16x3": 280, "f16": 0}
+FLOOR_MATCHED = {"fp32": 0.97, "bf16x3": 0.9, "f16": 0.6}
 _cache = {}
 
 
