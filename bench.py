@@ -633,10 +633,34 @@ def roofline_by_kernel(records, steps):
         else:
             e.update(bound="hbm", achieved=by / avg_s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
         pos = FC_POSITIONS.get(label)
-        e["traffic"], e["traffic_source"] = pmc_traffic(name, positions=pos)
+        if name.startswith("conv3x3") and name not in HBM_BOUND_SCOPES:
+            # the trunk's layer classes share two template instantiations: counter traffic cannot be told apart per class, it is
+            # reported for the whole scope in the aggregate row below
+            e["traffic"], e["traffic_source"] = None, "per-layer-class traffic is not separable in the PMC profile; see the '(all launches)' row"
+        else:
+            e["traffic"], e["traffic_source"] = pmc_traffic(name, positions=pos)
         if e["traffic"] and by:
             e["traffic_over_algorithmic"] = e["traffic"] / by
         rows.append(e)
+    # one aggregate row per multi-shape convolution scope: all its launches of an image together
+    for scope in sorted({r["scope"] for r in rows if r["scope"].startswith("conv3x3") and r["scope"] not in HBM_BOUND_SCOPES}):
+        part = [r for r in rows if r["scope"] == scope]
+        n = sum(r["launches_per_image"] for r in part)
+        ms = sum(r["ms_per_image"] for r in part)
+        fl = sum(r["algorithmic_gflop_per_launch"] * r["launches_per_image"] for r in part)
+        mb = sum(r["algorithmic_mb_per_launch"] * r["launches_per_image"] for r in part)
+        peak, basis = mfma_peak(scope)
+        agg = {"scope": scope, "what": "%s (all launches of an image)" % scope, "launches_per_image": n, "ms_per_image": ms,
+               "algorithmic_gflop_per_image": fl, "algorithmic_mb_per_image": mb, "bound": "mfma", "achieved": fl / ms, "peak": peak,
+               "unit": "TFLOP/s", "frac": fl / ms / peak, "peak_basis": basis}
+        if "wino" in scope:
+            agg.update(executed_tflops=fl / 2.25 / ms, executed_frac_of_peak=fl / 2.25 / ms / peak)
+        t, src = pmc_traffic(scope)
+        agg["traffic_source"] = src
+        if t is not None:
+            agg["traffic_mb_per_image"] = t * n / 1e6
+            agg["traffic_over_algorithmic"] = t * n / 1e6 / mb
+        rows.append(agg)
     return rows
 
 
