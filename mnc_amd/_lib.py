@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "mnc_hip.h")
-LIB_PATH = os.path.join(HERE, "libmnc_hip.so")
+LIB_PATH = os.environ.get("MNC_LIB_PATH") or os.path.join(HERE, "libmnc_hip.so")    # MNC_LIB_PATH: an experiment build (tools/probes)
 
 MNC_OK = 0
 
