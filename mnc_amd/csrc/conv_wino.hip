@@ -30,16 +30,9 @@
 #include <cstdlib>
 
 #include "mnc_internal.h"
+#include "wino_common.h"
 
 namespace mnc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kWCols = 32;                 // pixel columns per workgroup (16 Winograd tiles)
-constexpr int kWHaloCols = kWCols + 2;
-constexpr int kWPixPitch = 12;             // floats per halo pixel in LDS (8 channels + 4 pad)
-constexpr int kWRowPitch = 68;             // floats per (k half, output channel) weight row: 16 positions x 4 channels + 4 pad
-constexpr int kWPanel = 2 * 32 * kWRowPitch;   // floats per (channel block, 32-channel tile) weight panel = 4352
 
 // VAR: scheduling variant (tuning; MNC_WINO_VAR): bit 0 = pinned software pipeline of the two halves of a block (below).
 template <int ROWS, int VAR>
@@ -1129,6 +1122,15 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   // plain -> XCD-aware: conv1_2 197 -> 93 MB, conv2_x 153 -> 41, conv3_x 126 -> 60; for the 512-channel layers the 17.8 MB of
   // transformed weights dominate and every XCD would stream all of them (conv4_x 84 -> 248 MB, conv5_x 38 -> 93): plain order
   const bool plain_order = tune_set(ctx, T_WINO_XCD) ? tune(ctx, T_WINO_XCD, 1) == 0 : Cout > 256;
+#ifdef MNC_TUNING
+  // WINO_STREAM = k > 0: the layer as one stream of (tile, block) units in 512 k equal ranges (conv_wino_stream.hip: measured, slower)
+  const int stream_k = (ver == 2 && var == 7) ? tune(ctx, T_WINO_STREAM, 0) : 0;
+  if (stream_k > 0) {
+    rc = wino_stream_launch(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, pool, stream_k, plain_order ? 0 : 1);
+    if (rc == MNC_OK) return ls.finish("conv3x3_wino_stream_kernel");
+    if (rc != MNC_ERR_INVALID) return rc;
+  }
+#endif
   if (ver == 2 && var == 7)
     rc = plain_order ? launch_wino2<2, 7, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b)
                      : launch_wino2<2, 7, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
