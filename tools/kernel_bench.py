@@ -13,6 +13,7 @@ import argparse
 import ctypes
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -55,6 +56,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
+    ap.add_argument("--relu-input", action="store_true", help="fc*: activations max(x, 0) (half zeros, as behind a ReLU) instead of N(0, 1): "
+                    "the matrix pipe is power limited, operand values move the clock")
+    ap.add_argument("--gap-ms", type=float, default=0.0, help="fc*: synchronise and sleep this long before every timed launch (a kernel that "
+                    "starts on a rested chip runs at a higher clock than the same kernel back to back)")
     ap.add_argument("--packed", action="store_true", help="convx3 / convf16: 2-byte activation tensors in and out")
     ap.add_argument("--conv-shape", action="append", default=[], help="conv*: replace the layer list by H,W,Cin,Cout (repeatable)")
     args = ap.parse_args()
@@ -159,7 +164,8 @@ def main():
         for name, M, N, K in FC:
             if args.only and args.only not in name:
                 continue
-            a = dev.put(rng.normal(size=(M * K,)).astype(np.float32))
+            af = rng.normal(size=(M * K,)).astype(np.float32)
+            a = dev.put(np.maximum(af, 0) if args.relu_input else af)
             w = dev.put((rng.normal(size=(N * K,)) * 0.01).astype(np.float32))
             b = dev.put(np.zeros(N, np.float32))
             y = dev.empty((M * N,))
@@ -176,6 +182,9 @@ def main():
                 dev.call(fn, a, w, b, y, M, N, K, N, 1)
             dev.call("mnc_prof_reset")
             for _ in range(args.reps):
+                if args.gap_ms > 0:
+                    dev.call("mnc_ctx_sync")
+                    time.sleep(args.gap_ms * 1e-3)
                 dev.call(fn, a, w, b, y, M, N, K, N, 1)
             rec = records(dev)
             t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0] in ("fc_bf16x3", "fc_bf16x3_small", "fc_f16", "fc_f16_small")])
