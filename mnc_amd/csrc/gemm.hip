@@ -495,6 +495,167 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
   }
 }
 
+// ---- the eight-wave LDS-DMA kernel on v_mfma_f32_16x16x4_f32 fragments ---------------------------------------------------------
+// Same staging, swizzle, barrier protocol and workgroup tile (320 x 128, 32 K-values per stage) as fc_mfma_dma_kernel<10, 0, 2>;
+// the wave's 160 x 32 outputs are 10 x 2 accumulators of 16 x 16 (4 registers each) instead of 5 of 32 x 32 (16 each).  Why: an
+// fp32 MFMA's own result write-back (32x32x2: 4 KB per 4096 FLOP) competes with every other register-file writer -- LDS reads,
+// the DMA's bookkeeping -- for the same ports (tools/probes/mfma_f32_mix_probe.hip: the same FLOPs with the same LDS reads beside
+// them run 5 % faster as 16x16x4, 1 KB per 2048 FLOP), and the pipe is power limited, so cycles given back are clock given back.
+//   * operand layout of the instruction: lane l supplies A[row l % 16][k = l / 16] and B[col l % 16][k = l / 16]; D register i is
+//     row 4 (l / 16) + i, column l % 16.
+//   * a K-group is 16 values = chunks 4 G .. 4 G + 3 of a row (G = 0, 1 per stage): lane (r = l % 16, g = l / 16) reads chunk 4 G + g
+//     of row r of every 16-row sub-tile with ONE ds_read_b128 -- MFMA q of the group multiplies element q of those chunks, i.e.
+//     k = q, 4 + q, 8 + q, 12 + q across its four lane groups.  Per 16 K-values and wave: 10 + 2 ds_read_b128 and 80 MFMAs of
+//     32 cycles (the 32x32x2 kernel: 12 and 40 of 64).  Under the row swizzle (slot = chunk ^ ((row >> 1) & 7)) the 16 lanes of every
+//     ds_read_b128 service group (rows {0-3, 12-15} of lane group g with rows {4-11} of g + 1, ...) start on 16 different 16-byte
+//     slots of the 256-byte bank row: conflict-free, as before.
+//   * K order of an output: stage by stage, group by group, q = 0..3, the four k of an MFMA in the hardware's order -- fixed, but
+//     not the 32x32x2 kernel's (k0, k4, k1, k5, ...): results differ from it in the last bits.
+//   * a block whose last 16-row sub-tile is dead (M in (288, 304], e.g. 300 RoIs) skips that sub-tile's MFMAs in the waves that
+//     own it (LAST): the 32x32x2 kernel's half-tile special case is the general case here.
+template <int kMT>
+__global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            float* __restrict__ part, int M, int N, int K, int ldc, int kper,
+                                                            int act, int fused, int tn_, int splits_, int tm_, int drop_last) {
+  constexpr int kBM = 32 * kMT;
+  constexpr int kRows = kBM + kBN;
+  constexpr int kNW = 8;
+  constexpr int TS = kMT;                            // 16-row sub-tiles per wave (kMT / 2 row tiles x 2)
+  constexpr int kPer = kRows * 128 / 1024 / kNW;     // DMA instructions per wave and stage
+  static_assert(kRows % (8 * kNW) == 0 && kMT % 2 == 0, "whole pieces and row tiles per wave");
+  extern __shared__ __attribute__((aligned(1024))) char s_fc_dma[];
+  constexpr int kBufXor = 65536;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wm = wave >> 2;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  int bn, split, bmz;
+  xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  const int n0 = bn * kBN, m0 = bmz * kBM;
+  const int kbeg = split * kper, kend = min(K, kbeg + kper);
+  const int nstages = (kend - kbeg) / 32;
+  const int mrows = min(M - m0, kBM);
+
+  const float* src[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int slot = (wave + kNW * i) * 64 + lane, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    src[i] = (r < kBM ? A + (long)(m0 + min(r, mrows - 1)) * K
+                      : Wt + (long)min(n0 + r - kBM, N - 1) * K) + kbeg + c * 4;
+  }
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_fc_dma;
+  auto dma_piece = [&](int i, long off, int buf_byte) {
+    const float* g = src[i] + off;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + kNW * i) * 1024u);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
+  };
+  auto dma_stage = [&](int s, int buf_byte) {
+    const long off = (long)min(s, nstages - 1) * 32;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) dma_piece(i, off, buf_byte);
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v acc[TS][2];
+#pragma unroll
+  for (int i = 0; i < TS; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[i][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  // byte offsets of this lane's chunk of K-group G in sub-tile 0 of the wave's rows / columns (+ 2048 per further sub-tile)
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int G = 0; G < 2; ++G) {
+    const int sl = ((4 * G + g4) ^ ((r16 >> 1) & 7)) * 16;
+    a_off[G] = (wm * TS * 16 + r16) * 128 + sl;
+    b_off[G] = (kBM + wn * 32 + r16) * 128 + sl;
+  }
+  const bool last_wave = drop_last && wm == 1;       // wave-uniform: this wave's last sub-tile holds no live row
+
+  auto run = [&](auto last_tag) {
+    constexpr int NS = decltype(last_tag)::value ? TS - 1 : TS;    // live sub-tiles
+    constexpr int kNM = 8 * NS, kNR = NS + 2;                      // MFMAs / LDS reads per K-group
+    struct Frags { f32x4v a[NS]; f32x4v b[2]; };
+    auto read_frags = [&](int G, int flip, Frags& f) {
+      f.b[0] = *reinterpret_cast<const f32x4v*>(s_fc_dma + (b_off[G] ^ flip));
+      f.b[1] = *reinterpret_cast<const f32x4v*>(s_fc_dma + (b_off[G] ^ flip) + 2048);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) f.a[i] = *reinterpret_cast<const f32x4v*>(s_fc_dma + (a_off[G] ^ flip) + i * 2048);
+    };
+    Frags f0, f1;
+    dma_stage(0, 0);
+    dma_stage(1, kBufXor);
+    dma_wait();
+    __syncthreads();
+    read_frags(0, 0, f0);
+    int cur = 0;
+    for (int s = 0; s < nstages; ++s) {
+      // stage s sits in buffer `cur` with its group-0 fragments in f0; stage s + 1 is landing in (or already in) the other buffer
+      read_frags(1, 0, f1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.a[i][q], f0.b[0][q], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.a[i][q], f0.b[1][q], acc[i][1], 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < kNM; ++i) {                // one slot per MFMA; the fragment reads spread evenly over the first half
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if ((i + 1) * 2 * kNR / kNM > i * 2 * kNR / kNM && i * 2 < kNM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      dma_wait();                                    // stage s + 1 has landed ...
+      __syncthreads();                               // ... for every wave, and nobody reads buffer `cur` any more
+      read_frags(0, kBufXor, f0);                    // group 0 of stage s + 1
+      {                                              // group 1: the reads under the first MFMAs, then one copy every fourth MFMA
+        const long off = (long)min(s + 2, nstages - 1) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.a[i][q], f1.b[0][q], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.a[i][q], f1.b[1][q], acc[i][1], 0, 0, 0);
+            const int m = 2 * (q * NS + i);          // MFMAs issued before this pair
+            if (m >= kNM - 4 * kPer - 8 && m < kNM - 8 && (m - (kNM - 4 * kPer - 8)) % 4 == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              dma_piece((m - (kNM - 4 * kPer - 8)) / 4, off, cur);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
+#pragma unroll
+      for (int G = 0; G < 2; ++G) { a_off[G] ^= kBufXor; b_off[G] ^= kBufXor; }
+      cur ^= kBufXor;
+    }
+    dma_wait();                                      // the copies issued by the last two stages have landed before the LDS is released
+    __syncthreads();
+  };
+  if (nstages > 0) {
+    if (last_wave) run(std::true_type{});
+    else run(std::false_type{});
+  }
+
+  // D[row = 16 i + 4 (lane / 16) + reg][col = 16 c + lane % 16] of the wave's 160 x 32 outputs
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int n = n0 + wn * 32 + c * 16 + r16;
+    if (n >= N) continue;
+    const float bv = fused ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * TS * 16 + i * 16 + 4 * g4 + e;
+        if (m < M) {
+          if (fused) out[(long)m * ldc + n] = apply_act(acc[i][c][e] + bv, act);
+          else part[((long)split * M + m) * N + n] = acc[i][c][e];
+        }
+      }
+  }
+}
+
 // out = act(sum over splits (in split order) + bias).  VEC = 4: N % 4 == 0 and ldc % 4 == 0 -- one thread per four columns,
 // 16-byte loads, four splits in flight; the per-element order of the additions is that of the scalar kernel.
 // SM != 0 (VEC = 4 only): the result rows are written a second time in the stage-major 2-byte form the NEXT reduced-precision
@@ -696,19 +857,35 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   } while (0)
     if (dma) {
       constexpr int lds = 65536 + (320 + kBN) * 32 * 4;
-      // eight waves, two per SIMD (default; FC_DMA_WAVES=4: four waves, one per SIMD): fc6 610 -> 595 us, same bits
-      const int waves = tune(ctx, T_FC_DMA_WAVES, 8);
+      // the product build: eight waves on 16 x 16 x 4 fragments (fc_mfma_dma16_kernel).  Tuning builds keep the 32 x 32 x 2 kernel it
+      // replaced (FC_MFMA16=0; FC_DMA_WAVES=4: its four-wave form; FC_HALF=0: without the half tile; FC_DMA_ABL) for comparison:
+      // fc6 562 -> 514 us, fc7 100 -> 94, fc6_maskest 153 -> 144 (kernel_bench fc --relu-input, same box).
+      bool launched = false;
 #ifdef MNC_TUNING
-      // tuning builds: 1 every copy re-reads stage 0 (L2-hot operands), 3 only the weight copies do
-      const int dabl = tune(ctx, T_FC_DMA_ABL, 0);
-      if (dabl == 1) MNC_FC_DMA_LAUNCH(1, 1);
-      else if (dabl == 3) MNC_FC_DMA_LAUNCH(3, 1);
-      else
+      const int waves = tune(ctx, T_FC_DMA_WAVES, 8), dabl = tune(ctx, T_FC_DMA_ABL, 0);
+      if (tune(ctx, T_FC_MFMA16, 1) == 0 || waves == 4 || dabl) {
+        launched = true;
+        if (dabl == 1) MNC_FC_DMA_LAUNCH(1, 1);      // 1: every copy re-reads stage 0 (L2-hot operands), 3: only the weight copies do
+        else if (dabl == 3) MNC_FC_DMA_LAUNCH(3, 1);
+        else if (waves == 4) MNC_FC_DMA_LAUNCH(0, 1);
+        // one row block whose last row tile holds at most 16 rows (300 RoIs: 288 + 12): that tile on 16 x 16 x 4 MFMAs (FC_HALF=0: off)
+        else if (tm == 1 && M > 288 && M <= 304 && tune(ctx, T_FC_HALF, 1) != 0) MNC_FC_DMA_LAUNCH_H(0, 2, 1);
+        else MNC_FC_DMA_LAUNCH(0, 2);
+      }
 #endif
-      if (waves == 4) MNC_FC_DMA_LAUNCH(0, 1);
-      // one row block whose last row tile holds at most 16 rows (300 RoIs: 288 + 12): that tile on 16 x 16 x 4 MFMAs (FC_HALF=0: off)
-      else if (tm == 1 && M > 288 && M <= 304 && tune(ctx, T_FC_HALF, 1) != 0) MNC_FC_DMA_LAUNCH_H(0, 2, 1);
-      else MNC_FC_DMA_LAUNCH(0, 2);
+      if (!launched) {
+        static std::atomic<unsigned long long> attr16{0};            // one bit per device: function attributes are per device
+        const unsigned long long bit = 1ull << (ctx->device & 63);
+        if (!(attr16.load(std::memory_order_relaxed) & bit)) {
+          MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma16_kernel<10>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+          attr16.fetch_or(bit, std::memory_order_relaxed);
+        }
+        // one row block whose last 16-row sub-tile holds no live row (300 RoIs = 18 sub-tiles + 12 rows): its MFMAs are skipped
+        const int drop = tm == 1 && M > 288 && M <= 304 ? 1 : 0;
+        hipLaunchKernelGGL((fc_mfma_dma16_kernel<10>), dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out,
+                           part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
+      }
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
     else if (mt == 5) {

@@ -801,30 +801,41 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
     y = F.linear(torch.from_numpy(a), torch.from_numpy(w), torch.from_numpy(b))
     want = (F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y).numpy()
     tune("FC_TILE", "10")
-    outs = []
-    for dma in ("1", "0", "4"):        # default: eight waves (two per SIMD); "4": the four-wave build of the DMA kernel
-        tune("FC_DMA", "0" if dma == "0" else "1")
-        if dma == "4":
-            tune("FC_DMA_WAVES", "4")
-        else:
-            dev.tune("FC_DMA_WAVES", None)
+
+    def run():
         d_o = dev.empty((M * ld,), fill=np.nan)
         dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
         got = dev.get(d_o, (M, ld))
         assert not np.isnan(got[:, :N]).any() and np.isnan(got[:, N:]).all()
         d, rel = err(got[:, :N], want)
-        assert rel < 1e-4, (dma, d, rel)
-        outs.append(got[:, :N])
-    assert err(outs[0], outs[1])[1] < 1e-5 and np.array_equal(outs[0], outs[2])      # same K order per accumulator
+        assert rel < 1e-4, (d, rel)
+        return got[:, :N]
+
+    # the product build (eight waves, 16 x 16 x 4 fragments) and the register-staged kernel: same products, other order
+    tune("FC_DMA", "1")
+    prod = run()
+    tune("FC_DMA", "0")
+    staged = run()
+    assert err(prod, staged)[1] < 1e-5
+    if not TUNING_BUILD:
+        return
+    # tuning builds: the 32 x 32 x 2 DMA kernel the product build replaced -- eight waves, four waves, with and without its half tile
+    tune("FC_DMA", "1")
+    tune("FC_MFMA16", "0")
+    w8 = run()
+    tune("FC_DMA_WAVES", "4")
+    w4 = run()
+    dev.tune("FC_DMA_WAVES", None)
+    assert np.array_equal(w8, w4) and err(w8, staged)[1] < 1e-5      # same K order per accumulator
+    assert err(prod, w8)[1] < 1e-5
+    if 2.0 * M * N * K >= 2.0e9:           # (smaller problems run the 64-row kernel whatever the switches say)
+        assert not np.array_equal(prod, w8)
     if 288 < M <= 304:
-        # one row block whose last row tile has at most 16 live rows: the default run above multiplied it with 16 x 16 x 4 MFMAs
-        # (HALF build: 304 instead of 320 rows of matrix-pipe work); FC_HALF=0 is the all-32x32 build -- same K order per output
+        # one row block whose last row tile has at most 16 live rows: w8 multiplied it with 16 x 16 x 4 MFMAs (HALF build: 304
+        # instead of 320 rows of matrix-pipe work); FC_HALF=0 is the all-32x32 build -- same K order per output
         tune("FC_HALF", "0")
-        d_o = dev.empty((M * ld,), fill=np.nan)
-        dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
-        full = dev.get(d_o, (M, ld))[:, :N]
-        print("half tile vs full tile: max rel %.3e, identical %s" % (err(outs[0], full)[1], np.array_equal(outs[0], full)))
-        assert err(outs[0], full)[1] < 2e-6
+        full = run()
+        assert err(w8, full)[1] < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES + [(300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2)])
