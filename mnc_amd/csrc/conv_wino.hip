@@ -1131,6 +1131,11 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     if (rc != MNC_ERR_INVALID) return rc;
   }
 #endif
+#ifdef MNC_TUNING
+  if (ver == 2 && var == 7 && tune(ctx, T_WINO_MFMA16, 0) != 0)    // the same kernel on 16 x 16 x 4 fragments (conv_wino16.hip: measured, equal)
+    rc = wino16_launch(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b, plain_order ? 0 : 1);
+  else
+#endif
   if (ver == 2 && var == 7)
     rc = plain_order ? launch_wino2<2, 7, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b)
                      : launch_wino2<2, 7, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);

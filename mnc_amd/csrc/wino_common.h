@@ -20,4 +20,8 @@ constexpr int kWPanel = 2 * 32 * kWRowPitch;   // floats per (channel block, 32-
 int wino_stream_launch(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W,
                        int Cin, int Cout, int relu, int pool, int wgs_per_slot, int xcd_order);
 
+// conv_wino16.hip (-DMNC_TUNING builds only): conv3x3_wino2_kernel<2, 7, 1, *> re-tiled onto v_mfma_f32_16x16x4_f32 fragments (same arguments as launch_wino2)
+int wino16_launch(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                  int Cout, int relu, int ksplit, float* part, int pool, int pix_a, int ksplit_b, int xcd_order);
+
 }  // namespace mnc

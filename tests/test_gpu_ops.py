@@ -101,18 +101,21 @@ def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu, tune):
     # (MNC_WINO_VAR 3: rotated loop, 1: flat block with register staging, 0: round-2 v2 loop) and the default without the tail plan
     for rows, ks, var in ((None, None, None), ("1", "1", None), ("2", "2", None), ("4", "1", None), ("1", "4", None),
                           (None, None, "3"), (None, None, "1"), (None, None, "0"), ("2", "2", "1"), (None, None, "notail"),
-                          (None, None, "stream1"), (None, None, "stream2"), (None, None, "stream5")):
+                          (None, None, "stream1"), (None, None, "stream2"), (None, None, "stream5"), (None, None, "mfma16_0"),
+                          (None, None, "mfma16_1")):
         if ks is not None and (Cin // 8) % int(ks):
             continue
-        if (var in ("3", "1", "0") or (var or "").startswith("stream")) and not TUNING_BUILD:   # superseded / measurement builds: -DMNC_TUNING only
+        if (var in ("3", "1", "0") or (var or "").startswith(("stream", "mfma16"))) and not TUNING_BUILD:   # superseded / measurement builds: -DMNC_TUNING only
             continue
-        for k in ("WINO_ROWS", "CONV_KSPLIT", "WINO_VAR", "WINO_TAIL", "WINO_STREAM"):
+        for k in ("WINO_ROWS", "CONV_KSPLIT", "WINO_VAR", "WINO_TAIL", "WINO_STREAM", "WINO_MFMA16"):
             dev.tune(k, None)
         if rows is not None:
             tune("WINO_ROWS", rows)
             tune("CONV_KSPLIT", ks)
         if var == "notail":
             tune("WINO_TAIL", "0")
+        elif var is not None and var.startswith("mfma16"):       # the 16 x 16 x 4 build (conv_wino16.hip) on / off
+            tune("WINO_MFMA16", var[7:])
         elif var is not None and var.startswith("stream"):       # the layer as one stream of units, 512 k ranges (conv_wino_stream.hip)
             tune("WINO_STREAM", var[6:])
         elif var is not None:
