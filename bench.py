@@ -666,7 +666,7 @@ def roofline_by_kernel(records, steps):
 
 # profiling scope of the engine -> the kernels (rocprofv3 names, regular expressions) launched inside it
 PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"conv3x3_wino2?_kernel",
-              "fc_mfma": r"fc_mfma_(dma_)?kernel<(10|5),", "fc_mfma_small": r"fc_mfma_kernel<2,", "conv3x3_c3": r"conv3x3_c3_kernel",
+              "fc_mfma": r"fc_mfma_(dma(16)?_)?kernel<(10|5)[,>]", "fc_mfma_small": r"fc_mfma_kernel<2,", "conv3x3_c3": r"conv3x3_c3_kernel",
               "conv3x3_bf16x3": r"conv3x3_x3_kernel<\d+, \d+, \d+, 0,", "conv3x3_f16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 1,",
               "fc_bf16x3": r"fc_x3_kernel<\d+, \d+, \d+, 0>", "fc_f16": r"fc_x3_kernel<\d+, \d+, \d+, 1>"}
 HBM_BOUND_SCOPES = {"conv3x3_c3"}          # conv1_1: 2 GFLOP over 161 MB -- bound by writing its output

@@ -141,7 +141,7 @@ def test_bench_roofline_by_kernel_groups_shapes_and_tags_traffic(tmp_path, monke
         rec += [("fc_mfma", 0.14, 15.4140672e9, 223.5e6), ("fc_mfma", 0.47, 61.6562688e9, 446.1e6), ("fc_mfma", 0.09, 10.0663296e9, 76.9e6),
                 ("fc_mfma", 0.47, 61.6562688e9, 446.1e6), ("fc_mfma", 0.09, 10.0663296e9, 76.9e6),
                 ("conv3x3_wino_mfma", 0.2, 44.2368e9, 307.3e6), ("conv3x3_c3", 0.064, 2.0736e9, 160.8e6)]
-    prof = {"_build": "stale", "fc_mfma_dma_kernel<10, 0, 2, 1>": {"calls": 15, "hbm_bytes_corrected": 3.0e8,
+    prof = {"_build": "stale", "fc_mfma_dma16_kernel<10>": {"calls": 15, "hbm_bytes_corrected": 3.0e8,
             "by_position": [{"hbm_bytes_corrected": 2.6e8}, {"hbm_bytes_corrected": 4.8e8}, {"hbm_bytes_corrected": 1.2e8},
                             {"hbm_bytes_corrected": 4.8e8}, {"hbm_bytes_corrected": 1.2e8}] * 2},
             "conv3x3_c3_kernel<0>": {"calls": 3, "hbm_bytes_corrected": 1.7e8}}

@@ -246,6 +246,54 @@ def test_fc_dma_swizzle():
     assert not _b128_conflict_free((j * 32 + (2 * 0 + kk) * 4))
 
 
+def test_fc_dma16_fragments():
+    """gemm.hip fc_mfma_dma16_kernel<10> (the product fp32 InnerProduct): same copy and row swizzle as fc_mfma_dma_kernel, fragments
+    for v_mfma_f32_16x16x4_f32.  Lane (r = l % 16, g = l / 16) of wave (wm, wn) reads chunk 4 G + g of row r of every 16-row
+    sub-tile with one ds_read_b128; MFMA q of K-group G multiplies element q of those chunks, i.e. k = 16 G + 4 g + q in lane group
+    g.  Checks: the reads find their chunk in the copied image, every ds_read_b128 service group is conflict-free, one XOR
+    switches buffers, the 8 waves x (10 sub-tiles x 2 column halves) x D-register map cover the 320 x 128 outputs once, and a
+    stage's two groups x four MFMAs x four lane groups take every k of the stage once -- the same k on both operands."""
+    rows, kBM = 448, 320
+    where = {}
+    for wave in range(8):
+        for i in range(7):
+            p = wave + 8 * i
+            for lane in range(64):
+                slot = p * 64 + lane
+                r, c = slot >> 3, (slot & 7) ^ ((slot >> 4) & 7)
+                assert (r, c) not in where
+                where[(r, c)] = slot * 16
+    assert len(where) == rows * 8
+    r16, g4 = LANES & 15, LANES >> 4
+    covered = np.zeros((320, 128), np.int32)
+    for wave in range(8):
+        wn, wm = wave & 3, wave >> 2
+        ks = []
+        for G in range(2):
+            sl = ((4 * G + g4) ^ ((r16 >> 1) & 7)) * 16
+            a_off = (wm * 160 + r16) * 128 + sl
+            b_off = (kBM + wn * 32 + r16) * 128 + sl
+            for i in range(10):
+                got = a_off + i * 2048
+                want = np.array([where[(wm * 160 + 16 * i + int(r16[l]), 4 * G + int(g4[l]))] for l in LANES])
+                assert np.array_equal(got, want) and _b128_conflict_free(got // 4)
+            for c in range(2):
+                got = b_off + c * 2048
+                want = np.array([where[(kBM + wn * 32 + 16 * c + int(r16[l]), 4 * G + int(g4[l]))] for l in LANES])
+                assert np.array_equal(got, want) and _b128_conflict_free(got // 4)
+                assert got.max() + 16 <= rows * 128 <= 65536 and np.array_equal(got ^ 65536, got + 65536)
+            for q in range(4):                                        # MFMA q: lane group g supplies k = 4 (4 G + g) + q
+                ks.extend(sorted(set((4 * (4 * G + g4) + q).tolist())))
+        assert sorted(ks) == list(range(32))                          # every k of the stage exactly once
+        for i in range(10):
+            for c in range(2):
+                for e in range(4):                                    # D register e: row 4 g + e, column r
+                    m = wm * 160 + i * 16 + 4 * g4 + e
+                    n = wn * 32 + c * 16 + r16
+                    np.add.at(covered, (m, n), 1)
+    assert (covered == 1).all()
+
+
 def _wino_plan(H, W, Cin, Cout, slots=512):
     """wino_impl's tail plan (conv_wino.hip) for the two-row-group kernel: -> (pix_a, ksplit_a, ksplit_b)."""
     pix = -(-W // 32) * -(-H // 8)
