@@ -17,10 +17,10 @@ A "step" is one pass of the whole hot path over one synthetic image per GPU, mea
        the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
        device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
 Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
-Round 3: by default every GPU keeps TWO images in flight (--in-flight 2: one mnc_net + context + stream per image in flight;
-mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k), because a third of an image's GPU time is spent
-in kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- another image's convolutions
-run there.  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` in the
+Round 3: by default every GPU keeps FOUR images in flight (--in-flight 4: one mnc_net + context + stream per image in flight;
+mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 3), because a sixth of an image's GPU time is spent
+in kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- other images' convolutions
+run there (measured, same build and box: 1 -> 200, 2 -> 221, 3 -> 225, 4 -> 227 images/s).  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` in the
 same line is the rounds 1-2 protocol (--in-flight 1 makes it the headline).
 The old protocol (same image resident in HBM, no upload) is reported next to it as `resident_input`.
 
@@ -94,7 +94,7 @@ def parse():
                         "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
                         "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
                         "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
-    p.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4],
+    p.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4],
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
                         "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline)")

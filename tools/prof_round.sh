@@ -7,10 +7,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events --no-resident --no-resnet $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
-PMCB="$BENCH --no-graph"      # counter passes: direct launches (same kernels, same order; counters serialise the dispatches anyway)
+PMCB="$BENCH --no-graph --in-flight 1"      # counter passes: direct launches, one image at a time (same kernels in a fixed order per image; counters serialise the dispatches anyway)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $PMCB > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $PMCB > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT -d $OUT/pmc_mfma -o bench -- $PMCB > $OUT/pmc_mfma.log 2>&1
@@ -23,6 +22,10 @@ rm -rf $OUT/trace1
 BUILD=$(cd $REPO && python -m mnc_amd._build --hash)
 python $REPO/tools/pmc_report.py $OUT/pmc_mfma/bench_results.db $OUT/pmc_fetch/bench_results.db $OUT/pmc_write/bench_results.db --json $OUT/pmc.json --build $BUILD --cycle=fc_mfma_dma_kernel=10 > $OUT/pmc.txt
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+# the bench line LAST, with this build's counter profile in place: its roofline.traffic comes from profiles/pmc_latest.json and is
+# reported only when that file carries this build's hash (copy $OUT/pmc.json to profiles/pmc_latest.json in the repo afterwards)
+cp $OUT/pmc.json $REPO/profiles/pmc_latest.json
+python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
 head -12 $OUT/kernel_trace_stats.txt
 head -8 $OUT/pmc.txt
