@@ -343,6 +343,61 @@ def test_winograd_tail_plan_covers_every_tile_once():
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
 
 
+def test_winograd_stream_partition_and_fixup_ownership():
+    """conv_wino_stream.hip (tuning builds): the layer as units u = tile * (Cin / 8) + block cut into G ranges [start(l), start(l + 1)),
+    start(l) = 2 * floor(l * U / 2 / G).  The kernel walks a range segment by segment (a segment ends with its tile or with the
+    range); a segment that is not a whole tile leaves a piece in slot 0 (the range's first segment) or slot 1 (a later one).
+    wino_stream_fix_kernel's block l owns the tile that begins inside range l and ends outside it and adds range l's piece, then the
+    slot-0 pieces of the following ranges up to the tile's end.  Checks, for the trunk's shapes and awkward G: the ranges partition the
+    units, every segment has >= 2 blocks (the prefetch runs two ahead), every tile is either whole in one range or cut into pieces
+    that exactly one fix block collects, in block order, with the slots the kernel wrote."""
+    def start(l, u2, G):
+        return 2 * (l * u2 // G)
+
+    for tiles, nch, G in ((4800, 8, 512), (2432, 16, 512), (1216, 32, 512), (640, 64, 512), (160, 64, 512), (160, 64, 1024),
+                          (7, 2, 7), (33, 6, 512), (1216, 32, 2560)):
+        u2 = tiles * nch // 2
+        G = min(G, u2)
+        assert start(0, u2, G) == 0 and start(G, u2, G) == tiles * nch
+        pieces = {}                                   # tile -> [(range, slot, first block, end block)]
+        whole = set()
+        for l in range(G):
+            u0, u1 = start(l, u2, G), start(l + 1, u2, G)
+            assert u1 - u0 >= 2 and u0 % 2 == 0
+            u, t = u0, u0 // nch
+            while u < u1:
+                seg_end = min((t + 1) * nch, u1)
+                assert seg_end - u >= 2
+                if seg_end - u == nch:
+                    assert t not in whole and t not in pieces
+                    whole.add(t)
+                else:
+                    pieces.setdefault(t, []).append((l, 0 if u == u0 else 1, u - t * nch, seg_end - t * nch))
+                u, t = seg_end, t + 1
+        assert len(whole) + len(pieces) == tiles and not (whole & set(pieces))
+        for t, ps in pieces.items():                  # the pieces of a cut tile cover its blocks once, in range order
+            assert ps[0][2] == 0 and ps[-1][3] == nch and all(a[3] == b[2] and a[0] + 1 == b[0] for a, b in zip(ps, ps[1:]))
+        owned = {}
+        for l in range(G):                            # wino_stream_fix_kernel, block l
+            s_l, e_l = start(l, u2, G), start(l + 1, u2, G)
+            if e_l % nch == 0:
+                continue
+            t = e_l // nch
+            tb, te = t * nch, t * nch + nch
+            if tb < s_l:
+                continue
+            got = [(l, 0 if s_l // nch == t else 1)]
+            l2 = l + 1
+            while l2 < G and start(l2, u2, G) < te:
+                got.append((l2, 0))
+                l2 += 1
+            assert t not in owned
+            owned[t] = got
+        assert set(owned) == set(pieces)
+        for t, got in owned.items():
+            assert got == [(l, slot) for l, slot, _, _ in pieces[t]]
+
+
 def test_fc_dma_kernel_index_math():
     """fc_mfma_dma_kernel<10, 0, 2> lane by lane: the copy's slot -> (row, k-chunk) map with clamped rows, the swizzled fragment
     addresses of wave (wm, wn), the v_mfma_f32_32x32x2_f32 operand layout, the epilogue's accumulator -> (m, n) map and the
