@@ -338,12 +338,10 @@ __global__ void pack_f16_kernel(const float* __restrict__ in, uint4* __restrict_
 }
 
 // ---- fp16 / split-bf16 InnerProduct, 256-column workgroup tiles, operand panels copied by LDS-DMA (round 3) ----------------------------------
-// What bounds fc_x3_kernel in the fp16 mode is neither pipe nor HBM but the load path of a CU: ~11-13 B/clk/CU sustained
-// (MI355X_MICROARCH.md: LDS-DMA prologue burst 12-13 B/clk/CU; 6.4 TB/s over the chip).  A 320 x 128 tile moves (320 + 128) x 128 B
-// per 64-deep stage for 5.2 MFLOP: at 12.5 B/clk that is 4590 clk per stage against 1290 clk of MFMA -- 0.28 of the fp16 pipe at
-// best, 0.23 measured (fc6 at 300 RoIs), and at 1000 RoIs the activation panel re-streamed per 128-column tile (32 x 100 MB) plus
-// the weights per row block (4 x 411 MB) make 4.8 GB through that path per call: 641 us at 7.5 TB/s.  The lever is bytes per
-// flop: a 256-column tile reads the activations half as often.  This kernel: workgroup = 8 waves (two per SIMD) = 32 kMT rows x
+// fc_x3_kernel's 320 x 128 tile moves (320 + 128) x 128 B per 64-deep stage for 5.2 MFLOP, and at 1000 RoIs re-streams the activation
+// panel per 128-column tile (32 x 100 MB) plus the weights per row block (4 x 411 MB): 4.8 GB per call.  The lever is bytes per
+// flop (energy: the pipe is power limited -- 1.75 GHz under this kernel, DESIGN.md section 9 item 4 -- not a full load path): a
+// 256-column tile reads the activations half as often.  This kernel: workgroup = 8 waves (two per SIMD) = 32 kMT rows x
 // 256 columns, wave (wm, wn) owns kMT/2 row tiles x columns [64 wn, 64 wn + 64) (10 or 8 accumulator tiles = 160 / 128 AGPRs);
 // a stage's panels ([32 kMT][128 B] activations + [256][128 B] weights, both already stage-major and contiguous in memory) go
 // global -> LDS with global_load_lds_dwordx4 -- no staging registers, which is what lets eight 10-tile waves fit the register
@@ -605,13 +603,13 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   const int bm = 32 * mt;
   const int stages = K / kStage, tm = cdiv(M, bm);
   // 256- or 320-row blocks, N a multiple of 256: the 256-column LDS-DMA kernel (fc_lowp_dma_kernel) -- half the activation
-  // traffic per flop through the CU's load path, which is what bounds this mode -- when its K splits keep at least 8 stages
+  // bytes per flop (the reduced-precision pipe is power limited, DESIGN.md section 9 item 4: bytes are energy) -- when its K splits keep at least 8 stages
   // (fc7 at 300 RoIs would get 4: prologue and epilogue of a workgroup then outweigh the traffic saved).  FCX3_WIDE=0: off.
   bool wide = false;
   if ((mt == 8 || mt == 10) && N % 256 == 0 && N >= 512 && tune(ctx, T_FCX3_WIDE, 1) != 0) {
     const int sp = cdiv(256, (N / 256) * tm);
     wide = stages / (sp > 0 ? sp : 1) >= (F16 ? 8 : 16);
-    // split bf16 at one row block (300 RoIs): three MFMAs per term keep the matrix pipe busier than the load path, and the doubled
+    // split bf16 at one row block (300 RoIs): three MFMAs per term make the operand bytes a smaller share of the work, and the doubled
     // K splits cost in the reduction what the kernel gains (fc6: 213.9 + 10.8 us vs 204.5 + 16.9 us) -- the 128-column kernel stays
     if (!F16 && tm == 1 && !tune_set(ctx, T_FCX3_WIDE)) wide = false;
   }
