@@ -79,9 +79,9 @@ def parse():
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
     p.add_argument("--no-graph", action="store_true", help="native engine: direct launches on every step (counter-profiling runs)")
-    p.add_argument("--event-every", type=int, default=0,
-                   help="native engine: record the per-kernel HIP events on every N-th timed step (those steps run as direct "
-                        "launches, the others replay the captured HIP graph -- the library's default path); 0 = max(4, steps / 8)")
+    p.add_argument("--event-steps", type=int, default=0,
+                   help="images of the event pass that follows the timed region (one at a time, direct launches, HIP events around "
+                        "the MFMA launches on the engine's stream: what `roofline` is computed from); 0 = clamp(steps / 8, 8, 40)")
     p.add_argument("--math", default=os.environ.get("MNC_MATH"), choices=["fp32", "bf16x3", "f16"],
                    help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
@@ -131,8 +131,6 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     conf = CONFIGS[args.config]
-    if args.event_every <= 0:
-        args.event_every = max(4, args.steps // 8)
     math = args.math or conf["math"]
     if args.config != "vgg16" and args.engine == "native":
         # the hand-written native pipeline is the VGG-16 5-stage graph; any other prototxt runs on the engine's plan, captured
@@ -328,27 +326,30 @@ def main():
         events = not args.no_events
         fence()
         level = 1 if args.all_events else 2
-        every = max(1, args.event_every) if (native or engine == "graph") else 1
-        if events:
-            net.profile(level)                       # (resets the record list)
         for k in phase:
             phase[k] = 0.0
-        event_steps = 0
+        # the timed region: `steps` steps of the named protocol and nothing else (no event steps inside it since round 4)
         t0 = time.perf_counter()
         for k in range(steps):
-            if events and every > 1:
-                net.profile_enable(level if k % every == 0 else 0)
-            event_steps += int(events and k % every == 0)
             if inflight > 1:
-                step_pipelined(warmup + k, events and k % every == 0)
+                step_pipelined(warmup + k, False)
             else:
                 step(warmup + k)
         fence()
         elapsed = time.perf_counter() - t0
-        records = net.profile_records() if events else []
+        phase_ms = {k: 1e3 * v / steps for k, v in phase.items()}
+        # the event pass, AFTER the timed region: `event_steps` more images, one at a time (pipeline drained), as direct
+        # launches with a HIP event pair on the engine's stream around every MFMA launch -- what `roofline` is computed from
+        records, event_steps = [], 0
         if events:
+            event_steps = args.event_steps if args.event_steps > 0 else max(8, min(40, steps // 8))
+            net.profile(level)                       # (resets the record list)
+            for k in range(event_steps):
+                step(warmup + steps + k)
+            fence()
+            records = net.profile_records()
             net.profile(False)
-        out = {"elapsed": elapsed, "phase_ms": {k: 1e3 * v / steps for k, v in phase.items()}, "records": records,
+        out = {"elapsed": elapsed, "phase_ms": phase_ms, "records": records,
                "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None), "in_flight": inflight,
                "gather_transport": transport}
         for nn in nets[1:]:
@@ -419,7 +420,7 @@ def main():
     def summarise(steps, m):
         out = {"host_phase_ms_per_image": {k: round(v, 3) for k, v in m["phase_ms"].items()}}
         records = m["records"]
-        steps = m.get("event_steps") or steps        # the steps whose launches carry events
+        steps = m.get("event_steps") or steps        # the images of the event pass (their launches carry events)
         out["event_steps"] = steps if records else 0
         if records:
             agg = {}
@@ -472,6 +473,7 @@ def main():
                                    "included in the timed region; %s; seeded synthetic weights (no trained model here: "
                                    "mAP unverifiable)" % (conf["what"], H, W, conf["rois"], 2 * conf["rois"], H, W,
                                                           MATH_NOTE[math]),
+                       "what": conf["what"], "image": "%dx%d" % (H, W), "config_name": args.config,
                        "images_per_step": world, "rois_per_stage": conf["rois"], "math": math, "images_in_flight_per_gpu": m["in_flight"],
                        "parallelism": (("images sharded 1/GPU, %d ranks; ncclAllGather of [100,447] instance blocks on the "
                                         "engine stream" % world) if on_gpu else
@@ -499,14 +501,13 @@ def main():
                 "images_per_s_at_conv_roofline": at_peak, "value_as_frac_of_conv_roofline": out["value"] / world / at_peak,
                 "definition": "conv roofline = images/s one GPU would reach if the 3x3 convolutions (trunk + rpn_conv, algorithmic "
                               "direct-form flop) ran at the dense MFMA peak and nothing else took time; per-GPU value / that"}
-        out["config"]["engine"] = (("native: one mnc_forward_image call per image (csrc/pipeline.hip); the image size's captured HIP "
-                                    "graph is replayed, every %d%s timed step runs as direct launches with HIP events around the MFMA "
-                                    "kernels" % (max(1, args.event_every), {1: "st", 2: "nd", 3: "rd"}.get(max(1, args.event_every), "th")))
+        out["config"]["engine"] = (("native: one mnc_forward_image call per image (csrc/pipeline.hip), the image size's captured HIP graph "
+                                    "replayed on every timed step; the roofline events come from %d extra images run after the timed "
+                                    "region as direct launches, one at a time" % m["event_steps"])
                                    if args.engine == "native" else
-                                   ("graph: mnc_amd.engine.Net's own plan for the prototxt (Net.detect_image): the launch sequence of an image "
-                                    "size is captured into a HIP graph on its second image and replayed -- one graph launch + one "
-                                    "synchronisation per image; every %d%s timed step runs as direct launches with HIP events"
-                                    % (max(1, args.event_every), {1: "st", 2: "nd", 3: "rd"}.get(max(1, args.event_every), "th")))
+                                   ("graph: mnc_amd.engine.Net's own plan for the prototxt (Net.detect_image), captured into a HIP graph "
+                                    "per image size and replayed on every timed step; roofline events from %d extra images after the "
+                                    "timed region (direct launches)" % m["event_steps"])
                                    if args.engine == "graph" else "python: mnc_amd.engine.Net layer by layer (tools/demo.py body)")
         if "graph_s" in m:
             out["graph_replay"] = {"value": 1.0 / m["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m["graph_s"],
@@ -554,10 +555,115 @@ def main():
         if (world == 1 and not launched and args.config == "vgg16" and math == "fp32" and not args.no_resnet
                 and not args.no_alt_math):
             out["config_resnet50"] = resnet50_line()
-        print(json.dumps(out), flush=True)
+        emit(out)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _r(x, nd=4):
+    """round floats for the compact line (significant figures, not decimals)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    return x
+
+
+def compact_line(out):
+    """The LAST stdout line of a run: one JSON object well under 4 KB that carries what the driver parses (metric .. config,
+    `roofline`, `cpu_baseline`) and one scalar per alternative measurement.  Everything else stays in the detail file
+    (bench_detail.json).  Pure function of the full result dict, so a recorded result can be re-formatted (tests/test_bench_line.py).
+    VERDICT r3: the round-3 line was 24.5 KB, the driver keeps an 8 KB tail, and nothing could be parsed."""
+    c = out.get("config", {})
+    world = out.get("n_gpus", 1)
+    conf = {"workload": "%s; one %s uint8 image per GPU per step (8 seeded images rotating), %s RoIs per stage, H2D + device prep + "
+                        "forward + tail + gpu_mask_voting + D2H of the voted instances all inside the timed region; synthetic weights"
+                        % (c.get("what", out.get("metric", "")), c.get("image", "600x1000"), c.get("rois_per_stage")),
+            "images_per_step": c.get("images_per_step", world), "rois_per_stage": c.get("rois_per_stage"),
+            "math": c.get("math"), "images_in_flight_per_gpu": c.get("images_in_flight_per_gpu"),
+            "engine": (c.get("engine") or "").split(":")[0].split(" ")[0],
+            "parallelism": ("single GPU" if world == 1 else
+                            "images sharded 1 per rank, %d ranks, %s gather of [100,447] instance blocks" %
+                            (world, out.get("gather_transport") or out.get("dist_backend")))}
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline")}
+    line["dtype"] = (out.get("dtype") or "").split(" ")[0]
+    line["data"] = out.get("data")
+    line["config"] = conf
+    rf = out.get("roofline")
+    if rf:
+        line["roofline"] = {k: _r(rf.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                       "launches_per_image", "avg_launch_ms", "algorithmic_gflop_per_launch")
+                            if k in rf}
+        line["roofline"]["event_images"] = out.get("event_steps")
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                "kind": cb.get("kind"), "sample": (cb.get("sample") or "")[:160]}
+    if out.get("kernel_ms_per_image"):
+        line["kernel_ms_per_image"] = {k: _r(v, 3) for k, v in list(out["kernel_ms_per_image"].items())[:4]}
+    cr = out.get("conv_roofline")
+    if cr:
+        line["conv_roofline"] = {"conv_tflops": _r(cr.get("conv_achieved_tflops")), "peak_tflops": cr.get("peak_tflops"),
+                                 "frac": _r(cr.get("conv_kernels_frac_of_peak")),
+                                 "value_frac_of_conv_roofline": _r(cr.get("value_as_frac_of_conv_roofline"))}
+    tr = [r for r in out.get("roofline_by_kernel", []) if r.get("what", "").endswith("(all launches of an image)")
+          and "traffic_over_algorithmic" in r]
+    if tr:
+        line["trunk_traffic_over_algorithmic"] = {r["scope"]: _r(r["traffic_over_algorithmic"], 3) for r in tr}
+    alt = {}
+    if out.get("one_image_at_a_time"):
+        alt["one_image_at_a_time"] = _r(out["one_image_at_a_time"].get("value"))
+    if out.get("python_engine"):
+        alt["python_engine"] = _r(out["python_engine"].get("value"))
+    for key in sorted(k for k in out if k.startswith("alt_math")):
+        a = out[key]
+        alt[a.get("math", key)] = _r(a.get("value"))
+        if a.get("roofline"):
+            alt[a.get("math", key) + "_roofline_frac"] = _r(a["roofline"].get("frac"), 3)
+        if a.get("max_rel_diff_vs_fp32"):
+            alt[a.get("math", key) + "_max_rel_diff_vs_fp32"] = _r(max(a["max_rel_diff_vs_fp32"].values()), 2)
+    if isinstance(out.get("config_resnet50"), dict):
+        alt["resnet50_800x1333_1000rois"] = _r(out["config_resnet50"].get("value")) if "value" in out["config_resnet50"] \
+            else "error"
+        if "math" in out["config_resnet50"].get("config", {}):
+            alt["resnet50_math"] = out["config_resnet50"]["config"]["math"]
+    if alt:
+        line["images_per_s_other_protocols"] = alt
+    ranks = out.get("ranks") or []
+    if len(ranks) > 1:
+        ms = [r["ms_per_step"] for r in ranks]
+        line["ranks_ms_per_step"] = {"min": _r(min(ms)), "max": _r(max(ms)), "mean": _r(sum(ms) / len(ms)), "n": len(ms)}
+        mem = [r["device_mem_gb"] for r in ranks if r.get("device_mem_gb") is not None]
+        if mem:
+            line["ranks_device_mem_gb"] = {"max": _r(max(mem), 3)}
+        line["gather_transport"] = out.get("gather_transport")
+        line["rccl_version"] = out.get("rccl_version")
+    line["detail"] = out.get("_detail_path", "bench_detail.json")
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= 4000:                               # never let an optional block push the line past the driver's window
+        for k in ("kernel_ms_per_image", "images_per_s_other_protocols", "conv_roofline", "trunk_traffic_over_algorithmic"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < 4000:
+                break
+    return text
+
+
+def emit(out):
+    """Full result -> bench_detail.json (repo root, and gpurun_out/ when it exists so that it comes back from the GPU box); the
+    compact line is the LAST thing on stdout."""
+    name = "bench_detail.json" if out.get("n_gpus", 1) == 1 and out["config"].get("config_name", "vgg16") == "vgg16" else \
+        "bench_detail_%s_n%d.json" % (out["config"].get("config_name", "vgg16"), out.get("n_gpus", 1))
+    out["_detail_path"] = name
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as e:
+                print("bench.py: could not write %s: %s" % (os.path.join(d, name), e), file=sys.stderr)
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
 
 
 def shared_weights(proto, synth, rank, world, dist):
@@ -569,21 +675,31 @@ def shared_weights(proto, synth, rank, world, dist):
         return synth.synthetic_weights(proto, seed=0)
     import tempfile
     from mnc_amd import caffemodel
+    # One writer per NODE (LOCAL_RANK 0), a name nobody can predict or pre-create (mkstemp: O_EXCL, mode 0600), carried to the
+    # node's other ranks through the process group (a fixed name written by global rank 0 only failed on other nodes
+    # and could collide with a stale file).
+    local = int(os.environ.get("LOCAL_RANK", rank))
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    path = os.path.join(base, "mnc_bench_weights_%s_%s.mncw" % (os.environ.get("MASTER_PORT", "0"), os.path.basename(proto)))
-    if rank == 0:
-        w = synth.synthetic_weights(proto, seed=0)
-        caffemodel.save_flat(w, path + ".tmp")
-        os.replace(path + ".tmp", path)
-    dist.barrier()
-    if rank != 0:
-        w = caffemodel.load_flat(path)
-    dist.barrier()                      # everybody has the file mapped: the name can go (the pages stay while mapped)
-    if rank == 0:
-        try:
-            os.remove(path)
-        except OSError:
-            pass
+    host = socket.gethostname()
+    mine, w = None, None
+    try:
+        if local == 0:
+            fd, mine = tempfile.mkstemp(prefix="mnc_bench_weights_", suffix=".mncw", dir=base)
+            os.close(fd)
+            w = synth.synthetic_weights(proto, seed=0)
+            caffemodel.save_flat(w, mine)
+        names = [None] * world
+        dist.all_gather_object(names, (host, mine))               # doubles as the barrier: the files are complete
+        path = next(p for h, p in names if h == host and p is not None)
+        if local != 0:
+            w = caffemodel.load_flat(path)
+    finally:
+        dist.barrier()                  # everybody has the file mapped: the name can go (the pages stay while mapped)
+        if mine is not None:
+            try:
+                os.remove(mine)
+            except OSError:
+                pass
     return w
 
 
@@ -608,12 +724,15 @@ def resnet50_line():
 def roofline_by_kernel(records, steps):
     """One entry per (profiling scope, shape): the dominant InnerProduct split into its three shapes, the Winograd trunk with
     algorithmic AND executed flop, conv1_1 against HBM.  Same events as `roofline` (HIP events on the engine's stream)."""
+    # one group per (scope, algorithmic flop, algorithmic bytes): layers of equal flop but different bytes (conv1_2 / conv2_2 /
+    # conv3_2 / conv4_2 are all 44.24 GFLOP and move 307 / 154 / 79 / 48 MB) are different rows, and every row carries ITS OWN
+    # bytes (VERDICT r3: the first member's bytes used to stand for the whole flop class)
     groups = {}
     for name, kms, fl, by in records:
-        g = groups.setdefault((name, round(fl / 1e7)), [name, 0, 0.0, fl, by])
+        g = groups.setdefault((name, round(fl / 1e7), round(by / 1e5)), [name, 0, 0.0, fl, by])
         g[1] += 1; g[2] += kms
     rows = []
-    for (name, _), (_, cnt, tot_ms, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
+    for (name, _, _), (_, cnt, tot_ms, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][2]):
         avg_s = tot_ms / cnt * 1e-3
         label = FC_SHAPES.get((name, round(fl / 1e9, 2)), name)
         e = {"scope": name, "what": label, "launches_per_image": round(cnt / steps, 3), "avg_launch_ms": tot_ms / cnt,

@@ -181,9 +181,10 @@ MNC_API int mnc_ctx_get_layer_conventions(const mnc_ctx* ctx, mnc_layer_conventi
 /* Launch-sequence capture for hosts that drive the per-layer entry points themselves (the caffe-shaped Python engine does, for
  * any prototxt): everything the library enqueues on the context's stream between capture_begin and capture_end -- kernels,
  * mnc_h2d_async / mnc_d2h_async / mnc_d2d copies -- becomes one HIP graph; mnc_graph_launch replays it with one call.  Inside a
- * capture nothing may synchronise or allocate (mnc_h2d, mnc_d2h, mnc_dev_alloc / _free, a growing internal arena): such a call
- * fails with MNC_ERR_HIP and mnc_ctx_capture_end then returns the failure (run the sequence once eagerly first, so that every
- * buffer has its size).  The graph holds raw device addresses: mnc_graph_launch returns MNC_ERR_STATE when an internal arena of
+ * capture nothing may synchronise or allocate (mnc_h2d, mnc_d2h, mnc_ctx_sync, mnc_dev_alloc / _free, a growing internal
+ * arena): such a call is refused with MNC_ERR_STATE BEFORE it touches the stream (the capture stays intact: end it, discard the
+ * graph, run the sequence eagerly once so that every buffer has its size, capture again).  mnc_ctx_capture_begin itself returns
+ * MNC_ERR_STATE while per-launch profiling is on (mnc_prof_enable): event pairs cannot be captured.  The graph holds raw device addresses: mnc_graph_launch returns MNC_ERR_STATE when an internal arena of
  * the context has been re-allocated since the capture (mnc_ctx_arena_generation) -- capture again.  The caller keeps its own
  * buffers in place.  mnc_forward_image uses the same mechanism internally. */
 typedef struct mnc_graph mnc_graph;
@@ -525,7 +526,10 @@ typedef struct mnc_net_config {
   int math;                /* 0 fp32, 1 bf16x3, 2 f16 (the engine's math modes) */
   int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
   int winograd;            /* fp32 math: 1 = 3x3 convolutions by Winograd F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */
-  mnc_layer_conventions conventions;   /* ROIWarping / MaskResize / MaskPooling conventions; all zero = oracle/SPEC.md */
+  mnc_layer_conventions conventions;   /* ROIWarping / MaskResize / MaskPooling conventions; all zero = oracle/SPEC.md.  The RoI
+                                        * kernels read them from the CONTEXT: mnc_net_create applies this member to `ctx` only when
+                                        * it differs from the all-zero default, so conventions a host set on the context with
+                                        * mnc_ctx_set_layer_conventions survive a net built from mnc_net_default_config */
 } mnc_net_config;
 
 /* The reference's values for every field (VGG-16 widths, lib/mnc_config.py defaults). */
@@ -537,7 +541,8 @@ MNC_API int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** ou
  * (the *_ext layers share these by `param { name }`, test.prototxt:514-515 <-> :829-834).  index 0 = weights, 1 = bias. */
 MNC_API int mnc_net_set_param(mnc_net* net, const char* layer, int index, const float* data_host, size_t count);
 /* mnc_load_weights: every blob from a flat little-endian file written by mnc_amd.caffemodel.save_flat / tools/convert_weights.py:
- * "MNCW0001", uint32 n, then n x { uint16 name_len, name, uint8 blob index, uint8 ndim, uint32 dims[ndim], float32 data }. */
+ * "MNCW0001", uint32 n, then n x { uint16 name_len, name, uint8 blob index, uint8 ndim, uint32 dims[ndim], float32 data }.
+ * Entries with a blob index > 1 (a third blob of a layer, e.g. BatchNorm's moving-average factor) are read over and ignored. */
 MNC_API int mnc_net_load_file(mnc_net* net, const char* path);
 /* One image.  bgr_host: uint8 [H][W][3] (BGR, as cv2.imread gives the reference).  records_host: [record_cap][6 + S*S] float32
  * = (x1, y1, x2, y2, score, class id, mask) of the voted instances, rows past the count zero; counts_host [num_classes]:

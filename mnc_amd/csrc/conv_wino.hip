@@ -1105,7 +1105,10 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
   }
   const int kpool = (pool && ksplit == 1) ? 1 : 0;               // pooling inside the kernel's epilogue
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
-  const double bytes = 4.0 * ((double)H * W * (Cin + Cout) + 9.0 * Cin * Cout);
+  // algorithmic bytes: input + weights + what this launch must write -- the pooled tensor when the Pooling is fused (the
+  // full-resolution output then never exists)
+  const double out_px = pool ? (double)((H + 1) / 2) * ((W + 1) / 2) : (double)H * W;
+  const double bytes = 4.0 * ((double)H * W * Cin + out_px * Cout + 9.0 * Cin * Cout);
   LaunchScope ls(ctx, "conv3x3_wino_mfma", flops, bytes);
   // WINO_VAR: 7 (the product build) rotated loop, all halo rows read behind the barrier, LDS-DMA weight panel.  -DMNC_TUNING builds
   // also carry 3 (row B read at the head of the iteration), 1 (flat block schedule, register staging), 0 (the round-2 v2 loop)

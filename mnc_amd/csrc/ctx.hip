@@ -167,6 +167,10 @@ int mnc_ctx_arena_generation(const mnc_ctx* ctx, unsigned long* generation) {
 int mnc_ctx_capture_begin(mnc_ctx* ctx) {
   MNC_REQUIRE(ctx, "mnc_ctx_capture_begin: null context");
   MNC_REQUIRE(!ctx->capturing, "mnc_ctx_capture_begin: a capture is already open on this context");
+  if (ctx->profiling != 0) {       // LaunchScope would record event pairs into the captured stream: they never execute
+    set_error("mnc_ctx_capture_begin: per-launch profiling is on (mnc_prof_enable); event pairs cannot be captured");
+    return MNC_ERR_STATE;
+  }
   MNC_HIP_TRY(hipSetDevice(ctx->device));
   MNC_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
   ctx->capturing = true;
@@ -267,6 +271,7 @@ int mnc_ctx_get_layer_conventions(const mnc_ctx* ctx, mnc_layer_conventions* con
 int mnc_dev_alloc(mnc_ctx* ctx, size_t bytes, void** d_ptr) {
   MNC_REQUIRE(ctx && d_ptr, "mnc_dev_alloc: null pointer");
   *d_ptr = nullptr;
+  MNC_NO_CAPTURE(ctx, "mnc_dev_alloc");
   MNC_HIP_TRY(hipSetDevice(ctx->device));
   hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
   if (e != hipSuccess) {

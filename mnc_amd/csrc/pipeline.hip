@@ -666,18 +666,27 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 2, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3) or 2 (f16)");
   MNC_REQUIRE(cfg->target_size > 0 && cfg->max_size >= cfg->target_size, "mnc_net_create: target_size / max_size");
   {
-    int rc = mnc_ctx_set_layer_conventions(ctx, &cfg->conventions);      // validated; the RoI launchers read them from the context
-    if (rc) return rc;
+    // The RoI launchers read the conventions from the context.  An all-default member (mnc_net_default_config) leaves what the
+    // host set on the context alone (a net built from the default config used to revert them to the SPEC, for every
+    // user of a shared context); anything else is validated and applied.
+    const mnc_layer_conventions& cv = cfg->conventions;
+    const bool dflt = cv.warp_sample == 0 && cv.warp_round_edges == 0 && cv.warp_no_plus_one == 0 && cv.warp_oob == 0 &&
+                      cv.resize_mode == 0 && cv.maskpool_binary == 0;
+    if (!dflt) {
+      int rc = mnc_ctx_set_layer_conventions(ctx, &cfg->conventions);
+      if (rc) return rc;
+    }
   }
   mnc_net* n = new (std::nothrow) mnc_net();
   if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
   n->ctx = ctx;
   n->cfg = *cfg;
+  n->cfg.conventions = ctx->conv;          // the conventions in force (the member, or what the host had set on the context)
   n->fc_sm = tune(ctx, T_FC_SM, 1) != 0;
   n->fuse_pools = tune(ctx, T_FUSE_POOLS, 1) != 0;
   if (tune(ctx, T_BRANCH_STREAMS, 0) == 1) {
     if (mnc_ctx_create(&n->ctx_b, ctx->device) != MNC_OK) n->ctx_b = nullptr;     // optional: the net works on one stream
-    if (n->ctx_b) (void)mnc_ctx_set_layer_conventions(n->ctx_b, &cfg->conventions);
+    if (n->ctx_b) (void)mnc_ctx_set_layer_conventions(n->ctx_b, &ctx->conv);
     for (int i = 0; i < 2 && n->ctx_b; ++i) {
       if (hipEventCreateWithFlags(&n->ev_fork[i], hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&n->ev_join[i], hipEventDisableTiming) != hipSuccess) {
@@ -730,7 +739,7 @@ int mnc_net_load_file(mnc_net* net, const char* path) {
            fread(&nd, 1, 1, f) == 1 && nd <= 8 && fread(dims, 4, nd, f) == nd;
       if (!ok) break;
       name[len] = 0;
-      if (idx > 1) { ok = false; why = "holds a blob index > 1 (a layer has a weight [0] and a bias [1])"; break; }
+      const bool skip = idx > 1;     // a third blob (BatchNorm's moving-average factor in containers save_flat wrote): not a parameter of this graph
       const size_t left = (size_t)(file_bytes - ftell(f)) / 4;
       size_t count = 1;
       for (int d = 0; d < nd && ok; ++d) {
@@ -741,7 +750,7 @@ int mnc_net_load_file(mnc_net* net, const char* path) {
       v.resize(count);
       ok = fread(v.data(), 4, count, f) == count;
       if (!ok) break;
-      rc = mnc_net_set_param(net, name, idx, v.data(), count);
+      if (!skip) rc = mnc_net_set_param(net, name, idx, v.data(), count);
       if (rc) break;
     }
   } catch (const std::exception&) {

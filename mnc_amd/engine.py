@@ -1607,7 +1607,10 @@ class Net(object):
                 self._drop_image_graphs()                               # an arena of the context moved: this image runs eagerly
                 g = None
         elif g is not None:
-            self._drop_image_graphs()
+            # use_graph=False / profiling on: this image bypasses its graph, which stays valid for the next one (every
+            # event step of bench.py used to destroy the captured graphs of all sizes); only a moved buffer invalidates it
+            if g["allocs"] != self._ctx.allocs:
+                self._drop_image_graphs()
             g = None
         if mode == "eager":
             if use_graph and st["seen"] == key and key not in st.get("no_graph", ()):

@@ -30,12 +30,20 @@ class ImagePrep(object):
     def __init__(self, net):
         from .engine import _DevBuf
         self._net = net
-        self._im, self._taps, self._out = _DevBuf(net._ctx), _DevBuf(net._ctx), _DevBuf(net._ctx)
+        self._im, self._out = _DevBuf(net._ctx), _DevBuf(net._ctx)
+        # one IMMUTABLE tap table per geometry (H, W, factors): a captured launch sequence of an image size (Net.detect_image)
+        # holds the table's address and replays without running this Python -- a single shared buffer re-uploaded per geometry
+        # let a replay of size A read size B's taps (ADVICE r3, A A A B A with B smaller).  Insertion-ordered; the oldest table
+        # goes when more than kMaxTables geometries are alive, and the graphs that may hold it are dropped first.
+        self._tables = {}
         self._gen = 0
 
+    kMaxTables = 64
+
     def release(self):
-        for b in (self._im, self._taps, self._out):
+        for b in [self._im, self._out] + [t[0] for t in self._tables.values()]:
             b.release()
+        self._tables = {}
 
     def pyramid(self, im, pixel_means, factors, staged=None):
         """uint8 BGR [H,W,3] -> DeviceArray [L,3,PH,PW]: level l = (im - means) resized by factors[l] (both axes), zero-padded
@@ -54,7 +62,8 @@ class ImagePrep(object):
         # stream of same-sized images (a dataset at one scale, the bench) builds and uploads it once
         h = self._net._ctx.h
         key = (H, W, tuple(float(f) for f in factors))
-        if getattr(self, "_table_key", None) != key:
+        entry = self._tables.get(key)
+        if entry is None:
             parts, offs, pos = [], [], 0
             for (oh, ow), f in zip(sizes, factors):
                 x0, _, ax = linear_taps(ow, W, f)
@@ -63,11 +72,20 @@ class ImagePrep(object):
                 parts += [x0.astype(np.int32).view(np.float32), ax, y0.astype(np.int32).view(np.float32), ay]
                 pos += 2 * ow + 2 * oh
             table = np.ascontiguousarray(np.concatenate(parts))
-            _lib.call("mnc_h2d", h, self._taps.ensure(table.nbytes), _lib.ptr(table), table.nbytes)
-            self._table_key, self._offs = key, offs
-        offs = self._offs
+            if len(self._tables) >= self.kMaxTables:
+                drop = getattr(self._net, "_drop_image_graphs", None)
+                if drop is not None:
+                    drop()                                                  # a graph may hold the table that is about to go
+                _lib.call("mnc_ctx_sync", h)
+                self._tables.pop(next(iter(self._tables)))[0].release()
+            from .engine import _DevBuf
+            buf = _DevBuf(self._net._ctx)
+            _lib.call("mnc_h2d", h, buf.ensure(table.nbytes), _lib.ptr(table), table.nbytes)
+            entry = self._tables[key] = (buf, offs)
+        self._table_key = key
+        offs = entry[1]
         d_im = self._im.ensure(im.nbytes)
-        d_t = self._taps.ptr
+        d_t = entry[0].ptr
         d_out = self._out.ensure(L * 3 * PH * PW * 4)
         # stream-ordered before the kernels that read it; `staged` = the address of a pinned copy of `im` the caller keeps (a truly
         # asynchronous copy, and one a captured launch sequence may hold: Net.detect_image)

@@ -727,6 +727,40 @@ def test_detect_image_graph_replay_equals_layer_by_layer(graph, math, monkeypatc
         ref.close()
 
 
+def test_detect_image_replay_after_another_geometry_of_equal_size():
+    """sizes A, A, A (captured, replayed), then B with the SAME pixel count (no buffer grows, so graph A
+    survives), then A again.  B's resize taps used to overwrite the one shared table in place and the replay of A read them.
+    Each geometry now owns an immutable table (mnc_amd/prep.py); every call equals the layer-by-layer path bit for bit."""
+    import demo
+    from mnc_amd.engine import Net
+    from mnc_amd.instances import split_records
+    from transform.mask_transform import gpu_mask_voting
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=6)
+    net = Net(path, w, 1)
+    ref = Net(path, w, 1)
+    A, B = (120, 90), (75, 100)                                      # 800x600 and 600x800 network inputs: equal buffer sizes
+    try:
+        rng = np.random.default_rng(77)
+        replays = 0
+        for k, (H, W) in enumerate([A, A, A, B, A, A, A, B, B, A, B, A]):
+            im = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            had = (H, W) in [kk[:2] for kk in net._img["graphs"]] if hasattr(net, "_img") else False
+            counts, rec = net.detect_image(im)
+            replays += int(had and (H, W) in [kk[:2] for kk in net._img["graphs"]])
+            b, m, s = demo.im_detect(im, ref)
+            lm, lb = gpu_mask_voting(m, b, s, 21, 100, W, H)
+            gm, gb = split_records(rec, counts[1:], 21)
+            assert [len(x) for x in gb] == [len(x) for x in lb], (k, H, W)
+            assert np.array_equal(np.concatenate(gb, 0), np.concatenate(lb, 0)), (k, H, W)
+            assert np.array_equal(np.concatenate(gm, 0), np.concatenate(lm, 0), equal_nan=True), (k, H, W)
+            assert np.array_equal(net.blobs["data"]._host_read(), ref.blobs["data"]._host_read()), (k, H, W)
+        assert replays >= 3, replays                                     # the tail of the sequence really ran on surviving graphs
+    finally:
+        net.close()
+        ref.close()
+
+
 def test_detect_image_falls_back_when_the_sequence_cannot_be_captured():
     """With the three stock Python layers run as Python objects (native_pylayers=False) the forward has host hops (blobs down,
     numpy, tops up): such a sequence cannot be captured into a HIP graph.  detect_image notices (the capture is invalidated by the
