@@ -262,6 +262,18 @@ MNC_API int mnc_conv3x3_wino(mnc_ctx* ctx, const float* d_in_c8, const float* d_
  * full-resolution tensor never reaches HBM.  d_out_pooled_c8: [Cout/8][ceil(H/2)][ceil(W/2)][8] (Caffe's ceil output size). */
 MNC_API int mnc_conv3x3_wino_pool(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
                                   float* d_out_pooled_c8, int H, int W, int Cin, int Cout, int relu);
+/* The same convolution by Winograd's F(4x4, 3x3) (round 4; mnc_amd/csrc/conv_wino4.hip): 36 multiplies per (input channel, output
+ * channel, 4x4 output tile) = 2.25 per output against F(2x2)'s 4 and the direct form's 9.  Fused: input transform, the 36 channel
+ * contractions (v_mfma_f32_16x16x4_f32) and the output transform run in one kernel, one wave holding all 36 positions of its
+ * 16 channels x 16 tiles.  The transforms carry the coefficients 2, 4, 5, 8 and 1/6, 1/12, 1/24 (filter side, evaluated in double,
+ * rounded once): rounding error ~1e-5 of the output range at 512 input channels (F(2x2): ~1e-6; both inside the kernels' 1e-4
+ * bar).  d_w_packed from mnc_pack_conv3x3_wino4: Caffe [Cout][Cin][3][3] -> [Cin/8][Cout/32][2][64][76] floats (Cin*Cout*38 floats).
+ * Cin%8==0, Cout%32==0, H*W*8 < 2^31.  _pool: the following Pooling MAX 2x2/2 in the epilogue (a 4x4 tile is four windows). */
+MNC_API int mnc_pack_conv3x3_wino4(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin);
+MNC_API int mnc_conv3x3_wino4(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias, float* d_out_c8,
+                              int H, int W, int Cin, int Cout, int relu);
+MNC_API int mnc_conv3x3_wino4_pool(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
+                                   float* d_out_pooled_c8, int H, int W, int Cin, int Cout, int relu);
 /* Pooling MAX 2x2 stride 2 with Caffe's ceil output size (test.prototxt:69-79,...): c8 [C/8][H][W][8] ->
  * [C/8][OH][OW][8], OH = ceil((H-2)/2)+1. */
 MNC_API int mnc_maxpool2_c8(mnc_ctx* ctx, const float* d_in, float* d_out, int C, int H, int W);

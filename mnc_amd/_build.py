@@ -17,6 +17,10 @@ LIB = os.path.join(HERE, "libmnc_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 ARCH = "gfx950"
 NO_CONTRACT = {"nms.hip", "mv.hip", "bbox.hip", "roi.hip", "proposal.hip", "prep.hip"}
+# conv_wino4.hip: the transform arithmetic runs beside MFMAs as one-lane fma / add; hipcc's SLP pass would pair scalar operations of
+# different window elements into v_pk_* and pay for every pair with register moves (and packed fp32 beside MFMAs costs more issue
+# time than the two scalar operations: MI355X_MICROARCH.md, per-instruction constants)
+EXTRA_FLAGS = {"conv_wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -26,8 +30,23 @@ def _hipcc():
     return "hipcc"
 
 
+EXPERIMENTS = os.path.join(HERE, "..", "tools", "experiments")       # measurement-only kernels (the stream / 16x16x4 Winograd builds)
+
+
+def _tuning():
+    return "-DMNC_TUNING" in os.environ.get("MNC_HIPCC_EXTRA", "").split()
+
+
 def sources():
+    """The product library's translation units: every .hip under csrc/ (none of them is #ifdef MNC_TUNING as a whole).  A tuning
+    build (MNC_HIPCC_EXTRA=-DMNC_TUNING) additionally links tools/experiments/*.hip, which csrc/conv_wino.hip then dispatches to."""
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _experiment_sources():
+    if not _tuning() or not os.path.isdir(EXPERIMENTS):
+        return []
+    return sorted(f for f in os.listdir(EXPERIMENTS) if f.endswith(".hip"))
 
 
 def _deps_mtime():
@@ -86,11 +105,12 @@ def build(force=False, verbose=False):
                     [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] +
                     [os.path.join(HERE, "..", "include", "mnc_hip.h"), os.path.abspath(__file__)])
 
-    def one(src):
+    def one(item):
+        d, src = item
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if not force and os.path.isfile(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(CSRC, src)), hdr_mtime):
+        if not force and os.path.isfile(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(os.path.join(d, src)), hdr_mtime):
             return obj
-        cmd = base + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = base + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + EXTRA_FLAGS.get(src, []) + ["-I", CSRC, "-c", os.path.join(d, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -99,7 +119,7 @@ def build(force=False, verbose=False):
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
-        objs = list(ex.map(one, sources()))
+        objs = list(ex.map(one, [(CSRC, f) for f in sources()] + [(EXPERIMENTS, f) for f in _experiment_sources()]))
     tmp = LIB + ".tmp"
     r = subprocess.run([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs + ["-ldl"], capture_output=True, text=True)
     if r.returncode != 0:

@@ -1,0 +1,569 @@
+// 3x3 convolution (pad 1, stride 1) by Winograd's minimal filtering F(4x4, 3x3) on the fp32 matrix pipe, fused, for gfx950
+// (models/VGG16/mnc_5stage/test.prototxt:41-412: the trunk's 3x3 layers behind conv1_1 and rpn_conv_3x3; round 4).
+//
+// Why.  F(2x2, 3x3) (conv_wino.hip) spends 16 multiplies per 2x2 outputs = 4 per output and its loop sits at what the fp32 pipe
+// sustains beside its operand traffic.  F(4x4, 3x3) computes a 4x4 output tile from a 6x6 input tile with 36
+// multiplies per (input channel, output channel) = 2.25 per output: 0.5625x the matrix-pipe work for the same result.
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A          (Lavin & Gray 2015, interpolation points 0, +-1, +-2)
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// The filter transform is evaluated in double and rounded once; input and output transforms are fp32 fma chains.  Rounding error
+// measured 5e-6 .. 1.5e-5 of the output range for 64 .. 512 input channels (tools/studies/winograd_f4_error.py; F(2x2): 3e-7 ..
+// 7e-7, the direct fp32 sum 1e-6 .. 2e-6) -- under the kernels' 1e-4 bar and two orders under the path's 1e-3.
+//
+// Mapping -- everything a wave needs for its outputs stays in that wave (no cross-wave exchange, no LDS in the epilogue):
+//   * the contraction over input channels of each of the 36 transform positions is a GEMM  M_p[co][tile] += U_p[co][ci] V_p[ci][tile]
+//     on v_mfma_f32_16x16x4_f32: A = U (lane: co = l & 15, k = l >> 4), B = V (lane: tile = l & 15, k = l >> 4), D: lane holds
+//     co = 4 (l >> 4) + e of tile l & 15.  A wave owns 16 output channels x 16 tiles (one tile row: 4 pixel rows x 64 columns)
+//     x ALL 36 positions: 144 accumulator registers, two waves per SIMD; the output transform is per lane, in registers.
+//   * K is walked in 8-channel blocks.  Lane (tile t, k) transforms the 6x6 window of ITS tile for channels 2k and 2k + 1
+//     (36 ds_read_b64, 2 x 144 fma) and feeds 72 MFMAs: MFMA g of a position multiplies channels 2k + g over the four lane groups.
+//   * workgroup = 8 waves = 2 channel groups x 4 tile rows = 32 output channels x 64 tiles (16 x 64 pixels).  Per block the
+//     weight panel (2 x 64 lanes x 76 floats: 72 values per lane = 36 positions x 2 channels in the lane's fragment order, pitch 76
+//     = 19 x 16 B so that every 16-lane group of a ds_read_b128 covers all 64 banks; stored in global memory exactly as it sits
+//     in LDS) and the 18 x 66 pixel halo go global -> LDS by buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass),
+//     double buffered: 2 x 77 KB of LDS, one workgroup per CU.
+//   * halo image in LDS: dense 32-byte pixels (the DMA writes 16-byte pieces back to back), pixel column xh of a row sits in slot
+//     (xh & 3) * 17 + (xh >> 2) and its two 16-byte channel halves are swapped where bit 5 of xh is set.  Window column c of tile t
+//     is pixel 4 t + c: for a fixed c the 16 tiles of a wave read slots 17 (c & 3) + t (+ 1) -- consecutive 32-byte pixels -- and
+//     tiles t, t + 8 (whose pixels are 256 bytes = all 64 banks apart) read opposite halves: each 32-lane group of a
+//     ds_read_b64 covers the 64 banks exactly once.  Out-of-image pixels, pad slots and rows past the halo are buffer loads with an
+//     out-of-range offset: the hardware writes zeros.
+//   * epilogue: A^T M A per lane (100 fma per output channel), + bias, ReLU, optionally the following Pooling MAX 2x2/2 (a 4x4
+//     tile holds four whole pooling windows), 16-byte stores into the c8 layout; K ranges write raw partial outputs (the transform
+//     is linear) that wino4_section_reduce_kernel finishes.
+#include <atomic>
+
+#include "mnc_internal.h"
+
+namespace mnc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kF4Rows = 16;                          // output rows per workgroup (4 tile rows)
+constexpr int kF4Cols = 64;                          // output columns per workgroup (16 tiles)
+constexpr int kF4HaloRows = kF4Rows + 2;
+constexpr int kF4RowSlots = 68;                      // pixel slots per halo row: 4 residues x 17 (66 used)
+constexpr int kF4RowBytes = kF4RowSlots * 32;        // 2176
+constexpr int kF4HaloPieces = 40;                    // 18 x 2176 = 39168 bytes -> 40 DMA pieces of 1 KB (5 per wave; the tail is zero page)
+constexpr int kF4LanePitch = 76;                     // floats per lane of a weight panel (72 + 4 pad)
+constexpr int kF4PanelFloats = 2 * 64 * kF4LanePitch;            // per (channel block, 32-channel tile): 9728 floats
+constexpr int kF4PanelPieces = kF4PanelFloats * 4 / 1024;        // 38
+constexpr int kF4PanelBytes = kF4PanelFloats * 4;                // 38912
+constexpr int kF4LdsBytes = 2 * (kF4PanelBytes + kF4HaloPieces * 1024);     // two weight panels + two halo images: 159744
+static_assert(kF4PanelPieces * 1024 == kF4PanelBytes, "whole DMA pieces per weight panel");
+static_assert(kF4LdsBytes <= 160 * 1024, "conv3x3_wino4: LDS budget");
+
+// One dimension of the input transform, in place: x = B^T d (12 fma / add for 6 values).
+__device__ __forceinline__ void f4_bt(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
+  const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+  const float c = d4 - d2, e = d3 - d1;
+  const float x0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+  const float x5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+  d0 = x0;
+  d1 = a + b;
+  d2 = a - b;
+  d3 = fmaf(2.f, e, c);
+  d4 = fmaf(-2.f, e, c);
+  d5 = x5;
+}
+
+// One dimension of the output transform: y = A^T m (6 values -> 4).
+__device__ __forceinline__ void f4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2,
+                                      float& y3) {
+  const float p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
+  y0 = (m0 + p) + r;
+  y1 = fmaf(2.f, s, q);
+  y2 = fmaf(4.f, r, p);
+  y3 = fmaf(8.f, s, q) + m5;
+}
+
+// Block order.  The dispatcher puts block b on XCD b % 8 (used for speed only): blocks are re-numbered so that every XCD gets a
+// contiguous range of the logical order (output-channel tile fastest, then K range, then pixel tile) -- the Cout / 32 workgroups
+// that read one halo run on one XCD at about the same time.  Two SECTIONS (the launcher's tail plan): blocks [0, n_a) are the pixel
+// tiles [0, pix_a) with ksplit_a K ranges each, the blocks behind them the remaining tiles with ksplit_b ranges.  A tile with one
+// range writes the finished output; with several, each range writes raw partial outputs to its plane of `part`.
+// ABL (tuning builds only, wrong results): 1 no DMA inside the loop, 2 no halo reads (opaque register constants), 4 no input
+// transform, 8 no weight-fragment reads, 16 no wait / barrier -- what each part of a block costs (kernel_bench convwino4, MNC_WINO_F4).
+template <int XCD, int ABL = 0>
+__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            float* __restrict__ part, int H, int W, int Cin, int Cout, int relu,
+                                                            int pool_a, int tiles_x, int pix_a, int ksplit_a, int ksplit_b) {
+  extern __shared__ __attribute__((aligned(1024))) char s_f4[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave & 1, tg = wave >> 1;
+  const int t = lane & 15, k = lane >> 4;
+  const int ncot = Cout >> 5;
+  int bx, by, cot, split, ksplit;
+  {
+    const int n_a = pix_a * ncot * ksplit_a;
+    int b = blockIdx.x, total = n_a, pix0 = 0;
+    ksplit = ksplit_a;
+    if (b >= n_a) { b -= n_a; total = gridDim.x - n_a; pix0 = pix_a; ksplit = ksplit_b; }
+    const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
+    const int logical = XCD ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
+    const int nz = ncot * ksplit;
+    const int bz = logical % nz;
+    const int pixt = pix0 + logical / nz;
+    bx = pixt % tiles_x;
+    by = pixt / tiles_x;
+    split = bz / ncot;
+    cot = bz - split * ncot;
+  }
+  const int pool = ksplit == 1 ? pool_a : 0;
+  const int w0 = bx * kF4Cols, h0 = by * kF4Rows;
+  const int nblk = Cin >> 3;
+  const int chunk0 = split * nblk / ksplit;
+  const int nchunks = (split + 1) * nblk / ksplit - chunk0;
+  const long plane = (long)H * W * 8;                              // floats per 8-channel block of the input
+
+  // ---- DMA assignment (fixed per thread).  Halo piece p = wave + 8 i covers LDS bytes [1024 p, 1024 p + 1024) of the halo image:
+  // lane L fills 16-byte slot 64 p + L = pixel slot q = 32 p + (L >> 1) (row q / 68, slot q % 68 = a * 17 + b <-> pixel column
+  // xh = 4 b + a), half position L & 1, i.e. it fetches channel half (L & 1) ^ ((xh >> 5) & 1) of that pixel -- or the zero page.
+  // Out-of-image pixels, pad slots and rows past the halo carry an out-of-range offset: the buffer load answers them with zeros.
+  // The offsets are rebuilt from (wave, lane) at every copy (a dozen integer operations per piece) instead of living in five
+  // registers through the loop: the loop has none to spare.
+  auto halo_off = [&](int i) {
+    const int q = 32 * (wave + 8 * i) + (lane >> 1);
+    const int row = q / kF4RowSlots, sl = q - row * kF4RowSlots;
+    const int a = sl / 17, b = sl - a * 17;
+    const int xh = 4 * b + a;
+    const int half = (lane & 1) ^ ((xh >> 5) & 1);
+    const int y = h0 - 1 + row, x = w0 - 1 + xh;
+    const bool ok = row < kF4HaloRows && xh < kF4Cols + 2 && y >= 0 && y < H && x >= 0 && x < W;
+    return ok ? ((y * W + x) * 8 + half * 4) * 4 : 0x7FFFFFF0;             // byte offset inside an 8-channel block of the input
+  };
+  // One buffer descriptor per operand (wave-uniform), the block's offset in the scalar soffset, the lane's part in a 32-bit voffset:
+  // no 64-bit address registers.  (Inline assembly as in gemm.hip: behind the DMA builtins hipcc makes every later ds_read wait for
+  // vmcnt(0).)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [](const float* base, long bytes) {
+    const unsigned long a = (unsigned long)base;
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFFL ? bytes : 0x7FFFFFFFL));
+    r.w = 0x00020000;
+    return r;
+  };
+  const i32x4 in_rsrc = make_rsrc(in, (long)Cin * H * W * 4);
+  const i32x4 w_rsrc = make_rsrc(wpk, (long)nblk * ncot * kF4PanelBytes);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_f4;
+  const int w_voff = lane * 16;
+  // LDS: weight panels [2] then halo images [2]
+  constexpr int kUBuf = kF4PanelBytes, kHBuf = kF4HaloPieces * 1024, kHalo0 = 2 * kF4PanelBytes;
+  // A copy for a block past the end of this workgroup's K range is still ISSUED, with every lane out of range (no memory traffic,
+  // zeros into the free buffer): the loop body stays one basic block with a fixed copy count per barrier -- with branches around
+  // the copies hipcc sinks the transform arithmetic of a pass into the blocks behind them, where no MFMA covers it.
+  auto dma_u = [&](int c, int ubuf) {                              // weight panel of block c -> panel buffer `ubuf` (0 / 1)
+    const int voff = c < nchunks ? w_voff : 0x7FFFFFF0;
+    const int cb = chunk0 + min(c, nchunks - 1);
+    const int wsoff = __builtin_amdgcn_readfirstlane((cb * ncot + cot) * kF4PanelBytes);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      // branch-free: waves 6 and 7 have no fifth panel piece and copy pieces 36 / 37 a second time (same bytes, same place)
+      const int p = min(wave + 8 * i, kF4PanelPieces - 1);
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(ubuf * kUBuf) + (unsigned)p * 1024u);
+      const int so = __builtin_amdgcn_readfirstlane(wsoff + p * 1024);
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(w_rsrc), "s"(so), "s"(l) : "memory");
+    }
+  };
+  auto dma_h = [&](int c, int hbuf) {                              // halo of block c -> halo buffer `hbuf`
+    const bool live = c < nchunks;
+    const int cb = chunk0 + min(c, nchunks - 1);
+    const int hsoff = __builtin_amdgcn_readfirstlane(cb * (int)(plane * 4));
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int p = wave + 8 * i;
+      const int ho = live ? halo_off(i) : 0x7FFFFFF0;
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kHalo0 + hbuf * kHBuf) + (unsigned)p * 1024u);
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(ho), "s"(in_rsrc), "s"(hsoff), "s"(l) : "memory");
+    }
+  };
+  // wait until at most `left` of this wave's copies are in flight (they complete in issue order), then the workgroup barrier; the
+  // "memory" clobber keeps hipcc from moving LDS accesses across it (the copies are invisible to its own wait-count pass)
+#define MNC_F4_SYNC(left) asm volatile("s_waitcnt vmcnt(" #left ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  f32x4 acc[36];
+#pragma unroll
+  for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The accumulators stay in architectural registers: a 512-thread workgroup leaves a wave 256 registers, and once a function
+  // touches AGPRs hipcc splits that budget 128 / 128 (gemm_x3.hip).
+  auto pin_acc = [&]() {
+#pragma unroll
+    for (int p = 0; p < 36; ++p) asm volatile("" : "+v"(acc[p]));
+  };
+
+  // lane-constant LDS byte offsets
+  typedef __attribute__((address_space(3))) const char* lds_cp;   // (explicit LDS address space: a volatile access through a generic pointer is a flat_load)
+  const lds_cp lds = (lds_cp)(__attribute__((address_space(3))) char*)s_f4;
+  const int f0 = (t >> 3) & 1, f1 = ((t + 1) >> 3) & 1;
+  const int hb = kHalo0 + 4 * tg * kF4RowBytes + (k & 1) * 8;
+  const int base0 = hb + t * 32 + ((k >> 1) ^ f0) * 16;          // window columns 0..3: slot 17 c + t
+  const int base1 = hb + (t + 1) * 32 + ((k >> 1) ^ f1) * 16;    // window columns 4, 5: slot 17 (c - 4) + t + 1
+  const int ub = (cg * 64 + lane) * (kF4LanePitch * 4);
+
+  // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 2k + g of block s: 36 MFMAs from the
+  // transformed values of that channel and the 36 weights [g][n] of the lane's panel row, n = the order of use (position (i, j) =
+  // row i, column j of the 6x6 transform is n = 6 j + i: column by column).  WHILE it runs, the wave builds the operand of the next
+  // pass in the registers the previous pass has just freed: pass (s, 0) builds channel 2k + 1 of block s, pass (s, 1) channel 2k
+  // of block s + 1.  Column j of a pass: six reads of window row j for the next operand -> the six MFMAs of column j of the current
+  // one -> the second transform dimension of ITS column j + 1 (12 fma, in place) and the first dimension of the row just read
+  // (12 fma), both under those MFMAs.  The two buffers of each kind turn over half a block apart: block s's halo is last read in pass (s, 0), its panel
+  // in pass (s, 1); each is refilled right behind the barrier that ends its last reading pass and has a whole block to land.
+  float va[36], vb[36];
+  auto read_row = [&](int hbuf, int r, int g, float (&x)[36]) {
+    const lds_cp sh = lds + hbuf * kHBuf + r * kF4RowBytes;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      if (ABL & 2) {
+        x[r * 6 + c] = 1.f + r + c;
+        asm volatile("" : "+v"(x[r * 6 + c]));
+      } else {
+        // (volatile: hipcc otherwise pairs neighbouring reads into ds_read2_b64 -- half rate, 32-dword banking; the unused channel
+        // of the pair is read again by the pass that needs it: a ds_read_b64 costs the LDS what a ds_read_b32 does)
+        const f32x2 dv = *(__attribute__((address_space(3))) const volatile f32x2*)(sh + (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544));
+        x[r * 6 + c] = g ? dv.y : dv.x;
+      }
+    }
+  };
+  auto xpass_row = [&](float (&x)[36], int r) {
+    if (!(ABL & 4)) f4_bt(x[r * 6 + 0], x[r * 6 + 1], x[r * 6 + 2], x[r * 6 + 3], x[r * 6 + 4], x[r * 6 + 5]);
+  };
+  auto ypass_col = [&](float (&x)[36], int j) {
+    if (!(ABL & 4)) f4_bt(x[j], x[6 + j], x[12 + j], x[18 + j], x[24 + j], x[30 + j]);
+  };
+  f32x4 uq[9];
+  auto mfma_col = [&](int ubuf, int g, int j, const float (&x)[36]) {
+    const lds_cp su = lds + ubuf * kUBuf + ub + g * 144;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int n = 6 * j + i;
+      if ((n & 3) == 0) {
+        if (ABL & 8) {
+          uq[n >> 2] = f32x4{1.f, 2.f, 3.f, 4.f};
+          asm volatile("" : "+v"(uq[n >> 2]));
+        } else {
+          uq[n >> 2] = *(__attribute__((address_space(3))) const f32x4*)(su + (n >> 2) * 16);
+        }
+      }
+      acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[n >> 2][n & 3], x[i * 6 + j], acc[i * 6 + j], 0, 0, 0);
+    }
+  };
+  // (on entry column 0 of `cur` has its second dimension already -- the previous pass did it under its last MFMAs, so that a pass
+  // opens with MFMAs whose operands are in registers)
+  auto pass = [&](int ubuf, int g, float (&cur)[36], int hbuf_next, int g_next, float (&nxt)[36]) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      read_row(hbuf_next, j, g_next, nxt);
+      mfma_col(ubuf, g, j, cur);
+      if (j < 5) ypass_col(cur, j + 1);
+      xpass_row(nxt, j);
+      if (j == 5) ypass_col(nxt, 0);
+      // nothing moves across a column: left alone hipcc sinks the transform arithmetic behind the copies at the end of the pass,
+      // where no MFMA of this wave covers it
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  if (nchunks > 0) {
+    dma_u(0, 0);
+    dma_h(0, 0);
+    dma_h(1, 1);
+    dma_u(1, 1);
+    MNC_F4_SYNC(10);                                 // block 0 has landed; block 1's ten pieces may still fly
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      read_row(0, r, 0, va);
+      xpass_row(va, r);
+    }
+    ypass_col(va, 0);
+    for (int s = 0; s < nchunks; ++s) {
+      const int bsel = s & 1;
+      pass(bsel, 0, va, bsel, 1, vb);
+      pin_acc();
+      // middle of block s: every wave is done with halo s; halo s + 1 (requested a block ago) has landed, panel s + 1 may still fly
+      if (!(ABL & 16)) MNC_F4_SYNC(5);
+      if (!(ABL & 1)) dma_h(s + 2, bsel);
+      pass(bsel, 1, vb, bsel ^ 1, 0, va);
+      pin_acc();
+      // end of block s: every wave is done with panel s; panel s + 1 has landed, halo s + 2 may still fly
+      if (!(ABL & 16)) MNC_F4_SYNC(5);
+      if (!(ABL & 1)) dma_u(s + 2, bsel);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dead copies behind the last block write the LDS too: none may outlive the wave)
+  }
+#undef MNC_F4_SYNC
+
+  // ---- epilogue: Y = A^T M A per (output channel, tile); lane: tile t of tile row tg, channels cbase .. cbase + 3 ----
+  const int oy = h0 + 4 * tg, ox = w0 + 4 * t;
+  const int cbase = cot * 32 + cg * 16 + 4 * k;
+  float y[4][4][4];                                  // [row][column][channel]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float z[6][4];                                   // column pass: z[r][j] = sum_c M[r][c] A[c][j]
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      f4_at(acc[r * 6 + 0][e], acc[r * 6 + 1][e], acc[r * 6 + 2][e], acc[r * 6 + 3][e], acc[r * 6 + 4][e], acc[r * 6 + 5][e],
+            z[r][0], z[r][1], z[r][2], z[r][3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      f4_at(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j][e], y[1][j][e], y[2][j][e], y[3][j][e]);
+  }
+  if (oy >= H || ox >= W) return;
+  const bool fin = ksplit == 1;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fin) bv = *reinterpret_cast<const float4*>(bias + cbase);
+  float* dst = fin ? out : part + (long)split * Cout * H * W;
+  const long cplane = (long)(cbase >> 3);
+  const int chalf = ((cbase >> 2) & 1) * 4;
+  if (!pool) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int yy = oy + i, xx = ox + j;
+        if (yy < H && xx < W) {
+          float4 o = make_float4(y[i][j][0] + bv.x, y[i][j][1] + bv.y, y[i][j][2] + bv.z, y[i][j][3] + bv.w);
+          if (relu && fin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          *reinterpret_cast<float4*>(dst + ((cplane * H + yy) * W + xx) * 8 + chalf) = o;
+        }
+      }
+  } else {
+    // the following Pooling MAX 2x2 stride 2 (test.prototxt:69-79, ...; Caffe's ceil rule: the last window of an odd-sized map
+    // is clipped): tile origins are multiples of 4, so a tile is four whole pooling windows
+    const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) {
+        const int py = oy + 2 * pi, px = ox + 2 * pj;
+        if (py >= H || px >= W) continue;
+        float4 best = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+          for (int dj = 0; dj < 2; ++dj) {
+            if (py + di < H && px + dj < W) {
+              const int i = 2 * pi + di, j = 2 * pj + dj;
+              float4 o = make_float4(y[i][j][0] + bv.x, y[i][j][1] + bv.y, y[i][j][2] + bv.z, y[i][j][3] + bv.w);
+              if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+              best.x = fmaxf(best.x, o.x); best.y = fmaxf(best.y, o.y); best.z = fmaxf(best.z, o.z); best.w = fmaxf(best.w, o.w);
+            }
+          }
+        *reinterpret_cast<float4*>(dst + ((cplane * OH + (py >> 1)) * OW + (px >> 1)) * 8 + chalf) = best;
+      }
+  }
+}
+
+// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (channel group)][64 (lane)][76]: element (cb, ct, cg, lane = kk * 16 + i,
+// e = 36 * g + n) = (G g G^T)[row][column] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 + 2 * kk + g), n = 6 * column + row
+// (the order in which a pass multiplies the positions), evaluated in double and rounded once; the 4 pad floats are 0.
+__global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+  const double G[6][3] = {{0.25, 0.0, 0.0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const int ncot = Cout >> 5;
+  const long items = (long)(Cin >> 3) * ncot * 2 * 64 * 2;        // (cb, ct, cg, lane, g)
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(it & 1);
+    const long r = it >> 1;
+    const int lane = (int)(r & 63), cgi = (int)((r >> 6) & 1);
+    const long tt = r >> 7;
+    const int ct = (int)(tt % ncot), cb = (int)(tt / ncot);
+    const int kk = lane >> 4, i = lane & 15;
+    const int co = ct * 32 + cgi * 16 + i, ci = cb * 8 + 2 * kk + g;
+    const float* f = w + ((long)co * Cin + ci) * 9;
+    double tmp[6][3];                                             // G g
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) tmp[a][b] = G[a][0] * (double)f[b] + G[a][1] * (double)f[3 + b] + G[a][2] * (double)f[6 + b];
+    float* dst = out + r * kF4LanePitch;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b)                                 // (G g) G^T
+        dst[g * 36 + b * 6 + a] = (float)(tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2]);   // n = 6 column + row
+    if (g == 0) { dst[72] = 0.f; dst[73] = 0.f; dst[74] = 0.f; dst[75] = 0.f; }
+  }
+}
+
+// Finishes the pixel tiles [pix0, pix0 + npix) whose K was cut into `s` ranges: out = act(sum_k part[k] + bias) over the tile's
+// 16 x 64 pixels (clipped to the image), all channels; POOL: followed by the Pooling MAX 2x2/2 the unsplit tiles apply in their
+// epilogue (ReLU first, then the maximum over the window's in-image pixels).  One thread per 4 channels of a pixel (window).
+template <int POOL>
+__global__ __launch_bounds__(256) void wino4_section_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                   float* __restrict__ out, int H, int W, int Cout, int s, int relu,
+                                                                   int pix0, int npix, int tiles_x) {
+  constexpr int rows = POOL ? kF4Rows / 2 : kF4Rows, cols = POOL ? kF4Cols / 2 : kF4Cols;
+  const int per_tile = (Cout >> 3) * rows * cols * 2;
+  const long plane = (long)Cout * H * W;
+  const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)npix * per_tile; i += (long)gridDim.x * blockDim.x) {
+    const int tl = (int)(i / per_tile);
+    int r = (int)(i - (long)tl * per_tile);
+    const int half = r & 1; r >>= 1;
+    const int col = r % cols; r /= cols;
+    const int row = r % rows;
+    const int cb = r / rows;
+    const int pix = pix0 + tl, bx = pix % tiles_x, by = pix / tiles_x;
+    const int y0 = by * kF4Rows + (POOL ? 2 * row : row), x0 = bx * kF4Cols + (POOL ? 2 * col : col);
+    if (y0 >= H || x0 >= W) continue;
+    const float4 b = *reinterpret_cast<const float4*>(bias + cb * 8 + half * 4);
+    float4 best = make_float4(-3.402823466e38f, -3.402823466e38f, -3.402823466e38f, -3.402823466e38f);
+#pragma unroll
+    for (int dy = 0; dy < (POOL ? 2 : 1); ++dy)
+#pragma unroll
+      for (int dx = 0; dx < (POOL ? 2 : 1); ++dx) {
+        const int yy = y0 + dy, xx = x0 + dx;
+        if (yy >= H || xx >= W) continue;
+        const long e = (((long)cb * H + yy) * W + xx) * 8 + half * 4;
+        float4 v = *reinterpret_cast<const float4*>(part + e);
+        for (int kq = 1; kq < s; ++kq) {
+          const float4 q = *reinterpret_cast<const float4*>(part + kq * plane + e);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (POOL) {
+          best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+        } else {
+          *reinterpret_cast<float4*>(out + e) = v;
+        }
+      }
+    if (POOL) *reinterpret_cast<float4*>(out + (((long)cb * OH + (y0 >> 1)) * OW + (x0 >> 1)) * 8 + half * 4) = best;
+  }
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+// Plan of one layer: how many pixel tiles run whole (section A, ksplit_a ranges each) and into how many K ranges the others are cut.
+// The chip holds `slots` = 256 workgroups at a time (one per CU: 154 KB of LDS).  Full rounds run unsplit; the tiles of a last,
+// partly filled round are cut into as many K ranges (of >= 4 blocks) as fill that round once.  A layer that does not fill one
+// round at all (conv4_x: 160 workgroups, conv5_x / rpn_conv: 48) is cut uniformly.
+static void wino4_plan(int pix, int ncot, int blocks, int* pix_a, int* ksplit_a, int* ksplit_b) {
+  const int slots = 256, min_blocks = 4;
+  *pix_a = pix; *ksplit_a = 1; *ksplit_b = 1;
+  const long wgs = (long)pix * ncot;
+  const int smax = blocks / min_blocks > 1 ? blocks / min_blocks : 1;
+  if (wgs <= slots) {
+    // uniform cut: the range count whose rounds x range length is smallest; a range of `per` blocks costs `per`, every extra range a
+    // pass over its partial outputs (~1.5 blocks' worth at these sizes)
+    int best = 1;
+    double best_cost = 1e300;
+    for (int s = 1; s <= smax && s <= 8; ++s) {
+      const int per = (blocks + s - 1) / s;
+      const double cost = (double)((wgs * s + slots - 1) / slots) * per + (s > 1 ? 1.5 * s : 0.0);
+      if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    *ksplit_a = best;
+    return;
+  }
+  const int full_pix = (int)(wgs / slots) * slots / ncot;        // pixel tiles of the full rounds
+  const int rest = (pix - full_pix) * ncot;
+  if (rest > 0 && rest <= slots * 3 / 4) {
+    int sb = slots / rest;
+    if (sb > smax) sb = smax;
+    if (sb > 8) sb = 8;
+    if (sb >= 2) { *pix_a = full_pix; *ksplit_b = sb; }
+  }
+}
+
+static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                      int Cout, int relu, int pool) {
+  MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3_wino4: null pointer");
+  MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_conv3x3_wino4: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin, Cout);
+  MNC_REQUIRE((double)H * W * 8.0 < 2147483648.0, "mnc_conv3x3_wino4: map %dx%d too large for 32-bit pixel offsets", H, W);
+  const int ncot = Cout >> 5, blocks = Cin >> 3;
+  const int tiles_x = cdiv(W, kF4Cols), pix = tiles_x * cdiv(H, kF4Rows);
+  int pix_a, ksplit_a, ksplit_b;
+  wino4_plan(pix, ncot, blocks, &pix_a, &ksplit_a, &ksplit_b);
+  if (tune_set(ctx, T_CONV_KSPLIT)) {                            // uniform K ranges (tests, A/B)
+    const int v = tune(ctx, T_CONV_KSPLIT, 1);
+    if (v >= 1 && v <= 8 && v <= blocks) { pix_a = pix; ksplit_a = v; ksplit_b = 1; }
+  } else if (tune(ctx, T_WINO_TAIL, 1) == 0) {
+    if (pix_a < pix) { pix_a = pix; ksplit_b = 1; }
+  }
+  float* part = nullptr;
+  const int smax = ksplit_a > ksplit_b ? ksplit_a : ksplit_b;
+  if (smax > 1) {
+    int rc = ensure_scratch(ctx, (size_t)smax * Cout * H * W * 4);
+    if (rc) return rc;
+    part = (float*)ctx->scratch;
+  }
+  const double flops = 2.0 * H * W * 9.0 * Cin * Cout;           // ALGORITHMIC work of the convolution (direct form)
+  const double out_px = pool ? (double)((H + 1) / 2) * ((W + 1) / 2) : (double)H * W;
+  const double bytes = 4.0 * ((double)H * W * Cin + out_px * Cout + 9.0 * Cin * Cout);
+  LaunchScope ls(ctx, "conv3x3_wino4_mfma", flops, bytes);
+  // XCD-aware order where the channel tiles' shared halo dominates the traffic; for the 512-channel layers the transformed weights
+  // (Cin x Cout x 38 floats) dominate and every XCD would stream all of them: plain order (as conv_wino.hip measured)
+  const bool plain = tune_set(ctx, T_WINO_XCD) ? tune(ctx, T_WINO_XCD, 1) == 0 : Cout > 256;
+  auto kern = plain ? conv3x3_wino4_kernel<0> : conv3x3_wino4_kernel<1>;
+#ifdef MNC_TUNING
+  switch (tune(ctx, T_WINO_F4, 0)) {
+#define MNC_F4_ABL(A) case A: kern = conv3x3_wino4_kernel<1, A>; break;
+    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31)
+#undef MNC_F4_ABL
+    default: break;
+  }
+#endif
+  static std::atomic<unsigned long long> attr_set[2] = {{0}, {0}};      // one bit per device: function attributes are per device
+  const unsigned long long bit = 1ull << (ctx->device & 63);
+#ifdef MNC_TUNING
+  MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kF4LdsBytes));
+#else
+  if (!(attr_set[plain ? 0 : 1].load(std::memory_order_relaxed) & bit)) {
+    MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kF4LdsBytes));
+    attr_set[plain ? 0 : 1].fetch_or(bit, std::memory_order_relaxed);
+  }
+#endif
+  const long nblocks = ((long)pix_a * ksplit_a + (long)(pix - pix_a) * ksplit_b) * ncot;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), kF4LdsBytes, ctx->stream, d_in, d_wpk, d_bias, d_out, part, H, W,
+                     Cin, Cout, relu, pool, tiles_x, pix_a, ksplit_a, ksplit_b);
+  auto grid_for = [](long n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); };
+  auto reduce = [&](int s, int pix0, int npix) {
+    const long items = (long)npix * (Cout >> 3) * kF4Rows * kF4Cols * 2 / (pool ? 4 : 1);
+    if (pool)
+      hipLaunchKernelGGL(wino4_section_reduce_kernel<1>, dim3(grid_for(items)), dim3(256), 0, ctx->stream, part, d_bias, d_out, H, W,
+                         Cout, s, relu, pix0, npix, tiles_x);
+    else
+      hipLaunchKernelGGL(wino4_section_reduce_kernel<0>, dim3(grid_for(items)), dim3(256), 0, ctx->stream, part, d_bias, d_out, H, W,
+                         Cout, s, relu, pix0, npix, tiles_x);
+  };
+  if (ksplit_a > 1 && pix_a > 0) reduce(ksplit_a, 0, pix_a);
+  if (ksplit_b > 1 && pix_a < pix) reduce(ksplit_b, pix_a, pix - pix_a);
+  return ls.finish("conv3x3_wino4_kernel");
+}
+
+extern "C" {
+
+int mnc_pack_conv3x3_wino4(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_pack_conv3x3_wino4: bad argument (Cin%%8==0, Cout%%32==0)");
+  LaunchScope ls(ctx, "pack_conv3x3_wino4");
+  const long items = (long)(Cin >> 3) * (Cout >> 5) * 2 * 64 * 2;
+  long g = (items + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(pack_conv3x3_wino4_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_oihw, d_packed, Cout, Cin);
+  return ls.finish("pack_conv3x3_wino4_kernel");
+}
+
+int mnc_conv3x3_wino4(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                      int Cout, int relu) {
+  return wino4_impl(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, 0);
+}
+
+int mnc_conv3x3_wino4_pool(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const float* d_bias, float* d_out_pooled, int H,
+                           int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(H >= 2 && W >= 2, "mnc_conv3x3_wino4_pool: map %dx%d too small for MAX 2x2/2", H, W);
+  return wino4_impl(ctx, d_in, d_wpk, d_bias, d_out_pooled, H, W, Cin, Cout, relu, 1);
+}
+
+}  // extern "C"

@@ -136,6 +136,56 @@ def test_conv3x3_winograd(dev, monkeypatch, H, W, Cin, Cout, relu, tune):
             assert np.array_equal(pooled, ref), (rows, ks, var)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (5, 3, 8, 32), (38, 63, 128, 64), (75, 125, 256, 512),
+                                                        (37, 63, 256, 512), (150, 250, 64, 256), (300, 500, 64, 128)])
+@pytest.mark.parametrize("relu", [1, 0])
+def test_conv3x3_winograd_f4(dev, H, W, Cin, Cout, relu, tune):
+    """mnc_conv3x3_wino4 (Winograd F(4x4,3x3) fused on the fp32 matrix pipe, csrc/conv_wino4.hip) against torch fp32: odd heights /
+    widths (partial 4x4 tiles, partial 16x64 workgroup tiles, maps smaller than one tile), one and several channel tiles, the
+    launcher's plans -- unsplit, uniform K ranges (maps that do not fill the chip: (75,125,256,512) three ranges, (37,63,256,512)
+    five uneven ones), the tail plan ((150,250,64,256): 32 whole tiles + 8 tiles in two ranges; (300,500,64,128)) -- and forced
+    uniform cuts; both block orders.  The bar is the fp32 kernels' 1e-4 of the output range (F(4x4)'s transforms multiply by up to
+    8 and 1/24: measured ~1e-5 at 256 input channels, printed).  With the fused Pooling the result is exactly the maximum over the
+    un-fused kernel's own outputs under the same plan."""
+    rng = np.random.default_rng(H * 1000 + W + Cin + Cout)
+    x = rng.normal(0, 1, (Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(0, 0.1, Cout).astype(np.float32)
+    want = _conv_ref(x, w, b, bool(relu))
+    d_x, d_b = dev.put(to_c8(x)), dev.put(b)
+    d_w = dev.empty((Cin * Cout * 38,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_wino4", dev.put(w), d_w, Cout, Cin)
+    packed = dev.get(d_w, (Cin // 8, Cout // 32, 2, 64, 76))
+    assert not np.isnan(packed).any() and np.all(packed[..., 72:] == 0)
+    d_y = dev.empty((Cout, H, W), fill=-7.0)
+    worst = 0.0
+    for ks, tail, xcd in ((None, None, None), ("1", None, None), ("2", None, "0"), ("3", None, "1"), (None, "0", None)):
+        if ks is not None and int(ks) > Cin // 8:
+            continue
+        for k in ("CONV_KSPLIT", "WINO_TAIL", "WINO_XCD"):
+            dev.tune(k, None)
+        if ks is not None:
+            tune("CONV_KSPLIT", ks)
+        if tail is not None:
+            tune("WINO_TAIL", tail)
+        if xcd is not None:
+            tune("WINO_XCD", xcd)
+        dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
+        dev.call("mnc_conv3x3_wino4", d_x, d_w, d_b, d_y, H, W, Cin, Cout, relu)
+        got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+        rel = err(got, want)[1]
+        worst = max(worst, rel)
+        assert rel < 1e-4, (ks, tail, xcd, err(got, want))
+        if H >= 2 and W >= 2:
+            OH, OW = (H + 1) // 2, (W + 1) // 2
+            d_p = dev.empty((Cout, OH, OW), fill=-7.0)
+            dev.call("mnc_conv3x3_wino4_pool", d_x, d_w, d_b, d_p, H, W, Cin, Cout, relu)
+            pooled = from_c8(dev.get(d_p, (Cout * OH * OW,)), Cout, OH, OW)
+            ref = F.max_pool2d(torch.from_numpy(got)[None], 2, 2, ceil_mode=True)[0].numpy()
+            assert np.array_equal(pooled, ref), (ks, tail, xcd)
+    print("conv3x3 F(4x4) %dx%d %d->%d relu=%d: max rel err %.2e" % (H, W, Cin, Cout, relu, worst))
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):

@@ -4,6 +4,7 @@
     python tools/kernel_bench.py conv [--reps 20]      the 13 conv3x3 shapes of the VGG-16 trunk at 600x1000
     python tools/kernel_bench.py convx3                the same on the bf16x3 kernel (MNC_CONVX3_TILE=CT,PR overrides the tile)
     python tools/kernel_bench.py convwino              the same on the Winograd F(2x2,3x3) fp32 kernel (MNC_WINO_ROWS=1|2|4)
+    python tools/kernel_bench.py convwino4             the same on the fused Winograd F(4x4,3x3) fp32 kernel (csrc/conv_wino4.hip)
     python tools/kernel_bench.py fc   [--reps 20]      the FC shapes of one head stage at 300 RoIs
     python tools/kernel_bench.py fcx3                  the same on the bf16x3 kernel
     python tools/kernel_bench.py conv1x1 [--f16]       the 1x1 convolutions of the ResNet-50 C4 trunk at 800x1333: the GEMM kernel
@@ -51,7 +52,7 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "fc", "fcx3", "fcf16", "conv1x1"])
+    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "convwino4", "fc", "fcx3", "fcf16", "conv1x1"])
     ap.add_argument("--f16", action="store_true", help="conv1x1: packed fp16 tensors (mnc_conv1x1_f16_pk) instead of fp32")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
@@ -121,7 +122,7 @@ def main():
             print("all 1x1 layers of the trunk (%s): gemm %.3f ms = %.1f TF/s, %.2f TB/s algorithmic | general %.3f ms = %.1f TF/s"
                   % ("f16, packed tensors" if args.f16 else "fp32", tot_new, tot_fl / tot_new / 1e9, tot_by / tot_new / 1e9,
                      tot_old, tot_fl / tot_old / 1e9))
-    elif args.what in ("conv", "convx3", "convf16", "convwino"):
+    elif args.what in ("conv", "convx3", "convf16", "convwino", "convwino4"):
         for name, H, W, Cin, Cout in CONV:
             if args.only and args.only not in name:
                 continue
@@ -143,6 +144,11 @@ def main():
                 w = dev.empty((Cin * Cout * 17,))
                 dev.call("mnc_pack_conv3x3_wino", raw, w, Cout, Cin)
                 fn = "mnc_conv3x3_wino"
+            elif args.what == "convwino4":
+                raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
+                w = dev.empty((Cin * Cout * 38,))
+                dev.call("mnc_pack_conv3x3_wino4", raw, w, Cout, Cin)
+                fn = "mnc_conv3x3_wino4"
             else:
                 w = dev.put((rng.normal(size=((Cin // 8) * Cout * 76,)) * 0.05).astype(np.float32))
             for _ in range(3):
