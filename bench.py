@@ -349,7 +349,12 @@ def main():
             fence()
             records = net.profile_records()
             net.profile(False)
-        out = {"elapsed": elapsed, "phase_ms": phase_ms, "records": records,
+        try:                                             # device memory in use on this rank's GPU with every net of the run alive
+            fr, tot = _lib.device_mem_info(dev_id)
+            mem_gb = (tot - fr) / 1e9
+        except Exception:  # noqa: BLE001
+            mem_gb = None
+        out = {"elapsed": elapsed, "phase_ms": phase_ms, "records": records, "device_mem_gb": mem_gb,
                "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None), "in_flight": inflight,
                "gather_transport": transport}
         for nn in nets[1:]:
@@ -452,7 +457,8 @@ def main():
     elapsed = m["elapsed"]
     # every rank's own clock next to the max-over-ranks one: a straggler shows up as one large ms_per_step
     ranks = [{"rank": rank, "device": dev_id, "host": socket.gethostname(), "ms_per_step": 1e3 * elapsed / args.steps,
-              "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}]
+              "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+              "device_mem_gb": m.get("device_mem_gb")}]
     if launched:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -742,12 +748,12 @@ def roofline_by_kernel(records, steps):
             peak, basis = mfma_peak(name)
             e.update(bound="mfma", achieved=fl / avg_s / 1e12, peak=peak, unit="TFLOP/s", frac=fl / avg_s / 1e12 / peak,
                      peak_basis=basis)
-            if "wino" in name:          # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
-                ex = fl / 2.25
+            if "wino" in name:          # F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36; F(4x4,3x3): 36 per 4x4 instead of 144
+                ex = fl / wino_factor(name)
                 e.update(executed_gflop_per_launch=ex / 1e9, executed_tflops=ex / avg_s / 1e12,
                          executed_frac_of_peak=ex / avg_s / 1e12 / peak,
                          note="frac = algorithmic (direct-form) flop / time / peak, can exceed what the pipe executes; "
-                              "executed_* = the MFMA work Winograd F(2x2,3x3) actually issues (algorithmic / 2.25)")
+                              "executed_* = the MFMA work Winograd actually issues (algorithmic / %.4g)" % wino_factor(name))
             e["hbm_frac_algorithmic"] = hbm_frac
         else:
             e.update(bound="hbm", achieved=by / avg_s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
@@ -773,7 +779,7 @@ def roofline_by_kernel(records, steps):
                "algorithmic_gflop_per_image": fl, "algorithmic_mb_per_image": mb, "bound": "mfma", "achieved": fl / ms, "peak": peak,
                "unit": "TFLOP/s", "frac": fl / ms / peak, "peak_basis": basis}
         if "wino" in scope:
-            agg.update(executed_tflops=fl / 2.25 / ms, executed_frac_of_peak=fl / 2.25 / ms / peak)
+            agg.update(executed_tflops=fl / wino_factor(scope) / ms, executed_frac_of_peak=fl / wino_factor(scope) / ms / peak)
         t, src = pmc_traffic(scope)
         agg["traffic_source"] = src
         if t is not None:
@@ -784,7 +790,7 @@ def roofline_by_kernel(records, steps):
 
 
 # profiling scope of the engine -> the kernels (rocprofv3 names, regular expressions) launched inside it
-PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"conv3x3_wino2?_kernel",
+PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"conv3x3_wino2?_kernel", "conv3x3_wino4_mfma": r"conv3x3_wino4_kernel",
               "fc_mfma": r"fc_mfma_(dma(16)?_)?kernel<(10|5)[,>]", "fc_mfma_small": r"fc_mfma_kernel<2,", "conv3x3_c3": r"conv3x3_c3_kernel",
               "conv3x3_bf16x3": r"conv3x3_x3_kernel<\d+, \d+, \d+, 0,", "conv3x3_f16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 1,",
               "fc_bf16x3": r"fc_x3_kernel<\d+, \d+, \d+, 0>", "fc_f16": r"fc_x3_kernel<\d+, \d+, \d+, 1>"}
@@ -795,6 +801,11 @@ FC_SHAPES = {("fc_mfma", 15.41): "fc6_maskest (300 x 256 x 100352)", ("fc_mfma",
              ("fc_mfma", 10.07): "fc7 / fc7_mask (300 x 4096 x 4096)"}
 FC_POSITIONS = {"fc6_maskest (300 x 256 x 100352)": (0, 5), "fc6 / fc6_mask (300 x 4096 x 25088)": (1, 3, 6, 8),
                 "fc7 / fc7_mask (300 x 4096 x 4096)": (2, 4, 7, 9)}
+
+
+def wino_factor(scope_name):
+    """direct-form multiplies / Winograd multiplies: F(4x4,3x3) 144 / 36, F(2x2,3x3) 36 / 16"""
+    return 4.0 if "wino4" in scope_name else 2.25
 
 
 def mfma_peak(scope_name):

@@ -39,6 +39,9 @@ enum {
 /* Thread-local, never NULL; "" when the last call on this thread succeeded. */
 MNC_API const char* mnc_last_error(void);
 MNC_API int mnc_device_count(int* count);
+/* Free and total bytes of device `device_id` (hipMemGetInfo): what a host that keeps several nets per GPU checks its budget with
+ * (bench.py prints total - free per rank: four images in flight x 1.1 GB of replicated weights + activations). */
+MNC_API int mnc_device_mem_info(int device_id, size_t* free_bytes, size_t* total_bytes);
 MNC_API const char* mnc_version(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -265,9 +268,9 @@ MNC_API int mnc_conv3x3_wino_pool(mnc_ctx* ctx, const float* d_in_c8, const floa
 /* The same convolution by Winograd's F(4x4, 3x3) (round 4; mnc_amd/csrc/conv_wino4.hip): 36 multiplies per (input channel, output
  * channel, 4x4 output tile) = 2.25 per output against F(2x2)'s 4 and the direct form's 9.  Fused: input transform, the 36 channel
  * contractions (v_mfma_f32_16x16x4_f32) and the output transform run in one kernel, one wave holding all 36 positions of its
- * 16 channels x 16 tiles.  The transforms carry the coefficients 2, 4, 5, 8 and 1/6, 1/12, 1/24 (filter side, evaluated in double,
+ * 16 channels x 16 tiles; four-wave workgroups with half of a CU's LDS each, two per CU.  The transforms carry the coefficients 2, 4, 5, 8 and 1/6, 1/12, 1/24 (filter side, evaluated in double,
  * rounded once): rounding error ~1e-5 of the output range at 512 input channels (F(2x2): ~1e-6; both inside the kernels' 1e-4
- * bar).  d_w_packed from mnc_pack_conv3x3_wino4: Caffe [Cout][Cin][3][3] -> [Cin/8][Cout/32][2][64][76] floats (Cin*Cout*38 floats).
+ * bar).  d_w_packed from mnc_pack_conv3x3_wino4: Caffe [Cout][Cin][3][3] -> [Cin/8][Cout/32][2][2][64][36] floats (Cin*Cout*36 floats).
  * Cin%8==0, Cout%32==0, H*W*8 < 2^31.  _pool: the following Pooling MAX 2x2/2 in the epilogue (a 4x4 tile is four windows). */
 MNC_API int mnc_pack_conv3x3_wino4(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_wino4(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias, float* d_out_c8,
@@ -537,7 +540,8 @@ typedef struct mnc_net_config {
   float vote_nms_thresh, vote_iou_thresh;   /* TEST.MASK_MERGE_NMS_THRESH 0.3, TEST.MASK_MERGE_IOU_THRESH 0.5 */
   int math;                /* 0 fp32, 1 bf16x3, 2 f16 (the engine's math modes) */
   int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
-  int winograd;            /* fp32 math: 1 = 3x3 convolutions by Winograd F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */
+  int winograd;            /* fp32 math, the 3x3 convolutions: 4 = Winograd F(4x4,3x3) (mnc_conv3x3_wino4; default), 2 (or 1) =
+                            * F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */
   mnc_layer_conventions conventions;   /* ROIWarping / MaskResize / MaskPooling conventions; all zero = oracle/SPEC.md.  The RoI
                                         * kernels read them from the CONTEXT: mnc_net_create applies this member to `ctx` only when
                                         * it differs from the all-zero default, so conventions a host set on the context with

@@ -97,3 +97,10 @@ def device_count():
     n = ctypes.c_int(0)
     call("mnc_device_count", ctypes.addressof(n))
     return n.value
+
+
+def device_mem_info(device_id=0):
+    """-> (free bytes, total bytes) of a device."""
+    fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    call("mnc_device_mem_info", int(device_id), ctypes.addressof(fr), ctypes.addressof(tot))
+    return fr.value, tot.value

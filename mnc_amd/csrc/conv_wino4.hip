@@ -42,19 +42,23 @@ namespace mnc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kF4Rows = 16;                          // output rows per workgroup (4 tile rows)
+constexpr int kF4Rows = 8;                           // output rows per workgroup (2 tile rows)
 constexpr int kF4Cols = 64;                          // output columns per workgroup (16 tiles)
 constexpr int kF4HaloRows = kF4Rows + 2;
 constexpr int kF4RowSlots = 68;                      // pixel slots per halo row: 4 residues x 17 (66 used)
 constexpr int kF4RowBytes = kF4RowSlots * 32;        // 2176
-constexpr int kF4HaloPieces = 40;                    // 18 x 2176 = 39168 bytes -> 40 DMA pieces of 1 KB (5 per wave; the tail is zero page)
-constexpr int kF4LanePitch = 76;                     // floats per lane of a weight panel (72 + 4 pad)
-constexpr int kF4PanelFloats = 2 * 64 * kF4LanePitch;            // per (channel block, 32-channel tile): 9728 floats
-constexpr int kF4PanelPieces = kF4PanelFloats * 4 / 1024;        // 38
-constexpr int kF4PanelBytes = kF4PanelFloats * 4;                // 38912
-constexpr int kF4LdsBytes = 2 * (kF4PanelBytes + kF4HaloPieces * 1024);     // two weight panels + two halo images: 159744
-static_assert(kF4PanelPieces * 1024 == kF4PanelBytes, "whole DMA pieces per weight panel");
-static_assert(kF4LdsBytes <= 160 * 1024, "conv3x3_wino4: LDS budget");
+constexpr int kF4HaloPieces = 22;                    // 10 x 2176 = 21760 bytes -> 22 DMA pieces of 1 KB
+constexpr int kF4HaloBytes = kF4HaloPieces * 1024;   // 22528
+constexpr int kF4LanePitch = 36;                     // floats per lane of a HALF panel: the 36 positions of one channel (144 B = 9 x 16 B)
+constexpr int kF4HalfFloats = 2 * 64 * kF4LanePitch;             // half panel [channel group][lane][36]: 4608 floats
+constexpr int kF4HalfBytes = kF4HalfFloats * 4;                  // 18432
+constexpr int kF4HalfPieces = kF4HalfBytes / 1024;               // 18
+constexpr int kF4PanelFloats = 2 * kF4HalfFloats;                // per (channel block, 32-channel tile): [g][cg][lane][36] = 9216 floats
+constexpr int kF4PanelBytes = kF4PanelFloats * 4;                // 36864
+constexpr int kF4LdsBytes = 2 * kF4HalfBytes + 2 * kF4HaloBytes; // the two half panels + two halo images: 81920 = half a CU's LDS
+static_assert(kF4HalfPieces * 1024 == kF4HalfBytes, "whole DMA pieces per half panel");
+static_assert(kF4HaloBytes >= kF4HaloRows * kF4RowBytes, "halo image fits its pieces");
+static_assert(2 * kF4LdsBytes <= 160 * 1024, "conv3x3_wino4: two workgroups per CU");
 
 // One dimension of the input transform, in place: x = B^T d (12 fma / add for 6 values).
 __device__ __forceinline__ void f4_bt(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
@@ -88,14 +92,14 @@ __device__ __forceinline__ void f4_at(float m0, float m1, float m2, float m3, fl
 // ABL (tuning builds only, wrong results): 1 no DMA inside the loop, 2 no halo reads (opaque register constants), 4 no input
 // transform, 8 no weight-fragment reads, 16 no wait / barrier -- what each part of a block costs (kernel_bench convwino4, MNC_WINO_F4).
 template <int XCD, int ABL = 0>
-__global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
+__global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             float* __restrict__ part, int H, int W, int Cin, int Cout, int relu,
                                                             int pool_a, int tiles_x, int pix_a, int ksplit_a, int ksplit_b) {
   extern __shared__ __attribute__((aligned(1024))) char s_f4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave & 1, tg = wave >> 1;
+  const int cg = wave & 1, tg = wave >> 1;                        // 4 waves: channel group x tile row
   const int t = lane & 15, k = lane >> 4;
   const int ncot = Cout >> 5;
   int bx, by, cot, split, ksplit;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   // The offsets are rebuilt from (wave, lane) at every copy (a dozen integer operations per piece) instead of living in five
   // registers through the loop: the loop has none to spare.
   auto halo_off = [&](int i) {
-    const int q = 32 * (wave + 8 * i) + (lane >> 1);
+    const int q = 32 * min(wave + 4 * i, kF4HaloPieces - 1) + (lane >> 1);       // (the waves without a sixth piece repeat piece 21)
     const int row = q / kF4RowSlots, sl = q - row * kF4RowSlots;
     const int a = sl / 17, b = sl - a * 17;
     const int xh = 4 * b + a;
@@ -154,20 +158,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   const i32x4 w_rsrc = make_rsrc(wpk, (long)nblk * ncot * kF4PanelBytes);
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_f4;
   const int w_voff = lane * 16;
-  // LDS: weight panels [2] then halo images [2]
-  constexpr int kUBuf = kF4PanelBytes, kHBuf = kF4HaloPieces * 1024, kHalo0 = 2 * kF4PanelBytes;
+  // LDS: half panel of channel g at g * kF4HalfBytes, then the two halo images
+  constexpr int kHalo0 = 2 * kF4HalfBytes;
   // A copy for a block past the end of this workgroup's K range is still ISSUED, with every lane out of range (no memory traffic,
   // zeros into the free buffer): the loop body stays one basic block with a fixed copy count per barrier -- with branches around
   // the copies hipcc sinks the transform arithmetic of a pass into the blocks behind them, where no MFMA covers it.
-  auto dma_u = [&](int c, int ubuf) {                              // weight panel of block c -> panel buffer `ubuf` (0 / 1)
+  auto dma_u = [&](int c, int g) {                                 // half panel (channel g) of block c -> its buffer
     const int voff = c < nchunks ? w_voff : 0x7FFFFFF0;
     const int cb = chunk0 + min(c, nchunks - 1);
-    const int wsoff = __builtin_amdgcn_readfirstlane((cb * ncot + cot) * kF4PanelBytes);
+    const int wsoff = __builtin_amdgcn_readfirstlane((cb * ncot + cot) * kF4PanelBytes + g * kF4HalfBytes);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      // branch-free: waves 6 and 7 have no fifth panel piece and copy pieces 36 / 37 a second time (same bytes, same place)
-      const int p = min(wave + 8 * i, kF4PanelPieces - 1);
-      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(ubuf * kUBuf) + (unsigned)p * 1024u);
+      // branch-free: the waves without a fifth piece copy pieces 16 / 17 a second time (same bytes, same place)
+      const int p = min(wave + 4 * i, kF4HalfPieces - 1);
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(g * kF4HalfBytes) + (unsigned)p * 1024u);
       const int so = __builtin_amdgcn_readfirstlane(wsoff + p * 1024);
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(w_rsrc), "s"(so), "s"(l) : "memory");
     }
@@ -177,10 +181,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
     const int cb = chunk0 + min(c, nchunks - 1);
     const int hsoff = __builtin_amdgcn_readfirstlane(cb * (int)(plane * 4));
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int p = wave + 8 * i;
+    for (int i = 0; i < 6; ++i) {
+      const int p = min(wave + 4 * i, kF4HaloPieces - 1);
       const int ho = live ? halo_off(i) : 0x7FFFFFF0;
-      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kHalo0 + hbuf * kHBuf) + (unsigned)p * 1024u);
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kHalo0 + hbuf * kF4HaloBytes) + (unsigned)p * 1024u);
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(ho), "s"(in_rsrc), "s"(hsoff), "s"(l) : "memory");
     }
   };
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   f32x4 acc[36];
 #pragma unroll
   for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // The accumulators stay in architectural registers: a 512-thread workgroup leaves a wave 256 registers, and once a function
-  // touches AGPRs hipcc splits that budget 128 / 128 (gemm_x3.hip).
+  // The accumulators stay in architectural registers: two 256-thread workgroups per CU leave a wave 256 registers, and once a
+  // function touches AGPRs hipcc splits that budget 128 / 128 (gemm_x3.hip).
   auto pin_acc = [&]() {
 #pragma unroll
     for (int p = 0; p < 36; ++p) asm volatile("" : "+v"(acc[p]));
@@ -208,16 +212,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   const int ub = (cg * 64 + lane) * (kF4LanePitch * 4);
 
   // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 2k + g of block s: 36 MFMAs from the
-  // transformed values of that channel and the 36 weights [g][n] of the lane's panel row, n = the order of use (position (i, j) =
-  // row i, column j of the 6x6 transform is n = 6 j + i: column by column).  WHILE it runs, the wave builds the operand of the next
-  // pass in the registers the previous pass has just freed: pass (s, 0) builds channel 2k + 1 of block s, pass (s, 1) channel 2k
-  // of block s + 1.  Column j of a pass: six reads of window row j for the next operand -> the six MFMAs of column j of the current
-  // one -> the second transform dimension of ITS column j + 1 (12 fma, in place) and the first dimension of the row just read
-  // (12 fma), both under those MFMAs.  The two buffers of each kind turn over half a block apart: block s's halo is last read in pass (s, 0), its panel
-  // in pass (s, 1); each is refilled right behind the barrier that ends its last reading pass and has a whole block to land.
+  // transformed values of that channel and the lane's 36 weights of half panel g, in the order of use n = 6 j + i (position (i, j) =
+  // row i, column j of the 6x6 transform: column by column).  WHILE it runs, the wave builds the operand of the next pass in the
+  // registers the previous pass has just freed: pass (s, 0) builds channel 2k + 1 of block s, pass (s, 1) channel 2k of block
+  // s + 1.  Column j of a pass: six reads of window row j for the next operand -> the six MFMAs of column j of the current one ->
+  // the second transform dimension of ITS column j + 1 (12 fma, in place) and the first dimension of the row just read (12 fma),
+  // both under those MFMAs.  Buffers: half panel g is read by pass (s, g) only and refilled (block s + 1) right behind the barrier
+  // that ends that pass -- half a block to land 18 KB; halo s is read by passes (s - 1, 1) and (s, 0), its buffer refilled (block
+  // s + 2) behind the barrier in the middle of block s -- a whole block to land.
   float va[36], vb[36];
   auto read_row = [&](int hbuf, int r, int g, float (&x)[36]) {
-    const lds_cp sh = lds + hbuf * kHBuf + r * kF4RowBytes;
+    const lds_cp sh = lds + hbuf * kF4HaloBytes + r * kF4RowBytes;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       if (ABL & 2) {
@@ -238,8 +243,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
     if (!(ABL & 4)) f4_bt(x[j], x[6 + j], x[12 + j], x[18 + j], x[24 + j], x[30 + j]);
   };
   f32x4 uq[9];
-  auto mfma_col = [&](int ubuf, int g, int j, const float (&x)[36]) {
-    const lds_cp su = lds + ubuf * kUBuf + ub + g * 144;
+  auto mfma_col = [&](int g, int j, const float (&x)[36]) {
+    const lds_cp su = lds + g * kF4HalfBytes + ub;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int n = 6 * j + i;
@@ -256,11 +261,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   };
   // (on entry column 0 of `cur` has its second dimension already -- the previous pass did it under its last MFMAs, so that a pass
   // opens with MFMAs whose operands are in registers)
-  auto pass = [&](int ubuf, int g, float (&cur)[36], int hbuf_next, int g_next, float (&nxt)[36]) {
+  auto pass = [&](int g, float (&cur)[36], int hbuf_next, int g_next, float (&nxt)[36]) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       read_row(hbuf_next, j, g_next, nxt);
-      mfma_col(ubuf, g, j, cur);
+      mfma_col(g, j, cur);
       if (j < 5) ypass_col(cur, j + 1);
       xpass_row(nxt, j);
       if (j == 5) ypass_col(nxt, 0);
@@ -273,9 +278,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   if (nchunks > 0) {
     dma_u(0, 0);
     dma_h(0, 0);
+    dma_u(0, 1);
     dma_h(1, 1);
-    dma_u(1, 1);
-    MNC_F4_SYNC(10);                                 // block 0 has landed; block 1's ten pieces may still fly
+    MNC_F4_SYNC(11);                                 // half panel 0 and halo 0 of block 0 have landed; 5 + 6 pieces may still fly
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       read_row(0, r, 0, va);
@@ -284,16 +289,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
     ypass_col(va, 0);
     for (int s = 0; s < nchunks; ++s) {
       const int bsel = s & 1;
-      pass(bsel, 0, va, bsel, 1, vb);
+      pass(0, va, bsel, 1, vb);
       pin_acc();
-      // middle of block s: every wave is done with halo s; halo s + 1 (requested a block ago) has landed, panel s + 1 may still fly
-      if (!(ABL & 16)) MNC_F4_SYNC(5);
-      if (!(ABL & 1)) dma_h(s + 2, bsel);
-      pass(bsel, 1, vb, bsel ^ 1, 0, va);
+      // middle of block s: every wave is done with half panel 0 and halo s; half panel 1 (requested at the end of block s - 1) and
+      // halo s + 1 (requested in the middle of block s - 1) have landed -- everything this wave has in flight
+      if (!(ABL & 16)) MNC_F4_SYNC(0);
+      if (!(ABL & 1)) { dma_u(s + 1, 0); dma_h(s + 2, bsel); }
+      pass(1, vb, bsel ^ 1, 0, va);
       pin_acc();
-      // end of block s: every wave is done with panel s; panel s + 1 has landed, halo s + 2 may still fly
-      if (!(ABL & 16)) MNC_F4_SYNC(5);
-      if (!(ABL & 1)) dma_u(s + 2, bsel);
+      // end of block s: every wave is done with half panel 1; half panel 0 of block s + 1 has landed, halo s + 2's six may still fly
+      if (!(ABL & 16)) MNC_F4_SYNC(6);
+      if (!(ABL & 1)) dma_u(s + 1, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dead copies behind the last block write the LDS too: none may outlive the wave)
   }
@@ -360,19 +366,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino4_kernel(const float* __restr
   }
 }
 
-// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (channel group)][64 (lane)][76]: element (cb, ct, cg, lane = kk * 16 + i,
-// e = 36 * g + n) = (G g G^T)[row][column] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 + 2 * kk + g), n = 6 * column + row
-// (the order in which a pass multiplies the positions), evaluated in double and rounded once; the 4 pad floats are 0.
+// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (g)][2 (channel group)][64 (lane)][36]: element (cb, ct, g, cg, lane = kk * 16 + i,
+// n) = (G g G^T)[row][column] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 + 2 * kk + g), n = 6 * column + row (the order in
+// which a pass multiplies the positions), evaluated in double and rounded once.  Cin * Cout * 36 floats, no padding: a lane's 144
+// bytes are 9 x 16, and an odd multiple of 16 bytes as lane pitch is what keeps ds_read_b128 free of bank conflicts.
 __global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
   const double G[6][3] = {{0.25, 0.0, 0.0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
   const int ncot = Cout >> 5;
-  const long items = (long)(Cin >> 3) * ncot * 2 * 64 * 2;        // (cb, ct, cg, lane, g)
-  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-    const int g = (int)(it & 1);
-    const long r = it >> 1;
-    const int lane = (int)(r & 63), cgi = (int)((r >> 6) & 1);
-    const long tt = r >> 7;
+  const long items = (long)(Cin >> 3) * ncot * 2 * 2 * 64;        // (cb, ct, g, cg, lane)
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < items; r += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(r & 63), cgi = (int)((r >> 6) & 1), g = (int)((r >> 7) & 1);
+    const long tt = r >> 8;
     const int ct = (int)(tt % ncot), cb = (int)(tt / ncot);
     const int kk = lane >> 4, i = lane & 15;
     const int co = ct * 32 + cgi * 16 + i, ci = cb * 8 + 2 * kk + g;
@@ -386,9 +391,8 @@ __global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-      for (int b = 0; b < 6; ++b)                                 // (G g) G^T
-        dst[g * 36 + b * 6 + a] = (float)(tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2]);   // n = 6 column + row
-    if (g == 0) { dst[72] = 0.f; dst[73] = 0.f; dst[74] = 0.f; dst[75] = 0.f; }
+      for (int b = 0; b < 6; ++b)                                 // (G g) G^T, row a, column b -> n = 6 b + a
+        dst[b * 6 + a] = (float)(tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2]);
   }
 }
 
@@ -444,11 +448,11 @@ __global__ __launch_bounds__(256) void wino4_section_reduce_kernel(const float* 
 using namespace mnc;
 
 // Plan of one layer: how many pixel tiles run whole (section A, ksplit_a ranges each) and into how many K ranges the others are cut.
-// The chip holds `slots` = 256 workgroups at a time (one per CU: 154 KB of LDS).  Full rounds run unsplit; the tiles of a last,
+// The chip holds `slots` = 512 workgroups at a time (two per CU: 80 KB of LDS and 4 waves of 256 registers each).  Full rounds run unsplit; the tiles of a last,
 // partly filled round are cut into as many K ranges (of >= 4 blocks) as fill that round once.  A layer that does not fill one
 // round at all (conv4_x: 160 workgroups, conv5_x / rpn_conv: 48) is cut uniformly.
 static void wino4_plan(int pix, int ncot, int blocks, int* pix_a, int* ksplit_a, int* ksplit_b) {
-  const int slots = 256, min_blocks = 4;
+  const int slots = 512, min_blocks = 4;
   *pix_a = pix; *ksplit_a = 1; *ksplit_b = 1;
   const long wgs = (long)pix * ncot;
   const int smax = blocks / min_blocks > 1 ? blocks / min_blocks : 1;
@@ -471,7 +475,9 @@ static void wino4_plan(int pix, int ncot, int blocks, int* pix_a, int* ksplit_a,
     int sb = slots / rest;
     if (sb > smax) sb = smax;
     if (sb > 8) sb = 8;
-    if (sb >= 2) { *pix_a = full_pix; *ksplit_b = sb; }
+    // (two ranges do not pay: conv2_x, 192 tail workgroups, 113 / 194 us cut in two against 106 / 187 us whole; conv3_x, 96 tail
+    // workgroups in four or five ranges, 105 / 181 us against 115 / 211 us whole -- kernel_bench convwino4, MNC_WINO_TAIL)
+    if (sb >= 3) { *pix_a = full_pix; *ksplit_b = sb; }
   }
 }
 
@@ -525,7 +531,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
   }
 #endif
   const long nblocks = ((long)pix_a * ksplit_a + (long)(pix - pix_a) * ksplit_b) * ncot;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(512), kF4LdsBytes, ctx->stream, d_in, d_wpk, d_bias, d_out, part, H, W,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), kF4LdsBytes, ctx->stream, d_in, d_wpk, d_bias, d_out, part, H, W,
                      Cin, Cout, relu, pool, tiles_x, pix_a, ksplit_a, ksplit_b);
   auto grid_for = [](long n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); };
   auto reduce = [&](int s, int pix0, int npix) {
@@ -548,7 +554,7 @@ int mnc_pack_conv3x3_wino4(mnc_ctx* ctx, const float* d_oihw, float* d_packed, i
   MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
               "mnc_pack_conv3x3_wino4: bad argument (Cin%%8==0, Cout%%32==0)");
   LaunchScope ls(ctx, "pack_conv3x3_wino4");
-  const long items = (long)(Cin >> 3) * (Cout >> 5) * 2 * 64 * 2;
+  const long items = (long)(Cin >> 3) * (Cout >> 5) * 2 * 2 * 64;
   long g = (items + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(pack_conv3x3_wino4_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_oihw, d_packed, Cout, Cin);

@@ -82,6 +82,14 @@ const char* mnc_version(void) { return "mnc_hip 0.3 (gfx950, tuning build: ablat
 const char* mnc_version(void) { return "mnc_hip 0.3 (gfx950)"; }
 #endif
 
+int mnc_device_mem_info(int device_id, size_t* free_bytes, size_t* total_bytes) {
+  MNC_REQUIRE(free_bytes && total_bytes, "mnc_device_mem_info: null pointer");
+  MNC_HIP_TRY(hipSetDevice(device_id));
+  MNC_HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+  clear_error();
+  return MNC_OK;
+}
+
 int mnc_device_count(int* count) {
   MNC_REQUIRE(count, "mnc_device_count: null pointer");
   int n = 0;

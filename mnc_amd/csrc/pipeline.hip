@@ -240,10 +240,11 @@ int finalize(mnc_net* n) {
       NET_TRY(upload(n, w->v, &raw));
       n->conv_fast[i] = cout % 32 == 0;        // engine.py:_conv_kind: 'fast3x3' needs Cout % 32 == 0, otherwise 'general'
       if (n->conv_fast[i]) {
-        const int pitch = c.math == 0 ? (c.winograd ? 136 : 76) : 84;
+        const int pitch = c.math == 0 ? (c.winograd == 4 ? 288 : c.winograd ? 136 : 76) : 84;
         NET_TRY(mnc_dev_alloc(n->ctx, (size_t)(cin / 8) * cout * pitch * 4, &n->w_conv[i]));
-        NET_TRY(c.math == 0 ? (c.winograd ? mnc_pack_conv3x3_wino(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
-                                          : mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin))
+        NET_TRY(c.math == 0 ? (c.winograd == 4 ? mnc_pack_conv3x3_wino4(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
+                               : c.winograd ? mnc_pack_conv3x3_wino(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
+                                            : mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin))
                 : c.math == 1 ? mnc_pack_conv3x3_bf16x3(n->ctx, raw, n->w_conv[i], cout, cin)
                               : mnc_pack_conv3x3_f16(n->ctx, raw, n->w_conv[i], cout, cin));
       } else if (c.math == 2) {
@@ -397,6 +398,8 @@ int conv3(mnc_net* n, int i, const float* in, float* out, int h, int w, int cin,
     if (c.math == 2) return mnc_conv2d_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
     return mnc_conv2d(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
   }
+  if (c.math == 0 && c.winograd == 4)
+    return mnc_conv3x3_wino4(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
   if (c.math == 0 && c.winograd)
     return mnc_conv3x3_wino(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
   if (c.math == 0) return mnc_conv3x3(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
@@ -442,7 +445,8 @@ int run_trunk(mnc_net* n) {
     if (kPoolAfter[i] && i > 0 && c.math == 0 && c.winograd && n->conv_fast[i]) {
       // conv + ReLU + MAX 2x2/2 in one kernel (the engine's fused plan; the full-resolution blob is not produced)
       float* p = (float*)n->pooled[pi++].p;
-      NET_TRY(mnc_conv3x3_wino_pool(ctx, cur, (const float*)n->w_conv[i], n->b_conv[i], p, h, w, cin, cout, 1));
+      NET_TRY(c.winograd == 4 ? mnc_conv3x3_wino4_pool(ctx, cur, (const float*)n->w_conv[i], n->b_conv[i], p, h, w, cin, cout, 1)
+                              : mnc_conv3x3_wino_pool(ctx, cur, (const float*)n->w_conv[i], n->b_conv[i], p, h, w, cin, cout, 1));
       h = pool_out(h); w = pool_out(w);
       cur = p; cin = cout;
       continue;
@@ -643,7 +647,7 @@ int mnc_net_default_config(mnc_net_config* cfg) {
   cfg->vote_nms_thresh = 0.3f; cfg->vote_iou_thresh = 0.5f;
   cfg->math = 0;
   cfg->use_graph = 1;
-  cfg->winograd = 1;
+  cfg->winograd = 4;
   cfg->conventions.maskpool_thresh = 0.4f;         // every switch 0: oracle/SPEC.md
   clear_error();
   return MNC_OK;

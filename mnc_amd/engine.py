@@ -26,8 +26,24 @@ import numpy as np
 from . import _lib, install_paths, prototxt
 from .devarray import DeviceArray
 
-# fp32 mode: 3x3 convolutions by Winograd F(2x2,3x3) unless MNC_CONV_WINOGRAD=0 / Net(winograd=False)
-WINOGRAD_DEFAULT = "1"
+# fp32 mode: 3x3 convolutions by Winograd's minimal filtering on the fp32 matrix pipe.  MNC_CONV_WINOGRAD / Net(winograd=):
+# 4 (default; True) = F(4x4,3x3), csrc/conv_wino4.hip (round 4); 2 (also "1") = F(2x2,3x3), csrc/conv_wino.hip; 0 (False) = direct
+WINOGRAD_DEFAULT = "4"
+
+
+def winograd_mode(value):
+    """None / bool / 0 / 2 / 4 / "0" / "1" / "2" / "4" -> 0 (direct), 2 (F(2x2)) or 4 (F(4x4))."""
+    import os
+    if value is None:
+        value = os.environ.get("MNC_CONV_WINOGRAD", WINOGRAD_DEFAULT)
+    if value is True:
+        return 4
+    if value is False:
+        return 0
+    v = int(value)
+    if v not in (0, 1, 2, 4):
+        raise ValueError("winograd must be 0 (direct), 2 (F(2x2,3x3)) or 4 (F(4x4,3x3)), got %r" % (value,))
+    return 2 if v == 1 else v
 
 # bf16x3 mode: InnerProducts below this many flops stay on the fp32 kernel (its small-tile variant is as fast there)
 _X3_MIN_FLOPS = 2.0e9
@@ -388,7 +404,8 @@ class Net(object):
         self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
         if self.math not in ("fp32", "bf16x3", "f16"):
             raise ValueError("math must be 'fp32', 'bf16x3' or 'f16', got %r" % self.math)
-        self._winograd = (os.environ.get("MNC_CONV_WINOGRAD", WINOGRAD_DEFAULT) != "0") if winograd is None else bool(winograd)
+        self._wino = winograd_mode(winograd)
+        self._winograd = self._wino != 0
         # MNC_SPECULATE_ROIS=0: read the ProposalLayer's RoI count back before the heads are launched (one stream sync in the
         # middle of forward) instead of running the heads on RPN_POST_NMS_TOP_N rows and checking the count at the end
         self._speculate = os.environ.get("MNC_SPECULATE_ROIS", "1") != "0"
@@ -793,7 +810,8 @@ class Net(object):
             # equal to the direct form up to fp32 rounding; MNC_CONV_WINOGRAD / Net(winograd=))
             pitch, pack, conv = (84, "mnc_pack_conv3x3_f16", "mnc_conv3x3_f16") if self.math == "f16" else \
                                 (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
-                                (136, "mnc_pack_conv3x3_wino", "mnc_conv3x3_wino") if self._winograd else \
+                                (288, "mnc_pack_conv3x3_wino4", "mnc_conv3x3_wino4") if self._wino == 4 else \
+                                (136, "mnc_pack_conv3x3_wino", "mnc_conv3x3_wino") if self._wino == 2 else \
                                 (76, "mnc_pack_conv3x3_weights", "mnc_conv3x3")
 
             def build():
@@ -802,7 +820,7 @@ class Net(object):
                 _lib.call(pack, self._h(), raw, packed, cout, cin)
                 self._ctx.free(raw)
                 return packed
-            d_w = self._dev_param(key + ("w", self.math, "wino" if (self._winograd and not x3) else "direct"), build)
+            d_w = self._dev_param(key + ("w", self.math, ("wino%d" % self._wino) if (self._winograd and not x3) else "direct"), build)
 
             def run():
                 N, _, H, Wd = bot.shape
@@ -813,7 +831,7 @@ class Net(object):
                     top.reshape(N, cout, OH, OW)
                     dst = top.dev_out("c8")
                     for n in range(N):
-                        _lib.call("mnc_conv3x3_wino_pool", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
+                        _lib.call("mnc_conv3x3_wino4_pool" if self._wino == 4 else "mnc_conv3x3_wino_pool", self._h(), src + n * cin * H * Wd * 4, d_w, d_b,
                                   dst + n * cout * OH * OW * 4, H, Wd, cin, cout, relu)
                     return
                 top.reshape(N, cout, H, Wd)

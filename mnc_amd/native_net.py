@@ -68,11 +68,8 @@ def config_from_weights(weights, math="fp32", use_graph=True, winograd=None, **o
     cfg.num_classes = int(weights["cls_score"][0].shape[0])
     cfg.math = MATH[math]
     cfg.use_graph = 1 if use_graph else 0
-    if winograd is None:
-        import os
-        from .engine import WINOGRAD_DEFAULT
-        winograd = os.environ.get("MNC_CONV_WINOGRAD", WINOGRAD_DEFAULT) != "0"
-    cfg.winograd = 1 if winograd else 0
+    from .engine import winograd_mode
+    cfg.winograd = winograd_mode(winograd)             # 0 direct, 2 F(2x2,3x3), 4 F(4x4,3x3) (default)
     for k, v in overrides.items():
         if k == "layer_conventions":
             cfg.conventions = LayerConventions.make(v)

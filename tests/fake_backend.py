@@ -159,6 +159,17 @@ class Fake(object):
         # transform G g G^T and the kernel are checked against torch on the GPU (tests/test_gpu_ops.py::test_conv3x3_winograd)
         _f(dst, (Cout * Cin * 9,))[...] = _f(src, (Cout * Cin * 9,))
 
+    # F(4x4,3x3) (round 4): same test doubles, the real kernel is checked on the GPU (tests/test_gpu_ops.py::test_conv3x3_winograd_f4)
+    # and emulated formula for formula on the CPU (tests/test_wino4_index_math.py)
+    def mnc_pack_conv3x3_wino4(self, h, src, dst, Cout, Cin):
+        return self.mnc_pack_conv3x3_wino(h, src, dst, Cout, Cin)
+
+    def mnc_conv3x3_wino4(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        return self.mnc_conv3x3_wino(h, src, wpk, b, dst, H, W, Cin, Cout, relu)
+
+    def mnc_conv3x3_wino4_pool(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        return self.mnc_conv3x3_wino_pool(h, src, wpk, b, dst, H, W, Cin, Cout, relu)
+
     def mnc_conv3x3_wino(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu):
         w = _f(wpk, (Cout, Cin, 3, 3))
         x = _unc8(_f(src, (Cin // 8, H, W, 8)))

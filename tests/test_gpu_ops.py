@@ -153,10 +153,9 @@ def test_conv3x3_winograd_f4(dev, H, W, Cin, Cout, relu, tune):
     b = rng.normal(0, 0.1, Cout).astype(np.float32)
     want = _conv_ref(x, w, b, bool(relu))
     d_x, d_b = dev.put(to_c8(x)), dev.put(b)
-    d_w = dev.empty((Cin * Cout * 38,), fill=np.nan)
+    d_w = dev.empty((Cin * Cout * 36,), fill=np.nan)
     dev.call("mnc_pack_conv3x3_wino4", dev.put(w), d_w, Cout, Cin)
-    packed = dev.get(d_w, (Cin // 8, Cout // 32, 2, 64, 76))
-    assert not np.isnan(packed).any() and np.all(packed[..., 72:] == 0)
+    assert not np.isnan(dev.get(d_w, (Cin * Cout * 36,))).any()
     d_y = dev.empty((Cout, H, W), fill=-7.0)
     worst = 0.0
     for ks, tail, xcd in ((None, None, None), ("1", None, None), ("2", None, "0"), ("3", None, "1"), (None, "0", None)):

@@ -250,9 +250,16 @@ def test_bench_launcher_two_ranks_native_engine_on_one_gpu():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["images_per_step"] == 2 and d["dist_backend"] == "gloo"
+    c = json.loads(line)
+    # the LAST stdout line is the compact one (< 4 KB, ranks summarised); the full result -- every rank's own figures -- is the detail file
+    assert len(line) < 4096 and c["n_gpus"] == 2 and c["scaling"] == "weak" and c["config"]["images_per_step"] == 2
+    assert c["ranks_ms_per_step"]["n"] == 2 and c["ranks_ms_per_step"]["min"] > 0 and "ranks" not in c
+    assert c["gather_transport"] == "gloo"
+    with open(os.path.join(REPO, c["detail"])) as f:
+        d = json.load(f)
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "gloo" and d["value"] == pytest.approx(c["value"], rel=1e-4)
     assert [x["rank"] for x in d["ranks"]] == [0, 1] and all(x["ms_per_step"] > 0 for x in d["ranks"])
+    assert all(x.get("device_mem_gb") is None or x["device_mem_gb"] > 0 for x in d["ranks"])
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert d["ms_per_step"] >= max(x["ms_per_step"] for x in d["ranks"]) * 0.999       # the max over ranks is what is reported
     assert "native" in d["config"]["engine"]

@@ -146,7 +146,7 @@ def main():
                 fn = "mnc_conv3x3_wino"
             elif args.what == "convwino4":
                 raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
-                w = dev.empty((Cin * Cout * 38,))
+                w = dev.empty((Cin * Cout * 36,))
                 dev.call("mnc_pack_conv3x3_wino4", raw, w, Cout, Cin)
                 fn = "mnc_conv3x3_wino4"
             else:
