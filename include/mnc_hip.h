@@ -384,6 +384,12 @@ MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed
  * staged, fp32 accumulate).  mnc_pack_conv3x3_f16 writes [ceil(Cin/16)][Cout][76 dwords]: 9 taps x 16 channels fp16 + 16 B
  * pad, channels past Cin zero (at most the (Cin/8)*Cout*84 dwords of the bf16x3 layout: one buffer size serves both). */
 MNC_API int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
+/* Plain bf16 (round 4; BASELINE configs[2] "bf16 convs via MFMA" as written): the fp16 kernel and layout with both operands rounded
+ * to nearest-even bf16 instead -- ONE v_mfma_f32_32x32x16_bf16 per term, fp32 accumulation, fp32 c8 tensors in and out.  ~4e-3 of
+ * a layer's range per layer (8 mantissa bits): measured and recorded, outside the 1e-3 bar; bf16x3 is the bf16-pipe mode that keeps it. */
+MNC_API int mnc_pack_conv3x3_bf16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
+MNC_API int mnc_conv3x3_bf16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,
+                             int H, int W, int Cin, int Cout, int relu);
 MNC_API int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,
                             int H, int W, int Cin, int Cout, int relu);
 /* Packed 2-byte activations between MFMA layers (bf16x3 and f16 math modes).  A c8 tensor [C/8][H][W][8] is kept as
@@ -411,6 +417,10 @@ MNC_API int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size
  * mnc_pack_fc_f16: Caffe weight [N][K] -> [ceil(N/128)][K/64][128][64] halves (bytes: ceil(N/128)*128*K*2), once at load.
  * mnc_fc_f16: same interface as mnc_fc (fp32 activations in, fp32 out); K%64==0.  Relative error vs fp32 ~3e-4 per layer. */
 MNC_API int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
+/* The same InnerProduct in plain bf16 (nearest even, one product per term; the "bf16" math mode): mnc_fc_f16's layout and interface. */
+MNC_API int mnc_pack_fc_bf16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
+MNC_API int mnc_fc_bf16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N,
+                        int K, int ldc, int act);
 MNC_API int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N,
                        int K, int ldc, int act);
 /* ---- InnerProduct activations already in the reduced-precision kernels' own form ----
@@ -538,7 +548,9 @@ typedef struct mnc_net_config {
   double pixel_means[3];   /* cfg.PIXEL_MEANS, BGR */
   int max_per_image;       /* 100 */
   float vote_nms_thresh, vote_iou_thresh;   /* TEST.MASK_MERGE_NMS_THRESH 0.3, TEST.MASK_MERGE_IOU_THRESH 0.5 */
-  int math;                /* 0 fp32, 1 bf16x3, 2 f16 (the engine's math modes) */
+  int math;                /* 0 fp32, 1 bf16x3, 2 f16, 3 mixed = convolutions bf16x3 (fp32-class) + large InnerProducts fp16: the
+                            * reduced-precision mode that keeps the 1e-3 bar; 4 bf16 = plain bf16, one product per term (BASELINE
+                            * configs[2] as written; measured, outside the 1e-3 bar) (the engine's math modes) */
   int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
   int winograd;            /* fp32 math, the 3x3 convolutions: 4 = Winograd F(4x4,3x3) (mnc_conv3x3_wino4; default), 2 (or 1) =
                             * F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */

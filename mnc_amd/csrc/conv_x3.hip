@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
       if (F16) {
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         const f16x4 hv = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w};
-        uint2 hi = __builtin_bit_cast(uint2, hv);
+        uint2 hi = F16 == 2 ? x3_bf16x4(x) : __builtin_bit_cast(uint2, hv);     // F16 == 2: plain bf16 (one product per term)
         hi.x &= keep; hi.y &= keep;
         *reinterpret_cast<uint2*>(hdst + h_dst[u]) = hi;
         continue;
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
       for (int r = 0; r < PR; ++r)
 #pragma unroll
         for (int t = 0; t < CT; ++t)
-          acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.ah[t]), x3_as_f16x8(f.bh[r]), acc[r][t], 0, 0, 0);
+          acc[r][t] = F16 == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.ah[t]), x3_as_bf16x8(f.bh[r]), acc[r][t], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.ah[t]), x3_as_f16x8(f.bh[r]), acc[r][t], 0, 0, 0);
       return;
     }
     // term outermost: consecutive MFMAs never share an accumulator
@@ -462,6 +463,7 @@ __global__ void pack_conv_x3_kernel(const float* __restrict__ w, uint4* __restri
 
 // f16 layout: OIHW fp32 -> [ceil(Cin/16)][Cout][19 uint4]: tap t < 9: uint4 2t, 2t+1 = the 16 channels of the block rounded to
 // fp16 (channels past Cin: zero); uint4 18: pad
+template <int BF16>      // BF16 = 1: the same layout in bf16 (nearest even) for the plain "bf16" mode
 __global__ void pack_conv_f16_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin) {
   const int nblk = (Cin + 15) / 16;
   const long total = (long)nblk * Cout * 19;
@@ -472,10 +474,17 @@ __global__ void pack_conv_f16_kernel(const float* __restrict__ w, uint4* __restr
     uint4 v = make_uint4(0, 0, 0, 0);
     if (slot < 18) {
       const int tap = slot >> 1, c0 = blk * 16 + (slot & 1) * 8;
-      f16x8 h;
+      if (BF16) {
+        bf16x8 h;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) h[e] = c0 + e < Cin ? (_Float16)w[((long)co * Cin + c0 + e) * 9 + tap] : (_Float16)0.f;
-      v = __builtin_bit_cast(uint4, h);
+        for (int e = 0; e < 8; ++e) h[e] = c0 + e < Cin ? (__bf16)w[((long)co * Cin + c0 + e) * 9 + tap] : (__bf16)0.f;
+        v = __builtin_bit_cast(uint4, h);
+      } else {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = c0 + e < Cin ? (_Float16)w[((long)co * Cin + c0 + e) * 9 + tap] : (_Float16)0.f;
+        v = __builtin_bit_cast(uint4, h);
+      }
     }
     out[row * 19 + slot] = v;
   }
@@ -661,7 +670,8 @@ static int pack_conv_lowp(mnc_ctx* ctx, const char* name, const float* d_oihw, v
   MNC_REQUIRE(ctx && d_oihw && d_packed && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0, "%s: bad argument", name);
   LaunchScope ls(ctx, name);
   if (f16) {
-    hipLaunchKernelGGL(pack_conv_f16_kernel, dim3(x3_grid_for((long)((Cin + 15) / 16) * Cout * 19)), dim3(256), 0, ctx->stream, d_oihw,
+    auto kern = f16 == 2 ? pack_conv_f16_kernel<1> : pack_conv_f16_kernel<0>;
+    hipLaunchKernelGGL(kern, dim3(x3_grid_for((long)((Cin + 15) / 16) * Cout * 19)), dim3(256), 0, ctx->stream, d_oihw,
                        (uint4*)d_packed, Cout, Cin);
     return ls.finish("pack_conv_f16_kernel");
   }
@@ -747,6 +757,19 @@ int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const
 int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
                     int Cout, int relu) {
   return conv3x3_lowp<1, 0>(ctx, "conv3x3_f16", d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
+}
+
+// Plain bf16 (round 4; BASELINE configs[2] "bf16 convs via MFMA" as written): the f16 kernel with both operands rounded to bf16
+// (weights once at load, activations while the halo is staged), ONE v_mfma_f32_32x32x16_bf16 per term, fp32 accumulation.  fp32 c8
+// tensors in and out (no packed 2-byte form: the mode exists to be measured, not to be fast -- 8 mantissa bits put a layer at ~4e-3
+// of its range and the network far outside the 1e-3 bar; f16 runs the same pipe at the same rate with 11 bits).
+int mnc_pack_conv3x3_bf16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  return pack_conv_lowp(ctx, "pack_conv3x3_bf16", d_oihw, d_packed, Cout, Cin, 2);
+}
+
+int mnc_conv3x3_bf16(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                     int Cout, int relu) {
+  return conv3x3_lowp<2, 0>(ctx, "conv3x3_bf16", d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu);
 }
 
 int mnc_conv3x3_bf16x3_pk(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out, int H, int W,

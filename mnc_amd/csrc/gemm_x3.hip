@@ -187,12 +187,14 @@ __global__ __launch_bounds__(256) void fc_x3_kernel(const uint4* __restrict__ Ax
       for (int t = 0; t < TR; ++t)
 #pragma unroll
         for (int c = 0; c < TC; ++c)
-          acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.ah[t]), x3_as_f16x8(f.bh[c]), acc[t][c], 0, 0, 0);
+          acc[t][c] = F16 == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.ah[t]), x3_as_bf16x8(f.bh[c]), acc[t][c], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.ah[t]), x3_as_f16x8(f.bh[c]), acc[t][c], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < TR; ++t)
 #pragma unroll
         for (int c = 0; c < TC; ++c)
-          acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.al[t]), x3_as_f16x8(f.bl[c]), acc[t][c], 0, 0, 0);
+          acc[t][c] = F16 == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.al[t]), x3_as_bf16x8(f.bl[c]), acc[t][c], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.al[t]), x3_as_f16x8(f.bl[c]), acc[t][c], 0, 0, 0);
       return;
     }
 #pragma unroll
@@ -313,6 +315,7 @@ __global__ void pack_x3_kernel(const float* __restrict__ in, uint4* __restrict__
 
 // fp32 row-major [rows][K] -> fp16 (round to nearest even), stage-major with 64-value stages:
 // out[((tile * S + s) * tile_rows + r) * 8 + g] = 8 halves of values s*64 + g*8 .. +7 of row tile * tile_rows + r, S = K/64.
+template <int BF16>      // BF16 = 1: the same stage-major layout in bf16 (nearest even), the plain "bf16" math mode (round 4)
 __global__ void pack_f16_kernel(const float* __restrict__ in, uint4* __restrict__ out, int rows, int K, int tile_rows,
                                 int tiles) {
   const int S = K / 64;
@@ -329,9 +332,14 @@ __global__ void pack_f16_kernel(const float* __restrict__ in, uint4* __restrict_
     if (row < rows) {
       const float4* p = reinterpret_cast<const float4*>(in + row * K + st * 64 + g * 8);
       const float4 a = p[0], b = p[1];
-      f16x8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z,
-                 (_Float16)b.w};
-      v = __builtin_bit_cast(uint4, h);
+      if (BF16) {
+        const uint2 lo = x3_bf16x4(a), hi = x3_bf16x4(b);
+        v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      } else {
+        f16x8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z,
+                   (_Float16)b.w};
+        v = __builtin_bit_cast(uint4, h);
+      }
     }
     out[i] = v;
   }
@@ -455,7 +463,8 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
       for (int t = 0; t < TR; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-          acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.a[t]), x3_as_f16x8(f.b[c]), acc[t][c], 0, 0, 0);
+          acc[t][c] = F16 == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(f.a[t]), x3_as_bf16x8(f.b[c]), acc[t][c], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(f.a[t]), x3_as_f16x8(f.b[c]), acc[t][c], 0, 0, 0);
       return;
     }
     // a_lo b_hi + a_hi b_lo + a_hi b_hi, term outermost -- fc_x3_kernel's order
@@ -537,11 +546,12 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
   }
 }
 
-static int f16_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles) {
+static int f16_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles, int bf16 = 0) {
   const long total = (long)tiles * (K / 64) * tile_rows * 8;
   long g = (total + 255) / 256;
   if (g > 65536) g = 65536;
-  hipLaunchKernelGGL(pack_f16_kernel, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, rows, K, tile_rows, tiles);
+  if (bf16) hipLaunchKernelGGL(pack_f16_kernel<1>, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, rows, K, tile_rows, tiles);
+  else hipLaunchKernelGGL(pack_f16_kernel<0>, dim3((int)g), dim3(256), 0, ctx->stream, d_in, d_out, rows, K, tile_rows, tiles);
   return MNC_OK;
 }
 
@@ -633,7 +643,7 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   if (!d_pre) {
     uint4* conv = (uint4*)((char*)ctx->scratch + part_bytes);
     LaunchScope ls(ctx, F16 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (F16 ? 6.0 : 8.0) * M * (double)K);
-    if (F16) f16_pack_launch(ctx, d_a, conv, M, K, M, 1);
+    if (F16) f16_pack_launch(ctx, d_a, conv, M, K, M, 1, F16 == 2);
     else x3_pack_launch(ctx, d_a, conv, M, K, M, 1);
     rc = ls.finish(F16 ? "pack_f16_kernel" : "pack_x3_kernel");
     if (rc) return rc;
@@ -649,7 +659,7 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   const bool rows_fastest = tune_set(ctx, T_FC_ORDER) ? tune(ctx, T_FC_ORDER, 0) == 1 : tn >= 8;
   const int tm_arg = (rows_fastest && tm > 1) ? -tm : tm;
   {
-    LaunchScope ls(ctx, F16 ? (small ? "fc_f16_small" : "fc_f16") : (small ? "fc_bf16x3_small" : "fc_bf16x3"), flops, bytes);
+    LaunchScope ls(ctx, F16 == 2 ? (small ? "fc_bf16_small" : "fc_bf16") : F16 ? (small ? "fc_f16_small" : "fc_f16") : (small ? "fc_bf16x3_small" : "fc_bf16x3"), flops, bytes);
 #define MNC_X3_LAUNCH(MT, WR, A)                                                                                              \
   hipLaunchKernelGGL((fc_x3_kernel<MT, WR, A, F16>), dim3(tn * splits * tm), dim3(256), 0, ctx->stream, d_ax,                 \
                      (const uint4*)d_w_packed, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, \
@@ -744,6 +754,22 @@ int mnc_pack_fc_f16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K
   LaunchScope ls(ctx, "pack_fc_f16");
   f16_pack_launch(ctx, d_w, (uint4*)d_packed, N, K, kXBN, cdiv(N, kXBN));
   return ls.finish("pack_f16_kernel");
+}
+
+// Plain bf16 (round 4, the "bf16" math mode): both operands rounded to bf16 (nearest even), one v_mfma_f32_32x32x16_bf16 per term.
+int mnc_pack_fc_bf16(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K) {
+  MNC_REQUIRE(ctx && d_w && d_packed && N > 0 && K > 0 && K % 64 == 0, "mnc_pack_fc_bf16: bad argument (K%%64==0)");
+  LaunchScope ls(ctx, "pack_fc_bf16");
+  f16_pack_launch(ctx, d_w, (uint4*)d_packed, N, K, kXBN, cdiv(N, kXBN), 1);
+  return ls.finish("pack_f16_kernel<bf16>");
+}
+
+int mnc_fc_bf16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N, int K,
+                int ldc, int act) {
+  MNC_REQUIRE(ctx && d_a && d_w_packed && d_bias && d_out, "mnc_fc_bf16: null pointer");
+  MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2,
+              "mnc_fc_bf16: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%64==0)", M, N, K, ldc, act);
+  return fc_lowp<2>(ctx, "mnc_fc_bf16", d_a, nullptr, M, d_w_packed, d_bias, d_out, M, N, K, ldc, act);
 }
 
 // InnerProduct in fp16 arithmetic (fp32 accumulate): the same launcher with 64-value stages.

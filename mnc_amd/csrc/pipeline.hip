@@ -82,7 +82,7 @@ struct mnc_net {
   bool conv_fast[14] = {false};                // tuned 3x3 kernels (Cout % 32 == 0) or the general convolution (reduced widths)
   float* b_conv[14] = {nullptr};               // biases: trunk 0..12 -> [0..12], rpn -> [13]
   float *w_rpn = nullptr, *b_rpn = nullptr;    // rpn_cls_score (2A rows) and rpn_bbox_pred (4A rows) as ONE [6A][RC] 1x1 convolution
-  struct Fc { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, kind = 0; };   // kind 0 fp32, 1 bf16x3, 2 f16
+  struct Fc { void* w = nullptr; float* b = nullptr; int N = 0, K = 0, kind = 0; };   // kind 0 fp32, 1 bf16x3, 2 f16, 3 plain bf16
   Fc fc_maskest, fc_maskpred, fc6, fc7, fc6m, fc7m, fc_heads;
   // geometry of the buffers below
   int cap_ph = 0, cap_pw = 0, cap_src = 0;
@@ -159,6 +159,12 @@ int need(mnc_net* n, const char* layer, int index, size_t count, const HostBlob*
   return MNC_OK;
 }
 
+// math 3 ("mixed", round 4): the convolutions in bf16x3 (fp32-class), the large InnerProducts in fp16 -- the reduced-precision mode
+// that keeps the 1e-3 bar (mnc_hip.h, mnc_net_config::math)
+// math 4 ("bf16"): plain bf16, one product per term, fp32 tensors between the layers (BASELINE configs[2] as written; measured only)
+static inline int conv_math(const mnc_net_config& c) { return c.math == 3 ? 1 : c.math; }
+static inline int fc_math(const mnc_net_config& c) { return c.math == 3 ? 2 : c.math; }
+
 // One InnerProduct's weights: [N][K] in Caffe order; geo = (C, PH, PW) when the bottom is a per-RoI feature (the engine's
 // rows are (h, w, c): permute the columns once), then the math mode's packed form when the product is large enough
 // (engine.py: 2*M*N*K >= 2e9 with M = post_nms_topn; f16 needs K % 64 == 0, bf16x3 K % 32 == 0).
@@ -178,13 +184,18 @@ int prepare_fc(mnc_net* n, const char* layer, int N, int K, int C, int PH, int P
     raw = (float*)perm;
   }
   const bool big = 2.0 * n->cfg.post_nms_topn * (double)N * (double)K >= 2.0e9;
-  const bool f16 = n->cfg.math == 2 && K % 64 == 0 && big;
-  const bool x3 = !f16 && n->cfg.math != 0 && K % 32 == 0 && big;
-  fc->kind = f16 ? 2 : x3 ? 1 : 0;
+  // mixed: an InnerProduct over more than 50 000 inputs (fc6_maskest: 100 352) stays split-bf16 -- fp16 operands leave the sigmoid
+  // masks behind it at 1.0-1.2e-3, the only head output of the f16 mode on the wrong side of the bar (engine.py: the same rule)
+  const int fm = (n->cfg.math == 3 && K > 50000) ? 1 : fc_math(n->cfg);
+  const bool bf = fm == 4 && K % 64 == 0 && big;
+  const bool f16 = (fm == 2 && K % 64 == 0 && big) || bf;
+  const bool x3 = !f16 && (fm == 1 || fm == 2) && K % 32 == 0 && big;
+  fc->kind = bf ? 3 : f16 ? 2 : x3 ? 1 : 0;
   if (fc->kind == 0) { fc->w = raw; return MNC_OK; }
   void* packed = nullptr;
   NET_TRY(mnc_dev_alloc(n->ctx, (size_t)((N + 127) / 128) * 128 * K * (f16 ? 2 : 4), &packed));
-  NET_TRY(f16 ? mnc_pack_fc_f16(n->ctx, raw, packed, N, K) : mnc_pack_fc_bf16x3(n->ctx, raw, packed, N, K));
+  NET_TRY(bf ? mnc_pack_fc_bf16(n->ctx, raw, packed, N, K)
+             : f16 ? mnc_pack_fc_f16(n->ctx, raw, packed, N, K) : mnc_pack_fc_bf16x3(n->ctx, raw, packed, N, K));
   NET_TRY(mnc_dev_free(n->ctx, raw));
   fc->w = packed;
   return MNC_OK;
@@ -192,6 +203,7 @@ int prepare_fc(mnc_net* n, const char* layer, int N, int K, int C, int PH, int P
 
 int run_fc(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, float* out, int M, int ldc, int act) {
   if (M == 0) return MNC_OK;
+  if (fc.kind == 3) return mnc_fc_bf16(ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
   if (fc.kind == 2) return mnc_fc_f16(ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
   if (fc.kind == 1) return mnc_fc_bf16x3(ctx, a, fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
   return mnc_fc(ctx, a, (const float*)fc.w, fc.b, out, M, fc.N, fc.K, ldc, act);
@@ -240,14 +252,16 @@ int finalize(mnc_net* n) {
       NET_TRY(upload(n, w->v, &raw));
       n->conv_fast[i] = cout % 32 == 0;        // engine.py:_conv_kind: 'fast3x3' needs Cout % 32 == 0, otherwise 'general'
       if (n->conv_fast[i]) {
-        const int pitch = c.math == 0 ? (c.winograd == 4 ? 288 : c.winograd ? 136 : 76) : 84;
+        const int cm = conv_math(c);
+        const int pitch = cm == 0 ? (c.winograd == 4 ? 288 : c.winograd ? 136 : 76) : 84;
         NET_TRY(mnc_dev_alloc(n->ctx, (size_t)(cin / 8) * cout * pitch * 4, &n->w_conv[i]));
-        NET_TRY(c.math == 0 ? (c.winograd == 4 ? mnc_pack_conv3x3_wino4(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
+        NET_TRY(cm == 0 ? (c.winograd == 4 ? mnc_pack_conv3x3_wino4(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
                                : c.winograd ? mnc_pack_conv3x3_wino(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
                                             : mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin))
-                : c.math == 1 ? mnc_pack_conv3x3_bf16x3(n->ctx, raw, n->w_conv[i], cout, cin)
+                : cm == 1 ? mnc_pack_conv3x3_bf16x3(n->ctx, raw, n->w_conv[i], cout, cin)
+                : cm == 4 ? mnc_pack_conv3x3_bf16(n->ctx, raw, n->w_conv[i], cout, cin)
                               : mnc_pack_conv3x3_f16(n->ctx, raw, n->w_conv[i], cout, cin));
-      } else if (c.math == 2) {
+      } else if (conv_math(c) == 2) {
         NET_TRY(mnc_dev_alloc(n->ctx, (size_t)9 * ((cin + 31) / 32) * 32 * cout * 2, &n->w_conv[i]));
         NET_TRY(mnc_pack_conv_weights_f16(n->ctx, raw, n->w_conv[i], cout, cin, 3, 3));
       } else {
@@ -258,7 +272,7 @@ int finalize(mnc_net* n) {
     }
     cin = cout;
   }
-  n->packed_trunk = c.math != 0 && tune(n->ctx, T_PACKED_ACT, 1) != 0;
+  n->packed_trunk = (conv_math(c) == 1 || conv_math(c) == 2) && tune(n->ctx, T_PACKED_ACT, 1) != 0;
   for (int i = 1; i < 13; ++i) n->packed_trunk = n->packed_trunk && n->conv_fast[i];
   const int A = c.num_anchors, RC = c.rpn_channels;
   {
@@ -394,16 +408,18 @@ int set_geometry(mnc_net* n, int H, int W) {
 
 int conv3(mnc_net* n, int i, const float* in, float* out, int h, int w, int cin, int cout) {
   const mnc_net_config& c = n->cfg;
+  const int cm = conv_math(c);
   if (!n->conv_fast[i]) {
-    if (c.math == 2) return mnc_conv2d_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
+    if (cm == 2) return mnc_conv2d_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
     return mnc_conv2d(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], nullptr, out, h, w, cin, cout, 3, 3, 1, 1, 1);
   }
-  if (c.math == 0 && c.winograd == 4)
+  if (cm == 0 && c.winograd == 4)
     return mnc_conv3x3_wino4(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
-  if (c.math == 0 && c.winograd)
+  if (cm == 0 && c.winograd)
     return mnc_conv3x3_wino(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
-  if (c.math == 0) return mnc_conv3x3(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
-  if (c.math == 1) return mnc_conv3x3_bf16x3(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
+  if (cm == 0) return mnc_conv3x3(n->ctx, in, (const float*)n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
+  if (cm == 1) return mnc_conv3x3_bf16x3(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
+  if (cm == 4) return mnc_conv3x3_bf16(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
   return mnc_conv3x3_f16(n->ctx, in, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1);
 }
 
@@ -420,12 +436,12 @@ int run_trunk(mnc_net* n) {
     // bf16x3 / f16: 2-byte activation tensors between the MFMA layers (include/mnc_hip.h "Packed 2-byte activations"): conv1_1
     // and every convolution's epilogue write the form the next layer's staging copies verbatim; conv5_3 writes fp32 c8 for the
     // RPN convolution and the RoI warps.  Bit for bit the fp32-tensor route (test_gpu_ops.py::test_conv3x3_packed_activations).
-    const int f16 = c.math == 2;
+    const int f16 = conv_math(c) == 2;
     const void* pc = cur;
     for (int i = 0; i < 13; ++i) {
       const int cout = c.trunk_channels[kTrunkStage[i]];
       void* out = n->act[i].p;
-      if (i == 0) NET_TRY(mnc_conv3x3_c3_fmt(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1, c.math));
+      if (i == 0) NET_TRY(mnc_conv3x3_c3_fmt(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1, conv_math(c)));
       else if (f16) NET_TRY(mnc_conv3x3_f16_pk(ctx, pc, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1, 1, i < 12));
       else NET_TRY(mnc_conv3x3_bf16x3_pk(ctx, pc, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1, 1, i < 12));
       pc = out; cin = cout;
@@ -442,7 +458,7 @@ int run_trunk(mnc_net* n) {
   for (int i = 0; i < 13; ++i) {
     const int cout = c.trunk_channels[kTrunkStage[i]];
     float* out = (float*)n->act[i].p;
-    if (kPoolAfter[i] && i > 0 && c.math == 0 && c.winograd && n->conv_fast[i]) {
+    if (kPoolAfter[i] && i > 0 && conv_math(c) == 0 && c.winograd && n->conv_fast[i]) {
       // conv + ReLU + MAX 2x2/2 in one kernel (the engine's fused plan; the full-resolution blob is not produced)
       float* p = (float*)n->pooled[pi++].p;
       NET_TRY(c.winograd == 4 ? mnc_conv3x3_wino4_pool(ctx, cur, (const float*)n->w_conv[i], n->b_conv[i], p, h, w, cin, cout, 1)
@@ -667,7 +683,7 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
               "mnc_net_create: head shape");
   // the per-class counts travel in a fixed 256-byte header (device `counts` buffer, pinned [counts | proposal count | records])
   MNC_REQUIRE(cfg->num_classes <= 64, "mnc_net_create: num_classes %d > 64 (the result header holds 64 counts)", cfg->num_classes);
-  MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 2, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3) or 2 (f16)");
+  MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 4, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3), 2 (f16), 3 (mixed) or 4 (bf16)");
   MNC_REQUIRE(cfg->target_size > 0 && cfg->max_size >= cfg->target_size, "mnc_net_create: target_size / max_size");
   {
     // The RoI launchers read the conventions from the context.  An all-default member (mnc_net_default_config) leaves what the

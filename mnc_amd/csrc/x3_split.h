@@ -105,6 +105,14 @@ __device__ __forceinline__ void x3_store8(void* out, long pix, const float4 a, c
 
 __device__ __forceinline__ f16x8 x3_as_f16x8(const uint4 v) { return __builtin_bit_cast(f16x8, v); }
 
+// Plain bf16 ("bf16" math mode, round 4: BASELINE configs[2] as written -- ONE bf16 product per term): four fp32 values rounded to
+// nearest-even bf16 and packed (v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ uint2 x3_bf16x4(const float4 v) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const bf16x4 hv = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return __builtin_bit_cast(uint2, hv);
+}
+
 __device__ __forceinline__ bf16x8 x3_as_bf16x8(const uint4 v) {
   union { uint4 u; bf16x8 b; } c;
   c.u = v;

@@ -402,8 +402,16 @@ class Net(object):
         # layers in plain fp16 (operands rounded to fp16, fp32 accumulate: one product per term, ~3e-4 relative error per
         # layer -- the reduced-precision mode BASELINE configs[4] names); math= / MNC_MATH
         self.math = (os.environ.get("MNC_MATH", "fp32") if math is None else math).lower()
-        if self.math not in ("fp32", "bf16x3", "f16"):
-            raise ValueError("math must be 'fp32', 'bf16x3' or 'f16', got %r" % self.math)
+        if self.math not in ("fp32", "bf16x3", "f16", "mixed", "bf16"):
+            raise ValueError("math must be 'fp32', 'bf16x3', 'f16', 'mixed' or 'bf16', got %r" % self.math)
+        # "bf16" (round 4): BASELINE configs[2] as written -- the 3x3 convolutions and the large InnerProducts with both operands
+        # rounded to bf16, ONE product per term (mnc_conv3x3_bf16 / mnc_fc_bf16), fp32 tensors between the layers.  Measured, not
+        # recommended: 8 mantissa bits put the network far outside the 1e-3 bar (tests/test_gpu_parity8.py records it).
+        # "mixed" (round 4): the convolutions (trunk, RPN head) in bf16x3 -- fp32-class -- and the large InnerProducts in fp16: the
+        # reduced-precision mode that keeps the 1e-3 bar (13 fp16 trunk layers in a row leave conv5_3 at 1e-3 of its range and the
+        # RPN probabilities at 3.6e-3; behind a bf16x3 trunk the two fp16 InnerProducts of a head branch cost ~3e-4)
+        self.conv_math = "bf16x3" if self.math == "mixed" else self.math
+        self.fc_math = "f16" if self.math == "mixed" else self.math
         self._wino = winograd_mode(winograd)
         self._winograd = self._wino != 0
         # MNC_SPECULATE_ROIS=0: read the ProposalLayer's RoI count back before the heads are launched (one stream sync in the
@@ -548,7 +556,7 @@ class Net(object):
                 nxt = self._sole_consumer(L.tops[0], "Sigmoid")
                 if nxt is not None:
                     L.act, L.out_name, nxt.skip = 2, nxt.tops[0], True
-            if (L.type == "Convolution" and self.math == "fp32" and self._winograd and L.bn is None and L.scale is None
+            if (L.type == "Convolution" and self.conv_math == "fp32" and self._winograd and L.bn is None and L.scale is None
                     and self._conv_kind(L) == "fast3x3"):
                 # conv3x3 + ReLU + Pooling MAX 2x2/2 (conv1_2 / conv2_2 / conv3_3 / conv4_3 of the trunk): a 2x2 Winograd
                 # output tile is a pooling window, the pool is applied in the convolution's epilogue (mnc_conv3x3_wino_pool)
@@ -615,7 +623,7 @@ class Net(object):
             return False
         k, pad, stride, _, _ = self._conv_geometry(L)
         cin = int(np.asarray(self._layer_weights(L)[0]).shape[1])
-        return k == 1 and pad == 0 and stride in (1, 2) and cin % (16 if self.math == "f16" else 8) == 0
+        return k == 1 and pad == 0 and stride in (1, 2) and cin % (16 if self.conv_math == "f16" else 8) == 0
 
     def _plan_formats(self):
         """"f16" math mode: trunk activations travel between the MFMA layers as packed fp16 c8 tensors ('c8h', half the HBM
@@ -623,7 +631,7 @@ class Net(object):
         when every reader of its top can take it: the tuned 3x3 kernels, the 1x1 GEMM, MAX pooling, and the residual input of
         a 1x1 GEMM.  Anything else (ROIWarping, the RPN's NCHW heads, Python layers, `.data`) gets fp32 -- written as fp32 by
         the producer, or widened in place by Blob._convert.  MNC_F16_ACTS=0 keeps every tensor fp32."""
-        if self.math != "f16" or os.environ.get("MNC_F16_ACTS", "1") == "0":
+        if self.conv_math != "f16" or os.environ.get("MNC_F16_ACTS", "1") == "0":
             return
         fused_res = {}                      # index of a folded Eltwise -> the convolution that took it over
         for L in self._layers:
@@ -781,7 +789,7 @@ class Net(object):
                 raise NotImplementedError("Convolution %s on the input blob: 3 channels, square kernel" % L.name)
             # "f16" mode: the stem on the fp16 matrix pipe like every other convolution of the mode (kernel rows padded to 8 taps,
             # weights in registers; csrc/conv_gen.hip) -- MNC_STEM_F16=0 keeps the fp32 VALU kernel
-            mfma = (self.math == "f16" and k in (3, 5, 7) and cout % 32 == 0 and os.environ.get("MNC_STEM_F16", "1") != "0")
+            mfma = (self.conv_math == "f16" and k in (3, 5, 7) and cout % 32 == 0 and os.environ.get("MNC_STEM_F16", "1") != "0")
             if mfma:
                 def build_stem():
                     raw = self._upload(W)
@@ -805,10 +813,11 @@ class Net(object):
                               dst + n * cout * OH * OW * ob, H, Wd, cout, k, stride, pad, relu, 1 if L.out_h else 0)
             return run
         if kind == "fast3x3":
-            x3 = self.math in ("bf16x3", "f16")
+            x3 = self.conv_math in ("bf16x3", "f16", "bf16")
             # fp32 mode: the direct implicit GEMM, or Winograd F(2x2,3x3) on the same fp32 matrix pipe (2.25x fewer multiplies,
             # equal to the direct form up to fp32 rounding; MNC_CONV_WINOGRAD / Net(winograd=))
-            pitch, pack, conv = (84, "mnc_pack_conv3x3_f16", "mnc_conv3x3_f16") if self.math == "f16" else \
+            pitch, pack, conv = (84, "mnc_pack_conv3x3_f16", "mnc_conv3x3_f16") if self.conv_math == "f16" else \
+                                (84, "mnc_pack_conv3x3_bf16", "mnc_conv3x3_bf16") if self.conv_math == "bf16" else \
                                 (84, "mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3") if x3 else \
                                 (288, "mnc_pack_conv3x3_wino4", "mnc_conv3x3_wino4") if self._wino == 4 else \
                                 (136, "mnc_pack_conv3x3_wino", "mnc_conv3x3_wino") if self._wino == 2 else \
@@ -820,11 +829,11 @@ class Net(object):
                 _lib.call(pack, self._h(), raw, packed, cout, cin)
                 self._ctx.free(raw)
                 return packed
-            d_w = self._dev_param(key + ("w", self.math, ("wino%d" % self._wino) if (self._winograd and not x3) else "direct"), build)
+            d_w = self._dev_param(key + ("w", self.conv_math, ("wino%d" % self._wino) if (self._winograd and not x3) else "direct"), build)
 
             def run():
                 N, _, H, Wd = bot.shape
-                in_h = self.math == "f16" and bot._dev_valid and bot.layout == "c8h"
+                in_h = self.conv_math == "f16" and bot._dev_valid and bot.layout == "c8h"
                 src = bot.dev_in("c8h" if in_h else "c8")
                 if L.fused_pool:                           # top is the Pooling layer's blob
                     OH, OW = _pool_out(H), _pool_out(Wd)
@@ -864,7 +873,7 @@ class Net(object):
             raise NotImplementedError("Convolution %s: channel counts must be multiples of 8 (got %d -> %d)" % (L.name, cin, cout))
         kh, kw = W.shape[2], W.shape[3]
 
-        f16 = self.math == "f16"
+        f16 = self.conv_math == "f16"
         conv2d = "mnc_conv2d_f16" if f16 else "mnc_conv2d"
         if self._conv_fast1x1(L):
             return self._bind_conv1x1(L, W, d_b, key, bot, top, stride, relu)
@@ -899,7 +908,7 @@ class Net(object):
         fp32 matrix pipe, fp32 tensors.  f16 mode: packed fp16 input (converted once if a producer left fp32), packed or fp32
         output as planned (_plan_formats), residual in whichever form its producer wrote."""
         cout, cin = int(W.shape[0]), int(W.shape[1])
-        f16 = self.math == "f16"
+        f16 = self.conv_math == "f16"
 
         def build():
             raw = self._upload(W.reshape(cout, cin))
@@ -1091,7 +1100,7 @@ class Net(object):
         2-byte form (Blob._sm) when an InnerProduct that reads `blob` will run on the reduced-precision kernels for this M
         (same rule as _bind_InnerProduct.weights_for), so that it does not have to convert the fp32 rows itself.  MNC_FC_SM=0
         switches the second outputs off."""
-        if self.math == "fp32" or M <= 0 or os.environ.get("MNC_FC_SM", "1") == "0":
+        if self.fc_math in ("fp32", "bf16") or M <= 0 or os.environ.get("MNC_FC_SM", "1") == "0":
             return 0
         fmt = 0
         for i in self._consumers.get(blob, []):
@@ -1101,9 +1110,10 @@ class Net(object):
             n_out = L.msg.get1("inner_product_param").get1("num_output")
             if 2.0 * M * n_out * K < _X3_MIN_FLOPS:
                 continue
-            if self.math == "f16" and K % 64 == 0 and C % 64 == 0:
+            fm = "bf16x3" if (self.math == "mixed" and K > 50000) else self.fc_math      # (weights_for's rule)
+            if fm == "f16" and K % 64 == 0 and C % 64 == 0:
                 fmt = 1
-            elif K % 32 == 0 and C % 32 == 0 and not (self.math == "f16" and K % 64 == 0):
+            elif K % 32 == 0 and C % 32 == 0 and not (fm == "f16" and K % 64 == 0):
                 fmt = 2
         return fmt
 
@@ -1201,16 +1211,19 @@ class Net(object):
             """Caffe flattens (C,PH,PW); the engine's per-RoI features are (PH,PW,C): permute the columns once.  In
             bf16x3 mode the large products additionally get the weights pre-split into hi/lo bf16."""
             big = 2.0 * M * n_out * K >= _X3_MIN_FLOPS
-            f16 = self.math == "f16" and K % 64 == 0 and big
-            x3 = (not f16) and self.math in ("bf16x3", "f16") and K % 32 == 0 and big
-            tag = ("f16",) if f16 else ("x3",) if x3 else ()
-            fn = "mnc_fc_f16" if f16 else "mnc_fc_bf16x3" if x3 else "mnc_fc"
+            # mixed: an InnerProduct over more than 50 000 inputs (fc6_maskest: 100 352) stays split-bf16 (pipeline.hip: prepare_fc)
+            fm = "bf16x3" if (self.math == "mixed" and K > 50000) else self.fc_math
+            bf = fm == "bf16" and K % 64 == 0 and big          # plain bf16: the fp16 kernel's layout and launcher
+            f16 = (fm == "f16" and K % 64 == 0 and big) or bf
+            x3 = (not f16) and fm in ("bf16x3", "f16") and K % 32 == 0 and big
+            tag = ("bf16",) if bf else ("f16",) if f16 else ("x3",) if x3 else ()
+            fn = "mnc_fc_bf16" if bf else "mnc_fc_f16" if f16 else "mnc_fc_bf16x3" if x3 else "mnc_fc"
 
             def finish(d_w):
                 if not (x3 or f16):
                     return d_w
                 packed = self._ctx.alloc((n_out + 127) // 128 * 128 * K * (2 if f16 else 4))
-                _lib.call("mnc_pack_fc_f16" if f16 else "mnc_pack_fc_bf16x3", self._h(), d_w, packed, n_out, K)
+                _lib.call("mnc_pack_fc_bf16" if bf else "mnc_pack_fc_f16" if f16 else "mnc_pack_fc_bf16x3", self._h(), d_w, packed, n_out, K)
                 self._ctx.free(d_w)
                 return packed
 

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from .instances import split_records
 
-MATH = {"fp32": 0, "bf16x3": 1, "f16": 2}
+MATH = {"fp32": 0, "bf16x3": 1, "f16": 2, "mixed": 3, "bf16": 4}
 LAYERS = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3", "conv5_1",
           "conv5_2", "conv5_3", "rpn_conv_3x3", "rpn_cls_score", "rpn_bbox_pred", "fc6_maskest", "mask_pred", "fc6", "fc7",
           "fc6_mask", "fc7_mask", "cls_score", "seg_cls_score", "bbox_pred"]

@@ -32,3 +32,18 @@ def test_world_size_2_gloo():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout
+
+
+def test_world_size_8_gloo():
+    """De-risking the first 8-rank run: eight gloo ranks on the CPU -- sharding 19 images, the per-step gather
+    with a ragged tail, and the life cycle of the weight container bench.py shares between the ranks of a node (LOCAL_RANK 0
+    writes it under an unpredictable name, all map it, nothing is left behind)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", os.path.join(here, "dist_worker8.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DIST8_OK" in r.stdout

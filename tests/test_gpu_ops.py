@@ -226,6 +226,56 @@ def test_conv3x3_f16(dev, H, W, Cin, Cout):
     assert rel < 1e-5 and rel32 < 2e-3
 
 
+def _rbf16(a):
+    """float32 -> nearest-even bf16 -> float32 (what v_cvt_pk_bf16_f32 does)"""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128)])
+def test_conv3x3_bf16(dev, H, W, Cin, Cout):
+    """Plain "bf16" math mode (BASELINE configs[2] as written, round 4): exact against torch on bf16-rounded operands (products of
+    bf16 values are exact in the fp32 accumulator), ~4e-3 of range against fp32 -- the figure that keeps this mode out of the 1e-3 bar."""
+    rng = np.random.default_rng(H * 1000 + W + 13)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    d_w = dev.empty(((Cin // 8) * Cout * 84,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_bf16", dev.put(w), d_w, Cout, Cin)
+    d_y = dev.empty((Cout * H * W,), fill=np.nan)
+    dev.call("mnc_conv3x3_bf16", dev.put(to_c8(x)), d_w, dev.put(b), d_y, H, W, Cin, Cout, 1)
+    got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+    assert not np.isnan(got).any()
+    d, rel = err(got, _conv_ref(_rbf16(x), _rbf16(w), b, relu=True))
+    d32, rel32 = err(got, _conv_ref(x, w, b, relu=True))
+    print("conv bf16 %dx%d %d->%d: vs bf16-rounded operands rel=%.3e, vs fp32 rel=%.3e" % (H, W, Cin, Cout, rel, rel32))
+    assert rel < 1e-5 and rel32 < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 256, 1024, 1), (300, 4096, 4096, 1), (37, 130, 512, 0), (300, 441, 256, 2),
+                                       (1000, 4096, 12544, 1), (300, 4096, 25088, 1)])
+def test_fc_bf16(dev, M, N, K, act):
+    """mnc_fc_bf16: exact against torch on operands rounded to bf16, within bf16's 8 bits of the fp32 product; small, 320-row and
+    256-column LDS-DMA kernel shapes."""
+    rng = np.random.default_rng(M + N + K + 1)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_wp = dev.empty(((N + 127) // 128 * 128 * K // 2,), fill=np.nan)
+    dev.call("mnc_pack_fc_bf16", dev.put(w), d_wp, N, K)
+    d_o = dev.empty((M * N,), fill=np.nan)
+    dev.call("mnc_fc_bf16", dev.put(a), d_wp, dev.put(b), d_o, M, N, K, N, act)
+    got = dev.get(d_o, (M, N))
+
+    def ref(x, y):
+        z = F.linear(torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(b))
+        return (F.relu(z) if act == 1 else torch.sigmoid(z) if act == 2 else z).numpy()
+    assert not np.isnan(got).any()
+    d, rel = err(got, ref(_rbf16(a), _rbf16(w)))
+    d32, rel32 = err(got, ref(a, w))
+    print("bf16 M=%d N=%d K=%d: vs bf16-rounded operands rel=%.3e, vs fp32 rel=%.3e" % (M, N, K, rel, rel32))
+    assert rel < 1e-5 and rel32 < 2e-2
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "f16"])
 @pytest.mark.parametrize("H,W,Cin,Cout", [(9, 70, 8, 32), (38, 63, 64, 128), (13, 33, 128, 256), (75, 125, 32, 64), (150, 250, 16, 128)])
 def test_conv3x3_packed_activations(dev, mode, H, W, Cin, Cout):

@@ -29,20 +29,21 @@ from mnc_amd import models, synth
 from mnc_amd.native_net import NativeNet
 from oracle import host as ohost
 from oracle import net as onet
-from test_gpu_engine import F16_TOL, FP32_TOL, NUMPY_SIMD_EXP, X3_TOL, _log
+from test_gpu_engine import BF16_TOL, F16_TOL, FP32_TOL, MIXED_TOL, NUMPY_SIMD_EXP, X3_TOL, _log
 
 pytestmark = pytest.mark.gpu
 mnc_amd.install_paths()
 
 SEEDS = tuple(range(8))
-# set from the first recorded run (profiles/r03_parity_report_v1.txt) with margin; they guard against a regression, the figures
-# themselves are the result
-# first recorded run: fp32 300/300 rois on every image, 100/100 instances matched, 0-2 of 44100 mask cells off by > 1e-3;
-# bf16x3 290-299 rois, 98-100 instances matched
-# (f16 does not claim the 1e-3 bar: its floors only guard against a collapse)
-# (recorded f16 run: no `rois` row within 0.01 px -- its RPN deltas differ by 1e-3 of their range --, 78-92 of 100 instances matched)
-FLOOR_ROIS = {"fp32": 295, "bf16x3": 280, "f16": 0}
-FLOOR_MATCHED = {"fp32": 0.97, "bf16x3": 0.9, "f16": 0.6}
+# Floors = the recorded figures (profiles/r04_parity_report*.txt; VERDICT r3: the old floors -- 295 rois, 97 % matched -- would also
+# have passed a much worse run).  fp32 (F(4x4,3x3) trunk since round 4): 300 / 300 rois and 100 / 100 instances matched on every one
+# of the eight images; mask cells off by > 1e-3: 0-4 of 44100 on seven images, 392 on one (seed 0: one flipped `> 0.4` bound of mv moves
+# a box edge by a pixel and the resampled mask with it) -- the ceiling below is per image and leaves room for ONE such flip.
+# bf16x3: 290-299 rois, 98-100 matched.  f16 does not claim the 1e-3 bar (no `rois` row within 0.01 px, 78-92 of 100 matched): its
+# floors only guard against a collapse; the mode that does claim it is "mixed" (below).
+FLOOR_ROIS = {"fp32": 300, "bf16x3": 288, "f16": 0, "mixed": 285, "bf16": 0}            # mean over the eight images
+FLOOR_MATCHED = {"fp32": 1.0, "bf16x3": 0.97, "f16": 0.6, "mixed": 0.95, "bf16": 0.3}
+CEIL_CELLS_OFF = {"fp32": 0.01, "bf16x3": 0.06, "f16": 1.0, "mixed": 0.15, "bf16": 1.0}  # fraction of the matched instances' mask cells, per image
 _cache = {}
 
 
@@ -118,15 +119,15 @@ def _free_running(o, got_m, got_b, dev_rois, dev_rois_ext):
                 max_box=max_box)
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16", "mixed", "bf16"])
 def test_native_pipeline_vs_oracle_on_the_eight_baseline_images(vgg, math):
     w = vgg
-    tol = {"fp32": FP32_TOL, "bf16x3": X3_TOL, "f16": F16_TOL}[math]
+    tol = {"fp32": FP32_TOL, "bf16x3": X3_TOL, "f16": F16_TOL, "mixed": MIXED_TOL, "bf16": BF16_TOL}[math]
     nat = NativeNet(w, math=math)
     K, R = 21, 300
     lines, stats = [], []
     try:
-        for seed in SEEDS:
+        for seed in (SEEDS[:2] if math == "bf16" else SEEDS):      # (plain bf16 claims nothing: two images record its figures)
             o = _oracle_image(w, seed)
             im, im_info = o["im"], o["im_info"]
             got_m, got_b = nat.detect(im)
@@ -179,3 +180,4 @@ def test_native_pipeline_vs_oracle_on_the_eight_baseline_images(vgg, math):
     # loose floors (the recorded figures are the result; see the module docstring)
     assert np.mean([s["same_rois"] for s in stats]) >= FLOOR_ROIS[math], stats
     assert np.mean([s["matched"] / max(s["n_orc"], 1) for s in stats]) >= FLOOR_MATCHED[math], stats
+    assert max(s["cells_off"] / max(s["cells"], 1) for s in stats) <= CEIL_CELLS_OFF[math], stats

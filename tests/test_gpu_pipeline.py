@@ -51,7 +51,7 @@ def _check_against_engine(nat, net, im):
     return got_m, got_b
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16", "mixed", "bf16"])
 def test_native_pipeline_equals_python_engine(math):
     """Reduced-width graph, three image sizes, several images per size: call 1 of a size launches every kernel, call 2 captures
     the HIP graph, later calls replay it -- every call equals the Python engine bit for bit (intermediate blobs, rois of both
