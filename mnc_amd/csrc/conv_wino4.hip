@@ -16,23 +16,35 @@
 //   * the contraction over input channels of each of the 36 transform positions is a GEMM  M_p[co][tile] += U_p[co][ci] V_p[ci][tile]
 //     on v_mfma_f32_16x16x4_f32: A = U (lane: co = l & 15, k = l >> 4), B = V (lane: tile = l & 15, k = l >> 4), D: lane holds
 //     co = 4 (l >> 4) + e of tile l & 15.  A wave owns 16 output channels x 16 tiles (one tile row: 4 pixel rows x 64 columns)
-//     x ALL 36 positions: 144 accumulator registers, two waves per SIMD; the output transform is per lane, in registers.
-//   * K is walked in 8-channel blocks.  Lane (tile t, k) transforms the 6x6 window of ITS tile for channels 2k and 2k + 1
-//     (36 ds_read_b64, 2 x 144 fma) and feeds 72 MFMAs: MFMA g of a position multiplies channels 2k + g over the four lane groups.
-//   * workgroup = 8 waves = 2 channel groups x 4 tile rows = 32 output channels x 64 tiles (16 x 64 pixels).  Per block the
-//     weight panel (2 x 64 lanes x 76 floats: 72 values per lane = 36 positions x 2 channels in the lane's fragment order, pitch 76
-//     = 19 x 16 B so that every 16-lane group of a ds_read_b128 covers all 64 banks; stored in global memory exactly as it sits
-//     in LDS) and the 18 x 66 pixel halo go global -> LDS by buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass),
-//     double buffered: 2 x 77 KB of LDS, one workgroup per CU.
+//     x ALL 36 positions: 144 accumulator registers (architectural), two waves per SIMD; the output transform is per lane, in
+//     registers.
+//   * K is walked in 8-channel blocks, software-pipelined in HALF blocks: pass (s, g) multiplies channel 2k + g of block s (36
+//     MFMAs) while the wave reads the windows of the next pass's channel (36 ds_read_b64, the other channel of each pair is read
+//     again by its own pass) and transforms them (144 fma) in the registers the previous pass freed -- a pass opens with MFMAs whose
+//     operands are in registers, its transform arithmetic sits between them (7-8 VALU per MFMA).
+//   * workgroup = 4 waves = 2 channel groups x 2 tile rows = 32 output channels x 32 tiles (8 x 64 pixels), 80 KB of LDS, TWO
+//     workgroups per CU (one per-CU workgroup of eight waves with 2 x 77 KB was measured first: 1.85 ms for the trunk against 1.75 --
+//     an 8-block workgroup spends a quarter of its life in a prologue burst and an epilogue nothing overlapped).  LDS = the two HALF
+//     weight panels [g][channel group][lane][36 floats] (lane pitch 144 B = 9 x 16 B: every 16-lane group of a ds_read_b128 covers
+//     all 64 banks; stored in global memory exactly as they sit in LDS) + two halo images (10 x 66 pixels, 22 KB): exactly half a
+//     CU's 160 KB.  Half panel g is read by pass (s, g) only and refilled for block s + 1 right behind the barrier that ends the
+//     pass; halo s is read by passes (s - 1, 1) and (s, 0) and its buffer refilled for block s + 2 in the middle of block s.  All
+//     copies are buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass); two barriers per block.
 //   * halo image in LDS: dense 32-byte pixels (the DMA writes 16-byte pieces back to back), pixel column xh of a row sits in slot
 //     (xh & 3) * 17 + (xh >> 2) and its two 16-byte channel halves are swapped where bit 5 of xh is set.  Window column c of tile t
 //     is pixel 4 t + c: for a fixed c the 16 tiles of a wave read slots 17 (c & 3) + t (+ 1) -- consecutive 32-byte pixels -- and
 //     tiles t, t + 8 (whose pixels are 256 bytes = all 64 banks apart) read opposite halves: each 32-lane group of a
 //     ds_read_b64 covers the 64 banks exactly once.  Out-of-image pixels, pad slots and rows past the halo are buffer loads with an
-//     out-of-range offset: the hardware writes zeros.
+//     out-of-range offset: the hardware writes zeros.  (tests/test_wino4_index_math.py emulates all of this on the CPU.)
 //   * epilogue: A^T M A per lane (100 fma per output channel), + bias, ReLU, optionally the following Pooling MAX 2x2/2 (a 4x4
 //     tile holds four whole pooling windows), 16-byte stores into the c8 layout; K ranges write raw partial outputs (the transform
 //     is linear) that wino4_section_reduce_kernel finishes.
+// What it costs (kernel_bench convwino4 ablations, 13-layer trunk, MI355X): all 1.75 ms; without the output stores 1.62; without
+// window reads + transform arithmetic 1.46; without copies / barriers / weight reads as well 1.17; MFMAs alone 1.04 (the 100
+// executed GFLOP at the ~1.9 GHz the part sustains under fp32 MFMAs: 0.80).  F(2x2,3x3) (conv_wino.hip): 2.13 ms.
+// Built and measured on the way (git history): one 8-wave workgroup per CU with whole-block buffers, transform before the MFMAs
+// (1.85 ms) and half-block pipelined (1.94); one wave per SIMD owning 32 channels x 16 tiles = 288 accumulators (hipcc shuttles
+// them between the AGPR and VGPR halves of the file: 2.09).
 #include <atomic>
 
 #include "mnc_internal.h"
@@ -90,7 +102,7 @@ __device__ __forceinline__ void f4_at(float m0, float m1, float m2, float m3, fl
 // tiles [0, pix_a) with ksplit_a K ranges each, the blocks behind them the remaining tiles with ksplit_b ranges.  A tile with one
 // range writes the finished output; with several, each range writes raw partial outputs to its plane of `part`.
 // ABL (tuning builds only, wrong results): 1 no DMA inside the loop, 2 no halo reads (opaque register constants), 4 no input
-// transform, 8 no weight-fragment reads, 16 no wait / barrier -- what each part of a block costs (kernel_bench convwino4, MNC_WINO_F4).
+// transform, 8 no weight-fragment reads, 16 no wait / barrier, 32 no output stores -- what each part of a block costs (kernel_bench convwino4, MNC_WINO_F4).
 template <int XCD, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, float* __restrict__ out,
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     for (int j = 0; j < 4; ++j)
       f4_at(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j][e], y[1][j][e], y[2][j][e], y[3][j][e]);
   }
-  if (oy >= H || ox >= W) return;
+  if ((ABL & 32) && relu != 12345) return;           // ablation: no stores (the condition keeps the transform arithmetic alive)
   const bool fin = ksplit == 1;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (fin) bv = *reinterpret_cast<const float4*>(bias + cbase);
@@ -328,16 +340,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   const long cplane = (long)(cbase >> 3);
   const int chalf = ((cbase >> 2) & 1) * 4;
   if (!pool) {
+    // Full-resolution output (or a K range's partial outputs).  A lane holds 4 channels of a 4x4 pixel tile -- 16 bytes of every
+    // second 32-byte pixel segment, 128 bytes from its neighbour tile's: stored from there a wave instruction touches 32 cache
+    // lines with 32 bytes each (kernel_bench convwino4: the stores cost 0.13 of the trunk's 1.75 ms).  The wave's outputs are 8 runs
+    // of 2 KB in memory -- (8-channel block, pixel row) x 64 pixels x 32 B -- so they go through the wave's own 16 KB of LDS (the
+    // loop's buffers are free: every copy has landed, every wave is past the barrier): written as 16-byte chunks in memory order,
+    // chunk C = 8 t + 2 j + half at position C ^ (t & 7) (the eight lanes of a ds_write_b128 group then hit eight different
+    // 16-byte bank groups), read back a kilobyte per instruction (lane L: chunk 64 m + L, conflict-free under the same XOR) and
+    // stored as eight whole cache lines.
+    __syncthreads();                                 // (all waves' copies -- the dead ones behind the last block too -- have landed)
+    typedef __attribute__((address_space(3))) char* lds_p;
+    const lds_p reg = (lds_p)(__attribute__((address_space(3))) char*)s_f4 + wave * 16384;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int yy = oy + i, xx = ox + j;
-        if (yy < H && xx < W) {
-          float4 o = make_float4(y[i][j][0] + bv.x, y[i][j][1] + bv.y, y[i][j][2] + bv.z, y[i][j][3] + bv.w);
-          if (relu && fin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-          *reinterpret_cast<float4*>(dst + ((cplane * H + yy) * W + xx) * 8 + chalf) = o;
-        }
+        float4 o = make_float4(y[i][j][0] + bv.x, y[i][j][1] + bv.y, y[i][j][2] + bv.z, y[i][j][3] + bv.w);
+        if (relu && fin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        const int C = 8 * t + 2 * j + (k & 1);
+        *(__attribute__((address_space(3))) f32x4*)(reg + ((k >> 1) * 4 + i) * 2048 + (C ^ (t & 7)) * 16) = f32x4{o.x, o.y, o.z, o.w};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes are complete (LDS operations of a wave run in order)
+    const long cpl0 = (long)((cot * 32 + cg * 16) >> 3);
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int C = 64 * m + lane;
+        const f32x4 v = *(__attribute__((address_space(3))) const volatile f32x4*)(reg + sg * 2048 + (C ^ ((C >> 3) & 7)) * 16);
+        const int yy = oy + (sg & 3), xx = w0 + (C >> 1);
+        if (yy < H && xx < W)
+          *reinterpret_cast<f32x4*>(dst + (((cpl0 + (sg >> 2)) * H + yy) * W + xx) * 8 + (C & 1) * 4) = v;
       }
   } else {
     // the following Pooling MAX 2x2 stride 2 (test.prototxt:69-79, ...; Caffe's ceil rule: the last window of an odd-sized map
@@ -515,7 +548,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #ifdef MNC_TUNING
   switch (tune(ctx, T_WINO_F4, 0)) {
 #define MNC_F4_ABL(A) case A: kern = conv3x3_wino4_kernel<1, A>; break;
-    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31)
+    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63)
 #undef MNC_F4_ABL
     default: break;
   }

@@ -202,3 +202,41 @@ def test_whole_kernel_emulation_equals_the_direct_convolution(H, W, Cin, Cout):
                         got[cbase + e, oy + i, ox + j] = Y[i, j]
     assert not np.isnan(got).any()
     assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+
+
+def test_epilogue_lds_round_trip_puts_every_chunk_where_memory_wants_it():
+    """Full-resolution epilogue: lane (t, k) writes the 16-byte chunk of (row i, pixel j) to position C ^ (t & 7), C = 8 t + 2 j + (k & 1),
+    of run ((k >> 1) * 4 + i); lane L then reads chunk 64 m + L of each run from position C ^ ((C >> 3) & 7) and stores it at pixel
+    C >> 1, half C & 1.  Every chunk must come back as the one memory expects there, and both sides must be free of bank conflicts
+    (ds_write_b128: groups of 8 consecutive lanes, 32 banks; ds_read_b128: the four 16-lane groups, 64 banks)."""
+    lds = {}
+    for lane in range(64):
+        t, k = lane & 15, lane >> 4
+        for i, j in itertools.product(range(4), range(4)):
+            C = 8 * t + 2 * j + (k & 1)
+            pos = ((k >> 1) * 4 + i, C ^ (t & 7))
+            assert pos not in lds
+            lds[pos] = (t, k, i, j)
+    assert len(lds) == 8 * 128
+    for sg, m, lane in itertools.product(range(8), range(2), range(64)):
+        C = 64 * m + lane
+        t, k, i, j = lds[(sg, C ^ ((C >> 3) & 7))]
+        assert (4 * t + j, k & 1) == (C >> 1, C & 1) and (k >> 1, i) == (sg >> 2, sg & 3)
+    for i, j, k in itertools.product(range(4), range(4), range(4)):           # writes: 8 consecutive lanes (same k: t = 8 g .. 8 g + 7)
+        for g in range(2):
+            banks = set()
+            for t in range(8 * g, 8 * g + 8):
+                C = 8 * t + 2 * j + (k & 1)
+                a = ((k >> 1) * 4 + i) * 2048 + (C ^ (t & 7)) * 16
+                banks |= {(a // 4 + d) % 32 for d in range(4)}
+            assert len(banks) == 32
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+    groups += [[l + 32 for l in g] for g in groups]
+    for m in range(2):
+        for g in groups:
+            banks = []
+            for lane in g:
+                C = 64 * m + lane
+                a = (C ^ ((C >> 3) & 7)) * 16
+                banks += [(a // 4 + d) % 64 for d in range(4)]
+            assert len(set(banks)) == 64
