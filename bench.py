@@ -100,7 +100,7 @@ def parse():
                         "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
                         "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
                         "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
-    p.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4],
+    p.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
                         "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline)")
@@ -567,6 +567,9 @@ def main():
         if (world == 1 and not launched and args.config == "vgg16" and math == "fp32" and not args.no_resnet
                 and not args.no_alt_math):
             out["config_resnet50"] = resnet50_line()
+            # the same configuration in the reduced-precision mode that keeps the 1e-3 bar (3x3 convolutions bf16x3, 1x1 / stem fp32,
+            # InnerProducts fp16): what configs[4] costs when the parity claim is kept
+            out["config_resnet50_mixed"] = resnet50_line("mixed")
         emit(out)
     if launched:
         dist.barrier()
@@ -639,6 +642,8 @@ def compact_line(out):
             else "error"
         if "math" in out["config_resnet50"].get("config", {}):
             alt["resnet50_math"] = out["config_resnet50"]["config"]["math"]
+    if isinstance(out.get("config_resnet50_mixed"), dict) and "value" in out["config_resnet50_mixed"]:
+        alt["resnet50_mixed"] = _r(out["config_resnet50_mixed"]["value"])
     if alt:
         line["images_per_s_other_protocols"] = alt
     ranks = out.get("ranks") or []
@@ -715,13 +720,13 @@ def shared_weights(proto, synth, rank, world, dist):
     return w
 
 
-def resnet50_line():
-    """BASELINE configs[4] (ResNet-50 C4 trunk, 800x1333, 1000 proposals, fp16 math) measured with the same step and schema by a
-    child process of this file, so that the driver's plain `python bench.py` line carries it too.  -> the child's JSON line,
-    reduced to the fields that identify and size the measurement (or {"error": ...})."""
+def resnet50_line(math=None):
+    """BASELINE configs[4] (ResNet-50 C4 trunk, 800x1333, 1000 proposals; fp16 math as the configuration names it, or `math`)
+    measured with the same step and schema by a child process of this file, so that the driver's plain `python bench.py` line
+    carries it too.  -> the child's JSON line, reduced to the fields that identify and size the measurement (or {"error": ...})."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--config", "resnet50", "--steps", "40", "--warmup", "5",
-           "--no-cpu-baseline", "--no-resident"]
+           "--no-cpu-baseline", "--no-resident"] + (["--math", math] if math else [])
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]

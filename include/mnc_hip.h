@@ -271,7 +271,7 @@ MNC_API int mnc_conv3x3_wino_pool(mnc_ctx* ctx, const float* d_in_c8, const floa
  * 16 channels x 16 tiles; four-wave workgroups with half of a CU's LDS each, two per CU.  The transforms carry the coefficients 2, 4, 5, 8 and 1/6, 1/12, 1/24 (filter side, evaluated in double,
  * rounded once): rounding error ~1e-5 of the output range at 512 input channels (F(2x2): ~1e-6; both inside the kernels' 1e-4
  * bar).  d_w_packed from mnc_pack_conv3x3_wino4: Caffe [Cout][Cin][3][3] -> [Cin/8][Cout/32][2][2][64][36] floats (Cin*Cout*36 floats).
- * Cin%8==0, Cout%32==0, H*W*8 < 2^31.  _pool: the following Pooling MAX 2x2/2 in the epilogue (a 4x4 tile is four windows). */
+ * Cin%8==0, Cout%32==0; the input tensor and the packed weights each below 2 GB (32-bit buffer offsets; beyond that mnc_conv3x3_wino).  _pool: the following Pooling MAX 2x2/2 in the epilogue (a 4x4 tile is four windows). */
 MNC_API int mnc_pack_conv3x3_wino4(mnc_ctx* ctx, const float* d_oihw, float* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_wino4(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias, float* d_out_c8,
                               int H, int W, int Cin, int Cout, int relu);

@@ -137,12 +137,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   const int nchunks = (split + 1) * nblk / ksplit - chunk0;
   const long plane = (long)H * W * 8;                              // floats per 8-channel block of the input
 
-  // ---- DMA assignment (fixed per thread).  Halo piece p = wave + 8 i covers LDS bytes [1024 p, 1024 p + 1024) of the halo image:
+  // ---- DMA assignment (fixed per thread).  Halo piece p = wave + 4 i covers LDS bytes [1024 p, 1024 p + 1024) of the halo image:
   // lane L fills 16-byte slot 64 p + L = pixel slot q = 32 p + (L >> 1) (row q / 68, slot q % 68 = a * 17 + b <-> pixel column
-  // xh = 4 b + a), half position L & 1, i.e. it fetches channel half (L & 1) ^ ((xh >> 5) & 1) of that pixel -- or the zero page.
+  // xh = 4 b + a), half position L & 1, i.e. it fetches channel half (L & 1) ^ ((xh >> 5) & 1) of that pixel.
   // Out-of-image pixels, pad slots and rows past the halo carry an out-of-range offset: the buffer load answers them with zeros.
-  // The offsets are rebuilt from (wave, lane) at every copy (a dozen integer operations per piece) instead of living in five
-  // registers through the loop: the loop has none to spare.
   auto halo_off = [&](int i) {
     const int q = 32 * min(wave + 4 * i, kF4HaloPieces - 1) + (lane >> 1);       // (the waves without a sixth piece repeat piece 21)
     const int row = q / kF4RowSlots, sl = q - row * kF4RowSlots;
@@ -153,6 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     const bool ok = row < kF4HaloRows && xh < kF4Cols + 2 && y >= 0 && y < H && x >= 0 && x < W;
     return ok ? ((y * W + x) * 8 + half * 4) * 4 : 0x7FFFFFF0;             // byte offset inside an 8-channel block of the input
   };
+  int h_off[6];                                      // (six registers through the loop: rebuilding them costs 70 VALU per block)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) h_off[i] = halo_off(i);
   // One buffer descriptor per operand (wave-uniform), the block's offset in the scalar soffset, the lane's part in a 32-bit voffset:
   // no 64-bit address registers.  (Inline assembly as in gemm.hip: behind the DMA builtins hipcc makes every later ds_read wait for
   // vmcnt(0).)
@@ -175,30 +176,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   // A copy for a block past the end of this workgroup's K range is still ISSUED, with every lane out of range (no memory traffic,
   // zeros into the free buffer): the loop body stays one basic block with a fixed copy count per barrier -- with branches around
   // the copies hipcc sinks the transform arithmetic of a pass into the blocks behind them, where no MFMA covers it.
-  auto dma_u = [&](int c, int g) {                                 // half panel (channel g) of block c -> its buffer
+  auto dma_u_piece = [&](int c, int g, int i) {                    // piece i (of 5 per wave) of half panel g of block c -> its buffer
     const int voff = c < nchunks ? w_voff : 0x7FFFFFF0;
     const int cb = chunk0 + min(c, nchunks - 1);
     const int wsoff = __builtin_amdgcn_readfirstlane((cb * ncot + cot) * kF4PanelBytes + g * kF4HalfBytes);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      // branch-free: the waves without a fifth piece copy pieces 16 / 17 a second time (same bytes, same place)
-      const int p = min(wave + 4 * i, kF4HalfPieces - 1);
-      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(g * kF4HalfBytes) + (unsigned)p * 1024u);
-      const int so = __builtin_amdgcn_readfirstlane(wsoff + p * 1024);
-      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(w_rsrc), "s"(so), "s"(l) : "memory");
-    }
+    // branch-free: the waves without a fifth piece copy pieces 16 / 17 a second time (same bytes, same place)
+    const int p = min(wave + 4 * i, kF4HalfPieces - 1);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(g * kF4HalfBytes) + (unsigned)p * 1024u);
+    const int so = __builtin_amdgcn_readfirstlane(wsoff + p * 1024);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(w_rsrc), "s"(so), "s"(l) : "memory");
   };
-  auto dma_h = [&](int c, int hbuf) {                              // halo of block c -> halo buffer `hbuf`
+  auto dma_h_piece = [&](int c, int hbuf, int i) {                 // piece i (of 6 per wave) of the halo of block c -> halo buffer `hbuf`
     const bool live = c < nchunks;
     const int cb = chunk0 + min(c, nchunks - 1);
     const int hsoff = __builtin_amdgcn_readfirstlane(cb * (int)(plane * 4));
+    const int p = min(wave + 4 * i, kF4HaloPieces - 1);
+    const int ho = live ? h_off[i] : 0x7FFFFFF0;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kHalo0 + hbuf * kF4HaloBytes) + (unsigned)p * 1024u);
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(ho), "s"(in_rsrc), "s"(hsoff), "s"(l) : "memory");
+  };
+  auto dma_u = [&](int c, int g) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int p = min(wave + 4 * i, kF4HaloPieces - 1);
-      const int ho = live ? halo_off(i) : 0x7FFFFFF0;
-      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kHalo0 + hbuf * kF4HaloBytes) + (unsigned)p * 1024u);
-      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(ho), "s"(in_rsrc), "s"(hsoff), "s"(l) : "memory");
-    }
+    for (int i = 0; i < 5; ++i) dma_u_piece(c, g, i);
+  };
+  auto dma_h = [&](int c, int hbuf) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma_h_piece(c, hbuf, i);
   };
   // wait until at most `left` of this wave's copies are in flight (they complete in issue order), then the workgroup barrier; the
   // "memory" clobber keeps hipcc from moving LDS accesses across it (the copies are invisible to its own wait-count pass)
@@ -273,7 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   };
   // (on entry column 0 of `cur` has its second dimension already -- the previous pass did it under its last MFMAs, so that a pass
   // opens with MFMAs whose operands are in registers)
-  auto pass = [&](int g, float (&cur)[36], int hbuf_next, int g_next, float (&nxt)[36]) {
+  // SPREAD: the copies a pass owes (pass (s, 0): half panel 1 of block s, five pieces per wave; pass (s, 1): half panel 0 of block
+  // s + 1, then the halo of block s + 2, eleven pieces) are issued one or two per column instead of in a burst behind the barrier --
+  // a copy costs its wave 60-180 issue cycles (kernel_bench convwino4, MNC_WINO_F4=1: the loop without copies is 10 % faster,
+  // without waits 2 %), paid where the other wave of the SIMD has MFMAs to issue
+  constexpr bool SPREAD = (ABL & 64) == 0;
+  auto pass = [&](int g, float (&cur)[36], int hbuf_next, int g_next, float (&nxt)[36], int s) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       read_row(hbuf_next, j, g_next, nxt);
@@ -281,6 +289,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
       if (j < 5) ypass_col(cur, j + 1);
       xpass_row(nxt, j);
       if (j == 5) ypass_col(nxt, 0);
+      if (SPREAD && !(ABL & 1)) {
+        if (g == 0) {
+          if (j < 2) { dma_u_piece(s, 1, 2 * j); dma_u_piece(s, 1, 2 * j + 1); }
+          else if (j == 2) dma_u_piece(s, 1, 4);
+        } else {
+          if (j < 2) { dma_u_piece(s + 1, 0, 2 * j); dma_u_piece(s + 1, 0, 2 * j + 1); }
+          else if (j == 2) { dma_u_piece(s + 1, 0, 4); dma_h_piece(s + 2, s & 1, 0); }
+          else if (j < 5) { dma_h_piece(s + 2, s & 1, 2 * j - 5); dma_h_piece(s + 2, s & 1, 2 * j - 4); }
+          else dma_h_piece(s + 2, s & 1, 5);
+        }
+      }
       // nothing moves across a column: left alone hipcc sinks the transform arithmetic behind the copies at the end of the pass,
       // where no MFMA of this wave covers it
       __builtin_amdgcn_sched_barrier(0);
@@ -290,9 +309,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   if (nchunks > 0) {
     dma_u(0, 0);
     dma_h(0, 0);
-    dma_u(0, 1);
+    if (!SPREAD) dma_u(0, 1);
     dma_h(1, 1);
-    MNC_F4_SYNC(11);                                 // half panel 0 and halo 0 of block 0 have landed; 5 + 6 pieces may still fly
+    if (SPREAD) MNC_F4_SYNC(6); else MNC_F4_SYNC(11);   // half panel 0 and halo 0 of block 0 have landed; the rest may still fly
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       read_row(0, r, 0, va);
@@ -301,17 +320,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     ypass_col(va, 0);
     for (int s = 0; s < nchunks; ++s) {
       const int bsel = s & 1;
-      pass(0, va, bsel, 1, vb);
+      pass(0, va, bsel, 1, vb, s);
       pin_acc();
-      // middle of block s: every wave is done with half panel 0 and halo s; half panel 1 (requested at the end of block s - 1) and
-      // halo s + 1 (requested in the middle of block s - 1) have landed -- everything this wave has in flight
+      // middle of block s: every wave is done with half panel 0 and halo s; half panel 1 of this block and halo s + 1 (requested in
+      // the middle of block s - 1) have landed -- everything this wave has in flight
       if (!(ABL & 16)) MNC_F4_SYNC(0);
-      if (!(ABL & 1)) { dma_u(s + 1, 0); dma_h(s + 2, bsel); }
-      pass(1, vb, bsel ^ 1, 0, va);
+      if (!SPREAD && !(ABL & 1)) { dma_u(s + 1, 0); dma_h(s + 2, bsel); }
+      pass(1, vb, bsel ^ 1, 0, va, s);
       pin_acc();
       // end of block s: every wave is done with half panel 1; half panel 0 of block s + 1 has landed, halo s + 2's six may still fly
       if (!(ABL & 16)) MNC_F4_SYNC(6);
-      if (!(ABL & 1)) dma_u(s + 1, 1);
+      if (!SPREAD && !(ABL & 1)) dma_u(s + 1, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dead copies behind the last block write the LDS too: none may outlive the wave)
   }
@@ -519,7 +538,10 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
   MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && d_out, "mnc_conv3x3_wino4: null pointer");
   MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
               "mnc_conv3x3_wino4: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", H, W, Cin, Cout);
-  MNC_REQUIRE((double)H * W * 8.0 < 2147483648.0, "mnc_conv3x3_wino4: map %dx%d too large for 32-bit pixel offsets", H, W);
+  // the operands are addressed through buffer descriptors: 32-bit byte offsets into the whole input tensor and the packed weights
+  MNC_REQUIRE((double)Cin * H * W * 4.0 < 2147483648.0 && (double)Cin * Cout * 36.0 * 4.0 < 2147483648.0,
+              "mnc_conv3x3_wino4: input %d x %dx%d or weights %d x %d beyond 2 GB (32-bit buffer offsets); use mnc_conv3x3_wino", Cin, H, W,
+              Cin, Cout);
   const int ncot = Cout >> 5, blocks = Cin >> 3;
   const int tiles_x = cdiv(W, kF4Cols), pix = tiles_x * cdiv(H, kF4Rows);
   int pix_a, ksplit_a, ksplit_b;
@@ -548,7 +570,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #ifdef MNC_TUNING
   switch (tune(ctx, T_WINO_F4, 0)) {
 #define MNC_F4_ABL(A) case A: kern = conv3x3_wino4_kernel<1, A>; break;
-    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63)
+    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(64) MNC_F4_ABL(65)
 #undef MNC_F4_ABL
     default: break;
   }

@@ -505,7 +505,7 @@ def test_device_image_prep_is_bit_identical_to_the_numpy_path(small):
         assert np.array_equal(v, net.blobs[k]._host_read()), k
 
 
-@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3", "f16", "mixed"])
 def test_resnet50_trunk_graph(math, monkeypatch):
     """SURVEY 8f n4 (BASELINE configs[4]): the cascade on a ResNet-50 C4 trunk (reduced width): stem, folded BatchNorm/Scale,
     strided 1x1 convolutions, MAX 3x3/2 and the residual adds folded into branch2c -- every block output against the unfolded
