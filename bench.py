@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of the MNC 5-stage inference hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config vgg16|resnet50] [--math fp32|bf16x3|f16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config vgg16|resnet50] [--math fp32|bf16x3|f16|mixed|bf16]
 
 `--gpus N` with N > 1 and no launcher in the environment re-executes itself under `python -m torch.distributed.run
 --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, so the plain command really starts N ranks, one per GPU (it fails
@@ -17,24 +17,28 @@ A "step" is one pass of the whole hot path over one synthetic image per GPU, mea
        the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
        device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
 Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
-Round 3: by default every GPU keeps FOUR images in flight (--in-flight 4: one mnc_net + context + stream per image in flight;
-mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 3), because a sixth of an image's GPU time is spent
-in kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- other images' convolutions
-run there (measured, same build and box: 1 -> 200, 2 -> 221, 3 -> 225, 4 -> 227 images/s).  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` in the
-same line is the rounds 1-2 protocol (--in-flight 1 makes it the headline).
-The old protocol (same image resident in HBM, no upload) is reported next to it as `resident_input`.
+Every GPU keeps FOUR images in flight by default (--in-flight 4: one mnc_net + context + stream per image in flight;
+mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 3): a sixth of an image's GPU time is spent in
+kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- other images' convolutions run
+there.  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` is the
+rounds 1-2 protocol (--in-flight 1 makes it the headline).
 
-The headline `value` is measured with fp32 MFMA arithmetic (--math fp32, BASELINE configs[1]); at N = 1 the same run also
-measures BASELINE configs[2] ("bf16 convs via MFMA": bf16x3) and the f16 mode and reports them under `alt_math*`.
-`--config resnet50` measures BASELINE configs[4] (ResNet-50 C4 trunk, 800x1333, 1000 proposals, fp16 math) with the same
-step and the same JSON schema; the default N = 1 run appends that measurement (a child process of this file, 40 steps) as
-`config_resnet50`, so the driver's plain command carries it (--no-resnet skips it).
+OUTPUT (round 4).  The LAST stdout line is ONE compact JSON object, < 4 KB (compact_line): metric .. config, `roofline`,
+`cpu_baseline`, `kernel_ms_per_image`, `conv_roofline`, and one scalar per other protocol / math mode / configuration.  The full
+result -- roofline_by_kernel, alt_math*, config_resnet50*, python_engine, per-rank figures -- is written to bench_detail.json
+(repo root and gpurun_out/).  Round 3's line had grown to 24.5 KB and the driver, which keeps an 8 KB tail, could parse none of it.
 
-One JSON line is printed by rank 0.  `roofline` is computed from HIP events recorded by the engine on ITS stream around
-every launch of the dominant kernel on every --event-every-th step of the timed region (an event pair costs the stream
-about 3 us per bracketed launch -- 0.17 ms per image with all 30 MFMA launches bracketed -- and cannot be captured into
-the HIP graph the library replays by default, so the event steps run as direct launches and the others replay the graph); `cpu_baseline` times the CPU oracle (torch-CPU restatement
-of the graph + the reference's nms/mv code compiled for the CPU when oracle/_ref is present) on the same workload.
+The TIMED REGION holds exactly K steps of the protocol above and nothing else.  `roofline` is computed from HIP events the engine
+records on ITS stream around every launch of the MFMA kernels (mnc_prof_*) during an EVENT PASS that follows the timed region:
+clamp(K / 8, 8, 40) further images (--event-steps), one at a time, as direct launches (an event pair costs the stream ~3 us per
+bracketed launch and cannot be captured into the HIP graph the library replays by default).
+
+The headline `value` is measured with fp32 MFMA arithmetic (--math fp32, BASELINE configs[1]); at N = 1 the same run also measures
+bf16x3, f16, mixed and plain bf16 (BASELINE configs[2] as written) and reports one scalar each (`alt_math*` in the detail file).
+`--config resnet50` measures BASELINE configs[4] (ResNet-50 C4 trunk, 800x1333, 1000 proposals, fp16 math) with the same step and
+schema; the default N = 1 run appends that measurement (child processes of this file, 40 steps: f16 and mixed; --no-resnet skips).
+`cpu_baseline` times the CPU oracle (torch-CPU restatement of the graph + the reference's nms/mv code compiled for the CPU when
+oracle/_ref is present) on the same workload, thread count stated.
 """
 import argparse
 import json

@@ -240,3 +240,73 @@ def test_epilogue_lds_round_trip_puts_every_chunk_where_memory_wants_it():
                 a = (C ^ ((C >> 3) & 7)) * 16
                 banks += [(a // 4 + d) % 64 for d in range(4)]
             assert len(set(banks)) == 64
+
+
+def wino4_plan(pix, ncot, blocks):
+    """csrc/conv_wino4.hip: wino4_plan -- (pix_a, ksplit_a, ksplit_b)"""
+    slots, min_blocks = 512, 4
+    pix_a, ka, kb = pix, 1, 1
+    wgs = pix * ncot
+    smax = max(blocks // min_blocks, 1)
+    if wgs <= slots:
+        best, best_cost = 1, 1e300
+        for s in range(1, min(smax, 8) + 1):
+            per = -(-blocks // s)
+            cost = float(-(-wgs * s // slots)) * per + (1.5 * s if s > 1 else 0.0)
+            if cost < best_cost:
+                best, best_cost = s, cost
+        return pix, best, 1
+    full_pix = (wgs // slots) * slots // ncot
+    rest = (pix - full_pix) * ncot
+    if 0 < rest <= slots * 3 // 4:
+        sb = min(slots // rest, smax, 8)
+        if sb >= 3:
+            pix_a, kb = full_pix, sb
+    return pix_a, ka, kb
+
+
+def decode_block(b, nblocks, pix_a, ncot, ka, kb, tiles_x, xcd):
+    """the kernel's block decode -> (bx, by, cot, split, ksplit)"""
+    n_a = pix_a * ncot * ka
+    total, pix0, ks = n_a, 0, ka
+    if b >= n_a:
+        b, total, pix0, ks = b - n_a, nblocks - n_a, pix_a, kb
+    q, r, x, idx = total >> 3, total & 7, b & 7, b >> 3
+    logical = ((x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + idx) if xcd else b
+    nz = ncot * ks
+    bz, pixt = logical % nz, pix0 + logical // nz
+    return pixt % tiles_x, pixt // tiles_x, bz % ncot, bz // ncot, ks
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", [(600, 1000, 64, 64), (300, 500, 64, 128), (300, 500, 128, 128), (150, 250, 128, 256),
+                                          (150, 250, 256, 256), (75, 125, 256, 512), (75, 125, 512, 512), (38, 63, 512, 512),
+                                          (5, 3, 8, 32), (37, 63, 256, 512)])
+@pytest.mark.parametrize("xcd", [0, 1])
+def test_plan_and_block_order_cover_every_tile_channel_tile_and_k_range_once(H, W, Cin, Cout, xcd):
+    """the launcher's plan (whole tiles + a tail section in K ranges, or a uniform cut) and the kernel's XCD-aware block order
+    together visit every (pixel tile, 32-channel tile, K range) exactly once, and the K ranges of a tile partition its blocks"""
+    ncot, blocks = Cout // 32, Cin // 8
+    tiles_x, tiles_y = -(-W // COLS), -(-H // ROWS)
+    pix = tiles_x * tiles_y
+    pix_a, ka, kb = wino4_plan(pix, ncot, blocks)
+    assert 1 <= ka <= max(blocks, 1) and 1 <= kb <= max(blocks, 1) and 0 < pix_a <= pix
+    nblocks = (pix_a * ka + (pix - pix_a) * kb) * ncot
+    seen = set()
+    for b in range(nblocks):
+        bx, by, cot, split, ks = decode_block(b, nblocks, pix_a, ncot, ka, kb, tiles_x, xcd)
+        assert 0 <= bx < tiles_x and 0 <= by < tiles_y and 0 <= cot < ncot and 0 <= split < ks
+        assert ks == (ka if by * tiles_x + bx < pix_a else kb)
+        seen.add((bx, by, cot, split))
+    assert len(seen) == nblocks
+    for ks in {ka, kb}:                                                    # chunk0 / nchunks of the kernel: a partition of the blocks
+        edges = [s * blocks // ks for s in range(ks + 1)]
+        assert edges[0] == 0 and edges[-1] == blocks and all(b > a for a, b in zip(edges, edges[1:]))
+    # the documented plans at 600 x 1000
+    if (H, W, Cin, Cout) == (150, 250, 256, 256):
+        assert (pix_a, ka, kb) == (64, 1, 5)
+    if (H, W, Cin, Cout) == (75, 125, 512, 512):
+        assert (pix_a, ka, kb) == (pix, 3, 1)
+    if (H, W, Cin, Cout) == (38, 63, 512, 512):
+        assert (pix_a, ka, kb) == (pix, 6, 1)
+    if (H, W, Cin, Cout) == (300, 500, 128, 128):
+        assert (pix_a, ka, kb) == (pix, 1, 1)                               # two ranges do not pay: whole
