@@ -72,28 +72,67 @@ static_assert(kF4HalfPieces * 1024 == kF4HalfBytes, "whole DMA pieces per half p
 static_assert(kF4HaloBytes >= kF4HaloRows * kF4RowBytes, "halo image fits its pieces");
 static_assert(2 * kF4LdsBytes <= 160 * 1024, "conv3x3_wino4: two workgroups per CU");
 
-// One dimension of the input transform, in place: x = B^T d (12 fma / add for 6 values).
-__device__ __forceinline__ void f4_bt(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
-  const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
-  const float c = d4 - d2, e = d3 - d1;
-  const float x0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-  const float x5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
-  d0 = x0;
-  d1 = a + b;
-  d2 = a - b;
-  d3 = fmaf(2.f, e, c);
-  d4 = fmaf(-2.f, e, c);
-  d5 = x5;
+// The input transform runs on PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per instruction and register
+// pair).  kernel_bench convwino4 with MNC_WINO_F4=4 (no transform arithmetic): the scalar transform's 144 VALU instructions per 36
+// MFMAs were 0.35 ms of the trunk's 1.66 ms, by far the largest term next to the MFMAs themselves (window reads 0.03, weight reads
+// 0.02, barriers nothing) -- tools/probes/pk_f32_under_mfma_probe.hip: beside an fp32 MFMA stream EVERY VALU instruction costs the
+// stream about four cycles, packed or not (4 v_fma_f32 per MFMA: 90 TFLOP/s of 137; 2 v_pk_fma_f32: 102), so the count is what
+// matters.  A pair holds window rows 2h and 2h + 1 of one window column.
+//   first dimension (along a window row, two rows at a time): f4_bt2 -- the scalar chain on both halves, 12 instructions per row pair;
+//   second dimension (down a window column = INSIDE the three pairs of that column): f4_bt_in -- 6 instructions per column, the
+//   halves picked by the instructions' op_sel bits (op_sel[i]: which half of source i the LOW result uses, op_sel_hi[i]: the HIGH).
+// Every output is produced by the same operations in the same order as the scalar chain (a + b as fma(b, 1, a): exact).
+// Inline assembly, not vector C++: hipcc's pre-emit peephole UNPACKS a v_pk_*_f32 it finds behind an MFMA into two scalar
+// instructions (two thirds of the vector-typed version of this transform came out scalar, no faster than before).
+struct F4K {                                         // constant pairs in scalar registers (-5 is not an inline constant)
+  unsigned long long m5, m4m1, p1m1, p2m2;
+};
+__device__ __forceinline__ F4K f4_consts() {
+  F4K k;
+  k.m5 = 0xC0A00000C0A00000ull;                      // (-5, -5)
+  k.m4m1 = 0xBF800000C0800000ull;                    // (-4, -1)   (low half first)
+  k.p1m1 = 0xBF8000003F800000ull;                    // ( 1, -1)
+  k.p2m2 = 0xC000000040000000ull;                    // ( 2, -2)
+  asm volatile("" : "+s"(k.m5), "+s"(k.m4m1), "+s"(k.p1m1), "+s"(k.p2m2));   // (opaque: stay in four scalar register pairs)
+  return k;
 }
+__device__ __forceinline__ void f4_bt2(const F4K& K, f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
+  f32x2 a, b, c, e, t0, t5, x0, x1, x2, x3, x4, x5;
+  asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(d2), "v"(d4));
+  asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(b) : "v"(d1), "v"(d3));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(c) : "v"(d4), "v"(d2));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e) : "v"(d3), "v"(d1));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(d2), "s"(K.m5), "v"(d4));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(d3), "s"(K.m5), "v"(d5));
+  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(d0), "v"(t0));
+  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x5) : "v"(d1), "v"(t5));
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(x1) : "v"(a), "v"(b));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x2) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]" : "=v"(x3) : "v"(e), "v"(c));
+  asm("v_pk_fma_f32 %0, %1, -2.0, %2 op_sel_hi:[1,0,1]" : "=v"(x4) : "v"(e), "v"(c));
+  d0 = x0; d1 = x1; d2 = x2; d3 = x3; d4 = x4; d5 = x5;
+}
+// p0 = (d0, d1), p1 = (d2, d3), p2 = (d4, d5) -> p0 = (x0, x5), p1 = (x1, x2), p2 = (x3, x4)
+__device__ __forceinline__ void f4_bt_in(const F4K& K, f32x2& p0, f32x2& p1, f32x2& p2) {
+  f32x2 t, x05, ac, be, x12, x34;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(p1), "s"(K.m5), "v"(p2));                                   // (d4 - 5 d2, d5 - 5 d3)
+  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x05) : "v"(p0), "v"(t));                        // (x0, x5)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(ac) : "v"(p1), "s"(K.m4m1), "v"(p2));   // (a, c) = (d4 - 4 d2, d4 - d2)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(be) : "v"(p0), "s"(K.m4m1), "v"(p1));   // (b, e) = (d3 - 4 d1, d3 - d1)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(x12) : "v"(be), "s"(K.p1m1), "v"(ac));  // (a + b, a - b)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(x34) : "v"(be), "s"(K.p2m2), "v"(ac));  // (c + 2 e, c - 2 e)
+  p0 = x05; p1 = x12; p2 = x34;
+}
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// One dimension of the output transform: y = A^T m (6 values -> 4).
-__device__ __forceinline__ void f4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2,
-                                      float& y3) {
-  const float p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
+// One dimension of the output transform: y = A^T m (6 values -> 4), on pairs (two of a lane's four output channels).
+__device__ __forceinline__ void f4_at2(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32x2 m4, f32x2 m5, f32x2& y0, f32x2& y1, f32x2& y2,
+                                       f32x2& y3) {
+  const f32x2 p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4;
   y0 = (m0 + p) + r;
-  y1 = fmaf(2.f, s, q);
-  y2 = fmaf(4.f, r, p);
-  y3 = fmaf(8.f, s, q) + m5;
+  y1 = fma2(f32x2{2.f, 2.f}, s, q);
+  y2 = fma2(f32x2{4.f, 4.f}, r, p);
+  y3 = fma2(f32x2{8.f, 8.f}, s, q) + m5;
 }
 
 // Block order.  The dispatcher puts block b on XCD b % 8 (used for speed only): blocks are re-numbered so that every XCD gets a
@@ -235,30 +274,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   // both under those MFMAs.  Buffers: half panel g is read by pass (s, g) only and refilled (block s + 1) right behind the barrier
   // that ends that pass -- half a block to land 18 KB; halo s is read by passes (s - 1, 1) and (s, 0), its buffer refilled (block
   // s + 2) behind the barrier in the middle of block s -- a whole block to land.
-  float va[36], vb[36];
-  auto read_row = [&](int hbuf, int r, int g, float (&x)[36]) {
-    const lds_cp sh = lds + hbuf * kF4HaloBytes + r * kF4RowBytes;
+  // Operand registers: x[6 h + c] = the pair (window rows 2h, 2h + 1) of window column c.  After the second dimension of column c
+  // the three pairs of that column hold transform rows (0, 5), (1, 2), (3, 4): kPairOf / kHalfOf.
+  f32x2 va[18], vb[18];
+  const F4K K = f4_consts();
+  auto read_row = [&](int hbuf, int r, int g, f32x2 (&x)[18]) {
+    const lds_cp sh = lds + hbuf * kF4HaloBytes + r * kF4RowBytes + g * 4;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
+      float v;
       if (ABL & 2) {
-        x[r * 6 + c] = 1.f + r + c;
-        asm volatile("" : "+v"(x[r * 6 + c]));
+        v = 1.f + r + c;
+        asm volatile("" : "+v"(v));
       } else {
-        // (volatile: hipcc otherwise pairs neighbouring reads into ds_read2_b64 -- half rate, 32-dword banking; the unused channel
-        // of the pair is read again by the pass that needs it: a ds_read_b64 costs the LDS what a ds_read_b32 does)
-        const f32x2 dv = *(__attribute__((address_space(3))) const volatile f32x2*)(sh + (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544));
-        x[r * 6 + c] = g ? dv.y : dv.x;
+        // one channel of the pixel's pair, straight into its half of the register pair.  (volatile: hipcc otherwise merges
+        // neighbouring reads into ds_read2 forms -- half rate, 32-dword banking.  The 64 lanes of a ds_read_b32 are served as two
+        // groups of 32, k = 0, 1 and k = 2, 3: inside a group the same banks as the ds_read_b64 of the scalar-transform kernel.)
+        v = *(__attribute__((address_space(3))) const volatile float*)(sh + (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544));
       }
+      if (r & 1) x[(r >> 1) * 6 + c].y = v; else x[(r >> 1) * 6 + c].x = v;
     }
   };
-  auto xpass_row = [&](float (&x)[36], int r) {
-    if (!(ABL & 4)) f4_bt(x[r * 6 + 0], x[r * 6 + 1], x[r * 6 + 2], x[r * 6 + 3], x[r * 6 + 4], x[r * 6 + 5]);
+  auto xpass_pair = [&](f32x2 (&x)[18], int h) {
+    if (!(ABL & 4)) f4_bt2(K, x[h * 6 + 0], x[h * 6 + 1], x[h * 6 + 2], x[h * 6 + 3], x[h * 6 + 4], x[h * 6 + 5]);
   };
-  auto ypass_col = [&](float (&x)[36], int j) {
-    if (!(ABL & 4)) f4_bt(x[j], x[6 + j], x[12 + j], x[18 + j], x[24 + j], x[30 + j]);
+  auto ypass_col = [&](f32x2 (&x)[18], int j) {
+    if (!(ABL & 4)) f4_bt_in(K, x[j], x[6 + j], x[12 + j]);
   };
   f32x4 uq[9];
-  auto mfma_col = [&](int g, int j, const float (&x)[36]) {
+  auto mfma_col = [&](int g, int j, const f32x2 (&x)[18]) {
     const lds_cp su = lds + g * kF4HalfBytes + ub;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -271,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
           uq[n >> 2] = *(__attribute__((address_space(3))) const f32x4*)(su + (n >> 2) * 16);
         }
       }
-      acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[n >> 2][n & 3], x[i * 6 + j], acc[i * 6 + j], 0, 0, 0);
+      constexpr int kPairOf[6] = {0, 1, 1, 2, 2, 0}, kHalfOf[6] = {0, 0, 1, 0, 1, 1};
+      const f32x2 pr = x[kPairOf[i] * 6 + j];
+      acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[n >> 2][n & 3], kHalfOf[i] ? pr.y : pr.x, acc[i * 6 + j], 0, 0, 0);
     }
   };
   // (on entry column 0 of `cur` has its second dimension already -- the previous pass did it under its last MFMAs, so that a pass
@@ -281,13 +327,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   // a copy costs its wave 60-180 issue cycles (kernel_bench convwino4, MNC_WINO_F4=1: the loop without copies is 10 % faster,
   // without waits 2 %), paid where the other wave of the SIMD has MFMAs to issue
   constexpr bool SPREAD = (ABL & 64) == 0;
-  auto pass = [&](int g, float (&cur)[36], int hbuf_next, int g_next, float (&nxt)[36], int s) {
+  auto pass = [&](int g, f32x2 (&cur)[18], int hbuf_next, int g_next, f32x2 (&nxt)[18], int s) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       read_row(hbuf_next, j, g_next, nxt);
       mfma_col(g, j, cur);
+      // The column's MFMAs back to back, then its transform arithmetic in one run: the fp32 MFMA and the VALU share the SIMD's
+      // multipliers (the probe above: nothing overlaps) and every change between the two costs about ten cycles.  (Two columns at a
+      // time -- twelve MFMAs, then 24 VALU -- measured 2-3 % slower than this: kernel_bench convwino4, same box.)
+      if (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);
       if (j < 5) ypass_col(cur, j + 1);
-      xpass_row(nxt, j);
+      if (j & 1) xpass_pair(nxt, j >> 1);
       if (j == 5) ypass_col(nxt, 0);
       if (SPREAD && !(ABL & 1)) {
         if (g == 0) {
@@ -315,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       read_row(0, r, 0, va);
-      xpass_row(va, r);
+      if (r & 1) xpass_pair(va, r >> 1);
     }
     ypass_col(va, 0);
     for (int s = 0; s < nchunks; ++s) {
@@ -339,17 +389,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   // ---- epilogue: Y = A^T M A per (output channel, tile); lane: tile t of tile row tg, channels cbase .. cbase + 3 ----
   const int oy = h0 + 4 * tg, ox = w0 + 4 * t;
   const int cbase = cot * 32 + cg * 16 + 4 * k;
-  float y[4][4][4];                                  // [row][column][channel]
+  f32x2 y[4][4][2];                                  // [row][column][channel pair]
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float z[6][4];                                   // column pass: z[r][j] = sum_c M[r][c] A[c][j]
+  for (int e = 0; e < 2; ++e) {
+    f32x2 z[6][4];                                   // column pass: z[r][j] = sum_c M[r][c] A[c][j]
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-      f4_at(acc[r * 6 + 0][e], acc[r * 6 + 1][e], acc[r * 6 + 2][e], acc[r * 6 + 3][e], acc[r * 6 + 4][e], acc[r * 6 + 5][e],
-            z[r][0], z[r][1], z[r][2], z[r][3]);
+    for (int r = 0; r < 6; ++r) {
+      f32x2 m[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) m[c] = e ? f32x2{acc[r * 6 + c].z, acc[r * 6 + c].w} : f32x2{acc[r * 6 + c].x, acc[r * 6 + c].y};
+      f4_at2(m[0], m[1], m[2], m[3], m[4], m[5], z[r][0], z[r][1], z[r][2], z[r][3]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      f4_at(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j][e], y[1][j][e], y[2][j][e], y[3][j][e]);
+      f4_at2(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j][e], y[1][j][e], y[2][j][e], y[3][j][e]);
   }
   if ((ABL & 32) && relu != 12345) return;           // ablation: no stores (the condition keeps the transform arithmetic alive)
   const bool fin = ksplit == 1;
@@ -374,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float4 o = make_float4(y[i][j][0] + bv.x, y[i][j][1] + bv.y, y[i][j][2] + bv.z, y[i][j][3] + bv.w);
+        float4 o = make_float4(y[i][j][0].x + bv.x, y[i][j][0].y + bv.y, y[i][j][1].x + bv.z, y[i][j][1].y + bv.w);
         if (relu && fin) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         const int C = 8 * t + 2 * j + (k & 1);
         *(__attribute__((address_space(3))) f32x4*)(reg + ((k >> 1) * 4 + i) * 2048 + (C ^ (t & 7)) * 16) = f32x4{o.x, o.y, o.z, o.w};
@@ -408,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
           for (int dj = 0; dj < 2; ++dj) {
             if (py + di < H && px + dj < W) {
               const int i = 2 * pi + di, j = 2 * pj + dj;
-              float4 o = make_float4(y[i][j][0] + bv.x, y[i][j][1] + bv.y, y[i][j][2] + bv.z, y[i][j][3] + bv.w);
+              float4 o = make_float4(y[i][j][0].x + bv.x, y[i][j][0].y + bv.y, y[i][j][1].x + bv.z, y[i][j][1].y + bv.w);
               if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
               best.x = fmaxf(best.x, o.x); best.y = fmaxf(best.y, o.y); best.z = fmaxf(best.z, o.z); best.w = fmaxf(best.w, o.w);
             }
@@ -570,7 +623,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #ifdef MNC_TUNING
   switch (tune(ctx, T_WINO_F4, 0)) {
 #define MNC_F4_ABL(A) case A: kern = conv3x3_wino4_kernel<1, A>; break;
-    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(64) MNC_F4_ABL(65)
+    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(4) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(64) MNC_F4_ABL(65) MNC_F4_ABL(128)
 #undef MNC_F4_ABL
     default: break;
   }
