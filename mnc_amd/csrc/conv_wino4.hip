@@ -46,6 +46,7 @@
 // (1.85 ms) and half-block pipelined (1.94); one wave per SIMD owning 32 channels x 16 tiles = 288 accumulators (hipcc shuttles
 // them between the AGPR and VGPR halves of the file: 2.09).
 #include <atomic>
+#include <type_traits>
 
 #include "mnc_internal.h"
 
@@ -72,18 +73,25 @@ static_assert(kF4HalfPieces * 1024 == kF4HalfBytes, "whole DMA pieces per half p
 static_assert(kF4HaloBytes >= kF4HaloRows * kF4RowBytes, "halo image fits its pieces");
 static_assert(2 * kF4LdsBytes <= 160 * 1024, "conv3x3_wino4: two workgroups per CU");
 
-// The input transform runs on PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per instruction and register
-// pair).  kernel_bench convwino4 with MNC_WINO_F4=4 (no transform arithmetic): the scalar transform's 144 VALU instructions per 36
-// MFMAs were 0.35 ms of the trunk's 1.66 ms, by far the largest term next to the MFMAs themselves (window reads 0.03, weight reads
-// 0.02, barriers nothing) -- tools/probes/pk_f32_under_mfma_probe.hip: beside an fp32 MFMA stream EVERY VALU instruction costs the
-// stream about four cycles, packed or not (4 v_fma_f32 per MFMA: 90 TFLOP/s of 137; 2 v_pk_fma_f32: 102), so the count is what
-// matters.  A pair holds window rows 2h and 2h + 1 of one window column.
-//   first dimension (along a window row, two rows at a time): f4_bt2 -- the scalar chain on both halves, 12 instructions per row pair;
-//   second dimension (down a window column = INSIDE the three pairs of that column): f4_bt_in -- 6 instructions per column, the
-//   halves picked by the instructions' op_sel bits (op_sel[i]: which half of source i the LOW result uses, op_sel_hi[i]: the HIGH).
-// Every output is produced by the same operations in the same order as the scalar chain (a + b as fma(b, 1, a): exact).
+// The INPUT TRANSFORM is what the loop pays for next to its MFMAs: the fp32 MFMA and the VALU share the SIMD's multipliers
+// (tools/probes/pk_f32_under_mfma_probe.hip: beside an fp32 MFMA stream EVERY VALU instruction costs the stream 4-6 cycles, packed
+// or not, dependent or not; nothing overlaps -- 4 v_fma_f32 per MFMA: 97 TFLOP/s of 155, 2 v_pk_fma_f32: 102, 1: 113, and a run of
+// VALU behind a run of MFMAs is cheaper than alternating them), so the instruction COUNT is what matters.  History of this kernel
+// (kernel_bench convwino4, trunk + rpn): scalar transform, 144 VALU per 36 MFMAs, 1.68 ms (without the transform arithmetic:
+// 1.32); packed fp32, 72: 1.60; packed + the transform SPLIT between the two waves of a tile row (below), 36: see DESIGN.md.
+//   * Packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per instruction and register pair).  A pair holds window
+//     columns 2q and 2q + 1 of one window row.
+//   * The two waves that share 16 tiles do not split the 32 output channels (each would transform all 36 positions of every
+//     channel: the same arithmetic twice) but the 36 POSITIONS: wave hp owns transform rows 3 hp .. 3 hp + 2 (all six columns) of
+//     all 32 output channels -- 18 positions x 2 channel groups = the same 36 accumulators and 36 MFMAs per pass, half the
+//     transform.  V = B^T d B: first dimension DOWN the window columns, only the wave's three rows of B^T d (f4_bt_col<hp>: 6
+//     instructions per column pair, 18 per channel), second dimension ALONG those three rows = inside the three pairs of a row
+//     (f4_bt_in: 6 instructions per row, the halves picked by the instructions' op_sel bits -- op_sel[i]: which half of source i
+//     the LOW result uses, op_sel_hi[i]: the HIGH).  36 instructions per 36 MFMAs.  The price: the output transform needs all 36
+//     positions of an (output channel, tile) -- each wave applies A^T . A to its half (it is linear) and the two exchange partial
+//     sums through LDS once per workgroup, in the epilogue.
 // Inline assembly, not vector C++: hipcc's pre-emit peephole UNPACKS a v_pk_*_f32 it finds behind an MFMA into two scalar
-// instructions (two thirds of the vector-typed version of this transform came out scalar, no faster than before).
+// instructions (two thirds of a vector-typed version of the transform came out scalar, no faster than the scalar code).
 struct F4K {                                         // constant pairs in scalar registers (-5 is not an inline constant)
   unsigned long long m5, m4m1, p1m1, p2m2;
 };
@@ -96,29 +104,35 @@ __device__ __forceinline__ F4K f4_consts() {
   asm volatile("" : "+s"(k.m5), "+s"(k.m4m1), "+s"(k.p1m1), "+s"(k.p2m2));   // (opaque: stay in four scalar register pairs)
   return k;
 }
-__device__ __forceinline__ void f4_bt2(const F4K& K, f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
-  f32x2 a, b, c, e, t0, t5, x0, x1, x2, x3, x4, x5;
-  asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(d2), "v"(d4));
-  asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(b) : "v"(d1), "v"(d3));
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(c) : "v"(d4), "v"(d2));
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e) : "v"(d3), "v"(d1));
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(d2), "s"(K.m5), "v"(d4));
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(d3), "s"(K.m5), "v"(d5));
-  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(d0), "v"(t0));
-  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x5) : "v"(d1), "v"(t5));
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(x1) : "v"(a), "v"(b));
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x2) : "v"(a), "v"(b));
-  asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]" : "=v"(x3) : "v"(e), "v"(c));
-  asm("v_pk_fma_f32 %0, %1, -2.0, %2 op_sel_hi:[1,0,1]" : "=v"(x4) : "v"(e), "v"(c));
-  d0 = x0; d1 = x1; d2 = x2; d3 = x3; d4 = x4; d5 = x5;
+// First dimension, one column pair: rows r0 .. r5 of the window (pairs over the two columns) -> rows 3 HP .. 3 HP + 2 of B^T d.
+//   HP = 0: x0 = 4 d0 - 5 d2 + d4, x1 = (d4 - 4 d2) + (d3 - 4 d1), x2 = (d4 - 4 d2) - (d3 - 4 d1)          (d5 unused)
+//   HP = 1: x3 = (d4 - d2) + 2 (d3 - d1), x4 = (d4 - d2) - 2 (d3 - d1), x5 = 4 d1 - 5 d3 + d5                (d0 unused)
+template <int HP>
+__device__ __forceinline__ void f4_bt_col(const F4K& K, const f32x2 (&r)[6], f32x2& y0, f32x2& y1, f32x2& y2) {
+  f32x2 u, a, b;
+  if (HP == 0) {
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(u) : "v"(r[2]), "s"(K.m5), "v"(r[4]));
+    asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(r[0]), "v"(u));
+    asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(r[2]), "v"(r[4]));
+    asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(b) : "v"(r[1]), "v"(r[3]));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(y1) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(y2) : "v"(a), "v"(b));
+  } else {
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a) : "v"(r[4]), "v"(r[2]));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(b) : "v"(r[3]), "v"(r[1]));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(u) : "v"(r[3]), "s"(K.m5), "v"(r[5]));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]" : "=v"(y0) : "v"(b), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, -2.0, %2 op_sel_hi:[1,0,1]" : "=v"(y1) : "v"(b), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(y2) : "v"(r[1]), "v"(u));
+  }
 }
-// p0 = (d0, d1), p1 = (d2, d3), p2 = (d4, d5) -> p0 = (x0, x5), p1 = (x1, x2), p2 = (x3, x4)
+// Second dimension, one row, in place: p0 = (d0, d1), p1 = (d2, d3), p2 = (d4, d5) -> p0 = (x0, x5), p1 = (x1, x2), p2 = (x3, x4)
 __device__ __forceinline__ void f4_bt_in(const F4K& K, f32x2& p0, f32x2& p1, f32x2& p2) {
   f32x2 t, x05, ac, be, x12, x34;
   asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(p1), "s"(K.m5), "v"(p2));                                   // (d4 - 5 d2, d5 - 5 d3)
-  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x05) : "v"(p0), "v"(t));                        // (x0, x5)
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(ac) : "v"(p1), "s"(K.m4m1), "v"(p2));   // (a, c) = (d4 - 4 d2, d4 - d2)
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(be) : "v"(p0), "s"(K.m4m1), "v"(p1));   // (b, e) = (d3 - 4 d1, d3 - d1)
+  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x05) : "v"(p0), "v"(t));                        // (x0, x5)
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(x12) : "v"(be), "s"(K.p1m1), "v"(ac));  // (a + b, a - b)
   asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(x34) : "v"(be), "s"(K.p2m2), "v"(ac));  // (c + 2 e, c - 2 e)
   p0 = x05; p1 = x12; p2 = x34;
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   extern __shared__ __attribute__((aligned(1024))) char s_f4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cg = wave & 1, tg = wave >> 1;                        // 4 waves: channel group x tile row
+  const int hp = wave & 1, tg = wave >> 1;                        // 4 waves: position half (transform rows 3 hp .. 3 hp + 2) x tile row
   const int t = lane & 15, k = lane >> 4;
   const int ncot = Cout >> 5;
   int bx, by, cot, split, ksplit;
@@ -245,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   // wait until at most `left` of this wave's copies are in flight (they complete in issue order), then the workgroup barrier; the
   // "memory" clobber keeps hipcc from moving LDS accesses across it (the copies are invisible to its own wait-count pass)
 #define MNC_F4_SYNC(left) asm volatile("s_waitcnt vmcnt(" #left ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  // (ablations 256 / 512 -- no weight copies / no halo copies -- run with 16, no waits: the counts above assume every copy is issued)
 
   f32x4 acc[36];
 #pragma unroll
@@ -263,146 +278,233 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   const int hb = kHalo0 + 4 * tg * kF4RowBytes + (k & 1) * 8;
   const int base0 = hb + t * 32 + ((k >> 1) ^ f0) * 16;          // window columns 0..3: slot 17 c + t
   const int base1 = hb + (t + 1) * 32 + ((k >> 1) ^ f1) * 16;    // window columns 4, 5: slot 17 (c - 4) + t + 1
-  const int ub = (cg * 64 + lane) * (kF4LanePitch * 4);
+  const int ub = (hp * 64 + lane) * (kF4LanePitch * 4);
 
-  // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 2k + g of block s: 36 MFMAs from the
-  // transformed values of that channel and the lane's 36 weights of half panel g, in the order of use n = 6 j + i (position (i, j) =
-  // row i, column j of the 6x6 transform: column by column).  WHILE it runs, the wave builds the operand of the next pass in the
-  // registers the previous pass has just freed: pass (s, 0) builds channel 2k + 1 of block s, pass (s, 1) channel 2k of block
-  // s + 1.  Column j of a pass: six reads of window row j for the next operand -> the six MFMAs of column j of the current one ->
-  // the second transform dimension of ITS column j + 1 (12 fma, in place) and the first dimension of the row just read (12 fma),
-  // both under those MFMAs.  Buffers: half panel g is read by pass (s, g) only and refilled (block s + 1) right behind the barrier
-  // that ends that pass -- half a block to land 18 KB; halo s is read by passes (s - 1, 1) and (s, 0), its buffer refilled (block
-  // s + 2) behind the barrier in the middle of block s -- a whole block to land.
-  // Operand registers: x[6 h + c] = the pair (window rows 2h, 2h + 1) of window column c.  After the second dimension of column c
-  // the three pairs of that column hold transform rows (0, 5), (1, 2), (3, 4): kPairOf / kHalfOf.
-  f32x2 va[18], vb[18];
+  // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 2k + g of block s: 36 MFMAs -- the wave's 18
+  // positions (transform rows 3 hp .. 3 hp + 2, row by row) x the two 16-channel groups -- from the 18 transformed values of that
+  // channel and the lane's 36 weights of half panel g, in the order of use n = 12 ii + 4 p + 2 hh + cg (row ii, register pair p,
+  // half hh: transform column kColOf[p][hh]).  WHILE it runs, the wave builds the operand of the next pass in the registers the
+  // previous pass has just freed: pass (s, 0) builds channel 2k + 1 of block s, pass (s, 1) channel 2k of block s + 1.  Step m of a
+  // pass: ten reads of window columns 2m, 2m + 1 (the five window rows the wave's transform rows use) for the next operand -> the
+  // twelve MFMAs of row m of the current one -> one run of twelve VALU instructions: the second transform dimension of ITS row
+  // m + 1 (in place) and the first dimension of the column pair just read; behind the last row the second dimension of row 0 of
+  // the next operand, so that a pass opens with MFMAs whose operands are in registers.  Buffers: half panel g is read by pass
+  // (s, g) only and refilled (block s + 1) while the other pass runs; halo s is read by passes (s - 1, 1) and (s, 0), its buffer
+  // refilled (block s + 2) during pass (s, 1) -- a whole block to land.
+  // Operand registers: x[3 ii + q] = transform row ii (of the wave's three), window / transform column pair q.  After the second
+  // dimension of a row its three pairs hold transform columns (0, 5), (1, 2), (3, 4).
+  f32x2 va[9], vb[9];
   const F4K K = f4_consts();
-  auto read_row = [&](int hbuf, int r, int g, f32x2 (&x)[18]) {
-    const lds_cp sh = lds + hbuf * kF4HaloBytes + r * kF4RowBytes + g * 4;
+  auto run = [&](auto hp_tag) {
+    constexpr int HP = decltype(hp_tag)::value;
+    auto read_colpair = [&](int hbuf, int q, int g, f32x2 (&raw)[6]) {
+      const lds_cp sh = lds + hbuf * kF4HaloBytes + g * 4;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      float v;
-      if (ABL & 2) {
-        v = 1.f + r + c;
-        asm volatile("" : "+v"(v));
-      } else {
-        // one channel of the pixel's pair, straight into its half of the register pair.  (volatile: hipcc otherwise merges
-        // neighbouring reads into ds_read2 forms -- half rate, 32-dword banking.  The 64 lanes of a ds_read_b32 are served as two
-        // groups of 32, k = 0, 1 and k = 2, 3: inside a group the same banks as the ds_read_b64 of the scalar-transform kernel.)
-        v = *(__attribute__((address_space(3))) const volatile float*)(sh + (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544));
-      }
-      if (r & 1) x[(r >> 1) * 6 + c].y = v; else x[(r >> 1) * 6 + c].x = v;
-    }
-  };
-  auto xpass_pair = [&](f32x2 (&x)[18], int h) {
-    if (!(ABL & 4)) f4_bt2(K, x[h * 6 + 0], x[h * 6 + 1], x[h * 6 + 2], x[h * 6 + 3], x[h * 6 + 4], x[h * 6 + 5]);
-  };
-  auto ypass_col = [&](f32x2 (&x)[18], int j) {
-    if (!(ABL & 4)) f4_bt_in(K, x[j], x[6 + j], x[12 + j]);
-  };
-  f32x4 uq[9];
-  auto mfma_col = [&](int g, int j, const f32x2 (&x)[18]) {
-    const lds_cp su = lds + g * kF4HalfBytes + ub;
+      for (int r = HP; r < 5 + HP; ++r)              // (window row 5 is not used by transform rows 0..2, row 0 not by rows 3..5)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int n = 6 * j + i;
-      if ((n & 3) == 0) {
+        for (int hh = 0; hh < 2; ++hh) {
+          const int c = 2 * q + hh;
+          float v;
+          if (ABL & 2) {
+            v = 1.f + r + c;
+            asm volatile("" : "+v"(v));
+          } else {
+            // one channel of the pixel's pair, straight into its half of the register pair.  (volatile: hipcc otherwise merges
+            // neighbouring reads into ds_read2 forms -- half rate, 32-dword banking.  The 64 lanes of a ds_read_b32 are served as
+            // two groups of 32, k = 0, 1 and k = 2, 3: conflict-free inside a group, tests/test_wino4_index_math.py.)
+            v = *(__attribute__((address_space(3))) const volatile float*)(sh + r * kF4RowBytes +
+                                                                            (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544));
+          }
+          if (hh) raw[r].y = v; else raw[r].x = v;
+        }
+    };
+    auto first_dim = [&](int q, const f32x2 (&raw)[6], f32x2 (&x)[9]) {
+      if (ABL & 4) { x[q] = raw[1]; x[3 + q] = raw[2]; x[6 + q] = raw[3]; }
+      else f4_bt_col<HP>(K, raw, x[q], x[3 + q], x[6 + q]);
+    };
+    auto second_dim = [&](f32x2 (&x)[9], int ii) {
+      if (!(ABL & 4)) f4_bt_in(K, x[3 * ii], x[3 * ii + 1], x[3 * ii + 2]);
+    };
+    // the lane's weights of row ii: one ds_read_b128 per register pair of the operand, [half][channel group]
+    auto load_u = [&](int g, int ii, f32x4 (&uq)[3]) {
+      const lds_cp su = lds + g * kF4HalfBytes + ub;
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp) {
         if (ABL & 8) {
-          uq[n >> 2] = f32x4{1.f, 2.f, 3.f, 4.f};
-          asm volatile("" : "+v"(uq[n >> 2]));
+          uq[pp] = f32x4{1.f, 2.f, 3.f, 4.f};
+          asm volatile("" : "+v"(uq[pp]));
         } else {
-          uq[n >> 2] = *(__attribute__((address_space(3))) const f32x4*)(su + (n >> 2) * 16);
+          uq[pp] = *(__attribute__((address_space(3))) const f32x4*)(su + (ii * 3 + pp) * 16);
         }
       }
-      constexpr int kPairOf[6] = {0, 1, 1, 2, 2, 0}, kHalfOf[6] = {0, 0, 1, 0, 1, 1};
-      const f32x2 pr = x[kPairOf[i] * 6 + j];
-      acc[i * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[n >> 2][n & 3], kHalfOf[i] ? pr.y : pr.x, acc[i * 6 + j], 0, 0, 0);
-    }
-  };
-  // (on entry column 0 of `cur` has its second dimension already -- the previous pass did it under its last MFMAs, so that a pass
-  // opens with MFMAs whose operands are in registers)
-  // SPREAD: the copies a pass owes (pass (s, 0): half panel 1 of block s, five pieces per wave; pass (s, 1): half panel 0 of block
-  // s + 1, then the halo of block s + 2, eleven pieces) are issued one or two per column instead of in a burst behind the barrier --
-  // a copy costs its wave 60-180 issue cycles (kernel_bench convwino4, MNC_WINO_F4=1: the loop without copies is 10 % faster,
-  // without waits 2 %), paid where the other wave of the SIMD has MFMAs to issue
-  constexpr bool SPREAD = (ABL & 64) == 0;
-  auto pass = [&](int g, f32x2 (&cur)[18], int hbuf_next, int g_next, f32x2 (&nxt)[18], int s) {
+    };
+    auto mfma_row = [&](int ii, const f32x4 (&uq)[3], const f32x2 (&x)[9]) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      read_row(hbuf_next, j, g_next, nxt);
-      mfma_col(g, j, cur);
-      // The column's MFMAs back to back, then its transform arithmetic in one run: the fp32 MFMA and the VALU share the SIMD's
-      // multipliers (the probe above: nothing overlaps) and every change between the two costs about ten cycles.  (Two columns at a
-      // time -- twelve MFMAs, then 24 VALU -- measured 2-3 % slower than this: kernel_bench convwino4, same box.)
-      if (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);
-      if (j < 5) ypass_col(cur, j + 1);
-      if (j & 1) xpass_pair(nxt, j >> 1);
-      if (j == 5) ypass_col(nxt, 0);
-      if (SPREAD && !(ABL & 1)) {
-        if (g == 0) {
-          if (j < 2) { dma_u_piece(s, 1, 2 * j); dma_u_piece(s, 1, 2 * j + 1); }
-          else if (j == 2) dma_u_piece(s, 1, 4);
-        } else {
-          if (j < 2) { dma_u_piece(s + 1, 0, 2 * j); dma_u_piece(s + 1, 0, 2 * j + 1); }
-          else if (j == 2) { dma_u_piece(s + 1, 0, 4); dma_h_piece(s + 2, s & 1, 0); }
-          else if (j < 5) { dma_h_piece(s + 2, s & 1, 2 * j - 5); dma_h_piece(s + 2, s & 1, 2 * j - 4); }
-          else dma_h_piece(s + 2, s & 1, 5);
-        }
+      for (int pp = 0; pp < 3; ++pp) {
+        const f32x2 pr = x[3 * ii + pp];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int a = ((ii * 3 + pp) * 2 + hh) * 2 + c2;
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[pp][hh * 2 + c2], hh ? pr.y : pr.x, acc[a], 0, 0, 0);
+          }
       }
-      // nothing moves across a column: left alone hipcc sinks the transform arithmetic behind the copies at the end of the pass,
-      // where no MFMA of this wave covers it
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  if (nchunks > 0) {
+    };
+    // The copies a pass owes (pass (s, 0): half panel 1 of block s, five pieces per wave; pass (s, 1): half panel 0 of block s + 1,
+    // then the halo of block s + 2, eleven pieces) are issued one or two at a time in front of and behind the MFMA runs instead of
+    // in a burst behind the barrier -- a copy costs its wave 60-180 issue cycles (kernel_bench convwino4, MNC_WINO_F4=1: the loop
+    // without copies is 10 % faster, without waits 2 %), paid where the other wave of the SIMD has MFMAs to issue.  Issue ORDER is
+    // what MNC_F4_SYNC counts on: the six halo pieces last.
+    auto copies = [&](int g, int slot, int s) {      // slot 0..5: in front of / behind the MFMAs of step slot / 2
+      if (ABL & 1) return;
+      auto cu = [&](int c, int gg, int i) { if (!(ABL & 256)) dma_u_piece(c, gg, i); };
+      auto ch = [&](int c, int hbuf, int i) { if (!(ABL & 512)) dma_h_piece(c, hbuf, i); };
+      if (g == 0) {
+        if (slot < 5) cu(s, 1, slot);
+      } else if (slot < 2) {
+        cu(s + 1, 0, 2 * slot); cu(s + 1, 0, 2 * slot + 1);
+      } else if (slot == 2) {
+        cu(s + 1, 0, 4); ch(s + 2, s & 1, 0);
+      } else if (slot < 5) {
+        ch(s + 2, s & 1, 2 * slot - 5); ch(s + 2, s & 1, 2 * slot - 4);
+      } else {
+        ch(s + 2, s & 1, 5);
+      }
+    };
+    auto pass = [&](int g, f32x2 (&cur)[9], int hbuf_next, int g_next, f32x2 (&nxt)[9], int s) {
+      // LDS answers in order: a step's MFMAs must not have the ten window reads in front of the weights they wait for -- the
+      // weights of row m + 1 are requested at the end of step m (those of row 0 first thing in the pass, the half panel is only
+      // known to have landed behind the barrier), the window reads behind them, and nobody waits for the window reads before the
+      // MFMAs are issued (kernel_bench convwino4, MNC_WINO_F4 = 2 / 8: with the reads in front of the weights the LDS latency of
+      // every step was exposed, 0.1 ms of the trunk each).
+      f32x4 uq[3];
+      load_u(g, 0, uq);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        f32x2 raw[6];
+        read_colpair(hbuf_next, m, g_next, raw);
+        copies(g, 2 * m, s);
+        mfma_row(m, uq, cur);
+        // The row's MFMAs back to back, then the transform arithmetic in one run: every change between the two costs about ten
+        // cycles.  Nothing moves across a step either: left alone hipcc sinks the arithmetic behind the copies at the end of the pass.
+        if (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);
+        if (m < 2) load_u(g, m + 1, uq);
+        if (m < 2) second_dim(cur, m + 1);
+        first_dim(m, raw, nxt);
+        if (m == 2) second_dim(nxt, 0);
+        copies(g, 2 * m + 1, s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     dma_u(0, 0);
     dma_h(0, 0);
-    if (!SPREAD) dma_u(0, 1);
     dma_h(1, 1);
-    if (SPREAD) MNC_F4_SYNC(6); else MNC_F4_SYNC(11);   // half panel 0 and halo 0 of block 0 have landed; the rest may still fly
+    MNC_F4_SYNC(6);                                  // half panel 0 and halo 0 of block 0 have landed; halo 1 may still fly
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      read_row(0, r, 0, va);
-      if (r & 1) xpass_pair(va, r >> 1);
+    for (int q = 0; q < 3; ++q) {
+      f32x2 raw[6];
+      read_colpair(0, q, 0, raw);
+      first_dim(q, raw, va);
     }
-    ypass_col(va, 0);
+    second_dim(va, 0);
     for (int s = 0; s < nchunks; ++s) {
       const int bsel = s & 1;
       pass(0, va, bsel, 1, vb, s);
       pin_acc();
       // middle of block s: every wave is done with half panel 0 and halo s; half panel 1 of this block and halo s + 1 (requested in
-      // the middle of block s - 1) have landed -- everything this wave has in flight
+      // the second half of block s - 1) have landed -- everything this wave has in flight
       if (!(ABL & 16)) MNC_F4_SYNC(0);
-      if (!SPREAD && !(ABL & 1)) { dma_u(s + 1, 0); dma_h(s + 2, bsel); }
       pass(1, vb, bsel ^ 1, 0, va, s);
       pin_acc();
       // end of block s: every wave is done with half panel 1; half panel 0 of block s + 1 has landed, halo s + 2's six may still fly
       if (!(ABL & 16)) MNC_F4_SYNC(6);
-      if (!SPREAD && !(ABL & 1)) dma_u(s + 1, 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dead copies behind the last block write the LDS too: none may outlive the wave)
+  };
+  if (nchunks > 0) {
+    if (hp) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
   }
 #undef MNC_F4_SYNC
 
-  // ---- epilogue: Y = A^T M A per (output channel, tile); lane: tile t of tile row tg, channels cbase .. cbase + 3 ----
+  // ---- epilogue: Y = A^T M A per (output channel, tile).  The wave holds rows 3 hp .. 3 hp + 2 of M for both channel groups: it
+  // applies A along its rows (z = M A, 3 x 4 per channel), then the part of A^T that its rows feed -- hp = 0: (m0 + p, p, q) with
+  // p = z1 + z2, q = z1 - z2; hp = 1: (r, s, z5) with r = z3 + z4, s = z3 - z4 -- keeps the triple of channel group hp, hands the
+  // other group's to its partner (wave ^ 1: same tile row, same lanes) through LDS and finishes
+  //   Y0 = (m0 + p) + r, Y1 = 2 s + q, Y2 = 4 r + p, Y3 = (8 s + q) + z5                    (the operations of the one-wave form)
+  // for channel group cg = hp.  lane: tile t of tile row tg, channels cbase .. cbase + 3.
+  const int cg = hp;
   const int oy = h0 + 4 * tg, ox = w0 + 4 * t;
   const int cbase = cot * 32 + cg * 16 + 4 * k;
-  f32x2 y[4][4][2];                                  // [row][column][channel pair]
+  f32x2 tri[2][3][4][2];                             // [channel group][kind][output column][channel pair]
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    f32x2 z[6][4];                                   // column pass: z[r][j] = sum_c M[r][c] A[c][j]
+  for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      f32x2 m[6];
+    for (int e = 0; e < 2; ++e) {
+      f32x2 z[3][4];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) m[c] = e ? f32x2{acc[r * 6 + c].z, acc[r * 6 + c].w} : f32x2{acc[r * 6 + c].x, acc[r * 6 + c].y};
-      f4_at2(m[0], m[1], m[2], m[3], m[4], m[5], z[r][0], z[r][1], z[r][2], z[r][3]);
+      for (int ii = 0; ii < 3; ++ii) {
+        f32x2 m[6];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            constexpr int kColOf[3][2] = {{0, 5}, {1, 2}, {3, 4}};
+            const f32x4 v = acc[((ii * 3 + pp) * 2 + hh) * 2 + c2];
+            m[kColOf[pp][hh]] = e ? f32x2{v.z, v.w} : f32x2{v.x, v.y};
+          }
+        f4_at2(m[0], m[1], m[2], m[3], m[4], m[5], z[ii][0], z[ii][1], z[ii][2], z[ii][3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (hp == 0) {
+          const f32x2 pq = z[1][j] + z[2][j];
+          tri[c2][0][j][e] = z[0][j] + pq;
+          tri[c2][1][j][e] = pq;
+          tri[c2][2][j][e] = z[1][j] - z[2][j];
+        } else {
+          tri[c2][0][j][e] = z[0][j] + z[1][j];
+          tri[c2][1][j][e] = z[0][j] - z[1][j];
+          tri[c2][2][j][e] = z[2][j];
+        }
+      }
     }
+  // exchange: 12 KB per wave, slot (kind, column) x 64 lanes x 16 bytes (lane-contiguous: conflict-free both ways)
+  typedef __attribute__((address_space(3))) char* lds_p;
+  __syncthreads();                                   // (all waves' copies -- the dead ones behind the last block too -- have landed)
+  {
+    const lds_p mine = (lds_p)(__attribute__((address_space(3))) char*)s_f4 + wave * 12288 + lane * 16;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      f4_at2(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], y[0][j][e], y[1][j][e], y[2][j][e], y[3][j][e]);
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 a0 = hp ? tri[0][kd][j][0] : tri[1][kd][j][0], a1 = hp ? tri[0][kd][j][1] : tri[1][kd][j][1];
+        *(__attribute__((address_space(3))) f32x4*)(mine + (kd * 4 + j) * 1024) = f32x4{a0.x, a0.y, a1.x, a1.y};
+      }
+  }
+  __syncthreads();
+  f32x2 y[4][4][2];                                  // [row][column][channel pair]
+  {
+    const lds_p theirs = (lds_p)(__attribute__((address_space(3))) char*)s_f4 + (wave ^ 1) * 12288 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 got[3][2];
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const f32x4 v = *(__attribute__((address_space(3))) const f32x4*)(theirs + (kd * 4 + j) * 1024);
+        got[kd][0] = f32x2{v.x, v.y};
+        got[kd][1] = f32x2{v.z, v.w};
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x2 m0p = hp ? got[0][e] : tri[0][0][j][e], pq = hp ? got[1][e] : tri[0][1][j][e], q = hp ? got[2][e] : tri[0][2][j][e];
+        const f32x2 r = hp ? tri[1][0][j][e] : got[0][e], sd = hp ? tri[1][1][j][e] : got[1][e], z5 = hp ? tri[1][2][j][e] : got[2][e];
+        y[0][j][e] = m0p + r;
+        y[1][j][e] = fma2(f32x2{2.f, 2.f}, sd, q);
+        y[2][j][e] = fma2(f32x2{4.f, 4.f}, r, pq);
+        y[3][j][e] = fma2(f32x2{8.f, 8.f}, sd, q) + z5;
+      }
+    }
   }
   if ((ABL & 32) && relu != 12345) return;           // ablation: no stores (the condition keeps the transform arithmetic alive)
   const bool fin = ksplit == 1;
@@ -420,8 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     // chunk C = 8 t + 2 j + half at position C ^ (t & 7) (the eight lanes of a ds_write_b128 group then hit eight different
     // 16-byte bank groups), read back a kilobyte per instruction (lane L: chunk 64 m + L, conflict-free under the same XOR) and
     // stored as eight whole cache lines.
-    __syncthreads();                                 // (all waves' copies -- the dead ones behind the last block too -- have landed)
-    typedef __attribute__((address_space(3))) char* lds_p;
+    __syncthreads();                                 // (every wave has read its partner's partial sums: the exchange area is free)
     const lds_p reg = (lds_p)(__attribute__((address_space(3))) char*)s_f4 + wave * 16384;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -471,33 +572,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   }
 }
 
-// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (g)][2 (channel group)][64 (lane)][36]: element (cb, ct, g, cg, lane = kk * 16 + i,
-// n) = (G g G^T)[row][column] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 + 2 * kk + g), n = 6 * column + row (the order in
-// which a pass multiplies the positions), evaluated in double and rounded once.  Cin * Cout * 36 floats, no padding: a lane's 144
-// bytes are 9 x 16, and an odd multiple of 16 bytes as lane pitch is what keeps ds_read_b128 free of bank conflicts.
+// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (g)][2 (position half hp)][64 (lane)][36]: element (cb, ct, g, hp, lane = kk * 16 + i,
+// n = 12 ii + 4 p + 2 hh + cg) = (G f G^T)[row 3 hp + ii][column kColOf[p][hh]] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 +
+// 2 * kk + g) -- the order in which a pass of wave hp multiplies its positions (one ds_read_b128 = one register pair of the operand
+// x both channel groups), evaluated in double and rounded once.  Cin * Cout * 36 floats, no padding: a lane's 144 bytes are 9 x 16,
+// and an odd multiple of 16 bytes as lane pitch is what keeps ds_read_b128 free of bank conflicts.
 __global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
   const double G[6][3] = {{0.25, 0.0, 0.0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const int kColOf[3][2] = {{0, 5}, {1, 2}, {3, 4}};
   const int ncot = Cout >> 5;
-  const long items = (long)(Cin >> 3) * ncot * 2 * 2 * 64;        // (cb, ct, g, cg, lane)
+  const long items = (long)(Cin >> 3) * ncot * 2 * 2 * 64;        // (cb, ct, g, hp, lane)
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < items; r += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(r & 63), cgi = (int)((r >> 6) & 1), g = (int)((r >> 7) & 1);
+    const int lane = (int)(r & 63), hp = (int)((r >> 6) & 1), g = (int)((r >> 7) & 1);
     const long tt = r >> 8;
     const int ct = (int)(tt % ncot), cb = (int)(tt / ncot);
     const int kk = lane >> 4, i = lane & 15;
-    const int co = ct * 32 + cgi * 16 + i, ci = cb * 8 + 2 * kk + g;
-    const float* f = w + ((long)co * Cin + ci) * 9;
-    double tmp[6][3];                                             // G g
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) tmp[a][b] = G[a][0] * (double)f[b] + G[a][1] * (double)f[3 + b] + G[a][2] * (double)f[6 + b];
+    const int ci = cb * 8 + 2 * kk + g;
     float* dst = out + r * kF4LanePitch;
+    for (int cg = 0; cg < 2; ++cg) {
+      const int co = ct * 32 + cg * 16 + i;
+      const float* f = w + ((long)co * Cin + ci) * 9;
+      double tmp[3][3];                                           // rows 3 hp .. 3 hp + 2 of G f
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 6; ++b)                                 // (G g) G^T, row a, column b -> n = 6 b + a
-        dst[b * 6 + a] = (float)(tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2]);
+        for (int b = 0; b < 3; ++b)
+          tmp[a][b] = G[3 * hp + a][0] * (double)f[b] + G[3 * hp + a][1] * (double)f[3 + b] + G[3 * hp + a][2] * (double)f[6 + b];
+#pragma unroll
+      for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int b = kColOf[pp][hh];                          // (G f) G^T, row 3 hp + ii, column b
+            dst[12 * ii + 4 * pp + 2 * hh + cg] = (float)(tmp[ii][0] * G[b][0] + tmp[ii][1] * G[b][1] + tmp[ii][2] * G[b][2]);
+          }
+    }
   }
 }
 
@@ -623,7 +734,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #ifdef MNC_TUNING
   switch (tune(ctx, T_WINO_F4, 0)) {
 #define MNC_F4_ABL(A) case A: kern = conv3x3_wino4_kernel<1, A>; break;
-    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(4) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(64) MNC_F4_ABL(65) MNC_F4_ABL(128)
+    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(4) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(128) MNC_F4_ABL(272) MNC_F4_ABL(528)
 #undef MNC_F4_ABL
     default: break;
   }
