@@ -12,39 +12,45 @@
 // measured 5e-6 .. 1.5e-5 of the output range for 64 .. 512 input channels (tools/studies/winograd_f4_error.py; F(2x2): 3e-7 ..
 // 7e-7, the direct fp32 sum 1e-6 .. 2e-6) -- under the kernels' 1e-4 bar and two orders under the path's 1e-3.
 //
-// Mapping -- everything a wave needs for its outputs stays in that wave (no cross-wave exchange, no LDS in the epilogue):
+// Mapping:
 //   * the contraction over input channels of each of the 36 transform positions is a GEMM  M_p[co][tile] += U_p[co][ci] V_p[ci][tile]
 //     on v_mfma_f32_16x16x4_f32: A = U (lane: co = l & 15, k = l >> 4), B = V (lane: tile = l & 15, k = l >> 4), D: lane holds
-//     co = 4 (l >> 4) + e of tile l & 15.  A wave owns 16 output channels x 16 tiles (one tile row: 4 pixel rows x 64 columns)
-//     x ALL 36 positions: 144 accumulator registers (architectural), two waves per SIMD; the output transform is per lane, in
-//     registers.
-//   * K is walked in 8-channel blocks, software-pipelined in HALF blocks: pass (s, g) multiplies channel 2k + g of block s (36
-//     MFMAs) while the wave reads the windows of the next pass's channel (36 ds_read_b64, the other channel of each pair is read
-//     again by its own pass) and transforms them (144 fma) in the registers the previous pass freed -- a pass opens with MFMAs whose
-//     operands are in registers, its transform arithmetic sits between them (7-8 VALU per MFMA).
-//   * workgroup = 4 waves = 2 channel groups x 2 tile rows = 32 output channels x 32 tiles (8 x 64 pixels), 80 KB of LDS, TWO
-//     workgroups per CU (one per-CU workgroup of eight waves with 2 x 77 KB was measured first: 1.85 ms for the trunk against 1.75 --
-//     an 8-block workgroup spends a quarter of its life in a prologue burst and an epilogue nothing overlapped).  LDS = the two HALF
-//     weight panels [g][channel group][lane][36 floats] (lane pitch 144 B = 9 x 16 B: every 16-lane group of a ds_read_b128 covers
-//     all 64 banks; stored in global memory exactly as they sit in LDS) + two halo images (10 x 66 pixels, 22 KB): exactly half a
-//     CU's 160 KB.  Half panel g is read by pass (s, g) only and refilled for block s + 1 right behind the barrier that ends the
-//     pass; halo s is read by passes (s - 1, 1) and (s, 0) and its buffer refilled for block s + 2 in the middle of block s.  All
+//     co = 4 (l >> 4) + e of tile l & 15.
+//   * workgroup = 4 waves = 2 tile rows x 2 POSITION HALVES = 32 output channels x 32 tiles (8 x 64 pixels).  The two waves of a tile
+//     row (4 pixel rows x 64 columns = 16 tiles) both work on all 32 output channels; wave hp owns transform rows 3 hp .. 3 hp + 2
+//     (18 of the 36 positions): 18 positions x 2 channel groups = 36 accumulators of 4 registers (144, architectural), 36 MFMAs per
+//     channel, and HALF of the input transform each (see the note on the transform below: on this part the transform arithmetic,
+//     not the MFMAs' operand traffic, is what a Winograd loop pays for).  The output transform is linear: each wave applies it to its
+//     rows and the partner waves exchange partial sums through LDS once, in the epilogue.
+//   * K is walked in 8-channel blocks, software-pipelined in HALF blocks: pass (s, g) multiplies channel 4 g + k of block s (36
+//     MFMAs in three runs of twelve) while the wave reads the windows of the next pass's channel (30 ds_read_b32: five window rows x
+//     six columns) and transforms them (36 packed VALU instructions, in runs of twelve behind the MFMA runs) in the registers the
+//     previous pass freed -- a pass opens with MFMAs whose operands are in registers.
+//   * 80 KB of LDS, TWO workgroups per CU (one per-CU workgroup of eight waves with 2 x 77 KB was measured first: 1.85 ms for the
+//     trunk against 1.75 -- an 8-block workgroup spends a quarter of its life in a prologue burst and an epilogue nothing overlapped).
+//     LDS = the two HALF weight panels [g][position half][lane][36 floats] (lane pitch 144 B = 9 x 16 B: every 16-lane group of a
+//     ds_read_b128 covers all 64 banks; stored in global memory exactly as they sit in LDS) + two halo images (10 x 66 pixels,
+//     22 KB): exactly half a CU's 160 KB.  Half panel g is read by pass (s, g) only and refilled for block s + 1 while the other
+//     pass runs; halo s is read by passes (s - 1, 1) and (s, 0) and its buffer refilled for block s + 2 during pass (s, 1).  All
 //     copies are buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass); two barriers per block.
 //   * halo image in LDS: dense 32-byte pixels (the DMA writes 16-byte pieces back to back), pixel column xh of a row sits in slot
 //     (xh & 3) * 17 + (xh >> 2) and its two 16-byte channel halves are swapped where bit 5 of xh is set.  Window column c of tile t
 //     is pixel 4 t + c: for a fixed c the 16 tiles of a wave read slots 17 (c & 3) + t (+ 1) -- consecutive 32-byte pixels -- and
-//     tiles t, t + 8 (whose pixels are 256 bytes = all 64 banks apart) read opposite halves: each 32-lane group of a
-//     ds_read_b64 covers the 64 banks exactly once.  Out-of-image pixels, pad slots and rows past the halo are buffer loads with an
+//     tiles t, t + 8 (whose pixels are 256 bytes = all 64 banks apart) read opposite halves: the 64 lanes of a ds_read_b32 (dword k
+//     of half g) cover the 64 banks exactly once.  Out-of-image pixels, pad slots and rows past the halo are buffer loads with an
 //     out-of-range offset: the hardware writes zeros.  (tests/test_wino4_index_math.py emulates all of this on the CPU.)
-//   * epilogue: A^T M A per lane (100 fma per output channel), + bias, ReLU, optionally the following Pooling MAX 2x2/2 (a 4x4
-//     tile holds four whole pooling windows), 16-byte stores into the c8 layout; K ranges write raw partial outputs (the transform
-//     is linear) that wino4_section_reduce_kernel finishes.
-// What it costs (kernel_bench convwino4 ablations, 13-layer trunk, MI355X): all 1.75 ms; without the output stores 1.62; without
-// window reads + transform arithmetic 1.46; without copies / barriers / weight reads as well 1.17; MFMAs alone 1.04 (the 100
-// executed GFLOP at the ~1.9 GHz the part sustains under fp32 MFMAs: 0.80).  F(2x2,3x3) (conv_wino.hip): 2.13 ms.
-// Built and measured on the way (git history): one 8-wave workgroup per CU with whole-block buffers, transform before the MFMAs
-// (1.85 ms) and half-block pipelined (1.94); one wave per SIMD owning 32 channels x 16 tiles = 288 accumulators (hipcc shuttles
-// them between the AGPR and VGPR halves of the file: 2.09).
+//   * epilogue: z = M A along the wave's three rows, the rows' share of A^T z, exchange (12 KB per wave), the finished 4x4 tile per
+//     lane, + bias, ReLU, optionally the following Pooling MAX 2x2/2 (a 4x4 tile holds four whole pooling windows), stores into the
+//     c8 layout through the wave's own 16 KB of LDS (whole cache lines); K ranges write raw partial outputs (the transform is
+//     linear) that wino4_section_reduce_kernel finishes.
+// What it costs (kernel_bench convwino4 ablations, 13-layer trunk unpooled, MI355X; tuning builds, MNC_WINO_F4): all 1.44-1.46 ms;
+// without the copies 1.32 (weight copies 0.08, halo copies 0.07); without the output stores 1.33; without waits and barriers 1.42;
+// without the transform arithmetic 1.40 (it was 0.35 of 1.66 with the scalar transform, 0.23 of 1.60 packed, before the position
+// split); MFMAs alone 1.05.  F(2x2,3x3) (conv_wino.hip): 2.13 ms.
+// Built and measured on the way (git history, profiles/r04_wino4_variants.txt): one 8-wave workgroup per CU with whole-block
+// buffers, transform before the MFMAs (1.85 ms) and half-block pipelined (1.94); one wave per SIMD owning 32 channels x 16 tiles
+// = 288 accumulators (hipcc shuttles them between the AGPR and VGPR halves of the file: 2.09); waves splitting the output channels,
+// every wave transforming all 36 positions with scalar fma (1.66) and with packed fp32 (1.60).
 #include <atomic>
 #include <type_traits>
 
@@ -275,16 +281,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   typedef __attribute__((address_space(3))) const char* lds_cp;   // (explicit LDS address space: a volatile access through a generic pointer is a flat_load)
   const lds_cp lds = (lds_cp)(__attribute__((address_space(3))) char*)s_f4;
   const int f0 = (t >> 3) & 1, f1 = ((t + 1) >> 3) & 1;
-  const int hb = kHalo0 + 4 * tg * kF4RowBytes + (k & 1) * 8;
-  const int base0 = hb + t * 32 + ((k >> 1) ^ f0) * 16;          // window columns 0..3: slot 17 c + t
-  const int base1 = hb + (t + 1) * 32 + ((k >> 1) ^ f1) * 16;    // window columns 4, 5: slot 17 (c - 4) + t + 1
+  // Lane group k multiplies channel 4 g + k of the block in pass g: the 64 lanes of a window read then take dword k of 16-byte
+  // half g (stored at half position g ^ f, f = the pixel's swap bit) of 16 consecutive pixel slots -- bank 8 (t % 8) + 4 (g ^ f) +
+  // k, 64 different banks.  (Channels 2 k + g, as the scalar-transform kernel had them for its ds_read_b64, leave every second bank
+  // unused under a ds_read_b32: r04_pmc_v3.txt counted 20-30 thousand conflict cycles per CU and launch.)
+  const int hb = kHalo0 + 4 * tg * kF4RowBytes + k * 4;
+  const int base0[2] = {hb + t * 32 + f0 * 16, hb + t * 32 + (f0 ^ 1) * 16};                  // window columns 0..3: slot 17 c + t
+  const int base1[2] = {hb + (t + 1) * 32 + f1 * 16, hb + (t + 1) * 32 + (f1 ^ 1) * 16};      // window columns 4, 5: slot 17 (c - 4) + t + 1
   const int ub = (hp * 64 + lane) * (kF4LanePitch * 4);
 
-  // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 2k + g of block s: 36 MFMAs -- the wave's 18
+  // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 4g + k of block s: 36 MFMAs -- the wave's 18
   // positions (transform rows 3 hp .. 3 hp + 2, row by row) x the two 16-channel groups -- from the 18 transformed values of that
   // channel and the lane's 36 weights of half panel g, in the order of use n = 12 ii + 4 p + 2 hh + cg (row ii, register pair p,
   // half hh: transform column kColOf[p][hh]).  WHILE it runs, the wave builds the operand of the next pass in the registers the
-  // previous pass has just freed: pass (s, 0) builds channel 2k + 1 of block s, pass (s, 1) channel 2k of block s + 1.  Step m of a
+  // previous pass has just freed: pass (s, 0) builds channel 4 + k of block s, pass (s, 1) channel k of block s + 1.  Step m of a
   // pass: ten reads of window columns 2m, 2m + 1 (the five window rows the wave's transform rows use) for the next operand -> the
   // twelve MFMAs of row m of the current one -> one run of twelve VALU instructions: the second transform dimension of ITS row
   // m + 1 (in place) and the first dimension of the column pair just read; behind the last row the second dimension of row 0 of
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   auto run = [&](auto hp_tag) {
     constexpr int HP = decltype(hp_tag)::value;
     auto read_colpair = [&](int hbuf, int q, int g, f32x2 (&raw)[6]) {
-      const lds_cp sh = lds + hbuf * kF4HaloBytes + g * 4;
+      const lds_cp sh = lds + hbuf * kF4HaloBytes;
 #pragma unroll
       for (int r = HP; r < 5 + HP; ++r)              // (window row 5 is not used by transform rows 0..2, row 0 not by rows 3..5)
 #pragma unroll
@@ -309,11 +319,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
             v = 1.f + r + c;
             asm volatile("" : "+v"(v));
           } else {
-            // one channel of the pixel's pair, straight into its half of the register pair.  (volatile: hipcc otherwise merges
-            // neighbouring reads into ds_read2 forms -- half rate, 32-dword banking.  The 64 lanes of a ds_read_b32 are served as
-            // two groups of 32, k = 0, 1 and k = 2, 3: conflict-free inside a group, tests/test_wino4_index_math.py.)
+            // one channel of the pixel, straight into its half of the register pair.  (volatile: hipcc otherwise merges
+            // neighbouring reads into ds_read2 forms -- half rate, 32-dword banking.)
             v = *(__attribute__((address_space(3))) const volatile float*)(sh + r * kF4RowBytes +
-                                                                            (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544));
+                                                                            (c < 4 ? base0[g] + c * 544 : base1[g] + (c - 4) * 544));
           }
           if (hh) raw[r].y = v; else raw[r].x = v;
         }
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
 
 // OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (g)][2 (position half hp)][64 (lane)][36]: element (cb, ct, g, hp, lane = kk * 16 + i,
 // n = 12 ii + 4 p + 2 hh + cg) = (G f G^T)[row 3 hp + ii][column kColOf[p][hh]] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 +
-// 2 * kk + g) -- the order in which a pass of wave hp multiplies its positions (one ds_read_b128 = one register pair of the operand
+// 4 * g + kk) -- the order in which a pass of wave hp multiplies its positions (one ds_read_b128 = one register pair of the operand
 // x both channel groups), evaluated in double and rounded once.  Cin * Cout * 36 floats, no padding: a lane's 144 bytes are 9 x 16,
 // and an odd multiple of 16 bytes as lane pitch is what keeps ds_read_b128 free of bank conflicts.
 __global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
@@ -588,7 +597,7 @@ __global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __
     const long tt = r >> 8;
     const int ct = (int)(tt % ncot), cb = (int)(tt / ncot);
     const int kk = lane >> 4, i = lane & 15;
-    const int ci = cb * 8 + 2 * kk + g;
+    const int ci = cb * 8 + 4 * g + kk;
     float* dst = out + r * kF4LanePitch;
     for (int cg = 0; cg < 2; ++cg) {
       const int co = ct * 32 + cg * 16 + i;

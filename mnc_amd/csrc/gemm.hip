@@ -513,7 +513,8 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
 //     not the 32x32x2 kernel's (k0, k4, k1, k5, ...): results differ from it in the last bits.
 //   * a block whose last 16-row sub-tile is dead (M in (288, 304], e.g. 300 RoIs) skips that sub-tile's MFMAs in the waves that
 //     own it (LAST): the 32x32x2 kernel's half-tile special case is the general case here.
-template <int kMT>
+//   * ABL (tuning builds, wrong results): 1 no copies inside the loop, 2 no barrier inside the loop -- what they cost (kernel_bench fc, MNC_FC_DMA_ABL = 16 + ABL)
+template <int kMT, int ABL = 0>
 __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             float* __restrict__ part, int M, int N, int K, int ldc, int kper,
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
         if ((i + 1) * 2 * kNR / kNM > i * 2 * kNR / kNM && i * 2 < kNM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       dma_wait();                                    // stage s + 1 has landed ...
-      __syncthreads();                               // ... for every wave, and nobody reads buffer `cur` any more
+      if (!(ABL & 2)) __syncthreads();               // ... for every wave, and nobody reads buffer `cur` any more
       read_frags(0, kBufXor, f0);                    // group 0 of stage s + 1
       {                                              // group 1: the reads under the first MFMAs, then one copy every fourth MFMA
         const long off = (long)min(s + 2, nstages - 1) * 32;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
             const int m = 2 * (q * NS + i);          // MFMAs issued before this pair
             if (m >= kNM - 4 * kPer - 8 && m < kNM - 8 && (m - (kNM - 4 * kPer - 8)) % 4 == 0) {
               __builtin_amdgcn_sched_barrier(0);
-              dma_piece((m - (kNM - 4 * kPer - 8)) / 4, off, cur);
+              if (!(ABL & 1)) dma_piece((m - (kNM - 4 * kPer - 8)) / 4, off, cur);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -863,7 +864,14 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
       bool launched = false;
 #ifdef MNC_TUNING
       const int waves = tune(ctx, T_FC_DMA_WAVES, 8), dabl = tune(ctx, T_FC_DMA_ABL, 0);
-      if (tune(ctx, T_FC_MFMA16, 1) == 0 || waves == 4 || dabl) {
+      if (dabl >= 16) {                              // ablations of the product kernel
+        launched = true;
+        const int drop = tm == 1 && M > 288 && M <= 304 ? 1 : 0;
+        auto kern = dabl == 17 ? fc_mfma_dma16_kernel<10, 1> : dabl == 18 ? fc_mfma_dma16_kernel<10, 2> : dabl == 19 ? fc_mfma_dma16_kernel<10, 3> : fc_mfma_dma16_kernel<10, 0>;
+        MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper,
+                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
+      } else if (tune(ctx, T_FC_MFMA16, 1) == 0 || waves == 4 || dabl) {
         launched = true;
         if (dabl == 1) MNC_FC_DMA_LAUNCH(1, 1);      // 1: every copy re-reads stage 0 (L2-hot operands), 3: only the weight copies do
         else if (dabl == 3) MNC_FC_DMA_LAUNCH(3, 1);
