@@ -267,8 +267,9 @@ MNC_API int mnc_conv3x3_wino_pool(mnc_ctx* ctx, const float* d_in_c8, const floa
                                   float* d_out_pooled_c8, int H, int W, int Cin, int Cout, int relu);
 /* The same convolution by Winograd's F(4x4, 3x3) (round 4; mnc_amd/csrc/conv_wino4.hip): 36 multiplies per (input channel, output
  * channel, 4x4 output tile) = 2.25 per output against F(2x2)'s 4 and the direct form's 9.  Fused: input transform, the 36 channel
- * contractions (v_mfma_f32_16x16x4_f32) and the output transform run in one kernel, one wave holding all 36 positions of its
- * 16 channels x 16 tiles; four-wave workgroups with half of a CU's LDS each, two per CU.  The transforms carry the coefficients 2, 4, 5, 8 and 1/6, 1/12, 1/24 (filter side, evaluated in double,
+ * contractions (v_mfma_f32_16x16x4_f32) and the output transform run in one kernel; four-wave workgroups (32 channels x 8 x 64
+ * pixels) with half of a CU's LDS each, two per CU; the two waves of a tile row split the 36 positions (half of the packed-fp32
+ * input transform each) and exchange partial output sums through LDS in the epilogue.  The transforms carry the coefficients 2, 4, 5, 8 and 1/6, 1/12, 1/24 (filter side, evaluated in double,
  * rounded once): rounding error ~1e-5 of the output range at 512 input channels (F(2x2): ~1e-6; both inside the kernels' 1e-4
  * bar).  d_w_packed from mnc_pack_conv3x3_wino4: Caffe [Cout][Cin][3][3] -> [Cin/8][Cout/32][2][2][64][36] floats (Cin*Cout*36 floats).
  * Cin%8==0, Cout%32==0; the input tensor and the packed weights each below 2 GB (32-bit buffer offsets; beyond that mnc_conv3x3_wino).  _pool: the following Pooling MAX 2x2/2 in the epilogue (a 4x4 tile is four windows). */
