@@ -22,10 +22,10 @@
 //     channel, and HALF of the input transform each (see the note on the transform below: on this part the transform arithmetic,
 //     not the MFMAs' operand traffic, is what a Winograd loop pays for).  The output transform is linear: each wave applies it to its
 //     rows and the partner waves exchange partial sums through LDS once, in the epilogue.
-//   * K is walked in 8-channel blocks, software-pipelined in HALF blocks: pass (s, g) multiplies channel 4 g + k of block s (36
-//     MFMAs in three runs of twelve) while the wave reads the windows of the next pass's channel (30 ds_read_b32: five window rows x
-//     six columns) and transforms them (36 packed VALU instructions, in runs of twelve behind the MFMA runs) in the registers the
-//     previous pass freed -- a pass opens with MFMAs whose operands are in registers.
+//   * K is walked in 8-channel blocks (lane group k: channels 2k, 2k + 1).  A block is six steps of twelve MFMAs (one of the wave's
+//     three transform rows x one channel of the pair); meanwhile the wave reads the windows of the NEXT block (30 ds_read_b64: five
+//     window rows x six columns, both channels of the pair per read) and transforms them, both channels per instruction (72 packed
+//     VALU instructions per block, in runs behind the MFMA runs), in the registers the current block frees row by row.
 //   * 80 KB of LDS, TWO workgroups per CU (one per-CU workgroup of eight waves with 2 x 77 KB was measured first: 1.85 ms for the
 //     trunk against 1.75 -- an 8-block workgroup spends a quarter of its life in a prologue burst and an epilogue nothing overlapped).
 //     LDS = the two HALF weight panels [g][position half][lane][36 floats] (lane pitch 144 B = 9 x 16 B: every 16-lane group of a
@@ -36,21 +36,24 @@
 //   * halo image in LDS: dense 32-byte pixels (the DMA writes 16-byte pieces back to back), pixel column xh of a row sits in slot
 //     (xh & 3) * 17 + (xh >> 2) and its two 16-byte channel halves are swapped where bit 5 of xh is set.  Window column c of tile t
 //     is pixel 4 t + c: for a fixed c the 16 tiles of a wave read slots 17 (c & 3) + t (+ 1) -- consecutive 32-byte pixels -- and
-//     tiles t, t + 8 (whose pixels are 256 bytes = all 64 banks apart) read opposite halves: the 64 lanes of a ds_read_b32 (dword k
-//     of half g) cover the 64 banks exactly once.  Out-of-image pixels, pad slots and rows past the halo are buffer loads with an
+//     tiles t, t + 8 (whose pixels are 256 bytes = all 64 banks apart) read opposite halves: each 32-lane group of a
+//     ds_read_b64 covers the 64 banks exactly once.  Out-of-image pixels, pad slots and rows past the halo are buffer loads with an
 //     out-of-range offset: the hardware writes zeros.  (tests/test_wino4_index_math.py emulates all of this on the CPU.)
 //   * epilogue: z = M A along the wave's three rows, the rows' share of A^T z, exchange (12 KB per wave), the finished 4x4 tile per
 //     lane, + bias, ReLU, optionally the following Pooling MAX 2x2/2 (a 4x4 tile holds four whole pooling windows), stores into the
 //     c8 layout through the wave's own 16 KB of LDS (whole cache lines); K ranges write raw partial outputs (the transform is
 //     linear) that wino4_section_reduce_kernel finishes.
-// What it costs (kernel_bench convwino4 ablations, 13-layer trunk unpooled, MI355X; tuning builds, MNC_WINO_F4): all 1.44-1.46 ms;
-// without the copies 1.32 (weight copies 0.08, halo copies 0.07); without the output stores 1.33; without waits and barriers 1.42;
-// without the transform arithmetic 1.40 (it was 0.35 of 1.66 with the scalar transform, 0.23 of 1.60 packed, before the position
-// split); MFMAs alone 1.05.  F(2x2,3x3) (conv_wino.hip): 2.13 ms.
+// What it costs (kernel_bench convwino4 ablations, 13-layer trunk unpooled, MI355X; tuning builds, MNC_WINO_F4, operands that cost no
+// instruction in place of the reads): all 1.43 ms; without the window reads 1.29, without the weight reads 1.35, without both 1.21;
+// without the copies 1.28 (weight copies and halo copies about half each); without the output stores 1.33; without waits and
+// barriers 1.42; without the transform arithmetic 1.40 (it was 0.35 of 1.66 with the scalar transform, 0.23 of 1.60 packed, before
+// the position split).  On exact tilings the loop alone reaches 88 TFLOP/s of MFMA work, 149 with everything but the MFMAs removed
+// (the pipe's peak: profiles/r04_wino4_ablations.txt).  F(2x2,3x3) (conv_wino.hip): 2.13 ms.
 // Built and measured on the way (git history, profiles/r04_wino4_variants.txt): one 8-wave workgroup per CU with whole-block
 // buffers, transform before the MFMAs (1.85 ms) and half-block pipelined (1.94); one wave per SIMD owning 32 channels x 16 tiles
 // = 288 accumulators (hipcc shuttles them between the AGPR and VGPR halves of the file: 2.09); waves splitting the output channels,
-// every wave transforming all 36 positions with scalar fma (1.66) and with packed fp32 (1.60).
+// every wave transforming all 36 positions with scalar fma (1.66) and with packed fp32 (1.60); the position split with register
+// pairs of window COLUMNS, one channel per pass and ds_read_b32 windows (1.46).
 #include <atomic>
 #include <type_traits>
 
@@ -85,29 +88,25 @@ static_assert(2 * kF4LdsBytes <= 160 * 1024, "conv3x3_wino4: two workgroups per 
 // VALU behind a run of MFMAs is cheaper than alternating them), so the instruction COUNT is what matters.  History of this kernel
 // (kernel_bench convwino4, trunk + rpn): scalar transform, 144 VALU per 36 MFMAs, 1.68 ms (without the transform arithmetic:
 // 1.32); packed fp32, 72: 1.60; packed + the transform SPLIT between the two waves of a tile row (below), 36: see DESIGN.md.
-//   * Packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per instruction and register pair).  A pair holds window
-//     columns 2q and 2q + 1 of one window row.
+//   * Packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes of arithmetic per instruction and register pair).  A pair holds the two
+//     channels 2k, 2k + 1 of one position -- what one ds_read_b64 of the halo image delivers.
 //   * The two waves that share 16 tiles do not split the 32 output channels (each would transform all 36 positions of every
 //     channel: the same arithmetic twice) but the 36 POSITIONS: wave hp owns transform rows 3 hp .. 3 hp + 2 (all six columns) of
 //     all 32 output channels -- 18 positions x 2 channel groups = the same 36 accumulators and 36 MFMAs per pass, half the
 //     transform.  V = B^T d B: first dimension DOWN the window columns, only the wave's three rows of B^T d (f4_bt_col<hp>: 6
-//     instructions per column pair, 18 per channel), second dimension ALONG those three rows = inside the three pairs of a row
-//     (f4_bt_in: 6 instructions per row, the halves picked by the instructions' op_sel bits -- op_sel[i]: which half of source i
-//     the LOW result uses, op_sel_hi[i]: the HIGH).  36 instructions per 36 MFMAs.  The price: the output transform needs all 36
+//     instructions per column), second dimension ALONG those three rows (f4_bt2: 12 per row): 72 instructions per channel pair =
+//     36 per 36 MFMAs.  The price: the output transform needs all 36
 //     positions of an (output channel, tile) -- each wave applies A^T . A to its half (it is linear) and the two exchange partial
 //     sums through LDS once per workgroup, in the epilogue.
 // Inline assembly, not vector C++: hipcc's pre-emit peephole UNPACKS a v_pk_*_f32 it finds behind an MFMA into two scalar
 // instructions (two thirds of a vector-typed version of the transform came out scalar, no faster than the scalar code).
-struct F4K {                                         // constant pairs in scalar registers (-5 is not an inline constant)
-  unsigned long long m5, m4m1, p1m1, p2m2;
+struct F4K {                                         // the constant pair (-5, -5) in scalar registers (-5 is not an inline constant)
+  unsigned long long m5;
 };
 __device__ __forceinline__ F4K f4_consts() {
   F4K k;
-  k.m5 = 0xC0A00000C0A00000ull;                      // (-5, -5)
-  k.m4m1 = 0xBF800000C0800000ull;                    // (-4, -1)   (low half first)
-  k.p1m1 = 0xBF8000003F800000ull;                    // ( 1, -1)
-  k.p2m2 = 0xC000000040000000ull;                    // ( 2, -2)
-  asm volatile("" : "+s"(k.m5), "+s"(k.m4m1), "+s"(k.p1m1), "+s"(k.p2m2));   // (opaque: stay in four scalar register pairs)
+  k.m5 = 0xC0A00000C0A00000ull;
+  asm volatile("" : "+s"(k.m5));                     // (opaque: stays in one scalar register pair)
   return k;
 }
 // First dimension, one column pair: rows r0 .. r5 of the window (pairs over the two columns) -> rows 3 HP .. 3 HP + 2 of B^T d.
@@ -132,16 +131,22 @@ __device__ __forceinline__ void f4_bt_col(const F4K& K, const f32x2 (&r)[6], f32
     asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(y2) : "v"(r[1]), "v"(u));
   }
 }
-// Second dimension, one row, in place: p0 = (d0, d1), p1 = (d2, d3), p2 = (d4, d5) -> p0 = (x0, x5), p1 = (x1, x2), p2 = (x3, x4)
-__device__ __forceinline__ void f4_bt_in(const F4K& K, f32x2& p0, f32x2& p1, f32x2& p2) {
-  f32x2 t, x05, ac, be, x12, x34;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(p1), "s"(K.m5), "v"(p2));                                   // (d4 - 5 d2, d5 - 5 d3)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(ac) : "v"(p1), "s"(K.m4m1), "v"(p2));   // (a, c) = (d4 - 4 d2, d4 - d2)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(be) : "v"(p0), "s"(K.m4m1), "v"(p1));   // (b, e) = (d3 - 4 d1, d3 - d1)
-  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x05) : "v"(p0), "v"(t));                        // (x0, x5)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(x12) : "v"(be), "s"(K.p1m1), "v"(ac));  // (a + b, a - b)
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(x34) : "v"(be), "s"(K.p2m2), "v"(ac));  // (c + 2 e, c - 2 e)
-  p0 = x05; p1 = x12; p2 = x34;
+// One whole dimension on pairs, in place (12 instructions): the scalar chain on both halves.
+__device__ __forceinline__ void f4_bt2(const F4K& K, f32x2& d0, f32x2& d1, f32x2& d2, f32x2& d3, f32x2& d4, f32x2& d5) {
+  f32x2 a, b, c, e, t0, t5, x0, x1, x2, x3, x4, x5;
+  asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(d2), "v"(d4));
+  asm("v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]" : "=v"(b) : "v"(d1), "v"(d3));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(c) : "v"(d4), "v"(d2));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(e) : "v"(d3), "v"(d1));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(d2), "s"(K.m5), "v"(d4));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t5) : "v"(d3), "s"(K.m5), "v"(d5));
+  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(d0), "v"(t0));
+  asm("v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]" : "=v"(x5) : "v"(d1), "v"(t5));
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(x1) : "v"(a), "v"(b));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x2) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]" : "=v"(x3) : "v"(e), "v"(c));
+  asm("v_pk_fma_f32 %0, %1, -2.0, %2 op_sel_hi:[1,0,1]" : "=v"(x4) : "v"(e), "v"(c));
+  d0 = x0; d1 = x1; d2 = x2; d3 = x3; d4 = x4; d5 = x5;
 }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -281,154 +286,147 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   typedef __attribute__((address_space(3))) const char* lds_cp;   // (explicit LDS address space: a volatile access through a generic pointer is a flat_load)
   const lds_cp lds = (lds_cp)(__attribute__((address_space(3))) char*)s_f4;
   const int f0 = (t >> 3) & 1, f1 = ((t + 1) >> 3) & 1;
-  // Lane group k multiplies channel 4 g + k of the block in pass g: the 64 lanes of a window read then take dword k of 16-byte
-  // half g (stored at half position g ^ f, f = the pixel's swap bit) of 16 consecutive pixel slots -- bank 8 (t % 8) + 4 (g ^ f) +
-  // k, 64 different banks.  (Channels 2 k + g, as the scalar-transform kernel had them for its ds_read_b64, leave every second bank
-  // unused under a ds_read_b32: r04_pmc_v3.txt counted 20-30 thousand conflict cycles per CU and launch.)
-  const int hb = kHalo0 + 4 * tg * kF4RowBytes + k * 4;
-  const int base0[2] = {hb + t * 32 + f0 * 16, hb + t * 32 + (f0 ^ 1) * 16};                  // window columns 0..3: slot 17 c + t
-  const int base1[2] = {hb + (t + 1) * 32 + f1 * 16, hb + (t + 1) * 32 + (f1 ^ 1) * 16};      // window columns 4, 5: slot 17 (c - 4) + t + 1
+  // Lane group k multiplies channel 2k + g of the block in pass g; a window read is ONE ds_read_b64 of the pixel's channel pair
+  // (2k, 2k + 1) -- the register pair the packed transform works on (half = channel = pass).  16-byte half (k >> 1) of the pixel,
+  // stored at half position (k >> 1) ^ f (f = the pixel's swap bit): each 32-lane group of a ds_read_b64 covers the 64 banks once.
+  const int hb = kHalo0 + 4 * tg * kF4RowBytes + (k & 1) * 8;
+  const int base0 = hb + t * 32 + ((k >> 1) ^ f0) * 16;          // window columns 0..3: slot 17 c + t
+  const int base1 = hb + (t + 1) * 32 + ((k >> 1) ^ f1) * 16;    // window columns 4, 5: slot 17 (c - 4) + t + 1
   const int ub = (hp * 64 + lane) * (kF4LanePitch * 4);
 
-  // ---- the loop, software-pipelined in HALF blocks.  Pass (s, g) multiplies channel 4g + k of block s: 36 MFMAs -- the wave's 18
-  // positions (transform rows 3 hp .. 3 hp + 2, row by row) x the two 16-channel groups -- from the 18 transformed values of that
-  // channel and the lane's 36 weights of half panel g, in the order of use n = 12 ii + 4 p + 2 hh + cg (row ii, register pair p,
-  // half hh: transform column kColOf[p][hh]).  WHILE it runs, the wave builds the operand of the next pass in the registers the
-  // previous pass has just freed: pass (s, 0) builds channel 4 + k of block s, pass (s, 1) channel k of block s + 1.  Step m of a
-  // pass: ten reads of window columns 2m, 2m + 1 (the five window rows the wave's transform rows use) for the next operand -> the
-  // twelve MFMAs of row m of the current one -> one run of twelve VALU instructions: the second transform dimension of ITS row
-  // m + 1 (in place) and the first dimension of the column pair just read; behind the last row the second dimension of row 0 of
-  // the next operand, so that a pass opens with MFMAs whose operands are in registers.  Buffers: half panel g is read by pass
-  // (s, g) only and refilled (block s + 1) while the other pass runs; halo s is read by passes (s - 1, 1) and (s, 0), its buffer
-  // refilled (block s + 2) during pass (s, 1) -- a whole block to land.
-  // Operand registers: x[3 ii + q] = transform row ii (of the wave's three), window / transform column pair q.  After the second
-  // dimension of a row its three pairs hold transform columns (0, 5), (1, 2), (3, 4).
-  f32x2 va[9], vb[9];
+  // ---- the loop.  Block s = 8 input channels (lane group k: channels 2k, 2k + 1) = six steps of twelve MFMAs; step i multiplies
+  // row i / 2 (of the wave's three transform rows 3 hp .. 3 hp + 2) of channel 2k + (i & 1): six transform columns x the two
+  // 16-channel groups, from half i & 1 of that row's six register pairs and twelve of the lane's weights (order of use n = 12 (i %
+  // 3) + 2 j + cg in half panel i / 3).  A register pair holds the two channels (2k, 2k + 1) of one position: one ds_read_b64 fills
+  // it and both transform dimensions run on it as it is (v_pk_*: both channels per instruction).  WHILE block s is multiplied, the
+  // wave builds the operand of block s + 1: step i = five reads of window column i (the five window rows the wave's transform rows
+  // use) -> the twelve MFMAs -> one run of VALU: the first dimension of the column just read (6 instructions: three of the six
+  // rows of B^T d) and, in steps 0 and 2, the second dimension of the CURRENT operand's next row (12, in place; row 0 was done
+  // behind the last MFMAs of the block before).  A row of the current operand dies after its two steps, where two columns of the
+  // next one have been added: the operand registers stay at 36-48.  72 VALU instructions and 30 window reads per 72 MFMAs.
+  // (The kernel before this one read the two channels with separate ds_read_b32 into the halves of a pair of window COLUMNS: the
+  // same arithmetic, twice the read instructions -- and an LDS read costs the loop by the instruction: kernel_bench convwino4,
+  // MNC_WINO_F4 = 2 with operands that cost no instruction: 21 % of the loop were the 60 window reads, 15 % the 18 weight reads.)
+  // Buffers: half panel h (steps 3h .. 3h + 2) is refilled (block s + 1) while the other half is in use; halo s + 1 is read
+  // during block s, its buffer refilled (block s + 3) from the start of block s + 1 -- more than a block to land.
+  // Operand registers: x[6 ii + c] = row ii (of the wave's three) of B^T d, window column c; after the second dimension of row ii:
+  // transform column c.
+  f32x2 va[18], vb[18];
   const F4K K = f4_consts();
+  f32x2 abl_pair = {1.f, 2.f};                       // ablations 2 / 8 (tuning builds): operands that cost no instruction
+  f32x4 abl_quad = {1.f, 2.f, 3.f, 4.f};
+  if (ABL & 10) asm volatile("" : "+v"(abl_pair), "+v"(abl_quad));
   auto run = [&](auto hp_tag) {
     constexpr int HP = decltype(hp_tag)::value;
-    auto read_colpair = [&](int hbuf, int q, int g, f32x2 (&raw)[6]) {
-      const lds_cp sh = lds + hbuf * kF4HaloBytes;
+    auto read_col = [&](int hbuf, int c, f32x2 (&raw)[6]) {
+      const lds_cp sh = lds + hbuf * kF4HaloBytes + (c < 4 ? base0 + c * 544 : base1 + (c - 4) * 544);
 #pragma unroll
-      for (int r = HP; r < 5 + HP; ++r)              // (window row 5 is not used by transform rows 0..2, row 0 not by rows 3..5)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int c = 2 * q + hh;
-          float v;
-          if (ABL & 2) {
-            v = 1.f + r + c;
-            asm volatile("" : "+v"(v));
-          } else {
-            // one channel of the pixel, straight into its half of the register pair.  (volatile: hipcc otherwise merges
-            // neighbouring reads into ds_read2 forms -- half rate, 32-dword banking.)
-            v = *(__attribute__((address_space(3))) const volatile float*)(sh + r * kF4RowBytes +
-                                                                            (c < 4 ? base0[g] + c * 544 : base1[g] + (c - 4) * 544));
-          }
-          if (hh) raw[r].y = v; else raw[r].x = v;
-        }
+      for (int r = HP; r < 5 + HP; ++r) {            // (window row 5 is not used by transform rows 0..2, row 0 not by rows 3..5)
+        if (ABL & 2) raw[r] = abl_pair;
+        // (volatile: hipcc otherwise merges neighbouring reads into ds_read2_b64 -- half rate, 32-dword banking)
+        else raw[r] = *(__attribute__((address_space(3))) const volatile f32x2*)(sh + r * kF4RowBytes);
+      }
     };
-    auto first_dim = [&](int q, const f32x2 (&raw)[6], f32x2 (&x)[9]) {
-      if (ABL & 4) { x[q] = raw[1]; x[3 + q] = raw[2]; x[6 + q] = raw[3]; }
-      else f4_bt_col<HP>(K, raw, x[q], x[3 + q], x[6 + q]);
+    auto first_dim = [&](int c, const f32x2 (&raw)[6], f32x2 (&x)[18]) {
+      if (ABL & 4) { x[c] = raw[1]; x[6 + c] = raw[2]; x[12 + c] = raw[3]; }
+      else f4_bt_col<HP>(K, raw, x[c], x[6 + c], x[12 + c]);
     };
-    auto second_dim = [&](f32x2 (&x)[9], int ii) {
-      if (!(ABL & 4)) f4_bt_in(K, x[3 * ii], x[3 * ii + 1], x[3 * ii + 2]);
+    auto second_dim = [&](f32x2 (&x)[18], int ii) {
+      if (!(ABL & 4)) f4_bt2(K, x[6 * ii], x[6 * ii + 1], x[6 * ii + 2], x[6 * ii + 3], x[6 * ii + 4], x[6 * ii + 5]);
     };
-    // the lane's weights of row ii: one ds_read_b128 per register pair of the operand, [half][channel group]
-    auto load_u = [&](int g, int ii, f32x4 (&uq)[3]) {
-      const lds_cp su = lds + g * kF4HalfBytes + ub;
+    // the lane's twelve weights of step i: one ds_read_b128 per two transform columns, [column][channel group]
+    auto load_u = [&](int i, f32x4 (&uq)[3]) {
+      const lds_cp su = lds + (i / 3) * kF4HalfBytes + ub;
 #pragma unroll
       for (int pp = 0; pp < 3; ++pp) {
-        if (ABL & 8) {
-          uq[pp] = f32x4{1.f, 2.f, 3.f, 4.f};
-          asm volatile("" : "+v"(uq[pp]));
-        } else {
-          uq[pp] = *(__attribute__((address_space(3))) const f32x4*)(su + (ii * 3 + pp) * 16);
+        if (ABL & 8) uq[pp] = abl_quad;
+        else uq[pp] = *(__attribute__((address_space(3))) const f32x4*)(su + ((i % 3) * 3 + pp) * 16);
+      }
+    };
+    auto mfma_step = [&](int i, const f32x4 (&uq)[3], const f32x2 (&x)[18]) {
+      const int ii = i >> 1, g = i & 1;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const f32x2 pr = x[6 * ii + j];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int a = (ii * 6 + j) * 2 + c2;
+          acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[j >> 1][(j & 1) * 2 + c2], g ? pr.y : pr.x, acc[a], 0, 0, 0);
         }
       }
     };
-    auto mfma_row = [&](int ii, const f32x4 (&uq)[3], const f32x2 (&x)[9]) {
-#pragma unroll
-      for (int pp = 0; pp < 3; ++pp) {
-        const f32x2 pr = x[3 * ii + pp];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            const int a = ((ii * 3 + pp) * 2 + hh) * 2 + c2;
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(uq[pp][hh * 2 + c2], hh ? pr.y : pr.x, acc[a], 0, 0, 0);
-          }
-      }
-    };
-    // The copies a pass owes (pass (s, 0): half panel 1 of block s, five pieces per wave; pass (s, 1): half panel 0 of block s + 1,
-    // then the halo of block s + 2, eleven pieces) are issued one or two at a time in front of and behind the MFMA runs instead of
-    // in a burst behind the barrier -- a copy costs its wave 60-180 issue cycles (kernel_bench convwino4, MNC_WINO_F4=1: the loop
-    // without copies is 10 % faster, without waits 2 %), paid where the other wave of the SIMD has MFMAs to issue.  Issue ORDER is
-    // what MNC_F4_SYNC counts on: the six halo pieces last.
+    // The copies a block owes -- first half (h = 0): the halo of block s + 2 (six pieces per wave), then half panel 1 of block s
+    // (five); second half: half panel 0 of block s + 1 (five) -- are issued one or two at a time in front of and behind the MFMA runs
+    // instead of in a burst behind the barrier: a copy costs its wave 60-180 issue cycles, paid where the other wave of the SIMD
+    // has MFMAs to issue.  Both barriers of a block wait for everything in flight.
     auto copies = [&](int g, int slot, int s) {      // slot 0..5: in front of / behind the MFMAs of step slot / 2
       if (ABL & 1) return;
       auto cu = [&](int c, int gg, int i) { if (!(ABL & 256)) dma_u_piece(c, gg, i); };
       auto ch = [&](int c, int hbuf, int i) { if (!(ABL & 512)) dma_h_piece(c, hbuf, i); };
       if (g == 0) {
-        if (slot < 5) cu(s, 1, slot);
-      } else if (slot < 2) {
-        cu(s + 1, 0, 2 * slot); cu(s + 1, 0, 2 * slot + 1);
-      } else if (slot == 2) {
-        cu(s + 1, 0, 4); ch(s + 2, s & 1, 0);
+        if (slot < 3) { ch(s + 2, s & 1, 2 * slot); ch(s + 2, s & 1, 2 * slot + 1); }
+        else if (slot < 5) { cu(s, 1, 2 * slot - 6); cu(s, 1, 2 * slot - 5); }
+        else cu(s, 1, 4);
       } else if (slot < 5) {
-        ch(s + 2, s & 1, 2 * slot - 5); ch(s + 2, s & 1, 2 * slot - 4);
-      } else {
-        ch(s + 2, s & 1, 5);
+        cu(s + 1, 0, slot);
       }
     };
-    auto pass = [&](int g, f32x2 (&cur)[9], int hbuf_next, int g_next, f32x2 (&nxt)[9], int s) {
-      // LDS answers in order: a step's MFMAs must not have the ten window reads in front of the weights they wait for -- the
-      // weights of row m + 1 are requested at the end of step m (those of row 0 first thing in the pass, the half panel is only
-      // known to have landed behind the barrier), the window reads behind them, and nobody waits for the window reads before the
-      // MFMAs are issued (kernel_bench convwino4, MNC_WINO_F4 = 2 / 8: with the reads in front of the weights the LDS latency of
-      // every step was exposed, 0.1 ms of the trunk each).
+    // LDS answers in order: a step's MFMAs must not have the window reads in front of the weights they wait for -- the weights
+    // of row m + 1 are requested at the end of step m (those of row 0 first thing in the pass: the half panel is only known to
+    // have landed behind the barrier), the window reads behind them, and nobody waits for the window reads before the MFMAs are
+    // issued.
+    auto half = [&](int h, f32x2 (&cur)[18], int hbuf_next, f32x2 (&nxt)[18], int s) {
       f32x4 uq[3];
-      load_u(g, 0, uq);
+      load_u(3 * h, uq);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
+        const int i = 3 * h + m;
         f32x2 raw[6];
-        read_colpair(hbuf_next, m, g_next, raw);
-        copies(g, 2 * m, s);
-        mfma_row(m, uq, cur);
-        // The row's MFMAs back to back, then the transform arithmetic in one run: every change between the two costs about ten
-        // cycles.  Nothing moves across a step either: left alone hipcc sinks the arithmetic behind the copies at the end of the pass.
+        read_col(hbuf_next, i, raw);
+        copies(h, 2 * m, s);
+        mfma_step(i, uq, cur);
+        // The step's MFMAs back to back, then the transform arithmetic in one run: every change between the two costs about ten
+        // cycles.  Nothing moves across a step either: left alone hipcc sinks the arithmetic behind the copies at the end of the half.
         if (!(ABL & 128)) __builtin_amdgcn_sched_barrier(0);
-        if (m < 2) load_u(g, m + 1, uq);
-        if (m < 2) second_dim(cur, m + 1);
-        first_dim(m, raw, nxt);
-        if (m == 2) second_dim(nxt, 0);
-        copies(g, 2 * m + 1, s);
+        if (m < 2) load_u(i + 1, uq);
+        if (i == 0 || i == 2) second_dim(cur, (i >> 1) + 1);
+        first_dim(i, raw, nxt);
+        if (i == 5) second_dim(nxt, 0);
+        copies(h, 2 * m + 1, s);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     dma_u(0, 0);
     dma_h(0, 0);
     dma_h(1, 1);
-    MNC_F4_SYNC(6);                                  // half panel 0 and halo 0 of block 0 have landed; halo 1 may still fly
+    MNC_F4_SYNC(0);                                  // half panel 0, halo 0 and halo 1 have landed
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int c = 0; c < 6; ++c) {
       f32x2 raw[6];
-      read_colpair(0, q, 0, raw);
-      first_dim(q, raw, va);
+      read_col(0, c, raw);
+      first_dim(c, raw, va);
     }
     second_dim(va, 0);
-    for (int s = 0; s < nchunks; ++s) {
-      const int bsel = s & 1;
-      pass(0, va, bsel, 1, vb, s);
+    // every wave has read halo 0 before anybody's first copies (block 0 refills that buffer with the halo of block 2 from its first
+    // step on; inside the loop the barrier at the end of block s - 1 stands between the reads of halo s and its refill)
+    if (!(ABL & 16)) MNC_F4_SYNC(0);
+    // (the loop body names its operand arrays: two blocks per trip, the odd one peeled when the count is odd)
+    auto block = [&](f32x2 (&cur)[18], f32x2 (&nxt)[18], int s) {
+      half(0, cur, (s + 1) & 1, nxt, s);
       pin_acc();
-      // middle of block s: every wave is done with half panel 0 and halo s; half panel 1 of this block and halo s + 1 (requested in
-      // the second half of block s - 1) have landed -- everything this wave has in flight
+      // middle of block s: every wave is done with half panel 0; half panel 1 of this block has landed (and the halo of block s + 2)
       if (!(ABL & 16)) MNC_F4_SYNC(0);
-      pass(1, vb, bsel ^ 1, 0, va, s);
+      half(1, cur, (s + 1) & 1, nxt, s);
       pin_acc();
-      // end of block s: every wave is done with half panel 1; half panel 0 of block s + 1 has landed, halo s + 2's six may still fly
-      if (!(ABL & 16)) MNC_F4_SYNC(6);
+      // end of block s: every wave is done with half panel 1 and halo s + 1; half panel 0 of block s + 1 has landed
+      if (!(ABL & 16)) MNC_F4_SYNC(0);
+    };
+    int s = 0;
+    for (; s + 2 <= nchunks; s += 2) {
+      block(va, vb, s);
+      block(vb, va, s + 1);
     }
+    if (s < nchunks) block(va, vb, s);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dead copies behind the last block write the LDS too: none may outlive the wave)
   };
   if (nchunks > 0) {
@@ -455,13 +453,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
       for (int ii = 0; ii < 3; ++ii) {
         f32x2 m[6];
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            constexpr int kColOf[3][2] = {{0, 5}, {1, 2}, {3, 4}};
-            const f32x4 v = acc[((ii * 3 + pp) * 2 + hh) * 2 + c2];
-            m[kColOf[pp][hh]] = e ? f32x2{v.z, v.w} : f32x2{v.x, v.y};
-          }
+        for (int j = 0; j < 6; ++j) {
+          const f32x4 v = acc[(ii * 6 + j) * 2 + c2];
+          m[j] = e ? f32x2{v.z, v.w} : f32x2{v.x, v.y};
+        }
         f4_at2(m[0], m[1], m[2], m[3], m[4], m[5], z[ii][0], z[ii][1], z[ii][2], z[ii][3]);
       }
 #pragma unroll
@@ -581,42 +576,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   }
 }
 
-// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (g)][2 (position half hp)][64 (lane)][36]: element (cb, ct, g, hp, lane = kk * 16 + i,
-// n = 12 ii + 4 p + 2 hh + cg) = (G f G^T)[row 3 hp + ii][column kColOf[p][hh]] of filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 +
-// 4 * g + kk) -- the order in which a pass of wave hp multiplies its positions (one ds_read_b128 = one register pair of the operand
-// x both channel groups), evaluated in double and rounded once.  Cin * Cout * 36 floats, no padding: a lane's 144 bytes are 9 x 16,
-// and an odd multiple of 16 bytes as lane pitch is what keeps ds_read_b128 free of bank conflicts.
+// OIHW fp32 [Cout][Cin][3][3] -> [Cin/8][Cout/32][2 (half panel h)][2 (position half hp)][64 (lane)][36]: element (cb, ct, h, hp,
+// lane = kk * 16 + i, n = 12 m + 2 j + cg) belongs to step 3 h + m of a block: = (G f G^T)[row 3 hp + (3 h + m) / 2][column j] of
+// filter (co = ct * 32 + cg * 16 + i, ci = cb * 8 + 2 * kk + ((3 h + m) & 1)) -- the order in which wave hp multiplies (one
+// ds_read_b128 = two transform columns x both channel groups), evaluated in double and rounded once.  Cin * Cout * 36 floats, no
+// padding: a lane's 144 bytes are 9 x 16, and an odd multiple of 16 bytes as lane pitch is what keeps ds_read_b128 free of bank
+// conflicts.
 __global__ void pack_conv3x3_wino4_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
   const double G[6][3] = {{0.25, 0.0, 0.0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  const int kColOf[3][2] = {{0, 5}, {1, 2}, {3, 4}};
   const int ncot = Cout >> 5;
-  const long items = (long)(Cin >> 3) * ncot * 2 * 2 * 64;        // (cb, ct, g, hp, lane)
+  const long items = (long)(Cin >> 3) * ncot * 2 * 2 * 64;        // (cb, ct, h, hp, lane)
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < items; r += (long)gridDim.x * blockDim.x) {
-    const int lane = (int)(r & 63), hp = (int)((r >> 6) & 1), g = (int)((r >> 7) & 1);
+    const int lane = (int)(r & 63), hp = (int)((r >> 6) & 1), h = (int)((r >> 7) & 1);
     const long tt = r >> 8;
     const int ct = (int)(tt % ncot), cb = (int)(tt / ncot);
     const int kk = lane >> 4, i = lane & 15;
-    const int ci = cb * 8 + 4 * g + kk;
     float* dst = out + r * kF4LanePitch;
-    for (int cg = 0; cg < 2; ++cg) {
-      const int co = ct * 32 + cg * 16 + i;
-      const float* f = w + ((long)co * Cin + ci) * 9;
-      double tmp[3][3];                                           // rows 3 hp .. 3 hp + 2 of G f
+    for (int m = 0; m < 3; ++m) {
+      const int step = 3 * h + m, row = 3 * hp + (step >> 1), ci = cb * 8 + 2 * kk + (step & 1);
+      for (int cg = 0; cg < 2; ++cg) {
+        const int co = ct * 32 + cg * 16 + i;
+        const float* f = w + ((long)co * Cin + ci) * 9;
+        double tmp[3];                                            // row `row` of G f
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) tmp[b] = G[row][0] * (double)f[b] + G[row][1] * (double)f[3 + b] + G[row][2] * (double)f[6 + b];
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-          tmp[a][b] = G[3 * hp + a][0] * (double)f[b] + G[3 * hp + a][1] * (double)f[3 + b] + G[3 * hp + a][2] * (double)f[6 + b];
-#pragma unroll
-      for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const int b = kColOf[pp][hh];                          // (G f) G^T, row 3 hp + ii, column b
-            dst[12 * ii + 4 * pp + 2 * hh + cg] = (float)(tmp[ii][0] * G[b][0] + tmp[ii][1] * G[b][1] + tmp[ii][2] * G[b][2]);
-          }
+        for (int b = 0; b < 6; ++b)                               // (G f) G^T, column b
+          dst[12 * m + 2 * b + cg] = (float)(tmp[0] * G[b][0] + tmp[1] * G[b][1] + tmp[2] * G[b][2]);
+      }
     }
   }
 }
@@ -743,7 +731,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #ifdef MNC_TUNING
   switch (tune(ctx, T_WINO_F4, 0)) {
 #define MNC_F4_ABL(A) case A: kern = conv3x3_wino4_kernel<1, A>; break;
-    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(4) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(128) MNC_F4_ABL(272) MNC_F4_ABL(528)
+    MNC_F4_ABL(1) MNC_F4_ABL(2) MNC_F4_ABL(4) MNC_F4_ABL(6) MNC_F4_ABL(8) MNC_F4_ABL(10) MNC_F4_ABL(14) MNC_F4_ABL(15) MNC_F4_ABL(16) MNC_F4_ABL(31) MNC_F4_ABL(32) MNC_F4_ABL(63) MNC_F4_ABL(128) MNC_F4_ABL(272) MNC_F4_ABL(528)
 #undef MNC_F4_ABL
     default: break;
   }
