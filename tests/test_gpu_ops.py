@@ -185,6 +185,33 @@ def test_conv3x3_winograd_f4(dev, H, W, Cin, Cout, relu, tune):
     print("conv3x3 F(4x4) %dx%d %d->%d relu=%d: max rel err %.2e" % (H, W, Cin, Cout, relu, worst))
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout", [(150, 250, 64, 256), (75, 125, 256, 512), (300, 500, 16, 64), (19, 25, 32, 32), (10, 13, 64, 64),
+                                          (5, 7, 64, 64), (38, 50, 16, 32)])
+def test_conv3x3_winograd_f4_is_bit_reproducible(dev, H, W, Cin, Cout):
+    """The same launch forty (small maps: a hundred) times: every result bit-identical to the first.  The F(4x4) kernel refills its
+    LDS buffers by DMA while other waves of the workgroup read their neighbours; a missing barrier shows up as a difference between
+    runs, not necessarily as an error against the reference.  A weak guard on its own: round 4's race (a fast wave refilled halo
+    buffer 0 while a slow one was still reading it in its prologue) passed this test and every unit test -- back-to-back launches
+    of one kernel keep the waves in step -- and failed tests/test_gpu_pipeline.py::test_image_stream_returns_results_in_order six
+    times out of six, where other streams' kernels share the CUs.  That test is the guard; this one covers the shapes it runs."""
+    rng = np.random.default_rng(H + W + Cin + Cout)
+    x = rng.normal(0, 1, (Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(0, 0.1, Cout).astype(np.float32)
+    d_x, d_b = dev.put(to_c8(x)), dev.put(b)
+    d_w = dev.empty((Cin * Cout * 36,))
+    dev.call("mnc_pack_conv3x3_wino4", dev.put(w), d_w, Cout, Cin)
+    d_y = dev.empty((Cout, H, W), fill=-7.0)
+    first = None
+    for rep in range(40 if H * W > 2000 else 100):
+        dev.call("mnc_conv3x3_wino4", d_x, d_w, d_b, d_y, H, W, Cin, Cout, 1)
+        got = dev.get(d_y, (Cout * H * W,)).copy()
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(first, got), "run %d differs from run 0 in %d values" % (rep, int((first != got).sum()))
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):
