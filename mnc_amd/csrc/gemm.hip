@@ -514,7 +514,10 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
 //   * a block whose last 16-row sub-tile is dead (M in (288, 304], e.g. 300 RoIs) skips that sub-tile's MFMAs in the waves that
 //     own it (LAST): the 32x32x2 kernel's half-tile special case is the general case here.
 //   * ABL (tuning builds, wrong results): 1 no copies inside the loop, 2 no barrier inside the loop -- what they cost (kernel_bench fc, MNC_FC_DMA_ABL = 16 + ABL)
-template <int kMT, int ABL = 0>
+//   * BUF: the copies as buffer_load_dwordx4 ... lds (a descriptor per operand, the stage in the scalar offset, a 32-bit lane offset:
+//     no 64-bit address arithmetic on the VALU the fp32 MFMAs share) instead of global_load_lds_dwordx4 with a 64-bit lane address;
+//     ABL 4 (BUF only): every copy inside the loop issued with all lanes out of range -- the instruction without its memory traffic
+template <int kMT, int ABL = 0, int BUF = 0>
 __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             float* __restrict__ part, int M, int N, int K, int ldc, int kper,
@@ -546,10 +549,36 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
                       : Wt + (long)min(n0 + r - kBM, N - 1) * K) + kbeg + c * 4;
   }
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_fc_dma;
-  auto dma_piece = [&](int i, long off, int buf_byte) {
-    const float* g = src[i] + off;
+  // BUF: descriptors based at this workgroup's first row and K range (the lane offsets then stay far below 2 GB for any shape)
+  typedef int i32x4d __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [](const float* base) {
+    const unsigned long a = (unsigned long)base;
+    i32x4d r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+    r.z = 0x70000000;
+    r.w = 0x00020000;
+    return r;
+  };
+  const i32x4d rs_a = make_rsrc(A + (long)m0 * K + kbeg), rs_w = make_rsrc(Wt + (long)min(n0, N - 1) * K + kbeg);
+  int voff[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int slot = (wave + kNW * i) * 64 + lane, r = slot >> 3, c = (slot & 7) ^ ((r >> 1) & 7);
+    voff[i] = (r < kBM ? min(r, mrows - 1) * K : (min(n0 + r - kBM, N - 1) - min(n0, N - 1)) * K) * 4 + c * 16;
+  }
+  auto dma_piece = [&](int i, long off, int buf_byte, bool in_loop = false) {
     const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + kNW * i) * 1024u);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
+    if (BUF) {
+      const bool is_a = (wave + kNW * i) * 8 < kBM;                  // (a piece is eight whole rows: wave-uniform)
+      const i32x4d rs = is_a ? rs_a : rs_w;
+      const int so = __builtin_amdgcn_readfirstlane((int)off * 4);
+      const int vo = ((ABL & 4) && in_loop) ? 0x7FFFFFF0 : voff[i];
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rs), "s"(so), "s"(l) : "memory");
+    } else {
+      const float* g = src[i] + off;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
+    }
   };
   auto dma_stage = [&](int s, int buf_byte) {
     const long off = (long)min(s, nstages - 1) * 32;
@@ -621,7 +650,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
             const int m = 2 * (q * NS + i);          // MFMAs issued before this pair
             if (m >= kNM - 4 * kPer - 8 && m < kNM - 8 && (m - (kNM - 4 * kPer - 8)) % 4 == 0) {
               __builtin_amdgcn_sched_barrier(0);
-              if (!(ABL & 1)) dma_piece((m - (kNM - 4 * kPer - 8)) / 4, off, cur);
+              if (!(ABL & 1)) dma_piece((m - (kNM - 4 * kPer - 8)) / 4, off, cur, true);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -867,7 +896,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
       if (dabl >= 16) {                              // ablations of the product kernel
         launched = true;
         const int drop = tm == 1 && M > 288 && M <= 304 ? 1 : 0;
-        auto kern = dabl == 17 ? fc_mfma_dma16_kernel<10, 1> : dabl == 18 ? fc_mfma_dma16_kernel<10, 2> : dabl == 19 ? fc_mfma_dma16_kernel<10, 3> : fc_mfma_dma16_kernel<10, 0>;
+        auto kern = dabl == 17 ? fc_mfma_dma16_kernel<10, 1> : dabl == 18 ? fc_mfma_dma16_kernel<10, 2> : dabl == 19 ? fc_mfma_dma16_kernel<10, 3>
+                    : dabl == 20 ? fc_mfma_dma16_kernel<10, 0, 1> : dabl == 21 ? fc_mfma_dma16_kernel<10, 4, 1> : fc_mfma_dma16_kernel<10, 0>;
         MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper,
                            act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
@@ -885,14 +915,20 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
         static std::atomic<unsigned long long> attr16{0};            // one bit per device: function attributes are per device
         const unsigned long long bit = 1ull << (ctx->device & 63);
         if (!(attr16.load(std::memory_order_relaxed) & bit)) {
-          MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma16_kernel<10>),
+          MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma16_kernel<10, 0, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+          MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma16_kernel<10, 0, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
           attr16.fetch_or(bit, std::memory_order_relaxed);
         }
         // one row block whose last 16-row sub-tile holds no live row (300 RoIs = 18 sub-tiles + 12 rows): its MFMAs are skipped
         const int drop = tm == 1 && M > 288 && M <= 304 ? 1 : 0;
-        hipLaunchKernelGGL((fc_mfma_dma16_kernel<10>), dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out,
-                           part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
+        // copies through buffer descriptors (32-bit lane offsets from the workgroup's first row: 320 rows of K floats must stay
+        // below the descriptor's range) -- same bytes to the same places, bit-identical results, 2-4 % faster than 64-bit lane
+        // addresses (kernel_bench fc, MNC_FC_DMA_ABL=20 against 16: fc6 511 -> 500 us, fc7 92.9 -> 89.2, fc6_maskest 142 -> 137)
+        const bool buf = 320.0 * (double)K * 4.0 < 1.8e9;
+        hipLaunchKernelGGL((buf ? fc_mfma_dma16_kernel<10, 0, 1> : fc_mfma_dma16_kernel<10, 0, 0>), dim3(tn * splits * tm), dim3(512), lds,
+                           ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
       }
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
