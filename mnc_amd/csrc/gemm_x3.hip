@@ -404,22 +404,38 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
   const int panel0 = min(bn * 2, npanels - 1), panel1 = min(bn * 2 + 1, npanels - 1);     // a panel past N re-reads the last one
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)s_lp;
   // (inline assembly, as in fc_mfma_dma_kernel: behind the builtin hipcc makes every later ds_read wait for vmcnt(0))
+  // The copies go through buffer descriptors rebuilt per stage on the SCALAR unit (base = operand + stage offset, 64-bit scalar
+  // adds), the lane's part a 32-bit offset that does not change from stage to stage: no 64-bit lane address arithmetic -- VALU
+  // instructions cost an MFMA stream 3-5 cycles each, reduced precision too (tools/probes/valu_under_f16_mfma_probe.hip); the loop
+  // had 24 of them per stage and wave.  Same bytes to the same places as global_load_lds_dwordx4 with lane addresses (round 3).
+  typedef int i32x4d __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [](const uint4* base) {
+    const unsigned long a = (unsigned long)base;
+    i32x4d r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+    r.z = 0x00100000;                                // (the lane offsets stay below kBM x 128 bytes)
+    r.w = 0x00020000;
+    return r;
+  };
+  int voff_a[kPerA];
+#pragma unroll
+  for (int i = 0; i < kPerA; ++i) voff_a[i] = min(r0 + 64 * i, mrows - 1) * 128 + cch * 16;      // rows past M re-read the last valid row; never stored
+  const int voff_w0 = r0 * 128 + cch * 16, voff_w1 = (r0 + 64) * 128 + cch * 16;
   auto dma_stage = [&](int s, int buf_byte) {
     const long st = stage0 + min(s, nstages - 1);    // past the end: the last stage once more, never multiplied
-    const uint4* abase = Ax + ((st * mstride + m0) << 3) + cch;
-    const uint4* w0 = Wx + (((long)panel0 * S + st) << 10) + cch;
-    const uint4* w1 = Wx + (((long)panel1 * S + st) << 10) + cch;
+    const i32x4d ra = make_rsrc(Ax + ((st * mstride + m0) << 3));
+    const i32x4d rw0 = make_rsrc(Wx + (((long)panel0 * S + st) << 10)), rw1 = make_rsrc(Wx + (((long)panel1 * S + st) << 10));
 #pragma unroll
     for (int i = 0; i < kPer; ++i) {
-      const uint4* g;
+      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 8 * i) * 1024u);
       if (i < kPerA) {
-        g = abase + ((long)min(r0 + 64 * i, mrows - 1) << 3);     // rows past M re-read the last valid row; never stored
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff_a[i]), "s"(ra), "s"(l) : "memory");
       } else {
         const int k = i - kPerA;
-        g = ((k >> 1) ? w1 : w0) + ((r0 + 64 * (k & 1)) << 3);
+        const i32x4d rw = (k >> 1) ? rw1 : rw0;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((k & 1) ? voff_w1 : voff_w0), "s"(rw), "s"(l) : "memory");
       }
-      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 8 * i) * 1024u);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l));
     }
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
