@@ -702,25 +702,39 @@ def shared_weights(proto, synth, rank, world, dist):
     local = int(os.environ.get("LOCAL_RANK", rank))
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     host = socket.gethostname()
-    mine, w = None, None
+    # Every rank makes the SAME three collective calls on every path (a barrier in a `finally` met the other ranks'
+    # all_gather_object when one rank failed early, and the job hung until the process-group timeout): a failure travels in the
+    # gathered payload and is raised on all ranks; the file is removed without a collective.  The last barrier stands BEHIND the
+    # unlink (a rank used to return while LOCAL_RANK 0 had not removed the file yet -- anything that looked at the
+    # directory right after the call, e.g. tests/dist_worker8.py, raced with the removal).
+    mine, w, err = None, None, None
     try:
         if local == 0:
             fd, mine = tempfile.mkstemp(prefix="mnc_bench_weights_", suffix=".mncw", dir=base)
             os.close(fd)
             w = synth.synthetic_weights(proto, seed=0)
             caffemodel.save_flat(w, mine)
-        names = [None] * world
-        dist.all_gather_object(names, (host, mine))               # doubles as the barrier: the files are complete
-        path = next(p for h, p in names if h == host and p is not None)
-        if local != 0:
+    except Exception as e:  # noqa: BLE001 -- reported to every rank below
+        err = "rank %d: writing the weight container: %s: %s" % (rank, type(e).__name__, e)
+    names = [None] * world
+    dist.all_gather_object(names, (host, mine, err))                # doubles as the barrier: the files are complete
+    if not any(e for _, _, e in names) and local != 0:
+        try:
+            path = next(p for h, p, _ in names if h == host and p is not None)
             w = caffemodel.load_flat(path)
-    finally:
-        dist.barrier()                  # everybody has the file mapped: the name can go (the pages stay while mapped)
-        if mine is not None:
-            try:
-                os.remove(mine)
-            except OSError:
-                pass
+        except Exception as e:  # noqa: BLE001
+            err = "rank %d: reading the weight container: %s: %s" % (rank, type(e).__name__, e)
+    errs = [None] * world
+    dist.all_gather_object(errs, err)                               # everybody has the file mapped (or has failed): the name can go
+    if mine is not None:
+        try:
+            os.remove(mine)                                         # (the pages stay while mapped)
+        except OSError:
+            pass
+    dist.barrier()                                                  # the name is gone on every node before any rank returns
+    failed = [e for e in errs if e] or [e for _, _, e in names if e]
+    if failed:
+        raise RuntimeError("shared_weights: " + "; ".join(sorted(set(failed))))
     return w
 
 
