@@ -206,7 +206,9 @@ def main():
             net = Net(proto, weights, caffe.TEST, device_id=dev_id, math=math)
         inflight = args.in_flight if ((native or engine == "graph") and in_flight is None) else (in_flight or 1)
         if native:
-            nets = [net] + [NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph) for _ in range(inflight - 1)]
+            # one set of device weights for all images in flight (mnc_net_create_shared): the other nets own a context, a stream
+            # and their activation buffers only
+            nets = [net] + [NativeNet(net) for _ in range(inflight - 1)]
         else:
             nets = [net] + [Net(proto, weights, caffe.TEST, device_id=dev_id, math=math) for _ in range(inflight - 1)]
 
@@ -393,7 +395,7 @@ def main():
             # fetching image k -- independent images overlap on the GPU, the latency-bound stretches of one (proposal top-k, NMS
             # scan, voting) run beside the other's convolutions.  Direct launches, no events; drained inside the timed region.
             from mnc_amd.native_net import NativeNet
-            nets = [net, NativeNet(weights, device_id=dev_id, math=math, use_graph=True)]
+            nets = [net, NativeNet(net)]
             for k in range(6):
                 nets[k % 2].forward_image(images[k % N_IMAGES], record_cap=100)
             for nn in nets:

@@ -564,6 +564,13 @@ typedef struct mnc_net_config {
 /* The reference's values for every field (VGG-16 widths, lib/mnc_config.py defaults). */
 MNC_API int mnc_net_default_config(mnc_net_config* cfg);
 MNC_API int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out);
+/* A second net over the SAME device weights as `parent` (its configuration too): own context `ctx` (same device: own stream,
+ * scratch arenas, activation buffers, HIP graph), no weights of its own -- the reference shares parameters by `param { name }`
+ * inside one net (test.prototxt:514-515 <-> :829-834); several images in flight on one GPU share them across nets the same
+ * way (one 1.13 GB set instead of one per image in flight).  Packs `parent`'s weights first if that has not happened yet (its
+ * parameters must all be set).  `parent` must outlive the nets that share with it: mnc_net_destroy(parent) fails with
+ * MNC_ERR_STATE while one exists. */
+MNC_API int mnc_net_create_shared(mnc_ctx* ctx, mnc_net* parent, mnc_net** out);
 /* One parameter blob of one layer, in Caffe's own layout (what net.params[layer][index].data holds: Convolution
  * [Cout][Cin][3][3], InnerProduct [N][K] with K in (c,h,w) order, bias [N]).  Layers: conv1_1 .. conv5_3, rpn_conv_3x3,
  * rpn_cls_score, rpn_bbox_pred, fc6_maskest, mask_pred, fc6, fc7, fc6_mask, fc7_mask, cls_score, seg_cls_score, bbox_pred

@@ -171,14 +171,15 @@ template <int XCD, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __restrict__ in, const float* __restrict__ wpk,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             float* __restrict__ part, int H, int W, int Cin, int Cout, int relu,
-                                                            int pool_a, int tiles_x, int pix_a, int ksplit_a, int ksplit_b) {
+                                                            int pool_a, int tiles_x, int pix_a, int ksplit_a, int ksplit_b,
+                                                            unsigned* __restrict__ tickets) {
   extern __shared__ __attribute__((aligned(1024))) char s_f4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hp = wave & 1, tg = wave >> 1;                        // 4 waves: position half (transform rows 3 hp .. 3 hp + 2) x tile row
   const int t = lane & 15, k = lane >> 4;
   const int ncot = Cout >> 5;
-  int bx, by, cot, split, ksplit;
+  int bx, by, cot, split, ksplit, tile;            // tile: index of the (pixel tile, channel tile) inside its section
   {
     const int n_a = pix_a * ncot * ksplit_a;
     int b = blockIdx.x, total = n_a, pix0 = 0;
@@ -193,8 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     by = pixt / tiles_x;
     split = bz / ncot;
     cot = bz - split * ncot;
+    tile = (logical / nz) * ncot + cot;
   }
-  const int pool = ksplit == 1 ? pool_a : 0;
+  // K ranges: with `tickets` the tile's last arriver finishes it inside the launch (epilogue), so it pools like an unsplit tile
+  const int pool = (ksplit == 1 || tickets) ? pool_a : 0;
   const int w0 = bx * kF4Cols, h0 = by * kF4Rows;
   const int nblk = Cin >> 3;
   const int chunk0 = split * nblk / ksplit;
@@ -511,7 +514,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     }
   }
   if ((ABL & 32) && relu != 12345) return;           // ablation: no stores (the condition keeps the transform arithmetic alive)
-  const bool fin = ksplit == 1;
+  bool fin = ksplit == 1;
+  if (!fin && tickets) {
+    // K ranges finished inside the launch (mnc_internal.h, slab_last_arriver): the output transform is linear, so a range's slab
+    // is its partial 4x4 tiles as they sit in registers -- [wave][tile position (i, j)][lane] x 16 bytes (the lane's four channels),
+    // 64 KB per workgroup, a kilobyte per wave instruction, no trip through the LDS transposition.  The last arriver adds the
+    // slabs in range order starting from range 0 -- wino4_section_reduce_kernel's order: the same bits -- with the next range's
+    // sixteen loads in flight behind the current range's additions, then finishes the tile as an unsplit workgroup would.
+    // (only the multi-range section of a launch has slabs: either the whole launch -- uniform cut -- or its tail)
+    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(part + (size_t)tile * ksplit * 16384);
+    const int lane_off = (wave * 16 * 64 + lane) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        slab_store(rs, lane_off + (i * 4 + j) * 1024, split * 65536, f32x4{y[i][j][0].x, y[i][j][0].y, y[i][j][1].x, y[i][j][1].y});
+    if (!slab_last_arriver(tickets + tile, ksplit, reinterpret_cast<volatile unsigned*>(s_f4))) return;
+    f32x4 cur[16], nxt[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cur[q] = slab_load(rs, lane_off + q * 1024, 0);
+    f32x4 sum[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum[q] = cur[q];
+    for (int kq = 1; kq < ksplit; ++kq) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) nxt[q] = slab_load(rs, lane_off + q * 1024, kq * 65536);
+      if (kq > 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum[q] += cur[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+    }
+    if (ksplit > 1) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum[q] += cur[q];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = sum[i * 4 + j];
+        y[i][j][0] = f32x2{v.x, v.y};
+        y[i][j][1] = f32x2{v.z, v.w};
+      }
+    fin = true;
+  }
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (fin) bv = *reinterpret_cast<const float4*>(bias + cbase);
   float* dst = fin ? out : part + (long)split * Cout * H * W;
@@ -715,8 +763,15 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
   }
   float* part = nullptr;
   const int smax = ksplit_a > ksplit_b ? ksplit_a : ksplit_b;
+  // K ranges finished inside the launch by each tile's last arriver (the kernel's epilogue; FC_REDUCE bit 1, on by default; 0: by
+  // the separate wino4_section_reduce_kernel -- the same bits).  Only one section of a plan is ever cut; its tiles index slabs and
+  // tickets.  Time-neutral on the trunk (kernel_bench convwino4 1.491 vs 1.492 ms, profiles/r05_inlaunch_reduce.txt: a reducer
+  // reads <= 6 x 64 KB, two reducers per CU) and ten launches per image fewer.
+  const long cut_tiles = ksplit_a > 1 ? (long)pix_a * ncot : (long)(pix - pix_a) * ncot;
+  const bool inkernel = smax > 1 && !(ksplit_a > 1 && ksplit_b > 1 && pix_a < pix) && cut_tiles <= kTickets &&
+                        (tune(ctx, T_FC_REDUCE, 2) & 2) != 0;
   if (smax > 1) {
-    int rc = ensure_scratch(ctx, (size_t)smax * Cout * H * W * 4);
+    int rc = ensure_scratch(ctx, inkernel ? (size_t)cut_tiles * smax * 65536 : (size_t)smax * Cout * H * W * 4);
     if (rc) return rc;
     part = (float*)ctx->scratch;
   }
@@ -748,7 +803,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #endif
   const long nblocks = ((long)pix_a * ksplit_a + (long)(pix - pix_a) * ksplit_b) * ncot;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), kF4LdsBytes, ctx->stream, d_in, d_wpk, d_bias, d_out, part, H, W,
-                     Cin, Cout, relu, pool, tiles_x, pix_a, ksplit_a, ksplit_b);
+                     Cin, Cout, relu, pool, tiles_x, pix_a, ksplit_a, ksplit_b, inkernel ? ctx->tickets : nullptr);
   auto grid_for = [](long n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); };
   auto reduce = [&](int s, int pix0, int npix) {
     const long items = (long)npix * (Cout >> 3) * kF4Rows * kF4Cols * 2 / (pool ? 4 : 1);
@@ -759,8 +814,8 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
       hipLaunchKernelGGL(wino4_section_reduce_kernel<0>, dim3(grid_for(items)), dim3(256), 0, ctx->stream, part, d_bias, d_out, H, W,
                          Cout, s, relu, pix0, npix, tiles_x);
   };
-  if (ksplit_a > 1 && pix_a > 0) reduce(ksplit_a, 0, pix_a);
-  if (ksplit_b > 1 && pix_a < pix) reduce(ksplit_b, pix_a, pix - pix_a);
+  if (!inkernel && ksplit_a > 1 && pix_a > 0) reduce(ksplit_a, 0, pix_a);
+  if (!inkernel && ksplit_b > 1 && pix_a < pix) reduce(ksplit_b, pix_a, pix - pix_a);
   return ls.finish("conv3x3_wino4_kernel");
 }
 

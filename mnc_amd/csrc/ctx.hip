@@ -128,6 +128,15 @@ int mnc_ctx_create(mnc_ctx** out, int device_id) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
     return MNC_ERR_HIP;
   }
+  e = hipMalloc((void**)&ctx->tickets, kTickets * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(ctx->tickets, 0, kTickets * sizeof(unsigned));
+  if (e != hipSuccess) {
+    if (ctx->tickets) (void)hipFree(ctx->tickets);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    set_error("mnc_ctx_create: arrival tickets: %s", hipGetErrorString(e));
+    return MNC_ERR_HIP;
+  }
   *out = ctx;
   clear_error();
   return MNC_OK;
@@ -145,6 +154,7 @@ int mnc_ctx_destroy(mnc_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->proposal) mnc::proposal_state_free(ctx->proposal);
   if (ctx->vote_ws) (void)hipFree(ctx->vote_ws);
+  if (ctx->tickets) (void)hipFree(ctx->tickets);
   if (ctx->comm) mnc::comm_free(ctx);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;

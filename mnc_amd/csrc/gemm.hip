@@ -521,7 +521,8 @@ template <int kMT, int ABL = 0, int BUF = 0>
 __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             float* __restrict__ part, int M, int N, int K, int ldc, int kper,
-                                                            int act, int fused, int tn_, int splits_, int tm_, int drop_last) {
+                                                            int act, int fused, int tn_, int splits_, int tm_, int drop_last,
+                                                            unsigned* __restrict__ tickets) {
   constexpr int kBM = 32 * kMT;
   constexpr int kRows = kBM + kBN;
   constexpr int kNW = 8;
@@ -667,19 +668,63 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
     else run(std::false_type{});
   }
 
+  // fused == 2: the K ranges of a tile are summed INSIDE the launch (mnc_internal.h, slab_last_arriver).  A slab is the workgroup's
+  // accumulators as they sit in registers: [wave][sub-tile i][column half c][lane] x 16 bytes = 160 KB, one kilobyte per wave
+  // instruction (the separate reduction's partial sums were 80 four-byte stores per lane).  The last arriver adds the slabs in
+  // range order starting from zero -- fc_reduce_kernel's order: the same bits -- sixteen 16-byte loads in flight per lane.
+  bool final_out = fused == 1;
+  if (fused == 2) {
+    constexpr int kSlabBytes = kNW * TS * 2 * 64 * 16;
+    const int tile = bmz * tn_ + bn;
+    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(part + (size_t)tile * splits_ * (kSlabBytes / 4));
+    const int lane_off = (wave * TS * 2 * 64 + lane) * 16;
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) slab_store(rs, lane_off + (i * 2 + c) * 1024, split * kSlabBytes, acc[i][c]);
+    if (!slab_last_arriver(tickets + tile, splits_, reinterpret_cast<volatile unsigned*>(s_fc_dma))) return;
+#pragma unroll
+    for (int g0 = 0; g0 < TS * 2; g0 += 4) {
+      f32x4v sum[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      int sp = 0;
+      for (; sp + 4 <= splits_; sp += 4) {
+        f32x4v t[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[q][j] = slab_load(rs, lane_off + (g0 + j) * 1024, (sp + q) * kSlabBytes);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sum[j] += t[q][j];
+      }
+      for (; sp < splits_; ++sp) {
+        f32x4v t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = slab_load(rs, lane_off + (g0 + j) * 1024, sp * kSlabBytes);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] += t[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[(g0 + j) >> 1][(g0 + j) & 1] = sum[j];
+    }
+    final_out = true;
+  }
   // D[row = 16 i + 4 (lane / 16) + reg][col = 16 c + lane % 16] of the wave's 160 x 32 outputs
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int n = n0 + wn * 32 + c * 16 + r16;
     if (n >= N) continue;
-    const float bv = fused ? bias[n] : 0.f;
+    const float bv = final_out ? bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TS; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m0 + wm * TS * 16 + i * 16 + 4 * g4 + e;
         if (m < M) {
-          if (fused) out[(long)m * ldc + n] = apply_act(acc[i][c][e] + bv, act);
+          if (final_out) out[(long)m * ldc + n] = apply_act(acc[i][c][e] + bv, act);
           else part[((long)split * M + m) * N + n] = acc[i][c][e];
         }
       }
@@ -861,9 +906,19 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   const bool dma = mt == 10 && K % 64 == 0 && !tune_set(ctx, T_FC_ABL) && tune(ctx, T_FC_DMA, 1) != 0;
   if (dma) kper = cdiv(kper, 64) * 64;
   splits = cdiv(K, kper);
+  // FC_REDUCE bit 0 (off by default): the K ranges summed INSIDE the launch by each tile's last arriver (fc_mfma_dma16_kernel,
+  // fused == 2; up to 16 ranges) instead of by fc_reduce_kernel -- the same bits (tests/test_gpu_ops.py).  Built and measured in
+  // round 5 (profiles/r05_inlaunch_reduce.txt): a LOSS on this part.  The last arriver of a tile reads 8 x 160 KB of slabs on ONE
+  // CU at ~32 GB/s while 224 CUs idle: fc6 482 + 10 (reduce) -> 524 us, fc7 89 + 10 -> 119 us; the separate kernel spreads the
+  // same 39 MB over the chip at 4.5 TB/s and costs 10 us plus one launch boundary.  fc6_maskest (128 ranges x 2 column tiles)
+  // could not use it at all.  The guide's verdict for this seam ("cut at every all-to-all seam", splitk-seam) holds here too.
+  bool inkernel = dma && splits > 1 && splits <= 16 && tn * tm <= kTickets && (tune(ctx, T_FC_REDUCE, 2) & 1) != 0;
+#ifdef MNC_TUNING
+  if (tune(ctx, T_FC_MFMA16, 1) == 0 || tune(ctx, T_FC_DMA_WAVES, 8) == 4 || tune(ctx, T_FC_DMA_ABL, 0)) inkernel = false;
+#endif
   float* part = nullptr;
   if (splits > 1) {
-    int rc = ensure_scratch(ctx, (size_t)splits * M * N * 4);
+    int rc = ensure_scratch(ctx, inkernel ? (size_t)tn * tm * splits * 163840 : (size_t)splits * M * N * 4);
     if (rc) return rc;
     part = (float*)ctx->scratch;
   }
@@ -900,7 +955,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
                     : dabl == 20 ? fc_mfma_dma16_kernel<10, 0, 1> : dabl == 21 ? fc_mfma_dma16_kernel<10, 4, 1> : fc_mfma_dma16_kernel<10, 0>;
         MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper,
-                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
+                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop, ctx->tickets);
       } else if (tune(ctx, T_FC_MFMA16, 1) == 0 || waves == 4 || dabl) {
         launched = true;
         if (dabl == 1) MNC_FC_DMA_LAUNCH(1, 1);      // 1: every copy re-reads stage 0 (L2-hot operands), 3: only the weight copies do
@@ -928,7 +983,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
         // addresses (kernel_bench fc, MNC_FC_DMA_ABL=20 against 16: fc6 511 -> 500 us, fc7 92.9 -> 89.2, fc6_maskest 142 -> 137)
         const bool buf = 320.0 * (double)K * 4.0 < 1.8e9;
         hipLaunchKernelGGL((buf ? fc_mfma_dma16_kernel<10, 0, 1> : fc_mfma_dma16_kernel<10, 0, 0>), dim3(tn * splits * tm), dim3(512), lds,
-                           ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits, tm, drop);
+                           ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : inkernel ? 2 : 0, tn, splits,
+                           tm, drop, ctx->tickets);
       }
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
@@ -957,7 +1013,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }
-  if (splits > 1) {
+  if (splits > 1 && !inkernel) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
     fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
     return ls.finish("fc_reduce_kernel");

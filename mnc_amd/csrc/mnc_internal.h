@@ -42,6 +42,7 @@ enum TuneKey {
   T_COUNT
 };
 constexpr int kTuneUnset = INT_MIN;
+constexpr int kTickets = 4096;     // mnc_ctx::tickets
 }  // namespace mnc
 
 struct mnc_ctx {
@@ -57,6 +58,10 @@ struct mnc_ctx {
   void* vote_ws = nullptr;    // gpu_mask_voting scratch (mv.hip), grown on demand
   size_t vote_ws_bytes = 0;
   void* comm = nullptr;       // RCCL communicator state (comm.hip), set by mnc_comm_init
+  // Arrival tickets of the K-range reductions that finish INSIDE the launch (gemm.hip, conv_wino4.hip): kTickets counters, zero
+  // between launches -- allocated and zeroed with the context, every launch's last arriver of a tile puts its counter back to
+  // zero.  Launches of one context are stream-ordered, so all of them share the array.
+  unsigned* tickets = nullptr;
   // Bumped whenever one of the context-owned arenas above (scratch, proposal state, voting scratch) is re-allocated: a captured
   // HIP graph holds their raw addresses, so a graph owner (pipeline.hip) records the value at capture and drops its graph when
   // the value has moved on.
@@ -169,6 +174,42 @@ __device__ __forceinline__ void xcd_decode(int bid, int tn, int splits, int tm, 
   const int rest = logical / tn;
   split = rest % splits;
   bm = rest / splits;
+}
+
+// ---- K ranges finished inside the launch (cdna_hip_programming.md section 5, "In-launch split-K reduction"; Guideline 16) ----
+// Every workgroup of an output tile stores its partial sums as a SLAB in its own register layout (16-byte pieces, lane-contiguous,
+// write-through `sc1` stores: no release fence), drains them, and draws an arrival ticket; the workgroup that draws the last one
+// reads all slabs of the tile (sc1 loads behind one agent-scope acquire), adds them IN RANGE ORDER -- the order of the separate
+// reduction kernels, so the results are the same bits whichever workgroup arrives last -- and writes the finished tile.  Nobody
+// waits for anybody: a launch whose workgroups are not co-resident (several streams share the GPU) cannot deadlock.
+typedef unsigned mnc_u32x4 __attribute__((ext_vector_type(4)));
+typedef float mnc_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ void slab_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, mnc_f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mnc_u32x4, v), rs, voff, soff, /*sc1*/ 16);
+}
+__device__ __forceinline__ mnc_f32x4 slab_load(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(mnc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, /*sc1*/ 16));
+}
+// All threads of the workgroup call it after their slab stores; `flag` is a free LDS word of the kernel's ONE shared array (a
+// second __shared__ object de-pipelines LDS-DMA loops).  True in every thread of the tile's last arriver, which also puts the
+// ticket back to zero for the next launch and has acquired the other workgroups' slabs.
+__device__ __forceinline__ bool slab_last_arriver(unsigned* ticket, int arrivals, volatile unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through slab stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const bool last = __builtin_amdgcn_readfirstlane(*flag) == (unsigned)(arrivals - 1);
+  if (last) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  return last;
 }
 
 // Per-device stream + growable device buffer behind the host-pointer entry points (_nms/_mv): the reference

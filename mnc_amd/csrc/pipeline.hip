@@ -75,6 +75,10 @@ struct mnc_net {
   mnc_net_config cfg;
   std::map<std::string, HostBlob> params;      // "<layer>/<index>" as given by the caller (Caffe layout)
   bool finalized = false;
+  // mnc_net_create_shared: the device weights below belong to `owner` (this net holds copies of the pointers and frees none of
+  // them); `sharers` counts the nets that borrow from this one
+  mnc_net* owner = nullptr;
+  int sharers = 0;
   // device weights
   float* w_c3 = nullptr;                       // conv1_1 [Cout][3][3][3]
   void* w_conv[14] = {nullptr};                // packed conv3x3 weights: trunk 1..12, [13] = rpn_conv_3x3
@@ -720,8 +724,44 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   return MNC_OK;
 }
 
+int mnc_net_create_shared(mnc_ctx* ctx, mnc_net* parent, mnc_net** out) {
+  MNC_REQUIRE(ctx && parent && out, "mnc_net_create_shared: null pointer");
+  *out = nullptr;
+  MNC_REQUIRE(!parent->owner, "mnc_net_create_shared: `parent` borrows its weights itself; share with the net that owns them");
+  MNC_REQUIRE(ctx->device == parent->ctx->device, "mnc_net_create_shared: context on device %d, the weights live on device %d",
+              ctx->device, parent->ctx->device);
+  MNC_REQUIRE(ctx != parent->ctx, "mnc_net_create_shared: give the sharing net its own context (stream and scratch arenas)");
+  NET_TRY(finalize(parent));                       // packs and uploads once; synchronises the parent's stream
+  mnc_net* n = nullptr;
+  {
+    mnc_net_config cfg = parent->cfg;              // (the conventions in force on the parent's context included)
+    int rc = mnc_net_create(ctx, &cfg, &n);
+    if (rc) return rc;
+    rc = mnc_ctx_set_layer_conventions(ctx, &parent->cfg.conventions);
+    if (rc) { (void)mnc_net_destroy(n); return rc; }
+    n->cfg.conventions = ctx->conv;
+  }
+  n->owner = parent;
+  ++parent->sharers;
+  n->w_c3 = parent->w_c3;
+  for (int i = 0; i < 14; ++i) {
+    n->w_conv[i] = parent->w_conv[i];
+    n->b_conv[i] = parent->b_conv[i];
+    n->conv_fast[i] = parent->conv_fast[i];
+  }
+  n->packed_trunk = parent->packed_trunk;
+  n->w_rpn = parent->w_rpn; n->b_rpn = parent->b_rpn;
+  n->fc_maskest = parent->fc_maskest; n->fc_maskpred = parent->fc_maskpred;
+  n->fc6 = parent->fc6; n->fc7 = parent->fc7; n->fc6m = parent->fc6m; n->fc7m = parent->fc7m; n->fc_heads = parent->fc_heads;
+  n->finalized = true;
+  *out = n;
+  clear_error();
+  return MNC_OK;
+}
+
 int mnc_net_set_param(mnc_net* net, const char* layer, int index, const float* data_host, size_t count) {
   MNC_REQUIRE(net && layer && data_host && index >= 0 && index <= 1 && count > 0, "mnc_net_set_param: bad argument");
+  MNC_REQUIRE(!net->owner, "mnc_net_set_param: this net shares another net's weights (mnc_net_create_shared)");
   MNC_REQUIRE(!net->finalized, "mnc_net_set_param: the weights of this net are already packed (set them before the first image)");
   try {
     HostBlob& b = net->params[std::string(layer) + "/" + std::to_string(index)];
@@ -863,6 +903,11 @@ int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* n
 
 int mnc_net_destroy(mnc_net* net) {
   if (!net) return MNC_OK;
+  if (net->sharers > 0) {
+    set_error("mnc_net_destroy: %d net(s) created with mnc_net_create_shared still use this net's weights; destroy them first",
+              net->sharers);
+    return MNC_ERR_STATE;
+  }
   mnc_ctx* ctx = net->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -874,16 +919,20 @@ int mnc_net_destroy(mnc_net* net) {
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);
   for (auto& b : net->pooled) if (b.p) (void)hipFree(b.p);
-  void* singles[] = {net->w_c3, net->w_rpn, net->b_rpn};
-  for (void* p : singles) if (p) (void)hipFree(p);
-  for (int i = 0; i < 14; ++i) {
-    if (net->w_conv[i]) (void)hipFree(net->w_conv[i]);
-    if (net->b_conv[i]) (void)hipFree(net->b_conv[i]);
-  }
-  mnc_net::Fc* fcs[] = {&net->fc_maskest, &net->fc_maskpred, &net->fc6, &net->fc7, &net->fc6m, &net->fc7m, &net->fc_heads};
-  for (mnc_net::Fc* f : fcs) {
-    if (f->w) (void)hipFree(f->w);
-    if (f->b) (void)hipFree(f->b);
+  if (net->owner) {
+    --net->owner->sharers;                       // borrowed weights: nothing to free
+  } else {
+    void* singles[] = {net->w_c3, net->w_rpn, net->b_rpn};
+    for (void* p : singles) if (p) (void)hipFree(p);
+    for (int i = 0; i < 14; ++i) {
+      if (net->w_conv[i]) (void)hipFree(net->w_conv[i]);
+      if (net->b_conv[i]) (void)hipFree(net->b_conv[i]);
+    }
+    mnc_net::Fc* fcs[] = {&net->fc_maskest, &net->fc_maskpred, &net->fc6, &net->fc7, &net->fc6m, &net->fc7m, &net->fc_heads};
+    for (mnc_net::Fc* f : fcs) {
+      if (f->w) (void)hipFree(f->w);
+      if (f->b) (void)hipFree(f->b);
+    }
   }
   if (net->pin_img) (void)hipHostFree(net->pin_img);
   if (net->pin_out) (void)hipHostFree(net->pin_out);

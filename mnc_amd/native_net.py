@@ -84,8 +84,23 @@ def config_from_weights(weights, math="fp32", use_graph=True, winograd=None, **o
 class NativeNet(object):
     def __init__(self, weights, device_id=0, math="fp32", use_graph=True, winograd=None, **overrides):
         """weights: {layer: [W, b]} in Caffe layout (what mnc_amd.synth / caffemodel.load_weights return), or the path of a
-        flat MNCW0001 file (caffemodel.save_flat) together with cfg=<NetConfig>."""
+        flat MNCW0001 file (caffemodel.save_flat) together with cfg=<NetConfig>, or ANOTHER NativeNet: this net then runs on that
+        net's device weights and configuration (mnc_net_create_shared: own context, stream and buffers; nothing uploaded), which
+        must stay open while this one is in use."""
         from .engine import _Ctx
+        if isinstance(weights, NativeNet):
+            parent = weights
+            self._ctx = _Ctx(parent._ctx.device_id)
+            self.cfg = parent.cfg
+            self._parent = parent                       # (keeps the owner of the weights alive)
+            h = ctypes.c_void_p()
+            _lib.call("mnc_net_create_shared", self._ctx.h, parent.h, ctypes.addressof(h))
+            self.h = h.value
+            parent._sharers = getattr(parent, "_sharers", 0) + 1
+            self.S = parent.S
+            self.rec_dim = parent.rec_dim
+            self.rows_cap = parent.rows_cap
+            return
         cfg = overrides.pop("cfg", None)
         self._ctx = _Ctx(device_id)
         if cfg is None:
@@ -192,9 +207,15 @@ class NativeNet(object):
 
     def close(self):
         if getattr(self, "h", None):
+            if getattr(self, "_sharers", 0) > 0:
+                raise RuntimeError("NativeNet.close: %d net(s) sharing this net's weights are still open" % self._sharers)
             _lib.call("mnc_net_destroy", self.h)
             self.h = None
             self._ctx.close()
+            parent = getattr(self, "_parent", None)
+            if parent is not None:
+                parent._sharers -= 1
+                self._parent = None
 
     def __del__(self):
         try:
@@ -204,7 +225,8 @@ class NativeNet(object):
 
 
 class ImageStream(object):
-    """Throughput form of NativeNet: `in_flight` nets (own context, stream and buffers each; weights replicated) on ONE GPU, images
+    """Throughput form of NativeNet: `in_flight` nets (own context, stream and buffers each; ONE set of device weights, shared:
+    mnc_net_create_shared) on ONE GPU, images
     submitted round-robin -- image k+1 is launched before image k is fetched, so the stretches of an image that occupy one or a
     few workgroups (proposal top-k, NMS scans, voting) run beside another image's convolutions (+10 % images/s at 600x1000 in
     fp32 with two in flight, +25 % in f16).  Results come back in submission order and equal NativeNet.forward_image's.
@@ -216,7 +238,8 @@ class ImageStream(object):
     def __init__(self, weights, in_flight=2, **kwargs):
         if in_flight < 1:
             raise ValueError("in_flight must be >= 1")
-        self.nets = [NativeNet(weights, **kwargs) for _ in range(int(in_flight))]
+        first = NativeNet(weights, **kwargs)
+        self.nets = [first] + [NativeNet(first) for _ in range(int(in_flight) - 1)]
         self._pending = []                      # indices of the nets holding an unfetched image, oldest first
         self._next = 0
 
@@ -247,6 +270,6 @@ class ImageStream(object):
             yield r
 
     def close(self):
-        for n in self.nets:
+        for n in reversed(self.nets):                   # the sharers first, the owner of the weights last
             n.close()
         self.nets = []

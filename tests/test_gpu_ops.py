@@ -175,6 +175,13 @@ def test_conv3x3_winograd_f4(dev, H, W, Cin, Cout, relu, tune):
         rel = err(got, want)[1]
         worst = max(worst, rel)
         assert rel < 1e-4, (ks, tail, xcd, err(got, want))
+        # K ranges summed inside the launch by each tile's last arriver (default) == summed by wino4_section_reduce_kernel
+        # (FC_REDUCE=0): the same additions in the same order, bit for bit, whichever workgroup arrives last
+        tune("FC_REDUCE", "0")
+        dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
+        dev.call("mnc_conv3x3_wino4", d_x, d_w, d_b, d_y, H, W, Cin, Cout, relu)
+        assert np.array_equal(got, from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)), (ks, tail, xcd)
+        dev.tune("FC_REDUCE", None)
         if H >= 2 and W >= 2:
             OH, OW = (H + 1) // 2, (W + 1) // 2
             d_p = dev.empty((Cout, OH, OW), fill=-7.0)
@@ -943,6 +950,11 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
     # the product build (eight waves, 16 x 16 x 4 fragments) and the register-staged kernel: same products, other order
     tune("FC_DMA", "1")
     prod = run()
+    # its K ranges summed inside the launch by each tile's last arriver (FC_REDUCE bit 0; up to 16 ranges; measured slower, off by
+    # default) == by fc_reduce_kernel: the same additions in the same order
+    tune("FC_REDUCE", "3")
+    assert np.array_equal(prod, run())
+    dev.tune("FC_REDUCE", None)
     tune("FC_DMA", "0")
     staged = run()
     assert err(prod, staged)[1] < 1e-5
@@ -965,6 +977,36 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
         tune("FC_HALF", "0")
         full = run()
         assert err(w8, full)[1] < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 4096, 4096), (300, 1024, 25088), (640, 512, 8192), (300, 4096, 25088)])
+def test_fc_in_launch_reduction_is_bit_reproducible(dev, M, N, K):
+    """FC_REDUCE bit 0: the K ranges of the fp32 InnerProduct summed inside the launch -- every workgroup publishes its partial
+    sums as a slab (write-through stores), draws a ticket, and the tile's last arriver adds the slabs in range order
+    (csrc/mnc_internal.h, slab_last_arriver; the protocol the F(4x4) convolution's K ranges use by default).  Forty launches: every
+    result bit-identical to the first, and to the separate reduction kernel's -- a stale slab read (a missing acquire, a ticket
+    that overtook its stores) shows up as a difference between runs."""
+    rng = np.random.default_rng(M + N + K + 11)
+    a = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    d_a, d_w, d_b = dev.put(a), dev.put(w), dev.put(b)
+    d_o = dev.empty((M * N,), fill=np.nan)
+    first = None
+    dev.tune("FC_REDUCE", "3")
+    try:
+        for rep in range(40):
+            dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, N, 1)
+            got = dev.get(d_o, (M * N,)).copy()
+            if first is None:
+                first = got
+                assert not np.isnan(got).any()
+            else:
+                assert np.array_equal(first, got), "run %d differs from run 0 in %d values" % (rep, int((first != got).sum()))
+    finally:
+        dev.tune("FC_REDUCE", None)
+    dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, N, 1)               # the default: fc_reduce_kernel
+    assert np.array_equal(first, dev.get(d_o, (M * N,)))
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES + [(300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2)])

@@ -1,6 +1,7 @@
 """GPU: the whole-image C entry points (mnc_net_* / mnc_forward_image, csrc/pipeline.hip) against the Python engine running the
 prototxt layer by layer (same kernels, same fused plan -> the same bits), against the oracle voting, and from a plain C program
 with no Python in the process."""
+import ctypes
 import os
 import shutil
 import subprocess
@@ -195,6 +196,44 @@ def test_image_stream_returns_results_in_order():
         assert len(got) == len(want)
         for (c0, r0), (c1, r1) in zip(want, got):
             assert np.array_equal(c0, c1) and np.array_equal(r0, r1, equal_nan=True), n
+
+
+def test_nets_sharing_one_weight_set():
+    """mnc_net_create_shared (NativeNet(<another NativeNet>)): a second net on the first one's device weights -- the same results
+    as a net with its own copy, on a graph replay too; no weights of its own (device memory grows by its buffers only); the owner
+    cannot be destroyed under it, and it takes no parameters."""
+    from mnc_amd import _lib
+    path = models.write_mnc_5stage_test_prototxt(width_div=8)
+    w = synth.synthetic_weights(path, seed=6)
+    wbytes = sum(a.nbytes for v in w.values() for a in v)
+    rng = np.random.default_rng(3)
+    images = [rng.integers(0, 256, (90, 120, 3), dtype=np.uint8) for _ in range(4)]
+    free_a, _ = _lib.device_mem_info(0)
+    own = NativeNet(w)
+    try:
+        want = [own.forward_image(im) for im in images]
+        free0, _ = _lib.device_mem_info(0)
+        sh = NativeNet(own)
+        try:
+            got = [sh.forward_image(im) for im in images]          # eager, capture, replay, replay
+            free1, _ = _lib.device_mem_info(0)
+            for (c0, r0), (c1, r1) in zip(want, got):
+                assert np.array_equal(c0, c1) and np.array_equal(r0, r1, equal_nan=True)
+            # activations + arenas only, no second weight set: the sharer costs at least half a weight set less than the owner did
+            assert (free_a - free0) - (free0 - free1) > wbytes // 2, (free_a - free0, free0 - free1, wbytes)
+            with pytest.raises(RuntimeError, match="sharing"):
+                own.close()
+            with pytest.raises(_lib.MncError, match="still use"):
+                _lib.call("mnc_net_destroy", own.h)
+            a = np.zeros(4, np.float32)
+            with pytest.raises(_lib.MncError, match="shares"):
+                _lib.call("mnc_net_set_param", sh.h, ctypes.cast(ctypes.c_char_p(b"fc7"), ctypes.c_void_p), 1, _lib.ptr(a), 4)
+            c, r = own.forward_image(images[0])                      # the owner still works beside its sharer
+            assert np.array_equal(c, want[0][0]) and np.array_equal(r, want[0][1], equal_nan=True)
+        finally:
+            sh.close()
+    finally:
+        own.close()
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc to build the C host program")
