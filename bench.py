@@ -96,6 +96,7 @@ def parse():
                    help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
     p.add_argument("--no-resident", action="store_true", help="skip the secondary resident-input measurement")
+    p.add_argument("--no-repeats", action="store_true", help="steps < 100: do not run the timed loop three more times for value_min/max")
     p.add_argument("--no-resnet", action="store_true",
                    help="skip the BASELINE configs[4] measurement (ResNet-50 C4, 800x1333, 1000 RoIs, f16) that the default N = 1 "
                         "run appends as `config_resnet50` (a child process: python bench.py --config resnet50)")
@@ -350,6 +351,19 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         phase_ms = {k: 1e3 * v / steps for k, v in phase.items()}
+        # A short timed region (the driver's --steps 20 is 0.08 s) says nothing about its own spread: the same K steps are run
+        # three more times, untimed for `value`, and reported as value_min / value_max next to it.
+        repeats = [elapsed]
+        if steps < 100 and not args.no_repeats:
+            for rep in range(3):
+                t1 = time.perf_counter()
+                for k in range(steps):
+                    if inflight > 1:
+                        step_pipelined(warmup + (rep + 1) * steps + k, False)
+                    else:
+                        step(warmup + (rep + 1) * steps + k)
+                fence()
+                repeats.append(time.perf_counter() - t1)
         # the event pass, AFTER the timed region: `event_steps` more images, one at a time (pipeline drained), as direct
         # launches with a HIP event pair on the engine's stream around every MFMA launch -- what `roofline` is computed from
         records, event_steps = [], 0
@@ -366,7 +380,7 @@ def main():
             mem_gb = (tot - fr) / 1e9
         except Exception:  # noqa: BLE001
             mem_gb = None
-        out = {"elapsed": elapsed, "phase_ms": phase_ms, "records": records, "device_mem_gb": mem_gb,
+        out = {"elapsed": elapsed, "repeats": repeats, "math": math, "phase_ms": phase_ms, "records": records, "device_mem_gb": mem_gb,
                "event_steps": event_steps, "rccl_version": getattr(gatherer, "rccl_version", None), "in_flight": inflight,
                "gather_transport": transport}
         for nn in nets[1:]:
@@ -460,6 +474,9 @@ def main():
                                    "avg_launch_ms": tot_ms / cnt}
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = pmc_traffic(out["roofline"]["kernel"])
             out["roofline_by_kernel"] = roofline_by_kernel(records, steps)
+            c3 = conv3x_summary(records, steps, m.get("math", "fp32"))
+            if c3:
+                out["conv3_x"] = c3
         return out
 
     want_resident = world == 1 and not args.no_resident and args.engine == "python"
@@ -471,10 +488,12 @@ def main():
     ranks = [{"rank": rank, "device": dev_id, "host": socket.gethostname(), "ms_per_step": 1e3 * elapsed / args.steps,
               "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
               "device_mem_gb": m.get("device_mem_gb")}]
+    repeats = list(m.get("repeats") or [elapsed])
     if launched:
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed] + repeats, dtype=torch.float64)       # (every rank ran the same number of repeats)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        repeats = [float(x) for x in t[1:]]
         box = [None] * world
         dist.all_gather_object(box, ranks[0])
         ranks = box
@@ -504,6 +523,11 @@ def main():
             "ranks": ranks, "rccl_version": m["rccl_version"], "dist_backend": args.dist_backend if launched else None,
             "control_plane": "torch.distributed/gloo" if launched else None, "gather_transport": m.get("gather_transport"),
         }
+        if len(repeats) > 1:
+            vals = [world * args.steps / e for e in repeats]
+            out["value_repeats"] = {"values": [round(v, 3) for v in vals], "min": min(vals), "max": max(vals),
+                                    "note": "the timed loop of `steps` steps, then three more runs of it; `value` is the first"}
+
         out.update(summarise(args.steps, m))
         conv = [r for r in m["records"] if r[0].startswith("conv3x3")]
         if conv and out.get("event_steps"):
@@ -607,6 +631,8 @@ def compact_line(out):
                             (world, out.get("gather_transport") or out.get("dist_backend")))}
     line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                         "scaling", "vs_baseline")}
+    if out.get("value_repeats"):
+        line["value_min"], line["value_max"] = _r(out["value_repeats"]["min"]), _r(out["value_repeats"]["max"])
     line["dtype"] = (out.get("dtype") or "").split(" ")[0]
     line["data"] = out.get("data")
     line["config"] = conf
@@ -624,9 +650,16 @@ def compact_line(out):
         line["kernel_ms_per_image"] = {k: _r(v, 3) for k, v in list(out["kernel_ms_per_image"].items())[:4]}
     cr = out.get("conv_roofline")
     if cr:
+        # algorithmic_over_peak: direct-form flop / time / peak -- above 1 under Winograd, which executes 1/4 of them (conv3_x below)
         line["conv_roofline"] = {"conv_tflops": _r(cr.get("conv_achieved_tflops")), "peak_tflops": cr.get("peak_tflops"),
-                                 "frac": _r(cr.get("conv_kernels_frac_of_peak")),
+                                 "algorithmic_over_peak": _r(cr.get("conv_kernels_frac_of_peak")),
                                  "value_frac_of_conv_roofline": _r(cr.get("value_as_frac_of_conv_roofline"))}
+    if out.get("conv3_x"):
+        line["conv3_x"] = {k: _r(v, 3) for k, v in out["conv3_x"].items() if not isinstance(v, str)}
+        for key in sorted(k for k in out if k.startswith("alt_math")):
+            c3 = out[key].get("conv3_x") or {}
+            if "mfma_util_pct" in c3:
+                line["conv3_x"][out[key].get("math", key) + "_mfma_util_pct"] = _r(c3["mfma_util_pct"], 3)
     tr = [r for r in out.get("roofline_by_kernel", []) if r.get("what", "").endswith("(all launches of an image)")
           and "traffic_over_algorithmic" in r]
     if tr:
@@ -652,6 +685,11 @@ def compact_line(out):
         alt["resnet50_mixed"] = _r(out["config_resnet50_mixed"]["value"])
     if alt:
         line["images_per_s_other_protocols"] = alt
+    if out.get("gather_transport"):
+        line["gather_transport"] = out.get("gather_transport")
+    dm = [r.get("device_mem_gb") for r in (out.get("ranks") or []) if r.get("device_mem_gb") is not None]
+    if dm:
+        line["device_mem_gb"] = _r(max(dm), 3)
     ranks = out.get("ranks") or []
     if len(ranks) > 1:
         ms = [r["ms_per_step"] for r in ranks]
@@ -659,12 +697,11 @@ def compact_line(out):
         mem = [r["device_mem_gb"] for r in ranks if r.get("device_mem_gb") is not None]
         if mem:
             line["ranks_device_mem_gb"] = {"max": _r(max(mem), 3)}
-        line["gather_transport"] = out.get("gather_transport")
         line["rccl_version"] = out.get("rccl_version")
     line["detail"] = out.get("_detail_path", "bench_detail.json")
     text = json.dumps(line, separators=(",", ":"))
     if len(text) >= 4000:                               # never let an optional block push the line past the driver's window
-        for k in ("kernel_ms_per_image", "images_per_s_other_protocols", "conv_roofline", "trunk_traffic_over_algorithmic"):
+        for k in ("kernel_ms_per_image", "images_per_s_other_protocols", "conv_roofline", "trunk_traffic_over_algorithmic", "conv3_x"):
             line.pop(k, None)
             text = json.dumps(line, separators=(",", ":"))
             if len(text) < 4000:
@@ -847,6 +884,61 @@ def mfma_peak(scope_name):
     if f16:
         return PEAK_BF16_MATRIX_TFLOPS, "fp16 / bf16 dense MFMA peak (v_mfma_f32_32x32x16_f16 / _bf16)"
     return PEAK_FP32_MATRIX_TFLOPS, "fp32 dense MFMA peak (v_mfma_f32_32x32x2_f32)"
+
+
+# conv3_x (north_star: ">= 50 % MFMA util on conv3_x") = conv3_1, conv3_2, conv3_3 at 600x1000: told apart from the other
+# layers of their flop class by their algorithmic bytes; in every trunk kernel's per-image launch cycle of the LARGE-map template
+# instantiation (conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3: six launches) they are positions 3, 4, 5.
+def _conv3x_bytes():
+    hw, out = 150 * 250, set()
+    for cin, cout in ((128, 256), (256, 256)):
+        for ib in (2, 4):
+            for ob in (2, 4):
+                out.add(hw * (cin * ib + cout * ob) + 36.0 * cin * cout)      # the kernels' LaunchScope formula (4-byte weights)
+        out.add(4.0 * (hw * cin + (hw // 4) * cout + 9 * cin * cout))         # fp32 with the Pooling fused (conv3_3)
+    return tuple(sorted(out))
+
+
+CONV3X_BYTES = _conv3x_bytes()
+CONV3X_PMC = {"fp32": "conv3x3_wino4_kernel<1, 0>", "bf16": "conv3x3_x3_kernel<2, 2, 4, 2, 0>", "f16": "conv3x3_x3_kernel<2, 2, 4, 1, 3>",
+              "bf16x3": "conv3x3_x3_kernel<2, 2, 4, 0, 3>", "mixed": "conv3x3_x3_kernel<2, 2, 4, 0, 3>"}
+CONV_EXECUTED_DIVISOR = {"conv3x3_wino4_mfma": 4.0, "conv3x3_wino_mfma": 2.25}
+
+
+def conv3x_summary(records, steps, math):
+    """-> {"ms", "algorithmic_tflops", "executed_frac", "mfma_util_pct"} of the three conv3_x launches of an image (HIP events of
+    the event pass; MfmaUtil from the PMC profile of this build, positions 3..5 of the large-map kernel's cycle), or None."""
+    rows = [r for r in records if r[0].startswith("conv3x3") and any(abs(r[3] - b) < 1.0 for b in CONV3X_BYTES)
+            and r[2] in (2.0 * 150 * 250 * 9 * 128 * 256, 2.0 * 150 * 250 * 9 * 256 * 256)]
+    if not rows or not steps:
+        return None
+    ms = sum(r[1] for r in rows) / steps
+    fl = sum(r[2] for r in rows) / steps
+    peak, _ = mfma_peak(rows[0][0])
+    div = CONV_EXECUTED_DIVISOR.get(rows[0][0], 1.0)
+    out = {"ms": ms, "algorithmic_tflops": fl / ms / 1e9, "executed_frac": fl / div / ms / 1e9 / peak, "scope": rows[0][0]}
+    util, _src = pmc_value(CONV3X_PMC.get(math, ""), "mfma_util_pct", positions=(3, 4, 5))
+    if util is not None:
+        out["mfma_util_pct"] = util
+    return out
+
+
+def pmc_value(kernel_name, field, positions=None):
+    """-> (average `field` of one kernel of profiles/pmc_latest.json, source) when that profile is of this build, else (None, why)."""
+    from mnc_amd import _build
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_latest.json"
+    if data.get("_build") != _build.source_hash():
+        return None, "profiles/pmc_latest.json is of another build"
+    v = data.get(kernel_name)
+    if not v:
+        return None, "kernel not in profiles/pmc_latest.json"
+    if positions is not None and v.get("by_position"):
+        return sum(v["by_position"][i][field] for i in positions) / len(positions), "pmc_latest.json by_position"
+    return v.get(field), "pmc_latest.json (all launches of the kernel)"
 
 
 def pmc_traffic(scope_name, positions=None):

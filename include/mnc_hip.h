@@ -286,6 +286,12 @@ MNC_API int mnc_conv1x1_to_nchw(mnc_ctx* ctx, const float* d_in_c8, const float*
                                 float* d_out_nchw, int H, int W, int Cin, int Cout);
 /* Reshape(0,2,-1,0) -> Softmax(axis 1) -> Reshape(0,18,-1,0) (test.prototxt:440-462): pairs channel a with A+a. */
 MNC_API int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score_nchw, float* d_prob_nchw, int A, int H, int W);
+/* rpn_cls_score + rpn_bbox_pred + the softmax above in ONE launch (test.prototxt:413-462): d_w = [2A cls rows | 4A bbox rows] x
+ * [Cin] (the two layers' weights concatenated, biases likewise), d_score = the 6A score planes (NCHW: the first 2A are
+ * rpn_cls_score, the last 4A rpn_bbox_pred), d_prob = the 2A probability planes.  The same bits as mnc_conv1x1_to_nchw on the
+ * concatenated weights followed by mnc_rpn_softmax(A). */
+MNC_API int mnc_rpn_heads(mnc_ctx* ctx, const float* d_in_c8, const float* d_w, const float* d_bias, float* d_score_nchw,
+                          float* d_prob_nchw, int H, int W, int Cin, int A);
 /* ROIWarping (test.prototxt:479-492, 809-820) per oracle/SPEC.md section 1, c8 feature -> [R][PH][PW][C].
  * pool2 != 0 fuses the following Pooling MAX 2x2/2 (test.prototxt:494-505): the warp is evaluated at
  * 2PH x 2PW and max-reduced, so the 28x28 "premax" tensor never reaches HBM. */

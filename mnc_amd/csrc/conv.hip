@@ -303,6 +303,110 @@ __global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restr
   }
 }
 
+// conv1_1 on the fp32 matrix pipe (round 5; the kernel above is LDS bound: 54 broadcast weight reads per pixel and channel block,
+// 60 us = 2.6 TB/s on a layer whose floor is writing 153.6 MB).  GEMM view: M = Cout (<= 64: four 16-row tiles), N = 16 pixels
+// per wave step, K = 27 taps padded to 28 = seven v_mfma_f32_16x16x4_f32 steps.  The weights (A: lane (m = l % 16, g = l / 16)
+// holds w[16 t + m][4 ks + g]) sit in 28 registers for the whole kernel; the B operand is im2col on the fly -- lane (n, g) loads
+// tap 4 ks + g of pixel n straight from the NCHW input (16 consecutive pixels per lane group: 64-byte runs, L2 resident), seven
+// 4-byte loads per step, the next step's requested before this step's 28 MFMAs.  D: lane (n, g) holds channels 16 t + 4 g .. + 3
+// of pixel n = one half of a c8 pixel (block 2 t + g / 2, half g & 1): every store instruction writes two 512-byte runs.
+// Accumulation order: the k-ordered fma chain of the instruction from zero, bias added last (the VALU kernel starts from the
+// bias): the two differ in the last bit; a layer uses ONE of them for every output format (the launcher decides by Cout).
+// (NT = Cout / 16 is a template parameter: with a run-time tile count hipcc branched around every MFMA and shuttled the
+// accumulators through AGPRs -- 124 us, twice the VALU kernel)
+template <int OUT, int NT>
+__global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, void* __restrict__ out, int H, int W,
+                                                              int relu, int ntiles) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const long hw = (long)H * W;
+  float a[NT][7];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+      const int k = 4 * ks + g;
+      const float wv = w[(long)(16 * t + n) * 27 + min(k, 26)];
+      a[t][ks] = k < 27 ? wv : 0.f;
+    }
+  f32x4 bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bias + 16 * t + 4 * g);
+  // The lane's seven taps as lane constants: (dh, dw) and the element offset ci * H * W + dh * W + dw from the pixel; tap 27
+  // (g = 3, ks = 6) is the zero pad: a dh no row satisfies.  The first build of this kernel rebuilt clamped 64-bit addresses and a
+  // five-comparison mask per tap and divided by W per tile: ~350 VALU instructions beside 28 MFMAs (which the fp32 MFMAs do not
+  // overlap with) -- 62 us, exactly the VALU kernel's time.  Now: two unsigned range checks per tap, the loads through a buffer
+  // descriptor (an out-of-range offset answers zero: no select on the value, no 64-bit arithmetic), and (h, x) carried from tile
+  // to tile.
+  int toff[7], tdh[7], tdw[7];
+#pragma unroll
+  for (int ks = 0; ks < 7; ++ks) {
+    const int k = 4 * ks + g, kk = min(k, 26), ci = kk / 9, r = kk - ci * 9;
+    tdh[ks] = k < 27 ? r / 3 - 1 : (1 << 29);
+    tdw[ks] = r - (r / 3) * 3 - 1;
+    toff[ks] = ci * H * W + (r / 3 - 1) * W + tdw[ks];
+  }
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 3 * H * W * 4, 0x00020000);
+  const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int step = nwaves * 16, step_h = step / W, step_x = step - step_h * W;      // (wave-uniform: scalar division, once)
+  int pix_l = wave0 * 16 + n, h_l = pix_l / W, x_l = pix_l - h_l * W;               // the tile being LOADED (one division per lane, once)
+  auto load_taps = [&](float (&v)[7]) {
+    const int hh = pix_l < (int)hw ? h_l : (1 << 28);              // (a tile past the map: no row passes the check)
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+      // (& not &&: a select, not a branch around the load -- hipcc waits for vmcnt(0) where branches around loads join)
+      const bool ok = ((unsigned)(hh + tdh[ks]) < (unsigned)H) & ((unsigned)(x_l + tdw[ks]) < (unsigned)W);
+      v[ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, ok ? (pix_l + toff[ks]) * 4 : 0x7FFFFFF0, 0, 0));
+    }
+    pix_l += step; h_l += step_h; x_l += step_x;
+    if (x_l >= W) { x_l -= W; h_l += 1; }
+  };
+  // output: fp32 c8 / split-bf16 pixels are 32 bytes per 8-channel block (the lane's 4 channels: 16 bytes at half g & 1; split form:
+  // 8 bytes of hi at g & 1, 8 of lo 16 bytes behind), fp16 pixels 16 bytes (8 at g & 1); channels 16 t + 4 g .. : block 2 t + g / 2
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int kPB = OUT == 2 ? 16 : 32;
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, 2 * NT * (int)hw * kPB, 0x00020000);
+  const int lane_plane = (g >> 1) * (int)hw * kPB + (g & 1) * (OUT == 0 ? 16 : 8);
+  float cur[7], nxt[7];
+  load_taps(cur);
+  for (int tile = wave0; tile < ntiles; tile += nwaves) {
+    load_taps(nxt);                                                 // (past the last tile: every lane out of range, zeros)
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][ks], cur[ks], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(acc[t]));   // (architectural registers: no AGPR form of the MFMAs)
+    // stores through a buffer descriptor too: the lane's part of the offset is one multiply-add per tile, the channel tile's plane
+    // pair sits in the scalar offset, pixels past the map get an out-of-range offset (dropped) -- x3_store4's bytes, without its
+    // 64-bit address arithmetic per store
+    const int pix = tile * 16 + n;
+    const int voff = pix < (int)hw ? pix * kPB + lane_plane : 0x7FFFFFF0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float4 o = make_float4(acc[t][0] + bv[t][0], acc[t][1] + bv[t][1], acc[t][2] + bv[t][2], acc[t][3] + bv[t][3]);
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      const int soff = t * 2 * (int)hw * kPB;
+      if (OUT == 0) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mnc_u32x4, o), ors, voff, soff, 0);
+      } else if (OUT == 2) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x3_f16x4(o)), ors, voff, soff, 0);
+      } else {
+        uint2 hi, lo;
+        x3_split4(o, hi, lo);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), ors, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), ors, voff + 16, soff, 0);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) cur[ks] = nxt[ks];
+  }
+}
+
 // ---- Pooling MAX 2x2/2, Caffe ceil mode, c8 ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool2_c8_kernel(const float* __restrict__ in, float* __restrict__ out, int CB,
                                                           int H, int W, int OH, int OW) {
@@ -346,6 +450,92 @@ __global__ __launch_bounds__(256) void conv1x1_to_nchw_kernel(const float* __res
       acc = fmaf(a1.x, b1.x, acc); acc = fmaf(a1.y, b1.y, acc); acc = fmaf(a1.z, b1.z, acc); acc = fmaf(a1.w, b1.w, acc);
     }
     out[idx] = acc;
+  }
+}
+
+// ---- the 1x1 heads on the fp32 matrix pipe (round 5) ----------------------------------------------------------------
+// rpn_cls_score / rpn_bbox_pred (test.prototxt:413-439): 54 x 512 weights on 38 x 63 pixels -- 0.13 GFLOP that the one-thread-per-
+// output kernel above spends 22 us on (a 512-long dependent fma chain per thread).  Here a wave owns 16 pixels x two 16-row tiles
+// of output channels on v_mfma_f32_16x16x4_f32, no LDS, no barrier: per 16 input channels (two c8 blocks) a lane loads ONE 16-byte
+// piece of the input (lane (n = l % 16, g = l / 16): pixel n, channels 16 j + 4 g .. + 3 -- the c8 layout is already the B
+// operand's order) and one piece of each tile's weight row (row l % 16, the same channels), then MFMA q multiplies element q:
+// k-index g <-> channel 16 j + 4 g + q.  The next chunk's pieces are requested before the current chunk's MFMAs.
+// Every output is the same k-ordered fma chain whatever tile row it sits in, so the plain form (rows in order) and the fused
+// form below produce the same bits.
+// SOFTMAX: the (bg, fg) softmax of the RPN (test.prototxt:440-462; rpn_softmax_kernel's arithmetic) in the epilogue.  Rows are
+// arranged so that a lane holds both scores of an anchor: tile 0 = [bg 0 .. A-1 | the first 16 - A bbox rows], tile 1 = [fg 0 ..
+// A-1 | the next 16 - A bbox rows], tiles 2.. = the remaining bbox rows: bg a and fg a are row a of tiles 0 and 1 = the same lane
+// and register.
+__device__ __forceinline__ int rpn_row(int tile, int r, int A, int Cout, bool softmax) {
+  if (!softmax) { const int o = tile * 16 + r; return o < Cout ? o : -1; }
+  const int spare = 16 - A;                               // bbox rows that ride along in tiles 0 and 1
+  if (tile < 2) {
+    if (r < A) return tile * A + r;
+    const int o = 2 * A + tile * spare + (r - A);
+    return o < Cout ? o : -1;
+  }
+  const int o = 2 * A + 2 * spare + (tile - 2) * 16 + r;
+  return o < Cout ? o : -1;
+}
+
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           float* __restrict__ prob, int HW, int Cin, int Cout, int A, int pairs) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ptile = wid / pairs, pair = wid - ptile * pairs;
+  if (ptile * 16 >= HW) return;
+  const int n = lane & 15, g = lane >> 4;
+  const int p = min(ptile * 16 + n, HW - 1);                      // (clamped: the last tile's dead pixels repeat a live one)
+  int row[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) row[t] = rpn_row(2 * pair + t, n, A, Cout, SOFTMAX);
+  const float* wp[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) wp[t] = w + (long)max(row[t], 0) * Cin + 4 * g;
+  const float* ip = in + ((long)(g >> 1) * HW + p) * 8 + 4 * (g & 1);
+  const long istep = 2L * HW * 8;                                 // two c8 blocks per chunk
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int chunks = Cin >> 4;
+  f32x4 b = *reinterpret_cast<const f32x4*>(ip);
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(wp[0]), a1 = *reinterpret_cast<const f32x4*>(wp[1]);
+  for (int j = 0; j < chunks; ++j) {
+    const int jn = min(j + 1, chunks - 1);
+    const f32x4 bn = *reinterpret_cast<const f32x4*>(ip + jn * istep);
+    const f32x4 a0n = *reinterpret_cast<const f32x4*>(wp[0] + jn * 16), a1n = *reinterpret_cast<const f32x4*>(wp[1] + jn * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b[q], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b[q], acc[1], 0, 0, 0);
+    }
+    b = bn; a0 = a0n; a1 = a1n;
+  }
+  // D: lane (pixel n, g) holds rows 4 g + e of each tile
+  const bool live = ptile * 16 + n < HW;
+  float v[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = rpn_row(2 * pair + t, 4 * g + e, A, Cout, SOFTMAX);
+      v[t][e] = acc[t][e] + bias[max(o, 0)];
+      if (live && o >= 0) out[(long)o * HW + p] = v[t][e];
+    }
+  if (SOFTMAX && pair == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int a = 4 * g + e;
+      if (live && a < A) {
+        const float s0 = v[0][e], s1 = v[1][e];
+        const float m = fmaxf(s0, s1);
+        const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+        const float sum = e0 + e1;
+        prob[(long)a * HW + p] = e0 / sum;
+        prob[(long)(A + a) * HW + p] = e1 / sum;
+      }
+    }
   }
 }
 
@@ -487,6 +677,21 @@ int mnc_conv3x3_c3_fmt(mnc_ctx* ctx, const float* d_in, const float* d_w, const 
   MNC_REQUIRE(out_fmt >= 0 && out_fmt <= 2, "mnc_conv3x3_c3: out_fmt must be 0 (fp32), 1 (bf16x3 packed) or 2 (fp16 packed)");
   const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + (out_fmt == 2 ? 0.5 : 1.0) * Cout);
   LaunchScope ls(ctx, "conv3x3_c3", flops, bytes);
+  // Cout a multiple of 16 up to 64 (VGG-16: 64): the matrix-pipe kernel; other widths: the VALU kernel.  CONV_COT=-1 forces the latter.
+  if (Cout % 16 == 0 && Cout <= 64 && (long)H * W * Cout * 4 < 0x7FFFFFF0L && tune(ctx, T_CONV_COT, 0) != -1) {
+    const int ntiles = cdiv((long)H * W, 16);
+    typedef void (*c3_fn)(const float*, const float*, const float*, void*, int, int, int, int);
+#define MNC_C3(F) {conv3x3_c3_mfma_kernel<F, 1>, conv3x3_c3_mfma_kernel<F, 2>, conv3x3_c3_mfma_kernel<F, 3>, conv3x3_c3_mfma_kernel<F, 4>}
+    static const c3_fn table[3][4] = {MNC_C3(0), MNC_C3(1), MNC_C3(2)};
+#undef MNC_C3
+    const c3_fn kern = table[out_fmt][Cout / 16 - 1];
+    // three blocks per CU, each wave walking ~12 tiles: a wave's 28 weight gathers are paid once (grid cap 512 / 768 / 1024 / 2048 /
+    // 4096: 38.6 / 38.0 / 39.7 / 42.0 / 52.8 us at 600x1000, profiles/r05_conv1_1.txt; CONV_ROWS > 8 overrides the cap)
+    const int cap = tune(ctx, T_CONV_ROWS, 0) > 8 ? tune(ctx, T_CONV_ROWS, 0) : 768;
+    const int blocks = ntiles / 4 < cap ? (ntiles + 3) / 4 : cap;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, ctx->stream, d_in, d_w, d_bias, d_out, H, W, relu, ntiles);
+    return ls.finish("conv3x3_c3_mfma_kernel");
+  }
   auto kern = out_fmt == 0 ? conv3x3_c3_kernel<0> : (out_fmt == 1 ? conv3x3_c3_kernel<1> : conv3x3_c3_kernel<2>);
   hipLaunchKernelGGL(kern, dim3(grid_for((long)H * W)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w, d_bias, d_out,
                      H, W, Cout, relu);
@@ -512,10 +717,39 @@ int mnc_conv1x1_to_nchw(mnc_ctx* ctx, const float* d_in, const float* d_w, const
   MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out && H > 0 && W > 0 && Cin % 8 == 0 && Cout > 0,
               "mnc_conv1x1_to_nchw: bad argument");
   LaunchScope ls(ctx, "conv1x1_to_nchw", 2.0 * H * W * Cin * Cout, 4.0 * H * W * (Cin + Cout));
+  if (Cin % 16 == 0 && (reinterpret_cast<uintptr_t>(d_w) & 15) == 0) {        // the matrix-pipe form (16 channels per step)
+    const int pairs = cdiv(cdiv(Cout, 16), 2);
+    const long waves = (long)cdiv((long)H * W, 16) * pairs;
+    hipLaunchKernelGGL(conv1x1_mfma_kernel<false>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, ctx->stream, d_in, d_w, d_bias,
+                       d_out, (float*)nullptr, H * W, Cin, Cout, 0, pairs);
+    return ls.finish("conv1x1_mfma_kernel");
+  }
   const long total = (long)H * W * Cout;
   hipLaunchKernelGGL(conv1x1_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_in, d_w, d_bias, d_out,
                      H * W, Cin, Cout);
   return ls.finish("conv1x1_to_nchw_kernel");
+}
+
+// rpn_cls_score + rpn_bbox_pred as ONE 1x1 convolution over the concatenated weights ([2A cls rows | 4A bbox rows]) with the
+// RPN's 2-way softmax in its epilogue: d_score = the 6A score planes (NCHW), d_prob = the 2A probability planes -- the bits of
+// mnc_conv1x1_to_nchw followed by mnc_rpn_softmax(A), one launch (csrc/pipeline.hip).
+int mnc_rpn_heads(mnc_ctx* ctx, const float* d_in, const float* d_w, const float* d_bias, float* d_score, float* d_prob, int H,
+                  int W, int Cin, int A) {
+  MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_score && d_prob && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && A > 0,
+              "mnc_rpn_heads: bad argument");
+  const int Cout = 6 * A;
+  if (Cin % 16 != 0 || A > 16 || (reinterpret_cast<uintptr_t>(d_w) & 15) != 0) {
+    int rc = mnc_conv1x1_to_nchw(ctx, d_in, d_w, d_bias, d_score, H, W, Cin, Cout);
+    if (rc) return rc;
+    return mnc_rpn_softmax(ctx, d_score, d_prob, A, H, W);
+  }
+  LaunchScope ls(ctx, "rpn_heads", 2.0 * H * W * Cin * Cout, 4.0 * H * W * (Cin + Cout + 2 * A));
+  const int rest = 4 * A - 2 * (16 - A);                          // bbox rows behind tiles 0 and 1
+  const int tiles = 2 + (rest > 0 ? cdiv(rest, 16) : 0), pairs = cdiv(tiles, 2);
+  const long waves = (long)cdiv((long)H * W, 16) * pairs;
+  hipLaunchKernelGGL(conv1x1_mfma_kernel<true>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, ctx->stream, d_in, d_w, d_bias,
+                     d_score, d_prob, H * W, Cin, Cout, A, pairs);
+  return ls.finish("conv1x1_mfma_kernel");
 }
 
 int mnc_rpn_softmax(mnc_ctx* ctx, const float* d_score, float* d_prob, int A, int H, int W) {

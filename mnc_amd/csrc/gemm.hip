@@ -897,6 +897,9 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   // its reduction from 24 to 11 us and the total from 44 to 29 us; shallow K (mask_pred, K = 256) keeps 2
   const int min_stages = small ? (stages >= 64 ? 8 : 2) : (mt == 5 ? 16 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
+  // a small GEMM over at most 8 stages (mask_pred: K = 256) is not cut at all: four ranges of two stages each cost 9.5 us + a
+  // 6.3 us reduction launch (kernel_bench fc, round 5) for 0.07 GFLOP; one range of eight stages writes the result itself
+  if (small && stages <= 8) splits = 1;
   if (splits < 1) splits = 1;
   if (tm > 1 && !small)      // several row blocks: pick the split count by cost (see choose_splits); one block: as tuned above
     splits = choose_splits(tn * tm, stages, min_stages, mt == 10 ? 256 : 512,
@@ -1012,6 +1015,11 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
 #undef MNC_FC_DMA_LAUNCH_H
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
+  }
+  if (ctx->defer_reduce) {                           // the caller's next kernel sums the ranges (mnc_internal.h)
+    ctx->deferred_part = splits > 1 && !inkernel ? part : nullptr;
+    ctx->deferred_splits = splits > 1 && !inkernel ? splits : 1;
+    return MNC_OK;
   }
   if (splits > 1 && !inkernel) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);

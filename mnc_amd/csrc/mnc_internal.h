@@ -62,6 +62,12 @@ struct mnc_ctx {
   // between launches -- allocated and zeroed with the context, every launch's last arriver of a tile puts its counter back to
   // zero.  Launches of one context are stream-ordered, so all of them share the array.
   unsigned* tickets = nullptr;
+  // mnc_fc with defer_reduce set leaves the K ranges' partial sums in `scratch` ([splits][M][N]) instead of launching
+  // fc_reduce_kernel and reports them here: the caller's next kernel sums them in range order itself (pipeline.hip: the sibling
+  // classifiers' reduction, softmax, stage bridge and im_detect tail as one launch).  deferred_splits == 1: `out` is complete.
+  bool defer_reduce = false;
+  const float* deferred_part = nullptr;
+  int deferred_splits = 0;
   // Bumped whenever one of the context-owned arenas above (scratch, proposal state, voting scratch) is re-allocated: a captured
   // HIP graph holds their raw addresses, so a graph owner (pipeline.hip) records the value at capture and drops its graph when
   // the value has moved on.
@@ -243,6 +249,15 @@ bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bia
                          int act, void* sm, int sm_fmt, long sm_rows, long sm_row0);   // + the rows in the next InnerProduct's form
 void conv_splitk_reduce_launch(hipStream_t stream, const float* d_part, const float* d_bias, float* d_out, int H, int W,
                                int Cout, int ksplit, int relu);
+// proposal.hip: finishes the sibling classifiers of a head stage in one launch -- the K ranges of [cls_score | seg_cls_score |
+// bbox_pred] summed in range order + bias (fc_reduce_kernel's arithmetic), the softmax of the seg_cls_score columns
+// (softmax_rows_wave_kernel's), then StageBridgeLayer.forward_test (rois_ext != nullptr) or im_detect's tail (boxes != nullptr).
+int heads_finish_launch(mnc_ctx* ctx, const float* part, int splits, const float* bias, float* heads, int ld, int M, int K,
+                        float* scores, const float* rois, float im_h, float im_w, float* rois_ext, const float* rois1,
+                        const float* rois2, float scale, int image_height, int image_width, float* boxes, const int* copy_src,
+                        int* copy_dst);
+int detect_tail_launch(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale, int image_height,
+                       int image_width, float* d_boxes, const int* d_copy_src, int* d_copy_dst);   // mv.hip: mnc_detect_tail + one int moved
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
               const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, int* d_bounds,
               float* d_out_mask, int* d_out_box);

@@ -806,9 +806,13 @@ int mnc_mask_voting_dev(mnc_ctx* ctx, const float* d_boxes, const float* d_masks
 
 // im_detect's tail on the device (tools/demo.py:84-100, TesterWrapper.py:240-260): boxes = clip(rois[:, 1:5] / scale) of both
 // stages, stacked; float32 division and the clamp order of transform/bbox_transform.py:clip_boxes.
+// copy_src / copy_dst (optional): one int carried along -- the whole-image pipeline moves the ProposalLayer's row count into the
+// header of its result block here, so that counts, proposal count and records come down in ONE copy (pipeline.hip).
 __global__ void detect_tail_kernel(const float* __restrict__ rois1, int R1, const float* __restrict__ rois2, int R2, float scale,
-                                   float xmax, float ymax, float* __restrict__ boxes) {
+                                   float xmax, float ymax, float* __restrict__ boxes, const int* __restrict__ copy_src,
+                                   int* __restrict__ copy_dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && copy_src) *copy_dst = *copy_src;
   if (i >= (R1 + R2) * 4) return;
   const int r = i >> 2, k = i & 3;
   const float* roi = r < R1 ? rois1 + (long)r * 5 : rois2 + (long)(r - R1) * 5;
@@ -817,15 +821,25 @@ __global__ void detect_tail_kernel(const float* __restrict__ rois1, int R1, cons
   boxes[i] = fmaxf(fminf(v, hi), 0.0f);
 }
 
-int mnc_detect_tail(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale, int image_height,
-                    int image_width, float* d_boxes) {
+}  // extern "C"
+namespace mnc {
+int detect_tail_launch(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale, int image_height,
+                       int image_width, float* d_boxes, const int* d_copy_src, int* d_copy_dst) {
   MNC_REQUIRE(ctx && d_boxes && R1 >= 0 && R2 >= 0 && (R1 == 0 || d_rois1) && (R2 == 0 || d_rois2) && scale > 0.0f,
               "mnc_detect_tail: bad argument");
-  if (R1 + R2 == 0) return MNC_OK;
+  if (R1 + R2 == 0 && !d_copy_src) return MNC_OK;
   LaunchScope ls(ctx, "detect_tail");
-  hipLaunchKernelGGL(detect_tail_kernel, dim3(cdiv((R1 + R2) * 4, 256)), dim3(256), 0, ctx->stream, d_rois1, R1, d_rois2, R2,
-                     scale, (float)(image_width - 1), (float)(image_height - 1), d_boxes);
+  const int blocks = cdiv((R1 + R2) * 4, 256);
+  hipLaunchKernelGGL(detect_tail_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, ctx->stream, d_rois1, R1, d_rois2, R2,
+                     scale, (float)(image_width - 1), (float)(image_height - 1), d_boxes, d_copy_src, d_copy_dst);
   return ls.finish("detect_tail_kernel");
+}
+}  // namespace mnc
+extern "C" {
+
+int mnc_detect_tail(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale, int image_height,
+                    int image_width, float* d_boxes) {
+  return mnc::detect_tail_launch(ctx, d_rois1, R1, d_rois2, R2, scale, image_height, image_width, d_boxes, nullptr, nullptr);
 }
 
 void _mv(const float* all_boxes, const float* all_masks, const int all_boxes_num, const int* candidate_inds,

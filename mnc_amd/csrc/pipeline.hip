@@ -92,7 +92,13 @@ struct mnc_net {
   int cap_ph = 0, cap_pw = 0, cap_src = 0;
   DevBuf img, taps, data, act[13], pooled[4], rpn_out, rpn_score, rpn_prob;      // rpn_score: [2A score | 4A bbox] planes
   float* rpn_bbox_p = nullptr;                                                      // = rpn_score + 2A planes (set per image size)
-  DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores, records, counts;
+  DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores;
+  // the result block: [per-class counts: 256 B | the ProposalLayer's row count: 256 B | instance records] -- laid out like the
+  // pinned buffer it is copied into, so that an image's results come down in ONE copy
+  DevBuf outblk;
+  float* records() const { return (float*)((char*)outblk.p + 512); }
+  int* counts() const { return (int*)outblk.p; }
+  int* prop_count() const { return (int*)((char*)outblk.p + 256); }
   // the per-RoI tensors a second time, in the stage-major 2-byte form their reduced-precision InnerProduct multiplies from
   // (written by the producing kernel's epilogue: mnc_roi_warp_sm / mnc_maxpool2_rhwc_sm / mnc_mask_pool_sm), bf16x3 / f16 modes
   DevBuf feat14_sm, box7_sm, mask7_sm, f6_sm, f6m_sm;       // f6 / f6m: written by fc6 / fc6_mask's reduction for fc7 / fc7_mask
@@ -104,6 +110,8 @@ struct mnc_net {
   int tap_key_h = -1, tap_key_w = -1;
   int last_r1 = 0, last_r2 = 0;
   bool fc_sm = true, fuse_pools = true;   // plan switches, read from the context's tuning values when the net is created
+  bool fuse_small = true;                 // FUSE_SMALL (default on): heads_finish / rpn_heads instead of their separate launches
+  bool tail_done = false;                 // per image: the stage-5 finish kernel has run im_detect's tail
   bool in_flight = false;      // an image has been launched and not fetched: its staging buffers are still in use
   // HIP graph of one image size
   hipGraphExec_t gexec = nullptr;
@@ -364,8 +372,7 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   NET_TRY(dev_ensure(n, &n->masks, (size_t)2 * R * S * S * 4));
   NET_TRY(dev_ensure(n, &n->scores, (size_t)2 * R * K * 4));
   const size_t rows = (size_t)(K - 1) * c.max_per_image;
-  NET_TRY(dev_ensure(n, &n->records, rows * (6 + S * S) * 4));
-  NET_TRY(dev_ensure(n, &n->counts, 256));
+  NET_TRY(dev_ensure(n, &n->outblk, 512 + rows * (6 + S * S) * 4));
   if ((size_t)H * W * 3 > n->pin_img_cap) {
     if (n->pin_img) NET_TRY(mnc_host_free(n->ctx, n->pin_img));
     n->pin_img = nullptr;
@@ -484,9 +491,14 @@ int run_trunk(mnc_net* n) {
   n->fh = h; n->fw = w;
   const int A = c.num_anchors;
   NET_TRY(conv3(n, 13, cur, (float*)n->rpn_out.p, h, w, cin, c.rpn_channels));
-  NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn, n->b_rpn, (float*)n->rpn_score.p, h, w, c.rpn_channels,
-                              6 * A));
-  NET_TRY(mnc_rpn_softmax(ctx, (const float*)n->rpn_score.p, (float*)n->rpn_prob.p, A, h, w));
+  if (n->fuse_small) {
+    NET_TRY(mnc_rpn_heads(ctx, (const float*)n->rpn_out.p, n->w_rpn, n->b_rpn, (float*)n->rpn_score.p, (float*)n->rpn_prob.p, h, w,
+                          c.rpn_channels, A));
+  } else {
+    NET_TRY(mnc_conv1x1_to_nchw(ctx, (const float*)n->rpn_out.p, n->w_rpn, n->b_rpn, (float*)n->rpn_score.p, h, w, c.rpn_channels,
+                                6 * A));
+    NET_TRY(mnc_rpn_softmax(ctx, (const float*)n->rpn_score.p, (float*)n->rpn_prob.p, A, h, w));
+  }
   NET_TRY(mnc_proposal(ctx, (const float*)n->rpn_prob.p, (const float*)n->rpn_bbox_p, A, h, w, c.anchors, c.feat_stride,
                        (float)n->OH, (float)n->OW, n->im_scale, c.pre_nms_topn, c.post_nms_topn, c.rpn_nms_thresh,
                        c.rpn_min_size, (float*)n->rois.p, nullptr));
@@ -535,8 +547,23 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   NET_TRY(run_fc_sm(ctx, n->fc7m, (const float*)n->f6m.p, n->f6m_sm.p, n->fc6m.kind ? sm_f6m : 0, join, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));
   float* heads = (float*)n->heads.p + (size_t)row0 * 6 * K;      // kept per stage: mnc_net_blob("head_scores")
-  NET_TRY(run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0));
   float* scores = (float*)n->scores.p + (size_t)row0 * K;
+  n->tail_done = false;
+  if (n->fuse_small && R > 0 && K <= 64 && n->fc_heads.kind == 0 && 2.0 * R * 6.0 * K * n->fc_heads.K < 2.0e9) {
+    // the sibling classifiers' GEMM leaves its K ranges; ONE kernel sums them (+ bias), takes the seg_cls_score softmax and runs
+    // the stage bridge (stage 3) or im_detect's tail (stage 5) on the row -- the bits of the four separate launches below
+    ctx->defer_reduce = true;
+    int rc = run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0);
+    ctx->defer_reduce = false;
+    if (rc) return rc;
+    NET_TRY(heads_finish_launch(ctx, ctx->deferred_part, ctx->deferred_splits, n->fc_heads.b, heads, 6 * K, R, K, scores, rois,
+                                (float)n->OH, (float)n->OW, second ? nullptr : (float*)n->rois_ext.p, (const float*)n->rois.p,
+                                (const float*)n->rois_ext.p, n->im_scale, n->H, n->W, second ? (float*)n->boxes.p : nullptr,
+                                second ? proposal_count_ptr(ctx) : nullptr, second ? n->prop_count() : nullptr));
+    n->tail_done = second;
+    return MNC_OK;
+  }
+  NET_TRY(run_fc(n, n->fc_heads, join, heads, R, 6 * K, 0));
   if (R) NET_TRY(mnc_softmax_rows_ld(ctx, heads + K, 6 * K, scores, R, K));                     // seg_cls_prob
   if (!second)
     NET_TRY(mnc_stage_bridge(ctx, rois, heads + 2 * K, 6 * K, scores, K, R, K, (float)n->OH, (float)n->OW,
@@ -551,12 +578,12 @@ int run_heads_and_vote(mnc_net* n, int r1) {
   const int S = c.mask_size, K = c.num_classes;
   NET_TRY(run_stage(n, (const float*)n->rois.p, r1, false, 0));
   NET_TRY(run_stage(n, (const float*)n->rois_ext.p, r1, true, r1));
-  NET_TRY(mnc_detect_tail(ctx, (const float*)n->rois.p, r1, (const float*)n->rois_ext.p, r1, n->im_scale, n->H, n->W,
-                          (float*)n->boxes.p));
+  if (!n->tail_done)             // (otherwise the stage-5 finish kernel wrote the boxes and moved the proposal count)
+    NET_TRY(detect_tail_launch(ctx, (const float*)n->rois.p, r1, (const float*)n->rois_ext.p, r1, n->im_scale, n->H, n->W,
+                               (float*)n->boxes.p, proposal_count_ptr(ctx), n->prop_count()));
   const int rows = (K - 1) * c.max_per_image;
   NET_TRY(mnc_vote_instances(ctx, (const float*)n->boxes.p, (const float*)n->masks.p, (const float*)n->scores.p, 2 * r1, K, S,
-                             c.max_per_image, c.vote_nms_thresh, c.vote_iou_thresh, n->H, n->W, (float*)n->records.p, rows,
-                             (int*)n->counts.p));
+                             c.max_per_image, c.vote_nms_thresh, c.vote_iou_thresh, n->H, n->W, n->records(), rows, n->counts()));
   n->last_r1 = r1; n->last_r2 = r1;
   return MNC_OK;
 }
@@ -564,9 +591,8 @@ int run_heads_and_vote(mnc_net* n, int r1) {
 int enqueue_outputs(mnc_net* n) {
   const mnc_net_config& c = n->cfg;
   const size_t rec_bytes = (size_t)c.max_per_image * (6 + c.mask_size * c.mask_size) * 4;     // the first max_per_image rows
-  NET_TRY(mnc_d2h_async(n->ctx, n->pin_out, n->counts.p, (size_t)c.num_classes * 4));
-  NET_TRY(mnc_d2h_async(n->ctx, (char*)n->pin_out + 256, proposal_count_ptr(n->ctx), 4));
-  NET_TRY(mnc_d2h_async(n->ctx, (char*)n->pin_out + 512, n->records.p, rec_bytes));
+  // [counts | proposal count (moved into the block by the tail kernel) | the first max_per_image records]: one copy
+  NET_TRY(mnc_d2h_async(n->ctx, n->pin_out, n->outblk.p, 512 + rec_bytes));
   return MNC_OK;
 }
 
@@ -708,6 +734,7 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   n->cfg.conventions = ctx->conv;          // the conventions in force (the member, or what the host had set on the context)
   n->fc_sm = tune(ctx, T_FC_SM, 1) != 0;
   n->fuse_pools = tune(ctx, T_FUSE_POOLS, 1) != 0;
+  n->fuse_small = tune(ctx, T_FUSE_SMALL, 1) != 0;
   if (tune(ctx, T_BRANCH_STREAMS, 0) == 1) {
     if (mnc_ctx_create(&n->ctx_b, ctx->device) != MNC_OK) n->ctx_b = nullptr;     // optional: the net works on one stream
     if (n->ctx_b) (void)mnc_ctx_set_layer_conventions(n->ctx_b, &ctx->conv);
@@ -828,8 +855,8 @@ int mnc_net_load_file(mnc_net* net, const char* path) {
 int mnc_forward_image_async(mnc_net* net, const unsigned char* bgr_host, int H, int W, float** d_records, int** d_counts) {
   int rc = launch_image(net, bgr_host, H, W);
   if (rc) return rc;
-  if (d_records) *d_records = (float*)net->records.p;
-  if (d_counts) *d_counts = (int*)net->counts.p;
+  if (d_records) *d_records = net->records();
+  if (d_counts) *d_counts = net->counts();
   clear_error();
   return MNC_OK;
 }
@@ -861,7 +888,7 @@ int mnc_net_fetch(mnc_net* net, float* records_host, int record_cap, int* counts
   if (have < record_cap) memset(records_host + (size_t)have * D, 0, (size_t)(record_cap - have) * D * 4);
   if (R > first && record_cap > first) {          // scores tied at the voting threshold: rows beyond max_per_image
     const int more = (R < record_cap ? R : record_cap) - first;
-    NET_TRY(mnc_d2h(net->ctx, records_host + (size_t)first * D, (const float*)net->records.p + (size_t)first * D,
+    NET_TRY(mnc_d2h(net->ctx, records_host + (size_t)first * D, (const float*)net->records() + (size_t)first * D,
                     (size_t)more * D * 4));
   }
   clear_error();
@@ -896,7 +923,7 @@ int mnc_net_blob(mnc_net* net, const char* name, void** d_ptr, int* dims, int* n
   if (s == "boxes") return set(net->boxes.p, 2, R1 + R2, 4, 0, 0);
   // rows of both stages, columns [cls_score (K) | seg_cls_score (K) | bbox_pred (4K)]: the three sibling InnerProducts are one GEMM
   if (s == "head_scores") return set(net->heads.p, 2, R1 + R2, 6 * c.num_classes, 0, 0);
-  if (s == "records") return set(net->records.p, 2, (c.num_classes - 1) * c.max_per_image, 6 + c.mask_size * c.mask_size, 0, 0);
+  if (s == "records") return set(net->records(), 2, (c.num_classes - 1) * c.max_per_image, 6 + c.mask_size * c.mask_size, 0, 0);
   set_error("mnc_net_blob: unknown blob %s", name);
   return MNC_ERR_INVALID;
 }
@@ -915,7 +942,7 @@ int mnc_net_destroy(mnc_net* net) {
   DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_prob, &net->rois,
                     &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
                     &net->feat14_sm, &net->box7_sm, &net->mask7_sm, &net->f6_sm, &net->f6m_sm,
-                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->records, &net->counts};
+                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->outblk};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);
   for (auto& b : net->pooled) if (b.p) (void)hipFree(b.p);

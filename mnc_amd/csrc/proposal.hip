@@ -317,6 +317,76 @@ __global__ void stage_bridge_kernel(const float* __restrict__ rois, const float*
   out[r * 5 + 1] = ox1; out[r * 5 + 2] = oy1; out[r * 5 + 3] = ox2; out[r * 5 + 4] = oy2;
 }
 
+// One launch for what follows the sibling classifiers' GEMM of a head stage (test.prototxt:713-805 resp. :1040-1106 and
+// tools/demo.py:84-100), one 128-thread block per RoI row m:
+//   1. heads[m][n] = sum over the K ranges (in range order, from zero) + bias[n]   -- fc_reduce_kernel<1, 0>'s arithmetic (no activation);
+//      splits == 1: the GEMM wrote the row itself;
+//   2. scores[m][:] = softmax(heads[m][K .. 2K))                                    -- softmax_rows_wave_kernel's arithmetic (seg_cls_prob);
+//   3. rois_ext[m] = StageBridgeLayer.forward_test on row m (stage_bridge_kernel's arithmetic)           when rois_ext != nullptr,
+//      boxes[m], boxes[M + m] = im_detect's tail on rois1[m], rois2[m] (detect_tail_kernel's arithmetic)  when boxes != nullptr.
+// The same bits as the four separate launches (tests/test_gpu_pipeline.py: the Python engine runs those).
+__global__ __launch_bounds__(128) void heads_finish_kernel(const float* __restrict__ part, int splits, const float* __restrict__ bias,
+                                                           float* __restrict__ heads, int ld, int M, int K, float* __restrict__ scores,
+                                                           const float* __restrict__ rois, float im_h, float im_w,
+                                                           float* __restrict__ rois_ext, const float* __restrict__ rois1,
+                                                           const float* __restrict__ rois2, float scale, float xmax, float ymax,
+                                                           float* __restrict__ boxes, const int* __restrict__ copy_src,
+                                                           int* __restrict__ copy_dst) {
+  __shared__ float row[6 * 64 + 64];                               // the row's 6K values, then its K probabilities
+  const int m = blockIdx.x, t = threadIdx.x, N = 6 * K;
+  if (m == 0 && t == 0 && copy_src) *copy_dst = *copy_src;
+  for (int n = t; n < N; n += 128) {
+    float v;
+    if (splits > 1) {
+      v = 0.f;
+      const long total = (long)M * N, idx = (long)m * N + n;
+      for (int s = 0; s < splits; ++s) v += part[(long)s * total + idx];
+      v = v + bias[n];
+      heads[(long)m * ld + n] = v;
+    } else {
+      v = heads[(long)m * ld + n];
+    }
+    row[n] = v;
+  }
+  __syncthreads();
+  if (t >= 64) return;
+  const int lane = t;
+  const bool live = lane < K;
+  const float v = live ? row[K + lane] : -INFINITY;
+  float mx = v;
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float e = live ? expf(v - mx) : 0.f;
+  float sum = 0.f;
+  for (int i = 0; i < K; ++i) sum += __shfl(e, i);
+  const float pr = e / sum;
+  if (live) { scores[(long)m * K + lane] = pr; row[N + lane] = pr; }
+  if (rois_ext && lane == 0) {
+    const float* p = row + N;
+    int best = 0;
+    float bv = p[0];
+    for (int k = 1; k < K; ++k)
+      if (p[k] > bv) { bv = p[k]; best = k; }
+    const float x1 = rois[m * 5 + 1], y1 = rois[m * 5 + 2], x2 = rois[m * 5 + 3], y2 = rois[m * 5 + 4];
+    const float* d = row + 2 * K + 4 * best;
+    const float widths = x2 - x1 + 1.0f, heights = y2 - y1 + 1.0f;
+    const float ctr_x = x1 + 0.5f * widths, ctr_y = y1 + 0.5f * heights;
+    const float pcx = d[0] * widths + ctr_x, pcy = d[1] * heights + ctr_y;
+    const float pw = np_exp_f32(d[2]) * widths, ph = np_exp_f32(d[3]) * heights;
+    float ox1 = pcx - 0.5f * pw, oy1 = pcy - 0.5f * ph, ox2 = pcx + 0.5f * pw, oy2 = pcy + 0.5f * ph;
+    ox1 = fmaxf(fminf(ox1, im_w - 1.0f), 0.0f); oy1 = fmaxf(fminf(oy1, im_h - 1.0f), 0.0f);
+    ox2 = fmaxf(fminf(ox2, im_w - 1.0f), 0.0f); oy2 = fmaxf(fminf(oy2, im_h - 1.0f), 0.0f);
+    rois_ext[m * 5 + 0] = 0.f;
+    rois_ext[m * 5 + 1] = ox1; rois_ext[m * 5 + 2] = oy1; rois_ext[m * 5 + 3] = ox2; rois_ext[m * 5 + 4] = oy2;
+  }
+  if (boxes && lane < 8) {
+    const int which = lane >> 2, k = lane & 3;
+    const float* roi = (which ? rois2 : rois1) + (long)m * 5;
+    const float q = roi[1 + k] / scale;
+    const float hi = (k & 1) ? ymax : xmax;
+    boxes[((long)which * M + m) * 4 + k] = fmaxf(fminf(q, hi), 0.0f);
+  }
+}
+
 struct ProposalWs {
   float* boxes = nullptr; u64* keys = nullptr; float* scores = nullptr; u64* runs = nullptr;
   int* order = nullptr; float* sorted_scores = nullptr; int* n_cand = nullptr;
@@ -346,6 +416,21 @@ void proposal_state_free(void* state) {
   mnc_proposal_state* st = (mnc_proposal_state*)state;
   if (st->buf) (void)hipFree(st->buf);
   delete st;
+}
+}  // namespace mnc
+
+namespace mnc {
+int heads_finish_launch(mnc_ctx* ctx, const float* part, int splits, const float* bias, float* heads, int ld, int M, int K,
+                        float* scores, const float* rois, float im_h, float im_w, float* rois_ext, const float* rois1,
+                        const float* rois2, float scale, int image_height, int image_width, float* boxes, const int* copy_src,
+                        int* copy_dst) {
+  MNC_REQUIRE(ctx && bias && heads && scores && M > 0 && K >= 2 && K <= 64 && ld >= 6 * K && splits >= 1 && (splits == 1 || part),
+              "heads_finish: bad argument");
+  LaunchScope ls(ctx, "heads_finish");
+  hipLaunchKernelGGL(heads_finish_kernel, dim3(M), dim3(128), 0, ctx->stream, part, splits, bias, heads, ld, M, K, scores, rois,
+                     im_h, im_w, rois_ext, rois1, rois2, scale, (float)(image_width - 1), (float)(image_height - 1), boxes,
+                     copy_src, copy_dst);
+  return ls.finish("heads_finish_kernel");
 }
 }  // namespace mnc
 

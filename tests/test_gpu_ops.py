@@ -392,16 +392,29 @@ def test_conv3x3_packed_weight_layout(dev):
 
 
 @pytest.mark.parametrize("H,W", [(20, 33), (600, 1000)])
-def test_conv1_1_direct(dev, H, W):
+def test_conv1_1_direct(dev, H, W, tune):
+    """conv1_1 (3 input channels, NCHW in, c8 out) against torch: the matrix-pipe kernel (Cout a multiple of 16 up to 64: im2col on
+    the fly, 16 pixels x 64 channels per wave step) and the VALU kernel (other widths; CONV_COT=-1 forces it) -- every width the
+    launcher splits on, ragged pixel tiles, no ReLU."""
     rng = np.random.default_rng(1)
     x = rng.normal(size=(3, H, W)).astype(np.float32)
-    w = (rng.normal(size=(64, 3, 3, 3)) * 0.2).astype(np.float32)
-    b = rng.normal(size=64).astype(np.float32)
-    d_y = dev.empty((64 * H * W,), fill=np.nan)
-    dev.call("mnc_conv3x3_c3", dev.put(x), dev.put(w), dev.put(b), d_y, H, W, 64, 1)
-    got = from_c8(dev.get(d_y, (64 * H * W,)), 64, H, W)
-    _, rel = err(got, _conv_ref(x, w, b))
-    assert rel < 1e-5, rel
+    for Cout, relu in ((64, 1), (16, 0), (48, 1), (8, 1), (72, 0)):
+        w = (rng.normal(size=(Cout, 3, 3, 3)) * 0.2).astype(np.float32)
+        b = rng.normal(size=Cout).astype(np.float32)
+        want = _conv_ref(x, w, b, relu=bool(relu))
+        d_x, d_w, d_b = dev.put(x), dev.put(w), dev.put(b)
+        d_y = dev.empty((Cout * H * W,), fill=np.nan)
+        dev.call("mnc_conv3x3_c3", d_x, d_w, d_b, d_y, H, W, Cout, relu)
+        got = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+        assert not np.isnan(got).any()
+        _, rel = err(got, want)
+        assert rel < 1e-5, (Cout, rel)
+        tune("CONV_COT", "-1")
+        dev.put_into(d_y, np.full((Cout * H * W,), np.nan, np.float32))
+        dev.call("mnc_conv3x3_c3", d_x, d_w, d_b, d_y, H, W, Cout, relu)
+        valu = from_c8(dev.get(d_y, (Cout * H * W,)), Cout, H, W)
+        dev.tune("CONV_COT", None)
+        assert err(valu, want)[1] < 1e-5 and err(valu, got)[1] < 2e-6, Cout
 
 
 @pytest.mark.parametrize("C,H,W", [(16, 75, 125), (8, 2, 2), (64, 600, 1000), (32, 37, 64)])
@@ -435,6 +448,24 @@ def test_conv1x1_and_rpn_softmax(dev):
     wantp = F.softmax(t.reshape(1, 2, -1, W), dim=1).reshape(1, 18, H, W)[0].numpy()
     assert err(prob, wantp)[0] < 1e-6
     assert np.abs(prob[:9] + prob[9:] - 1).max() < 1e-6
+    # both heads and the softmax as ONE launch (mnc_rpn_heads: what the whole-image pipeline runs): the bits of the three calls;
+    # a reduced-width RPN (Cin % 16 != 0) and a ragged last pixel tile too
+    for (H2, W2, C2, A) in ((38, 63, 512, 9), (7, 9, 24, 9), (5, 13, 64, 3), (6, 8, 32, 16)):
+        x2 = rng.normal(size=(C2, H2, W2)).astype(np.float32)
+        w2 = (rng.normal(size=(6 * A, C2)) * 0.05).astype(np.float32)
+        b2 = rng.normal(size=6 * A).astype(np.float32)
+        d_x2, d_w2, d_b2 = dev.put(to_c8(x2)), dev.put(w2), dev.put(b2)
+        d_s2, d_p2 = dev.empty((6 * A * H2 * W2,), fill=np.nan), dev.empty((2 * A * H2 * W2,), fill=np.nan)
+        dev.call("mnc_conv1x1_to_nchw", d_x2, d_w2, d_b2, d_s2, H2, W2, C2, 6 * A)
+        dev.call("mnc_rpn_softmax", d_s2, d_p2, A, H2, W2)
+        s_sep, p_sep = dev.get(d_s2, (6 * A, H2, W2)).copy(), dev.get(d_p2, (2 * A, H2, W2)).copy()
+        ref = _conv_ref(x2, w2.reshape(6 * A, C2, 1, 1), b2, relu=False, pad=0)
+        assert err(s_sep, ref)[1] < 1e-5
+        dev.put_into(d_s2, np.full((6 * A, H2, W2), np.nan, np.float32))
+        dev.put_into(d_p2, np.full((2 * A, H2, W2), np.nan, np.float32))
+        dev.call("mnc_rpn_heads", d_x2, d_w2, d_b2, d_s2, d_p2, H2, W2, C2, A)
+        assert np.array_equal(dev.get(d_s2, (6 * A, H2, W2)), s_sep), (H2, W2, C2, A)
+        assert np.array_equal(dev.get(d_p2, (2 * A, H2, W2)), p_sep), (H2, W2, C2, A)
 
 
 GEN_CONV = [  # H, W, Cin, Cout, K, stride, pad, residual   (ResNet-50 shapes in miniature, plus ragged tiles)
