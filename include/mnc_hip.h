@@ -170,7 +170,10 @@ typedef struct mnc_layer_conventions {
                           * | 1 (dst+0.5)*in/out - 0.5 (half-pixel centres) | 2 dst*(in-1)/(out-1) (align_corners) */
   int maskpool_binary;   /* MaskPooling: 0 feature * continuous mask (SPEC) | 1 feature * (mask >= maskpool_thresh) */
   float maskpool_thresh; /* 0.4 = cfg.BINARIZE_THRESH */
-  int reserved;          /* 0 */
+  int inherit;           /* read by mnc_net_create only (mnc_net_config.conventions): 1 = leave the conventions in force on the
+                          * context alone (what mnc_net_default_config sets), 0 = apply this struct to the context -- all other
+                          * fields zero then selects the SPEC explicitly, whatever an earlier net or the host had set.
+                          * mnc_ctx_set_layer_conventions ignores it. */
 } mnc_layer_conventions;
 MNC_API int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventions* conv);   /* NULL: back to the SPEC */
 /* Override one of the launchers' own choices on this context (a tile shape, a kernel variant, a plan switch): name as in
@@ -561,10 +564,11 @@ typedef struct mnc_net_config {
   int use_graph;           /* 1: replay a captured HIP graph per image size; 0: launch every kernel every time */
   int winograd;            /* fp32 math, the 3x3 convolutions: 4 = Winograd F(4x4,3x3) (mnc_conv3x3_wino4; default), 2 (or 1) =
                             * F(2x2,3x3) (mnc_conv3x3_wino), 0 = direct implicit GEMM */
-  mnc_layer_conventions conventions;   /* ROIWarping / MaskResize / MaskPooling conventions; all zero = oracle/SPEC.md.  The RoI
-                                        * kernels read them from the CONTEXT: mnc_net_create applies this member to `ctx` only when
-                                        * it differs from the all-zero default, so conventions a host set on the context with
-                                        * mnc_ctx_set_layer_conventions survive a net built from mnc_net_default_config */
+  mnc_layer_conventions conventions;   /* ROIWarping / MaskResize / MaskPooling conventions.  The RoI kernels read them from the
+                                        * CONTEXT: with conventions.inherit == 1 (mnc_net_default_config) mnc_net_create leaves the
+                                        * context's alone (the SPEC on a fresh context, or what the host set with
+                                        * mnc_ctx_set_layer_conventions); with inherit == 0 it applies this member to `ctx` (all
+                                        * other fields zero = oracle/SPEC.md) -- for every net on that context */
 } mnc_net_config;
 
 /* The reference's values for every field (VGG-16 widths, lib/mnc_config.py defaults). */

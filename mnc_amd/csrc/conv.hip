@@ -499,18 +499,35 @@ __global__ __launch_bounds__(256) void conv1x1_mfma_kernel(const float* __restri
   const long istep = 2L * HW * 8;                                 // two c8 blocks per chunk
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const int chunks = Cin >> 4;
-  f32x4 b = *reinterpret_cast<const f32x4*>(ip);
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(wp[0]), a1 = *reinterpret_cast<const f32x4*>(wp[1]);
-  for (int j = 0; j < chunks; ++j) {
-    const int jn = min(j + 1, chunks - 1);
-    const f32x4 bn = *reinterpret_cast<const f32x4*>(ip + jn * istep);
-    const f32x4 a0n = *reinterpret_cast<const f32x4*>(wp[0] + jn * 16), a1n = *reinterpret_cast<const f32x4*>(wp[1] + jn * 16);
+  // four chunks per trip, the next trip's twelve pieces requested before this trip's 32 MFMAs: only ~300 waves exist (38 x 63
+  // pixels), so a wave's own loads in flight are all the latency hiding there is (one chunk ahead: 20 us, the VALU kernel's 22)
+  constexpr int kD = 4;
+  f32x4 b[kD], a0[kD], a1[kD];
+  auto fetch = [&](int j0, f32x4 (&bb)[kD], f32x4 (&x0)[kD], f32x4 (&x1)[kD]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b[q], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b[q], acc[1], 0, 0, 0);
+    for (int d = 0; d < kD; ++d) {
+      const int j = min(j0 + d, chunks - 1);                      // (clamped: a trip past the end repeats the last chunk, unused)
+      bb[d] = *reinterpret_cast<const f32x4*>(ip + j * istep);
+      x0[d] = *reinterpret_cast<const f32x4*>(wp[0] + j * 16);
+      x1[d] = *reinterpret_cast<const f32x4*>(wp[1] + j * 16);
     }
-    b = bn; a0 = a0n; a1 = a1n;
+  };
+  fetch(0, b, a0, a1);
+  for (int j0 = 0; j0 < chunks; j0 += kD) {
+    f32x4 bn[kD], a0n[kD], a1n[kD];
+    fetch(j0 + kD, bn, a0n, a1n);
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+      if (j0 + d < chunks) {                                      // (wave-uniform; chunks % 4 != 0 only for reduced widths)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[d][q], b[d][q], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[d][q], b[d][q], acc[1], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < kD; ++d) { b[d] = bn[d]; a0[d] = a0n[d]; a1[d] = a1n[d]; }
   }
   // D: lane (pixel n, g) holds rows 4 g + e of each tile
   const bool live = ptile * 16 + n < HW;

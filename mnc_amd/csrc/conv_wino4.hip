@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
     dma_u(0, 0);
     dma_h(0, 0);
     dma_h(1, 1);
-    MNC_F4_SYNC(0);                                  // half panel 0, halo 0 and halo 1 have landed
+    // half panel 0 and halo 0 have landed; halo 1 (this wave's last six copies; they complete in issue order) may still be in
+    // flight under the prologue transform -- the barrier behind it waits for everything (round 5)
+    if (ABL & 768) { MNC_F4_SYNC(0); } else { MNC_F4_SYNC(6); }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       f32x2 raw[6];

@@ -275,7 +275,7 @@ int mnc_ctx_set_layer_conventions(mnc_ctx* ctx, const mnc_layer_conventions* con
               "layer conventions: warp_round_edges / warp_no_plus_one / warp_oob / maskpool_binary are 0 or 1");
   MNC_REQUIRE(c.maskpool_thresh == c.maskpool_thresh, "layer conventions: maskpool_thresh is NaN");
   ctx->conv = c;
-  ctx->conv.reserved = 0;
+  ctx->conv.inherit = 0;
   clear_error();
   return MNC_OK;
 }

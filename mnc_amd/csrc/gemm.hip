@@ -618,7 +618,11 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
     Frags f0, f1;
     dma_stage(0, 0);
     dma_stage(1, kBufXor);
-    dma_wait();
+    // only stage 0 has to have landed before the first MFMA (copies complete in issue order: kPer of this wave's may still be in
+    // flight); stage 1 is waited for in front of the loop's first barrier, half a stage of MFMAs later.  All 256 workgroups pull
+    // their first stages at once (29 MB): waiting for both cost every InnerProduct ~3 us of prologue (round 5).
+    static_assert(kPer == 7, "the literal in the wait below");
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     __syncthreads();
     read_frags(0, 0, f0);
     int cur = 0;

@@ -694,7 +694,8 @@ int mnc_net_default_config(mnc_net_config* cfg) {
   cfg->math = 0;
   cfg->use_graph = 1;
   cfg->winograd = 4;
-  cfg->conventions.maskpool_thresh = 0.4f;         // every switch 0: oracle/SPEC.md
+  cfg->conventions.maskpool_thresh = 0.4f;         // every switch 0: oracle/SPEC.md ...
+  cfg->conventions.inherit = 1;                    // ... but the context's conventions stay in force unless the host clears this
   clear_error();
   return MNC_OK;
 }
@@ -715,18 +716,19 @@ int mnc_net_create(mnc_ctx* ctx, const mnc_net_config* cfg, mnc_net** out) {
   MNC_REQUIRE(cfg->num_classes <= 64, "mnc_net_create: num_classes %d > 64 (the result header holds 64 counts)", cfg->num_classes);
   MNC_REQUIRE(cfg->math >= 0 && cfg->math <= 4, "mnc_net_create: math must be 0 (fp32), 1 (bf16x3), 2 (f16), 3 (mixed) or 4 (bf16)");
   MNC_REQUIRE(cfg->target_size > 0 && cfg->max_size >= cfg->target_size, "mnc_net_create: target_size / max_size");
-  {
-    // The RoI launchers read the conventions from the context.  An all-default member (mnc_net_default_config) leaves what the
-    // host set on the context alone (a net built from the default config used to revert them to the SPEC, for every
-    // user of a shared context); anything else is validated and applied.
-    const mnc_layer_conventions& cv = cfg->conventions;
-    const bool dflt = cv.warp_sample == 0 && cv.warp_round_edges == 0 && cv.warp_no_plus_one == 0 && cv.warp_oob == 0 &&
-                      cv.resize_mode == 0 && cv.maskpool_binary == 0;
-    if (!dflt) {
-      int rc = mnc_ctx_set_layer_conventions(ctx, &cfg->conventions);
-      if (rc) return rc;
-    }
+  // The RoI launchers read the conventions from the context.  conventions.inherit (set by mnc_net_default_config) keeps what is
+  // in force there; anything else is validated and applied -- an explicit all-zero member included (the all-zero value
+  // used to double as "inherit", so a host could not ask for the SPEC on a context an earlier net had changed).
+  if (!cfg->conventions.inherit) {
+    int rc = mnc_ctx_set_layer_conventions(ctx, &cfg->conventions);
+    if (rc) return rc;
   }
+  // F(4x4,3x3) addresses its operands through 32-bit buffer offsets (conv_wino4.hip): the largest trunk map must stay below 2 GB
+  // (a 64-channel map of 8.4 Mpixel).  Refused here, with the remedy, rather than at the first oversized image.
+  MNC_REQUIRE(cfg->math != 0 || cfg->winograd != 4 ||
+                  (double)cfg->trunk_channels[0] * cfg->max_size * (double)cfg->max_size * 4.0 < 2147483648.0,
+              "mnc_net_create: winograd = 4 with max_size %d: a %d-channel %dx%d map exceeds the F(4x4) kernel's 2 GB operand range; "
+              "use winograd = 2", cfg->max_size, cfg->trunk_channels[0], cfg->max_size, cfg->max_size);
   mnc_net* n = new (std::nothrow) mnc_net();
   if (!n) { set_error("mnc_net_create: out of host memory"); return MNC_ERR_NOMEM; }
   n->ctx = ctx;

@@ -21,11 +21,11 @@ class LayerConventions(ctypes.Structure):
     """Mirror of `mnc_layer_conventions` (include/mnc_hip.h): the SPEC-CHOICEs of ROIWarping / MaskResize / MaskPooling."""
     _fields_ = [("warp_sample", ctypes.c_int), ("warp_round_edges", ctypes.c_int), ("warp_no_plus_one", ctypes.c_int),
                 ("warp_oob", ctypes.c_int), ("resize_mode", ctypes.c_int), ("maskpool_binary", ctypes.c_int),
-                ("maskpool_thresh", ctypes.c_float), ("reserved", ctypes.c_int)]
+                ("maskpool_thresh", ctypes.c_float), ("inherit", ctypes.c_int)]
 
     @classmethod
     def make(cls, conv=None):
-        """dict {field: value} (None / {} = the SPEC) -> struct; unknown names raise."""
+        """dict {field: value} (None / {} = the SPEC) -> struct with inherit = 0 (mnc_net_create APPLIES it); unknown names raise."""
         c = cls(0, 0, 0, 0, 0, 0, 0.4, 0)
         for k, v in (conv or {}).items():
             if k not in ("warp_sample", "warp_round_edges", "warp_no_plus_one", "warp_oob", "resize_mode", "maskpool_binary",
@@ -35,7 +35,7 @@ class LayerConventions(ctypes.Structure):
         return c
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "inherit"}
 
 
 class NetConfig(ctypes.Structure):

@@ -217,6 +217,43 @@ def test_invalid_conventions_fail_loudly(dev):
 
 
 @pytest.mark.gpu
+def test_net_config_inherits_or_applies_conventions(dev):
+    """mnc_net_create and the conventions in force on its context: the default config (conventions.inherit = 1) leaves them alone;
+    a config with inherit = 0 applies its member -- an all-zero one too, i.e. a host CAN ask for the SPEC on a context an earlier
+    net or call had changed (the all-zero value used to mean "inherit", so the result depended on creation order)."""
+    import ctypes
+    from mnc_amd import _lib
+    from mnc_amd.native_net import LayerConventions, default_config
+
+    def in_force():
+        back = LayerConventions()
+        dev.call("mnc_ctx_get_layer_conventions", ctypes.addressof(back))
+        return back.as_dict()
+
+    def create(cfg):
+        h = ctypes.c_void_p()
+        _lib.call("mnc_net_create", dev.h, ctypes.addressof(cfg), ctypes.addressof(h))
+        _lib.call("mnc_net_destroy", h.value)
+
+    alt = {"warp_sample": 2, "resize_mode": 1}
+    try:
+        _set(dev, alt)
+        want = in_force()
+        cfg = default_config()
+        assert cfg.conventions.inherit == 1
+        create(cfg)
+        assert in_force() == want                                   # inherited
+        cfg.conventions = LayerConventions.make({})                 # explicit SPEC (inherit = 0)
+        create(cfg)
+        assert in_force() == LayerConventions.make({}).as_dict()
+        cfg.conventions = LayerConventions.make({"maskpool_binary": 1})
+        create(cfg)
+        assert in_force()["maskpool_binary"] == 1
+    finally:
+        _set(dev, {})
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("conv", [{"warp_sample": 2, "warp_oob": 1, "resize_mode": 1},
                                   {"warp_round_edges": 1, "warp_no_plus_one": 1, "resize_mode": 2, "maskpool_binary": 1}],
                          ids=["roialign_like", "roipool_like"])
