@@ -381,6 +381,13 @@ MNC_API int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask
  * act: 0 none, 1 ReLU, 2 sigmoid. */
 MNC_API int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, float* d_out, int M,
                    int N, int K, int ldc, int act);
+/* Two InnerProducts of ONE shape in one launch: out_i = act(a_i . w_i^T + bias_i), i = 0, 1 (the box and the mask branch of a head
+ * stage: fc6 + fc6_mask, fc7 + fc7_mask, test.prototxt:584-627 / :652-696).  Twice the column tiles fill the chip with half as
+ * many K ranges: longer ranges per workgroup, half the partial sums.  Shapes mnc_fc would not give to its 320-row kernel in one
+ * launch run as two mnc_fc calls.  The paired launch groups the partial sums differently from mnc_fc (results differ in the last
+ * bits): every executor of a graph pairs the same layers. */
+MNC_API int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, const float* d_bias0, float* d_out0, const float* d_a1,
+                        const float* d_w1, const float* d_bias1, float* d_out1, int M, int N, int K, int ldc, int act);
 /* InnerProduct on the bf16 matrix pipe with fp32-class accuracy ("bf16x3": every operand split into hi + lo bf16, product =
  * a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; relative error ~1e-5 per product, see mnc_amd/csrc/gemm_x3.hip).
  * d_w_packed comes from mnc_pack_fc_bf16x3: fp32 [N][K] -> stage-major tiles [ceil(N/128)][K/32][128][(hi x8 | lo x8) x 4] bf16,

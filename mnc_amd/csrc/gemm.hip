@@ -517,12 +517,19 @@ __global__ __launch_bounds__(256 * kWM) void fc_mfma_dma_kernel(const float* __r
 //   * BUF: the copies as buffer_load_dwordx4 ... lds (a descriptor per operand, the stage in the scalar offset, a 32-bit lane offset:
 //     no 64-bit address arithmetic on the VALU the fp32 MFMAs share) instead of global_load_lds_dwordx4 with a 64-bit lane address;
 //     ABL 4 (BUF only): every copy inside the loop issued with all lanes out of range -- the instruction without its memory traffic
+// PAIR (round 5): two InnerProducts of one shape in ONE launch (mnc_fc_pair: fc6 + fc6_mask, fc7 + fc7_mask -- the box and the
+// mask branch of a head stage, test.prototxt:584-627 / :652-696).  The column tiles of product 1 follow those of product 0
+// (tn_ counts both; pair_tn = the tiles of one), so 2 x 32 tiles need 4 K ranges instead of 8 to fill the chip: a workgroup's
+// K range is twice as long (prologue and epilogue paid once per 196 instead of 98 stages) and half as many partial sums are
+// written and read back.
 template <int kMT, int ABL = 0, int BUF = 0>
-__global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restrict__ A, const float* __restrict__ Wt,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                            float* __restrict__ part, int M, int N, int K, int ldc, int kper,
+__global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restrict__ A_0, const float* __restrict__ Wt_0,
+                                                            const float* __restrict__ bias_0, float* __restrict__ out_0,
+                                                            float* __restrict__ part_0, int M, int N, int K, int ldc, int kper,
                                                             int act, int fused, int tn_, int splits_, int tm_, int drop_last,
-                                                            unsigned* __restrict__ tickets) {
+                                                            unsigned* __restrict__ tickets, const float* __restrict__ A_1,
+                                                            const float* __restrict__ Wt_1, const float* __restrict__ bias_1,
+                                                            float* __restrict__ out_1, int pair_tn) {
   constexpr int kBM = 32 * kMT;
   constexpr int kRows = kBM + kBN;
   constexpr int kNW = 8;
@@ -537,6 +544,13 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
   const int r16 = lane & 15, g4 = lane >> 4;
   int bn, split, bmz;
   xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
+  const int which = (pair_tn && bn >= pair_tn) ? 1 : 0;             // (block-uniform) which product of a pair this tile belongs to
+  bn -= which * pair_tn;
+  const float* __restrict__ A = which ? A_1 : A_0;
+  const float* __restrict__ Wt = which ? Wt_1 : Wt_0;
+  const float* __restrict__ bias = which ? bias_1 : bias_0;
+  float* __restrict__ out = which ? out_1 : out_0;
+  float* __restrict__ part = part_0 + (fused == 0 ? (size_t)which * splits_ * M * N : (size_t)0);   // partial sums: [product][range][M][N]
   const int n0 = bn * kBN, m0 = bmz * kBM;
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
   const int nstages = (kend - kbeg) / 32;
@@ -679,7 +693,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
   bool final_out = fused == 1;
   if (fused == 2) {
     constexpr int kSlabBytes = kNW * TS * 2 * 64 * 16;
-    const int tile = bmz * tn_ + bn;
+    const int tile = bmz * tn_ + which * pair_tn + bn;
     const __amdgpu_buffer_rsrc_t rs = slab_rsrc(part + (size_t)tile * splits_ * (kSlabBytes / 4));
     const int lane_off = (wave * TS * 2 * 64 + lane) * 16;
 #pragma unroll
@@ -781,6 +795,39 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += part[(long)s * total + idx];
     out[m * ldc + n] = apply_act(v + bias[n], act);
+  }
+}
+
+// The reduction of a PAIR (mnc_fc_pair): partial sums [product][range][M][N], one launch for both products; per element the
+// additions of fc_reduce_kernel<4, 0> (range order, from zero, + bias, activation).
+__global__ __launch_bounds__(256) void fc_reduce_pair_kernel(const float* __restrict__ part, const float* __restrict__ bias0,
+                                                             const float* __restrict__ bias1, float* __restrict__ out0,
+                                                             float* __restrict__ out1, int M, int N, int ldc, int splits, int act) {
+  const int n4 = N >> 2;
+  const long total4 = ((long)M * N) >> 2;
+  for (long i2 = (long)blockIdx.x * blockDim.x + threadIdx.x; i2 < 2 * total4; i2 += (long)gridDim.x * blockDim.x) {
+    const int which = i2 >= total4;
+    const long i = i2 - which * total4;
+    const float4* p4 = reinterpret_cast<const float4*>(part) + (long)which * splits * total4;
+    const int n = (int)(i % n4) * 4;
+    const long m = i / n4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+      const float4 a = p4[(long)s * total4 + i], b = p4[(long)(s + 1) * total4 + i], c = p4[(long)(s + 2) * total4 + i],
+                   d = p4[(long)(s + 3) * total4 + i];
+      v.x = (((v.x + a.x) + b.x) + c.x) + d.x;
+      v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+      v.z = (((v.z + a.z) + b.z) + c.z) + d.z;
+      v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; s < splits; ++s) {
+      const float4 a = p4[(long)s * total4 + i];
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>((which ? bias1 : bias0) + n);
+    *reinterpret_cast<float4*>((which ? out1 : out0) + m * ldc + n) =
+        make_float4(apply_act(v.x + b.x, act), apply_act(v.y + b.y, act), apply_act(v.z + b.z, act), apply_act(v.w + b.w, act));
   }
 }
 
@@ -962,7 +1009,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
                     : dabl == 20 ? fc_mfma_dma16_kernel<10, 0, 1> : dabl == 21 ? fc_mfma_dma16_kernel<10, 4, 1> : fc_mfma_dma16_kernel<10, 0>;
         MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper,
-                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop, ctx->tickets);
+                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop, ctx->tickets, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, 0);
       } else if (tune(ctx, T_FC_MFMA16, 1) == 0 || waves == 4 || dabl) {
         launched = true;
         if (dabl == 1) MNC_FC_DMA_LAUNCH(1, 1);      // 1: every copy re-reads stage 0 (L2-hot operands), 3: only the weight copies do
@@ -991,7 +1039,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
         const bool buf = 320.0 * (double)K * 4.0 < 1.8e9;
         hipLaunchKernelGGL((buf ? fc_mfma_dma16_kernel<10, 0, 1> : fc_mfma_dma16_kernel<10, 0, 0>), dim3(tn * splits * tm), dim3(512), lds,
                            ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : inkernel ? 2 : 0, tn, splits,
-                           tm, drop, ctx->tickets);
+                           tm, drop, ctx->tickets, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0);
       }
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
@@ -1029,6 +1077,76 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
     fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
     return ls.finish("fc_reduce_kernel");
+  }
+  return MNC_OK;
+}
+
+// Two InnerProducts of one shape -- out_i[M][N] = act(a_i . w_i^T + b_i), i = 0, 1 -- as ONE launch of the eight-wave LDS-DMA
+// kernel (+ one reduction launch) when that kernel would run each of them anyway (fp32, >= 2 GFLOP, 160 < M, K % 64 == 0, N and
+// ldc multiples of 4); otherwise exactly two mnc_fc calls.  The paired launch cuts K into HALF as many ranges as mnc_fc would
+// (twice the column tiles fill the chip), so its results differ from two mnc_fc calls in the last bits (other grouping of the
+// partial sums); every executor of a graph must pair the same layers (engine.py: _plan_fusions; pipeline.hip: run_stage).
+int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, const float* d_bias0, float* d_out0, const float* d_a1,
+                const float* d_w1, const float* d_bias1, float* d_out1, int M, int N, int K, int ldc, int act) {
+  MNC_REQUIRE(ctx && d_a0 && d_w0 && d_bias0 && d_out0 && d_a1 && d_w1 && d_bias1 && d_out1, "mnc_fc_pair: null pointer");
+  MNC_REQUIRE(M >= 0 && N > 0 && K > 0 && K % kBK == 0 && ldc >= N && act >= 0 && act <= 2,
+              "mnc_fc_pair: unsupported shape M=%d N=%d K=%d ldc=%d act=%d (need K%%32==0)", M, N, K, ldc, act);
+  if (M == 0) return MNC_OK;
+  // what mnc_fc would do with ONE of them: the 320-row LDS-DMA kernel in a single launch?  (small products run the 64-row kernel,
+  // M <= 160 the 160-row one, several row blocks with a ragged tail two launches: none of these is paired)
+  const bool big = 2.0 * M * (double)N * K >= 2.0e9;
+  const bool ragged = M > 320 && M % 320 != 0 && M % 320 <= 160 && !tune(ctx, T_FC_NOTAIL, 0);
+  const bool paired = big && M > 160 && !ragged;
+  const bool vec = N % 4 == 0 && ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(d_out0) | reinterpret_cast<uintptr_t>(d_out1) |
+                                                   reinterpret_cast<uintptr_t>(d_bias0) | reinterpret_cast<uintptr_t>(d_bias1)) & 15) == 0;
+  bool fast = paired && vec && K % 64 == 0 && tune(ctx, T_FC_DMA, 1) != 0 && !tune_set(ctx, T_FC_ABL) && !tune_set(ctx, T_FC_TILE) &&
+              320.0 * (double)K * 4.0 < 1.8e9 && !ctx->defer_reduce;
+#ifdef MNC_TUNING
+  if (tune(ctx, T_FC_MFMA16, 1) == 0 || tune(ctx, T_FC_DMA_WAVES, 8) == 4 || tune(ctx, T_FC_DMA_ABL, 0)) fast = false;
+#endif
+  if (!fast) {
+    int rc = mnc_fc(ctx, d_a0, d_w0, d_bias0, d_out0, M, N, K, ldc, act);
+    if (rc) return rc;
+    return mnc_fc(ctx, d_a1, d_w1, d_bias1, d_out1, M, N, K, ldc, act);
+  }
+  const int tn = cdiv(N, kBN), tm = cdiv(M, 320), stages = K / 32;
+  int splits = cdiv(256, 2 * tn * tm);
+  if (splits > stages / 8) splits = stages / 8;
+  if (splits < 1) splits = 1;
+  if (tm > 1) splits = choose_splits(2 * tn * tm, stages, 8, 256, 320.0 * kBN * 32 * 2.0 / 460.0e3, 8.0 * M * (double)N);
+  int kper = cdiv(cdiv(stages, splits) * 32, 64) * 64;
+  splits = cdiv(K, kper);
+  float* part = nullptr;
+  if (splits > 1) {
+    int rc = ensure_scratch(ctx, (size_t)2 * splits * M * N * 4);
+    if (rc) return rc;
+    part = (float*)ctx->scratch;
+  }
+  constexpr int lds = 65536 + (320 + kBN) * 32 * 4;
+  {
+    const double flops = 4.0 * M * (double)N * K, bytes = 8.0 * ((double)N * K + (double)M * K + (double)M * N);
+    LaunchScope ls(ctx, "fc_mfma", flops, bytes);
+    static std::atomic<unsigned long long> attr{0};
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr.load(std::memory_order_relaxed) & bit)) {
+      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_mfma_dma16_kernel<10, 0, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr.fetch_or(bit, std::memory_order_relaxed);
+    }
+    const int drop = tm == 1 && M > 288 && M <= 304 ? 1 : 0;
+    hipLaunchKernelGGL((fc_mfma_dma16_kernel<10, 0, 1>), dim3(2 * tn * splits * tm), dim3(512), lds, ctx->stream, d_a0, d_w0, d_bias0,
+                       d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, tm, drop, ctx->tickets, d_a1, d_w1,
+                       d_bias1, d_out1, tn);
+    int rc = ls.finish("fc_mfma_dma16_kernel");
+    if (rc) return rc;
+  }
+  if (splits > 1) {
+    LaunchScope ls(ctx, "fc_reduce", 0.0, 8.0 * ((double)splits + 1.0) * M * N);
+    long g = ((long)M * N / 2 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(fc_reduce_pair_kernel, dim3((int)g), dim3(256), 0, ctx->stream, part, d_bias0, d_bias1, d_out0, d_out1, M, N,
+                       ldc, splits, act);
+    return ls.finish("fc_reduce_pair_kernel");
   }
   return MNC_OK;
 }

@@ -538,6 +538,15 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   }
   if (!one_pass) NET_TRY(mnc_maxpool2_rhwc_sm(cb, feat14, (float*)n->box7.p, R, P, P, C5, n->box7_sm.p, sm_box));
   const int sm_f6 = sm_format(n, n->fc7, F), sm_f6m = sm_format(n, n->fc7m, F);
+  if (n->fuse_small && one_pass && !fork && n->fc6.kind == 0 && n->fc6m.kind == 0 && n->fc7.kind == 0 && n->fc7m.kind == 0 &&
+      n->fc6.K == n->fc6m.K) {
+    // fp32: the two branches' InnerProducts in pairs (box7 and mask7 both exist since the one-pass pooling): fc6 + fc6_mask, then
+    // fc7 + fc7_mask, each ONE launch (mnc_fc_pair; the Python engine pairs the same layers: engine.py, _plan_fusions)
+    NET_TRY(mnc_fc_pair(ctx, (const float*)n->box7.p, (const float*)n->fc6.w, n->fc6.b, (float*)n->f6.p, (const float*)n->mask7.p,
+                        (const float*)n->fc6m.w, n->fc6m.b, (float*)n->f6m.p, R, F, n->fc6.K, F, 1));
+    NET_TRY(mnc_fc_pair(ctx, (const float*)n->f6.p, (const float*)n->fc7.w, n->fc7.b, join + F, (const float*)n->f6m.p,
+                        (const float*)n->fc7m.w, n->fc7m.b, join, R, F, F, 2 * F, 1));
+  } else {
   NET_TRY(run_fc_sm(cb, n->fc6, (const float*)n->box7.p, n->box7_sm.p, sm_box, (float*)n->f6.p, R, F, 1, n->f6_sm.p, sm_f6));
   NET_TRY(run_fc_sm(cb, n->fc7, (const float*)n->f6.p, n->f6_sm.p, n->fc6.kind ? sm_f6 : 0, join + F, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipEventRecord(n->ev_join[si], cb->stream));
@@ -546,6 +555,7 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   NET_TRY(run_fc_sm(ctx, n->fc6m, (const float*)n->mask7.p, n->mask7_sm.p, sm_mask, (float*)n->f6m.p, R, F, 1, n->f6m_sm.p, sm_f6m));
   NET_TRY(run_fc_sm(ctx, n->fc7m, (const float*)n->f6m.p, n->f6m_sm.p, n->fc6m.kind ? sm_f6m : 0, join, R, 2 * F, 1));
   if (fork) MNC_HIP_TRY(hipStreamWaitEvent(ctx->stream, n->ev_join[si], 0));
+  }
   float* heads = (float*)n->heads.p + (size_t)row0 * 6 * K;      // kept per stage: mnc_net_blob("head_scores")
   float* scores = (float*)n->scores.p + (size_t)row0 * K;
   n->tail_done = false;

@@ -347,6 +347,10 @@ class _Layer(object):
         self.residual = None       # blob added in this Convolution's epilogue (a following Eltwise SUM folded in)
         self.out_h = False         # "f16" math mode: this layer writes its top as a packed fp16 c8 tensor ('c8h')
         self.with_mask = None      # Pooling on a per-RoI tensor: the MaskPooling (+ its Pooling) of the same tensor done in the same pass
+        self.pair = None           # InnerProduct: a later InnerProduct of the same shape computed in the same launch (mnc_fc_pair)
+        self.pair_leader = None    # ... set on that later layer
+        self.ip_prepare = None     # InnerProduct (fp32 kernel): () -> the arguments of its mnc_fc call, tops made ready
+        self.pair_done = False     # per forward: the leader has computed this layer
         self.run = None
 
 
@@ -615,6 +619,35 @@ class Net(object):
                 members[0].group = members
                 for m in members[1:]:
                     m.group_leader = members[0]
+        # Two InnerProducts + ReLU of one shape whose inputs both exist when the first one runs -- the box and the mask branch of a
+        # head stage (fc6 / fc6_mask, then fc7 / fc7_mask: test.prototxt:584-627 and :652-696; the mask branch's input exists that
+        # early because of the one-pass pooling above) -- are ONE launch (mnc_fc_pair: half the K ranges, half the partial sums).
+        # The whole-image pipeline pairs the same layers (csrc/pipeline.hip: run_stage), so the two executors keep the same bits.
+        if os.environ.get("MNC_FUSE_SMALL", "1") != "0" and self.fc_math == "fp32":
+            produced_at = {}
+            for i, L in enumerate(self._layers):
+                if L.skip:
+                    continue
+                for t in ([L.out_name] if L.out_name else L.tops):
+                    produced_at.setdefault(t, i)
+                if L.with_mask is not None:
+                    Lm = L.with_mask
+                    produced_at.setdefault(Lm.out_name or Lm.tops[0], i)
+
+            def ip_shape(L):                       # (K is not known before the first forward: checked when the pair runs)
+                return self._layer_nout(L)
+            ips = [(i, L) for i, L in enumerate(self._layers)
+                   if L.type == "InnerProduct" and L.relu and not L.skip and L.group is None and L.group_leader is None]
+            for a, (i1, L1) in enumerate(ips):
+                if L1.pair is not None or L1.pair_leader is not None:
+                    continue
+                for i2, L2 in ips[a + 1:]:
+                    if L2.pair is not None or L2.pair_leader is not None or ip_shape(L2) != ip_shape(L1):
+                        continue
+                    if produced_at.get(L2.bottoms[0], len(self._layers)) < i1 and L2.bottoms[0] not in L1.tops:
+                        L1.pair, L2.pair_leader = L2, L1
+                        produced_at[L2.out_name or L2.tops[0]] = i1       # (fc7_mask's input now exists when fc7 runs)
+                        break
 
     def _conv_fast1x1(self, L):
         """A 'general' Convolution that is a plain GEMM: 1x1, no padding, stride 1 or 2 (csrc/conv1x1.hip; MNC_CONV1X1=0 sends
@@ -1259,11 +1292,42 @@ class Net(object):
                 _lib.call(state["fn"] + "_ex", self._h(), src, sm["ptr"] if pre else None, M, state["w"], d_b, dst, M, n_out, K,
                           top._ld(), act, top.sm_out(ofmt, M, n_out) if ofmt else None, ofmt)
                 return
+            if L.pair_done:                        # computed with its pair leader earlier in this forward
+                L.pair_done = False
+                return
             src = bot.dev_in(state["layout"]) if M else 0
             top.reshape(M, n_out)
             dst = top.dev_out("plain")
-            if M:
-                _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+            if not M:
+                return
+            P = L.pair
+            if P is not None and state["fn"] == "mnc_fc" and P.ip_prepare is not None:
+                other = P.ip_prepare(M, K)
+                if other is not None:
+                    _lib.call("mnc_fc_pair", self._h(), src, state["w"], d_b, dst, other[0], other[1], other[2], other[3], M, n_out,
+                              K, top._ld(), act)
+                    P.pair_done = True
+                    return
+            _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+
+        def prepare(M_leader, K_leader):
+            """As the second member of a pair: (src, weights, bias, dst) of this layer's own mnc_fc call with its top made ready,
+            or None when it cannot share the leader's launch (other row count, other kernel, other leading dimension / activation)."""
+            M = bot.shape[0]
+            if M != M_leader or K != K_leader or int(np.prod(bot.shape[1:])) != K or not (bot._dev_valid or bot._host_valid):
+                return None
+            if "w" not in state:
+                state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
+            if state["fn"] != "mnc_fc":
+                return None
+            lead_top = self.blobs[L.pair_leader.out_name or L.pair_leader.tops[0]]
+            src = bot.dev_in(state["layout"])
+            top.reshape(M, n_out)
+            if top._ld() != lead_top._ld() or (1 if L.pair_leader.relu else L.pair_leader.act) != act:
+                return None
+            return src, state["w"], d_b, top.dev_out("plain")
+        if L.pair_leader is not None:
+            L.ip_prepare = prepare
         return run
 
     def _bind_ip_group(self, L):

@@ -389,6 +389,10 @@ class Fake(object):
         for m in range(M):
             full[m * ldc: m * ldc + N] = y[m]
 
+    def mnc_fc_pair(self, h, a0, w0, b0, dst0, a1, w1, b1, dst1, M, N, K, ldc, act):
+        self.mnc_fc(h, a0, w0, b0, dst0, M, N, K, ldc, act)
+        self.mnc_fc(h, a1, w1, b1, dst1, M, N, K, ldc, act)
+
     def mnc_pack_fc_bf16x3(self, h, src, dst, N, K):
         T, S = (N + 127) // 128, K // 32
         w = np.zeros((T * 128, K), np.float32)

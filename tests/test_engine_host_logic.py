@@ -115,7 +115,22 @@ def test_fusion_plan(fake_gpu):
     assert net.outputs == ["cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"]
     assert [m.name for m in L["cls_score"].group] == ["cls_score", "seg_cls_score", "bbox_pred"]
     assert L["bbox_pred"].group_leader is L["cls_score"] and net.blobs["bbox_pred"]._view[1] == 42
+    # the box and the mask branch's InnerProducts of a stage are launched in pairs (mnc_fc_pair) -- fp32 InnerProducts only
+    for a, b in (("fc6", "fc6_mask"), ("fc7", "fc7_mask"), ("fc6_ext", "fc6_mask_ext"), ("fc7_ext", "fc7_mask_ext")):
+        assert L[a].pair is L[b] and L[b].pair_leader is L[a], (a, b)
+    assert L["fc6_maskest"].pair is None and L["fc6_maskest"].pair_leader is None
+    import demo
+    im = np.random.default_rng(0).integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    fake_gpu.calls.clear()
+    demo.im_detect(im, net)
+    stages = fake_gpu.calls.get("mnc_box_mask_pool")                # head stages run (two; four when the heads are re-run on the exact RoI count)
+    assert stages in (2, 4)
+    assert fake_gpu.calls.get("mnc_fc_pair") == 2 * stages          # fc6 + fc6_mask, fc7 + fc7_mask per stage
+    assert fake_gpu.calls.get("mnc_fc") == 3 * stages               # fc6_maskest, mask_pred, the sibling classifiers' GEMM per stage
     net.close()
+    net3 = Net(path, w, 1, device_id=0, math="bf16x3")
+    assert all(l.pair is None for l in net3._layers)
+    net3.close()
 
 
 def test_demo_im_detect_and_voting(fake_gpu):

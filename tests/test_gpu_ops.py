@@ -1010,6 +1010,59 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
         assert err(w8, full)[1] < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,act,ldc_pad,fast", [(300, 4096, 4096, 1, 4096, True), (300, 1024, 25088, 1, 0, True),
+                                                     (640, 512, 8192, 0, 0, True), (290, 520, 4096, 2, 8, False), (300, 640, 8192, 2, 4, True),
+                                                     (120, 512, 2048, 1, 0, False), (300, 130, 512, 1, 6, False),
+                                                     (760, 1024, 1536, 1, 0, False)])
+def test_fc_pair(dev, M, N, K, act, ldc_pad, fast):
+    """mnc_fc_pair: two InnerProducts of one shape in ONE launch of the 320-row LDS-DMA kernel (the box and the mask branch of a
+    head stage) -- each output against torch and against its own mnc_fc call (other grouping of the K ranges: 1e-5, not bits),
+    column slices of one buffer (ldc > N: Concat(fc7_mask, fc7)), the same bits on every launch; shapes that kernel would not take
+    in one launch (small products, M <= 160, a ragged tail of row blocks) are exactly two mnc_fc calls."""
+    rng = np.random.default_rng(M + N + K + 17)
+    ld = N + ldc_pad
+    ops = []
+    for i in range(2):
+        a = rng.normal(size=(M, K)).astype(np.float32)
+        w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+        b = rng.normal(size=N).astype(np.float32)
+        y = F.linear(torch.from_numpy(a), torch.from_numpy(w), torch.from_numpy(b))
+        want = (F.relu(y) if act == 1 else torch.sigmoid(y) if act == 2 else y).numpy()
+        ops.append((dev.put(a), dev.put(w), dev.put(b), want))
+    # two outputs side by side in one buffer when the slice is wide enough (ldc_pad >= N), separate buffers otherwise
+    if ldc_pad >= N:
+        d_o0 = dev.empty((M * ld,), fill=np.nan)
+        d_o1 = d_o0 + N * 4
+    else:
+        d_o0, d_o1 = dev.empty((M * ld,), fill=np.nan), dev.empty((M * ld,), fill=np.nan)
+
+    def run_pair():
+        dev.call("mnc_fc_pair", ops[0][0], ops[0][1], ops[0][2], d_o0, ops[1][0], ops[1][1], ops[1][2], d_o1, M, N, K, ld, act)
+        full = dev.get(d_o0, (M, ld)).copy()
+        o0 = full[:, :N]
+        o1 = full[:, N:2 * N] if ldc_pad >= N else dev.get(d_o1, (M, ld))[:, :N].copy()
+        return o0, o1
+
+    first = run_pair()
+    for got, (_, _, _, want) in zip(first, ops):
+        assert not np.isnan(got).any()
+        assert err(got, want)[1] < 1e-4
+    for _ in range(5):
+        again = run_pair()
+        assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+    for (d_a, d_w, d_b, _), d_o in zip(ops, (d_o0, d_o1)):
+        dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, ld, act)
+    full = dev.get(d_o0, (M, ld)).copy()
+    singles = [full[:, :N], full[:, N:2 * N] if ldc_pad >= N else dev.get(d_o1, (M, ld))[:, :N].copy()]
+    for got, one in zip(first, singles):
+        if fast:
+            assert err(got, one)[1] < 1e-5
+        else:
+            assert np.array_equal(got, one)
+    if fast and 2.0 * M * N * K >= 8.0e9:
+        assert not np.array_equal(first[0], singles[0])             # (the paired launch really cut K differently)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 4096, 4096), (300, 1024, 25088), (640, 512, 8192), (300, 4096, 25088)])
 def test_fc_in_launch_reduction_is_bit_reproducible(dev, M, N, K):
     """FC_REDUCE bit 0: the K ranges of the fp32 InnerProduct summed inside the launch -- every workgroup publishes its partial

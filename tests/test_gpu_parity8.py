@@ -37,13 +37,17 @@ mnc_amd.install_paths()
 SEEDS = tuple(range(8))
 # Floors = the recorded figures (profiles/r04_parity_report*.txt; VERDICT r3: the old floors -- 295 rois, 97 % matched -- would also
 # have passed a much worse run).  fp32 (F(4x4,3x3) trunk since round 4): 300 / 300 rois and 100 / 100 instances matched on every one
-# of the eight images; mask cells off by > 1e-3: 0-4 of 44100 on seven images, 392 on one (seed 0: one flipped `> 0.4` bound of mv moves
-# a box edge by a pixel and the resampled mask with it) -- the ceiling below is per image and leaves room for ONE such flip.
+# of the eight images; mask cells off by > 1e-3: 0-2 of 44100 on every image with the builds since round 4's third (and round 5's:
+# profiles/r05_parity_report*.txt).  Round 4's first two builds (d7ddce37de4ff8ec and its predecessor: the scalar-transform F(4x4)
+# kernel, profiles/r04_parity_report_v1 / _v2.txt) recorded 392 on seed 0 -- one flipped `> 0.4` bound of mv moves a box edge by a
+# pixel and the whole resampled mask of that ONE instance with it.  So the fp32 ceiling has two parts: at most 8 cells off per image
+# outside the single worst instance (CEIL_CELLS_REST), and room for one flipped bound in that instance (CEIL_CELLS_OFF).
 # bf16x3: 290-299 rois, 98-100 matched.  f16 does not claim the 1e-3 bar (no `rois` row within 0.01 px, 78-92 of 100 matched): its
 # floors only guard against a collapse; the mode that does claim it is "mixed" (below).
 FLOOR_ROIS = {"fp32": 300, "bf16x3": 288, "f16": 0, "mixed": 285, "bf16": 0}            # mean over the eight images
 FLOOR_MATCHED = {"fp32": 1.0, "bf16x3": 0.97, "f16": 0.6, "mixed": 0.95, "bf16": 0.3}
 CEIL_CELLS_OFF = {"fp32": 0.01, "bf16x3": 0.06, "f16": 1.0, "mixed": 0.15, "bf16": 1.0}  # fraction of the matched instances' mask cells, per image
+CEIL_CELLS_REST = {"fp32": 8}    # cells off per image NOT counting the instance with the most (absent: not checked)
 _cache = {}
 
 
@@ -95,6 +99,7 @@ def _free_running(o, got_m, got_b, dev_rois, dev_rois_ext):
     n_dev = sum(len(b) for b in got_b)
     n_orc = sum(len(b) for b in o["lb"])
     matched, max_mask, max_score, max_box, cells, cells_off, sum_mask = 0, 0.0, 0.0, 0.0, 0, 0, 0.0
+    worst_instance = 0
     for c in range(20):
         gb, ob = np.asarray(got_b[c], np.float64), np.asarray(o["lb"][c], np.float64)
         used = set()
@@ -111,11 +116,13 @@ def _free_running(o, got_m, got_b, dev_rois, dev_rois_ext):
                 max_mask = max(max_mask, float(dm.max()) if dm.size else 0.0)
                 cells += dm.size
                 cells_off += int((dm > 1e-3).sum())
+                worst_instance = max(worst_instance, int((dm > 1e-3).sum()))
                 sum_mask += float(dm.sum())
                 max_score = max(max_score, abs(gb[i, 4] - ob[j, 4]))
                 max_box = max(max_box, float(np.abs(gb[i, :4] - ob[j, :4]).max()))
     return dict(same_rois=same_rois, same_order=same_order, same_rois_ext=same_ext, n_dev=n_dev, n_orc=n_orc, matched=matched,
-                max_mask=max_mask, mean_mask=sum_mask / max(cells, 1), cells=cells, cells_off=cells_off, max_score=max_score,
+                max_mask=max_mask, mean_mask=sum_mask / max(cells, 1), cells=cells, cells_off=cells_off,
+                cells_off_rest=cells_off - worst_instance, max_score=max_score,
                 max_box=max_box)
 
 
@@ -181,3 +188,5 @@ def test_native_pipeline_vs_oracle_on_the_eight_baseline_images(vgg, math):
     assert np.mean([s["same_rois"] for s in stats]) >= FLOOR_ROIS[math], stats
     assert np.mean([s["matched"] / max(s["n_orc"], 1) for s in stats]) >= FLOOR_MATCHED[math], stats
     assert max(s["cells_off"] / max(s["cells"], 1) for s in stats) <= CEIL_CELLS_OFF[math], stats
+    if math in CEIL_CELLS_REST:
+        assert max(s["cells_off_rest"] for s in stats) <= CEIL_CELLS_REST[math], stats
