@@ -96,6 +96,8 @@ def parse():
                    help="arithmetic of the dense contractions for the headline number (default: fp32; resnet50: f16)")
     p.add_argument("--no-alt-math", action="store_true", help="skip the bf16x3 / f16 measurements (N = 1, vgg16)")
     p.add_argument("--no-resident", action="store_true", help="skip the secondary resident-input measurement")
+    p.add_argument("--no-share-weights", action="store_true",
+                   help="every image in flight gets its own copy of the device weights (rounds 2-4) instead of sharing one set")
     p.add_argument("--no-repeats", action="store_true", help="steps < 100: do not run the timed loop three more times for value_min/max")
     p.add_argument("--no-resnet", action="store_true",
                    help="skip the BASELINE configs[4] measurement (ResNet-50 C4, 800x1333, 1000 RoIs, f16) that the default N = 1 "
@@ -209,7 +211,8 @@ def main():
         if native:
             # one set of device weights for all images in flight (mnc_net_create_shared): the other nets own a context, a stream
             # and their activation buffers only
-            nets = [net] + [NativeNet(net) for _ in range(inflight - 1)]
+            nets = [net] + [NativeNet(weights, device_id=dev_id, math=math, use_graph=not args.no_graph) if args.no_share_weights
+                            else NativeNet(net) for _ in range(inflight - 1)]
         else:
             nets = [net] + [Net(proto, weights, caffe.TEST, device_id=dev_id, math=math) for _ in range(inflight - 1)]
 
@@ -825,7 +828,7 @@ def roofline_by_kernel(records, steps):
             e["hbm_frac_algorithmic"] = hbm_frac
         else:
             e.update(bound="hbm", achieved=by / avg_s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=hbm_frac)
-        pos = FC_POSITIONS.get(label)
+        pos = fc_positions(label)
         if name.startswith("conv3x3") and name not in HBM_BOUND_SCOPES:
             # the trunk's layer classes share two template instantiations: counter traffic cannot be told apart per class, it is
             # reported for the whole scope in the aggregate row below
@@ -864,12 +867,32 @@ PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"co
               "fc_bf16x3": r"fc_x3_kernel<\d+, \d+, \d+, 0>", "fc_f16": r"fc_x3_kernel<\d+, \d+, \d+, 1>",
               "conv3x3_bf16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 2,", "fc_bf16": r"(fc_x3_kernel<\d+, \d+, \d+, 2>|fc_lowp_dma_kernel<\d+, 2>)"}
 HBM_BOUND_SCOPES = {"conv3x3_c3"}          # conv1_1: 2 GFLOP over 161 MB -- bound by writing its output
-# the big InnerProducts of one 300-RoI head stage by algorithmic GFLOP, and their positions in the 10-launch
-# cycle of the InnerProduct kernel per image (tools/pmc_report.py --cycle): fc6_maskest, fc6, fc7, fc6_mask, fc7_mask, twice
+# the big InnerProducts of one 300-RoI head stage by algorithmic GFLOP, and their positions in the per-image
+# launch cycle of the InnerProduct kernel (tools/pmc_report.py --cycle).  Round 5: the box and the mask branch are launched in
+# pairs (mnc_fc_pair) -- six launches per image: fc6_maskest, fc6 + fc6_mask, fc7 + fc7_mask, twice; unpaired (MNC_FUSE_SMALL=0,
+# rounds 1-4): ten -- fc6_maskest, fc6, fc7, fc6_mask, fc7_mask, twice.
 FC_SHAPES = {("fc_mfma", 15.41): "fc6_maskest (300 x 256 x 100352)", ("fc_mfma", 61.66): "fc6 / fc6_mask (300 x 4096 x 25088)",
-             ("fc_mfma", 10.07): "fc7 / fc7_mask (300 x 4096 x 4096)"}
-FC_POSITIONS = {"fc6_maskest (300 x 256 x 100352)": (0, 5), "fc6 / fc6_mask (300 x 4096 x 25088)": (1, 3, 6, 8),
-                "fc7 / fc7_mask (300 x 4096 x 4096)": (2, 4, 7, 9)}
+             ("fc_mfma", 10.07): "fc7 / fc7_mask (300 x 4096 x 4096)",
+             ("fc_mfma", 123.31): "fc6 + fc6_mask, one launch (2 x 300 x 4096 x 25088)",
+             ("fc_mfma", 20.13): "fc7 + fc7_mask, one launch (2 x 300 x 4096 x 4096)"}
+FC_POSITIONS_BY_PERIOD = {
+    10: {"fc6_maskest (300 x 256 x 100352)": (0, 5), "fc6 / fc6_mask (300 x 4096 x 25088)": (1, 3, 6, 8),
+         "fc7 / fc7_mask (300 x 4096 x 4096)": (2, 4, 7, 9)},
+    6: {"fc6_maskest (300 x 256 x 100352)": (0, 3), "fc6 + fc6_mask, one launch (2 x 300 x 4096 x 25088)": (1, 4),
+        "fc7 + fc7_mask, one launch (2 x 300 x 4096 x 4096)": (2, 5)}}
+
+
+def fc_positions(label):
+    """positions of an InnerProduct shape in the kernel's per-image cycle, for the period the committed PMC profile was cut with"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for k, v in data.items():
+        if k.startswith("fc_mfma_dma") and isinstance(v, dict) and v.get("by_position"):
+            return FC_POSITIONS_BY_PERIOD.get(len(v["by_position"]), {}).get(label)
+    return None
 
 
 def wino_factor(scope_name):
