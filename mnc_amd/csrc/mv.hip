@@ -272,8 +272,10 @@ constexpr int kSelMaxClasses = 1024;
 //   rows   = [(box, class) for class-major kept boxes with score >= thresh]            (NaN >= x is false)
 // Outputs: rows [R][2] = (box index, class - 1), rscore [R], counts[0] = R, counts[c] = rows of class c (1..B).
 // pool_* are global scratch of P entries.  NP = power of two >= P capacity (dynamic LDS: NP keys).
+// (round 5: the kept boxes are read through order[keep[]] here -- the mv_keepbox launch that materialised them is gone)
 __global__ __launch_bounds__(kSelThreads) void mv_select_kernel(const float* __restrict__ scores, int n, int C,
-                                                                const int* __restrict__ keepbox, const int* __restrict__ num,
+                                                                const int* __restrict__ order, const int* __restrict__ keep,
+                                                                const int* __restrict__ num,
                                                                 int max_per_image, int NP, int* __restrict__ pool_box,
                                                                 float* __restrict__ pool_score, int* __restrict__ pool_cls,
                                                                 int* __restrict__ rows, float* __restrict__ rscore,
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kSelThreads) void mv_select_kernel(const float* __r
         if (s_off[mid] <= j) lo = mid; else hi = mid - 1;
       }
       const int c = lo, k = j - s_off[c];
-      const int bi = keepbox[(long)c * n + k];
+      const int bi = order[(long)c * n + keep[(long)c * n + k]];   // keep lists index the sorted order; the voting wants box indices
       const float v = scores[(long)bi * C + c + 1];
       pool_box[j] = bi; pool_cls[j] = c; pool_score[j] = v;
       if (v != v) {
@@ -381,10 +383,12 @@ __global__ __launch_bounds__(64) void mv_candidates_kernel(const float* __restri
                                                            int n, int C, const int* __restrict__ rows,
                                                            const int* __restrict__ rcount, int R, float iou_thresh,
                                                            int* __restrict__ cinds, float* __restrict__ cw,
-                                                           int* __restrict__ cbegin, int* __restrict__ cend) {
+                                                           int* __restrict__ cbegin, int* __restrict__ cend,
+                                                           int* __restrict__ bounds) {
   const int lane = threadIdx.x;
   const int Rv = rcount ? *rcount : R;
   for (int r = blockIdx.x; r < Rv; r += gridDim.x) {
+    if (bounds && lane < 4) bounds[r * 4 + lane] = lane < 2 ? INT_MAX : -1;      // (mv_init_bounds_kernel's values, for mv_bounds_kernel)
     const int bi = rows[2 * r], c = rows[2 * r + 1];
     const double q0 = boxes[bi * 4 + 0], q1 = boxes[bi * 4 + 1], q2 = boxes[bi * 4 + 2], q3 = boxes[bi * 4 + 3];
     const double qarea = (q2 - q0 + 1) * (q3 - q1 + 1);
@@ -452,9 +456,10 @@ __global__ __launch_bounds__(256) void mv_pack_kernel(const float* __restrict__ 
 // workgroups striding over the rows.
 static int mv_launch_impl(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
                           const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, const int* d_rcount,
-                          int grid_rows, int* d_bounds, float* d_out_mask, int* d_out_box) {
+                          int grid_rows, int* d_bounds, float* d_out_mask, int* d_out_box, bool bounds_ready = false) {
   if (R <= 0) return MNC_OK;
-  hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
+  // (the voting sequence initialises the rows' bounds in its candidates kernel; the extension's own entry point does it here)
+  if (!bounds_ready) hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
   // ~2048 blocks in flight: rows x `splits` row slabs each
   int splits = 2048 / grid_rows;
   if (splits < 1) splits = 1;
@@ -532,18 +537,17 @@ static int vote_async(hipStream_t s, const VoteWs& w, const float* d_boxes, cons
   }
   nms_mask_launch(s, d_boxes, w.order, n, 4, nms_thresh, w.bits, B);
   nms_scan_launch(s, w.bits, n, keep_cap, w.keep, w.num, B);
-  hipLaunchKernelGGL(mv_keepbox_kernel, dim3(cdiv(keep_cap, 256), B), dim3(256), 0, s, w.order, w.keep, w.num, n, w.keepbox);
   int NP = 64;
   while (NP < Rmax) NP <<= 1;
-  hipLaunchKernelGGL(mv_select_kernel, dim3(1), dim3(kSelThreads), (size_t)NP * 4, s, d_scores, n, C, w.keepbox, w.num,
+  hipLaunchKernelGGL(mv_select_kernel, dim3(1), dim3(kSelThreads), (size_t)NP * 4, s, d_scores, n, C, w.order, w.keep, w.num,
                      max_per_image, NP, w.pool_box, w.pool_score, w.pool_cls, w.rows, w.rscore, d_counts);
   // the row count R = d_counts[0] stays on the device: R <= max_per_image unless scores tie at the threshold, so that many
   // workgroups stride over the rows
   const int grid_rows = Rmax < max_per_image ? Rmax : max_per_image;
   hipLaunchKernelGGL(mv_candidates_kernel, dim3(grid_rows), dim3(64), 0, s, d_boxes, d_scores, n, C, w.rows, d_counts, Rmax,
-                     iou_thresh, w.cinds, w.cw, w.cbegin, w.cend);
+                     iou_thresh, w.cinds, w.cw, w.cbegin, w.cend, w.bounds);
   mv_launch_impl(s, d_boxes, 4, d_masks, S, w.cinds, w.cbegin, w.cend, w.cw, H, W, Rmax, d_counts, grid_rows, w.bounds, w.omask,
-                 w.obox);
+                 w.obox, /*bounds_ready=*/true);
   hipLaunchKernelGGL(mv_pack_kernel, dim3(record_cap), dim3(256), 0, s, w.omask, w.obox, w.rscore, w.rows, d_counts, record_cap, S,
                      d_records);
   MNC_HIP_TRY(hipGetLastError());

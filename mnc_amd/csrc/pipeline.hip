@@ -96,6 +96,7 @@ struct mnc_net {
   // the result block: [per-class counts: 256 B | the ProposalLayer's row count: 256 B | instance records] -- laid out like the
   // pinned buffer it is copied into, so that an image's results come down in ONE copy
   DevBuf outblk;
+  DevBuf hwc5;            // conv5_3 pixel-major: made once per image, gathered from by both stages' ROIWarping
   float* records() const { return (float*)((char*)outblk.p + 512); }
   int* counts() const { return (int*)outblk.p; }
   int* prop_count() const { return (int*)((char*)outblk.p + 256); }
@@ -347,6 +348,7 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
     }
   }
   const int A = c.num_anchors;
+  NET_TRY(dev_ensure(n, &n->hwc5, (size_t)c.trunk_channels[4] * h * w * 4));
   NET_TRY(dev_ensure(n, &n->rpn_out, (size_t)c.rpn_channels * h * w * 4));
   NET_TRY(dev_ensure(n, &n->rpn_score, (size_t)6 * A * h * w * 4));
   NET_TRY(dev_ensure(n, &n->rpn_prob, (size_t)2 * A * h * w * 4));
@@ -489,6 +491,8 @@ int run_trunk(mnc_net* n) {
     }
   }
   n->fh = h; n->fw = w;
+  if (n->fuse_small)      // (both head stages warp from this copy; otherwise each mnc_roi_warp_sm call makes its own)
+    NET_TRY(c8_to_hwc_launch(ctx, (const float*)n->act[12].p, (float*)n->hwc5.p, c.trunk_channels[4], h, w));
   const int A = c.num_anchors;
   NET_TRY(conv3(n, 13, cur, (float*)n->rpn_out.p, h, w, cin, c.rpn_channels));
   if (n->fuse_small) {
@@ -515,8 +519,12 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   float* feat14 = (float*)n->feat14.p;
   // stage 2: ROIWarping 28x28 + MAX 2x2/2 fused; stage 4: ROIWarping 14x14 directly (test.prototxt:479-505 vs :809-820)
   const int sm_feat = sm_format(n, n->fc_maskest, C5), sm_box = sm_format(n, n->fc6, C5), sm_mask = sm_format(n, n->fc6m, C5);
-  NET_TRY(mnc_roi_warp_sm(ctx, conv5, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14, n->feat14_sm.p,
-                          sm_feat));
+  if (n->fuse_small)
+    NET_TRY(roi_warp_from_hwc(ctx, (const float*)n->hwc5.p, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14,
+                              n->feat14_sm.p, sm_feat));
+  else
+    NET_TRY(mnc_roi_warp_sm(ctx, conv5, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14, n->feat14_sm.p,
+                            sm_feat));
   float* masks = (float*)n->masks.p + (size_t)row0 * S * S;
   NET_TRY(run_fc_sm(ctx, n->fc_maskest, feat14, n->feat14_sm.p, sm_feat, (float*)n->h_mask.p, R, c.mask_fc, 1));
   NET_TRY(run_fc(n, n->fc_maskpred, (const float*)n->h_mask.p, masks, R, S * S, 2));            // + Sigmoid; MaskLayer = reshape
@@ -954,7 +962,7 @@ int mnc_net_destroy(mnc_net* net) {
   DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_prob, &net->rois,
                     &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
                     &net->feat14_sm, &net->box7_sm, &net->mask7_sm, &net->f6_sm, &net->f6m_sm,
-                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->outblk};
+                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->outblk, &net->hwc5};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);
   for (auto& b : net->pooled) if (b.p) (void)hipFree(b.p);

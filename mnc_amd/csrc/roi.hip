@@ -588,9 +588,39 @@ using namespace mnc;
 
 extern "C" {
 
+}  // extern "C"
+
+namespace mnc {
+// pixel-major copy [H][W][C] of a c8 feature map: what the warp kernels gather from (a pixel's channels contiguous).  The
+// whole-image pipeline makes it ONCE per image for both head stages (pipeline.hip); mnc_roi_warp_sm makes its own per call.
+int c8_to_hwc_launch(mnc_ctx* ctx, const float* d_feat, float* d_hwc, int C, int H, int W) {
+  LaunchScope lt(ctx, "c8_to_hwc", 0.0, 8.0 * C * (double)H * W);
+  hipLaunchKernelGGL(c8_to_hwc_kernel, dim3(grid_for((long)H * W * (C / 8) * 2)), dim3(256), 0, ctx->stream, d_feat, d_hwc, C / 8,
+                     (long)H * W);
+  return lt.finish("c8_to_hwc_kernel");
+}
+static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_ready, int C, int H, int W, const float* d_rois, int R,
+                         int PH, int PW, float scale, int pool2, float* d_out, void* d_sm, int sm_fmt);
+int roi_warp_from_hwc(mnc_ctx* ctx, const float* d_hwc, int C, int H, int W, const float* d_rois, int R, int PH, int PW, float scale,
+                      int pool2, float* d_out, void* d_sm, int sm_fmt) {
+  return roi_warp_impl(ctx, nullptr, d_hwc, C, H, W, d_rois, R, PH, PW, scale, pool2, d_out, d_sm, sm_fmt);
+}
+}  // namespace mnc
+
+extern "C" {
+
 int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
                     float scale, int pool2, float* d_out, void* d_sm, int sm_fmt) {
-  MNC_REQUIRE(ctx && d_feat && d_out && (R == 0 || d_rois), "mnc_roi_warp: null pointer");
+  MNC_REQUIRE(d_feat, "mnc_roi_warp: null pointer");
+  return mnc::roi_warp_impl(ctx, d_feat, nullptr, C, H, W, d_rois, R, PH, PW, scale, pool2, d_out, d_sm, sm_fmt);
+}
+
+}  // extern "C"
+
+namespace mnc {
+static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_ready, int C, int H, int W, const float* d_rois, int R,
+                         int PH, int PW, float scale, int pool2, float* d_out, void* d_sm, int sm_fmt) {
+  MNC_REQUIRE(ctx && (d_feat || d_hwc_ready) && d_out && (R == 0 || d_rois), "mnc_roi_warp: null pointer");
   MNC_REQUIRE(C > 0 && C % 8 == 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "mnc_roi_warp: bad shape");
   if (!d_sm) sm_fmt = 0;
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_roi_warp_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
@@ -599,16 +629,16 @@ int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, cons
   const long total = (long)R * PH * PW * (C / 4);
   MNC_REQUIRE(total < (1L << 31), "mnc_roi_warp: %ld outputs exceed the kernel's 32-bit index range", total * 4);
   const double samples = pool2 ? 4.0 : 1.0;
-  // pixel-major copy of the feature map in the context's scratch arena (same stream: ordered after any earlier user)
-  int rc = ensure_scratch(ctx, (size_t)C * H * W * 4);
-  if (rc) return rc;
-  float* d_hwc = (float*)ctx->scratch;
-  {
-    LaunchScope lt(ctx, "c8_to_hwc", 0.0, 8.0 * C * (double)H * W);
-    hipLaunchKernelGGL(c8_to_hwc_kernel, dim3(grid_for((long)H * W * (C / 8) * 2)), dim3(256), 0, ctx->stream, d_feat, d_hwc,
-                       C / 8, (long)H * W);
-    rc = lt.finish("c8_to_hwc_kernel");
+  // pixel-major copy of the feature map: the caller's, or made here in the context's scratch arena (same stream: ordered after
+  // any earlier user)
+  int rc = MNC_OK;
+  const float* d_hwc = d_hwc_ready;
+  if (!d_hwc) {
+    rc = ensure_scratch(ctx, (size_t)C * H * W * 4);
     if (rc) return rc;
+    rc = c8_to_hwc_launch(ctx, d_feat, (float*)ctx->scratch, C, H, W);
+    if (rc) return rc;
+    d_hwc = (const float*)ctx->scratch;
   }
   LaunchScope ls(ctx, pool2 ? "roi_warp_pool2" : "roi_warp", 0.0,
                  4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)) + (sm_fmt == 1 ? 2.0 : sm_fmt == 2 ? 4.0 : 0.0) * R * PH * PW * C);
@@ -656,6 +686,9 @@ int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, cons
 #undef MNC_WARP
   return ls.finish("roi_warp_kernel");
 }
+}  // namespace mnc
+
+extern "C" {
 
 int mnc_roi_warp(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
                  float scale, int pool2, float* d_out) {

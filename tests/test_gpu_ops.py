@@ -219,6 +219,33 @@ def test_conv3x3_winograd_f4_is_bit_reproducible(dev, H, W, Cin, Cout):
             assert np.array_equal(first, got), "run %d differs from run 0 in %d values" % (rep, int((first != got).sum()))
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout", [(75, 125, 256, 512), (37, 63, 256, 512), (150, 250, 64, 256)])
+def test_conv3x3_winograd_f4_in_launch_reduction_reads_fresh_slabs(dev, tune, H, W, Cin, Cout):
+    """The K ranges of a launch are summed by each tile's last arriver from slabs the other workgroups published (mnc_internal.h).
+    Repeating ONE launch cannot see a stale slab (the stale bytes equal the fresh ones), so two different inputs alternate through
+    the same slab addresses: every result must equal that input's own result under the separate reduction kernel."""
+    rng = np.random.default_rng(H + W + Cin + 5)
+    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(0, 0.1, Cout).astype(np.float32)
+    d_b = dev.put(b)
+    d_w = dev.empty((Cin * Cout * 36,))
+    dev.call("mnc_pack_conv3x3_wino4", dev.put(w), d_w, Cout, Cin)
+    d_y = dev.empty((Cout, H, W), fill=-7.0)
+    xs = [dev.put(to_c8(rng.normal(0, 1 + i, (Cin, H, W)).astype(np.float32))) for i in range(2)]
+    tune("FC_REDUCE", "0")
+    refs = []
+    for d_x in xs:
+        dev.call("mnc_conv3x3_wino4", d_x, d_w, d_b, d_y, H, W, Cin, Cout, 1)
+        refs.append(dev.get(d_y, (Cout * H * W,)).copy())
+    dev.tune("FC_REDUCE", None)
+    assert not np.array_equal(refs[0], refs[1])
+    for rep in range(12):
+        k = rep & 1
+        dev.call("mnc_conv3x3_wino4", xs[k], d_w, d_b, d_y, H, W, Cin, Cout, 1)
+        got = dev.get(d_y, (Cout * H * W,))
+        assert np.array_equal(got, refs[k]), "launch %d (input %d): %d values differ" % (rep, k, int((got != refs[k]).sum()))
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):
@@ -1091,6 +1118,19 @@ def test_fc_in_launch_reduction_is_bit_reproducible(dev, M, N, K):
         dev.tune("FC_REDUCE", None)
     dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, N, 1)               # the default: fc_reduce_kernel
     assert np.array_equal(first, dev.get(d_o, (M * N,)))
+    # a second input alternating with the first through the same slab addresses: a stale slab read would mix the two
+    a2 = rng.normal(size=(M, K)).astype(np.float32) * 3.0
+    d_a2 = dev.put(a2)
+    dev.call("mnc_fc", d_a2, d_w, d_b, d_o, M, N, K, N, 1)
+    second = dev.get(d_o, (M * N,)).copy()
+    dev.tune("FC_REDUCE", "3")
+    try:
+        for rep in range(8):
+            src, want = (d_a2, second) if rep & 1 else (d_a, first)
+            dev.call("mnc_fc", src, d_w, d_b, d_o, M, N, K, N, 1)
+            assert np.array_equal(dev.get(d_o, (M * N,)), want), rep
+    finally:
+        dev.tune("FC_REDUCE", None)
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES + [(300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2)])
