@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
   const float* __restrict__ Wt = which ? Wt_1 : Wt_0;
   const float* __restrict__ bias = which ? bias_1 : bias_0;
   float* __restrict__ out = which ? out_1 : out_0;
-  float* __restrict__ part = part_0 + (fused == 0 ? (size_t)which * splits_ * M * N : (size_t)0);   // partial sums: [product][range][M][N]
+  float* __restrict__ part = part_0;                  // K ranges' partial sums: slabs [tile (both products' column tiles)][range]
   const int n0 = bn * kBN, m0 = bmz * kBM;
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
   const int nstages = (kend - kbeg) / 32;
@@ -691,6 +691,19 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
   // instruction (the separate reduction's partial sums were 80 four-byte stores per lane).  The last arriver adds the slabs in
   // range order starting from zero -- fc_reduce_kernel's order: the same bits -- sixteen 16-byte loads in flight per lane.
   bool final_out = fused == 1;
+  if (fused == 0) {
+    // K ranges finished by the reduction launch (fc_reduce_slab_kernel): the accumulators as they sit in registers, [tile][range]
+    // [wave][sub-tile i][column half c][lane] x 16 bytes -- one kilobyte per wave instruction (rounds 1-4 stored them row-major:
+    // 80 four-byte stores per lane)
+    constexpr int kSlabF4 = kNW * TS * 2 * 64;
+    const int tile = bmz * tn_ + which * pair_tn + bn;
+    f32x4v* slab = reinterpret_cast<f32x4v*>(part) + ((size_t)tile * splits_ + split) * kSlabF4 + wave * TS * 2 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) slab[(i * 2 + c) * 64] = acc[i][c];
+    return;
+  }
   if (fused == 2) {
     constexpr int kSlabBytes = kNW * TS * 2 * 64 * 16;
     const int tile = bmz * tn_ + which * pair_tn + bn;
@@ -742,10 +755,49 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) {
         const int m = m0 + wm * TS * 16 + i * 16 + 4 * g4 + e;
         if (m < M) {
-          if (final_out) out[(long)m * ldc + n] = apply_act(acc[i][c][e] + bv, act);
-          else part[((long)split * M + m) * N + n] = acc[i][c][e];
+          out[(long)m * ldc + n] = apply_act(acc[i][c][e] + bv, act);
         }
       }
+  }
+}
+
+// The reduction behind fc_mfma_dma16_kernel's slabs (one or two products of a launch): one thread per 16-byte piece of a tile
+// sums the K ranges in range order from zero (fc_reduce_kernel's additions: the same bits as rounds 1-4), adds the bias, applies
+// the activation and writes the piece's four rows.  piece = (wave = 4 wm + wn, sub-tile i, column half c, lane = 16 g4 + r16):
+// rows 160 wm + 16 i + 4 g4 + e, column 32 wn + 16 c + r16 of the tile.
+__global__ __launch_bounds__(256) void fc_reduce_slab_kernel(const float* __restrict__ part, const float* __restrict__ bias0,
+                                                             const float* __restrict__ bias1, float* __restrict__ out0,
+                                                             float* __restrict__ out1, int M, int N, int ldc, int splits, int act,
+                                                             int tn_all, int pair_tn, int ntiles) {
+  constexpr int kSlabF4 = 8 * 10 * 2 * 64;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const f32x4v* p4 = reinterpret_cast<const f32x4v*>(part);
+  const long total = (long)ntiles * kSlabF4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int tile = (int)(idx / kSlabF4), piece = (int)(idx - (long)tile * kSlabF4);
+    const int lane = piece & 63, ic = (piece >> 6) % 20, wave = piece / (64 * 20);
+    const int i = ic >> 1, c = ic & 1, wn = wave & 3, wm = wave >> 2, r16 = lane & 15, g4 = lane >> 4;
+    const int bmz = tile / tn_all;
+    int bn = tile - bmz * tn_all;
+    const int which = (pair_tn && bn >= pair_tn) ? 1 : 0;
+    bn -= which * pair_tn;
+    const int n = bn * kBN + wn * 32 + c * 16 + r16;
+    const int m0 = bmz * 320 + wm * 160 + i * 16 + 4 * g4;
+    if (n >= N || m0 >= M) continue;
+    const f32x4v* src = p4 + (long)tile * splits * kSlabF4 + piece;
+    f32x4v v = {0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 4 <= splits; sp += 4) {
+      const f32x4v a = src[(long)sp * kSlabF4], b = src[(long)(sp + 1) * kSlabF4], cc = src[(long)(sp + 2) * kSlabF4],
+                   d = src[(long)(sp + 3) * kSlabF4];
+      v = (((v + a) + b) + cc) + d;
+    }
+    for (; sp < splits; ++sp) v += src[(long)sp * kSlabF4];
+    const float bv = (which ? bias1 : bias0)[n];
+    float* o = (which ? out1 : out0) + (long)m0 * ldc + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (m0 + e < M) o[(long)e * ldc] = apply_act(v[e] + bv, act);
   }
 }
 
@@ -795,39 +847,6 @@ __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict_
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += part[(long)s * total + idx];
     out[m * ldc + n] = apply_act(v + bias[n], act);
-  }
-}
-
-// The reduction of a PAIR (mnc_fc_pair): partial sums [product][range][M][N], one launch for both products; per element the
-// additions of fc_reduce_kernel<4, 0> (range order, from zero, + bias, activation).
-__global__ __launch_bounds__(256) void fc_reduce_pair_kernel(const float* __restrict__ part, const float* __restrict__ bias0,
-                                                             const float* __restrict__ bias1, float* __restrict__ out0,
-                                                             float* __restrict__ out1, int M, int N, int ldc, int splits, int act) {
-  const int n4 = N >> 2;
-  const long total4 = ((long)M * N) >> 2;
-  for (long i2 = (long)blockIdx.x * blockDim.x + threadIdx.x; i2 < 2 * total4; i2 += (long)gridDim.x * blockDim.x) {
-    const int which = i2 >= total4;
-    const long i = i2 - which * total4;
-    const float4* p4 = reinterpret_cast<const float4*>(part) + (long)which * splits * total4;
-    const int n = (int)(i % n4) * 4;
-    const long m = i / n4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 4 <= splits; s += 4) {
-      const float4 a = p4[(long)s * total4 + i], b = p4[(long)(s + 1) * total4 + i], c = p4[(long)(s + 2) * total4 + i],
-                   d = p4[(long)(s + 3) * total4 + i];
-      v.x = (((v.x + a.x) + b.x) + c.x) + d.x;
-      v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
-      v.z = (((v.z + a.z) + b.z) + c.z) + d.z;
-      v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
-    }
-    for (; s < splits; ++s) {
-      const float4 a = p4[(long)s * total4 + i];
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    }
-    const float4 b = *reinterpret_cast<const float4*>((which ? bias1 : bias0) + n);
-    *reinterpret_cast<float4*>((which ? out1 : out0) + m * ldc + n) =
-        make_float4(apply_act(v.x + b.x, act), apply_act(v.y + b.y, act), apply_act(v.z + b.z, act), apply_act(v.w + b.w, act));
   }
 }
 
@@ -970,9 +989,17 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
 #ifdef MNC_TUNING
   if (tune(ctx, T_FC_MFMA16, 1) == 0 || tune(ctx, T_FC_DMA_WAVES, 8) == 4 || tune(ctx, T_FC_DMA_ABL, 0)) inkernel = false;
 #endif
+  // the eight-wave 16x16x4 kernel leaves its K ranges as SLABS (its accumulators in register layout, 160 KB per tile and range:
+  // fc_reduce_slab_kernel); every other kernel as [range][M][N] rows (fc_reduce_kernel)
+  bool slab = dma;
+#ifdef MNC_TUNING
+  if (dma && tune(ctx, T_FC_DMA_ABL, 0) < 16 &&
+      (tune(ctx, T_FC_MFMA16, 1) == 0 || tune(ctx, T_FC_DMA_WAVES, 8) == 4 || tune(ctx, T_FC_DMA_ABL, 0)))
+    slab = false;                                    // (the 32x32x2 builds of the tuning library)
+#endif
   float* part = nullptr;
   if (splits > 1) {
-    int rc = ensure_scratch(ctx, inkernel ? (size_t)tn * tm * splits * 163840 : (size_t)splits * M * N * 4);
+    int rc = ensure_scratch(ctx, slab ? (size_t)tn * tm * splits * 163840 : (size_t)splits * M * N * 4);
     if (rc) return rc;
     part = (float*)ctx->scratch;
   }
@@ -1068,10 +1095,20 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     int rc = ls.finish("fc_mfma_kernel");
     if (rc) return rc;
   }
-  if (ctx->defer_reduce) {                           // the caller's next kernel sums the ranges (mnc_internal.h)
+  if (ctx->defer_reduce && !slab) {                  // the caller's next kernel sums the ranges (mnc_internal.h; row layout only)
     ctx->deferred_part = splits > 1 && !inkernel ? part : nullptr;
     ctx->deferred_splits = splits > 1 && !inkernel ? splits : 1;
     return MNC_OK;
+  }
+  ctx->deferred_part = nullptr;
+  ctx->deferred_splits = 1;
+  if (splits > 1 && !inkernel && slab) {
+    LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
+    long g = ((long)tn * tm * 10240 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fc_reduce_slab_kernel, dim3((int)g), dim3(256), 0, ctx->stream, part, d_bias, (const float*)nullptr, d_out,
+                       (float*)nullptr, M, N, ldc, splits, act, tn, 0, tn * tm);
+    return ls.finish("fc_reduce_slab_kernel");
   }
   if (splits > 1 && !inkernel) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
@@ -1118,7 +1155,7 @@ int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, const float*
   splits = cdiv(K, kper);
   float* part = nullptr;
   if (splits > 1) {
-    int rc = ensure_scratch(ctx, (size_t)2 * splits * M * N * 4);
+    int rc = ensure_scratch(ctx, (size_t)2 * tn * tm * splits * 163840);
     if (rc) return rc;
     part = (float*)ctx->scratch;
   }
@@ -1142,11 +1179,11 @@ int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, const float*
   }
   if (splits > 1) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 8.0 * ((double)splits + 1.0) * M * N);
-    long g = ((long)M * N / 2 + 255) / 256;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(fc_reduce_pair_kernel, dim3((int)g), dim3(256), 0, ctx->stream, part, d_bias0, d_bias1, d_out0, d_out1, M, N,
-                       ldc, splits, act);
-    return ls.finish("fc_reduce_pair_kernel");
+    long g = ((long)2 * tn * tm * 10240 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(fc_reduce_slab_kernel, dim3((int)g), dim3(256), 0, ctx->stream, part, d_bias0, d_bias1, d_out0, d_out1, M, N,
+                       ldc, splits, act, 2 * tn, tn, 2 * tn * tm);
+    return ls.finish("fc_reduce_slab_kernel");
   }
   return MNC_OK;
 }
