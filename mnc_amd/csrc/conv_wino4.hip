@@ -223,7 +223,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   for (int i = 0; i < 6; ++i) h_off[i] = halo_off(i);
   // One buffer descriptor per operand (wave-uniform), the block's offset in the scalar soffset, the lane's part in a 32-bit voffset:
   // no 64-bit address registers.  (Inline assembly as in gemm.hip: behind the DMA builtins hipcc makes every later ds_read wait for
-  // vmcnt(0).)
+  // vmcnt(0).)  M0 (the LDS destination of a DMA) is written and consumed inside ONE asm statement each time: hipcc reserves m0,
+  // does not keep values in it across statements it cannot see into, and rejects it as a clobber ("reserved register ... undefined
+  // behaviour" -- ADVICE r4 asked for the clobber); cdna_hip_programming.md 5.7 prescribes exactly this form.
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   auto make_rsrc = [](const float* base, long bytes) {
     const unsigned long a = (unsigned long)base;

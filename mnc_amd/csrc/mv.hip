@@ -254,14 +254,6 @@ __global__ __launch_bounds__(1024) void mv_order_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[(long)c * n + i] = (int)(s_keys[i] & 0xFFFFFFFFu);
 }
 
-// keep lists index the sorted order; the voting wants box indices: keepbox[c][k] = order[c][keep[c][k]]
-__global__ void mv_keepbox_kernel(const int* __restrict__ order, const int* __restrict__ keep, const int* __restrict__ num,
-                                  int n, int* __restrict__ keepbox) {
-  const int c = blockIdx.y;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < num[c]) keepbox[(long)c * n + k] = order[(long)c * n + keep[(long)c * n + k]];
-}
-
 constexpr int kSelThreads = 1024;
 constexpr int kSelCap = 8192;        // kept boxes over all classes the in-LDS selection sorts (20 classes x 100: 2000)
 constexpr int kSelMaxClasses = 1024;
@@ -483,7 +475,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Device scratch of one gpu_mask_voting problem (n boxes, C classes incl. background, S x S masks, keep_cap kept per class).
 struct VoteWs {
   float *boxes, *masks, *scores;        // staging for host inputs (unused when the inputs are already on the device)
-  int* order; unsigned long long* bits; int *keep, *keepbox, *num;
+  int* order; unsigned long long* bits; int *keep, *num;
   int *pool_box, *pool_cls; float* pool_score;
   int* rows; float* rscore; int* counts;
   int *cinds; float* cw; int *cbegin, *cend, *bounds; float* omask; int* obox;
@@ -500,7 +492,6 @@ static size_t vote_ws_layout(char* base, int n, int C, int S, int keep_cap, Vote
   w->order = (int*)take((size_t)B * n * 4);
   w->bits = (unsigned long long*)take((size_t)B * n * cb * 8);
   w->keep = (int*)take((size_t)B * n * 4);
-  w->keepbox = (int*)take((size_t)B * n * 4);
   w->num = (int*)take((size_t)B * 4);
   w->pool_box = (int*)take((size_t)Rmax * 4);
   w->pool_cls = (int*)take((size_t)Rmax * 4);
