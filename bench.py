@@ -17,8 +17,11 @@ A "step" is one pass of the whole hot path over one synthetic image per GPU, mea
        the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
        device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
 Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
-Every GPU keeps FOUR images in flight by default (--in-flight 4: one mnc_net + context + stream per image in flight;
-mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 3): a sixth of an image's GPU time is spent in
+Every GPU keeps THREE images in flight by default (--in-flight 3: one mnc_net + context + stream per image in flight, ONE shared set
+of device weights; rounds 3-4: four.  Swept in round 5 on the final build, profiles/r05_in_flight_sweep.txt: 2 / 3 / 4 / 5 / 6 / 8 in
+flight = 262 / 264 / 254 / 259 / 261 / 259 images/s in fp32, 649 / 708 / 632 / 665 / 684 in f16 -- three is the best in every math
+mode, four a dip that GPU_MAX_HW_QUEUES does not move);
+mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 2): a sixth of an image's GPU time is spent in
 kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- other images' convolutions run
 there.  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` is the
 rounds 1-2 protocol (--in-flight 1 makes it the headline).
@@ -107,10 +110,12 @@ def parse():
                         "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
                         "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
                         "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
-    p.add_argument("--in-flight", type=int, default=4, choices=[1, 2, 3, 4, 5, 6, 8],
+    p.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
-                        "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline)")
+                        "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline); "
+                        "0 (default) = 3, or 2 under a launcher, where the RCCL gather has a stream of its own: three streams per GPU "
+                        "is where the throughput peaks (profiles/r05_in_flight_sweep.txt)")
     p.add_argument("--dist-backend", default="nccl",
                    help="transport of the instance blocks: nccl = RCCL all-gather issued by libmnc_hip.so on a device stream (one rank "
                         "per GPU) | gloo = host tensors (functional test on fewer GPUs than ranks).  torch.distributed itself -- the "
@@ -150,6 +155,11 @@ def main():
         # into a HIP graph per image size and replayed (Net.detect_image)
         args.engine = "graph"
     launched = "WORLD_SIZE" in os.environ
+    if args.in_flight == 0:
+        # three streams per GPU is where the throughput peaks on this part (profiles/r05_in_flight_sweep.txt: 2 / 3 / 4 / 5 / 6 / 8
+        # images in flight = 262 / 264 / 254 / 259 / 261 / 259 images/s without a launcher; with the RCCL gather on a stream of
+        # its own 260 / 256 / 250 for 2 / 3 / 4): three images in flight, two when the gather holds the third stream
+        args.in_flight = 2 if launched else 3
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
     if launched:
@@ -334,6 +344,13 @@ def main():
             if launched:
                 dist.barrier()
 
+        if native and not args.no_graph:
+            # part of building the nets, not of the W warm-up steps: every net of the pipeline sees the image size twice (eager,
+            # then the capture of its HIP graph), so that neither the warm-up nor a short timed region (the driver's --steps 20
+            # --warmup 5 with three nets) contains a graph capture
+            for nn in nets:
+                for _ in range(2):
+                    nn.forward_image(images[rank % N_IMAGES], record_cap=100)
         for k in range(warmup):
             if inflight > 1:
                 step_pipelined(k, False)
