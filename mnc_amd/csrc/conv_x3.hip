@@ -93,7 +93,7 @@ template <int CT, int PR, int ROWS, int F16 = 0, int FMT = 0>
 __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __restrict__ in_, const uint4* __restrict__ wpk,
                                                                const float* __restrict__ bias, void* __restrict__ out_,
                                                                int H, int W, int Cin, int Cout, int relu, int main_tiles,
-                                                               int tail_ks, float* __restrict__ part) {
+                                                               int tail_ks, float* __restrict__ part, int tail_first) {
   constexpr bool kInPk = (FMT & kFmtInPacked) != 0, kOutPk = (FMT & kFmtOutPacked) != 0;
   constexpr int NT = 64 * ROWS;
   constexpr int R = ROWS * PR;                               // pixel rows per workgroup
@@ -123,7 +123,10 @@ __global__ __launch_bounds__(64 * ROWS) void conv3x3_x3_kernel(const void* __res
   // tail_ks K ranges, one block each, whose raw partial sums go to `part` ([tail tile][range][row][channel block][col][8])
   // and are finished by x3_tail_reduce_kernel.
   const int nx = (W + kX3Cols - 1) / kX3Cols, ny = (H + R - 1) / R;
+  // tail_first (CONVX3_TAIL=2): the tail's K ranges take the low block numbers and start with the launch
+  const int n_tail_blocks = (int)gridDim.x - main_tiles;
   int tile = blockIdx.x, split = 0, ksplit = 1;
+  if (tail_first) tile = tile < n_tail_blocks ? main_tiles + tile : tile - n_tail_blocks;
   if (tile >= main_tiles) {
     const int q = tile - main_tiles;
     ksplit = tail_ks;
@@ -581,7 +584,8 @@ static int launch_x3(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
     part = (float*)ctx->scratch;
   }
   hipLaunchKernelGGL(kern, dim3(main_tiles + ntail * ks), dim3(64 * ROWS), lds, ctx->stream, d_in, (const uint4*)d_wpk, d_bias,
-                     d_out, H, W, Cin, Cout, relu, main_tiles, ks, part);
+                     d_out, H, W, Cin, Cout, relu, main_tiles, ks, part,
+                     main_tiles > 0 && ntail > 0 && tune(ctx, T_CONVX3_TAIL, 1) == 2 ? 1 : 0);
   if (ntail > 0)
     hipLaunchKernelGGL((x3_tail_reduce_kernel<F16, (FMT & kFmtOutPacked) != 0>), dim3(x3_grid_for((long)ntail * R * (NCO / 8) * 32)),
                        dim3(256), 0, ctx->stream, (const float4*)part, d_bias, d_out, H, W, R, NCO, main_tiles, ntail, ks, relu);

@@ -965,7 +965,9 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   int splits = cdiv(mt == 10 ? 256 : 512, tn * tm);
   // small variant: deep K (the N = 126 heads, K = 8192) gets at least 8 stages per split -- 32 splits instead of 103 cut
   // its reduction from 24 to 11 us and the total from 44 to 29 us; shallow K (mask_pred, K = 256) keeps 2
-  const int min_stages = small ? (stages >= 64 ? 8 : 2) : (mt == 5 ? 16 : 8);
+  int small_min = tune(ctx, T_FC_SMALL_MIN, 8);      // A/B switch of the rule above (FC_SMALL_MIN=4: 32 ranges for the K = 4096 heads)
+  if (small_min < 2) small_min = 2;
+  const int min_stages = small ? (stages >= 64 ? small_min : 2) : (mt == 5 ? 16 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
   // a small GEMM over at most 8 stages (mask_pred: K = 256) is not cut at all: four ranges of two stages each cost 9.5 us + a
   // 6.3 us reduction launch (kernel_bench fc, round 5) for 0.07 GFLOP; one range of eight stages writes the result itself

@@ -246,6 +246,34 @@ def test_conv3x3_winograd_f4_in_launch_reduction_reads_fresh_slabs(dev, tune, H,
         assert np.array_equal(got, refs[k]), "launch %d (input %d): %d values differ" % (rep, k, int((got != refs[k]).sum()))
 
 
+def test_conv3x3_tail_plan_tail_first_is_the_same_result(dev, tune):
+    """WINO_TAIL=2 / CONVX3_TAIL=2 (A/B switches, round 5): the K ranges of a plan's tail take the LOW block numbers, so they start
+    with the launch instead of behind the whole tiles.  Same tiles, same ranges, same order of additions: the same bits.  Shape
+    (150, 250, 64, 256): 608 workgroup tiles on 512 resident workgroups in all three kernels -- the conv3_x plan."""
+    H, W, Cin, Cout = 150, 250, 64, 256
+    rng = np.random.default_rng(77)
+    x = rng.normal(0, 1, (Cin, H, W)).astype(np.float32)
+    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    d_x, d_b, d_wraw = dev.put(to_c8(x)), dev.put(rng.normal(0, 0.1, Cout).astype(np.float32)), dev.put(w)
+    d_y = dev.empty((Cout, H, W), fill=-7.0)
+    for pack, fn, nw, key in (("mnc_pack_conv3x3_wino4", "mnc_conv3x3_wino4", Cin * Cout * 36, "WINO_TAIL"),
+                              ("mnc_pack_conv3x3_bf16x3", "mnc_conv3x3_bf16x3", (Cin // 8) * Cout * 84, "CONVX3_TAIL"),
+                              ("mnc_pack_conv3x3_f16", "mnc_conv3x3_f16", (Cin // 8) * Cout * 84, "CONVX3_TAIL")):
+        d_w = dev.empty((nw,))
+        dev.call(pack, d_wraw, d_w, Cout, Cin)
+        res = []
+        for v in (None, "2", "0"):
+            dev.tune(key, None)
+            if v is not None:
+                tune(key, v)
+            dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
+            dev.call(fn, d_x, d_w, d_b, d_y, H, W, Cin, Cout, 1)
+            res.append(dev.get(d_y, (Cout * H * W,)).copy())
+        dev.tune(key, None)
+        assert np.array_equal(res[0], res[1]), (fn, int((res[0] != res[1]).sum()))
+        assert err(res[0], res[2])[1] < 1e-4, fn             # (no tail plan: other K ranges, not the same bits)
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):
