@@ -1,4 +1,5 @@
 // Context, device memory, error reporting and HIP-event profiling for libmnc_hip.so.
+#include <atomic>
 #include <cstdlib>
 
 #include "mnc_internal.h"
@@ -122,7 +123,19 @@ int mnc_ctx_create(mnc_ctx** out, int device_id) {
     const char* v = getenv(name);
     ctx->tune[k] = v && *v ? parse_tune(v) : kTuneUnset;
   }
-  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  // STREAM_PRIO (environment only: the stream is made here): the context's stream at that HIP priority; 9 = the contexts of the
+  // process take the device's priority levels in turn (an A/B switch for several images in flight, profiles/r05_stream_prio.txt)
+  hipError_t e;
+  if (ctx->tune[T_STREAM_PRIO] != kTuneUnset) {
+    static std::atomic<int> made{0};
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    int prio = ctx->tune[T_STREAM_PRIO];
+    if (prio == 9) prio = least - made.fetch_add(1) % (least - greatest + 1);
+    e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  }
   if (e != hipSuccess) {
     delete ctx;
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
