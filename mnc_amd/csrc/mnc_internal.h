@@ -34,7 +34,7 @@ namespace mnc {
   X(CONV_COT) X(CONV_ROWS) X(CONV_KSPLIT) X(CONV_ABL) X(CONV1X1_TILE) X(CONV2D_WIDE) X(WINO_ROWS) X(WINO_TAIL) X(WINO_V) X(WINO_VAR)  \
   X(WINO_DMA) X(WINO_XCD) X(CONVX3_TAIL) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
   X(FC_NO256) X(FCX3_TILE) X(FC_ORDER) X(FCX3_ABL) X(FC_SM) X(PACKED_ACT) X(FUSE_POOLS) X(BRANCH_STREAMS) X(TOPK_SINGLE_WG)           \
-  X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(FC_SMALL_MIN) X(STREAM_PRIO)
+  X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(FC_SMALL_MIN) X(STREAM_PRIO) X(ROI_ROW_SEGS)
 enum TuneKey {
 #define MNC_TUNE_ENUM(n) T_##n,
   MNC_TUNE_KEYS(MNC_TUNE_ENUM)

@@ -387,6 +387,172 @@ __global__ __launch_bounds__(256) void roi_warp_wave_kernel(const float* __restr
   }
 }
 
+// ---- ROIWarping, one wave per output ROW (ROI_WARP_VARIANT = 3; round 5) ---------------------------------------------------------
+// The wave kernel above gives every output position its own taps: 4 .. 9 pixel reads of a kilobyte per position and 256 channels,
+// ~6x the bytes it writes, all through L2 -- that, not the 120 MB it writes, is what its 60 us are.  Neighbouring positions of a
+// row sample neighbouring (mostly the same) feature-map columns: a wave that walks a whole output row (r, ph, 256 channels) keeps
+// the last columns it read in registers (3 columns x 2-3 rows for the fused 28x28 + pool, 2 x 2 for the plain warp) and reads only
+// the columns the next position adds: 3 + 27 bin-widths columns per row instead of 14 x 2-3.  Per position: the same set-up
+// (warp_setup), the same four taps with the same weights in the same order, the same maximum order -- the same bits.  A position
+// that the window does not serve (a tap outside the map, samples more than one cell apart) takes the wave kernel's own code and
+// the window starts again behind it.
+template <int NC, int NR>
+struct WarpWindow {
+  float4 g[NC][NR];                  // [column cx + i][row y0 + j]
+  int cx;                            // first column held; INT_MIN: nothing
+};
+
+template <int NC, int NR>
+__device__ __forceinline__ void warp_window_seek(WarpWindow<NC, NR>& w, const float* __restrict__ px, int W, int C, int y0, int x0) {
+  // px = feature map + the lane's channel offset.  Columns past the last one are clamped (read again, never used: a position
+  // that needed them would have a tap outside the map and does not come here).
+  auto col = [&](int i, int x) {
+    const float* p = px + ((long)y0 * W + min(x, W - 1)) * C;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w.g[i][j] = ld4(p + (long)j * W * C);
+  };
+  const int s = w.cx == INT_MIN ? NC : x0 - w.cx;          // wave-uniform
+  if (s == 0) return;
+  if (NC == 3 && s == 1) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { w.g[0][j] = w.g[1][j]; w.g[1][j] = w.g[2][j]; }
+    col(2, x0 + 2);
+  } else if (NC == 3 && s == 2) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w.g[0][j] = w.g[2][j];
+    col(1, x0 + 1);
+    col(2, x0 + 2);
+  } else if (NC == 2 && s == 1) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) w.g[0][j] = w.g[1][j];
+    col(1, x0 + 1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) col(i, x0 + i);
+  }
+  w.cx = x0;
+}
+
+// What the row kernel pays for is VALU work, not bytes (the first version, with warp_setup per sample and scalar blends, gained
+// 4 % from reading 3.4 instead of 6 pixels per position): so the set-up is split into its x and y halves -- the y half once per
+// row, the x half once per sample COLUMN, the same expressions as warp_setup, value for value -- and the blend runs on packed
+// fp32 (v_pk_mul_f32 / v_pk_add_f32: two channels per instruction, each lane of a packed operation rounds like the scalar one).
+typedef float warp_f2 __attribute__((ext_vector_type(2)));
+struct WarpAxis {                    // one coordinate of a sample: cell, fraction, 1 - fraction, validity of the two taps
+  int i0;
+  float a, oma;
+  bool v0, v1;
+};
+__device__ __forceinline__ WarpAxis warp_axis(float s, int n) {
+  WarpAxis r;
+  r.i0 = (int)floorf(s);
+  r.a = s - (float)r.i0;
+  r.oma = 1.0f - r.a;
+  r.v0 = r.i0 >= 0 && r.i0 < n;
+  r.v1 = r.i0 + 1 >= 0 && r.i0 + 1 < n;
+  return r;
+}
+// w00 * a00 + w01 * a01 + w10 * a10 + w11 * a11, left to right, on the two halves of a float4
+__device__ __forceinline__ float4 warp_blend_pk(float w00, float w01, float w10, float w11, float4 a00, float4 a01, float4 a10,
+                                                float4 a11) {
+  auto lo = [](float4 v) { return warp_f2{v.x, v.y}; };
+  auto hi = [](float4 v) { return warp_f2{v.z, v.w}; };
+  const warp_f2 rl = ((w00 * lo(a00) + w01 * lo(a01)) + w10 * lo(a10)) + w11 * lo(a11);
+  const warp_f2 rh = ((w00 * hi(a00) + w01 * hi(a01)) + w10 * hi(a10)) + w11 * hi(a11);
+  return make_float4(rl.x, rl.y, rh.x, rh.y);
+}
+
+template <int POOL2, int DY, int SM>
+__device__ __forceinline__ void warp_row_walk(const float* __restrict__ feat_hwc, int C, int H, int W, int PW, int ph, float x1s,
+                                              float y1s, float bw, float bh, int c4, float* __restrict__ orow0, int pw0, int pw1,
+                                              void* __restrict__ sm, long M, long r) {
+  constexpr int NSX = POOL2 ? 2 : 1, NSY = POOL2 ? 2 : 1, NC = POOL2 ? 3 : 2, NR = 2 + (POOL2 ? DY : 0);
+  const float* px = feat_hwc + c4 * 4;
+  WarpWindow<NC, NR> win;
+  win.cx = INT_MIN;
+  // the sample rows of this output row
+  WarpAxis ya[NSY];
+  bool ysafe = true;
+#pragma unroll
+  for (int j = 0; j < NSY; ++j) {
+    ya[j] = warp_axis(y1s + (float)(POOL2 ? 2 * ph + j : ph) * bh, H);
+    ysafe = ysafe && ya[j].v0 && ya[j].v1;
+  }
+  const bool rows_ok = ysafe && (!POOL2 || ya[NSY - 1].i0 - ya[0].i0 == DY);
+  for (int pw = pw0; pw < pw1; ++pw) {
+    WarpAxis xa[NSX];
+    bool xsafe = true;
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      xa[i] = warp_axis(x1s + (float)(POOL2 ? 2 * pw + i : pw) * bw, W);
+      xsafe = xsafe && xa[i].v0 && xa[i].v1;
+    }
+    const int dx = xa[NSX - 1].i0 - xa[0].i0;
+    float* orow = orow0 + (long)pw * C;
+    float4 o;
+    if (rows_ok && xsafe && dx >= 0 && dx <= 1) {
+      warp_window_seek<NC, NR>(win, px, W, C, ya[0].i0, xa[0].i0);
+#pragma unroll
+      for (int j = 0; j < NSY; ++j)
+#pragma unroll
+        for (int i = 0; i < NSX; ++i) {
+          // (sample order as in the wave kernel: x fastest.)  Columns of the sample's taps inside the window: 0 / 1, or 1 / 2 for
+          // the right-hand sample of a pair one cell apart; rows j * DY, j * DY + 1
+          const bool right = NC == 3 && i == 1 && dx == 1;
+          const int oy = j * (POOL2 ? DY : 0);
+          const float4 a00 = right ? win.g[NC - 2][oy] : win.g[0][oy], a01 = right ? win.g[NC - 1][oy] : win.g[1][oy];
+          const float4 a10 = right ? win.g[NC - 2][oy + 1] : win.g[0][oy + 1], a11 = right ? win.g[NC - 1][oy + 1] : win.g[1][oy + 1];
+          const float w00 = xa[i].oma * ya[j].oma, w01 = xa[i].a * ya[j].oma, w10 = xa[i].oma * ya[j].a, w11 = xa[i].a * ya[j].a;
+          const float4 v = warp_blend_pk(w00, w01, w10, w11, a00, a01, a10, a11);
+          o = (i == 0 && j == 0) ? v : max4(o, v);
+        }
+    } else {
+      win.cx = INT_MIN;
+#pragma unroll
+      for (int j = 0; j < NSY; ++j)
+#pragma unroll
+        for (int i = 0; i < NSX; ++i) {
+          const float4 v = warp_sample(px, H, W, C, x1s + (float)(POOL2 ? 2 * pw + i : pw) * bw, y1s + (float)(POOL2 ? 2 * ph + j : ph) * bh);
+          o = (i == 0 && j == 0) ? v : max4(o, v);
+        }
+    }
+    *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+    if (SM) sm_store4<SM>(sm, M, r, ((long)ph * PW + pw) * C + c4 * 4, o);
+  }
+}
+
+// nseg: a row is walked by nseg waves, PW / nseg positions each (a wave's positions are a chain: each waits for its own loads)
+template <int POOL2, int SM>
+__global__ __launch_bounds__(256, 4) void roi_warp_row_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
+                                                              const float* __restrict__ rois, int R, int PH, int PW, float scale,
+                                                              float* __restrict__ out, int nseg, void* __restrict__ sm) {
+  const int C4 = C >> 2, lane = threadIdx.x & 63;
+  const int citers = ((C4 + 63) >> 6) * nseg;                      // 256-channel pieces of a row x its segments
+  const unsigned nitems = (unsigned)R * PH * citers;
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int GH = POOL2 ? 2 * PH : PH, GW = POOL2 ? 2 * PW : PW;
+  for (unsigned it = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; it < nitems; it += nwaves) {
+    const unsigned item = __builtin_amdgcn_readfirstlane(it);
+    const int cs = (int)(item % (unsigned)citers);
+    const int seg = cs % nseg, ci = cs / nseg;
+    const int pw0 = seg * PW / nseg, pw1 = (seg + 1) * PW / nseg;
+    const unsigned t = item / (unsigned)citers;
+    const int ph = (int)(t % (unsigned)PH), r = (int)(t / (unsigned)PH);
+    const int c4 = ci * 64 + lane;
+    if (c4 >= C4) continue;                                        // (a ragged last piece: the lanes past C just sit the row out)
+    const float* roi = rois + (long)r * 5;
+    const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
+    const float rw = fmaxf(x2s - x1s + 1.0f, 1.0f), rh = fmaxf(y2s - y1s + 1.0f, 1.0f);
+    const float bw = rw / (float)GW, bh = rh / (float)GH;
+    float* orow0 = out + ((long)r * PH + ph) * PW * C;
+    // the two sample rows of a pooled output row are the same for every position of the row: one cell apart or not
+    int dy = 0;
+    if (POOL2) dy = (int)floorf(y1s + (float)(2 * ph + 1) * bh) - (int)floorf(y1s + (float)(2 * ph) * bh);
+    if (POOL2 && dy == 1) warp_row_walk<POOL2, 1, SM>(feat_hwc, C, H, W, PW, ph, x1s, y1s, bw, bh, c4, orow0, pw0, pw1, sm, R, r);
+    else warp_row_walk<POOL2, 0, SM>(feat_hwc, C, H, W, PW, ph, x1s, y1s, bw, bh, c4, orow0, pw0, pw1, sm, R, r);
+  }
+}
+
 // ---- 8 channels per thread: the variant used when a second output is written (except the fused 28x28 warp).  A thread then owns
 // a whole 16-byte group of the stage-major tensor, and the per-thread index arithmetic of the second output is spent once per 8
 // channels: measured at 1000 RoIs x 1024 channels with the fp16 second output: 14x14 warp 430 us (4 channels per thread + lane
@@ -646,7 +812,7 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
   // shared), and for the plain warp from 1024 channels on (4+ channel iterations share a position's set-up).  Measured, fp16
   // second output, 1000 RoIs x 1024 channels: 28x28+pool 452 us against 629 / 680 for the 4- / 8-channels-per-thread kernels,
   // 14x14 407 against 520 / 430; fp32 only, 300 RoIs x 512 channels: 28x28+pool 61 against 68, 14x14 44 against 32 (so the
-  // 4-channels-per-thread kernel keeps that case).  MNC_ROI_WARP_VARIANT = 1 (wave) / 4 / 8 forces one.
+  // 4-channels-per-thread kernel keeps that case).  MNC_ROI_WARP_VARIANT = 1 (wave) / 3 (wave per output row) / 4 / 8 forces one.
   if (ctx->conv.warp_sample || ctx->conv.warp_round_edges || ctx->conv.warp_no_plus_one || ctx->conv.warp_oob) {
     // a convention other than the SPEC's: the generic kernel (see roi_warp_conv_kernel)
 #define MNC_WARPC(P2, SM)                                                                                                       \
@@ -657,7 +823,23 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
 #undef MNC_WARPC
     return ls.finish("roi_warp_conv_kernel");
   }
-  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, (pool2 || C >= 1024) ? 1 : 4);
+  // the fused 28x28 + pool: one wave per half output row (roi_warp_row_kernel; in the pipeline's serial trace,
+  // 300 RoIs x 512 channels: 59.8 -> 46.2 us; the plain 14x14 warp gains nothing from it -- 33.0 against 34.1 -- and keeps its kernel).
+  // profiles/r05_roi_warp_row.txt.  MNC_ROI_WARP_VARIANT = 3 forces the row kernel, MNC_ROI_ROW_SEGS the waves per row.
+  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, pool2 ? 3 : C >= 1024 ? 1 : 4);
+  if (vsel == 3) {                                                 // one wave per (half) output row
+    MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
+    int nseg = tune(ctx, T_ROI_ROW_SEGS, 2);
+    if (nseg < 1 || nseg > PW) nseg = 1;
+    const int g = grid_for((long)R * PH * ((C / 4 + 63) / 64) * nseg * 64);
+#define MNC_WARPR(P2, SM)                                                                                                   \
+  hipLaunchKernelGGL((roi_warp_row_kernel<P2, SM>), dim3(g), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, PW, scale, \
+                     d_out, nseg, d_sm)
+    if (pool2) { if (sm_fmt == 1) MNC_WARPR(1, 1); else if (sm_fmt == 2) MNC_WARPR(1, 2); else MNC_WARPR(1, 0); }
+    else { if (sm_fmt == 1) MNC_WARPR(0, 1); else if (sm_fmt == 2) MNC_WARPR(0, 2); else MNC_WARPR(0, 0); }
+#undef MNC_WARPR
+    return ls.finish("roi_warp_row_kernel");
+  }
   if (vsel != 4 && vsel != 8) {
     MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
     const int g = grid_for((long)R * PH * PW * 64);

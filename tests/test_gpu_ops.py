@@ -767,10 +767,11 @@ def _rois(rng, R, W, H):
 
 
 @pytest.mark.parametrize("pool2,P", [(0, 14), (1, 14), (0, 7)])
-@pytest.mark.parametrize("variant", [None, "1", "4"])
+@pytest.mark.parametrize("variant", [None, "1", "4", "3"])
 def test_roi_warp(dev, monkeypatch, pool2, P, variant, tune):
     """(variant: the library's choice by channel count, or MNC_ROI_WARP_VARIANT forcing the one-wave-per-position / the
-    4-channels-per-thread kernel -- all bit-exact with the oracle, rois partly and wholly outside the map included.)"""
+    4-channels-per-thread / the one-wave-per-output-row kernel -- all bit-exact with the oracle, rois partly and wholly outside the
+    map included.)"""
     if variant:
         tune("ROI_WARP_VARIANT", variant)
     rng = np.random.default_rng(4)
@@ -785,6 +786,35 @@ def test_roi_warp(dev, monkeypatch, pool2, P, variant, tune):
     else:
         want = native.roi_warp(feat, rois, P, P, 0.0625)
     assert np.array_equal(got, want)      # roi.hip is built with -ffp-contract=off and mirrors the oracle op by op
+
+
+@pytest.mark.parametrize("pool2", [0, 1])
+@pytest.mark.parametrize("C", [512, 320])
+def test_roi_warp_row_kernel_at_head_width(dev, pool2, C, tune):
+    """ROI_WARP_VARIANT=3: one wave per output row, the feature-map columns of neighbouring positions kept in registers.  512
+    channels (two 256-channel pieces per row) and 320 (a ragged second piece), 120 rois of every kind -- proposal-sized, thin, tiny
+    (all samples in one cell), wider than 28 cells (samples more than a cell apart), touching every border, outside the map:
+    bit-exact with the oracle and with the one-wave-per-position kernel."""
+    rng = np.random.default_rng(31 + pool2 + C)
+    H, W, R, P = 38, 63, 120, 14
+    feat = rng.normal(size=(C, H, W)).astype(np.float32)
+    rois = _rois(rng, R, 1000, 600)
+    rois[5] = [0, 0, 0, 999, 40]                 # full width, thin: 63 cells over 14 / 28 samples
+    rois[6] = [0, 980, 560, 999, 599]            # bottom-right corner region
+    rois[7] = [0, 0, 0, 5, 5]                    # inside one cell
+    rois[8] = [0, -50, -30, 80, 70]              # partly left / above the map
+    rois[9] = [0, 300.5, 200.25, 310.75, 590.0]  # thin and tall
+    d_out = dev.empty((R * P * P * C,), fill=np.nan)
+    d_feat, d_rois = dev.put(to_c8(feat)), dev.put(rois)
+    res = {}
+    for v in ("3", "1"):
+        tune("ROI_WARP_VARIANT", v)
+        dev.put_into(d_out, np.full((R * P * P * C,), np.nan, np.float32))
+        dev.call("mnc_roi_warp", d_feat, C, H, W, d_rois, R, P, P, 0.0625, pool2, d_out)
+        res[v] = dev.get(d_out, (R, P, P, C)).copy()
+    assert np.array_equal(res["3"], res["1"])
+    want = native.maxpool2(native.roi_warp(feat, rois, 2 * P, 2 * P, 0.0625)) if pool2 else native.roi_warp(feat, rois, P, P, 0.0625)
+    assert np.array_equal(res["3"].transpose(0, 3, 1, 2), want)
 
 
 @pytest.mark.parametrize("fmt", [1, 2])
