@@ -11,6 +11,7 @@
 // first re-lays it out pixel-major so that every bilinear tap of a wave is one contiguous kilobyte.
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mnc_internal.h"
 #include "x3_split.h"
@@ -492,20 +493,25 @@ __device__ __forceinline__ void warp_row_walk(const float* __restrict__ feat_hwc
     float4 o;
     if (rows_ok && xsafe && dx >= 0 && dx <= 1) {
       warp_window_seek<NC, NR>(win, px, W, C, ya[0].i0, xa[0].i0);
+      // (sample order as in the wave kernel: x fastest.)  Columns of a sample's taps inside the window: 0 / 1, or 1 / 2 for the
+      // right-hand sample of a pair one cell apart (dx is wave-uniform: a branch, not 32 selects per position); rows j DY, j DY + 1
+      auto blend_all = [&](auto right_) {
+        constexpr int RIGHT = decltype(right_)::value;
 #pragma unroll
-      for (int j = 0; j < NSY; ++j)
+        for (int j = 0; j < NSY; ++j)
 #pragma unroll
-        for (int i = 0; i < NSX; ++i) {
-          // (sample order as in the wave kernel: x fastest.)  Columns of the sample's taps inside the window: 0 / 1, or 1 / 2 for
-          // the right-hand sample of a pair one cell apart; rows j * DY, j * DY + 1
-          const bool right = NC == 3 && i == 1 && dx == 1;
-          const int oy = j * (POOL2 ? DY : 0);
-          const float4 a00 = right ? win.g[NC - 2][oy] : win.g[0][oy], a01 = right ? win.g[NC - 1][oy] : win.g[1][oy];
-          const float4 a10 = right ? win.g[NC - 2][oy + 1] : win.g[0][oy + 1], a11 = right ? win.g[NC - 1][oy + 1] : win.g[1][oy + 1];
-          const float w00 = xa[i].oma * ya[j].oma, w01 = xa[i].a * ya[j].oma, w10 = xa[i].oma * ya[j].a, w11 = xa[i].a * ya[j].a;
-          const float4 v = warp_blend_pk(w00, w01, w10, w11, a00, a01, a10, a11);
-          o = (i == 0 && j == 0) ? v : max4(o, v);
-        }
+          for (int i = 0; i < NSX; ++i) {
+            constexpr int oy0 = 0;
+            const int oy = oy0 + j * (POOL2 ? DY : 0);
+            const int cl = (RIGHT && i == 1) ? 1 : 0;
+            const float4 a00 = win.g[cl][oy], a01 = win.g[cl + 1][oy], a10 = win.g[cl][oy + 1], a11 = win.g[cl + 1][oy + 1];
+            const float w00 = xa[i].oma * ya[j].oma, w01 = xa[i].a * ya[j].oma, w10 = xa[i].oma * ya[j].a, w11 = xa[i].a * ya[j].a;
+            const float4 v = warp_blend_pk(w00, w01, w10, w11, a00, a01, a10, a11);
+            o = (i == 0 && j == 0) ? v : max4(o, v);
+          }
+      };
+      if (NC == 3 && dx == 1) blend_all(std::integral_constant<int, NC == 3 ? 1 : 0>());
+      else blend_all(std::integral_constant<int, 0>());
     } else {
       win.cx = INT_MIN;
 #pragma unroll
