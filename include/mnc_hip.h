@@ -429,6 +429,16 @@ MNC_API int mnc_maxpool2_c8_bf16x3(mnc_ctx* ctx, const void* d_in, void* d_out, 
 MNC_API int mnc_maxpool2_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W);
 MNC_API int mnc_act_pack(mnc_ctx* ctx, const float* d_c8, void* d_packed, size_t n, int f16);
 MNC_API int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size_t n, int f16);
+/* Round 6: the reduced-precision 3x3 convolution on PACKED activations (csrc/conv_sw.hip: sliding-window implicit GEMM, every
+ * operand by LDS-DMA, K ranges summed inside the workgroup).  mode: 0 = bf16x3, 1 = f16, 2 = bf16 (packed bf16 tensors have the
+ * f16 form with bf16 values, mnc_act_pack's f16 = 2).  mnc_pack_conv3x3_lowp writes [ceil(Cin/16)][Cout/32][planes][9 taps][32] x
+ * 16 B (planes: the two 8-channel halves of the block; bf16x3: hi of each half, then lo of each half);
+ * mnc_conv3x3_lowp_weight_bytes is that buffer's size.  d_out_packed and / or d_out_c8 (fp32 c8) are written, a null one is not
+ * (conv5_3 feeds the RPN convolution packed and the RoI warps in fp32: test.prototxt:395-424, 479-492). */
+MNC_API size_t mnc_conv3x3_lowp_weight_bytes(int mode, int Cout, int Cin);
+MNC_API int mnc_pack_conv3x3_lowp(mnc_ctx* ctx, int mode, const float* d_oihw, void* d_packed, int Cout, int Cin);
+MNC_API int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias,
+                             void* d_out_packed, float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
 /* "f16" math mode (BASELINE.json configs[4] names fp16): InnerProduct with both operands rounded to IEEE fp16 (nearest even)
  * and fp32 accumulation on v_mfma_f32_32x32x16_f16 -- one product per term, 2 bytes per value streamed instead of 4.
  * mnc_pack_fc_f16: Caffe weight [N][K] -> [ceil(N/128)][K/64][128][64] halves (bytes: ceil(N/128)*128*K*2), once at load.

@@ -1,0 +1,422 @@
+// 3x3 convolution on the bf16 / fp16 matrix pipe, round 6: sliding-window implicit GEMM on 2-byte activation planes, every operand
+// by LDS-DMA (models/VGG16/mnc_5stage/test.prototxt:41-412; BASELINE.json configs[2] "bf16 convs via MFMA").  Replaces the
+// round-1/2 kernel (conv3x3_x3_kernel: register staging, 2x2 register tile, 12-dword pixel pitch, separate tail-reduction launch).
+//
+// Arithmetic.  M = output channels (MFMA A operand), N = 32 pixels of one image row (B operand), K = 16 input channels x one tap
+// per v_mfma_f32_32x32x16_{f16,bf16}; fp32 accumulation.  Three math modes share the kernel:
+//   f16  (1): operands rounded to fp16 (weights at load, activations by their producer);
+//   bf16 (2): the same with bf16 (BASELINE configs[2] as written: one product per term);
+//   x3   (0): "bf16x3" split precision (x3_split.h): every fp32 operand is hi + lo (both bf16) and a product is
+//             w_hi x_hi + w_hi x_lo + w_lo x_hi.  A 16-channel block is multiplied in three PASSES that each look like one fp16
+//             block: pass 0 = [w_hi(c 0-7) | w_hi(c 0-7)] x [x_hi(c 0-7) | x_lo(c 0-7)], pass 1 the same for channels 8-15,
+//             pass 2 = [w_lo(c 0-7) | w_lo(c 8-15)] x [x_hi(c 0-7) | x_hi(c 8-15)]: 27 MFMAs per block and tile, no padding slot
+//             (the old kernel: 30).
+//
+// Register tile and LDS traffic.  A wave owns PR = 5 consecutive pixel rows x 32 columns x 32 output channels (80 accumulator
+// registers).  Per 16-channel block it reads its nine weight fragments once (9 x ds_read_b128) and every halo row's three column
+// shifts once (7 rows x 3 = 21 reads); a halo fragment feeds the up to three output rows it is a tap of (45 MFMAs).  30 fragment
+// reads per 45 MFMAs = 0.67 per MFMA, what a 3x3 register tile gets with 144 accumulators, and the LDS carries no transposed or
+// padded image: the weight panel [tap][k half][32 channels] x 16 B and the halo planes [k half][row][34 columns] x 16 B are both
+// read as 512 contiguous bytes per 32 lanes -- conflict-free without padding, which is what lets LDS-DMA fill them
+// (buffer_load_dwordx4 ... lds writes 64 lanes x 16 B linearly; the gather is on the global side, out-of-image pixels carry an
+// out-of-range offset and arrive as zeros).  No staging registers, no ds_write, no conversion arithmetic in the loop.
+//
+// Work decomposition.  Workgroup = KW K-ranges x RG row groups x CG channel tiles (waves).  600x1000 VGG-16 maps are 600 / 300 /
+// 150 / 75 / 38 rows: five-row wave tiles divide all but the last exactly.  (RG, CG, KW) = (2, 2, 1): 10 rows x 32 columns x 64
+// channels per 256-thread workgroup, 64 KB of LDS, two per CU -- 1920 / 960 / 480 workgroups on conv1_2 / conv2_x / conv3_x = 3.75 /
+// 1.875 / 0.94 rounds of the chip's 512 slots.  conv4_x would be 256 such workgroups (one per CU, one wave per SIMD): (2, 2, 2) puts
+// two K ranges of the same tile into one 512-thread workgroup instead (own LDS buffers per range, one shared barrier), summed through
+// LDS at the end -- no partial sums in HBM, no second launch.  conv5_x / rpn (38 x 63) run (1, 1, 4): 256 workgroups of four K
+// ranges.  The old kernel's K-split tail with its x3_tail_reduce launch is gone.
+//
+// Pipeline.  One barrier per pass: wait for my copies of pass v, barrier (everybody's copies landed, everybody finished reading the
+// other buffer), issue the copies of pass v + 1 into the other buffer, multiply pass v.
+#include <atomic>
+#include <type_traits>
+
+#include "mnc_internal.h"
+#include "x3_split.h"
+
+namespace mnc {
+
+typedef float sw_f32x16 __attribute__((ext_vector_type(16)));
+typedef int sw_i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSwCols = 32, kSwHC = kSwCols + 2;
+constexpr int kSwOOB = 0x7FFFFFF0;                 // per-lane offset no buffer reaches: the copy answers with zeros
+constexpr int kSwTapB = 32 * 16;                   // one (plane, tap) of a 32-channel tile: 32 x 16 B
+constexpr int kSwPlaneB = 9 * kSwTapB;
+
+__host__ __device__ constexpr int sw_planes(int mode) { return mode == 0 ? 4 : 2; }
+__host__ __device__ constexpr int sw_pixb(int mode) { return mode == 0 ? 32 : 16; }
+
+// Geometry of one instantiation (host and device)
+template <int PR, int RG, int CG, int KW>
+struct SwGeom {
+  static constexpr int NWG = RG * CG;                        // waves of one K range
+  static constexpr int NT = 64 * NWG * KW;
+  static constexpr int ROWS = RG * PR;
+  static constexpr int HR = ROWS + 2;
+  static constexpr int UPL = HR * kSwHC;                     // 16-byte units of one halo plane
+  static constexpr int PP = (UPL + 63) / 64;                 // 1 KB copy pieces per halo plane
+  static constexpr int PLANEB = PP * 1024;
+  static constexpr int AB = CG * 9 * 1024;                   // weight panel: [channel tile][tap][k half][32] x 16 B
+  static constexpr int BUFB = AB + 2 * PLANEB;
+  static constexpr int NAS = (9 * CG + NWG - 1) / NWG;       // copy slots per wave and pass
+  static constexpr int NBS = (2 * PP + NWG - 1) / NWG;
+  static constexpr int DUMMY = KW * 2 * BUFB;                // 1 KB that surplus slots fill with zeros
+  static constexpr int RED = (KW - 1) * NWG * PR * 4096;     // K ranges' accumulators on their way to range 0
+  static constexpr int LDS = (DUMMY > RED ? DUMMY : RED) + 1024;
+};
+
+template <int MODE, int PR, int RG, int CG, int KW>
+__global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const void* __restrict__ in_, const void* __restrict__ wpk_,
+                                                                       const float* __restrict__ bias, void* __restrict__ out_pk,
+                                                                       float* __restrict__ out_f32, int H, int W, int Cin, int Cout,
+                                                                       int relu) {
+  typedef SwGeom<PR, RG, CG, KW> G;
+  constexpr int NPL = sw_planes(MODE), NPASS = MODE == 0 ? 3 : 1, PIXB = sw_pixb(MODE);
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_sw[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kw = wave / G::NWG, wl = wave - kw * G::NWG;
+  const int rg = wl / CG, cg = wl - rg * CG;
+  const int j = lane & 31, kb = lane >> 5;
+
+  // ---- tile of this workgroup: channel group fastest, then column tile, then row tile; every XCD (block b runs on XCD b % 8,
+  // used for speed only) takes a contiguous range of that order, so the channel groups of a spatial tile share one L2
+  const int tiles_x = (W + kSwCols - 1) / kSwCols, ncog = Cout / (32 * CG), ncot = Cout >> 5;
+  int logical;
+  {
+    const int total = (int)gridDim.x, q = total >> 3, r = total & 7;
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cog = logical % ncog, sp = logical / ncog;
+  const int tx = sp % tiles_x, ty = sp / tiles_x;
+  const int w0 = tx * kSwCols, h0 = ty * G::ROWS, cot0 = cog * CG;
+  const int nblk = Cin >> 3, nchunks = (nblk + 1) >> 1;
+  const int c_begin = kw * nchunks / KW, c_end = (kw + 1) * nchunks / KW;      // (the launcher makes nchunks a multiple of KW)
+
+  // ---- copy assignment, fixed per thread.  Weight slot i of wave wl = piece wl + NWG i of the panel (channel tile pa / 9, tap
+  // pa % 9): lanes 0-31 fetch the tap's k-half-0 plane, lanes 32-63 its k-half-1 plane.  Halo slot i = piece pb of the two planes:
+  // unit 64 (pb % PP) + lane = (row, column) of the halo.  Slots past the last piece fill the dummy kilobyte with zeros.
+  auto make_rsrc = [](const void* base, long bytes) {
+    const unsigned long a = (unsigned long)base;
+    sw_i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+    r.z = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFFL ? bytes : 0x7FFFFFFFL));
+    r.w = 0x00020000;
+    return r;
+  };
+  const int blk_bytes = H * W * PIXB;                              // one 8-channel block of the input
+  const sw_i32x4 in_rsrc = make_rsrc(in_, (long)nblk * blk_bytes);
+  const sw_i32x4 w_rsrc = make_rsrc(wpk_, (long)nchunks * ncot * NPL * kSwPlaneB);
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)s_sw;
+  const int kwbase = kw * 2 * G::BUFB;
+
+  int vb[G::NBS];
+#pragma unroll
+  for (int i = 0; i < G::NBS; ++i) {
+    const int pb = wl + G::NWG * i;
+    const int unit = (pb % G::PP) * 64 + lane;
+    const int row = unit / kSwHC, col = unit - row * kSwHC;
+    const int y = h0 - 1 + row, x = w0 - 1 + col;
+    const bool ok = pb < 2 * G::PP && unit < G::UPL && y >= 0 && y < H && x >= 0 && x < W;
+    vb[i] = ok ? (y * W + x) * PIXB : kSwOOB;
+  }
+  const int va0 = j * 16, va1 = j * 16 + kb * kSwPlaneB;
+
+  // pass v of chunk c -> buffer `buf` of this K range
+  auto dma = [&](int c, auto pass_, int buf) {
+    constexpr int pass = decltype(pass_)::value;
+    const sw_i32x4 wr = w_rsrc, ir = in_rsrc;                  // (named here: a generic lambda does not capture what only an asm operand uses)
+    const unsigned base = lds0 + (unsigned)(kwbase + buf * G::BUFB);
+    // weights: plane pair of the pass = (h0, h0) | (h1, h1) | (l0, l1) in x3, (k half 0, k half 1) otherwise
+    constexpr int a_plane0 = MODE == 0 ? (pass == 2 ? 2 : pass) : 0;
+    constexpr bool a_two = MODE != 0 || pass == 2;
+    const int a_chunk = (c * ncot + cot0) * (NPL * kSwPlaneB) + a_plane0 * kSwPlaneB;
+#pragma unroll
+    for (int i = 0; i < G::NAS; ++i) {
+      const int pa = wl + G::NWG * i;
+      const bool live = pa < 9 * CG;
+      const int cgi = pa / 9, tap = pa - cgi * 9;
+      const int so = __builtin_amdgcn_readfirstlane(a_chunk + cgi * (NPL * kSwPlaneB) + tap * kSwTapB);
+      const unsigned l = __builtin_amdgcn_readfirstlane(live ? base + (unsigned)pa * 1024u : lds0 + (unsigned)G::DUMMY);
+      const int vo = live ? (a_two ? va1 : va0) : kSwOOB;
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(wr), "s"(so), "s"(l) : "memory");
+    }
+    // halo: block and 16-byte half of the pixel record per k half.  x3: pass 0 (2c: hi | lo), pass 1 (2c + 1: hi | lo),
+    // pass 2 (hi of 2c | hi of 2c + 1); otherwise (2c | 2c + 1).  A block past the input's last (odd block count) reads as zeros.
+#pragma unroll
+    for (int i = 0; i < G::NBS; ++i) {
+      const int pb = wl + G::NWG * i;
+      const bool live = pb < 2 * G::PP;
+      const int kbp = pb / G::PP;
+      int blk, half;
+      if (MODE == 0 && pass < 2) { blk = 2 * c + pass; half = kbp; }
+      else { blk = 2 * c + kbp; half = 0; }
+      const int so = __builtin_amdgcn_readfirstlane(min(blk, nblk - 1) * blk_bytes + half * 16);
+      const unsigned l = __builtin_amdgcn_readfirstlane(live ? base + (unsigned)(G::AB + pb * 1024) : lds0 + (unsigned)G::DUMMY);
+      const int vo = (live && blk < nblk) ? vb[i] : kSwOOB;
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(ir), "s"(so), "s"(l) : "memory");
+    }
+  };
+#define MNC_SW_SYNC() asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  sw_f32x16 acc[PR];
+#pragma unroll
+  for (int r = 0; r < PR; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+  auto mfma = [](const uint4 a, const uint4 b, const sw_f32x16 c) {
+    if constexpr (MODE == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(a), x3_as_f16x8(b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(a), x3_as_bf16x8(b), c, 0, 0, 0);
+  };
+  // one pass out of buffer `buf`: halo row hr, column shift dx is tap (dy, dx) of output row hr - dy
+  auto compute = [&](int buf) {
+    const unsigned char* pb_ = s_sw + kwbase + buf * G::BUFB;
+    const uint4* Ap = reinterpret_cast<const uint4*>(pb_ + cg * 9 * 1024) + lane;
+    const uint4* Bp = reinterpret_cast<const uint4*>(pb_ + G::AB + kb * G::PLANEB) + (rg * PR * kSwHC + j);
+    uint4 a[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a[t] = Ap[t * 64];
+#pragma unroll
+    for (int hr = 0; hr < PR + 2; ++hr)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const uint4 b = Bp[hr * kSwHC + dx];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int r = hr - dy;
+          if (r >= 0 && r < PR) acc[r] = mfma(a[dy * 3 + dx], b, acc[r]);
+        }
+      }
+  };
+
+  // ---- main loop over the passes of this K range
+  dma(c_begin, std::integral_constant<int, 0>(), 0);
+  int buf = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    if constexpr (NPASS == 1) {
+      MNC_SW_SYNC();
+      if (c + 1 < c_end) dma(c + 1, std::integral_constant<int, 0>(), buf ^ 1);
+      compute(buf);
+      buf ^= 1;
+    } else {
+      MNC_SW_SYNC();
+      dma(c, std::integral_constant<int, 1>(), buf ^ 1);
+      compute(buf);
+      MNC_SW_SYNC();
+      dma(c, std::integral_constant<int, 2>(), buf);
+      compute(buf ^ 1);
+      MNC_SW_SYNC();
+      if (c + 1 < c_end) dma(c + 1, std::integral_constant<int, 0>(), buf ^ 1);
+      compute(buf);
+      buf ^= 1;
+    }
+  }
+
+  // ---- K ranges of the workgroup: ranges 1.. hand their accumulators to range 0 through LDS (summed in range order)
+  if constexpr (KW > 1) {
+    MNC_SW_SYNC();
+    float4* red = reinterpret_cast<float4*>(s_sw);
+    if (kw > 0) {
+#pragma unroll
+      for (int r = 0; r < PR; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          red[((((kw - 1) * G::NWG + wl) * PR + r) * 4 + q) * 64 + lane] =
+              make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+    }
+    __syncthreads();
+    if (kw > 0) return;
+#pragma unroll
+    for (int k = 1; k < KW; ++k)
+#pragma unroll
+      for (int r = 0; r < PR; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 p = red[((((k - 1) * G::NWG + wl) * PR + r) * 4 + q) * 64 + lane];
+          acc[r][4 * q] += p.x; acc[r][4 * q + 1] += p.y; acc[r][4 * q + 2] += p.z; acc[r][4 * q + 3] += p.w;
+        }
+  }
+
+  // ---- epilogue: D[row = channel (e & 3) + 8 (e >> 2) + 4 kb][column = pixel j]; bias, ReLU, the requested output forms
+  const int ow = w0 + j, co0 = (cot0 + cg) * 32;
+  const long gstride = (long)H * W;
+#pragma unroll
+  for (int r = 0; r < PR; ++r) {
+    const int oh = h0 + rg * PR + r;
+    if (oh < H && ow < W) {                                  // lanes j and j + 32 (the two channel halves of a pixel) agree
+      float4 v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + co0 + g * 8 + kb * 4);
+        v[g] = make_float4(acc[r][4 * g + 0] + b.x, acc[r][4 * g + 1] + b.y, acc[r][4 * g + 2] + b.z, acc[r][4 * g + 3] + b.w);
+        if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+      }
+      const long pix0 = ((long)(co0 >> 3) * H + oh) * W + ow;   // + g * H * W
+      if (out_f32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(out_f32 + (pix0 + g * gstride) * 8 + kb * 4) = v[g];
+      }
+      if (out_pk) {
+        if constexpr (MODE != 0) {
+          // 16-byte stores: v_permlane32_swap hands lane j the whole pixel of channel block g and lane j + 32 that of g + 1
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const uint2 A = MODE == 2 ? x3_bf16x4(v[g]) : x3_f16x4(v[g]), B = MODE == 2 ? x3_bf16x4(v[g + 1]) : x3_f16x4(v[g + 1]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(A.x, B.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(A.y, B.y, false, false);
+            reinterpret_cast<uint4*>(out_pk)[pix0 + (g + kb) * gstride] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
+        } else {
+          // lane j stores the pixel's hi x8 (its own four channels and lane j + 32's), lane j + 32 the lo x8
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hi, lo;
+            x3_split4(v[g], hi, lo);
+            const auto sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+            reinterpret_cast<uint4*>(out_pk)[(pix0 + g * gstride) * 2 + kb] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
+        }
+      }
+    }
+  }
+#undef MNC_SW_SYNC
+}
+
+// OIHW fp32 -> [ceil(Cin/16)][Cout/32][planes][9 taps][32 channels] x 16 B (8 two-byte values).  f16 / bf16: plane p = channels
+// 8p .. 8p + 7 of the 16-channel block, rounded to nearest even.  x3: planes (hi of channels 0-7, hi of 8-15, lo of 0-7, lo of
+// 8-15), hi = rne(w), lo = rne(w - hi).  Channels past Cin are zero.
+template <int MODE>
+__global__ void pack_conv_sw_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cout, int Cin) {
+  constexpr int NPL = sw_planes(MODE);
+  const int nchunks = (Cin + 15) / 16, ncot = Cout >> 5;
+  const long total = (long)nchunks * ncot * NPL * 9 * 32;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long q = i;
+    const int col = (int)(q & 31); q >>= 5;
+    const int tap = (int)(q % 9); q /= 9;
+    const int plane = (int)(q % NPL); q /= NPL;
+    const int cot = (int)(q % ncot), chunk = (int)(q / ncot);
+    const int co = cot * 32 + col, c0 = chunk * 16 + (plane & 1) * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = c0 + e < Cin ? w[((long)co * Cin + c0 + e) * 9 + tap] : 0.f;
+    uint4 v;
+    if (MODE == 1) {
+      const f16x8 h = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3], (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
+      v = __builtin_bit_cast(uint4, h);
+    } else if (MODE == 2) {
+      bf16x8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (__bf16)x[e];
+      v = __builtin_bit_cast(uint4, h);
+    } else {
+      uint4 hi, lo;
+      x3_split8_rne(x, hi, lo);
+      v = plane < 2 ? hi : lo;
+    }
+    out[i] = v;
+  }
+}
+
+static int sw_grid_for(long total) {
+  const long g = (total + 255) / 256;
+  return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+template <int MODE, int PR, int RG, int CG, int KW>
+static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out_pk, float* d_out_f32, int H,
+                     int W, int Cin, int Cout, int relu) {
+  typedef SwGeom<PR, RG, CG, KW> G;
+  static_assert(G::LDS <= 160 * 1024, "conv3x3_sw: LDS budget");
+  auto kern = conv3x3_sw_kernel<MODE, PR, RG, CG, KW>;
+  static std::atomic<unsigned long long> attr_set{0};          // one bit per device: function attributes are per device
+  const unsigned long long bit = 1ull << (ctx->device & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+    MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+    attr_set.fetch_or(bit, std::memory_order_relaxed);
+  }
+  const int blocks = cdiv(W, kSwCols) * cdiv(H, G::ROWS) * (Cout / (32 * CG));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NT), G::LDS, ctx->stream, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout,
+                     relu);
+  return MNC_OK;
+}
+
+// Which (RG, CG, KW) a shape runs on -- see the header comment.  Plan 0: (2, 2, 1); 1: (2, 2, 2); 2: (1, 1, 4); 3: (1, 1, 1), the
+// form every shape fits (Cout % 32 == 0).  CONVX3_TILE = 100 + plan overrides the choice where the plan fits the shape.
+static int sw_plan(const mnc_ctx* ctx, int H, int W, int Cin, int Cout) {
+  const int nchunks = (Cin / 8 + 1) / 2;
+  const bool fits[4] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true};
+  if (tune_set(ctx, T_CONVX3_TILE)) {
+    const int p = tune(ctx, T_CONVX3_TILE, 0) - 100;
+    if (p >= 0 && p < 4 && fits[p]) return p;
+  }
+  const long wg0 = (long)cdiv(W, kSwCols) * cdiv(H, 10) * (Cout / 64);
+  if (fits[0] && wg0 >= 384) return 0;
+  if (fits[1] && wg0 >= 128) return 1;
+  if (fits[2] && (long)cdiv(W, kSwCols) * cdiv(H, 5) * (Cout / 32) <= 640) return 2;
+  if (fits[0] && wg0 >= 128) return 0;
+  return fits[0] && wg0 >= 64 ? 0 : 3;
+}
+
+template <int MODE>
+static int conv3x3_sw(mnc_ctx* ctx, const char* name, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out_pk,
+                      float* d_out_f32, int H, int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && (d_out_pk || d_out_f32), "%s: null pointer", name);
+  MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "%s: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", name, H, W, Cin, Cout);
+  MNC_REQUIRE((double)H * W * Cin * (sw_pixb(MODE) / 8) < 2.0e9 && (double)H * W * Cout * 4 < 8.0e9,
+              "%s: the input tensor must stay below 2 GB (32-bit copy offsets)", name);
+  const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
+  const double ib = MODE == 0 ? 4.0 : 2.0;
+  const double bytes = (double)H * W * (Cin * ib + Cout * ((d_out_pk ? ib : 0.0) + (d_out_f32 ? 4.0 : 0.0))) + 4.0 * 9.0 * Cin * Cout;
+  LaunchScope ls(ctx, name, flops, bytes);
+  int rc;
+  switch (sw_plan(ctx, H, W, Cin, Cout)) {
+    case 0: rc = launch_sw<MODE, 5, 2, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+    case 1: rc = launch_sw<MODE, 5, 2, 2, 2>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+    case 2: rc = launch_sw<MODE, 5, 1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+    default: rc = launch_sw<MODE, 5, 1, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+  }
+  if (rc) return rc;
+  return ls.finish("conv3x3_sw_kernel");
+}
+
+}  // namespace mnc
+
+using namespace mnc;
+
+extern "C" {
+
+size_t mnc_conv3x3_lowp_weight_bytes(int mode, int Cout, int Cin) {
+  if (mode < 0 || mode > 2 || Cout <= 0 || Cin <= 0) return 0;
+  return (size_t)((Cin + 15) / 16) * (size_t)((Cout + 31) / 32) * sw_planes(mode) * kSwPlaneB;
+}
+
+int mnc_pack_conv3x3_lowp(mnc_ctx* ctx, int mode, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  MNC_REQUIRE(ctx && d_oihw && d_packed && mode >= 0 && mode <= 2 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
+              "mnc_pack_conv3x3_lowp: bad argument");
+  LaunchScope ls(ctx, "pack_conv3x3_lowp");
+  const long total = (long)((Cin + 15) / 16) * (Cout / 32) * sw_planes(mode) * 9 * 32;
+  auto kern = mode == 0 ? pack_conv_sw_kernel<0> : mode == 1 ? pack_conv_sw_kernel<1> : pack_conv_sw_kernel<2>;
+  hipLaunchKernelGGL(kern, dim3(sw_grid_for(total)), dim3(256), 0, ctx->stream, d_oihw, (uint4*)d_packed, Cout, Cin);
+  return ls.finish("pack_conv_sw_kernel");
+}
+
+int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias, void* d_out_packed,
+                     float* d_out_c8, int H, int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(mode >= 0 && mode <= 2, "mnc_conv3x3_lowp: mode must be 0 (bf16x3), 1 (f16) or 2 (bf16)");
+  if (mode == 0) return conv3x3_sw<0>(ctx, "conv3x3_bf16x3", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
+  if (mode == 1) return conv3x3_sw<1>(ctx, "conv3x3_f16", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
+  return conv3x3_sw<2>(ctx, "conv3x3_bf16", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
+}
+
+}  // extern "C"

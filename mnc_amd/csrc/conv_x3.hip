@@ -653,7 +653,10 @@ __global__ void unpack_act_kernel(const unsigned* __restrict__ in, float4* __res
     const long pix = i >> 1;
     const int kb = (int)(i & 1);
     float4 v;
-    if (F16) {
+    if (F16 == 2) {
+      const uint2 h = *reinterpret_cast<const uint2*>(in + pix * 4 + kb * 2);
+      v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xFFFF0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xFFFF0000u));
+    } else if (F16) {
       typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
       const f16x4 h = __builtin_bit_cast(f16x4, *reinterpret_cast<const uint2*>(in + pix * 4 + kb * 2));
       v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
@@ -797,7 +800,8 @@ int mnc_maxpool2_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int 
 int mnc_act_pack(mnc_ctx* ctx, const float* d_c8, void* d_packed, size_t n, int f16) {
   MNC_REQUIRE(ctx && d_c8 && d_packed && n > 0 && n % 8 == 0, "mnc_act_pack: bad argument");
   LaunchScope ls(ctx, "act_pack", 0.0, (f16 ? 6.0 : 8.0) * n);
-  if (f16) hipLaunchKernelGGL(pack_act_kernel<1>, dim3(x3_grid_for((long)(n / 8))), dim3(256), 0, ctx->stream, (const float4*)d_c8, d_packed, (long)(n / 8));
+  if (f16 == 2) hipLaunchKernelGGL(pack_act_kernel<2>, dim3(x3_grid_for((long)(n / 8))), dim3(256), 0, ctx->stream, (const float4*)d_c8, d_packed, (long)(n / 8));
+  else if (f16) hipLaunchKernelGGL(pack_act_kernel<1>, dim3(x3_grid_for((long)(n / 8))), dim3(256), 0, ctx->stream, (const float4*)d_c8, d_packed, (long)(n / 8));
   else hipLaunchKernelGGL(pack_act_kernel<0>, dim3(x3_grid_for((long)(n / 8))), dim3(256), 0, ctx->stream, (const float4*)d_c8, d_packed, (long)(n / 8));
   return ls.finish("pack_act_kernel");
 }
@@ -805,7 +809,8 @@ int mnc_act_pack(mnc_ctx* ctx, const float* d_c8, void* d_packed, size_t n, int 
 int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size_t n, int f16) {
   MNC_REQUIRE(ctx && d_c8 && d_packed && n > 0 && n % 8 == 0, "mnc_act_unpack: bad argument");
   LaunchScope ls(ctx, "act_unpack", 0.0, (f16 ? 6.0 : 8.0) * n);
-  if (f16) hipLaunchKernelGGL(unpack_act_kernel<1>, dim3(x3_grid_for((long)(n / 4))), dim3(256), 0, ctx->stream, (const unsigned*)d_packed, (float4*)d_c8, (long)(n / 4));
+  if (f16 == 2) hipLaunchKernelGGL(unpack_act_kernel<2>, dim3(x3_grid_for((long)(n / 4))), dim3(256), 0, ctx->stream, (const unsigned*)d_packed, (float4*)d_c8, (long)(n / 4));
+  else if (f16) hipLaunchKernelGGL(unpack_act_kernel<1>, dim3(x3_grid_for((long)(n / 4))), dim3(256), 0, ctx->stream, (const unsigned*)d_packed, (float4*)d_c8, (long)(n / 4));
   else hipLaunchKernelGGL(unpack_act_kernel<0>, dim3(x3_grid_for((long)(n / 4))), dim3(256), 0, ctx->stream, (const unsigned*)d_packed, (float4*)d_c8, (long)(n / 4));
   return ls.finish("unpack_act_kernel");
 }

@@ -58,12 +58,23 @@ __device__ __forceinline__ void x3_split8_rne(const float* x, uint4& hi, uint4& 
   lo = make_uint4(x3_pack_hi16(l[0], l[1]), x3_pack_hi16(l[2], l[3]), x3_pack_hi16(l[4], l[5]), x3_pack_hi16(l[6], l[7]));
 }
 
+// Plain bf16 ("bf16" math mode, round 4: BASELINE configs[2] as written -- ONE bf16 product per term): four fp32 values rounded to
+// nearest-even bf16 and packed (v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ uint2 x3_bf16x4(const float4 v) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const bf16x4 hv = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  return __builtin_bit_cast(uint2, hv);
+}
+
 // 4 consecutive channels (channel-block half kb) of pixel `pix` of a c8 plane set, in the activation format of the math mode:
-// fp32 [..][8] float | packed bf16x3 [..][hi x8 | lo x8] (the x3_split of the value) | packed f16 [..][8] fp16 (nearest even)
+// fp32 [..][8] float | packed bf16x3 [..][hi x8 | lo x8] (the x3_split of the value) | packed f16 [..][8] fp16 (nearest even) |
+// F16 == 2: packed bf16 [..][8] bf16 (nearest even)
 template <int F16, bool PACKED>
 __device__ __forceinline__ void x3_store4(void* out, long pix, int kb, const float4 v) {
   if (!PACKED) {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + pix * 8 + kb * 4) = v;
+  } else if (F16 == 2) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(out) + pix * 4 + kb * 2) = x3_bf16x4(v);
   } else if (F16) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const f16x4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
@@ -91,7 +102,7 @@ __device__ __forceinline__ void x3_store8(void* out, long pix, const float4 a, c
     p[0] = a;
     p[1] = b;
   } else if (F16) {
-    const uint2 lo = x3_f16x4(a), hi = x3_f16x4(b);
+    const uint2 lo = F16 == 2 ? x3_bf16x4(a) : x3_f16x4(a), hi = F16 == 2 ? x3_bf16x4(b) : x3_f16x4(b);
     reinterpret_cast<uint4*>(out)[pix] = make_uint4(lo.x, lo.y, hi.x, hi.y);
   } else {
     uint2 ah, al, bh, bl;
@@ -104,14 +115,6 @@ __device__ __forceinline__ void x3_store8(void* out, long pix, const float4 a, c
 }
 
 __device__ __forceinline__ f16x8 x3_as_f16x8(const uint4 v) { return __builtin_bit_cast(f16x8, v); }
-
-// Plain bf16 ("bf16" math mode, round 4: BASELINE configs[2] as written -- ONE bf16 product per term): four fp32 values rounded to
-// nearest-even bf16 and packed (v_cvt_pk_bf16_f32 on gfx950).
-__device__ __forceinline__ uint2 x3_bf16x4(const float4 v) {
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-  const bf16x4 hv = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-  return __builtin_bit_cast(uint2, hv);
-}
 
 __device__ __forceinline__ bf16x8 x3_as_bf16x8(const uint4 v) {
   union { uint4 u; bf16x8 b; } c;

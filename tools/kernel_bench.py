@@ -52,8 +52,9 @@ def records(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convwino", "convwino4", "fc", "fcx3", "fcf16", "conv1x1"])
+    ap.add_argument("what", choices=["conv", "convx3", "convf16", "convsw", "convwino", "convwino4", "fc", "fcx3", "fcf16", "conv1x1"])
     ap.add_argument("--f16", action="store_true", help="conv1x1: packed fp16 tensors (mnc_conv1x1_f16_pk) instead of fp32")
+    ap.add_argument("--mode", default="f16", help="convsw: bf16x3 | f16 | bf16 (mnc_conv3x3_lowp, packed tensors)")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None)
     ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
@@ -122,6 +123,36 @@ def main():
             print("all 1x1 layers of the trunk (%s): gemm %.3f ms = %.1f TF/s, %.2f TB/s algorithmic | general %.3f ms = %.1f TF/s"
                   % ("f16, packed tensors" if args.f16 else "fp32", tot_new, tot_fl / tot_new / 1e9, tot_by / tot_new / 1e9,
                      tot_old, tot_fl / tot_old / 1e9))
+    elif args.what == "convsw":
+        from mnc_amd import _lib
+        m = {"bf16x3": 0, "f16": 1, "bf16": 2}[args.mode]
+        for name, H, W, Cin, Cout in CONV:
+            if args.only and args.only not in name:
+                continue
+            xf = dev.put(np.maximum(rng.normal(size=(Cin * H * W,)), 0).astype(np.float32) if args.relu_input else
+                         rng.normal(size=(Cin * H * W,)).astype(np.float32))
+            x = dev.empty((Cin * H * W,))
+            dev.call("mnc_act_pack", xf, x, Cin * H * W, m)
+            b = dev.put(np.zeros(Cout, np.float32))
+            y = dev.empty((Cout * H * W,))
+            raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
+            w = dev.empty((_lib.load().mnc_conv3x3_lowp_weight_bytes(m, Cout, Cin) // 4,))
+            dev.call("mnc_pack_conv3x3_lowp", m, raw, w, Cout, Cin)
+            for _ in range(3):
+                dev.call("mnc_conv3x3_lowp", m, x, w, b, y, None, H, W, Cin, Cout, 1)
+            dev.call("mnc_prof_reset")
+            for _ in range(args.reps):
+                dev.call("mnc_conv3x3_lowp", m, x, w, b, y, None, H, W, Cin, Cout, 1)
+            t = np.array([r[1] for r in records(dev) if r[0].startswith("conv3x3")])
+            fl = 2.0 * H * W * 9 * Cin * Cout
+            print("%-10s %4dx%-4d %3d->%-3d  med %.1f us  min %.1f us  %.1f TF/s (med)  %.1f TF/s (best)" %
+                  (name, H, W, Cin, Cout, 1e3 * np.median(t), 1e3 * t.min(), fl / np.median(t) / 1e9, fl / t.min() / 1e9),
+                  flush=True)
+            mult = {"conv2_2": 1, "conv3_2": 2, "conv4_2": 2, "conv5_1": 4}.get(name, 1)
+            total_ms += mult * np.median(t)
+            total_fl += mult * fl
+        if not args.only:
+            print("trunk(12 layers)+rpn, %s: %.3f ms, %.1f TF/s" % (args.mode, total_ms, total_fl / total_ms / 1e9))
     elif args.what in ("conv", "convx3", "convf16", "convwino", "convwino4"):
         for name, H, W, Cin, Cout in CONV:
             if args.only and args.only not in name:
