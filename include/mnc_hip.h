@@ -249,9 +249,9 @@ MNC_API int mnc_conv3x3_c3(mnc_ctx* ctx, const float* d_in_nchw, const float* d_
 MNC_API int mnc_conv3x3(mnc_ctx* ctx, const float* d_in_c8, const float* d_w_packed, const float* d_bias,
                         float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
 /* The same convolution on the bf16 matrix pipe with fp32-class accuracy ("bf16x3", see mnc_fc_bf16x3 and
- * mnc_amd/csrc/conv_x3.hip; BASELINE.json configs[2] "bf16 convs via MFMA").  Activations stay fp32 c8 in and out;
- * d_w_packed comes from mnc_pack_conv3x3_bf16x3: Caffe [Cout][Cin][3][3] fp32 -> [Cin/8][Cout][84 dwords]
- * (10 tap slots x (hi x8 | lo x8) bf16 + 16 B pad; Cin/8*Cout*336 bytes).  Cin%8==0, Cout%32==0. */
+ * mnc_amd/csrc/conv_sw.hip; BASELINE.json configs[2] "bf16 convs via MFMA").  Activations fp32 c8 in and out at this entry point
+ * (packed forms: "Reduced-precision 3x3 convolutions" below); d_w_packed comes from mnc_pack_conv3x3_bf16x3 =
+ * mnc_pack_conv3x3_lowp(mode 0), mnc_conv3x3_lowp_weight_bytes(0, Cout, Cin) bytes.  Cin%8==0, Cout%32==0. */
 MNC_API int mnc_pack_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias,
                                float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
@@ -397,48 +397,52 @@ MNC_API int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, cons
 MNC_API int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K);
 MNC_API int mnc_fc_bf16x3(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M,
                           int N, int K, int ldc, int act);
-/* "f16" math mode, 3x3 convolution: one fp16 product per term on v_mfma_f32_32x32x16_f16 (activations rounded to fp16 while
- * staged, fp32 accumulate).  mnc_pack_conv3x3_f16 writes [ceil(Cin/16)][Cout][76 dwords]: 9 taps x 16 channels fp16 + 16 B
- * pad, channels past Cin zero (at most the (Cin/8)*Cout*84 dwords of the bf16x3 layout: one buffer size serves both). */
+/* Reduced-precision 3x3 convolutions (round 6: csrc/conv_sw.hip -- sliding-window implicit GEMM on 2-byte activation planes, every
+ * operand by LDS-DMA, K ranges summed inside the workgroup; models/VGG16/mnc_5stage/test.prototxt:41-412).  mode: 0 = bf16x3 (split
+ * precision, above), 1 = f16 (one fp16 product per term on v_mfma_f32_32x32x16_f16, operands rounded to nearest even, fp32
+ * accumulation), 2 = bf16 (the same with bf16: BASELINE configs[2] "bf16 convs via MFMA" as written; ~4e-3 of a layer's range per
+ * layer, measured and recorded, outside the 1e-3 bar -- bf16x3 is the bf16-pipe mode that keeps it).
+ * Packed weights: mnc_pack_conv3x3_lowp (and the per-mode names of rounds 1-5, which call it) writes
+ *   [ceil(Cin/16)][Cout/32][planes][9 taps][32 channels] x 16 B (8 two-byte values)
+ * planes = the two 8-channel halves of the 16-channel block (f16 / bf16), or hi of each half then lo of each half (bf16x3: hi =
+ * rne(w), lo = rne(w - hi)); channels past Cin are zero.  mnc_conv3x3_lowp_weight_bytes(mode, Cout, Cin) is the buffer's size:
+ * ceil(Cin/16) * (Cout/32) * (mode == 0 ? 4 : 2) * 4608 bytes.
+ * Packed 2-byte activations between MFMA layers.  A c8 tensor [C/8][H][W][8] is kept as
+ *   bf16x3:  [C/8][H][W][hi x8 | lo x8] bf16 -- the split the kernels apply to an fp32 value (hi = truncation, lo = the
+ *            remainder rounded half-up), two 2-byte planes interleaved per pixel, 32 B per pixel and channel block;
+ *   f16:     [C/8][H][W][8] fp16 (round to nearest even), 16 B per pixel and channel block;
+ *   bf16:    [C/8][H][W][8] bf16 (round to nearest even), 16 B (round 6).
+ * The convolution multiplies PACKED inputs; an fp32 c8 input (in_packed = 0, and the fp32-tensor entry points) is packed into the
+ * context's scratch arena first.  A producer's epilogue applies exactly that packing to its fp32 result, so a packed chain gives bit
+ * for bit the results of the fp32-tensor chain (test.prototxt:41-412 is such a chain: conv1_1 .. conv5_3 with four MAX 2x2/2 pools).
+ * mnc_conv3x3_lowp writes d_out_packed and / or d_out_c8 (fp32 c8); a null one is not written (conv5_3 feeds the RPN convolution
+ * packed and the RoI warps in fp32: test.prototxt:395-424, 479-492).  The *_pk forms select one format per side.
+ * mnc_maxpool2_c8_{bf16x3,f16,bf16}: Pooling MAX 2x2/2 (ceil output size) on the packed form; mnc_act_pack / mnc_act_unpack:
+ * fp32 c8 <-> packed, n = element count (multiple of 8), f16 = the mode number (0 bf16x3, 1 f16, 2 bf16). */
+MNC_API size_t mnc_conv3x3_lowp_weight_bytes(int mode, int Cout, int Cin);
+MNC_API int mnc_pack_conv3x3_lowp(mnc_ctx* ctx, int mode, const float* d_oihw, void* d_packed, int Cout, int Cin);
+MNC_API int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias,
+                             void* d_out_packed, float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
 MNC_API int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
-/* Plain bf16 (round 4; BASELINE configs[2] "bf16 convs via MFMA" as written): the fp16 kernel and layout with both operands rounded
- * to nearest-even bf16 instead -- ONE v_mfma_f32_32x32x16_bf16 per term, fp32 accumulation, fp32 c8 tensors in and out.  ~4e-3 of
- * a layer's range per layer (8 mantissa bits): measured and recorded, outside the 1e-3 bar; bf16x3 is the bf16-pipe mode that keeps it. */
 MNC_API int mnc_pack_conv3x3_bf16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_bf16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,
                              int H, int W, int Cin, int Cout, int relu);
 MNC_API int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,
                             int H, int W, int Cin, int Cout, int relu);
-/* Packed 2-byte activations between MFMA layers (bf16x3 and f16 math modes).  A c8 tensor [C/8][H][W][8] is kept as
- *   bf16x3:  [C/8][H][W][hi x8 | lo x8] bf16 -- the split the kernels apply to an fp32 value (hi = truncation, lo = the
- *            remainder rounded half-up), two 2-byte planes interleaved per pixel, 32 B per pixel and channel block;
- *   f16:     [C/8][H][W][8] fp16 (round to nearest even), 16 B per pixel and channel block.
- * A producer (in_packed / out_packed select the format of each side) applies in its epilogue exactly what the consumer's
- * staging would apply to the fp32 value, so a packed chain gives bit for bit the results of the fp32-tensor chain
- * (models/VGG16/mnc_5stage/test.prototxt:41-412 is such a chain: conv1_1 .. conv5_3 with four MAX 2x2/2 pools).
- * mnc_maxpool2_c8_{bf16x3,f16}: Pooling MAX 2x2/2 (ceil output size) on the packed form; mnc_act_pack / mnc_act_unpack:
- * fp32 c8 <-> packed, n = element count (multiple of 8), f16 = 0 for the bf16x3 form. */
 MNC_API int mnc_conv3x3_bf16x3_pk(mnc_ctx* ctx, const void* d_in, const void* d_w_packed, const float* d_bias, void* d_out,
                                   int H, int W, int Cin, int Cout, int relu, int in_packed, int out_packed);
 MNC_API int mnc_conv3x3_f16_pk(mnc_ctx* ctx, const void* d_in, const void* d_w_packed, const float* d_bias, void* d_out,
                                int H, int W, int Cin, int Cout, int relu, int in_packed, int out_packed);
-/* conv1_1 (mnc_conv3x3_c3) writing the packed form: out_fmt 0 = fp32 c8, 1 = bf16x3 packed, 2 = fp16 packed */
+MNC_API int mnc_conv3x3_bf16_pk(mnc_ctx* ctx, const void* d_in, const void* d_w_packed, const float* d_bias, void* d_out,
+                                int H, int W, int Cin, int Cout, int relu, int in_packed, int out_packed);
+/* conv1_1 (mnc_conv3x3_c3) writing the packed form: out_fmt 0 = fp32 c8, 1 = bf16x3 packed, 2 = fp16 packed, 3 = bf16 packed */
 MNC_API int mnc_conv3x3_c3_fmt(mnc_ctx* ctx, const float* d_in_nchw, const float* d_w_oihw, const float* d_bias, void* d_out,
                                int H, int W, int Cout, int relu, int out_fmt);
 MNC_API int mnc_maxpool2_c8_bf16x3(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W);
 MNC_API int mnc_maxpool2_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W);
+MNC_API int mnc_maxpool2_c8_bf16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W);
 MNC_API int mnc_act_pack(mnc_ctx* ctx, const float* d_c8, void* d_packed, size_t n, int f16);
 MNC_API int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size_t n, int f16);
-/* Round 6: the reduced-precision 3x3 convolution on PACKED activations (csrc/conv_sw.hip: sliding-window implicit GEMM, every
- * operand by LDS-DMA, K ranges summed inside the workgroup).  mode: 0 = bf16x3, 1 = f16, 2 = bf16 (packed bf16 tensors have the
- * f16 form with bf16 values, mnc_act_pack's f16 = 2).  mnc_pack_conv3x3_lowp writes [ceil(Cin/16)][Cout/32][planes][9 taps][32] x
- * 16 B (planes: the two 8-channel halves of the block; bf16x3: hi of each half, then lo of each half);
- * mnc_conv3x3_lowp_weight_bytes is that buffer's size.  d_out_packed and / or d_out_c8 (fp32 c8) are written, a null one is not
- * (conv5_3 feeds the RPN convolution packed and the RoI warps in fp32: test.prototxt:395-424, 479-492). */
-MNC_API size_t mnc_conv3x3_lowp_weight_bytes(int mode, int Cout, int Cin);
-MNC_API int mnc_pack_conv3x3_lowp(mnc_ctx* ctx, int mode, const float* d_oihw, void* d_packed, int Cout, int Cin);
-MNC_API int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias,
-                             void* d_out_packed, float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
 /* "f16" math mode (BASELINE.json configs[4] names fp16): InnerProduct with both operands rounded to IEEE fp16 (nearest even)
  * and fp32 accumulation on v_mfma_f32_32x32x16_f16 -- one product per term, 2 bytes per value streamed instead of 4.
  * mnc_pack_fc_f16: Caffe weight [N][K] -> [ceil(N/128)][K/64][128][64] halves (bytes: ceil(N/128)*128*K*2), once at load.

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 // ---- conv1_1: Cin = 3 (K = 27): HBM-bound (154 MB written at 600x1000), VALU.  One thread = one pixel: its 27 inputs are
 // loaded once into registers and all Cout channels are produced from them, 8 at a time, with the weights read from LDS at
 // wave-uniform addresses (broadcast reads).  A wave writes 64 pixels x 32 B contiguous per channel block.
-// OUT: 0 = fp32 c8, 1 = packed bf16x3 (hi x8 | lo x8), 2 = packed fp16 -- the activation formats of conv_x3.hip
+// OUT: 0 = fp32 c8, 1 = packed bf16x3 (hi x8 | lo x8), 2 = packed fp16, 3 = packed bf16 -- the activation formats of conv_sw.hip
 template <int OUT>
 __global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                          const float* __restrict__ bias, void* __restrict__ out, int H,
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_c3_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
       }
-      x3_store8<OUT == 2, OUT != 0>(out, (long)cb * hw + pix, make_float4(acc[0], acc[1], acc[2], acc[3]),
+      x3_store8<(OUT == 2 ? 1 : OUT == 3 ? 2 : 0), OUT != 0>(out, (long)cb * hw + pix, make_float4(acc[0], acc[1], acc[2], acc[3]),
                                     make_float4(acc[4], acc[5], acc[6], acc[7]));
     }
   }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(const float* __res
   // output: fp32 c8 / split-bf16 pixels are 32 bytes per 8-channel block (the lane's 4 channels: 16 bytes at half g & 1; split form:
   // 8 bytes of hi at g & 1, 8 of lo 16 bytes behind), fp16 pixels 16 bytes (8 at g & 1); channels 16 t + 4 g .. : block 2 t + g / 2
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  constexpr int kPB = OUT == 2 ? 16 : 32;
+  constexpr int kPB = OUT >= 2 ? 16 : 32;
   const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, 2 * NT * (int)hw * kPB, 0x00020000);
   const int lane_plane = (g >> 1) * (int)hw * kPB + (g & 1) * (OUT == 0 ? 16 : 8);
   float cur[7], nxt[7];
@@ -395,6 +395,8 @@ __global__ __launch_bounds__(256) void conv3x3_c3_mfma_kernel(const float* __res
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mnc_u32x4, o), ors, voff, soff, 0);
       } else if (OUT == 2) {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x3_f16x4(o)), ors, voff, soff, 0);
+      } else if (OUT == 3) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x3_bf16x4(o)), ors, voff, soff, 0);
       } else {
         uint2 hi, lo;
         x3_split4(o, hi, lo);
@@ -691,15 +693,15 @@ int mnc_conv3x3_c3_fmt(mnc_ctx* ctx, const float* d_in, const float* d_w, const 
                        int Cout, int relu, int out_fmt) {
   MNC_REQUIRE(ctx && d_in && d_w && d_bias && d_out, "mnc_conv3x3_c3: null pointer");
   MNC_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0 && Cout <= 512, "mnc_conv3x3_c3: unsupported shape");
-  MNC_REQUIRE(out_fmt >= 0 && out_fmt <= 2, "mnc_conv3x3_c3: out_fmt must be 0 (fp32), 1 (bf16x3 packed) or 2 (fp16 packed)");
-  const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + (out_fmt == 2 ? 0.5 : 1.0) * Cout);
+  MNC_REQUIRE(out_fmt >= 0 && out_fmt <= 3, "mnc_conv3x3_c3: out_fmt must be 0 (fp32), 1 (bf16x3 packed), 2 (fp16 packed) or 3 (bf16 packed)");
+  const double flops = 2.0 * H * W * 27.0 * Cout, bytes = 4.0 * H * W * (3.0 + (out_fmt >= 2 ? 0.5 : 1.0) * Cout);
   LaunchScope ls(ctx, "conv3x3_c3", flops, bytes);
   // Cout a multiple of 16 up to 64 (VGG-16: 64): the matrix-pipe kernel; other widths: the VALU kernel.  CONV_COT=-1 forces the latter.
   if (Cout % 16 == 0 && Cout <= 64 && (long)H * W * Cout * 4 < 0x7FFFFFF0L && tune(ctx, T_CONV_COT, 0) != -1) {
     const int ntiles = cdiv((long)H * W, 16);
     typedef void (*c3_fn)(const float*, const float*, const float*, void*, int, int, int, int);
 #define MNC_C3(F) {conv3x3_c3_mfma_kernel<F, 1>, conv3x3_c3_mfma_kernel<F, 2>, conv3x3_c3_mfma_kernel<F, 3>, conv3x3_c3_mfma_kernel<F, 4>}
-    static const c3_fn table[3][4] = {MNC_C3(0), MNC_C3(1), MNC_C3(2)};
+    static const c3_fn table[4][4] = {MNC_C3(0), MNC_C3(1), MNC_C3(2), MNC_C3(3)};
 #undef MNC_C3
     const c3_fn kern = table[out_fmt][Cout / 16 - 1];
     // three blocks per CU, each wave walking ~12 tiles: a wave's 28 weight gathers are paid once (grid cap 512 / 768 / 1024 / 2048 /
@@ -709,7 +711,7 @@ int mnc_conv3x3_c3_fmt(mnc_ctx* ctx, const float* d_in, const float* d_w, const 
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, ctx->stream, d_in, d_w, d_bias, d_out, H, W, relu, ntiles);
     return ls.finish("conv3x3_c3_mfma_kernel");
   }
-  auto kern = out_fmt == 0 ? conv3x3_c3_kernel<0> : (out_fmt == 1 ? conv3x3_c3_kernel<1> : conv3x3_c3_kernel<2>);
+  auto kern = out_fmt == 0 ? conv3x3_c3_kernel<0> : out_fmt == 1 ? conv3x3_c3_kernel<1> : out_fmt == 2 ? conv3x3_c3_kernel<2> : conv3x3_c3_kernel<3>;
   hipLaunchKernelGGL(kern, dim3(grid_for((long)H * W)), dim3(256), (size_t)(28 * Cout) * 4, ctx->stream, d_in, d_w, d_bias, d_out,
                      H, W, Cout, relu);
   return ls.finish("conv3x3_c3_kernel");

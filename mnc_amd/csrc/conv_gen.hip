@@ -1,6 +1,6 @@
 // General convolution / pooling / residual kernels for graphs beyond VGG-16 (a ResNet-50 trunk has
 // 1x1, strided and 7x7 convolutions, 3x3/2 max pooling and residual adds; BASELINE.json configs[4]).  First correct path:
-// the stride-1 3x3 layers keep using the tuned kernels of conv.hip / conv_x3.hip; everything else comes through here.
+// the stride-1 3x3 layers keep using the tuned kernels of conv.hip / conv_sw.hip; everything else comes through here.
 //
 //   conv2d_c8_kernel   any KHxKW / stride / pad, c8 -> c8, fp32 MFMA implicit GEMM (v_mfma_f32_32x32x2_f32):
 //                      M = output channels (A = weights), N = output pixels (B = gathered input pixels), K = taps x Cin walked

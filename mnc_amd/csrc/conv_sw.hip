@@ -37,6 +37,13 @@
 #include "mnc_internal.h"
 #include "x3_split.h"
 
+// Tuning ablations (never set in a product build; wrong results): 1 = no copies inside the loop, 2 = no fragment reads (MFMAs on
+// register constants), 4 = no output stores, 8 = the copies inside the loop carry only out-of-range lanes,
+// 16 / 32 = every pass copies the first chunk's weights / halo again (cache hits)
+#ifndef MNC_SW_ABL
+#define MNC_SW_ABL 0
+#endif
+
 namespace mnc {
 
 typedef float sw_f32x16 __attribute__((ext_vector_type(16)));
@@ -129,38 +136,41 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
   }
   const int va0 = j * 16, va1 = j * 16 + kb * kSwPlaneB;
 
-  // pass v of chunk c -> buffer `buf` of this K range
-  auto dma = [&](int c, auto pass_, int buf) {
+  // Copy slot k (of NS per wave and pass) of pass `pass` of chunk c -> buffer `buf` of this K range.  live == false (behind the
+  // last pass): every lane out of range -- zeros into the free buffer, no memory traffic, the loop body stays one basic block.
+  constexpr int NS = G::NAS + G::NBS;
+  auto dma_slot = [&](int c, auto pass_, int buf, int k, bool more) {
     constexpr int pass = decltype(pass_)::value;
+    if (MNC_SW_ABL & 1) return;
+    if (MNC_SW_ABL & 8) more = false;                          // copies issued, every lane out of range: issue cost without traffic
     const sw_i32x4 wr = w_rsrc, ir = in_rsrc;                  // (named here: a generic lambda does not capture what only an asm operand uses)
     const unsigned base = lds0 + (unsigned)(kwbase + buf * G::BUFB);
-    // weights: plane pair of the pass = (h0, h0) | (h1, h1) | (l0, l1) in x3, (k half 0, k half 1) otherwise
-    constexpr int a_plane0 = MODE == 0 ? (pass == 2 ? 2 : pass) : 0;
-    constexpr bool a_two = MODE != 0 || pass == 2;
-    const int a_chunk = (c * ncot + cot0) * (NPL * kSwPlaneB) + a_plane0 * kSwPlaneB;
-#pragma unroll
-    for (int i = 0; i < G::NAS; ++i) {
-      const int pa = wl + G::NWG * i;
+    if (k < G::NAS) {
+      // weights: plane pair of the pass = (h0, h0) | (h1, h1) | (l0, l1) in x3, (k half 0, k half 1) otherwise
+      constexpr int a_plane0 = MODE == 0 ? (pass == 2 ? 2 : pass) : 0;
+      constexpr bool a_two = MODE != 0 || pass == 2;
+      const int pa = wl + G::NWG * k;
       const bool live = pa < 9 * CG;
       const int cgi = pa / 9, tap = pa - cgi * 9;
-      const int so = __builtin_amdgcn_readfirstlane(a_chunk + cgi * (NPL * kSwPlaneB) + tap * kSwTapB);
+      const int ca = (MNC_SW_ABL & 16) ? c_begin : c;          // ablation: the same weight panel every pass (L2 hits)
+      const int so = __builtin_amdgcn_readfirstlane(((ca * ncot + cot0 + cgi) * NPL + a_plane0) * kSwPlaneB + tap * kSwTapB);
       const unsigned l = __builtin_amdgcn_readfirstlane(live ? base + (unsigned)pa * 1024u : lds0 + (unsigned)G::DUMMY);
-      const int vo = live ? (a_two ? va1 : va0) : kSwOOB;
+      const int vo = (live && more) ? (a_two ? va1 : va0) : kSwOOB;
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(wr), "s"(so), "s"(l) : "memory");
-    }
-    // halo: block and 16-byte half of the pixel record per k half.  x3: pass 0 (2c: hi | lo), pass 1 (2c + 1: hi | lo),
-    // pass 2 (hi of 2c | hi of 2c + 1); otherwise (2c | 2c + 1).  A block past the input's last (odd block count) reads as zeros.
-#pragma unroll
-    for (int i = 0; i < G::NBS; ++i) {
+    } else {
+      // halo: block and 16-byte half of the pixel record per k half.  x3: pass 0 (2c: hi | lo), pass 1 (2c + 1: hi | lo),
+      // pass 2 (hi of 2c | hi of 2c + 1); otherwise (2c | 2c + 1).  A block past the input's last (odd block count) reads as zeros.
+      const int i = k - G::NAS;
       const int pb = wl + G::NWG * i;
       const bool live = pb < 2 * G::PP;
       const int kbp = pb / G::PP;
       int blk, half;
-      if (MODE == 0 && pass < 2) { blk = 2 * c + pass; half = kbp; }
-      else { blk = 2 * c + kbp; half = 0; }
+      const int ch = (MNC_SW_ABL & 32) ? c_begin : c;          // ablation: the same halo every pass
+      if (MODE == 0 && pass < 2) { blk = 2 * ch + pass; half = kbp; }
+      else { blk = 2 * ch + kbp; half = 0; }
       const int so = __builtin_amdgcn_readfirstlane(min(blk, nblk - 1) * blk_bytes + half * 16);
       const unsigned l = __builtin_amdgcn_readfirstlane(live ? base + (unsigned)(G::AB + pb * 1024) : lds0 + (unsigned)G::DUMMY);
-      const int vo = (live && blk < nblk) ? vb[i] : kSwOOB;
+      const int vo = (live && more && blk < nblk) ? vb[i] : kSwOOB;
       asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(ir), "s"(so), "s"(l) : "memory");
     }
   };
@@ -176,49 +186,62 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
     if constexpr (MODE == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x3_as_f16x8(a), x3_as_f16x8(b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3_as_bf16x8(a), x3_as_bf16x8(b), c, 0, 0, 0);
   };
-  // one pass out of buffer `buf`: halo row hr, column shift dx is tap (dy, dx) of output row hr - dy
-  auto compute = [&](int buf) {
+  auto opaque = [](uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+  // One pass out of buffer `buf`: halo row hr, column shift dx is tap (dy, dx) of output row hr - dy.  The NS copies of the NEXT
+  // pass (`issue(k)`) are spread over the 3 (PR + 2) fragment groups, so that the matrix pipe works off queued MFMAs while the
+  // wave issues a copy.
+  auto compute = [&](int buf, auto&& issue) {
     const unsigned char* pb_ = s_sw + kwbase + buf * G::BUFB;
     const uint4* Ap = reinterpret_cast<const uint4*>(pb_ + cg * 9 * 1024) + lane;
     const uint4* Bp = reinterpret_cast<const uint4*>(pb_ + G::AB + kb * G::PLANEB) + (rg * PR * kSwHC + j);
+    constexpr int NGRP = 3 * (PR + 2);
     uint4 a[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) a[t] = Ap[t * 64];
+    for (int t = 0; t < 9; ++t) {
+      if (MNC_SW_ABL & 2) { a[t] = make_uint4(0x3c003c00u + t, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); opaque(a[t]); }
+      else a[t] = Ap[t * 64];
+    }
+    int k = 0;
 #pragma unroll
     for (int hr = 0; hr < PR + 2; ++hr)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const uint4 b = Bp[hr * kSwHC + dx];
+        uint4 b;
+        if (MNC_SW_ABL & 2) { b = make_uint4(0x3c003c00u + hr, 0x3c003c00u + dx, 0x3c003c00u, 0x3c003c00u); opaque(b); }
+        else b = Bp[hr * kSwHC + dx];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int r = hr - dy;
           if (r >= 0 && r < PR) acc[r] = mfma(a[dy * 3 + dx], b, acc[r]);
         }
+        const int g = hr * 3 + dx;
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+          if (q == k && k * NGRP < (g + 1) * NS) { issue(k); ++k; }
       }
   };
 
   // ---- main loop over the passes of this K range
-  dma(c_begin, std::integral_constant<int, 0>(), 0);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) dma_slot(c_begin, std::integral_constant<int, 0>(), 0, k, true);
   int buf = 0;
   for (int c = c_begin; c < c_end; ++c) {
+    const bool more = c + 1 < c_end;
+    const int cn = more ? c + 1 : c;
     if constexpr (NPASS == 1) {
       MNC_SW_SYNC();
-      if (c + 1 < c_end) dma(c + 1, std::integral_constant<int, 0>(), buf ^ 1);
-      compute(buf);
-      buf ^= 1;
+      compute(buf, [&](int k) { dma_slot(cn, std::integral_constant<int, 0>(), buf ^ 1, k, more); });
     } else {
       MNC_SW_SYNC();
-      dma(c, std::integral_constant<int, 1>(), buf ^ 1);
-      compute(buf);
+      compute(buf, [&](int k) { dma_slot(c, std::integral_constant<int, 1>(), buf ^ 1, k, true); });
       MNC_SW_SYNC();
-      dma(c, std::integral_constant<int, 2>(), buf);
-      compute(buf ^ 1);
+      compute(buf ^ 1, [&](int k) { dma_slot(c, std::integral_constant<int, 2>(), buf, k, true); });
       MNC_SW_SYNC();
-      if (c + 1 < c_end) dma(c + 1, std::integral_constant<int, 0>(), buf ^ 1);
-      compute(buf);
-      buf ^= 1;
+      compute(buf, [&](int k) { dma_slot(cn, std::integral_constant<int, 0>(), buf ^ 1, k, more); });
     }
+    buf ^= 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the last pass's all-out-of-range copies)
 
   // ---- K ranges of the workgroup: ranges 1.. hand their accumulators to range 0 through LDS (summed in range order)
   if constexpr (KW > 1) {
@@ -251,7 +274,7 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
 #pragma unroll
   for (int r = 0; r < PR; ++r) {
     const int oh = h0 + rg * PR + r;
-    if (oh < H && ow < W) {                                  // lanes j and j + 32 (the two channel halves of a pixel) agree
+    if (oh < H && ow < W && (!(MNC_SW_ABL & 4) || relu == 0x7fff)) {             // lanes j and j + 32 (the two channel halves of a pixel) agree
       float4 v[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -354,10 +377,10 @@ static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
 // form every shape fits (Cout % 32 == 0).  CONVX3_TILE = 100 + plan overrides the choice where the plan fits the shape.
 static int sw_plan(const mnc_ctx* ctx, int H, int W, int Cin, int Cout) {
   const int nchunks = (Cin / 8 + 1) / 2;
-  const bool fits[4] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true};
+  const bool fits[6] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true, Cout % 64 == 0, Cout % 128 == 0};
   if (tune_set(ctx, T_CONVX3_TILE)) {
     const int p = tune(ctx, T_CONVX3_TILE, 0) - 100;
-    if (p >= 0 && p < 4 && fits[p]) return p;
+    if (p >= 0 && p < 6 && fits[p]) return p;
   }
   const long wg0 = (long)cdiv(W, kSwCols) * cdiv(H, 10) * (Cout / 64);
   if (fits[0] && wg0 >= 384) return 0;
@@ -384,10 +407,141 @@ static int conv3x3_sw(mnc_ctx* ctx, const char* name, const void* d_in, const vo
     case 0: rc = launch_sw<MODE, 5, 2, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
     case 1: rc = launch_sw<MODE, 5, 2, 2, 2>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
     case 2: rc = launch_sw<MODE, 5, 1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+    case 4: rc = launch_sw<MODE, 5, 4, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+    case 5: rc = launch_sw<MODE, 5, 2, 4, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
     default: rc = launch_sw<MODE, 5, 1, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
   }
   if (rc) return rc;
   return ls.finish("conv3x3_sw_kernel");
+}
+
+// Pooling MAX 2x2/2 (Caffe's ceil output size) on packed activations.  f16 / bf16: the maximum of the rounded values is the rounded
+// maximum (rounding is monotonic).  bf16x3: the window's largest (hi, lo) pair in lexicographic order is copied; x -> (hi, lo)
+// is monotonic for that order (hi truncates toward zero, lo rounds the remainder), so this is the split of the fp32 maximum.
+template <int F16>
+__global__ __launch_bounds__(256) void maxpool2_packed_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int CB, int H,
+                                                              int W, int OH, int OW) {
+  const long total = (long)CB * OH * OW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long p = idx;
+    const int ow = (int)(p % OW);
+    p /= OW;
+    const int oh = (int)(p % OH);
+    const int cb = (int)(p / OH);
+    const int h0 = oh * 2, x0 = ow * 2;
+    const int h1 = min(h0 + 1, H - 1), x1 = min(x0 + 1, W - 1);      // a clipped window repeats its last row / column
+    const long base = (long)cb * H * W;
+    const long q[4] = {base + (long)h0 * W + x0, base + (long)h0 * W + x1, base + (long)h1 * W + x0, base + (long)h1 * W + x1};
+    if (F16 == 2) {                                        // bf16: compare as fp32 (exact widening), keep the upper halves
+      uint4 m = in[q[0]];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const uint4 v = in[q[k]];
+        auto mx = [](unsigned a, unsigned b) {
+          const float lo = fmaxf(__uint_as_float(a << 16), __uint_as_float(b << 16));
+          const float hi = fmaxf(__uint_as_float(a & 0xFFFF0000u), __uint_as_float(b & 0xFFFF0000u));
+          return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+        };
+        m = make_uint4(mx(m.x, v.x), mx(m.y, v.y), mx(m.z, v.z), mx(m.w, v.w));
+      }
+      out[idx] = m;
+    } else if (F16) {
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      h8 m = __builtin_bit_cast(h8, in[q[0]]);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const h8 v = __builtin_bit_cast(h8, in[q[k]]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+      out[idx] = __builtin_bit_cast(uint4, m);
+    } else {
+      unsigned short mh[8], ml[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint4 hi = in[q[k] * 2], lo = in[q[k] * 2 + 1];
+        const unsigned hw_[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned short h = (unsigned short)(hw_[e >> 1] >> ((e & 1) * 16)), l = (unsigned short)(lw[e >> 1] >> ((e & 1) * 16));
+          const float fh = __uint_as_float((unsigned)h << 16), fl = __uint_as_float((unsigned)l << 16);
+          const float gh = __uint_as_float((unsigned)mh[e] << 16), gl = __uint_as_float((unsigned)ml[e] << 16);
+          if (k == 0 || fh > gh || (fh == gh && fl > gl)) { mh[e] = h; ml[e] = l; }
+        }
+      }
+      out[idx * 2] = make_uint4(mh[0] | ((unsigned)mh[1] << 16), mh[2] | ((unsigned)mh[3] << 16), mh[4] | ((unsigned)mh[5] << 16),
+                                mh[6] | ((unsigned)mh[7] << 16));
+      out[idx * 2 + 1] = make_uint4(ml[0] | ((unsigned)ml[1] << 16), ml[2] | ((unsigned)ml[3] << 16),
+                                    ml[4] | ((unsigned)ml[5] << 16), ml[6] | ((unsigned)ml[7] << 16));
+    }
+  }
+}
+
+// fp32 c8 <-> packed (tests, and the boundaries of a packed chain that no producer epilogue covers)
+template <int F16>
+__global__ void pack_act_kernel(const float4* __restrict__ in, void* __restrict__ out, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x)
+    x3_store8<F16, true>(out, i, in[2 * i], in[2 * i + 1]);
+}
+template <int F16>
+__global__ void unpack_act_kernel(const unsigned* __restrict__ in, float4* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i >> 1;
+    const int kb = (int)(i & 1);
+    float4 v;
+    if (F16 == 2) {
+      const uint2 h = *reinterpret_cast<const uint2*>(in + pix * 4 + kb * 2);
+      v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xFFFF0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xFFFF0000u));
+    } else if (F16) {
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      const f16x4 h = __builtin_bit_cast(f16x4, *reinterpret_cast<const uint2*>(in + pix * 4 + kb * 2));
+      v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+      const uint2 hi = *reinterpret_cast<const uint2*>(in + pix * 8 + kb * 2), lo = *reinterpret_cast<const uint2*>(in + pix * 8 + 4 + kb * 2);
+      auto f = [](unsigned w, int k) { return __uint_as_float(k ? (w & 0xFFFF0000u) : (w << 16)); };
+      v = make_float4(f(hi.x, 0) + f(lo.x, 0), f(hi.x, 1) + f(lo.x, 1), f(hi.y, 0) + f(lo.y, 0), f(hi.y, 1) + f(lo.y, 1));
+    }
+    out[i] = v;
+  }
+}
+
+
+// fp32 c8 -> the mode's packed form in the context's scratch arena (an input no producer wrote packed: tests, the fp32-tensor
+// entry points, the Python engine's bf16x3 graph)
+static int sw_pack_input(mnc_ctx* ctx, int mode, const float* d_c8, size_t n, const void** packed) {
+  const size_t bytes = n * (mode == 0 ? 4 : 2);
+  (void)hipSetDevice(ctx->device);
+  int rc = ensure_scratch(ctx, bytes);
+  if (rc) return rc;
+  const long npix = (long)(n / 8);
+  auto kern = mode == 0 ? pack_act_kernel<0> : mode == 1 ? pack_act_kernel<1> : pack_act_kernel<2>;
+  hipLaunchKernelGGL(kern, dim3(sw_grid_for(npix)), dim3(256), 0, ctx->stream, (const float4*)d_c8, ctx->scratch, npix);
+  *packed = ctx->scratch;
+  return MNC_OK;
+}
+
+template <int MODE>
+static int conv3x3_sw_any(mnc_ctx* ctx, const char* name, const void* d_in, int in_packed, const void* d_wpk, const float* d_bias,
+                          void* d_out, int out_packed, int H, int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(ctx && d_in && d_out, "%s: null pointer", name);
+  if (!in_packed) {
+    MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0, "%s: unsupported shape", name);
+    int rc = sw_pack_input(ctx, MODE, (const float*)d_in, (size_t)Cin * H * W, &d_in);
+    if (rc) return rc;
+  }
+  return conv3x3_sw<MODE>(ctx, name, d_in, d_wpk, d_bias, out_packed ? d_out : nullptr, out_packed ? nullptr : (float*)d_out, H, W,
+                          Cin, Cout, relu);
+}
+
+template <int F16>
+static int maxpool2_packed(mnc_ctx* ctx, const char* name, const void* d_in, void* d_out, int C, int H, int W) {
+  MNC_REQUIRE(ctx && d_in && d_out && C > 0 && C % 8 == 0 && H > 0 && W > 0, "%s: bad argument", name);
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const double b = (F16 ? 2.0 : 4.0) * C;
+  LaunchScope ls(ctx, name, 0.0, b * ((double)H * W + (double)OH * OW));
+  hipLaunchKernelGGL(maxpool2_packed_kernel<F16>, dim3(sw_grid_for((long)(C / 8) * OH * OW)), dim3(256), 0, ctx->stream,
+                     (const uint4*)d_in, (uint4*)d_out, C / 8, H, W, OH, OW);
+  return ls.finish("maxpool2_packed_kernel");
 }
 
 }  // namespace mnc
@@ -417,6 +571,70 @@ int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void
   if (mode == 0) return conv3x3_sw<0>(ctx, "conv3x3_bf16x3", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
   if (mode == 1) return conv3x3_sw<1>(ctx, "conv3x3_f16", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
   return conv3x3_sw<2>(ctx, "conv3x3_bf16", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
+}
+
+// ---- the entry points of rounds 1-5, on the round-6 kernel (same names and argument meaning; the packed weight layout and its size
+// are mnc_pack_conv3x3_lowp's).  fp32 inputs are packed into the context's scratch arena first -- the producer's own rounding /
+// split, so the fp32-tensor route and the packed route give the same bits.
+int mnc_pack_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  return mnc_pack_conv3x3_lowp(ctx, 0, d_oihw, d_packed, Cout, Cin);
+}
+int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  return mnc_pack_conv3x3_lowp(ctx, 1, d_oihw, d_packed, Cout, Cin);
+}
+int mnc_pack_conv3x3_bf16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin) {
+  return mnc_pack_conv3x3_lowp(ctx, 2, d_oihw, d_packed, Cout, Cin);
+}
+
+int mnc_conv3x3_bf16x3(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W,
+                       int Cin, int Cout, int relu) {
+  return conv3x3_sw_any<0>(ctx, "conv3x3_bf16x3", d_in, 0, d_wpk, d_bias, d_out, 0, H, W, Cin, Cout, relu);
+}
+int mnc_conv3x3_f16(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                    int Cout, int relu) {
+  return conv3x3_sw_any<1>(ctx, "conv3x3_f16", d_in, 0, d_wpk, d_bias, d_out, 0, H, W, Cin, Cout, relu);
+}
+int mnc_conv3x3_bf16(mnc_ctx* ctx, const float* d_in, const void* d_wpk, const float* d_bias, float* d_out, int H, int W, int Cin,
+                     int Cout, int relu) {
+  return conv3x3_sw_any<2>(ctx, "conv3x3_bf16", d_in, 0, d_wpk, d_bias, d_out, 0, H, W, Cin, Cout, relu);
+}
+int mnc_conv3x3_bf16x3_pk(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out, int H, int W,
+                          int Cin, int Cout, int relu, int in_packed, int out_packed) {
+  return conv3x3_sw_any<0>(ctx, "conv3x3_bf16x3", d_in, in_packed, d_wpk, d_bias, d_out, out_packed, H, W, Cin, Cout, relu);
+}
+int mnc_conv3x3_f16_pk(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out, int H, int W, int Cin,
+                       int Cout, int relu, int in_packed, int out_packed) {
+  return conv3x3_sw_any<1>(ctx, "conv3x3_f16", d_in, in_packed, d_wpk, d_bias, d_out, out_packed, H, W, Cin, Cout, relu);
+}
+int mnc_conv3x3_bf16_pk(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out, int H, int W, int Cin,
+                        int Cout, int relu, int in_packed, int out_packed) {
+  return conv3x3_sw_any<2>(ctx, "conv3x3_bf16", d_in, in_packed, d_wpk, d_bias, d_out, out_packed, H, W, Cin, Cout, relu);
+}
+
+int mnc_maxpool2_c8_bf16x3(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W) {
+  return maxpool2_packed<0>(ctx, "maxpool2_c8_bf16x3", d_in, d_out, C, H, W);
+}
+int mnc_maxpool2_c8_f16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W) {
+  return maxpool2_packed<1>(ctx, "maxpool2_c8_f16", d_in, d_out, C, H, W);
+}
+int mnc_maxpool2_c8_bf16(mnc_ctx* ctx, const void* d_in, void* d_out, int C, int H, int W) {
+  return maxpool2_packed<2>(ctx, "maxpool2_c8_bf16", d_in, d_out, C, H, W);
+}
+
+int mnc_act_pack(mnc_ctx* ctx, const float* d_c8, void* d_packed, size_t n, int f16) {
+  MNC_REQUIRE(ctx && d_c8 && d_packed && n > 0 && n % 8 == 0 && f16 >= 0 && f16 <= 2, "mnc_act_pack: bad argument");
+  LaunchScope ls(ctx, "act_pack", 0.0, (f16 ? 6.0 : 8.0) * n);
+  auto kern = f16 == 0 ? pack_act_kernel<0> : f16 == 1 ? pack_act_kernel<1> : pack_act_kernel<2>;
+  hipLaunchKernelGGL(kern, dim3(sw_grid_for((long)(n / 8))), dim3(256), 0, ctx->stream, (const float4*)d_c8, d_packed, (long)(n / 8));
+  return ls.finish("pack_act_kernel");
+}
+
+int mnc_act_unpack(mnc_ctx* ctx, const void* d_packed, float* d_c8, size_t n, int f16) {
+  MNC_REQUIRE(ctx && d_c8 && d_packed && n > 0 && n % 8 == 0 && f16 >= 0 && f16 <= 2, "mnc_act_unpack: bad argument");
+  LaunchScope ls(ctx, "act_unpack", 0.0, (f16 ? 6.0 : 8.0) * n);
+  auto kern = f16 == 0 ? unpack_act_kernel<0> : f16 == 1 ? unpack_act_kernel<1> : unpack_act_kernel<2>;
+  hipLaunchKernelGGL(kern, dim3(sw_grid_for((long)(n / 4))), dim3(256), 0, ctx->stream, (const unsigned*)d_packed, (float4*)d_c8, (long)(n / 4));
+  return ls.finish("unpack_act_kernel");
 }
 
 }  // extern "C"

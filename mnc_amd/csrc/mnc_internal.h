@@ -242,7 +242,7 @@ int nms_scan_launch_indirect(hipStream_t stream, const unsigned long long* d_mas
                              int* d_keep, int* d_num);
 void proposal_state_free(void* state);  // proposal.hip
 void comm_free(mnc_ctx* ctx);           // comm.hip
-// out = act(sum of the ksplit partial c8 tensors + bias)  (conv.hip; shared with conv_x3.hip)
+// out = act(sum of the ksplit partial c8 tensors + bias)  (conv.hip)
 void fc_reduce_launch(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
                       int act);   // gemm.hip: out = act(sum of the K splits' partial sums + bias), shared by the three FC kernels
 bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,

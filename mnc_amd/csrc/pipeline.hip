@@ -82,7 +82,7 @@ struct mnc_net {
   // device weights
   float* w_c3 = nullptr;                       // conv1_1 [Cout][3][3][3]
   void* w_conv[14] = {nullptr};                // packed conv3x3 weights: trunk 1..12, [13] = rpn_conv_3x3
-  bool packed_trunk = false;                   // bf16x3 / f16 with every trunk layer on the tuned kernel: 2-byte activations
+  bool packed_trunk = false;                   // bf16x3 / f16 / bf16 with every trunk layer on the tuned kernel: 2-byte activations
   bool conv_fast[14] = {false};                // tuned 3x3 kernels (Cout % 32 == 0) or the general convolution (reduced widths)
   float* b_conv[14] = {nullptr};               // biases: trunk 0..12 -> [0..12], rpn -> [13]
   float *w_rpn = nullptr, *b_rpn = nullptr;    // rpn_cls_score (2A rows) and rpn_bbox_pred (4A rows) as ONE [6A][RC] 1x1 convolution
@@ -90,7 +90,7 @@ struct mnc_net {
   Fc fc_maskest, fc_maskpred, fc6, fc7, fc6m, fc7m, fc_heads;
   // geometry of the buffers below
   int cap_ph = 0, cap_pw = 0, cap_src = 0;
-  DevBuf img, taps, data, act[13], pooled[4], rpn_out, rpn_score, rpn_prob;      // rpn_score: [2A score | 4A bbox] planes
+  DevBuf img, taps, data, act[13], pooled[4], act12_pk, rpn_out, rpn_score, rpn_prob;   // act12_pk: conv5_3 packed (for rpn_conv); rpn_score: [2A score | 4A bbox] planes
   float* rpn_bbox_p = nullptr;                                                      // = rpn_score + 2A planes (set per image size)
   DevBuf rois, rois_ext, feat14, h_mask, m14, box7, mask7, f6, f6m, join, heads, boxes, masks, scores;
   // the result block: [per-class counts: 256 B | the ProposalLayer's row count: 256 B | instance records] -- laid out like the
@@ -176,6 +176,7 @@ int need(mnc_net* n, const char* layer, int index, size_t count, const HostBlob*
 // that keeps the 1e-3 bar (mnc_hip.h, mnc_net_config::math)
 // math 4 ("bf16"): plain bf16, one product per term, fp32 tensors between the layers (BASELINE configs[2] as written; measured only)
 static inline int conv_math(const mnc_net_config& c) { return c.math == 3 ? 1 : c.math; }
+static inline int lowp_mode(int cm) { return cm == 1 ? 0 : cm == 2 ? 1 : 2; }      // conv_math 1 / 2 / 4 -> mnc_conv3x3_lowp's mode
 static inline int fc_math(const mnc_net_config& c) { return c.math == 3 ? 2 : c.math; }
 
 // One InnerProduct's weights: [N][K] in Caffe order; geo = (C, PH, PW) when the bottom is a per-RoI feature (the engine's
@@ -266,8 +267,9 @@ int finalize(mnc_net* n) {
       n->conv_fast[i] = cout % 32 == 0;        // engine.py:_conv_kind: 'fast3x3' needs Cout % 32 == 0, otherwise 'general'
       if (n->conv_fast[i]) {
         const int cm = conv_math(c);
-        const int pitch = cm == 0 ? (c.winograd == 4 ? 288 : c.winograd ? 136 : 76) : 84;
-        NET_TRY(mnc_dev_alloc(n->ctx, (size_t)(cin / 8) * cout * pitch * 4, &n->w_conv[i]));
+        const int pitch = c.winograd == 4 ? 288 : c.winograd ? 136 : 76;
+        const size_t wbytes = cm == 0 ? (size_t)(cin / 8) * cout * pitch * 4 : mnc_conv3x3_lowp_weight_bytes(lowp_mode(cm), cout, cin);
+        NET_TRY(mnc_dev_alloc(n->ctx, wbytes, &n->w_conv[i]));
         NET_TRY(cm == 0 ? (c.winograd == 4 ? mnc_pack_conv3x3_wino4(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
                                : c.winograd ? mnc_pack_conv3x3_wino(n->ctx, raw, (float*)n->w_conv[i], cout, cin)
                                             : mnc_pack_conv3x3_weights(n->ctx, raw, (float*)n->w_conv[i], cout, cin))
@@ -285,7 +287,7 @@ int finalize(mnc_net* n) {
     }
     cin = cout;
   }
-  n->packed_trunk = (conv_math(c) == 1 || conv_math(c) == 2) && tune(n->ctx, T_PACKED_ACT, 1) != 0;
+  n->packed_trunk = conv_math(c) != 0 && tune(n->ctx, T_PACKED_ACT, 1) != 0;
   for (int i = 1; i < 13; ++i) n->packed_trunk = n->packed_trunk && n->conv_fast[i];
   const int A = c.num_anchors, RC = c.rpn_channels;
   {
@@ -348,6 +350,7 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
     }
   }
   const int A = c.num_anchors;
+  if (n->packed_trunk) NET_TRY(dev_ensure(n, &n->act12_pk, (size_t)c.trunk_channels[4] * h * w * 4));
   NET_TRY(dev_ensure(n, &n->hwc5, (size_t)c.trunk_channels[4] * h * w * 4));
   NET_TRY(dev_ensure(n, &n->rpn_out, (size_t)c.rpn_channels * h * w * 4));
   NET_TRY(dev_ensure(n, &n->rpn_score, (size_t)6 * A * h * w * 4));
@@ -446,22 +449,22 @@ int run_trunk(mnc_net* n) {
   int h = n->OH, w = n->OW, pi = 0, cin = 3;
   const float* cur = (const float*)n->data.p;
   if (n->packed_trunk) {
-    // bf16x3 / f16: 2-byte activation tensors between the MFMA layers (include/mnc_hip.h "Packed 2-byte activations"): conv1_1
-    // and every convolution's epilogue write the form the next layer's staging copies verbatim; conv5_3 writes fp32 c8 for the
-    // RPN convolution and the RoI warps.  Bit for bit the fp32-tensor route (test_gpu_ops.py::test_conv3x3_packed_activations).
-    const int f16 = conv_math(c) == 2;
+    // bf16x3 / f16 / bf16: 2-byte activation tensors between the MFMA layers (include/mnc_hip.h "Packed 2-byte activations"): conv1_1
+    // and every convolution's epilogue write the form the next layer multiplies from; conv5_3 writes fp32 c8 for the RoI warps AND
+    // the packed form for the RPN convolution.  Bit for bit the fp32-tensor route (test_gpu_ops.py::test_conv3x3_packed_activations).
+    const int mode = lowp_mode(conv_math(c));
     const void* pc = cur;
     for (int i = 0; i < 13; ++i) {
       const int cout = c.trunk_channels[kTrunkStage[i]];
       void* out = n->act[i].p;
-      if (i == 0) NET_TRY(mnc_conv3x3_c3_fmt(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1, conv_math(c)));
-      else if (f16) NET_TRY(mnc_conv3x3_f16_pk(ctx, pc, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1, 1, i < 12));
-      else NET_TRY(mnc_conv3x3_bf16x3_pk(ctx, pc, n->w_conv[i], n->b_conv[i], out, h, w, cin, cout, 1, 1, i < 12));
+      if (i == 0) NET_TRY(mnc_conv3x3_c3_fmt(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1, mode + 1));
+      else if (i < 12) NET_TRY(mnc_conv3x3_lowp(ctx, mode, pc, n->w_conv[i], n->b_conv[i], out, nullptr, h, w, cin, cout, 1));
+      else NET_TRY(mnc_conv3x3_lowp(ctx, mode, pc, n->w_conv[i], n->b_conv[i], n->act12_pk.p, (float*)out, h, w, cin, cout, 1));
       pc = out; cin = cout;
       if (kPoolAfter[i]) {
         void* p = n->pooled[pi++].p;
-        if (f16) NET_TRY(mnc_maxpool2_c8_f16(ctx, pc, p, cout, h, w));
-        else NET_TRY(mnc_maxpool2_c8_bf16x3(ctx, pc, p, cout, h, w));
+        NET_TRY(mode == 1 ? mnc_maxpool2_c8_f16(ctx, pc, p, cout, h, w)
+                          : mode == 2 ? mnc_maxpool2_c8_bf16(ctx, pc, p, cout, h, w) : mnc_maxpool2_c8_bf16x3(ctx, pc, p, cout, h, w));
         h = pool_out(h); w = pool_out(w);
         pc = p;
       }
@@ -494,7 +497,10 @@ int run_trunk(mnc_net* n) {
   if (n->fuse_small)      // (both head stages warp from this copy; otherwise each mnc_roi_warp_sm call makes its own)
     NET_TRY(c8_to_hwc_launch(ctx, (const float*)n->act[12].p, (float*)n->hwc5.p, c.trunk_channels[4], h, w));
   const int A = c.num_anchors;
-  NET_TRY(conv3(n, 13, cur, (float*)n->rpn_out.p, h, w, cin, c.rpn_channels));
+  if (n->packed_trunk && n->conv_fast[13])
+    NET_TRY(mnc_conv3x3_lowp(ctx, lowp_mode(conv_math(c)), n->act12_pk.p, n->w_conv[13], n->b_conv[13], nullptr, (float*)n->rpn_out.p, h, w,
+                             cin, c.rpn_channels, 1));
+  else NET_TRY(conv3(n, 13, cur, (float*)n->rpn_out.p, h, w, cin, c.rpn_channels));
   if (n->fuse_small) {
     NET_TRY(mnc_rpn_heads(ctx, (const float*)n->rpn_out.p, n->w_rpn, n->b_rpn, (float*)n->rpn_score.p, (float*)n->rpn_prob.p, h, w,
                           c.rpn_channels, A));
@@ -962,7 +968,7 @@ int mnc_net_destroy(mnc_net* net) {
   DevBuf* bufs[] = {&net->img, &net->taps, &net->data, &net->rpn_out, &net->rpn_score, &net->rpn_prob, &net->rois,
                     &net->rois_ext, &net->feat14, &net->h_mask, &net->m14, &net->box7, &net->mask7, &net->f6, &net->f6m, &net->join,
                     &net->feat14_sm, &net->box7_sm, &net->mask7_sm, &net->f6_sm, &net->f6m_sm,
-                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->outblk, &net->hwc5};
+                    &net->heads, &net->boxes, &net->masks, &net->scores, &net->outblk, &net->hwc5, &net->act12_pk};
   for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
   for (auto& b : net->act) if (b.p) (void)hipFree(b.p);
   for (auto& b : net->pooled) if (b.p) (void)hipFree(b.p);

@@ -1,4 +1,4 @@
-// Split-precision helpers shared by the bf16x3 kernels (gemm_x3.hip, conv_x3.hip).
+// Split-precision helpers shared by the bf16x3 kernels (gemm_x3.hip, conv_sw.hip).
 //
 // x = hi + lo with hi, lo bf16.  A product a*b is evaluated as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on
 // v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in the fp32 accumulator); the dropped terms are a_lo*b_lo

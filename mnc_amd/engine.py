@@ -858,7 +858,10 @@ class Net(object):
 
             def build():
                 raw = self._upload(W)
-                packed = self._ctx.alloc((cin // 8) * cout * pitch * 4)
+                nbytes = (cin // 8) * cout * pitch * 4
+                if x3:     # include/mnc_hip.h: mnc_conv3x3_lowp_weight_bytes (bf16x3: four planes per 16-channel block, else two)
+                    nbytes = max(nbytes, ((cin + 15) // 16) * (cout // 32) * (4 if self.conv_math == "bf16x3" else 2) * 4608)
+                packed = self._ctx.alloc(nbytes)
                 _lib.call(pack, self._h(), raw, packed, cout, cin)
                 self._ctx.free(raw)
                 return packed

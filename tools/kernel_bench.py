@@ -165,7 +165,8 @@ def main():
             if args.what in ("convx3", "convf16"):
                 mode = "bf16x3" if args.what == "convx3" else "f16"
                 raw = dev.put((rng.normal(size=(Cout * Cin * 9,)) * 0.05).astype(np.float32))
-                w = dev.empty(((Cin // 8) * Cout * 84,))
+                from mnc_amd import _lib
+                w = dev.empty((_lib.load().mnc_conv3x3_lowp_weight_bytes(0 if mode == "bf16x3" else 1, Cout, Cin) // 4,))
                 dev.call("mnc_pack_conv3x3_" + mode, raw, w, Cout, Cin)
                 fn = "mnc_conv3x3_" + mode
                 if args.packed:                       # 2-byte activations on both sides (buffers are large enough either way)
