@@ -423,6 +423,11 @@ MNC_API size_t mnc_conv3x3_lowp_weight_bytes(int mode, int Cout, int Cin);
 MNC_API int mnc_pack_conv3x3_lowp(mnc_ctx* ctx, int mode, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias,
                              void* d_out_packed, float* d_out_c8, int H, int W, int Cin, int Cout, int relu);
+/* The same convolution with the following Pooling MAX 2x2/2 (Caffe's ceil output size) folded into the epilogue: writes only the
+ * pooled tensor [Cout/8][ceil(H/2)][ceil(W/2)] in the packed form -- bit for bit mnc_maxpool2_c8_* of the unpooled packed output
+ * (conv1_2 / conv2_2 / conv3_3 / conv4_3 + pool1..4: test.prototxt:61-92, 117-148, 193-232, 277-316).  Cout % 64 == 0. */
+MNC_API int mnc_conv3x3_lowp_pool(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias,
+                                  void* d_out_pooled_packed, int H, int W, int Cin, int Cout, int relu);
 MNC_API int mnc_pack_conv3x3_f16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_pack_conv3x3_bf16(mnc_ctx* ctx, const float* d_oihw, void* d_packed, int Cout, int Cin);
 MNC_API int mnc_conv3x3_bf16(mnc_ctx* ctx, const float* d_in_c8, const void* d_w_packed, const float* d_bias, float* d_out_c8,

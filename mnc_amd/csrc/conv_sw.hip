@@ -54,11 +54,20 @@ constexpr int kSwOOB = 0x7FFFFFF0;                 // per-lane offset no buffer 
 constexpr int kSwTapB = 32 * 16;                   // one (plane, tap) of a 32-channel tile: 32 x 16 B
 constexpr int kSwPlaneB = 9 * kSwTapB;
 
+// compile-time loop: f(std::integral_constant<int, 0>()) ... f(<N - 1>)
+template <int I, int N, class F>
+__device__ __forceinline__ void x3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    x3_static_for<I + 1, N>(f);
+  }
+}
+
 __host__ __device__ constexpr int sw_planes(int mode) { return mode == 0 ? 4 : 2; }
 __host__ __device__ constexpr int sw_pixb(int mode) { return mode == 0 ? 32 : 16; }
 
 // Geometry of one instantiation (host and device)
-template <int PR, int RG, int CG, int KW>
+template <int PR, int RG, int CG, int KW, int NBUF = 2>
 struct SwGeom {
   static constexpr int NWG = RG * CG;                        // waves of one K range
   static constexpr int NT = 64 * NWG * KW;
@@ -71,17 +80,17 @@ struct SwGeom {
   static constexpr int BUFB = AB + 2 * PLANEB;
   static constexpr int NAS = (9 * CG + NWG - 1) / NWG;       // copy slots per wave and pass
   static constexpr int NBS = (2 * PP + NWG - 1) / NWG;
-  static constexpr int DUMMY = KW * 2 * BUFB;                // 1 KB that surplus slots fill with zeros
+  static constexpr int DUMMY = KW * NBUF * BUFB;             // 1 KB that surplus slots fill with zeros
   static constexpr int RED = (KW - 1) * NWG * PR * 4096;     // K ranges' accumulators on their way to range 0
   static constexpr int LDS = (DUMMY > RED ? DUMMY : RED) + 1024;
 };
 
-template <int MODE, int PR, int RG, int CG, int KW>
+template <int MODE, int PR, int RG, int CG, int KW, int NBUF>
 __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const void* __restrict__ in_, const void* __restrict__ wpk_,
                                                                        const float* __restrict__ bias, void* __restrict__ out_pk,
                                                                        float* __restrict__ out_f32, int H, int W, int Cin, int Cout,
-                                                                       int relu) {
-  typedef SwGeom<PR, RG, CG, KW> G;
+                                                                       int relu, int pool) {
+  typedef SwGeom<PR, RG, CG, KW, NBUF> G;
   constexpr int NPL = sw_planes(MODE), NPASS = MODE == 0 ? 3 : 1, PIXB = sw_pixb(MODE);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_sw[];
 
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
   const sw_i32x4 in_rsrc = make_rsrc(in_, (long)nblk * blk_bytes);
   const sw_i32x4 w_rsrc = make_rsrc(wpk_, (long)nchunks * ncot * NPL * kSwPlaneB);
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)s_sw;
-  const int kwbase = kw * 2 * G::BUFB;
+  const int kwbase = kw * NBUF * G::BUFB;
 
   int vb[G::NBS];
 #pragma unroll
@@ -221,25 +230,31 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
       }
   };
 
-  // ---- main loop over the passes of this K range
+  // ---- main loop over the passes of this K range: NBUF buffers, the copies of pass v + NBUF - 1 are issued while pass v is
+  // multiplied (NBUF = 2: one pass ahead, wait for everything; 3: two ahead, the newest pass's NS copies may stay in flight)
+  constexpr int AHEAD = NBUF - 1;
+  auto pass_sync = []() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 1) * NS) : "memory");
+  };
+  x3_static_for<0, AHEAD>([&](auto a_) {
+    constexpr int a = decltype(a_)::value;
+    const int c = c_begin + a / NPASS;
+    const bool more = c < c_end;
 #pragma unroll
-  for (int k = 0; k < NS; ++k) dma_slot(c_begin, std::integral_constant<int, 0>(), 0, k, true);
-  int buf = 0;
+    for (int k = 0; k < NS; ++k) dma_slot(more ? c : c_end - 1, std::integral_constant<int, a % NPASS>(), a, k, more);
+  });
+  int bc = 0, tb = AHEAD;                                    // buffer of the pass being multiplied / being filled
   for (int c = c_begin; c < c_end; ++c) {
-    const bool more = c + 1 < c_end;
-    const int cn = more ? c + 1 : c;
-    if constexpr (NPASS == 1) {
-      MNC_SW_SYNC();
-      compute(buf, [&](int k) { dma_slot(cn, std::integral_constant<int, 0>(), buf ^ 1, k, more); });
-    } else {
-      MNC_SW_SYNC();
-      compute(buf, [&](int k) { dma_slot(c, std::integral_constant<int, 1>(), buf ^ 1, k, true); });
-      MNC_SW_SYNC();
-      compute(buf ^ 1, [&](int k) { dma_slot(c, std::integral_constant<int, 2>(), buf, k, true); });
-      MNC_SW_SYNC();
-      compute(buf, [&](int k) { dma_slot(cn, std::integral_constant<int, 0>(), buf ^ 1, k, more); });
-    }
-    buf ^= 1;
+    x3_static_for<0, NPASS>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      const int ct = c + (p + AHEAD) / NPASS;
+      const bool more = ct < c_end;
+      const int ctc = more ? ct : c_end - 1;
+      pass_sync();
+      compute(bc, [&](int k) { dma_slot(ctc, std::integral_constant<int, (p + AHEAD) % NPASS>(), tb, k, more); });
+      bc = bc + 1 == NBUF ? 0 : bc + 1;
+      tb = tb + 1 == NBUF ? 0 : tb + 1;
+    });
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the last pass's all-out-of-range copies)
 
@@ -256,7 +271,8 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
               make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
     }
     __syncthreads();
-    if (kw > 0) return;
+    if (kw > 0 && !pool) return;                             // (with the pooling epilogue: two more barriers to attend)
+    if (kw == 0)
 #pragma unroll
     for (int k = 1; k < KW; ++k)
 #pragma unroll
@@ -266,6 +282,89 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
           const float4 p = red[((((k - 1) * G::NWG + wl) * PR + r) * 4 + q) * 64 + lane];
           acc[r][4 * q] += p.x; acc[r][4 * q + 1] += p.y; acc[r][4 * q + 2] += p.z; acc[r][4 * q + 3] += p.w;
         }
+  }
+
+  // ---- epilogue with the following Pooling MAX 2x2/2 (Caffe's ceil output size) folded in (test.prototxt:81-92, 137-148, 221-232,
+  // 305-316; row groups even: a workgroup's rows start at an even image row).  A wave's five rows are two whole window rows and half
+  // of a third: the odd row group hands its first row to the even one below it through LDS.  Columns: lanes 2m, 2m + 1 (DPP
+  // quad_perm) -- even lanes keep the window's maximum.  max commutes with + bias and ReLU, so this is the packed form of the pooled
+  // fp32 tensor, and (rounding is monotonic, x -> (hi, lo) too) what mnc_maxpool2_c8_* makes of the unpooled packed output.
+  if constexpr (RG % 2 == 0) {
+    if (pool) {
+      MNC_SW_SYNC();                                         // (KW == 1: the other waves' last fragment reads)
+      float4* xch = reinterpret_cast<float4*>(s_sw + G::RED);
+      const int slot = (rg >> 1) * CG + cg;
+      if (kw == 0 && (rg & 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          xch[(slot * 4 + q) * 64 + lane] = make_float4(acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]);
+      }
+      __syncthreads();
+      if (kw > 0) return;
+      sw_f32x16 recv = acc[0];
+      if (!(rg & 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 p = xch[(slot * 4 + q) * 64 + lane];
+          recv[4 * q] = p.x; recv[4 * q + 1] = p.y; recv[4 * q + 2] = p.z; recv[4 * q + 3] = p.w;
+        }
+      }
+      const int OH = (H + 1) >> 1, OW = (W + 1) >> 1;
+      const int ow = w0 + j, co0 = (cot0 + cg) * 32;
+      const bool partner = (ow | 1) < W;                     // the window's second column exists
+      const bool active = !(j & 1) && ow < W && (!(MNC_SW_ABL & 4) || relu == 0x7fff);
+      const long gstride = (long)OH * OW;
+      auto emit = [&](const sw_f32x16& top, const sw_f32x16& bot, int rtop) {      // rows rtop (even), rtop + 1 of the image
+        if (rtop >= H) return;
+        const bool two = rtop + 1 < H;
+        float4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + co0 + g * 8 + kb * 4);
+          float x[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float m = two ? fmaxf(top[4 * g + e], bot[4 * g + e]) : top[4 * g + e];
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, true));
+            m = partner ? fmaxf(m, o) : m;
+            x[e] = m;
+          }
+          v[g] = make_float4(x[0] + b.x, x[1] + b.y, x[2] + b.z, x[3] + b.w);
+          if (relu) { v[g].x = fmaxf(v[g].x, 0.f); v[g].y = fmaxf(v[g].y, 0.f); v[g].z = fmaxf(v[g].z, 0.f); v[g].w = fmaxf(v[g].w, 0.f); }
+        }
+        if (!active) return;                                 // (lanes j and j + 32 agree)
+        const long pix0 = ((long)(co0 >> 3) * OH + (rtop >> 1)) * OW + (ow >> 1);
+        if constexpr (MODE != 0) {
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const uint2 A = MODE == 2 ? x3_bf16x4(v[g]) : x3_f16x4(v[g]), B = MODE == 2 ? x3_bf16x4(v[g + 1]) : x3_f16x4(v[g + 1]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(A.x, B.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(A.y, B.y, false, false);
+            reinterpret_cast<uint4*>(out_pk)[pix0 + (g + kb) * gstride] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hi, lo;
+            x3_split4(v[g], hi, lo);
+            const auto sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+            reinterpret_cast<uint4*>(out_pk)[(pix0 + g * gstride) * 2 + kb] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          }
+        }
+      };
+      const int rbase = h0 + rg * PR;
+      static_assert(PR == 5, "pooling epilogue: five rows per wave");
+      if (rg & 1) {
+        emit(acc[1], acc[2], rbase + 1);
+        emit(acc[3], acc[4], rbase + 3);
+      } else {
+        emit(acc[0], acc[1], rbase);
+        emit(acc[2], acc[3], rbase + 2);
+        emit(acc[4], recv, rbase + 4);
+      }
+      return;
+    }
   }
 
   // ---- epilogue: D[row = channel (e & 3) + 8 (e >> 2) + 4 kb][column = pixel j]; bias, ReLU, the requested output forms
@@ -350,17 +449,21 @@ __global__ void pack_conv_sw_kernel(const float* __restrict__ w, uint4* __restri
   }
 }
 
+template <int F16>
+__global__ __launch_bounds__(256) void maxpool2_packed_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int CB, int H,
+                                                              int W, int OH, int OW);
+
 static int sw_grid_for(long total) {
   const long g = (total + 255) / 256;
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
-template <int MODE, int PR, int RG, int CG, int KW>
+template <int MODE, int PR, int RG, int CG, int KW, int NBUF = 2>
 static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out_pk, float* d_out_f32, int H,
-                     int W, int Cin, int Cout, int relu) {
-  typedef SwGeom<PR, RG, CG, KW> G;
+                     int W, int Cin, int Cout, int relu, int pool) {
+  typedef SwGeom<PR, RG, CG, KW, NBUF> G;
   static_assert(G::LDS <= 160 * 1024, "conv3x3_sw: LDS budget");
-  auto kern = conv3x3_sw_kernel<MODE, PR, RG, CG, KW>;
+  auto kern = conv3x3_sw_kernel<MODE, PR, RG, CG, KW, NBUF>;
   static std::atomic<unsigned long long> attr_set{0};          // one bit per device: function attributes are per device
   const unsigned long long bit = 1ull << (ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
@@ -369,7 +472,7 @@ static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
   }
   const int blocks = cdiv(W, kSwCols) * cdiv(H, G::ROWS) * (Cout / (32 * CG));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NT), G::LDS, ctx->stream, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout,
-                     relu);
+                     relu, RG % 2 == 0 ? pool : 0);
   return MNC_OK;
 }
 
@@ -377,10 +480,11 @@ static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
 // form every shape fits (Cout % 32 == 0).  CONVX3_TILE = 100 + plan overrides the choice where the plan fits the shape.
 static int sw_plan(const mnc_ctx* ctx, int H, int W, int Cin, int Cout) {
   const int nchunks = (Cin / 8 + 1) / 2;
-  const bool fits[6] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true, Cout % 64 == 0, Cout % 128 == 0};
+  const bool fits[8] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true, Cout % 64 == 0, Cout % 128 == 0,
+                        Cout % 64 == 0, Cout % 128 == 0};
   if (tune_set(ctx, T_CONVX3_TILE)) {
     const int p = tune(ctx, T_CONVX3_TILE, 0) - 100;
-    if (p >= 0 && p < 6 && fits[p]) return p;
+    if (p >= 0 && p < 8 && fits[p]) return p;
   }
   const long wg0 = (long)cdiv(W, kSwCols) * cdiv(H, 10) * (Cout / 64);
   if (fits[0] && wg0 >= 384) return 0;
@@ -392,7 +496,7 @@ static int sw_plan(const mnc_ctx* ctx, int H, int W, int Cin, int Cout) {
 
 template <int MODE>
 static int conv3x3_sw(mnc_ctx* ctx, const char* name, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out_pk,
-                      float* d_out_f32, int H, int W, int Cin, int Cout, int relu) {
+                      float* d_out_f32, int H, int W, int Cin, int Cout, int relu, int pool = 0) {
   MNC_REQUIRE(ctx && d_in && d_wpk && d_bias && (d_out_pk || d_out_f32), "%s: null pointer", name);
   MNC_REQUIRE(H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout % 32 == 0,
               "%s: unsupported shape H=%d W=%d Cin=%d Cout=%d (need Cin%%8==0, Cout%%32==0)", name, H, W, Cin, Cout);
@@ -400,18 +504,36 @@ static int conv3x3_sw(mnc_ctx* ctx, const char* name, const void* d_in, const vo
               "%s: the input tensor must stay below 2 GB (32-bit copy offsets)", name);
   const double flops = 2.0 * H * W * 9.0 * Cin * Cout;
   const double ib = MODE == 0 ? 4.0 : 2.0;
-  const double bytes = (double)H * W * (Cin * ib + Cout * ((d_out_pk ? ib : 0.0) + (d_out_f32 ? 4.0 : 0.0))) + 4.0 * 9.0 * Cin * Cout;
+  MNC_REQUIRE(!pool || (d_out_pk && !d_out_f32), "%s: the pooling epilogue writes the packed form only", name);
+  // The plan is the unpooled convolution's (same K ranges, same bits).  Plans with one row group per workgroup (tiles that start on odd
+  // image rows) have no pooling epilogue: the convolution goes to the scratch arena and the pooling kernel follows.
+  const int plan = sw_plan(ctx, H, W, Cin, Cout);
+  void* d_pooled = nullptr;
+  if (pool && (plan == 2 || plan == 3)) {
+    int rc = ensure_scratch(ctx, (size_t)H * W * Cout * (MODE == 0 ? 4 : 2));
+    if (rc) return rc;
+    d_pooled = d_out_pk;
+    d_out_pk = ctx->scratch;
+    pool = 0;
+  }
+  const double opix = pool ? (double)((H + 1) / 2) * ((W + 1) / 2) : (double)H * W;
+  const double bytes = (double)H * W * Cin * ib + opix * Cout * ((d_out_pk ? ib : 0.0) + (d_out_f32 ? 4.0 : 0.0)) + 4.0 * 9.0 * Cin * Cout;
   LaunchScope ls(ctx, name, flops, bytes);
   int rc;
-  switch (sw_plan(ctx, H, W, Cin, Cout)) {
-    case 0: rc = launch_sw<MODE, 5, 2, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
-    case 1: rc = launch_sw<MODE, 5, 2, 2, 2>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
-    case 2: rc = launch_sw<MODE, 5, 1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
-    case 4: rc = launch_sw<MODE, 5, 4, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
-    case 5: rc = launch_sw<MODE, 5, 2, 4, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
-    default: rc = launch_sw<MODE, 5, 1, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu); break;
+  switch (plan) {
+    case 0: rc = launch_sw<MODE, 5, 2, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    case 1: rc = launch_sw<MODE, 5, 2, 2, 2>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    case 2: rc = launch_sw<MODE, 5, 1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    case 4: rc = launch_sw<MODE, 5, 4, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    case 5: rc = launch_sw<MODE, 5, 2, 4, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    case 6: rc = launch_sw<MODE, 5, 4, 2, 1, 3>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    case 7: rc = launch_sw<MODE, 5, 2, 4, 1, 3>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
+    default: rc = launch_sw<MODE, 5, 1, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
   }
   if (rc) return rc;
+  if (d_pooled)
+    hipLaunchKernelGGL(maxpool2_packed_kernel<MODE>, dim3(sw_grid_for((long)(Cout / 8) * ((H + 1) / 2) * ((W + 1) / 2))), dim3(256), 0,
+                       ctx->stream, (const uint4*)d_out_pk, (uint4*)d_pooled, Cout / 8, H, W, (H + 1) / 2, (W + 1) / 2);
   return ls.finish("conv3x3_sw_kernel");
 }
 
@@ -571,6 +693,14 @@ int mnc_conv3x3_lowp(mnc_ctx* ctx, int mode, const void* d_in_packed, const void
   if (mode == 0) return conv3x3_sw<0>(ctx, "conv3x3_bf16x3", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
   if (mode == 1) return conv3x3_sw<1>(ctx, "conv3x3_f16", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
   return conv3x3_sw<2>(ctx, "conv3x3_bf16", d_in_packed, d_w_packed, d_bias, d_out_packed, d_out_c8, H, W, Cin, Cout, relu);
+}
+
+int mnc_conv3x3_lowp_pool(mnc_ctx* ctx, int mode, const void* d_in_packed, const void* d_w_packed, const float* d_bias,
+                          void* d_out_pooled_packed, int H, int W, int Cin, int Cout, int relu) {
+  MNC_REQUIRE(mode >= 0 && mode <= 2, "mnc_conv3x3_lowp_pool: mode must be 0 (bf16x3), 1 (f16) or 2 (bf16)");
+  if (mode == 0) return conv3x3_sw<0>(ctx, "conv3x3_bf16x3", d_in_packed, d_w_packed, d_bias, d_out_pooled_packed, nullptr, H, W, Cin, Cout, relu, 1);
+  if (mode == 1) return conv3x3_sw<1>(ctx, "conv3x3_f16", d_in_packed, d_w_packed, d_bias, d_out_pooled_packed, nullptr, H, W, Cin, Cout, relu, 1);
+  return conv3x3_sw<2>(ctx, "conv3x3_bf16", d_in_packed, d_w_packed, d_bias, d_out_pooled_packed, nullptr, H, W, Cin, Cout, relu, 1);
 }
 
 // ---- the entry points of rounds 1-5, on the round-6 kernel (same names and argument meaning; the packed weight layout and its size

@@ -457,6 +457,14 @@ int run_trunk(mnc_net* n) {
     for (int i = 0; i < 13; ++i) {
       const int cout = c.trunk_channels[kTrunkStage[i]];
       void* out = n->act[i].p;
+      if (kPoolAfter[i] && i > 0 && n->fuse_small) {
+        // conv + ReLU + MAX 2x2/2 in one kernel (round 6): the full-resolution blob is not produced
+        void* p = n->pooled[pi++].p;
+        NET_TRY(mnc_conv3x3_lowp_pool(ctx, mode, pc, n->w_conv[i], n->b_conv[i], p, h, w, cin, cout, 1));
+        h = pool_out(h); w = pool_out(w);
+        pc = p; cin = cout;
+        continue;
+      }
       if (i == 0) NET_TRY(mnc_conv3x3_c3_fmt(ctx, cur, n->w_c3, n->b_conv[0], out, h, w, cout, 1, mode + 1));
       else if (i < 12) NET_TRY(mnc_conv3x3_lowp(ctx, mode, pc, n->w_conv[i], n->b_conv[i], out, nullptr, h, w, cin, cout, 1));
       else NET_TRY(mnc_conv3x3_lowp(ctx, mode, pc, n->w_conv[i], n->b_conv[i], n->act12_pk.p, (float*)out, h, w, cin, cout, 1));

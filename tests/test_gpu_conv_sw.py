@@ -105,7 +105,7 @@ def test_conv3x3_lowp(dev, mode, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("plan", [0, 1, 2, 3])
+@pytest.mark.parametrize("plan", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv3x3_lowp_every_plan(dev, mode, plan):
     """Each (row groups, channel tiles, K ranges) instantiation at a small shape that fits it, same bits wanted from none of them
     (K ranges regroup the sums) but every one inside the mode's bar; one output form at a time as well."""
@@ -164,3 +164,39 @@ def test_lowp_weight_layout(dev):
             assert not rec[~nz].any()
         else:
             assert np.array_equal(val, _round(mode, want))
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("H,W,Cin,Cout,plan", [(75, 125, 32, 64, None), (20, 64, 16, 128, 0), (23, 70, 64, 128, 1), (37, 33, 32, 128, 4),
+                                               (10, 31, 16, 128, 5), (41, 97, 48, 128, 6), (30, 100, 32, 128, 7), (150, 250, 16, 256, None)])
+def test_conv3x3_lowp_pool(dev, mode, H, W, Cin, Cout, plan):
+    """The Pooling MAX 2x2/2 (ceil output size) folded into the epilogue == mnc_maxpool2_c8_<mode> of the unpooled packed output, bit
+    for bit: odd heights and widths (a window of one row / one column), every plan with even row groups, K ranges inside the workgroup."""
+    m = MODES[mode]
+    rng = np.random.default_rng(H * 7 + W)
+    x = rng.normal(size=(Cin, H, W)).astype(np.float32)
+    w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.normal(size=Cout).astype(np.float32)
+    nb = _lib.load().mnc_conv3x3_lowp_weight_bytes(m, Cout, Cin)
+    d_w = dev.empty((nb // 4,), fill=np.nan)
+    dev.call("mnc_pack_conv3x3_lowp", m, dev.put(w), d_w, Cout, Cin)
+    d_xp = dev.empty((_words(mode, Cin * H * W),), fill=np.nan)
+    dev.call("mnc_act_pack", dev.put(to_c8(x)), d_xp, Cin * H * W, m)
+    d_b = dev.put(b)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    for relu in (1, 0):
+        d_full = dev.empty((_words(mode, Cout * H * W),), fill=np.nan)
+        d_ref = dev.empty((_words(mode, Cout * OH * OW),), fill=np.nan)
+        d_got = dev.empty((_words(mode, Cout * OH * OW),), fill=np.nan)
+        if plan is not None:
+            dev.tune("CONVX3_TILE", 100 + plan)
+        try:
+            dev.call("mnc_conv3x3_lowp", m, d_xp, d_w, d_b, d_full, None, H, W, Cin, Cout, relu)
+            dev.call("mnc_conv3x3_lowp_pool", m, d_xp, d_w, d_b, d_got, H, W, Cin, Cout, relu)
+        finally:
+            if plan is not None:
+                dev.tune("CONVX3_TILE", None)
+        dev.call("mnc_maxpool2_c8_" + mode, d_full, d_ref, Cout, H, W)
+        ref = dev.get(d_ref, (_words(mode, Cout * OH * OW),)).view(np.uint32)
+        got = dev.get(d_got, (_words(mode, Cout * OH * OW),)).view(np.uint32)
+        assert np.array_equal(ref, got), (mode, relu, int((ref != got).sum()))
