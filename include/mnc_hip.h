@@ -459,6 +459,17 @@ MNC_API int mnc_fc_bf16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, 
                         int K, int ldc, int act);
 MNC_API int mnc_fc_f16(mnc_ctx* ctx, const float* d_a, const void* d_w_packed, const float* d_bias, float* d_out, int M, int N,
                        int K, int ldc, int act);
+/* Two reduced-precision InnerProducts of one shape as ONE launch (round 6; mode 1 = fp16, 2 = plain bf16): the box and the mask
+ * branch of a head stage (fc6 + fc6_mask, fc7 + fc7_mask; test.prototxt:584-627, 652-696) -- mnc_fc_pair's idea on the 256-column
+ * LDS-DMA kernel: twice the column tiles fill the chip with half the K ranges (half the partial sums: 2 x 39 MB instead of 2 x 79 at
+ * fc6 / 300 RoIs).  Per product exactly the arguments of mnc_fc_f16_ex (one of d_a / d_a_sm; m_stride rows per stage of the
+ * stage-major inputs; an optional second output in the next InnerProduct's form).  mode 0 (split bf16) and shapes the paired kernel
+ * does not take (it needs 160 < M <= 320, N % 256 == 0, >= 8 stages per K range) run as the two single calls.  The paired launch
+ * groups the partial sums differently from two single calls: every executor of a graph pairs the same layers. */
+MNC_API int mnc_fc_lowp_pair(mnc_ctx* ctx, int mode, const float* d_a0, const void* d_a_sm0, const float* d_a1, const void* d_a_sm1,
+                             int m_stride, const void* d_w0, const void* d_w1, const float* d_bias0, const float* d_bias1,
+                             float* d_out0, float* d_out1, int M, int N, int K, int ldc, int act, void* d_out_sm0, void* d_out_sm1,
+                             int out_sm_fmt);
 /* ---- InnerProduct activations already in the reduced-precision kernels' own form ----
  * mnc_fc_bf16x3 / mnc_fc_f16 multiply the activations from a stage-major 2-byte tensor, which they otherwise make from the fp32
  * rows on every call (an elementwise pass over M x K: 0.2 ms per image at 300 RoIs, 0.75 ms at 1000 RoIs x 1024 channels):

@@ -362,7 +362,10 @@ template <int kMT, int F16>
 __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restrict__ Ax, const uint4* __restrict__ Wx,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          float* __restrict__ part, int M, int N, int K, int ldc, int kper, int act,
-                                                         int fused, int tn_, int splits_, int tm_, int mstride) {
+                                                         int fused, int tn_, int splits_, int tm_, int mstride,
+                                                         const uint4* __restrict__ Ax1 = nullptr, const uint4* __restrict__ Wx1 = nullptr,
+                                                         const float* __restrict__ bias1 = nullptr, float* __restrict__ out1 = nullptr,
+                                                         int pair_tn = 0) {
   constexpr int kBM = 32 * kMT, kBN2 = 256;
   constexpr int kRows = kBM + kBN2;                  // operand rows per stage: activations, then weights
   constexpr int kBuf = kRows * 128;                  // bytes per stage buffer
@@ -383,6 +386,11 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
   } else {
     xcd_decode(blockIdx.x, tn_, splits_, tm_, bn, split, bmz);
   }
+  // PAIR (round 6, mnc_fc_lowp_pair: fc6 + fc6_mask, fc7 + fc7_mask): two products of one shape in one launch -- tn_ counts the
+  // column tiles of both, pair_tn those of one; twice the tiles fill the chip with half the K ranges (half the partial sums)
+  const int which = (pair_tn && bn >= pair_tn) ? 1 : 0;      // (block-uniform)
+  bn -= which * pair_tn;
+  if (which) { Ax = Ax1; Wx = Wx1; bias = bias1; out = out1; }
   const int n0 = bn * kBN2, m0 = bmz * kBM;
   constexpr int kStageK = F16 ? 64 : kXBK;           // K values per stage: 128 bytes per row in either format
   const int S = K / kStageK;
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
           const int m = m0 + tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * kb;
           if (m < M) {
             if (fused) out[(long)m * ldc + n] = x3_act(acc[t][c][e] + bv, act);
-            else part[((long)split * M + m) * N + n] = acc[t][c][e];
+            else part[((long)(which * splits_ + split) * M + m) * N + n] = acc[t][c][e];
           }
         }
       }
@@ -739,6 +747,102 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   return MNC_OK;
 }
 
+// Two reduced-precision InnerProducts of one shape (fp16 / plain bf16) as ONE launch of the 256-column LDS-DMA kernel: the box and
+// the mask branch of a head stage (fc6 + fc6_mask, fc7 + fc7_mask; test.prototxt:584-627, 652-696).  Twice the column tiles fill
+// the chip with half the K ranges: fc6 at 300 RoIs writes 2 x 39 MB of partial sums instead of 2 x 79, fc7 (whose 64 stages are
+// too few for the 256-column kernel alone) gets it with 8-stage ranges.  Shapes the paired kernel does not take (one row block of
+// 161..320 rows, N a multiple of 256, >= 8 stages per range) run as two fc_lowp calls -- every executor of a graph calls this entry
+// point for the same layers, so they keep the same bits either way.
+template <int F16>
+static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const uint4* d_pre0, const float* d_a1, const uint4* d_pre1,
+                        int mstride, const void* d_w0, const void* d_w1, const float* d_bias0, const float* d_bias1, float* d_out0,
+                        float* d_out1, int M, int N, int K, int ldc, int act, void* d_osm0, void* d_osm1, int osm_fmt) {
+  static_assert(F16 != 0, "pairs: fp16 / bf16 only");
+  constexpr int kStage = 64;
+  if (M == 0) return MNC_OK;
+  const int stages = K / kStage, tn = N / 256;
+  bool paired = M > 160 && M <= 320 && N % 256 == 0 && N >= 512 && 2.0 * M * (double)N * K >= 2.0e9 && tune(ctx, T_FCX3_WIDE, 1) != 0 &&
+                !tune_set(ctx, T_FCX3_TILE) && tune(ctx, T_FUSE_SMALL, 1) != 0;
+  int splits = 1;
+  if (paired) {
+    splits = cdiv(256, 2 * tn);
+    if (splits > stages / 4) splits = stages / 4;
+    if (splits < 1) splits = 1;
+    paired = stages / splits >= 8;
+  }
+  if (!paired) {
+    int rc = fc_lowp<F16>(ctx, what, d_a0, d_pre0, d_a0 ? M : mstride, d_w0, d_bias0, d_out0, M, N, K, ldc, act, d_osm0,
+                          d_osm0 ? osm_fmt : 0, M, 0);
+    if (rc) return rc;
+    return fc_lowp<F16>(ctx, what, d_a1, d_pre1, d_a1 ? M : mstride, d_w1, d_bias1, d_out1, M, N, K, ldc, act, d_osm1,
+                        d_osm1 ? osm_fmt : 0, M, 0);
+  }
+  const int kper = cdiv(stages, splits) * kStage;
+  splits = cdiv(K, kper);
+  // scratch arena: [partial sums of both products | activations that arrive as fp32, in their 2-byte stage-major form]
+  const size_t part_bytes = splits > 1 ? (((size_t)2 * splits * M * N * 4 + 255) & ~(size_t)255) : 0;
+  const size_t conv_bytes = ((size_t)M * K * 2 + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, part_bytes + (d_pre0 ? 0 : conv_bytes) + (d_pre1 ? 0 : conv_bytes));
+  if (rc) return rc;
+  float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
+  const uint4* ax[2] = {d_pre0, d_pre1};
+  int ms[2] = {mstride, mstride};
+  {
+    char* conv = (char*)ctx->scratch + part_bytes;
+    const float* a32[2] = {d_a0, d_a1};
+    for (int i = 0; i < 2; ++i) {
+      if (ax[i]) continue;
+      LaunchScope ls(ctx, "fc_f16_convert", 0.0, 6.0 * M * (double)K);
+      f16_pack_launch(ctx, a32[i], (uint4*)conv, M, K, M, 1, F16 == 2);
+      rc = ls.finish("pack_f16_kernel");
+      if (rc) return rc;
+      ax[i] = (const uint4*)conv;
+      ms[i] = M;
+      conv += conv_bytes;
+    }
+  }
+  MNC_REQUIRE(ms[0] == ms[1], "%s: the two activation panels need one row stride", what);
+  {
+    const double flops = 4.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K) + 8.0 * (double)M * N;
+    LaunchScope ls(ctx, F16 == 2 ? "fc_bf16" : "fc_f16", flops, bytes);
+    constexpr int lds = 2 * (320 + 256) * 128;
+    static std::atomic<unsigned long long> attr_set{0};            // one bit per device
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_lowp_dma_kernel<10, F16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_set.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((fc_lowp_dma_kernel<10, F16>), dim3(2 * tn * splits), dim3(512), lds, ctx->stream, ax[0], (const uint4*)d_w0,
+                       d_bias0, d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, 1, ms[0], ax[1],
+                       (const uint4*)d_w1, d_bias1, d_out1, tn);
+    rc = ls.finish("fc_lowp_dma_kernel<pair>");
+    if (rc) return rc;
+  }
+  float* outs[2] = {d_out0, d_out1};
+  const float* biases[2] = {d_bias0, d_bias1};
+  void* osms[2] = {d_osm0, d_osm1};
+  for (int i = 0; i < 2; ++i) {
+    bool osm_done = false;
+    if (splits > 1) {
+      LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
+      osm_done = fc_reduce_launch_sm(ctx->stream, part + (size_t)i * splits * M * N, biases[i], outs[i], M, N, ldc, splits, act, osms[i],
+                                     osms[i] ? osm_fmt : 0, M, 0);
+      rc = ls.finish("fc_reduce_kernel");
+      if (rc) return rc;
+    }
+    if (osms[i] && !osm_done) {
+      MNC_REQUIRE(ldc == N, "%s: the second output needs a K-split reduction or dense rows", what);
+      LaunchScope ls(ctx, osm_fmt == 1 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (osm_fmt == 1 ? 6.0 : 8.0) * M * (double)N);
+      if (osm_fmt == 1) f16_pack_launch(ctx, outs[i], (uint4*)osms[i], M, N, M, 1);
+      else x3_pack_launch(ctx, outs[i], (uint4*)osms[i], M, N, M, 1);
+      rc = ls.finish("pack kernel");
+      if (rc) return rc;
+    }
+  }
+  return MNC_OK;
+}
+
 extern "C" {
 
 int mnc_pack_fc_bf16x3(mnc_ctx* ctx, const float* d_w, void* d_packed, int N, int K) {
@@ -837,6 +941,31 @@ int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, 
   if (f16) f16_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
   else x3_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
   return ls.finish(f16 ? "pack_f16_kernel" : "pack_x3_kernel");
+}
+
+// Two InnerProducts of one shape in reduced precision (mode 1 = fp16, 2 = plain bf16; each input as fp32 rows OR stage-major, each
+// output optionally a second time in the next InnerProduct's stage-major form): see fc_lowp_pair above.  mode 0 (split bf16) and
+// shapes the paired kernel does not take: exactly the two single calls.
+int mnc_fc_lowp_pair(mnc_ctx* ctx, int mode, const float* d_a0, const void* d_a_sm0, const float* d_a1, const void* d_a_sm1, int m_stride,
+                     const void* d_w0, const void* d_w1, const float* d_bias0, const float* d_bias1, float* d_out0, float* d_out1, int M,
+                     int N, int K, int ldc, int act, void* d_out_sm0, void* d_out_sm1, int out_sm_fmt) {
+  MNC_REQUIRE(ctx && mode >= 0 && mode <= 2 && (d_a0 != nullptr) != (d_a_sm0 != nullptr) && (d_a1 != nullptr) != (d_a_sm1 != nullptr) && d_w0 &&
+                  d_w1 && d_bias0 && d_bias1 && d_out0 && d_out1, "mnc_fc_lowp_pair: null pointer / both inputs");
+  MNC_REQUIRE(M >= 0 && ((d_a0 && d_a1) || m_stride >= M) && N > 0 && K > 0 && K % (mode ? 64 : kXBK) == 0 && ldc >= N && act >= 0 && act <= 2 &&
+                  ((!d_out_sm0 && !d_out_sm1) || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
+              "mnc_fc_lowp_pair: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
+  if (mode == 0) {
+    int rc = fc_lowp<0>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a0 ? M : m_stride, d_w0, d_bias0, d_out0, M, N, K, ldc, act,
+                        d_out_sm0, d_out_sm0 ? out_sm_fmt : 0, M, 0);
+    if (rc) return rc;
+    return fc_lowp<0>(ctx, "mnc_fc_lowp_pair", d_a1, (const uint4*)d_a_sm1, d_a1 ? M : m_stride, d_w1, d_bias1, d_out1, M, N, K, ldc, act,
+                      d_out_sm1, d_out_sm1 ? out_sm_fmt : 0, M, 0);
+  }
+  if (mode == 1)
+    return fc_lowp_pair<1>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a1, (const uint4*)d_a_sm1, m_stride, d_w0, d_w1, d_bias0,
+                           d_bias1, d_out0, d_out1, M, N, K, ldc, act, d_out_sm0, d_out_sm1, out_sm_fmt);
+  return fc_lowp_pair<2>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a1, (const uint4*)d_a_sm1, m_stride, d_w0, d_w1, d_bias0,
+                         d_bias1, d_out0, d_out1, M, N, K, ldc, act, d_out_sm0, d_out_sm1, out_sm_fmt);
 }
 
 }  // extern "C"

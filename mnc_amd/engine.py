@@ -623,7 +623,8 @@ class Net(object):
         # head stage (fc6 / fc6_mask, then fc7 / fc7_mask: test.prototxt:584-627 and :652-696; the mask branch's input exists that
         # early because of the one-pass pooling above) -- are ONE launch (mnc_fc_pair: half the K ranges, half the partial sums).
         # The whole-image pipeline pairs the same layers (csrc/pipeline.hip: run_stage), so the two executors keep the same bits.
-        if os.environ.get("MNC_FUSE_SMALL", "1") != "0" and self.fc_math == "fp32":
+        # Round 6: fp16 / plain bf16 InnerProducts pair the same way (mnc_fc_lowp_pair).
+        if os.environ.get("MNC_FUSE_SMALL", "1") != "0" and self.fc_math in ("fp32", "f16", "bf16"):
             produced_at = {}
             for i, L in enumerate(self._layers):
                 if L.skip:
@@ -1275,35 +1276,54 @@ class Net(object):
                 return self._dev_param(key + ("w",) + geo + tag, build), "rhwc", fn
             return self._dev_param(key + ("w", "plain") + tag, lambda: finish(self._upload(W))), "plain", fn
 
+        LOWP_PAIR = {"mnc_fc_f16": 1, "mnc_fc_bf16": 2}          # mnc_fc_lowp_pair's mode per single-call entry point
+
+        def lowp_args(M):
+            """(fp32 rows or None, stage-major rows or None, dst, second-output format, second output or None) of this layer's
+            reduced-precision call, with its top made ready: the rows arrive in the kernel's own 2-byte form when the producer
+            wrote them (Blob._sm: no conversion pass), and leave in the NEXT InnerProduct's form as well when one will read them."""
+            want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2}.get(state.get("fn"), 0)
+            sm = bot._sm
+            pre = bool(want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K and bot._dev_valid
+                       and bot.layout == state["layout"])
+            src = None if pre else bot.dev_in(state["layout"])
+            top.reshape(M, n_out)
+            dst = top.dev_out("plain")
+            ofmt = self._sm_format(top.name, M, n_out, n_out) if (want and top._view is None) else 0
+            return src, (sm["ptr"] if pre else None), dst, ofmt, (top.sm_out(ofmt, M, n_out) if ofmt else None)
+
         def run():
             M = bot.shape[0]
             if int(np.prod(bot.shape[1:])) != K:
                 raise ValueError("InnerProduct %s: input %r does not flatten to K=%d" % (L.name, bot.shape, K))
-            if M and "w" not in state:
-                state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
-            want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2}.get(state.get("fn"), 0)
-            sm = bot._sm
-            pre = (M and want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K and bot._dev_valid
-                   and bot.layout == state["layout"])
-            if M and want:
-                # reduced-precision kernel: the rows arrive in its own 2-byte form when the producer wrote them (Blob._sm: no
-                # conversion pass), and leave in the NEXT InnerProduct's form as well when one will read them (fc6 -> fc7)
-                src = None if pre else bot.dev_in(state["layout"])
-                top.reshape(M, n_out)
-                dst = top.dev_out("plain")
-                ofmt = self._sm_format(top.name, M, n_out, n_out) if top._view is None else 0
-                _lib.call(state["fn"] + "_ex", self._h(), src, sm["ptr"] if pre else None, M, state["w"], d_b, dst, M, n_out, K,
-                          top._ld(), act, top.sm_out(ofmt, M, n_out) if ofmt else None, ofmt)
-                return
             if L.pair_done:                        # computed with its pair leader earlier in this forward
                 L.pair_done = False
+                return
+            if M and "w" not in state:
+                state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
+            P = L.pair
+            if M and state.get("fn") in LOWP_PAIR and P is not None and P.ip_prepare is not None:
+                src, pre, dst, ofmt, osm = lowp_args(M)
+                other = P.ip_prepare(M, K, state["fn"])
+                if other is not None and other["ofmt"] == ofmt and other["ld"] == top._ld():
+                    _lib.call("mnc_fc_lowp_pair", self._h(), LOWP_PAIR[state["fn"]], src, pre, other["src"], other["pre"], M, state["w"],
+                              other["w"], d_b, other["b"], dst, other["dst"], M, n_out, K, top._ld(), act, osm, other["osm"], ofmt)
+                    P.pair_done = True
+                    return
+                if state["fn"] == "mnc_fc_f16":
+                    _lib.call("mnc_fc_f16_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
+                else:
+                    _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+                return
+            if M and state.get("fn") in ("mnc_fc_f16", "mnc_fc_bf16x3"):
+                src, pre, dst, ofmt, osm = lowp_args(M)
+                _lib.call(state["fn"] + "_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
                 return
             src = bot.dev_in(state["layout"]) if M else 0
             top.reshape(M, n_out)
             dst = top.dev_out("plain")
             if not M:
                 return
-            P = L.pair
             if P is not None and state["fn"] == "mnc_fc" and P.ip_prepare is not None:
                 other = P.ip_prepare(M, K)
                 if other is not None:
@@ -1313,20 +1333,26 @@ class Net(object):
                     return
             _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
 
-        def prepare(M_leader, K_leader):
-            """As the second member of a pair: (src, weights, bias, dst) of this layer's own mnc_fc call with its top made ready,
-            or None when it cannot share the leader's launch (other row count, other kernel, other leading dimension / activation)."""
+        def prepare(M_leader, K_leader, fn_leader="mnc_fc"):
+            """As the second member of a pair: (src, weights, bias, dst) of this layer's own mnc_fc call with its top made ready
+            (a dict of its mnc_fc_lowp_pair arguments for the reduced-precision entry points), or None when it cannot share the
+            leader's launch (other row count, other kernel, other leading dimension / activation)."""
             M = bot.shape[0]
             if M != M_leader or K != K_leader or int(np.prod(bot.shape[1:])) != K or not (bot._dev_valid or bot._host_valid):
                 return None
             if "w" not in state:
                 state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
-            if state["fn"] != "mnc_fc":
+            if state["fn"] != fn_leader:
                 return None
             lead_top = self.blobs[L.pair_leader.out_name or L.pair_leader.tops[0]]
+            if (1 if L.pair_leader.relu else L.pair_leader.act) != act:
+                return None
+            if fn_leader in LOWP_PAIR:
+                src, pre, dst, ofmt, osm = lowp_args(M)
+                return {"src": src, "pre": pre, "w": state["w"], "b": d_b, "dst": dst, "ofmt": ofmt, "osm": osm, "ld": top._ld()}
             src = bot.dev_in(state["layout"])
             top.reshape(M, n_out)
-            if top._ld() != lead_top._ld() or (1 if L.pair_leader.relu else L.pair_leader.act) != act:
+            if top._ld() != lead_top._ld():
                 return None
             return src, state["w"], d_b, top.dev_out("plain")
         if L.pair_leader is not None:

@@ -475,6 +475,15 @@ class Fake(object):
     def mnc_fc_f16_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
         self._fc_ex(self.mnc_fc_f16, True, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt)
 
+    def mnc_fc_lowp_pair(self, h, mode, a0, sm0, a1, sm1, mstride, w0, w1, b0, b1, dst0, dst1, M, N, K, ldc, act, osm0, osm1, ofmt):
+        fn = {0: self.mnc_fc_bf16x3_ex, 1: self.mnc_fc_f16_ex, 2: self.mnc_fc_bf16_ex}[mode]
+        fn(h, a0, sm0, mstride, w0, b0, dst0, M, N, K, ldc, act, osm0, ofmt if osm0 else 0)
+        fn(h, a1, sm1, mstride, w1, b1, dst1, M, N, K, ldc, act, osm1, ofmt if osm1 else 0)
+
+    def mnc_fc_bf16_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
+        assert sm is None and not osm, "test double: plain bf16 takes fp32 rows"
+        self.mnc_fc_bf16(h, a, wpk, b, dst, M, N, K, ldc, act)
+
     def mnc_fc_bf16x3_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
         self._fc_ex(self.mnc_fc_bf16x3, False, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt)
 

@@ -59,7 +59,12 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
         # fc7, fc6_mask, fc7_mask -- _X3_MIN_FLOPS = 0 makes mask_pred one of them, and with K = 32 it takes the split-bf16 kernel
         # in the f16 mode too; the merged sibling heads stay fp32); none converts its input rows itself
         n_ex = calls.get("mnc_fc_f16_ex", 0) + calls.get("mnc_fc_bf16x3_ex", 0)
-        assert runs in (1, 2) and n_ex == 12 * runs and calls.get(ex, 0) >= 10 * runs and "mnc_roi_warp" not in calls
+        # round 6: in the f16 mode fc6 + fc6_mask and fc7 + fc7_mask of a stage are one mnc_fc_lowp_pair call each (their inputs both
+        # exist when the first runs: the one-pass pooling of the fused plan)
+        n_pair = calls.get("mnc_fc_lowp_pair", 0)
+        assert runs in (1, 2) and n_ex + 2 * n_pair == 12 * runs and "mnc_roi_warp" not in calls
+        assert n_pair == (4 * runs if (fuse and math == "f16") else 0)
+        assert calls.get(ex, 0) + (2 * n_pair if math == "f16" else 0) >= 10 * runs
         assert "mnc_fc_f16" not in calls and "mnc_fc_bf16x3" not in calls
         # the box-feature Pooling and MaskPooling + Pooling of a stage read the same tensor: one pass, both second outputs
         assert calls.get("mnc_box_mask_pool") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
