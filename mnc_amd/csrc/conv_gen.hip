@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void conv2d_c8_kernel(const float* __restrict_
     w_row[c] = w_live[c] ? co0 + w_co + 64 * c : Cout - 1;
   }
 
-  float4 ra0, ra1, rw[CT];
+  // (initialised: hipcc keeps registers that a lambda writes first as allocas -- 80 bytes of scratch at CT = 2)
+  float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0, rw[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) rw[c] = ra0;
   auto load = [&](int s) {
     const int t = s / CP, cp = s - t * CP;
     const int cb0 = cp * 2, cb1 = min(cb0 + 1, CB - 1);

@@ -1143,8 +1143,12 @@ static int wino_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const 
     rc = plain_order ? launch_wino2<2, 7, 1, 0>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b)
                      : launch_wino2<2, 7, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
   else if (ver == 2 && var == 0 && !tune_set(ctx, T_WINO_DMA) && !(rows == 4 && tune_set(ctx, T_WINO_ROWS)))
+#ifdef MNC_TUNING            // (the one-row-group build spills ten registers at its 256-register budget: measurement builds only, round 6)
     rc = rows >= 2 ? launch_wino2<2, 0, 0, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b)
                    : launch_wino2<1, 0, 0, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
+#else
+    rc = launch_wino2<2, 0, 0, 1>(ctx, d_in, d_wpk, d_bias, d_out, H, W, Cin, Cout, relu, ksplit, part, kpool, pix_a, ksplit_b);
+#endif
 #ifdef MNC_TUNING
   else if (ver == 2) {              // wave pairs, 128 accumulators, two workgroups per CU (rows = row groups per workgroup: 1 | 2)
     // measured (kernel_bench convwino, 13-layer trunk): register staging 2.526 ms, LDS-DMA weight panel 2.564 ms -- the DMA saves

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             float* __restrict__ part, int H, int W, int Cin, int Cout, int relu,
                                                             int pool_a, int tiles_x, int pix_a, int ksplit_a, int ksplit_b,
-                                                            unsigned* __restrict__ tickets, int tail_first) {
+                                                            unsigned* __restrict__ tickets) {
   extern __shared__ __attribute__((aligned(1024))) char s_f4[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,15 +181,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(const float* __re
   const int ncot = Cout >> 5;
   int bx, by, cot, split, ksplit, tile;            // tile: index of the (pixel tile, channel tile) inside its section
   {
-    // section a = the first pix_a pixel tiles, section b (the tail of a plan) the rest; tail_first: section b takes the LOW block
-    // numbers, i.e. its short K ranges start with the launch and their epilogues (slabs, the last arriver's sum) run beside the
-    // whole tiles' loops instead of behind them (WINO_TAIL=2)
+    // section a = the first pix_a pixel tiles, section b (the tail of a plan) the rest.  (The tail's ranges FIRST in the block
+    // order was measured neutral in round 5 -- profiles/r05_ab_switches_and_plans.txt -- and removed in round 6.)
     const int n_a = pix_a * ncot * ksplit_a, n_b = (int)gridDim.x - n_a;
     int b = blockIdx.x, total = n_a, pix0 = 0;
     ksplit = ksplit_a;
-    const bool sec_b = tail_first ? b < n_b : b >= n_a;
-    if (sec_b) { b -= tail_first ? 0 : n_a; total = n_b; pix0 = pix_a; ksplit = ksplit_b; }
-    else if (tail_first) b -= n_b;
+    if (b >= n_a) { b -= n_a; total = n_b; pix0 = pix_a; ksplit = ksplit_b; }
     const int q = total >> 3, r = total & 7, xcd = b & 7, idx = b >> 3;
     const int logical = XCD ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
     const int nz = ncot * ksplit;
@@ -812,8 +809,7 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
 #endif
   const long nblocks = ((long)pix_a * ksplit_a + (long)(pix - pix_a) * ksplit_b) * ncot;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), kF4LdsBytes, ctx->stream, d_in, d_wpk, d_bias, d_out, part, H, W,
-                     Cin, Cout, relu, pool, tiles_x, pix_a, ksplit_a, ksplit_b, inkernel ? ctx->tickets : nullptr,
-                     pix_a < pix && pix_a > 0 && tune(ctx, T_WINO_TAIL, 1) == 2 ? 1 : 0);
+                     Cin, Cout, relu, pool, tiles_x, pix_a, ksplit_a, ksplit_b, inkernel ? ctx->tickets : nullptr);
   auto grid_for = [](long n) { return (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384); };
   auto reduce = [&](int s, int pix0, int npix) {
     const long items = (long)npix * (Cout >> 3) * kF4Rows * kF4Cols * 2 / (pool ? 4 : 1);

@@ -123,26 +123,15 @@ int mnc_ctx_create(mnc_ctx** out, int device_id) {
     const char* v = getenv(name);
     ctx->tune[k] = v && *v ? parse_tune(v) : kTuneUnset;
   }
-  // STREAM_PRIO (environment only: the stream is made here): the context's stream at that HIP priority; 9 = the contexts of the
-  // process take the device's priority levels in turn (an A/B switch for several images in flight, profiles/r05_stream_prio.txt)
-  hipError_t e;
-  if (ctx->tune[T_STREAM_PRIO] != kTuneUnset) {
-    static std::atomic<int> made{0};
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    int prio = ctx->tune[T_STREAM_PRIO];
-    if (prio == 9) prio = least - made.fetch_add(1) % (least - greatest + 1);
-    e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio);
-  } else {
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  }
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete ctx;
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
     return MNC_ERR_HIP;
   }
   e = hipMalloc((void**)&ctx->tickets, kTickets * sizeof(unsigned));
-  if (e == hipSuccess) e = hipMemset(ctx->tickets, 0, kTickets * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->tickets, 0, kTickets * sizeof(unsigned), ctx->stream);   // (ordered before the stream's launches)
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
     if (ctx->tickets) (void)hipFree(ctx->tickets);
     (void)hipStreamDestroy(ctx->stream);
@@ -178,7 +167,15 @@ int mnc_ctx_destroy(mnc_ctx* ctx) {
 int mnc_ctx_sync(mnc_ctx* ctx) {
   MNC_REQUIRE(ctx, "mnc_ctx_sync: null context");
   MNC_NO_CAPTURE(ctx, "mnc_ctx_sync");
-  MNC_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    // A launch that failed or faulted midway may have left arrival tickets of the in-launch K-range reductions non-zero
+    // (mnc_internal.h: slab_last_arriver resets a tile's ticket only when its last workgroup arrives); every later launch would
+    // then never see "arrivals - 1" and leave its tiles unfinished.  Put the counters back before reporting the error.
+    if (ctx->tickets) (void)hipMemsetAsync(ctx->tickets, 0, mnc::kTickets * sizeof(unsigned), ctx->stream);
+    mnc::set_error("hipStreamSynchronize failed: %s (%s:%d)", hipGetErrorString(e), __FILE__, __LINE__);
+    return MNC_ERR_HIP;
+  }
   clear_error();
   return MNC_OK;
 }

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
                                                             const float* __restrict__ bias_0, float* __restrict__ out_0,
                                                             float* __restrict__ part_0, int M, int N, int K, int ldc, int kper,
                                                             int act, int fused, int tn_, int splits_, int tm_, int drop_last,
-                                                            unsigned* __restrict__ tickets, const float* __restrict__ A_1,
+                                                            const float* __restrict__ A_1,
                                                             const float* __restrict__ Wt_1, const float* __restrict__ bias_1,
                                                             float* __restrict__ out_1, int pair_tn) {
   constexpr int kBM = 32 * kMT;
@@ -686,11 +686,7 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
     else run(std::false_type{});
   }
 
-  // fused == 2: the K ranges of a tile are summed INSIDE the launch (mnc_internal.h, slab_last_arriver).  A slab is the workgroup's
-  // accumulators as they sit in registers: [wave][sub-tile i][column half c][lane] x 16 bytes = 160 KB, one kilobyte per wave
-  // instruction (the separate reduction's partial sums were 80 four-byte stores per lane).  The last arriver adds the slabs in
-  // range order starting from zero -- fc_reduce_kernel's order: the same bits -- sixteen 16-byte loads in flight per lane.
-  bool final_out = fused == 1;
+  const bool final_out = fused == 1;
   if (fused == 0) {
     // K ranges finished by the reduction launch (fc_reduce_slab_kernel): the accumulators as they sit in registers, [tile][range]
     // [wave][sub-tile i][column half c][lane] x 16 bytes -- one kilobyte per wave instruction (rounds 1-4 stored them row-major:
@@ -703,45 +699,6 @@ __global__ __launch_bounds__(512) void fc_mfma_dma16_kernel(const float* __restr
 #pragma unroll
       for (int c = 0; c < 2; ++c) slab[(i * 2 + c) * 64] = acc[i][c];
     return;
-  }
-  if (fused == 2) {
-    constexpr int kSlabBytes = kNW * TS * 2 * 64 * 16;
-    const int tile = bmz * tn_ + which * pair_tn + bn;
-    const __amdgpu_buffer_rsrc_t rs = slab_rsrc(part + (size_t)tile * splits_ * (kSlabBytes / 4));
-    const int lane_off = (wave * TS * 2 * 64 + lane) * 16;
-#pragma unroll
-    for (int i = 0; i < TS; ++i)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) slab_store(rs, lane_off + (i * 2 + c) * 1024, split * kSlabBytes, acc[i][c]);
-    if (!slab_last_arriver(tickets + tile, splits_, reinterpret_cast<volatile unsigned*>(s_fc_dma))) return;
-#pragma unroll
-    for (int g0 = 0; g0 < TS * 2; g0 += 4) {
-      f32x4v sum[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sum[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      int sp = 0;
-      for (; sp + 4 <= splits_; sp += 4) {
-        f32x4v t[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) t[q][j] = slab_load(rs, lane_off + (g0 + j) * 1024, (sp + q) * kSlabBytes);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sum[j] += t[q][j];
-      }
-      for (; sp < splits_; ++sp) {
-        f32x4v t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = slab_load(rs, lane_off + (g0 + j) * 1024, sp * kSlabBytes);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum[j] += t[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[(g0 + j) >> 1][(g0 + j) & 1] = sum[j];
-    }
-    final_out = true;
   }
   // D[row = 16 i + 4 (lane / 16) + reg][col = 16 c + lane % 16] of the wave's 160 x 32 outputs
 #pragma unroll
@@ -938,9 +895,16 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   // the split-K scratch after the first one's reduction.  MNC_FC_NOTAIL=1 keeps one launch.
   if (M > 320 && M % 320 != 0 && M % 320 <= 160 && 2.0 * M * (double)N * K >= 2.0e9 && !tune(ctx, T_FC_NOTAIL, 0)) {
     const int head = M / 320 * 320;
+    // (two launches cannot hand ONE set of partial sums to the caller: the deferred reduction is for single-launch products only --
+    // both halves finish their own reduction, the caller sees deferred_splits == 1)
+    const bool defer = ctx->defer_reduce;
+    ctx->defer_reduce = false;
     int rc = mnc_fc(ctx, d_a, d_w, d_bias, d_out, head, N, K, ldc, act);
-    if (rc) return rc;
-    return mnc_fc(ctx, d_a + (size_t)head * K, d_w, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+    if (!rc) rc = mnc_fc(ctx, d_a + (size_t)head * K, d_w, d_bias, d_out + (size_t)head * ldc, M - head, N, K, ldc, act);
+    ctx->defer_reduce = defer;
+    ctx->deferred_part = nullptr;
+    ctx->deferred_splits = 1;
+    return rc;
   }
   // small problems (< 2 GFLOP) use 64-row workgroups so that rows, column tiles and K splits together fill the chip; the
   // large ones the smallest of {160, 320} rows that covers M in one block (weights streamed once).  Measured at M = 300
@@ -965,9 +929,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   int splits = cdiv(mt == 10 ? 256 : 512, tn * tm);
   // small variant: deep K (the N = 126 heads, K = 8192) gets at least 8 stages per split -- 32 splits instead of 103 cut
   // its reduction from 24 to 11 us and the total from 44 to 29 us; shallow K (mask_pred, K = 256) keeps 2
-  int small_min = tune(ctx, T_FC_SMALL_MIN, 8);      // A/B switch of the rule above (FC_SMALL_MIN=4: 32 ranges for the K = 4096 heads)
-  if (small_min < 2) small_min = 2;
-  const int min_stages = small ? (stages >= 64 ? small_min : 2) : (mt == 5 ? 16 : 8);
+  const int min_stages = small ? (stages >= 64 ? 8 : 2) : (mt == 5 ? 16 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
   // a small GEMM over at most 8 stages (mask_pred: K = 256) is not cut at all: four ranges of two stages each cost 9.5 us + a
   // 6.3 us reduction launch (kernel_bench fc, round 5) for 0.07 GFLOP; one range of eight stages writes the result itself
@@ -981,16 +943,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   const bool dma = mt == 10 && K % 64 == 0 && !tune_set(ctx, T_FC_ABL) && tune(ctx, T_FC_DMA, 1) != 0;
   if (dma) kper = cdiv(kper, 64) * 64;
   splits = cdiv(K, kper);
-  // FC_REDUCE bit 0 (off by default): the K ranges summed INSIDE the launch by each tile's last arriver (fc_mfma_dma16_kernel,
-  // fused == 2; up to 16 ranges) instead of by fc_reduce_kernel -- the same bits (tests/test_gpu_ops.py).  Built and measured in
-  // round 5 (profiles/r05_inlaunch_reduce.txt): a LOSS on this part.  The last arriver of a tile reads 8 x 160 KB of slabs on ONE
-  // CU at ~32 GB/s while 224 CUs idle: fc6 482 + 10 (reduce) -> 524 us, fc7 89 + 10 -> 119 us; the separate kernel spreads the
-  // same 39 MB over the chip at 4.5 TB/s and costs 10 us plus one launch boundary.  fc6_maskest (128 ranges x 2 column tiles)
-  // could not use it at all.  The guide's verdict for this seam ("cut at every all-to-all seam", splitk-seam) holds here too.
-  bool inkernel = dma && splits > 1 && splits <= 16 && tn * tm <= kTickets && (tune(ctx, T_FC_REDUCE, 2) & 1) != 0;
-#ifdef MNC_TUNING
-  if (tune(ctx, T_FC_MFMA16, 1) == 0 || tune(ctx, T_FC_DMA_WAVES, 8) == 4 || tune(ctx, T_FC_DMA_ABL, 0)) inkernel = false;
-#endif
+  // (In-launch reduction of the K ranges by each tile's last arriver: built and measured in round 5 -- a loss here, the last arriver
+  // reads 8 x 160 KB on one CU while 224 idle, profiles/r05_inlaunch_reduce.txt -- and removed in round 6.)
   // the eight-wave 16x16x4 kernel leaves its K ranges as SLABS (its accumulators in register layout, 160 KB per tile and range:
   // fc_reduce_slab_kernel); every other kernel as [range][M][N] rows (fc_reduce_kernel)
   bool slab = dma;
@@ -1038,7 +992,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
                     : dabl == 20 ? fc_mfma_dma16_kernel<10, 0, 1> : dabl == 21 ? fc_mfma_dma16_kernel<10, 4, 1> : fc_mfma_dma16_kernel<10, 0>;
         MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, dim3(tn * splits * tm), dim3(512), lds, ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper,
-                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop, ctx->tickets, (const float*)nullptr, (const float*)nullptr,
+                           act, splits == 1 ? 1 : 0, tn, splits, tm, drop, (const float*)nullptr, (const float*)nullptr,
                            (const float*)nullptr, (float*)nullptr, 0);
       } else if (tune(ctx, T_FC_MFMA16, 1) == 0 || waves == 4 || dabl) {
         launched = true;
@@ -1067,8 +1021,8 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
         // addresses (kernel_bench fc, MNC_FC_DMA_ABL=20 against 16: fc6 511 -> 500 us, fc7 92.9 -> 89.2, fc6_maskest 142 -> 137)
         const bool buf = 320.0 * (double)K * 4.0 < 1.8e9;
         hipLaunchKernelGGL((buf ? fc_mfma_dma16_kernel<10, 0, 1> : fc_mfma_dma16_kernel<10, 0, 0>), dim3(tn * splits * tm), dim3(512), lds,
-                           ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : inkernel ? 2 : 0, tn, splits,
-                           tm, drop, ctx->tickets, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0);
+                           ctx->stream, d_a, d_w, d_bias, d_out, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, tn, splits,
+                           tm, drop, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0);
       }
     }
     else if (mt == 2) MNC_FC_LAUNCH(2, 32, 0);
@@ -1098,13 +1052,13 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
     if (rc) return rc;
   }
   if (ctx->defer_reduce && !slab) {                  // the caller's next kernel sums the ranges (mnc_internal.h; row layout only)
-    ctx->deferred_part = splits > 1 && !inkernel ? part : nullptr;
-    ctx->deferred_splits = splits > 1 && !inkernel ? splits : 1;
+    ctx->deferred_part = splits > 1 ? part : nullptr;
+    ctx->deferred_splits = splits > 1 ? splits : 1;
     return MNC_OK;
   }
   ctx->deferred_part = nullptr;
   ctx->deferred_splits = 1;
-  if (splits > 1 && !inkernel && slab) {
+  if (splits > 1 && slab) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
     long g = ((long)tn * tm * 10240 + 255) / 256;
     if (g > 8192) g = 8192;
@@ -1112,7 +1066,7 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
                        (float*)nullptr, M, N, ldc, splits, act, tn, 0, tn * tm);
     return ls.finish("fc_reduce_slab_kernel");
   }
-  if (splits > 1 && !inkernel) {
+  if (splits > 1) {
     LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
     fc_reduce_launch(ctx->stream, part, d_bias, d_out, M, N, ldc, splits, act);
     return ls.finish("fc_reduce_kernel");
@@ -1174,7 +1128,7 @@ int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, const float*
     }
     const int drop = tm == 1 && M > 288 && M <= 304 ? 1 : 0;
     hipLaunchKernelGGL((fc_mfma_dma16_kernel<10, 0, 1>), dim3(2 * tn * splits * tm), dim3(512), lds, ctx->stream, d_a0, d_w0, d_bias0,
-                       d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, tm, drop, ctx->tickets, d_a1, d_w1,
+                       d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, tm, drop, d_a1, d_w1,
                        d_bias1, d_out1, tn);
     int rc = ls.finish("fc_mfma_dma16_kernel");
     if (rc) return rc;

@@ -32,9 +32,9 @@ namespace mnc {
 // superseded kernel builds (FC_ABL, FC_DMA_ABL, FCX3_ABL, CONV_ABL, WINO_V = 1, WINO_VAR != 7) are only compiled with -DMNC_TUNING.
 #define MNC_TUNE_KEYS(X)                                                                                                          \
   X(CONV_COT) X(CONV_ROWS) X(CONV_KSPLIT) X(CONV_ABL) X(CONV1X1_TILE) X(CONV2D_WIDE) X(WINO_ROWS) X(WINO_TAIL) X(WINO_V) X(WINO_VAR)  \
-  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TAIL) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
+  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
   X(FC_NO256) X(FCX3_TILE) X(FC_ORDER) X(FCX3_ABL) X(FC_SM) X(PACKED_ACT) X(FUSE_POOLS) X(BRANCH_STREAMS) X(TOPK_SINGLE_WG)           \
-  X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(FC_SMALL_MIN) X(STREAM_PRIO) X(ROI_ROW_SEGS)
+  X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(ROI_ROW_SEGS)
 enum TuneKey {
 #define MNC_TUNE_ENUM(n) T_##n,
   MNC_TUNE_KEYS(MNC_TUNE_ENUM)
@@ -188,6 +188,10 @@ __device__ __forceinline__ void xcd_decode(int bid, int tn, int splits, int tm, 
 // reads all slabs of the tile (sc1 loads behind one agent-scope acquire), adds them IN RANGE ORDER -- the order of the separate
 // reduction kernels, so the results are the same bits whichever workgroup arrives last -- and writes the finished tile.  Nobody
 // waits for anybody: a launch whose workgroups are not co-resident (several streams share the GPU) cannot deadlock.
+// Memory-model assumption (MI355X_MICROARCH.md, "Valid forms"): sc1 stores are write-through to the memory side, the asm
+// `s_waitcnt vmcnt(0)` in front of the barrier retires them before the ticket's relaxed agent-scope atomic can issue, and the last
+// arriver reads them behind ONE agent-scope acquire -- there is no formal release fence; the ordering is the drained write-through.
+// A launch that is aborted midway leaves tickets non-zero: mnc_ctx_sync zeroes the array when the stream reports an error.
 typedef unsigned mnc_u32x4 __attribute__((ext_vector_type(4)));
 typedef float mnc_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(float* base) {

@@ -15,6 +15,7 @@
 // seen; later images of that size are one hipGraphLaunch + one stream synchronisation.  The RoI count of the ProposalLayer
 // stays on the device (the heads run on all post_nms_topn rows, rows past the count are zero boxes); it comes down with the
 // records, and only if fewer proposals survived are the heads re-run on the exact count -- what the reference computes.
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <string>
@@ -78,7 +79,7 @@ struct mnc_net {
   // mnc_net_create_shared: the device weights below belong to `owner` (this net holds copies of the pointers and frees none of
   // them); `sharers` counts the nets that borrow from this one
   mnc_net* owner = nullptr;
-  int sharers = 0;
+  std::atomic<int> sharers{0};
   // device weights
   float* w_c3 = nullptr;                       // conv1_1 [Cout][3][3][3]
   void* w_conv[14] = {nullptr};                // packed conv3x3 weights: trunk 1..12, [13] = rpn_conv_3x3
@@ -979,7 +980,7 @@ int mnc_net_destroy(mnc_net* net) {
   if (!net) return MNC_OK;
   if (net->sharers > 0) {
     set_error("mnc_net_destroy: %d net(s) created with mnc_net_create_shared still use this net's weights; destroy them first",
-              net->sharers);
+              net->sharers.load());
     return MNC_ERR_STATE;
   }
   mnc_ctx* ctx = net->ctx;

@@ -360,6 +360,9 @@ __global__ __launch_bounds__(128) void heads_finish_kernel(const float* __restri
   for (int i = 0; i < K; ++i) sum += __shfl(e, i);
   const float pr = e / sum;
   if (live) { scores[(long)m * K + lane] = pr; row[N + lane] = pr; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // lane 0 reads what lanes 0 .. K - 1 just wrote (one wave: no barrier left)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (rois_ext && lane == 0) {
     const float* p = row + N;
     int best = 0;

@@ -528,8 +528,9 @@ __device__ __forceinline__ void warp_row_walk(const float* __restrict__ feat_hwc
 }
 
 // nseg: a row is walked by nseg waves, PW / nseg positions each (a wave's positions are a chain: each waits for its own loads)
+// (three workgroups per CU for the variants with a second, stage-major output: at four the 128-register budget spilled seven)
 template <int POOL2, int SM>
-__global__ __launch_bounds__(256, 4) void roi_warp_row_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
+__global__ __launch_bounds__(256, SM ? 3 : 4) void roi_warp_row_kernel(const float* __restrict__ feat_hwc, int C, int H, int W,
                                                               const float* __restrict__ rois, int R, int PH, int PW, float scale,
                                                               float* __restrict__ out, int nseg, void* __restrict__ sm) {
   const int C4 = C >> 2, lane = threadIdx.x & 63;

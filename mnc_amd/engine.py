@@ -1835,6 +1835,8 @@ class Net(object):
 
     def _run_layers(self, start, stop=None):
         pre = getattr(self, "_pre_steps", {})
+        for L in self._layers:                     # a partial forward may have run a pair's leader without its follower
+            L.pair_done = False
         for i in range(start, len(self._layers) if stop is None else stop):
             L = self._layers[i]
             if L.run is None:

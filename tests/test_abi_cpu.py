@@ -182,3 +182,23 @@ def test_tuning_values_are_per_context_and_checked():
     import glob
     users = [os.path.basename(p) for p in glob.glob(os.path.join(REPO, "mnc_amd", "csrc", "*.hip")) if "getenv(" in open(p).read()]
     assert users == ["ctx.hip"], users
+
+
+def test_no_product_kernel_spills_registers():
+    """every kernel of the product library's gfx950 code objects has .vgpr_spill_count == 0 and no scratch
+    (private segment) at all -- read from the code-object notes (llvm-readelf), no GPU needed.  Round 5 shipped four offenders
+    (roi_warp_row_kernel<1, 1> / <1, 2>, conv2d_c8_kernel<2>, conv3x3_wino2_kernel<1, 0, 0, 1>)."""
+    import importlib.util
+    if not os.path.isfile("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no llvm-readelf in this image")
+    _lib.load()
+    if b"tuning" in _lib.load().mnc_version():
+        pytest.skip("tuning build: measurement kernels are exempt")
+    spec = importlib.util.spec_from_file_location("spill_report", os.path.join(REPO, "tools", "spill_report.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    notes = mod.kernel_notes(_lib.LIB_PATH)
+    assert len(notes) > 150, len(notes)
+    assert any("conv3x3_sw_kernel" in k for k in notes) and any("fc_mfma_dma16_kernel" in k for k in notes)
+    bad = {k: v for k, v in notes.items() if v["vgpr_spill"] or v["scratch"]}
+    assert not bad, bad

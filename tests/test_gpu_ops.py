@@ -253,33 +253,6 @@ def test_conv3x3_winograd_f4_in_launch_reduction_reads_fresh_slabs(dev, tune, H,
         assert np.array_equal(got, refs[k]), "launch %d (input %d): %d values differ" % (rep, k, int((got != refs[k]).sum()))
 
 
-def test_conv3x3_tail_plan_tail_first_is_the_same_result(dev, tune):
-    """WINO_TAIL=2 / CONVX3_TAIL=2 (A/B switches, round 5): the K ranges of a plan's tail take the LOW block numbers, so they start
-    with the launch instead of behind the whole tiles.  Same tiles, same ranges, same order of additions: the same bits.  Shape
-    (150, 250, 64, 256): 608 workgroup tiles on 512 resident workgroups in all three kernels -- the conv3_x plan."""
-    H, W, Cin, Cout = 150, 250, 64, 256
-    rng = np.random.default_rng(77)
-    x = rng.normal(0, 1, (Cin, H, W)).astype(np.float32)
-    w = (rng.normal(0, 1, (Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
-    d_x, d_b, d_wraw = dev.put(to_c8(x)), dev.put(rng.normal(0, 0.1, Cout).astype(np.float32)), dev.put(w)
-    d_y = dev.empty((Cout, H, W), fill=-7.0)
-    for pack, fn, nw, key in (("mnc_pack_conv3x3_wino4", "mnc_conv3x3_wino4", Cin * Cout * 36, "WINO_TAIL"),
-                              ):
-        d_w = dev.empty((nw,))
-        dev.call(pack, d_wraw, d_w, Cout, Cin)
-        res = []
-        for v in (None, "2", "0"):
-            dev.tune(key, None)
-            if v is not None:
-                tune(key, v)
-            dev.put_into(d_y, np.full((Cout, H, W), -7.0, np.float32))
-            dev.call(fn, d_x, d_w, d_b, d_y, H, W, Cin, Cout, 1)
-            res.append(dev.get(d_y, (Cout * H * W,)).copy())
-        dev.tune(key, None)
-        assert np.array_equal(res[0], res[1]), (fn, int((res[0] != res[1]).sum()))
-        assert err(res[0], res[2])[1] < 1e-4, fn             # (no tail plan: other K ranges, not the same bits)
-
-
 @pytest.mark.parametrize("H,W,Cin,Cout", CONV_SHAPES + [(150, 250, 16, 128), (80, 100, 24, 256)])
 @pytest.mark.parametrize("relu", [1, 0])
 def test_conv3x3_bf16x3(dev, H, W, Cin, Cout, relu):
@@ -1057,11 +1030,6 @@ def test_fc_mfma_lds_dma(dev, monkeypatch, M, N, K, act, ldc_pad, tune):
     # the product build (eight waves, 16 x 16 x 4 fragments) and the register-staged kernel: same products, other order
     tune("FC_DMA", "1")
     prod = run()
-    # its K ranges summed inside the launch by each tile's last arriver (FC_REDUCE bit 0; up to 16 ranges; measured slower, off by
-    # default) == by fc_reduce_kernel: the same additions in the same order
-    tune("FC_REDUCE", "3")
-    assert np.array_equal(prod, run())
-    dev.tune("FC_REDUCE", None)
     tune("FC_DMA", "0")
     staged = run()
     assert err(prod, staged)[1] < 1e-5
@@ -1137,49 +1105,6 @@ def test_fc_pair(dev, M, N, K, act, ldc_pad, fast):
             assert np.array_equal(got, one)
     if fast and 2.0 * M * N * K >= 8.0e9:
         assert not np.array_equal(first[0], singles[0])             # (the paired launch really cut K differently)
-
-
-@pytest.mark.parametrize("M,N,K", [(300, 4096, 4096), (300, 1024, 25088), (640, 512, 8192), (300, 4096, 25088)])
-def test_fc_in_launch_reduction_is_bit_reproducible(dev, M, N, K):
-    """FC_REDUCE bit 0: the K ranges of the fp32 InnerProduct summed inside the launch -- every workgroup publishes its partial
-    sums as a slab (write-through stores), draws a ticket, and the tile's last arriver adds the slabs in range order
-    (csrc/mnc_internal.h, slab_last_arriver; the protocol the F(4x4) convolution's K ranges use by default).  Forty launches: every
-    result bit-identical to the first, and to the separate reduction kernel's -- a stale slab read (a missing acquire, a ticket
-    that overtook its stores) shows up as a difference between runs."""
-    rng = np.random.default_rng(M + N + K + 11)
-    a = rng.normal(size=(M, K)).astype(np.float32)
-    w = (rng.normal(size=(N, K)) * np.sqrt(2.0 / K)).astype(np.float32)
-    b = rng.normal(size=N).astype(np.float32)
-    d_a, d_w, d_b = dev.put(a), dev.put(w), dev.put(b)
-    d_o = dev.empty((M * N,), fill=np.nan)
-    first = None
-    dev.tune("FC_REDUCE", "3")
-    try:
-        for rep in range(40):
-            dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, N, 1)
-            got = dev.get(d_o, (M * N,)).copy()
-            if first is None:
-                first = got
-                assert not np.isnan(got).any()
-            else:
-                assert np.array_equal(first, got), "run %d differs from run 0 in %d values" % (rep, int((first != got).sum()))
-    finally:
-        dev.tune("FC_REDUCE", None)
-    dev.call("mnc_fc", d_a, d_w, d_b, d_o, M, N, K, N, 1)               # the default: fc_reduce_kernel
-    assert np.array_equal(first, dev.get(d_o, (M * N,)))
-    # a second input alternating with the first through the same slab addresses: a stale slab read would mix the two
-    a2 = rng.normal(size=(M, K)).astype(np.float32) * 3.0
-    d_a2 = dev.put(a2)
-    dev.call("mnc_fc", d_a2, d_w, d_b, d_o, M, N, K, N, 1)
-    second = dev.get(d_o, (M * N,)).copy()
-    dev.tune("FC_REDUCE", "3")
-    try:
-        for rep in range(8):
-            src, want = (d_a2, second) if rep & 1 else (d_a, first)
-            dev.call("mnc_fc", src, d_w, d_b, d_o, M, N, K, N, 1)
-            assert np.array_equal(dev.get(d_o, (M * N,)), want), rep
-    finally:
-        dev.tune("FC_REDUCE", None)
 
 
 @pytest.mark.parametrize("M,N,K,act", FC_SHAPES + [(300, 4096, 25088, 1), (290, 512, 65536, 0), (1000, 768, 16384, 2)])
