@@ -274,9 +274,9 @@ def main():
                 last["gathered"] = gatherer.fetch(rows=int(counts[0]) if blk is None else None)   # [world, 100, 447] on the host
             elif gatherer is not None:                              # gloo functional path (host tensors)
                 lists = split_records(rec, counts[1:], 21) if blk is None else blk.lists()
-                packed, _ = mdist.pack_instances(*lists)
+                packed, total = mdist.pack_instances(*lists, lossless=True)
                 t_d = time.perf_counter()
-                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(packed)])
+                last["gathered"] = np.stack([t.numpy() for t in gatherer.gather(packed, total)])
             else:
                 t_d = t_c
                 # numpy lists per class, exactly what gpu_mask_voting returns
@@ -880,9 +880,9 @@ def roofline_by_kernel(records, steps):
 # profiling scope of the engine -> the kernels (rocprofv3 names, regular expressions) launched inside it
 PMC_KERNEL = {"conv3x3_c8_mfma": r"conv3x3_c8_kernel", "conv3x3_wino_mfma": r"conv3x3_wino2?_kernel", "conv3x3_wino4_mfma": r"conv3x3_wino4_kernel",
               "fc_mfma": r"fc_mfma_(dma(16)?_)?kernel<(10|5)[,>]", "fc_mfma_small": r"fc_mfma_kernel<2,", "conv3x3_c3": r"conv3x3_c3_kernel",
-              "conv3x3_bf16x3": r"conv3x3_x3_kernel<\d+, \d+, \d+, 0,", "conv3x3_f16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 1,",
-              "fc_bf16x3": r"fc_x3_kernel<\d+, \d+, \d+, 0>", "fc_f16": r"fc_x3_kernel<\d+, \d+, \d+, 1>",
-              "conv3x3_bf16": r"conv3x3_x3_kernel<\d+, \d+, \d+, 2,", "fc_bf16": r"(fc_x3_kernel<\d+, \d+, \d+, 2>|fc_lowp_dma_kernel<\d+, 2>)"}
+              "conv3x3_bf16x3": r"conv3x3_sw_kernel<0,", "conv3x3_f16": r"conv3x3_sw_kernel<1,",
+              "fc_bf16x3": r"(fc_x3_kernel<\d+, \d+, \d+, 0>|fc_lowp_dma_kernel<\d+, 0>)", "fc_f16": r"(fc_x3_kernel<\d+, \d+, \d+, 1>|fc_lowp_dma_kernel<\d+, 1>)",
+              "conv3x3_bf16": r"conv3x3_sw_kernel<2,", "fc_bf16": r"(fc_x3_kernel<\d+, \d+, \d+, 2>|fc_lowp_dma_kernel<\d+, 2>)"}
 HBM_BOUND_SCOPES = {"conv3x3_c3"}          # conv1_1: 2 GFLOP over 161 MB -- bound by writing its output
 # the big InnerProducts of one 300-RoI head stage by algorithmic GFLOP, and their positions in the per-image
 # launch cycle of the InnerProduct kernel (tools/pmc_report.py --cycle).  Round 5: the box and the mask branch are launched in
@@ -940,8 +940,8 @@ def _conv3x_bytes():
 
 
 CONV3X_BYTES = _conv3x_bytes()
-CONV3X_PMC = {"fp32": "conv3x3_wino4_kernel<1, 0>", "bf16": "conv3x3_x3_kernel<2, 2, 4, 2, 0>", "f16": "conv3x3_x3_kernel<2, 2, 4, 1, 3>",
-              "bf16x3": "conv3x3_x3_kernel<2, 2, 4, 0, 3>", "mixed": "conv3x3_x3_kernel<2, 2, 4, 0, 3>"}
+CONV3X_PMC = {"fp32": "conv3x3_wino4_kernel<1, 0>", "bf16": "conv3x3_sw_kernel<2, 5, 2, 2, 1, 2>", "f16": "conv3x3_sw_kernel<1, 5, 2, 2, 1, 2>",
+              "bf16x3": "conv3x3_sw_kernel<0, 5, 2, 2, 1, 2>", "mixed": "conv3x3_sw_kernel<0, 5, 2, 2, 1, 2>"}
 CONV_EXECUTED_DIVISOR = {"conv3x3_wino4_mfma": 4.0, "conv3x3_wino_mfma": 2.25}
 
 

@@ -160,7 +160,9 @@ class NativeNet(object):
         p, dims, nd = ctypes.c_void_p(), (ctypes.c_int * 4)(), ctypes.c_int(0)
         _lib.call("mnc_net_blob", self.h, ctypes.cast(ctypes.c_char_p(b"records"), ctypes.c_void_p), ctypes.addressof(p),
                   ctypes.addressof(dims), ctypes.addressof(nd))
-        return types.SimpleNamespace(records_ptr=p.value, gather_rows=int(self.cfg.max_per_image), rec_dim=self.rec_dim)
+        # (csrc/pipeline.hip: mnc_net::outblk = [counts 256 B | proposal count 256 B | records]; counts[0] = rows of this image)
+        return types.SimpleNamespace(records_ptr=p.value, counts_ptr=p.value - 512, gather_rows=int(self.cfg.max_per_image),
+                                     rec_dim=self.rec_dim, rows_cap=self.rows_cap)
 
     def blob(self, name):
         """(host copy, shape) of an intermediate blob of the last image in the engine's device layout (tests)."""

@@ -77,6 +77,29 @@ def main():
         boxes, classes, masks = mdist.unpack_instances(got[i])
         assert np.array_equal(boxes, np.concatenate(lb, 0).astype(np.float32))
         assert np.array_equal(masks, np.concatenate(lm, 0))
+    # ---- an image whose scores tie at the voting threshold has MORE than 100 instances (gpu_mask_voting keeps
+    # every box with cls_score >= thresh: lib/transform/mask_transform.py:242-258).  Rank 5's image has 131; the lossless gather
+    # (counts first, then blocks of max(100, largest count) rows) returns every one of them on every rank, the others' unchanged.
+    def tied_results(seed, per_class):
+        rng = np.random.default_rng(seed)
+        lb = [np.hstack([rng.integers(0, 500, (n, 4)).astype(np.float64), np.full((n, 1), 0.5)]) for n in per_class]
+        lm = [rng.uniform(0, 1, (n, 1, 21, 21)).astype(np.float32) for n in per_class]
+        return lm, lb
+    per_class = [7] * 18 + [5, 0] if rank == 5 else None
+    lm, lb = tied_results(900 + rank, per_class) if rank == 5 else fake_results(900 + rank)
+    rec, total = mdist.pack_instances(lm, lb, lossless=True)
+    assert total == (131 if rank == 5 else sum(len(b) for b in lb)) and rec.shape[0] == max(mdist.REC_CAP, total)
+    blocks = g.gather(rec, total)
+    assert list(g.last_counts)[5] == 131 and all(tuple(b.shape) == (131, mdist.REC_DIM) for b in blocks)
+    for r, blk in enumerate(blocks):
+        wm, wb = tied_results(900 + r, [7] * 18 + [5, 0]) if r == 5 else fake_results(900 + r)
+        boxes, classes, masks = mdist.unpack_instances(blk.numpy())
+        assert len(boxes) == int(g.last_counts[r]) == sum(len(b) for b in wb), (r, len(boxes))
+        assert np.array_equal(boxes, np.concatenate(wb, 0).astype(np.float32)) and np.array_equal(masks, np.concatenate(wm, 0))
+    # the next step (nobody above 100) is back to [100, 447] blocks
+    rec, total = mdist.pack_instances(*fake_results(950 + rank), lossless=True)
+    blocks = g.gather(rec, total)
+    assert all(tuple(b.shape) == (mdist.REC_CAP, mdist.REC_DIM) for b in blocks)
     # ---- max-over-ranks timing as bench.py reports it
     t = torch.tensor([1.0 + 0.1 * rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

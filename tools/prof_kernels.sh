@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC stall breakdown of kernels run by tools/kernel_bench.py (run on the GPU box).
-# usage: bash tools/prof_kernels.sh <sql-like pattern, e.g. %conv3x3_x3%> <kernel_bench args...>
+# usage: bash tools/prof_kernels.sh <sql-like pattern, e.g. %conv3x3_sw%> <kernel_bench args...>
 PAT=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_k
