@@ -67,7 +67,7 @@ __host__ __device__ constexpr int sw_planes(int mode) { return mode == 0 ? 4 : 2
 __host__ __device__ constexpr int sw_pixb(int mode) { return mode == 0 ? 32 : 16; }
 
 // Geometry of one instantiation (host and device)
-template <int PR, int RG, int CG, int KW, int NBUF = 2>
+template <int PR, int RG, int CG, int KW>
 struct SwGeom {
   static constexpr int NWG = RG * CG;                        // waves of one K range
   static constexpr int NT = 64 * NWG * KW;
@@ -80,17 +80,17 @@ struct SwGeom {
   static constexpr int BUFB = AB + 2 * PLANEB;
   static constexpr int NAS = (9 * CG + NWG - 1) / NWG;       // copy slots per wave and pass
   static constexpr int NBS = (2 * PP + NWG - 1) / NWG;
-  static constexpr int DUMMY = KW * NBUF * BUFB;             // 1 KB that surplus slots fill with zeros
+  static constexpr int DUMMY = KW * 2 * BUFB;                // 1 KB that surplus slots fill with zeros
   static constexpr int RED = (KW - 1) * NWG * PR * 4096;     // K ranges' accumulators on their way to range 0
   static constexpr int LDS = (DUMMY > RED ? DUMMY : RED) + 1024;
 };
 
-template <int MODE, int PR, int RG, int CG, int KW, int NBUF>
+template <int MODE, int PR, int RG, int CG, int KW>
 __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const void* __restrict__ in_, const void* __restrict__ wpk_,
                                                                        const float* __restrict__ bias, void* __restrict__ out_pk,
                                                                        float* __restrict__ out_f32, int H, int W, int Cin, int Cout,
                                                                        int relu, int pool) {
-  typedef SwGeom<PR, RG, CG, KW, NBUF> G;
+  typedef SwGeom<PR, RG, CG, KW> G;
   constexpr int NPL = sw_planes(MODE), NPASS = MODE == 0 ? 3 : 1, PIXB = sw_pixb(MODE);
   extern __shared__ __attribute__((aligned(16))) unsigned char s_sw[];
 
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
   const sw_i32x4 in_rsrc = make_rsrc(in_, (long)nblk * blk_bytes);
   const sw_i32x4 w_rsrc = make_rsrc(wpk_, (long)nchunks * ncot * NPL * kSwPlaneB);
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)s_sw;
-  const int kwbase = kw * NBUF * G::BUFB;
+  const int kwbase = kw * 2 * G::BUFB;
 
   int vb[G::NBS];
 #pragma unroll
@@ -230,30 +230,21 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
       }
   };
 
-  // ---- main loop over the passes of this K range: NBUF buffers, the copies of pass v + NBUF - 1 are issued while pass v is
-  // multiplied (NBUF = 2: one pass ahead, wait for everything; 3: two ahead, the newest pass's NS copies may stay in flight)
-  constexpr int AHEAD = NBUF - 1;
-  auto pass_sync = []() {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((AHEAD - 1) * NS) : "memory");
-  };
-  x3_static_for<0, AHEAD>([&](auto a_) {
-    constexpr int a = decltype(a_)::value;
-    const int c = c_begin + a / NPASS;
-    const bool more = c < c_end;
+  // ---- main loop over the passes of this K range, two buffers: the copies of pass v + 1 are issued while pass v is multiplied.
+  // (Three buffers -- two passes ahead, the newest pass's copies left in flight across the barrier -- were built and measured on the
+  // 8-wave plans whose LDS holds them: no gain, profiles/r06_conv_sw.txt; removed.)
 #pragma unroll
-    for (int k = 0; k < NS; ++k) dma_slot(more ? c : c_end - 1, std::integral_constant<int, a % NPASS>(), a, k, more);
-  });
-  int bc = 0, tb = AHEAD;                                    // buffer of the pass being multiplied / being filled
+  for (int k = 0; k < NS; ++k) dma_slot(c_begin, std::integral_constant<int, 0>(), 0, k, true);
+  int bc = 0;                                                // buffer of the pass being multiplied
   for (int c = c_begin; c < c_end; ++c) {
     x3_static_for<0, NPASS>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
-      const int ct = c + (p + AHEAD) / NPASS;
+      const int ct = c + (p + 1) / NPASS;
       const bool more = ct < c_end;
       const int ctc = more ? ct : c_end - 1;
-      pass_sync();
-      compute(bc, [&](int k) { dma_slot(ctc, std::integral_constant<int, (p + AHEAD) % NPASS>(), tb, k, more); });
-      bc = bc + 1 == NBUF ? 0 : bc + 1;
-      tb = tb + 1 == NBUF ? 0 : tb + 1;
+      MNC_SW_SYNC();
+      compute(bc, [&](int k) { dma_slot(ctc, std::integral_constant<int, (p + 1) % NPASS>(), bc ^ 1, k, more); });
+      bc ^= 1;
     });
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the last pass's all-out-of-range copies)
@@ -458,12 +449,12 @@ static int sw_grid_for(long total) {
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
-template <int MODE, int PR, int RG, int CG, int KW, int NBUF = 2>
+template <int MODE, int PR, int RG, int CG, int KW>
 static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const float* d_bias, void* d_out_pk, float* d_out_f32, int H,
                      int W, int Cin, int Cout, int relu, int pool) {
-  typedef SwGeom<PR, RG, CG, KW, NBUF> G;
+  typedef SwGeom<PR, RG, CG, KW> G;
   static_assert(G::LDS <= 160 * 1024, "conv3x3_sw: LDS budget");
-  auto kern = conv3x3_sw_kernel<MODE, PR, RG, CG, KW, NBUF>;
+  auto kern = conv3x3_sw_kernel<MODE, PR, RG, CG, KW>;
   static std::atomic<unsigned long long> attr_set{0};          // one bit per device: function attributes are per device
   const unsigned long long bit = 1ull << (ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
@@ -477,14 +468,15 @@ static int launch_sw(mnc_ctx* ctx, const void* d_in, const void* d_wpk, const fl
 }
 
 // Which (RG, CG, KW) a shape runs on -- see the header comment.  Plan 0: (2, 2, 1); 1: (2, 2, 2); 2: (1, 1, 4); 3: (1, 1, 1), the
-// form every shape fits (Cout % 32 == 0).  CONVX3_TILE = 100 + plan overrides the choice where the plan fits the shape.
+// form every shape fits (Cout % 32 == 0).  CONVX3_TILE = 100 + plan overrides the choice where the plan fits the shape.  (8-wave
+// workgroups of 20 rows x 64 channels / 10 rows x 128 channels, with two and three staging buffers, were measured on conv1_2 ..
+// conv3_3 in round 6: within 2 % of plan 0 everywhere, never better -- profiles/r06_conv_sw.txt -- and removed.)
 static int sw_plan(const mnc_ctx* ctx, int H, int W, int Cin, int Cout) {
   const int nchunks = (Cin / 8 + 1) / 2;
-  const bool fits[8] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true, Cout % 64 == 0, Cout % 128 == 0,
-                        Cout % 64 == 0, Cout % 128 == 0};
+  const bool fits[4] = {Cout % 64 == 0, Cout % 64 == 0 && nchunks % 2 == 0, nchunks % 4 == 0, true};
   if (tune_set(ctx, T_CONVX3_TILE)) {
     const int p = tune(ctx, T_CONVX3_TILE, 0) - 100;
-    if (p >= 0 && p < 8 && fits[p]) return p;
+    if (p >= 0 && p < 4 && fits[p]) return p;
   }
   const long wg0 = (long)cdiv(W, kSwCols) * cdiv(H, 10) * (Cout / 64);
   if (fits[0] && wg0 >= 384) return 0;
@@ -524,10 +516,6 @@ static int conv3x3_sw(mnc_ctx* ctx, const char* name, const void* d_in, const vo
     case 0: rc = launch_sw<MODE, 5, 2, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
     case 1: rc = launch_sw<MODE, 5, 2, 2, 2>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
     case 2: rc = launch_sw<MODE, 5, 1, 1, 4>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
-    case 4: rc = launch_sw<MODE, 5, 4, 2, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
-    case 5: rc = launch_sw<MODE, 5, 2, 4, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
-    case 6: rc = launch_sw<MODE, 5, 4, 2, 1, 3>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
-    case 7: rc = launch_sw<MODE, 5, 2, 4, 1, 3>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
     default: rc = launch_sw<MODE, 5, 1, 1, 1>(ctx, d_in, d_wpk, d_bias, d_out_pk, d_out_f32, H, W, Cin, Cout, relu, pool); break;
   }
   if (rc) return rc;

@@ -105,7 +105,7 @@ def test_conv3x3_lowp(dev, mode, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("plan", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("plan", [0, 1, 2, 3])
 def test_conv3x3_lowp_every_plan(dev, mode, plan):
     """Each (row groups, channel tiles, K ranges) instantiation at a small shape that fits it, same bits wanted from none of them
     (K ranges regroup the sums) but every one inside the mode's bar; one output form at a time as well."""
@@ -167,11 +167,11 @@ def test_lowp_weight_layout(dev):
 
 
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("H,W,Cin,Cout,plan", [(75, 125, 32, 64, None), (20, 64, 16, 128, 0), (23, 70, 64, 128, 1), (37, 33, 32, 128, 4),
-                                               (10, 31, 16, 128, 5), (41, 97, 48, 128, 6), (30, 100, 32, 128, 7), (150, 250, 16, 256, None)])
+@pytest.mark.parametrize("H,W,Cin,Cout,plan", [(75, 125, 32, 64, None), (20, 64, 16, 128, 0), (23, 70, 64, 128, 1), (37, 33, 64, 128, 2),
+                                               (10, 31, 16, 96, 3), (41, 97, 48, 128, 0), (30, 100, 32, 128, 1), (150, 250, 16, 256, None)])
 def test_conv3x3_lowp_pool(dev, mode, H, W, Cin, Cout, plan):
     """The Pooling MAX 2x2/2 (ceil output size) folded into the epilogue == mnc_maxpool2_c8_<mode> of the unpooled packed output, bit
-    for bit: odd heights and widths (a window of one row / one column), every plan with even row groups, K ranges inside the workgroup."""
+    for bit: odd heights and widths (a window of one row / one column), every plan (the one-row-group plans pool through the pooling kernel), K ranges inside the workgroup."""
     m = MODES[mode]
     rng = np.random.default_rng(H * 7 + W)
     x = rng.normal(size=(Cin, H, W)).astype(np.float32)
