@@ -936,12 +936,14 @@ def _conv3x_bytes():
             for ob in (2, 4):
                 out.add(hw * (cin * ib + cout * ob) + 36.0 * cin * cout)      # the kernels' LaunchScope formula (4-byte weights)
         out.add(4.0 * (hw * cin + (hw // 4) * cout + 9 * cin * cout))         # fp32 with the Pooling fused (conv3_3)
+        for ib in (2, 4):                                                      # reduced precision, Pooling fused (round 6: conv_sw.hip)
+            out.add(hw * cin * ib + 75 * 125 * cout * ib + 36.0 * cin * cout)
     return tuple(sorted(out))
 
 
 CONV3X_BYTES = _conv3x_bytes()
-CONV3X_PMC = {"fp32": "conv3x3_wino4_kernel<1, 0>", "bf16": "conv3x3_sw_kernel<2, 5, 2, 2, 1, 2>", "f16": "conv3x3_sw_kernel<1, 5, 2, 2, 1, 2>",
-              "bf16x3": "conv3x3_sw_kernel<0, 5, 2, 2, 1, 2>", "mixed": "conv3x3_sw_kernel<0, 5, 2, 2, 1, 2>"}
+CONV3X_PMC = {"fp32": "conv3x3_wino4_kernel<1, 0>", "bf16": "conv3x3_sw_kernel<2, 5, 2, 2, 1>", "f16": "conv3x3_sw_kernel<1, 5, 2, 2, 1>",
+              "bf16x3": "conv3x3_sw_kernel<0, 5, 2, 2, 1>", "mixed": "conv3x3_sw_kernel<0, 5, 2, 2, 1>"}
 CONV_EXECUTED_DIVISOR = {"conv3x3_wino4_mfma": 4.0, "conv3x3_wino_mfma": 2.25}
 
 

@@ -20,7 +20,7 @@ python $REPO/tools/rocpd_summary.py $OUT/trace1/bench_results.db > $OUT/kernel_t
 python $REPO/tools/timeline_gaps.py $OUT/trace1/bench_results.db --top 15 > $OUT/timeline_gaps_fp32_serial.txt
 rm -rf $OUT/trace1
 BUILD=$(cd $REPO && python -m mnc_amd._build --hash)
-python $REPO/tools/pmc_report.py $OUT/pmc_mfma/bench_results.db $OUT/pmc_fetch/bench_results.db $OUT/pmc_write/bench_results.db --json $OUT/pmc.json --build $BUILD --cycle=fc_mfma_dma=6 '--cycle=conv3x3_wino4_kernel<1, 0>=6' '--cycle=conv3x3_sw_kernel<2, 5, 2, 2, 1, 2>=6' '--cycle=conv3x3_sw_kernel<1, 5, 2, 2, 1, 2>=6' '--cycle=conv3x3_sw_kernel<0, 5, 2, 2, 1, 2>=6' > $OUT/pmc.txt
+python $REPO/tools/pmc_report.py $OUT/pmc_mfma/bench_results.db $OUT/pmc_fetch/bench_results.db $OUT/pmc_write/bench_results.db --json $OUT/pmc.json --build $BUILD --cycle=fc_mfma_dma=6 '--cycle=conv3x3_wino4_kernel<1, 0>=6' '--cycle=conv3x3_sw_kernel<2, 5, 2, 2, 1>=6' '--cycle=conv3x3_sw_kernel<1, 5, 2, 2, 1>=6' '--cycle=conv3x3_sw_kernel<0, 5, 2, 2, 1>=6' > $OUT/pmc.txt
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
 # the bench line LAST, with this build's counter profile in place: its roofline.traffic comes from profiles/pmc_latest.json and is
 # reported only when that file carries this build's hash (copy $OUT/pmc.json to profiles/pmc_latest.json in the repo afterwards)
