@@ -39,7 +39,7 @@
 
 // Tuning ablations (never set in a product build; wrong results): 1 = no copies inside the loop, 2 = no fragment reads (MFMAs on
 // register constants), 4 = no output stores, 8 = the copies inside the loop carry only out-of-range lanes,
-// 16 / 32 = every pass copies the first chunk's weights / halo again (cache hits)
+// 16 / 32 = every pass copies the first chunk's weights / halo again (cache hits), 64 = no wait and no barrier between the passes, 128 = both buffers filled with the first pass's (real) data before the loop (with 1: MFMAs on real operands, no copies)
 #ifndef MNC_SW_ABL
 #define MNC_SW_ABL 0
 #endif
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
   // Copy slot k (of NS per wave and pass) of pass `pass` of chunk c -> buffer `buf` of this K range.  live == false (behind the
   // last pass): every lane out of range -- zeros into the free buffer, no memory traffic, the loop body stays one basic block.
   constexpr int NS = G::NAS + G::NBS;
-  auto dma_slot = [&](int c, auto pass_, int buf, int k, bool more) {
+  auto dma_slot = [&](int c, auto pass_, int buf, int k, bool more, bool in_loop = true) {
     constexpr int pass = decltype(pass_)::value;
-    if (MNC_SW_ABL & 1) return;
+    if ((MNC_SW_ABL & 1) && in_loop) return;
     if (MNC_SW_ABL & 8) more = false;                          // copies issued, every lane out of range: issue cost without traffic
     const sw_i32x4 wr = w_rsrc, ir = in_rsrc;                  // (named here: a generic lambda does not capture what only an asm operand uses)
     const unsigned base = lds0 + (unsigned)(kwbase + buf * G::BUFB);
@@ -234,7 +234,11 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
   // (Three buffers -- two passes ahead, the newest pass's copies left in flight across the barrier -- were built and measured on the
   // 8-wave plans whose LDS holds them: no gain, profiles/r06_conv_sw.txt; removed.)
 #pragma unroll
-  for (int k = 0; k < NS; ++k) dma_slot(c_begin, std::integral_constant<int, 0>(), 0, k, true);
+  for (int k = 0; k < NS; ++k) dma_slot(c_begin, std::integral_constant<int, 0>(), 0, k, true, false);
+  if (MNC_SW_ABL & 128) {                                    // ablation 128 (+ 1): both buffers hold real data, no copies in the loop
+#pragma unroll
+    for (int k = 0; k < NS; ++k) dma_slot(c_begin, std::integral_constant<int, 0>(), 1, k, true, false);
+  }
   int bc = 0;                                                // buffer of the pass being multiplied
   for (int c = c_begin; c < c_end; ++c) {
     x3_static_for<0, NPASS>([&](auto p_) {
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
       const int ct = c + (p + 1) / NPASS;
       const bool more = ct < c_end;
       const int ctc = more ? ct : c_end - 1;
-      MNC_SW_SYNC();
+      if (!(MNC_SW_ABL & 64)) MNC_SW_SYNC();                  // (ablation 64: no wait, no barrier -- racy, timing only)
       compute(bc, [&](int k) { dma_slot(ctc, std::integral_constant<int, (p + 1) % NPASS>(), bc ^ 1, k, more); });
       bc ^= 1;
     });

@@ -763,11 +763,15 @@ __global__ __launch_bounds__(256) void fc_reduce_slab_kernel(const float* __rest
 // SM != 0 (VEC = 4 only): the result rows are written a second time in the stage-major 2-byte form the NEXT reduced-precision
 // InnerProduct multiplies from (x3_split.h: sm_store4; sm_rows rows, this call's rows start at sm_row0) -- fc6 -> fc7 without
 // a conversion pass.
+// blockIdx.y == 1 (round 6: the reductions of a PAIR of products in one launch, mnc_fc_lowp_pair): the second set of pointers.
 template <int VEC, int SM = 0>
 __global__ __launch_bounds__(256) void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                         float* __restrict__ out, int M, int N, int ldc, int splits,
                                                         int act, void* __restrict__ sm = nullptr, long sm_rows = 0,
-                                                        long sm_row0 = 0) {
+                                                        long sm_row0 = 0, const float* __restrict__ part1 = nullptr,
+                                                        const float* __restrict__ bias1 = nullptr, float* __restrict__ out1 = nullptr,
+                                                        void* __restrict__ sm1 = nullptr) {
+  if (blockIdx.y) { part = part1; bias = bias1; out = out1; sm = sm1; }
   const long total = (long)M * N;
   if (VEC == 4) {
     const int n4 = N >> 2;
@@ -829,6 +833,31 @@ bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bia
   else if (vec) hipLaunchKernelGGL((fc_reduce_kernel<4, 0>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0L, 0L);
   else hipLaunchKernelGGL((fc_reduce_kernel<1, 0>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0L, 0L);
   return sm_ok;
+}
+
+// The reductions of two products of one shape as ONE launch (grid.y = 2); false when the pair cannot share a launch (the caller then
+// makes two fc_reduce_launch_sm calls): both need the vector path and the same second-output decision.
+bool fc_reduce_pair_launch_sm(hipStream_t stream, const float* part0, const float* part1, const float* bias0, const float* bias1,
+                              float* out0, float* out1, int M, int N, int ldc, int splits, int act, void* sm0, void* sm1, int sm_fmt,
+                              long sm_rows, bool* sm_done) {
+  const bool vec = N % 4 == 0 && ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(out0) | reinterpret_cast<uintptr_t>(out1) |
+                                                   reinterpret_cast<uintptr_t>(bias0) | reinterpret_cast<uintptr_t>(bias1)) & 15) == 0;
+  if (!vec || (sm0 != nullptr) != (sm1 != nullptr)) return false;
+  const long items = (long)M * N / 4;
+  int g = (int)((items + 255) / 256);
+  if (g > 4096) g = 4096;
+  const bool sm_ok = sm0 && ((sm_fmt == 1 && N % 64 == 0) || (sm_fmt == 2 && N % 32 == 0));
+  if (sm_ok && sm_fmt == 1)
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 1>), dim3(g, 2), dim3(256), 0, stream, part0, bias0, out0, M, N, ldc, splits, act, sm0, sm_rows, 0L,
+                       part1, bias1, out1, sm1);
+  else if (sm_ok)
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 2>), dim3(g, 2), dim3(256), 0, stream, part0, bias0, out0, M, N, ldc, splits, act, sm0, sm_rows, 0L,
+                       part1, bias1, out1, sm1);
+  else
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 0>), dim3(g, 2), dim3(256), 0, stream, part0, bias0, out0, M, N, ldc, splits, act, (void*)nullptr, 0L,
+                       0L, part1, bias1, out1, (void*)nullptr);
+  *sm_done = sm_ok;
+  return true;
 }
 
 __global__ void softmax_rows_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int M, int N) {

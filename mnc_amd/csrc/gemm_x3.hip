@@ -822,9 +822,17 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   float* outs[2] = {d_out0, d_out1};
   const float* biases[2] = {d_bias0, d_bias1};
   void* osms[2] = {d_osm0, d_osm1};
+  bool pair_done = false, pair_sm = false;
+  if (splits > 1) {                                  // both products' K ranges summed by ONE launch (grid.y = 2) where they can share it
+    LaunchScope ls(ctx, "fc_reduce", 0.0, 8.0 * ((double)splits + 1.0) * M * N);
+    pair_done = fc_reduce_pair_launch_sm(ctx->stream, part, part + (size_t)splits * M * N, d_bias0, d_bias1, d_out0, d_out1, M, N, ldc, splits,
+                                         act, d_osm0, d_osm1, osm_fmt, M, &pair_sm);
+    rc = ls.finish("fc_reduce_kernel<pair>");
+    if (rc) return rc;
+  }
   for (int i = 0; i < 2; ++i) {
-    bool osm_done = false;
-    if (splits > 1) {
+    bool osm_done = pair_done && pair_sm;
+    if (splits > 1 && !pair_done) {
       LaunchScope ls(ctx, "fc_reduce", 0.0, 4.0 * ((double)splits + 1.0) * M * N);
       osm_done = fc_reduce_launch_sm(ctx->stream, part + (size_t)i * splits * M * N, biases[i], outs[i], M, N, ldc, splits, act, osms[i],
                                      osms[i] ? osm_fmt : 0, M, 0);

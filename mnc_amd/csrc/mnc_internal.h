@@ -251,6 +251,9 @@ void fc_reduce_launch(hipStream_t stream, const float* part, const float* bias, 
                       int act);   // gemm.hip: out = act(sum of the K splits' partial sums + bias), shared by the three FC kernels
 bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
                          int act, void* sm, int sm_fmt, long sm_rows, long sm_row0);   // + the rows in the next InnerProduct's form
+bool fc_reduce_pair_launch_sm(hipStream_t stream, const float* part0, const float* part1, const float* bias0, const float* bias1,
+                              float* out0, float* out1, int M, int N, int ldc, int splits, int act, void* sm0, void* sm1, int sm_fmt,
+                              long sm_rows, bool* sm_done);   // two products' reductions in one launch (gemm.hip)
 void conv_splitk_reduce_launch(hipStream_t stream, const float* d_part, const float* d_bias, float* d_out, int H, int W,
                                int Cout, int ksplit, int relu);
 // proposal.hip: finishes the sibling classifiers of a head stage in one launch -- the K ranges of [cls_score | seg_cls_score |
