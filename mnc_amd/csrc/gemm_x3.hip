@@ -757,8 +757,7 @@ template <int F16>
 static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const uint4* d_pre0, const float* d_a1, const uint4* d_pre1,
                         int mstride, const void* d_w0, const void* d_w1, const float* d_bias0, const float* d_bias1, float* d_out0,
                         float* d_out1, int M, int N, int K, int ldc, int act, void* d_osm0, void* d_osm1, int osm_fmt) {
-  static_assert(F16 != 0, "pairs: fp16 / bf16 only");
-  constexpr int kStage = 64;
+  constexpr int kStage = F16 ? 64 : kXBK;
   if (M == 0) return MNC_OK;
   const int stages = K / kStage, tn = N / 256;
   bool paired = M > 160 && M <= 320 && N % 256 == 0 && N >= 512 && 2.0 * M * (double)N * K >= 2.0e9 && tune(ctx, T_FCX3_WIDE, 1) != 0 &&
@@ -766,9 +765,9 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   int splits = 1;
   if (paired) {
     splits = cdiv(256, 2 * tn);
-    if (splits > stages / 4) splits = stages / 4;
+    if (splits > stages / (F16 ? 4 : 8)) splits = stages / (F16 ? 4 : 8);
     if (splits < 1) splits = 1;
-    paired = stages / splits >= 8;
+    paired = stages / splits >= (F16 ? 8 : 16);                // (the 256-column kernel's own bar: fc_lowp)
   }
   if (!paired) {
     int rc = fc_lowp<F16>(ctx, what, d_a0, d_pre0, d_a0 ? M : mstride, d_w0, d_bias0, d_out0, M, N, K, ldc, act, d_osm0,
@@ -781,7 +780,7 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   splits = cdiv(K, kper);
   // scratch arena: [partial sums of both products | activations that arrive as fp32, in their 2-byte stage-major form]
   const size_t part_bytes = splits > 1 ? (((size_t)2 * splits * M * N * 4 + 255) & ~(size_t)255) : 0;
-  const size_t conv_bytes = ((size_t)M * K * 2 + 255) & ~(size_t)255;
+  const size_t conv_bytes = ((size_t)M * K * (F16 ? 2 : 4) + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, part_bytes + (d_pre0 ? 0 : conv_bytes) + (d_pre1 ? 0 : conv_bytes));
   if (rc) return rc;
   float* part = splits > 1 ? (float*)ctx->scratch : nullptr;
@@ -792,9 +791,10 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
     const float* a32[2] = {d_a0, d_a1};
     for (int i = 0; i < 2; ++i) {
       if (ax[i]) continue;
-      LaunchScope ls(ctx, "fc_f16_convert", 0.0, 6.0 * M * (double)K);
-      f16_pack_launch(ctx, a32[i], (uint4*)conv, M, K, M, 1, F16 == 2);
-      rc = ls.finish("pack_f16_kernel");
+      LaunchScope ls(ctx, F16 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (F16 ? 6.0 : 8.0) * M * (double)K);
+      if (F16) f16_pack_launch(ctx, a32[i], (uint4*)conv, M, K, M, 1, F16 == 2);
+      else x3_pack_launch(ctx, a32[i], (uint4*)conv, M, K, M, 1);
+      rc = ls.finish(F16 ? "pack_f16_kernel" : "pack_x3_kernel");
       if (rc) return rc;
       ax[i] = (const uint4*)conv;
       ms[i] = M;
@@ -803,8 +803,8 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   }
   MNC_REQUIRE(ms[0] == ms[1], "%s: the two activation panels need one row stride", what);
   {
-    const double flops = 4.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K) + 8.0 * (double)M * N;
-    LaunchScope ls(ctx, F16 == 2 ? "fc_bf16" : "fc_f16", flops, bytes);
+    const double flops = 4.0 * M * (double)N * K, bytes = (F16 ? 4.0 : 8.0) * ((double)N * K + (double)M * K) + 8.0 * (double)M * N;
+    LaunchScope ls(ctx, F16 == 2 ? "fc_bf16" : F16 ? "fc_f16" : "fc_bf16x3", flops, bytes);
     constexpr int lds = 2 * (320 + 256) * 128;
     static std::atomic<unsigned long long> attr_set{0};            // one bit per device
     const unsigned long long bit = 1ull << (ctx->device & 63);
@@ -952,8 +952,8 @@ int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, 
 }
 
 // Two InnerProducts of one shape in reduced precision (mode 1 = fp16, 2 = plain bf16; each input as fp32 rows OR stage-major, each
-// output optionally a second time in the next InnerProduct's stage-major form): see fc_lowp_pair above.  mode 0 (split bf16) and
-// shapes the paired kernel does not take: exactly the two single calls.
+// output optionally a second time in the next InnerProduct's stage-major form): see fc_lowp_pair above.  mode 0 = split bf16 (32-deep
+// stages, >= 16 per K range).  Shapes the paired kernel does not take: exactly the two single calls.
 int mnc_fc_lowp_pair(mnc_ctx* ctx, int mode, const float* d_a0, const void* d_a_sm0, const float* d_a1, const void* d_a_sm1, int m_stride,
                      const void* d_w0, const void* d_w1, const float* d_bias0, const float* d_bias1, float* d_out0, float* d_out1, int M,
                      int N, int K, int ldc, int act, void* d_out_sm0, void* d_out_sm1, int out_sm_fmt) {
@@ -962,13 +962,9 @@ int mnc_fc_lowp_pair(mnc_ctx* ctx, int mode, const float* d_a0, const void* d_a_
   MNC_REQUIRE(M >= 0 && ((d_a0 && d_a1) || m_stride >= M) && N > 0 && K > 0 && K % (mode ? 64 : kXBK) == 0 && ldc >= N && act >= 0 && act <= 2 &&
                   ((!d_out_sm0 && !d_out_sm1) || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
               "mnc_fc_lowp_pair: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
-  if (mode == 0) {
-    int rc = fc_lowp<0>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a0 ? M : m_stride, d_w0, d_bias0, d_out0, M, N, K, ldc, act,
-                        d_out_sm0, d_out_sm0 ? out_sm_fmt : 0, M, 0);
-    if (rc) return rc;
-    return fc_lowp<0>(ctx, "mnc_fc_lowp_pair", d_a1, (const uint4*)d_a_sm1, d_a1 ? M : m_stride, d_w1, d_bias1, d_out1, M, N, K, ldc, act,
-                      d_out_sm1, d_out_sm1 ? out_sm_fmt : 0, M, 0);
-  }
+  if (mode == 0)
+    return fc_lowp_pair<0>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a1, (const uint4*)d_a_sm1, m_stride, d_w0, d_w1, d_bias0,
+                           d_bias1, d_out0, d_out1, M, N, K, ldc, act, d_out_sm0, d_out_sm1, out_sm_fmt);
   if (mode == 1)
     return fc_lowp_pair<1>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a1, (const uint4*)d_a_sm1, m_stride, d_w0, d_w1, d_bias0,
                            d_bias1, d_out0, d_out1, M, N, K, ldc, act, d_out_sm0, d_out_sm1, out_sm_fmt);

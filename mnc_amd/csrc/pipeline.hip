@@ -569,16 +569,17 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
                         (const float*)n->fc6m.w, n->fc6m.b, (float*)n->f6m.p, R, F, n->fc6.K, F, 1));
     NET_TRY(mnc_fc_pair(ctx, (const float*)n->f6.p, (const float*)n->fc7.w, n->fc7.b, join + F, (const float*)n->f6m.p,
                         (const float*)n->fc7m.w, n->fc7m.b, join, R, F, F, 2 * F, 1));
-  } else if (n->fuse_small && one_pass && !fork && (n->fc6.kind == 2 || n->fc6.kind == 3) && n->fc6m.kind == n->fc6.kind &&
+  } else if (n->fuse_small && one_pass && !fork && n->fc6.kind != 0 && n->fc6m.kind == n->fc6.kind &&
              n->fc7.kind == n->fc6.kind && n->fc7m.kind == n->fc6.kind && n->fc6.K == n->fc6m.K && sm_f6 == sm_f6m && R > 0) {
-    // fp16 / plain bf16 (round 6): the same pairs on the 256-column reduced-precision kernel (mnc_fc_lowp_pair; engine.py pairs the
-    // same layers).  Inputs in their stage-major form where the producer wrote it, outputs of fc6 / fc6_mask a second time in fc7's.
-    const int mode = n->fc6.kind == 2 ? 1 : 2;
-    const bool pre6 = sm_box == 1, pre7 = sm_f6 == 1;
+    // fp16 / plain bf16 / split bf16 (round 6): the same pairs on the 256-column reduced-precision kernel (mnc_fc_lowp_pair; engine.py
+    // pairs the same layers).  Inputs in their stage-major form where the producer wrote it, outputs of fc6 / fc6_mask a second time in
+    // fc7's (format 1 = fp16, 2 = split bf16).
+    const int mode = n->fc6.kind == 1 ? 0 : n->fc6.kind == 2 ? 1 : 2;
+    const bool pre6 = sm_box != 0, pre7 = sm_f6 != 0;
     NET_TRY(mnc_fc_lowp_pair(ctx, mode, pre6 ? nullptr : (const float*)n->box7.p, pre6 ? n->box7_sm.p : nullptr,
                              pre6 ? nullptr : (const float*)n->mask7.p, pre6 ? n->mask7_sm.p : nullptr, R, n->fc6.w, n->fc6m.w, n->fc6.b,
                              n->fc6m.b, (float*)n->f6.p, (float*)n->f6m.p, R, F, n->fc6.K, F, 1, pre7 ? n->f6_sm.p : nullptr,
-                             pre7 ? n->f6m_sm.p : nullptr, pre7 ? 1 : 0));
+                             pre7 ? n->f6m_sm.p : nullptr, sm_f6));
     NET_TRY(mnc_fc_lowp_pair(ctx, mode, pre7 ? nullptr : (const float*)n->f6.p, pre7 ? n->f6_sm.p : nullptr,
                              pre7 ? nullptr : (const float*)n->f6m.p, pre7 ? n->f6m_sm.p : nullptr, R, n->fc7.w, n->fc7m.w, n->fc7.b,
                              n->fc7m.b, join + F, join, R, F, F, 2 * F, 1, nullptr, nullptr, 0));

@@ -624,7 +624,7 @@ class Net(object):
         # early because of the one-pass pooling above) -- are ONE launch (mnc_fc_pair: half the K ranges, half the partial sums).
         # The whole-image pipeline pairs the same layers (csrc/pipeline.hip: run_stage), so the two executors keep the same bits.
         # Round 6: fp16 / plain bf16 InnerProducts pair the same way (mnc_fc_lowp_pair).
-        if os.environ.get("MNC_FUSE_SMALL", "1") != "0" and self.fc_math in ("fp32", "f16", "bf16"):
+        if os.environ.get("MNC_FUSE_SMALL", "1") != "0" and self.fc_math in ("fp32", "f16", "bf16", "bf16x3"):
             produced_at = {}
             for i, L in enumerate(self._layers):
                 if L.skip:
@@ -1276,7 +1276,7 @@ class Net(object):
                 return self._dev_param(key + ("w",) + geo + tag, build), "rhwc", fn
             return self._dev_param(key + ("w", "plain") + tag, lambda: finish(self._upload(W))), "plain", fn
 
-        LOWP_PAIR = {"mnc_fc_f16": 1, "mnc_fc_bf16": 2}          # mnc_fc_lowp_pair's mode per single-call entry point
+        LOWP_PAIR = {"mnc_fc_bf16x3": 0, "mnc_fc_f16": 1, "mnc_fc_bf16": 2}          # mnc_fc_lowp_pair's mode per single-call entry point
 
         def lowp_args(M):
             """(fp32 rows or None, stage-major rows or None, dst, second-output format, second output or None) of this layer's
@@ -1310,8 +1310,8 @@ class Net(object):
                               other["w"], d_b, other["b"], dst, other["dst"], M, n_out, K, top._ld(), act, osm, other["osm"], ofmt)
                     P.pair_done = True
                     return
-                if state["fn"] == "mnc_fc_f16":
-                    _lib.call("mnc_fc_f16_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
+                if state["fn"] in ("mnc_fc_f16", "mnc_fc_bf16x3"):
+                    _lib.call(state["fn"] + "_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
                 else:
                     _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
                 return

@@ -59,12 +59,12 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
         # fc7, fc6_mask, fc7_mask -- _X3_MIN_FLOPS = 0 makes mask_pred one of them, and with K = 32 it takes the split-bf16 kernel
         # in the f16 mode too; the merged sibling heads stay fp32); none converts its input rows itself
         n_ex = calls.get("mnc_fc_f16_ex", 0) + calls.get("mnc_fc_bf16x3_ex", 0)
-        # round 6: in the f16 mode fc6 + fc6_mask and fc7 + fc7_mask of a stage are one mnc_fc_lowp_pair call each (their inputs both
+        # round 6: fc6 + fc6_mask and fc7 + fc7_mask of a stage are one mnc_fc_lowp_pair call each (fp16 and split bf16) (their inputs both
         # exist when the first runs: the one-pass pooling of the fused plan)
         n_pair = calls.get("mnc_fc_lowp_pair", 0)
         assert runs in (1, 2) and n_ex + 2 * n_pair == 12 * runs and "mnc_roi_warp" not in calls
-        assert n_pair == (4 * runs if (fuse and math == "f16") else 0)
-        assert calls.get(ex, 0) + (2 * n_pair if math == "f16" else 0) >= 10 * runs
+        assert n_pair == (4 * runs if fuse else 0)
+        assert calls.get(ex, 0) + 2 * n_pair >= 10 * runs
         assert "mnc_fc_f16" not in calls and "mnc_fc_bf16x3" not in calls
         # the box-feature Pooling and MaskPooling + Pooling of a stage read the same tensor: one pass, both second outputs
         assert calls.get("mnc_box_mask_pool") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
@@ -120,7 +120,7 @@ def test_fusion_plan(fake_gpu):
     assert net.outputs == ["cls_prob", "cls_prob_ext", "seg_cls_prob_ext", "bbox_pred_ext"]
     assert [m.name for m in L["cls_score"].group] == ["cls_score", "seg_cls_score", "bbox_pred"]
     assert L["bbox_pred"].group_leader is L["cls_score"] and net.blobs["bbox_pred"]._view[1] == 42
-    # the box and the mask branch's InnerProducts of a stage are launched in pairs (mnc_fc_pair) -- fp32 InnerProducts only
+    # the box and the mask branch's InnerProducts of a stage are launched in pairs (mnc_fc_pair; the reduced-precision modes: mnc_fc_lowp_pair)
     for a, b in (("fc6", "fc6_mask"), ("fc7", "fc7_mask"), ("fc6_ext", "fc6_mask_ext"), ("fc7_ext", "fc7_mask_ext")):
         assert L[a].pair is L[b] and L[b].pair_leader is L[a], (a, b)
     assert L["fc6_maskest"].pair is None and L["fc6_maskest"].pair_leader is None
@@ -133,8 +133,9 @@ def test_fusion_plan(fake_gpu):
     assert fake_gpu.calls.get("mnc_fc_pair") == 2 * stages          # fc6 + fc6_mask, fc7 + fc7_mask per stage
     assert fake_gpu.calls.get("mnc_fc") == 3 * stages               # fc6_maskest, mask_pred, the sibling classifiers' GEMM per stage
     net.close()
-    net3 = Net(path, w, 1, device_id=0, math="bf16x3")
-    assert all(l.pair is None for l in net3._layers)
+    net3 = Net(path, w, 1, device_id=0, math="bf16x3")           # round 6: the reduced-precision modes pair the same layers (mnc_fc_lowp_pair)
+    L3 = {l.name: l for l in net3._layers}
+    assert L3["fc6"].pair is L3["fc6_mask"] and L3["fc7"].pair is L3["fc7_mask"] and L3["fc6_maskest"].pair is None
     net3.close()
 
 

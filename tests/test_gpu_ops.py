@@ -1179,54 +1179,57 @@ def test_fc_f16(dev, M, N, K, act, tune):
         assert np.array_equal(wide[:, :N], got) and np.isnan(wide[:, N:]).all()
 
 
-@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("mode", ["f16", "bf16", "bf16x3"])
 @pytest.mark.parametrize("M,N,K,pre", [(300, 4096, 6272, True), (300, 1024, 4096, False), (200, 512, 2048, True), (300, 4096, 25088, True),
                                        (120, 512, 4096, False), (300, 384, 4096, False)])
 def test_fc_lowp_pair(dev, mode, M, N, K, pre, tune):
-    """mnc_fc_lowp_pair (round 6): two reduced-precision InnerProducts of one shape in one launch.  Each product exact against torch
-    on the rounded operands (1e-5 of the range: only the summation order differs), written as a column slice (ldc = 2 N: fc7 /
-    fc7_mask's Concat in place), inputs as fp32 rows or stage-major, the second outputs bit for bit mnc_fc_pack_act of the fp32 rows;
-    the same bits on every launch; shapes the paired kernel does not take (M <= 160, N % 256 != 0) equal the two single calls."""
-    m = {"f16": 1, "bf16": 2}[mode]
-    rnd = (lambda x: x.astype(np.float16).astype(np.float32)) if mode == "f16" else _rbf16
+    """mnc_fc_lowp_pair (round 6): two reduced-precision InnerProducts of one shape in one launch.  Each product against torch on the
+    operands the mode rounds to (fp16 / bf16: 1e-5 of the range -- only the summation order differs; split bf16: 1e-4 against fp32),
+    written as a column slice (ldc = 2 N: fc7 / fc7_mask's Concat in place), inputs as fp32 rows or stage-major, the second outputs
+    bit for bit mnc_fc_pack_act of the fp32 rows; the same bits on every launch; shapes the paired kernel does not take (M <= 160,
+    N % 256 != 0) equal the two single calls."""
+    m = {"bf16x3": 0, "f16": 1, "bf16": 2}[mode]
+    rnd = (lambda x: x.astype(np.float16).astype(np.float32)) if mode == "f16" else _rbf16 if mode == "bf16" else (lambda x: x)
     rng = np.random.default_rng(M + N + K + m)
     a = [rng.normal(size=(M, K)).astype(np.float32) for _ in range(2)]
     w = [(rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32) for _ in range(2)]
     b = [rng.normal(size=N).astype(np.float32) for _ in range(2)]
     d_a = [dev.put(x) for x in a]
     d_b = [dev.put(x) for x in b]
+    wpv = 1 if mode == "bf16x3" else 2                    # values per 32-bit word of the packed forms
     d_w = []
     for x in w:
-        d = dev.empty(((N + 127) // 128 * 128 * K // 2,), fill=np.nan)
+        d = dev.empty(((N + 127) // 128 * 128 * K // wpv,), fill=np.nan)
         dev.call("mnc_pack_fc_" + mode, dev.put(x), d, N, K)
         d_w.append(d)
-    use_pre = pre and mode == "f16"                      # (the stage-major activation form exists for fp16 / split bf16)
+    sm_fmt = {"f16": 1, "bf16x3": 2}.get(mode, 0)         # (the stage-major activation form exists for fp16 / split bf16)
+    use_pre = pre and sm_fmt != 0
     d_sm = [None, None]
     if use_pre:
         for i in range(2):
-            d_sm[i] = dev.empty((M * K // 2,), fill=np.nan)
-            dev.call("mnc_fc_pack_act", d_a[i], d_sm[i], M, K, 1)
+            d_sm[i] = dev.empty((M * K // wpv,), fill=np.nan)
+            dev.call("mnc_fc_pack_act", d_a[i], d_sm[i], M, K, 1 if mode == "f16" else 0)
     ld = 2 * N
-    want_osm = mode == "f16" and N % 64 == 0
+    want_osm = sm_fmt != 0 and N % 64 == 0
     outs = []
     for rep in range(2):
         d_o = dev.empty((M * ld,), fill=np.nan)
-        d_osm = [dev.empty((M * N // 2,), fill=np.nan) if want_osm else None for _ in range(2)]
+        d_osm = [dev.empty((M * N // wpv,), fill=np.nan) if want_osm else None for _ in range(2)]
         dev.call("mnc_fc_lowp_pair", m, None if use_pre else d_a[0], d_sm[0], None if use_pre else d_a[1], d_sm[1], M, d_w[0], d_w[1],
-                 d_b[0], d_b[1], d_o + N * 4, d_o, M, N, K, ld, 1, d_osm[0], d_osm[1], 1 if want_osm else 0)
+                 d_b[0], d_b[1], d_o + N * 4, d_o, M, N, K, ld, 1, d_osm[0], d_osm[1], sm_fmt if want_osm else 0)
         o = dev.get(d_o, (M, ld))
-        outs.append((o, [dev.get(x, (M * N // 2,)).view(np.uint32) if x else None for x in d_osm]))
+        outs.append((o, [dev.get(x, (M * N // wpv,)).view(np.uint32) if x else None for x in d_osm]))
     o = outs[0][0]
     assert np.array_equal(o, outs[1][0]) and not np.isnan(o).any()
     got = [o[:, N:], o[:, :N]]
     for i in range(2):
-        ref = np.maximum(rnd(a[i]) @ rnd(w[i]).T.astype(np.float64) + b[i], 0)
+        ref = np.maximum(rnd(a[i]).astype(np.float64) @ rnd(w[i]).T.astype(np.float64) + b[i], 0)
         d, rel = err(got[i], ref)
-        assert rel < 1e-5, (i, d, rel)
+        assert rel < (1e-4 if mode == "bf16x3" else 1e-5), (i, d, rel)
         if want_osm:
-            d_chk = dev.empty((M * N // 2,), fill=np.nan)
-            dev.call("mnc_fc_pack_act", dev.put(np.ascontiguousarray(got[i])), d_chk, M, N, 1)
-            assert np.array_equal(dev.get(d_chk, (M * N // 2,)).view(np.uint32), outs[0][1][i])
+            d_chk = dev.empty((M * N // wpv,), fill=np.nan)
+            dev.call("mnc_fc_pack_act", dev.put(np.ascontiguousarray(got[i])), d_chk, M, N, 1 if mode == "f16" else 0)
+            assert np.array_equal(dev.get(d_chk, (M * N // wpv,)).view(np.uint32), outs[0][1][i])
     if M <= 160 or N % 256:       # not paired: the two single calls, bit for bit
         for i in range(2):
             d_s = dev.empty((M * N,), fill=np.nan)
