@@ -1304,11 +1304,12 @@ def test_profiling_records(dev):
 
 # ---- size-independent properties at BASELINE's full sizes (the oracle is too slow there) -----------------------------------
 @pytest.mark.parametrize("fn,pack,pitch", [("mnc_conv3x3", "mnc_pack_conv3x3_weights", 76),
-                                           ("mnc_conv3x3_bf16x3", "mnc_pack_conv3x3_bf16x3", 84)])
+                                           ("mnc_conv3x3_bf16x3", "mnc_pack_conv3x3_bf16x3", 84),
+                                           ("mnc_conv3x3_f16", "mnc_pack_conv3x3_f16", 84), ("mnc_conv3x3_bf16", "mnc_pack_conv3x3_bf16", 84)])
 def test_conv3x3_full_size_linearity_and_shift(dev, fn, pack, pitch):
     """conv3_2's shape (150x250, 256 -> 256), no bias / ReLU: scaling the input by a power of two scales the output exactly
-    (fp32 and split-bf16 arithmetic alike), an impulse input reproduces the (flipped) filter taps, and a zero input gives
-    exactly the bias."""
+    (fp32, split-bf16, fp16 and bf16 arithmetic alike: rounding commutes with a power of two), an impulse input reproduces the
+    (flipped) filter taps to the mode's precision, and a zero input gives exactly the bias."""
     H, W, Cin, Cout = 150, 250, 256, 256
     rng = np.random.default_rng(5)
     x = rng.normal(size=(Cin, H, W)).astype(np.float32)
@@ -1324,17 +1325,18 @@ def test_conv3x3_full_size_linearity_and_shift(dev, fn, pack, pitch):
 
     y = run(x, b0)
     assert np.isfinite(y).all()
-    assert np.array_equal(run(x * np.float32(4.0), b0), y * np.float32(4.0))
+    if fn != "mnc_conv3x3_f16":          # (fp16: inputs below 2^-14 are subnormal -- x and 4 x do not round alike)
+        assert np.array_equal(run(x * np.float32(4.0), b0), y * np.float32(4.0))
     z = run(np.zeros_like(x), b1)
     assert np.array_equal(z, np.broadcast_to(b1[:, None, None], z.shape))
     imp = np.zeros_like(x)
     imp[17, 70, 123] = 1.0
     r = run(imp, b0)
-    tol = 0 if fn == "mnc_conv3x3" else 2.0 ** -15
+    tol = {"mnc_conv3x3": 0, "mnc_conv3x3_bf16x3": 2.0 ** -15, "mnc_conv3x3_f16": 2.0 ** -11, "mnc_conv3x3_bf16": 2.0 ** -8}[fn]
     for kh in range(3):
         for kw in range(3):
             got, want = r[:, 70 + 1 - kh, 123 + 1 - kw], w[:, 17, kh, kw]
-            assert np.all(np.abs(got - want) <= tol * np.abs(want)), (kh, kw)
+            assert np.all(np.abs(got - want) <= tol * np.abs(want) + (2.0 ** -25 if fn == "mnc_conv3x3_f16" else 0.0)), (kh, kw)   # (fp16 subnormals)
     r[:, 69:72, 122:125] = 0
     assert not r.any()
 
