@@ -43,6 +43,9 @@
 #ifndef MNC_SW_ABL
 #define MNC_SW_ABL 0
 #endif
+#ifndef MNC_SW_ISSUE
+#define MNC_SW_ISSUE 0
+#endif
 
 namespace mnc {
 
@@ -204,6 +207,12 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
     const uint4* Ap = reinterpret_cast<const uint4*>(pb_ + cg * 9 * 1024) + lane;
     const uint4* Bp = reinterpret_cast<const uint4*>(pb_ + G::AB + kb * G::PLANEB) + (rg * PR * kSwHC + j);
     constexpr int NGRP = 3 * (PR + 2);
+    // copy slot k goes behind fragment group k * kIssueDen / kIssueNum: spread over all groups of the pass -- except in the one-wave
+    // K ranges of the split-bf16 mode (the 38x63 layers: 17 copies per wave and pass, nobody else on the SIMD to cover a late one),
+    // which issue four per group from the start of the pass: conv5_1 42.9 -> 37.9 us (profiles/r06_conv_sw.txt section 8; every
+    // other plan and mode is within run-to-run noise of the spread form, fp16's one-wave plan 4 % slower).  MNC_SW_ISSUE = n: n per 2 groups.
+    constexpr bool kFront = MNC_SW_ISSUE != 0 || (G::NWG == 1 && MODE == 0);
+    constexpr int kIssueNum = MNC_SW_ISSUE ? MNC_SW_ISSUE : kFront ? 8 : NS, kIssueDen = kFront ? 2 : NGRP;
     uint4 a[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
         const int g = hr * 3 + dx;
 #pragma unroll
         for (int q = 0; q < NS; ++q)
-          if (q == k && k * NGRP < (g + 1) * NS) { issue(k); ++k; }
+          if (q == k && k * kIssueDen < (g + 1) * kIssueNum) { issue(k); ++k; }
       }
   };
 
@@ -246,7 +255,10 @@ __global__ __launch_bounds__(64 * RG * CG * KW) void conv3x3_sw_kernel(const voi
       const int ct = c + (p + 1) / NPASS;
       const bool more = ct < c_end;
       const int ctc = more ? ct : c_end - 1;
-      if (!(MNC_SW_ABL & 64)) MNC_SW_SYNC();                  // (ablation 64: no wait, no barrier -- racy, timing only)
+      // (a K range of ONE wave -- the 38x63 plan -- reads only what it copied itself: its own wait is the whole synchronisation, the
+      // four ranges of the workgroup meet only at the final sum)
+      if constexpr (G::NWG == 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else if (!(MNC_SW_ABL & 64)) MNC_SW_SYNC();            // (ablation 64: no wait, no barrier -- racy, timing only)
       compute(bc, [&](int k) { dma_slot(ctc, std::integral_constant<int, (p + 1) % NPASS>(), bc ^ 1, k, more); });
       bc ^= 1;
     });
