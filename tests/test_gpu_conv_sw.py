@@ -88,7 +88,7 @@ def check(mode, got, x, w, b, relu):
 
 # (H, W, Cin, Cout): ragged edges, odd block counts (Cin % 16 == 8), every channel width, VGG-sized slices
 SHAPES = [(6, 37, 16, 64), (9, 70, 8, 32), (38, 63, 64, 128), (13, 33, 128, 256), (75, 125, 32, 64), (4, 32, 8, 512),
-          (80, 100, 24, 256), (150, 250, 16, 128), (11, 65, 40, 96)]
+          (80, 100, 24, 256), (150, 250, 16, 128), (11, 65, 40, 96), (1, 1, 8, 32), (2, 40, 16, 64), (5, 31, 72, 160)]
 
 
 @pytest.mark.parametrize("mode", list(MODES))
