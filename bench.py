@@ -17,11 +17,12 @@ A "step" is one pass of the whole hot path over one synthetic image per GPU, mea
        the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
        device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
 Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
-Every GPU keeps THREE images in flight by default (--in-flight 3: one mnc_net + context + stream per image in flight, ONE shared set
-of device weights; rounds 3-4: four.  Swept in round 5 on the final build, profiles/r05_in_flight_sweep.txt: 2 / 3 / 4 / 5 / 6 / 8 in
-flight = 262 / 264 / 254 / 259 / 261 / 259 images/s in fp32, 649 / 708 / 632 / 665 / 684 in f16 -- three is the best in every math
-mode, four a dip that GPU_MAX_HW_QUEUES does not move);
-mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 2): a sixth of an image's GPU time is spent in
+Every GPU keeps FOUR images in flight by default, three under a launcher (--in-flight: one mnc_net + context + stream per image in
+flight, ONE shared set of device weights).  The part runs four hardware queues: with the round-6 fix of the null-stream memset that
+took a queue of its own (profiles/r06_streams.txt) the images own one queue each up to four -- fp32 2 / 3 / 4 in flight = 265.9 / 267.0
+/ 268.1 images/s, f16 774 / 849 / 866, mixed 528 / 555 / 560 -- and under a launcher the RCCL gather's stream is the fourth (1 rank:
+2 / 3 / 4 in flight = 264.1 / 265.2 / 258.2).  Round 5's sweep (three the best, four a dip) is profiles/r05_in_flight_sweep.txt;
+mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 3): a sixth of an image's GPU time is spent in
 kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- other images' convolutions run
 there.  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` is the
 rounds 1-2 protocol (--in-flight 1 makes it the headline).
@@ -114,8 +115,8 @@ def parse():
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
                         "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline); "
-                        "0 (default) = 3, or 2 under a launcher, where the RCCL gather has a stream of its own: three streams per GPU "
-                        "is where the throughput peaks (profiles/r05_in_flight_sweep.txt)")
+                        "0 (default) = 4, or 3 under a launcher, where the RCCL gather has a stream of its own: one hardware queue per "
+                        "stream, four queues on the part (profiles/r06_streams.txt)")
     p.add_argument("--dist-backend", default="nccl",
                    help="transport of the instance blocks: nccl = RCCL all-gather issued by libmnc_hip.so on a device stream (one rank "
                         "per GPU) | gloo = host tensors (functional test on fewer GPUs than ranks).  torch.distributed itself -- the "
@@ -156,10 +157,10 @@ def main():
         args.engine = "graph"
     launched = "WORLD_SIZE" in os.environ
     if args.in_flight == 0:
-        # three streams per GPU is where the throughput peaks on this part (profiles/r05_in_flight_sweep.txt: 2 / 3 / 4 / 5 / 6 / 8
-        # images in flight = 262 / 264 / 254 / 259 / 261 / 259 images/s without a launcher; with the RCCL gather on a stream of
-        # its own 260 / 256 / 250 for 2 / 3 / 4): three images in flight, two when the gather holds the third stream
-        args.in_flight = 2 if launched else 3
+        # one hardware queue per stream, four queues on this part (profiles/r06_streams.txt): four images in flight without a
+        # launcher (fp32 2 / 3 / 4 in flight = 265.9 / 267.0 / 268.1 images/s, f16 774 / 849 / 866, mixed 528 / 555 / 560), three
+        # when the RCCL gather's stream holds the fourth queue (1 rank under the launcher: 264.1 / 265.2 / 258.2 for 2 / 3 / 4)
+        args.in_flight = 3 if launched else 4
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
     if launched:
