@@ -695,6 +695,7 @@ def compact_line(out):
         alt[a.get("math", key)] = _r(a.get("value"))
         if a.get("roofline"):
             alt[a.get("math", key) + "_roofline_frac"] = _r(a["roofline"].get("frac"), 3)
+            alt[a.get("math", key) + "_roofline_kernel"] = a["roofline"].get("kernel")
         if a.get("max_rel_diff_vs_fp32"):
             alt[a.get("math", key) + "_max_rel_diff_vs_fp32"] = _r(max(a["max_rel_diff_vs_fp32"].values()), 2)
     if isinstance(out.get("config_resnet50"), dict):

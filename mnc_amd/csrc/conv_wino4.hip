@@ -718,7 +718,7 @@ using namespace mnc;
 // The chip holds `slots` = 512 workgroups at a time (two per CU: 80 KB of LDS and 4 waves of 256 registers each).  Full rounds run unsplit; the tiles of a last,
 // partly filled round are cut into as many K ranges (of >= 4 blocks) as fill that round once.  A layer that does not fill one
 // round at all (conv4_x: 160 workgroups, conv5_x / rpn_conv: 48) is cut uniformly.
-static void wino4_plan(int pix, int ncot, int blocks, int* pix_a, int* ksplit_a, int* ksplit_b) {
+static void wino4_plan(int pix, int ncot, int blocks, int* pix_a, int* ksplit_a, int* ksplit_b, int fill = 512) {
   const int slots = 512, min_blocks = 4;
   *pix_a = pix; *ksplit_a = 1; *ksplit_b = 1;
   const long wgs = (long)pix * ncot;
@@ -730,7 +730,7 @@ static void wino4_plan(int pix, int ncot, int blocks, int* pix_a, int* ksplit_a,
     double best_cost = 1e300;
     for (int s = 1; s <= smax && s <= 8; ++s) {
       const int per = (blocks + s - 1) / s;
-      const double cost = (double)((wgs * s + slots - 1) / slots) * per + (s > 1 ? 1.5 * s : 0.0);
+      const double cost = (double)((wgs * s + fill - 1) / fill) * per + (s > 1 ? 1.5 * s : 0.0);
       if (cost < best_cost) { best_cost = cost; best = s; }
     }
     *ksplit_a = best;
@@ -760,11 +760,19 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
   const int ncot = Cout >> 5, blocks = Cin >> 3;
   const int tiles_x = cdiv(W, kF4Cols), pix = tiles_x * cdiv(H, kF4Rows);
   int pix_a, ksplit_a, ksplit_b;
-  wino4_plan(pix, ncot, blocks, &pix_a, &ksplit_a, &ksplit_b);
+  // WINO_FILL: the workgroup slots a layer smaller than one round (conv4_x, conv5_x, rpn_conv) is cut to fill.  512 = the chip, the
+  // shortest launch for an image that has the chip to itself (rounds 4-5); 384 = three quarters (round 6): conv4_x in 2 ranges instead
+  // of 3, conv5_x / rpn_conv in 4 instead of 6 -- fewer prologues, slabs and reducers, less CU time, and with four images in flight the
+  // CUs left free run the other images' kernels: 265.9 -> 271.0 images/s (three runs each; 320: 271.4, 448: 264.7, 256: 266.2), one
+  // image at a time 236.4 -> 230.6 (profiles/r06_fc_ranges.txt)
+  wino4_plan(pix, ncot, blocks, &pix_a, &ksplit_a, &ksplit_b, tune(ctx, T_WINO_FILL, 384));
   if (tune_set(ctx, T_CONV_KSPLIT)) {                            // uniform K ranges (tests, A/B)
     const int v = tune(ctx, T_CONV_KSPLIT, 1);
     if (v >= 1 && v <= 8 && v <= blocks) { pix_a = pix; ksplit_a = v; ksplit_b = 1; }
-  } else if (tune(ctx, T_WINO_TAIL, 1) == 0) {
+  } else if (tune(ctx, T_WINO_TAIL, 0) == 0) {
+    // round 6: the tail round of a layer larger than one round is NOT cut by default (WINO_TAIL=1: rounds 4-5) -- the cut shortens
+    // the launch of an image that has the chip to itself (one at a time 231.8 -> 229.5 images/s without it) and costs slabs and
+    // reducers; with four images in flight the tail's free CUs are not idle: 271.4 -> 273.6 images/s (two runs each)
     if (pix_a < pix) { pix_a = pix; ksplit_b = 1; }
   }
   float* part = nullptr;

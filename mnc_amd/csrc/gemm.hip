@@ -964,13 +964,16 @@ int mnc_fc(mnc_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias
   // 6.3 us reduction launch (kernel_bench fc, round 5) for 0.07 GFLOP; one range of eight stages writes the result itself
   if (small && stages <= 8) splits = 1;
   if (splits < 1) splits = 1;
+  if (!small && tm == 1) splits = fc_split_div(ctx, splits, K);
   if (tm > 1 && !small)      // several row blocks: pick the split count by cost (see choose_splits); one block: as tuned above
     splits = choose_splits(tn * tm, stages, min_stages, mt == 10 ? 256 : 512,
                            (double)bm * kBN * sk * 2.0 / 460.0e3 * (mt == 10 ? 1.0 : 2.0), 4.0 * M * (double)N);
   int kper = cdiv(stages, splits) * sk;
-  // LDS-DMA build of the 320-row kernel (fc_mfma_dma_kernel; MNC_FC_DMA=0: the register-staged one): even stage counts per split
+  // LDS-DMA build of the 320-row kernel (fc_mfma_dma16_kernel; MNC_FC_DMA=0: the register-staged one).  Its loop walks one stage per
+  // iteration, so a K range may hold an odd number of stages (rounds 3-5 rounded the ranges up to even counts, a leftover of the first
+  // DMA build: fc6_maskest then ran 121 ranges of 26 stages on 242 CUs where 126 ranges of 25 fit 252 -- profiles/r06_fc_maskest.txt)
   const bool dma = mt == 10 && K % 64 == 0 && !tune_set(ctx, T_FC_ABL) && tune(ctx, T_FC_DMA, 1) != 0;
-  if (dma) kper = cdiv(kper, 64) * 64;
+  if (dma && tune(ctx, T_FC_EVEN, 0)) kper = cdiv(kper, 64) * 64;
   splits = cdiv(K, kper);
   // (In-launch reduction of the K ranges by each tile's last arriver: built and measured in round 5 -- a loss here, the last arriver
   // reads 8 x 160 KB on one CU while 224 idle, profiles/r05_inlaunch_reduce.txt -- and removed in round 6.)
@@ -1136,6 +1139,7 @@ int mnc_fc_pair(mnc_ctx* ctx, const float* d_a0, const float* d_w0, const float*
   if (splits > stages / 8) splits = stages / 8;
   if (splits < 1) splits = 1;
   if (tm > 1) splits = choose_splits(2 * tn * tm, stages, 8, 256, 320.0 * kBN * 32 * 2.0 / 460.0e3, 8.0 * M * (double)N);
+  else splits = fc_split_div(ctx, splits, K);
   int kper = cdiv(cdiv(stages, splits) * 32, 64) * 64;
   splits = cdiv(K, kper);
   float* part = nullptr;

@@ -358,6 +358,15 @@ __global__ void pack_f16_kernel(const float* __restrict__ in, uint4* __restrict_
 // F16 = 0: the split-bf16 products (three MFMAs per term, 32-deep stages) on the same panels.
 // Same operands, same K order per accumulator and the same epilogue as fc_x3_kernel: results differ from it only by
 // the K-split grouping (fewer column tiles -> more splits).
+// MNC_LP_ABL (tuning builds only, -DMNC_LP_ABL=bits, wrong results; tools/lp_abl.sh): 1 no copies inside the loop, 2 no fragment
+// reads inside the loop, 4 no barrier, 8 the copies inside the loop issued out of range (the instruction without its memory
+// traffic), 16 / 32 no weight / activation copies inside the loop -- what each costs (profiles/r06_fc_lowp.txt)
+#ifndef MNC_LP_ABL
+#define MNC_LP_ABL 0
+#endif
+#ifndef MNC_LP_PIPE
+#define MNC_LP_PIPE 1      // (tuning: 0 = rounds 3-5's single fragment set in the fp16 / bf16 build too)
+#endif
 template <int kMT, int F16>
 __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restrict__ Ax, const uint4* __restrict__ Wx,
                                                          const float* __restrict__ bias, float* __restrict__ out,
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
   constexpr int kStageK = F16 ? 64 : kXBK;           // K values per stage: 128 bytes per row in either format
   const int S = K / kStageK;
   const int kbeg = split * kper, kend = min(K, kbeg + kper);
-  const int stage0 = kbeg / kStageK, nstages = (kend - kbeg) / kStageK;
+  const int stage0 = kbeg / kStageK, nstages = (MNC_LP_ABL & 64) ? 0 : (kend - kbeg) / kStageK;   // (64: tuning, no loop at all)
   const int mrows = min(M - m0, kBM);
   const int mtiles = (mrows + 31) >> 5;
   const int npanels = (N + 127) >> 7;
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
     i32x4d r;
     r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
     r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
-    r.z = 0x00100000;                                // (the lane offsets stay below kBM x 128 bytes)
+    r.z = 0x70000000;                                // (no lane relies on the range check: rows past M are clamped)
     r.w = 0x00020000;
     return r;
   };
@@ -430,21 +439,31 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
 #pragma unroll
   for (int i = 0; i < kPerA; ++i) voff_a[i] = min(r0 + 64 * i, mrows - 1) * 128 + cch * 16;      // rows past M re-read the last valid row; never stored
   const int voff_w0 = r0 * 128 + cch * 16, voff_w1 = (r0 + 64) * 128 + cch * 16;
-  auto dma_stage = [&](int s, int buf_byte) {
-    const long st = stage0 + min(s, nstages - 1);    // past the end: the last stage once more, never multiplied
-    const i32x4d ra = make_rsrc(Ax + ((st * mstride + m0) << 3));
-    const i32x4d rw0 = make_rsrc(Wx + (((long)panel0 * S + st) << 10)), rw1 = make_rsrc(Wx + (((long)panel1 * S + st) << 10));
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 8 * i) * 1024u);
-      if (i < kPerA) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff_a[i]), "s"(ra), "s"(l) : "memory");
-      } else {
-        const int k = i - kPerA;
-        const i32x4d rw = (k >> 1) ? rw1 : rw0;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((k & 1) ? voff_w1 : voff_w0), "s"(rw), "s"(l) : "memory");
-      }
+  // one descriptor per operand panel, built once (round 6; rounds 3-5 rebuilt three per stage: six v_readfirstlane + 64-bit scalar
+  // arithmetic per stage and wave); the stage is the instruction's SCALAR offset: st x mstride x 128 bytes into the activations
+  // (< 4 GB for M x K below 2e9 values -- fc_lowp checks), st x 16 KB into a weight panel
+  const i32x4d ra = make_rsrc(Ax + (((long)stage0 * mstride + m0) << 3));
+  const i32x4d rw0 = make_rsrc(Wx + (((long)panel0 * S + stage0) << 10)), rw1 = make_rsrc(Wx + (((long)panel1 * S + stage0) << 10));
+  const unsigned a_stage_bytes = (unsigned)mstride * 128u;
+  auto dma_piece = [&](int i, int s, int buf_byte) {
+    const unsigned st = (unsigned)min(s, nstages - 1);  // past the end: the last stage once more, never multiplied
+    const unsigned so_a = st * a_stage_bytes, so_w = st << 14;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf_byte + (unsigned)(wave + 8 * i) * 1024u);
+    if (i < kPerA) {
+      if ((MNC_LP_ABL & 32) && s >= 2) return;       // tuning: no activation copies inside the loop
+      const int vo = ((MNC_LP_ABL & 8) && s >= 2) ? 0x7FFFFFF0 : voff_a[i];
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(ra), "s"(so_a), "s"(l) : "memory");
+    } else {
+      if ((MNC_LP_ABL & 16) && s >= 2) return;       // tuning: no weight copies inside the loop
+      const int k = i - kPerA;
+      const i32x4d rw = (k >> 1) ? rw1 : rw0;
+      const int vo = ((MNC_LP_ABL & 8) && s >= 2) ? 0x7FFFFFF0 : ((k & 1) ? voff_w1 : voff_w0);
+      asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(vo), "s"(rw), "s"(so_w), "s"(l) : "memory");
     }
+  };
+  auto dma_stage = [&](int s, int buf_byte) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) dma_piece(i, s, buf_byte);
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
@@ -518,31 +537,71 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
       for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(acc[t][c]));
   };
 
-  // One fragment set: with 160 accumulator registers a wave has ~90 VGPRs left, and two waves share each SIMD -- one wave's
-  // fragment reads run under its partner's MFMAs.  (Two sets, software-pipelined as in fc_mfma_dma_kernel, spilled 400 registers.)
   if (nstages > 0) {
-    Frags f;
     dma_stage(0, 0);
     dma_stage(1, kBuf);
     dma_wait();
     __syncthreads();
     int cur = 0;                                     // byte offset of the buffer stage s sits in
-    for (int s = 0; s < nstages; ++s) {
+    if constexpr (F16 != 0 && MNC_LP_PIPE) {
+      // fp16 / bf16 (round 6): TWO fragment sets (28 registers each beside the 160 accumulators: 244 of 256), software-pipelined as
+      // fc_mfma_dma16_kernel's -- the fragments of K-step q + 1 are read under the MFMAs of step q, step 0 of the next stage behind
+      // the stage barrier under the last step.  With one set the seven ds_read_b128 of a step and their wait stood in front of its ten
+      // MFMAs in every wave and only the partner wave of the SIMD could cover them (ablation, fc6 + fc6_mask: 15 of 135 us;
+      // profiles/r06_fc_lowp.txt).  sched_group_barrier pins one read behind each of a step's first seven MFMAs.
+      constexpr int kNM = 2 * TR, kNR = TR + 2;
+      auto interleave = [&]() {
 #pragma unroll
-      for (int q = 0; q < kSteps - 1; ++q) {
-        read_frags(cur, q, f);
-        mfmas(f);
+        for (int i = 0; i < kNM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < kNR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      };
+      Frags f0, f1;
+      read_frags(0, 0, f0);
+      for (int s = 0; s < nstages; ++s) {
+        read_frags(cur, 1, f1);
+        mfmas(f0);
+        interleave();
+        read_frags(cur, 2, f0);
+        mfmas(f1);
+        interleave();
+        read_frags(cur, 3, f1);
+        mfmas(f0);
+        interleave();
+        pin_acc();
+        dma_wait();                                  // stage s + 1 has landed ...
+        if (!(MNC_LP_ABL & 4)) __syncthreads();      // ... for every wave, and every wave holds its last fragments of buffer `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(MNC_LP_ABL & 1)) dma_stage(s + 2, cur);  // refill the buffer just released: a whole stage to land (one copy behind
+        __builtin_amdgcn_sched_barrier(0);           // each of the last MFMAs instead of this run: measured, no difference)
+        read_frags(kBuf - cur, 0, f0);               // step 0 of stage s + 1 (behind the last stage: a copy of it, never multiplied)
+        mfmas(f1);
+        interleave();
+        pin_acc();
+        cur = kBuf - cur;
       }
-      read_frags(cur, kSteps - 1, f);
-      pin_acc();
-      dma_wait();                                    // stage s + 1 has landed ...
-      __syncthreads();                               // ... for every wave, and every wave holds its last fragments of buffer `cur`
-      __builtin_amdgcn_sched_barrier(0);
-      dma_stage(s + 2, cur);                         // refill the buffer just released: a whole stage to land
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(f);                                      // the last step
-      pin_acc();
-      cur = kBuf - cur;
+    } else {
+      // One fragment set (split bf16: 56 registers a set): two waves share each SIMD -- one wave's fragment reads run under its
+      // partner's MFMAs.
+      Frags f;
+      for (int s = 0; s < nstages; ++s) {
+#pragma unroll
+        for (int q = 0; q < kSteps - 1; ++q) {
+          if (!(MNC_LP_ABL & 2) || s == 0) read_frags(cur, q, f);
+          mfmas(f);
+        }
+        if (!(MNC_LP_ABL & 2) || s == 0) read_frags(cur, kSteps - 1, f);
+        pin_acc();
+        dma_wait();                                  // stage s + 1 has landed ...
+        if (!(MNC_LP_ABL & 4)) __syncthreads();      // ... for every wave, and every wave holds its last fragments of buffer `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(MNC_LP_ABL & 1)) dma_stage(s + 2, cur);  // refill the buffer just released: a whole stage to land
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(f);                                    // the last step
+        pin_acc();
+        cur = kBuf - cur;
+      }
     }
     dma_wait();                                      // the copies issued by the last two stages have landed before the LDS is released
     __syncthreads();
@@ -653,6 +712,11 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   const int min_stages = F16 ? (mt == 2 ? 1 : 4) : (mt == 2 ? 2 : 8);
   if (splits > stages / min_stages) splits = stages / min_stages;
   if (splits < 1) splits = 1;
+  if (tm == 1 && mt != 2) {
+    const int full = splits;
+    splits = fc_lowp_ranges(ctx, splits, K, tn);      // (round 6: CU time, not launch time -- mnc_internal.h)
+    if (splits == 1 && full > 1 && d_osm && (ldc != N || osm_rows != M || osm_row0 != 0)) splits = 2;
+  }
   if (tm > 1 && mt != 2)     // several row blocks: split count by cost (mnc_internal.h: choose_splits)
     splits = choose_splits(tn * tm, stages, min_stages, 256,
                            (double)bm * bn_w * kStage * 2.0 / (F16 ? 2000.0e3 : 1050.0e3), 4.0 * M * (double)N);
@@ -768,6 +832,10 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
     if (splits > stages / (F16 ? 4 : 8)) splits = stages / (F16 ? 4 : 8);
     if (splits < 1) splits = 1;
     paired = stages / splits >= (F16 ? 8 : 16);                // (the 256-column kernel's own bar: fc_lowp)
+    const int full = splits;
+    splits = fc_lowp_ranges(ctx, splits, K, 2 * tn);           // (round 6: CU time, not launch time -- mnc_internal.h)
+    // (a second output in stage-major form is written by the reduction pass; without one only dense rows can be converted)
+    if (splits == 1 && full > 1 && (d_osm0 || d_osm1) && ldc != N) splits = 2;
   }
   if (!paired) {
     int rc = fc_lowp<F16>(ctx, what, d_a0, d_pre0, d_a0 ? M : mstride, d_w0, d_bias0, d_out0, M, N, K, ldc, act, d_osm0,

@@ -165,7 +165,7 @@ def test_conv3x3_winograd_f4(dev, H, W, Cin, Cout, relu, tune):
     assert not np.isnan(dev.get(d_w, (Cin * Cout * 36,))).any()
     d_y = dev.empty((Cout, H, W), fill=-7.0)
     worst = 0.0
-    for ks, tail, xcd in ((None, None, None), ("1", None, None), ("2", None, "0"), ("3", None, "1"), (None, "0", None)):
+    for ks, tail, xcd in ((None, None, None), ("1", None, None), ("2", None, "0"), ("3", None, "1"), (None, "0", None), (None, "1", None)):
         if ks is not None and int(ks) > Cin // 8:
             continue
         for k in ("CONV_KSPLIT", "WINO_TAIL", "WINO_XCD"):

@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--shape", default=None, help="fc / fcx3: one extra shape M,N,K (e.g. 40,4096,50176)")
     ap.add_argument("--relu-input", action="store_true", help="fc*: activations max(x, 0) (half zeros, as behind a ReLU) instead of N(0, 1): "
                     "the matrix pipe is power limited, operand values move the clock")
+    ap.add_argument("--pair", action="store_true", help="fcx3 / fcf16: TWO products of the shape in one launch (mnc_fc_lowp_pair, activations "
+                    "already stage-major: the box + mask branch call of the head stages)")
     ap.add_argument("--gap-ms", type=float, default=0.0, help="fc*: synchronise and sleep this long before every timed launch (a kernel that "
                     "starts on a rested chip runs at a higher clock than the same kernel back to back)")
     ap.add_argument("--packed", action="store_true", help="convx3 / convf16: 2-byte activation tensors in and out")
@@ -216,19 +218,31 @@ def main():
                 wp = dev.empty(((N + 127) // 128 * 128 * K // 2,))
                 dev.call("mnc_pack_fc_f16", w, wp, N, K)
                 w, fn = wp, "mnc_fc_f16"
+            if args.pair and args.what in ("fcx3", "fcf16"):
+                f16 = 1 if args.what == "fcf16" else 0
+                asm = dev.empty((M * K // 2 if f16 else M * K,))
+                dev.call("mnc_fc_pack_act", a, asm, M, K, f16)
+                y1 = dev.empty((M * N,))
+                mode = 1 if f16 else 0
+
+                def run():
+                    dev.call("mnc_fc_lowp_pair", mode, None, asm, None, asm, M, w, w, b, b, y, y1, M, N, K, N, 1, None, None, 0)
+            else:
+                def run():
+                    dev.call(fn, a, w, b, y, M, N, K, N, 1)
             for _ in range(3):
-                dev.call(fn, a, w, b, y, M, N, K, N, 1)
+                run()
             dev.call("mnc_prof_reset")
             for _ in range(args.reps):
                 if args.gap_ms > 0:
                     dev.call("mnc_ctx_sync")
                     time.sleep(args.gap_ms * 1e-3)
-                dev.call(fn, a, w, b, y, M, N, K, N, 1)
+                run()
             rec = records(dev)
             t = np.array([r[1] for r in rec if r[0].startswith("fc_mfma") or r[0] in ("fc_bf16x3", "fc_bf16x3_small", "fc_f16", "fc_f16_small")])
             tr = np.array([r[1] for r in rec if r[0] == "fc_reduce"] or [0.0])
             ts = np.array([r[1] for r in rec if r[0] in ("fc_bf16x3_split", "fc_f16_convert")] or [0.0])
-            fl = 2.0 * M * N * K
+            fl = 2.0 * M * N * K * (2 if args.pair and args.what in ("fcx3", "fcf16") else 1)
             tot = np.median(t) + np.median(tr) + np.median(ts)
             print("%-12s M=%d N=%-4d K=%-6d  gemm %.1f us + reduce %.1f us + split %.1f us = %.1f us   %.1f TF/s (gemm)  %.1f TF/s (all)" %
                   (name, M, N, K, 1e3 * np.median(t), 1e3 * np.median(tr), 1e3 * np.median(ts), 1e3 * tot,
