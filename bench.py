@@ -90,6 +90,10 @@ def parse():
     p.add_argument("--config", default="vgg16", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
+    p.add_argument("--no-latency-plan", action="store_true",
+                   help="skip the measurements on the launch plans for latency (MNC_PLAN=1): `one_image_at_a_time` is then the figure on "
+                        "the headline's plans and the per-mode `roofline_latency_plan` passes are not run (tools/prof_round.sh: the "
+                        "counter passes need one fixed kernel sequence per image)")
     p.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     p.add_argument("--all-events", action="store_true", help="time every launch (default: only the MFMA kernels)")
     p.add_argument("--no-graph", action="store_true", help="native engine: direct launches on every step (counter-profiling runs)")
@@ -206,10 +210,23 @@ def main():
     images = [np.random.default_rng(s).integers(0, 256, (H, W, 3), dtype=np.uint8) for s in range(N_IMAGES)]
     nms_t, iou_t = float(cfg.TEST.MASK_MERGE_NMS_THRESH), float(cfg.TEST.MASK_MERGE_IOU_THRESH)
 
-    def measure(math, steps, warmup, resident_steps=0, engine=None, pipelined_steps=0, in_flight=None):
+    def measure(math, steps, warmup, resident_steps=0, engine=None, pipelined_steps=0, in_flight=None, plan=None):
         """Build the net in `math` mode; warmup + `steps` timed steps of the full protocol (upload .. results on the host), then
-        optionally `resident_steps` steps of the old resident-input protocol.  -> dict."""
+        optionally `resident_steps` steps of the old resident-input protocol.  -> dict.
+        plan="1": the contexts are created under MNC_PLAN=1 (launch plans for latency); only the timed
+        steps and the event pass run."""
         engine = engine or args.engine
+        native = engine == "native"
+        had_plan = os.environ.get("MNC_PLAN")
+        if plan is not None and had_plan is None:
+            os.environ["MNC_PLAN"] = plan
+        try:
+            return _measure(math, steps, warmup, resident_steps, engine, pipelined_steps, in_flight, plan)
+        finally:
+            if plan is not None and had_plan is None:
+                del os.environ["MNC_PLAN"]
+
+    def _measure(math, steps, warmup, resident_steps, engine, pipelined_steps, in_flight, plan):
         native = engine == "native"
         if native:
             from mnc_amd.native_net import NativeNet
@@ -412,20 +429,34 @@ def main():
             gatherer = None
         out["feats"] = {n: (net.blob(n) if native else net.blobs[n]._host_read().copy())
                         for n in ("rpn_bbox_pred", "rpn_cls_prob_reshape")}
-        if native and not launched:
+        if native and not launched and plan is None:
             # the same step with every image on the captured HIP graph (no event steps): one hipGraphLaunch + one
             # synchronisation per image
+            # Round 6: measured twice -- on the launch plans made for this protocol (MNC_PLAN=1: every launch cut until it fills the
+            # chip, the shortest launch; rounds 1-5) and on the headline's plans (least CU time per launch: DESIGN.md section 9 item 10)
             from mnc_amd.native_net import NativeNet
             net.close()
-            net = NativeNet(weights, device_id=dev_id, math=math, use_graph=True)
             gsteps = min(steps, 100)
-            for k in range(5):
-                net.forward_image(images[k % N_IMAGES], record_cap=100)
-            t0 = time.perf_counter()
-            for k in range(gsteps):
-                net.forward_image(images[(5 + k) % N_IMAGES], record_cap=100)
-            out["graph_s"] = (time.perf_counter() - t0) / gsteps
-        if native and not launched and pipelined_steps:
+            for plan_key, plan in ((("graph_tp_s", None),) if args.no_latency_plan else (("graph_s", "1"), ("graph_tp_s", None))):
+                had = os.environ.get("MNC_PLAN")
+                if plan is not None and had is None:
+                    os.environ["MNC_PLAN"] = plan
+                try:
+                    net = NativeNet(weights, device_id=dev_id, math=math, use_graph=True)
+                finally:
+                    if plan is not None and had is None:
+                        del os.environ["MNC_PLAN"]
+                for k in range(5):
+                    net.forward_image(images[k % N_IMAGES], record_cap=100)
+                t0 = time.perf_counter()
+                for k in range(gsteps):
+                    net.forward_image(images[(5 + k) % N_IMAGES], record_cap=100)
+                out[plan_key] = (time.perf_counter() - t0) / gsteps
+                if plan_key == "graph_s":
+                    net.close()
+            if args.no_latency_plan:
+                out["graph_s"] = out["graph_tp_s"]
+        if native and not launched and pipelined_steps and plan is None:
             # two images in flight: one mnc_net (own context / stream / buffers) per image in flight, launch image k+1 before
             # fetching image k -- independent images overlap on the GPU, the latency-bound stretches of one (proposal top-k, NMS
             # scan, voting) run beside the other's convolutions.  Direct launches, no events; drained inside the timed region.
@@ -468,6 +499,16 @@ def main():
             gatherer.close()
         net.close()
         return out
+
+    def latency_plan_roofline(math_):
+        """The event pass once more on the launch plans for latency (MNC_PLAN=1: every launch cut until it fills the chip).  The headline's
+        plans minimise CU time, so their launches deliberately do NOT fill the chip when measured one at a time; this is what the same
+        kernels reach when they do.  -> {"roofline": .., "roofline_by_kernel": ..} of 8 images."""
+        ml = measure(math_, 8, 3, in_flight=1, plan="1")
+        sm = summarise(8, ml)
+        return {"plan": "MNC_PLAN=1 (latency): 8 images, one at a time, direct launches with events",
+                "roofline": sm.get("roofline"), "kernel_ms_per_image": sm.get("kernel_ms_per_image"),
+                "roofline_by_kernel": sm.get("roofline_by_kernel"), "conv3_x": sm.get("conv3_x")}
 
     def summarise(steps, m):
         out = {"host_phase_ms_per_image": {k: round(v, 3) for k, v in m["phase_ms"].items()}}
@@ -576,7 +617,9 @@ def main():
             out["graph_replay"] = {"value": 1.0 / m["graph_s"], "unit": "images/s", "ms_per_step": 1e3 * m["graph_s"],
                                    "protocol": "ONE image at a time (the rounds 1-2 headline protocol; latency of an image): same step, "
                                                "every image on the captured HIP graph (one hipGraphLaunch + one synchronisation per "
-                                               "image; no event steps)"}
+                                               "image; no event steps); launch plans for latency (MNC_PLAN=1: every launch cut until it "
+                                               "fills the chip -- rounds 1-5's plans)",
+                                   "value_on_the_headline_plans": 1.0 / m["graph_tp_s"] if "graph_tp_s" in m else None}
             out["one_image_at_a_time"] = out["graph_replay"]
         if args.engine == "native" and world == 1 and not launched and not args.no_resident:
             mp = measure(math, min(args.steps, 100), args.warmup, resident_steps=50, engine="python")
@@ -596,6 +639,9 @@ def main():
             out["resident_input"] = {"value": 1.0 / m["resident_s"], "unit": "images/s", "ms_per_step": 1e3 * m["resident_s"],
                                      "protocol": "round-1 protocol: one image, input blob resident in HBM, no upload / device "
                                                  "prep; voted results copied to the host"}
+        if world == 1 and not launched and args.config == "vgg16" and not args.no_alt_math and not args.no_events and args.engine == "native" \
+                and not args.no_latency_plan:
+            out["roofline_latency_plan"] = latency_plan_roofline(math)
         if world == 1 and not launched and args.config == "vgg16" and math == "fp32" and not args.no_alt_math:
             # BASELINE configs[2] ("bf16 convs via MFMA") and the fp16 mode measured in the same run, same protocol; their RPN
             # outputs on the LAST image are compared with the fp32 run's (blobs that do not depend on which RoIs survived)
@@ -612,6 +658,8 @@ def main():
                                                  "ms_per_step": 1e3 * m2["pipelined_s"]}
                 a["max_rel_diff_vs_fp32"] = {n: float(np.abs(m2["feats"][n] - m["feats"][n]).max() /
                                                       max(np.abs(m["feats"][n]).max(), 1e-30)) for n in m["feats"]}
+                if not args.no_events and not args.no_latency_plan:
+                    a["roofline_latency_plan"] = latency_plan_roofline(alt)
                 out[key] = a
         if world == 1 and not launched and not args.no_cpu_baseline and args.config == "vgg16":
             out["cpu_baseline"] = cpu_baseline(weights, images[0], args.cpu_images)
@@ -688,6 +736,8 @@ def compact_line(out):
     alt = {}
     if out.get("one_image_at_a_time"):
         alt["one_image_at_a_time"] = _r(out["one_image_at_a_time"].get("value"))
+        if out["one_image_at_a_time"].get("value_on_the_headline_plans"):
+            alt["one_image_at_a_time_headline_plans"] = _r(out["one_image_at_a_time"]["value_on_the_headline_plans"])
     if out.get("python_engine"):
         alt["python_engine"] = _r(out["python_engine"].get("value"))
     for key in sorted(k for k in out if k.startswith("alt_math")):
@@ -696,6 +746,11 @@ def compact_line(out):
         if a.get("roofline"):
             alt[a.get("math", key) + "_roofline_frac"] = _r(a["roofline"].get("frac"), 3)
             alt[a.get("math", key) + "_roofline_kernel"] = a["roofline"].get("kernel")
+        lp = (a.get("roofline_latency_plan") or {}).get("roofline")
+        if lp:
+            alt[a.get("math", key) + "_roofline_frac_latency_plan"] = _r(lp.get("frac"), 3)
+            if lp.get("kernel") != (a.get("roofline") or {}).get("kernel"):
+                alt[a.get("math", key) + "_roofline_kernel_latency_plan"] = lp.get("kernel")
         if a.get("max_rel_diff_vs_fp32"):
             alt[a.get("math", key) + "_max_rel_diff_vs_fp32"] = _r(max(a["max_rel_diff_vs_fp32"].values()), 2)
     if isinstance(out.get("config_resnet50"), dict):
@@ -930,7 +985,9 @@ def mfma_peak(scope_name):
 
 # conv3_x (north_star: ">= 50 % MFMA util on conv3_x") = conv3_1, conv3_2, conv3_3 at 600x1000: told apart from the other
 # layers of their flop class by their algorithmic bytes; in every trunk kernel's per-image launch cycle of the LARGE-map template
-# instantiation (conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3: six launches) they are positions 3, 4, 5.
+# instantiation (conv1_2, conv2_1, conv2_2, conv3_1, conv3_2, conv3_3: six launches of the fp32 F(4x4) kernel; the reduced-precision
+# kernel runs all 13 layers on one instantiation since the CU-time plans of round 6, tools/prof_round.sh cuts its cycle at 13) they are
+# positions 3, 4, 5.
 def _conv3x_bytes():
     hw, out = 150 * 250, set()
     for cin, cout in ((128, 256), (256, 256)):

@@ -495,8 +495,14 @@ static int sw_plan(const mnc_ctx* ctx, int H, int W, int Cin, int Cout) {
     if (p >= 0 && p < 4 && fits[p]) return p;
   }
   const long wg0 = (long)cdiv(W, kSwCols) * cdiv(H, 10) * (Cout / 64);
-  if (fits[0] && wg0 >= 384) return 0;
-  if (fits[1] && wg0 >= 128) return 1;
+  // Round 6 (profiles/r06_fc_ranges.txt): with several images in flight the plan that costs the least CU time wins, and that is plan 0
+  // -- four-wave workgroups, each wave its own K loop, no sums through LDS -- down to 64 workgroups (conv5_x / rpn_conv on a quarter of
+  // the chip): f16 918 -> 978 images/s, mixed 578 -> 611 against the chip-filling plans 1 / 2 (conv4_x in two K ranges per workgroup,
+  // conv5_x in four), which remain the latency plan (PLAN=1: one image at a time f16 572 vs 549, mixed 425 vs 377).
+  const bool lat = plan_latency(ctx);
+  const int p0min = tune(ctx, T_CONVX3_P0MIN, lat ? 384 : 64), p1min = tune(ctx, T_CONVX3_P1MIN, lat ? 128 : 64);
+  if (fits[0] && wg0 >= p0min) return 0;
+  if (fits[1] && wg0 >= p1min) return 1;
   if (fits[2] && (long)cdiv(W, kSwCols) * cdiv(H, 5) * (Cout / 32) <= 640) return 2;
   if (fits[0] && wg0 >= 128) return 0;
   return fits[0] && wg0 >= 64 ? 0 : 3;

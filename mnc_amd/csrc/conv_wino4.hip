@@ -765,11 +765,11 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
   // of 3, conv5_x / rpn_conv in 4 instead of 6 -- fewer prologues, slabs and reducers, less CU time, and with four images in flight the
   // CUs left free run the other images' kernels: 265.9 -> 271.0 images/s (three runs each; 320: 271.4, 448: 264.7, 256: 266.2), one
   // image at a time 236.4 -> 230.6 (profiles/r06_fc_ranges.txt)
-  wino4_plan(pix, ncot, blocks, &pix_a, &ksplit_a, &ksplit_b, tune(ctx, T_WINO_FILL, 384));
+  wino4_plan(pix, ncot, blocks, &pix_a, &ksplit_a, &ksplit_b, tune(ctx, T_WINO_FILL, plan_latency(ctx) ? 512 : 384));
   if (tune_set(ctx, T_CONV_KSPLIT)) {                            // uniform K ranges (tests, A/B)
     const int v = tune(ctx, T_CONV_KSPLIT, 1);
     if (v >= 1 && v <= 8 && v <= blocks) { pix_a = pix; ksplit_a = v; ksplit_b = 1; }
-  } else if (tune(ctx, T_WINO_TAIL, 0) == 0) {
+  } else if (tune(ctx, T_WINO_TAIL, plan_latency(ctx) ? 1 : 0) == 0) {
     // round 6: the tail round of a layer larger than one round is NOT cut by default (WINO_TAIL=1: rounds 4-5) -- the cut shortens
     // the launch of an image that has the chip to itself (one at a time 231.8 -> 229.5 images/s without it) and costs slabs and
     // reducers; with four images in flight the tail's free CUs are not idle: 271.4 -> 273.6 images/s (two runs each)

@@ -32,7 +32,7 @@ namespace mnc {
 // superseded kernel builds (FC_ABL, FC_DMA_ABL, FCX3_ABL, CONV_ABL, WINO_V = 1, WINO_VAR != 7) are only compiled with -DMNC_TUNING.
 #define MNC_TUNE_KEYS(X)                                                                                                          \
   X(CONV_COT) X(CONV_ROWS) X(CONV_KSPLIT) X(CONV_ABL) X(CONV1X1_TILE) X(CONV2D_WIDE) X(WINO_ROWS) X(WINO_TAIL) X(WINO_V) X(WINO_VAR)  \
-  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(FC_EVEN) X(FC_SPLIT_DIV) X(WINO_FILL) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
+  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(PLAN) X(FC_EVEN) X(FC_SPLIT_DIV) X(WINO_FILL) X(CONVX3_P0MIN) X(CONVX3_P1MIN) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
   X(FC_NO256) X(FCX3_TILE) X(FC_ORDER) X(FCX3_ABL) X(FC_SM) X(PACKED_ACT) X(FUSE_POOLS) X(BRANCH_STREAMS) X(TOPK_SINGLE_WG)           \
   X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(ROI_ROW_SEGS)
 enum TuneKey {
@@ -88,6 +88,11 @@ struct mnc_graph {
 namespace mnc {
 inline bool tune_set(const mnc_ctx* ctx, TuneKey k) { return ctx->tune[k] != kTuneUnset; }
 inline int tune(const mnc_ctx* ctx, TuneKey k, int dflt) { return ctx->tune[k] != kTuneUnset ? ctx->tune[k] : dflt; }
+// PLAN (round 6, profiles/r06_fc_ranges.txt): what the launchers' plans minimise.  0 (default) = the CU TIME of a launch -- the
+// deployment the headline measures, several images in flight per GPU: the CUs a launch leaves free run the other images' kernels.
+// 1 = the DURATION of a launch (rounds 1-5: every product cut until it fills the chip) -- one image at a time, latency.  One value
+// per context (MNC_PLAN=1 or mnc_ctx_set_tuning(ctx, "PLAN", "1")); the nets that share results bit for bit must share it.
+inline bool plan_latency(const mnc_ctx* ctx) { return tune(ctx, T_PLAN, 0) == 1; }
 // K ranges of a reduced-precision InnerProduct over ONE row block (round 6, profiles/r06_fc_ranges.txt).  Rounds 2-5 cut K so that
 // tiles x ranges filled all 256 CUs -- the shortest launch when the product has the chip to itself.  With several images in flight it
 // does not: other images' kernels run on the CUs a launch leaves free, and what a product costs is its CU TIME.  Every range pays a
@@ -100,12 +105,13 @@ inline int tune(const mnc_ctx* ctx, TuneKey k, int dflt) { return ctx->tune[k] !
 // FC_SPLIT_DIV (A/B): 0 = the full cut everywhere; otherwise the full cut divided by the low decimal digit (K > 8192) / the high
 // digit (K <= 8192; 0 = the low digit), fp32 included.
 inline int fc_split_div(const mnc_ctx* ctx, int splits, int K) {
-  const int v = tune(ctx, T_FC_SPLIT_DIV, 1), lo = v % 10, hi = (v / 10) % 10 ? (v / 10) % 10 : lo, top = v / 100 ? v / 100 : lo;
+  const int v = tune(ctx, T_FC_SPLIT_DIV, 1), lo = v % 10, hi = (v / 10) % 10 ? (v / 10) % 10 : lo, top = (v / 100) % 10 ? (v / 100) % 10 : lo;
   const int d = K <= 8192 ? hi : K > 50000 ? top : lo;      // (hundreds digit: K > 50000, fc6_maskest)
   return d > 1 && splits > 1 ? (splits / d > 1 ? splits / d : 1) : splits;
 }
 inline int fc_lowp_ranges(const mnc_ctx* ctx, int splits, int K, int tiles) {
   if (tune_set(ctx, T_FC_SPLIT_DIV)) return fc_split_div(ctx, splits, K);
+  if (plan_latency(ctx)) return splits;
   int r = K / 2048 > 1 ? K / 2048 : 1;
   const int half = (128 + tiles - 1) / tiles;
   if (r > half) r = half;
