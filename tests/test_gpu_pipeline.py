@@ -118,6 +118,39 @@ def test_native_pipeline_full_size_vgg16(math):
         net.close()
 
 
+@pytest.mark.parametrize("math", ["fp32", "mixed", "f16"])
+def test_latency_plan_equals_python_engine_and_throughput_plan(math, monkeypatch):
+    """PLAN (round 6): the launch plans for latency (MNC_PLAN=1 at context creation: every product cut until it fills the chip --
+    rounds 1-5's K ranges and conv_sw plans) against the default plans for CU time, full size.  Both executors of the graph follow the
+    context's plan, so native == Python engine bit for bit under either; between the plans only the grouping of the K ranges differs:
+    the RPN outputs agree to 1e-5 of their range (fp32) / the reduced-precision modes' own noise."""
+    from mnc_amd.engine import Net
+    path = models.write_mnc_5stage_test_prototxt()
+    w = synth.synthetic_weights(path, seed=0)
+    im = np.random.default_rng(3).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+    feats = {}
+    for plan in ("0", "1"):
+        monkeypatch.setenv("MNC_PLAN", plan)
+        net = Net(path, w, 1, math=math)
+        nat = NativeNet(w, math=math)
+        try:
+            _check_against_engine(nat, net, im)
+            feats[plan] = {n: nat.blob(n).copy() for n in ("rpn_cls_prob_reshape", "rpn_bbox_pred")}
+        finally:
+            nat.close()
+            net.close()
+    monkeypatch.delenv("MNC_PLAN")
+    differs = False
+    for n, a in feats["0"].items():
+        b = feats["1"][n]
+        rel = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-30))
+        # (f16 rounds every activation to 11 bits: another summation order flips roundings; the mode itself sits 4e-3 from fp32)
+        assert rel < {"fp32": 1e-5, "mixed": 1e-3, "f16": 8e-3}[math], (n, rel)
+        differs = differs or not np.array_equal(a, b)
+    if math == "fp32":
+        assert differs, "the two plans cut the F(4x4) layers' K ranges differently: identical bits mean the switch did nothing"
+
+
 def test_graph_is_dropped_when_a_context_arena_moves():
     """A, A (graph captured), B (seen once: runs eagerly), A again.  With full VGG widths the Winograd tail plan's split-K scratch
     is not monotonic in the image size (net input 600x898 needs less than the SMALLER 562x1000), so B re-allocates the context's
