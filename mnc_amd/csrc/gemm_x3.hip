@@ -687,7 +687,14 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   // 320-row blocks stream the weights once but need many K splits to fill the chip; when a split would be shorter than 64 stages
   // (bf16x3; 32 for fp16), 160-row blocks (twice the tiles, half the splits and half the partial-sum traffic) are faster
   // (measured at M = 300, bf16x3: fc7 59 vs 69 us, fc6_maskest 132 vs 151 us, fc6 274 vs 262 us)
-  if (mt == 10 && (K / kStage) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < (F16 ? 32 : 64)) mt = 5;
+  // Round 6, throughput plan: ONE row block runs on the 256-column LDS-DMA kernel from N = 256 on, in fc_lowp_ranges' K ranges, split
+  // bf16 included -- fc6_maskest (N = 256, K = 100352): one column tile x 49 ranges of 2048 K values on 49 CUs, each operand read
+  // once (111 MB), instead of 2 x 2 tiles x 64 ranges on the 160-row register-staged kernel.  The launch is longer (fp16 37 -> 67 us,
+  // split bf16 65 -> 159) and costs a fifth of the CU time: f16 985 -> 991 images/s, mixed 616 -> 620, bf16x3 488 -> 491 (two runs
+  // each, profiles/r06_fc_ranges.txt); the latency plan keeps the old choice.
+  const bool wide1 = tune(ctx, T_FCX3_WIDE, 1) != 0 && !tune_set(ctx, T_FCX3_TILE) && !plan_latency(ctx) && mt == 10 && N % 256 == 0 && N >= 256 &&
+                     (K / kStage) / fc_lowp_ranges(ctx, 256, K, N / 256) >= (F16 ? 8 : 16);
+  if (!wide1 && mt == 10 && (K / kStage) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < (F16 ? 32 : 64)) mt = 5;
   if (rows256) mt = 8;
   if (tune_set(ctx, T_FCX3_TILE)) {
     const int v = tune(ctx, T_FCX3_TILE, 0);
@@ -706,6 +713,7 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     // K splits cost in the reduction what the kernel gains (fc6: 213.9 + 10.8 us vs 204.5 + 16.9 us) -- the 128-column kernel stays
     if (!F16 && tm == 1 && !tune_set(ctx, T_FCX3_WIDE)) wide = false;
   }
+  if (wide1) wide = true;
   const int bn_w = wide ? 256 : kXBN;
   const int tn = cdiv(N, bn_w);
   int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);

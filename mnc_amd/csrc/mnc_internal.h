@@ -296,6 +296,7 @@ int heads_finish_launch(mnc_ctx* ctx, const float* part, int splits, const float
 int c8_to_hwc_launch(mnc_ctx* ctx, const float* d_feat, float* d_hwc, int C, int H, int W);
 int roi_warp_from_hwc(mnc_ctx* ctx, const float* d_hwc, int C, int H, int W, const float* d_rois, int R, int PH, int PW, float scale,
                       int pool2, float* d_out, void* d_sm, int sm_fmt);
+bool roi_warp_sm_only_ok(const mnc_ctx* ctx, int C, int pool2);      // may d_out be null (with a stage-major output)?
 int detect_tail_launch(mnc_ctx* ctx, const float* d_rois1, int R1, const float* d_rois2, int R2, float scale, int image_height,
                        int image_width, float* d_boxes, const int* d_copy_src, int* d_copy_dst);   // mv.hip: mnc_detect_tail + one int moved
 int mv_launch(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,

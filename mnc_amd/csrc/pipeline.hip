@@ -534,6 +534,15 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   float* feat14 = (float*)n->feat14.p;
   // stage 2: ROIWarping 28x28 + MAX 2x2/2 fused; stage 4: ROIWarping 14x14 directly (test.prototxt:479-505 vs :809-820)
   const int sm_feat = sm_format(n, n->fc_maskest, C5), sm_box = sm_format(n, n->fc6, C5), sm_mask = sm_format(n, n->fc6m, C5);
+  // Round 6: in the fp16 InnerProduct modes whose head runs as paired launches the 14x14 tensor exists in its stage-major fp16 form
+  // only -- fc6_maskest multiplies from it, the poolings read it (mnc_box_mask_pool_ex) -- 120 MB per stage neither written nor read
+  const bool fork0 = n->ctx_b && ctx->profiling == 0 && R > 0;
+  const bool lowp_pairs = n->fuse_small && n->fuse_pools && sm_box == sm_mask && !fork0 && n->fc6.kind != 0 && n->fc6m.kind == n->fc6.kind &&
+                          n->fc7.kind == n->fc6.kind && n->fc7m.kind == n->fc6.kind && n->fc6.K == n->fc6m.K &&
+                          sm_format(n, n->fc7, F) == sm_format(n, n->fc7m, F) && R > 0;
+  const bool sm_only = lowp_pairs && sm_box != 0;                 // box7 / mask7: stage-major only
+  const bool feat_sm_only = sm_only && sm_feat != 0 && (P * P * C5) % 64 == 0 && roi_warp_sm_only_ok(ctx, C5, second ? 0 : 1);
+  if (feat_sm_only) feat14 = nullptr;
   if (n->fuse_small)
     NET_TRY(roi_warp_from_hwc(ctx, (const float*)n->hwc5.p, C5, n->fh, n->fw, rois, R, P, P, c.spatial_scale, second ? 0 : 1, feat14,
                               n->feat14_sm.p, sm_feat));
@@ -548,9 +557,11 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
   // box-feature Pooling and MaskPooling + Pooling read the same 14x14 tensor: one pass (mnc_box_mask_pool) when their
   // InnerProducts take the same activation form (always, with fc6 / fc6_mask of equal shape); MNC_FUSE_POOLS=0: two kernels
   const bool one_pass = n->fuse_pools && sm_box == sm_mask;
+  // (round 6: when the paired reduced-precision InnerProducts below read the stage-major forms, the fp32 copies are not written)
   if (one_pass)
-    NET_TRY(mnc_box_mask_pool(ctx, feat14, (const float*)n->m14.p, (float*)n->box7.p, (float*)n->mask7.p, R, P, P, C5,
-                              n->box7_sm.p, n->mask7_sm.p, sm_box));
+    NET_TRY(mnc_box_mask_pool_ex(ctx, feat14, sm_feat ? n->feat14_sm.p : nullptr, sm_feat, (const float*)n->m14.p,
+                                 sm_only ? nullptr : (float*)n->box7.p, sm_only ? nullptr : (float*)n->mask7.p, R, P, P, C5, n->box7_sm.p,
+                                 n->mask7_sm.p, sm_box));
   // box-feature branch (test.prototxt:604-652): on the second stream when it is available, otherwise in line
   const bool fork = n->ctx_b && ctx->profiling == 0 && R > 0;
   mnc_ctx* cb = fork ? n->ctx_b : ctx;
@@ -569,8 +580,7 @@ int run_stage(mnc_net* n, const float* rois, int R, bool second, int row0) {
                         (const float*)n->fc6m.w, n->fc6m.b, (float*)n->f6m.p, R, F, n->fc6.K, F, 1));
     NET_TRY(mnc_fc_pair(ctx, (const float*)n->f6.p, (const float*)n->fc7.w, n->fc7.b, join + F, (const float*)n->f6m.p,
                         (const float*)n->fc7m.w, n->fc7m.b, join, R, F, F, 2 * F, 1));
-  } else if (n->fuse_small && one_pass && !fork && n->fc6.kind != 0 && n->fc6m.kind == n->fc6.kind &&
-             n->fc7.kind == n->fc6.kind && n->fc7m.kind == n->fc6.kind && n->fc6.K == n->fc6m.K && sm_f6 == sm_f6m && R > 0) {
+  } else if (lowp_pairs) {
     // fp16 / plain bf16 / split bf16 (round 6): the same pairs on the 256-column reduced-precision kernel (mnc_fc_lowp_pair; engine.py
     // pairs the same layers).  Inputs in their stage-major form where the producer wrote it, outputs of fc6 / fc6_mask a second time in
     // fc7's (format 1 = fp16, 2 = split bf16).

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void roi_warp_kernel(const float* __restrict__
     } else {
       o = warp_sample(px, H, W, C, x1s + (float)pw * bw, y1s + (float)ph * bh);
     }
-    *reinterpret_cast<float4*>(out + (long)idx * 4) = o;      // == (((r*PH + ph)*PW + pw)*C + c4*4)
+    if (!SM || out) *reinterpret_cast<float4*>(out + (long)idx * 4) = o;      // == (((r*PH + ph)*PW + pw)*C + c4*4); (SM: optional)
     if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
   }
 }
@@ -522,7 +522,7 @@ __device__ __forceinline__ void warp_row_walk(const float* __restrict__ feat_hwc
           o = (i == 0 && j == 0) ? v : max4(o, v);
         }
     }
-    *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+    if (!SM || orow0) *reinterpret_cast<float4*>(orow + c4 * 4) = o;           // (with a stage-major output the fp32 one is optional)
     if (SM) sm_store4<SM>(sm, M, r, ((long)ph * PW + pw) * C + c4 * 4, o);
   }
 }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void roi_warp_row_kernel(const flo
     const float x1s = roi[1] * scale, y1s = roi[2] * scale, x2s = roi[3] * scale, y2s = roi[4] * scale;
     const float rw = fmaxf(x2s - x1s + 1.0f, 1.0f), rh = fmaxf(y2s - y1s + 1.0f, 1.0f);
     const float bw = rw / (float)GW, bh = rh / (float)GH;
-    float* orow0 = out + ((long)r * PH + ph) * PW * C;
+    float* orow0 = out ? out + ((long)r * PH + ph) * PW * C : nullptr;
     // the two sample rows of a pooled output row are the same for every position of the row: one cell apart or not
     int dy = 0;
     if (POOL2) dy = (int)floorf(y1s + (float)(2 * ph + 1) * bh) - (int)floorf(y1s + (float)(2 * ph) * bh);
@@ -709,15 +709,82 @@ __global__ __launch_bounds__(256) void box_mask_pool_kernel(const float* __restr
       auto mul = [](const float4 f, float k) { return make_float4(f.x * k, f.y * k, f.z * k, f.w * k); };
       v[h] = max4(max4(mul(f00, k00), mul(f01, k01)), max4(mul(f10, k10), mul(f11, k11)));      // mask_pool_kernel<1>'s order
     }
-    float4* db = reinterpret_cast<float4*>(out_box + (long)idx * 4 * NV);
-    float4* dm = reinterpret_cast<float4*>(out_mask + (long)idx * 4 * NV);
+    if (!SM || out_box) {                            // (round 6: a caller whose InnerProducts read the stage-major forms only passes no fp32 outputs)
+      float4* db = reinterpret_cast<float4*>(out_box + (long)idx * 4 * NV);
+      float4* dm = reinterpret_cast<float4*>(out_mask + (long)idx * 4 * NV);
 #pragma unroll
-    for (int h = 0; h < NV; ++h) { db[h] = b[h]; dm[h] = v[h]; }
+      for (int h = 0; h < NV; ++h) { db[h] = b[h]; dm[h] = v[h]; }
+    }
     if (SM) {
       const long k = ((long)oh * OW + ow) * CV * 4 * NV + cv * 4 * NV;
       sm_store8<SM>(sm_box, R, r, k, b[0], b[NV - 1]);
       sm_store8<SM>(sm_mask, R, r, k, v[0], v[NV - 1]);
     }
+  }
+}
+
+// The same pass reading the 14x14 tensor from its STAGE-MAJOR fp16 form (round 6: what the ROIWarping launch wrote for fc6_maskest,
+// [K/64][R][64] halves, K = PH x PW x C) instead of the fp32 tensor -- 60 instead of 120 MB at 300 RoIs x 512 channels, and the warp
+// need not write the fp32 tensor at all.  One thread = one 16-byte group (8 channels) of an output position.  The box pool is the
+// same bits as before (rounding to fp16 is monotonic: the max of the rounded values is the rounded max); MaskPooling multiplies
+// the ROUNDED features by the mask, so its outputs differ from the fp32-input pass in the last fp16 bit -- every executor of a graph
+// reads the same form (pipeline.hip: run_stage; engine.py: Pooling with_mask), so they agree bit for bit.
+// IN = 2: the split-bf16 stage-major form ([K/32][R][4][hi x8 | lo x8], the `mixed` mode's fc6_maskest input): a value is hi + lo, the
+// fp32 value rounded to 16 significant bits, so here the box pool too can differ from the fp32-input pass in the last fp16 bit.
+template <int SM, int IN>
+__global__ __launch_bounds__(256) void box_mask_pool_h_kernel(const uint4* __restrict__ feat_sm, const float* __restrict__ mask,
+                                                              float* __restrict__ out_box, float* __restrict__ out_mask, int R,
+                                                              int PH, int PW, int C8, void* __restrict__ sm_box,
+                                                              void* __restrict__ sm_mask, int bin_on, float bin_thr) {
+  const int OH = PH / 2, OW = PW / 2;
+  const unsigned total = (unsigned)R * OH * OW * C8;
+  for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % (unsigned)C8);
+    unsigned t = idx / (unsigned)C8;
+    const int ow = (int)(t % (unsigned)OW);
+    t /= (unsigned)OW;
+    const int oh = (int)(t % (unsigned)OH);
+    const long r = t / (unsigned)OH;
+    const long m00 = (r * PH + 2 * oh) * PW + 2 * ow;
+    const float k00 = mask_value(mask[m00], bin_on, bin_thr), k01 = mask_value(mask[m00 + 1], bin_on, bin_thr),
+                k10 = mask_value(mask[m00 + PW], bin_on, bin_thr), k11 = mask_value(mask[m00 + PW + 1], bin_on, bin_thr);
+    auto load = [&](int y, int x, float4& lo, float4& hi) {
+      const long k = ((long)(y * PW + x) * C8 + c8) * 8;           // K index of the group's first channel in the roi's row
+      if (IN == 1) {
+        const uint4 u = feat_sm[((k >> 6) * R + r) * 8 + ((k & 63) >> 3)];
+        const f16x8 h = __builtin_bit_cast(f16x8, u);
+        lo = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        hi = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+      } else {
+        const uint4* p = feat_sm + (((k >> 5) * R + r) * 4 + ((k & 31) >> 3)) * 2;
+        const uint4 a = p[0], b = p[1];                              // hi x8, lo x8 (bf16 pairs: element 2i in the low half of word i)
+        auto val = [](unsigned wh, unsigned wl, int odd) {
+          return __uint_as_float(odd ? (wh & 0xFFFF0000u) : (wh << 16)) + __uint_as_float(odd ? (wl & 0xFFFF0000u) : (wl << 16));
+        };
+        lo = make_float4(val(a.x, b.x, 0), val(a.x, b.x, 1), val(a.y, b.y, 0), val(a.y, b.y, 1));
+        hi = make_float4(val(a.z, b.z, 0), val(a.z, b.z, 1), val(a.w, b.w, 0), val(a.w, b.w, 1));
+      }
+    };
+    float4 f[4][2];
+    load(2 * oh, 2 * ow, f[0][0], f[0][1]);
+    load(2 * oh, 2 * ow + 1, f[1][0], f[1][1]);
+    load(2 * oh + 1, 2 * ow, f[2][0], f[2][1]);
+    load(2 * oh + 1, 2 * ow + 1, f[3][0], f[3][1]);
+    auto mul = [](const float4 a, float k) { return make_float4(a.x * k, a.y * k, a.z * k, a.w * k); };
+    float4 b[2], v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      b[h] = max4(max4(max4(f[0][h], f[1][h]), f[2][h]), f[3][h]);                                           // maxpool2_rhwc_kernel's order
+      v[h] = max4(max4(mul(f[0][h], k00), mul(f[1][h], k01)), max4(mul(f[2][h], k10), mul(f[3][h], k11)));   // mask_pool_kernel<1>'s
+    }
+    if (out_box) {
+      float4* db = reinterpret_cast<float4*>(out_box + (long)idx * 8);
+      float4* dm = reinterpret_cast<float4*>(out_mask + (long)idx * 8);
+      db[0] = b[0]; db[1] = b[1]; dm[0] = v[0]; dm[1] = v[1];
+    }
+    const long k = ((long)oh * OW + ow) * C8 * 8 + c8 * 8;
+    sm_store8<SM>(sm_box, R, r, k, b[0], b[1]);
+    sm_store8<SM>(sm_mask, R, r, k, v[0], v[1]);
   }
 }
 
@@ -774,6 +841,13 @@ int c8_to_hwc_launch(mnc_ctx* ctx, const float* d_feat, float* d_hwc, int C, int
 }
 static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_ready, int C, int H, int W, const float* d_rois, int R,
                          int PH, int PW, float scale, int pool2, float* d_out, void* d_sm, int sm_fmt);
+// The fp32 output of a warp that also writes the stage-major form may be omitted on the two kernels the SPEC's convention runs at
+// fewer than 1024 channels (roi_warp_row_kernel for the fused 28x28 + pool, roi_warp_kernel for the plain warp).
+bool roi_warp_sm_only_ok(const mnc_ctx* ctx, int C, int pool2) {
+  if (ctx->conv.warp_sample || ctx->conv.warp_round_edges || ctx->conv.warp_no_plus_one || ctx->conv.warp_oob) return false;
+  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, pool2 ? 3 : C >= 1024 ? 1 : 4);
+  return vsel == 3 || vsel == 4;
+}
 int roi_warp_from_hwc(mnc_ctx* ctx, const float* d_hwc, int C, int H, int W, const float* d_rois, int R, int PH, int PW, float scale,
                       int pool2, float* d_out, void* d_sm, int sm_fmt) {
   return roi_warp_impl(ctx, nullptr, d_hwc, C, H, W, d_rois, R, PH, PW, scale, pool2, d_out, d_sm, sm_fmt);
@@ -793,7 +867,8 @@ int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, cons
 namespace mnc {
 static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_ready, int C, int H, int W, const float* d_rois, int R,
                          int PH, int PW, float scale, int pool2, float* d_out, void* d_sm, int sm_fmt) {
-  MNC_REQUIRE(ctx && (d_feat || d_hwc_ready) && d_out && (R == 0 || d_rois), "mnc_roi_warp: null pointer");
+  MNC_REQUIRE(ctx && (d_feat || d_hwc_ready) && (d_out || (d_sm && sm_fmt)) && (R == 0 || d_rois), "mnc_roi_warp: null pointer");
+  MNC_REQUIRE(d_out || roi_warp_sm_only_ok(ctx, C, pool2), "mnc_roi_warp: this variant / convention writes the fp32 tensor");
   MNC_REQUIRE(C > 0 && C % 8 == 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "mnc_roi_warp: bad shape");
   if (!d_sm) sm_fmt = 0;
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_roi_warp_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
@@ -1017,16 +1092,36 @@ int mnc_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float*
 
 int mnc_box_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, float* d_box_out, float* d_mask_out, int R, int PH,
                       int PW, int C, void* d_box_sm, void* d_mask_sm, int sm_fmt) {
-  MNC_REQUIRE(ctx && d_feat && d_mask && d_box_out && d_mask_out && R >= 0 && PH > 0 && PW > 0 && PH % 2 == 0 && PW % 2 == 0 &&
-                  C > 0 && C % 8 == 0,
+  return mnc_box_mask_pool_ex(ctx, d_feat, nullptr, 0, d_mask, d_box_out, d_mask_out, R, PH, PW, C, d_box_sm, d_mask_sm, sm_fmt);
+}
+
+int mnc_box_mask_pool_ex(mnc_ctx* ctx, const float* d_feat, const void* d_feat_sm, int feat_sm_fmt, const float* d_mask, float* d_box_out,
+                         float* d_mask_out, int R, int PH, int PW, int C, void* d_box_sm, void* d_mask_sm, int sm_fmt) {
+  if ((feat_sm_fmt != 1 && feat_sm_fmt != 2) || !d_box_sm || !d_mask_sm || sm_fmt == 0) d_feat_sm = nullptr;      // (read only on the way to stage-major outputs)
+  MNC_REQUIRE(ctx && (d_feat || d_feat_sm) && d_mask && (d_box_out != nullptr) == (d_mask_out != nullptr) && R >= 0 && PH > 0 && PW > 0 &&
+                  PH % 2 == 0 && PW % 2 == 0 && C > 0 && C % 8 == 0,
               "mnc_box_mask_pool: bad argument (PH, PW even, C%%8==0)");
   if (!d_box_sm || !d_mask_sm) sm_fmt = 0;
+  // the fp32 outputs may be omitted (both null) when the stage-major ones are written: 60 of 210 MB per call at 300 RoIs x 512 channels
+  MNC_REQUIRE(d_box_out || sm_fmt != 0, "mnc_box_mask_pool: no output");
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_box_mask_pool: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
               sm_fmt == 1 ? 64 : 32, C);
   if (R == 0) return MNC_OK;
   MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_box_mask_pool: tensor exceeds the kernel's 32-bit index range");
   const int OH = PH / 2, OW = PW / 2;
-  LaunchScope ls(ctx, "box_mask_pool", 0.0, 4.0 * R * (double)C * (PH * PW + 2.0 * OH * OW));
+  LaunchScope ls(ctx, "box_mask_pool", 0.0, (d_feat_sm && feat_sm_fmt == 1 ? 2.0 : 4.0) * R * (double)C * PH * PW + 4.0 * R * (double)C * (d_box_out ? 2.0 : 0.0) * OH * OW +
+                                                (sm_fmt == 1 ? 4.0 : sm_fmt == 2 ? 8.0 : 0.0) * R * (double)C * OH * OW);
+  if (d_feat_sm) {
+    MNC_REQUIRE(((long)PH * PW * C) % 64 == 0, "mnc_box_mask_pool: the stage-major input needs PH x PW x C %% 64 == 0");
+#define MNC_BMPH(SM, IN)                                                                                                        \
+  hipLaunchKernelGGL((box_mask_pool_h_kernel<SM, IN>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream,   \
+                     (const uint4*)d_feat_sm, d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm,              \
+                     ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)
+    if (feat_sm_fmt == 1) { if (sm_fmt == 1) MNC_BMPH(1, 1); else MNC_BMPH(2, 1); }
+    else { if (sm_fmt == 1) MNC_BMPH(1, 2); else MNC_BMPH(2, 2); }
+#undef MNC_BMPH
+    return ls.finish("box_mask_pool_h_kernel");
+  }
   if (sm_fmt == 1)
     hipLaunchKernelGGL((box_mask_pool_kernel<1, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
                        d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);

@@ -1057,8 +1057,13 @@ class Net(object):
                     mdst = mtop.dev_out("rhwc")
                     mfmt = self._sm_format(mtop.name, R, K, C) if R else 0
                     if R and fmt == mfmt and C % 8 == 0:
-                        _lib.call("mnc_box_mask_pool", self._h(), src, d_mask, dst, mdst, R, PH, PW, C,
-                                  top.sm_out(fmt, R, K) if fmt else None, mtop.sm_out(fmt, R, K) if fmt else None, fmt)
+                        # round 6: the tensor is read from its stage-major fp16 copy when its producer wrote one (what
+                        # csrc/pipeline.hip's run_stage does: mnc_hip.h, mnc_box_mask_pool_ex -- same bits in both executors)
+                        sm_in = bot._sm if (fmt and bot._sm and bot._sm["fmt"] in (1, 2) and bot._sm["M"] == R
+                                            and bot._sm["K"] == C * PH * PW) else None
+                        _lib.call("mnc_box_mask_pool_ex", self._h(), src, sm_in["ptr"] if sm_in else None, sm_in["fmt"] if sm_in else 0, d_mask,
+                                  dst, mdst, R, PH, PW, C, top.sm_out(fmt, R, K) if fmt else None,
+                                  mtop.sm_out(fmt, R, K) if fmt else None, fmt)
                         return
                     if R:
                         if mfmt:

@@ -461,6 +461,15 @@ class Fake(object):
         self.mnc_maxpool2_rhwc_sm(h, feat, box, R, PH, PW, C, box_sm, fmt)
         self.mnc_mask_pool_sm(h, feat, mask, mout, R, PH, PW, C, 1, mask_sm, fmt)
 
+    def mnc_box_mask_pool_ex(self, h, feat, feat_sm, feat_fmt, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt):
+        if feat_sm and feat_fmt in (1, 2) and box_sm and mask_sm and fmt:
+            # the pooling reads the stage-major copy: the fp32 tensor rounded to fp16 (what its producer wrote); the split-bf16
+            # stand-in of this double keeps the fp32 values
+            rows = _h16(feat_sm, (R, PH * PW * C)).astype(np.float32) if feat_fmt == 1 else _f(feat_sm, (R, PH * PW * C)).copy()
+            self._keep_feat = np.ascontiguousarray(rows)
+            feat = self._keep_feat.ctypes.data
+        self.mnc_box_mask_pool(h, feat, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt)
+
     def _fc_ex(self, fn, fmt16, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
         if sm:
             rows = _h16(sm, (mstride, K))[:M].astype(np.float32) if fmt16 else _f(sm, (mstride, K))[:M]

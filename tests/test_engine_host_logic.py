@@ -48,7 +48,7 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     calls = fake_gpu.calls
     if math == "fp32":
         assert not any(k.endswith(("_sm", "_pre")) for k in calls)
-        assert (calls.get("mnc_box_mask_pool", 0) > 0) == fuse and ("mnc_mask_pool" in calls) == (not fuse)
+        assert (calls.get("mnc_box_mask_pool_ex", 0) > 0) == fuse and ("mnc_mask_pool" in calls) == (not fuse)
     else:
         # reduced-precision InnerProducts: the per-RoI producers write the rows in the GEMM's own stage-major 2-byte form and the
         # six big InnerProducts on per-RoI features (fc6_maskest, fc6, fc6_mask of both stages) take them without converting
@@ -67,7 +67,7 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
         assert calls.get(ex, 0) + 2 * n_pair >= 10 * runs
         assert "mnc_fc_f16" not in calls and "mnc_fc_bf16x3" not in calls
         # the box-feature Pooling and MaskPooling + Pooling of a stage read the same tensor: one pass, both second outputs
-        assert calls.get("mnc_box_mask_pool") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
+        assert calls.get("mnc_box_mask_pool_ex") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
     if math == "f16":
         # 2-byte trunk activations: conv1_1 .. conv5_2 write packed fp16, conv5_3 (read by the RoI layers) fp32
         assert calls.get("mnc_conv3x3_f16_pk") == 12 and calls.get("mnc_conv3x3_c3_fmt") == 1 and calls.get("mnc_maxpool2_c8_f16") == 4
@@ -128,7 +128,7 @@ def test_fusion_plan(fake_gpu):
     im = np.random.default_rng(0).integers(0, 256, (40, 56, 3), dtype=np.uint8)
     fake_gpu.calls.clear()
     demo.im_detect(im, net)
-    stages = fake_gpu.calls.get("mnc_box_mask_pool")                # head stages run (two; four when the heads are re-run on the exact RoI count)
+    stages = fake_gpu.calls.get("mnc_box_mask_pool_ex")              # head stages run (two; four when the heads are re-run on the exact RoI count)
     assert stages in (2, 4)
     assert fake_gpu.calls.get("mnc_fc_pair") == 2 * stages          # fc6 + fc6_mask, fc7 + fc7_mask per stage
     assert fake_gpu.calls.get("mnc_fc") == 3 * stages               # fc6_maskest, mask_pred, the sibling classifiers' GEMM per stage

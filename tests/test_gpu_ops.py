@@ -848,6 +848,47 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
         if f:
             assert np.array_equal(dev.get(d_bsm, (R * K7 * eb,), dtype=np.uint8), shadow_of(d_b2, R, K7))
             assert np.array_equal(dev.get(d_msm, (R * K7 * eb,), dtype=np.uint8), shadow_of(d_m2, R, K7))
+    # round 6 (mnc_box_mask_pool_ex): the fp32 outputs omitted -> the same stage-major bits; the tensor read from its stage-major fp16
+    # copy (format 1) -> exactly the fp32 pass on the fp16-ROUNDED tensor (box pool: the bits of the pass on the unrounded one)
+    d_bs, d_ms = (dev.empty((R * K7 * eb,), dtype=np.uint8, fill=0xAB) for _ in range(2))
+    dev.call("mnc_box_mask_pool_ex", d_x, None, 0, d_m, None, None, R, P, P, C, d_bs, d_ms, fmt)
+    assert np.array_equal(dev.get(d_bs, (R * K7 * eb,), dtype=np.uint8), dev.get(d_bsm, (R * K7 * eb,), dtype=np.uint8))
+    assert np.array_equal(dev.get(d_ms, (R * K7 * eb,), dtype=np.uint8), dev.get(d_msm, (R * K7 * eb,), dtype=np.uint8))
+    K14 = P * P * C
+    for in_fmt in (1, 2):
+        ib = 2 if in_fmt == 1 else 4
+        d_xsm = dev.empty((R * K14 * ib,), dtype=np.uint8, fill=0xAB)
+        dev.call("mnc_fc_pack_act", d_x, d_xsm, R, K14, 1 if in_fmt == 1 else 0)
+        if in_fmt == 1:
+            xr = x.astype(np.float16).astype(np.float32)
+        else:                                          # split bf16: hi = rne(x), lo = rne(x - hi); the form holds hi + lo
+            hi = _rbf16(x)
+            xr = hi + _rbf16(x - hi)
+        d_xr = dev.put(xr)
+        want = [dev.empty((R * K7 * eb,), dtype=np.uint8, fill=0) for _ in range(2)]
+        d_wb, d_wm = dev.empty((R * K7,), fill=np.nan), dev.empty((R * K7,), fill=np.nan)
+        dev.call("mnc_box_mask_pool", d_xr, d_m, d_wb, d_wm, R, P, P, C, want[0], want[1], fmt)
+        for with_f32 in (True, False):
+            d_b3, d_m3 = dev.empty((R * K7,), fill=np.nan), dev.empty((R * K7,), fill=np.nan)
+            d_bs, d_ms = (dev.empty((R * K7 * eb,), dtype=np.uint8, fill=0xAB) for _ in range(2))
+            dev.call("mnc_box_mask_pool_ex", None, d_xsm, in_fmt, d_m, d_b3 if with_f32 else None, d_m3 if with_f32 else None, R, P, P, C,
+                     d_bs, d_ms, fmt)
+            assert np.array_equal(dev.get(d_bs, (R * K7 * eb,), dtype=np.uint8), dev.get(want[0], (R * K7 * eb,), dtype=np.uint8)), in_fmt
+            assert np.array_equal(dev.get(d_ms, (R * K7 * eb,), dtype=np.uint8), dev.get(want[1], (R * K7 * eb,), dtype=np.uint8)), in_fmt
+            if with_f32:
+                assert np.array_equal(dev.get(d_b3, (R * K7,)), dev.get(d_wb, (R * K7,)))
+                assert np.array_equal(dev.get(d_m3, (R * K7,)), dev.get(d_wm, (R * K7,)))
+        if fmt == 1 and in_fmt == 1:
+            assert np.array_equal(dev.get(want[0], (R * K7 * eb,), dtype=np.uint8), dev.get(d_bsm, (R * K7 * eb,), dtype=np.uint8))
+    # the warp with its fp32 output omitted: the same stage-major bits (both kernels the SPEC's convention runs below 1024 channels)
+    for pool2 in ((0, 1) if variant != "8" else ()):
+        K = P * P * C
+        d_f, d_s0, d_s1 = dev.empty((R * K,), fill=np.nan), dev.empty((R * K * eb,), dtype=np.uint8, fill=0xAB), dev.empty((R * K * eb,), dtype=np.uint8, fill=0xCD)
+        dev.call("mnc_roi_warp_sm", d_feat, C, H, W, d_rois, R, P, P, 0.0625, pool2, d_f, d_s0, fmt)
+        dev.call("mnc_roi_warp_sm", d_feat, C, H, W, d_rois, R, P, P, 0.0625, pool2, None, d_s1, fmt)
+        assert np.array_equal(dev.get(d_s0, (R * K * eb,), dtype=np.uint8), dev.get(d_s1, (R * K * eb,), dtype=np.uint8)), pool2
+    with pytest.raises(Exception):
+        dev.call("mnc_roi_warp_sm", d_feat, C, H, W, d_rois, R, P, P, 0.0625, 0, None, None, 0)
     # a channel count whose 8-channel groups would straddle a stage is refused, not mis-packed
     with pytest.raises(Exception):
         dev.call("mnc_maxpool2_rhwc_sm", d_x, d_b, R, P, P, 24, d_sm, fmt)
