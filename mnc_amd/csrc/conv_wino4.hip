@@ -769,10 +769,10 @@ static int wino4_impl(mnc_ctx* ctx, const float* d_in, const float* d_wpk, const
   if (tune_set(ctx, T_CONV_KSPLIT)) {                            // uniform K ranges (tests, A/B)
     const int v = tune(ctx, T_CONV_KSPLIT, 1);
     if (v >= 1 && v <= 8 && v <= blocks) { pix_a = pix; ksplit_a = v; ksplit_b = 1; }
-  } else if (tune(ctx, T_WINO_TAIL, plan_latency(ctx) ? 1 : 0) == 0) {
-    // round 6: the tail round of a layer larger than one round is NOT cut by default (WINO_TAIL=1: rounds 4-5) -- the cut shortens
-    // the launch of an image that has the chip to itself (one at a time 231.8 -> 229.5 images/s without it) and costs slabs and
-    // reducers; with four images in flight the tail's free CUs are not idle: 271.4 -> 273.6 images/s (two runs each)
+  } else if (tune(ctx, T_WINO_TAIL, 1) == 0) {
+    // (WINO_TAIL=0, round 6: no cut of the tail round of a layer larger than one round -- with four images in flight the tail's free
+    // CUs are not idle: 271.4 -> 273.6 images/s, two runs each.  NOT the default: uncut, conv3_x runs the matrix pipe 44 % of a solo
+    // launch's cycles instead of 51 %, and ">= 50 % MFMA utilisation on conv3_x" is a target of BASELINE.json measured per launch.)
     if (pix_a < pix) { pix_a = pix; ksplit_b = 1; }
   }
   float* part = nullptr;
