@@ -692,7 +692,7 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   // once (111 MB), instead of 2 x 2 tiles x 64 ranges on the 160-row register-staged kernel.  The launch is longer (fp16 37 -> 67 us,
   // split bf16 65 -> 159) and costs a fifth of the CU time: f16 985 -> 991 images/s, mixed 616 -> 620, bf16x3 488 -> 491 (two runs
   // each, profiles/r06_fc_ranges.txt); the latency plan keeps the old choice.
-  const bool wide1 = tune(ctx, T_FCX3_WIDE, 1) != 0 && !tune_set(ctx, T_FCX3_TILE) && !plan_latency(ctx) && mt == 10 && N % 256 == 0 && N >= 256 &&
+  const bool wide1 = tune(ctx, T_FCX3_WIDE, 1) != 0 && !tune_set(ctx, T_FCX3_TILE) && !plan_latency(ctx) && mt == 10 && M <= 320 && N % 256 == 0 && N >= 256 &&
                      (K / kStage) / fc_lowp_ranges(ctx, 256, K, N / 256) >= (F16 ? 8 : 16);
   if (!wide1 && mt == 10 && (K / kStage) / cdiv(256, cdiv(N, kXBN) * cdiv(M, 320)) < (F16 ? 32 : 64)) mt = 5;
   if (rows256) mt = 8;
