@@ -714,6 +714,8 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     if (!F16 && tm == 1 && !tune_set(ctx, T_FCX3_WIDE)) wide = false;
   }
   if (wide1) wide = true;
+  // (the 256-column kernel addresses a stage of the activations by a 32-bit scalar offset: stages x m_stride x 128 bytes)
+  if (wide && (double)stages * (double)(d_pre ? mstride : M) * 128.0 >= 4.0e9) wide = false;
   const int bn_w = wide ? 256 : kXBN;
   const int tn = cdiv(N, bn_w);
   int splits = cdiv(mt == 2 ? 512 : 256, tn * tm);
@@ -833,6 +835,7 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   if (M == 0) return MNC_OK;
   const int stages = K / kStage, tn = N / 256;
   bool paired = M > 160 && M <= 320 && N % 256 == 0 && N >= 512 && 2.0 * M * (double)N * K >= 2.0e9 && tune(ctx, T_FCX3_WIDE, 1) != 0 &&
+                (double)stages * (double)((d_pre0 || d_pre1) ? mstride : M) * 128.0 < 4.0e9 &&
                 !tune_set(ctx, T_FCX3_TILE) && tune(ctx, T_FUSE_SMALL, 1) != 0;
   int splits = 1;
   if (paired) {
