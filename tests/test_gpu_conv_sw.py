@@ -135,6 +135,26 @@ def test_conv3x3_lowp_vgg_layers(dev, mode):
         print("conv lowp %s %dx%d %d->%d: rel=%.3e" % (mode, H, W, Cin, Cout, rel))
 
 
+@pytest.mark.parametrize("mode", ["f16", "bf16x3"])
+def test_conv3x3_lowp_plan_switch(dev, mode):
+    """PLAN (round 6): the default plans are made for CU time -- the plain plan 0 down to 64 workgroups -- and PLAN=1 brings back the
+    chip-filling choices of rounds 1-5: conv4_x (75x125, 512 channels) on plan 1, conv5_x (38x63) on plan 2.  Held bit for bit
+    against the forced plan (CONVX3_TILE), at a quarter of the layers' input channels."""
+    for H, W, Cin, Cout, lat_plan in ((75, 125, 64, 512, 1), (38, 63, 128, 512, 2)):
+        rng = np.random.default_rng(H + 3)
+        x = np.maximum(rng.normal(size=(Cin, H, W)), 0).astype(np.float32)
+        w = (rng.normal(size=(Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+        b = rng.normal(size=Cout).astype(np.float32)
+        forced = {p: run_lowp(dev, mode, x, w, b, 1, plan=p, want_packed=False)[0] for p in (0, lat_plan)}
+        assert not np.array_equal(forced[0], forced[lat_plan])          # (the plans group the K sums differently)
+        assert np.array_equal(run_lowp(dev, mode, x, w, b, 1, want_packed=False)[0], forced[0])
+        dev.tune("PLAN", 1)
+        try:
+            assert np.array_equal(run_lowp(dev, mode, x, w, b, 1, want_packed=False)[0], forced[lat_plan])
+        finally:
+            dev.tune("PLAN", None)
+
+
 def test_lowp_weight_layout(dev):
     """[chunk][Cout/32][plane][tap][32] x 8 values: f16 plane p = channels 8p..8p+7; bf16x3 planes (hi 0-7, hi 8-15, lo 0-7, lo 8-15)
     with hi + lo reproducing the weight to 2^-15; channels past Cin are zero."""
