@@ -1276,6 +1276,22 @@ def test_fc_lowp_pair(dev, mode, M, N, K, pre, tune):
             d_s = dev.empty((M * N,), fill=np.nan)
             dev.call("mnc_fc_" + mode, d_a[i], d_w[i], d_b[i], d_s, M, N, K, N, 1)
             assert np.array_equal(dev.get(d_s, (M, N)), got[i])
+    if K >= 16384 and M > 160 and N % 256 == 0:
+        # PLAN (round 6): the default cuts K into ranges of >= 2048 values on at most half the chip; PLAN=1 is rounds 3-5's full cut
+        # (= FC_SPLIT_DIV=0): the same product, another grouping of the partial sums
+        def again():
+            d_o2 = dev.empty((M * ld,), fill=np.nan)
+            dev.call("mnc_fc_lowp_pair", m, None if use_pre else d_a[0], d_sm[0], None if use_pre else d_a[1], d_sm[1], M, d_w[0], d_w[1],
+                     d_b[0], d_b[1], d_o2 + N * 4, d_o2, M, N, K, ld, 1, None, None, 0)
+            return dev.get(d_o2, (M, ld))
+        tune("PLAN", "1")
+        lat = again()
+        dev.tune("PLAN", None)
+        tune("FC_SPLIT_DIV", "0")
+        full = again()
+        dev.tune("FC_SPLIT_DIV", None)
+        assert np.array_equal(lat, full) and not np.array_equal(lat, o)
+        assert err(lat, o)[1] < (1e-4 if mode == "bf16x3" else 1e-5)
 
 
 def test_fc_column_slice_and_pack(dev):
