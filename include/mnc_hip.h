@@ -512,7 +512,7 @@ MNC_API int mnc_box_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_
  * per call at 300 RoIs x 512 channels) -- and (b) the 14x14 tensor read from its stage-major fp16 form d_feat_sm (feat_sm_fmt = 1:
  * [PH*PW*C/64][R][64] halves, what mnc_roi_warp_sm wrote for fc6_maskest) when stage-major outputs are written: 60 instead of 120 MB
  * read, and the producer need not write the fp32 tensor (mnc_roi_warp_sm accepts d_out_rhwc = NULL with a stage-major output on the
- * SPEC's convention below 1024 channels).  d_box_sm is then the same bits as from the fp32 tensor (rounding is monotonic); d_mask_sm
+ * SPEC's convention and the launcher's own kernel choice).  d_box_sm is then the same bits as from the fp32 tensor (rounding is monotonic); d_mask_sm
  * multiplies the ROUNDED features by the mask and differs in the last fp16 bit -- every executor of a graph must pass the same
  * inputs (csrc/pipeline.hip and engine.py both pass d_feat_sm whenever the producer wrote it).  feat_sm_fmt = 2: the split-bf16 form
  * ([PH*PW*C/32][R][4][hi x8 | lo x8]; a value is hi + lo, 16 significant bits -- the box pool too may then differ in the last fp16

@@ -706,7 +706,9 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
   // bytes per flop (the reduced-precision pipe is power limited, DESIGN.md section 9 item 4: bytes are energy) -- when its K splits keep at least 8 stages
   // (fc7 at 300 RoIs would get 4: prologue and epilogue of a workgroup then outweigh the traffic saved).  FCX3_WIDE=0: off.
   bool wide = false;
-  if ((mt == 8 || mt == 10) && N % 256 == 0 && N >= 512 && tune(ctx, T_FCX3_WIDE, 1) != 0) {
+  // (throughput plan, round 6: from N = 256 on -- one column tile per row block; ResNet-50 configuration, fc6_maskest at 1000 RoIs:
+  // f16 260.5 -> 264.6 images/s, mixed 130.2 -> 134.2)
+  if ((mt == 8 || mt == 10) && N % 256 == 0 && N >= (plan_latency(ctx) ? 512 : 256) && tune(ctx, T_FCX3_WIDE, 1) != 0) {
     const int sp = cdiv(256, (N / 256) * tm);
     wide = stages / (sp > 0 ? sp : 1) >= (F16 ? 8 : 16);
     // split bf16 at one row block (300 RoIs): three MFMAs per term make the operand bytes a smaller share of the work, and the doubled
@@ -728,7 +730,9 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     if (splits == 1 && full > 1 && d_osm && (ldc != N || osm_rows != M || osm_row0 != 0)) splits = 2;
   }
   if (tm > 1 && mt != 2)     // several row blocks: split count by cost (mnc_internal.h: choose_splits)
-    splits = choose_splits(tn * tm, stages, min_stages, 256,
+    // (round 6, throughput plan: the K ranges fill HALF the chip here too -- ResNet-50 configuration, 1000 RoIs, four images in
+    // flight: f16 249 -> 262 images/s, mixed 126.5 -> 131.6 with 128 slots, 259 with 64; FC_SLOTS overrides)
+    splits = choose_splits(tn * tm, stages, min_stages, tune(ctx, T_FC_SLOTS, plan_latency(ctx) ? 256 : 128),
                            (double)bm * bn_w * kStage * 2.0 / (F16 ? 2000.0e3 : 1050.0e3), 4.0 * M * (double)N);
   const int kper = cdiv(stages, splits) * kStage;
   splits = cdiv(K, kper);
@@ -834,11 +838,29 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   constexpr int kStage = F16 ? 64 : kXBK;
   if (M == 0) return MNC_OK;
   const int stages = K / kStage, tn = N / 256;
-  bool paired = M > 160 && M <= 320 && N % 256 == 0 && N >= 512 && 2.0 * M * (double)N * K >= 2.0e9 && tune(ctx, T_FCX3_WIDE, 1) != 0 &&
+  // Several row blocks (round 6, throughput plan only; the ResNet-50 configuration's 1000 RoIs): the pair runs as ONE launch too when
+  // fc_lowp would run each product as one launch -- 256-row blocks, or 320-row blocks without a ragged tail of <= 160 rows
+  int mt = 10, tm = 1;
+  bool multi = false;
+  if (M > 320 && !plan_latency(ctx)) {
+    const int tail = M % 320;
+    const long cost320 = (long)(M / 320) * 448 + (tail == 0 ? 0 : tail <= 160 ? 288 : 448);
+    const long cost256 = (long)cdiv(M, 256) * 384;
+    const bool rows256 = cost256 < cost320 && !tune(ctx, T_FC_NO256, 0);
+    multi = rows256 || tail == 0 || tail > 160 || tune(ctx, T_FC_NOTAIL, 0);
+    mt = rows256 ? 8 : 10;
+    tm = cdiv(M, 32 * mt);
+  }
+  bool paired = M > 160 && (M <= 320 || multi) && N % 256 == 0 && N >= 512 && 2.0 * M * (double)N * K >= 2.0e9 && tune(ctx, T_FCX3_WIDE, 1) != 0 &&
                 (double)stages * (double)((d_pre0 || d_pre1) ? mstride : M) * 128.0 < 4.0e9 &&
                 !tune_set(ctx, T_FCX3_TILE) && tune(ctx, T_FUSE_SMALL, 1) != 0;
   int splits = 1;
-  if (paired) {
+  if (paired && tm > 1) {
+    splits = choose_splits(2 * tn * tm, stages, F16 ? 4 : 8, tune(ctx, T_FC_SLOTS, 128),
+                           (double)(32 * mt) * 256 * kStage * 2.0 / (F16 ? 2000.0e3 : 1050.0e3), 8.0 * M * (double)N);
+    paired = stages / splits >= (F16 ? 8 : 16);
+    if (splits == 1 && stages >= 2 * (F16 ? 8 : 16) && (d_osm0 || d_osm1) && ldc != N) splits = 2;
+  } else if (paired) {
     splits = cdiv(256, 2 * tn);
     if (splits > stages / (F16 ? 4 : 8)) splits = stages / (F16 ? 4 : 8);
     if (splits < 1) splits = 1;
@@ -884,17 +906,25 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
   {
     const double flops = 4.0 * M * (double)N * K, bytes = (F16 ? 4.0 : 8.0) * ((double)N * K + (double)M * K) + 8.0 * (double)M * N;
     LaunchScope ls(ctx, F16 == 2 ? "fc_bf16" : F16 ? "fc_f16" : "fc_bf16x3", flops, bytes);
-    constexpr int lds = 2 * (320 + 256) * 128;
     static std::atomic<unsigned long long> attr_set{0};            // one bit per device
     const unsigned long long bit = 1ull << (ctx->device & 63);
     if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
       MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_lowp_dma_kernel<10, F16>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (320 + 256) * 128));
+      MNC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fc_lowp_dma_kernel<8, F16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 256) * 128));
       attr_set.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((fc_lowp_dma_kernel<10, F16>), dim3(2 * tn * splits), dim3(512), lds, ctx->stream, ax[0], (const uint4*)d_w0,
-                       d_bias0, d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, 1, ms[0], ax[1],
-                       (const uint4*)d_w1, d_bias1, d_out1, tn);
+    // (several row blocks: row block fastest, so that the workgroups sharing a weight panel are neighbours on one XCD -- fc_lowp)
+    const int tm_arg = tm > 1 ? -tm : 1;
+    if (mt == 8)
+      hipLaunchKernelGGL((fc_lowp_dma_kernel<8, F16>), dim3(2 * tn * splits * tm), dim3(512), 2 * (256 + 256) * 128, ctx->stream, ax[0],
+                         (const uint4*)d_w0, d_bias0, d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, tm_arg,
+                         ms[0], ax[1], (const uint4*)d_w1, d_bias1, d_out1, tn);
+    else
+      hipLaunchKernelGGL((fc_lowp_dma_kernel<10, F16>), dim3(2 * tn * splits * tm), dim3(512), 2 * (320 + 256) * 128, ctx->stream, ax[0],
+                         (const uint4*)d_w0, d_bias0, d_out0, part, M, N, K, ldc, kper, act, splits == 1 ? 1 : 0, 2 * tn, splits, tm_arg,
+                         ms[0], ax[1], (const uint4*)d_w1, d_bias1, d_out1, tn);
     rc = ls.finish("fc_lowp_dma_kernel<pair>");
     if (rc) return rc;
   }

@@ -32,7 +32,7 @@ namespace mnc {
 // superseded kernel builds (FC_ABL, FC_DMA_ABL, FCX3_ABL, CONV_ABL, WINO_V = 1, WINO_VAR != 7) are only compiled with -DMNC_TUNING.
 #define MNC_TUNE_KEYS(X)                                                                                                          \
   X(CONV_COT) X(CONV_ROWS) X(CONV_KSPLIT) X(CONV_ABL) X(CONV1X1_TILE) X(CONV2D_WIDE) X(WINO_ROWS) X(WINO_TAIL) X(WINO_V) X(WINO_VAR)  \
-  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(PLAN) X(FC_EVEN) X(FC_SPLIT_DIV) X(WINO_FILL) X(CONVX3_P0MIN) X(CONVX3_P1MIN) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
+  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(PLAN) X(FC_SLOTS) X(FC_EVEN) X(FC_SPLIT_DIV) X(WINO_FILL) X(CONVX3_P0MIN) X(CONVX3_P1MIN) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
   X(FC_NO256) X(FCX3_TILE) X(FC_ORDER) X(FCX3_ABL) X(FC_SM) X(PACKED_ACT) X(FUSE_POOLS) X(BRANCH_STREAMS) X(TOPK_SINGLE_WG)           \
   X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(ROI_ROW_SEGS)
 enum TuneKey {

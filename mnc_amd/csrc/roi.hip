@@ -322,7 +322,7 @@ __device__ __forceinline__ void warp_pool2_shared_taps(const float* __restrict__
 #undef MNC_BL
       o = i == 0 ? v : max4(o, v);
     }
-    *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+    if (!SM || orow) *reinterpret_cast<float4*>(orow + c4 * 4) = o;
     if (SM) sm_store4<SM>(sm, M, r, kpos + c4 * 4, o);
   }
 }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void roi_warp_wave_kernel(const float* __restr
       smp[i] = warp_setup(H, W, C, x1s + (float)gx * bw, y1s + (float)gy * bh);
       safe = safe && smp[i].v00 && smp[i].v01 && smp[i].v10 && smp[i].v11;
     }
-    float* orow = out + (long)pos * C;
+    float* orow = out ? out + (long)pos * C : nullptr;          // (null with a stage-major output only: round 6)
     const long kpos = ((long)ph * PW + pw) * C;
     if (POOL2 && safe && smp[NS - 1].x0 - smp[0].x0 <= 1 && smp[NS - 1].y0 - smp[0].y0 <= 1) {
       const int dx = smp[NS - 1].x0 - smp[0].x0, dy = smp[NS - 1].y0 - smp[0].y0;      // 0 or 1 each, wave-uniform
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void roi_warp_wave_kernel(const float* __restr
         float4 o = warp_taps(px, W, C, smp[0]);
 #pragma unroll
         for (int i = 1; i < NS; ++i) o = max4(o, warp_taps(px, W, C, smp[i]));
-        *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+        if (!SM || orow) *reinterpret_cast<float4*>(orow + c4 * 4) = o;
         if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
       }
     } else {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void roi_warp_wave_kernel(const float* __restr
           const float4 v = warp_sample(px, H, W, C, x1s + (float)gx * bw, y1s + (float)gy * bh);
           o = i == 0 ? v : max4(o, v);
         }
-        *reinterpret_cast<float4*>(orow + c4 * 4) = o;
+        if (!SM || orow) *reinterpret_cast<float4*>(orow + c4 * 4) = o;
         if (SM) sm_store4<SM>(sm, R, r, ((long)ph * PW + pw) * C + c4 * 4, o);
       }
     }
@@ -841,12 +841,13 @@ int c8_to_hwc_launch(mnc_ctx* ctx, const float* d_feat, float* d_hwc, int C, int
 }
 static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_ready, int C, int H, int W, const float* d_rois, int R,
                          int PH, int PW, float scale, int pool2, float* d_out, void* d_sm, int sm_fmt);
-// The fp32 output of a warp that also writes the stage-major form may be omitted on the two kernels the SPEC's convention runs at
-// fewer than 1024 channels (roi_warp_row_kernel for the fused 28x28 + pool, roi_warp_kernel for the plain warp).
+// The fp32 output of a warp that also writes the stage-major form may be omitted on the kernels the SPEC's convention runs by
+// default (roi_warp_row_kernel for the fused 28x28 + pool, roi_warp_kernel / roi_warp_wave_kernel for the plain warp below / from
+// 1024 channels); not on the 8-channels-per-thread variant and the generic-convention kernel.
 bool roi_warp_sm_only_ok(const mnc_ctx* ctx, int C, int pool2) {
   if (ctx->conv.warp_sample || ctx->conv.warp_round_edges || ctx->conv.warp_no_plus_one || ctx->conv.warp_oob) return false;
   const int vsel = tune(ctx, T_ROI_WARP_VARIANT, pool2 ? 3 : C >= 1024 ? 1 : 4);
-  return vsel == 3 || vsel == 4;
+  return vsel == 3 || vsel == 4 || vsel == 1;
 }
 int roi_warp_from_hwc(mnc_ctx* ctx, const float* d_hwc, int C, int H, int W, const float* d_rois, int R, int PH, int PW, float scale,
                       int pool2, float* d_out, void* d_sm, int sm_fmt) {

@@ -1222,13 +1222,15 @@ def test_fc_f16(dev, M, N, K, act, tune):
 
 @pytest.mark.parametrize("mode", ["f16", "bf16", "bf16x3"])
 @pytest.mark.parametrize("M,N,K,pre", [(300, 4096, 6272, True), (300, 1024, 4096, False), (200, 512, 2048, True), (300, 4096, 25088, True),
-                                       (120, 512, 4096, False), (300, 384, 4096, False)])
+                                       (120, 512, 4096, False), (300, 384, 4096, False), (1000, 1024, 4096, True), (640, 512, 8192, False),
+                                       (700, 512, 4096, True)])
 def test_fc_lowp_pair(dev, mode, M, N, K, pre, tune):
     """mnc_fc_lowp_pair (round 6): two reduced-precision InnerProducts of one shape in one launch.  Each product against torch on the
     operands the mode rounds to (fp16 / bf16: 1e-5 of the range -- only the summation order differs; split bf16: 1e-4 against fp32),
     written as a column slice (ldc = 2 N: fc7 / fc7_mask's Concat in place), inputs as fp32 rows or stage-major, the second outputs
     bit for bit mnc_fc_pack_act of the fp32 rows; the same bits on every launch; shapes the paired kernel does not take (M <= 160,
-    N % 256 != 0) equal the two single calls."""
+    N % 256 != 0) equal the two single calls.  M > 320 (round 6, throughput plan): several row blocks in the one launch -- 256-row
+    blocks (1000), 320-row blocks (640); 700 rows = 2 x 320 + a ragged 60-row tail stay two single calls."""
     m = {"bf16x3": 0, "f16": 1, "bf16": 2}[mode]
     rnd = (lambda x: x.astype(np.float16).astype(np.float32)) if mode == "f16" else _rbf16 if mode == "bf16" else (lambda x: x)
     rng = np.random.default_rng(M + N + K + m)
@@ -1271,7 +1273,7 @@ def test_fc_lowp_pair(dev, mode, M, N, K, pre, tune):
             d_chk = dev.empty((M * N // wpv,), fill=np.nan)
             dev.call("mnc_fc_pack_act", dev.put(np.ascontiguousarray(got[i])), d_chk, M, N, 1 if mode == "f16" else 0)
             assert np.array_equal(dev.get(d_chk, (M * N // wpv,)).view(np.uint32), outs[0][1][i])
-    if M <= 160 or N % 256:       # not paired: the two single calls, bit for bit
+    if M <= 160 or N % 256 or M == 700:       # not paired: the two single calls, bit for bit
         for i in range(2):
             d_s = dev.empty((M * N,), fill=np.nan)
             dev.call("mnc_fc_" + mode, d_a[i], d_w[i], d_b[i], d_s, M, N, K, N, 1)
