@@ -103,10 +103,18 @@ class _DevBuf(object):
         self.ptr, self.cap = 0, 0
 
 
+# Packed 2-byte-class activation layouts of the reduced-precision trunks (include/mnc_hip.h "Packed 2-byte activations"): the c8
+# order in the mode's own operand form.  layout -> (bytes per value, mnc_act_pack format); conv math -> layout.
+_PACKED = {"c8h": (2, 1), "c8x": (4, 0), "c8b": (2, 2)}
+_PACKED_OF = {"f16": "c8h", "bf16x3": "c8x", "bf16": "c8b"}
+
+
 class Blob(object):
     """A named tensor with Caffe's logical shape.  Device storage uses one of the engine layouts:
          'plain' row-major in Caffe order (optionally a column slice of a wider matrix: ld > shape[1])
          'c8'    [N][C/8][H][W][8]   for shape (N, C, H, W): N whole images back to back (N > 1 only in the CFM pyramid)
+         'c8x' / 'c8b'  the same order in split bf16 ([hi x8 | lo x8] per pixel and 8 channels, 4 bytes a value) / plain bf16: the
+                 "bf16x3" / "mixed" and "bf16" modes' trunk tensors (round 6), handled exactly like 'c8h'
          'c8h'   the same order in IEEE fp16 (the "f16" math mode's 2-byte activation tensors between trunk layers; the buffer
                  keeps its fp32 size, so the blob can be widened to 'c8' in place when a consumer or `.data` wants fp32)
          'rhwc'  [R][PH][PW][C]      for shape (R, C, PH, PW)
@@ -237,10 +245,10 @@ class Blob(object):
         tmp = net._tmp.ensure(self.count * 4)
         h = net._ctx.h
         src = self.dev_ptr()
-        if self.layout == "c8h" or layout == "c8h":
-            # fp16 <-> fp32 in the c8 order is elementwise (batch and all); any other pairing goes through 'c8'
-            if self.layout == "c8h":
-                _lib.call("mnc_act_unpack", h, src, tmp, self.count, 1)
+        if self.layout in _PACKED or layout in _PACKED:
+            # packed <-> fp32 in the c8 order is elementwise (batch and all); any other pairing goes through 'c8'
+            if self.layout in _PACKED:
+                _lib.call("mnc_act_unpack", h, src, tmp, self.count, _PACKED[self.layout][1])
                 _lib.call("mnc_d2d", h, src, tmp, self.count * 4)
                 self.layout = "c8"
                 if layout != "c8":
@@ -248,9 +256,10 @@ class Blob(object):
                 return
             if self.layout != "c8":
                 self._convert("c8")
-            _lib.call("mnc_act_pack", h, src, tmp, self.count, 1)
-            _lib.call("mnc_d2d", h, src, tmp, self.count * 2)
-            self.layout = "c8h"
+            eb, fmt = _PACKED[layout]
+            _lib.call("mnc_act_pack", h, src, tmp, self.count, fmt)
+            _lib.call("mnc_d2d", h, src, tmp, self.count * eb)
+            self.layout = layout
             return
         if self.layout == "plain" and layout == "c8":
             N, C, H, W = self.shape
@@ -283,8 +292,8 @@ class Blob(object):
             _lib.call("mnc_copy2d", h, tmp, cols, self.dev_ptr(), self._ld(), rows, cols)
             _lib.call("mnc_d2h", h, _lib.ptr(self._host), tmp, n * 4)
             return
-        if self.layout == "c8h":
-            self._convert("c8")          # widened in place: the values are unchanged, a later fp16 consumer re-packs them exactly
+        if self.layout in _PACKED:
+            self._convert("c8")          # widened in place: the values are unchanged, a later packed consumer re-packs them exactly
         if self.layout == "plain":
             _lib.call("mnc_d2h", h, _lib.ptr(self._host), self.dev_ptr(), n * 4)
             return
@@ -560,8 +569,11 @@ class Net(object):
                 nxt = self._sole_consumer(L.tops[0], "Sigmoid")
                 if nxt is not None:
                     L.act, L.out_name, nxt.skip = 2, nxt.tops[0], True
-            if (L.type == "Convolution" and self.conv_math == "fp32" and self._winograd and L.bn is None and L.scale is None
-                    and self._conv_kind(L) == "fast3x3"):
+            # (round 6: in the reduced-precision modes too -- mnc_conv3x3_lowp_pool, packed tensors in and out, the convolution's own
+            # bits through the pool's; what csrc/pipeline.hip's packed trunk launches)
+            if (L.type == "Convolution" and ((self.conv_math == "fp32" and self._winograd) or
+                                             (self.conv_math in _PACKED_OF and os.environ.get("MNC_F16_ACTS", "1") != "0"))
+                    and L.bn is None and L.scale is None and L.residual is None and self._conv_kind(L) == "fast3x3"):
                 # conv3x3 + ReLU + Pooling MAX 2x2/2 (conv1_2 / conv2_2 / conv3_3 / conv4_3 of the trunk): a 2x2 Winograd
                 # output tile is a pooling window, the pool is applied in the convolution's epilogue (mnc_conv3x3_wino_pool)
                 nxt = self._sole_consumer(L.tops[0], "Pooling")
@@ -665,8 +677,11 @@ class Net(object):
         when every reader of its top can take it: the tuned 3x3 kernels, the 1x1 GEMM, MAX pooling, and the residual input of
         a 1x1 GEMM.  Anything else (ROIWarping, the RPN's NCHW heads, Python layers, `.data`) gets fp32 -- written as fp32 by
         the producer, or widened in place by Blob._convert.  MNC_F16_ACTS=0 keeps every tensor fp32."""
-        if self.conv_math != "f16" or os.environ.get("MNC_F16_ACTS", "1") == "0":
+        # (round 6: the "bf16x3" / "mixed" and "bf16" modes too -- 'c8x' / 'c8b' between the tuned 3x3 kernels and the MAX 2x2/2
+        # poolings, what csrc/pipeline.hip's packed trunk does; the 1x1 GEMM, the general pooling and the stem exist in fp16 only)
+        if self.conv_math not in _PACKED_OF or os.environ.get("MNC_F16_ACTS", "1") == "0":
             return
+        f16 = self.conv_math == "f16"
         fused_res = {}                      # index of a folded Eltwise -> the convolution that took it over
         for L in self._layers:
             if L.type == "Convolution" and L.residual is not None:
@@ -677,18 +692,20 @@ class Net(object):
         def reads_h(i, blob):
             C = self._layers[i]
             if C.type == "Convolution" and not C.skip and C.bottoms[0] == blob:
-                return self._conv_kind(C) == "fast3x3" or self._conv_fast1x1(C)
+                return self._conv_kind(C) == "fast3x3" or (f16 and self._conv_fast1x1(C))
             if C.type == "Pooling" and not C.skip:
-                return (C.msg.get1("pooling_param").get1("pool", "MAX") == "MAX")
+                if C.msg.get1("pooling_param").get1("pool", "MAX") != "MAX":
+                    return False
+                return f16 or self._is_pool2(C)
             if i in fused_res:              # read as the residual (the convolution's own output never exists as a blob)
-                return blob == fused_res[i].residual and self._conv_fast1x1(fused_res[i])
+                return f16 and blob == fused_res[i].residual and self._conv_fast1x1(fused_res[i])
             return False
 
         for L in self._layers:
             if L.skip or L.type != "Convolution":
                 continue
             kind = self._conv_kind(L)
-            if not (kind in ("c3", "stem", "fast3x3") or self._conv_fast1x1(L)):
+            if not (kind in (("c3", "stem", "fast3x3") if f16 else ("c3", "fast3x3")) or (f16 and self._conv_fast1x1(L))):
                 continue
             top = L.out_name or L.tops[0]
             cons = self._consumers.get(top, [])
@@ -808,12 +825,13 @@ class Net(object):
                 N, _, H, Wd = bot.shape
                 src = bot.dev_in("plain")
                 top.reshape(N, cout, H, Wd)
-                dst = top.dev_out("c8h" if L.out_h else "c8")
-                ob = 2 if L.out_h else 4
+                pk = _PACKED_OF.get(self.conv_math, "c8h")
+                dst = top.dev_out(pk if L.out_h else "c8")
+                ob = _PACKED[pk][0] if L.out_h else 4
                 for n in range(N):                       # one launch sequence per image of the batch
-                    if L.out_h:
+                    if L.out_h:                          # (out_fmt of mnc_conv3x3_c3_fmt: 1 split bf16, 2 fp16, 3 bf16)
                         _lib.call("mnc_conv3x3_c3_fmt", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b,
-                                  dst + n * cout * H * Wd * ob, H, Wd, cout, relu, 2)
+                                  dst + n * cout * H * Wd * ob, H, Wd, cout, relu, _PACKED[pk][1] + 1)
                     else:
                         _lib.call("mnc_conv3x3_c3", self._h(), src + n * 3 * H * Wd * 4, d_w, d_b, dst + n * cout * H * Wd * 4,
                                   H, Wd, cout, relu)
@@ -870,8 +888,20 @@ class Net(object):
 
             def run():
                 N, _, H, Wd = bot.shape
-                in_h = self.conv_math == "f16" and bot._dev_valid and bot.layout == "c8h"
-                src = bot.dev_in("c8h" if in_h else "c8")
+                pk = _PACKED_OF.get(self.conv_math)
+                in_h = pk is not None and bot._dev_valid and bot.layout == pk
+                src = bot.dev_in(pk if in_h else "c8")
+                if L.fused_pool and pk is not None:        # reduced precision: packed in, pooled packed out (a fp32 consumer widens it)
+                    if not in_h:
+                        src = bot.dev_in(pk)
+                    OH, OW = _pool_out(H), _pool_out(Wd)
+                    top.reshape(N, cout, OH, OW)
+                    dst = top.dev_out(pk)
+                    eb, mode = _PACKED[pk]
+                    for n in range(N):
+                        _lib.call("mnc_conv3x3_lowp_pool", self._h(), mode, src + n * cin * H * Wd * eb, d_w, d_b,
+                                  dst + n * cout * OH * OW * eb, H, Wd, cin, cout, relu)
+                    return
                 if L.fused_pool:                           # top is the Pooling layer's blob
                     OH, OW = _pool_out(H), _pool_out(Wd)
                     top.reshape(N, cout, OH, OW)
@@ -881,11 +911,12 @@ class Net(object):
                                   dst + n * cout * OH * OW * 4, H, Wd, cin, cout, relu)
                     return
                 top.reshape(N, cout, H, Wd)
-                if in_h or L.out_h:                        # "f16" mode with 2-byte activation tensors on either side
-                    dst = top.dev_out("c8h" if L.out_h else "c8")
-                    ib, ob = (2 if in_h else 4), (2 if L.out_h else 4)
+                if in_h or L.out_h:                        # packed activation tensors on either side (the mode's own form)
+                    dst = top.dev_out(pk if L.out_h else "c8")
+                    eb = _PACKED[pk][0]
+                    ib, ob = (eb if in_h else 4), (eb if L.out_h else 4)
                     for n in range(N):
-                        _lib.call("mnc_conv3x3_f16_pk", self._h(), src + n * cin * H * Wd * ib, d_w, d_b,
+                        _lib.call(conv + "_pk", self._h(), src + n * cin * H * Wd * ib, d_w, d_b,
                                   dst + n * cout * H * Wd * ob, H, Wd, cin, cout, relu, 1 if in_h else 0, 1 if L.out_h else 0)
                     return
                 dst = top.dev_out("c8")
@@ -1029,17 +1060,17 @@ class Net(object):
             return run_general
 
         def run():
-            if bot._dev_valid and bot.layout in ("c8", "c8h"):
+            if bot._dev_valid and (bot.layout == "c8" or bot.layout in _PACKED):
                 N, C, H, W = bot.shape
-                half = bot.layout == "c8h"
-                lay, eb = ("c8h", 2) if half else ("c8", 4)
+                lay = bot.layout                           # packed in -> packed out (max commutes with the rounding / the split)
+                eb = _PACKED[lay][0] if lay in _PACKED else 4
+                fn = {"c8": "mnc_maxpool2_c8", "c8h": "mnc_maxpool2_c8_f16", "c8x": "mnc_maxpool2_c8_bf16x3", "c8b": "mnc_maxpool2_c8_bf16"}[lay]
                 src = bot.dev_in(lay)
                 OH, OW = _pool_out(H), _pool_out(W)
                 top.reshape(N, C, OH, OW)
                 dst = top.dev_out(lay)
                 for n in range(N):
-                    _lib.call("mnc_maxpool2_c8_f16" if half else "mnc_maxpool2_c8", self._h(), src + n * C * H * W * eb,
-                              dst + n * C * OH * OW * eb, C, H, W)
+                    _lib.call(fn, self._h(), src + n * C * H * W * eb, dst + n * C * OH * OW * eb, C, H, W)
             else:
                 R, C, PH, PW = bot.shape
                 if PH % 2 or PW % 2:            # Caffe's ceil rule would give (PH + 1) // 2 (a 7x7 input -> 4x4): no kernel for it
@@ -1087,7 +1118,7 @@ class Net(object):
         def run():
             if tuple(a.shape) != tuple(b.shape):
                 raise ValueError("Eltwise %s: shapes %r and %r differ" % (L.name, a.shape, b.shape))
-            layout = "c8" if len(a.shape) == 4 and a.shape[1] % 8 == 0 and (a._dev_valid and a.layout in ("c8", "c8h")) else "plain"
+            layout = "c8" if len(a.shape) == 4 and a.shape[1] % 8 == 0 and (a._dev_valid and (a.layout == "c8" or a.layout in _PACKED)) else "plain"
             pa, pb = a.dev_in(layout), b.dev_in(layout)
             top.reshape(*a.shape)
             _lib.call("mnc_add", self._h(), pa, pb, top.dev_out(layout), a.count, relu)

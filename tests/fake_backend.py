@@ -54,16 +54,31 @@ def _h16(ptr, shape):
     return np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(ptr))).view(np.float16).reshape(shape)
 
 
+def _bf16_bits(a):
+    """float32 -> bf16 bit patterns (nearest even), uint16."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
 def _rd_c8(ptr, C, H, W, packed):
-    """[C,H,W] float32 from a c8 tensor that is fp32 or (packed) fp16."""
-    x = _h16(ptr, (C // 8, H, W, 8)).astype(np.float32) if packed else _f(ptr, (C // 8, H, W, 8))
+    """[C,H,W] float32 from a c8 tensor that is fp32 (packed 0 / False), packed fp16 (1 / True), or the test double's stand-ins for
+    the split-bf16 form ('x3': the fp32 values as they are, 4 bytes a value) and plain bf16 ('bf16': bf16 bit patterns)."""
+    shp = (C // 8, H, W, 8)
+    if packed == "bf16":
+        n = int(np.prod(shp))
+        u = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(ptr))).astype(np.uint32) << 16
+        return _unc8(u.view(np.float32).reshape(shp))
+    x = _h16(ptr, shp).astype(np.float32) if (packed and packed != "x3") else _f(ptr, shp)
     return _unc8(x)
 
 
 def _wr_c8(ptr, y, packed):
-    """[C,H,W] float32 -> c8 tensor, rounded to fp16 (nearest even) when packed."""
+    """[C,H,W] float32 -> c8 tensor, rounded to fp16 (nearest even) when packed (see _rd_c8 for 'x3' / 'bf16')."""
     C, H, W = y.shape
-    if packed:
+    if packed == "bf16":
+        n = C * H * W
+        np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(ptr)))[...] = _bf16_bits(_c8(y)).reshape(-1)
+    elif packed and packed != "x3":
         _h16(ptr, (C // 8, H, W, 8))[...] = _c8(y).astype(np.float16)
     else:
         _f(ptr, (C // 8, H, W, 8))[...] = _c8(y)
@@ -280,17 +295,62 @@ class Fake(object):
 
     # ---- 2-byte activation tensors of the "f16" mode and the 1x1 GEMM (csrc/conv1x1.hip) ----
     def mnc_act_pack(self, h, src, dst, n, f16):
-        assert f16 == 1, "test double: fp16 form only"
-        _h16(dst, (n,))[...] = _f(src, (n,)).astype(np.float16)
+        if f16 == 1:
+            _h16(dst, (n,))[...] = _f(src, (n,)).astype(np.float16)
+        elif f16 == 2:
+            np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(dst)))[...] = _bf16_bits(_f(src, (n,)))
+        else:                                               # split bf16 stand-in: the fp32 values
+            _f(dst, (n,))[...] = _f(src, (n,)).copy()
 
     def mnc_act_unpack(self, h, src, dst, n, f16):
-        assert f16 == 1, "test double: fp16 form only"
-        _f(dst, (n,))[...] = _h16(src, (n,)).astype(np.float32)
+        if f16 == 1:
+            _f(dst, (n,))[...] = _h16(src, (n,)).astype(np.float32)
+        elif f16 == 2:
+            u = np.ctypeslib.as_array((ctypes.c_uint16 * n).from_address(int(src))).astype(np.uint32) << 16
+            _f(dst, (n,))[...] = u.view(np.float32)
+        else:
+            _f(dst, (n,))[...] = _f(src, (n,)).copy()
 
     def mnc_conv3x3_c3_fmt(self, h, src, w, b, dst, H, W, Cout, relu, out_fmt):
-        assert out_fmt in (0, 2), "test double: fp32 or fp16 output"
         y = F.conv2d(_t(_f(src, (1, 3, H, W))), _t(_f(w, (Cout, 3, 3, 3))), _t(_f(b, (Cout,))), padding=1)
-        _wr_c8(dst, _act(y, relu)[0].numpy(), out_fmt == 2)
+        _wr_c8(dst, _act(y, relu)[0].numpy(), {0: False, 1: "x3", 2: True, 3: "bf16"}[out_fmt])
+
+    def _conv_pk(self, kind, round_, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed):
+        x = _t(round_(_rd_c8(src, Cin, H, W, kind if in_packed else False)))[None]
+        if kind == "x3":                                    # mnc_pack_conv3x3_bf16x3's stand-in layout (above)
+            pk = np.ctypeslib.as_array(ctypes.cast(wpk, ctypes.POINTER(ctypes.c_uint16)), (Cin // 8, Cout, 168))
+            fw = (pk[:, :, :144].astype(np.uint32) << 16).view(np.float32).reshape(Cin // 8, Cout, 9, 2, 8)
+            w = np.ascontiguousarray((fw[:, :, :, 0, :] + fw[:, :, :, 1, :]).transpose(1, 0, 3, 2)).reshape(Cout, Cin, 3, 3)
+        else:
+            w = _f(wpk, (Cout, Cin, 3, 3))
+        y = F.conv2d(x, _t(w), _t(_f(b, (Cout,))), padding=1)[0]
+        if relu:
+            y = F.relu(y)
+        _wr_c8(dst, y.numpy(), kind if out_packed else False)
+
+    def mnc_conv3x3_bf16x3_pk(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed):
+        self._conv_pk("x3", lambda a: a, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed)
+
+    def mnc_conv3x3_bf16_pk(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed):
+        rb = lambda a: (_bf16_bits(a).astype(np.uint32) << 16).view(np.float32).reshape(a.shape)
+        self._conv_pk("bf16", rb, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed)
+
+    def mnc_conv3x3_lowp_pool(self, h, mode, src, wpk, b, dst, H, W, Cin, Cout, relu):
+        kind = {0: "x3", 1: True, 2: "bf16"}[mode]
+        rnd = {0: (lambda a: a), 1: (lambda a: a.astype(np.float16).astype(np.float32)),
+               2: (lambda a: (_bf16_bits(a).astype(np.uint32) << 16).view(np.float32).reshape(a.shape))}[mode]
+        tmp = np.zeros((Cout // 8, H, W, 8), np.float32)
+        self._conv_pk(kind, rnd, src, wpk, b, tmp.ctypes.data, H, W, Cin, Cout, relu, True, False)
+        y = F.max_pool2d(_t(_unc8(tmp))[None], 2, 2, ceil_mode=True)[0].numpy()
+        _wr_c8(dst, y, kind)
+
+    def mnc_maxpool2_c8_bf16x3(self, h, src, dst, C, H, W):
+        y = F.max_pool2d(_t(_rd_c8(src, C, H, W, "x3"))[None], 2, 2, ceil_mode=True)[0].numpy()
+        _wr_c8(dst, y, "x3")
+
+    def mnc_maxpool2_c8_bf16(self, h, src, dst, C, H, W):
+        y = F.max_pool2d(_t(_rd_c8(src, C, H, W, "bf16"))[None], 2, 2, ceil_mode=True)[0].numpy()
+        _wr_c8(dst, y, "bf16")
 
     def mnc_conv3x3_f16_pk(self, h, src, wpk, b, dst, H, W, Cin, Cout, relu, in_packed, out_packed):
         x = _t(_rd_c8(src, Cin, H, W, in_packed).astype(np.float16).astype(np.float32))[None]

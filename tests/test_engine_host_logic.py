@@ -68,14 +68,21 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
         assert "mnc_fc_f16" not in calls and "mnc_fc_bf16x3" not in calls
         # the box-feature Pooling and MaskPooling + Pooling of a stage read the same tensor: one pass, both second outputs
         assert calls.get("mnc_box_mask_pool_ex") == 2 * runs and "mnc_mask_pool_sm" not in calls and "mnc_maxpool2_rhwc_sm" not in calls
+    if math == "bf16x3":
+        # round 6: the split-bf16 trunk keeps its packed form between the MFMA layers too ('c8x'), conv5_3 fp32 for the RoI layers
+        # (fused plan: the four pooled layers run as conv + ReLU + pool in one launch, mnc_conv3x3_lowp_pool)
+        assert calls.get("mnc_conv3x3_bf16x3_pk") == (8 if fuse else 12) and calls.get("mnc_conv3x3_c3_fmt") == 1
+        assert calls.get("mnc_maxpool2_c8_bf16x3", 0) == (0 if fuse else 4) and calls.get("mnc_conv3x3_lowp_pool", 0) == (4 if fuse else 0)
+        assert net.blobs["conv5_2"].layout == "c8x" and net.blobs["conv5_3"].layout == "c8"
     if math == "f16":
         # 2-byte trunk activations: conv1_1 .. conv5_2 write packed fp16, conv5_3 (read by the RoI layers) fp32
-        assert calls.get("mnc_conv3x3_f16_pk") == 12 and calls.get("mnc_conv3x3_c3_fmt") == 1 and calls.get("mnc_maxpool2_c8_f16") == 4
+        assert calls.get("mnc_conv3x3_f16_pk") == (8 if fuse else 12) and calls.get("mnc_conv3x3_c3_fmt") == 1
+        assert calls.get("mnc_maxpool2_c8_f16", 0) == (0 if fuse else 4) and calls.get("mnc_conv3x3_lowp_pool", 0) == (4 if fuse else 0)
         assert net.blobs["conv5_2"].layout == "c8h" and net.blobs["conv5_3"].layout == "c8"
     ref = onet.forward(w, data, im_info)
     names = BLOBS + ([] if fuse else ["roi_interpolate_conv5_premax", "roi_mask_conv5", "roi_mask_conv5_ext"])
-    if fuse and math == "fp32":
-        # the Winograd convolution applies the following MAX 2x2/2 pool in its epilogue: conv3_3 is not materialised
+    if fuse:
+        # the convolution applies the following MAX 2x2/2 pool in its epilogue (fp32 Winograd; round 6: the reduced-precision kernel too): conv3_3 is not materialised
         assert not (net.blobs["conv3_3"]._dev_valid or net.blobs["conv3_3"]._host_valid)
         names = [("pool3" if n == "conv3_3" else n) for n in names]
     # split weights are exact to 2^-16 only; 1e-3 is the end-to-end bar.  f16 rounds both FC operands to 11 bits: 1e-2 here
@@ -84,7 +91,7 @@ def test_reduced_graph_every_blob(fake_gpu, monkeypatch, fuse, math):
     if math == "f16":
         # fp16 rounding in the trunk can flip a borderline NMS / min-size decision, after which the RoI lists differ row by
         # row: only the blobs upstream of the ProposalLayer are compared here (the GPU tests teacher-force the rest)
-        names = ["conv1_1", "pool1", "conv3_3", "conv5_3", "rpn_cls_prob_reshape", "rpn_bbox_pred"]
+        names = ["conv1_1", "pool1", "pool3" if fuse else "conv3_3", "conv5_3", "rpn_cls_prob_reshape", "rpn_bbox_pred"]
         assert net.blobs["seg_cls_prob_ext"].data.shape[1] == 21 and net.blobs["rois"].data.shape[1] == 5
     for n in names:
         got, want = net.blobs[n].data, ref[n]
