@@ -484,6 +484,13 @@ MNC_API int mnc_fc_lowp_pair(mnc_ctx* ctx, int mode, const float* d_a0, const vo
  *   mnc_mask_pool_sm       = mnc_mask_pool       (+ d_sm of d_out)
  * C%64==0 (fmt 1) / C%32==0 (fmt 2) so that an 8-channel group never straddles a stage. */
 MNC_API int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, int f16);
+/* Round 6.  The inverse: fp32 rows [M][K] out of a stage-major tensor (fmt 1 = fp16: the rounded values; fmt 2 = split bf16: hi + lo)
+ * -- for a consumer, or the host, that needs the rows of a tensor whose producer wrote the stage-major form ONLY
+ * (mnc_roi_warp_sm / mnc_box_mask_pool_ex with null fp32 outputs; mnc_amd/engine.py materialises such blobs on demand). */
+MNC_API int mnc_fc_unpack_act(mnc_ctx* ctx, const void* d_a_sm, float* d_a, int M, int K, int fmt);
+/* *ok = 1 when mnc_roi_warp_sm on this context (its layer conventions, its kernel choice for C channels / pool2) accepts
+ * d_out_rhwc = NULL next to a stage-major output. */
+MNC_API int mnc_roi_warp_sm_only_ok(mnc_ctx* ctx, int C, int pool2, int* ok);
 MNC_API int mnc_fc_f16_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
                            float* d_out, int M, int N, int K, int ldc, int act);
 MNC_API int mnc_fc_bf16x3_pre(mnc_ctx* ctx, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,

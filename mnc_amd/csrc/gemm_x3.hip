@@ -629,6 +629,34 @@ __global__ __launch_bounds__(512) void fc_lowp_dma_kernel(const uint4* __restric
   }
 }
 
+// The inverse of the stage-major activation forms (round 6: a consumer or the host that needs fp32 rows of a tensor its producer wrote
+// in the stage-major form only): fmt 1: [K/64][M][64] fp16 -> the values; fmt 2: [K/32][M][4][hi x8 | lo x8] bf16 -> hi + lo.
+// One thread per 8 consecutive K values of a row.
+__global__ void unpack_act_sm_kernel(const uint4* __restrict__ sm, float* __restrict__ out, long M, long K, int fmt) {
+  const long total = M * (K >> 3);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (K >> 3), k = (i % (K >> 3)) << 3;
+    float v[8];
+    if (fmt == 1) {
+      const f16x8 h = x3_as_f16x8(sm[((k >> 6) * M + r) * 8 + ((k & 63) >> 3)]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    } else {
+      const uint4* p = sm + (((k >> 5) * M + r) * 4 + ((k & 31) >> 3)) * 2;
+      const uint4 a = p[0], b = p[1];
+      const unsigned wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(wa[e] << 16) + __uint_as_float(wb[e] << 16);
+        v[2 * e + 1] = __uint_as_float(wa[e] & 0xFFFF0000u) + __uint_as_float(wb[e] & 0xFFFF0000u);
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(out + r * K + k);
+    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
 static int f16_pack_launch(mnc_ctx* ctx, const float* d_in, uint4* d_out, int rows, int K, int tile_rows, int tiles, int bf16 = 0) {
   const long total = (long)tiles * (K / 64) * tile_rows * 8;
   long g = (total + 255) / 256;
@@ -1058,6 +1086,16 @@ int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, 
   if (f16) f16_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
   else x3_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
   return ls.finish(f16 ? "pack_f16_kernel" : "pack_x3_kernel");
+}
+
+int mnc_fc_unpack_act(mnc_ctx* ctx, const void* d_a_sm, float* d_a, int M, int K, int fmt) {
+  MNC_REQUIRE(ctx && d_a_sm && d_a && M > 0 && K > 0 && (fmt == 1 || fmt == 2) && K % (fmt == 1 ? 64 : kXBK) == 0,
+              "mnc_fc_unpack_act: bad argument (fmt 1: K %% 64 == 0, fmt 2: K %% 32 == 0)");
+  LaunchScope ls(ctx, "fc_act_unpack", 0.0, (fmt == 1 ? 6.0 : 8.0) * M * (double)K);
+  long g = ((long)M * (K / 8) + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(unpack_act_sm_kernel, dim3((int)g), dim3(256), 0, ctx->stream, (const uint4*)d_a_sm, d_a, (long)M, (long)K, fmt);
+  return ls.finish("unpack_act_sm_kernel");
 }
 
 // Two InnerProducts of one shape in reduced precision (mode 1 = fp16, 2 = plain bf16; each input as fp32 rows OR stage-major, each

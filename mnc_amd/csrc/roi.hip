@@ -857,6 +857,13 @@ int roi_warp_from_hwc(mnc_ctx* ctx, const float* d_hwc, int C, int H, int W, con
 
 extern "C" {
 
+int mnc_roi_warp_sm_only_ok(mnc_ctx* ctx, int C, int pool2, int* ok) {
+  MNC_REQUIRE(ctx && ok, "mnc_roi_warp_sm_only_ok: null pointer");
+  *ok = mnc::roi_warp_sm_only_ok(ctx, C, pool2) ? 1 : 0;
+  mnc::clear_error();
+  return MNC_OK;
+}
+
 int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
                     float scale, int pool2, float* d_out, void* d_sm, int sm_fmt) {
   MNC_REQUIRE(d_feat, "mnc_roi_warp: null pointer");

@@ -135,6 +135,9 @@ class Blob(object):
         # by the tensor's producer (mnc_*_sm): {"fmt": 1 f16 | 2 bf16x3, "M": rows, "K": row length, "ptr": device address}
         self._sm = None
         self._smbuf = None
+        # round 6: the producer wrote the stage-major form ONLY (mnc_roi_warp_sm / mnc_box_mask_pool_ex with null fp32 outputs); the
+        # fp32 rows are materialised from it (mnc_fc_unpack_act) the first time a consumer or `.data` asks for them
+        self._sm_only = False
 
     # ---- pycaffe surface ----
     @property
@@ -156,6 +159,13 @@ class Blob(object):
             self._host = None
             self._host_valid = False
             self._dev_valid = False
+            self._sm_only = False
+
+    def _materialize(self):
+        """fp32 rows of a stage-major-only tensor (see __init__), in the layout its producer would have written."""
+        sm = self._sm
+        _lib.call("mnc_fc_unpack_act", self._net._ctx.h, sm["ptr"], self._buf.ensure(self.count * 4), sm["M"], sm["K"], sm["fmt"])
+        self._dev_valid, self._sm_only = True, False
 
     @property
     def data(self):
@@ -163,10 +173,13 @@ class Blob(object):
         arr = self._host_read()
         self._dev_valid = False
         self._sm = None
+        self._sm_only = False
         return arr
 
     # ---- engine side ----
     def _host_read(self):
+        if not self._dev_valid and not self._host_valid and self._sm_only and self._sm is not None:
+            self._materialize()
         if self._host is None or self._host.shape != self.shape:
             self._host = np.zeros(self.shape, dtype=F32)
             if not self._dev_valid:
@@ -185,6 +198,7 @@ class Blob(object):
         self._host_valid = True
         self._dev_valid = False
         self._sm = None
+        self._sm_only = False
 
     def set_device(self, darr):
         """Adopt the contents of a DeviceArray of this net (plain layout): one device-to-device copy, no host round trip."""
@@ -197,6 +211,7 @@ class Blob(object):
         self.layout = "plain"
         self._dev_valid = True
         self._sm = None
+        self._sm_only = False
 
     def _ld(self):
         if self._view is not None:
@@ -215,7 +230,17 @@ class Blob(object):
         self._dev_valid = True
         self._host_valid = False
         self._sm = None
+        self._sm_only = False
         return self.dev_ptr()
+
+    def dev_out_sm_only(self, layout):
+        """The producer is about to write this blob in its stage-major form only (sm_out follows): no fp32 pointer."""
+        self.layout = layout
+        self._dev_valid = False
+        self._host_valid = False
+        self._sm = None
+        self._sm_only = True
+        return None
 
     def sm_out(self, fmt, M, K):
         """Device address for the producer's second output (stage-major 2-byte form, see __init__); call after dev_out."""
@@ -228,6 +253,8 @@ class Blob(object):
     def dev_in(self, layout):
         """Pointer to current contents in `layout`, uploading / converting as needed."""
         net = self._net
+        if not self._dev_valid and self._sm_only and self._sm is not None:
+            self._materialize()
         if not self._dev_valid:
             if not self._host_valid:
                 raise RuntimeError("blob %r is read before it was produced" % self.name)
@@ -1076,31 +1103,39 @@ class Net(object):
                 if PH % 2 or PW % 2:            # Caffe's ceil rule would give (PH + 1) // 2 (a 7x7 input -> 4x4): no kernel for it
                     raise NotImplementedError("Pooling %s on per-RoI features: odd size %dx%d (MAX 2x2/2 needs even sizes)"
                                               % (L.name, PH, PW))
-                src = bot.dev_in("rhwc")
                 top.reshape(R, C, PH // 2, PW // 2)
-                dst = top.dev_out("rhwc")
                 K = C * (PH // 2) * (PW // 2)
                 fmt = self._sm_format(top.name, R, K, C) if R else 0
                 if L.with_mask is not None:             # + MaskPooling and its Pooling of the same tensor, same pass
                     mtop = self.blobs[L.with_mask.out_name]
                     d_mask = self.blobs[L.with_mask.bottoms[1]].dev_in("plain")
                     mtop.reshape(R, C, PH // 2, PW // 2)
-                    mdst = mtop.dev_out("rhwc")
                     mfmt = self._sm_format(mtop.name, R, K, C) if R else 0
                     if R and fmt == mfmt and C % 8 == 0:
-                        # round 6: the tensor is read from its stage-major fp16 copy when its producer wrote one (what
-                        # csrc/pipeline.hip's run_stage does: mnc_hip.h, mnc_box_mask_pool_ex -- same bits in both executors)
+                        # round 6: the tensor is read from its stage-major copy when its producer wrote one (what
+                        # csrc/pipeline.hip's run_stage does: mnc_hip.h, mnc_box_mask_pool_ex -- same bits in both executors), and
+                        # the pooled tensors are written in the stage-major form only when nothing else reads them
                         sm_in = bot._sm if (fmt and bot._sm and bot._sm["fmt"] in (1, 2) and bot._sm["M"] == R
-                                            and bot._sm["K"] == C * PH * PW) else None
+                                            and bot._sm["K"] == C * PH * PW and (bot._dev_valid or bot._sm_only)) else None
+                        src = None if (sm_in and not bot._dev_valid) else bot.dev_in("rhwc")
+                        sm_only = bool(fmt) and self._sm_only_ok(top.name) and self._sm_only_ok(mtop.name)
+                        dst = top.dev_out_sm_only("rhwc") if sm_only else top.dev_out("rhwc")
+                        mdst = mtop.dev_out_sm_only("rhwc") if sm_only else mtop.dev_out("rhwc")
                         _lib.call("mnc_box_mask_pool_ex", self._h(), src, sm_in["ptr"] if sm_in else None, sm_in["fmt"] if sm_in else 0, d_mask,
                                   dst, mdst, R, PH, PW, C, top.sm_out(fmt, R, K) if fmt else None,
                                   mtop.sm_out(fmt, R, K) if fmt else None, fmt)
                         return
+                    src = bot.dev_in("rhwc")
+                    dst = top.dev_out("rhwc")
+                    mdst = mtop.dev_out("rhwc")
                     if R:
                         if mfmt:
                             _lib.call("mnc_mask_pool_sm", self._h(), src, d_mask, mdst, R, PH, PW, C, 1, mtop.sm_out(mfmt, R, K), mfmt)
                         else:
                             _lib.call("mnc_mask_pool", self._h(), src, d_mask, mdst, R, PH, PW, C, 1)
+                else:
+                    src = bot.dev_in("rhwc")
+                    dst = top.dev_out("rhwc")
                 if fmt:
                     _lib.call("mnc_maxpool2_rhwc_sm", self._h(), src, dst, R, PH, PW, C, top.sm_out(fmt, R, K), fmt)
                 elif R:
@@ -1190,6 +1225,26 @@ class Net(object):
                 fmt = 2
         return fmt
 
+    def _sm_only_ok(self, blob):
+        """May a per-RoI tensor exist in its stage-major form only?  Every reader must take that form: the reduced-precision
+        InnerProducts (they multiply from it) and the one-pass box / mask pooling (mnc_box_mask_pool_ex reads it).  Anything
+        else -- or `.data` -- still works (Blob._materialize), it just pays a conversion pass, so the answer is 'no' then."""
+        if blob in self.outputs or os.environ.get("MNC_SM_ONLY", "1") == "0":
+            return False
+        cons = self._consumers.get(blob, [])
+        if not cons:
+            return False
+        for i in cons:
+            L = self._layers[i]
+            if L.type == "InnerProduct" and not L.skip and L.group is None and L.group_leader is None:
+                continue
+            if L.type == "Pooling" and not L.skip and L.with_mask is not None:
+                continue
+            if L.type == "MaskPooling" and L.skip:          # folded into the Pooling above
+                continue
+            return False
+        return True
+
     def _bind_ROIWarping(self, L, i):
         rp = L.msg.get1("roi_warping_param")
         ph, pw, scale = rp.get1("pooled_h"), rp.get1("pooled_w"), float(rp.get1("spatial_scale"))
@@ -1205,8 +1260,13 @@ class Net(object):
             R = rois.shape[0]
             d_feat, d_rois = feat.dev_in("c8"), rois.dev_in("plain")
             top.reshape(R, C, oh, ow)
-            dst = top.dev_out("rhwc")
             fmt = self._sm_format(top.name, R, C * oh * ow, C)
+            sm_only = False
+            if fmt and R and (C * oh * ow) % 64 == 0 and self._sm_only_ok(top.name):
+                ok = ctypes.c_int(0)
+                _lib.call("mnc_roi_warp_sm_only_ok", self._h(), C, pool2, ctypes.addressof(ok))
+                sm_only = bool(ok.value)
+            dst = top.dev_out_sm_only("rhwc") if sm_only else top.dev_out("rhwc")
             if fmt:
                 _lib.call("mnc_roi_warp_sm", self._h(), d_feat, C, H, W, d_rois, R, oh, ow, scale, pool2, dst,
                           top.sm_out(fmt, R, C * oh * ow), fmt)
@@ -1320,8 +1380,8 @@ class Net(object):
             wrote them (Blob._sm: no conversion pass), and leave in the NEXT InnerProduct's form as well when one will read them."""
             want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2}.get(state.get("fn"), 0)
             sm = bot._sm
-            pre = bool(want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K and bot._dev_valid
-                       and bot.layout == state["layout"])
+            pre = bool(want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K
+                       and (bot._dev_valid or bot._sm_only) and bot.layout == state["layout"])
             src = None if pre else bot.dev_in(state["layout"])
             top.reshape(M, n_out)
             dst = top.dev_out("plain")
@@ -1374,7 +1434,7 @@ class Net(object):
             (a dict of its mnc_fc_lowp_pair arguments for the reduced-precision entry points), or None when it cannot share the
             leader's launch (other row count, other kernel, other leading dimension / activation)."""
             M = bot.shape[0]
-            if M != M_leader or K != K_leader or int(np.prod(bot.shape[1:])) != K or not (bot._dev_valid or bot._host_valid):
+            if M != M_leader or K != K_leader or int(np.prod(bot.shape[1:])) != K or not (bot._dev_valid or bot._host_valid or bot._sm_only):
                 return None
             if "w" not in state:
                 state["w"], state["layout"], state["fn"] = weights_for(bot.shape, M)
@@ -1800,7 +1860,7 @@ class Net(object):
                 else:
                     # what the pycaffe surface knows about every blob after this sequence: a replay runs no Python, so it restores
                     # this state (and drops host copies, which belong to an earlier image)
-                    snap = [(b, b.shape, b.layout, b._dev_valid, b._sm) for b in list(self.blobs.values()) + getattr(self, "_hidden", [])]
+                    snap = [(b, b.shape, b.layout, b._dev_valid, b._sm, b._sm_only) for b in list(self.blobs.values()) + getattr(self, "_hidden", [])]
                     g = {"graph": gp.value, "allocs": self._ctx.allocs, "blk": blk, "nbytes": nbytes, "snap": snap,
                          "speculated": self._speculated is not None, "post": self._speculated[2] if self._speculated else 0}
                     st["graphs"][key] = g
@@ -1812,10 +1872,10 @@ class Net(object):
         if g is not None:
             blk, nbytes, speculated, post = g["blk"], g["nbytes"], g["speculated"], g["post"]
             if mode == "replay":
-                for b, shape, layout, dev_valid, sm in g["snap"]:
-                    if b._host_valid and not dev_valid:
+                for b, shape, layout, dev_valid, sm, sm_only in g["snap"]:
+                    if b._host_valid and not dev_valid and not sm_only:
                         continue                                        # an input set from the host (im_info): same values
-                    b.shape, b.layout, b._dev_valid, b._sm = shape, layout, dev_valid, sm
+                    b.shape, b.layout, b._dev_valid, b._sm, b._sm_only = shape, layout, dev_valid, sm, sm_only
                     b._host, b._host_valid = None, False
                 blk._blk.invalidate()                                   # the buffer now holds this image
                 blk = blk._blk.view()

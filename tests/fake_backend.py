@@ -502,6 +502,10 @@ class Fake(object):
             _f(dst, (M, K))[...] = rows
 
     def mnc_roi_warp_sm(self, h, feat, C, H, W, rois, R, PH, PW, scale, pool2, dst, sm, fmt):
+        if not dst:                                          # stage-major output only (round 6)
+            assert sm and fmt
+            self._tmp_warp = np.zeros((R * PH * PW * C,), np.float32)
+            dst = self._tmp_warp.ctypes.data
         self.mnc_roi_warp(h, feat, C, H, W, rois, R, PH, PW, scale, pool2, dst)
         if sm and fmt:
             self._sm_write(sm, _f(dst, (R, PH * PW * C)), fmt)
@@ -518,8 +522,19 @@ class Fake(object):
             self._sm_write(sm, _f(dst, (R, oh * ow * C)), fmt)
 
     def mnc_box_mask_pool(self, h, feat, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt):
+        if not box:                                          # stage-major outputs only (round 6)
+            assert not mout and box_sm and mask_sm and fmt
+            n = R * (PH // 2) * (PW // 2) * C
+            self._tmp_pool = (np.zeros((n,), np.float32), np.zeros((n,), np.float32))
+            box, mout = self._tmp_pool[0].ctypes.data, self._tmp_pool[1].ctypes.data
         self.mnc_maxpool2_rhwc_sm(h, feat, box, R, PH, PW, C, box_sm, fmt)
         self.mnc_mask_pool_sm(h, feat, mask, mout, R, PH, PW, C, 1, mask_sm, fmt)
+
+    def mnc_roi_warp_sm_only_ok(self, h, C, pool2, ok):
+        ctypes.c_int.from_address(int(ok)).value = 1
+
+    def mnc_fc_unpack_act(self, h, sm, dst, M, K, fmt):
+        _f(dst, (M, K))[...] = _h16(sm, (M, K)).astype(np.float32) if fmt == 1 else _f(sm, (M, K))
 
     def mnc_box_mask_pool_ex(self, h, feat, feat_sm, feat_fmt, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt):
         if feat_sm and feat_fmt in (1, 2) and box_sm and mask_sm and fmt:

@@ -257,6 +257,42 @@ def test_full_vgg16_600x1000_f16_math(full, monkeypatch):
         net.close()
 
 
+@pytest.mark.parametrize("math", ["f16", "mixed"])
+def test_stage_major_only_blobs_materialise_on_demand(full, math, monkeypatch):
+    """Round 6: in the reduced-precision InnerProduct modes the per-RoI tensors whose readers all take the stage-major form are
+    written in that form only (Blob._sm_only; mnc_roi_warp_sm / mnc_box_mask_pool_ex with null fp32 outputs) -- and `.data` still
+    works: the rows are materialised from the stage-major copy (mnc_fc_unpack_act), i.e. the values the consumers multiplied.
+    Held against the same net with MNC_SM_ONLY=0 (fp32 blobs written): the warp's blob equals the fp32 blob ROUNDED to the form
+    (fp16 / split bf16), the outputs downstream agree bit for bit."""
+    from mnc_amd.engine import Net
+    _, w = full
+    im = np.random.default_rng(5).integers(0, 256, (600, 1000, 3), dtype=np.uint8)
+    data, im_info, scale = ohost.prepare_mnc_args(im)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MNC_SM_ONLY", flag)
+        net = Net(models.write_mnc_5stage_test_prototxt(), w, 1, math=math)
+        try:
+            net.forward(data=data, im_info=im_info)
+            warp = net.blobs["roi_interpolate_conv5"]
+            assert warp._sm_only == (flag == "1") and (warp._dev_valid == (flag == "0"))
+            for n in ("roi_interpolate_conv5_box", "roi_interpolate_conv5_mask"):
+                assert net.blobs[n]._sm_only == (flag == "1"), n
+            got[flag] = {n: net.blobs[n].data.copy() for n in ("roi_interpolate_conv5", "roi_interpolate_conv5_box", "fc6", "fc7_mask",
+                                                                  "seg_cls_prob_ext", "bbox_pred_ext", "mask_proposal_ext")}
+        finally:
+            net.close()
+    a, b = got["1"], got["0"]
+    for n in ("fc6", "fc7_mask", "seg_cls_prob_ext", "bbox_pred_ext", "mask_proposal_ext"):
+        assert np.array_equal(a[n], b[n]), n
+    if math == "f16":
+        assert np.array_equal(a["roi_interpolate_conv5"], b["roi_interpolate_conv5"].astype(np.float16).astype(np.float32))
+        assert np.array_equal(a["roi_interpolate_conv5_box"], b["roi_interpolate_conv5_box"].astype(np.float16).astype(np.float32))
+    else:                                      # split bf16 (fc6_maskest's form in `mixed`): hi + lo keeps 16 significant bits
+        d = np.abs(a["roi_interpolate_conv5"] - b["roi_interpolate_conv5"])
+        assert d.max() <= 2.0 ** -15 * np.abs(b["roi_interpolate_conv5"]).max()
+
+
 def test_demo_pipeline_matches_oracle(full):
     """tools/demo.py path: im_detect (prepare args, forward, un-scale, clip, concat) + gpu_mask_voting, on a VOC-sized
     image that exercises the resize (375x500 -> 600x800, scale 1.6)."""
