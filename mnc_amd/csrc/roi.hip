@@ -846,7 +846,7 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
 // 1024 channels); not on the 8-channels-per-thread variant and the generic-convention kernel.
 bool roi_warp_sm_only_ok(const mnc_ctx* ctx, int C, int pool2) {
   if (ctx->conv.warp_sample || ctx->conv.warp_round_edges || ctx->conv.warp_no_plus_one || ctx->conv.warp_oob) return false;
-  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, pool2 ? 3 : C >= 1024 ? 1 : 4);
+  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, (pool2 || C >= 1024) ? 3 : 4);
   return vsel == 3 || vsel == 4 || vsel == 1;
 }
 int roi_warp_from_hwc(mnc_ctx* ctx, const float* d_hwc, int C, int H, int W, const float* d_rois, int R, int PH, int PW, float scale,
@@ -903,6 +903,8 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
   // second output, 1000 RoIs x 1024 channels: 28x28+pool 452 us against 629 / 680 for the 4- / 8-channels-per-thread kernels,
   // 14x14 407 against 520 / 430; fp32 only, 300 RoIs x 512 channels: 28x28+pool 61 against 68, 14x14 44 against 32 (so the
   // 4-channels-per-thread kernel keeps that case).  MNC_ROI_WARP_VARIANT = 1 (wave) / 3 (wave per output row) / 4 / 8 forces one.
+  // Round 6: from 1024 channels on the plain warp runs on the row kernel too (ResNet-50 configuration, stage-major output only,
+  // four images in flight: 291 -> 296 images/s against the wave kernel; same bits).
   if (ctx->conv.warp_sample || ctx->conv.warp_round_edges || ctx->conv.warp_no_plus_one || ctx->conv.warp_oob) {
     // a convention other than the SPEC's: the generic kernel (see roi_warp_conv_kernel)
 #define MNC_WARPC(P2, SM)                                                                                                       \
@@ -916,7 +918,7 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
   // the fused 28x28 + pool: one wave per half output row (roi_warp_row_kernel; in the pipeline's serial trace,
   // 300 RoIs x 512 channels: 59.8 -> 46.2 us; the plain 14x14 warp gains nothing from it -- 33.0 against 34.1 -- and keeps its kernel).
   // profiles/r05_roi_warp_row.txt.  MNC_ROI_WARP_VARIANT = 3 forces the row kernel, MNC_ROI_ROW_SEGS the waves per row.
-  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, pool2 ? 3 : C >= 1024 ? 1 : 4);
+  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, (pool2 || C >= 1024) ? 3 : 4);
   if (vsel == 3) {                                                 // one wave per (half) output row
     MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
     int nseg = tune(ctx, T_ROI_ROW_SEGS, 2);
