@@ -918,7 +918,9 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
   // the fused 28x28 + pool: one wave per half output row (roi_warp_row_kernel; in the pipeline's serial trace,
   // 300 RoIs x 512 channels: 59.8 -> 46.2 us; the plain 14x14 warp gains nothing from it -- 33.0 against 34.1 -- and keeps its kernel).
   // profiles/r05_roi_warp_row.txt.  MNC_ROI_WARP_VARIANT = 3 forces the row kernel, MNC_ROI_ROW_SEGS the waves per row.
-  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, (pool2 || C >= 1024) ? 3 : 4);
+  // (with a stage-major output the row kernel for the plain warp below 1024 channels as well: f16 1056 -> 1069 images/s, mixed
+  // 633 -> 637, two runs each; fp32 -- no second output -- 272.8 against 272.9: the 4-channels-per-thread kernel stays there)
+  const int vsel = tune(ctx, T_ROI_WARP_VARIANT, (pool2 || C >= 1024 || sm_fmt != 0) ? 3 : 4);
   if (vsel == 3) {                                                 // one wave per (half) output row
     MNC_REQUIRE((double)H * W * C < 2.0e9, "mnc_roi_warp: feature map too large for 32-bit offsets");
     int nseg = tune(ctx, T_ROI_ROW_SEGS, 2);
