@@ -504,6 +504,13 @@ MNC_API int mnc_fc_f16_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, in
 MNC_API int mnc_fc_bf16x3_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed,
                              const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm,
                              int out_sm_fmt);
+/* Round 6: the plain bf16 mode's stage-major form, FORMAT 3 = format 1's layout ([K/64][M][64] 2-byte values) with the values
+ * rounded to bf16 (nearest even) instead of fp16.  Written by the same producers (sm_fmt = 3: mnc_roi_warp_sm, mnc_maxpool2_rhwc_sm,
+ * mnc_mask_pool_sm, mnc_box_mask_pool[_ex] -- whose stage-major input may be format 3 too, with format-3 outputs -- and the K-split
+ * reduction of an InnerProduct, out_sm_fmt = 3), by mnc_fc_pack_act(.., f16 = 2), read by mnc_fc_bf16_ex / mnc_fc_lowp_pair(mode 2)
+ * and mnc_fc_unpack_act(.., fmt = 3). */
+MNC_API int mnc_fc_bf16_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed,
+                           const float* d_bias, float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt);
 MNC_API int mnc_roi_warp_sm(mnc_ctx* ctx, const float* d_feat_c8, int C, int H, int W, const float* d_rois, int R, int PH, int PW,
                             float spatial_scale, int pool2, float* d_out_rhwc, void* d_sm, int sm_fmt);
 MNC_API int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, int R, int PH, int PW, int C, void* d_sm,

@@ -816,7 +816,7 @@ void fc_reduce_launch(hipStream_t stream, const float* part, const float* bias, 
   fc_reduce_launch_sm(stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0, 0, 0);
 }
 
-// as above + the second output (sm_fmt 1 fp16 / 2 split bf16; needs N % 64 resp. % 32 == 0 and the vector path); returns false
+// as above + the second output (sm_fmt 1 fp16 / 2 split bf16 / 3 bf16; needs N % 64 resp. % 32 == 0 and the vector path); returns false
 // when the second output could not be written (the caller then converts the fp32 rows)
 bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bias, float* out, int M, int N, int ldc, int splits,
                          int act, void* sm, int sm_fmt, long sm_rows, long sm_row0) {
@@ -825,9 +825,11 @@ bool fc_reduce_launch_sm(hipStream_t stream, const float* part, const float* bia
   const long items = vec ? (long)M * N / 4 : (long)M * N;
   int g = (int)((items + 255) / 256);
   if (g > 4096) g = 4096;
-  const bool sm_ok = sm && vec && ((sm_fmt == 1 && N % 64 == 0) || (sm_fmt == 2 && N % 32 == 0));
+  const bool sm_ok = sm && vec && (((sm_fmt == 1 || sm_fmt == 3) && N % 64 == 0) || (sm_fmt == 2 && N % 32 == 0));
   if (sm_ok && sm_fmt == 1)
     hipLaunchKernelGGL((fc_reduce_kernel<4, 1>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, sm, sm_rows, sm_row0);
+  else if (sm_ok && sm_fmt == 3)
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 3>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, sm, sm_rows, sm_row0);
   else if (sm_ok)
     hipLaunchKernelGGL((fc_reduce_kernel<4, 2>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, sm, sm_rows, sm_row0);
   else if (vec) hipLaunchKernelGGL((fc_reduce_kernel<4, 0>), dim3(g), dim3(256), 0, stream, part, bias, out, M, N, ldc, splits, act, nullptr, 0L, 0L);
@@ -846,9 +848,12 @@ bool fc_reduce_pair_launch_sm(hipStream_t stream, const float* part0, const floa
   const long items = (long)M * N / 4;
   int g = (int)((items + 255) / 256);
   if (g > 4096) g = 4096;
-  const bool sm_ok = sm0 && ((sm_fmt == 1 && N % 64 == 0) || (sm_fmt == 2 && N % 32 == 0));
+  const bool sm_ok = sm0 && (((sm_fmt == 1 || sm_fmt == 3) && N % 64 == 0) || (sm_fmt == 2 && N % 32 == 0));
   if (sm_ok && sm_fmt == 1)
     hipLaunchKernelGGL((fc_reduce_kernel<4, 1>), dim3(g, 2), dim3(256), 0, stream, part0, bias0, out0, M, N, ldc, splits, act, sm0, sm_rows, 0L,
+                       part1, bias1, out1, sm1);
+  else if (sm_ok && sm_fmt == 3)
+    hipLaunchKernelGGL((fc_reduce_kernel<4, 3>), dim3(g, 2), dim3(256), 0, stream, part0, bias0, out0, M, N, ldc, splits, act, sm0, sm_rows, 0L,
                        part1, bias1, out1, sm1);
   else if (sm_ok)
     hipLaunchKernelGGL((fc_reduce_kernel<4, 2>), dim3(g, 2), dim3(256), 0, stream, part0, bias0, out0, M, N, ldc, splits, act, sm0, sm_rows, 0L,

@@ -641,6 +641,14 @@ __global__ void unpack_act_sm_kernel(const uint4* __restrict__ sm, float* __rest
       const f16x8 h = x3_as_f16x8(sm[((k >> 6) * M + r) * 8 + ((k & 63) >> 3)]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+    } else if (fmt == 3) {
+      const uint4 u = sm[((k >> 6) * M + r) * 8 + ((k & 63) >> 3)];
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(w[e] << 16);
+        v[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u);
+      }
     } else {
       const uint4* p = sm + (((k >> 5) * M + r) * 4 + ((k & 31) >> 3)) * 2;
       const uint4 a = p[0], b = p[1];
@@ -845,8 +853,8 @@ static int fc_lowp(mnc_ctx* ctx, const char* what, const float* d_a, const uint4
     // no reduction pass to write it from (one K split: the GEMM's epilogue stored the rows), or a shape the reduction's vector
     // path does not take: convert the rows just written (row-major, ldc == N required by the entry point in that case)
     MNC_REQUIRE(ldc == N && osm_rows == M && osm_row0 == 0, "%s: the second output needs a K-split reduction or dense rows", what);
-    LaunchScope ls(ctx, osm_fmt == 1 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (osm_fmt == 1 ? 6.0 : 8.0) * M * (double)N);
-    if (osm_fmt == 1) f16_pack_launch(ctx, d_out, (uint4*)d_osm, M, N, M, 1);
+    LaunchScope ls(ctx, osm_fmt != 2 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (osm_fmt != 2 ? 6.0 : 8.0) * M * (double)N);
+    if (osm_fmt != 2) f16_pack_launch(ctx, d_out, (uint4*)d_osm, M, N, M, 1, osm_fmt == 3);
     else x3_pack_launch(ctx, d_out, (uint4*)d_osm, M, N, M, 1);
     return ls.finish("pack kernel");
   }
@@ -978,8 +986,8 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
     }
     if (osms[i] && !osm_done) {
       MNC_REQUIRE(ldc == N, "%s: the second output needs a K-split reduction or dense rows", what);
-      LaunchScope ls(ctx, osm_fmt == 1 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (osm_fmt == 1 ? 6.0 : 8.0) * M * (double)N);
-      if (osm_fmt == 1) f16_pack_launch(ctx, outs[i], (uint4*)osms[i], M, N, M, 1);
+      LaunchScope ls(ctx, osm_fmt != 2 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (osm_fmt != 2 ? 6.0 : 8.0) * M * (double)N);
+      if (osm_fmt != 2) f16_pack_launch(ctx, outs[i], (uint4*)osms[i], M, N, M, 1, osm_fmt == 3);
       else x3_pack_launch(ctx, outs[i], (uint4*)osms[i], M, N, M, 1);
       rc = ls.finish("pack kernel");
       if (rc) return rc;
@@ -1062,7 +1070,7 @@ int mnc_fc_f16_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stri
                   float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt) {
   MNC_REQUIRE(ctx && (d_a != nullptr) != (d_a_sm != nullptr) && d_w_packed && d_bias && d_out, "mnc_fc_f16_ex: null pointer / both inputs");
   MNC_REQUIRE(M >= 0 && (d_a || m_stride >= M) && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2 &&
-                  (!d_out_sm || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
+                  (!d_out_sm || (((out_sm_fmt == 1 || out_sm_fmt == 3) && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
               "mnc_fc_f16_ex: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
   return fc_lowp<1>(ctx, "mnc_fc_f16_ex", d_a, (const uint4*)d_a_sm, d_a ? M : m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act,
                     d_out_sm, d_out_sm ? out_sm_fmt : 0, M, 0);
@@ -1072,26 +1080,37 @@ int mnc_fc_bf16x3_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_s
                      float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt) {
   MNC_REQUIRE(ctx && (d_a != nullptr) != (d_a_sm != nullptr) && d_w_packed && d_bias && d_out, "mnc_fc_bf16x3_ex: null pointer / both inputs");
   MNC_REQUIRE(M >= 0 && (d_a || m_stride >= M) && N > 0 && K > 0 && K % kXBK == 0 && ldc >= N && act >= 0 && act <= 2 &&
-                  (!d_out_sm || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
+                  (!d_out_sm || (((out_sm_fmt == 1 || out_sm_fmt == 3) && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
               "mnc_fc_bf16x3_ex: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
   return fc_lowp<0>(ctx, "mnc_fc_bf16x3_ex", d_a, (const uint4*)d_a_sm, d_a ? M : m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act,
+                    d_out_sm, d_out_sm ? out_sm_fmt : 0, M, 0);
+}
+
+int mnc_fc_bf16_ex(mnc_ctx* ctx, const float* d_a, const void* d_a_sm, int m_stride, const void* d_w_packed, const float* d_bias,
+                   float* d_out, int M, int N, int K, int ldc, int act, void* d_out_sm, int out_sm_fmt) {
+  MNC_REQUIRE(ctx && (d_a != nullptr) != (d_a_sm != nullptr) && d_w_packed && d_bias && d_out, "mnc_fc_bf16_ex: null pointer / both inputs");
+  MNC_REQUIRE(M >= 0 && (d_a || m_stride >= M) && N > 0 && K > 0 && K % 64 == 0 && ldc >= N && act >= 0 && act <= 2 &&
+                  (!d_out_sm || (out_sm_fmt == 3 && N % 64 == 0)),
+              "mnc_fc_bf16_ex: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d (the bf16 form is format 3)", M, N, K, ldc, act,
+              out_sm_fmt);
+  return fc_lowp<2>(ctx, "mnc_fc_bf16_ex", d_a, (const uint4*)d_a_sm, d_a ? M : m_stride, d_w_packed, d_bias, d_out, M, N, K, ldc, act,
                     d_out_sm, d_out_sm ? out_sm_fmt : 0, M, 0);
 }
 
 // fp32 row-major [M][K] -> the stage-major 2-byte activation form of mnc_fc_{f16,bf16x3}_pre (what those entry points' producers
 // write in their epilogues): f16 != 0: [K/64][M][64 halves], M*K*2 bytes; else [K/32][M][(hi x8 | lo x8) x 4] bf16, M*K*4 bytes.
 int mnc_fc_pack_act(mnc_ctx* ctx, const float* d_a, void* d_a_sm, int M, int K, int f16) {
-  MNC_REQUIRE(ctx && d_a && d_a_sm && M > 0 && K > 0 && K % (f16 ? 64 : kXBK) == 0, "mnc_fc_pack_act: bad argument");
+  MNC_REQUIRE(ctx && d_a && d_a_sm && M > 0 && K > 0 && f16 >= 0 && f16 <= 2 && K % (f16 ? 64 : kXBK) == 0, "mnc_fc_pack_act: bad argument");
   LaunchScope ls(ctx, f16 ? "fc_f16_convert" : "fc_bf16x3_split", 0.0, (f16 ? 6.0 : 8.0) * M * (double)K);
-  if (f16) f16_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
+  if (f16) f16_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1, f16 == 2);      // (2, round 6: bf16 in fp16's layout = stage-major format 3)
   else x3_pack_launch(ctx, d_a, (uint4*)d_a_sm, M, K, M, 1);
   return ls.finish(f16 ? "pack_f16_kernel" : "pack_x3_kernel");
 }
 
 int mnc_fc_unpack_act(mnc_ctx* ctx, const void* d_a_sm, float* d_a, int M, int K, int fmt) {
-  MNC_REQUIRE(ctx && d_a_sm && d_a && M > 0 && K > 0 && (fmt == 1 || fmt == 2) && K % (fmt == 1 ? 64 : kXBK) == 0,
-              "mnc_fc_unpack_act: bad argument (fmt 1: K %% 64 == 0, fmt 2: K %% 32 == 0)");
-  LaunchScope ls(ctx, "fc_act_unpack", 0.0, (fmt == 1 ? 6.0 : 8.0) * M * (double)K);
+  MNC_REQUIRE(ctx && d_a_sm && d_a && M > 0 && K > 0 && fmt >= 1 && fmt <= 3 && K % (fmt == 2 ? kXBK : 64) == 0,
+              "mnc_fc_unpack_act: bad argument (fmt 1 / 3: K %% 64 == 0, fmt 2: K %% 32 == 0)");
+  LaunchScope ls(ctx, "fc_act_unpack", 0.0, (fmt == 2 ? 8.0 : 6.0) * M * (double)K);
   long g = ((long)M * (K / 8) + 255) / 256;
   if (g > 65536) g = 65536;
   hipLaunchKernelGGL(unpack_act_sm_kernel, dim3((int)g), dim3(256), 0, ctx->stream, (const uint4*)d_a_sm, d_a, (long)M, (long)K, fmt);
@@ -1107,7 +1126,7 @@ int mnc_fc_lowp_pair(mnc_ctx* ctx, int mode, const float* d_a0, const void* d_a_
   MNC_REQUIRE(ctx && mode >= 0 && mode <= 2 && (d_a0 != nullptr) != (d_a_sm0 != nullptr) && (d_a1 != nullptr) != (d_a_sm1 != nullptr) && d_w0 &&
                   d_w1 && d_bias0 && d_bias1 && d_out0 && d_out1, "mnc_fc_lowp_pair: null pointer / both inputs");
   MNC_REQUIRE(M >= 0 && ((d_a0 && d_a1) || m_stride >= M) && N > 0 && K > 0 && K % (mode ? 64 : kXBK) == 0 && ldc >= N && act >= 0 && act <= 2 &&
-                  ((!d_out_sm0 && !d_out_sm1) || ((out_sm_fmt == 1 && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
+                  ((!d_out_sm0 && !d_out_sm1) || (((out_sm_fmt == 1 || out_sm_fmt == 3) && N % 64 == 0) || (out_sm_fmt == 2 && N % 32 == 0))),
               "mnc_fc_lowp_pair: unsupported shape M=%d N=%d K=%d ldc=%d act=%d out_sm_fmt=%d", M, N, K, ldc, act, out_sm_fmt);
   if (mode == 0)
     return fc_lowp_pair<0>(ctx, "mnc_fc_lowp_pair", d_a0, (const uint4*)d_a_sm0, d_a1, (const uint4*)d_a_sm1, m_stride, d_w0, d_w1, d_bias0,

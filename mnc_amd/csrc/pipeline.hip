@@ -233,6 +233,7 @@ int sm_format(const mnc_net* n, const mnc_net::Fc& fc, int C) {
   if (!n->fc_sm) return 0;
   if (fc.kind == 2) return C % 64 == 0 ? 1 : 0;
   if (fc.kind == 1) return C % 32 == 0 ? 2 : 0;
+  if (fc.kind == 3) return C % 64 == 0 ? 3 : 0;          // plain bf16 (round 6): fp16's layout, bf16 values
   return 0;
 }
 // the InnerProduct on rows that exist in both forms: a_sm (m_stride = M rows) when the kernel takes it, the fp32 rows otherwise
@@ -245,6 +246,8 @@ int run_fc_sm(mnc_ctx* ctx, const mnc_net::Fc& fc, const float* a, const void* a
                                          act, out_fmt ? out_sm : nullptr, out_fmt);
   if (fc.kind == 1) return mnc_fc_bf16x3_ex(ctx, fmt == 2 ? nullptr : a, fmt == 2 ? a_sm : nullptr, M, fc.w, fc.b, out, M, fc.N, fc.K,
                                             ldc, act, out_fmt ? out_sm : nullptr, out_fmt);
+  if (fc.kind == 3) return mnc_fc_bf16_ex(ctx, fmt == 3 ? nullptr : a, fmt == 3 ? a_sm : nullptr, M, fc.w, fc.b, out, M, fc.N, fc.K, ldc,
+                                          act, out_fmt ? out_sm : nullptr, out_fmt);
   return run_fc(ctx, fc, a, out, M, ldc, act);
 }
 
@@ -365,13 +368,13 @@ int ensure_buffers(mnc_net* n, int H, int W, int OH, int OW) {
   NET_TRY(dev_ensure(n, &n->m14, (size_t)R * P * P * 4));
   NET_TRY(dev_ensure(n, &n->box7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
   NET_TRY(dev_ensure(n, &n->mask7, (size_t)R * (P / 2) * (P / 2) * C5 * 4));
-  if (sm_format(n, n->fc_maskest, C5)) NET_TRY(dev_ensure(n, &n->feat14_sm, (size_t)R * P * P * C5 * (n->fc_maskest.kind == 2 ? 2 : 4)));
-  if (sm_format(n, n->fc6, C5)) NET_TRY(dev_ensure(n, &n->box7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6.kind == 2 ? 2 : 4)));
-  if (sm_format(n, n->fc6m, C5)) NET_TRY(dev_ensure(n, &n->mask7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6m.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc_maskest, C5)) NET_TRY(dev_ensure(n, &n->feat14_sm, (size_t)R * P * P * C5 * (n->fc_maskest.kind == 1 ? 4 : 2)));
+  if (sm_format(n, n->fc6, C5)) NET_TRY(dev_ensure(n, &n->box7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6.kind == 1 ? 4 : 2)));
+  if (sm_format(n, n->fc6m, C5)) NET_TRY(dev_ensure(n, &n->mask7_sm, (size_t)R * (P / 2) * (P / 2) * C5 * (n->fc6m.kind == 1 ? 4 : 2)));
   NET_TRY(dev_ensure(n, &n->f6, (size_t)R * F * 4));
   NET_TRY(dev_ensure(n, &n->f6m, (size_t)R * F * 4));
-  if (sm_format(n, n->fc7, F)) NET_TRY(dev_ensure(n, &n->f6_sm, (size_t)R * F * (n->fc7.kind == 2 ? 2 : 4)));
-  if (sm_format(n, n->fc7m, F)) NET_TRY(dev_ensure(n, &n->f6m_sm, (size_t)R * F * (n->fc7m.kind == 2 ? 2 : 4)));
+  if (sm_format(n, n->fc7, F)) NET_TRY(dev_ensure(n, &n->f6_sm, (size_t)R * F * (n->fc7.kind == 1 ? 4 : 2)));
+  if (sm_format(n, n->fc7m, F)) NET_TRY(dev_ensure(n, &n->f6m_sm, (size_t)R * F * (n->fc7m.kind == 1 ? 4 : 2)));
   NET_TRY(dev_ensure(n, &n->join, (size_t)R * 2 * F * 4));
   NET_TRY(dev_ensure(n, &n->heads, (size_t)2 * R * 6 * K * 4));        // both stages' rows (stage 4/5 behind stage 2/3)
   NET_TRY(dev_ensure(n, &n->boxes, (size_t)2 * R * 4 * 4));

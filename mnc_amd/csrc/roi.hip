@@ -566,8 +566,8 @@ __global__ __launch_bounds__(256, SM ? 3 : 4) void roi_warp_row_kernel(const flo
 // exchange: 520; no second output: 432), MAX pool 175 (190; 174), MaskPooling + pool 184 (192; 173).  Same fp32 arithmetic.
 template <int SM>
 __device__ __forceinline__ void sm_store8(void* __restrict__ sm, long M, long r, long k, const float4 a, const float4 b) {
-  if (SM == 1) {
-    const uint2 lo = x3_f16x4(a), hi = x3_f16x4(b);
+  if (SM == 1 || SM == 3) {
+    const uint2 lo = SM == 3 ? x3_bf16x4(a) : x3_f16x4(a), hi = SM == 3 ? x3_bf16x4(b) : x3_f16x4(b);
     reinterpret_cast<uint4*>(sm)[((k >> 6) * M + r) * 8 + ((k & 63) >> 3)] = make_uint4(lo.x, lo.y, hi.x, hi.y);
   } else {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -755,6 +755,11 @@ __global__ __launch_bounds__(256) void box_mask_pool_h_kernel(const uint4* __res
         const f16x8 h = __builtin_bit_cast(f16x8, u);
         lo = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
         hi = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+      } else if (IN == 3) {                          // bf16 in fp16's layout: element 2i in the low half of word i
+        const uint4 u = feat_sm[((k >> 6) * R + r) * 8 + ((k & 63) >> 3)];
+        auto b = [](unsigned w, int odd) { return __uint_as_float(odd ? (w & 0xFFFF0000u) : (w << 16)); };
+        lo = make_float4(b(u.x, 0), b(u.x, 1), b(u.y, 0), b(u.y, 1));
+        hi = make_float4(b(u.z, 0), b(u.z, 1), b(u.w, 0), b(u.w, 1));
       } else {
         const uint4* p = feat_sm + (((k >> 5) * R + r) * 4 + ((k & 31) >> 3)) * 2;
         const uint4 a = p[0], b = p[1];                              // hi x8, lo x8 (bf16 pairs: element 2i in the low half of word i)
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(256) void box_mask_pool_h_kernel(const uint4* __res
 // which variant of the two pooling kernels writes the second output: 8 channels per thread (MNC_ROI_SM_VARIANT=4 forces the other)
 static bool sm_variant8(const mnc_ctx* ctx) { return tune(ctx, T_ROI_SM_VARIANT, 8) == 8; }
 
-static bool sm_ok(int C, int fmt) { return fmt == 1 ? C % 64 == 0 : fmt == 2 ? C % 32 == 0 : false; }
+static bool sm_ok(int C, int fmt) { return (fmt == 1 || fmt == 3) ? C % 64 == 0 : fmt == 2 ? C % 32 == 0 : false; }
 
 // [R][C][P] <-> [R][P][C]  (P = PH*PW)
 __global__ void rchw_to_rhwc_kernel(const float* __restrict__ in, float* __restrict__ out, long R, int C, int P) {
@@ -880,7 +885,7 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
   MNC_REQUIRE(C > 0 && C % 8 == 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "mnc_roi_warp: bad shape");
   if (!d_sm) sm_fmt = 0;
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_roi_warp_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
-              sm_fmt == 1 ? 64 : 32, C);
+              (sm_fmt == 1 || sm_fmt == 3) ? 64 : 32, C);
   if (R == 0) return MNC_OK;
   const long total = (long)R * PH * PW * (C / 4);
   MNC_REQUIRE(total < (1L << 31), "mnc_roi_warp: %ld outputs exceed the kernel's 32-bit index range", total * 4);
@@ -897,7 +902,7 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
     d_hwc = (const float*)ctx->scratch;
   }
   LaunchScope ls(ctx, pool2 ? "roi_warp_pool2" : "roi_warp", 0.0,
-                 4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)) + (sm_fmt == 1 ? 2.0 : sm_fmt == 2 ? 4.0 : 0.0) * R * PH * PW * C);
+                 4.0 * ((double)R * PH * PW * C * (1.0 + 4.0 * samples)) + ((sm_fmt == 1 || sm_fmt == 3) ? 2.0 : sm_fmt == 2 ? 4.0 : 0.0) * R * PH * PW * C);
   // One wave per output position for the fused 28x28 warp + pool (its set-up is four samples' worth and the window's taps are
   // shared), and for the plain warp from 1024 channels on (4+ channel iterations share a position's set-up).  Measured, fp16
   // second output, 1000 RoIs x 1024 channels: 28x28+pool 452 us against 629 / 680 for the 4- / 8-channels-per-thread kernels,
@@ -910,8 +915,8 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
 #define MNC_WARPC(P2, SM)                                                                                                       \
   hipLaunchKernelGGL((roi_warp_conv_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, \
                      PW, scale, ctx->conv, d_out, d_sm)
-    if (pool2) { if (sm_fmt == 1) MNC_WARPC(1, 1); else if (sm_fmt == 2) MNC_WARPC(1, 2); else MNC_WARPC(1, 0); }
-    else { if (sm_fmt == 1) MNC_WARPC(0, 1); else if (sm_fmt == 2) MNC_WARPC(0, 2); else MNC_WARPC(0, 0); }
+    if (pool2) { if (sm_fmt == 1) MNC_WARPC(1, 1); else if (sm_fmt == 2) MNC_WARPC(1, 2); else if (sm_fmt == 3) MNC_WARPC(1, 3); else MNC_WARPC(1, 0); }
+    else { if (sm_fmt == 1) MNC_WARPC(0, 1); else if (sm_fmt == 2) MNC_WARPC(0, 2); else if (sm_fmt == 3) MNC_WARPC(0, 3); else MNC_WARPC(0, 0); }
 #undef MNC_WARPC
     return ls.finish("roi_warp_conv_kernel");
   }
@@ -929,8 +934,8 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
 #define MNC_WARPR(P2, SM)                                                                                                   \
   hipLaunchKernelGGL((roi_warp_row_kernel<P2, SM>), dim3(g), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, PW, scale, \
                      d_out, nseg, d_sm)
-    if (pool2) { if (sm_fmt == 1) MNC_WARPR(1, 1); else if (sm_fmt == 2) MNC_WARPR(1, 2); else MNC_WARPR(1, 0); }
-    else { if (sm_fmt == 1) MNC_WARPR(0, 1); else if (sm_fmt == 2) MNC_WARPR(0, 2); else MNC_WARPR(0, 0); }
+    if (pool2) { if (sm_fmt == 1) MNC_WARPR(1, 1); else if (sm_fmt == 2) MNC_WARPR(1, 2); else if (sm_fmt == 3) MNC_WARPR(1, 3); else MNC_WARPR(1, 0); }
+    else { if (sm_fmt == 1) MNC_WARPR(0, 1); else if (sm_fmt == 2) MNC_WARPR(0, 2); else if (sm_fmt == 3) MNC_WARPR(0, 3); else MNC_WARPR(0, 0); }
 #undef MNC_WARPR
     return ls.finish("roi_warp_row_kernel");
   }
@@ -940,8 +945,8 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
 #define MNC_WARPW(P2, SM)                                                                                                    \
   hipLaunchKernelGGL((roi_warp_wave_kernel<P2, SM>), dim3(g), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, PW, scale, \
                      d_out, d_sm)
-    if (pool2) { if (sm_fmt == 1) MNC_WARPW(1, 1); else if (sm_fmt == 2) MNC_WARPW(1, 2); else MNC_WARPW(1, 0); }
-    else { if (sm_fmt == 1) MNC_WARPW(0, 1); else if (sm_fmt == 2) MNC_WARPW(0, 2); else MNC_WARPW(0, 0); }
+    if (pool2) { if (sm_fmt == 1) MNC_WARPW(1, 1); else if (sm_fmt == 2) MNC_WARPW(1, 2); else if (sm_fmt == 3) MNC_WARPW(1, 3); else MNC_WARPW(1, 0); }
+    else { if (sm_fmt == 1) MNC_WARPW(0, 1); else if (sm_fmt == 2) MNC_WARPW(0, 2); else if (sm_fmt == 3) MNC_WARPW(0, 3); else MNC_WARPW(0, 0); }
 #undef MNC_WARPW
     return ls.finish("roi_warp_wave_kernel");
   }
@@ -949,16 +954,16 @@ static int roi_warp_impl(mnc_ctx* ctx, const float* d_feat, const float* d_hwc_r
 #define MNC_WARP8(P2, SM)                                                                                                   \
   hipLaunchKernelGGL((roi_warp8_kernel<P2, SM>), dim3(grid_for(total / 2)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, \
                      PH, PW, scale, d_out, d_sm)
-    if (pool2) { if (sm_fmt == 1) MNC_WARP8(1, 1); else MNC_WARP8(1, 2); }
-    else { if (sm_fmt == 1) MNC_WARP8(0, 1); else MNC_WARP8(0, 2); }
+    if (pool2) { if (sm_fmt == 1) MNC_WARP8(1, 1); else if (sm_fmt == 3) MNC_WARP8(1, 3); else MNC_WARP8(1, 2); }
+    else { if (sm_fmt == 1) MNC_WARP8(0, 1); else if (sm_fmt == 3) MNC_WARP8(0, 3); else MNC_WARP8(0, 2); }
 #undef MNC_WARP8
     return ls.finish("roi_warp8_kernel");
   }
 #define MNC_WARP(P2, SM)                                                                                                \
   hipLaunchKernelGGL((roi_warp_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_hwc, C, H, W, d_rois, R, PH, \
                      PW, scale, d_out, d_sm)
-  if (pool2) { if (sm_fmt == 1) MNC_WARP(1, 1); else if (sm_fmt == 2) MNC_WARP(1, 2); else MNC_WARP(1, 0); }
-  else { if (sm_fmt == 1) MNC_WARP(0, 1); else if (sm_fmt == 2) MNC_WARP(0, 2); else MNC_WARP(0, 0); }
+  if (pool2) { if (sm_fmt == 1) MNC_WARP(1, 1); else if (sm_fmt == 2) MNC_WARP(1, 2); else if (sm_fmt == 3) MNC_WARP(1, 3); else MNC_WARP(1, 0); }
+  else { if (sm_fmt == 1) MNC_WARP(0, 1); else if (sm_fmt == 2) MNC_WARP(0, 2); else if (sm_fmt == 3) MNC_WARP(0, 3); else MNC_WARP(0, 0); }
 #undef MNC_WARP
   return ls.finish("roi_warp_kernel");
 }
@@ -1035,20 +1040,21 @@ int mnc_maxpool2_rhwc_sm(mnc_ctx* ctx, const float* d_in, float* d_out, int R, i
               "mnc_maxpool2_rhwc: bad argument (PH, PW must be even, C%%4==0)");
   if (!d_sm) sm_fmt = 0;
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_maxpool2_rhwc_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
-              sm_fmt == 1 ? 64 : 32, C);
+              (sm_fmt == 1 || sm_fmt == 3) ? 64 : 32, C);
   if (R == 0) return MNC_OK;
   MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_maxpool2_rhwc: tensor exceeds the kernel's 32-bit index range");
   LaunchScope ls(ctx, "maxpool2_rhwc", 0.0, 4.0 * R * (double)C * PH * PW * 1.25);
   if (sm_fmt && sm_variant8(ctx)) {
     const int g8 = grid_for((long)R * (PH / 2) * (PW / 2) * (C / 8));
     if (sm_fmt == 1) hipLaunchKernelGGL(maxpool2_rhwc8_kernel<1>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
+    else if (sm_fmt == 3) hipLaunchKernelGGL(maxpool2_rhwc8_kernel<3>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
     else hipLaunchKernelGGL(maxpool2_rhwc8_kernel<2>, dim3(g8), dim3(256), 0, ctx->stream, d_in, d_out, R, PH, PW, C / 8, d_sm);
     return ls.finish("maxpool2_rhwc8_kernel");
   }
 #define MNC_POOLR(SM)                                                                                                  \
   hipLaunchKernelGGL(maxpool2_rhwc_kernel<SM>, dim3(grid_for((long)R * (PH / 2) * (PW / 2) * (C / 4))), dim3(256), 0, ctx->stream, \
                      d_in, d_out, R, PH, PW, C / 4, d_sm)
-  if (sm_fmt == 1) MNC_POOLR(1); else if (sm_fmt == 2) MNC_POOLR(2); else MNC_POOLR(0);
+  if (sm_fmt == 1) MNC_POOLR(1); else if (sm_fmt == 2) MNC_POOLR(2); else if (sm_fmt == 3) MNC_POOLR(3); else MNC_POOLR(0);
 #undef MNC_POOLR
   return ls.finish("maxpool2_rhwc_kernel");
 }
@@ -1073,7 +1079,7 @@ int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, flo
   MNC_REQUIRE(!pool2 || (PH % 2 == 0 && PW % 2 == 0), "mnc_mask_pool: pool2 needs even PH, PW");
   if (!d_sm) sm_fmt = 0;
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_mask_pool_sm: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
-              sm_fmt == 1 ? 64 : 32, C);
+              (sm_fmt == 1 || sm_fmt == 3) ? 64 : 32, C);
   if (R == 0) return MNC_OK;
   MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_mask_pool: tensor exceeds the kernel's 32-bit index range");
   const int OH = pool2 ? PH / 2 : PH, OW = pool2 ? PW / 2 : PW;
@@ -1083,16 +1089,16 @@ int mnc_mask_pool_sm(mnc_ctx* ctx, const float* d_feat, const float* d_mask, flo
 #define MNC_MP8(P2, SM)                                                                                                     \
   hipLaunchKernelGGL((mask_pool8_kernel<P2, SM>), dim3(grid_for(total / 2)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, \
                      PH, PW, C / 8, d_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)
-    if (pool2) { if (sm_fmt == 1) MNC_MP8(1, 1); else MNC_MP8(1, 2); }
-    else { if (sm_fmt == 1) MNC_MP8(0, 1); else MNC_MP8(0, 2); }
+    if (pool2) { if (sm_fmt == 1) MNC_MP8(1, 1); else if (sm_fmt == 3) MNC_MP8(1, 3); else MNC_MP8(1, 2); }
+    else { if (sm_fmt == 1) MNC_MP8(0, 1); else if (sm_fmt == 3) MNC_MP8(0, 3); else MNC_MP8(0, 2); }
 #undef MNC_MP8
     return ls.finish("mask_pool8_kernel");
   }
 #define MNC_MP(P2, SM)                                                                                                  \
   hipLaunchKernelGGL((mask_pool_kernel<P2, SM>), dim3(grid_for(total)), dim3(256), 0, ctx->stream, d_feat, d_mask, d_out, R, PH, \
                      PW, C / 4, d_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)
-  if (pool2) { if (sm_fmt == 1) MNC_MP(1, 1); else if (sm_fmt == 2) MNC_MP(1, 2); else MNC_MP(1, 0); }
-  else { if (sm_fmt == 1) MNC_MP(0, 1); else if (sm_fmt == 2) MNC_MP(0, 2); else MNC_MP(0, 0); }
+  if (pool2) { if (sm_fmt == 1) MNC_MP(1, 1); else if (sm_fmt == 2) MNC_MP(1, 2); else if (sm_fmt == 3) MNC_MP(1, 3); else MNC_MP(1, 0); }
+  else { if (sm_fmt == 1) MNC_MP(0, 1); else if (sm_fmt == 2) MNC_MP(0, 2); else if (sm_fmt == 3) MNC_MP(0, 3); else MNC_MP(0, 0); }
 #undef MNC_MP
   return ls.finish("mask_pool_kernel");
 }
@@ -1109,7 +1115,7 @@ int mnc_box_mask_pool(mnc_ctx* ctx, const float* d_feat, const float* d_mask, fl
 
 int mnc_box_mask_pool_ex(mnc_ctx* ctx, const float* d_feat, const void* d_feat_sm, int feat_sm_fmt, const float* d_mask, float* d_box_out,
                          float* d_mask_out, int R, int PH, int PW, int C, void* d_box_sm, void* d_mask_sm, int sm_fmt) {
-  if ((feat_sm_fmt != 1 && feat_sm_fmt != 2) || !d_box_sm || !d_mask_sm || sm_fmt == 0) d_feat_sm = nullptr;      // (read only on the way to stage-major outputs)
+  if (feat_sm_fmt < 1 || feat_sm_fmt > 3 || !d_box_sm || !d_mask_sm || sm_fmt == 0) d_feat_sm = nullptr;      // (read only on the way to stage-major outputs)
   MNC_REQUIRE(ctx && (d_feat || d_feat_sm) && d_mask && (d_box_out != nullptr) == (d_mask_out != nullptr) && R >= 0 && PH > 0 && PW > 0 &&
                   PH % 2 == 0 && PW % 2 == 0 && C > 0 && C % 8 == 0,
               "mnc_box_mask_pool: bad argument (PH, PW even, C%%8==0)");
@@ -1117,19 +1123,23 @@ int mnc_box_mask_pool_ex(mnc_ctx* ctx, const float* d_feat, const void* d_feat_s
   // the fp32 outputs may be omitted (both null) when the stage-major ones are written: 60 of 210 MB per call at 300 RoIs x 512 channels
   MNC_REQUIRE(d_box_out || sm_fmt != 0, "mnc_box_mask_pool: no output");
   MNC_REQUIRE(sm_fmt == 0 || sm_ok(C, sm_fmt), "mnc_box_mask_pool: format %d needs C %% %d == 0 (C = %d)", sm_fmt,
-              sm_fmt == 1 ? 64 : 32, C);
+              (sm_fmt == 1 || sm_fmt == 3) ? 64 : 32, C);
   if (R == 0) return MNC_OK;
   MNC_REQUIRE((long)R * PH * PW * (C / 4) < (1L << 31), "mnc_box_mask_pool: tensor exceeds the kernel's 32-bit index range");
   const int OH = PH / 2, OW = PW / 2;
-  LaunchScope ls(ctx, "box_mask_pool", 0.0, (d_feat_sm && feat_sm_fmt == 1 ? 2.0 : 4.0) * R * (double)C * PH * PW + 4.0 * R * (double)C * (d_box_out ? 2.0 : 0.0) * OH * OW +
-                                                (sm_fmt == 1 ? 4.0 : sm_fmt == 2 ? 8.0 : 0.0) * R * (double)C * OH * OW);
+  LaunchScope ls(ctx, "box_mask_pool", 0.0, (d_feat_sm && feat_sm_fmt != 2 ? 2.0 : 4.0) * R * (double)C * PH * PW + 4.0 * R * (double)C * (d_box_out ? 2.0 : 0.0) * OH * OW +
+                                                ((sm_fmt == 1 || sm_fmt == 3) ? 4.0 : sm_fmt == 2 ? 8.0 : 0.0) * R * (double)C * OH * OW);
   if (d_feat_sm) {
     MNC_REQUIRE(((long)PH * PW * C) % 64 == 0, "mnc_box_mask_pool: the stage-major input needs PH x PW x C %% 64 == 0");
 #define MNC_BMPH(SM, IN)                                                                                                        \
   hipLaunchKernelGGL((box_mask_pool_h_kernel<SM, IN>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream,   \
                      (const uint4*)d_feat_sm, d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm,              \
                      ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh)
-    if (feat_sm_fmt == 1) { if (sm_fmt == 1) MNC_BMPH(1, 1); else MNC_BMPH(2, 1); }
+    if (feat_sm_fmt == 3 || sm_fmt == 3) {           // plain bf16: both sides in that form (the mode has no other)
+      MNC_REQUIRE(feat_sm_fmt == 3 && sm_fmt == 3, "mnc_box_mask_pool: the bf16 stage-major form pairs with itself only");
+      MNC_BMPH(3, 3);
+    }
+    else if (feat_sm_fmt == 1) { if (sm_fmt == 1) MNC_BMPH(1, 1); else MNC_BMPH(2, 1); }
     else { if (sm_fmt == 1) MNC_BMPH(1, 2); else MNC_BMPH(2, 2); }
 #undef MNC_BMPH
     return ls.finish("box_mask_pool_h_kernel");
@@ -1139,6 +1149,9 @@ int mnc_box_mask_pool_ex(mnc_ctx* ctx, const float* d_feat, const void* d_feat_s
                        d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);
   else if (sm_fmt == 2)
     hipLaunchKernelGGL((box_mask_pool_kernel<2, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
+                       d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);
+  else if (sm_fmt == 3)
+    hipLaunchKernelGGL((box_mask_pool_kernel<3, 2>), dim3(grid_for((long)R * OH * OW * (C / 8))), dim3(256), 0, ctx->stream, d_feat,
                        d_mask, d_box_out, d_mask_out, R, PH, PW, C / 8, d_box_sm, d_mask_sm, ctx->conv.maskpool_binary, ctx->conv.maskpool_thresh);
   else
     hipLaunchKernelGGL((box_mask_pool_kernel<0, 1>), dim3(grid_for((long)R * OH * OW * (C / 4))), dim3(256), 0, ctx->stream, d_feat,

@@ -125,7 +125,7 @@ __device__ __forceinline__ bf16x8 x3_as_bf16x8(const uint4 v) {
 // Second output of a producer of InnerProduct activations (the per-RoI kernels of roi.hip, the split-K reduction of gemm.hip): the tensor in the stage-major 2-byte form the reduced-precision InnerProducts multiply
 // from (mnc_hip.h: mnc_fc_{f16,bf16x3}_pre), written by the threads that hold the fp32 values -- the FC's own conversion pass
 // (read M x K fp32, write M x K halves; 0.2 ms per image at 300 RoIs, 0.75 ms at 1000 RoIs x 1024 channels) disappears.
-// SM: 0 none, 1 = fp16 [K/64][M][64], 2 = split bf16 [K/32][M][4][hi x8 | lo x8]; k = position * C + channel.
+// SM: 0 none, 1 = fp16 [K/64][M][64], 2 = split bf16 [K/32][M][4][hi x8 | lo x8], 3 = bf16 [K/64][M][64]; k = position * C + channel.
 // A thread owns 4 consecutive channels (k a multiple of 4), its neighbour lane (lane ^ 1) the other half of the same 8-channel
 // group: the two exchange halves so that every store is a full 16-byte group (8-byte stores from every lane measured 15-20 %
 // slower on these kernels: 521 vs 430 us for the 14x14 warp of 1000 RoIs x 1024 channels).  All 64 lanes must call it together
@@ -134,8 +134,8 @@ template <int SM>
 __device__ __forceinline__ void sm_store4(void* __restrict__ sm, long M, long r, long k, const float4 v) {
   const bool odd = (k >> 2) & 1;
   const long k8 = k & ~7L;
-  if (SM == 1) {
-    const uint2 mine = x3_f16x4(v);
+  if (SM == 1 || SM == 3) {                          // 3 (round 6): fp16's layout, the values rounded to bf16 (the plain bf16 mode)
+    const uint2 mine = SM == 3 ? x3_bf16x4(v) : x3_f16x4(v);
     const unsigned ox = __shfl_xor(mine.x, 1), oy = __shfl_xor(mine.y, 1);
     if (!odd) reinterpret_cast<uint4*>(sm)[((k8 >> 6) * M + r) * 8 + ((k8 & 63) >> 3)] = make_uint4(mine.x, mine.y, ox, oy);
   } else if (SM == 2) {

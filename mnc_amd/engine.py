@@ -132,7 +132,7 @@ class Blob(object):
         self._view = None           # (parent Blob, column offset) for Concat inputs written in place
         self.diff = None
         # second copy of a per-RoI tensor in the stage-major 2-byte form a reduced-precision InnerProduct multiplies from, written
-        # by the tensor's producer (mnc_*_sm): {"fmt": 1 f16 | 2 bf16x3, "M": rows, "K": row length, "ptr": device address}
+        # by the tensor's producer (mnc_*_sm): {"fmt": 1 f16 | 2 bf16x3 | 3 bf16, "M": rows, "K": row length, "ptr": device address}
         self._sm = None
         self._smbuf = None
         # round 6: the producer wrote the stage-major form ONLY (mnc_roi_warp_sm / mnc_box_mask_pool_ex with null fp32 outputs); the
@@ -246,7 +246,7 @@ class Blob(object):
         """Device address for the producer's second output (stage-major 2-byte form, see __init__); call after dev_out."""
         if self._smbuf is None:
             self._smbuf = _DevBuf(self._net._ctx)
-        ptr = self._smbuf.ensure(M * K * (2 if fmt == 1 else 4))
+        ptr = self._smbuf.ensure(M * K * (4 if fmt == 2 else 2))
         self._sm = {"fmt": fmt, "M": M, "K": K, "ptr": ptr}
         return ptr
 
@@ -1115,7 +1115,7 @@ class Net(object):
                         # round 6: the tensor is read from its stage-major copy when its producer wrote one (what
                         # csrc/pipeline.hip's run_stage does: mnc_hip.h, mnc_box_mask_pool_ex -- same bits in both executors), and
                         # the pooled tensors are written in the stage-major form only when nothing else reads them
-                        sm_in = bot._sm if (fmt and bot._sm and bot._sm["fmt"] in (1, 2) and bot._sm["M"] == R
+                        sm_in = bot._sm if (fmt and bot._sm and bot._sm["fmt"] in (1, 2, 3) and bot._sm["M"] == R
                                             and bot._sm["K"] == C * PH * PW and (bot._dev_valid or bot._sm_only)) else None
                         src = None if (sm_in and not bot._dev_valid) else bot.dev_in("rhwc")
                         sm_only = bool(fmt) and self._sm_only_ok(top.name) and self._sm_only_ok(mtop.name)
@@ -1204,11 +1204,11 @@ class Net(object):
         return run
 
     def _sm_format(self, blob, M, K, C):
-        """Second output of a per-RoI producer (ROIWarping / Pooling / MaskPooling) -> 0 none, 1 f16, 2 bf16x3: the stage-major
+        """Second output of a per-RoI producer (ROIWarping / Pooling / MaskPooling) -> 0 none, 1 f16, 2 bf16x3, 3 bf16: the stage-major
         2-byte form (Blob._sm) when an InnerProduct that reads `blob` will run on the reduced-precision kernels for this M
         (same rule as _bind_InnerProduct.weights_for), so that it does not have to convert the fp32 rows itself.  MNC_FC_SM=0
         switches the second outputs off."""
-        if self.fc_math in ("fp32", "bf16") or M <= 0 or os.environ.get("MNC_FC_SM", "1") == "0":
+        if self.fc_math == "fp32" or M <= 0 or os.environ.get("MNC_FC_SM", "1") == "0":
             return 0
         fmt = 0
         for i in self._consumers.get(blob, []):
@@ -1221,6 +1221,9 @@ class Net(object):
             fm = "bf16x3" if (self.math == "mixed" and K > 50000) else self.fc_math      # (weights_for's rule)
             if fm == "f16" and K % 64 == 0 and C % 64 == 0:
                 fmt = 1
+            elif fm == "bf16":                            # round 6: format 3 = fp16's layout, bf16 values (mnc_fc_bf16_ex)
+                if K % 64 == 0 and C % 64 == 0:
+                    fmt = 3
             elif K % 32 == 0 and C % 32 == 0 and not (fm == "f16" and K % 64 == 0):
                 fmt = 2
         return fmt
@@ -1378,7 +1381,7 @@ class Net(object):
             """(fp32 rows or None, stage-major rows or None, dst, second-output format, second output or None) of this layer's
             reduced-precision call, with its top made ready: the rows arrive in the kernel's own 2-byte form when the producer
             wrote them (Blob._sm: no conversion pass), and leave in the NEXT InnerProduct's form as well when one will read them."""
-            want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2}.get(state.get("fn"), 0)
+            want = {"mnc_fc_f16": 1, "mnc_fc_bf16x3": 2, "mnc_fc_bf16": 3}.get(state.get("fn"), 0)
             sm = bot._sm
             pre = bool(want and sm is not None and sm["fmt"] == want and sm["M"] == M and sm["K"] == K
                        and (bot._dev_valid or bot._sm_only) and bot.layout == state["layout"])
@@ -1406,12 +1409,9 @@ class Net(object):
                               other["w"], d_b, other["b"], dst, other["dst"], M, n_out, K, top._ld(), act, osm, other["osm"], ofmt)
                     P.pair_done = True
                     return
-                if state["fn"] in ("mnc_fc_f16", "mnc_fc_bf16x3"):
-                    _lib.call(state["fn"] + "_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
-                else:
-                    _lib.call(state["fn"], self._h(), src, state["w"], d_b, dst, M, n_out, K, top._ld(), act)
+                _lib.call(state["fn"] + "_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
                 return
-            if M and state.get("fn") in ("mnc_fc_f16", "mnc_fc_bf16x3"):
+            if M and state.get("fn") in LOWP_PAIR:
                 src, pre, dst, ofmt, osm = lowp_args(M)
                 _lib.call(state["fn"] + "_ex", self._h(), src, pre, M, state["w"], d_b, dst, M, n_out, K, top._ld(), act, osm, ofmt)
                 return

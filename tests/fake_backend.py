@@ -498,6 +498,8 @@ class Fake(object):
         M, K = rows.shape
         if fmt == 1:
             _h16(dst, (M, K))[...] = rows.astype(np.float16)
+        elif fmt == 3:                                       # bf16 bit patterns (round 6)
+            np.ctypeslib.as_array((ctypes.c_uint16 * (M * K)).from_address(int(dst)))[...] = _bf16_bits(rows).reshape(-1)
         else:
             _f(dst, (M, K))[...] = rows
 
@@ -533,14 +535,23 @@ class Fake(object):
     def mnc_roi_warp_sm_only_ok(self, h, C, pool2, ok):
         ctypes.c_int.from_address(int(ok)).value = 1
 
+    @staticmethod
+    def _sm_rows(sm, M, K, fmt):
+        if fmt == 1:
+            return _h16(sm, (M, K)).astype(np.float32)
+        if fmt == 3:
+            u = np.ctypeslib.as_array((ctypes.c_uint16 * (M * K)).from_address(int(sm))).astype(np.uint32) << 16
+            return u.view(np.float32).reshape(M, K).copy()
+        return _f(sm, (M, K)).copy()
+
     def mnc_fc_unpack_act(self, h, sm, dst, M, K, fmt):
-        _f(dst, (M, K))[...] = _h16(sm, (M, K)).astype(np.float32) if fmt == 1 else _f(sm, (M, K))
+        _f(dst, (M, K))[...] = self._sm_rows(sm, M, K, fmt)
 
     def mnc_box_mask_pool_ex(self, h, feat, feat_sm, feat_fmt, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt):
-        if feat_sm and feat_fmt in (1, 2) and box_sm and mask_sm and fmt:
-            # the pooling reads the stage-major copy: the fp32 tensor rounded to fp16 (what its producer wrote); the split-bf16
+        if feat_sm and feat_fmt in (1, 2, 3) and box_sm and mask_sm and fmt:
+            # the pooling reads the stage-major copy: the fp32 tensor rounded to fp16 / bf16 (what its producer wrote); the split-bf16
             # stand-in of this double keeps the fp32 values
-            rows = _h16(feat_sm, (R, PH * PW * C)).astype(np.float32) if feat_fmt == 1 else _f(feat_sm, (R, PH * PW * C)).copy()
+            rows = self._sm_rows(feat_sm, R, PH * PW * C, feat_fmt)
             self._keep_feat = np.ascontiguousarray(rows)
             feat = self._keep_feat.ctypes.data
         self.mnc_box_mask_pool(h, feat, mask, box, mout, R, PH, PW, C, box_sm, mask_sm, fmt)
@@ -565,8 +576,14 @@ class Fake(object):
         fn(h, a1, sm1, mstride, w1, b1, dst1, M, N, K, ldc, act, osm1, ofmt if osm1 else 0)
 
     def mnc_fc_bf16_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
-        assert sm is None and not osm, "test double: plain bf16 takes fp32 rows"
+        if sm:                                               # stage-major format 3: bf16 bit patterns (round 6)
+            rows = self._sm_rows(sm, mstride, K, 3)[:M]
+            self._keep = np.ascontiguousarray(rows)
+            a = self._keep.ctypes.data
         self.mnc_fc_bf16(h, a, wpk, b, dst, M, N, K, ldc, act)
+        if osm and ofmt:
+            full = _f(dst, ((M - 1) * ldc + N,))
+            self._sm_write(osm, np.stack([full[m * ldc:m * ldc + N] for m in range(M)]), ofmt)
 
     def mnc_fc_bf16x3_ex(self, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt):
         self._fc_ex(self.mnc_fc_bf16x3, False, h, a, sm, mstride, wpk, b, dst, M, N, K, ldc, act, osm, ofmt)

@@ -781,7 +781,7 @@ def test_roi_warp_row_kernel_at_head_width(dev, pool2, C, tune):
     assert np.array_equal(res["3"].transpose(0, 3, 1, 2), want)
 
 
-@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("fmt", [1, 2, 3])
 @pytest.mark.parametrize("variant", [None, "4", "8"])
 def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, variant, tune):
     """(variant: the library's choice, or MNC_ROI_SM_VARIANT forcing the 4- / 8-channels-per-thread kernels.)
@@ -796,11 +796,12 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
     feat = rng.normal(size=(C, H, W)).astype(np.float32)
     rois = _rois(rng, R, 1000, 600)
     d_feat, d_rois = dev.put(to_c8(feat)), dev.put(rois)
-    eb = 2 if fmt == 1 else 4
+    eb = 4 if fmt == 2 else 2
+    pack_flag = {1: 1, 2: 0, 3: 2}                   # mnc_fc_pack_act's argument for stage-major format 1 / 2 / 3
 
     def shadow_of(d_rows, M, K):
         d = dev.empty((M * K * eb,), dtype=np.uint8, fill=0)
-        dev.call("mnc_fc_pack_act", d_rows, d, M, K, 1 if fmt == 1 else 0)
+        dev.call("mnc_fc_pack_act", d_rows, d, M, K, pack_flag[fmt])
         return dev.get(d, (M * K * eb,), dtype=np.uint8)
 
     for pool2, wave in ((0, False), (1, False), (0, True), (1, True)):
@@ -855,12 +856,14 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
     assert np.array_equal(dev.get(d_bs, (R * K7 * eb,), dtype=np.uint8), dev.get(d_bsm, (R * K7 * eb,), dtype=np.uint8))
     assert np.array_equal(dev.get(d_ms, (R * K7 * eb,), dtype=np.uint8), dev.get(d_msm, (R * K7 * eb,), dtype=np.uint8))
     K14 = P * P * C
-    for in_fmt in (1, 2):
-        ib = 2 if in_fmt == 1 else 4
+    for in_fmt in ((3,) if fmt == 3 else (1, 2)):    # (the bf16 form pairs with itself only)
+        ib = 4 if in_fmt == 2 else 2
         d_xsm = dev.empty((R * K14 * ib,), dtype=np.uint8, fill=0xAB)
-        dev.call("mnc_fc_pack_act", d_x, d_xsm, R, K14, 1 if in_fmt == 1 else 0)
+        dev.call("mnc_fc_pack_act", d_x, d_xsm, R, K14, pack_flag[in_fmt])
         if in_fmt == 1:
             xr = x.astype(np.float16).astype(np.float32)
+        elif in_fmt == 3:
+            xr = _rbf16(x)
         else:                                          # split bf16: hi = rne(x), lo = rne(x - hi); the form holds hi + lo
             hi = _rbf16(x)
             xr = hi + _rbf16(x - hi)
@@ -894,7 +897,7 @@ def test_per_roi_producers_write_the_fc_activation_form(dev, monkeypatch, fmt, v
         dev.call("mnc_maxpool2_rhwc_sm", d_x, d_b, R, P, P, 24, d_sm, fmt)
 
 
-@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("fmt", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(300, 512, 12544), (1000, 512, 12544), (700, 256, 6272), (37, 256, 12544), (160, 4096, 1024)])
 def test_fc_on_prepacked_activations(dev, fmt, M, N, K):
     """mnc_fc_{f16,bf16x3}_pre on the stage-major activation tensor == mnc_fc_{f16,bf16x3} on the fp32 rows, bit for bit, for
@@ -904,37 +907,55 @@ def test_fc_on_prepacked_activations(dev, fmt, M, N, K):
     a = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.normal(size=(N, K)) * 0.02).astype(np.float32)
     b = rng.normal(size=N).astype(np.float32)
-    eb = 2 if fmt == 1 else 4
-    name = "f16" if fmt == 1 else "bf16x3"
+    eb = 4 if fmt == 2 else 2
+    name = {1: "f16", 2: "bf16x3", 3: "bf16"}[fmt]           # (3, round 6: the plain bf16 mode's form -- fp16's layout, bf16 values)
+    pack_flag = {1: 1, 2: 0, 3: 2}
     d_w = dev.empty(((N + 127) // 128 * 128 * K * eb,), dtype=np.uint8)
     dev.call("mnc_pack_fc_" + name, dev.put(w), d_w, N, K)
     d_a, d_b = dev.put(a), dev.put(b)
     d_sm = dev.empty((M * K * eb,), dtype=np.uint8)
-    dev.call("mnc_fc_pack_act", d_a, d_sm, M, K, 1 if fmt == 1 else 0)
+    dev.call("mnc_fc_pack_act", d_a, d_sm, M, K, pack_flag[fmt])
     d_y0, d_y1 = dev.empty((M * N,), fill=np.nan), dev.empty((M * N,), fill=np.nan)
     dev.call("mnc_fc_" + name, d_a, d_w, d_b, d_y0, M, N, K, N, 1)
-    dev.call("mnc_fc_%s_pre" % name, d_sm, M, d_w, d_b, d_y1, M, N, K, N, 1)
+
+    def pre(d_out, rows):
+        if fmt == 3:
+            dev.call("mnc_fc_bf16_ex", None, d_sm, M, d_w, d_b, d_out, rows, N, K, N, 1, None, 0)
+        else:
+            dev.call("mnc_fc_%s_pre" % name, d_sm, M, d_w, d_b, d_out, rows, N, K, N, 1)
+    pre(d_y1, M)
     y0 = dev.get(d_y0, (M, N))
     assert not np.isnan(y0).any() and np.array_equal(y0, dev.get(d_y1, (M, N)))
     # the general entry point: either input form, and the result rows a second time in the NEXT InnerProduct's form (written by
     # the K-split reduction, or converted from the stored rows when there is a single split) == mnc_fc_pack_act of the output
     if N % 64 == 0:
-        for ofmt in (1, 2):
-            oeb = 2 if ofmt == 1 else 4
+        for ofmt in ((3,) if fmt == 3 else (1, 2)):
+            oeb = 4 if ofmt == 2 else 2
             d_y4, d_osm = dev.empty((M * N,), fill=np.nan), dev.empty((M * N * oeb,), dtype=np.uint8, fill=0xCD)
             dev.call("mnc_fc_%s_ex" % name, None, d_sm, M, d_w, d_b, d_y4, M, N, K, N, 1, d_osm, ofmt)
             assert np.array_equal(y0, dev.get(d_y4, (M, N)))
             d_ref = dev.empty((M * N * oeb,), dtype=np.uint8, fill=0)
-            dev.call("mnc_fc_pack_act", d_y4, d_ref, M, N, 1 if ofmt == 1 else 0)
+            dev.call("mnc_fc_pack_act", d_y4, d_ref, M, N, pack_flag[ofmt])
             assert np.array_equal(dev.get(d_osm, (M * N * oeb,), dtype=np.uint8), dev.get(d_ref, (M * N * oeb,), dtype=np.uint8)), ofmt
         d_y5 = dev.empty((M * N,), fill=np.nan)
         dev.call("mnc_fc_%s_ex" % name, d_a, None, 0, d_w, d_b, d_y5, M, N, K, N, 1, None, 0)
         assert np.array_equal(y0, dev.get(d_y5, (M, N)))
+    # mnc_fc_unpack_act (round 6): the rows back out of the stage-major tensor = the fp32 rows rounded to the form
+    d_back = dev.empty((M * K,), fill=np.nan)
+    dev.call("mnc_fc_unpack_act", d_sm, d_back, M, K, fmt)
+    back = dev.get(d_back, (M, K))
+    if fmt == 1:
+        assert np.array_equal(back, a.astype(np.float16).astype(np.float32))
+    elif fmt == 3:
+        assert np.array_equal(back, _rbf16(a))
+    else:
+        hi = _rbf16(a)
+        assert np.array_equal(back, hi + _rbf16(a - hi))
     if M >= 300:        # the first 2/3 of the rows of the same tensor (m_stride = M > rows multiplied)
         Mh = M * 2 // 3
         d_y2, d_y3 = dev.empty((Mh * N,), fill=np.nan), dev.empty((Mh * N,), fill=np.nan)
         dev.call("mnc_fc_" + name, d_a, d_w, d_b, d_y2, Mh, N, K, N, 1)
-        dev.call("mnc_fc_%s_pre" % name, d_sm, M, d_w, d_b, d_y3, Mh, N, K, N, 1)
+        pre(d_y3, Mh)
         assert np.array_equal(dev.get(d_y2, (Mh, N)), dev.get(d_y3, (Mh, N)))
 
 
@@ -1245,13 +1266,14 @@ def test_fc_lowp_pair(dev, mode, M, N, K, pre, tune):
         d = dev.empty(((N + 127) // 128 * 128 * K // wpv,), fill=np.nan)
         dev.call("mnc_pack_fc_" + mode, dev.put(x), d, N, K)
         d_w.append(d)
-    sm_fmt = {"f16": 1, "bf16x3": 2}.get(mode, 0)         # (the stage-major activation form exists for fp16 / split bf16)
+    sm_fmt = {"f16": 1, "bf16x3": 2, "bf16": 3}[mode]     # (round 6: the plain bf16 mode has its stage-major form too, format 3)
+    pack_flag = {"f16": 1, "bf16x3": 0, "bf16": 2}[mode]
     use_pre = pre and sm_fmt != 0
     d_sm = [None, None]
     if use_pre:
         for i in range(2):
             d_sm[i] = dev.empty((M * K // wpv,), fill=np.nan)
-            dev.call("mnc_fc_pack_act", d_a[i], d_sm[i], M, K, 1 if mode == "f16" else 0)
+            dev.call("mnc_fc_pack_act", d_a[i], d_sm[i], M, K, pack_flag)
     ld = 2 * N
     want_osm = sm_fmt != 0 and N % 64 == 0
     outs = []
@@ -1271,7 +1293,7 @@ def test_fc_lowp_pair(dev, mode, M, N, K, pre, tune):
         assert rel < (1e-4 if mode == "bf16x3" else 1e-5), (i, d, rel)
         if want_osm:
             d_chk = dev.empty((M * N // wpv,), fill=np.nan)
-            dev.call("mnc_fc_pack_act", dev.put(np.ascontiguousarray(got[i])), d_chk, M, N, 1 if mode == "f16" else 0)
+            dev.call("mnc_fc_pack_act", dev.put(np.ascontiguousarray(got[i])), d_chk, M, N, pack_flag)
             assert np.array_equal(dev.get(d_chk, (M * N // wpv,)).view(np.uint32), outs[0][1][i])
     if M <= 160 or N % 256 or M == 700:       # not paired: the two single calls, bit for bit
         for i in range(2):
