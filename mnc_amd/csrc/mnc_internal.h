@@ -272,7 +272,8 @@ int nms_scan_launch(hipStream_t stream, const unsigned long long* d_mask, int n,
 int nms_mask_launch_indirect(hipStream_t stream, const float* d_boxes, const int* d_order, const int* d_n, int n_cap,
                              int dim, float thr, unsigned long long* d_mask);
 int nms_scan_launch_indirect(hipStream_t stream, const unsigned long long* d_mask, const int* d_n, int n_cap, int max_keep,
-                             int* d_keep, int* d_num);
+                             int* d_keep, int* d_num, const float* d_gather_boxes = nullptr, const int* d_gather_order = nullptr,
+                             float* d_rois = nullptr, int rois_cap = 0);   // d_rois: the ProposalLayer's RoI rows written by the same launch
 void proposal_state_free(void* state);  // proposal.hip
 void comm_free(mnc_ctx* ctx);           // comm.hip
 // out = act(sum of the ksplit partial c8 tensors + bias)  (conv.hip)

@@ -176,9 +176,17 @@ __global__ __launch_bounds__(448) void mv_resample_kernel(const float* __restric
                                                           const int* __restrict__ ends, const float* __restrict__ wts,
                                                           int H, int W, const int* __restrict__ bounds,
                                                           const int* __restrict__ rcount, int R,
-                                                          float* __restrict__ out_mask, int* __restrict__ out_box) {
+                                                          float* __restrict__ out_mask, int* __restrict__ out_box,
+                                                          float* __restrict__ records = nullptr, const float* __restrict__ rscore = nullptr,
+                                                          const int* __restrict__ rows = nullptr, int record_cap = 0) {
   __shared__ CandLds cl;
   const int Rv = rcount ? *rcount : R;
+  // Round 6: the fixed-shape records (x1, y1, x2, y2, score, class id 1..B, S*S mask values; rows from the count up to record_cap
+  // zero: class 0 == padding -- SURVEY.md 8e) are written here as well, what mv_pack_kernel did as a launch of its own
+  const int D = 6 + S * S;
+  if (records)
+    for (int r = Rv + blockIdx.x; r < record_cap; r += gridDim.x)
+      for (int i = threadIdx.x; i < D; i += blockDim.x) records[(long)r * D + i] = 0.0f;
   for (int r = blockIdx.x; r < Rv; r += gridDim.x) {
     __syncthreads();
     const int c0 = begins[r], c1 = ends[r];
@@ -191,6 +199,12 @@ __global__ __launch_bounds__(448) void mv_resample_kernel(const float* __restric
     if (by2 < 0) { by1 = H / 2; by2 = H / 2; }
     if (threadIdx.x == 0) {
       out_box[r * 4 + 0] = bx1; out_box[r * 4 + 1] = by1; out_box[r * 4 + 2] = bx2; out_box[r * 4 + 3] = by2;
+    }
+    float* rec = (records && r < record_cap) ? records + (long)r * D : nullptr;
+    if (rec && threadIdx.x == 64) {                  // (another wave than lane 0's stores above)
+      rec[0] = (float)bx1; rec[1] = (float)by1; rec[2] = (float)bx2; rec[3] = (float)by2;
+      rec[4] = rscore[r];
+      rec[5] = (float)(rows[2 * r + 1] + 1);
     }
     for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
       const int w = idx % S, h = idx / S;
@@ -211,6 +225,7 @@ __global__ __launch_bounds__(448) void mv_resample_kernel(const float* __restric
       }
 #undef MNC_AGG
       out_mask[((long)r * S + h) * S + w] = v;
+      if (rec) rec[6 + idx] = v;
     }
   }
 }
@@ -423,32 +438,13 @@ __global__ __launch_bounds__(64) void mv_candidates_kernel(const float* __restri
   }
 }
 
-// Final instances as fixed-shape records (the block the multi-GPU path gathers): record r < min(R, cap) =
-// (x1, y1, x2, y2, score, class id 1..B, S*S mask values); rows from R up to cap are zero (class 0 == padding).
-__global__ __launch_bounds__(256) void mv_pack_kernel(const float* __restrict__ omask, const int* __restrict__ obox,
-                                                      const float* __restrict__ rscore, const int* __restrict__ rows,
-                                                      const int* __restrict__ counts, int cap, int S,
-                                                      float* __restrict__ records) {
-  const int r = blockIdx.x;
-  const int R = counts[0];
-  const int D = 6 + S * S;
-  float* rec = records + (long)r * D;
-  if (r >= R) {
-    for (int i = threadIdx.x; i < D; i += blockDim.x) rec[i] = 0.0f;
-    return;
-  }
-  if (threadIdx.x < 4) rec[threadIdx.x] = (float)obox[r * 4 + threadIdx.x];
-  if (threadIdx.x == 4) rec[4] = rscore[r];
-  if (threadIdx.x == 5) rec[5] = (float)(rows[2 * r + 1] + 1);
-  for (int i = threadIdx.x; i < S * S; i += blockDim.x) rec[6 + i] = omask[(long)r * S * S + i];
-}
-
 // All pointers device.  d_bounds: R*4 ints scratch.  Result r's candidates are d_inds/d_wts[d_begins[r] .. d_ends[r]).
 // d_rcount != nullptr: the row count is read from the device (<= R rows of scratch/output exist) and the grid is `grid_rows`
 // workgroups striding over the rows.
 static int mv_launch_impl(hipStream_t stream, const float* d_boxes, int box_dim, const float* d_masks, int S, const int* d_inds,
                           const int* d_begins, const int* d_ends, const float* d_wts, int H, int W, int R, const int* d_rcount,
-                          int grid_rows, int* d_bounds, float* d_out_mask, int* d_out_box, bool bounds_ready = false) {
+                          int grid_rows, int* d_bounds, float* d_out_mask, int* d_out_box, bool bounds_ready = false,
+                          float* d_records = nullptr, const float* d_rscore = nullptr, const int* d_rows = nullptr, int record_cap = 0) {
   if (R <= 0) return MNC_OK;
   // (the voting sequence initialises the rows' bounds in its candidates kernel; the extension's own entry point does it here)
   if (!bounds_ready) hipLaunchKernelGGL(mv_init_bounds_kernel, dim3(cdiv(R * 4, 256)), dim3(256), 0, stream, d_bounds, R);
@@ -459,7 +455,7 @@ static int mv_launch_impl(hipStream_t stream, const float* d_boxes, int box_dim,
   hipLaunchKernelGGL(mv_bounds_kernel, dim3(grid_rows, splits), dim3(256), 0, stream, d_boxes, box_dim, d_masks, S, d_inds,
                      d_begins, d_ends, d_wts, H, W, d_rcount, R, d_bounds);
   hipLaunchKernelGGL(mv_resample_kernel, dim3(grid_rows), dim3(448), 0, stream, d_boxes, box_dim, d_masks, S, d_inds, d_begins,
-                     d_ends, d_wts, H, W, d_bounds, d_rcount, R, d_out_mask, d_out_box);
+                     d_ends, d_wts, H, W, d_bounds, d_rcount, R, d_out_mask, d_out_box, d_records, d_rscore, d_rows, record_cap);
   return MNC_OK;
 }
 
@@ -537,10 +533,9 @@ static int vote_async(hipStream_t s, const VoteWs& w, const float* d_boxes, cons
   const int grid_rows = Rmax < max_per_image ? Rmax : max_per_image;
   hipLaunchKernelGGL(mv_candidates_kernel, dim3(grid_rows), dim3(64), 0, s, d_boxes, d_scores, n, C, w.rows, d_counts, Rmax,
                      iou_thresh, w.cinds, w.cw, w.cbegin, w.cend, w.bounds);
+  // (round 6: the resampling kernel writes the records too -- mv_pack_kernel's launch is gone)
   mv_launch_impl(s, d_boxes, 4, d_masks, S, w.cinds, w.cbegin, w.cend, w.cw, H, W, Rmax, d_counts, grid_rows, w.bounds, w.omask,
-                 w.obox, /*bounds_ready=*/true);
-  hipLaunchKernelGGL(mv_pack_kernel, dim3(record_cap), dim3(256), 0, s, w.omask, w.obox, w.rscore, w.rows, d_counts, record_cap, S,
-                     d_records);
+                 w.obox, /*bounds_ready=*/true, d_records, w.rscore, w.rows, record_cap);
   MNC_HIP_TRY(hipGetLastError());
   return MNC_OK;
 }

@@ -122,9 +122,13 @@ __device__ __forceinline__ void resolve_block(u64 diag, int rows, int max_keep, 
 //      wave-wide OR reduction -- one load latency per block, not one per survivor;
 //   2. the intra-block chain runs on the scalar unit: v_readlane of the 64 diagonal words, 64 unrolled steps;
 //   3. survivors write their indices with one compacting vector store (prefix popcount).
+// Round 6: the ProposalLayer's tail in the same launch -- g_rois[r] = (0, g_boxes[g_order[keep[r]]]) for r < the survivor count, zero
+// rows up to g_cap (what proposal_gather_kernel did as a launch of its own: one of the 57 launches of an image).
 __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, int n_arg, const int* __restrict__ n_ptr,
                                                       int n_stride, int cb_cap, int max_keep, int* __restrict__ keep,
-                                                      int* __restrict__ num_out) {
+                                                      int* __restrict__ num_out, const float* __restrict__ g_boxes = nullptr,
+                                                      const int* __restrict__ g_order = nullptr, float* __restrict__ g_rois = nullptr,
+                                                      int g_cap = 0) {
   __shared__ u64 s_kept[kMaxScanBlocks];
   __shared__ unsigned short s_surv[kSurvCap];       // rows of the survivors so far (n <= 32768: a row fits in 16 bits)
   const int lane = threadIdx.x;
@@ -177,6 +181,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
       __syncthreads();                               // s_surv of this block is read by the next iteration's list loads
     }
     if (lane == 0) num_out[blockIdx.x] = nk;
+    if (g_rois) {                                    // (single-problem launches only; the survivors' rows are in LDS)
+      for (int r = lane; r < g_cap; r += 64) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nk) b = reinterpret_cast<const float4*>(g_boxes)[g_order[s_surv[r]]];
+        g_rois[r * 5 + 0] = 0.f;
+        g_rois[r * 5 + 1] = b.x; g_rois[r * 5 + 2] = b.y; g_rois[r * 5 + 3] = b.z; g_rois[r * 5 + 4] = b.w;
+      }
+    }
     return;
   }
   // unbounded survivor count (mnc_nms with max_keep < 0 on a large n): one pass over the earlier blocks per block
@@ -199,6 +211,16 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
     __syncthreads();
   }
   if (lane == 0) num_out[blockIdx.x] = nk;
+  if (g_rois) {                                      // (the survivors' rows were written to `keep` by this wave: visible behind the barrier)
+    __threadfence_block();
+    __syncthreads();
+    for (int r = lane; r < g_cap; r += 64) {
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nk) b = reinterpret_cast<const float4*>(g_boxes)[g_order[kp[r]]];
+      g_rois[r * 5 + 0] = 0.f;
+      g_rois[r * 5 + 1] = b.x; g_rois[r * 5 + 2] = b.y; g_rois[r * 5 + 3] = b.z; g_rois[r * 5 + 4] = b.w;
+    }
+  }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------
@@ -227,9 +249,9 @@ int nms_scan_launch(hipStream_t stream, const u64* d_mask, int n, int max_keep, 
 }
 
 int nms_scan_launch_indirect(hipStream_t stream, const u64* d_mask, const int* d_n, int n_cap, int max_keep, int* d_keep,
-                             int* d_num) {
+                             int* d_num, const float* d_gather_boxes, const int* d_gather_order, float* d_rois, int rois_cap) {
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, d_mask, 0, d_n, n_cap, cdiv(n_cap, 64), max_keep, d_keep,
-                     d_num);
+                     d_num, d_gather_boxes, d_gather_order, d_rois, rois_cap);
   return MNC_OK;
 }
 

@@ -281,18 +281,6 @@ __global__ __launch_bounds__(256) void proposal_rank_kernel(const u64* __restric
   }
 }
 
-// rois[r] = (0, boxes[order[keep[r]]]) for r < *num
-__global__ void proposal_gather_kernel(const float* __restrict__ boxes, const int* __restrict__ order,
-                                       const int* __restrict__ keep, const int* __restrict__ num, float* __restrict__ rois,
-                                       int cap) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= cap) return;
-  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (r < *num) b = reinterpret_cast<const float4*>(boxes)[order[keep[r]]];
-  rois[r * 5 + 0] = 0.f;
-  rois[r * 5 + 1] = b.x; rois[r * 5 + 2] = b.y; rois[r * 5 + 3] = b.z; rois[r * 5 + 4] = b.w;
-}
-
 // StageBridgeLayer.forward_test: box of argmax class (first maximum, background included), decoded and clipped.
 __global__ void stage_bridge_kernel(const float* __restrict__ rois, const float* __restrict__ bbox_pred, int ld_bbox,
                                     const float* __restrict__ probs, int ld_probs, int R, int K, float im_h, float im_w,
@@ -521,9 +509,8 @@ int mnc_proposal(mnc_ctx* ctx, const float* d_cls_prob, const float* d_bbox_pred
   {
     LaunchScope ls(ctx, "proposal_nms");
     nms_mask_launch_indirect(ctx->stream, w.boxes, w.order, w.n_cand, topn, 4, nms_thresh, w.mask);
-    nms_scan_launch_indirect(ctx->stream, w.mask, w.n_cand, topn, post_nms_topn, w.keep, w.num);
-    hipLaunchKernelGGL(proposal_gather_kernel, dim3(cdiv(post_nms_topn, 256)), dim3(256), 0, ctx->stream, w.boxes, w.order,
-                       w.keep, w.num, d_rois, post_nms_topn);
+    // (round 6: the scan's wave also writes the RoI rows -- the survivors' boxes through `order` -- one launch fewer per image)
+    nms_scan_launch_indirect(ctx->stream, w.mask, w.n_cand, topn, post_nms_topn, w.keep, w.num, w.boxes, w.order, d_rois, post_nms_topn);
     int rc = ls.finish("proposal_nms");
     if (rc) return rc;
   }
