@@ -17,12 +17,13 @@ A "step" is one pass of the whole hot path over one synthetic image per GPU, mea
        the RCCL all-gather of every rank's [100, 447] instance block over xGMI, issued on the engine's stream from the
        device-resident block (mnc_gather_instances), and the gathered blocks copied to the host (N > 1)
 Images are sharded one per rank (weak scaling, no data-path collective).  `value` = images of all ranks / max-over-ranks time.
-Every GPU keeps FOUR images in flight by default, three under a launcher (--in-flight: one mnc_net + context + stream per image in
-flight, ONE shared set of device weights).  The part runs four hardware queues: with the round-6 fix of the null-stream memset that
-took a queue of its own (profiles/r06_streams.txt) the images own one queue each up to four -- fp32 2 / 3 / 4 in flight = 265.9 / 267.0
-/ 268.1 images/s, f16 774 / 849 / 866, mixed 528 / 555 / 560 -- and under a launcher the RCCL gather's stream is the fourth (1 rank:
-2 / 3 / 4 in flight = 264.1 / 265.2 / 258.2).  Round 5's sweep (three the best, four a dip) is profiles/r05_in_flight_sweep.txt;
-mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 3): a sixth of an image's GPU time is spent in
+Every GPU keeps TWELVE images in flight by default (--in-flight: one mnc_net + context + stream per image in flight, ONE shared set
+of device weights, 16 GB resident).  Streams map one to one onto hardware queues while there are enough of them; the runtime's default
+is four (four images in flight then: fp32 2 / 3 / 4 in flight = 265.9 / 267.0 / 268.1 images/s, a fifth stream shares a queue and costs
+3-4 %: profiles/r06_streams.txt), the library asks for 16 (GPU_MAX_HW_QUEUES, set when libmnc_hip.so is loaded unless the host
+exported its own), and with round 6's launch plans -- made for CU time, not for the duration of a launch -- 4 / 8 / 12 / 16 images in
+flight measure 270.0 / 278.2 / 280.6 / 280.3 images/s.  Round 5's sweep (three the best, four a dip) is profiles/r05_in_flight_sweep.txt;
+mnc_forward_image_async of image k+1 is issued before mnc_net_fetch of image k - 11): a sixth of an image's GPU time is spent in
 kernels of one or a few workgroups (proposal top-k, NMS scan, voting) that leave the chip idle -- other images' convolutions run
 there.  Every image still goes through the whole path, upload to results; K steps = K images.  `one_image_at_a_time` is the
 rounds 1-2 protocol (--in-flight 1 makes it the headline).
@@ -115,12 +116,12 @@ def parse():
                         "Net executing the prototxt layer by layer + demo.im_detect + gpu_mask_voting (tools/demo.py's own body); "
                         "graph: the same Net's launch sequence for an image, captured into a HIP graph per image size and replayed "
                         "(Net.detect_image: one graph launch + one synchronisation per image, any prototxt)")
-    p.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 8],
+    p.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16],
                    help="native engine: images in flight per GPU (own mnc_net + context + stream each; image k+1 is launched before "
                         "image k is fetched, so the latency-bound stretches of one image -- proposal top-k, NMS scan, voting: one or a "
                         "few workgroups -- run beside the other's convolutions).  1 = one image at a time (rounds 1-2 headline); "
-                        "0 (default) = 4, or 3 under a launcher, where the RCCL gather has a stream of its own: one hardware queue per "
-                        "stream, four queues on the part (profiles/r06_streams.txt)")
+                        "0 (default) = 12: one hardware queue per stream, 16 queues requested by the library "
+                        "(profiles/r06_streams.txt)")
     p.add_argument("--dist-backend", default="nccl",
                    help="transport of the instance blocks: nccl = RCCL all-gather issued by libmnc_hip.so on a device stream (one rank "
                         "per GPU) | gloo = host tensors (functional test on fewer GPUs than ranks).  torch.distributed itself -- the "
@@ -161,10 +162,14 @@ def main():
         args.engine = "graph"
     launched = "WORLD_SIZE" in os.environ
     if args.in_flight == 0:
-        # one hardware queue per stream, four queues on this part (profiles/r06_streams.txt): four images in flight without a
-        # launcher (fp32 2 / 3 / 4 in flight = 265.9 / 267.0 / 268.1 images/s, f16 774 / 849 / 866, mixed 528 / 555 / 560), three
-        # when the RCCL gather's stream holds the fourth queue (1 rank under the launcher: 264.1 / 265.2 / 258.2 for 2 / 3 / 4)
-        args.in_flight = 3 if launched else 4
+        # one hardware queue per stream (profiles/r06_streams.txt).  The runtime's default is four queues: four images in flight then
+        # (fp32 2 / 3 / 4 in flight = 265.9 / 267.0 / 268.1 images/s; a fifth stream shares a queue and costs 3-4 %).  The library asks
+        # for 16 queues when it is loaded (GPU_MAX_HW_QUEUES, csrc/ctx.hip), and with the launch plans made for CU time there is room
+        # beside every launch: 4 / 8 / 12 / 16 images in flight = 270.0 / 278.2 / 280.6 / 280.3 (fp32, one box; 272.5 -> 284.6 on
+        # another; f16 1033 -> 1047, mixed 613 -> 624 with 12; 1 rank under the launcher, the RCCL gather on a stream of its own: 284.3).
+        # (the caffe-shaped Net on HIP graphs -- `--engine graph`, the ResNet-50 configuration -- keeps four: every Net in flight holds
+        # its own weight copy, and in the driver's 20-step runs a dozen 1000-RoI images draining cost more than they gain: 303 vs 286)
+        args.in_flight = 12 if args.engine == "native" else 4
     dist = torch = None
     on_gpu = args.dist_backend == "nccl"
     if launched:
@@ -369,6 +374,13 @@ def main():
             for nn in nets:
                 for _ in range(2):
                     nn.forward_image(images[rank % N_IMAGES], record_cap=100)
+        elif engine == "graph" and not args.no_graph:
+            # the same for the caffe-shaped Net's captured launch sequence (Net.detect_image): eager, then the capture (round 6: with
+            # a dozen nets in flight a 20-step run otherwise times little else than captures)
+            for which in range(len(nets)):
+                for _ in range(2):
+                    launch_on(which, images[rank % N_IMAGES])
+                    fetch_from(which)
         for k in range(warmup):
             if inflight > 1:
                 step_pipelined(k, False)
@@ -631,7 +643,7 @@ def main():
             m["resident_s"] = mp["resident_s"]
             # the same caffe-shaped Net with every image on its captured HIP graph (Net.detect_image) and the headline's images in
             # flight: what the drop-in API reaches when the host keeps several images going
-            mg = measure(math, min(args.steps, 100), args.warmup, engine="graph")
+            mg = measure(math, min(args.steps, 100), args.warmup, engine="graph", in_flight=4)
             out["python_engine_graph"] = {"value": min(args.steps, 100) / mg["elapsed"], "unit": "images/s",
                                           "ms_per_step": 1e3 * mg["elapsed"] / min(args.steps, 100),
                                           "images_in_flight_per_gpu": mg["in_flight"],

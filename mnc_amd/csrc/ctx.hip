@@ -104,6 +104,14 @@ int mnc_device_count(int* count) {
   return MNC_OK;
 }
 
+// Round 6: the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); a host that keeps more images in flight
+// than that has streams sharing a queue, and a shared queue serialises them (profiles/r06_streams.txt: the dip at the fifth stream).
+// With 16 queues twelve images in flight measure 280.6 images/s against 270.0 with four (fp32, one box, two runs each; 8 queues / 8
+// images: 278.2).  The variable is read when the runtime initialises -- at the process's first HIP call -- so the library sets a
+// default when it is loaded, before it makes any (an already exported value wins; a process that initialised HIP earlier keeps its
+// own setting).
+__attribute__((constructor)) static void mnc_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+
 int mnc_ctx_create(mnc_ctx** out, int device_id) {
   MNC_REQUIRE(out, "mnc_ctx_create: null out pointer");
   *out = nullptr;

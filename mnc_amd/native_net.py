@@ -230,16 +230,17 @@ class ImageStream(object):
     """Throughput form of NativeNet: `in_flight` nets (own context, stream and buffers each; ONE set of device weights, shared:
     mnc_net_create_shared) on ONE GPU, images
     submitted round-robin -- image k+1 is launched before image k is fetched, so the stretches of an image that occupy one or a
-    few workgroups (proposal top-k, NMS scans, voting) run beside another image's convolutions.  The default is one image per
-    hardware queue of an MI355X (round 6, profiles/r06_streams.txt: 274 images/s at 600x1000 in fp32 with four in flight, 239 one at a
-    time; the library's launch plans are made for this form -- least CU time per launch, MNC_PLAN=1 for the latency plans).  Results
-    come back in submission order and equal NativeNet.forward_image's.
+    few workgroups (proposal top-k, NMS scans, voting) run beside another image's convolutions.  Every image in flight has a
+    hardware queue of its own (the library asks the runtime for 16: GPU_MAX_HW_QUEUES) and 1.2 GB of activation buffers; round 6,
+    profiles/r06_streams.txt: 270 / 278 / 281 images/s at 600x1000 in fp32 with 4 / 8 / 12 in flight, 239 one at a time (the
+    library's launch plans are made for this form -- least CU time per launch, MNC_PLAN=1 for the latency plans).  Results come back
+    in submission order and equal NativeNet.forward_image's.
 
-        stream = ImageStream(weights, in_flight=4)
+        stream = ImageStream(weights, in_flight=8)
         for counts, records in stream.map(images): ...
     """
 
-    def __init__(self, weights, in_flight=4, **kwargs):
+    def __init__(self, weights, in_flight=8, **kwargs):
         if in_flight < 1:
             raise ValueError("in_flight must be >= 1")
         first = NativeNet(weights, **kwargs)
