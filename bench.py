@@ -666,7 +666,10 @@ def main():
             # BASELINE configs[2] ("bf16 convs via MFMA") and the fp16 mode measured in the same run, same protocol; their RPN
             # outputs on the LAST image are compared with the fp32 run's (blobs that do not depend on which RoIs survived)
             for key, alt in (("alt_math", "bf16x3"), ("alt_math_f16", "f16"), ("alt_math_mixed", "mixed"), ("alt_math_bf16", "bf16")):
-                m2 = measure(alt, args.steps, args.warmup,
+                # (an image takes 1-2 ms in these modes: in a run of fewer than 100 steps the fill and the drain of twelve images
+                # outweigh what they gain -- K = 20: f16 1021 / 994, mixed 619 / 611 with 4 / 12 in flight -- so short runs keep four)
+                alt_in_flight = None if (args.steps >= 100 or args.in_flight <= 4 or args.engine != "native") else 4
+                m2 = measure(alt, args.steps, args.warmup, in_flight=alt_in_flight,
                              pipelined_steps=0 if (args.no_resident or headline_pipelined) else min(args.steps, 100))
                 a = {"math": alt, "dtype": DTYPE[alt], "value": args.steps / m2["elapsed"], "unit": "images/s",
                      "ms_per_step": 1e3 * m2["elapsed"] / args.steps, "images_in_flight_per_gpu": m2["in_flight"]}
