@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B sweeps of the launch-plan knobs with the headline protocol (four images in flight), run on the GPU box:
-#   bash tools/plan_ab.sh fc | wino | convsw | plan | traced | soak          -> profiles/r06_fc_ranges.txt, r06_streams.txt
+#   bash tools/plan_ab.sh fc | wino | convsw | plan | traced | queues | soak          -> profiles/r06_fc_ranges.txt, r06_streams.txt
 # Every line: images/s with four images in flight, then one image at a time (both on the plans the knobs select).
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 B="python bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-events --no-resident --no-resnet --no-alt-math --no-repeats --no-latency-plan"
@@ -25,7 +25,10 @@ case "$1" in
       echo "=== $m, MNC_PLAN=$plan, four images in flight"
       python $R/tools/stream_report.py /tmp/tr/b_results.db --images 30 130 | grep -v "columns of"
     done; done ;;
+  queues)  # hardware queues x images in flight (the library's own default is 16 queues; an exported value wins)
+    for q in 4 8 16; do for n in 4 8 12 16; do if [ $n -le $q ] || [ $q = 4 ]; then echo "fp32 GPU_MAX_HW_QUEUES=$q in-flight $n: $(GPU_MAX_HW_QUEUES=$q $B --math fp32 --in-flight $n 2>/dev/null | val)"; fi; done; done
+    for m in f16 mixed; do for n in 4 12; do echo "$m in-flight $n: $($B --math $m --in-flight $n 2>/dev/null | val)"; done; done ;;
   soak)
     for p in "fp32 5000" "mixed 8000" "f16 10000"; do set -- $p; echo "$1 $2 steps: $(python bench.py --steps $2 --warmup 10 --math $1 --no-cpu-baseline --no-events --no-resident --no-resnet --no-alt-math --no-repeats --no-latency-plan 2>/dev/null | val)"; done ;;
-  *) echo "usage: $0 fc | wino | convsw | plan | traced | soak"; exit 2 ;;
+  *) echo "usage: $0 fc | wino | convsw | plan | traced | queues | soak"; exit 2 ;;
 esac
