@@ -902,7 +902,7 @@ static int fc_lowp_pair(mnc_ctx* ctx, const char* what, const float* d_a0, const
     if (splits < 1) splits = 1;
     paired = stages / splits >= (F16 ? 8 : 16);                // (the 256-column kernel's own bar: fc_lowp)
     const int full = splits;
-    splits = fc_lowp_ranges(ctx, splits, K, 2 * tn);           // (round 6: CU time, not launch time -- mnc_internal.h)
+    splits = fc_lowp_ranges(ctx, splits, K, 2 * tn, true);     // (round 6: CU time, not launch time -- mnc_internal.h)
     // (a second output in stage-major form is written by the reduction pass; without one only dense rows can be converted)
     if (splits == 1 && full > 1 && (d_osm0 || d_osm1) && ldc != N) splits = 2;
   }

@@ -32,7 +32,7 @@ namespace mnc {
 // superseded kernel builds (FC_ABL, FC_DMA_ABL, FCX3_ABL, CONV_ABL, WINO_V = 1, WINO_VAR != 7) are only compiled with -DMNC_TUNING.
 #define MNC_TUNE_KEYS(X)                                                                                                          \
   X(CONV_COT) X(CONV_ROWS) X(CONV_KSPLIT) X(CONV_ABL) X(CONV1X1_TILE) X(CONV2D_WIDE) X(WINO_ROWS) X(WINO_TAIL) X(WINO_V) X(WINO_VAR)  \
-  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(PLAN) X(FC_SLOTS) X(FC_EVEN) X(FC_SPLIT_DIV) X(WINO_FILL) X(CONVX3_P0MIN) X(CONVX3_P1MIN) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
+  X(WINO_DMA) X(WINO_XCD) X(CONVX3_TILE) X(FC_NOTAIL) X(FC_TILE) X(FC_ABL) X(FC_DMA) X(PLAN) X(FC_RANGE_K) X(FC_SLOTS) X(FC_EVEN) X(FC_SPLIT_DIV) X(WINO_FILL) X(CONVX3_P0MIN) X(CONVX3_P1MIN) X(FC_DMA_ABL) X(FC_DMA_WAVES)    \
   X(FC_NO256) X(FCX3_TILE) X(FC_ORDER) X(FCX3_ABL) X(FC_SM) X(PACKED_ACT) X(FUSE_POOLS) X(BRANCH_STREAMS) X(TOPK_SINGLE_WG)           \
   X(ROI_SM_VARIANT) X(ROI_WARP_VARIANT) X(FC_REDUCE) X(WINO_F4) X(FUSE_SMALL) X(FCX3_WIDE) X(FC_HALF) X(WINO_STREAM) X(FC_MFMA16) X(WINO_MFMA16) X(ROI_ROW_SEGS)
 enum TuneKey {
@@ -97,8 +97,8 @@ inline bool plan_latency(const mnc_ctx* ctx) { return tune(ctx, T_PLAN, 0) == 1;
 // tiles x ranges filled all 256 CUs -- the shortest launch when the product has the chip to itself.  With several images in flight it
 // does not: other images' kernels run on the CUs a launch leaves free, and what a product costs is its CU TIME.  Every range pays a
 // prologue, an epilogue that writes 300 KB of partial sums, and its share of the reduction pass -- fc7 + fc7_mask in fp16: 17 us of
-// MFMA loop inside 38 us + a 16 us reduction with 8 ranges of 8 stages.  So: ranges of at least 2048 K values, and no more ranges than
-// fill HALF the chip (fc6 + fc6_mask: 8 -> 4 ranges, fc7 + fc7_mask: 8 -> 2).  Four images in flight: f16 870 -> 914 images/s, bf16
+// MFMA loop inside 38 us + a 16 us reduction with 8 ranges of 8 stages.  So: ranges of at least 2048 K values (pairs: 12288, below), and
+// no more ranges than fill HALF the chip (first: fc6 + fc6_mask 8 -> 4 ranges, fc7 + fc7_mask 8 -> 2; then 2 and 1).  Four images in flight: f16 870 -> 914 images/s, bf16
 // 841 -> 902, mixed 553 -> 579, bf16x3 451 -> 472; one image at a time f16 566 -> 555, bf16x3 372 -> 322 (the price: a launch is
 // longer).  One range for fc7 is the same throughput and 5-8 % more latency.  The fp32 InnerProducts keep the full cut (their loops
 // are 10x longer than their fixed costs: 266 -> 260 images/s with half the ranges).
@@ -109,11 +109,16 @@ inline int fc_split_div(const mnc_ctx* ctx, int splits, int K) {
   const int d = K <= 8192 ? hi : K > 50000 ? top : lo;      // (hundreds digit: K > 50000, fc6_maskest)
   return d > 1 && splits > 1 ? (splits / d > 1 ? splits / d : 1) : splits;
 }
-inline int fc_lowp_ranges(const mnc_ctx* ctx, int splits, int K, int tiles) {
+inline int fc_lowp_ranges(const mnc_ctx* ctx, int splits, int K, int tiles, bool pair = false) {
   if (tune_set(ctx, T_FC_SPLIT_DIV)) return fc_split_div(ctx, splits, K);
   if (plan_latency(ctx)) return splits;
-  int r = K / 2048 > 1 ? K / 2048 : 1;
-  const int half = (128 + tiles - 1) / tiles;
+  // pairs (fc6 + fc6_mask, fc7 + fc7_mask): ranges of >= 12288 K values -- 2 ranges for the fc6 pair, none for the fc7 pair (no
+  // partial sums, no reduction launch): with the images in flight on 16 hardware queues (12 in flight) f16 1087 -> 1118 images/s,
+  // mixed 652 -> 660, bf16x3 506 -> 513; with four in flight 1078 -> 1072 / 638 -> 645 / 499 -> 499; no cut at all (32768): 1119 /
+  // 662 / 515 with twelve but 984 / 627 / 457 with four.  A single product (fc6_maskest: one column tile) keeps 2048.  FC_RANGE_K.
+  const int per = pair ? tune(ctx, T_FC_RANGE_K, 12288) : 2048, part = 128;
+  int r = K / per > 1 ? K / per : 1;
+  const int half = (part + tiles - 1) / tiles;
   if (r > half) r = half;
   return r < splits ? r : splits;
 }
