@@ -91,6 +91,9 @@ def parse():
     p.add_argument("--config", default="vgg16", choices=sorted(CONFIGS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-images", type=int, default=3, help="images timed on the CPU oracle (after 1 warm-up)")
+    p.add_argument("--ramp-ms", type=float, default=-1.0,
+                   help="with more than four images in flight the pipeline is filled four images at once, then one more per this "
+                        "many ms (-1, default: two thirds of one image's own time; 0: all at once)")
     p.add_argument("--no-latency-plan", action="store_true",
                    help="skip the measurements on the launch plans for latency (MNC_PLAN=1): `one_image_at_a_time` is then the figure on "
                         "the headline's plans and the per-mode `roofline_latency_plan` passes are not run (tools/prof_round.sh: the "
@@ -329,6 +332,7 @@ def main():
             finish(counts, rec, blk, 0, t_c)
 
         pending = []                                 # (which net) of the images launched and not yet fetched, oldest first
+        ramp = {"pace": 0.0, "next": 0.0, "left": 0}  # see step_pipelined
 
         def drain():
             while pending:
@@ -348,6 +352,18 @@ def main():
                 step(k)
                 return
             which = k % inflight
+            if ramp["pace"] and ramp["left"] > 0 and 4 <= len(pending) < inflight:
+                # filling the pipeline behind a fence: the first four images start together (they saturate the chip), the next
+                # inflight - 4 follow one per `pace` instead of all at once -- a dozen images launched in the same instant run in
+                # lock step (their latency-bound stretches coincide) for tens of images; staggered they are spread as in the steady
+                # state (profiles/r06_streams.txt: 20 steps 271 -> 277 images/s, 40 steps 277 -> 281; a pace above the steady
+                # interval would throttle, hence only these launches are paced)
+                ramp["left"] -= 1
+                ramp["next"] = max(ramp["next"] + ramp["pace"], time.perf_counter())
+                while time.perf_counter() < ramp["next"]:
+                    pass
+            elif len(pending) < 4:
+                ramp["next"] = time.perf_counter()
             t_a = time.perf_counter()
             launch_on(which, images[(rank + k) % N_IMAGES])
             phase["prep+forward+tail"] += time.perf_counter() - t_a
@@ -366,6 +382,7 @@ def main():
                 nn.sync()
             if launched:
                 dist.barrier()
+            ramp["left"] = inflight - 4              # the pipeline is empty: its next fill is paced
 
         if native and not args.no_graph:
             # part of building the nets, not of the W warm-up steps: every net of the pipeline sees the image size twice (eager,
@@ -381,6 +398,13 @@ def main():
                 for _ in range(2):
                     launch_on(which, images[rank % N_IMAGES])
                     fetch_from(which)
+        if native and inflight > 4 and args.ramp_ms != 0:
+            if args.ramp_ms > 0:
+                ramp["pace"] = args.ramp_ms * 1e-3
+            else:                                    # two thirds of one image's own time (one image alone on the chip: fp32 4.2 ms -> 2.8)
+                t_i = time.perf_counter()
+                nets[0].forward_image(images[rank % N_IMAGES], record_cap=100)
+                ramp["pace"] = (time.perf_counter() - t_i) / 1.5
         for k in range(warmup):
             if inflight > 1:
                 step_pipelined(k, False)
