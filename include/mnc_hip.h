@@ -140,6 +140,10 @@ MNC_API int mnc_bbox_overlaps(const double* boxes, int n, const double* query_bo
 /* ---------------------------------------------------------------------------------------------------------------
  * Engine context: one per process per GPU (b5: `caffe.set_device`, one `caffe.Net` per process).  Owns a HIP
  * stream and all device scratch.  Not thread-safe; use one context per thread.
+ * Hosts that keep several images in flight use one context (stream) per image.  The HIP runtime maps streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (default 4; streams that share a queue serialise): when this library is loaded it sets
+ * GPU_MAX_HW_QUEUES=16 in the process environment unless the variable is already set -- effective when that happens before the
+ * process's first HIP call (round 6; profiles/r06_streams.txt).
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct mnc_ctx mnc_ctx;
 
