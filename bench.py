@@ -385,17 +385,22 @@ def main():
             ramp["left"] = inflight - 4              # the pipeline is empty: its next fill is paced
 
         if native and not args.no_graph:
-            # part of building the nets, not of the W warm-up steps: every net of the pipeline sees the image size twice (eager,
-            # then the capture of its HIP graph), so that neither the warm-up nor a short timed region (the driver's --steps 20
+            # part of building the nets, not of the W warm-up steps: every net of the pipeline sees the image size three times (eager,
+            # the capture of its HIP graph, the first replay), so that neither the warm-up nor a short timed region (the driver's --steps 20
             # --warmup 5 with three nets) contains a graph capture
-            for nn in nets:
-                for _ in range(2):
-                    nn.forward_image(images[rank % N_IMAGES], record_cap=100)
+            for which, nn in enumerate(nets):
+                for _ in range(3):                   # eager, the capture, the graph's first replay (it uploads the executable graph)
+                    counts, rec = nn.forward_image(images[rank % N_IMAGES], record_cap=100)
+                if gatherer is not None:
+                    # ... and its instance block goes through the gather once (N > 1: the first collective on a buffer carries one-time
+                    # set-up; with twelve nets the W warm-up steps do not reach every net's block -- the first timed loop of a 20-step
+                    # run under the launcher measured 269 images/s, its repeats 276-280)
+                    finish(counts, rec, None, which, time.perf_counter())
         elif engine == "graph" and not args.no_graph:
             # the same for the caffe-shaped Net's captured launch sequence (Net.detect_image): eager, then the capture (round 6: with
             # a dozen nets in flight a 20-step run otherwise times little else than captures)
             for which in range(len(nets)):
-                for _ in range(2):
+                for _ in range(3):
                     launch_on(which, images[rank % N_IMAGES])
                     fetch_from(which)
         if native and inflight > 4 and args.ramp_ms != 0:
