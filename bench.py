@@ -403,6 +403,11 @@ def main():
                 for _ in range(3):
                     launch_on(which, images[rank % N_IMAGES])
                     fetch_from(which)
+        if launched:
+            # the control plane's first barrier sets its connections up (37 ms on one rank): here, not between the warm-up and the timed
+            # region, where the GPU would sit idle and start the timed steps from its idle clocks (the first timed loop of a 20-step
+            # run under the launcher measured 269 images/s, the three repeats behind it 277-279)
+            dist.barrier()
         if native and inflight > 4 and args.ramp_ms != 0:
             if args.ramp_ms > 0:
                 ramp["pace"] = args.ramp_ms * 1e-3
